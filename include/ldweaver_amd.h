@@ -1,0 +1,169 @@
+/*
+ * ldweaver_amd.h — C ABI of the MI355X-native all-pairs weighted-MI engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of Sudaraka88/LDWeaver:
+ *   perform_MI_computation()            R/computePairwiseMI.R:46-145
+ *   estimate_Hamming_distance_weights() R/performPopulationStuctureCorrection.R:20-81
+ *   .ACGTN2num()                        src/ACGTN2num_parallel.cpp:10-43
+ * and the native helpers they call through `.Call` (src/RcppExports.cpp:154-167).
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes (no R, Rcpp or
+ * torch types), returns an int status (0 = LDW_OK) and leaves a thread-local
+ * message retrievable with ldw_last_error().  The caller allocates every output
+ * (variable-length link tables use a two-call size query).  The R-side binding a
+ * maintainer would add is shown in INTEGRATION.md and kept as source in r_shim/.
+ *
+ * Conventions
+ *   states  uint8 [L][N] row-major, values 0..4 = A,C,G,T,N: the dense equivalent of the five
+ *           one-hot sparse matrices of `snp.dat` (R/extractSNPs.R:138-141), encoded by the rule of
+ *           src/getACGTNsites.cpp:229-265.
+ *   SNP indices in block descriptors are 1-based inclusive like make_blocks()
+ *           (R/computePairwiseMI.R:147-165); index arrays are 0-based.
+ *   MI blocks are column-major nf x nt doubles, element (a,b) at a + b*nf, exactly the R matrix
+ *           `MI` of perform_MI_computation_ACGTN (R/computePairwiseMI.R:268).
+ */
+#ifndef LDWEAVER_AMD_H
+#define LDWEAVER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDW_OK 0
+#define LDW_ERR_ARG 1      /* bad argument (shape, range, null pointer)            */
+#define LDW_ERR_HIP 2      /* a HIP runtime call or kernel launch failed            */
+#define LDW_ERR_STATE 3    /* call order violated (e.g. MI before weights are set)  */
+#define LDW_ERR_NOGPU 4    /* no usable gfx950 device: there is NO CPU fallback     */
+#define LDW_ERR_SIZE 5     /* caller buffer too small (see the size query)          */
+
+/* quirk modes of the block kernel */
+#define LDW_QUIRK_REFERENCE 0 /* reproduce Q1: RXY read by linear index of the nt x nf matrix (R/computePairwiseMI.R:261 + src/computeMI.cpp:19) */
+#define LDW_QUIRK_INTENDED 1  /* RXY = 0.25*r_a*r_b */
+
+#define LDW_ENGINE_MFMA 0 /* i8 MFMA fixed-point co-occurrence GEMM + fp64 epilogue (default) */
+#define LDW_ENGINE_HIST 1 /* LDS-tiled per-pair 5x5 histogram kernel (VALU), same results      */
+
+typedef struct ldw_ctx ldw_ctx;
+
+/* ---- library / device ------------------------------------------------------------------ */
+int ldw_version(void);
+const char *ldw_last_error(void);
+/* number of visible HIP devices (0 when none); never initialises a context */
+int ldw_device_count(void);
+
+int ldw_ctx_create(int device, ldw_ctx **out);
+int ldw_ctx_destroy(ldw_ctx *ctx);
+/* run everything on an externally owned hipStream_t (e.g. torch's current stream); NULL = own stream */
+int ldw_ctx_set_stream(ldw_ctx *ctx, void *hip_stream);
+int ldw_ctx_sync(ldw_ctx *ctx);
+/* elapsed ms of the kernels of the last ldw_mi_block / ldw_mi_all_pairs call, by stage, measured with
+ * HIP events on the context's stream: [0] gemm, [1] epilogue, [2] selection, [3] total */
+int ldw_ctx_last_timing(ldw_ctx *ctx, double ms_out[4]);
+
+/* ---- (1) .ACGTN2num  — src/ACGTN2num_parallel.cpp:10-43, R/RcppExports.R:4-6 ------------ */
+/* nv: 5 x L doubles, column-major, mutated IN PLACE (host memory, as R hands it over);
+ * ref: L bytes = first character of each element of `cv`; ncores is accepted and ignored. */
+int ldw_acgtn2num(ldw_ctx *ctx, double *nv, const char *ref, int64_t L, int ncores);
+/* same on device-resident buffers (no copies) */
+int ldw_acgtn2num_dev(ldw_ctx *ctx, double *nv_dev, const char *ref_dev, int64_t L);
+
+/* ---- (3) .fastHadamard — src/computeMI.cpp:11-21, R/RcppExports.R:8-10 ------------------- */
+/* element-wise twin over the linear index c < n; MI updated in place. on_device != 0: all pointers
+ * are device pointers. */
+int ldw_fast_hadamard(ldw_ctx *ctx, double *MI, const double *den, const double *uq, const double *pxy,
+                      const double *pxpy, const double *RXY, const double *pXrX, const double *pYrY,
+                      int64_t n, int on_device);
+
+/* ---- alignment residency ------------------------------------------------------------------ */
+/* Upload (on_device == 0) or adopt a copy of (on_device != 0) the L x N state matrix. */
+int ldw_set_alignment(ldw_ctx *ctx, const uint8_t *states, int64_t L, int64_t N, int on_device);
+/* 5-state encoder of src/getACGTNsites.cpp:229-265 on the device: chars [N][L_total] (sequence-major,
+ * as a FASTA holds them) -> states [n_pos][N] for the 1-based retained columns pos[n_pos]; the result
+ * becomes the context's alignment.  Also returns the 5 x n_pos ACGTN_table (may be NULL). */
+int ldw_encode_alignment(ldw_ctx *ctx, const char *chars, int64_t N, int64_t L_total, const int32_t *pos,
+                         int64_t n_pos, int32_t *acgtn_table_out);
+/* per-SNP state counts (5 x L, column-major like ACGTN_table) of the resident alignment */
+int ldw_state_counts(ldw_ctx *ctx, int32_t *counts_out);
+/* copy the resident states back (tests) */
+int ldw_get_alignment(ldw_ctx *ctx, uint8_t *states_out);
+
+/* ---- (2) estimate_Hamming_distance_weights — R/performPopulationStuctureCorrection.R:20-81 */
+/* hdw_out[j] = 1 / (#{i : L - shared[i][j] < thresh} + 1), thresh = as.integer(L*threshold) computed by
+ * the caller.  shared_out (N x N int32, may be NULL) receives the exact shared-state counts. */
+int ldw_hamming_weights(ldw_ctx *ctx, int32_t thresh, double *hdw_out, int32_t *shared_out);
+
+/* ---- MI set-up ------------------------------------------------------------------------------ */
+/* Per-sequence weights hdw[N] (R/computePairwiseMI.R:77,89).  The engine uses v_s = fl(sqrt(hdw_s))^2
+ * like the reference's sqrt-scaled one-hots, quantised to nlimbs*8-bit fixed point (nlimbs in 1..6,
+ * 0 = default 5; see DESIGN.md "fixed-point weights"). */
+int ldw_set_weights(ldw_ctx *ctx, const double *hdw, int64_t N, int nlimbs);
+/* r[L] (snp.dat$r), uqe[L][5] row-major 0/1 (snp.dat$uqe), POS[L] ascending, paint[L] (cds_var$paint),
+ * g genome length (snp.dat$g). */
+int ldw_set_snp_meta(ldw_ctx *ctx, const double *r, const uint8_t *uqe, const int32_t *POS,
+                     const int32_t *paint, double g);
+int ldw_set_engine(ldw_ctx *ctx, int engine);
+
+/* ---- (4) one block: perform_MI_computation_ACGTN + computeMI_Sprase + fastHadamard fused --- */
+/* from_idx[nf], to_idx[nt]: 0-based SNP indices (contiguous ranges for ordinary blocks, arbitrary
+ * subsets in SR-only mode, R/computePairwiseMI.R:179-189).  MI_out: nf*nt doubles column-major, host
+ * (on_device == 0) or device.  All nf*nt entries are produced, like the reference's MI matrix. */
+int ldw_mi_block(ldw_ctx *ctx, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt,
+                 int quirk_mode, double *MI_out, int on_device);
+/* exact weighted joint tables in fixed point and plain integer joint counts for a list of SNP pairs:
+ * counts_out[p][25] (row X of SNP a, column Y of SNP b), fixed_out[p][25] (sum of quantised weights,
+ * value = fixed * 2^-frac_bits).  Either output may be NULL. */
+int ldw_joint_tables(ldw_ctx *ctx, const int32_t *pair_a, const int32_t *pair_b, int64_t npairs,
+                     int64_t *counts_out, int64_t *fixed_out, int *frac_bits_out);
+
+/* ---- (5) the a-5 loop: blocks -> sr / lr link tables --------------------------------------- */
+typedef struct ldw_mi_params {
+    double sr_dist;          /* R/computePairwiseMI.R:47  default 20000 */
+    double lr_retain_links;  /* default 1e6 */
+    double lr_links_approx;  /* R/computePairwiseMI.R:94-97, computed by the host (R RNG) */
+    int32_t sr_only;         /* perform_SR_analysis_only: lr part skipped */
+    int32_t quirk_mode;      /* LDW_QUIRK_* */
+    int32_t keep_sr;         /* 0: do not materialise sr links (throughput measurement of lr only) */
+    int32_t reserved;
+} ldw_mi_params;
+
+/* blocks[nblocks][4] = (from_s, from_e, to_s, to_e), 1-based inclusive, e.g. this rank's share of
+ * make_blocks().  Links are appended to the context's device-resident tables in block order and, within
+ * a block, in the reference's row order (R/computePairwiseMI.R:306-310).  reset != 0 clears the tables. */
+int ldw_mi_all_pairs(ldw_ctx *ctx, const int32_t *blocks, int64_t nblocks, const ldw_mi_params *p,
+                     int reset);
+/* which: 0 = short-range, 1 = long-range (after the per-block quantile filter). */
+int ldw_links_count(ldw_ctx *ctx, int which, int64_t *n_out);
+/* a_out/b_out: 0-based SNP index of the from-side (pos2) and to-side (pos1) SNP; MI_out. capacity in
+ * rows; on_device selects the destination space.  block_row_offsets_out[nblocks+1] (host, may be NULL)
+ * gives each processed block's first row. */
+int ldw_links_fetch(ldw_ctx *ctx, int which, int32_t *a_out, int32_t *b_out, double *MI_out,
+                    int64_t capacity, int on_device);
+/* per-block diagnostics of the last ldw_mi_all_pairs call: n_lr_total, n_lr_kept, n_sr, and the
+ * quantile threshold (NaN when no lr links); arrays of length nblocks (may be NULL). */
+int ldw_block_stats(ldw_ctx *ctx, int64_t nblocks, int64_t *n_lr_total, int64_t *n_lr_kept,
+                    int64_t *n_sr, double *disc_thresh);
+
+/* ---- (6) ARACNE — R/io_functions.R:101-164 + src/fintersect.cpp, src/computeMI.cpp:44-77 ---- */
+/* flags_out[i] = 1 unless some common neighbour Y of (X,Z) = (chk_pos1[i], chk_pos2[i]) in the full link
+ * set has MI(X,Z) < MI(X,Y) and MI(X,Z) < MI(Z,Y).  Positions are compared as exact values. */
+int ldw_aracne(ldw_ctx *ctx, const double *chk_pos1, const double *chk_pos2, const double *chk_MI,
+               int64_t n_chk, const double *full_pos1, const double *full_pos2, const double *full_MI,
+               int64_t n_full, uint8_t *flags_out);
+
+/* ---- small native helpers kept for finest-grain A/B parity (host memory) -------------------- */
+/* .compareToRow src/computeMI.cpp:25-41: ret[j] = any(x[j,] in y); x is nr x nc column-major */
+int ldw_compare_to_row(const double *x, int64_t nr, int64_t nc, const double *y, int64_t ny, uint8_t *ret);
+/* .vecPosMatch src/computeMI.cpp:44-59: 1-based first position of x[i] in y, 0 if absent */
+int ldw_vec_pos_match(const double *x, int64_t nx, const double *y, int64_t ny, double *ret);
+/* .compareTriplet src/computeMI.cpp:63-77 */
+int ldw_compare_triplet(const double *MI0X, const double *MI0Z, int64_t n, double MI0, int *ret);
+/* .fast_intersect src/fintersect.cpp:6-32; out capacity >= min(na, nb); *n_out = result length */
+int ldw_fast_intersect(const int32_t *A, int64_t na, const int32_t *B, int64_t nb, int32_t *out,
+                       int64_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDWEAVER_AMD_H */

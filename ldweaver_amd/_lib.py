@@ -1,0 +1,113 @@
+"""ctypes binding of libldweaver_amd.so (the C ABI declared in include/ldweaver_amd.h).
+
+There is NO fallback: if the shared library is missing or a call fails, an
+exception is raised.  Nothing in this package computes MI, Hamming weights or
+the ACGTN2num mask on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libldweaver_amd.so")
+
+LDW_OK = 0
+QUIRK_REFERENCE, QUIRK_INTENDED = 0, 1
+ENGINE_MFMA, ENGINE_HIST = 0, 1
+
+
+class LdwError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libldweaver_amd error {code}: {msg}")
+        self.code = code
+
+
+class MIParams(C.Structure):
+    _fields_ = [("sr_dist", C.c_double), ("lr_retain_links", C.c_double), ("lr_links_approx", C.c_double),
+                ("sr_only", C.c_int32), ("quirk_mode", C.c_int32), ("keep_sr", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_SIGS = {
+    "ldw_version": (C.c_int, []),
+    "ldw_last_error": (C.c_char_p, []),
+    "ldw_device_count": (C.c_int, []),
+    "ldw_ctx_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
+    "ldw_ctx_destroy": (C.c_int, [_p]),
+    "ldw_ctx_set_stream": (C.c_int, [_p, _p]),
+    "ldw_ctx_sync": (C.c_int, [_p]),
+    "ldw_ctx_last_timing": (C.c_int, [_p, _p]),
+    "ldw_acgtn2num": (C.c_int, [_p, _p, _p, _i64, C.c_int]),
+    "ldw_acgtn2num_dev": (C.c_int, [_p, _p, _p, _i64]),
+    "ldw_fast_hadamard": (C.c_int, [_p] + [_p] * 8 + [_i64, C.c_int]),
+    "ldw_set_alignment": (C.c_int, [_p, _p, _i64, _i64, C.c_int]),
+    "ldw_encode_alignment": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
+    "ldw_state_counts": (C.c_int, [_p, _p]),
+    "ldw_get_alignment": (C.c_int, [_p, _p]),
+    "ldw_hamming_weights": (C.c_int, [_p, C.c_int32, _p, _p]),
+    "ldw_set_weights": (C.c_int, [_p, _p, _i64, C.c_int]),
+    "ldw_set_snp_meta": (C.c_int, [_p, _p, _p, _p, _p, C.c_double]),
+    "ldw_set_engine": (C.c_int, [_p, C.c_int]),
+    "ldw_mi_block": (C.c_int, [_p, _p, _i64, _p, _i64, C.c_int, _p, C.c_int]),
+    "ldw_joint_tables": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
+    "ldw_mi_all_pairs": (C.c_int, [_p, _p, _i64, C.POINTER(MIParams), C.c_int]),
+    "ldw_links_count": (C.c_int, [_p, C.c_int, C.POINTER(_i64)]),
+    "ldw_links_fetch": (C.c_int, [_p, C.c_int, _p, _p, _p, _i64, C.c_int]),
+    "ldw_block_stats": (C.c_int, [_p, _i64, _p, _p, _p, _p]),
+    "ldw_aracne": (C.c_int, [_p, _p, _p, _p, _i64, _p, _p, _p, _i64, _p]),
+    "ldw_compare_to_row": (C.c_int, [_p, _i64, _i64, _p, _i64, _p]),
+    "ldw_vec_pos_match": (C.c_int, [_p, _i64, _p, _i64, _p]),
+    "ldw_compare_triplet": (C.c_int, [_p, _p, _i64, C.c_double, C.POINTER(C.c_int)]),
+    "ldw_fast_intersect": (C.c_int, [_p, _i64, _p, _i64, _p, C.POINTER(_i64)]),
+}
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} not found: build it with `make -C ldweaver_amd/csrc` or "
+                "`python -c 'import __graft_entry__ as g; g.build()'` — there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code: int):
+    if code != LDW_OK:
+        raise LdwError(code, lib().ldw_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a):
+    """Device or host pointer of a numpy array / torch tensor / int / None."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    if hasattr(a, "data_ptr"):  # torch tensor
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(f"cannot take a pointer of {type(a)}")
+
+
+def as_c(a, dtype, name="array"):
+    """C-contiguous numpy array of the given dtype (copy only if needed)."""
+    out = np.ascontiguousarray(a, dtype=dtype)
+    return out

@@ -1,0 +1,606 @@
+// Context, residency, set-up kernels and the small element-wise twins of libldweaver_amd.so.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "ldw_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+namespace ldw {
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    return LDW_ERR_HIP;
+}
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap && p) return LDW_OK;
+    if (p) {
+        LDW_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    LDW_HIP(hipMalloc(&p, want));
+    cap = want;
+    return LDW_OK;
+}
+
+int DevBuf::reserve_keep(size_t bytes, size_t used, hipStream_t s) {
+    if (bytes <= cap && p) return LDW_OK;
+    size_t want = bytes < 256 ? 256 : bytes;
+    if (want < cap * 2) want = cap * 2;  // geometric growth for the link tables
+    void *np = nullptr;
+    LDW_HIP(hipMalloc(&np, want));
+    if (p && used) {
+        LDW_HIP(hipMemcpyAsync(np, p, used, hipMemcpyDeviceToDevice, s));
+        LDW_HIP(hipStreamSynchronize(s));
+    }
+    if (p) LDW_HIP(hipFree(p));
+    p = np;
+    cap = want;
+    return LDW_OK;
+}
+
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+int check_gpu(ldw_ctx *ctx) {
+    LDW_REQUIRE(ctx != nullptr, LDW_ERR_ARG, "null context");
+    LDW_HIP(hipSetDevice(ctx->device));
+    return LDW_OK;
+}
+}  // namespace ldw
+
+using namespace ldw;
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+namespace ldw {
+
+// states [L][N] (tight) -> padded [L][Npad], pad value 255 (matches no state)
+__global__ void k_pad_states(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int64_t L, int64_t N,
+                             int64_t Npad) {
+    const int64_t a = blockIdx.x;
+    for (int64_t s = threadIdx.x; s < Npad; s += blockDim.x)
+        dst[a * Npad + s] = s < N ? src[a * N + s] : (uint8_t)255;
+}
+
+__global__ void k_unpad_states(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int64_t L, int64_t N,
+                               int64_t Npad) {
+    const int64_t a = blockIdx.x;
+    for (int64_t s = threadIdx.x; s < N; s += blockDim.x)
+        dst[a * N + s] = src[a * Npad + s];
+}
+
+// 5-state encoder (src/getACGTNsites.cpp:229-265): chars [N][L_total] -> states [n_pos][Npad]
+__device__ __forceinline__ uint8_t encode_char(unsigned char c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return 4;
+    }
+}
+
+__global__ void k_encode(const char *__restrict__ chars, int64_t N, int64_t L_total, const int32_t *__restrict__ pos,
+                         int64_t n_pos, uint8_t *__restrict__ states, int64_t Npad) {
+    // tile transpose through LDS: 64 positions x 64 sequences per workgroup, coalesced on both sides
+    // when the retained columns are dense; gathers when they are sparse.
+    __shared__ uint8_t tile[64][65];
+    const int64_t p0 = (int64_t)blockIdx.x * 64, s0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 256 threads: 64 x 4
+    for (int i = ty; i < 64; i += 4) {                       // i: sequence within tile, tx: position
+        const int64_t s = s0 + i, p = p0 + tx;
+        uint8_t v = 255;
+        if (s < N && p < n_pos) v = encode_char((unsigned char)chars[s * L_total + (pos[p] - 1)]);
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {  // i: position within tile, tx: sequence
+        const int64_t p = p0 + i, s = s0 + tx;
+        if (p < n_pos && s < Npad) states[p * Npad + s] = (s < N) ? tile[tx][i] : (uint8_t)255;
+    }
+}
+
+// per-SNP state counts and fixed-point weighted marginals.  One wave per SNP; each lane reads 4
+// consecutive sequences (one dword) per step.
+__global__ __launch_bounds__(256) void k_counts_marginals(const uint8_t *__restrict__ states, int64_t L, int64_t Npad,
+                                                          const int64_t *__restrict__ vfixed,  // may be null
+                                                          int32_t *__restrict__ counts, int64_t *__restrict__ pfix) {
+    const int lane = threadIdx.x & 63;
+    const int64_t a = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= L) return;
+    int cnt[5] = {0, 0, 0, 0, 0};
+    long long pf[5] = {0, 0, 0, 0, 0};
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(states + a * Npad);
+    for (int64_t q = lane; q < Npad / 4; q += 64) {
+        const uint32_t w = row[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t st = (w >> (8 * k)) & 0xFF;
+            const long long v = vfixed ? vfixed[q * 4 + k] : 0;
+#pragma unroll
+            for (int x = 0; x < 5; ++x) {
+                const bool hit = st == (uint32_t)x;
+                cnt[x] += hit ? 1 : 0;
+                pf[x] += hit ? v : 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 5; ++x) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            cnt[x] += __shfl_xor(cnt[x], off);
+            pf[x] += __shfl_xor(pf[x], off);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int x = 0; x < 5; ++x) {
+            counts[a * 5 + x] = cnt[x];
+            if (pfix) pfix[a * 5 + x] = pf[x];
+        }
+    }
+}
+
+// indicator rows: M[row][s] = 0xFF iff states[snp(row)][s] == state(row); 16 sequences per thread
+__global__ __launch_bounds__(256) void k_fill_rows(const uint8_t *__restrict__ states, int64_t Npad,
+                                                   const int32_t *__restrict__ rowinfo,  // snp*8 + state
+                                                   int64_t R, uint8_t *__restrict__ M) {
+    const int64_t row = blockIdx.x;
+    const int32_t info = rowinfo[row];
+    const int64_t snp = info >> 3;
+    const uint32_t pat = (uint32_t)(info & 7) * 0x01010101u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(states + snp * Npad);
+    uint4 *dst = reinterpret_cast<uint4 *>(M + row * Npad);
+    for (int64_t q = threadIdx.x; q < Npad / 16; q += blockDim.x) {
+        uint4 v = src[q];
+        auto eqmask = [pat](uint32_t x) -> uint32_t {
+            const uint32_t t = x ^ pat;  // zero bytes where equal
+            uint32_t m = ((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t;
+            m = ~(m | 0x7F7F7F7Fu);      // 0x80 where the byte of t is zero
+            return (m >> 7) * 0xFFu;
+        };
+        v.x = eqmask(v.x);
+        v.y = eqmask(v.y);
+        v.z = eqmask(v.z);
+        v.w = eqmask(v.w);
+        dst[q] = v;
+    }
+}
+
+// .ACGTN2num (src/ACGTN2num_parallel.cpp:10-43): zero the reference-allele entry of each 5-column
+__global__ void k_acgtn2num(double *__restrict__ nv, const char *__restrict__ ref, int64_t L) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= L) return;
+    const char cc = ref[c];
+    int rowi = -1;
+    if (cc == 'A') rowi = 0;
+    else if (cc == 'C') rowi = 1;
+    else if (cc == 'G') rowi = 2;
+    else if (cc == 'T') rowi = 3;
+    else if (cc == 'N' || cc == '-') rowi = 4;
+    if (rowi >= 0) nv[c * 5 + rowi] = 0.0;
+}
+
+// .fastHadamard (src/computeMI.cpp:19), same association order
+__global__ void k_fast_hadamard(double *__restrict__ MI, const double *__restrict__ den, const double *__restrict__ uq,
+                                const double *__restrict__ pxy, const double *__restrict__ pxpy,
+                                const double *__restrict__ RXY, const double *__restrict__ pXrX,
+                                const double *__restrict__ pYrY, int64_t n) {
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x) {
+        const double d = ((pxpy[c] + RXY[c]) + pXrX[c]) + pYrY[c];
+        MI[c] += ((uq[c] * pxy[c]) / den[c]) * log((pxy[c] / d) * den[c]);
+    }
+}
+
+}  // namespace ldw
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int ldw_version(void) { return 100; }
+
+const char *ldw_last_error(void) { return ldw::g_err; }
+
+int ldw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ldw_ctx_create(int device, ldw_ctx **out) {
+    LDW_REQUIRE(out != nullptr, LDW_ERR_ARG, "ldw_ctx_create: out is null");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("ldw_ctx_create: no HIP device visible; this library has no CPU fallback");
+        return LDW_ERR_NOGPU;
+    }
+    LDW_REQUIRE(device >= 0 && device < n, LDW_ERR_ARG, "ldw_ctx_create: device %d out of range (0..%d)", device, n - 1);
+    LDW_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    LDW_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("ldw_ctx_create: device %d is %s; kernels are built for gfx950 only", device, prop.gcnArchName);
+        return LDW_ERR_NOGPU;
+    }
+    ldw_ctx *c = new ldw_ctx();
+    c->device = device;
+    LDW_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    for (auto &e : c->ev) LDW_HIP(hipEventCreate(&e));
+    *out = c;
+    return LDW_OK;
+}
+
+int ldw_ctx_destroy(ldw_ctx *c) {
+    if (!c) return LDW_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    ldw::DevBuf *bufs[] = {&c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->M, &c->row0,
+                           &c->slot_meta, &c->slot_pfix, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
+                           &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->hist, &c->colcnt, &c->cand_key,
+                           &c->cand_val, &c->cand_key2, &c->cand_val2, &c->scratch, &c->small, &c->sr_a, &c->sr_b,
+                           &c->sr_mi, &c->lr_a, &c->lr_b, &c->lr_mi};
+    for (auto *b : bufs) b->release();
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return LDW_OK;
+}
+
+int ldw_ctx_set_stream(ldw_ctx *c, void *s) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) LDW_HIP(hipStreamDestroy(c->stream));
+    if (s) {
+        c->stream = (hipStream_t)s;
+        c->own_stream = false;
+    } else {
+        LDW_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return LDW_OK;
+}
+
+int ldw_ctx_sync(ldw_ctx *c) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
+
+int ldw_ctx_last_timing(ldw_ctx *c, double ms_out[4]) {
+    LDW_REQUIRE(c && ms_out, LDW_ERR_ARG, "ldw_ctx_last_timing: null argument");
+    for (int i = 0; i < 4; ++i) ms_out[i] = c->last_ms[i];
+    return LDW_OK;
+}
+
+int ldw_set_engine(ldw_ctx *c, int engine) {
+    LDW_REQUIRE(c, LDW_ERR_ARG, "null context");
+    LDW_REQUIRE(engine == LDW_ENGINE_MFMA || engine == LDW_ENGINE_HIST, LDW_ERR_ARG, "unknown engine %d", engine);
+    c->engine = engine;
+    return LDW_OK;
+}
+
+// ---- (1) ACGTN2num --------------------------------------------------------------------------------
+int ldw_acgtn2num_dev(ldw_ctx *c, double *nv_dev, const char *ref_dev, int64_t L) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(nv_dev && ref_dev && L >= 0, LDW_ERR_ARG, "ldw_acgtn2num_dev: bad argument");
+    if (L == 0) return LDW_OK;
+    hipLaunchKernelGGL(k_acgtn2num, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, c->stream, nv_dev, ref_dev, L);
+    LDW_HIP(hipGetLastError());
+    return LDW_OK;
+}
+
+int ldw_acgtn2num(ldw_ctx *c, double *nv, const char *ref, int64_t L, int /*ncores*/) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(nv && ref && L >= 0, LDW_ERR_ARG, "ldw_acgtn2num: bad argument");
+    if (L == 0) return LDW_OK;
+    if (int rc = c->scratch.reserve((size_t)L * 41 + 64)) return rc;
+    double *d_nv = c->scratch.as<double>();
+    char *d_ref = reinterpret_cast<char *>(d_nv + 5 * L);
+    LDW_HIP(hipMemcpyAsync(d_nv, nv, (size_t)L * 40, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemcpyAsync(d_ref, ref, (size_t)L, hipMemcpyHostToDevice, c->stream));
+    if (int rc = ldw_acgtn2num_dev(c, d_nv, d_ref, L)) return rc;
+    LDW_HIP(hipMemcpyAsync(nv, d_nv, (size_t)L * 40, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
+
+// ---- (3) fastHadamard ---------------------------------------------------------------------------
+int ldw_fast_hadamard(ldw_ctx *c, double *MI, const double *den, const double *uq, const double *pxy,
+                      const double *pxpy, const double *RXY, const double *pXrX, const double *pYrY, int64_t n,
+                      int on_device) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(MI && den && uq && pxy && pxpy && RXY && pXrX && pYrY && n >= 0, LDW_ERR_ARG,
+                "ldw_fast_hadamard: bad argument");
+    if (n == 0) return LDW_OK;
+    const double *src[8] = {MI, den, uq, pxy, pxpy, RXY, pXrX, pYrY};
+    const double *dv[8];
+    if (on_device) {
+        for (int i = 0; i < 8; ++i) dv[i] = src[i];
+    } else {
+        if (int rc = c->scratch.reserve((size_t)n * 64)) return rc;
+        for (int i = 0; i < 8; ++i) {
+            double *d = c->scratch.as<double>() + (size_t)i * n;
+            LDW_HIP(hipMemcpyAsync(d, src[i], (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+            dv[i] = d;
+        }
+    }
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_fast_hadamard, dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)), dim3(256), 0,
+                       c->stream, const_cast<double *>(dv[0]), dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], dv[7], n);
+    LDW_HIP(hipGetLastError());
+    if (!on_device) {
+        LDW_HIP(hipMemcpyAsync(MI, dv[0], (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+    }
+    return LDW_OK;
+}
+
+// ---- alignment residency ------------------------------------------------------------------------
+static int set_dims(ldw_ctx *c, int64_t L, int64_t N) {
+    LDW_REQUIRE(L > 0 && N > 0, LDW_ERR_ARG, "alignment must be non-empty (L=%lld N=%lld)", (long long)L, (long long)N);
+    LDW_REQUIRE(L < (int64_t)1 << 27, LDW_ERR_ARG, "L too large (%lld)", (long long)L);
+    c->L = L;
+    c->N = N;
+    c->Npad = (N + KSTEP - 1) / KSTEP * KSTEP;
+    c->rows_ready = false;
+    c->have_weights = false;
+    c->have_meta = false;
+    return c->states.reserve((size_t)L * c->Npad);
+}
+
+int ldw_set_alignment(ldw_ctx *c, const uint8_t *states, int64_t L, int64_t N, int on_device) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(states, LDW_ERR_ARG, "ldw_set_alignment: states is null");
+    if (int rc = set_dims(c, L, N)) return rc;
+    const uint8_t *src = states;
+    if (!on_device) {
+        if (int rc = c->scratch.reserve((size_t)L * N)) return rc;
+        LDW_HIP(hipMemcpyAsync(c->scratch.p, states, (size_t)L * N, hipMemcpyHostToDevice, c->stream));
+        src = c->scratch.as<uint8_t>();
+    }
+    hipLaunchKernelGGL(k_pad_states, dim3((unsigned)L), dim3(256), 0, c->stream, src, c->states.as<uint8_t>(), L, N, c->Npad);
+    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
+
+int ldw_get_alignment(ldw_ctx *c, uint8_t *out) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(out && c->L > 0, LDW_ERR_STATE, "ldw_get_alignment: no alignment resident");
+    if (int rc = c->scratch.reserve((size_t)c->L * c->N)) return rc;
+    hipLaunchKernelGGL(k_unpad_states, dim3((unsigned)c->L), dim3(256), 0, c->stream, c->states.as<uint8_t>(), c->scratch.as<uint8_t>(),
+                       c->L, c->N, c->Npad);
+    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipMemcpyAsync(out, c->scratch.p, (size_t)c->L * c->N, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
+
+int ldw_state_counts(ldw_ctx *c, int32_t *counts_out) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(counts_out && c->L > 0, LDW_ERR_STATE, "ldw_state_counts: no alignment resident");
+    if (int rc = c->counts.reserve((size_t)c->L * 5 * 4)) return rc;
+    hipLaunchKernelGGL(k_counts_marginals, dim3((unsigned)((c->L + 3) / 4)), dim3(256), 0, c->stream,
+                       c->states.as<uint8_t>(), c->L, c->Npad, (const int64_t *)nullptr, c->counts.as<int32_t>(),
+                       (int64_t *)nullptr);
+    LDW_HIP(hipGetLastError());
+    // stored [L][5] row-major == 5 x L column-major (ACGTN_table layout)
+    LDW_HIP(hipMemcpyAsync(counts_out, c->counts.p, (size_t)c->L * 20, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
+
+int ldw_encode_alignment(ldw_ctx *c, const char *chars, int64_t N, int64_t L_total, const int32_t *pos, int64_t n_pos,
+                         int32_t *acgtn_table_out) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(chars && pos && N > 0 && L_total > 0 && n_pos > 0, LDW_ERR_ARG, "ldw_encode_alignment: bad argument");
+    for (int64_t i = 0; i < n_pos; ++i)
+        LDW_REQUIRE(pos[i] >= 1 && pos[i] <= L_total, LDW_ERR_ARG, "ldw_encode_alignment: pos[%lld]=%d outside 1..%lld",
+                    (long long)i, pos[i], (long long)L_total);
+    if (int rc = set_dims(c, n_pos, N)) return rc;
+    const size_t cb = (size_t)N * L_total, cb16 = ((cb + 15) / 16) * 16;
+    if (int rc = c->scratch.reserve(cb16 + (size_t)n_pos * 4)) return rc;
+    char *d_chars = c->scratch.as<char>();
+    int32_t *d_pos = reinterpret_cast<int32_t *>(d_chars + cb16);
+    LDW_HIP(hipMemcpyAsync(d_chars, chars, cb, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemcpyAsync(d_pos, pos, (size_t)n_pos * 4, hipMemcpyHostToDevice, c->stream));
+    dim3 grid((unsigned)((n_pos + 63) / 64), (unsigned)((c->Npad + 63) / 64));
+    hipLaunchKernelGGL(k_encode, grid, dim3(256), 0, c->stream, d_chars, N, L_total, d_pos, n_pos,
+                       c->states.as<uint8_t>(), c->Npad);
+    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    if (acgtn_table_out) return ldw_state_counts(c, acgtn_table_out);
+    return LDW_OK;
+}
+
+// ---- weights / meta -------------------------------------------------------------------------------
+int ldw_set_weights(ldw_ctx *c, const double *hdw, int64_t N, int nlimbs) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(c->L > 0, LDW_ERR_STATE, "ldw_set_weights: set the alignment first");
+    LDW_REQUIRE(hdw && N == c->N, LDW_ERR_ARG, "ldw_set_weights: hdw has %lld entries, alignment has %lld sequences",
+                (long long)N, (long long)c->N);
+    if (nlimbs == 0) nlimbs = 5;
+    LDW_REQUIRE(nlimbs >= 1 && nlimbs <= 6, LDW_ERR_ARG, "ldw_set_weights: nlimbs must be 1..6");
+    std::vector<double> v((size_t)N);
+    long double neff = 0.0L, vsum = 0.0L;
+    double vmax = 0;
+    for (int64_t s = 0; s < N; ++s) {
+        LDW_REQUIRE(std::isfinite(hdw[s]) && hdw[s] >= 0, LDW_ERR_ARG, "ldw_set_weights: hdw[%lld] = %g is not a finite non-negative weight",
+                    (long long)s, hdw[s]);
+        const double sq = std::sqrt(hdw[s]);
+        v[s] = sq * sq;  // the reference multiplies two sqrt(w)-scaled one-hots (R/computePairwiseMI.R:238,391)
+        neff += (long double)hdw[s];
+        vsum += (long double)v[s];
+        if (v[s] > vmax) vmax = v[s];
+    }
+    LDW_REQUIRE(vmax > 0, LDW_ERR_ARG, "ldw_set_weights: all weights are zero");
+    // fixed point: V_s = round(v_s * 2^F) must fit nlimbs balanced base-256 digits and every sum of V_s must
+    // stay below 2^52 so that counts convert to double exactly.
+    const double lim_digits = 0.99 * std::ldexp(1.0, 8 * nlimbs - 1) / vmax;
+    const double lim_sum = std::ldexp(1.0, 52) / (double)vsum;
+    int F = (int)std::floor(std::log2(std::fmin(lim_digits, lim_sum)));
+    bool unit = true;  // all weights exactly 1 (unweighted counts): F = 0 is exact with one limb
+    for (int64_t s = 0; s < N; ++s) unit = unit && (v[s] == 1.0);
+    if (unit) F = 0;
+    c->nlimbs = nlimbs;
+    c->frac_bits = F;
+    c->neff = (double)neff;
+    c->h_vfixed.assign((size_t)c->Npad, 0);
+    std::vector<int8_t> dig((size_t)nlimbs * c->Npad, 0);
+    int64_t total = 0;
+    for (int64_t s = 0; s < N; ++s) {
+        int64_t V = (int64_t)std::llround(std::ldexp(v[s], F));
+        c->h_vfixed[s] = V;
+        total += V;
+        int64_t rem = V;
+        for (int j = 0; j < nlimbs; ++j) {
+            int64_t d = ((rem + 128) & 255) - 128;  // balanced digit in [-128, 127]
+            dig[(size_t)j * c->Npad + s] = (int8_t)d;
+            rem = (rem - d) / 256;
+        }
+        LDW_REQUIRE(rem == 0, LDW_ERR_ARG, "ldw_set_weights: internal: weight %g does not fit %d limbs at F=%d", v[s], nlimbs, F);
+    }
+    c->total_fixed = total;
+    if (int rc = c->digits.reserve(dig.size())) return rc;
+    if (int rc = c->vfixed.reserve((size_t)c->Npad * 8)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->digits.p, dig.data(), dig.size(), hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemcpyAsync(c->vfixed.p, c->h_vfixed.data(), (size_t)c->Npad * 8, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    c->have_weights = true;
+    c->rows_ready = false;
+    return LDW_OK;
+}
+
+int ldw_set_snp_meta(ldw_ctx *c, const double *r, const uint8_t *uqe, const int32_t *POS, const int32_t *paint, double g) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(c->L > 0, LDW_ERR_STATE, "ldw_set_snp_meta: set the alignment first");
+    LDW_REQUIRE(r && uqe && POS, LDW_ERR_ARG, "ldw_set_snp_meta: null argument");
+    LDW_REQUIRE(g > 0, LDW_ERR_ARG, "ldw_set_snp_meta: genome length g must be positive (snp.dat$g)");
+    const int64_t L = c->L;
+    for (int64_t i = 0; i < L * 5; ++i) LDW_REQUIRE(uqe[i] <= 1, LDW_ERR_ARG, "ldw_set_snp_meta: uqe must be 0/1");
+    if (int rc = c->r.reserve((size_t)L * 8)) return rc;
+    if (int rc = c->uqe.reserve((size_t)L * 5)) return rc;
+    if (int rc = c->POS.reserve((size_t)L * 4)) return rc;
+    if (int rc = c->paint.reserve((size_t)L * 4)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->r.p, r, (size_t)L * 8, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemcpyAsync(c->uqe.p, uqe, (size_t)L * 5, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemcpyAsync(c->POS.p, POS, (size_t)L * 4, hipMemcpyHostToDevice, c->stream));
+    if (paint) LDW_HIP(hipMemcpyAsync(c->paint.p, paint, (size_t)L * 4, hipMemcpyHostToDevice, c->stream));
+    else LDW_HIP(hipMemsetAsync(c->paint.p, 0, (size_t)L * 4, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    c->h_r.assign(r, r + L);
+    c->h_POS.assign(POS, POS + L);
+    c->g = g;
+    c->have_meta = true;
+    c->rows_ready = false;
+    return LDW_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// row map: which (SNP, state) pairs get an indicator row
+// ------------------------------------------------------------------------------------------------
+namespace ldw {
+
+int ensure_rows(ldw_ctx *c) {
+    if (c->rows_ready) return LDW_OK;
+    LDW_REQUIRE(c->L > 0 && c->have_weights && c->have_meta, LDW_ERR_STATE,
+                "MI needs the alignment, the weights and the SNP meta data to be set first");
+    const int64_t L = c->L, Npad = c->Npad;
+    if (int rc = c->counts.reserve((size_t)L * 20)) return rc;
+    if (int rc = c->slot_pfix.reserve((size_t)L * 40)) return rc;
+    if (int rc = c->pfix_state.reserve((size_t)L * 40)) return rc;
+    int64_t *d_pfix_state = c->pfix_state.as<int64_t>();  // [L][5] by state
+    hipLaunchKernelGGL(k_counts_marginals, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, c->stream,
+                       c->states.as<uint8_t>(), L, Npad, c->vfixed.as<int64_t>(), c->counts.as<int32_t>(), d_pfix_state);
+    LDW_HIP(hipGetLastError());
+    c->h_counts.resize((size_t)L * 5);
+    std::vector<int64_t> pfs((size_t)L * 5);
+    std::vector<uint8_t> uqe((size_t)L * 5);
+    LDW_HIP(hipMemcpyAsync(c->h_counts.data(), c->counts.p, (size_t)L * 20, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(pfs.data(), d_pfix_state, (size_t)L * 40, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(uqe.data(), c->uqe.p, (size_t)L * 5, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+
+    // Slots of SNP a: one per state that is present (count > 0) or flagged in uqe.  The most frequent
+    // present state is the "drop" slot: it gets no indicator row, its joint cells follow from the
+    // marginals by exact integer subtraction.  Rows are the remaining slots in increasing state order.
+    c->h_row0.assign((size_t)L + 1, 0);
+    std::vector<uint32_t> meta((size_t)L);
+    std::vector<int64_t> spf((size_t)L * 5, 0);
+    std::vector<int32_t> rowinfo;
+    rowinfo.reserve((size_t)L * 2);
+    for (int64_t a = 0; a < L; ++a) {
+        const int32_t *cnt = &c->h_counts[a * 5];
+        int drop = -1;
+        for (int x = 0; x < 5; ++x)
+            if (cnt[x] > 0 && (drop < 0 || cnt[x] > cnt[drop])) drop = x;
+        LDW_REQUIRE(drop >= 0, LDW_ERR_ARG, "SNP %lld has no valid state (all sequences outside 0..4)", (long long)a);
+        uint32_t m = 0;
+        int nrows = 0;
+        for (int x = 0; x < 5; ++x) {
+            if (x == drop) continue;
+            if (cnt[x] > 0 || uqe[a * 5 + x]) {
+                m |= (uint32_t)uqe[a * 5 + x] << (3 + nrows);
+                m |= (uint32_t)x << (8 + 3 * nrows);
+                spf[a * 5 + nrows] = pfs[a * 5 + x];
+                rowinfo.push_back((int32_t)(a * 8 + x));
+                ++nrows;
+            }
+        }
+        m |= (uint32_t)uqe[a * 5 + drop] << (3 + nrows);
+        m |= (uint32_t)drop << (8 + 3 * nrows);
+        spf[a * 5 + nrows] = pfs[a * 5 + drop];
+        m |= (uint32_t)nrows;
+        meta[a] = m;
+        c->h_row0[a + 1] = c->h_row0[a] + nrows;
+    }
+    c->R = c->h_row0[L];
+    const int64_t R = c->R;
+    if (int rc = c->row0.reserve((size_t)(L + 1) * 4)) return rc;
+    if (int rc = c->slot_meta.reserve((size_t)L * 4)) return rc;
+    if (int rc = c->M.reserve((size_t)(R + TILE) * Npad)) return rc;
+    if (int rc = c->small.reserve((size_t)(R + 1) * 4)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->row0.p, c->h_row0.data(), (size_t)(L + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemcpyAsync(c->slot_meta.p, meta.data(), (size_t)L * 4, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemcpyAsync(c->slot_pfix.p, spf.data(), (size_t)L * 40, hipMemcpyHostToDevice, c->stream));
+    // rows R .. R+TILE-1 stay zero: tile padding of the row lists points at row R
+    LDW_HIP(hipMemsetAsync(c->M.as<uint8_t>() + (size_t)R * Npad, 0, (size_t)TILE * Npad, c->stream));
+    if (R > 0) {
+        LDW_HIP(hipMemcpyAsync(c->small.p, rowinfo.data(), (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+        LDW_REQUIRE(R < 2147483647LL, LDW_ERR_ARG, "too many indicator rows");
+        hipLaunchKernelGGL(k_fill_rows, dim3((unsigned)R), dim3(256), 0, c->stream, c->states.as<uint8_t>(), Npad,
+                           c->small.as<int32_t>(), R, c->M.as<uint8_t>());
+        LDW_HIP(hipGetLastError());
+    }
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    c->rows_ready = true;
+    return LDW_OK;
+}
+
+}  // namespace ldw

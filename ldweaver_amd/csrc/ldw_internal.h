@@ -1,0 +1,113 @@
+// Internal declarations shared by the translation units of libldweaver_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ldweaver_amd.h"
+
+namespace ldw {
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define LDW_HIP(call)                                                        \
+    do {                                                                     \
+        hipError_t e__ = (call);                                             \
+        if (e__ != hipSuccess) return ldw::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define LDW_REQUIRE(cond, code, ...)   \
+    do {                               \
+        if (!(cond)) {                 \
+            ldw::set_error(__VA_ARGS__); \
+            return (code);             \
+        }                              \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);  // returns LDW_OK / error; contents NOT preserved on growth
+    int reserve_keep(size_t bytes, size_t used, hipStream_t s);  // preserves the first `used` bytes
+    void release();
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+constexpr int TILE = 128;     // GEMM block tile (rows on both sides)
+constexpr int KSTEP = 64;     // bytes of K (sequences) per pipeline stage
+constexpr int NBINS = 4096;   // level-1 histogram bins of the lr quantile search
+constexpr double MI_HIST_MAX = 1.75;  // > log(5): upper bound of a 5-state MI with pseudocounts
+
+struct BlockStat {
+    int64_t n_lr_total = 0, n_lr_kept = 0, n_sr = 0;
+    double disc_thresh = 0;
+};
+
+}  // namespace ldw
+
+struct ldw_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double last_ms[4] = {0, 0, 0, 0};
+    int engine = LDW_ENGINE_MFMA;
+
+    // ---- alignment ----
+    int64_t L = 0, N = 0, Npad = 0;  // Npad: N rounded up to a multiple of KSTEP
+    ldw::DevBuf states;              // uint8 [L][N]
+
+    // ---- weights ----
+    bool have_weights = false;
+    int nlimbs = 5;
+    int frac_bits = 0;
+    double neff = 0;            // sum(hdw) like R's sum()
+    int64_t total_fixed = 0;    // sum of quantised weights
+    ldw::DevBuf digits;         // int8 [nlimbs][Npad] balanced base-256 digits of V_s
+    ldw::DevBuf vfixed;         // int64 [Npad] quantised weights V_s (0 in the padding)
+    std::vector<int64_t> h_vfixed;
+
+    // ---- per-SNP meta ----
+    bool have_meta = false;
+    double g = 0;
+    ldw::DevBuf r, uqe, POS, paint;  // double[L], uint8[L][5], int32[L], int32[L]
+    std::vector<double> h_r;
+    std::vector<int32_t> h_POS;
+
+    // ---- row map (built lazily from alignment + weights + meta) ----
+    bool rows_ready = false;
+    int64_t R = 0;               // number of indicator rows over all SNPs
+    ldw::DevBuf M;               // uint8 [R + TILE][Npad]: 0xFF where the sequence carries the row's state
+    ldw::DevBuf row0;            // int32 [L+1]: first row of each SNP
+    ldw::DevBuf slot_meta;       // uint32 [L]: nrows (3 bits) | uq-by-slot (5 bits <<3) | slot states (5 x 3 bits << 8)
+    ldw::DevBuf slot_pfix;       // int64 [L][5]: fixed-point marginal of the state in each slot
+    ldw::DevBuf counts;          // int32 [L][5] per-SNP state counts
+    ldw::DevBuf pfix_state;      // int64 [L][5]: fixed-point marginal of each state (histogram engine)
+    std::vector<int32_t> h_row0;
+    std::vector<int32_t> h_counts;
+
+    // ---- per-block workspaces ----
+    ldw::DevBuf G;               // int64 [RTpad][RFpad]
+    ldw::DevBuf MIblk;           // double [nf*nt]
+    ldw::DevBuf rowlist_f, rowlist_t, idx_f, idx_t, lrow_f, lrow_t;
+    ldw::DevBuf hist, colcnt, cand_key, cand_val, cand_key2, cand_val2, scratch, small;
+
+    // ---- link tables (device resident) ----
+    ldw::DevBuf sr_a, sr_b, sr_mi, lr_a, lr_b, lr_mi;
+    int64_t n_sr = 0, n_lr = 0;
+    std::vector<ldw::BlockStat> stats;
+};
+
+namespace ldw {
+// launchers implemented in the .hip files (all asynchronous on ctx->stream)
+int ensure_rows(ldw_ctx *ctx);
+int launch_gemm(ldw_ctx *ctx, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f, int RFpad,
+                int64_t *G, int nlimbs, const int8_t *digits, const uint8_t *Mbase, int64_t Kpad,
+                int lower_only, int accumulate);
+int launch_hist(ldw_ctx *ctx, const int32_t *idx_f, int nf, const int32_t *idx_t, int nt, const int64_t *pfix_state,
+                int quirk, int lower_only, double *MI);
+int check_gpu(ldw_ctx *ctx);
+}  // namespace ldw

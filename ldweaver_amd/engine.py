@@ -1,0 +1,197 @@
+"""Thin object wrapper over the C ABI: one Engine = one ldw_ctx on one GPU."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _is_torch(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+class Engine:
+    def __init__(self, device: int = 0, stream=None):
+        self._ctx = C.c_void_p()
+        L.check(L.lib().ldw_ctx_create(int(device), C.byref(self._ctx)))
+        self.device = int(device)
+        self.L = self.N = 0
+        if stream is not None:
+            self.set_stream(stream)
+
+    # -- lifetime ------------------------------------------------------------
+    def close(self):
+        if self._ctx:
+            L.lib().ldw_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream):
+        """stream: a raw hipStream_t value (int), e.g. torch.cuda.current_stream().cuda_stream; None/0 = own stream."""
+        L.check(L.lib().ldw_ctx_set_stream(self._ctx, C.c_void_p(int(stream) if stream else 0)))
+
+    def sync(self):
+        L.check(L.lib().ldw_ctx_sync(self._ctx))
+
+    def last_timing(self):
+        t = np.zeros(4)
+        L.check(L.lib().ldw_ctx_last_timing(self._ctx, L.ptr(t)))
+        return dict(gemm_ms=t[0], epilogue_ms=t[1], select_ms=t[2], total_ms=t[3])
+
+    def set_engine(self, engine: int):
+        L.check(L.lib().ldw_set_engine(self._ctx, int(engine)))
+
+    # -- alignment -----------------------------------------------------------
+    def set_alignment(self, states):
+        """states: (L, N) uint8 numpy array or CUDA torch tensor (values 0..4)."""
+        if _is_torch(states):
+            assert states.dtype.__str__() == "torch.uint8" and states.dim() == 2 and states.is_contiguous()
+            Ls, Ns = states.shape
+            L.check(L.lib().ldw_set_alignment(self._ctx, L.ptr(states), Ls, Ns, 1 if states.is_cuda else 0))
+        else:
+            st = L.as_c(states, np.uint8)
+            assert st.ndim == 2
+            Ls, Ns = st.shape
+            L.check(L.lib().ldw_set_alignment(self._ctx, L.ptr(st), Ls, Ns, 0))
+        self.L, self.N = int(Ls), int(Ns)
+
+    def encode_alignment(self, chars: np.ndarray, pos: np.ndarray, want_table=True):
+        """chars: (N, L_total) bytes (S1/uint8), pos: 1-based retained columns. Returns ACGTN_table (5, n_pos)."""
+        ch = L.as_c(chars.view(np.uint8) if chars.dtype != np.uint8 else chars, np.uint8)
+        ps = L.as_c(pos, np.int32)
+        tab = np.zeros((len(ps), 5), dtype=np.int32) if want_table else None
+        L.check(L.lib().ldw_encode_alignment(self._ctx, L.ptr(ch), ch.shape[0], ch.shape[1], L.ptr(ps), len(ps), L.ptr(tab)))
+        self.L, self.N = len(ps), ch.shape[0]
+        return None if tab is None else np.ascontiguousarray(tab.T)
+
+    def get_alignment(self) -> np.ndarray:
+        out = np.empty((self.L, self.N), dtype=np.uint8)
+        L.check(L.lib().ldw_get_alignment(self._ctx, L.ptr(out)))
+        return out
+
+    def state_counts(self) -> np.ndarray:
+        out = np.empty((self.L, 5), dtype=np.int32)
+        L.check(L.lib().ldw_state_counts(self._ctx, L.ptr(out)))
+        return np.ascontiguousarray(out.T)  # 5 x L like ACGTN_table
+
+    # -- Hamming weights -------------------------------------------------------
+    def hamming_weights(self, thresh: int, want_shared=False):
+        hdw = np.empty(self.N, dtype=np.float64)
+        shared = np.empty((self.N, self.N), dtype=np.int32) if want_shared else None
+        L.check(L.lib().ldw_hamming_weights(self._ctx, int(thresh), L.ptr(hdw), L.ptr(shared)))
+        return (hdw, shared) if want_shared else hdw
+
+    # -- MI --------------------------------------------------------------------
+    def set_weights(self, hdw, nlimbs: int = 0):
+        w = L.as_c(hdw, np.float64)
+        L.check(L.lib().ldw_set_weights(self._ctx, L.ptr(w), len(w), int(nlimbs)))
+
+    def set_snp_meta(self, r, uqe, POS, paint, g):
+        r_ = L.as_c(r, np.float64)
+        uq = L.as_c(np.asarray(uqe) != 0, np.uint8)
+        ps = L.as_c(POS, np.int32)
+        pt = None if paint is None else L.as_c(paint, np.int32)
+        assert r_.shape == (self.L,) and uq.shape == (self.L, 5) and ps.shape == (self.L,)
+        L.check(L.lib().ldw_set_snp_meta(self._ctx, L.ptr(r_), L.ptr(uq), L.ptr(ps), L.ptr(pt), float(g)))
+
+    def mi_block(self, from_idx, to_idx, quirk=L.QUIRK_REFERENCE, out=None) -> np.ndarray:
+        """MI of one block as the reference's nf x nt matrix (Fortran order)."""
+        fi = L.as_c(from_idx, np.int32)
+        ti = L.as_c(to_idx, np.int32)
+        if out is not None and _is_torch(out):
+            L.check(L.lib().ldw_mi_block(self._ctx, L.ptr(fi), len(fi), L.ptr(ti), len(ti), quirk, L.ptr(out), 1))
+            return out
+        buf = np.empty(len(fi) * len(ti), dtype=np.float64)
+        L.check(L.lib().ldw_mi_block(self._ctx, L.ptr(fi), len(fi), L.ptr(ti), len(ti), quirk, L.ptr(buf), 0))
+        return buf.reshape((len(fi), len(ti)), order="F")
+
+    def joint_tables(self, pair_a, pair_b):
+        """(counts, fixed, frac_bits): int64 (P,5,5) unweighted joint counts and fixed-point weighted sums."""
+        pa = L.as_c(pair_a, np.int32)
+        pb = L.as_c(pair_b, np.int32)
+        cnt = np.empty((len(pa), 5, 5), dtype=np.int64)
+        fix = np.empty((len(pa), 5, 5), dtype=np.int64)
+        fb = C.c_int(0)
+        L.check(L.lib().ldw_joint_tables(self._ctx, L.ptr(pa), L.ptr(pb), len(pa), L.ptr(cnt), L.ptr(fix), C.byref(fb)))
+        return cnt, fix, fb.value
+
+    def mi_all_pairs(self, blocks, sr_dist=20000.0, lr_retain_links=1e6, lr_links_approx=1.0, sr_only=False,
+                     quirk=L.QUIRK_REFERENCE, keep_sr=True):
+        """blocks: (nb, 4) int32 rows (from_s, from_e, to_s, to_e), 1-based inclusive."""
+        bl = L.as_c(blocks, np.int32).reshape(-1, 4)
+        p = L.MIParams(float(sr_dist), float(lr_retain_links), float(lr_links_approx), int(bool(sr_only)), int(quirk),
+                       int(bool(keep_sr)), 0)
+        L.check(L.lib().ldw_mi_all_pairs(self._ctx, L.ptr(bl), len(bl), C.byref(p), 1))
+        self._nblocks = len(bl)
+
+    def links_count(self, which: int) -> int:
+        n = C.c_int64(0)
+        L.check(L.lib().ldw_links_count(self._ctx, int(which), C.byref(n)))
+        return int(n.value)
+
+    def links(self, which: int, device_tensors=False):
+        """(a, b, MI): 0-based from-side / to-side SNP indices and MI of the short-range (0) or long-range (1) table."""
+        n = self.links_count(which)
+        if device_tensors:
+            import torch
+            dev = torch.device("cuda", self.device)
+            a = torch.empty(n, dtype=torch.int32, device=dev)
+            b = torch.empty(n, dtype=torch.int32, device=dev)
+            mi = torch.empty(n, dtype=torch.float64, device=dev)
+            L.check(L.lib().ldw_links_fetch(self._ctx, which, L.ptr(a), L.ptr(b), L.ptr(mi), n, 1))
+            return a, b, mi
+        a = np.empty(n, dtype=np.int32)
+        b = np.empty(n, dtype=np.int32)
+        mi = np.empty(n, dtype=np.float64)
+        L.check(L.lib().ldw_links_fetch(self._ctx, which, L.ptr(a), L.ptr(b), L.ptr(mi), n, 0))
+        return a, b, mi
+
+    def block_stats(self):
+        nb = self._nblocks
+        t = np.empty(nb, dtype=np.int64)
+        k = np.empty(nb, dtype=np.int64)
+        s = np.empty(nb, dtype=np.int64)
+        d = np.empty(nb, dtype=np.float64)
+        L.check(L.lib().ldw_block_stats(self._ctx, nb, L.ptr(t), L.ptr(k), L.ptr(s), L.ptr(d)))
+        return dict(n_lr_total=t, n_lr_kept=k, n_sr=s, disc_thresh=d)
+
+    # -- element-wise twins ------------------------------------------------------
+    def acgtn2num(self, nv: np.ndarray, ref_chars) -> None:
+        """In-place twin of .ACGTN2num: nv is a Fortran-ordered (5, L) float64 matrix."""
+        assert nv.dtype == np.float64 and nv.shape[0] == 5 and nv.flags.f_contiguous
+        if isinstance(ref_chars, (bytes, bytearray)):
+            ref = bytes(ref_chars)
+        else:  # like as<char>(cv[c]): first character of each string ("" -> NUL, leaves the column untouched)
+            ref = b"".join((bytes(s[:1]) if isinstance(s, (bytes, bytearray)) else str(s)[:1].encode("latin1")) or b"\0"
+                           for s in ref_chars)
+        assert len(ref) == nv.shape[1]
+        buf = C.create_string_buffer(ref, len(ref))
+        L.check(L.lib().ldw_acgtn2num(self._ctx, L.ptr(nv), C.cast(buf, C.c_void_p), nv.shape[1], 1))
+
+    def fast_hadamard(self, MI, den, uq, pxy, pxpy, RXY, pXrX, pYrY) -> None:
+        ops = [np.asarray(a, dtype=np.float64).reshape(-1, order="F") for a in (den, uq, pxy, pxpy, RXY, pXrX, pYrY)]
+        flat = np.ascontiguousarray(MI.reshape(-1, order="F"))
+        L.check(L.lib().ldw_fast_hadamard(self._ctx, L.ptr(flat), *[L.ptr(o) for o in ops], flat.size, 0))
+        np.copyto(MI, flat.reshape(MI.shape, order="F"))
+
+
+def aracne(chk_pos1, chk_pos2, chk_MI, full_pos1, full_pos2, full_MI) -> np.ndarray:
+    c = [L.as_c(x, np.float64) for x in (chk_pos1, chk_pos2, chk_MI)]
+    f = [L.as_c(x, np.float64) for x in (full_pos1, full_pos2, full_MI)]
+    out = np.ones(len(c[0]), dtype=np.uint8)
+    L.check(L.lib().ldw_aracne(None, L.ptr(c[0]), L.ptr(c[1]), L.ptr(c[2]), len(c[0]), L.ptr(f[0]), L.ptr(f[1]), L.ptr(f[2]),
+                               len(f[0]), L.ptr(out)))
+    return out.astype(bool)
