@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MI SNP-pairs/sec of the all-pairs weighted-MI path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--L 100000] [--N 5000]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE pass of the hot path over the whole synthetic alignment: every block pair of
+make_blocks(L, 10000) -> MI of every SNP pair -> short-range table + per-block top long-range links, final link
+tables assembled on rank 0 (BASELINE.json: synthetic 100k SNPs x 5k sequences, reference defaults).  The state
+matrix, weights and SNP meta data are resident in HBM before the timed region.  With N > 1 the block pairs are
+dealt over the ranks (total work fixed -> "strong" scaling) and gathered with one RCCL gatherv.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--L", type=int, default=100_000)
+    ap.add_argument("--N", type=int, default=5_000)
+    ap.add_argument("--max-blk-sz", type=int, default=10_000)
+    ap.add_argument("--nlimbs", type=int, default=0)
+    ap.add_argument("--engine", choices=["mfma", "hist"], default="mfma")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="SNPs per side of the CPU-baseline sample block (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(states_np, hdw, r, uqe, N, sample):
+    """The C/OpenMP block-faithful restatement (oracle/ldw_oracle.c, kind 'port') on one diagonal and one
+    off-diagonal sample block of the same workload, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    cores = c_oracle.max_threads()
+    s = sample
+    fi, ti = np.arange(0, s), np.arange(s, 2 * s)
+    t0 = time.time()
+    c_oracle.mi_block(states_np, hdw, r, uqe, fi, fi, cores)
+    c_oracle.mi_block(states_np, hdw, r, uqe, fi, ti, cores)
+    dt = time.time() - t0
+    pairs = s * (s - 1) // 2 + s * s
+    return dict(value=pairs / dt, unit="MI SNP-pairs/s", cores=cores, kind="port",
+                sample=f"one diagonal + one off-diagonal {s}x{s} block at N={N} (all 25 state pairs, dense x CSR + fused "
+                       f"Hadamard), {dt:.1f} s wall; extrapolates linearly in pairs")
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from ldweaver_amd import _lib as LL
+    from ldweaver_amd.dist import deal_blocks, gather_link_tables
+    from ldweaver_amd.engine import Engine
+    from ldweaver_amd.mi import lr_links_approx, make_blocks
+    from ldweaver_amd.synth import synth_alignment
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- synthetic workload (same seed on every rank -> identical replicated alignment) ----
+    L, N = args.L, args.N
+    t_setup = time.time()
+    syn = synth_alignment(L, N, seed=1988, device=dev, as_numpy=False)
+    states = syn["states"]
+    POS, paint, g = syn["POS"], syn["paint"], float(syn["g"])
+    stream = torch.cuda.Stream(device=dev)   # a real (non-null) stream shared by torch and the library
+    torch.cuda.set_stream(stream)
+    eng = Engine(local_rank, stream=stream.cuda_stream)
+    eng.set_engine(LL.ENGINE_HIST if args.engine == "hist" else LL.ENGINE_MFMA)
+    eng.set_alignment(states)
+    counts = eng.state_counts()
+    uqe = (counts > 0).T.astype(np.float64)
+    r = uqe.sum(axis=1)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    hdw = eng.hamming_weights(int(L * 0.1))
+    torch.cuda.synchronize()
+    hamming_s = time.time() - t0
+    hamming_kernel_ms = eng.last_timing()["gemm_ms"]
+    eng.set_weights(hdw, args.nlimbs)
+    eng.set_snp_meta(r, uqe, POS, paint, g)
+    sr_dist, lr_retain = 20000.0, 1e6
+    approx = lr_links_approx(POS, g, sr_dist)
+    blocks = make_blocks(L, args.max_blk_sz)
+    nblocks = len(blocks)
+    mine = deal_blocks(blocks, world)[rank]
+    my_blocks = blocks[mine]
+    setup_s = time.time() - t_setup
+
+    pairs = 0
+    for fs, fe, ts, te in blocks.tolist():
+        nf, nt = fe - fs + 1, te - ts + 1
+        pairs += nf * (nf - 1) // 2 if (fs == ts and fe == te) else nf * nt - min(nf, nt)  # Q3: off-diagonal blocks drop their diagonal
+
+    tim = dict(gemm_ms=0.0, epilogue_ms=0.0, select_ms=0.0, total_ms=0.0)
+    result = {}
+
+    def step(accumulate_timing):
+        if len(my_blocks):
+            eng.mi_all_pairs(my_blocks, sr_dist, lr_retain, approx)
+            st = eng.block_stats()
+            local = {"sr": eng.links(0, device_tensors=True), "lr": eng.links(1, device_tensors=True)}
+            cnt = {"sr": st["n_sr"], "lr": st["n_lr_kept"]}
+            if accumulate_timing:
+                for k, v in eng.last_timing().items():
+                    tim[k] += v
+        else:
+            e = lambda dt: torch.empty(0, dtype=dt, device=dev)
+            local = {k: (e(torch.int32), e(torch.int32), e(torch.float64)) for k in ("sr", "lr")}
+            cnt = {"sr": np.zeros(0, dtype=np.int64), "lr": np.zeros(0, dtype=np.int64)}
+        out = gather_link_tables(local, mine, cnt, nblocks)
+        if out is not None:
+            result["n_sr"] = int(out["sr"][2].numel())
+            result["n_lr"] = int(out["lr"][2].numel())
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step(True)
+    ev1.record()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        K = args.steps
+        ms_per_step = dt / K * 1e3
+        value = pairs * K / dt
+        # ---- roofline of the dominant kernel (live HIP-event times accumulated by the library on this stream) ----
+        n_launch = max(1, len(my_blocks) * K)
+        stage = max(("gemm_ms", "epilogue_ms", "select_ms"), key=lambda k: tim[k])
+        my_pairs = 0
+        for fs, fe, ts, te in my_blocks.tolist():
+            nf, nt = fe - fs + 1, te - ts + 1
+            my_pairs += nf * (nf - 1) // 2 if (fs == ts and fe == te) else nf * nt - min(nf, nt)
+        gemm_avg_ms = tim["gemm_ms"] / n_launch
+        epi_avg_ms = tim["epilogue_ms"] / n_launch
+        alg_flops_per_launch = 50.0 * N * my_pairs / max(1, len(my_blocks))       # 50*N MAC-flops per pair
+        alg_bytes_per_launch = (L * N / max(1, nblocks) + 8.0 * my_pairs / max(1, len(my_blocks)))
+        i8_peak = 5000.0  # TOP/s dense (MI355X_MICROARCH.md: i8 = 2 x bf16 per clock, bf16 ~2.5 PF dense)
+        roof = dict(bound="mfma", kernel="gemm_limb_kernel", achieved=alg_flops_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms else None,
+                    peak=i8_peak, unit="TFLOP/s", traffic=None,
+                    avg_launch_ms=gemm_avg_ms, launches=n_launch,
+                    note="achieved = ALGORITHMIC 50*N flops/pair (SURVEY 8d) x pairs per launch / avg launch time of the co-occurrence GEMM; "
+                         "the kernel executes fewer ops than that (most-frequent-state rows dropped, J int8 limbs): see DESIGN.md")
+        roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
+        roof["epilogue_avg_launch_ms"] = epi_avg_ms
+        roof["dominant_stage"] = stage
+        roof["hbm_alg_GBps_whole_step"] = (L * N + 8.0 * pairs) / (dt / K) / 1e9
+        roof["hbm_frac_whole_step"] = roof["hbm_alg_GBps_whole_step"] / 8000.0
+        out = dict(metric="MI SNP-pairs/sec", value=value, unit="pairs/s", n_gpus=world, steps=K, warmup=args.warmup,
+                   ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="i8->i64 counts, f64 MI",
+                   data="synthetic",
+                   config=dict(workload=f"synthetic {L} SNPs x {N} seqs, all {nblocks} block pairs of make_blocks(max_blk_sz={args.max_blk_sz}), "
+                                        f"sr_dist=20000, lr_retain_links=1e6, sr+lr link tables on rank 0",
+                               L=L, N=N, pairs=int(pairs), engine=args.engine, nlimbs=args.nlimbs or 5,
+                               parallelism=f"pair-space blocks over {world} GPU(s)"),
+                   roofline=roof,
+                   stages_ms_per_step={k: v / K for k, v in tim.items()},
+                   links=result, hamming_weights_s=hamming_s, hamming_gemm_ms=hamming_kernel_ms, setup_s=setup_s)
+        if not args.no_cpu_baseline:
+            sample = args.cpu_sample or max(200, min(1000, L // 2))
+            st_np = states[: 2 * sample].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(st_np, hdw, r[: 2 * sample], uqe[: 2 * sample], N, sample)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

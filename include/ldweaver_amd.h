@@ -133,6 +133,13 @@ typedef struct ldw_mi_params {
  * a block, in the reference's row order (R/computePairwiseMI.R:306-310).  reset != 0 clears the tables. */
 int ldw_mi_all_pairs(ldw_ctx *ctx, const int32_t *blocks, int64_t nblocks, const ldw_mi_params *p,
                      int reset);
+/* The same loop opened up for blocks that are not contiguous index ranges (SR-only mode drops SNPs
+ * without a short-range partner before each block, R/computePairwiseMI.R:179-189):
+ * ldw_links_begin(capacity in blocks) ; ldw_mi_block_links(...) per block ; ldw_links_end(). */
+int ldw_links_begin(ldw_ctx *ctx, int64_t nblocks_capacity);
+int ldw_mi_block_links(ldw_ctx *ctx, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt,
+                       const ldw_mi_params *p);
+int ldw_links_end(ldw_ctx *ctx);
 /* which: 0 = short-range, 1 = long-range (after the per-block quantile filter). */
 int ldw_links_count(ldw_ctx *ctx, int which, int64_t *n_out);
 /* a_out/b_out: 0-based SNP index of the from-side (pos2) and to-side (pos1) SNP; MI_out. capacity in

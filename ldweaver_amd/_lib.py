@@ -57,6 +57,9 @@ _SIGS = {
     "ldw_mi_block": (C.c_int, [_p, _p, _i64, _p, _i64, C.c_int, _p, C.c_int]),
     "ldw_joint_tables": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
     "ldw_mi_all_pairs": (C.c_int, [_p, _p, _i64, C.POINTER(MIParams), C.c_int]),
+    "ldw_links_begin": (C.c_int, [_p, _i64]),
+    "ldw_mi_block_links": (C.c_int, [_p, _p, _i64, _p, _i64, C.POINTER(MIParams)]),
+    "ldw_links_end": (C.c_int, [_p]),
     "ldw_links_count": (C.c_int, [_p, C.c_int, C.POINTER(_i64)]),
     "ldw_links_fetch": (C.c_int, [_p, C.c_int, _p, _p, _p, _i64, C.c_int]),
     "ldw_block_stats": (C.c_int, [_p, _i64, _p, _p, _p, _p]),

@@ -98,6 +98,7 @@ struct ldw_ctx {
     // ---- link tables (device resident) ----
     ldw::DevBuf sr_a, sr_b, sr_mi, lr_a, lr_b, lr_mi;
     int64_t n_sr = 0, n_lr = 0;
+    int64_t blk_capacity = 0, blk_cursor = 0;  // ldw_links_begin / ldw_mi_block_links / ldw_links_end
     std::vector<ldw::BlockStat> stats;
 };
 

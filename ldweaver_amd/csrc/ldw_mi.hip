@@ -780,35 +780,80 @@ int ldw_joint_tables(ldw_ctx *c, const int32_t *pair_a, const int32_t *pair_b, i
     return rc;
 }
 
-static int links_setup(ldw_ctx *c, int64_t nblocks, int reset, SmallLayout &sl) {
-    const size_t need = 64 + sizeof(ldw::PickOut) + (size_t)nblocks * 32 + 64;
-    if (reset || !c->small.p || c->small.cap < need || c->stats.empty()) {
-        // (re)initialise tables and counters
-        if (int rc = c->small.reserve(need)) return rc;
-        LDW_HIP(hipMemsetAsync(c->small.p, 0, need, c->stream));
-        c->n_sr = 0;
-        c->n_lr = 0;
-        c->stats.clear();
-    }
+static void links_layout(ldw_ctx *c, SmallLayout &sl) {
     char *base = c->small.as<char>();
     sl.lr_count = reinterpret_cast<int64_t *>(base);
     sl.blk_sr = reinterpret_cast<int64_t *>(base + 8);
     sl.pick = reinterpret_cast<ldw::PickOut *>(base + 64);
     sl.stats_i = reinterpret_cast<int64_t *>(base + 64 + ((sizeof(ldw::PickOut) + 63) / 64) * 64);
-    sl.stats_d = reinterpret_cast<double *>(sl.stats_i + nblocks * 3);
+    sl.stats_d = reinterpret_cast<double *>(sl.stats_i + c->blk_capacity * 3);
+}
+
+int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(nblocks_capacity > 0, LDW_ERR_ARG, "ldw_links_begin: capacity must be positive");
+    if (int rc = ensure_rows(c)) return rc;  // uses ctx->small for staging; link bookkeeping takes it over below
+    const size_t need = 64 + ((sizeof(ldw::PickOut) + 63) / 64) * 64 + (size_t)nblocks_capacity * 32 + 64;
+    if (int rc = c->small.reserve(need)) return rc;
+    LDW_HIP(hipMemsetAsync(c->small.p, 0, need, c->stream));
+    c->n_sr = 0;
+    c->n_lr = 0;
+    c->stats.clear();
+    c->blk_capacity = nblocks_capacity;
+    c->blk_cursor = 0;
+    for (int i = 0; i < 4; ++i) c->last_ms[i] = 0;
+    return LDW_OK;
+}
+
+int ldw_mi_block_links(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt,
+                       const ldw_mi_params *p) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(from_idx && to_idx && p, LDW_ERR_ARG, "ldw_mi_block_links: null argument");
+    LDW_REQUIRE(c->blk_capacity > 0 && c->blk_cursor < c->blk_capacity, LDW_ERR_STATE,
+                "ldw_mi_block_links: call ldw_links_begin with enough capacity first");
+    LDW_REQUIRE(p->sr_only || p->lr_links_approx > 0, LDW_ERR_ARG, "lr_links_approx must be positive");
+    LDW_REQUIRE(p->quirk_mode == LDW_QUIRK_REFERENCE || p->quirk_mode == LDW_QUIRK_INTENDED, LDW_ERR_ARG, "bad quirk mode");
+    SmallLayout sl;
+    links_layout(c, sl);
+    if (int rc = block_links(c, from_idx, nf, to_idx, nt, p, c->blk_cursor, sl.lr_count, sl.stats_i, sl.stats_d,
+                             sl.pick, sl.blk_sr))
+        return rc;
+    ++c->blk_cursor;
+    return LDW_OK;
+}
+
+int ldw_links_end(ldw_ctx *c) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(c->blk_capacity > 0, LDW_ERR_STATE, "ldw_links_end without ldw_links_begin");
+    SmallLayout sl;
+    links_layout(c, sl);
+    const int64_t nb = c->blk_cursor;
+    int64_t h_lr = 0;
+    std::vector<int64_t> si((size_t)nb * 3 + 1);
+    std::vector<double> sd((size_t)nb + 1);
+    LDW_HIP(hipMemcpyAsync(&h_lr, sl.lr_count, 8, hipMemcpyDeviceToHost, c->stream));
+    if (nb > 0) {
+        LDW_HIP(hipMemcpyAsync(si.data(), sl.stats_i, (size_t)nb * 24, hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipMemcpyAsync(sd.data(), sl.stats_d, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    c->n_lr = h_lr;
+    c->stats.resize((size_t)nb);
+    for (int64_t b = 0; b < nb; ++b) {
+        c->stats[b].n_lr_total = si[b * 3 + 0];
+        c->stats[b].n_lr_kept = si[b * 3 + 1];
+        c->stats[b].n_sr = si[b * 3 + 2];
+        c->stats[b].disc_thresh = sd[b];
+    }
+    c->blk_capacity = 0;
     return LDW_OK;
 }
 
 int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const ldw_mi_params *p, int reset) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(blocks && p && nblocks > 0, LDW_ERR_ARG, "ldw_mi_all_pairs: bad argument");
-    LDW_REQUIRE(reset, LDW_ERR_ARG, "ldw_mi_all_pairs: appending to earlier calls is not supported yet (reset must be 1)");
-    LDW_REQUIRE(p->sr_only || p->lr_links_approx > 0, LDW_ERR_ARG, "ldw_mi_all_pairs: lr_links_approx must be positive");
-    if (int rc = ensure_rows(c)) return rc;
-    SmallLayout sl;
-    // ensure_rows used ctx->small for its own staging; link bookkeeping takes it over from here
-    if (int rc = links_setup(c, nblocks, 1, sl)) return rc;
-    for (int i = 0; i < 4; ++i) c->last_ms[i] = 0;
+    LDW_REQUIRE(reset, LDW_ERR_ARG, "ldw_mi_all_pairs: appending to earlier calls is not supported (reset must be 1)");
+    if (int rc = ldw_links_begin(c, nblocks)) return rc;
     std::vector<int32_t> fi, ti;
     for (int64_t b = 0; b < nblocks; ++b) {
         const int32_t fs = blocks[b * 4 + 0], fe = blocks[b * 4 + 1], ts = blocks[b * 4 + 2], te = blocks[b * 4 + 3];
@@ -818,27 +863,9 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         ti.resize((size_t)(te - ts + 1));
         for (int32_t k = fs; k <= fe; ++k) fi[k - fs] = k - 1;
         for (int32_t k = ts; k <= te; ++k) ti[k - ts] = k - 1;
-        if (int rc = block_links(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, b, sl.lr_count,
-                                 sl.stats_i, sl.stats_d, sl.pick, sl.blk_sr))
-            return rc;
+        if (int rc = ldw_mi_block_links(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p)) return rc;
     }
-    // exact long-range row count and per-block stats
-    int64_t h_lr = 0;
-    std::vector<int64_t> si((size_t)nblocks * 3);
-    std::vector<double> sd((size_t)nblocks);
-    LDW_HIP(hipMemcpyAsync(&h_lr, sl.lr_count, 8, hipMemcpyDeviceToHost, c->stream));
-    LDW_HIP(hipMemcpyAsync(si.data(), sl.stats_i, si.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    LDW_HIP(hipMemcpyAsync(sd.data(), sl.stats_d, sd.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    LDW_HIP(hipStreamSynchronize(c->stream));
-    c->n_lr = h_lr;
-    c->stats.resize((size_t)nblocks);
-    for (int64_t b = 0; b < nblocks; ++b) {
-        c->stats[b].n_lr_total = si[b * 3 + 0];
-        c->stats[b].n_lr_kept = si[b * 3 + 1];
-        c->stats[b].n_sr = si[b * 3 + 2];
-        c->stats[b].disc_thresh = sd[b];
-    }
-    return LDW_OK;
+    return ldw_links_end(c);
 }
 
 int ldw_links_count(ldw_ctx *c, int which, int64_t *n_out) {

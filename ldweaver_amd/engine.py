@@ -137,6 +137,22 @@ class Engine:
         L.check(L.lib().ldw_mi_all_pairs(self._ctx, L.ptr(bl), len(bl), C.byref(p), 1))
         self._nblocks = len(bl)
 
+    def links_begin(self, nblocks: int):
+        L.check(L.lib().ldw_links_begin(self._ctx, int(nblocks)))
+        self._nblocks = 0
+
+    def mi_block_links(self, from_idx, to_idx, sr_dist=20000.0, lr_retain_links=1e6, lr_links_approx=1.0, sr_only=False,
+                       quirk=L.QUIRK_REFERENCE, keep_sr=True):
+        fi = L.as_c(from_idx, np.int32)
+        ti = L.as_c(to_idx, np.int32)
+        p = L.MIParams(float(sr_dist), float(lr_retain_links), float(lr_links_approx), int(bool(sr_only)), int(quirk),
+                       int(bool(keep_sr)), 0)
+        L.check(L.lib().ldw_mi_block_links(self._ctx, L.ptr(fi), len(fi), L.ptr(ti), len(ti), C.byref(p)))
+        self._nblocks += 1
+
+    def links_end(self):
+        L.check(L.lib().ldw_links_end(self._ctx))
+
     def links_count(self, which: int) -> int:
         n = C.c_int64(0)
         L.check(L.lib().ldw_links_count(self._ctx, int(which), C.byref(n)))

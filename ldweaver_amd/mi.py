@@ -1,0 +1,192 @@
+"""Host side of the hot path with the reference's own interface.
+
+``perform_MI_computation``, ``estimate_Hamming_distance_weights`` and ``ACGTN2num`` keep the argument names,
+meaning and error behaviour of the R functions (R/computePairwiseMI.R:46-48,
+R/performPopulationStuctureCorrection.R:20, R/RcppExports.R:4-6); all numerics run in
+libldweaver_amd.so on the GPU.  R is absent from this image, so this module is the Python mirror of the
+R shim kept as source in r_shim/ (see INTEGRATION.md).
+"""
+from __future__ import annotations
+
+import math
+import os
+import time
+import warnings
+
+import numpy as np
+import pandas as pd
+
+from . import _lib as L
+from . import rcompat
+from .engine import Engine, aracne
+from .snpdat import CdsVar, SnpDat
+from .srp import COLS, merge_n_sort_sr_links
+
+
+# ---------------------------------------------------------------------------------------------
+# a-6 make_blocks                                                  R/computePairwiseMI.R:147-165
+# ---------------------------------------------------------------------------------------------
+def make_blocks(nsnp: int, max_blk_sz: int = 10000) -> np.ndarray:
+    if max_blk_sz <= 0:
+        raise ValueError("max_blk_sz rounds to 0 (round(max_blk_sz, -3)); use a block size >= 500")
+    part1 = math.ceil(nsnp / max_blk_sz)
+    fs = [(i - 1) * max_blk_sz + 1 for i in range(1, part1 + 1)]
+    fe = [min(i * max_blk_sz, nsnp) for i in range(1, part1 + 1)]
+    return np.array([(fs[i], fe[i], fs[j], fe[j]) for i in range(part1) for j in range(i, part1)], dtype=np.int32)
+
+
+def lr_links_approx(POS, g, sr_dist, seed: int = 1988) -> float:
+    """R/computePairwiseMI.R:94-97: 10 % of the SNPs drawn with ``set.seed(1988); sample()``."""
+    POS = np.asarray(POS, dtype=np.float64)
+    nsnp = len(POS)
+    snp_subset = min(nsnp, int(round(nsnp * 0.1)))
+    idx = rcompat.RRandom(seed).sample(nsnp, snp_subset) - 1
+    total = 0
+    step = max(1, 4_000_000 // nsnp)
+    for lo in range(0, snp_subset, step):
+        x = POS[idx[lo:lo + step]]
+        total += int((rcompat.circ_len(x[:, None], POS[None, :], g) > sr_dist).sum())
+    return total / snp_subset * nsnp / 2
+
+
+# ---------------------------------------------------------------------------------------------
+# a-4 estimate_Hamming_distance_weights            R/performPopulationStuctureCorrection.R:20-81
+# ---------------------------------------------------------------------------------------------
+def estimate_Hamming_distance_weights(snp_dat: SnpDat, threshold: float = 0.1, mega_dset: bool = False,
+                                      engine: Engine | None = None, alignment_resident: bool = False) -> np.ndarray:
+    t0 = time.time()
+    thresh = int(snp_dat.nsnp * threshold)  # as.integer() truncates
+    own = engine is None
+    eng = engine or Engine(0)
+    try:
+        if not alignment_resident:
+            eng.set_alignment(snp_dat.states)
+        hdw = eng.hamming_weights(thresh)
+    finally:
+        if own:
+            eng.close()
+    print(f"Done in {round(time.time() - t0, 2)} s")
+    return hdw
+
+
+# ---------------------------------------------------------------------------------------------
+# a-3 .ACGTN2num                                            src/ACGTN2num_parallel.cpp:10-43
+# ---------------------------------------------------------------------------------------------
+def ACGTN2num(nv: np.ndarray, cv, ncores: int = 1, engine: Engine | None = None) -> None:
+    """In place; returns None like the reference (invisible NULL)."""
+    own = engine is None
+    eng = engine or Engine(0)
+    try:
+        eng.acgtn2num(nv, cv)
+    finally:
+        if own:
+            eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# tsv output                                                R/computePairwiseMI.R:140,362
+# ---------------------------------------------------------------------------------------------
+def _fmt_col(v) -> list:
+    v = np.asarray(v)
+    if v.dtype.kind in "iub":
+        return [str(int(x)) for x in v]
+    return [rcompat.format_number(float(x)) for x in v]
+
+
+def append_table(path: str, columns: list) -> None:
+    """write.table(append = T, quote = F, row.names = F, col.names = F, sep = '\\t')."""
+    cols = [_fmt_col(c) for c in columns]
+    with open(path, "a") as fh:
+        for row in zip(*cols):
+            fh.write("\t".join(row) + "\n")
+
+
+def links_frame(a, b, mi, POS, paint, g) -> pd.DataFrame:
+    """(a, b, MI) index triples -> the reference's MI_df columns (R/computePairwiseMI.R:319-331)."""
+    pos2 = np.asarray(POS, dtype=np.float64)[a]      # from side
+    pos1 = np.asarray(POS, dtype=np.float64)[b]      # to side
+    return pd.DataFrame({"pos1": pos1, "pos2": pos2, "clust1": np.asarray(paint)[b], "clust2": np.asarray(paint)[a],
+                         "len": rcompat.circ_len(pos1, pos2, g), "MI": mi})
+
+
+# ---------------------------------------------------------------------------------------------
+# a-5 perform_MI_computation                                      R/computePairwiseMI.R:46-145
+# ---------------------------------------------------------------------------------------------
+def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 1, lr_save_path=None, sr_save_path=None,
+                           plt_folder=None, sr_dist=20000, lr_retain_links=1e6, max_blk_sz=10000, srp_cutoff=3,
+                           runARACNE=True, perform_SR_analysis_only=False, order_links=True, mega_dset=False, *,
+                           engine: Engine | None = None, alignment_resident: bool = False,
+                           quirk_mode: int = L.QUIRK_REFERENCE, nlimbs: int = 0, verbose: bool = True,
+                           return_aux: bool = False):
+    """Returns the short-range link data.frame (clust_c,pos1,pos2,clust1,clust2,len,MI,srp_max,ARACNE);
+    long-range links are appended to ``lr_save_path`` and the returned frame to ``sr_save_path``."""
+    t000 = time.time()
+    say = print if verbose else (lambda *a, **k: None)
+    if lr_save_path is None:
+        lr_save_path = os.path.join(os.getcwd(), "lr_links.tsv")
+    if sr_save_path is None:
+        sr_save_path = os.path.join(os.getcwd(), "sr_links.tsv")
+    if plt_folder is None:
+        plt_folder = os.path.join(os.getcwd(), "PLOTS")
+    os.makedirs(plt_folder, exist_ok=True)
+    if snp_dat.g is None:
+        raise ValueError("snp.dat$g is NULL: set the genome length first (R/BacGWES.R:338-345)")
+    say("Begin MI computation... ")
+    max_blk_sz = rcompat.round_thousands(max_blk_sz)
+    blocks = make_blocks(snp_dat.nsnp, max_blk_sz)
+    POS, g, paint = snp_dat.POS, float(snp_dat.g), np.asarray(cds_var.paint)
+    approx = None if perform_SR_analysis_only else lr_links_approx(POS, g, sr_dist)
+
+    own = engine is None
+    eng = engine or Engine(0)
+    try:
+        if not alignment_resident:   # pass alignment_resident=True when `engine` already holds snp_dat.states
+            eng.set_alignment(snp_dat.states)
+        eng.set_weights(hdw, nlimbs)
+        eng.set_snp_meta(snp_dat.r, snp_dat.uqe, POS, paint, g)
+        kw = dict(sr_dist=sr_dist, lr_retain_links=lr_retain_links, lr_links_approx=approx or 1.0,
+                  sr_only=perform_SR_analysis_only, quirk=quirk_mode)
+        if not perform_SR_analysis_only:
+            eng.mi_all_pairs(blocks, **kw)
+        else:
+            # drop sites that form no link < sr_dist with the other side (R/computePairwiseMI.R:179-189)
+            eng.links_begin(len(blocks))
+            POSf = np.asarray(POS, dtype=np.float64)
+            for fs, fe, ts, te in blocks:
+                fi, ti = np.arange(fs - 1, fe), np.arange(ts - 1, te)
+                ln = np.abs(rcompat.circ_len(POSf[ti][None, :], POSf[fi][:, None], g))
+                fi, ti = fi[(ln < sr_dist).any(axis=1)], ti[(ln < sr_dist).any(axis=0)]
+                if len(fi) == 0 or len(ti) == 0:
+                    continue
+                eng.mi_block_links(fi, ti, **kw)
+            eng.links_end()
+        sa, sb, smi = eng.links(0)
+        la, lb, lmi = eng.links(1)
+        stats = eng.block_stats()
+    finally:
+        if own:
+            eng.close()
+    for bi in range(len(stats["n_sr"])):
+        say(f"Block {bi + 1} of {len(blocks)} ... Adding {stats['n_lr_kept'][bi]} LR links with MI>"
+            f"{round(float(stats['disc_thresh'][bi]), 3)} to file ... Adding {stats['n_sr'][bi]} SR links to list ...")
+
+    if not perform_SR_analysis_only and len(lmi):
+        lr = links_frame(la, lb, lmi, POS, paint, g)
+        append_table(lr_save_path, [lr[c].to_numpy() for c in COLS])
+
+    sr = links_frame(sa, sb, smi, POS, paint, g)
+    sr_links = [sr[(sr["clust1"] == ci) | (sr["clust2"] == ci)] for ci in range(1, cds_var.nclust + 1)]
+    red, chk = merge_n_sort_sr_links(sr_links, cds_var.nclust, sr_dist, srp_cutoff)
+    if runARACNE:
+        say(f"Running ARACNE on {len(red)} links... ")
+        red["ARACNE"] = aracne(red["pos1"], red["pos2"], red["MI"], chk["pos1"], chk["pos2"], chk["MI"]).astype(np.float64)
+    else:
+        warnings.warn("ARACNE not run, all values will be set to 1")
+        red["ARACNE"] = 1.0
+    if order_links:
+        red = red.iloc[np.argsort(-red["srp_max"].to_numpy(), kind="stable")].reset_index(drop=True)
+    append_table(sr_save_path, [red[c].to_numpy() for c in ["clust_c"] + COLS + ["srp_max", "ARACNE"]])
+    say(f"All done in {round((time.time() - t000) / 60, 2)} mins ")
+    if return_aux:   # not part of the reference's return value: the ARACNE pool and per-block statistics
+        return red, dict(sr_links_ARACNE_check=chk, block_stats=stats, lr_links_approx=approx)
+    return red

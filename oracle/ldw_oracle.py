@@ -516,7 +516,19 @@ def _beta_mle(x: np.ndarray):
 
     res = optimize.minimize(nll, start, method="Nelder-Mead",
                             options=dict(xatol=1e-10, fatol=1e-12, maxiter=5000, maxfev=10000))
-    return float(res.x[0]), float(res.x[1])
+    # Newton polish on the score equations (the simplex stops at optimiser tolerance; the MLE itself is unique)
+    a, b = float(res.x[0]), float(res.x[1])
+    dg, tg = special.digamma, lambda z: special.polygamma(1, z)
+    for _ in range(60):
+        grad = np.array([n * (dg(a + b) - dg(a)) + slx, n * (dg(a + b) - dg(b)) + sl1x])
+        H = n * np.array([[tg(a + b) - tg(a), tg(a + b)], [tg(a + b), tg(a + b) - tg(b)]])
+        step = np.linalg.solve(H, grad)
+        if not np.all(np.isfinite(step)) or a - step[0] <= 0 or b - step[1] <= 0:
+            break
+        a, b = a - step[0], b - step[1]
+        if np.all(np.abs(step) < 1e-13 * np.array([a, b])):
+            break
+    return float(a), float(b)
 
 
 def merge_n_sort_sr_links(sr_links_by_clust, nclust: int, sr_dist: float, srp_cutoff: float):
@@ -675,6 +687,12 @@ def perform_mi_computation(states, POS, g, r, uqe, hdw, paint, nclust, sr_dist=2
     for (fs, fe, ts, te) in blocks:
         from_idx = np.arange(fs - 1, fe)
         to_idx = np.arange(ts - 1, te)
+        if sr_only:  # drop sites that form no link < sr_dist with the other side (R/computePairwiseMI.R:179-189)
+            POSf = np.asarray(POS, dtype=np.float64)
+            ln = np.abs(circ_len(POSf[to_idx][None, :], POSf[from_idx][:, None], g))
+            from_idx, to_idx = from_idx[(ln < sr_dist).any(axis=1)], to_idx[(ln < sr_dist).any(axis=0)]
+            if len(from_idx) == 0 or len(to_idx) == 0:
+                continue
         MI = mi_block_faithful(states, hdw, r, uqe, from_idx, to_idx)
         bl = block_links(MI, from_idx, to_idx, POS, paint, g, sr_dist, lr_retain_links, approx, sr_only)
         for k in cols:

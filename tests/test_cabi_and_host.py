@@ -1,0 +1,165 @@
+"""CPU: the C-ABI library loads and exports what include/ldweaver_amd.h declares; host logic (blocks, RNG-driven
+lr_links_approx, srp model, ARACNE and the small native helpers) against the oracle.  No GPU compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import ldw_oracle as orc
+from ldweaver_amd import _lib as L
+from ldweaver_amd import mi as MI
+from ldweaver_amd import srp
+from ldweaver_amd.dist import block_cost, deal_blocks
+from ldweaver_amd.engine import aracne
+from ldweaver_amd.snpdat import SnpDat, encode_chars
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ldweaver_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ldw_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("ldw_ctx")
+    assert len(declared) >= 30
+    lib = L.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(L.declared_symbols()), declared ^ set(L.declared_symbols())
+    assert lib.ldw_version() >= 100
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the context cannot be created and says so; with one the test is vacuous."""
+    lib = L.lib()
+    if lib.ldw_device_count() > 0:
+        pytest.skip("GPU present")
+    ctx = C.c_void_p()
+    rc = lib.ldw_ctx_create(0, C.byref(ctx))
+    assert rc == 4  # LDW_ERR_NOGPU
+    assert b"no CPU fallback" in lib.ldw_last_error()
+    from ldweaver_amd.engine import Engine
+    with pytest.raises(L.LdwError):
+        Engine(0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "ldweaver_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "ldw_oracle" not in txt and "c_oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_make_blocks_and_deal():
+    b = MI.make_blocks(1268, 1000)
+    assert b.tolist() == [list(x) for x in orc.make_blocks(1268, 1000)] == [[1, 1000, 1, 1000], [1, 1000, 1001, 1268], [1001, 1268, 1001, 1268]]
+    b = MI.make_blocks(100000, 10000)
+    assert len(b) == 55 and b[0].tolist() == [1, 10000, 1, 10000] and b[-1].tolist() == [90001, 100000, 90001, 100000]
+    with pytest.raises(ValueError):
+        MI.make_blocks(100, 0)
+    cost = block_cost(b)
+    assert cost[0] == 10000 * 9999 // 2 and cost[1] == 10 ** 8
+    for world in (1, 2, 4, 8):
+        parts = deal_blocks(b, world)
+        assert sorted(np.concatenate(parts).tolist()) == list(range(55))
+        loads = np.array([cost[p].sum() for p in parts])
+        assert loads.max() <= 1.08 * loads.mean() + 1
+        assert all((np.diff(p) > 0).all() for p in parts if len(p) > 1)
+
+
+def test_lr_links_approx_matches_oracle(sample):
+    a = MI.lr_links_approx(sample["POS"], sample["g"], 20000)
+    assert a == orc.lr_links_approx(sample["POS"], sample["g"], 20000) == float(sample["single_lr_approx"])
+
+
+def test_snpdat_and_encoder():
+    st = np.array([[0, 1, 4], [2, 2, 3]], dtype=np.uint8)
+    sd = SnpDat.from_states(st, [5, 9], 100)
+    assert sd.nsnp == 2 and sd.nseq == 3 and sd.r.tolist() == [3.0, 2.0]
+    assert sd.uqe.tolist() == [[1, 1, 0, 0, 1], [0, 0, 1, 1, 0]]
+    sd2 = SnpDat.from_onehots(sd.onehots(), [5, 9], 100)
+    assert np.array_equal(sd2.states, st)
+    with pytest.raises(ValueError):
+        SnpDat.from_onehots([np.zeros((2, 3))] * 5, [5, 9], 100)
+    assert encode_chars(np.frombuffer(b"AcgTn-RY*", dtype=np.uint8)).tolist() == [0, 1, 2, 3, 4, 4, 4, 4, 4]
+
+
+def _toy_links(seed=0, n=4000):
+    rng = np.random.default_rng(seed)
+    pos1 = rng.integers(1, 3000, n).astype(float)
+    ln = rng.integers(1, 400, n).astype(float)
+    pos2 = pos1 + ln
+    c1 = rng.integers(1, 3, n)
+    c2 = np.where(rng.random(n) < 0.8, c1, 3 - c1)
+    base = 0.05 * ln ** -0.3
+    mi = base * rng.gamma(2.0, 0.5, n)
+    return pd.DataFrame({"pos1": pos1, "pos2": pos2, "clust1": c1, "clust2": c2, "len": ln, "MI": mi})
+
+
+def test_srp_model_matches_oracle():
+    df = _toy_links()
+    by_clust = [df[(df.clust1 == ci) | (df.clust2 == ci)] for ci in (1, 2)]
+    red, chk = srp.merge_n_sort_sr_links(by_clust, 2, 20000, 1.0)
+    ored, ochk = orc.merge_n_sort_sr_links([{k: d[k].to_numpy() for k in srp.COLS} for d in by_clust], 2, 20000, 1.0)
+    assert len(red) == len(ored["MI"]) > 10 and len(chk) == len(ochk["MI"])
+    for k in ("clust_c", "pos1", "pos2", "clust1", "clust2", "len", "MI"):
+        assert np.array_equal(red[k].to_numpy(dtype=float), np.asarray(ored[k], dtype=float)), k
+    np.testing.assert_allclose(red["srp_max"].to_numpy(), ored["srp_max"], rtol=1e-9)
+    assert (red["srp_max"] > 1.0).all()
+    with pytest.raises(ValueError):
+        srp.merge_n_sort_sr_links(by_clust, 3, 20000, 1.0)
+
+
+def test_aracne_native_matches_oracle():
+    rng = np.random.default_rng(3)       # dense graph on 60 positions: plenty of triangles, some duplicated links
+    p1 = rng.integers(1, 61, 700).astype(float) * 10
+    p2 = rng.integers(1, 61, 700).astype(float) * 10
+    keep = p1 != p2
+    full = pd.DataFrame({"pos1": p1[keep], "pos2": p2[keep], "MI": rng.random(int(keep.sum()))})
+    chk = full[full.MI > full.MI.quantile(0.5)]
+    got = aracne(chk.pos1, chk.pos2, chk.MI, full.pos1, full.pos2, full.MI)
+    ref = orc.run_aracne(chk.pos1.to_numpy(), chk.pos2.to_numpy(), chk.MI.to_numpy(), full.pos1.to_numpy(), full.pos2.to_numpy(),
+                         full.MI.to_numpy())
+    assert np.array_equal(got, ref) and (~ref).sum() > 0 and ref.sum() > 0
+    # links with no neighbours stay TRUE; empty input
+    assert aracne([1.], [2.], [0.3], [1.], [2.], [0.3]).tolist() == [True]
+    assert aracne([], [], [], [], [], []).tolist() == []
+
+
+def test_native_helper_twins():
+    lib = L.lib()
+    rng = np.random.default_rng(1)
+    x = np.asfortranarray(rng.integers(1, 6, (40, 2)).astype(np.float64))
+    y = np.array([2.0, 5.0])
+    ret = np.zeros(40, dtype=np.uint8)
+    L.check(lib.ldw_compare_to_row(L.ptr(x), 40, 2, L.ptr(y), 2, L.ptr(ret)))
+    assert np.array_equal(ret.astype(bool), orc.compare_to_row(x, y))
+    xs, ys = np.array([3.0, 9.0, 1.0]), np.array([1.0, 3.0, 3.0])
+    out = np.zeros(3)
+    L.check(lib.ldw_vec_pos_match(L.ptr(xs), 3, L.ptr(ys), 3, L.ptr(out)))
+    assert out.tolist() == list(orc.vec_pos_match(xs, ys)) == [2.0, 0.0, 1.0]
+    r = C.c_int(-1)
+    a, b = np.array([0.5, 0.1]), np.array([0.3, 0.9])
+    L.check(lib.ldw_compare_triplet(L.ptr(a), L.ptr(b), 2, 0.2, C.byref(r)))
+    assert r.value == 0 == int(orc.compare_triplet(a, b, 0.2))
+    L.check(lib.ldw_compare_triplet(L.ptr(a), L.ptr(b), 2, 0.4, C.byref(r)))
+    assert r.value == 1
+    A, B = np.array([5, 1, 3, 3], dtype=np.int32), np.array([3, 3, 7, 5], dtype=np.int32)
+    o = np.zeros(4, dtype=np.int32)
+    n = C.c_int64(0)
+    L.check(lib.ldw_fast_intersect(L.ptr(A), 4, L.ptr(B), 4, L.ptr(o), C.byref(n)))
+    assert o[:n.value].tolist() == orc.fast_intersect(A, B) == [3, 3, 5]
+    assert lib.ldw_fast_intersect(None, 0, None, 0, None, None) == 1  # LDW_ERR_ARG with a message
+    assert b"bad argument" in lib.ldw_last_error()
+
+
+def test_append_table_format(tmp_path):
+    p = tmp_path / "t.tsv"
+    MI.append_table(str(p), [np.array([1, 2]), np.array([100000.0, 20000.0]), np.array([0.123456789012345678, 1e-5])])
+    MI.append_table(str(p), [np.array([3]), np.array([5.0]), np.array([0.5])])
+    assert p.read_text() == "1\t1e+05\t0.123456789012346\n2\t20000\t1e-05\n3\t5\t0.5\n"

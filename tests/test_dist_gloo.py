@@ -1,0 +1,74 @@
+"""CPU: the N > 1 path (block deal + variable-length gather of link tables) with world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ldweaver_amd.dist import deal_blocks, gather_link_tables
+from ldweaver_amd.mi import make_blocks
+
+
+def _fake_block_links(bi, kind):
+    """Deterministic fake link rows of block bi (so every rank can recompute the expected global table)."""
+    rng = np.random.default_rng(1000 * bi + (7 if kind == "lr" else 3))
+    n = int(rng.integers(0, 50)) if bi % 5 else 0   # some blocks contribute nothing
+    return rng.integers(0, 10 ** 6, n).astype(np.int32), rng.integers(0, 10 ** 6, n).astype(np.int32), rng.random(n)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        blocks = make_blocks(23000, 4000)          # 6 from-blocks -> 21 block pairs
+        mine = deal_blocks(blocks, world)[rank]
+        local, counts = {}, {}
+        for kind in ("sr", "lr"):
+            segs = [_fake_block_links(int(bi), kind) for bi in mine]
+            counts[kind] = np.array([len(s[2]) for s in segs], dtype=np.int64)
+            cat = lambda j, dt: torch.as_tensor(np.concatenate([s[j] for s in segs]) if segs else np.zeros(0), dtype=dt)
+            local[kind] = (cat(0, torch.int32), cat(1, torch.int32), cat(2, torch.float64))
+        out = gather_link_tables(local, mine, counts, len(blocks))
+        if rank == 0:
+            ok = True
+            for kind in ("sr", "lr"):
+                exp = [_fake_block_links(bi, kind) for bi in range(len(blocks))]
+                for j in range(3):
+                    ok &= np.array_equal(out[kind][j].numpy(), np.concatenate([e[j] for e in exp]))
+            q.put(bool(ok))
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_world2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(rk, 2, port, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get() is True
+
+
+def test_gather_single_process():
+    blocks = make_blocks(9000, 4000)
+    mine = np.arange(len(blocks))
+    local, counts = {}, {}
+    for kind in ("sr", "lr"):
+        segs = [_fake_block_links(int(bi), kind) for bi in mine]
+        counts[kind] = np.array([len(s[2]) for s in segs], dtype=np.int64)
+        local[kind] = tuple(torch.as_tensor(np.concatenate([s[j] for s in segs]), dtype=dt)
+                            for j, dt in enumerate((torch.int32, torch.int32, torch.float64)))
+    out = gather_link_tables(local, mine, counts, len(blocks))
+    for kind in ("sr", "lr"):
+        for j in range(3):
+            assert torch.equal(out[kind][j], local[kind][j])

@@ -1,0 +1,350 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+inputs, against the committed golden fixtures, and — at BASELINE.json's sizes — through size-independent properties.
+Bars: integer / index work bit-exact; MI within 1e-6 (north_star), typically ~1e-12 (weight quantisation)."""
+import os
+
+import numpy as np
+import pytest
+
+import c_oracle
+import ldw_oracle as orc
+from ldweaver_amd import _lib as L
+from ldweaver_amd import mi as MIH
+from ldweaver_amd.engine import Engine
+from ldweaver_amd.snpdat import CdsVar, SnpDat
+from ldweaver_amd.synth import synth_alignment
+
+pytestmark = pytest.mark.gpu
+MI_TOL = 1e-6          # tolerance stated by BASELINE.json's north_star
+MI_TIGHT = 1e-10       # what the 40-bit fixed-point weights actually deliver
+
+
+def _setup(eng, d, nlimbs=0):
+    eng.set_engine(L.ENGINE_MFMA)
+    eng.set_alignment(d["states"])
+    eng.set_weights(d["hdw"], nlimbs)
+    eng.set_snp_meta(d["r"], d["uqe"], d["POS"], d["paint"], d["g"])
+
+
+def test_alignment_roundtrip_counts_and_encoder(engine, sample):
+    st = sample["states"]
+    engine.set_alignment(st)
+    assert np.array_equal(engine.get_alignment(), st)
+    assert np.array_equal(engine.state_counts(), orc.acgtn_table(st))
+    # device encoder (src/getACGTNsites.cpp:229-265): mixed case, IUPAC, gaps; retained-column gather
+    rng = np.random.default_rng(0)
+    chars = rng.choice(np.frombuffer(b"ACGTacgtNn-RYK*", dtype=np.uint8), size=(37, 501))
+    pos = np.sort(rng.choice(501, 133, replace=False) + 1).astype(np.int32)
+    tab = engine.encode_alignment(chars, pos)
+    ref = orc.encode_states([bytes(row[pos - 1]) for row in chars])
+    assert np.array_equal(engine.get_alignment(), ref)
+    assert np.array_equal(tab, orc.acgtn_table(ref))
+
+
+def test_hamming_weights_bit_exact(engine, sample, synth):
+    for d, thr in ((sample, 0.1), (synth, 0.1), (synth, 0.25)):
+        st = d["states"]
+        engine.set_alignment(st)
+        thresh = int(st.shape[0] * thr)
+        hdw, shared = engine.hamming_weights(thresh, want_shared=True)
+        assert np.array_equal(shared, orc.shared_counts(st))
+        assert np.array_equal(hdw, orc.hamming_weights(st, thr))
+    assert np.array_equal(engine.hamming_weights(int(512 * 0.1)), synth["hdw"])      # golden
+    # threshold 0: nobody is closer than 0 mismatches -> all weights 1; huge threshold -> 1/(N+1)
+    engine.set_alignment(sample["states"])
+    assert np.array_equal(engine.hamming_weights(0), np.ones(400))
+    assert np.array_equal(engine.hamming_weights(10 ** 6), np.full(400, 1 / 401))
+
+
+def test_joint_counts_bit_exact(engine, sample, synth):
+    for d in (sample, synth):
+        _setup(engine, d)
+        st = d["states"]
+        rng = np.random.default_rng(2)
+        pa, pb = rng.integers(0, st.shape[0], 400), rng.integers(0, st.shape[0], 400)
+        pa[:4], pb[:4] = (0, 5, st.shape[0] - 1, 100), (1, 300, 17, 100)       # includes a self pair
+        cnt, fix, fb = engine.joint_tables(pa, pb)
+        sq = np.sqrt(d["hdw"])
+        V = np.rint(np.ldexp(sq * sq, fb)).astype(np.int64)
+        for k in range(len(pa)):
+            code = st[pa[k]].astype(np.int64) * 5 + st[pb[k]]
+            assert np.array_equal(cnt[k], np.bincount(code, minlength=25).reshape(5, 5))
+            assert np.array_equal(fix[k].ravel(), np.array([V[code == c].sum() for c in range(25)]))
+    assert np.array_equal(cnt[:4], synth["joint_counts"])                       # golden
+
+
+@pytest.mark.parametrize("eng_kind", [L.ENGINE_MFMA, L.ENGINE_HIST])
+def test_mi_blocks_match_oracle_and_golden(engine, sample, eng_kind):
+    _setup(engine, sample)
+    engine.set_engine(eng_kind)
+    idx = np.arange(1268)
+    MI = engine.mi_block(idx, idx)
+    assert np.abs(MI[np.ix_(sample["sub_r"], sample["sub_c"])] - sample["MI_single_sub"]).max() < MI_TIGHT
+    assert np.abs(MI.sum(axis=0) - sample["MI_single_colsum"]).max() < 1e-7
+    st = sample["states"]
+    for bi, (fs, fe, ts, te) in enumerate(sample["blocks"]):   # forced multi-block: Q1 on the non-square block
+        fi, ti = np.arange(fs - 1, fe), np.arange(ts - 1, te)
+        Mb = engine.mi_block(fi, ti)
+        ref = c_oracle.mi_block(st, sample["hdw"], sample["r"], sample["uqe"], fi, ti)
+        assert np.abs(Mb - ref).max() < MI_TIGHT
+        assert np.abs(Mb[::7, ::5] - sample[f"MI_blk{bi}_sub"]).max() < MI_TIGHT
+    engine.set_engine(L.ENGINE_MFMA)
+
+
+def test_quirk_modes(engine, sample):
+    _setup(engine, sample)
+    fs, fe, ts, te = sample["blocks"][1]
+    fi, ti = np.arange(fs - 1, fe), np.arange(ts - 1, te)
+    Mq = engine.mi_block(fi, ti, quirk=L.QUIRK_REFERENCE)
+    Mi = engine.mi_block(fi, ti, quirk=L.QUIRK_INTENDED)
+    assert np.abs(Mq - Mi).max() > 1e-4                      # the scramble is visible on a non-square block
+    st, hdw, r, uqe = sample["states"], sample["hdw"], sample["r"], sample["uqe"]
+    for a, b in ((0, 0), (999, 267), (17, 133)):
+        assert abs(Mi[a, b] - orc.mi_pair_direct(st, hdw, r, uqe, fi[a], ti[b])) < MI_TIGHT
+        assert abs(Mq[a, b] - orc.mi_pair_direct(st, hdw, r, uqe, fi[a], ti[b], orc.q1_rxy(a, b, 1000, 268, r[fi], r[ti]))) < MI_TIGHT
+    # intended mode is symmetric under exchanging the two sides
+    Mt = engine.mi_block(ti, fi, quirk=L.QUIRK_INTENDED)
+    assert np.abs(Mi - Mt.T).max() < 1e-12
+
+
+@pytest.mark.parametrize("nlimbs,tol", [(3, 1e-4), (4, 1e-7), (5, 1e-10), (6, 1e-12)])
+def test_limb_precision_ladder(engine, synth, nlimbs, tol):
+    _setup(engine, synth, nlimbs)
+    idx = np.arange(512)
+    MI = engine.mi_block(idx, idx)
+    err = np.abs(MI[::3, ::5] - synth["MI_sub"]).max()
+    assert err < tol, err
+    assert np.abs(MI.sum(axis=1) - synth["MI_rowsum"]).max() < tol * 512
+
+
+def test_unit_weights_are_exact_counts(engine, synth):
+    d = dict(synth)
+    d["hdw"] = np.ones(1000)
+    _setup(engine, d, 1)
+    cnt, fix, fb = engine.joint_tables([3, 400], [77, 2])
+    assert fb == 0 and np.array_equal(cnt, fix)
+    idx = np.arange(128)
+    MI = engine.mi_block(idx, idx)
+    ref = c_oracle.mi_block(d["states"], d["hdw"], d["r"], d["uqe"], idx, idx)
+    assert np.abs(MI - ref).max() < 1e-12
+
+
+def test_edge_cases_ragged_and_degenerate(engine):
+    """N not a multiple of the K step, tiny blocks, a monomorphic column, an all-gap column, a 5-state column,
+    uqe that disagrees with the data (flag set for an absent state / cleared for a present one)."""
+    rng = np.random.default_rng(11)
+    Ls, Ns = 77, 131
+    st = rng.integers(0, 2, (Ls, Ns)).astype(np.uint8)
+    st[3] = 2                              # monomorphic
+    st[4] = 4                              # all gaps
+    st[5] = rng.integers(0, 5, Ns)         # all five states
+    st[6, :5] = (0, 1, 2, 3, 4)
+    uqe, r = orc.uqe_r(st)
+    uqe[7, 3] = 1.0                        # flagged but absent
+    uqe[8, 0] = 0.0                        # present but masked
+    hdw = rng.choice([1.0, 0.5, 1 / 3, 1 / 7, 1 / 131], Ns)
+    POS = np.sort(rng.choice(5000, Ls, replace=False) + 1).astype(np.int32)
+    d = dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=POS, paint=np.ones(Ls, dtype=np.int32), g=5001.0)
+    for kind in (L.ENGINE_MFMA, L.ENGINE_HIST):
+        _setup(engine, d)
+        engine.set_engine(kind)
+        for fi, ti in ((np.arange(Ls), np.arange(Ls)), (np.arange(0, 40), np.arange(40, 77)), (np.array([5]), np.array([6])),
+                       (np.array([3, 4, 5, 7, 8]), np.arange(Ls))):
+            MI = engine.mi_block(fi, ti)
+            ref = c_oracle.mi_block(st, hdw, r, uqe, fi, ti)
+            assert np.abs(MI - ref).max() < MI_TIGHT, (kind, len(fi), len(ti))
+    engine.set_engine(L.ENGINE_MFMA)
+    with pytest.raises(L.LdwError):
+        engine.mi_block(np.array([Ls]), np.array([0]))           # index out of range
+    with pytest.raises(L.LdwError):
+        engine.mi_block(np.array([], dtype=np.int32), np.array([0]))  # empty block
+    with pytest.raises(L.LdwError):
+        engine.set_weights(np.ones(Ns + 1))                      # wrong length
+    with pytest.raises(L.LdwError):
+        engine.set_weights(np.full(Ns, -1.0))
+
+
+def _check_tables(eng, d, tag, POS, paint):
+    a, b, mi = eng.links(1)
+    assert len(mi) == int(d[f"{tag}_lr_n"])
+    pos1, pos2 = POS[b].astype(float), POS[a].astype(float)
+    assert np.array_equal(pos1[:200], d[f"{tag}_lr_pos1_head"]) and np.array_equal(pos2[-200:], d[f"{tag}_lr_pos2_tail"])
+    assert np.abs(mi[:200] - d[f"{tag}_lr_MI_head"]).max() < MI_TIGHT and np.abs(mi[-200:] - d[f"{tag}_lr_MI_tail"]).max() < MI_TIGHT
+    w = np.arange(len(mi)) % 1009 + 1
+    assert abs((pos1 * w).sum() - float(d[f"{tag}_lr_pos1_wsum"])) < 1e-3      # order-sensitive checksum of the whole table
+    a, b, mi = eng.links(0)
+    pos1, pos2, c1, c2 = POS[b].astype(float), POS[a].astype(float), paint[b], paint[a]
+    for ci in (1, 2, 3):
+        sel = (c1 == ci) | (c2 == ci)
+        n = int(sel.sum())
+        assert n == int(d[f"{tag}_sr{ci}_n"])
+        assert np.array_equal(pos1[sel][:200], d[f"{tag}_sr{ci}_pos1_head"]) and np.array_equal(pos2[sel][-200:], d[f"{tag}_sr{ci}_pos2_tail"])
+        w = np.arange(n) % 1009 + 1
+        assert abs((pos2[sel] * w).sum() - float(d[f"{tag}_sr{ci}_pos2_wsum"])) < 1e-3
+        assert abs((mi[sel] * w).sum() - float(d[f"{tag}_sr{ci}_MI_wsum"])) < MI_TIGHT * w.sum()  # mean |dMI| below 1e-10
+
+
+def test_link_tables_match_golden(engine, sample):
+    """The a-5 loop: row counts, row ORDER (Q3/Q4) and values of the sr / lr tables, single- and multi-block."""
+    _setup(engine, sample)
+    for tag, mb, retain in (("single", 10000, 1e6), ("multi", 1000, 1e5)):
+        blocks = MIH.make_blocks(1268, mb)
+        engine.mi_all_pairs(blocks, 20000.0, retain, float(sample[f"{tag}_lr_approx"]))
+        _check_tables(engine, sample, tag, sample["POS"], sample["paint"])
+        st = engine.block_stats()
+        assert st["n_lr_kept"].sum() == int(sample[f"{tag}_lr_n"])
+
+
+def test_lr_quantile_filter_exact(engine, synth):
+    """Per-block type-7 quantile threshold and retained set == oracle when only a small top fraction is kept."""
+    _setup(engine, synth)
+    POS, g = synth["POS"], synth["g"]
+    approx = orc.lr_links_approx(POS, g, 20000.0)
+    for retain, mb in ((500.0, 10000), (2000.0, 1000)):
+        blocks = orc.make_blocks(512, orc.r_round_thousands(mb))
+        engine.mi_all_pairs(np.array(blocks, dtype=np.int32), 20000.0, retain, approx)
+        st = engine.block_stats()
+        a, b, mi = engine.links(1)
+        off = 0
+        for bi, (fs, fe, ts, te) in enumerate(blocks):
+            fi, ti = np.arange(fs - 1, fe), np.arange(ts - 1, te)
+            Mb = c_oracle.mi_block(synth["states"], synth["hdw"], synth["r"], synth["uqe"], fi, ti)
+            bl = orc.block_links(Mb, fi, ti, POS, synth["paint"], g, 20000.0, retain, approx)
+            assert st["n_lr_total"][bi] == bl.n_lr_total
+            n = len(bl.lr["MI"])
+            assert st["n_lr_kept"][bi] == n, (bi, st["n_lr_kept"][bi], n)
+            assert abs(st["disc_thresh"][bi] - bl.disc_thresh) < MI_TIGHT
+            assert np.array_equal(a[off:off + n], bl.lr["a"]) and np.array_equal(b[off:off + n], bl.lr["b"])
+            assert np.abs(mi[off:off + n] - bl.lr["MI"]).max() < MI_TIGHT
+            off += n
+        assert off == len(mi)
+
+
+def test_perform_mi_computation_end_to_end(engine, sample, tmp_path):
+    """Drop-in entry point with the reference's signature: returned frame and both tsv files vs the oracle's a-5 loop
+    (srp model: same optimiser on both sides; parity with R's fitdist is unpinned)."""
+    st = sample["states"]
+    sd = SnpDat(states=st, POS=sample["POS"], g=sample["g"], uqe=sample["uqe"], r=sample["r"])
+    cv = CdsVar(paint=sample["paint"], nclust=3)
+    lr_p, sr_p = str(tmp_path / "lr.tsv"), str(tmp_path / "sr.tsv")
+    red, aux = MIH.perform_MI_computation(sd, sample["hdw"], cv, ncores=1, lr_save_path=lr_p, sr_save_path=sr_p,
+                                          plt_folder=str(tmp_path / "plots"), max_blk_sz=10000, lr_retain_links=1e6,
+                                          engine=engine, verbose=False, return_aux=True)
+    ref = orc.perform_mi_computation(st, sample["POS"], sample["g"], sample["r"], sample["uqe"], sample["hdw"], sample["paint"], 3,
+                                     lr_retain_links=1e6, max_blk_sz=10000)
+    rr = ref.sr_links_red
+    assert len(red) == len(rr["MI"]) > 100
+    # both are ordered by decreasing srp_max; MI differs by ~1e-12 so near-ties may swap: compare as keyed tables
+    assert (np.diff(red["srp_max"].to_numpy()) <= 0).all()
+    ko = np.lexsort((np.asarray(rr["clust_c"]), rr["pos2"], rr["pos1"]))
+    kg = np.lexsort((red["clust_c"].to_numpy(), red["pos2"].to_numpy(), red["pos1"].to_numpy()))
+    for k in ("clust_c", "pos1", "pos2", "clust1", "clust2", "len"):
+        assert np.array_equal(red[k].to_numpy(dtype=float)[kg], np.asarray(rr[k], dtype=float)[ko]), k
+    # ARACNE is a chain of strict MI comparisons: exact on identical inputs; against the oracle's own MI (1e-12 away)
+    # only exact MI ties (SNPs in perfect LD) may flip
+    chk = aux["sr_links_ARACNE_check"]
+    flags = orc.run_aracne(red["pos1"].to_numpy(), red["pos2"].to_numpy(), red["MI"].to_numpy(), chk["pos1"].to_numpy(),
+                           chk["pos2"].to_numpy(), chk["MI"].to_numpy())
+    assert np.array_equal(red["ARACNE"].to_numpy(), flags.astype(float))
+    # links whose triangle test is decided by a margin > eps must agree with the oracle's flags; the rest are exact ties
+    eps = 1e-9
+    adj = {}
+    for p1, p2, m in zip(chk["pos1"].to_numpy(), chk["pos2"].to_numpy(), chk["MI"].to_numpy()):
+        adj.setdefault(p1, {}).setdefault(p2, m)
+        adj.setdefault(p2, {}).setdefault(p1, m)
+    got, want = red["ARACNE"].to_numpy()[kg], np.asarray(rr["ARACNE"])[ko]
+    n_decided = 0
+    for i, (x, z, m0) in enumerate(zip(red["pos1"].to_numpy()[kg], red["pos2"].to_numpy()[kg], red["MI"].to_numpy()[kg])):
+        common = set(adj.get(x, {})) & set(adj.get(z, {}))
+        surely_indirect = any(m0 < adj[x][y] - eps and m0 < adj[z][y] - eps for y in common)
+        maybe_indirect = any(m0 < adj[x][y] + eps and m0 < adj[z][y] + eps for y in common)
+        if surely_indirect or not maybe_indirect:
+            n_decided += 1
+            assert got[i] == want[i] == (0.0 if surely_indirect else 1.0), (i, x, z)
+    assert n_decided > 0.5 * len(got)   # the sample is clonal: ~1/3 of its links sit in exact MI ties (perfect LD)
+    assert np.abs(red["MI"].to_numpy()[kg] - rr["MI"][ko]).max() < MI_TIGHT
+    assert np.abs(red["srp_max"].to_numpy()[kg] - rr["srp_max"][ko]).max() < 1e-6
+    assert 0 < red["ARACNE"].sum() < len(red)
+    lines = open(lr_p).read().splitlines()
+    assert len(lines) == len(ref.lr_rows["MI"]) == int(sample["single_lr_n"])
+    first = lines[0].split("\t")
+    assert len(first) == 6 and float(first[0]) == ref.lr_rows["pos1"][0] and abs(float(first[5]) - ref.lr_rows["MI"][0]) < 1e-9
+    srl = open(sr_p).read().splitlines()
+    assert len(srl) == len(red) and len(srl[0].split("\t")) == 9
+
+
+def test_sr_only_mode(engine, synth):
+    """perform_SR_analysis_only drops SNPs without a short-range partner before each block (non-contiguous,
+    non-square blocks -> Q1 scramble differs from the full run)."""
+    d = synth
+    _setup(engine, d)
+    POS, g, sr_dist = d["POS"], d["g"], 3000.0
+    blocks = orc.make_blocks(512, 1000)
+    engine.links_begin(len(blocks))
+    ref = orc.perform_mi_computation(d["states"], POS, g, d["r"], d["uqe"], d["hdw"], d["paint"], 3, sr_dist=sr_dist,
+                                     max_blk_sz=1000, sr_only=True, do_srp=False)
+    POSf = POS.astype(float)
+    for fs, fe, ts, te in blocks:
+        fi, ti = np.arange(fs - 1, fe), np.arange(ts - 1, te)
+        ln = np.abs(orc.circ_len(POSf[ti][None, :], POSf[fi][:, None], g))
+        fi, ti = fi[(ln < sr_dist).any(axis=1)], ti[(ln < sr_dist).any(axis=0)]
+        engine.mi_block_links(fi, ti, sr_dist=sr_dist, sr_only=True)
+    engine.links_end()
+    a, b, mi = engine.links(0)
+    assert engine.links_count(1) == 0
+    tot = sum(len(x["MI"]) for x in ref.sr_links_by_clust)
+    c1, c2 = d["paint"][b], d["paint"][a]
+    got = sum(int(((c1 == ci) | (c2 == ci)).sum()) for ci in (1, 2, 3))
+    assert got == tot > 0
+    sel = (c1 == 1) | (c2 == 1)
+    assert np.abs(mi[sel] - ref.sr_links_by_clust[0]["MI"]).max() < MI_TIGHT
+
+
+def test_elementwise_twins(engine, kat):
+    ops = [kat[f"op_{k}"] for k in ("den", "uq", "pxy", "pxpy", "RXY", "pXrX", "pYrY")]
+    MI = kat["MI0"].copy()
+    engine.fast_hadamard(MI, *ops)
+    np.testing.assert_allclose(MI, kat["MI1"], rtol=1e-15, atol=1e-15)   # device log() may differ from libm in the last ulp
+    nv = np.ones((5, len(kat["ref_chars"])), order="F")
+    engine.acgtn2num(nv, list(kat["ref_chars"]))
+    assert np.array_equal(nv, kat["nv"])
+    nv0 = np.ones((5, 0), order="F")
+    engine.acgtn2num(nv0, [])                  # empty input is a no-op
+
+
+def test_c2_full_size_properties(engine):
+    """BASELINE config 2 (5k SNPs x 1k seqs) at full size: size-independent properties + sampled oracle parity."""
+    syn = synth_alignment(5000, 1000, seed=1988)
+    st = syn["states"]
+    uqe, r = orc.uqe_r(st)
+    engine.set_alignment(st)
+    hdw = engine.hamming_weights(500)
+    assert np.array_equal(hdw, c_oracle.hamming_weights(st, 500))
+    d = dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=syn["POS"], paint=syn["paint"], g=float(syn["g"]))
+    _setup(engine, d)
+    idx = np.arange(5000)
+    MI = engine.mi_block(idx, idx, quirk=L.QUIRK_INTENDED)
+    assert np.abs(MI - MI.T).max() < 1e-12                      # symmetry
+    assert MI.min() > -1e-9                                     # a KL divergence of smoothed tables
+    # self-information on the diagonal: MI(a,a) equals the smoothed entropy-like value of the oracle
+    rng = np.random.default_rng(4)
+    for a, b in zip(rng.integers(0, 5000, 25), rng.integers(0, 5000, 25)):
+        assert abs(MI[a, b] - orc.mi_pair_direct(st, hdw, r, uqe, int(a), int(b))) < MI_TIGHT
+    # sampled rows against the C oracle (reference quirk mode)
+    Mq = engine.mi_block(idx, idx)
+    rows = np.array([0, 17, 2500, 4999])
+    ref = c_oracle.mi_block(st, hdw, r, uqe, rows, idx)
+    # row a of the square block uses RXY(c / nt, c % nt): compute the reference with the same full-block geometry
+    ref_full_rows = np.stack([[orc.mi_pair_direct(st, hdw, r, uqe, int(a), int(b), orc.q1_rxy(int(a), int(b), 5000, 5000, r, r))
+                               for b in (0, 1234, 4999)] for a in rows])
+    assert np.abs(Mq[np.ix_(rows, [0, 1234, 4999])] - ref_full_rows).max() < MI_TIGHT
+    del ref
+    # link tables: every pair lands in exactly one of sr / lr-before-filter
+    approx = MIH.lr_links_approx(syn["POS"], float(syn["g"]), 20000.0)
+    engine.mi_all_pairs(MIH.make_blocks(5000, 10000), 20000.0, 1e6, approx)
+    stt = engine.block_stats()
+    assert stt["n_sr"][0] + stt["n_lr_total"][0] == 5000 * 4999 // 2
+    a, b, mi = engine.links(1)
+    assert (a > b).all() and np.all(mi >= stt["disc_thresh"][0])
+    key = a.astype(np.int64) + b.astype(np.int64) * 5000
+    assert (np.diff(key) > 0).all()                              # reference row order (column-major, a > b)
