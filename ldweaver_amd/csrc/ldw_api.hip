@@ -259,7 +259,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     ldw::DevBuf *bufs[] = {&c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->M, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
-                           &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->hist, &c->colcnt, &c->cand_key,
+                           &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->hist, &c->colcnt, &c->cand_key,
                            &c->cand_val, &c->cand_key2, &c->cand_val2, &c->scratch, &c->small, &c->sr_a, &c->sr_b,
                            &c->sr_mi, &c->lr_a, &c->lr_b, &c->lr_mi};
     for (auto *b : bufs) b->release();

@@ -15,9 +15,9 @@
 // matrix, the five `crossprod`s of R/performPopulationStuctureCorrection.R:49-74.
 //
 // Tiling: 128 x 128 rows per workgroup (8 waves, 2 x 4), 64 x 32 per wave = 2 x 1 MFMA tiles of
-// v_mfma_i32_32x32x32_i8, K staged through LDS in 64-byte steps (register-staged double buffer).
-// LDS rows are 64 B; the 16-B slot is XOR-swizzled with (row>>2)&3 so that each ds_read_b128 lane
-// group touches 16 distinct slots of the 256-B bank row.
+// v_mfma_i32_32x32x32_i8, K staged through LDS in KSTEP-byte steps (register-staged double buffer).
+// LDS rows are KSTEP bytes; the 16-B slot index is XOR-swizzled with the bank-row number so that each
+// ds_read_b128 lane group touches 16 distinct slots of the 256-B bank row.
 #include "ldw_internal.h"
 
 namespace ldw {
@@ -25,7 +25,15 @@ namespace ldw {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ int lds_off(int row, int slot) { return row * KSTEP + ((slot ^ ((row >> 2) & 3)) << 4); }
+constexpr int SPR = KSTEP / 16;          // 16-B slots per LDS row
+constexpr int RPB = 256 / KSTEP;         // LDS rows per 256-B bank row
+constexpr int NKK = KSTEP / 32;          // MFMA k-steps per stage
+constexpr int PIECES = TILE * SPR / 512; // 16-B pieces per thread per operand tile
+static_assert(KSTEP == 64 || KSTEP == 128, "KSTEP must be 64 or 128");
+
+__device__ __forceinline__ int lds_off(int row, int slot) {
+    return row * KSTEP + ((slot ^ ((row / RPB) & (SPR - 1))) << 4);
+}
 
 template <int J>
 __global__ __launch_bounds__(512, 2) void gemm_limb_kernel(const uint8_t *__restrict__ Mbase, int64_t Kpad,
@@ -46,15 +54,21 @@ __global__ __launch_bounds__(512, 2) void gemm_limb_kernel(const uint8_t *__rest
     const int wave = tid >> 6;  // 8 waves: 2 (to-side, M-dim) x 4 (from-side, N-dim)
     const int wm = wave >> 2, wn = wave & 3;
 
-    // staging assignment: one 16-B piece per operand tile per thread
-    const int srow = tid >> 2;  // 0..127
-    const int sslot = tid & 3;
-    const uint8_t *gT = Mbase + (int64_t)rowlist_t[by * TILE + srow] * Kpad + sslot * 16;
-    const uint8_t *gF = Mbase + (int64_t)rowlist_f[bx * TILE + srow] * Kpad + sslot * 16;
-    const int w0 = lds_off(srow, sslot);
-    // digits: J*64 bytes per stage = J*4 pieces of 16 B, loaded by the first J*4 threads
-    const bool dig_loader = tid < J * 4;
-    const int8_t *gD = digits + (int64_t)(tid >> 2) * Kpad + (tid & 3) * 16;
+    // staging assignment: PIECES 16-B pieces per operand tile per thread
+    const int srow = tid / SPR;  // row of the first piece; piece p adds p * (512 / SPR) rows
+    const int sslot = tid % SPR;
+    const uint8_t *gT[PIECES], *gF[PIECES];
+    int wofs[PIECES];
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+        const int row = srow + p * (512 / SPR);
+        gT[p] = Mbase + (int64_t)rowlist_t[by * TILE + row] * Kpad + sslot * 16;
+        gF[p] = Mbase + (int64_t)rowlist_f[bx * TILE + row] * Kpad + sslot * 16;
+        wofs[p] = lds_off(row, sslot);
+    }
+    // digits: J*KSTEP bytes per stage = J*SPR pieces of 16 B, loaded by the first J*SPR threads
+    const bool dig_loader = tid < J * SPR;
+    const int8_t *gD = digits + (int64_t)(tid / SPR) * Kpad + (tid % SPR) * 16;
 
     v16i acc[J][2];
 #pragma unroll
@@ -65,49 +79,66 @@ __global__ __launch_bounds__(512, 2) void gemm_limb_kernel(const uint8_t *__rest
             for (int e = 0; e < 16; ++e) acc[j][m][e] = 0;
 
     const int nk = (int)(Kpad / KSTEP);
-    v4i rT, rF, rD;
+    v4i rT[PIECES], rF[PIECES], rD;
     rD = v4i{0, 0, 0, 0};
     // prologue: stage 0
-    rT = *reinterpret_cast<const v4i *>(gT);
-    rF = *reinterpret_cast<const v4i *>(gF);
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+        rT[p] = *reinterpret_cast<const v4i *>(gT[p]);
+        rF[p] = *reinterpret_cast<const v4i *>(gF[p]);
+    }
     if (dig_loader) rD = *reinterpret_cast<const v4i *>(gD);
-    *reinterpret_cast<v4i *>(&sT[0][w0]) = rT;
-    *reinterpret_cast<v4i *>(&sF[0][w0]) = rF;
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+        *reinterpret_cast<v4i *>(&sT[0][wofs[p]]) = rT[p];
+        *reinterpret_cast<v4i *>(&sF[0][wofs[p]]) = rF[p];
+    }
     if (dig_loader) *reinterpret_cast<v4i *>(&sD[0][tid * 16]) = rD;
     __syncthreads();
 
     const int frow = lane & 31;
     const int fh = lane >> 5;
+    const int arow0 = wm * 64 + frow, arow1 = arow0 + 32, brow = wn * 32 + frow;
 
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
         if (ks + 1 < nk) {  // issue next stage's global loads early
             const int64_t ko = (int64_t)(ks + 1) * KSTEP;
-            rT = *reinterpret_cast<const v4i *>(gT + ko);
-            rF = *reinterpret_cast<const v4i *>(gF + ko);
+#pragma unroll
+            for (int p = 0; p < PIECES; ++p) {
+                rT[p] = *reinterpret_cast<const v4i *>(gT[p] + ko);
+                rF[p] = *reinterpret_cast<const v4i *>(gF[p] + ko);
+            }
             if (dig_loader) rD = *reinterpret_cast<const v4i *>(gD + ko);
         }
+        // fragments of k-step kk+1 are read while the MFMAs of k-step kk run
+        v4i a0[2], a1[2], b[2];
+        a0[0] = *reinterpret_cast<const v4i *>(&sT[cur][lds_off(arow0, fh)]);
+        a1[0] = *reinterpret_cast<const v4i *>(&sT[cur][lds_off(arow1, fh)]);
+        b[0] = *reinterpret_cast<const v4i *>(&sF[cur][lds_off(brow, fh)]);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < NKK; ++kk) {
             const int slot = kk * 2 + fh;
-            v4i a[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-                a[m] = *reinterpret_cast<const v4i *>(&sT[cur][lds_off(wm * 64 + m * 32 + frow, slot)]);
-            const v4i b = *reinterpret_cast<const v4i *>(&sF[cur][lds_off(wn * 32 + frow, slot)]);
+            if (kk + 1 < NKK) {
+                a0[(kk + 1) & 1] = *reinterpret_cast<const v4i *>(&sT[cur][lds_off(arow0, slot + 2)]);
+                a1[(kk + 1) & 1] = *reinterpret_cast<const v4i *>(&sT[cur][lds_off(arow1, slot + 2)]);
+                b[(kk + 1) & 1] = *reinterpret_cast<const v4i *>(&sF[cur][lds_off(brow, slot + 2)]);
+            }
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const v4i d = *reinterpret_cast<const v4i *>(&sD[cur][j * KSTEP + slot * 16]);
-                const v4i bm = b & d;  // digit where the from-side indicator is set
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    acc[j][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], bm, acc[j][m], 0, 0, 0);
+                const v4i bm = b[kk & 1] & d;  // digit where the from-side indicator is set
+                acc[j][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0[kk & 1], bm, acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1[kk & 1], bm, acc[j][1], 0, 0, 0);
             }
         }
         if (ks + 1 < nk) {
             const int nxt = cur ^ 1;
-            *reinterpret_cast<v4i *>(&sT[nxt][w0]) = rT;
-            *reinterpret_cast<v4i *>(&sF[nxt][w0]) = rF;
+#pragma unroll
+            for (int p = 0; p < PIECES; ++p) {
+                *reinterpret_cast<v4i *>(&sT[nxt][wofs[p]]) = rT[p];
+                *reinterpret_cast<v4i *>(&sF[nxt][wofs[p]]) = rF[p];
+            }
             if (dig_loader) *reinterpret_cast<v4i *>(&sD[nxt][tid * 16]) = rD;
         }
         __syncthreads();

@@ -92,7 +92,7 @@ struct ldw_ctx {
     // ---- per-block workspaces ----
     ldw::DevBuf G;               // int64 [RTpad][RFpad]
     ldw::DevBuf MIblk;           // double [nf*nt]
-    ldw::DevBuf rowlist_f, rowlist_t, idx_f, idx_t, lrow_f, lrow_t;
+    ldw::DevBuf rowlist_f, rowlist_t, idx_f, idx_t, lrow_f, lrow_t, perm_f;
     ldw::DevBuf hist, colcnt, cand_key, cand_val, cand_key2, cand_val2, scratch, small;
 
     // ---- link tables (device resident) ----

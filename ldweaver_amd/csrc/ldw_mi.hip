@@ -1,5 +1,14 @@
 // MI epilogue, link selection and the block drivers (twins of perform_MI_computation_ACGTN,
 // R/computePairwiseMI.R:167-386, and of the block loop of perform_MI_computation, :103-116).
+//
+// Per block:  GEMM (ldw_gemm.hip) -> k_mi_epilogue: one thread per SNP pair turns the fixed-point joint
+// sums into MI (src/computeMI.cpp:19), writes the dense MI block, scatters the short-range links straight
+// to their final rows and histograms the long-range MI values in LDS -> k_pick_bucket: ranks of the two
+// order statistics of quantile type 7 and the histogram bucket holding them -> k_lr_gather: every
+// long-range pair at or above that bucket -> two radix sorts (by MI, then by reference row order) with
+// k_lr_thresh in between -> k_lr_append.  The short-range test needs no arithmetic per pair: POS is
+// ascending, so the partners of a to-side SNP within sr_dist (circularly) are at most three index
+// intervals of the from-side list, found on the host by binary search (ColInfo).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -12,7 +21,7 @@ using namespace ldw;
 namespace ldw {
 
 // ------------------------------------------------------------------------------------------------
-// device helpers
+// helpers shared by host and device
 // ------------------------------------------------------------------------------------------------
 // len = 0.5*g - abs((pos1 - pos2) %% g - 0.5*g)   (R/computePairwiseMI.R:330; R's floored %%)
 __host__ __device__ __forceinline__ double circ_len(double pos1, double pos2, double g) {
@@ -21,11 +30,6 @@ __host__ __device__ __forceinline__ double circ_len(double pos1, double pos2, do
     if (d < 0) d += g;
     if (d >= g) d -= g;
     return 0.5 * g - fabs(d - 0.5 * g);
-}
-
-__device__ __forceinline__ int mi_bucket(double mi) {
-    int b = (int)floor(mi * ((double)NBINS / MI_HIST_MAX));
-    return b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
 }
 
 // order-preserving map double -> uint64 (ascending)
@@ -41,17 +45,123 @@ __host__ __device__ __forceinline__ double key_f64(uint64_t k) {
     return v;
 }
 
-// one term of src/computeMI.cpp:19 with uq = 1:  pxy/den * log(pxy/(pxpy+RXY+pXrX+pYrY)*den)
-__device__ __forceinline__ double mi_term(int64_t nfix, double scale, double pX, double pY, double RXY, double rX,
-                                          double rY, double den) {
-    const double pxy = (double)nfix * scale + 0.5;
-    const double d = ((pX * pY + RXY) + pX * rX) + pY * rY;
-    return (pxy / den) * log((pxy / d) * den);
+__device__ __forceinline__ int mi_bucket(double mi) {
+    int b = (int)floor(mi * ((double)NBINS / MI_HIST_MAX));
+    return b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
+}
+
+// Short-range partners of one to-side SNP: up to three disjoint, ascending index intervals [s,e) of the
+// from-side list, plus the first row of its upper (a_loc < b_loc) and lower (a_loc > b_loc) segment in
+// the short-range table (relative to the block's base row).
+struct ColInfo {
+    int32_t s[3], e[3];
+    int32_t pad[2];
+    int64_t off_u, off_l;
+};
+
+__host__ __device__ __forceinline__ bool col_is_sr(const ColInfo &c, int a) {
+    return (a >= c.s[0] && a < c.e[0]) || (a >= c.s[1] && a < c.e[1]) || (a >= c.s[2] && a < c.e[2]);
+}
+// number of short-range partners in [lo, hi)
+__host__ __device__ __forceinline__ int col_count(const ColInfo &c, int lo, int hi) {
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = c.s[k] > lo ? c.s[k] : lo, b = c.e[k] < hi ? c.e[k] : hi;
+        n += b > a ? b - a : 0;
+    }
+    return n;
+}
+
+// which segment a pair belongs to: 0 = upper (a<b, off-diagonal blocks only), 1 = lower (a>b), -1 = not a pair
+__host__ __device__ __forceinline__ int pair_seg(int a_loc, int b_loc, int lower_only) {
+    if (a_loc == b_loc) return -1;
+    if (a_loc > b_loc) return 1;
+    return lower_only ? -1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
-// MI epilogue: one thread per SNP pair; wave = 64 consecutive from-side SNPs at one to-side SNP
+// fp64 helpers of the epilogue: no IEEE division, no libm call.  Relative accuracy ~1e-16 / 2e-16; the
+// epilogue is not bit-matched to the reference (tolerance 1e-6 on MI), see DESIGN.md.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// exact conversion of an integer 0 <= n < 2^52 to double (two integer ops and one add instead of the
+// multi-instruction int64 -> f64 sequence)
+__device__ __forceinline__ double u52_to_double(int64_t n) {
+    return __longlong_as_double(n | 0x4330000000000000LL) - 4503599627370496.0;
+}
+
+// log(N / D) for positive, finite, normal doubles with ONE reciprocal: D is rescaled by a power of two so that
+// N / D' lies in [1/sqrt2, sqrt2]; then log(N/D') = 2 atanh(s), s = (N - D')/(N + D'), |s| <= 0.1716, odd series
+// to s^21 (relative error ~1e-16), and log(N/D) = k ln2 + log(N/D').
+__device__ __forceinline__ double fast_log_ratio(double N, double D) {
+    const int hn = __double2hiint(N), hd = __double2hiint(D);
+    int k = ((hn >> 20) & 0x7FF) - ((hd >> 20) & 0x7FF);
+    double Dp = __hiloint2double(hd + (k << 20), __double2loint(D));   // D * 2^k: same exponent as N
+    // N / Dp is in (1/2, 2): fold it into [1/sqrt2, sqrt2]
+    const bool big = N > Dp * 1.4142135623730951, small = N * 1.4142135623730951 < Dp;
+    const int adj = big ? 1 : (small ? -1 : 0);
+    Dp = __hiloint2double(__double2hiint(Dp) + (adj << 20), __double2loint(Dp));
+    k += adj;
+    const double s = (N - Dp) * fast_rcp(N + Dp);
+    const double z = s * s;
+    double p = 1.0 / 21.0;
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    p = p * z;  // atanh(s)/s - 1
+    const double lm = fma(s + s, p, s + s);
+    return fma((double)k, 0.693147180559945309417, lm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// what happens to one finished pair: dense store, short-range scatter, long-range histogram
+// ------------------------------------------------------------------------------------------------
+struct EmitArgs {
+    double *MI;            // dense block, column-major nf x nt
+    const ColInfo *cols;   // null: dense store only (ldw_mi_block)
+    int nf, lower_only, keep_sr, do_lr;
+    int64_t sr_base;
+    int32_t *sr_a, *sr_b;
+    double *sr_mi;
+};
+
+__device__ __forceinline__ void emit_pair(const EmitArgs &E, const ColInfo &c, int a_loc, int b_loc, int sa, int sb,
+                                          double mi, unsigned int *sh_hist) {
+    E.MI[(int64_t)a_loc + (int64_t)b_loc * E.nf] = mi;
+    if (!E.cols) return;
+    const int seg = pair_seg(a_loc, b_loc, E.lower_only);
+    if (seg < 0) return;
+    if (col_is_sr(c, a_loc)) {
+        if (E.keep_sr) {
+            const int64_t dst = E.sr_base + (seg == 0 ? c.off_u + col_count(c, 0, a_loc) : c.off_l + col_count(c, b_loc + 1, a_loc));
+            E.sr_a[dst] = sa;
+            E.sr_b[dst] = sb;
+            E.sr_mi[dst] = mi;
+        }
+    } else if (E.do_lr) {
+        atomicAdd(&sh_hist[mi_bucket(mi)], 1u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MI epilogue: one thread per SNP pair; a wave = 64 consecutive from-side SNPs at one to-side SNP and walks
+// EPI_COLS/4 consecutive to-side SNPs, so everything indexed by the to-side SNP is wave-uniform.
+// ------------------------------------------------------------------------------------------------
+constexpr int EPI_COLS = 128;  // to-side SNPs per workgroup (4 waves x 32)
+
 struct EpiArgs {
     const int64_t *G;
     int RFpad;
@@ -61,83 +171,214 @@ struct EpiArgs {
     const int64_t *slot_pfix;
     const double *r;
     double neff, scale;
-    int quirk, lower_only;
-    double *MI;
+    int quirk;
+    EmitArgs E;
 };
 
-__global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A) {
-    const int a_loc = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int b_loc = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
-    if (a_loc >= A.nf || b_loc >= A.nt) return;
-    if (A.lower_only && a_loc <= b_loc) return;
-    const int sa = A.idx_f[a_loc], sb = A.idx_t[b_loc];
-    const uint32_t ma = A.slot_meta[sa], mb = A.slot_meta[sb];
-    const int na = ma & 7, nb = mb & 7;
-    const int64_t ra0 = A.lrow_f[a_loc], rb0 = A.lrow_t[b_loc];
+// everything the epilogue needs about one to-side SNP, staged in LDS once per workgroup so that the
+// per-pair loop has no dependent global loads except its G entries
+struct ColMeta {
+    int32_t sb;
+    uint32_t mb;
+    int32_t rb0, pad;
+    double rb;      // r of the to-side SNP
+    double rq;      // Q1 on square blocks: r[idx_f[b_loc]]
+    double pYd[5];
+    int64_t pb[5];
+    ColInfo ci;
+};
 
-    int64_t pa[5], pb[5];
+// per-lane constants of the from-side SNP
+struct RowSide {
+    int sa, na;
+    uint32_t ma;
+    int64_t ra0;
+    double ra, rta;  // rta: Q1 on square blocks, r[idx_t[a_loc]]
+    int64_t pa[5];
+    double pXd[5];
+};
+
+// MI of one pair.  NAM / NB bound the unrolled slot loops (na <= NAM for every lane of the wave, nb <= NB);
+// the run-time slot counts still mask the individual cells.
+template <int NAM, int NB>
+__device__ __forceinline__ double pair_mi(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc,
+                                          bool square) {
+    const int na = R.na, nb = M.mb & 7;
+    const uint32_t ma = R.ma, mb = M.mb;
+    // joint sums of the row slots (from G), their row / column sums
+    int64_t g[NAM][NB], rs[NAM], cs[NB];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        pa[i] = A.slot_pfix[(int64_t)sa * 5 + i];
-        pb[i] = A.slot_pfix[(int64_t)sb * 5 + i];
-    }
-    // joint counts of the row slots, their row / column sums
-    int64_t g[4][4], rs[4] = {0, 0, 0, 0}, cs[4] = {0, 0, 0, 0};
+    for (int i = 0; i < NAM; ++i) rs[i] = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NB; ++j) cs[j] = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int i = 0; i < NAM; ++i) {
             int64_t v = 0;
-            if (i < na && j < nb) v = A.G[(rb0 + j) * A.RFpad + ra0 + i];
+            if (i < na && j < nb) v = A.G[((int64_t)M.rb0 + j) * A.RFpad + R.ra0 + i];
             g[i][j] = v;
             rs[i] += v;
             cs[j] += v;
         }
-    // drop-slot marginals
-    int64_t pa_drop = 0, pb_drop = 0, dd = 0;
+    int64_t pa_drop = 0;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        if (i == na) pa_drop = pa[i];
-        if (i == nb) pb_drop = pb[i];
-    }
-    dd = pa_drop;
+    for (int i = 0; i <= NAM; ++i)
+        if (i == na) pa_drop = R.pa[i];
+    int64_t dd = pa_drop;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (j < nb) dd -= pb[j] - cs[j];
-    (void)pb_drop;
+    for (int j = 0; j < NB; ++j)
+        if (j < nb) dd -= M.pb[j] - cs[j];
 
-    const double ra = A.r[sa], rb = A.r[sb];
+    const double ra = R.ra, rb = M.rb;
     const double den = A.neff + (ra * rb) * 0.5;  // R/computePairwiseMI.R:260
     double RXY;
     if (A.quirk == LDW_QUIRK_REFERENCE) {
-        // rft is nt x nf but read by the linear index of the nf x nt matrix (Q1)
-        const int64_t c = (int64_t)a_loc + (int64_t)b_loc * A.nf;
-        RXY = (A.r[A.idx_f[c / A.nt]] * A.r[A.idx_t[c % A.nt]]) * 0.25;
+        // rft is nt x nf but read by the linear index c = a + b*nf of the nf x nt matrix (Q1):
+        // 0.25 * rf[c / nt] * rt[c % nt]; on square blocks c / nt = b_loc and c % nt = a_loc
+        if (square) {
+            RXY = (M.rq * R.rta) * 0.25;
+        } else {
+            const uint32_t c = (uint32_t)a_loc + (uint32_t)b_loc * (uint32_t)A.nf;
+            const uint32_t q = c / (uint32_t)A.nt;
+            RXY = (A.r[A.idx_f[q]] * A.r[A.idx_t[c - q * (uint32_t)A.nt]]) * 0.25;
+        }
     } else {
         RXY = (ra * rb) * 0.25;
     }
     const double rX = 0.5 * ra, rY = 0.5 * rb;
 
-    double mi = 0.0;
+    // sum over cells of pxy * log(pxy / (pX pY + RXY + pX rX + pY rY) * den), divided by den at the end
+    double acc = 0.0;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i <= NAM; ++i) {
         if (i <= na && ((ma >> (3 + i)) & 1)) {
-            const double pX = (double)pa[i] * A.scale;
+            const double pX = R.pXd[i];
+            const double pXr = fma(pX, rX, RXY);
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
+            for (int j = 0; j <= NB; ++j) {
                 if (j <= nb && ((mb >> (3 + j)) & 1)) {
                     int64_t nfix;
-                    if (i < 4 && j < 4 && i < na && j < nb) nfix = g[i < 4 ? i : 0][j < 4 ? j : 0];
-                    else if (i < 4 && i < na) nfix = pa[i] - rs[i < 4 ? i : 0];   // j == nb
-                    else if (j < 4 && j < nb) nfix = pb[j] - cs[j < 4 ? j : 0];   // i == na
+                    if (i < NAM && j < NB && i < na && j < nb) nfix = g[i < NAM ? i : 0][j < NB ? j : 0];
+                    else if (i < NAM && i < na) nfix = R.pa[i] - rs[i < NAM ? i : 0];   // j == nb
+                    else if (j < NB && j < nb) nfix = M.pb[j] - cs[j < NB ? j : 0];     // i == na
                     else nfix = dd;
-                    const double pY = (double)pb[j] * A.scale;
-                    mi += mi_term(nfix, A.scale, pX, pY, RXY, rX, rY, den);
+                    const double pY = M.pYd[j];
+                    const double pxy = fma(u52_to_double(nfix), A.scale, 0.5);
+                    const double d = fma(pY, rY, fma(pX, pY, pXr));
+                    acc = fma(pxy, fast_log_ratio(pxy * den, d), acc);
                 }
             }
         }
     }
-    A.MI[(int64_t)a_loc + (int64_t)b_loc * A.nf] = mi;
+    return acc * fast_rcp(den);
+}
+
+__global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *__restrict__ perm_f,
+                                                     unsigned long long *__restrict__ ghist) {
+    __shared__ unsigned int sh_hist[NBINS];
+    __shared__ ColMeta cm[EPI_COLS];
+    const bool use_hist = A.E.cols && A.E.do_lr;
+    if (use_hist)
+        for (int i = threadIdx.x; i < NBINS; i += 256) sh_hist[i] = 0;
+    const bool square = A.nf == A.nt;
+    if (threadIdx.x < EPI_COLS) {
+        const int b_loc = blockIdx.y * EPI_COLS + threadIdx.x;
+        if (b_loc < A.nt) {
+            ColMeta m;
+            m.sb = A.idx_t[b_loc];
+            m.mb = A.slot_meta[m.sb];
+            m.rb0 = A.lrow_t[b_loc];
+            m.pad = 0;
+            m.rb = A.r[m.sb];
+            m.rq = square ? A.r[A.idx_f[b_loc]] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                m.pb[j] = A.slot_pfix[(int64_t)m.sb * 5 + j];
+                m.pYd[j] = (double)m.pb[j] * A.scale;
+            }
+            if (A.E.cols) m.ci = A.E.cols[b_loc];
+            cm[threadIdx.x] = m;
+        }
+    }
+    __syncthreads();
+
+    // lanes walk the from-side SNPs in an order that groups equal slot counts, so that a wave runs the same cells
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int wave = threadIdx.x >> 6;
+    const bool a_ok = t < A.nf;
+    const int a_loc = perm_f[a_ok ? t : A.nf - 1];
+    RowSide R;
+    R.sa = A.idx_f[a_loc];
+    R.ma = A.slot_meta[R.sa];
+    R.na = a_ok ? (int)(R.ma & 7) : 0;
+    R.ra0 = A.lrow_f[a_loc];
+    R.ra = A.r[R.sa];
+    R.rta = (square && a_ok) ? A.r[A.idx_t[a_loc]] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        R.pa[i] = A.slot_pfix[(int64_t)R.sa * 5 + i];
+        R.pXd[i] = (double)R.pa[i] * A.scale;
+    }
+    const int na_max = (__ballot(R.na > 2) != 0ull) ? 4 : ((__ballot(R.na > 1) != 0ull) ? 2 : 1);
+
+    const int c_first = wave * (EPI_COLS / 4);
+    const int b_base = blockIdx.y * EPI_COLS;
+    int n_it = A.nt - (b_base + c_first);
+    n_it = n_it > EPI_COLS / 4 ? EPI_COLS / 4 : n_it;
+    for (int it = 0; it < n_it; ++it) {
+        const int cl = c_first + it;
+        const int b_loc = b_base + cl;
+        if (!a_ok) continue;
+        if (A.E.lower_only && a_loc <= b_loc) continue;
+        const ColMeta &M = cm[cl];
+        const int nb = __builtin_amdgcn_readfirstlane((int)(M.mb & 7));
+        double mi;
+        if (na_max == 1) {
+            if (nb <= 1) mi = pair_mi<1, 1>(A, R, M, a_loc, b_loc, square);
+            else if (nb == 2) mi = pair_mi<1, 2>(A, R, M, a_loc, b_loc, square);
+            else mi = pair_mi<1, 4>(A, R, M, a_loc, b_loc, square);
+        } else if (na_max == 2) {
+            if (nb <= 1) mi = pair_mi<2, 1>(A, R, M, a_loc, b_loc, square);
+            else if (nb == 2) mi = pair_mi<2, 2>(A, R, M, a_loc, b_loc, square);
+            else mi = pair_mi<2, 4>(A, R, M, a_loc, b_loc, square);
+        } else {
+            if (nb <= 1) mi = pair_mi<4, 1>(A, R, M, a_loc, b_loc, square);
+            else if (nb == 2) mi = pair_mi<4, 2>(A, R, M, a_loc, b_loc, square);
+            else mi = pair_mi<4, 4>(A, R, M, a_loc, b_loc, square);
+        }
+        emit_pair(A.E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, sh_hist);
+    }
+    if (use_hist) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < NBINS; i += 256)
+            if (sh_hist[i]) atomicAdd(&ghist[i], (unsigned long long)sh_hist[i]);
+    }
+}
+
+// the same emission for an MI block produced elsewhere (LDW_ENGINE_HIST)
+__global__ __launch_bounds__(256) void k_post_mi(EmitArgs E, const int32_t *__restrict__ idx_f,
+                                                 const int32_t *__restrict__ idx_t, int nt,
+                                                 unsigned long long *__restrict__ ghist) {
+    __shared__ unsigned int sh_hist[NBINS];
+    for (int i = threadIdx.x; i < NBINS; i += 256) sh_hist[i] = 0;
+    __syncthreads();
+    const int a_loc = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int wave = threadIdx.x >> 6;
+    const int b_first = blockIdx.y * EPI_COLS + wave * (EPI_COLS / 4);
+    if (a_loc < E.nf) {
+        const int sa = idx_f[a_loc];
+        for (int it = 0; it < EPI_COLS / 4; ++it) {
+            const int b_loc = b_first + it;
+            if (b_loc >= nt) break;
+            if (E.lower_only && a_loc <= b_loc) continue;
+            const ColInfo c = E.cols[b_loc];
+            emit_pair(E, c, a_loc, b_loc, sa, idx_t[b_loc], E.MI[(int64_t)a_loc + (int64_t)b_loc * E.nf], sh_hist);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NBINS; i += 256)
+        if (sh_hist[i]) atomicAdd(&ghist[i], (unsigned long long)sh_hist[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -188,138 +429,8 @@ __global__ void k_slot_counts(const int32_t *counts, const uint32_t *slot_meta, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// selection
+// long-range selection
 // ------------------------------------------------------------------------------------------------
-struct SelArgs {
-    const double *MI;
-    const int32_t *idx_f, *idx_t;
-    int nf, nt;
-    const int32_t *POS;
-    double g, sr_dist;
-    int lower_only;
-};
-
-// which segment a pair belongs to: 0 = upper (a<b, off-diagonal blocks only), 1 = lower (a>b), -1 = not a pair
-__device__ __forceinline__ int pair_seg(int a_loc, int b_loc, int lower_only) {
-    if (a_loc == b_loc) return -1;
-    if (a_loc > b_loc) return 1;
-    return lower_only ? -1 : 0;
-}
-
-// per-column short-range counts: colcnt[seg*nt + b]
-__global__ __launch_bounds__(256) void k_sr_count(SelArgs S, int32_t *__restrict__ colcnt) {
-    const int lane = threadIdx.x & 63;
-    const int b_loc = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b_loc >= S.nt) return;
-    const double pos1 = (double)S.POS[S.idx_t[b_loc]];
-    int cu = 0, cl = 0;
-    for (int a0 = 0; a0 < S.nf; a0 += 64) {
-        const int a_loc = a0 + lane;
-        if (a_loc < S.nf) {
-            const int seg = pair_seg(a_loc, b_loc, S.lower_only);
-            if (seg >= 0) {
-                const bool sr = circ_len(pos1, (double)S.POS[S.idx_f[a_loc]], S.g) <= S.sr_dist;
-                cu += (sr && seg == 0);
-                cl += (sr && seg == 1);
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        cu += __shfl_xor(cu, off);
-        cl += __shfl_xor(cl, off);
-    }
-    if (lane == 0) {
-        colcnt[b_loc] = cu;
-        colcnt[S.nt + b_loc] = cl;
-    }
-}
-
-// exclusive scan of 2*nt column counts (single workgroup); ctr[0] += total (running sr rows), ctr[3] = block total
-__global__ __launch_bounds__(1024) void k_scan_cols(const int32_t *__restrict__ colcnt, int n, int64_t *__restrict__ offs,
-                                                    int64_t *__restrict__ blk_total) {
-    __shared__ int64_t part[1024];
-    const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int lo = t * per, hi = min(n, lo + per);
-    int64_t s = 0;
-    for (int i = lo; i < hi; ++i) s += colcnt[i];
-    part[t] = s;
-    __syncthreads();
-    if (t == 0) {
-        int64_t run = 0;
-        for (int i = 0; i < 1024; ++i) {
-            const int64_t v = part[i];
-            part[i] = run;
-            run += v;
-        }
-        *blk_total = run;
-    }
-    __syncthreads();
-    int64_t run = part[t];
-    for (int i = lo; i < hi; ++i) {
-        offs[i] = run;
-        run += colcnt[i];
-    }
-}
-
-// ordered scatter of the short-range links of one block
-__global__ __launch_bounds__(256) void k_sr_scatter(SelArgs S, const int64_t *__restrict__ offs, int64_t base,
-                                                    int32_t *__restrict__ out_a, int32_t *__restrict__ out_b,
-                                                    double *__restrict__ out_mi) {
-    const int lane = threadIdx.x & 63;
-    const int b_loc = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b_loc >= S.nt) return;
-    const int sb = S.idx_t[b_loc];
-    const double pos1 = (double)S.POS[sb];
-    int64_t wu = base + offs[b_loc], wl = base + offs[S.nt + b_loc];
-    for (int a0 = 0; a0 < S.nf; a0 += 64) {
-        const int a_loc = a0 + lane;
-        int seg = -1;
-        bool sr = false;
-        int sa = 0;
-        if (a_loc < S.nf) {
-            seg = pair_seg(a_loc, b_loc, S.lower_only);
-            if (seg >= 0) {
-                sa = S.idx_f[a_loc];
-                sr = circ_len(pos1, (double)S.POS[sa], S.g) <= S.sr_dist;
-            }
-        }
-        const unsigned long long mu = __ballot(sr && seg == 0), ml = __ballot(sr && seg == 1);
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        if (sr) {
-            const int64_t dst = seg == 0 ? wu + __popcll(mu & lt) : wl + __popcll(ml & lt);
-            out_a[dst] = sa;
-            out_b[dst] = sb;
-            out_mi[dst] = S.MI[(int64_t)a_loc + (int64_t)b_loc * S.nf];
-        }
-        wu += __popcll(mu);
-        wl += __popcll(ml);
-    }
-}
-
-// level-1 histogram of the long-range MI values of one block (16 columns per workgroup)
-__global__ __launch_bounds__(256) void k_lr_hist(SelArgs S, unsigned long long *__restrict__ hist) {
-    __shared__ unsigned int sh[NBINS];
-    for (int i = threadIdx.x; i < NBINS; i += 256) sh[i] = 0;
-    __syncthreads();
-    const int b0 = blockIdx.x * 16;
-    for (int bb = 0; bb < 16; ++bb) {
-        const int b_loc = b0 + bb;
-        if (b_loc >= S.nt) break;
-        const double pos1 = (double)S.POS[S.idx_t[b_loc]];
-        const double *col = S.MI + (int64_t)b_loc * S.nf;
-        for (int a_loc = threadIdx.x; a_loc < S.nf; a_loc += 256) {
-            if (pair_seg(a_loc, b_loc, S.lower_only) < 0) continue;
-            if (circ_len(pos1, (double)S.POS[S.idx_f[a_loc]], S.g) <= S.sr_dist) continue;
-            atomicAdd(&sh[mi_bucket(col[a_loc])], 1u);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < NBINS; i += 256)
-        if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
-}
-
 struct PickOut {
     long long n;        // number of long-range pairs in the block
     long long lo, hi;   // 1-based ranks of the two order statistics of quantile type 7
@@ -334,55 +445,83 @@ struct PickOut {
 };
 
 // prob and quantile ranks of R/computePairwiseMI.R:352-354 (stats::quantile type 7), then the bucket
-// holding rank lo
-__global__ void k_pick_bucket(const unsigned long long *__restrict__ hist, double lr_retain, double lr_approx,
-                              PickOut *__restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    long long n = 0;
-    for (int i = 0; i < NBINS; ++i) n += (long long)hist[i];
-    PickOut o;
-    memset(&o, 0, sizeof(o));
-    o.n = n;
-    o.B = NBINS;
-    o.disc_thresh = nan("");
-    if (n > 0) {
-        const double dn = (double)n;
-        double prob = 1.0 - ((lr_retain * (dn / lr_approx)) / dn);
-        if (!(prob > 0.0)) prob = 0.0;
-        o.prob = prob;
-        o.index = 1.0 + (dn - 1.0) * prob;
-        o.lo = (long long)floor(o.index);
-        o.hi = (long long)ceil(o.index);
-        long long cum = 0;
-        for (int i = 0; i < NBINS; ++i) {
-            const long long h = (long long)hist[i];
-            if (cum + h >= o.lo) {
-                o.B = i;
-                o.n_below = cum;
-                break;
-            }
-            cum += h;
-        }
+// holding rank lo.  One workgroup: chunked prefix sum over the NBINS counters.
+__global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *__restrict__ hist, double lr_retain,
+                                                     double lr_approx, PickOut *__restrict__ out) {
+    __shared__ long long part[256];
+    __shared__ long long s_lo;
+    constexpr int PER = NBINS / 256;
+    const int t = threadIdx.x;
+    long long loc[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        loc[k] = (long long)hist[t * PER + k];
+        sum += loc[k];
     }
-    *out = o;
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        long long run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const long long v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        PickOut o;
+        memset(&o, 0, sizeof(o));
+        o.n = run;
+        o.B = NBINS;
+        o.disc_thresh = nan("");
+        if (run > 0) {
+            const double dn = (double)run;
+            double prob = 1.0 - ((lr_retain * (dn / lr_approx)) / dn);
+            if (!(prob > 0.0)) prob = 0.0;
+            o.prob = prob;
+            o.index = 1.0 + (dn - 1.0) * prob;
+            o.lo = (long long)floor(o.index);
+            o.hi = (long long)ceil(o.index);
+        }
+        *out = o;
+        s_lo = o.lo;
+    }
+    __syncthreads();
+    const long long lo = s_lo;
+    if (lo <= 0) return;
+    long long cum = part[t];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (cum < lo && cum + loc[k] >= lo) {  // exactly one (thread, k) satisfies this
+            out->B = t * PER + k;
+            out->n_below = cum;
+        }
+        cum += loc[k];
+    }
 }
 
+struct GatherArgs {
+    const double *MI;
+    const ColInfo *cols;
+    int nf, nt, lower_only;
+};
+
 // gather every long-range pair whose bucket is >= B: (MI key, order key)
-__global__ __launch_bounds__(256) void k_lr_gather(SelArgs S, PickOut *__restrict__ pick, uint64_t *__restrict__ ckey,
+__global__ __launch_bounds__(256) void k_lr_gather(GatherArgs S, PickOut *__restrict__ pick, uint64_t *__restrict__ ckey,
                                                    uint64_t *__restrict__ cval) {
     const int B = pick->B;
     if (B >= NBINS) return;
+    const double lo_val = (double)B * (MI_HIST_MAX / (double)NBINS);
     const int b0 = blockIdx.x * 16;
     for (int bb = 0; bb < 16; ++bb) {
         const int b_loc = b0 + bb;
         if (b_loc >= S.nt) break;
-        const double pos1 = (double)S.POS[S.idx_t[b_loc]];
+        const ColInfo c = S.cols[b_loc];
         const double *col = S.MI + (int64_t)b_loc * S.nf;
         for (int a_loc = threadIdx.x; a_loc < S.nf; a_loc += 256) {
             const int seg = pair_seg(a_loc, b_loc, S.lower_only);
-            if (seg < 0) continue;
-            if (circ_len(pos1, (double)S.POS[S.idx_f[a_loc]], S.g) <= S.sr_dist) continue;
+            if (seg < 0) continue;  // also skips the never-written part of a diagonal block
             const double mi = col[a_loc];
+            if (B > 0 && mi < lo_val - 1e-9) continue;  // cheap reject; the bucket test below decides
+            if (col_is_sr(c, a_loc)) continue;
             if (mi_bucket(mi) < B) continue;
             const unsigned long long p = atomicAdd(&pick->n_cand, 1ull);
             ckey[p] = f64_key(mi);
@@ -409,7 +548,6 @@ __global__ void k_lr_thresh(const uint64_t *__restrict__ skey, PickOut *__restri
         const double h = o.index - (double)o.lo;
         qs = (1.0 - h) * qs + h * xhi;
     }
-    // first candidate with MI >= qs (binary search on the order-preserving keys)
     const uint64_t kq = f64_key(qs);
     long long lo = 0, hi = m;
     while (lo < hi) {
@@ -466,7 +604,6 @@ namespace {
 struct BlockGeom {
     int64_t nf = 0, nt = 0;
     int RFpad = 0, RTpad = 0;
-    bool diag = false;
 };
 
 int upload_i32(ldw_ctx *c, ldw::DevBuf &buf, const std::vector<int32_t> &v) {
@@ -494,9 +631,94 @@ int build_side(ldw_ctx *c, const int32_t *idx, int64_t n, std::vector<int32_t> &
     return LDW_OK;
 }
 
-// stage index lists, run GEMM + epilogue for one block; MI lands in ctx->MIblk (column-major nf x nt)
+// Short-range intervals of every to-side SNP (host, O(nt log nf)); returns the block's short-range row count.
+// Requires the from-side list to be ascending in POS (true for contiguous blocks and for the order-preserving
+// subsets of SR-only mode).  Every interval boundary is verified with the exact predicate of the reference
+// (circ_len <= sr_dist); a column that fails the check is rebuilt by scanning.
+int build_cols(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt, bool diag, double sr_dist,
+               std::vector<ColInfo> &cols, int64_t &n_sr_blk) {
+    const double g = c->g;
+    std::vector<double> pf((size_t)nf);
+    for (int64_t a = 0; a < nf; ++a) {
+        pf[a] = (double)c->h_POS[from_idx[a]];
+        LDW_REQUIRE(a == 0 || pf[a] >= pf[a - 1], LDW_ERR_ARG, "from-side SNP list must be ascending in POS (position %lld)", (long long)a);
+    }
+    cols.resize((size_t)nt);
+    int64_t total_u = 0, total_l = 0;
+    std::vector<int32_t> cu((size_t)nt), cl((size_t)nt);
+    for (int64_t b = 0; b < nt; ++b) {
+        const double p1 = (double)c->h_POS[to_idx[b]];
+        auto P = [&](int64_t a) { return circ_len(p1, pf[a], g) <= sr_dist; };
+        ColInfo ci;
+        memset(&ci, 0, sizeof(ci));
+        // candidate intervals from the three position windows
+        int64_t iv[3][2];
+        iv[0][0] = 0;                                                                                // wrap-low: x <= p1 + sr - g
+        iv[0][1] = std::upper_bound(pf.begin(), pf.end(), p1 + sr_dist - g) - pf.begin();
+        iv[1][0] = std::lower_bound(pf.begin(), pf.end(), p1 - sr_dist) - pf.begin();               // centre
+        iv[1][1] = std::upper_bound(pf.begin(), pf.end(), p1 + sr_dist) - pf.begin();
+        iv[2][0] = std::lower_bound(pf.begin(), pf.end(), p1 - sr_dist + g) - pf.begin();           // wrap-high
+        iv[2][1] = nf;
+        // merge overlapping / touching intervals, keep ascending order
+        int n = 0;
+        int64_t m[3][2];
+        for (int k = 0; k < 3; ++k) {
+            if (iv[k][1] <= iv[k][0]) continue;
+            if (n > 0 && iv[k][0] <= m[n - 1][1]) m[n - 1][1] = std::max(m[n - 1][1], iv[k][1]);
+            else { m[n][0] = iv[k][0]; m[n][1] = iv[k][1]; ++n; }
+        }
+        bool ok = true;
+        for (int k = 0; k < n && ok; ++k) {
+            ok = P(m[k][0]) && P(m[k][1] - 1);
+            if (ok && m[k][0] > 0) ok = !P(m[k][0] - 1);
+            if (ok && m[k][1] < nf) ok = !P(m[k][1]);
+        }
+        if (n == 0 && nf > 0) ok = !P(0) && !P(nf - 1);
+        if (!ok) {  // rebuild from the exact predicate
+            n = 0;
+            int64_t a = 0;
+            while (a < nf) {
+                if (!P(a)) { ++a; continue; }
+                int64_t e = a;
+                while (e < nf && P(e)) ++e;
+                LDW_REQUIRE(n < 3, LDW_ERR_ARG, "short-range partners of SNP %d form more than three index runs", to_idx[b]);
+                m[n][0] = a; m[n][1] = e; ++n;
+                a = e;
+            }
+        }
+        for (int k = 0; k < 3; ++k) {
+            ci.s[k] = k < n ? (int32_t)m[k][0] : 0;
+            ci.e[k] = k < n ? (int32_t)m[k][1] : 0;
+        }
+        cu[b] = diag ? 0 : col_count(ci, 0, (int)std::min<int64_t>(b, nf));
+        cl[b] = col_count(ci, (int)std::min<int64_t>(b + 1, nf), (int)nf);
+        total_u += cu[b];
+        total_l += cl[b];
+        cols[b] = ci;
+    }
+    // row order of the block: all upper-segment columns, then all lower-segment columns (R/computePairwiseMI.R:306-310)
+    int64_t ru = 0, rl = total_u;
+    for (int64_t b = 0; b < nt; ++b) {
+        cols[b].off_u = ru;
+        cols[b].off_l = rl;
+        ru += cu[b];
+        rl += cl[b];
+    }
+    n_sr_blk = total_u + total_l;
+    return LDW_OK;
+}
+
+bool same_list(const int32_t *a, int64_t na, const int32_t *b, int64_t nb) {
+    if (na != nb) return false;
+    for (int64_t i = 0; i < na; ++i)
+        if (a[i] != b[i]) return false;
+    return true;
+}
+
+// Stage the index lists and produce the dense MI block in ctx->MIblk; with E.cols set, the short-range
+// scatter and the long-range histogram ride along (fused in the epilogue for the MFMA engine).
 int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt, int quirk,
-                 bool lower_only, BlockGeom &geo) {
+                 EmitArgs E, BlockGeom &geo) {
     if (int rc = ensure_rows(c)) return rc;
     LDW_REQUIRE(nf > 0 && nt > 0, LDW_ERR_ARG, "empty block (nf=%lld nt=%lld)", (long long)nf, (long long)nt);
     LDW_REQUIRE(nf <= 1000000 && nt <= 1000000, LDW_ERR_ARG, "block side too long");
@@ -504,8 +726,14 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     if (int rc = upload_i32(c, c->idx_f, vf)) return rc;
     if (int rc = upload_i32(c, c->idx_t, vt)) return rc;
     if (int rc = c->MIblk.reserve((size_t)nf * nt * 8)) return rc;
+    if (int rc = c->hist.reserve((size_t)NBINS * 8)) return rc;
     geo.nf = nf;
     geo.nt = nt;
+    E.MI = c->MIblk.as<double>();
+    E.nf = (int)nf;
+    dim3 egrid((unsigned)((nf + 63) / 64), (unsigned)((nt + EPI_COLS - 1) / EPI_COLS));
+    LDW_REQUIRE(egrid.y <= 65535u, LDW_ERR_ARG, "nt too large for the epilogue grid");
+    unsigned long long *ghist = c->hist.as<unsigned long long>();
     if (c->engine == LDW_ENGINE_HIST) {
         for (int64_t k = 0; k < nf; ++k)
             LDW_REQUIRE(from_idx[k] >= 0 && from_idx[k] < c->L, LDW_ERR_ARG, "SNP index %d out of range", from_idx[k]);
@@ -515,8 +743,13 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
         LDW_HIP(hipEventRecord(c->ev[0], c->stream));
         LDW_HIP(hipEventRecord(c->ev[1], c->stream));
         if (int rc = launch_hist(c, c->idx_f.as<int32_t>(), (int)nf, c->idx_t.as<int32_t>(), (int)nt,
-                                 c->pfix_state.as<int64_t>(), quirk, lower_only ? 1 : 0, c->MIblk.as<double>()))
+                                 c->pfix_state.as<int64_t>(), quirk, E.lower_only, c->MIblk.as<double>()))
             return rc;
+        if (E.cols) {
+            hipLaunchKernelGGL(k_post_mi, egrid, dim3(256), 0, c->stream, E, c->idx_f.as<int32_t>(), c->idx_t.as<int32_t>(),
+                               (int)nt, ghist);
+            LDW_HIP(hipGetLastError());
+        }
         LDW_HIP(hipEventRecord(c->ev[2], c->stream));
         return LDW_OK;
     }
@@ -530,6 +763,14 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     if (int rc = upload_i32(c, c->rowlist_t, rl_t)) return rc;
     if (int rc = upload_i32(c, c->lrow_f, lr_f)) return rc;
     if (int rc = upload_i32(c, c->lrow_t, lr_t)) return rc;
+    {   // lane order of the epilogue: from-side SNPs grouped by their number of indicator rows (1, 2, 3, 4, 0)
+        std::vector<int32_t> perm((size_t)nf);
+        int64_t w = 0;
+        for (int want : {1, 2, 3, 4, 0})
+            for (int64_t k = 0; k < nf; ++k)
+                if (c->h_row0[from_idx[k] + 1] - c->h_row0[from_idx[k]] == want) perm[w++] = (int32_t)k;
+        if (int rc = upload_i32(c, c->perm_f, perm)) return rc;
+    }
     // pageable H2D copies above are complete only after a sync
     LDW_HIP(hipStreamSynchronize(c->stream));
     if (int rc = c->G.reserve((size_t)RFpad * RTpad * 8)) return rc;
@@ -537,7 +778,7 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     LDW_HIP(hipEventRecord(c->ev[0], c->stream));
     if (int rc = launch_gemm(c, c->rowlist_t.as<int32_t>(), RTpad, c->rowlist_f.as<int32_t>(), RFpad,
                              c->G.as<int64_t>(), c->nlimbs, c->digits.as<int8_t>(), c->M.as<uint8_t>(), c->Npad,
-                             lower_only ? 1 : 0, 0))
+                             E.lower_only, 0))
         return rc;
     LDW_HIP(hipEventRecord(c->ev[1], c->stream));
     EpiArgs A;
@@ -555,21 +796,11 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     A.neff = c->neff;
     A.scale = std::ldexp(1.0, -c->frac_bits);
     A.quirk = quirk;
-    A.lower_only = lower_only ? 1 : 0;
-    A.MI = c->MIblk.as<double>();
-    dim3 grid((unsigned)((nf + 63) / 64), (unsigned)((nt + 3) / 4));
-    LDW_REQUIRE(grid.y <= 65535u, LDW_ERR_ARG, "nt too large for the epilogue grid");
-    hipLaunchKernelGGL(k_mi_epilogue, grid, dim3(256), 0, c->stream, A);
+    A.E = E;
+    hipLaunchKernelGGL(k_mi_epilogue, egrid, dim3(256), 0, c->stream, A, c->perm_f.as<int32_t>(), ghist);
     LDW_HIP(hipGetLastError());
     LDW_HIP(hipEventRecord(c->ev[2], c->stream));
     return LDW_OK;
-}
-
-bool same_list(const int32_t *a, int64_t na, const int32_t *b, int64_t nb) {
-    if (na != nb) return false;
-    for (int64_t i = 0; i < na; ++i)
-        if (a[i] != b[i]) return false;
-    return true;
 }
 
 int ensure_links_capacity(ldw_ctx *c, int64_t sr_rows, int64_t lr_rows) {
@@ -585,78 +816,82 @@ int ensure_links_capacity(ldw_ctx *c, int64_t sr_rows, int64_t lr_rows) {
 // layout of ctx->small during link selection
 struct SmallLayout {
     int64_t *lr_count;   // running number of kept long-range rows (device side)
-    int64_t *blk_sr;     // short-range rows of the current block
     ldw::PickOut *pick;
-    int64_t *stats_i;    // [nblocks_cap][3]
-    double *stats_d;     // [nblocks_cap]
+    int64_t *stats_i;    // [capacity][3]
+    double *stats_d;     // [capacity]
 };
 
-}  // namespace
+void links_layout(ldw_ctx *c, SmallLayout &sl) {
+    char *base = c->small.as<char>();
+    sl.lr_count = reinterpret_cast<int64_t *>(base);
+    sl.pick = reinterpret_cast<ldw::PickOut *>(base + 64);
+    sl.stats_i = reinterpret_cast<int64_t *>(base + 64 + ((sizeof(ldw::PickOut) + 63) / 64) * 64);
+    sl.stats_d = reinterpret_cast<double *>(sl.stats_i + c->blk_capacity * 3);
+}
 
-namespace ldw {
-
-// one block, links appended.  n_lr (host) is an upper bound while running; the exact count lives in lr_count.
-static int block_links(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt,
-                       const ldw_mi_params *p, int64_t blk_no, int64_t *d_lr_count, int64_t *d_stats_i,
-                       double *d_stats_d, ldw::PickOut *d_pick, int64_t *d_blk_sr) {
+// one block, links appended.  ctx->n_lr is an upper bound while running; the exact count lives in *lr_count.
+int block_links(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt,
+                const ldw_mi_params *p, int64_t blk_no, const SmallLayout &sl) {
+    for (int64_t k = 0; k < nf; ++k)
+        LDW_REQUIRE(from_idx[k] >= 0 && from_idx[k] < c->L, LDW_ERR_ARG, "SNP index %d out of range", from_idx[k]);
+    for (int64_t k = 0; k < nt; ++k)
+        LDW_REQUIRE(to_idx[k] >= 0 && to_idx[k] < c->L, LDW_ERR_ARG, "SNP index %d out of range", to_idx[k]);
     const bool diag = same_list(from_idx, nf, to_idx, nt);
-    BlockGeom geo;
-    if (int rc = run_block_mi(c, from_idx, nf, to_idx, nt, p->quirk_mode, diag, geo)) return rc;
-    SelArgs S;
-    S.MI = c->MIblk.as<double>();
-    S.idx_f = c->idx_f.as<int32_t>();
-    S.idx_t = c->idx_t.as<int32_t>();
-    S.nf = (int)nf;
-    S.nt = (int)nt;
-    S.POS = c->POS.as<int32_t>();
-    S.g = c->g;
-    S.sr_dist = p->sr_dist;
-    S.lower_only = diag ? 1 : 0;
-
-    // ---- counts / histogram (no host involvement) ----
-    if (int rc = c->colcnt.reserve((size_t)(2 * nt + 4) * 4 + (size_t)(2 * nt) * 8)) return rc;
-    int32_t *d_colcnt = c->colcnt.as<int32_t>();
-    int64_t *d_offs = reinterpret_cast<int64_t *>(d_colcnt + 2 * ((nt + 1) / 2 * 2));
-    hipLaunchKernelGGL(k_sr_count, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, c->stream, S, d_colcnt);
-    LDW_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_scan_cols, dim3(1), dim3(1024), 0, c->stream, d_colcnt, (int)(2 * nt), d_offs, d_blk_sr);
-    LDW_HIP(hipGetLastError());
     const bool do_lr = !p->sr_only;
+    // ---- host: short-range intervals, row offsets, capacity (no device round trip) ----
+    std::vector<ColInfo> cols;
+    int64_t n_sr_blk = 0;
+    if (int rc = build_cols(c, from_idx, nf, to_idx, nt, diag, p->sr_dist, cols, n_sr_blk)) return rc;
+    if (int rc = c->colcnt.reserve(cols.size() * sizeof(ColInfo))) return rc;
+    LDW_HIP(hipMemcpyAsync(c->colcnt.p, cols.data(), cols.size() * sizeof(ColInfo), hipMemcpyHostToDevice, c->stream));
+    const int64_t sr_add = p->keep_sr ? n_sr_blk : 0;
+    if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr)) return rc;
+    if (int rc = c->hist.reserve((size_t)NBINS * 8)) return rc;
+    LDW_HIP(hipMemsetAsync(c->hist.p, 0, (size_t)NBINS * 8, c->stream));
+
+    EmitArgs E;
+    memset(&E, 0, sizeof(E));
+    E.cols = reinterpret_cast<const ColInfo *>(c->colcnt.p);
+    E.lower_only = diag ? 1 : 0;
+    E.keep_sr = p->keep_sr ? 1 : 0;
+    E.do_lr = do_lr ? 1 : 0;
+    E.sr_base = c->n_sr;
+    E.sr_a = c->sr_a.as<int32_t>();
+    E.sr_b = c->sr_b.as<int32_t>();
+    E.sr_mi = c->sr_mi.as<double>();
+    BlockGeom geo;
+    if (int rc = run_block_mi(c, from_idx, nf, to_idx, nt, p->quirk_mode, E, geo)) return rc;
+    c->n_sr += sr_add;
+
+    int64_t m = 0;
     if (do_lr) {
-        if (int rc = c->hist.reserve((size_t)NBINS * 8)) return rc;
-        LDW_HIP(hipMemsetAsync(c->hist.p, 0, (size_t)NBINS * 8, c->stream));
-        hipLaunchKernelGGL(k_lr_hist, dim3((unsigned)((nt + 15) / 16)), dim3(256), 0, c->stream, S,
-                           c->hist.as<unsigned long long>());
-        LDW_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(64), 0, c->stream, c->hist.as<unsigned long long>(),
-                           p->lr_retain_links, p->lr_links_approx, d_pick);
+        hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, c->stream, c->hist.as<unsigned long long>(),
+                           p->lr_retain_links, p->lr_links_approx, sl.pick);
         LDW_HIP(hipGetLastError());
         // candidate capacity: every pair of the block in the worst case (all MI in one bucket)
         const size_t cap = (size_t)nf * nt;
         if (int rc = c->cand_key.reserve(cap * 8)) return rc;
         if (int rc = c->cand_val.reserve(cap * 8)) return rc;
-        hipLaunchKernelGGL(k_lr_gather, dim3((unsigned)((nt + 15) / 16)), dim3(256), 0, c->stream, S, d_pick,
+        GatherArgs S;
+        S.MI = c->MIblk.as<double>();
+        S.cols = E.cols;
+        S.nf = (int)nf;
+        S.nt = (int)nt;
+        S.lower_only = E.lower_only;
+        hipLaunchKernelGGL(k_lr_gather, dim3((unsigned)((nt + 15) / 16)), dim3(256), 0, c->stream, S, sl.pick,
                            c->cand_key.as<uint64_t>(), c->cand_val.as<uint64_t>());
         LDW_HIP(hipGetLastError());
+        // ---- the one host round trip of the block: the candidate count sizes the sorts ----
+        ldw::PickOut h_pick;
+        LDW_HIP(hipMemcpyAsync(&h_pick, sl.pick, sizeof(h_pick), hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+        m = (int64_t)h_pick.n_cand;
     } else {
-        LDW_HIP(hipMemsetAsync(d_pick, 0, sizeof(ldw::PickOut), c->stream));
-    }
-    // ---- the one host round trip of the block: sizes ----
-    ldw::PickOut h_pick;
-    int64_t h_blk_sr = 0;
-    LDW_HIP(hipMemcpyAsync(&h_pick, d_pick, sizeof(h_pick), hipMemcpyDeviceToHost, c->stream));
-    LDW_HIP(hipMemcpyAsync(&h_blk_sr, d_blk_sr, 8, hipMemcpyDeviceToHost, c->stream));
-    LDW_HIP(hipStreamSynchronize(c->stream));
-    const int64_t m = (int64_t)h_pick.n_cand;
-    const int64_t sr_add = p->keep_sr ? h_blk_sr : 0;
-    if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr + m)) return rc;
-    if (p->keep_sr && h_blk_sr > 0) {
-        hipLaunchKernelGGL(k_sr_scatter, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, c->stream, S, d_offs, c->n_sr,
-                           c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), c->sr_mi.as<double>());
-        LDW_HIP(hipGetLastError());
-        c->n_sr += h_blk_sr;
+        LDW_HIP(hipMemsetAsync(sl.pick, 0, sizeof(ldw::PickOut), c->stream));
     }
     if (do_lr && m > 0) {
+        LDW_REQUIRE(m < 2147483647LL, LDW_ERR_SIZE, "too many quantile candidates (%lld)", (long long)m);
+        if (int rc = ensure_links_capacity(c, c->n_sr, c->n_lr + m)) return rc;
         if (int rc = c->cand_key2.reserve((size_t)m * 8)) return rc;
         if (int rc = c->cand_val2.reserve((size_t)m * 8)) return rc;
         size_t tmp_bytes = 0;
@@ -664,31 +899,30 @@ static int block_links(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const in
                                                    c->cand_key2.as<uint64_t>(), c->cand_val.as<uint64_t>(),
                                                    c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
         if (int rc = c->scratch.reserve(tmp_bytes)) return rc;
-        LDW_REQUIRE(m < 2147483647LL, LDW_ERR_SIZE, "too many quantile candidates (%lld)", (long long)m);
         LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tmp_bytes, c->cand_key.as<uint64_t>(),
                                                    c->cand_key2.as<uint64_t>(), c->cand_val.as<uint64_t>(),
                                                    c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
-        hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, c->cand_key2.as<uint64_t>(), d_pick);
+        hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, c->cand_key2.as<uint64_t>(), sl.pick);
         LDW_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_lr_mark, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), d_pick,
+                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), sl.pick,
                            c->cand_key.as<uint64_t>(), c->cand_val.as<uint64_t>(), (long long)m);
         LDW_HIP(hipGetLastError());
         LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tmp_bytes, c->cand_key.as<uint64_t>(),
                                                    c->cand_key2.as<uint64_t>(), c->cand_val.as<uint64_t>(),
                                                    c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
         hipLaunchKernelGGL(k_lr_append, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), d_pick, c->idx_f.as<int32_t>(),
-                           c->idx_t.as<int32_t>(), (int)nf, d_lr_count, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(),
+                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), sl.pick, c->idx_f.as<int32_t>(),
+                           c->idx_t.as<int32_t>(), (int)nf, sl.lr_count, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(),
                            c->lr_mi.as<double>());
         LDW_HIP(hipGetLastError());
-        c->n_lr += m;  // upper bound; exact value is *d_lr_count
+        c->n_lr += m;  // upper bound; the exact value is *lr_count
     } else if (do_lr) {
-        hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, c->cand_key.as<uint64_t>(), d_pick);
+        hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, c->cand_key.as<uint64_t>(), sl.pick);
         LDW_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_block_done, dim3(1), dim3(64), 0, c->stream, d_pick, d_lr_count, h_blk_sr,
-                       d_stats_i + blk_no * 3, d_stats_d + blk_no);
+    hipLaunchKernelGGL(k_block_done, dim3(1), dim3(64), 0, c->stream, sl.pick, sl.lr_count, n_sr_blk,
+                       sl.stats_i + blk_no * 3, sl.stats_d + blk_no);
     LDW_HIP(hipGetLastError());
     LDW_HIP(hipEventRecord(c->ev[3], c->stream));
     LDW_HIP(hipEventSynchronize(c->ev[3]));
@@ -703,7 +937,7 @@ static int block_links(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const in
     return LDW_OK;
 }
 
-}  // namespace ldw
+}  // namespace
 
 extern "C" {
 
@@ -713,7 +947,9 @@ int ldw_mi_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     LDW_REQUIRE(from_idx && to_idx && MI_out, LDW_ERR_ARG, "ldw_mi_block: null argument");
     LDW_REQUIRE(quirk_mode == LDW_QUIRK_REFERENCE || quirk_mode == LDW_QUIRK_INTENDED, LDW_ERR_ARG, "bad quirk mode");
     BlockGeom geo;
-    if (int rc = run_block_mi(c, from_idx, nf, to_idx, nt, quirk_mode, false, geo)) return rc;
+    EmitArgs E;
+    memset(&E, 0, sizeof(E));
+    if (int rc = run_block_mi(c, from_idx, nf, to_idx, nt, quirk_mode, E, geo)) return rc;
     LDW_HIP(hipMemcpyAsync(MI_out, c->MIblk.p, (size_t)nf * nt * 8, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                            c->stream));
     LDW_HIP(hipStreamSynchronize(c->stream));
@@ -780,15 +1016,6 @@ int ldw_joint_tables(ldw_ctx *c, const int32_t *pair_a, const int32_t *pair_b, i
     return rc;
 }
 
-static void links_layout(ldw_ctx *c, SmallLayout &sl) {
-    char *base = c->small.as<char>();
-    sl.lr_count = reinterpret_cast<int64_t *>(base);
-    sl.blk_sr = reinterpret_cast<int64_t *>(base + 8);
-    sl.pick = reinterpret_cast<ldw::PickOut *>(base + 64);
-    sl.stats_i = reinterpret_cast<int64_t *>(base + 64 + ((sizeof(ldw::PickOut) + 63) / 64) * 64);
-    sl.stats_d = reinterpret_cast<double *>(sl.stats_i + c->blk_capacity * 3);
-}
-
 int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(nblocks_capacity > 0, LDW_ERR_ARG, "ldw_links_begin: capacity must be positive");
@@ -813,11 +1040,10 @@ int ldw_mi_block_links(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const in
                 "ldw_mi_block_links: call ldw_links_begin with enough capacity first");
     LDW_REQUIRE(p->sr_only || p->lr_links_approx > 0, LDW_ERR_ARG, "lr_links_approx must be positive");
     LDW_REQUIRE(p->quirk_mode == LDW_QUIRK_REFERENCE || p->quirk_mode == LDW_QUIRK_INTENDED, LDW_ERR_ARG, "bad quirk mode");
+    LDW_REQUIRE(c->have_meta, LDW_ERR_STATE, "ldw_mi_block_links: SNP meta data (POS, g) not set");
     SmallLayout sl;
     links_layout(c, sl);
-    if (int rc = block_links(c, from_idx, nf, to_idx, nt, p, c->blk_cursor, sl.lr_count, sl.stats_i, sl.stats_d,
-                             sl.pick, sl.blk_sr))
-        return rc;
+    if (int rc = block_links(c, from_idx, nf, to_idx, nt, p, c->blk_cursor, sl)) return rc;
     ++c->blk_cursor;
     return LDW_OK;
 }
