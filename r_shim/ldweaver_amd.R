@@ -1,0 +1,71 @@
+# Drop-in R definitions on top of the shim (same signatures as the reference).  NOT run in this repository
+# (no R in the build image); the Python mirror ldweaver_amd/mi.py implements and tests the same logic.
+
+.ldwamd_states_from_snpdat <- function(snp.dat) {
+  # five L x N one-hot sparse matrices -> one raw L x N matrix, row-major, values 0..4
+  st <- matrix(as.raw(0), nrow = snp.dat$nseq, ncol = snp.dat$nsnp)           # N x L column-major == L x N row-major
+  for (k in 1:4) {
+    m <- Matrix::t(snp.dat[[c("snp.matrix_C", "snp.matrix_G", "snp.matrix_T", "snp.matrix_N")[k]]])  # N x L
+    idx <- Matrix::which(m)
+    st[idx] <- as.raw(k)
+  }
+  st
+}
+
+.ACGTN2num <- function(nv, cv, ncores) invisible(.Call("ldwamd_ACGTN2num", nv, cv, as.integer(ncores)))
+
+estimate_Hamming_distance_weights <- function(snp.dat, threshold = 0.1, mega_dset = F) {
+  t0 <- Sys.time()
+  .Call("ldwamd_set_alignment", .ldwamd_states_from_snpdat(snp.dat), snp.dat$nsnp, snp.dat$nseq)
+  hdw <- .Call("ldwamd_hamming_weights", as.integer(snp.dat$nsnp * threshold), snp.dat$nseq)
+  names(hdw) <- snp.dat$seq.names
+  cat(paste("Done in", round(difftime(Sys.time(), t0, units = "secs"), 2), "s\n"))
+  hdw
+}
+
+perform_MI_computation <- function(snp.dat, hdw, cds_var, ncores, lr_save_path = NULL, sr_save_path = NULL, plt_folder = NULL,
+                                   sr_dist = 20000, lr_retain_links = 1e6, max_blk_sz = 10000, srp_cutoff = 3, runARACNE = TRUE,
+                                   perform_SR_analysis_only = FALSE, order_links = T, mega_dset = F) {
+  if (is.null(lr_save_path)) lr_save_path <- file.path(getwd(), "lr_links.tsv")
+  if (is.null(sr_save_path)) sr_save_path <- file.path(getwd(), "sr_links.tsv")
+  if (is.null(plt_folder)) plt_folder <- file.path(getwd(), "PLOTS")
+  if (!file.exists(plt_folder)) dir.create(plt_folder)
+  max_blk_sz <- round(max_blk_sz, -3)
+  MI_cmp_blks <- make_blocks(snp.dat$nsnp, max_blk_sz)                       # reference's own helper, unchanged
+  lr_links_approx <- 1
+  if (!perform_SR_analysis_only) {                                           # R/computePairwiseMI.R:94-97, stays in R
+    snp_subset <- min(snp.dat$nsnp, round(snp.dat$nsnp * 0.1))
+    set.seed(1988)
+    cnt <- sapply(snp.dat$POS[sample(snp.dat$nsnp, snp_subset)],
+                  function(x) sum((0.5 * snp.dat$g - abs((x - snp.dat$POS) %% snp.dat$g - 0.5 * snp.dat$g)) > sr_dist))
+    lr_links_approx <- sum(cnt) / snp_subset * snp.dat$nsnp / 2
+  }
+  .Call("ldwamd_set_alignment", .ldwamd_states_from_snpdat(snp.dat), snp.dat$nsnp, snp.dat$nseq)
+  .Call("ldwamd_set_weights", as.numeric(hdw))
+  .Call("ldwamd_set_snp_meta", as.numeric(snp.dat$r), as.raw(t(snp.dat$uqe)), as.integer(snp.dat$POS),
+        as.integer(cds_var$paint), as.numeric(snp.dat$g))
+  res <- .Call("ldwamd_mi_all_pairs", as.integer(t(as.matrix(MI_cmp_blks))), sr_dist, lr_retain_links, lr_links_approx,
+               perform_SR_analysis_only, 0L)
+  to_df <- function(t) {
+    pos2 <- as.numeric(snp.dat$POS[t[[1]] + 1]); pos1 <- as.numeric(snp.dat$POS[t[[2]] + 1])
+    data.frame(pos1 = pos1, pos2 = pos2, clust1 = cds_var$paint[t[[2]] + 1], clust2 = cds_var$paint[t[[1]] + 1],
+               len = 0.5 * snp.dat$g - abs((pos1 - pos2) %% snp.dat$g - 0.5 * snp.dat$g), MI = t[[3]])
+  }
+  if (!perform_SR_analysis_only && length(res[[2]][[3]]) > 0)
+    write.table(to_df(res[[2]]), file = lr_save_path, append = T, quote = F, row.names = F, col.names = F, sep = "\t")
+  sr <- to_df(res[[1]])
+  sr_links <- lapply(1:cds_var$nclust, function(i) sr[sr$clust1 == i | sr$clust2 == i, ])
+  sr_links_all <- mergeNsort_sr_links(cds_var = cds_var, sr_links = sr_links, sr_dist = sr_dist, plt_path = plt_folder,
+                                      srp_cutoff = srp_cutoff)                # reference's own function, unchanged
+  sr_links_red <- sr_links_all$sr_links_red
+  chk <- sr_links_all$sr_links_ARACNE_check
+  if (runARACNE) {
+    sr_links_red$ARACNE <- as.numeric(.Call("ldwamd_aracne", sr_links_red$pos1, sr_links_red$pos2, sr_links_red$MI,
+                                            chk$pos1, chk$pos2, chk$MI))
+  } else {
+    warning("ARACNE not run, all values will be set to 1"); sr_links_red$ARACNE <- 1
+  }
+  if (order_links) { sr_links_red <- sr_links_red[order(sr_links_red$srp_max, decreasing = T), ]; rownames(sr_links_red) <- NULL }
+  write.table(x = sr_links_red, file = sr_save_path, append = T, quote = F, row.names = F, col.names = F, sep = "\t")
+  sr_links_red
+}
