@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libldweaver_amd.so")
+LIB_PATH = os.environ.get("LDW_AMD_LIB") or os.path.join(_HERE, "libldweaver_amd.so")  # override for kernel A/B experiments
 
 LDW_OK = 0
 QUIRK_REFERENCE, QUIRK_INTENDED = 0, 1

@@ -265,6 +265,16 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     for (auto *b : bufs) b->release();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; ++k) {
+        c->dstage[k].release();
+        if (c->pin[k]) (void)hipHostFree(c->pin[k]);
+        if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]);
+        if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
+    }
+    if (c->pin_pick) (void)hipHostFree(c->pin_pick);
+    if (c->ev_pick) (void)hipEventDestroy(c->ev_pick);
+    for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LDW_OK;

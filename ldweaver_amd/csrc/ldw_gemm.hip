@@ -102,6 +102,7 @@ __global__ __launch_bounds__(512, 2) void gemm_limb_kernel(const uint8_t *__rest
 
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
+#ifndef LDW_ABL_NOSTAGE
         if (ks + 1 < nk) {  // issue next stage's global loads early
             const int64_t ko = (int64_t)(ks + 1) * KSTEP;
 #pragma unroll
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(512, 2) void gemm_limb_kernel(const uint8_t *__rest
             }
             if (dig_loader) rD = *reinterpret_cast<const v4i *>(gD + ko);
         }
+#endif
         // fragments of k-step kk+1 are read while the MFMAs of k-step kk run
         v4i a0[2], a1[2], b[2];
         a0[0] = *reinterpret_cast<const v4i *>(&sT[cur][lds_off(arow0, fh)]);
@@ -126,12 +128,17 @@ __global__ __launch_bounds__(512, 2) void gemm_limb_kernel(const uint8_t *__rest
             }
 #pragma unroll
             for (int j = 0; j < J; ++j) {
+#ifdef LDW_ABL_NODIG
+                const v4i d = v4i{0x01010101 * (j + 1), 0x01010101, 0x01010101, 0x01010101};
+#else
                 const v4i d = *reinterpret_cast<const v4i *>(&sD[cur][j * KSTEP + slot * 16]);
+#endif
                 const v4i bm = b[kk & 1] & d;  // digit where the from-side indicator is set
                 acc[j][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0[kk & 1], bm, acc[j][0], 0, 0, 0);
                 acc[j][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1[kk & 1], bm, acc[j][1], 0, 0, 0);
             }
         }
+#ifndef LDW_ABL_NOSTAGE
         if (ks + 1 < nk) {
             const int nxt = cur ^ 1;
 #pragma unroll
@@ -141,7 +148,10 @@ __global__ __launch_bounds__(512, 2) void gemm_limb_kernel(const uint8_t *__rest
             }
             if (dig_loader) *reinterpret_cast<v4i *>(&sD[nxt][tid * 16]) = rD;
         }
+#endif
+#ifndef LDW_ABL_NOBARRIER
         __syncthreads();
+#endif
     }
 
     // epilogue: Horner over limbs in int64, negate (the un-masked operand is -1), store.  C/D layout of

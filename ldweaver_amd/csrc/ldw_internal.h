@@ -99,6 +99,17 @@ struct ldw_ctx {
     ldw::DevBuf sr_a, sr_b, sr_mi, lr_a, lr_b, lr_mi;
     int64_t n_sr = 0, n_lr = 0;
     int64_t blk_capacity = 0, blk_cursor = 0;  // ldw_links_begin / ldw_mi_block_links / ldw_links_end
+
+    // ---- pipelined block staging: host prep of block i+1 overlaps the GPU work of block i ----
+    hipStream_t copy_stream = nullptr;
+    void *pin[2] = {nullptr, nullptr};   // pinned host staging, one packed buffer per slot
+    size_t pin_cap[2] = {0, 0};
+    ldw::DevBuf dstage[2];               // device image of the packed buffer
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool done_recorded[2] = {false, false};
+    void *pin_pick = nullptr;            // pinned landing zone of the per-block PickOut
+    hipEvent_t ev_pick = nullptr;
+    std::vector<hipEvent_t> ev_pool;     // 4 timing events per block
     std::vector<ldw::BlockStat> stats;
 };
 

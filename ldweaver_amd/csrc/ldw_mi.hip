@@ -599,11 +599,6 @@ __global__ void k_block_done(PickOut *pick, int64_t *lr_count, int64_t n_sr_blk,
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-struct BlockGeom {
-    int64_t nf = 0, nt = 0;
-    int RFpad = 0, RTpad = 0;
-};
-
 int upload_i32(ldw_ctx *c, ldw::DevBuf &buf, const std::vector<int32_t> &v) {
     if (int rc = buf.reserve(v.size() * 4 + 4)) return rc;
     if (!v.empty()) LDW_HIP(hipMemcpyAsync(buf.p, v.data(), v.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -713,79 +708,49 @@ bool same_list(const int32_t *a, int64_t na, const int32_t *b, int64_t nb) {
     return true;
 }
 
-// Stage the index lists and produce the dense MI block in ctx->MIblk; with E.cols set, the short-range
-// scatter and the long-range histogram ride along (fused in the epilogue for the MFMA engine).
-int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt, int quirk,
-                 EmitArgs E, BlockGeom &geo) {
-    if (int rc = ensure_rows(c)) return rc;
-    LDW_REQUIRE(nf > 0 && nt > 0, LDW_ERR_ARG, "empty block (nf=%lld nt=%lld)", (long long)nf, (long long)nt);
-    LDW_REQUIRE(nf <= 1000000 && nt <= 1000000, LDW_ERR_ARG, "block side too long");
-    std::vector<int32_t> vf(from_idx, from_idx + nf), vt(to_idx, to_idx + nt);
-    if (int rc = upload_i32(c, c->idx_f, vf)) return rc;
-    if (int rc = upload_i32(c, c->idx_t, vt)) return rc;
+// device pointers of one block's index structures
+struct DevPtrs {
+    const int32_t *idx_f, *idx_t, *rl_f, *rl_t, *lrow_f, *lrow_t, *perm;
+};
+
+// GEMM + epilogue (or the histogram engine) of one block into ctx->MIblk; with E.cols set, the short-range
+// scatter and the long-range histogram ride along.  ev[0..2] are recorded before the GEMM, between the two
+// kernels and after the epilogue.  Everything is asynchronous on ctx->stream.
+int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E,
+                    hipEvent_t *ev) {
     if (int rc = c->MIblk.reserve((size_t)nf * nt * 8)) return rc;
     if (int rc = c->hist.reserve((size_t)NBINS * 8)) return rc;
-    geo.nf = nf;
-    geo.nt = nt;
     E.MI = c->MIblk.as<double>();
     E.nf = (int)nf;
     dim3 egrid((unsigned)((nf + 63) / 64), (unsigned)((nt + EPI_COLS - 1) / EPI_COLS));
     LDW_REQUIRE(egrid.y <= 65535u, LDW_ERR_ARG, "nt too large for the epilogue grid");
     unsigned long long *ghist = c->hist.as<unsigned long long>();
     if (c->engine == LDW_ENGINE_HIST) {
-        for (int64_t k = 0; k < nf; ++k)
-            LDW_REQUIRE(from_idx[k] >= 0 && from_idx[k] < c->L, LDW_ERR_ARG, "SNP index %d out of range", from_idx[k]);
-        for (int64_t k = 0; k < nt; ++k)
-            LDW_REQUIRE(to_idx[k] >= 0 && to_idx[k] < c->L, LDW_ERR_ARG, "SNP index %d out of range", to_idx[k]);
-        LDW_HIP(hipStreamSynchronize(c->stream));
-        LDW_HIP(hipEventRecord(c->ev[0], c->stream));
-        LDW_HIP(hipEventRecord(c->ev[1], c->stream));
-        if (int rc = launch_hist(c, c->idx_f.as<int32_t>(), (int)nf, c->idx_t.as<int32_t>(), (int)nt,
-                                 c->pfix_state.as<int64_t>(), quirk, E.lower_only, c->MIblk.as<double>()))
+        LDW_HIP(hipEventRecord(ev[0], c->stream));
+        LDW_HIP(hipEventRecord(ev[1], c->stream));
+        if (int rc = launch_hist(c, D.idx_f, (int)nf, D.idx_t, (int)nt, c->pfix_state.as<int64_t>(), quirk, E.lower_only,
+                                 c->MIblk.as<double>()))
             return rc;
         if (E.cols) {
-            hipLaunchKernelGGL(k_post_mi, egrid, dim3(256), 0, c->stream, E, c->idx_f.as<int32_t>(), c->idx_t.as<int32_t>(),
-                               (int)nt, ghist);
+            hipLaunchKernelGGL(k_post_mi, egrid, dim3(256), 0, c->stream, E, D.idx_f, D.idx_t, (int)nt, ghist);
             LDW_HIP(hipGetLastError());
         }
-        LDW_HIP(hipEventRecord(c->ev[2], c->stream));
+        LDW_HIP(hipEventRecord(ev[2], c->stream));
         return LDW_OK;
     }
-    std::vector<int32_t> rl_f, rl_t, lr_f, lr_t;
-    int RFpad = 0, RTpad = 0;
-    if (int rc = build_side(c, from_idx, nf, rl_f, lr_f, RFpad)) return rc;
-    if (int rc = build_side(c, to_idx, nt, rl_t, lr_t, RTpad)) return rc;
-    geo.RFpad = RFpad;
-    geo.RTpad = RTpad;
-    if (int rc = upload_i32(c, c->rowlist_f, rl_f)) return rc;
-    if (int rc = upload_i32(c, c->rowlist_t, rl_t)) return rc;
-    if (int rc = upload_i32(c, c->lrow_f, lr_f)) return rc;
-    if (int rc = upload_i32(c, c->lrow_t, lr_t)) return rc;
-    {   // lane order of the epilogue: from-side SNPs grouped by their number of indicator rows (1, 2, 3, 4, 0)
-        std::vector<int32_t> perm((size_t)nf);
-        int64_t w = 0;
-        for (int want : {1, 2, 3, 4, 0})
-            for (int64_t k = 0; k < nf; ++k)
-                if (c->h_row0[from_idx[k] + 1] - c->h_row0[from_idx[k]] == want) perm[w++] = (int32_t)k;
-        if (int rc = upload_i32(c, c->perm_f, perm)) return rc;
-    }
-    // pageable H2D copies above are complete only after a sync
-    LDW_HIP(hipStreamSynchronize(c->stream));
     if (int rc = c->G.reserve((size_t)RFpad * RTpad * 8)) return rc;
-
-    LDW_HIP(hipEventRecord(c->ev[0], c->stream));
-    if (int rc = launch_gemm(c, c->rowlist_t.as<int32_t>(), RTpad, c->rowlist_f.as<int32_t>(), RFpad,
-                             c->G.as<int64_t>(), c->nlimbs, c->digits.as<int8_t>(), c->M.as<uint8_t>(), c->Npad,
-                             E.lower_only, 0))
+    LDW_HIP(hipEventRecord(ev[0], c->stream));
+    if (int rc = launch_gemm(c, D.rl_t, RTpad, D.rl_f, RFpad, c->G.as<int64_t>(), c->nlimbs, c->digits.as<int8_t>(),
+                             c->M.as<uint8_t>(), c->Npad, E.lower_only, 0))
         return rc;
-    LDW_HIP(hipEventRecord(c->ev[1], c->stream));
+    LDW_HIP(hipEventRecord(ev[1], c->stream));
     EpiArgs A;
     A.G = c->G.as<int64_t>();
     A.RFpad = RFpad;
-    A.idx_f = c->idx_f.as<int32_t>();
-    A.lrow_f = c->lrow_f.as<int32_t>();
-    A.idx_t = c->idx_t.as<int32_t>();
-    A.lrow_t = c->lrow_t.as<int32_t>();
+    A.idx_f = D.idx_f;
+    A.lrow_f = D.lrow_f;
+    A.idx_t = D.idx_t;
+    A.lrow_t = D.lrow_t;
     A.nf = (int)nf;
     A.nt = (int)nt;
     A.slot_meta = c->slot_meta.as<uint32_t>();
@@ -795,10 +760,42 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     A.scale = std::ldexp(1.0, -c->frac_bits);
     A.quirk = quirk;
     A.E = E;
-    hipLaunchKernelGGL(k_mi_epilogue, egrid, dim3(256), 0, c->stream, A, c->perm_f.as<int32_t>(), ghist);
+    hipLaunchKernelGGL(k_mi_epilogue, egrid, dim3(256), 0, c->stream, A, D.perm, ghist);
     LDW_HIP(hipGetLastError());
-    LDW_HIP(hipEventRecord(c->ev[2], c->stream));
+    LDW_HIP(hipEventRecord(ev[2], c->stream));
     return LDW_OK;
+}
+
+// lane order of the epilogue: from-side SNPs grouped by their number of indicator rows (1, 2, 3, 4, 0)
+void build_perm(ldw_ctx *c, const int32_t *from_idx, int64_t nf, int32_t *perm) {
+    int64_t w = 0;
+    for (int want : {1, 2, 3, 4, 0})
+        for (int64_t k = 0; k < nf; ++k)
+            if (c->h_row0[from_idx[k] + 1] - c->h_row0[from_idx[k]] == want) perm[w++] = (int32_t)k;
+}
+
+// dense MI of one block, synchronous staging through ctx-owned buffers (ldw_mi_block, ldw_joint_tables style)
+int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt, int quirk,
+                 EmitArgs E) {
+    if (int rc = ensure_rows(c)) return rc;
+    LDW_REQUIRE(nf > 0 && nt > 0, LDW_ERR_ARG, "empty block (nf=%lld nt=%lld)", (long long)nf, (long long)nt);
+    LDW_REQUIRE(nf <= 1000000 && nt <= 1000000, LDW_ERR_ARG, "block side too long");
+    std::vector<int32_t> vf(from_idx, from_idx + nf), vt(to_idx, to_idx + nt), rl_f, rl_t, lr_f, lr_t, perm((size_t)nf);
+    int RFpad = 0, RTpad = 0;
+    if (int rc = build_side(c, from_idx, nf, rl_f, lr_f, RFpad)) return rc;
+    if (int rc = build_side(c, to_idx, nt, rl_t, lr_t, RTpad)) return rc;
+    build_perm(c, from_idx, nf, perm.data());
+    if (int rc = upload_i32(c, c->idx_f, vf)) return rc;
+    if (int rc = upload_i32(c, c->idx_t, vt)) return rc;
+    if (int rc = upload_i32(c, c->rowlist_f, rl_f)) return rc;
+    if (int rc = upload_i32(c, c->rowlist_t, rl_t)) return rc;
+    if (int rc = upload_i32(c, c->lrow_f, lr_f)) return rc;
+    if (int rc = upload_i32(c, c->lrow_t, lr_t)) return rc;
+    if (int rc = upload_i32(c, c->perm_f, perm)) return rc;
+    LDW_HIP(hipStreamSynchronize(c->stream));  // pageable H2D copies are complete only after a sync
+    DevPtrs D{c->idx_f.as<int32_t>(), c->idx_t.as<int32_t>(), c->rowlist_f.as<int32_t>(), c->rowlist_t.as<int32_t>(),
+              c->lrow_f.as<int32_t>(), c->lrow_t.as<int32_t>(), c->perm_f.as<int32_t>()};
+    return launch_block_mi(c, D, nf, nt, RFpad, RTpad, quirk, E, c->ev);
 }
 
 int ensure_links_capacity(ldw_ctx *c, int64_t sr_rows, int64_t lr_rows) {
@@ -827,66 +824,127 @@ void links_layout(ldw_ctx *c, SmallLayout &sl) {
     sl.stats_d = reinterpret_cast<double *>(sl.stats_i + c->blk_capacity * 3);
 }
 
-// one block, links appended.  ctx->n_lr is an upper bound while running; the exact count lives in *lr_count.
-int block_links(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt,
-                const ldw_mi_params *p, int64_t blk_no, const SmallLayout &sl) {
+// ---- one block of the link loop in three phases so that the host work of block i+1 overlaps the GPU work of
+// ---- block i:  prep (pure host, into pinned memory)  ->  submit (upload + kernels up to the candidate gather)
+// ---- ->  finish (the one host round trip: candidate count, then sorts / threshold / append)
+struct HostBlock {
+    int64_t nf = 0, nt = 0, n_sr_blk = 0, blk_no = 0;
+    int RFpad = 0, RTpad = 0, slot = 0;
+    bool diag = false;
+    size_t o_idx_f = 0, o_idx_t = 0, o_rl_f = 0, o_rl_t = 0, o_lrow_f = 0, o_lrow_t = 0, o_perm = 0, o_cols = 0, total = 0;
+};
+
+int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt, const ldw_mi_params *p,
+               int slot, int64_t blk_no, HostBlock &hb) {
+    LDW_REQUIRE(nf > 0 && nt > 0, LDW_ERR_ARG, "empty block (nf=%lld nt=%lld)", (long long)nf, (long long)nt);
+    LDW_REQUIRE(nf <= 1000000 && nt <= 1000000 && nf * nt < 2147483647LL, LDW_ERR_ARG, "block too large (%lld x %lld)",
+                (long long)nf, (long long)nt);
     for (int64_t k = 0; k < nf; ++k)
         LDW_REQUIRE(from_idx[k] >= 0 && from_idx[k] < c->L, LDW_ERR_ARG, "SNP index %d out of range", from_idx[k]);
     for (int64_t k = 0; k < nt; ++k)
         LDW_REQUIRE(to_idx[k] >= 0 && to_idx[k] < c->L, LDW_ERR_ARG, "SNP index %d out of range", to_idx[k]);
-    const bool diag = same_list(from_idx, nf, to_idx, nt);
-    const bool do_lr = !p->sr_only;
-    // ---- host: short-range intervals, row offsets, capacity (no device round trip) ----
+    hb.nf = nf;
+    hb.nt = nt;
+    hb.slot = slot;
+    hb.blk_no = blk_no;
+    hb.diag = same_list(from_idx, nf, to_idx, nt);
+    std::vector<int32_t> rl_f, rl_t, lr_f, lr_t;
+    if (int rc = build_side(c, from_idx, nf, rl_f, lr_f, hb.RFpad)) return rc;
+    if (int rc = build_side(c, to_idx, nt, rl_t, lr_t, hb.RTpad)) return rc;
     std::vector<ColInfo> cols;
-    int64_t n_sr_blk = 0;
-    if (int rc = build_cols(c, from_idx, nf, to_idx, nt, diag, p->sr_dist, cols, n_sr_blk)) return rc;
-    if (int rc = c->colcnt.reserve(cols.size() * sizeof(ColInfo))) return rc;
-    LDW_HIP(hipMemcpyAsync(c->colcnt.p, cols.data(), cols.size() * sizeof(ColInfo), hipMemcpyHostToDevice, c->stream));
-    const int64_t sr_add = p->keep_sr ? n_sr_blk : 0;
+    if (int rc = build_cols(c, from_idx, nf, to_idx, nt, hb.diag, p->sr_dist, cols, hb.n_sr_blk)) return rc;
+    auto al = [](size_t x) { return (x + 63) / 64 * 64; };
+    size_t o = 0;
+    hb.o_idx_f = o; o = al(o + (size_t)nf * 4);
+    hb.o_idx_t = o; o = al(o + (size_t)nt * 4);
+    hb.o_rl_f = o; o = al(o + rl_f.size() * 4);
+    hb.o_rl_t = o; o = al(o + rl_t.size() * 4);
+    hb.o_lrow_f = o; o = al(o + (size_t)nf * 4);
+    hb.o_lrow_t = o; o = al(o + (size_t)nt * 4);
+    hb.o_perm = o; o = al(o + (size_t)nf * 4);
+    hb.o_cols = o; o = al(o + cols.size() * sizeof(ColInfo));
+    hb.total = o;
+    if (c->pin_cap[slot] < o) {
+        if (c->pin[slot]) LDW_HIP(hipHostFree(c->pin[slot]));
+        c->pin[slot] = nullptr;
+        c->pin_cap[slot] = 0;
+        LDW_HIP(hipHostMalloc(&c->pin[slot], o * 2, hipHostMallocDefault));
+        c->pin_cap[slot] = o * 2;
+    }
+    char *b = static_cast<char *>(c->pin[slot]);
+    memcpy(b + hb.o_idx_f, from_idx, (size_t)nf * 4);
+    memcpy(b + hb.o_idx_t, to_idx, (size_t)nt * 4);
+    memcpy(b + hb.o_rl_f, rl_f.data(), rl_f.size() * 4);
+    memcpy(b + hb.o_rl_t, rl_t.data(), rl_t.size() * 4);
+    memcpy(b + hb.o_lrow_f, lr_f.data(), (size_t)nf * 4);
+    memcpy(b + hb.o_lrow_t, lr_t.data(), (size_t)nt * 4);
+    build_perm(c, from_idx, nf, reinterpret_cast<int32_t *>(b + hb.o_perm));
+    memcpy(b + hb.o_cols, cols.data(), cols.size() * sizeof(ColInfo));
+    return LDW_OK;
+}
+
+int submit_block(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
+    const int s = hb.slot;
+    if (int rc = c->dstage[s].reserve(hb.total)) return rc;
+    // the device image of this slot was last read by the block two steps back
+    if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_done[s], 0));
+    LDW_HIP(hipMemcpyAsync(c->dstage[s].p, c->pin[s], hb.total, hipMemcpyHostToDevice, c->copy_stream));
+    LDW_HIP(hipEventRecord(c->ev_up[s], c->copy_stream));
+    LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_up[s], 0));
+    const char *d = c->dstage[s].as<char>();
+    auto I = [&](size_t off) { return reinterpret_cast<const int32_t *>(d + off); };
+    DevPtrs D{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm)};
+    const bool do_lr = !p->sr_only;
+    const int64_t sr_add = p->keep_sr ? hb.n_sr_blk : 0;
     if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr)) return rc;
     if (int rc = c->hist.reserve((size_t)NBINS * 8)) return rc;
     LDW_HIP(hipMemsetAsync(c->hist.p, 0, (size_t)NBINS * 8, c->stream));
-
     EmitArgs E;
     memset(&E, 0, sizeof(E));
-    E.cols = reinterpret_cast<const ColInfo *>(c->colcnt.p);
-    E.lower_only = diag ? 1 : 0;
+    E.cols = reinterpret_cast<const ColInfo *>(d + hb.o_cols);
+    E.lower_only = hb.diag ? 1 : 0;
     E.keep_sr = p->keep_sr ? 1 : 0;
     E.do_lr = do_lr ? 1 : 0;
     E.sr_base = c->n_sr;
     E.sr_a = c->sr_a.as<int32_t>();
     E.sr_b = c->sr_b.as<int32_t>();
     E.sr_mi = c->sr_mi.as<double>();
-    BlockGeom geo;
-    if (int rc = run_block_mi(c, from_idx, nf, to_idx, nt, p->quirk_mode, E, geo)) return rc;
+    hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * 4];
+    if (int rc = launch_block_mi(c, D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, ev)) return rc;
     c->n_sr += sr_add;
-
-    int64_t m = 0;
     if (do_lr) {
         hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, c->stream, c->hist.as<unsigned long long>(),
                            p->lr_retain_links, p->lr_links_approx, sl.pick);
         LDW_HIP(hipGetLastError());
         // candidate capacity: every pair of the block in the worst case (all MI in one bucket)
-        const size_t cap = (size_t)nf * nt;
+        const size_t cap = (size_t)hb.nf * hb.nt;
         if (int rc = c->cand_key.reserve(cap * 8)) return rc;
         if (int rc = c->cand_val.reserve(cap * 8)) return rc;
         GatherArgs S;
         S.MI = c->MIblk.as<double>();
         S.cols = E.cols;
-        S.nf = (int)nf;
-        S.nt = (int)nt;
+        S.nf = (int)hb.nf;
+        S.nt = (int)hb.nt;
         S.lower_only = E.lower_only;
-        hipLaunchKernelGGL(k_lr_gather, dim3((unsigned)((nt + 15) / 16)), dim3(256), 0, c->stream, S, sl.pick,
+        hipLaunchKernelGGL(k_lr_gather, dim3((unsigned)((hb.nt + 15) / 16)), dim3(256), 0, c->stream, S, sl.pick,
                            c->cand_key.as<uint64_t>(), c->cand_val.as<uint64_t>());
         LDW_HIP(hipGetLastError());
-        // ---- the one host round trip of the block: the candidate count sizes the sorts ----
-        ldw::PickOut h_pick;
-        LDW_HIP(hipMemcpyAsync(&h_pick, sl.pick, sizeof(h_pick), hipMemcpyDeviceToHost, c->stream));
-        LDW_HIP(hipStreamSynchronize(c->stream));
-        m = (int64_t)h_pick.n_cand;
     } else {
         LDW_HIP(hipMemsetAsync(sl.pick, 0, sizeof(ldw::PickOut), c->stream));
     }
+    LDW_HIP(hipMemcpyAsync(c->pin_pick, sl.pick, sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipEventRecord(c->ev_pick, c->stream));
+    return LDW_OK;
+}
+
+int finish_block(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
+    const bool do_lr = !p->sr_only;
+    // ---- the one host round trip of the block: the candidate count sizes the sorts ----
+    LDW_HIP(hipEventSynchronize(c->ev_pick));
+    const int64_t m = do_lr ? (int64_t)static_cast<ldw::PickOut *>(c->pin_pick)->n_cand : 0;
+    const int64_t nf = hb.nf;
+    const char *d = c->dstage[hb.slot].as<char>();
+    const int32_t *idx_f = reinterpret_cast<const int32_t *>(d + hb.o_idx_f), *idx_t = reinterpret_cast<const int32_t *>(d + hb.o_idx_t);
     if (do_lr && m > 0) {
         LDW_REQUIRE(m < 2147483647LL, LDW_ERR_SIZE, "too many quantile candidates (%lld)", (long long)m);
         if (int rc = ensure_links_capacity(c, c->n_sr, c->n_lr + m)) return rc;
@@ -910,28 +968,20 @@ int block_links(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *
                                                    c->cand_key2.as<uint64_t>(), c->cand_val.as<uint64_t>(),
                                                    c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
         hipLaunchKernelGGL(k_lr_append, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), sl.pick, c->idx_f.as<int32_t>(),
-                           c->idx_t.as<int32_t>(), (int)nf, sl.lr_count, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(),
-                           c->lr_mi.as<double>());
+                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), sl.pick, idx_f, idx_t, (int)nf,
+                           sl.lr_count, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), c->lr_mi.as<double>());
         LDW_HIP(hipGetLastError());
         c->n_lr += m;  // upper bound; the exact value is *lr_count
     } else if (do_lr) {
         hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, c->cand_key.as<uint64_t>(), sl.pick);
         LDW_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_block_done, dim3(1), dim3(64), 0, c->stream, sl.pick, sl.lr_count, n_sr_blk,
-                       sl.stats_i + blk_no * 3, sl.stats_d + blk_no);
+    hipLaunchKernelGGL(k_block_done, dim3(1), dim3(64), 0, c->stream, sl.pick, sl.lr_count, hb.n_sr_blk,
+                       sl.stats_i + hb.blk_no * 3, sl.stats_d + hb.blk_no);
     LDW_HIP(hipGetLastError());
-    LDW_HIP(hipEventRecord(c->ev[3], c->stream));
-    LDW_HIP(hipEventSynchronize(c->ev[3]));
-    float t01 = 0, t12 = 0, t23 = 0;
-    LDW_HIP(hipEventElapsedTime(&t01, c->ev[0], c->ev[1]));
-    LDW_HIP(hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
-    LDW_HIP(hipEventElapsedTime(&t23, c->ev[2], c->ev[3]));
-    c->last_ms[0] += t01;
-    c->last_ms[1] += t12;
-    c->last_ms[2] += t23;
-    c->last_ms[3] += t01 + t12 + t23;
+    LDW_HIP(hipEventRecord(c->ev_pool[(size_t)hb.blk_no * 4 + 3], c->stream));
+    LDW_HIP(hipEventRecord(c->ev_done[hb.slot], c->stream));
+    c->done_recorded[hb.slot] = true;
     return LDW_OK;
 }
 
@@ -944,10 +994,9 @@ int ldw_mi_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(from_idx && to_idx && MI_out, LDW_ERR_ARG, "ldw_mi_block: null argument");
     LDW_REQUIRE(quirk_mode == LDW_QUIRK_REFERENCE || quirk_mode == LDW_QUIRK_INTENDED, LDW_ERR_ARG, "bad quirk mode");
-    BlockGeom geo;
     EmitArgs E;
     memset(&E, 0, sizeof(E));
-    if (int rc = run_block_mi(c, from_idx, nf, to_idx, nt, quirk_mode, E, geo)) return rc;
+    if (int rc = run_block_mi(c, from_idx, nf, to_idx, nt, quirk_mode, E)) return rc;
     LDW_HIP(hipMemcpyAsync(MI_out, c->MIblk.p, (size_t)nf * nt * 8, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                            c->stream));
     LDW_HIP(hipStreamSynchronize(c->stream));
@@ -1021,6 +1070,21 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
     const size_t need = 64 + ((sizeof(ldw::PickOut) + 63) / 64) * 64 + (size_t)nblocks_capacity * 32 + 64;
     if (int rc = c->small.reserve(need)) return rc;
     LDW_HIP(hipMemsetAsync(c->small.p, 0, need, c->stream));
+    if (!c->copy_stream) {
+        LDW_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            LDW_HIP(hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming));
+            LDW_HIP(hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
+        }
+        LDW_HIP(hipEventCreateWithFlags(&c->ev_pick, hipEventDisableTiming));
+        LDW_HIP(hipHostMalloc(&c->pin_pick, sizeof(ldw::PickOut) + 64, hipHostMallocDefault));
+    }
+    while ((int64_t)c->ev_pool.size() < nblocks_capacity * 4) {
+        hipEvent_t e;
+        LDW_HIP(hipEventCreate(&e));
+        c->ev_pool.push_back(e);
+    }
+    c->done_recorded[0] = c->done_recorded[1] = false;
     c->n_sr = 0;
     c->n_lr = 0;
     c->stats.clear();
@@ -1030,18 +1094,26 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
     return LDW_OK;
 }
 
+static int links_check(ldw_ctx *c, const ldw_mi_params *p) {
+    LDW_REQUIRE(c->blk_capacity > 0 && c->blk_cursor < c->blk_capacity, LDW_ERR_STATE,
+                "call ldw_links_begin with enough capacity first");
+    LDW_REQUIRE(p->sr_only || p->lr_links_approx > 0, LDW_ERR_ARG, "lr_links_approx must be positive");
+    LDW_REQUIRE(p->quirk_mode == LDW_QUIRK_REFERENCE || p->quirk_mode == LDW_QUIRK_INTENDED, LDW_ERR_ARG, "bad quirk mode");
+    LDW_REQUIRE(c->have_meta, LDW_ERR_STATE, "SNP meta data (POS, g) not set");
+    return LDW_OK;
+}
+
 int ldw_mi_block_links(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt,
                        const ldw_mi_params *p) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(from_idx && to_idx && p, LDW_ERR_ARG, "ldw_mi_block_links: null argument");
-    LDW_REQUIRE(c->blk_capacity > 0 && c->blk_cursor < c->blk_capacity, LDW_ERR_STATE,
-                "ldw_mi_block_links: call ldw_links_begin with enough capacity first");
-    LDW_REQUIRE(p->sr_only || p->lr_links_approx > 0, LDW_ERR_ARG, "lr_links_approx must be positive");
-    LDW_REQUIRE(p->quirk_mode == LDW_QUIRK_REFERENCE || p->quirk_mode == LDW_QUIRK_INTENDED, LDW_ERR_ARG, "bad quirk mode");
-    LDW_REQUIRE(c->have_meta, LDW_ERR_STATE, "ldw_mi_block_links: SNP meta data (POS, g) not set");
+    if (int rc = links_check(c, p)) return rc;
     SmallLayout sl;
     links_layout(c, sl);
-    if (int rc = block_links(c, from_idx, nf, to_idx, nt, p, c->blk_cursor, sl)) return rc;
+    HostBlock hb;
+    if (int rc = prep_block(c, from_idx, nf, to_idx, nt, p, (int)(c->blk_cursor & 1), c->blk_cursor, hb)) return rc;
+    if (int rc = submit_block(c, hb, p, sl)) return rc;
+    if (int rc = finish_block(c, hb, p, sl)) return rc;
     ++c->blk_cursor;
     return LDW_OK;
 }
@@ -1068,6 +1140,15 @@ int ldw_links_end(ldw_ctx *c) {
         c->stats[b].n_lr_kept = si[b * 3 + 1];
         c->stats[b].n_sr = si[b * 3 + 2];
         c->stats[b].disc_thresh = sd[b];
+        float t01 = 0, t12 = 0, t23 = 0;
+        hipEvent_t *ev = &c->ev_pool[(size_t)b * 4];
+        LDW_HIP(hipEventElapsedTime(&t01, ev[0], ev[1]));
+        LDW_HIP(hipEventElapsedTime(&t12, ev[1], ev[2]));
+        LDW_HIP(hipEventElapsedTime(&t23, ev[2], ev[3]));
+        c->last_ms[0] += t01;
+        c->last_ms[1] += t12;
+        c->last_ms[2] += t23;
+        c->last_ms[3] += t01 + t12 + t23;
     }
     c->blk_capacity = 0;
     return LDW_OK;
@@ -1078,8 +1159,11 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     LDW_REQUIRE(blocks && p && nblocks > 0, LDW_ERR_ARG, "ldw_mi_all_pairs: bad argument");
     LDW_REQUIRE(reset, LDW_ERR_ARG, "ldw_mi_all_pairs: appending to earlier calls is not supported (reset must be 1)");
     if (int rc = ldw_links_begin(c, nblocks)) return rc;
+    if (int rc = links_check(c, p)) return rc;
+    SmallLayout sl;
+    links_layout(c, sl);
     std::vector<int32_t> fi, ti;
-    for (int64_t b = 0; b < nblocks; ++b) {
+    auto fill = [&](int64_t b) -> int {
         const int32_t fs = blocks[b * 4 + 0], fe = blocks[b * 4 + 1], ts = blocks[b * 4 + 2], te = blocks[b * 4 + 3];
         LDW_REQUIRE(fs >= 1 && fe >= fs && fe <= c->L && ts >= 1 && te >= ts && te <= c->L, LDW_ERR_ARG,
                     "block %lld = (%d,%d,%d,%d) outside 1..%lld", (long long)b, fs, fe, ts, te, (long long)c->L);
@@ -1087,7 +1171,22 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         ti.resize((size_t)(te - ts + 1));
         for (int32_t k = fs; k <= fe; ++k) fi[k - fs] = k - 1;
         for (int32_t k = ts; k <= te; ++k) ti[k - ts] = k - 1;
-        if (int rc = ldw_mi_block_links(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p)) return rc;
+        return LDW_OK;
+    };
+    // software pipeline: while the GPU works on block b, the host prepares block b+1
+    HostBlock hb[2];
+    if (int rc = fill(0)) return rc;
+    if (int rc = prep_block(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, 0, 0, hb[0])) return rc;
+    for (int64_t b = 0; b < nblocks; ++b) {
+        const int s = (int)(b & 1);
+        if (int rc = submit_block(c, hb[s], p, sl)) return rc;
+        if (b + 1 < nblocks) {
+            if (int rc = fill(b + 1)) return rc;
+            if (int rc = prep_block(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, s ^ 1, b + 1, hb[s ^ 1]))
+                return rc;
+        }
+        if (int rc = finish_block(c, hb[s], p, sl)) return rc;
+        ++c->blk_cursor;
     }
     return ldw_links_end(c);
 }
