@@ -110,6 +110,8 @@ struct ldw_ctx {
     void *pin_pick = nullptr;            // pinned landing zone of the per-block PickOut
     hipEvent_t ev_pick = nullptr;
     std::vector<hipEvent_t> ev_pool;     // 4 timing events per block
+    int spec_B_next = -1;                // bucket guess for the speculative long-range gather of the next block
+    int64_t spec_misses = 0;
     std::vector<ldw::BlockStat> stats;
 };
 

@@ -131,14 +131,18 @@ struct EmitArgs {
     double *MI;            // dense block, column-major nf x nt
     const ColInfo *cols;   // null: dense store only (ldw_mi_block)
     int nf, lower_only, keep_sr, do_lr;
+    int write_dense;       // store the dense MI block (needed by k_lr_gather; off when the gather is speculative)
+    int spec_B;            // >= 0: append long-range pairs with bucket >= spec_B to the candidate list right here
     int64_t sr_base;
     int32_t *sr_a, *sr_b;
     double *sr_mi;
+    unsigned long long *n_cand;
+    uint64_t *ckey, *cval;
 };
 
 __device__ __forceinline__ void emit_pair(const EmitArgs &E, const ColInfo &c, int a_loc, int b_loc, int sa, int sb,
                                           double mi, unsigned int *sh_hist) {
-    E.MI[(int64_t)a_loc + (int64_t)b_loc * E.nf] = mi;
+    if (E.write_dense) E.MI[(int64_t)a_loc + (int64_t)b_loc * E.nf] = mi;
     if (!E.cols) return;
     const int seg = pair_seg(a_loc, b_loc, E.lower_only);
     if (seg < 0) return;
@@ -150,7 +154,13 @@ __device__ __forceinline__ void emit_pair(const EmitArgs &E, const ColInfo &c, i
             E.sr_mi[dst] = mi;
         }
     } else if (E.do_lr) {
-        atomicAdd(&sh_hist[mi_bucket(mi)], 1u);
+        const int bk = mi_bucket(mi);
+        atomicAdd(&sh_hist[bk], 1u);
+        if (E.spec_B >= 0 && bk >= E.spec_B) {
+            const unsigned long long p = atomicAdd(E.n_cand, 1ull);
+            E.ckey[p] = f64_key(mi);
+            E.cval[p] = ((uint64_t)seg << 62) | ((uint64_t)a_loc + (uint64_t)b_loc * (uint64_t)E.nf);
+        }
     }
 }
 
@@ -435,7 +445,8 @@ struct PickOut {
     long long n_below;  // pairs in buckets below B
     double index, prob;
     int B;              // first bucket gathered
-    int pad;
+    int spec_ok;        // the speculative candidate list of the epilogue covers bucket B
+    int B_true, pad2;   // bucket that holds rank lo (before the speculative override)
     unsigned long long n_cand;  // filled by k_lr_gather
     long long n_kept;           // filled by k_lr_thresh
     double disc_thresh;
@@ -445,7 +456,7 @@ struct PickOut {
 // prob and quantile ranks of R/computePairwiseMI.R:352-354 (stats::quantile type 7), then the bucket
 // holding rank lo.  One workgroup: chunked prefix sum over the NBINS counters.
 __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *__restrict__ hist, double lr_retain,
-                                                     double lr_approx, PickOut *__restrict__ out) {
+                                                     double lr_approx, int spec_B, PickOut *__restrict__ out) {
     __shared__ long long part[256];
     __shared__ long long s_lo;
     constexpr int PER = NBINS / 256;
@@ -467,8 +478,10 @@ __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *_
         }
         PickOut o;
         memset(&o, 0, sizeof(o));
+        o.n_cand = out->n_cand;  // speculative candidates appended by the epilogue
         o.n = run;
         o.B = NBINS;
+        o.B_true = NBINS;
         o.disc_thresh = nan("");
         if (run > 0) {
             const double dn = (double)run;
@@ -485,14 +498,34 @@ __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *_
     __syncthreads();
     const long long lo = s_lo;
     if (lo <= 0) return;
+    __shared__ int s_B;
     long long cum = part[t];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         if (cum < lo && cum + loc[k] >= lo) {  // exactly one (thread, k) satisfies this
             out->B = t * PER + k;
+            out->B_true = t * PER + k;
             out->n_below = cum;
+            s_B = t * PER + k;
         }
         cum += loc[k];
+    }
+    __syncthreads();
+    if (spec_B < 0) return;
+    // speculative list = every long-range pair with bucket >= spec_B: usable iff spec_B <= B
+    if (spec_B <= s_B) {
+        cum = part[t];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (t * PER + k == spec_B) {
+                out->B = spec_B;
+                out->n_below = cum;
+                out->spec_ok = 1;
+            }
+            cum += loc[k];
+        }
+    } else if (t == 0) {
+        out->n_cand = 0;  // guess too high: the fallback gather starts from an empty list
     }
 }
 
@@ -717,7 +750,7 @@ struct DevPtrs {
 // scatter and the long-range histogram ride along.  ev[0..2] are recorded before the GEMM, between the two
 // kernels and after the epilogue.  Everything is asynchronous on ctx->stream.
 int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E,
-                    hipEvent_t *ev) {
+                    hipEvent_t *ev, bool epilogue_only = false) {
     if (int rc = c->MIblk.reserve((size_t)nf * nt * 8)) return rc;
     if (int rc = c->hist.reserve((size_t)NBINS * 8)) return rc;
     E.MI = c->MIblk.as<double>();
@@ -738,12 +771,14 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
         LDW_HIP(hipEventRecord(ev[2], c->stream));
         return LDW_OK;
     }
-    if (int rc = c->G.reserve((size_t)RFpad * RTpad * 8)) return rc;
-    LDW_HIP(hipEventRecord(ev[0], c->stream));
-    if (int rc = launch_gemm(c, D.rl_t, RTpad, D.rl_f, RFpad, c->G.as<int64_t>(), c->nlimbs, c->digits.as<int8_t>(),
-                             c->M.as<uint8_t>(), c->Npad, E.lower_only, 0))
-        return rc;
-    LDW_HIP(hipEventRecord(ev[1], c->stream));
+    if (!epilogue_only) {
+        if (int rc = c->G.reserve((size_t)RFpad * RTpad * 8)) return rc;
+        LDW_HIP(hipEventRecord(ev[0], c->stream));
+        if (int rc = launch_gemm(c, D.rl_t, RTpad, D.rl_f, RFpad, c->G.as<int64_t>(), c->nlimbs, c->digits.as<int8_t>(),
+                                 c->M.as<uint8_t>(), c->Npad, E.lower_only, 0))
+            return rc;
+        LDW_HIP(hipEventRecord(ev[1], c->stream));
+    }
     EpiArgs A;
     A.G = c->G.as<int64_t>();
     A.RFpad = RFpad;
@@ -762,7 +797,7 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
     A.E = E;
     hipLaunchKernelGGL(k_mi_epilogue, egrid, dim3(256), 0, c->stream, A, D.perm, ghist);
     LDW_HIP(hipGetLastError());
-    LDW_HIP(hipEventRecord(ev[2], c->stream));
+    if (!epilogue_only) LDW_HIP(hipEventRecord(ev[2], c->stream));
     return LDW_OK;
 }
 
@@ -795,6 +830,8 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     LDW_HIP(hipStreamSynchronize(c->stream));  // pageable H2D copies are complete only after a sync
     DevPtrs D{c->idx_f.as<int32_t>(), c->idx_t.as<int32_t>(), c->rowlist_f.as<int32_t>(), c->rowlist_t.as<int32_t>(),
               c->lrow_f.as<int32_t>(), c->lrow_t.as<int32_t>(), c->perm_f.as<int32_t>()};
+    E.write_dense = 1;
+    E.spec_B = -1;
     return launch_block_mi(c, D, nf, nt, RFpad, RTpad, quirk, E, c->ev);
 }
 
@@ -832,6 +869,10 @@ struct HostBlock {
     int RFpad = 0, RTpad = 0, slot = 0;
     bool diag = false;
     size_t o_idx_f = 0, o_idx_t = 0, o_rl_f = 0, o_rl_t = 0, o_lrow_f = 0, o_lrow_t = 0, o_perm = 0, o_cols = 0, total = 0;
+    // set by submit_block, used by the fallback of finish_block
+    DevPtrs D{};
+    EmitArgs E{};
+    int spec_B = -1;
 };
 
 int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt, const ldw_mi_params *p,
@@ -883,7 +924,20 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     return LDW_OK;
 }
 
-int submit_block(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
+int launch_gather(ldw_ctx *c, const HostBlock &hb, const EmitArgs &E, const SmallLayout &sl) {
+    GatherArgs S;
+    S.MI = c->MIblk.as<double>();
+    S.cols = E.cols;
+    S.nf = (int)hb.nf;
+    S.nt = (int)hb.nt;
+    S.lower_only = E.lower_only;
+    hipLaunchKernelGGL(k_lr_gather, dim3((unsigned)((hb.nt + 15) / 16)), dim3(256), 0, c->stream, S, sl.pick,
+                       c->cand_key.as<uint64_t>(), c->cand_val.as<uint64_t>());
+    LDW_HIP(hipGetLastError());
+    return LDW_OK;
+}
+
+int submit_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
     const int s = hb.slot;
     if (int rc = c->dstage[s].reserve(hb.total)) return rc;
     // the device image of this slot was last read by the block two steps back
@@ -909,39 +963,64 @@ int submit_block(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p, const 
     E.sr_a = c->sr_a.as<int32_t>();
     E.sr_b = c->sr_b.as<int32_t>();
     E.sr_mi = c->sr_mi.as<double>();
+    // Long-range candidates: with a bucket guess from the previous block the epilogue appends them itself and the
+    // dense MI block is neither written nor re-read; without one (first block, histogram engine) the dense block
+    // is written and k_lr_gather collects them once the true bucket is known.
+    hb.spec_B = (do_lr && c->engine == LDW_ENGINE_MFMA) ? c->spec_B_next : -1;
+    const size_t cap = (size_t)hb.nf * hb.nt;  // worst case: every pair of the block
+    if (do_lr) {
+        if (int rc = c->cand_key.reserve(cap * 8)) return rc;
+        if (int rc = c->cand_val.reserve(cap * 8)) return rc;
+    }
+    E.write_dense = hb.spec_B < 0 ? 1 : 0;
+    E.spec_B = hb.spec_B;
+    E.n_cand = &sl.pick->n_cand;
+    E.ckey = c->cand_key.as<uint64_t>();
+    E.cval = c->cand_val.as<uint64_t>();
+    hb.D = D;
+    hb.E = E;
+    LDW_HIP(hipMemsetAsync(sl.pick, 0, sizeof(ldw::PickOut), c->stream));
     hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * 4];
     if (int rc = launch_block_mi(c, D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, ev)) return rc;
     c->n_sr += sr_add;
     if (do_lr) {
         hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, c->stream, c->hist.as<unsigned long long>(),
-                           p->lr_retain_links, p->lr_links_approx, sl.pick);
+                           p->lr_retain_links, p->lr_links_approx, hb.spec_B, sl.pick);
         LDW_HIP(hipGetLastError());
-        // candidate capacity: every pair of the block in the worst case (all MI in one bucket)
-        const size_t cap = (size_t)hb.nf * hb.nt;
-        if (int rc = c->cand_key.reserve(cap * 8)) return rc;
-        if (int rc = c->cand_val.reserve(cap * 8)) return rc;
-        GatherArgs S;
-        S.MI = c->MIblk.as<double>();
-        S.cols = E.cols;
-        S.nf = (int)hb.nf;
-        S.nt = (int)hb.nt;
-        S.lower_only = E.lower_only;
-        hipLaunchKernelGGL(k_lr_gather, dim3((unsigned)((hb.nt + 15) / 16)), dim3(256), 0, c->stream, S, sl.pick,
-                           c->cand_key.as<uint64_t>(), c->cand_val.as<uint64_t>());
-        LDW_HIP(hipGetLastError());
-    } else {
-        LDW_HIP(hipMemsetAsync(sl.pick, 0, sizeof(ldw::PickOut), c->stream));
+        if (hb.spec_B < 0)
+            if (int rc = launch_gather(c, hb, E, sl)) return rc;
     }
     LDW_HIP(hipMemcpyAsync(c->pin_pick, sl.pick, sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
     LDW_HIP(hipEventRecord(c->ev_pick, c->stream));
     return LDW_OK;
 }
 
-int finish_block(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
+int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
     const bool do_lr = !p->sr_only;
     // ---- the one host round trip of the block: the candidate count sizes the sorts ----
     LDW_HIP(hipEventSynchronize(c->ev_pick));
-    const int64_t m = do_lr ? (int64_t)static_cast<ldw::PickOut *>(c->pin_pick)->n_cand : 0;
+    ldw::PickOut *hp = static_cast<ldw::PickOut *>(c->pin_pick);
+    if (do_lr && hb.spec_B >= 0 && hp->n > 0 && !hp->spec_ok) {
+        // the bucket guess was above the true bucket: redo the epilogue with the dense store (G is still intact,
+        // the short-range rows and the histogram are already final) and gather with the true bucket
+        EmitArgs E = hb.E;
+        E.write_dense = 1;
+        E.spec_B = -1;
+        E.keep_sr = 0;
+        E.do_lr = 0;
+        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E,
+                                     &c->ev_pool[(size_t)hb.blk_no * 4], true))
+            return rc;
+        if (int rc = launch_gather(c, hb, E, sl)) return rc;
+        LDW_HIP(hipMemcpyAsync(c->pin_pick, sl.pick, sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+        ++c->spec_misses;
+    }
+    if (do_lr && hp->n > 0) {  // next block's guess: a little below this block's bucket
+        const int margin = hp->B_true / 8 > 2 ? hp->B_true / 8 : 2;
+        c->spec_B_next = hp->B_true - margin > 0 ? hp->B_true - margin : 0;
+    }
+    const int64_t m = do_lr ? (int64_t)hp->n_cand : 0;
     const int64_t nf = hb.nf;
     const char *d = c->dstage[hb.slot].as<char>();
     const int32_t *idx_f = reinterpret_cast<const int32_t *>(d + hb.o_idx_f), *idx_t = reinterpret_cast<const int32_t *>(d + hb.o_idx_t);

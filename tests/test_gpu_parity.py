@@ -348,3 +348,31 @@ def test_c2_full_size_properties(engine):
     assert (a > b).all() and np.all(mi >= stt["disc_thresh"][0])
     key = a.astype(np.int64) + b.astype(np.int64) * 5000
     assert (np.diff(key) > 0).all()                              # reference row order (column-major, a > b)
+
+
+def test_speculative_gather_and_fallback(engine, synth):
+    """From the second block on, the epilogue gathers long-range candidates itself using the previous block's
+    histogram bucket as a guess; a guess that turns out too high must fall back to the dense gather.  Three blocks:
+    same filter twice (guess holds), then keep-everything (true bucket 0 < guess -> fallback)."""
+    _setup(engine, synth)
+    POS, g = synth["POS"], synth["g"]
+    approx = orc.lr_links_approx(POS, g, 20000.0)
+    plan = [(np.arange(0, 200), np.arange(200, 400), 300.0), (np.arange(100, 300), np.arange(300, 500), 300.0),
+            (np.arange(0, 256), np.arange(256, 512), 1e12), (np.arange(0, 300), np.arange(0, 300), 250.0)]
+    engine.links_begin(len(plan))
+    for fi, ti, retain in plan:
+        engine.mi_block_links(fi, ti, lr_retain_links=retain, lr_links_approx=approx)
+    engine.links_end()
+    st = engine.block_stats()
+    a, b, mi = engine.links(1)
+    off = 0
+    for bi, (fi, ti, retain) in enumerate(plan):
+        Mb = c_oracle.mi_block(synth["states"], synth["hdw"], synth["r"], synth["uqe"], fi, ti)
+        bl = orc.block_links(Mb, fi, ti, POS, synth["paint"], g, 20000.0, retain, approx)
+        n = len(bl.lr["MI"])
+        assert st["n_lr_total"][bi] == bl.n_lr_total and st["n_lr_kept"][bi] == n, (bi, st["n_lr_kept"][bi], n)
+        assert np.array_equal(a[off:off + n], bl.lr["a"]) and np.array_equal(b[off:off + n], bl.lr["b"]), bi
+        assert np.abs(mi[off:off + n] - bl.lr["MI"]).max() < MI_TIGHT
+        off += n
+    assert off == len(mi)
+    assert st["n_lr_kept"][2] == st["n_lr_total"][2] > 10 * st["n_lr_kept"][1]   # block 3 kept everything
