@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--nlimbs", type=int, default=0)
     ap.add_argument("--engine", choices=["mfma", "hist"], default="mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
+                                                      "smoke-testing the N > 1 path on a single GPU)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="SNPs per side of the CPU-baseline sample block (0 = auto)")
     return ap.parse_args()
 
@@ -72,8 +74,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":      # every rank shares GPU 0: exercises sharding + gather logic only
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:
@@ -152,7 +159,7 @@ def main():
     ev1.record()
     fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.backend == "gloo" else dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

@@ -46,6 +46,12 @@ def gather_link_tables(local: dict, my_blocks: np.ndarray, counts: dict, nblocks
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    out_dev = local["sr"][2].device
+    # gloo cannot move GPU tensors point to point: stage through the host in that case (CPU tests, or a
+    # multi-process run on one GPU); RCCL ("nccl") exchanges device memory directly over xGMI
+    via_host = world > 1 and dist.get_backend(group) == "gloo" and out_dev.type != "cpu"
+    if via_host:
+        local = {k: tuple(t.cpu() for t in v) for k, v in local.items()}
     dev = local["sr"][2].device
     kinds = ("sr", "lr")
     # 1) everyone learns every block's row counts and owner
@@ -111,5 +117,5 @@ def gather_link_tables(local: dict, my_blocks: np.ndarray, counts: dict, nblocks
                 for j in range(3):
                     segs[j].append(per_rank[rk][k][j][c0:c0 + n])
                 cursor[rk] = c0 + n
-        out[k] = tuple(torch.cat(s) if s else per_rank[0][k][j][:0] for j, s in enumerate(segs))
+        out[k] = tuple((torch.cat(s) if s else per_rank[0][k][j][:0]).to(out_dev) for j, s in enumerate(segs))
     return out
