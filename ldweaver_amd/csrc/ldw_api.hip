@@ -161,32 +161,6 @@ __global__ __launch_bounds__(256) void k_counts_marginals(const uint8_t *__restr
     }
 }
 
-// indicator rows: M[row][s] = 0xFF iff states[snp(row)][s] == state(row); 16 sequences per thread
-__global__ __launch_bounds__(256) void k_fill_rows(const uint8_t *__restrict__ states, int64_t Npad,
-                                                   const int32_t *__restrict__ rowinfo,  // snp*8 + state
-                                                   int64_t R, uint8_t *__restrict__ M) {
-    const int64_t row = blockIdx.x;
-    const int32_t info = rowinfo[row];
-    const int64_t snp = info >> 3;
-    const uint32_t pat = (uint32_t)(info & 7) * 0x01010101u;
-    const uint4 *src = reinterpret_cast<const uint4 *>(states + snp * Npad);
-    uint4 *dst = reinterpret_cast<uint4 *>(M + row * Npad);
-    for (int64_t q = threadIdx.x; q < Npad / 16; q += blockDim.x) {
-        uint4 v = src[q];
-        auto eqmask = [pat](uint32_t x) -> uint32_t {
-            const uint32_t t = x ^ pat;  // zero bytes where equal
-            uint32_t m = ((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t;
-            m = ~(m | 0x7F7F7F7Fu);      // 0x80 where the byte of t is zero
-            return (m >> 7) * 0xFFu;
-        };
-        v.x = eqmask(v.x);
-        v.y = eqmask(v.y);
-        v.z = eqmask(v.z);
-        v.w = eqmask(v.w);
-        dst[q] = v;
-    }
-}
-
 // .ACGTN2num (src/ACGTN2num_parallel.cpp:10-43): zero the reference-allele entry of each 5-column
 __global__ void k_acgtn2num(double *__restrict__ nv, const char *__restrict__ ref, int64_t L) {
     const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -257,7 +231,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     if (!c) return LDW_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    ldw::DevBuf *bufs[] = {&c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->M, &c->row0,
+    ldw::DevBuf *bufs[] = {&c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
                            &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->hist, &c->colcnt, &c->cand_key,
                            &c->cand_val, &c->cand_key2, &c->cand_val2, &c->scratch, &c->small, &c->sr_a, &c->sr_b,
@@ -376,6 +350,7 @@ static int set_dims(ldw_ctx *c, int64_t L, int64_t N) {
     c->L = L;
     c->N = N;
     c->Npad = (N + KSTEP - 1) / KSTEP * KSTEP;
+    c->KW = c->Npad / 64;
     c->rows_ready = false;
     c->have_weights = false;
     c->have_meta = false;
@@ -594,19 +569,17 @@ int ensure_rows(ldw_ctx *c) {
     const int64_t R = c->R;
     if (int rc = c->row0.reserve((size_t)(L + 1) * 4)) return rc;
     if (int rc = c->slot_meta.reserve((size_t)L * 4)) return rc;
-    if (int rc = c->M.reserve((size_t)(R + TILE) * Npad)) return rc;
+    if (int rc = c->Mbits.reserve((size_t)(R + TILE) * c->KW * 8)) return rc;
     if (int rc = c->small.reserve((size_t)(R + 1) * 4)) return rc;
     LDW_HIP(hipMemcpyAsync(c->row0.p, c->h_row0.data(), (size_t)(L + 1) * 4, hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipMemcpyAsync(c->slot_meta.p, meta.data(), (size_t)L * 4, hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipMemcpyAsync(c->slot_pfix.p, spf.data(), (size_t)L * 40, hipMemcpyHostToDevice, c->stream));
     // rows R .. R+TILE-1 stay zero: tile padding of the row lists points at row R
-    LDW_HIP(hipMemsetAsync(c->M.as<uint8_t>() + (size_t)R * Npad, 0, (size_t)TILE * Npad, c->stream));
+    LDW_HIP(hipMemsetAsync(c->Mbits.as<uint64_t>() + (size_t)R * c->KW, 0, (size_t)TILE * c->KW * 8, c->stream));
     if (R > 0) {
         LDW_HIP(hipMemcpyAsync(c->small.p, rowinfo.data(), (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
         LDW_REQUIRE(R < 2147483647LL, LDW_ERR_ARG, "too many indicator rows");
-        hipLaunchKernelGGL(k_fill_rows, dim3((unsigned)R), dim3(256), 0, c->stream, c->states.as<uint8_t>(), Npad,
-                           c->small.as<int32_t>(), R, c->M.as<uint8_t>());
-        LDW_HIP(hipGetLastError());
+        if (int rc = fill_rows_bits(c, c->small.as<int32_t>(), R)) return rc;
     }
     LDW_HIP(hipStreamSynchronize(c->stream));
     c->rows_ready = true;

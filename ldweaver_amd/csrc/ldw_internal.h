@@ -37,7 +37,7 @@ struct DevBuf {
 };
 
 constexpr int TILE = 128;     // GEMM block tile (rows on both sides)
-constexpr int KSTEP = 64;     // bytes of K (sequences) per pipeline stage
+constexpr int KSTEP = 128;    // bytes of K (sequences) per pipeline stage
 constexpr int NBINS = 4096;   // level-1 histogram bins of the lr quantile search
 constexpr double MI_HIST_MAX = 1.75;  // > log(5): upper bound of a 5-state MI with pseudocounts
 
@@ -57,7 +57,8 @@ struct ldw_ctx {
     int engine = LDW_ENGINE_MFMA;
 
     // ---- alignment ----
-    int64_t L = 0, N = 0, Npad = 0;  // Npad: N rounded up to a multiple of KSTEP
+    int64_t L = 0, N = 0, Npad = 0;  // Npad: N rounded up to a multiple of KSTEP (128)
+    int64_t KW = 0;                  // 64-bit words per bit row = Npad / 64
     ldw::DevBuf states;              // uint8 [L][N]
 
     // ---- weights ----
@@ -80,7 +81,7 @@ struct ldw_ctx {
     // ---- row map (built lazily from alignment + weights + meta) ----
     bool rows_ready = false;
     int64_t R = 0;               // number of indicator rows over all SNPs
-    ldw::DevBuf M;               // uint8 [R + TILE][Npad]: 0xFF where the sequence carries the row's state
+    ldw::DevBuf Mbits;           // uint64 [R + TILE][KW]: bit s set where sequence s carries the row's state
     ldw::DevBuf row0;            // int32 [L+1]: first row of each SNP
     ldw::DevBuf slot_meta;       // uint32 [L]: nrows (3 bits) | uq-by-slot (5 bits <<3) | slot states (5 x 3 bits << 8)
     ldw::DevBuf slot_pfix;       // int64 [L][5]: fixed-point marginal of the state in each slot
@@ -123,5 +124,8 @@ int launch_gemm(ldw_ctx *ctx, const int32_t *rowlist_t, int RTpad, const int32_t
                 int lower_only, int accumulate);
 int launch_hist(ldw_ctx *ctx, const int32_t *idx_f, int nf, const int32_t *idx_t, int nt, const int64_t *pfix_state,
                 int quirk, int lower_only, double *MI);
+int launch_gemm_bits(ldw_ctx *ctx, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f, int RFpad, int64_t *G,
+                     int nlimbs, const int8_t *digits, int lower_only);
+int fill_rows_bits(ldw_ctx *ctx, const int32_t *d_rowinfo, int64_t R);
 int check_gpu(ldw_ctx *ctx);
 }  // namespace ldw

@@ -774,8 +774,8 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
     if (!epilogue_only) {
         if (int rc = c->G.reserve((size_t)RFpad * RTpad * 8)) return rc;
         LDW_HIP(hipEventRecord(ev[0], c->stream));
-        if (int rc = launch_gemm(c, D.rl_t, RTpad, D.rl_f, RFpad, c->G.as<int64_t>(), c->nlimbs, c->digits.as<int8_t>(),
-                                 c->M.as<uint8_t>(), c->Npad, E.lower_only, 0))
+        if (int rc = launch_gemm_bits(c, D.rl_t, RTpad, D.rl_f, RFpad, c->G.as<int64_t>(), c->nlimbs,
+                                      c->digits.as<int8_t>(), E.lower_only))
             return rc;
         LDW_HIP(hipEventRecord(ev[1], c->stream));
     }
@@ -1125,9 +1125,8 @@ int ldw_joint_tables(ldw_ctx *c, const int32_t *pair_a, const int32_t *pair_b, i
         for (int pass = 0; pass < 2 && rc == LDW_OK; ++pass) {
             int64_t *host_out = pass == 0 ? counts_out : fixed_out;
             if (!host_out) continue;
-            rc = launch_gemm(c, c->rowlist_t.as<int32_t>(), RTpad, c->rowlist_f.as<int32_t>(), RFpad, c->G.as<int64_t>(),
-                             pass == 0 ? 1 : c->nlimbs, pass == 0 ? d_ones.as<int8_t>() : c->digits.as<int8_t>(),
-                             c->M.as<uint8_t>(), c->Npad, 0, 0);
+            rc = launch_gemm_bits(c, c->rowlist_t.as<int32_t>(), RTpad, c->rowlist_f.as<int32_t>(), RFpad, c->G.as<int64_t>(),
+                                  pass == 0 ? 1 : c->nlimbs, pass == 0 ? d_ones.as<int8_t>() : c->digits.as<int8_t>(), 0);
             if (rc) break;
             hipLaunchKernelGGL(k_tables, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->G.as<int64_t>(), RFpad,
                                c->idx_f.as<int32_t>(), c->lrow_f.as<int32_t>(), c->idx_t.as<int32_t>(),
