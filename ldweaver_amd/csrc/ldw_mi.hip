@@ -132,7 +132,10 @@ struct EmitArgs {
     const ColInfo *cols;   // null: dense store only (ldw_mi_block)
     int nf, lower_only, keep_sr, do_lr;
     int write_dense;       // store the dense MI block (needed by k_lr_gather; off when the gather is speculative)
-    int spec_B;            // >= 0: append long-range pairs with bucket >= spec_B to the candidate list right here
+    int spec_B;            // >= 0: append long-range pairs with bucket >= spec_B to the candidate list right here,
+                           //       and histogram ONLY those (the pairs below are counted analytically)
+    int any_sr;            // 0: no pair of this block is short-range (skip the interval tests)
+    double spec_lo;        // lower edge of bucket spec_B minus a guard: cheap reject before the bucket arithmetic
     int64_t sr_base;
     int32_t *sr_a, *sr_b;
     double *sr_mi;
@@ -146,7 +149,7 @@ __device__ __forceinline__ void emit_pair(const EmitArgs &E, const ColInfo &c, i
     if (!E.cols) return;
     const int seg = pair_seg(a_loc, b_loc, E.lower_only);
     if (seg < 0) return;
-    if (col_is_sr(c, a_loc)) {
+    if (E.any_sr && col_is_sr(c, a_loc)) {
         if (E.keep_sr) {
             const int64_t dst = E.sr_base + (seg == 0 ? c.off_u + col_count(c, 0, a_loc) : c.off_l + col_count(c, b_loc + 1, a_loc));
             E.sr_a[dst] = sa;
@@ -154,12 +157,19 @@ __device__ __forceinline__ void emit_pair(const EmitArgs &E, const ColInfo &c, i
             E.sr_mi[dst] = mi;
         }
     } else if (E.do_lr) {
-        const int bk = mi_bucket(mi);
-        atomicAdd(&sh_hist[bk], 1u);
-        if (E.spec_B >= 0 && bk >= E.spec_B) {
-            const unsigned long long p = atomicAdd(E.n_cand, 1ull);
-            E.ckey[p] = f64_key(mi);
-            E.cval[p] = ((uint64_t)seg << 62) | ((uint64_t)a_loc + (uint64_t)b_loc * (uint64_t)E.nf);
+        if (E.spec_B >= 0) {
+            // speculative mode: only the (rare) pairs at or above the guessed bucket are histogrammed and appended
+            if (mi >= E.spec_lo) {
+                const int bk = mi_bucket(mi);
+                if (bk >= E.spec_B) {
+                    atomicAdd(&sh_hist[bk], 1u);
+                    const unsigned long long p = atomicAdd(E.n_cand, 1ull);
+                    E.ckey[p] = f64_key(mi);
+                    E.cval[p] = ((uint64_t)seg << 62) | ((uint64_t)a_loc + (uint64_t)b_loc * (uint64_t)E.nf);
+                }
+            }
+        } else {
+            atomicAdd(&sh_hist[mi_bucket(mi)], 1u);
         }
     }
 }
@@ -455,8 +465,11 @@ struct PickOut {
 
 // prob and quantile ranks of R/computePairwiseMI.R:352-354 (stats::quantile type 7), then the bucket
 // holding rank lo.  One workgroup: chunked prefix sum over the NBINS counters.
+// In speculative mode (spec_B >= 0) the histogram only holds buckets >= spec_B; n_total is the block's long-range
+// pair count known to the host, and everything below spec_B is lumped into one virtual bucket.
 __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *__restrict__ hist, double lr_retain,
-                                                     double lr_approx, int spec_B, PickOut *__restrict__ out) {
+                                                     double lr_approx, int spec_B, long long n_total,
+                                                     PickOut *__restrict__ out) {
     __shared__ long long part[256];
     __shared__ long long s_lo;
     constexpr int PER = NBINS / 256;
@@ -470,7 +483,10 @@ __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *_
     part[t] = sum;
     __syncthreads();
     if (t == 0) {
-        long long run = 0;
+        long long above = 0;
+        for (int i = 0; i < 256; ++i) above += part[i];
+        // speculative mode: pairs below spec_B were not histogrammed
+        long long run = spec_B >= 0 ? n_total - above : 0;
         for (int i = 0; i < 256; ++i) {
             const long long v = part[i];
             part[i] = run;
@@ -512,8 +528,9 @@ __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *_
     }
     __syncthreads();
     if (spec_B < 0) return;
-    // speculative list = every long-range pair with bucket >= spec_B: usable iff spec_B <= B
-    if (spec_B <= s_B) {
+    // speculative list = every long-range pair with bucket >= spec_B: usable iff rank lo lies at or above spec_B,
+    // i.e. iff some bucket >= spec_B was found to hold it (the unhistogrammed mass below spec_B precedes part[0])
+    if (lo > part[0]) {
         cum = part[t];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -865,7 +882,7 @@ void links_layout(ldw_ctx *c, SmallLayout &sl) {
 // ---- block i:  prep (pure host, into pinned memory)  ->  submit (upload + kernels up to the candidate gather)
 // ---- ->  finish (the one host round trip: candidate count, then sorts / threshold / append)
 struct HostBlock {
-    int64_t nf = 0, nt = 0, n_sr_blk = 0, blk_no = 0;
+    int64_t nf = 0, nt = 0, n_sr_blk = 0, n_lr_total = 0, blk_no = 0;
     int RFpad = 0, RTpad = 0, slot = 0;
     bool diag = false;
     size_t o_idx_f = 0, o_idx_t = 0, o_rl_f = 0, o_rl_t = 0, o_lrow_f = 0, o_lrow_t = 0, o_perm = 0, o_cols = 0, total = 0;
@@ -894,6 +911,7 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     if (int rc = build_side(c, to_idx, nt, rl_t, lr_t, hb.RTpad)) return rc;
     std::vector<ColInfo> cols;
     if (int rc = build_cols(c, from_idx, nf, to_idx, nt, hb.diag, p->sr_dist, cols, hb.n_sr_blk)) return rc;
+    hb.n_lr_total = (hb.diag ? nf * (nf - 1) / 2 : nf * nt - std::min(nf, nt)) - hb.n_sr_blk;
     auto al = [](size_t x) { return (x + 63) / 64 * 64; };
     size_t o = 0;
     hb.o_idx_f = o; o = al(o + (size_t)nf * 4);
@@ -974,6 +992,8 @@ int submit_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
     }
     E.write_dense = hb.spec_B < 0 ? 1 : 0;
     E.spec_B = hb.spec_B;
+    E.spec_lo = hb.spec_B * (MI_HIST_MAX / (double)NBINS) - 1e-9;
+    E.any_sr = hb.n_sr_blk > 0 ? 1 : 0;
     E.n_cand = &sl.pick->n_cand;
     E.ckey = c->cand_key.as<uint64_t>();
     E.cval = c->cand_val.as<uint64_t>();
@@ -985,7 +1005,7 @@ int submit_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
     c->n_sr += sr_add;
     if (do_lr) {
         hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, c->stream, c->hist.as<unsigned long long>(),
-                           p->lr_retain_links, p->lr_links_approx, hb.spec_B, sl.pick);
+                           p->lr_retain_links, p->lr_links_approx, hb.spec_B, (long long)hb.n_lr_total, sl.pick);
         LDW_HIP(hipGetLastError());
         if (hb.spec_B < 0)
             if (int rc = launch_gather(c, hb, E, sl)) return rc;
@@ -1001,16 +1021,20 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
     LDW_HIP(hipEventSynchronize(c->ev_pick));
     ldw::PickOut *hp = static_cast<ldw::PickOut *>(c->pin_pick);
     if (do_lr && hb.spec_B >= 0 && hp->n > 0 && !hp->spec_ok) {
-        // the bucket guess was above the true bucket: redo the epilogue with the dense store (G is still intact,
-        // the short-range rows and the histogram are already final) and gather with the true bucket
+        // the bucket guess was above the true bucket: redo the epilogue non-speculatively (G is still intact, the
+        // short-range rows are already final): full histogram, dense store, then pick and gather with the true bucket
         EmitArgs E = hb.E;
         E.write_dense = 1;
         E.spec_B = -1;
         E.keep_sr = 0;
-        E.do_lr = 0;
+        LDW_HIP(hipMemsetAsync(c->hist.p, 0, (size_t)NBINS * 8, c->stream));
+        LDW_HIP(hipMemsetAsync(sl.pick, 0, sizeof(ldw::PickOut), c->stream));
         if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E,
                                      &c->ev_pool[(size_t)hb.blk_no * 4], true))
             return rc;
+        hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, c->stream, c->hist.as<unsigned long long>(),
+                           p->lr_retain_links, p->lr_links_approx, -1, 0LL, sl.pick);
+        LDW_HIP(hipGetLastError());
         if (int rc = launch_gather(c, hb, E, sl)) return rc;
         LDW_HIP(hipMemcpyAsync(c->pin_pick, sl.pick, sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
         LDW_HIP(hipStreamSynchronize(c->stream));
