@@ -177,31 +177,54 @@ def main():
             my_pairs += nf * (nf - 1) // 2 if (fs == ts and fe == te) else nf * nt - min(nf, nt)
         gemm_avg_ms = tim["gemm_ms"] / n_launch
         epi_avg_ms = tim["epilogue_ms"] / n_launch
-        alg_flops_per_launch = 50.0 * N * my_pairs / max(1, len(my_blocks))       # 50*N MAC-flops per pair
-        alg_bytes_per_launch = (L * N / max(1, nblocks) + 8.0 * my_pairs / max(1, len(my_blocks)))
+        nb_mine = max(1, len(my_blocks))
+        alg_flops_per_launch = 50.0 * N * my_pairs / nb_mine       # 50*N MAC-flops per pair
+        # int8 ops the GEMM actually executes: 2 * (to-rows x from-rows, padded to 128) * Npad * limbs, tiles above
+        # the diagonal of a diagonal block skipped.  One indicator row per present state minus one per SNP.
+        nrow = np.maximum(r.astype(np.int64) - 1, 0)
+        crow = np.concatenate([[0], np.cumsum(nrow)])
+        Npad = (N + 127) // 128 * 128
+        J = args.nlimbs or 5
+        exec_ops = 0.0
+        for fs, fe, ts, te in my_blocks.tolist():
+            tf = -(-int(crow[fe] - crow[fs - 1]) // 128)
+            tt = -(-int(crow[te] - crow[ts - 1]) // 128)
+            tiles = tf * (tf + 1) // 2 if (fs == ts and fe == te) else tf * tt
+            exec_ops += 2.0 * tiles * 128 * 128 * Npad * J
+        exec_per_launch = exec_ops / nb_mine
         i8_peak = 5000.0  # TOP/s dense (MI355X_MICROARCH.md: i8 = 2 x bf16 per clock, bf16 ~2.5 PF dense)
-        roof = dict(bound="mfma", kernel="gemm_limb_kernel", achieved=alg_flops_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms else None,
-                    peak=i8_peak, unit="TFLOP/s", traffic=None,
+        achieved = alg_flops_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms else None
+        roof = dict(bound="mfma", kernel=f"gemm_bits_kernel<{J}>", achieved=achieved, peak=i8_peak, unit="TFLOP/s",
+                    frac=achieved / i8_peak if achieved else None, traffic=None,
                     avg_launch_ms=gemm_avg_ms, launches=n_launch,
-                    note="achieved = ALGORITHMIC 50*N flops/pair (SURVEY 8d) x pairs per launch / avg launch time of the co-occurrence GEMM; "
-                         "the kernel executes fewer ops than that (most-frequent-state rows dropped, J int8 limbs): see DESIGN.md")
-        roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
+                    executed_TOPs=exec_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms else None,
+                    note="achieved = ALGORITHMIC 50*N flops/pair (SURVEY 8d) x pairs per launch / avg launch time (HIP events) of the "
+                         "co-occurrence GEMM; the kernel EXECUTES fewer ops (one indicator row per minor state, 5 int8 limbs): "
+                         "executed_TOPs / peak = executed_frac is the matrix-core utilisation")
+        roof["executed_frac"] = roof["executed_TOPs"] / i8_peak if roof["executed_TOPs"] else None
+        # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (rocprofv3 cannot run inside
+        # the bench); only quoted for the configuration they were collected on
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and (L, N, world, J) == (100_000, 5_000, 1, 5):
+            roof["traffic"] = json.load(open(tpath)).get("gemm_bits_kernel<5>", {}).get("hbm_bytes_per_launch_corrected")
+            roof["traffic_source"] = "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
         roof["epilogue_avg_launch_ms"] = epi_avg_ms
         roof["dominant_stage"] = stage
         roof["hbm_alg_GBps_whole_step"] = (L * N + 8.0 * pairs) / (dt / K) / 1e9
         roof["hbm_frac_whole_step"] = roof["hbm_alg_GBps_whole_step"] / 8000.0
         out = dict(metric="MI SNP-pairs/sec", value=value, unit="pairs/s", n_gpus=world, steps=K, warmup=args.warmup,
-                   ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="i8->i64 counts, f64 MI",
+                   ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="i8",
                    data="synthetic",
                    config=dict(workload=f"synthetic {L} SNPs x {N} seqs, all {nblocks} block pairs of make_blocks(max_blk_sz={args.max_blk_sz}), "
                                         f"sr_dist=20000, lr_retain_links=1e6, sr+lr link tables on rank 0",
                                L=L, N=N, pairs=int(pairs), engine=args.engine, nlimbs=args.nlimbs or 5,
+                               arithmetic="joint sums: int8 MFMA -> exact int64 fixed point; MI epilogue: f64",
                                parallelism=f"pair-space blocks over {world} GPU(s)"),
                    roofline=roof,
                    stages_ms_per_step={k: v / K for k, v in tim.items()},
                    links=result, hamming_weights_s=hamming_s, hamming_gemm_ms=hamming_kernel_ms, setup_s=setup_s)
         if not args.no_cpu_baseline:
-            sample = args.cpu_sample or max(200, min(1000, L // 2))
+            sample = args.cpu_sample or max(200, min(2000, L // 2))   # ~10-30 s of host work at N = 5000
             st_np = states[: 2 * sample].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(st_np, hdw, r[: 2 * sample], uqe[: 2 * sample], N, sample)
         print(json.dumps(out))
