@@ -222,7 +222,7 @@ def main():
                                parallelism=f"pair-space blocks over {world} GPU(s)"),
                    roofline=roof,
                    stages_ms_per_step={k: v / K for k, v in tim.items()},
-                   links=result, hamming_weights_s=hamming_s, hamming_gemm_ms=hamming_kernel_ms, setup_s=setup_s)
+                   links=result, counters=eng.counters(), hamming_weights_s=hamming_s, hamming_gemm_ms=hamming_kernel_ms, setup_s=setup_s)
         if not args.no_cpu_baseline:
             sample = args.cpu_sample or max(200, min(2000, L // 2))   # ~10-30 s of host work at N = 5000
             st_np = states[: 2 * sample].cpu().numpy()

@@ -62,6 +62,10 @@ int ldw_ctx_sync(ldw_ctx *ctx);
  * HIP events on the context's stream: [0] gemm, [1] epilogue, [2] selection, [3] total */
 int ldw_ctx_last_timing(ldw_ctx *ctx, double ms_out[4]);
 
+/* diagnostics: out[0] = blocks whose speculative long-range gather had to fall back to the dense pass since the
+ * context was created, out[1..3] reserved */
+int ldw_ctx_counters(ldw_ctx *ctx, int64_t out[4]);
+
 /* ---- (1) .ACGTN2num  — src/ACGTN2num_parallel.cpp:10-43, R/RcppExports.R:4-6 ------------ */
 /* nv: 5 x L doubles, column-major, mutated IN PLACE (host memory, as R hands it over);
  * ref: L bytes = first character of each element of `cv`; ncores is accepted and ignored. */

@@ -43,6 +43,7 @@ _SIGS = {
     "ldw_ctx_set_stream": (C.c_int, [_p, _p]),
     "ldw_ctx_sync": (C.c_int, [_p]),
     "ldw_ctx_last_timing": (C.c_int, [_p, _p]),
+    "ldw_ctx_counters": (C.c_int, [_p, _p]),
     "ldw_acgtn2num": (C.c_int, [_p, _p, _p, _i64, C.c_int]),
     "ldw_acgtn2num_dev": (C.c_int, [_p, _p, _p, _i64]),
     "ldw_fast_hadamard": (C.c_int, [_p] + [_p] * 8 + [_i64, C.c_int]),

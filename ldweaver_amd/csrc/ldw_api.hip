@@ -40,9 +40,17 @@ int DevBuf::reserve(size_t bytes) {
 int DevBuf::reserve_keep(size_t bytes, size_t used, hipStream_t s) {
     if (bytes <= cap && p) return LDW_OK;
     size_t want = bytes < 256 ? 256 : bytes;
-    if (want < cap * 2) want = cap * 2;  // geometric growth for the link tables
+    if (want < cap + cap / 2) want = cap + cap / 2;  // geometric growth for the link tables
     void *np = nullptr;
-    LDW_HIP(hipMalloc(&np, want));
+    {
+        hipError_t e = hipMalloc(&np, want);
+        if (e != hipSuccess) {
+            size_t fr = 0, tot = 0;
+            (void)hipMemGetInfo(&fr, &tot);
+            set_error("hipMalloc of %zu bytes failed (%s); %zu of %zu bytes free on the device", want, hipGetErrorString(e), fr, tot);
+            return LDW_ERR_HIP;
+        }
+    }
     if (p && used) {
         LDW_HIP(hipMemcpyAsync(np, p, used, hipMemcpyDeviceToDevice, s));
         LDW_HIP(hipStreamSynchronize(s));
@@ -277,6 +285,13 @@ int ldw_ctx_sync(ldw_ctx *c) {
 int ldw_ctx_last_timing(ldw_ctx *c, double ms_out[4]) {
     LDW_REQUIRE(c && ms_out, LDW_ERR_ARG, "ldw_ctx_last_timing: null argument");
     for (int i = 0; i < 4; ++i) ms_out[i] = c->last_ms[i];
+    return LDW_OK;
+}
+
+int ldw_ctx_counters(ldw_ctx *c, int64_t out[4]) {
+    LDW_REQUIRE(c && out, LDW_ERR_ARG, "ldw_ctx_counters: null argument");
+    out[0] = c->spec_misses;
+    out[1] = out[2] = out[3] = 0;
     return LDW_OK;
 }
 

@@ -39,7 +39,6 @@ struct DevBuf {
 constexpr int TILE = 128;     // GEMM block tile (rows on both sides)
 constexpr int KSTEP = 128;    // bytes of K (sequences) per pipeline stage
 constexpr int NBINS = 4096;   // level-1 histogram bins of the lr quantile search
-constexpr double MI_HIST_MAX = 1.75;  // > log(5): upper bound of a 5-state MI with pseudocounts
 
 struct BlockStat {
     int64_t n_lr_total = 0, n_lr_kept = 0, n_sr = 0;
@@ -111,7 +110,7 @@ struct ldw_ctx {
     void *pin_pick = nullptr;            // pinned landing zone of the per-block PickOut
     hipEvent_t ev_pick = nullptr;
     std::vector<hipEvent_t> ev_pool;     // 4 timing events per block
-    int spec_B_next = -1;                // bucket guess for the speculative long-range gather of the next block
+    int spec_B_next[2] = {-1, -1};       // bucket guess for the speculative long-range gather: [off-diagonal, diagonal]
     int64_t spec_misses = 0;
     std::vector<ldw::BlockStat> stats;
 };

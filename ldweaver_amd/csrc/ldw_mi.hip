@@ -45,9 +45,23 @@ __host__ __device__ __forceinline__ double key_f64(uint64_t k) {
     return v;
 }
 
-__device__ __forceinline__ int mi_bucket(double mi) {
-    int b = (int)floor(mi * ((double)NBINS / MI_HIST_MAX));
+// Histogram bucket of an MI value: monotone non-decreasing in mi, 128 buckets per octave (0.5 % wide) from 2^-20
+// up, taken straight from the IEEE-754 bits (exponent + 7 mantissa bits) — no floating-point arithmetic.  Values
+// below 2^-20 (and negatives, which quirk Q1 can produce) fall in bucket 0.
+constexpr int BUCKET_OFF = (1023 - 20) << 7;
+__host__ __device__ __forceinline__ int mi_bucket(double mi) {
+    long long u;
+    memcpy(&u, &mi, 8);
+    if (u <= 0) return 0;  // -x, -0, +0
+    const int b = (int)(u >> 45) - BUCKET_OFF;
     return b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
+}
+// lower edge of bucket B (B >= 1)
+__host__ __device__ __forceinline__ double bucket_lo(int B) {
+    const long long u = (long long)(B + BUCKET_OFF) << 45;
+    double v;
+    memcpy(&v, &u, 8);
+    return v;
 }
 
 // Short-range partners of one to-side SNP: up to three disjoint, ascending index intervals [s,e) of the
@@ -557,7 +571,7 @@ __global__ __launch_bounds__(256) void k_lr_gather(GatherArgs S, PickOut *__rest
                                                    uint64_t *__restrict__ cval) {
     const int B = pick->B;
     if (B >= NBINS) return;
-    const double lo_val = (double)B * (MI_HIST_MAX / (double)NBINS);
+    const double lo_val = B > 0 ? bucket_lo(B) : 0.0;
     const int b0 = blockIdx.x * 16;
     for (int bb = 0; bb < 16; ++bb) {
         const int b_loc = b0 + bb;
@@ -568,7 +582,7 @@ __global__ __launch_bounds__(256) void k_lr_gather(GatherArgs S, PickOut *__rest
             const int seg = pair_seg(a_loc, b_loc, S.lower_only);
             if (seg < 0) continue;  // also skips the never-written part of a diagonal block
             const double mi = col[a_loc];
-            if (B > 0 && mi < lo_val - 1e-9) continue;  // cheap reject; the bucket test below decides
+            if (B > 0 && mi < lo_val) continue;  // cheap reject; the bucket test below decides
             if (col_is_sr(c, a_loc)) continue;
             if (mi_bucket(mi) < B) continue;
             const unsigned long long p = atomicAdd(&pick->n_cand, 1ull);
@@ -687,6 +701,25 @@ int build_cols(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
         LDW_REQUIRE(a == 0 || pf[a] >= pf[a - 1], LDW_ERR_ARG, "from-side SNP list must be ascending in POS (position %lld)", (long long)a);
     }
     cols.resize((size_t)nt);
+    {   // quick reject: when the two position ranges are farther apart than sr_dist both directly and around the
+        // origin, no pair of the block is short-range (true for most off-diagonal blocks)
+        double pt_min = (double)c->h_POS[to_idx[0]], pt_max = pt_min;
+        for (int64_t b = 1; b < nt; ++b) {
+            const double v = (double)c->h_POS[to_idx[b]];
+            pt_min = v < pt_min ? v : pt_min;
+            pt_max = v > pt_max ? v : pt_max;
+        }
+        const double pf_min = pf.front(), pf_max = pf.back();
+        const bool apart = (pt_min - pf_max > sr_dist && pf_min + g - pt_max > sr_dist) ||
+                           (pf_min - pt_max > sr_dist && pt_min + g - pf_max > sr_dist);
+        if (apart && 2 * sr_dist < g) {
+            ColInfo z;
+            memset(&z, 0, sizeof(z));
+            std::fill(cols.begin(), cols.end(), z);
+            n_sr_blk = 0;
+            return LDW_OK;
+        }
+    }
     int64_t total_u = 0, total_l = 0;
     std::vector<int32_t> cu((size_t)nt), cl((size_t)nt);
     for (int64_t b = 0; b < nt; ++b) {
@@ -984,7 +1017,7 @@ int submit_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
     // Long-range candidates: with a bucket guess from the previous block the epilogue appends them itself and the
     // dense MI block is neither written nor re-read; without one (first block, histogram engine) the dense block
     // is written and k_lr_gather collects them once the true bucket is known.
-    hb.spec_B = (do_lr && c->engine == LDW_ENGINE_MFMA) ? c->spec_B_next : -1;
+    hb.spec_B = (do_lr && c->engine == LDW_ENGINE_MFMA) ? c->spec_B_next[hb.diag ? 1 : 0] : -1;
     const size_t cap = (size_t)hb.nf * hb.nt;  // worst case: every pair of the block
     if (do_lr) {
         if (int rc = c->cand_key.reserve(cap * 8)) return rc;
@@ -992,7 +1025,7 @@ int submit_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
     }
     E.write_dense = hb.spec_B < 0 ? 1 : 0;
     E.spec_B = hb.spec_B;
-    E.spec_lo = hb.spec_B * (MI_HIST_MAX / (double)NBINS) - 1e-9;
+    E.spec_lo = hb.spec_B > 0 ? bucket_lo(hb.spec_B) : -1e300;
     E.any_sr = hb.n_sr_blk > 0 ? 1 : 0;
     E.n_cand = &sl.pick->n_cand;
     E.ckey = c->cand_key.as<uint64_t>();
@@ -1011,6 +1044,8 @@ int submit_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
             if (int rc = launch_gather(c, hb, E, sl)) return rc;
     }
     LDW_HIP(hipMemcpyAsync(c->pin_pick, sl.pick, sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
+    // exact number of long-range rows kept by all EARLIER blocks (this block's append has not run yet)
+    LDW_HIP(hipMemcpyAsync(static_cast<char *>(c->pin_pick) + sizeof(ldw::PickOut), sl.lr_count, 8, hipMemcpyDeviceToHost, c->stream));
     LDW_HIP(hipEventRecord(c->ev_pick, c->stream));
     return LDW_OK;
 }
@@ -1041,10 +1076,17 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
         ++c->spec_misses;
     }
     if (do_lr && hp->n > 0) {  // next block's guess: a little below this block's bucket
-        const int margin = hp->B_true / 8 > 2 ? hp->B_true / 8 : 2;
-        c->spec_B_next = hp->B_true - margin > 0 ? hp->B_true - margin : 0;
+        // buckets are 0.5 % wide: guess ~5 % below the threshold of the last block of the same kind (diagonal blocks
+        // lose their closest pairs to the short-range table and sit ~8 % lower than off-diagonal ones)
+        const int margin = 10;
+        c->spec_B_next[hb.diag ? 1 : 0] = hp->B_true - margin > 0 ? hp->B_true - margin : 0;
     }
     const int64_t m = do_lr ? (int64_t)hp->n_cand : 0;
+    {   // tighten the upper bound on the long-range row count: exact up to the previous block + this block's candidates
+        int64_t exact_before = 0;
+        memcpy(&exact_before, static_cast<char *>(c->pin_pick) + sizeof(ldw::PickOut), 8);
+        c->n_lr = exact_before;
+    }
     const int64_t nf = hb.nf;
     const char *d = c->dstage[hb.slot].as<char>();
     const int32_t *idx_f = reinterpret_cast<const int32_t *>(d + hb.o_idx_f), *idx_t = reinterpret_cast<const int32_t *>(d + hb.o_idx_t);
@@ -1275,6 +1317,20 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         for (int32_t k = ts; k <= te; ++k) ti[k - ts] = k - 1;
         return LDW_OK;
     };
+    if (p->keep_sr && nblocks > 200) {  // big runs: size the short-range table once (its row count follows from POS alone)
+                                        // instead of growing it geometrically, which would double-buffer tens of GB
+        int64_t total_sr = 0;
+        std::vector<ColInfo> cols;
+        for (int64_t b = 0; b < nblocks; ++b) {
+            if (int rc = fill(b)) return rc;
+            int64_t n_sr_blk = 0;
+            const bool diag = same_list(fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size());
+            if (int rc = build_cols(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), diag, p->sr_dist, cols, n_sr_blk))
+                return rc;
+            total_sr += n_sr_blk;
+        }
+        if (int rc = ensure_links_capacity(c, total_sr, 0)) return rc;
+    }
     // software pipeline: while the GPU works on block b, the host prepares block b+1
     HostBlock hb[2];
     if (int rc = fill(0)) return rc;

@@ -51,6 +51,11 @@ class Engine:
         L.check(L.lib().ldw_ctx_last_timing(self._ctx, L.ptr(t)))
         return dict(gemm_ms=t[0], epilogue_ms=t[1], select_ms=t[2], total_ms=t[3])
 
+    def counters(self):
+        v = np.zeros(4, dtype=np.int64)
+        L.check(L.lib().ldw_ctx_counters(self._ctx, L.ptr(v)))
+        return dict(spec_misses=int(v[0]))
+
     def set_engine(self, engine: int):
         L.check(L.lib().ldw_set_engine(self._ctx, int(engine)))
 

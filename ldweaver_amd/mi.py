@@ -42,10 +42,20 @@ def lr_links_approx(POS, g, sr_dist, seed: int = 1988) -> float:
     snp_subset = min(nsnp, int(round(nsnp * 0.1)))
     idx = rcompat.RRandom(seed).sample(nsnp, snp_subset) - 1
     total = 0
-    step = max(1, 4_000_000 // nsnp)
-    for lo in range(0, snp_subset, step):
-        x = POS[idx[lo:lo + step]]
-        total += int((rcompat.circ_len(x[:, None], POS[None, :], g) > sr_dist).sum())
+    gi, si = float(g), float(sr_dist)
+    if nsnp > 2000 and np.all(np.diff(POS) >= 0) and gi == int(gi) and np.all(POS == np.rint(POS)) and 2 * si < gi:
+        # POS ascending, everything integral: len > sr_dist  <=>  the partner is outside [x - sr, x + sr] and outside
+        # the two wrap-around windows; count the complement with binary searches (identical result, O(k log n))
+        x = POS[idx]
+        centre = np.searchsorted(POS, x + si, "right") - np.searchsorted(POS, x - si, "left")
+        wrap_lo = np.searchsorted(POS, x + si - gi, "right")            # partners <= x + sr - g
+        wrap_hi = nsnp - np.searchsorted(POS, x - si + gi, "left")      # partners >= x - sr + g
+        total = int((nsnp - centre - wrap_lo - wrap_hi).sum())
+    else:
+        step = max(1, 4_000_000 // nsnp)
+        for lo in range(0, snp_subset, step):
+            x = POS[idx[lo:lo + step]]
+            total += int((rcompat.circ_len(x[:, None], POS[None, :], g) > sr_dist).sum())
     return total / snp_subset * nsnp / 2
 
 
