@@ -65,6 +65,10 @@ class Engine:
         if _is_torch(states):
             assert states.dtype.__str__() == "torch.uint8" and states.dim() == 2 and states.is_contiguous()
             Ls, Ns = states.shape
+            if states.is_cuda:
+                # the library reads the tensor on ITS stream: make sure whatever torch stream produced it is done
+                import torch
+                torch.cuda.synchronize(states.device)
             L.check(L.lib().ldw_set_alignment(self._ctx, L.ptr(states), Ls, Ns, 1 if states.is_cuda else 0))
         else:
             st = L.as_c(states, np.uint8)

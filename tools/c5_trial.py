@@ -24,3 +24,4 @@ st = eng.block_stats()
 pairs = L * (L - 1) // 2
 print(f"blocks {len(blocks)} step {dt:.2f} s  {pairs / dt:.3e} pairs/s  sr rows {eng.links_count(0)}  lr rows {eng.links_count(1)}  timing {eng.last_timing()}")
 print("mem GB", torch.cuda.max_memory_allocated() / 1e9)
+print("thresh", np.round(st["disc_thresh"], 6).tolist()); print("kept", st["n_lr_kept"].tolist()); print("nlr", st["n_lr_total"].tolist()); print(eng.counters())
