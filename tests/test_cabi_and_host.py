@@ -163,3 +163,12 @@ def test_append_table_format(tmp_path):
     MI.append_table(str(p), [np.array([1, 2]), np.array([100000.0, 20000.0]), np.array([0.123456789012345678, 1e-5])])
     MI.append_table(str(p), [np.array([3]), np.array([5.0]), np.array([0.5])])
     assert p.read_text() == "1\t1e+05\t0.123456789012346\n2\t20000\t1e-05\n3\t5\t0.5\n"
+
+
+def test_lr_links_approx_fast_path_equals_brute_force():
+    """Above 2000 SNPs the host uses binary searches on the ascending POS instead of the reference's O(n^2/10) scan:
+    same seeded sample, identical count (also across the origin)."""
+    rng = np.random.default_rng(8)
+    for n, g, sr in ((5000, 2_221_315, 20000), (3000, 60_001, 20000), (2500, 50_000, 12000)):
+        POS = np.sort(rng.choice(g, n, replace=False) + 1)
+        assert MI.lr_links_approx(POS, g, sr) == orc.lr_links_approx(POS, g, sr)
