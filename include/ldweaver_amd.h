@@ -88,6 +88,11 @@ int ldw_set_alignment(ldw_ctx *ctx, const uint8_t *states, int64_t L, int64_t N,
  * becomes the context's alignment.  Also returns the 5 x n_pos ACGTN_table (may be NULL). */
 int ldw_encode_alignment(ldw_ctx *ctx, const char *chars, int64_t N, int64_t L_total, const int32_t *pos,
                          int64_t n_pos, int32_t *acgtn_table_out);
+/* First half of `extractAlnParam` (src/getACGTNsites.cpp:47-90): upload the raw alignment chars [N][L_total]
+ * (they stay resident: a following ldw_encode_alignment may pass chars = NULL) and count A/a, C/c, G/g, T/t and
+ * "everything else" per column: allele_counts_out is 5 x L_total int32, column-major like `allele_counts`.
+ * The SNP filter itself (:104-166) is O(L_total) host logic on these counts. */
+int ldw_alignment_scan(ldw_ctx *ctx, const char *chars, int64_t N, int64_t L_total, int32_t *allele_counts_out);
 /* per-SNP state counts (5 x L, column-major like ACGTN_table) of the resident alignment */
 int ldw_state_counts(ldw_ctx *ctx, int32_t *counts_out);
 /* copy the resident states back (tests) */

@@ -49,6 +49,7 @@ _SIGS = {
     "ldw_fast_hadamard": (C.c_int, [_p] + [_p] * 8 + [_i64, C.c_int]),
     "ldw_set_alignment": (C.c_int, [_p, _p, _i64, _i64, C.c_int]),
     "ldw_encode_alignment": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
+    "ldw_alignment_scan": (C.c_int, [_p, _p, _i64, _i64, _p]),
     "ldw_state_counts": (C.c_int, [_p, _p]),
     "ldw_get_alignment": (C.c_int, [_p, _p]),
     "ldw_hamming_weights": (C.c_int, [_p, C.c_int32, _p, _p]),

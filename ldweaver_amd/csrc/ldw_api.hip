@@ -127,6 +127,22 @@ __global__ void k_encode(const char *__restrict__ chars, int64_t N, int64_t L_to
     }
 }
 
+// per-column allele counts of a raw alignment (src/getACGTNsites.cpp:58-70): one thread per column, coalesced along
+// the sequence, five counters in registers
+__global__ __launch_bounds__(256) void k_column_counts(const char *__restrict__ chars, int64_t N, int64_t L_total,
+                                                       int32_t *__restrict__ counts) {
+    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j >= L_total) return;
+    int c[5] = {0, 0, 0, 0, 0};
+    for (int64_t s = 0; s < N; ++s) {
+        const uint8_t st = encode_char((unsigned char)chars[s * L_total + j]);
+#pragma unroll
+        for (int x = 0; x < 5; ++x) c[x] += st == x;
+    }
+#pragma unroll
+    for (int x = 0; x < 5; ++x) counts[j * 5 + x] = c[x];
+}
+
 // per-SNP state counts and fixed-point weighted marginals.  One wave per SNP; each lane reads 4
 // consecutive sequences (one dword) per step.
 __global__ __launch_bounds__(256) void k_counts_marginals(const uint8_t *__restrict__ states, int64_t L, int64_t Npad,
@@ -239,7 +255,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     if (!c) return LDW_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    ldw::DevBuf *bufs[] = {&c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
+    ldw::DevBuf *bufs[] = {&c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
                            &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->hist, &c->colcnt, &c->cand_key,
                            &c->cand_val, &c->cand_key2, &c->cand_val2, &c->scratch, &c->small, &c->sr_a, &c->sr_b,
@@ -414,19 +430,44 @@ int ldw_state_counts(ldw_ctx *c, int32_t *counts_out) {
     return LDW_OK;
 }
 
+int ldw_alignment_scan(ldw_ctx *c, const char *chars, int64_t N, int64_t L_total, int32_t *allele_counts_out) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(chars && allele_counts_out && N > 0 && L_total > 0, LDW_ERR_ARG, "ldw_alignment_scan: bad argument");
+    const size_t cb = (size_t)N * L_total;
+    if (int rc = c->chars.reserve(cb)) return rc;
+    if (int rc = c->scratch.reserve((size_t)L_total * 20)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->chars.p, chars, cb, hipMemcpyHostToDevice, c->stream));
+    c->cN = N;
+    c->cL = L_total;
+    hipLaunchKernelGGL(k_column_counts, dim3((unsigned)((L_total + 255) / 256)), dim3(256), 0, c->stream, c->chars.as<char>(),
+                       N, L_total, c->scratch.as<int32_t>());
+    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipMemcpyAsync(allele_counts_out, c->scratch.p, (size_t)L_total * 20, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
+
 int ldw_encode_alignment(ldw_ctx *c, const char *chars, int64_t N, int64_t L_total, const int32_t *pos, int64_t n_pos,
                          int32_t *acgtn_table_out) {
     if (int rc = check_gpu(c)) return rc;
-    LDW_REQUIRE(chars && pos && N > 0 && L_total > 0 && n_pos > 0, LDW_ERR_ARG, "ldw_encode_alignment: bad argument");
+    LDW_REQUIRE(pos && N > 0 && L_total > 0 && n_pos > 0, LDW_ERR_ARG, "ldw_encode_alignment: bad argument");
+    LDW_REQUIRE(chars || (c->chars.p && c->cN == N && c->cL == L_total), LDW_ERR_STATE,
+                "ldw_encode_alignment: chars is NULL and no alignment of that shape was scanned");
     for (int64_t i = 0; i < n_pos; ++i)
         LDW_REQUIRE(pos[i] >= 1 && pos[i] <= L_total, LDW_ERR_ARG, "ldw_encode_alignment: pos[%lld]=%d outside 1..%lld",
                     (long long)i, pos[i], (long long)L_total);
     if (int rc = set_dims(c, n_pos, N)) return rc;
-    const size_t cb = (size_t)N * L_total, cb16 = ((cb + 15) / 16) * 16;
-    if (int rc = c->scratch.reserve(cb16 + (size_t)n_pos * 4)) return rc;
-    char *d_chars = c->scratch.as<char>();
-    int32_t *d_pos = reinterpret_cast<int32_t *>(d_chars + cb16);
-    LDW_HIP(hipMemcpyAsync(d_chars, chars, cb, hipMemcpyHostToDevice, c->stream));
+    const size_t cb = (size_t)N * L_total;
+    const char *d_chars;
+    if (chars) {
+        if (int rc = c->chars.reserve(cb)) return rc;
+        LDW_HIP(hipMemcpyAsync(c->chars.p, chars, cb, hipMemcpyHostToDevice, c->stream));
+        c->cN = N;
+        c->cL = L_total;
+    }
+    d_chars = c->chars.as<char>();
+    if (int rc = c->scratch.reserve((size_t)n_pos * 4)) return rc;
+    int32_t *d_pos = c->scratch.as<int32_t>();
     LDW_HIP(hipMemcpyAsync(d_pos, pos, (size_t)n_pos * 4, hipMemcpyHostToDevice, c->stream));
     dim3 grid((unsigned)((n_pos + 63) / 64), (unsigned)((c->Npad + 63) / 64));
     hipLaunchKernelGGL(k_encode, grid, dim3(256), 0, c->stream, d_chars, N, L_total, d_pos, n_pos,

@@ -59,6 +59,8 @@ struct ldw_ctx {
     int64_t L = 0, N = 0, Npad = 0;  // Npad: N rounded up to a multiple of KSTEP (128)
     int64_t KW = 0;                  // 64-bit words per bit row = Npad / 64
     ldw::DevBuf states;              // uint8 [L][N]
+    ldw::DevBuf chars;               // raw alignment characters [cN][cL] kept by ldw_alignment_scan
+    int64_t cN = 0, cL = 0;
 
     // ---- weights ----
     bool have_weights = false;

@@ -77,13 +77,27 @@ class Engine:
             L.check(L.lib().ldw_set_alignment(self._ctx, L.ptr(st), Ls, Ns, 0))
         self.L, self.N = int(Ls), int(Ns)
 
-    def encode_alignment(self, chars: np.ndarray, pos: np.ndarray, want_table=True):
-        """chars: (N, L_total) bytes (S1/uint8), pos: 1-based retained columns. Returns ACGTN_table (5, n_pos)."""
+    def alignment_scan(self, chars: np.ndarray) -> np.ndarray:
+        """Upload the raw (N, L_total) alignment and return the 5 x L_total allele counts of every column."""
         ch = L.as_c(chars.view(np.uint8) if chars.dtype != np.uint8 else chars, np.uint8)
+        out = np.empty((ch.shape[1], 5), dtype=np.int32)
+        L.check(L.lib().ldw_alignment_scan(self._ctx, L.ptr(ch), ch.shape[0], ch.shape[1], L.ptr(out)))
+        self._scanned = ch.shape
+        return np.ascontiguousarray(out.T)
+
+    def encode_alignment(self, chars, pos: np.ndarray, want_table=True, shape=None):
+        """chars: (N, L_total) bytes, or None to reuse the alignment kept by ``alignment_scan``; pos: 1-based retained
+        columns.  The result becomes the engine's alignment; returns ACGTN_table (5, n_pos)."""
         ps = L.as_c(pos, np.int32)
         tab = np.zeros((len(ps), 5), dtype=np.int32) if want_table else None
-        L.check(L.lib().ldw_encode_alignment(self._ctx, L.ptr(ch), ch.shape[0], ch.shape[1], L.ptr(ps), len(ps), L.ptr(tab)))
-        self.L, self.N = len(ps), ch.shape[0]
+        if chars is None:
+            n, lt = shape or self._scanned
+            L.check(L.lib().ldw_encode_alignment(self._ctx, None, n, lt, L.ptr(ps), len(ps), L.ptr(tab)))
+        else:
+            ch = L.as_c(chars.view(np.uint8) if chars.dtype != np.uint8 else chars, np.uint8)
+            n, lt = ch.shape
+            L.check(L.lib().ldw_encode_alignment(self._ctx, L.ptr(ch), n, lt, L.ptr(ps), len(ps), L.ptr(tab)))
+        self.L, self.N = len(ps), n
         return None if tab is None else np.ascontiguousarray(tab.T)
 
     def get_alignment(self) -> np.ndarray:

@@ -62,6 +62,31 @@ def uqe_r(states: np.ndarray):
     return uqe, uqe.sum(axis=1)
 
 
+def snp_filter(allele_counts, n: int, gap_thresh: float = 0.15, maf_thresh: float = 0.01, filt: int = 0):
+    """Literal restatement of the column filter of ``extractAlnParam`` (src/getACGTNsites.cpp:104-166): 1-based POS.
+    ``allele_counts``: 5 x L (A,C,G,T,other) as produced at :58-70."""
+    ac = np.asarray(allele_counts, dtype=np.float64)
+    L = ac.shape[1]
+    POS = []
+    min_maf = int(n * maf_thresh) if filt == 0 else int(n * (1 - maf_thresh))
+    for j in range(L):
+        chk = 0
+        for k in range(4):
+            if ac[k, j] > 0:                       # we need at least one non-gap allele
+                chk += 1
+                if chk > 1:                        # seems polymorphic
+                    if ac[4, j] / n < gap_thresh:  # now check gap content
+                        if filt == 0:
+                            snp = sorted(ac[:4, j])
+                            if snp[2] > min_maf:   # second largest non-gap element
+                                POS.append(j + 1)
+                        else:
+                            if ac[:, j].max() <= min_maf:
+                                POS.append(j + 1)
+                    break
+    return np.array(POS, dtype=np.int32)
+
+
 # --------------------------------------------------------------------------
 # a-3  .ACGTN2num                      src/ACGTN2num_parallel.cpp:10-43
 # --------------------------------------------------------------------------
