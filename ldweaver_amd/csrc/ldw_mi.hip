@@ -306,6 +306,66 @@ __device__ __forceinline__ double pair_mi(const EpiArgs &A, const RowSide &R, co
     return acc * fast_rcp(den);
 }
 
+// Straight-line variant for the common case: every lane has exactly NA row slots, the column has exactly NB,
+// and every slot of both SNPs is flagged in uqe — no per-cell predication, every index static.
+template <int NA, int NB>
+__device__ __forceinline__ double pair_mi_full(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc,
+                                               bool square) {
+    int64_t g[NA > 0 ? NA : 1][NB > 0 ? NB : 1], rs[NA > 0 ? NA : 1], cs[NB > 0 ? NB : 1];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) rs[i] = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) cs[j] = 0;
+    const int64_t base = (int64_t)M.rb0 * A.RFpad + R.ra0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int64_t v = A.G[base + (int64_t)j * A.RFpad + i];
+            g[i][j] = v;
+            rs[i] += v;
+            cs[j] += v;
+        }
+    int64_t dd = R.pa[NA];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dd -= M.pb[j] - cs[j];
+
+    const double ra = R.ra, rb = M.rb;
+    const double den = A.neff + (ra * rb) * 0.5;
+    double RXY;
+    if (A.quirk == LDW_QUIRK_REFERENCE) {
+        if (square) {
+            RXY = (M.rq * R.rta) * 0.25;
+        } else {
+            const uint32_t c = (uint32_t)a_loc + (uint32_t)b_loc * (uint32_t)A.nf;
+            const uint32_t q = c / (uint32_t)A.nt;
+            RXY = (A.r[A.idx_f[q]] * A.r[A.idx_t[c - q * (uint32_t)A.nt]]) * 0.25;
+        }
+    } else {
+        RXY = (ra * rb) * 0.25;
+    }
+    const double rX = 0.5 * ra, rY = 0.5 * rb;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i <= NA; ++i) {
+        const double pX = R.pXd[i];
+        const double pXr = fma(pX, rX, RXY);
+#pragma unroll
+        for (int j = 0; j <= NB; ++j) {
+            int64_t nfix;
+            if (i < NA && j < NB) nfix = g[i < NA ? i : 0][j < NB ? j : 0];
+            else if (i < NA) nfix = R.pa[i] - rs[i < NA ? i : 0];
+            else if (j < NB) nfix = M.pb[j] - cs[j < NB ? j : 0];
+            else nfix = dd;
+            const double pY = M.pYd[j];
+            const double pxy = fma(u52_to_double(nfix), A.scale, 0.5);
+            const double d = fma(pY, rY, fma(pX, pY, pXr));
+            acc = fma(pxy, fast_log_ratio(pxy * den, d), acc);
+        }
+    }
+    return acc * fast_rcp(den);
+}
+
 __global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *__restrict__ perm_f,
                                                      unsigned long long *__restrict__ ghist) {
     __shared__ unsigned int sh_hist[NBINS];
@@ -353,6 +413,10 @@ __global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *_
         R.pXd[i] = (double)R.pa[i] * A.scale;
     }
     const int na_max = (__ballot(R.na > 2) != 0ull) ? 4 : ((__ballot(R.na > 1) != 0ull) ? 2 : 1);
+    // wave-uniform: every active lane has the same slot count (1 or 2) and all its slots flagged in uqe
+    const int na0 = __builtin_amdgcn_readfirstlane(R.na);
+    const bool a_full = a_ok && R.na == na0 && (((R.ma >> 3) & ((2u << na0) - 1u)) == ((2u << na0) - 1u));
+    const bool wave_full = (na0 == 1 || na0 == 2) && __ballot(!a_full) == 0ull;
 
     const int c_first = wave * (EPI_COLS / 4);
     const int b_base = blockIdx.y * EPI_COLS;
@@ -366,7 +430,11 @@ __global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *_
         const ColMeta &M = cm[cl];
         const int nb = __builtin_amdgcn_readfirstlane((int)(M.mb & 7));
         double mi;
-        if (na_max == 1) {
+        const bool b_full = ((M.mb >> 3) & ((2u << nb) - 1u)) == ((2u << nb) - 1u);
+        if (wave_full && b_full && (nb == 1 || nb == 2)) {
+            if (na0 == 1) mi = nb == 1 ? pair_mi_full<1, 1>(A, R, M, a_loc, b_loc, square) : pair_mi_full<1, 2>(A, R, M, a_loc, b_loc, square);
+            else mi = nb == 1 ? pair_mi_full<2, 1>(A, R, M, a_loc, b_loc, square) : pair_mi_full<2, 2>(A, R, M, a_loc, b_loc, square);
+        } else if (na_max == 1) {
             if (nb <= 1) mi = pair_mi<1, 1>(A, R, M, a_loc, b_loc, square);
             else if (nb == 2) mi = pair_mi<1, 2>(A, R, M, a_loc, b_loc, square);
             else mi = pair_mi<1, 4>(A, R, M, a_loc, b_loc, square);
