@@ -168,6 +168,38 @@ int ldw_aracne(ldw_ctx *ctx, const double *chk_pos1, const double *chk_pos2, con
                int64_t n_chk, const double *full_pos1, const double *full_pos2, const double *full_MI,
                int64_t n_full, uint8_t *flags_out);
 
+/* ---- (7) short-range model on the device-resident sr table — mergeNsort_sr_links,
+ *          R/computePairwiseMI.R:400-495 — and ARACNE on its result.  The table is the one left by
+ *          ldw_mi_all_pairs / ldw_links_end; cluster ids come from the paint of ldw_set_snp_meta
+ *          (1..nclust, nclust <= 255); len must be integral (integer genome length).  The caller keeps the two
+ *          O(1)-sized numerical steps (the log-log OLS fit :428 and the beta MLE :452) and calls, in order: ---- */
+/* (:417-424) per cluster c (0-based) and integer len l = 1..S, S = ceil(sr_dist)-1: n_out[c*S + l-1] = number
+ * of links with that len touching cluster c+1 (0 < len < sr_dist), and the two order statistics that
+ * quantile(type 7, prob) interpolates: ranks floor(h) and ceil(h) of the ascending MI values, h = (n-1)*prob
+ * (NaN where n = 0). */
+int ldw_sr_len_quantiles(ldw_ctx *ctx, int nclust, double sr_dist, double prob, int32_t S,
+                         double *q_lo_out, double *q_hi_out, int64_t *n_out);
+/* (:444-452) mean_dist[c*S + l-1] = fitted decay of cluster c+1 looked up BY THE VALUE of len (quirk Q5:
+ * NaN beyond the number of distinct lens).  stats_out[c*5 + k] over the links with diff = MI - mean_dist > 0:
+ * n, sum diff, sum diff^2, sum log(diff), sum log(1-diff) — reduced in a fixed order. */
+int ldw_sr_excess_stats(ldw_ctx *ctx, int nclust, int32_t S, const double *mean_dist, double *stats_out);
+/* (:453, :475-490) shape[c*3 + {0,1,2}] = beta shape1, shape2, log B(shape1, shape2).  srp = -log P(X > diff)
+ * per link and cluster, maximum over the link's clusters (ties: smaller cluster id), links with
+ * srp > srp_cutoff are kept on the device (n_red), and the ARACNE pool = links with a positive excess in
+ * some cluster and MI >= min MI kept (n_pool). */
+int ldw_sr_pvalues(ldw_ctx *ctx, int nclust, int32_t S, const double *mean_dist, const double *shape,
+                   double srp_cutoff, int64_t *n_red_out, int64_t *n_pool_out, double *min_mi_out);
+/* kept links in no particular order: row in the sr table (ldw_links_fetch order) and that row's (a, b, MI),
+ * clust_c, the first cluster (ascending id) in which the link has a positive excess, whether
+ * clust1 != clust2, srp_max. */
+int ldw_sr_reduced_fetch(ldw_ctx *ctx, int64_t capacity, int64_t *row_out, int32_t *a_out, int32_t *b_out,
+                         double *MI_out, int32_t *clust_c_out, int32_t *first_clust_out, uint8_t *dup_out,
+                         double *srp_out);
+int ldw_sr_pool_fetch(ldw_ctx *ctx, int64_t capacity, int32_t *a_out, int32_t *b_out, double *MI_out);
+/* runARACNE (R/io_functions.R:101-164) for the kept links against the pool, both device resident;
+ * flags_out[i] belongs to row_out[i] of ldw_sr_reduced_fetch. */
+int ldw_aracne_device(ldw_ctx *ctx, int64_t capacity, uint8_t *flags_out);
+
 /* ---- small native helpers kept for finest-grain A/B parity (host memory) -------------------- */
 /* .compareToRow src/computeMI.cpp:25-41: ret[j] = any(x[j,] in y); x is nr x nc column-major */
 int ldw_compare_to_row(const double *x, int64_t nr, int64_t nc, const double *y, int64_t ny, uint8_t *ret);

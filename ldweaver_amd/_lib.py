@@ -66,6 +66,12 @@ _SIGS = {
     "ldw_links_fetch": (C.c_int, [_p, C.c_int, _p, _p, _p, _i64, C.c_int]),
     "ldw_block_stats": (C.c_int, [_p, _i64, _p, _p, _p, _p]),
     "ldw_aracne": (C.c_int, [_p, _p, _p, _p, _i64, _p, _p, _p, _i64, _p]),
+    "ldw_sr_len_quantiles": (C.c_int, [_p, C.c_int, C.c_double, C.c_double, C.c_int32, _p, _p, _p]),
+    "ldw_sr_excess_stats": (C.c_int, [_p, C.c_int, C.c_int32, _p, _p]),
+    "ldw_sr_pvalues": (C.c_int, [_p, C.c_int, C.c_int32, _p, _p, C.c_double, _p, _p, _p]),
+    "ldw_sr_reduced_fetch": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "ldw_sr_pool_fetch": (C.c_int, [_p, _i64, _p, _p, _p]),
+    "ldw_aracne_device": (C.c_int, [_p, _i64, _p]),
     "ldw_compare_to_row": (C.c_int, [_p, _i64, _i64, _p, _i64, _p]),
     "ldw_vec_pos_match": (C.c_int, [_p, _i64, _p, _i64, _p]),
     "ldw_compare_triplet": (C.c_int, [_p, _p, _i64, C.c_double, C.POINTER(C.c_int)]),

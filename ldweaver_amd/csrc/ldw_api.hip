@@ -259,7 +259,10 @@ int ldw_ctx_destroy(ldw_ctx *c) {
                            &c->slot_meta, &c->slot_pfix, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
                            &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->hist, &c->colcnt, &c->cand_key,
                            &c->cand_val, &c->cand_key2, &c->cand_val2, &c->scratch, &c->small, &c->sr_a, &c->sr_b,
-                           &c->sr_mi, &c->lr_a, &c->lr_b, &c->lr_mi};
+                           &c->sr_mi, &c->lr_a, &c->lr_b, &c->lr_mi, &c->srm_pack, &c->srm_key, &c->srm_pack2, &c->srm_key2, &c->srm_pay, &c->srm_pay2, &c->srm_off,
+                           &c->srm_q, &c->srm_n, &c->srm_md, &c->srm_part, &c->srm_shape, &c->srm_cnt, &c->red_row, &c->red_meta,
+                           &c->red_srp, &c->pool_a, &c->pool_b, &c->pool_mi, &c->ar_key, &c->ar_val, &c->ar_key2, &c->ar_val2,
+                           &c->ar_off, &c->ar_flags};
     for (auto *b : bufs) b->release();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -555,6 +558,14 @@ int ldw_set_snp_meta(ldw_ctx *c, const double *r, const uint8_t *uqe, const int3
     LDW_HIP(hipStreamSynchronize(c->stream));
     c->h_r.assign(r, r + L);
     c->h_POS.assign(POS, POS + L);
+    c->paint_min = c->paint_max = 0;
+    if (paint) {
+        c->paint_min = c->paint_max = paint[0];
+        for (int64_t i = 1; i < L; ++i) {
+            c->paint_min = paint[i] < c->paint_min ? paint[i] : c->paint_min;
+            c->paint_max = paint[i] > c->paint_max ? paint[i] : c->paint_max;
+        }
+    }
     c->g = g;
     c->have_meta = true;
     c->rows_ready = false;

@@ -78,6 +78,7 @@ struct ldw_ctx {
     ldw::DevBuf r, uqe, POS, paint;  // double[L], uint8[L][5], int32[L], int32[L]
     std::vector<double> h_r;
     std::vector<int32_t> h_POS;
+    int32_t paint_min = 0, paint_max = 0;
 
     // ---- row map (built lazily from alignment + weights + meta) ----
     bool rows_ready = false;
@@ -101,6 +102,13 @@ struct ldw_ctx {
     ldw::DevBuf sr_a, sr_b, sr_mi, lr_a, lr_b, lr_mi;
     int64_t n_sr = 0, n_lr = 0;
     int64_t blk_capacity = 0, blk_cursor = 0;  // ldw_links_begin / ldw_mi_block_links / ldw_links_end
+
+    // ---- short-range model and ARACNE on the device-resident sr table (ldw_srp.hip) ----
+    ldw::DevBuf srm_pack, srm_key, srm_pack2, srm_key2, srm_pay, srm_pay2, srm_off, srm_q, srm_n, srm_md, srm_part, srm_shape, srm_cnt;
+    ldw::DevBuf red_row, red_meta, red_srp, pool_a, pool_b, pool_mi, ar_key, ar_val, ar_key2, ar_val2, ar_off, ar_flags;
+    int64_t n_red = 0, n_pool = 0;
+    int srm_S = 0, srm_nclust = 0;   // geometry of the last ldw_sr_len_quantiles call
+    double srm_sr_dist = 0;
 
     // ---- pipelined block staging: host prep of block i+1 overlaps the GPU work of block i ----
     hipStream_t copy_stream = nullptr;

@@ -15,6 +15,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "ldw_internal.h"
+#include "ldw_dev.h"
 
 using namespace ldw;
 
@@ -23,28 +24,6 @@ namespace ldw {
 // ------------------------------------------------------------------------------------------------
 // helpers shared by host and device
 // ------------------------------------------------------------------------------------------------
-// len = 0.5*g - abs((pos1 - pos2) %% g - 0.5*g)   (R/computePairwiseMI.R:330; R's floored %%)
-__host__ __device__ __forceinline__ double circ_len(double pos1, double pos2, double g) {
-    const double x = pos1 - pos2;
-    double d = x - floor(x / g) * g;
-    if (d < 0) d += g;
-    if (d >= g) d -= g;
-    return 0.5 * g - fabs(d - 0.5 * g);
-}
-
-// order-preserving map double -> uint64 (ascending)
-__host__ __device__ __forceinline__ uint64_t f64_key(double v) {
-    uint64_t u;
-    memcpy(&u, &v, 8);
-    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
-}
-__host__ __device__ __forceinline__ double key_f64(uint64_t k) {
-    uint64_t u = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
-    double v;
-    memcpy(&v, &u, 8);
-    return v;
-}
-
 // Histogram bucket of an MI value: monotone non-decreasing in mi, 128 buckets per octave (0.5 % wide) from 2^-20
 // up, taken straight from the IEEE-754 bits (exponent + 7 mantissa bits) — no floating-point arithmetic.  Values
 // below 2^-20 (and negatives, which quirk Q1 can produce) fall in bucket 0.

@@ -1,0 +1,696 @@
+// Short-range p-value model and ARACNE on the device-resident short-range link table: the O(#links) parts of
+// mergeNsort_sr_links (R/computePairwiseMI.R:400-495) and runARACNE (R/io_functions.R:101-164).
+//
+// The table stays in HBM (C5: 2.25e9 rows, 36 GB); what crosses to the host are the per-(cluster, len) order
+// statistics (<= nclust x sr_dist doubles), five sums per cluster, and the reduced link set.  The two tiny
+// numerical steps in between — the log-log least-squares fit (:428) and the two-parameter beta MLE (:452) — stay
+// with the caller (they are O(sr_dist) and O(1)); the library offers the data reductions either side of them:
+//
+//   ldw_sr_len_quantiles : rows -> (len, cluster, cluster) tags; two stable radix sorts (MI, then len); one
+//                          workgroup per len counts the members of every cluster and picks the two order
+//                          statistics quantile type 7 interpolates between           (:417-424)
+//   ldw_sr_excess_stats  : diff = MI - mean_dist[len] (positional index, quirk Q5); n, sum x, sum x^2,
+//                          sum log x, sum log(1-x) of the positive excesses per cluster — the sufficient
+//                          statistics of the beta likelihood, reduced in a fixed order      (:444-452)
+//   ldw_sr_pvalues       : srp = -log P_beta(X > diff) per row and cluster (continued fraction, log-space tail),
+//                          max over the clusters a link belongs to (:475-486), cut at srp_cutoff, ARACNE pool
+//                          MI >= min(MI kept) (:489-490)
+//   ldw_aracne_device    : CSR adjacency of the pool by one radix sort; one wave per link to check intersects the
+//                          two sorted neighbour lists
+//
+// HBM-bound integer/byte work apart from the log/continued-fraction arithmetic of the p-values.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <hipcub/hipcub.hpp>
+#include <vector>
+
+#include "ldw_internal.h"
+#include "ldw_dev.h"
+
+using namespace ldw;
+
+namespace ldw {
+
+constexpr int SRM_MAXCL = 255;   // cluster ids 1..255 fit the 8-bit tags
+constexpr int SRM_GRID = 2048;   // fixed grid of the row-streaming kernels (deterministic reduction order)
+
+struct RowTag {
+    int len;      // integer len, 0 = not in (0, sr_dist)
+    int c1, c2;   // clust1 (to side, pos1), clust2 (from side, pos2)
+};
+
+__device__ __forceinline__ RowTag row_tag(int32_t a, int32_t b, const int32_t *__restrict__ POS,
+                                          const int32_t *__restrict__ paint, double g, double sr_dist) {
+    RowTag t;
+    const double len = circ_len((double)POS[b], (double)POS[a], g);
+    t.len = (len > 0.0 && len < sr_dist) ? (int)len : 0;
+    t.c1 = paint[b];
+    t.c2 = paint[a];
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// quantiles per (cluster, len)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sr_tag(const int32_t *__restrict__ sa, const int32_t *__restrict__ sb,
+                                                const double *__restrict__ smi, int64_t n, const int32_t *__restrict__ POS,
+                                                const int32_t *__restrict__ paint, double g, double sr_dist,
+                                                uint32_t *__restrict__ pack, uint64_t *__restrict__ key) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const RowTag t = row_tag(sa[i], sb[i], POS, paint, g, sr_dist);
+        pack[i] = ((uint32_t)t.len << 16) | ((uint32_t)t.c1 << 8) | (uint32_t)t.c2;
+        key[i] = f64_key(smi[i]);
+    }
+}
+
+// payload of the second (by len) sort: the MI key and the tag, 12 bytes
+struct SrPay {
+    uint32_t klo, khi, tag;
+};
+
+__global__ __launch_bounds__(256) void k_sr_split(const uint32_t *__restrict__ pack, const uint64_t *__restrict__ key, int64_t n,
+                                                  uint16_t *__restrict__ len16, SrPay *__restrict__ pay) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t p = pack[i];
+        const uint64_t k = key[i];
+        len16[i] = (uint16_t)(p >> 16);
+        pay[i] = SrPay{(uint32_t)k, (uint32_t)(k >> 32), p};
+    }
+}
+
+// off[l] = first sorted row with len >= l, l = 0..S+1
+__global__ void k_sr_seg_offsets(const uint16_t *__restrict__ pack, int64_t n, int S, int64_t *__restrict__ off) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l > S + 1) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int)pack[mid] < l) lo = mid + 1;
+        else hi = mid;
+    }
+    off[l] = lo;
+}
+
+// One workgroup per len.  q[(c*S + l-1)*2 + {0,1}] = the order statistics of rank floor(h), ceil(h), h = (n-1)*prob,
+// among the MI values of the links of that len that touch cluster c+1; cnt[c*S + l-1] = n.
+__global__ __launch_bounds__(256) void k_sr_quant(const SrPay *__restrict__ pay, const int64_t *__restrict__ off, int S, int nclust, double prob,
+                                                  double *__restrict__ q, int64_t *__restrict__ cnt) {
+    __shared__ unsigned long long tot[SRM_MAXCL + 1], run[SRM_MAXCL + 1], tlo[SRM_MAXCL + 1], thi[SRM_MAXCL + 1];
+    __shared__ unsigned int ccnt[SRM_MAXCL + 1];
+    __shared__ unsigned int wcnt[4];
+    const int l = blockIdx.x + 1;
+    const int64_t beg = off[l], end = off[l + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int c = tid; c <= SRM_MAXCL; c += 256) {
+        tot[c] = 0;
+        run[c] = 0;
+        ccnt[c] = 0;
+    }
+    __syncthreads();
+    for (int64_t i = beg + tid; i < end; i += 256) {
+        const uint32_t p = pay[i].tag;
+        const int c1 = (p >> 8) & 0xFF, c2 = p & 0xFF;
+        atomicAdd(&tot[c1], 1ull);
+        if (c2 != c1) atomicAdd(&tot[c2], 1ull);
+    }
+    __syncthreads();
+    for (int c = tid + 1; c <= nclust; c += 256) {
+        const unsigned long long n = tot[c];
+        cnt[(int64_t)(c - 1) * S + (l - 1)] = (int64_t)n;
+        if (n) {
+            const double index = 1.0 + (double)(n - 1) * prob;   // R's 1-based index, rounded as R rounds it
+            tlo[c] = (unsigned long long)floor(index) - 1ull;
+            thi[c] = (unsigned long long)ceil(index) - 1ull;
+        } else {
+            tlo[c] = thi[c] = ~0ull;
+        }
+    }
+    __syncthreads();
+    for (int64_t base = beg; base < end; base += 256) {
+        const int64_t i = base + tid;
+        int c1 = 0, c2 = 0;
+        uint64_t k = 0;
+        if (i < end) {
+            const SrPay py = pay[i];
+            c1 = (py.tag >> 8) & 0xFF;
+            c2 = py.tag & 0xFF;
+            k = ((uint64_t)py.khi << 32) | py.klo;
+            atomicAdd(&ccnt[c1], 1u);
+            if (c2 != c1) atomicAdd(&ccnt[c2], 1u);
+        }
+        __syncthreads();
+        for (int c = 1; c <= nclust; ++c) {   // uniform: everything tested here lives in LDS
+            const unsigned long long r0 = run[c], cc = ccnt[c];
+            const bool hit_lo = tlo[c] >= r0 && tlo[c] < r0 + cc, hit_hi = thi[c] >= r0 && thi[c] < r0 + cc;
+            if (!(hit_lo || hit_hi)) continue;
+            const bool m = i < end && (c1 == c || c2 == c);
+            const unsigned long long bal = __ballot(m);
+            if (lane == 0) wcnt[wv] = (unsigned int)__popcll(bal);
+            __syncthreads();
+            unsigned long long rank = r0 + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wv; ++w) rank += wcnt[w];
+            if (m) {
+                const int64_t o = ((int64_t)(c - 1) * S + (l - 1)) * 2;
+                if (rank == tlo[c]) q[o] = key_f64(k);
+                if (rank == thi[c]) q[o + 1] = key_f64(k);
+            }
+            __syncthreads();
+        }
+        for (int c = tid + 1; c <= nclust; c += 256) {
+            run[c] += ccnt[c];
+            ccnt[c] = 0;
+        }
+        if (tid == 0) ccnt[0] = 0;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// positive excesses over the fitted decay: sufficient statistics of the beta likelihood
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// excess of a link over cluster c's fitted decay; NaN when the link has no valid len or the table has no entry
+__device__ __forceinline__ double excess(double mi, int len, int c, const double *__restrict__ md, int S) {
+    if (len <= 0 || c < 1) return __builtin_nan("");
+    return mi - md[(int64_t)(c - 1) * S + (len - 1)];
+}
+
+// part[(blockIdx.x * nclust + c) * 5 + k]
+__global__ __launch_bounds__(256) void k_sr_stats(const int32_t *__restrict__ sa, const int32_t *__restrict__ sb,
+                                                  const double *__restrict__ smi, int64_t n, const int32_t *__restrict__ POS,
+                                                  const int32_t *__restrict__ paint, double g, double sr_dist,
+                                                  const double *__restrict__ md, int S, int nclust,
+                                                  double *__restrict__ part) {
+    extern __shared__ double acc[];   // [4 waves][nclust][5]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int k = tid; k < 4 * nclust * 5; k += 256) acc[k] = 0.0;
+    __syncthreads();
+    double *mine = acc + (int64_t)wv * nclust * 5;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;   // contiguous strip per workgroup
+    const int64_t beg = (int64_t)blockIdx.x * per, end = beg + per < n ? beg + per : n;
+    for (int64_t base = beg; base < end; base += 256) {
+        const int64_t i = base + tid;
+        int cs[2] = {0, 0};
+        double ds[2] = {0, 0};
+        if (i < end) {
+            const RowTag t = row_tag(sa[i], sb[i], POS, paint, g, sr_dist);
+            const double mi = smi[i];
+            const double d1 = excess(mi, t.len, t.c1, md, S);
+            if (d1 > 0) {
+                cs[0] = t.c1;
+                ds[0] = d1;
+            }
+            if (t.c2 != t.c1) {
+                const double d2 = excess(mi, t.len, t.c2, md, S);
+                if (d2 > 0) {
+                    cs[1] = t.c2;
+                    ds[1] = d2;
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            int c = cs[s];
+            const double x = ds[s];
+            const double lx = c ? log(x) : 0.0, l1x = c ? log1p(-x) : 0.0;
+            unsigned long long todo = __ballot(c != 0);
+            while (todo) {   // peel the distinct clusters of this wave, lowest lane first: fixed order
+                const int src = __ffsll((long long)todo) - 1;
+                const int c0 = __shfl(c, src);
+                const bool in = c == c0;
+                const double s0 = wave_sum(in ? 1.0 : 0.0), s1 = wave_sum(in ? x : 0.0), s2 = wave_sum(in ? x * x : 0.0),
+                             s3 = wave_sum(in ? lx : 0.0), s4 = wave_sum(in ? l1x : 0.0);
+                if (lane == 0) {
+                    double *a = mine + (int64_t)(c0 - 1) * 5;
+                    a[0] += s0;
+                    a[1] += s1;
+                    a[2] += s2;
+                    a[3] += s3;
+                    a[4] += s4;
+                }
+                todo &= ~__ballot(in);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < nclust * 5; k += 256)
+        part[(int64_t)blockIdx.x * nclust * 5 + k] = ((acc[k] + acc[nclust * 5 + k]) + acc[2 * nclust * 5 + k]) + acc[3 * nclust * 5 + k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// -log P_beta(X > x) for shape (a, b): continued fraction of the regularised incomplete beta function
+// (modified Lentz), evaluated on the side where it converges fast, tail kept in log space
+// ------------------------------------------------------------------------------------------------
+__device__ double beta_cf(double a, double b, double x) {
+    const double tiny = 1e-300;
+    const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+    double c = 1.0, d = 1.0 - qab * x / qap;
+    if (fabs(d) < tiny) d = tiny;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 1000; ++m) {
+        const double m2 = 2.0 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d;
+        if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c;
+        if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d;
+        if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c;
+        if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < 4e-16) break;
+    }
+    return h;
+}
+
+__device__ double neg_log_beta_sf(double x, double a, double b, double lbeta) {
+    if (!(x > 0.0)) return 0.0;
+    if (x >= 1.0) return __builtin_inf();
+    const double lfront = a * log(x) + b * log1p(-x) - lbeta;
+    if (x < (a + 1.0) / (a + b + 2.0)) {
+        const double I = exp(lfront) * beta_cf(a, b, x) / a;   // lower tail, well below 1 here
+        return -log1p(-I);
+    }
+    return -(lfront + log(beta_cf(b, a, 1.0 - x) / b));
+}
+
+struct SrCounters {
+    unsigned long long n_red, n_pool, min_key;
+};
+
+// MODE 0: count reduced rows and min MI key; MODE 1: also write them.  meta = clust_c | first_cluster << 8 | dup << 16
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sr_pval(const int32_t *__restrict__ sa, const int32_t *__restrict__ sb,
+                                                 const double *__restrict__ smi, int64_t n, const int32_t *__restrict__ POS,
+                                                 const int32_t *__restrict__ paint, double g, double sr_dist,
+                                                 const double *__restrict__ md, int S, const double *__restrict__ shape,
+                                                 double cutoff, SrCounters *__restrict__ ctr, int64_t *__restrict__ red_row,
+                                                 uint32_t *__restrict__ red_meta, double *__restrict__ red_srp, int64_t cap) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const RowTag t = row_tag(sa[i], sb[i], POS, paint, g, sr_dist);
+        const double mi = smi[i];
+        const double d1 = excess(mi, t.len, t.c1, md, S);
+        const bool v1 = d1 > 0;
+        double s = 0.0;
+        int cc = 0, first = 0;
+        if (v1) {
+            const double *sh = shape + (int64_t)(t.c1 - 1) * 3;
+            s = neg_log_beta_sf(d1, sh[0], sh[1], sh[2]);
+            cc = first = t.c1;
+        }
+        const bool dup = t.c2 != t.c1;
+        if (dup) {
+            const double d2 = excess(mi, t.len, t.c2, md, S);
+            if (d2 > 0) {
+                const double *sh = shape + (int64_t)(t.c2 - 1) * 3;
+                const double s2 = neg_log_beta_sf(d2, sh[0], sh[1], sh[2]);
+                // which.max over the rows of the group in cluster order: ties go to the smaller cluster id
+                if (!v1 || s2 > s || (s2 == s && t.c2 < cc)) {
+                    s = s2;
+                    cc = t.c2;
+                }
+                first = (!v1 || t.c2 < first) ? t.c2 : first;
+            }
+        }
+        if (cc && s > cutoff) {
+            const unsigned long long slot = atomicAdd(&ctr->n_red, 1ull);
+            atomicMin(&ctr->min_key, (unsigned long long)f64_key(mi));
+            if (MODE == 1 && (int64_t)slot < cap) {
+                red_row[slot] = i;
+                red_meta[slot] = (uint32_t)cc | ((uint32_t)first << 8) | ((uint32_t)dup << 16);
+                red_srp[slot] = s;
+            }
+        }
+    }
+}
+
+// ARACNE pool: rows of the merged table (positive excess in some cluster) with MI >= min(MI kept)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sr_pool(const int32_t *__restrict__ sa, const int32_t *__restrict__ sb,
+                                                 const double *__restrict__ smi, int64_t n, const int32_t *__restrict__ POS,
+                                                 const int32_t *__restrict__ paint, double g, double sr_dist,
+                                                 const double *__restrict__ md, int S, SrCounters *__restrict__ ctr,
+                                                 int32_t *__restrict__ pa, int32_t *__restrict__ pb, double *__restrict__ pmi,
+                                                 int64_t cap) {
+    const uint64_t kmin = ctr->min_key;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double mi = smi[i];
+        if (f64_key(mi) < kmin) continue;
+        const int32_t a = sa[i], b = sb[i];
+        const RowTag t = row_tag(a, b, POS, paint, g, sr_dist);
+        bool v = excess(mi, t.len, t.c1, md, S) > 0;
+        if (!v && t.c2 != t.c1) v = excess(mi, t.len, t.c2, md, S) > 0;
+        if (!v) continue;
+        const unsigned long long slot = atomicAdd(&ctr->n_pool, 1ull);
+        if (MODE == 1 && (int64_t)slot < cap) {
+            pa[slot] = a;
+            pb[slot] = b;
+            pmi[slot] = mi;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ARACNE
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ar_edges(const int32_t *__restrict__ pa, const int32_t *__restrict__ pb,
+                                                  const double *__restrict__ pmi, int64_t n, uint64_t *__restrict__ key,
+                                                  double *__restrict__ val) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint64_t a = (uint32_t)pa[i], b = (uint32_t)pb[i];
+        const double m = pmi[i];
+        key[2 * i] = (a << 32) | b;
+        val[2 * i] = m;
+        key[2 * i + 1] = (b << 32) | a;
+        val[2 * i + 1] = m;
+    }
+}
+
+// off[v] = first directed edge whose node is >= v, v = 0..L
+__global__ void k_ar_offsets(const uint64_t *__restrict__ key, int64_t n2, int64_t L, int64_t *__restrict__ off) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > L) return;
+    int64_t lo = 0, hi = n2;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)(key[mid] >> 32) < v) lo = mid + 1;
+        else hi = mid;
+    }
+    off[v] = lo;
+}
+
+// One wave per link (X,Z) = (to side, from side): lanes stride over the shorter neighbour list and binary-search the
+// longer one.  flag = 0 iff some common neighbour Y has MI(X,Z) < MI(X,Y) and MI(X,Z) < MI(Z,Y)  (src/computeMI.cpp:63-77).
+__global__ __launch_bounds__(256) void k_ar_check(const int64_t *__restrict__ red_row, int64_t n_red,
+                                                  const int32_t *__restrict__ sa, const int32_t *__restrict__ sb,
+                                                  const double *__restrict__ smi, const uint64_t *__restrict__ key,
+                                                  const double *__restrict__ val, const int64_t *__restrict__ off,
+                                                  uint8_t *__restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_red) return;
+    const int64_t row = red_row[w];
+    const int32_t X = sb[row], Z = sa[row];
+    const double mi0 = smi[row];
+    int64_t xs = off[X], xe = off[X + 1], zs = off[Z], ze = off[Z + 1];
+    if (xe - xs > ze - zs) {   // iterate over the shorter list
+        int64_t t = xs; xs = zs; zs = t;
+        t = xe; xe = ze; ze = t;
+    }
+    bool indirect = false;
+    for (int64_t i = xs + lane; i < xe && !indirect; i += 64) {
+        const uint32_t y = (uint32_t)key[i];
+        if (!(mi0 < val[i])) continue;
+        int64_t lo = zs, hi = ze;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((uint32_t)key[mid] < y) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < ze && (uint32_t)key[lo] == y && mi0 < val[lo]) indirect = true;
+    }
+    const bool any = __ballot(indirect) != 0ull;
+    if (lane == 0) flags[w] = any ? 0 : 1;
+}
+
+__global__ void k_red_gather(const int64_t *__restrict__ row, int64_t n, const int32_t *__restrict__ sa, const int32_t *__restrict__ sb,
+                             const double *__restrict__ smi, int32_t *__restrict__ a, int32_t *__restrict__ b, double *__restrict__ mi) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = row[i];
+    a[i] = sa[r];
+    b[i] = sb[r];
+    mi[i] = smi[r];
+}
+
+static int sr_ready(ldw_ctx *c, const char *who) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(c->have_meta, LDW_ERR_STATE, "%s: ldw_set_snp_meta has not been called", who);
+    return LDW_OK;
+}
+
+}  // namespace ldw
+
+extern "C" {
+
+int ldw_sr_len_quantiles(ldw_ctx *c, int nclust, double sr_dist, double prob, int32_t S, double *q_lo_out, double *q_hi_out,
+                         int64_t *n_out) {
+    if (int rc = sr_ready(c, "ldw_sr_len_quantiles")) return rc;
+    LDW_REQUIRE(nclust >= 1 && nclust <= SRM_MAXCL, LDW_ERR_ARG, "ldw_sr_len_quantiles: nclust must be in 1..%d", SRM_MAXCL);
+    LDW_REQUIRE(sr_dist > 1 && sr_dist <= 65535, LDW_ERR_ARG, "ldw_sr_len_quantiles: sr_dist must be in (1, 65535]");
+    LDW_REQUIRE(prob >= 0 && prob <= 1, LDW_ERR_ARG, "ldw_sr_len_quantiles: prob outside [0,1]");
+    LDW_REQUIRE(S == (int32_t)std::ceil(sr_dist) - 1, LDW_ERR_ARG, "ldw_sr_len_quantiles: S must be ceil(sr_dist)-1 = %d",
+                (int)std::ceil(sr_dist) - 1);
+    LDW_REQUIRE(c->g == std::floor(c->g), LDW_ERR_ARG, "ldw_sr_len_quantiles: the genome length must be an integer");
+    LDW_REQUIRE(q_lo_out && q_hi_out && n_out, LDW_ERR_ARG, "ldw_sr_len_quantiles: null output");
+    LDW_REQUIRE(c->paint_min >= 1 && c->paint_max <= nclust, LDW_ERR_ARG,
+                "ldw_sr_len_quantiles: cds_var$paint must lie in 1..nclust (found %d..%d, nclust %d)", (int)c->paint_min,
+                (int)c->paint_max, nclust);
+    for (size_t i = 1; i < c->h_POS.size(); ++i)
+        LDW_REQUIRE(c->h_POS[i] > c->h_POS[i - 1], LDW_ERR_ARG, "ldw_sr_len_quantiles: POS must be strictly increasing");
+    const int64_t n = c->n_sr;
+    c->srm_S = S;
+    c->srm_nclust = nclust;
+    c->srm_sr_dist = sr_dist;
+    const size_t cells = (size_t)nclust * S;
+    std::vector<double> q(cells * 2, std::nan(""));
+    if (n == 0) {
+        for (size_t k = 0; k < cells; ++k) {
+            q_lo_out[k] = q_hi_out[k] = std::nan("");
+            n_out[k] = 0;
+        }
+        return LDW_OK;
+    }
+    if (int rc = c->srm_pack.reserve((size_t)n * 4)) return rc;
+    if (int rc = c->srm_pack2.reserve((size_t)n * 4)) return rc;
+    if (int rc = c->srm_key.reserve((size_t)n * 8)) return rc;
+    if (int rc = c->srm_key2.reserve((size_t)n * 8)) return rc;
+    if (int rc = c->srm_off.reserve((size_t)(S + 2) * 8)) return rc;
+    if (int rc = c->srm_q.reserve(cells * 16)) return rc;
+    if (int rc = c->srm_n.reserve(cells * 8)) return rc;
+    uint32_t *pack = c->srm_pack.as<uint32_t>(), *pack2 = c->srm_pack2.as<uint32_t>();
+    uint64_t *key = c->srm_key.as<uint64_t>(), *key2 = c->srm_key2.as<uint64_t>();
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 65536);
+    hipLaunchKernelGGL(k_sr_tag, dim3(grid), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(),
+                       c->sr_mi.as<double>(), n, c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, sr_dist, pack, key);
+    // Two stable LSD sorts, both over the FULL width of their key type: by MI (u64 keys, tags as values), then by len
+    // (u16 keys, {MI key, tag} as values) -> ordered by (len, MI).  rocPRIM 7.2's merge-sort path mis-sorts u32 keys on a
+    // partial bit range at mid sizes (tools/scratch/sorttest.hip), so no begin_bit/end_bit tricks here.
+    if (int rc = c->srm_pay.reserve((size_t)n * sizeof(SrPay))) return rc;
+    if (int rc = c->srm_pay2.reserve((size_t)n * sizeof(SrPay))) return rc;
+    uint16_t *len16 = reinterpret_cast<uint16_t *>(pack), *len16b = len16 + n;   // pack is free after the first sort
+    SrPay *pay = c->srm_pay.as<SrPay>(), *pay2 = c->srm_pay2.as<SrPay>();
+    size_t t1 = 0, t2 = 0;
+    LDW_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t1, key, key2, pack, pack2, n, 0, 64, c->stream));
+    LDW_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t2, len16, len16b, pay, pay2, n, 0, 16, c->stream));
+    if (int rc = c->scratch.reserve(std::max(t1, t2))) return rc;
+    size_t tb = c->scratch.cap;
+    LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tb, key, key2, pack, pack2, n, 0, 64, c->stream));
+    hipLaunchKernelGGL(k_sr_split, dim3(grid), dim3(256), 0, c->stream, pack2, key2, n, len16, pay);
+    tb = c->scratch.cap;
+    LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tb, len16, len16b, pay, pay2, n, 0, 16, c->stream));
+    hipLaunchKernelGGL(k_sr_seg_offsets, dim3((S + 2 + 255) / 256), dim3(256), 0, c->stream, len16b, n, S, c->srm_off.as<int64_t>());
+    LDW_HIP(hipMemcpyAsync(c->srm_q.p, q.data(), cells * 16, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_sr_quant, dim3(S), dim3(256), 0, c->stream, pay2, c->srm_off.as<int64_t>(), S, nclust, prob,
+                       c->srm_q.as<double>(), c->srm_n.as<int64_t>());
+    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipMemcpyAsync(q.data(), c->srm_q.p, cells * 16, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(n_out, c->srm_n.p, cells * 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < cells; ++k) {
+        q_lo_out[k] = q[2 * k];
+        q_hi_out[k] = q[2 * k + 1];
+    }
+    return LDW_OK;
+}
+
+static int upload_md(ldw_ctx *c, int nclust, int32_t S, const double *mean_dist, const char *who) {
+    LDW_REQUIRE(nclust == c->srm_nclust && S == c->srm_S, LDW_ERR_STATE, "%s: nclust/S differ from the last ldw_sr_len_quantiles call", who);
+    LDW_REQUIRE(mean_dist, LDW_ERR_ARG, "%s: null mean_dist", who);
+    if (int rc = c->srm_md.reserve((size_t)nclust * S * 8)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->srm_md.p, mean_dist, (size_t)nclust * S * 8, hipMemcpyHostToDevice, c->stream));
+    return LDW_OK;
+}
+
+int ldw_sr_excess_stats(ldw_ctx *c, int nclust, int32_t S, const double *mean_dist, double *stats_out) {
+    if (int rc = sr_ready(c, "ldw_sr_excess_stats")) return rc;
+    if (int rc = upload_md(c, nclust, S, mean_dist, "ldw_sr_excess_stats")) return rc;
+    LDW_REQUIRE(stats_out, LDW_ERR_ARG, "ldw_sr_excess_stats: null output");
+    const int64_t n = c->n_sr;
+    for (int k = 0; k < nclust * 5; ++k) stats_out[k] = 0.0;
+    if (n == 0) return LDW_OK;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, SRM_GRID);
+    const size_t pbytes = (size_t)grid * nclust * 5 * 8;
+    if (int rc = c->srm_part.reserve(pbytes)) return rc;
+    hipLaunchKernelGGL(k_sr_stats, dim3(grid), dim3(256), (size_t)4 * nclust * 5 * 8, c->stream, c->sr_a.as<int32_t>(),
+                       c->sr_b.as<int32_t>(), c->sr_mi.as<double>(), n, c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g,
+                       c->srm_sr_dist, c->srm_md.as<double>(), S, nclust, c->srm_part.as<double>());
+    LDW_HIP(hipGetLastError());
+    std::vector<double> part((size_t)grid * nclust * 5);
+    LDW_HIP(hipMemcpyAsync(part.data(), c->srm_part.p, pbytes, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < grid; ++b)   // fixed order: the result does not depend on scheduling
+        for (int k = 0; k < nclust * 5; ++k) stats_out[k] += part[(size_t)b * nclust * 5 + k];
+    return LDW_OK;
+}
+
+int ldw_sr_pvalues(ldw_ctx *c, int nclust, int32_t S, const double *mean_dist, const double *shape, double srp_cutoff,
+                   int64_t *n_red_out, int64_t *n_pool_out, double *min_mi_out) {
+    if (int rc = sr_ready(c, "ldw_sr_pvalues")) return rc;
+    if (int rc = upload_md(c, nclust, S, mean_dist, "ldw_sr_pvalues")) return rc;
+    LDW_REQUIRE(shape && n_red_out && n_pool_out, LDW_ERR_ARG, "ldw_sr_pvalues: null argument");
+    for (int k = 0; k < nclust; ++k)
+        LDW_REQUIRE(shape[3 * k] > 0 && shape[3 * k + 1] > 0 && std::isfinite(shape[3 * k + 2]), LDW_ERR_ARG,
+                    "ldw_sr_pvalues: cluster %d has an invalid beta shape", k + 1);
+    const int64_t n = c->n_sr;
+    c->n_red = c->n_pool = 0;
+    *n_red_out = *n_pool_out = 0;
+    if (min_mi_out) *min_mi_out = std::nan("");
+    if (n == 0) return LDW_OK;
+    if (int rc = c->srm_shape.reserve((size_t)nclust * 24)) return rc;
+    if (int rc = c->srm_cnt.reserve(sizeof(SrCounters))) return rc;
+    LDW_HIP(hipMemcpyAsync(c->srm_shape.p, shape, (size_t)nclust * 24, hipMemcpyHostToDevice, c->stream));
+    SrCounters h = {0, 0, ~0ull};
+    SrCounters *d = c->srm_cnt.as<SrCounters>();
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 16384);
+    const int32_t *sa = c->sr_a.as<int32_t>(), *sb = c->sr_b.as<int32_t>();
+    const double *smi = c->sr_mi.as<double>();
+    const int32_t *POS = c->POS.as<int32_t>(), *paint = c->paint.as<int32_t>();
+    // pass 1 writes into whatever capacity is there; a second pass runs only if it was too small
+    for (int pass = 0; pass < 2; ++pass) {
+        const int64_t cap = (int64_t)(c->red_row.cap / 8);
+        LDW_HIP(hipMemcpyAsync(d, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_sr_pval<1>, dim3(grid), dim3(256), 0, c->stream, sa, sb, smi, n, POS, paint, c->g, c->srm_sr_dist,
+                           c->srm_md.as<double>(), S, c->srm_shape.as<double>(), srp_cutoff, d, c->red_row.as<int64_t>(),
+                           c->red_meta.as<uint32_t>(), c->red_srp.as<double>(),
+                           std::min<int64_t>(cap, std::min<int64_t>((int64_t)(c->red_meta.cap / 4), (int64_t)(c->red_srp.cap / 8))));
+        LDW_HIP(hipGetLastError());
+        SrCounters got;
+        LDW_HIP(hipMemcpyAsync(&got, d, sizeof(got), hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+        c->n_red = (int64_t)got.n_red;
+        h.min_key = got.min_key;
+        const int64_t have = std::min<int64_t>(cap, std::min<int64_t>((int64_t)(c->red_meta.cap / 4), (int64_t)(c->red_srp.cap / 8)));
+        if (c->n_red <= have) break;
+        LDW_REQUIRE(pass == 0, LDW_ERR_STATE, "ldw_sr_pvalues: reduced set changed size between passes");
+        if (int rc = c->red_row.reserve((size_t)c->n_red * 8)) return rc;
+        if (int rc = c->red_meta.reserve((size_t)c->n_red * 4)) return rc;
+        if (int rc = c->red_srp.reserve((size_t)c->n_red * 8)) return rc;
+        h.min_key = ~0ull;
+    }
+    *n_red_out = c->n_red;
+    if (c->n_red == 0) return LDW_OK;
+    if (min_mi_out) *min_mi_out = key_f64(h.min_key);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int64_t cap = std::min<int64_t>((int64_t)(c->pool_a.cap / 4), std::min<int64_t>((int64_t)(c->pool_b.cap / 4), (int64_t)(c->pool_mi.cap / 8)));
+        SrCounters h2 = {0, 0, h.min_key};
+        LDW_HIP(hipMemcpyAsync(d, &h2, sizeof(h2), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_sr_pool<1>, dim3(grid), dim3(256), 0, c->stream, sa, sb, smi, n, POS, paint, c->g, c->srm_sr_dist,
+                           c->srm_md.as<double>(), S, d, c->pool_a.as<int32_t>(), c->pool_b.as<int32_t>(), c->pool_mi.as<double>(), cap);
+        LDW_HIP(hipGetLastError());
+        SrCounters got;
+        LDW_HIP(hipMemcpyAsync(&got, d, sizeof(got), hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+        c->n_pool = (int64_t)got.n_pool;
+        if (c->n_pool <= cap) break;
+        LDW_REQUIRE(pass == 0, LDW_ERR_STATE, "ldw_sr_pvalues: pool changed size between passes");
+        if (int rc = c->pool_a.reserve((size_t)c->n_pool * 4)) return rc;
+        if (int rc = c->pool_b.reserve((size_t)c->n_pool * 4)) return rc;
+        if (int rc = c->pool_mi.reserve((size_t)c->n_pool * 8)) return rc;
+    }
+    *n_pool_out = c->n_pool;
+    return LDW_OK;
+}
+
+int ldw_sr_reduced_fetch(ldw_ctx *c, int64_t capacity, int64_t *row_out, int32_t *a_out, int32_t *b_out, double *MI_out,
+                         int32_t *clust_c_out, int32_t *first_clust_out, uint8_t *dup_out, double *srp_out) {
+    if (int rc = check_gpu(c)) return rc;
+    const int64_t n = c->n_red;
+    LDW_REQUIRE(capacity >= n, LDW_ERR_SIZE, "ldw_sr_reduced_fetch: capacity %lld < %lld rows", (long long)capacity, (long long)n);
+    if (n == 0) return LDW_OK;
+    LDW_REQUIRE(row_out && a_out && b_out && MI_out && clust_c_out && first_clust_out && dup_out && srp_out, LDW_ERR_ARG,
+                "ldw_sr_reduced_fetch: null output");
+    std::vector<uint32_t> meta((size_t)n);
+    if (int rc = c->scratch.reserve((size_t)n * 16)) return rc;
+    double *gmi = c->scratch.as<double>();
+    int32_t *ga = reinterpret_cast<int32_t *>(gmi + n), *gb = ga + n;
+    hipLaunchKernelGGL(k_red_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->red_row.as<int64_t>(), n,
+                       c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), c->sr_mi.as<double>(), ga, gb, gmi);
+    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipMemcpyAsync(a_out, ga, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(b_out, gb, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(MI_out, gmi, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(row_out, c->red_row.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(meta.data(), c->red_meta.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(srp_out, c->red_srp.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < n; ++i) {
+        clust_c_out[i] = (int32_t)(meta[i] & 0xFF);
+        first_clust_out[i] = (int32_t)((meta[i] >> 8) & 0xFF);
+        dup_out[i] = (uint8_t)((meta[i] >> 16) & 1);
+    }
+    return LDW_OK;
+}
+
+int ldw_sr_pool_fetch(ldw_ctx *c, int64_t capacity, int32_t *a_out, int32_t *b_out, double *MI_out) {
+    if (int rc = check_gpu(c)) return rc;
+    const int64_t n = c->n_pool;
+    LDW_REQUIRE(capacity >= n, LDW_ERR_SIZE, "ldw_sr_pool_fetch: capacity %lld < %lld rows", (long long)capacity, (long long)n);
+    if (n == 0) return LDW_OK;
+    LDW_REQUIRE(a_out && b_out && MI_out, LDW_ERR_ARG, "ldw_sr_pool_fetch: null output");
+    LDW_HIP(hipMemcpyAsync(a_out, c->pool_a.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(b_out, c->pool_b.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(MI_out, c->pool_mi.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
+
+int ldw_aracne_device(ldw_ctx *c, int64_t capacity, uint8_t *flags_out) {
+    if (int rc = check_gpu(c)) return rc;
+    const int64_t nr = c->n_red, np = c->n_pool;
+    LDW_REQUIRE(capacity >= nr, LDW_ERR_SIZE, "ldw_aracne_device: capacity %lld < %lld links", (long long)capacity, (long long)nr);
+    if (nr == 0) return LDW_OK;
+    LDW_REQUIRE(flags_out, LDW_ERR_ARG, "ldw_aracne_device: null output");
+    LDW_REQUIRE(np > 0, LDW_ERR_STATE, "ldw_aracne_device: no pool (call ldw_sr_pvalues first)");
+    const int64_t n2 = 2 * np, L = c->L;
+    if (int rc = c->ar_key.reserve((size_t)n2 * 8)) return rc;
+    if (int rc = c->ar_key2.reserve((size_t)n2 * 8)) return rc;
+    if (int rc = c->ar_val.reserve((size_t)n2 * 8)) return rc;
+    if (int rc = c->ar_val2.reserve((size_t)n2 * 8)) return rc;
+    if (int rc = c->ar_off.reserve((size_t)(L + 2) * 8)) return rc;
+    if (int rc = c->ar_flags.reserve((size_t)nr)) return rc;
+    const int grid = (int)std::min<int64_t>((np + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_ar_edges, dim3(grid), dim3(256), 0, c->stream, c->pool_a.as<int32_t>(), c->pool_b.as<int32_t>(),
+                       c->pool_mi.as<double>(), np, c->ar_key.as<uint64_t>(), c->ar_val.as<double>());
+    size_t tb = 0;
+    LDW_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, c->ar_key.as<uint64_t>(), c->ar_key2.as<uint64_t>(), c->ar_val.as<double>(),
+                                               c->ar_val2.as<double>(), n2, 0, 64, c->stream));
+    if (int rc = c->scratch.reserve(tb)) return rc;
+    tb = c->scratch.cap;
+    LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tb, c->ar_key.as<uint64_t>(), c->ar_key2.as<uint64_t>(),
+                                               c->ar_val.as<double>(), c->ar_val2.as<double>(), n2, 0, 64, c->stream));
+    hipLaunchKernelGGL(k_ar_offsets, dim3((unsigned)((L + 1 + 255) / 256)), dim3(256), 0, c->stream, c->ar_key2.as<uint64_t>(), n2, L,
+                       c->ar_off.as<int64_t>());
+    hipLaunchKernelGGL(k_ar_check, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, c->stream, c->red_row.as<int64_t>(), nr,
+                       c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), c->sr_mi.as<double>(), c->ar_key2.as<uint64_t>(),
+                       c->ar_val2.as<double>(), c->ar_off.as<int64_t>(), c->ar_flags.as<uint8_t>());
+    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipMemcpyAsync(flags_out, c->ar_flags.p, (size_t)nr, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
+
+}  // extern "C"

@@ -207,6 +207,61 @@ class Engine:
         L.check(L.lib().ldw_block_stats(self._ctx, nb, L.ptr(t), L.ptr(k), L.ptr(s), L.ptr(d)))
         return dict(n_lr_total=t, n_lr_kept=k, n_sr=s, disc_thresh=d)
 
+    # -- short-range model / ARACNE on the device-resident sr table ---------------
+    def sr_len_quantiles(self, nclust: int, sr_dist: float, prob: float = 0.95):
+        """(q_lo, q_hi, n), each (nclust, S) with S = ceil(sr_dist)-1; column l-1 is len l."""
+        S = int(np.ceil(sr_dist)) - 1
+        qlo = np.empty((nclust, S), dtype=np.float64)
+        qhi = np.empty((nclust, S), dtype=np.float64)
+        n = np.empty((nclust, S), dtype=np.int64)
+        L.check(L.lib().ldw_sr_len_quantiles(self._ctx, int(nclust), float(sr_dist), float(prob), S, L.ptr(qlo), L.ptr(qhi), L.ptr(n)))
+        return qlo, qhi, n
+
+    def sr_excess_stats(self, mean_dist: np.ndarray) -> np.ndarray:
+        md = np.ascontiguousarray(mean_dist, dtype=np.float64)
+        out = np.empty((md.shape[0], 5), dtype=np.float64)
+        L.check(L.lib().ldw_sr_excess_stats(self._ctx, md.shape[0], md.shape[1], L.ptr(md), L.ptr(out)))
+        return out
+
+    def sr_pvalues(self, mean_dist: np.ndarray, shape: np.ndarray, srp_cutoff: float):
+        """Returns (n_red, n_pool, min MI kept)."""
+        md = np.ascontiguousarray(mean_dist, dtype=np.float64)
+        sh = np.ascontiguousarray(shape, dtype=np.float64)
+        assert sh.shape == (md.shape[0], 3)
+        nr, npool, mn = C.c_int64(0), C.c_int64(0), C.c_double(0)
+        L.check(L.lib().ldw_sr_pvalues(self._ctx, md.shape[0], md.shape[1], L.ptr(md), L.ptr(sh), float(srp_cutoff),
+                                       C.byref(nr), C.byref(npool), C.byref(mn)))
+        self._n_red, self._n_pool = nr.value, npool.value
+        return nr.value, npool.value, mn.value
+
+    def sr_reduced(self):
+        n = self._n_red
+        row = np.empty(n, dtype=np.int64)
+        cc = np.empty(n, dtype=np.int32)
+        first = np.empty(n, dtype=np.int32)
+        dup = np.empty(n, dtype=np.uint8)
+        srp = np.empty(n, dtype=np.float64)
+        a = np.empty(n, dtype=np.int32)
+        b = np.empty(n, dtype=np.int32)
+        mi = np.empty(n, dtype=np.float64)
+        L.check(L.lib().ldw_sr_reduced_fetch(self._ctx, n, L.ptr(row), L.ptr(a), L.ptr(b), L.ptr(mi), L.ptr(cc), L.ptr(first),
+                                             L.ptr(dup), L.ptr(srp)))
+        return dict(row=row, a=a, b=b, MI=mi, clust_c=cc, first_clust=first, dup=dup.astype(bool), srp_max=srp)
+
+    def sr_pool(self):
+        n = self._n_pool
+        a = np.empty(n, dtype=np.int32)
+        b = np.empty(n, dtype=np.int32)
+        mi = np.empty(n, dtype=np.float64)
+        L.check(L.lib().ldw_sr_pool_fetch(self._ctx, n, L.ptr(a), L.ptr(b), L.ptr(mi)))
+        return a, b, mi
+
+    def aracne_device(self) -> np.ndarray:
+        """ARACNE flags of the kept links (order of sr_reduced()) against the device-resident pool."""
+        out = np.ones(self._n_red, dtype=np.uint8)
+        L.check(L.lib().ldw_aracne_device(self._ctx, self._n_red, L.ptr(out)))
+        return out.astype(bool)
+
     # -- element-wise twins ------------------------------------------------------
     def acgtn2num(self, nv: np.ndarray, ref_chars) -> None:
         """In-place twin of .ACGTN2num: nv is a Fortran-ordered (5, L) float64 matrix."""

@@ -20,7 +20,7 @@ from . import _lib as L
 from . import rcompat
 from .engine import Engine, aracne
 from .snpdat import CdsVar, SnpDat
-from .srp import COLS, merge_n_sort_sr_links
+from .srp import COLS, merge_n_sort_sr_links, merge_n_sort_sr_links_device
 
 
 # ---------------------------------------------------------------------------------------------
@@ -127,7 +127,7 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
                            runARACNE=True, perform_SR_analysis_only=False, order_links=True, mega_dset=False, *,
                            engine: Engine | None = None, alignment_resident: bool = False,
                            quirk_mode: int = L.QUIRK_REFERENCE, nlimbs: int = 0, verbose: bool = True,
-                           return_aux: bool = False):
+                           return_aux: bool = False, sr_model: str = "device"):
     """Returns the short-range link data.frame (clust_c,pos1,pos2,clust1,clust2,len,MI,srp_max,ARACNE);
     long-range links are appended to ``lr_save_path`` and the returned frame to ``sr_save_path``."""
     t000 = time.time()
@@ -170,9 +170,18 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
                     continue
                 eng.mi_block_links(fi, ti, **kw)
             eng.links_end()
-        sa, sb, smi = eng.links(0)
         la, lb, lmi = eng.links(1)
         stats = eng.block_stats()
+        if sr_model == "device":
+            # mergeNsort_sr_links + runARACNE on the device-resident table; only the kept links come back
+            redd, flags, model_aux = merge_n_sort_sr_links_device(eng, cds_var.nclust, sr_dist, srp_cutoff, POS, paint, g,
+                                                                  run_aracne=runARACNE)
+            pool = eng.sr_pool() if return_aux else None
+            sa, sb, smi = redd["a"], redd["b"], redd["MI"]
+        elif sr_model == "host":
+            sa, sb, smi = eng.links(0)
+        else:
+            raise ValueError("sr_model must be 'device' or 'host'")
     finally:
         if own:
             eng.close()
@@ -185,12 +194,21 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
         append_table(lr_save_path, [lr[c].to_numpy() for c in COLS])
 
     sr = links_frame(sa, sb, smi, POS, paint, g)
-    sr_links = [sr[(sr["clust1"] == ci) | (sr["clust2"] == ci)] for ci in range(1, cds_var.nclust + 1)]
-    red, chk = merge_n_sort_sr_links(sr_links, cds_var.nclust, sr_dist, srp_cutoff)
-    if runARACNE:
-        say(f"Running ARACNE on {len(red)} links... ")
-        red["ARACNE"] = aracne(red["pos1"], red["pos2"], red["MI"], chk["pos1"], chk["pos2"], chk["MI"]).astype(np.float64)
+    if sr_model == "device":
+        red = sr
+        red.insert(0, "clust_c", redd["clust_c"].astype(np.int64))
+        red["srp_max"] = redd["srp_max"]
+        chk = links_frame(*pool, POS, paint, g) if pool is not None else None
+        if runARACNE:
+            say(f"Running ARACNE on {len(red)} links... ")
+            red["ARACNE"] = flags.astype(np.float64)
     else:
+        sr_links = [sr[(sr["clust1"] == ci) | (sr["clust2"] == ci)] for ci in range(1, cds_var.nclust + 1)]
+        red, chk = merge_n_sort_sr_links(sr_links, cds_var.nclust, sr_dist, srp_cutoff)
+        if runARACNE:
+            say(f"Running ARACNE on {len(red)} links... ")
+            red["ARACNE"] = aracne(red["pos1"], red["pos2"], red["MI"], chk["pos1"], chk["pos2"], chk["MI"]).astype(np.float64)
+    if not runARACNE:
         warnings.warn("ARACNE not run, all values will be set to 1")
         red["ARACNE"] = 1.0
     if order_links:

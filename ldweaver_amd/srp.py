@@ -1,6 +1,7 @@
 """Short-range p-value model and link merge: host logic of ``mergeNsort_sr_links``
-(R/computePairwiseMI.R:400-495).  Runs on the host like the reference (it is O(#sr links) table work plus
-a two-parameter optimiser); the device-resident version is listed as "next" in DESIGN.md.
+(R/computePairwiseMI.R:400-495).  Runs on the host like the reference (pandas table work plus a two-parameter
+optimiser) in ``merge_n_sort_sr_links``; ``merge_n_sort_sr_links_device`` is the same model with the O(#sr links) work
+done on the device-resident link table (csrc/ldw_srp.hip), which is what ``perform_MI_computation`` uses.
 
 Reproduced quirks: Q5 ``mean_dist[len]`` is indexed by the VALUE of ``len`` (:448) and Q6 ``srp_max`` is
 a natural-log tail probability (:453).  The plot / RDS side outputs (:430-440) are not produced.
@@ -13,16 +14,15 @@ import pandas as pd
 COLS = ["pos1", "pos2", "clust1", "clust2", "len", "MI"]
 
 
-def beta_mle(x: np.ndarray):
-    """coef(fitdistrplus::fitdist(x, "beta")): moment start + Nelder-Mead on the log-likelihood (optim default)."""
+def beta_mle_stats(n: float, sx: float, sxx: float, slx: float, sl1x: float):
+    """coef(fitdistrplus::fitdist(x, "beta")) from the sufficient statistics n, sum x, sum x^2, sum log x, sum log(1-x):
+    moment start + Nelder-Mead on the log-likelihood (optim default), then Newton on the score equations."""
     from scipy import optimize, special
-    n = x.size
     if n < 2:  # fitdistrplus::fitdist stops the same way; happens when the fit of (:428) is NaN or no link exceeds it
         raise ValueError("fitdist: data must be a numeric vector of length greater than 1 (no short-range link exceeds the fitted decay)")
-    m = float(np.mean(x))
-    v = (n - 1) / n * float(np.var(x, ddof=1))
+    m = sx / n
+    v = sxx / n - m * m                      # (n-1)/n * var(x)
     aux = m * (1 - m) / v - 1
-    slx, sl1x = float(np.sum(np.log(x))), float(np.sum(np.log1p(-x)))
 
     def nll(p):
         a, b = p
@@ -50,6 +50,100 @@ def beta_mle(x: np.ndarray):
     return a, b
 
 
+def beta_mle(x: np.ndarray):
+    x = np.asarray(x, dtype=np.float64)
+    return beta_mle_stats(x.size, float(np.sum(x)), float(np.sum(x * x)), float(np.sum(np.log(x))), float(np.sum(np.log1p(-x))))
+
+
+def _beta_cf(a, b, x):
+    """Continued fraction of the incomplete beta function (modified Lentz), vectorised over x."""
+    tiny = 1e-300
+    qab, qap, qam = a + b, a + 1.0, a - 1.0
+    c = np.ones_like(x)
+    d = 1.0 - qab * x / qap
+    d = 1.0 / np.where(np.abs(d) < tiny, tiny, d)
+    h = d.copy()
+    live = np.ones(x.shape, dtype=bool)
+    for m in range(1, 1001):
+        m2 = 2.0 * m
+        for aa in (m * (b - m) * x / ((qam + m2) * (a + m2)), -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2))):
+            d = 1.0 + aa * d
+            d = 1.0 / np.where(np.abs(d) < tiny, tiny, d)
+            c = 1.0 + aa / c
+            c = np.where(np.abs(c) < tiny, tiny, c)
+            delta = d * c
+            h = np.where(live, h * delta, h)
+        live &= np.abs(delta - 1.0) >= 4e-16
+        if not live.any():
+            break
+    return h
+
+
+def neg_log_beta_sf(x, a: float, b: float) -> np.ndarray:
+    """-pbeta(x, a, b, lower.tail = FALSE, log.p = TRUE)  (R/computePairwiseMI.R:453): the tail stays in log space, so
+    p-values far below the smallest double keep their -log (scipy's logsf returns inf there).  Same evaluation as the
+    device kernel (csrc/ldw_srp.hip)."""
+    from scipy import special
+    x = np.asarray(x, dtype=np.float64)
+    out = np.zeros(x.shape)
+    out[x >= 1.0] = np.inf
+    ok = (x > 0.0) & (x < 1.0)
+    xo = x[ok]
+    lfront = a * np.log(xo) + b * np.log1p(-xo) - special.betaln(a, b)
+    low = xo < (a + 1.0) / (a + b + 2.0)
+    res = np.empty(xo.shape)
+    if low.any():
+        res[low] = -np.log1p(-np.exp(lfront[low]) * _beta_cf(a, b, xo[low]) / a)
+    if (~low).any():
+        res[~low] = -(lfront[~low] + np.log(_beta_cf(b, a, 1.0 - xo[~low]) / b))
+    out[ok] = res
+    return out
+
+
+def fit_decay(ulen: np.ndarray, maxvls: np.ndarray) -> np.ndarray:
+    """mean_dist = exp(fitted(fastLm(log(maxvls) ~ log(len))))  (R/computePairwiseMI.R:428-429)."""
+    X = np.column_stack([np.log(ulen), np.ones(len(ulen))])
+    coef, *_ = np.linalg.lstsq(X, np.log(maxvls), rcond=None)
+    return np.exp(X @ coef)
+
+
+def merge_n_sort_sr_links_device(eng, nclust: int, sr_dist: float, srp_cutoff: float, POS, paint, g, run_aracne=True):
+    """mergeNsort_sr_links + runARACNE with the link table left on the device by ``eng.mi_all_pairs``: the O(#links)
+    work (per-length quantiles, excess statistics, p-values, de-duplication, ARACNE) runs in HBM, the host keeps the
+    least-squares fit and the beta MLE.  Returns sr_links_red (same rows, order and columns as the host path) with the
+    ARACNE column filled, and a dict of side results."""
+    from scipy import special
+    if int(np.max(paint)) > nclust or int(np.min(paint)) < 1:
+        raise ValueError("Cluster mismatch detected, stopping!")
+    qlo, qhi, cnt = eng.sr_len_quantiles(nclust, sr_dist, 0.95)
+    S = qlo.shape[1]
+    md = np.full((nclust, S), np.nan)
+    lens = np.arange(1, S + 1, dtype=np.float64)
+    for ci in range(nclust):
+        has = cnt[ci] > 0
+        n = cnt[ci][has].astype(np.float64)
+        index = 1 + (n - 1) * 0.95                      # quantile type 7 (stats::quantile)
+        h = index - np.floor(index)
+        lo, hi = qlo[ci][has], qhi[ci][has]
+        maxvls = np.where((h > 0) & (hi != lo), (1 - h) * lo + h * hi, lo)
+        mean_dist = fit_decay(lens[has], maxvls)
+        md[ci, :len(mean_dist)] = mean_dist             # looked up by the VALUE of len (Q5)
+    stats = eng.sr_excess_stats(md)
+    shape = np.empty((nclust, 3))
+    for ci in range(nclust):
+        a_, b_ = beta_mle_stats(*stats[ci])
+        shape[ci] = a_, b_, special.betaln(a_, b_)
+    n_red, n_pool, min_mi = eng.sr_pvalues(md, shape, srp_cutoff)
+    red = eng.sr_reduced()
+    flags = eng.aracne_device() if (run_aracne and n_red) else np.ones(n_red, dtype=bool)
+    # reference row order: per cluster the links inside one cluster, then the cross-cluster links in order of first
+    # appearance (R/computePairwiseMI.R:470-486)
+    key_cl = np.where(red["dup"], red["first_clust"], red["clust_c"])
+    order = np.lexsort((red["row"], key_cl, red["dup"]))
+    return {k: v[order] for k, v in red.items()}, flags[order], dict(mean_dist=md, shape=shape, stats=stats, n_pool=n_pool,
+                                                                     min_mi=min_mi, counts=cnt)
+
+
 def merge_n_sort_sr_links(sr_links: list, nclust: int, sr_dist: float, srp_cutoff: float):
     """sr_links: list (one per cluster) of DataFrames with COLS.  Returns (sr_links_red, sr_links_ARACNE_check)."""
     from scipy import stats
@@ -61,10 +155,7 @@ def merge_n_sort_sr_links(sr_links: list, nclust: int, sr_dist: float, srp_cutof
         t = t[t["len"].notna() & (t["len"] < sr_dist) & (t["len"] > 0)]
         # per-length 95th percentile (type 7 == pandas' linear interpolation), sorted by len   (:422)
         maxvls = t.groupby("len", sort=True)["MI"].quantile(0.95)
-        ulen = maxvls.index.to_numpy(dtype=np.float64)
-        X = np.column_stack([np.log(ulen), np.ones(len(ulen))])
-        coef, *_ = np.linalg.lstsq(X, np.log(maxvls.to_numpy()), rcond=None)     # fastLm (:428)
-        mean_dist = np.exp(X @ coef)                                               # (:429)
+        mean_dist = fit_decay(maxvls.index.to_numpy(dtype=np.float64), maxvls.to_numpy())   # fastLm (:428-429)
         li = t["len"].to_numpy().astype(np.int64)                                  # positional index (Q5)
         ok = (li >= 1) & (li <= len(mean_dist))
         md = np.full(len(li), np.nan)
@@ -73,7 +164,7 @@ def merge_n_sort_sr_links(sr_links: list, nclust: int, sr_dist: float, srp_cutof
         idx = np.nonzero(diff > 0)[0]
         a_, b_ = beta_mle(diff[idx])                                               # (:452)
         t = t.iloc[idx].copy()
-        t["srp_max"] = -stats.beta.logsf(diff[idx], a_, b_)                        # (:453, natural log: Q6)
+        t["srp_max"] = neg_log_beta_sf(diff[idx], a_, b_)                          # (:453, natural log: Q6)
         t.insert(0, "clust_c", ci)
         isdup = (t["clust1"] != t["clust2"]).to_numpy()
         main.append(t[~isdup])

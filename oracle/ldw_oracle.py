@@ -556,6 +556,22 @@ def _beta_mle(x: np.ndarray):
     return float(a), float(b)
 
 
+def neg_log_beta_sf(x, a: float, b: float) -> np.ndarray:
+    """-pbeta(x, a, b, lower.tail = FALSE, log.p = TRUE): scipy where the tail is representable, 60-digit mpmath
+    where P(X > x) underflows a double (R's TOMS-708 bratio works in log space there)."""
+    from scipy import stats
+    x = np.asarray(x, dtype=np.float64)
+    with np.errstate(divide="ignore"):
+        out = -stats.beta.logsf(x, a, b)
+    deep = (~np.isfinite(out) | (out > 600.0)) & (x < 1)      # denormal tails lose digits before they vanish
+    if deep.any():
+        import mpmath
+        mpmath.mp.dps = 60
+        for i in np.nonzero(deep)[0]:   # P(X > x) = I_{1-x}(b, a)
+            out[i] = -float(mpmath.log(mpmath.betainc(b, a, 0, 1 - mpmath.mpf(float(x[i])), regularized=True)).real)
+    return out
+
+
 def merge_n_sort_sr_links(sr_links_by_clust, nclust: int, sr_dist: float, srp_cutoff: float):
     """Returns (sr_links_red, sr_links_ARACNE_check) as dicts of columns
     clust_c,pos1,pos2,clust1,clust2,len,MI,srp_max.  Plot/RDS side outputs (:439-440) are not produced.
@@ -585,7 +601,7 @@ def merge_n_sort_sr_links(sr_links_by_clust, nclust: int, sr_dist: float, srp_cu
         diff = t["MI"] - md
         idx = np.nonzero(diff > 0)[0]                                 # NA > 0 is dropped by which()
         a_, b_ = _beta_mle(diff[idx])                                 # (:452)
-        srp = -stats.beta.logsf(diff[idx], a_, b_)                    # (:453)
+        srp = neg_log_beta_sf(diff[idx], a_, b_)                      # (:453)
         t = {k: v[idx] for k, v in t.items()}
         t["srp_max"] = srp
         t["clust_c"] = np.full(len(idx), ci)

@@ -10,6 +10,7 @@ import c_oracle
 import ldw_oracle as orc
 from ldweaver_amd import _lib as L
 from ldweaver_amd import mi as MIH
+from ldweaver_amd import srp as srp_host
 from ldweaver_amd.engine import Engine
 from ldweaver_amd.snpdat import CdsVar, SnpDat
 from ldweaver_amd.synth import synth_alignment
@@ -271,6 +272,92 @@ def test_perform_mi_computation_end_to_end(engine, sample, tmp_path):
     assert len(first) == 6 and float(first[0]) == ref.lr_rows["pos1"][0] and abs(float(first[5]) - ref.lr_rows["MI"][0]) < 1e-9
     srl = open(sr_p).read().splitlines()
     assert len(srl) == len(red) and len(srl[0].split("\t")) == 9
+
+
+@pytest.mark.parametrize("max_blk_sz", [10000, 1000])
+def test_device_sr_model_matches_host_model(engine, sample, tmp_path, max_blk_sz):
+    """mergeNsort_sr_links + runARACNE on the device-resident link table (csrc/ldw_srp.hip) against the host mirror
+    (pandas + the native ARACNE) on the same MI table: same rows in the same order, srp within 1e-9, same flags; and
+    each device reduction against numpy on the fetched table."""
+    st = sample["states"]
+    sd = SnpDat(states=st, POS=sample["POS"], g=sample["g"], uqe=sample["uqe"], r=sample["r"])
+    cv = CdsVar(paint=sample["paint"], nclust=3)
+    kw = dict(ncores=1, plt_folder=str(tmp_path / "plots"), max_blk_sz=max_blk_sz, lr_retain_links=1e6, engine=engine,
+              verbose=False, return_aux=True, order_links=False, srp_cutoff=2.0,
+              quirk_mode=L.QUIRK_REFERENCE if max_blk_sz == 10000 else L.QUIRK_INTENDED)
+    out = {}
+    for model in ("host", "device"):
+        out[model] = MIH.perform_MI_computation(sd, sample["hdw"], cv, lr_save_path=str(tmp_path / f"lr_{model}.tsv"),
+                                                sr_save_path=str(tmp_path / f"sr_{model}.tsv"), sr_model=model, **kw)
+    (rh, ah), (rd, ad) = out["host"], out["device"]
+    assert len(rh) == len(rd) > 100
+    for k in ("clust_c", "pos1", "pos2", "clust1", "clust2", "len", "MI", "ARACNE"):
+        assert np.array_equal(rh[k].to_numpy(dtype=float), rd[k].to_numpy(dtype=float)), k
+    np.testing.assert_allclose(rd["srp_max"].to_numpy(), rh["srp_max"].to_numpy(), rtol=1e-9)
+    assert 0 < rd["ARACNE"].sum() < len(rd) and (rd["clust1"] != rd["clust2"]).any()
+    ch, cd = ah["sr_links_ARACNE_check"], ad["sr_links_ARACNE_check"]
+    key = lambda f: np.lexsort((f["pos2"].to_numpy(), f["pos1"].to_numpy()))
+    assert len(ch) == len(cd)
+    for k in ("pos1", "pos2", "MI"):
+        assert np.array_equal(ch[k].to_numpy()[key(ch)], cd[k].to_numpy()[key(cd)]), k
+    hl, dl = open(tmp_path / "sr_host.tsv").read().splitlines(), open(tmp_path / "sr_device.tsv").read().splitlines()
+    assert len(hl) == len(dl) == len(rd)
+    for x, y in zip(hl, dl):   # identical text except the 15-digit srp_max column
+        x, y = x.split("\t"), y.split("\t")
+        assert x[:7] == y[:7] and x[8] == y[8] and abs(float(x[7]) - float(y[7])) <= 1e-9 * float(x[7])
+
+    # the reductions one by one, on the table the engine still holds
+    a, b, mi = engine.links(0)
+    POS, paint, g = sample["POS"].astype(float), sample["paint"], float(sample["g"])
+    ln = orc.circ_len(POS[b], POS[a], g)
+    qlo, qhi, cnt = engine.sr_len_quantiles(3, 20000, 0.95)
+    assert qlo.shape == (3, 19999)
+    for ci in (1, 2, 3):
+        sel = ((paint[b] == ci) | (paint[a] == ci)) & (ln > 0) & (ln < 20000)
+        li = ln[sel].astype(int)
+        assert np.array_equal(cnt[ci - 1], np.bincount(li, minlength=20000)[1:20000])
+        for l in np.unique(li)[:50]:
+            x = np.sort(mi[sel][li == l])
+            idx = 1 + (len(x) - 1) * 0.95
+            assert qlo[ci - 1, l - 1] == x[int(np.floor(idx)) - 1] and qhi[ci - 1, l - 1] == x[int(np.ceil(idx)) - 1]
+        assert np.isnan(qlo[ci - 1][cnt[ci - 1] == 0]).all()
+    md = np.full((3, 19999), np.nan)
+    md[:, :400] = 0.05 * np.arange(1, 401, dtype=float) ** -0.4     # an arbitrary decay: positional lookup, NaN beyond
+    stats = engine.sr_excess_stats(md)
+    for ci in (1, 2, 3):
+        sel = ((paint[b] == ci) | (paint[a] == ci)) & (ln > 0) & (ln < 20000)
+        li = ln[sel].astype(int)
+        d = mi[sel] - np.where(li <= 19999, md[ci - 1][np.minimum(li, 19999) - 1], np.nan)
+        x = d[d > 0]
+        want = [len(x), x.sum(), (x * x).sum(), np.log(x).sum(), np.log1p(-x).sum()]
+        np.testing.assert_allclose(stats[ci - 1], want, rtol=1e-12)
+    assert np.array_equal(stats, engine.sr_excess_stats(md))     # fixed reduction order: bit-identical on a re-run
+
+
+def test_device_beta_tail_against_scipy(engine, synth):
+    """-log P_beta(X > x): the device continued fraction against scipy (mpmath where the tail underflows a double) over
+    both branches and deep tails, through ldw_sr_pvalues on a table whose MI values are the probes themselves."""
+    from scipy import special
+    d = synth
+    _setup(engine, d)
+    blocks = orc.make_blocks(512, 1000)
+    engine.mi_all_pairs(blocks, sr_dist=3000.0, lr_retain_links=1e6, lr_links_approx=1e5)
+    a, b, mi = engine.links(0)
+    ln = orc.circ_len(d["POS"][b].astype(float), d["POS"][a].astype(float), float(d["g"]))
+    qlo, qhi, cnt = engine.sr_len_quantiles(3, 3000.0, 0.95)
+    for (sa_, sb_) in ((0.7, 3.0), (1.4, 60.0), (2.5, 900.0), (25.0, 4000.0)):
+        md = np.zeros((3, 2999))                              # zero decay: diff = MI itself
+        shape = np.tile([sa_, sb_, special.betaln(sa_, sb_)], (3, 1))
+        n_red, n_pool, mn = engine.sr_pvalues(md, shape, -1.0)
+        red = engine.sr_reduced()
+        ok = (ln > 0) & (ln < 3000) & (mi > 0)
+        assert n_red == int(ok.sum()) == n_pool and mn == mi[ok].min()
+        assert np.array_equal(red["MI"], mi[red["row"]])
+        pick = np.argsort(red["MI"])[np.linspace(0, n_red - 1, 400).astype(int)]
+        want = orc.neg_log_beta_sf(red["MI"][pick], sa_, sb_)
+        np.testing.assert_allclose(red["srp_max"][pick], want, rtol=2e-10, atol=1e-13)
+        np.testing.assert_allclose(red["srp_max"], srp_host.neg_log_beta_sf(red["MI"], sa_, sb_), rtol=2e-10, atol=1e-13)
+        assert want.max() > 5 * max(want.min(), 1e-3)
 
 
 def test_sr_only_mode(engine, synth):
