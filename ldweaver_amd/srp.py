@@ -16,7 +16,9 @@ COLS = ["pos1", "pos2", "clust1", "clust2", "len", "MI"]
 
 def beta_mle_stats(n: float, sx: float, sxx: float, slx: float, sl1x: float):
     """coef(fitdistrplus::fitdist(x, "beta")) from the sufficient statistics n, sum x, sum x^2, sum log x, sum log(1-x):
-    moment start + Nelder-Mead on the log-likelihood (optim default), then Newton on the score equations."""
+    the maximiser of the (strictly concave) beta log-likelihood, found by damped Newton steps on the score equations
+    from fitdistrplus' moment start.  The reference reaches the same point with optim's Nelder-Mead to reltol 1e-8; the
+    simplex is kept only as a fallback for starts Newton cannot use."""
     from scipy import optimize, special
     if n < 2:  # fitdistrplus::fitdist stops the same way; happens when the fit of (:428) is NaN or no link exceeds it
         raise ValueError("fitdist: data must be a numeric vector of length greater than 1 (no short-range link exceeds the fitted decay)")
@@ -24,29 +26,41 @@ def beta_mle_stats(n: float, sx: float, sxx: float, slx: float, sl1x: float):
     v = sxx / n - m * m                      # (n-1)/n * var(x)
     aux = m * (1 - m) / v - 1
 
-    def nll(p):
-        a, b = p
-        if a <= 0 or b <= 0:
-            return np.inf
-        return -((a - 1) * slx + (b - 1) * sl1x - n * special.betaln(a, b))
+    def ll(a, b):
+        if not (a > 0 and b > 0):
+            return -np.inf
+        return (a - 1) * slx + (b - 1) * sl1x - n * special.betaln(a, b)
 
-    res = optimize.minimize(nll, np.array([m * aux, (1 - m) * aux]), method="Nelder-Mead",
+    def newton(a, b, iters):
+        cur = ll(a, b)
+        for _ in range(iters):
+            ga = n * (special.digamma(a + b) - special.digamma(a)) + slx
+            gb = n * (special.digamma(a + b) - special.digamma(b)) + sl1x
+            tab = special.polygamma(1, a + b)
+            haa, hbb, hab = n * (tab - special.polygamma(1, a)), n * (tab - special.polygamma(1, b)), n * tab
+            det = haa * hbb - hab * hab
+            da, db = (hbb * ga - hab * gb) / det, (haa * gb - hab * ga) / det
+            if not (np.isfinite(da) and np.isfinite(db)):
+                return a, b, False
+            t = 1.0
+            while t > 1e-10 and not ll(a - t * da, b - t * db) >= cur - 1e-12 * abs(cur):   # damping: stay feasible, do not go downhill
+                t *= 0.5
+            if t <= 1e-10:
+                return a, b, abs(da) < 1e-9 * a and abs(db) < 1e-9 * b
+            a, b = a - t * da, b - t * db
+            cur = ll(a, b)
+            if t == 1.0 and abs(da) < 1e-13 * a and abs(db) < 1e-13 * b:
+                return a, b, True
+        return a, b, False
+
+    a0, b0 = m * aux, (1 - m) * aux
+    if a0 > 0 and b0 > 0 and np.isfinite(a0) and np.isfinite(b0):
+        a, b, ok = newton(float(a0), float(b0), 100)
+        if ok:
+            return a, b
+    res = optimize.minimize(lambda p: -ll(p[0], p[1]), np.array([a0, b0]), method="Nelder-Mead",
                             options=dict(xatol=1e-10, fatol=1e-12, maxiter=5000, maxfev=10000))
-    # optim() stops at reltol 1e-8 on the log-likelihood; polish to the stationary point with Newton steps on the
-    # score equations so that the result does not depend on the simplex path (deterministic to ~1e-12)
-    a, b = float(res.x[0]), float(res.x[1])
-    for _ in range(50):
-        ga = n * (special.digamma(a + b) - special.digamma(a)) + slx
-        gb = n * (special.digamma(a + b) - special.digamma(b)) + sl1x
-        tab = special.polygamma(1, a + b)
-        haa, hbb, hab = n * (tab - special.polygamma(1, a)), n * (tab - special.polygamma(1, b)), n * tab
-        det = haa * hbb - hab * hab
-        da, db = (hbb * ga - hab * gb) / det, (haa * gb - hab * ga) / det
-        if not (np.isfinite(da) and np.isfinite(db)) or a - da <= 0 or b - db <= 0:
-            break
-        a, b = a - da, b - db
-        if abs(da) < 1e-13 * a and abs(db) < 1e-13 * b:
-            break
+    a, b, _ = newton(float(res.x[0]), float(res.x[1]), 50)
     return a, b
 
 

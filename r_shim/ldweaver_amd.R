@@ -69,3 +69,37 @@ perform_MI_computation <- function(snp.dat, hdw, cds_var, ncores, lr_save_path =
   write.table(x = sr_links_red, file = sr_save_path, append = T, quote = F, row.names = F, col.names = F, sep = "\t")
   sr_links_red
 }
+
+# mergeNsort_sr_links + runARACNE with the short-range table left on the GPU by ldwamd_mi_all_pairs
+# (R/computePairwiseMI.R:400-495): the O(#links) work runs in HBM, R keeps fastLm and fitdist.  Same rows, order and
+# columns as the reference's sr_links_red; use it instead of the to_df(res[[1]]) / mergeNsort_sr_links lines of
+# perform_MI_computation above when the table is too large to bring into R (config 5: 2.25e9 rows).
+mergeNsort_sr_links_device <- function(snp.dat, cds_var, sr_dist, srp_cutoff, runARACNE = TRUE) {
+  nclust <- cds_var$nclust
+  S <- ceiling(sr_dist) - 1
+  q <- .Call("ldwamd_sr_len_quantiles", as.integer(nclust), sr_dist, 0.95)
+  byrow <- function(v) matrix(v, ncol = S, byrow = TRUE)
+  qlo <- byrow(q[[1]]); qhi <- byrow(q[[2]]); cnt <- byrow(q[[3]])
+  md <- matrix(NA_real_, nrow = nclust, ncol = S)
+  for (ci in 1:nclust) {
+    has <- which(cnt[ci, ] > 0)
+    index <- 1 + (cnt[ci, has] - 1) * 0.95; h <- index - floor(index)           # stats::quantile type 7
+    mx <- ifelse(h > 0 & qhi[ci, has] != qlo[ci, has], (1 - h) * qlo[ci, has] + h * qhi[ci, has], qlo[ci, has])
+    mod <- RcppArmadillo::fastLm(cbind(log(has), 1), log(mx))                    # :428
+    md[ci, seq_along(has)] <- exp(fitted(mod))                                   # looked up by the VALUE of len (:448)
+  }
+  st <- matrix(.Call("ldwamd_sr_excess_stats", as.integer(nclust), as.numeric(t(md))), ncol = 5, byrow = TRUE)
+  shape <- t(sapply(1:nclust, function(ci) {
+    n <- st[ci, 1]; slx <- st[ci, 4]; sl1x <- st[ci, 5]; m <- st[ci, 2] / n; v <- st[ci, 3] / n - m^2
+    aux <- m * (1 - m) / v - 1                                                   # fitdistrplus' moment start
+    nll <- function(p) if (any(p <= 0)) Inf else -((p[1] - 1) * slx + (p[2] - 1) * sl1x - n * lbeta(p[1], p[2]))
+    p <- optim(c(m * aux, (1 - m) * aux), nll, control = list(reltol = 1e-14))$par   # the beta likelihood only needs these sums
+    c(p, lbeta(p[1], p[2]))
+  }))
+  r <- .Call("ldwamd_sr_pvalues_aracne", as.integer(nclust), as.numeric(t(md)), as.numeric(t(shape)), srp_cutoff, runARACNE)
+  pos2 <- as.numeric(snp.dat$POS[r[[2]] + 1]); pos1 <- as.numeric(snp.dat$POS[r[[3]] + 1])
+  df <- data.frame(clust_c = r[[5]], pos1 = pos1, pos2 = pos2, clust1 = cds_var$paint[r[[3]] + 1], clust2 = cds_var$paint[r[[2]] + 1],
+                   len = 0.5 * snp.dat$g - abs((pos1 - pos2) %% snp.dat$g - 0.5 * snp.dat$g), MI = r[[4]], srp_max = r[[8]],
+                   ARACNE = r[[9]])
+  df[order(r[[7]], ifelse(r[[7]], r[[6]], r[[5]]), r[[1]]), ]                    # reference row order (:470-486)
+}

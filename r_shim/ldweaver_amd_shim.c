@@ -8,6 +8,7 @@
 #include <R.h>
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -98,7 +99,66 @@ SEXP ldwamd_aracne(SEXP cp1, SEXP cp2, SEXP cmi, SEXP fp1, SEXP fp2, SEXP fmi) {
     return out;
 }
 
+/* ---- mergeNsort_sr_links / runARACNE on the device-resident sr table (R/computePairwiseMI.R:400-495) ---- */
+/* list(q_lo, q_hi, n): nclust x S matrices stored row-major (read them with matrix(., ncol = S, byrow = TRUE)) */
+SEXP ldwamd_sr_len_quantiles(SEXP nclust, SEXP sr_dist, SEXP prob) {
+    ldw_ctx *c = ctx_or_stop();
+    const int nc = asInteger(nclust);
+    const int32_t S = (int32_t)ceil(asReal(sr_dist)) - 1;
+    SEXP res = PROTECT(allocVector(VECSXP, 3));
+    SEXP lo = PROTECT(allocVector(REALSXP, (R_xlen_t)nc * S)), hi = PROTECT(allocVector(REALSXP, (R_xlen_t)nc * S));
+    int64_t *n = (int64_t *)R_alloc((size_t)nc * S, sizeof(int64_t));
+    CHK(ldw_sr_len_quantiles(c, nc, asReal(sr_dist), asReal(prob), S, REAL(lo), REAL(hi), n));
+    SEXP nn = PROTECT(allocVector(REALSXP, (R_xlen_t)nc * S));
+    for (R_xlen_t i = 0; i < (R_xlen_t)nc * S; ++i) REAL(nn)[i] = (double)n[i];
+    SET_VECTOR_ELT(res, 0, lo); SET_VECTOR_ELT(res, 1, hi); SET_VECTOR_ELT(res, 2, nn);
+    UNPROTECT(4);
+    return res;
+}
+
+/* mean_dist: nclust x S row-major doubles (NA beyond the fitted lens) -> nclust x 5 row-major sufficient statistics */
+SEXP ldwamd_sr_excess_stats(SEXP nclust, SEXP mean_dist) {
+    ldw_ctx *c = ctx_or_stop();
+    const int nc = asInteger(nclust);
+    SEXP out = PROTECT(allocVector(REALSXP, (R_xlen_t)nc * 5));
+    CHK(ldw_sr_excess_stats(c, nc, (int32_t)(XLENGTH(mean_dist) / nc), REAL(mean_dist), REAL(out)));
+    UNPROTECT(1);
+    return out;
+}
+
+/* shape: nclust x 3 row-major (shape1, shape2, lbeta).  Returns the kept links with their ARACNE flags:
+ * list(row, a, b, MI, clust_c, first_clust, dup, srp_max, ARACNE) in no particular order. */
+SEXP ldwamd_sr_pvalues_aracne(SEXP nclust, SEXP mean_dist, SEXP shape, SEXP srp_cutoff, SEXP run_aracne) {
+    ldw_ctx *c = ctx_or_stop();
+    const int nc = asInteger(nclust);
+    int64_t n_red = 0, n_pool = 0;
+    double min_mi = 0;
+    CHK(ldw_sr_pvalues(c, nc, (int32_t)(XLENGTH(mean_dist) / nc), REAL(mean_dist), REAL(shape), asReal(srp_cutoff), &n_red, &n_pool, &min_mi));
+    const R_xlen_t n = (R_xlen_t)n_red;
+    SEXP res = PROTECT(allocVector(VECSXP, 9));
+    SEXP row = PROTECT(allocVector(REALSXP, n)), a = PROTECT(allocVector(INTSXP, n)), b = PROTECT(allocVector(INTSXP, n));
+    SEXP mi = PROTECT(allocVector(REALSXP, n)), cc = PROTECT(allocVector(INTSXP, n)), fc = PROTECT(allocVector(INTSXP, n));
+    SEXP dup = PROTECT(allocVector(LGLSXP, n)), srp = PROTECT(allocVector(REALSXP, n)), ar = PROTECT(allocVector(REALSXP, n));
+    int64_t *r64 = (int64_t *)R_alloc((size_t)n + 1, sizeof(int64_t));
+    unsigned char *d8 = (unsigned char *)R_alloc((size_t)n + 1, 1), *f8 = (unsigned char *)R_alloc((size_t)n + 1, 1);
+    CHK(ldw_sr_reduced_fetch(c, n_red, r64, INTEGER(a), INTEGER(b), REAL(mi), INTEGER(cc), INTEGER(fc), d8, REAL(srp)));
+    memset(f8, 1, (size_t)n + 1);
+    if (asLogical(run_aracne)) CHK(ldw_aracne_device(c, n_red, f8));
+    for (R_xlen_t i = 0; i < n; ++i) {
+        REAL(row)[i] = (double)r64[i] + 1;
+        LOGICAL(dup)[i] = d8[i];
+        REAL(ar)[i] = f8[i];
+    }
+    SEXP parts[9] = {row, a, b, mi, cc, fc, dup, srp, ar};
+    for (int k = 0; k < 9; ++k) SET_VECTOR_ELT(res, k, parts[k]);
+    UNPROTECT(10);
+    return res;
+}
+
 static const R_CallMethodDef CallEntries[] = {
+    {"ldwamd_sr_len_quantiles", (DL_FUNC)&ldwamd_sr_len_quantiles, 3},
+    {"ldwamd_sr_excess_stats", (DL_FUNC)&ldwamd_sr_excess_stats, 2},
+    {"ldwamd_sr_pvalues_aracne", (DL_FUNC)&ldwamd_sr_pvalues_aracne, 5},
     {"ldwamd_ACGTN2num", (DL_FUNC)&ldwamd_ACGTN2num, 3},
     {"ldwamd_set_alignment", (DL_FUNC)&ldwamd_set_alignment, 3},
     {"ldwamd_hamming_weights", (DL_FUNC)&ldwamd_hamming_weights, 2},
