@@ -18,7 +18,7 @@
 // and MFMA k-step kk consumes its bits [16kk, 16kk+16); both operands and the digits use the same mapping, and
 // a sum over sequences does not care about their order.
 //
-// Tiling: 128 x 128 rows per workgroup, 8 waves (2 x 4), 64 x 32 per wave = 2 MFMA tiles x J limbs.
+// Tiling: 128 (to side) x 64 (from side) rows per workgroup, 4 waves (2 x 2), 64 x 32 per wave = 2 MFMA tiles x J limbs.
 #include "ldw_internal.h"
 
 namespace ldw {
@@ -38,44 +38,64 @@ __device__ __forceinline__ v4i expand01(uint32_t b16) {
     return r;
 }
 
+// 256-thread workgroups (4 waves, 2 x 2), tile 128 (to side) x 64 (from side), 64 x 32 per wave.  Two workgroups are
+// resident per CU (256 VGPRs per wave, 66.5 KB LDS each), so the prologue (LUT build, first chunk), the per-chunk
+// barrier and the Horner/store tail of one overlap the MFMA loop of the other: 5 % faster than one 512-thread
+// workgroup of 128 x 128 with the same wave tile.
+constexpr int TILE_F4 = 64;
 template <int J>
-__global__ __launch_bounds__(512, 2) void gemm_bits_kernel(const uint64_t *__restrict__ Mbits, int64_t KW,
-                                                           const int32_t *__restrict__ rowlist_t,
-                                                           const int32_t *__restrict__ rowlist_f,
-                                                           const int8_t *__restrict__ digits, int64_t Kpad,
-                                                           int64_t *__restrict__ G, int RFpad, int lower_only,
-                                                           int shift_bits, int accumulate) {
-    const int bx = blockIdx.x, by = blockIdx.y;  // bx: from-side (lanes / N-dim), by: to-side (M-dim)
-    if (lower_only && bx < by) return;
+__global__ __launch_bounds__(256, 2) void gemm_bits_kernel(const uint64_t *__restrict__ Mbits, int64_t KW,
+                                                              const int32_t *__restrict__ rowlist_t,
+                                                              const int32_t *__restrict__ rowlist_f,
+                                                              const int8_t *__restrict__ digits, int64_t Kpad,
+                                                              int64_t *__restrict__ G, int RFpad, int lower_only,
+                                                              int shift_bits, int accumulate) {
+    const int bx = blockIdx.x, by = blockIdx.y;  // bx: from-side tile of 64 rows, by: to-side tile of 128 rows
+    if (lower_only && bx * TILE_F4 + TILE_F4 - 1 < by * TILE) return;
 
     __shared__ __attribute__((aligned(16))) uint64_t sT[2][TILE * BROW];
-    __shared__ __attribute__((aligned(16))) uint64_t sF[2][TILE * BROW];
+    __shared__ __attribute__((aligned(16))) uint64_t sF[2][TILE_F4 * BROW];
     __shared__ __attribute__((aligned(16))) int8_t sD[2][J * BW_CHUNK * 64];
-    // byte -> 8 expanded bytes (0x01 resp. 0xFF where the bit is set): two LDS look-ups replace ~20 VALU
-    // instructions per 16-sequence operand fragment
     __shared__ uint64_t lut01[256], lutFF[256];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave >> 1, wn = wave & 1;
 
-    // staging: a chunk of one operand tile is 128 rows x 16 words = 1024 pieces of 2 words; 2 per thread
-    const uint64_t *gT[2], *gF[2];
-    int wofs[2], wp[2];
+    // staging: to side 128 rows x 8 word pairs = 1024 pieces (4 per thread), from side 64 x 8 = 512 (2 per thread)
+    const uint64_t *gT[4], *gF[2];
+    int woT[4], woF[2], wpT[4], wpF[2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int idx = tid + 256 * p;
+        const int row = idx >> 3;
+        wpT[p] = idx & 7;
+        gT[p] = Mbits + (int64_t)rowlist_t[by * TILE + row] * KW + 2 * wpT[p];
+        woT[p] = row * BROW + 2 * wpT[p];
+    }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const int idx = tid + 512 * p;
+        const int idx = tid + 256 * p;
         const int row = idx >> 3;
-        wp[p] = idx & 7;  // word pair within the chunk
-        gT[p] = Mbits + (int64_t)rowlist_t[by * TILE + row] * KW + 2 * wp[p];
-        gF[p] = Mbits + (int64_t)rowlist_f[bx * TILE + row] * KW + 2 * wp[p];
-        wofs[p] = row * BROW + 2 * wp[p];
+        wpF[p] = idx & 7;
+        gF[p] = Mbits + (int64_t)rowlist_f[bx * TILE_F4 + row] * KW + 2 * wpF[p];
+        woF[p] = row * BROW + 2 * wpF[p];
     }
-    // digits of a chunk: J x 1024 bytes = J*64 pieces of 16 B
-    const bool dig_loader = tid < J * 64;
-    const int dj = tid >> 6, dq = tid & 63;
-    const int8_t *gD = digits + (int64_t)dj * Kpad + dq * 16;
+    // digits of a chunk: J*64 pieces of 16 B over 256 threads
+    constexpr int DP = (J * 64 + 255) / 256;
+    const int8_t *gD[DP];
+    int dOfs[DP], dq[DP];
+    bool dOn[DP];
+#pragma unroll
+    for (int p = 0; p < DP; ++p) {
+        const int idx = tid + 256 * p;
+        dOn[p] = idx < J * 64;
+        const int dj = idx >> 6;
+        dq[p] = idx & 63;
+        gD[p] = digits + (int64_t)(dOn[p] ? dj : 0) * Kpad + dq[p] * 16;
+        dOfs[p] = dj * (BW_CHUNK * 64) + dq[p] * 16;
+    }
 
     v16i acc[J][2];
 #pragma unroll
@@ -87,33 +107,38 @@ __global__ __launch_bounds__(512, 2) void gemm_bits_kernel(const uint64_t *__res
 
     const int nchunk = (int)((KW + BW_CHUNK - 1) / BW_CHUNK);
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    u64x2 rT[2], rF[2];
-    v4i rD = v4i{0, 0, 0, 0};
+    u64x2 rT[4], rF[2];
+    v4i rD[DP];
 
     auto load_chunk = [&](int c) {
         const int64_t w0 = (int64_t)c * BW_CHUNK;
         const int cw = (int)((KW - w0) < BW_CHUNK ? (KW - w0) : BW_CHUNK);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const bool in = 2 * wp[p] < cw;  // KW is even: a word pair is inside or outside as a whole
-            rT[p] = in ? *reinterpret_cast<const u64x2 *>(gT[p] + w0) : u64x2{0ull, 0ull};
-            rF[p] = in ? *reinterpret_cast<const u64x2 *>(gF[p] + w0) : u64x2{0ull, 0ull};
-        }
-        if (dig_loader) rD = (dq * 16 < cw * 64) ? *reinterpret_cast<const v4i *>(gD + w0 * 64) : v4i{0, 0, 0, 0};
+        for (int p = 0; p < 4; ++p) rT[p] = (2 * wpT[p] < cw) ? *reinterpret_cast<const u64x2 *>(gT[p] + w0) : u64x2{0ull, 0ull};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) rF[p] = (2 * wpF[p] < cw) ? *reinterpret_cast<const u64x2 *>(gF[p] + w0) : u64x2{0ull, 0ull};
+#pragma unroll
+        for (int p = 0; p < DP; ++p)
+            rD[p] = (dOn[p] && dq[p] * 16 < cw * 64) ? *reinterpret_cast<const v4i *>(gD[p] + w0 * 64) : v4i{0, 0, 0, 0};
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            sT[buf][wofs[p]] = rT[p][0];
-            sT[buf][wofs[p] + 1] = rT[p][1];
-            sF[buf][wofs[p]] = rF[p][0];
-            sF[buf][wofs[p] + 1] = rF[p][1];
+        for (int p = 0; p < 4; ++p) {
+            sT[buf][woT[p]] = rT[p][0];
+            sT[buf][woT[p] + 1] = rT[p][1];
         }
-        if (dig_loader) *reinterpret_cast<v4i *>(&sD[buf][dj * (BW_CHUNK * 64) + dq * 16]) = rD;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            sF[buf][woF[p]] = rF[p][0];
+            sF[buf][woF[p] + 1] = rF[p][1];
+        }
+#pragma unroll
+        for (int p = 0; p < DP; ++p)
+            if (dOn[p]) *reinterpret_cast<v4i *>(&sD[buf][dOfs[p]]) = rD[p];
     };
 
-    if (tid < 256) {
-        const v4i lo = expand01((uint32_t)tid & 0xFFu);  // only its first two dwords are populated by 8 bits
+    {
+        const v4i lo = expand01((uint32_t)tid & 0xFFu);
         const uint64_t e01 = (uint64_t)(uint32_t)lo[0] | ((uint64_t)(uint32_t)lo[1] << 32);
         lut01[tid] = e01;
         lutFF[tid] = (e01 << 8) - e01;
@@ -128,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bits_kernel(const uint64_t *__res
 
     for (int c = 0; c < nchunk; ++c) {
         const int cur = c & 1;
-        if (c + 1 < nchunk) load_chunk(c + 1);  // lands while this chunk's ~20k MFMA cycles run
+        if (c + 1 < nchunk) load_chunk(c + 1);
         const int64_t w0 = (int64_t)c * BW_CHUNK;
         const int nmac = (int)(((KW - w0) < BW_CHUNK ? (KW - w0) : BW_CHUNK) >> 1);
         for (int m = 0; m < nmac; ++m) {
@@ -141,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bits_kernel(const uint64_t *__res
                 const u64x2v bq = {lutFF[(bw >> (16 * kk)) & 0xFFu], lutFF[(bw >> (16 * kk + 8)) & 0xFFu]};
                 const v4i a0 = __builtin_bit_cast(v4i, a0q), a1 = __builtin_bit_cast(v4i, a1q);
                 const v4i bmask = __builtin_bit_cast(v4i, bq);
-                const int doff = (2 * m + fh) * 64 + kk * 16;  // digits of sequences 128m + 64h + 16kk ..
+                const int doff = (2 * m + fh) * 64 + kk * 16;
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
                     const v4i d = *reinterpret_cast<const v4i *>(&sD[cur][j * (BW_CHUNK * 64) + doff]);
@@ -155,9 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bits_kernel(const uint64_t *__res
         __syncthreads();
     }
 
-    // Horner over limbs in int64 (both operands are non-negative here: no negation).  C/D layout of the 32x32
-    // MFMA: col (N-dim, from-side row) = lane & 31, row (M-dim, to-side row) = (e&3) + 8*(e>>2) + 4*(lane>>5).
-    const int fcol = bx * TILE + wn * 32 + frow;
+    const int fcol = bx * TILE_F4 + wn * 32 + frow;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -203,7 +226,7 @@ int launch_gemm_bits(ldw_ctx *ctx, const int32_t *rowlist_t, int RTpad, const in
     LDW_REQUIRE(RTpad % TILE == 0 && RFpad % TILE == 0 && KW > 0 && KW % 2 == 0 && Kpad == KW * 64, LDW_ERR_ARG,
                 "launch_gemm_bits: padding violated (RT %d RF %d KW %lld)", RTpad, RFpad, (long long)KW);
     LDW_REQUIRE(nlimbs >= 1 && nlimbs <= 6, LDW_ERR_ARG, "launch_gemm_bits: nlimbs %d out of range", nlimbs);
-    dim3 grid(RFpad / TILE, RTpad / TILE), block(512);
+    dim3 grid(RFpad / TILE_F4, RTpad / TILE), block(256);
     int done = 0;
     while (done < nlimbs) {  // up to 5 limbs share one pass over K; 6 limbs run as 3 + 3
         const int J = (nlimbs == 6) ? 3 : nlimbs;
