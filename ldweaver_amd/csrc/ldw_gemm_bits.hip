@@ -1,12 +1,13 @@
-// Bit-packed form of the fixed-point co-occurrence GEMM (the MI path's default).
+// Bit-packed fixed-point co-occurrence GEMM (MI path and Hamming weights).
 //
-// Same contraction as ldw_gemm.hip,  G[t][f] = sum_s V_s [t carries its state in s][f carries its state in s],
-// V_s = sum_j d_j(s) 256^j, but the indicator matrix is stored as BITS (one uint64 per 64 sequences): the byte
-// form was bound by what one CU can pull from L2 / Infinity Cache (16 KB per 64-sequence step and workgroup,
-// ~33 GB/s per CU measured, i.e. ~2.1 ms per 11.6k x 11.6k x 5056 launch whatever the limb count), not by the
-// matrix cores.  Bits cut the global and LDS traffic 8x: a whole 1024-sequence chunk of both operand tiles is
-// 37 KB, loaded once per ~20k MFMA cycles, so the loop between two chunk barriers is pure
-// ds_read_b64 -> expand -> mask -> MFMA with no global load and no barrier.
+//   G[t][f] = sum_s V_s [row t has bit s][row f has bit s],   V_s = sum_j d_j(s) 256^j   (J int8 digit limbs)
+//
+// The indicator matrix is stored as BITS (one uint64 per 64 sequences).  A first version kept it as bytes and was
+// bound by what one CU can pull from L2 / Infinity Cache (16 KB per 64-sequence step and workgroup, ~33 GB/s per CU
+// measured, i.e. ~2.1 ms per 11.6k x 11.6k x 5056 launch whatever the limb count), not by the matrix cores.  Bits
+// cut the global and LDS traffic 8x: a whole 1024-sequence chunk of both operand tiles is 28 KB, loaded once per
+// ~20k MFMA cycles, so the loop between two chunk barriers is pure ds_read_b64 -> expand -> mask -> MFMA with no
+// global load and no barrier.
 //
 // Expansion, per 16 sequences (one MFMA operand fragment): two look-ups in a 256-entry LDS table (byte of bits ->
 // 8 bytes of 0x01 for the M-dim operand, of 0xFF for the N-dim operand, built once per workgroup with
@@ -220,9 +221,9 @@ __global__ __launch_bounds__(256) void k_fill_rows_bits(const uint8_t *__restric
     }
 }
 
-int launch_gemm_bits(ldw_ctx *ctx, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f, int RFpad, int64_t *G,
-                     int nlimbs, const int8_t *digits, int lower_only) {
-    const int64_t KW = ctx->KW, Kpad = ctx->Npad;
+int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f,
+                     int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only) {
+    const int64_t Kpad = KW * 64;
     LDW_REQUIRE(RTpad % TILE == 0 && RFpad % TILE == 0 && KW > 0 && KW % 2 == 0 && Kpad == KW * 64, LDW_ERR_ARG,
                 "launch_gemm_bits: padding violated (RT %d RF %d KW %lld)", RTpad, RFpad, (long long)KW);
     LDW_REQUIRE(nlimbs >= 1 && nlimbs <= 6, LDW_ERR_ARG, "launch_gemm_bits: nlimbs %d out of range", nlimbs);
@@ -234,7 +235,7 @@ int launch_gemm_bits(ldw_ctx *ctx, const int32_t *rowlist_t, int RTpad, const in
         const int shift = 8 * done, accum = done > 0;
 #define LDW_LAUNCH_B(JJ)                                                                                        \
     case JJ:                                                                                                    \
-        hipLaunchKernelGGL(gemm_bits_kernel<JJ>, grid, block, 0, ctx->stream, ctx->Mbits.as<uint64_t>(), KW,   \
+        hipLaunchKernelGGL(gemm_bits_kernel<JJ>, grid, block, 0, ctx->stream, Mbits, KW,                           \
                            rowlist_t, rowlist_f, dg, Kpad, G, RFpad, lower_only, shift, accum);                 \
         break;
         switch (J) {

@@ -3,11 +3,19 @@
 //   shared[i][j] = #{snps a : state(a,i) == state(a,j)} = sum over the 5 states of crossprod(M_X)   (:49-74)
 //   hdw[j]       = 1 / (#{i : L - shared[i][j] < thresh} + 1)                                        (:76)
 //
-// The five sparse x dense crossprods become ONE exact i8 GEMM: a sequence-major one-hot matrix
-// H[s][5a+X] (0xFF where sequence s carries state X at SNP a) multiplied with itself over K = 5L with
-// unit digits (gemm_limb_kernel<1>), accumulated in int64 over SNP chunks.
+// The five sparse x dense crossprods become ONE exact bit-packed i8 GEMM over far fewer than 5L indicator columns.
+// Per SNP let d be its most frequent state and A_i = [x_i != d].  Then
+//     [x_i == x_j] = sum_{s != d} [x_i = s][x_j = s] + (1 - A_i)(1 - A_j)
+//                  = 1 - A_i - A_j + A_i A_j + sum_{s != d} [x_i = s][x_j = s],
+// so with c_i = sum_snps A_i,
+//     shared[i][j] = L - c_i - c_j + sum_k w_k B_ki B_kj
+// over the columns k = (SNP, minor state) with weight 1, plus one column A per SNP with weight 1; a SNP with a single
+// minor state has A == that column, which then simply gets weight 2 (a biallelic SNP is ONE column, a monomorphic SNP
+// none).  The GEMM is gemm_bits_kernel<1> (ldw_gemm_bits.hip) on a sequence-major bit matrix with the weights as
+// its per-k digit; only tiles on or below the diagonal are computed.  Everything is integer arithmetic: bit-exact.
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 #include "ldw_internal.h"
 
@@ -15,46 +23,86 @@ using namespace ldw;
 
 namespace ldw {
 
-// states [L][Npad] chunk (SNPs a0 .. a0+nl) -> H[s][5*(a-a0)+X], rows of Kc bytes.  64 SNPs x 64 sequences
-// per workgroup through LDS so that both the read (along sequences) and the write (along 5a+X) are
-// contiguous.
-__global__ __launch_bounds__(256) void k_onehot_T(const uint8_t *__restrict__ states, int64_t Npad, int64_t a0,
-                                                  int64_t nl, int64_t N, uint8_t *__restrict__ H, int64_t Kc) {
-    __shared__ uint8_t tile[64][65];
-    const int64_t la0 = (int64_t)blockIdx.x * 64, s0 = (int64_t)blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4) {  // i: SNP in tile, tx: sequence
-        const int64_t la = la0 + i, s = s0 + tx;
-        tile[i][tx] = (la < nl && s < N) ? states[(a0 + la) * Npad + s] : (uint8_t)255;
-    }
-    __syncthreads();
-    // each sequence row of the tile is 320 output bytes; 256 threads cover 64 rows x 320 B in 80 steps of 1 row x 256.. use byte loop
-    for (int i = ty; i < 64; i += 4) {  // i: sequence in tile
-        const int64_t s = s0 + i;
-        if (s >= N) continue;
-        uint8_t *dst = H + s * Kc + la0 * 5;
-        for (int k = tx; k < 320; k += 64) {
-            const int la = k / 5, X = k - la * 5;
-            if (la0 + la < nl) dst[k] = tile[la][i] == X ? (uint8_t)0xFF : (uint8_t)0;
+// Column bits, SNP-major like Mbits: Hb[k][w] bit i = predicate(states[snp(k)][64 w + i]); info = snp*16 + mode*8 + state,
+// mode 0: x == state, mode 1: x != state (and x is a real state, not padding)
+__global__ __launch_bounds__(256) void k_hamming_cols(const uint8_t *__restrict__ states, int64_t Npad, const int32_t *__restrict__ info,
+                                                      int64_t KW, uint64_t *__restrict__ Hb) {
+    const int64_t k = blockIdx.x;
+    const int32_t inf = info[k];
+    const int64_t snp = inf >> 4;
+    const uint32_t st = (uint32_t)(inf & 7);
+    const bool neq = (inf >> 3) & 1;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(states + snp * Npad);
+    for (int64_t w = threadIdx.x; w < KW; w += blockDim.x) {
+        uint64_t bits = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t x = src[w * 16 + q];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t v = (x >> (8 * b)) & 0xFFu;
+                const bool on = neq ? (v != st && v < 5u) : (v == st);
+                bits |= (uint64_t)on << (4 * q + b);
+            }
         }
+        Hb[k * KW + w] = bits;
     }
 }
 
-__global__ __launch_bounds__(256) void k_hdw(const int64_t *__restrict__ G, int ld, int64_t N, int64_t L, int thresh,
-                                             double *__restrict__ hdw) {
+// 64 x 64 bit-tile transpose: Hb[KR][KW] (columns x sequence words) -> T[KW*64][KWr] (sequences x column words).
+// One wave per tile; ballot b collects bit b of every lane's word = the output word of sequence 64 w + b.
+__global__ __launch_bounds__(256) void k_bits_transpose(const uint64_t *__restrict__ Hb, int64_t KR, int64_t KW,
+                                                        uint64_t *__restrict__ T, int64_t KWr) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), w = blockIdx.y;
+    if (v >= KWr) return;
+    const int64_t k = v * 64 + lane;
+    const uint64_t x = k < KR ? Hb[k * KW + w] : 0ull;
+    uint64_t out = 0;
+#pragma unroll 8
+    for (int b = 0; b < 64; ++b) {
+        const uint64_t m = __ballot((x >> b) & 1ull);
+        if (lane == b) out = m;
+    }
+    T[(w * 64 + lane) * KWr + v] = out;
+}
+
+// c[i] = number of SNPs at which sequence i does not carry the SNP's most frequent state
+__global__ __launch_bounds__(256) void k_seq_minor_count(const uint64_t *__restrict__ T, const uint64_t *__restrict__ umask,
+                                                         int64_t rows, int64_t KWr, int32_t *__restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    int c = 0;
+    for (int64_t v = lane; v < KWr; v += 64) c += __popcll(T[i * KWr + v] & umask[v]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if (lane == 0) cnt[i] = c;
+}
+
+// shared(i, j) from the lower-triangular G (element (t, f) with t <= f is always inside a computed tile)
+__device__ __forceinline__ int64_t shared_ij(const int64_t *__restrict__ G, int ld, const int32_t *__restrict__ cnt, int64_t L,
+                                             int64_t i, int64_t j) {
+    const int64_t t = i < j ? i : j, f = i < j ? j : i;
+    return L - cnt[i] - cnt[j] + G[t * ld + f];
+}
+
+__global__ __launch_bounds__(256) void k_hdw(const int64_t *__restrict__ G, int ld, const int32_t *__restrict__ cnt, int64_t N,
+                                             int64_t L, int thresh, double *__restrict__ hdw) {
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= N) return;
-    int cnt = 0;
-    for (int64_t i = lane; i < N; i += 64) cnt += ((L - G[j * ld + i]) < (int64_t)thresh) ? 1 : 0;  // shared is symmetric
+    int n = 0;
+    for (int64_t i = lane; i < N; i += 64) n += ((L - shared_ij(G, ld, cnt, L, i, j)) < (int64_t)thresh) ? 1 : 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-    if (lane == 0) hdw[j] = 1.0 / ((double)cnt + 1.0);
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
+    if (lane == 0) hdw[j] = 1.0 / ((double)n + 1.0);
 }
 
-__global__ void k_shared_i32(const int64_t *__restrict__ G, int ld, int64_t N, int32_t *__restrict__ out) {
+__global__ void k_shared_i32(const int64_t *__restrict__ G, int ld, const int32_t *__restrict__ cnt, int64_t N, int64_t L,
+                             int32_t *__restrict__ out) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, j = blockIdx.y;
-    if (i < N) out[j * N + i] = (int32_t)G[j * ld + i];
+    if (i < N) out[j * N + i] = (int32_t)shared_ij(G, ld, cnt, L, i, j);
 }
 
 }  // namespace ldw
@@ -63,43 +111,84 @@ extern "C" int ldw_hamming_weights(ldw_ctx *c, int32_t thresh, double *hdw_out, 
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(c->L > 0, LDW_ERR_STATE, "ldw_hamming_weights: set the alignment first");
     LDW_REQUIRE(hdw_out, LDW_ERR_ARG, "ldw_hamming_weights: hdw_out is null");
-    const int64_t L = c->L, N = c->N, Npad = c->Npad;
-    const int Rp = (int)((N + TILE - 1) / TILE * TILE);
-    // SNP chunk: keep the one-hot matrix below ~2 GiB
-    int64_t Lc = std::max<int64_t>(64, (int64_t)((2147483648LL / 5) / std::max<int64_t>(N, 1)) / 64 * 64);
-    Lc = std::min<int64_t>(Lc, (L + 63) / 64 * 64);
-    const int64_t Kc = (Lc * 5 + KSTEP - 1) / KSTEP * KSTEP;
-    ldw::DevBuf H, Gh, ones, rl, dhdw;
+    const int64_t L = c->L, N = c->N, Npad = c->Npad, KW = c->KW;
+    const int Rp = (int)Npad;  // sequences padded to the GEMM tile (Npad is a multiple of 128)
+    ldw::DevBuf info, Hb, T, dig, um, Gh, rl, scnt, dhdw;
     int rc = LDW_OK;
     auto done = [&](int code) {
-        H.release(); Gh.release(); ones.release(); rl.release(); dhdw.release();
+        for (ldw::DevBuf *b : {&info, &Hb, &T, &dig, &um, &Gh, &rl, &scnt, &dhdw}) b->release();
         return code;
     };
-    if ((rc = H.reserve((size_t)(N + 1) * Kc)) || (rc = Gh.reserve((size_t)Rp * Rp * 8)) || (rc = ones.reserve((size_t)Kc)) ||
-        (rc = rl.reserve((size_t)Rp * 4)) || (rc = dhdw.reserve((size_t)N * 8)))
-        return done(rc);
-    std::vector<int32_t> rowlist((size_t)Rp);
-    for (int i = 0; i < Rp; ++i) rowlist[i] = i < N ? i : (int32_t)N;  // row N is the zero row
     hipError_t he;
 #define HC(x) do { he = (x); if (he != hipSuccess) return done(ldw::hip_fail(he, #x, __FILE__, __LINE__)); } while (0)
-    HC(hipMemcpyAsync(rl.p, rowlist.data(), (size_t)Rp * 4, hipMemcpyHostToDevice, c->stream));
-    HC(hipMemsetAsync(ones.p, 1, (size_t)Kc, c->stream));
-    HC(hipStreamSynchronize(c->stream));
     HC(hipEventRecord(c->ev[0], c->stream));
-    int chunk = 0;
-    for (int64_t a0 = 0; a0 < L; a0 += Lc, ++chunk) {
-        const int64_t nl = std::min(Lc, L - a0);
-        HC(hipMemsetAsync(H.p, 0, (size_t)(N + 1) * Kc, c->stream));
-        dim3 grid((unsigned)((nl + 63) / 64), (unsigned)((N + 63) / 64));
-        hipLaunchKernelGGL(k_onehot_T, grid, dim3(256), 0, c->stream, c->states.as<uint8_t>(), Npad, a0, nl, N,
-                           H.as<uint8_t>(), Kc);
-        HC(hipGetLastError());
-        if ((rc = launch_gemm(c, rl.as<int32_t>(), Rp, rl.as<int32_t>(), Rp, Gh.as<int64_t>(), 1, ones.as<int8_t>(),
-                              H.as<uint8_t>(), Kc, 0, chunk > 0)))
-            return done(rc);
+    // per-SNP state counts -> which state is dropped, which columns exist
+    std::vector<int32_t> hc((size_t)L * 5);   // [L][5]
+    if ((rc = ldw_state_counts(c, hc.data()))) return done(rc);
+    std::vector<int32_t> colinfo;
+    std::vector<int8_t> weight;
+    std::vector<uint8_t> isA;
+    colinfo.reserve((size_t)L * 2);
+    for (int64_t a = 0; a < L; ++a) {
+        const int32_t *cnt = &hc[(size_t)a * 5];
+        int drop = -1, present = 0;
+        for (int x = 0; x < 5; ++x)
+            if (cnt[x] > 0) {
+                ++present;
+                if (drop < 0 || cnt[x] > cnt[drop]) drop = x;
+            }
+        if (present <= 1) continue;  // monomorphic: every pair of sequences shares it, the constant L covers that
+        const bool single = present == 2;
+        for (int x = 0; x < 5; ++x)
+            if (x != drop && cnt[x] > 0) {
+                colinfo.push_back((int32_t)(a * 16 + x));
+                weight.push_back(single ? 2 : 1);
+                isA.push_back(single ? 1 : 0);
+            }
+        if (!single) {
+            colinfo.push_back((int32_t)(a * 16 + 8 + drop));
+            weight.push_back(1);
+            isA.push_back(1);
+        }
     }
+    const int64_t KR = (int64_t)colinfo.size();
+    LDW_REQUIRE(L < (1ll << 27), LDW_ERR_ARG, "ldw_hamming_weights: too many SNPs");
+    int64_t KWr = (KR + 63) / 64;
+    KWr = std::max<int64_t>(2, (KWr + 1) / 2 * 2);  // the GEMM loads word pairs
+    const int64_t Kpad = KWr * 64;
+    std::vector<int8_t> digits((size_t)Kpad, 0);
+    std::vector<uint64_t> umask((size_t)KWr, 0);
+    for (int64_t k = 0; k < KR; ++k) {
+        digits[(size_t)k] = weight[(size_t)k];
+        if (isA[(size_t)k]) umask[(size_t)(k >> 6)] |= 1ull << (k & 63);
+    }
+    if ((rc = info.reserve((size_t)std::max<int64_t>(KR, 1) * 4)) || (rc = Hb.reserve((size_t)std::max<int64_t>(KR, 1) * KW * 8)) ||
+        (rc = T.reserve((size_t)Rp * KWr * 8)) || (rc = dig.reserve((size_t)Kpad)) || (rc = um.reserve((size_t)KWr * 8)) ||
+        (rc = Gh.reserve((size_t)Rp * Rp * 8)) || (rc = rl.reserve((size_t)Rp * 4)) || (rc = scnt.reserve((size_t)Rp * 4)) ||
+        (rc = dhdw.reserve((size_t)N * 8)))
+        return done(rc);
+    std::vector<int32_t> rowlist((size_t)Rp);
+    for (int i = 0; i < Rp; ++i) rowlist[i] = i;
+    if (KR > 0) HC(hipMemcpyAsync(info.p, colinfo.data(), (size_t)KR * 4, hipMemcpyHostToDevice, c->stream));
+    HC(hipMemcpyAsync(dig.p, digits.data(), (size_t)Kpad, hipMemcpyHostToDevice, c->stream));
+    HC(hipMemcpyAsync(um.p, umask.data(), (size_t)KWr * 8, hipMemcpyHostToDevice, c->stream));
+    HC(hipMemcpyAsync(rl.p, rowlist.data(), (size_t)Rp * 4, hipMemcpyHostToDevice, c->stream));
+    if (KR > 0) {
+        hipLaunchKernelGGL(k_hamming_cols, dim3((unsigned)KR), dim3(256), 0, c->stream, c->states.as<uint8_t>(), Npad, info.as<int32_t>(),
+                           KW, Hb.as<uint64_t>());
+        HC(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_bits_transpose, dim3((unsigned)((KWr + 3) / 4), (unsigned)KW), dim3(256), 0, c->stream, Hb.as<uint64_t>(), KR, KW,
+                       T.as<uint64_t>(), KWr);
+    HC(hipGetLastError());
+    hipLaunchKernelGGL(k_seq_minor_count, dim3((unsigned)((Rp + 3) / 4)), dim3(256), 0, c->stream, T.as<uint64_t>(), um.as<uint64_t>(),
+                       (int64_t)Rp, KWr, scnt.as<int32_t>());
+    HC(hipGetLastError());
+    HC(hipEventRecord(c->ev[2], c->stream));
+    if ((rc = launch_gemm_bits(c, T.as<uint64_t>(), KWr, rl.as<int32_t>(), Rp, rl.as<int32_t>(), Rp, Gh.as<int64_t>(), 1, dig.as<int8_t>(), 1)))
+        return done(rc);
     HC(hipEventRecord(c->ev[1], c->stream));
-    hipLaunchKernelGGL(k_hdw, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream, Gh.as<int64_t>(), Rp, N, L,
+    hipLaunchKernelGGL(k_hdw, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream, Gh.as<int64_t>(), Rp, scnt.as<int32_t>(), N, L,
                        (int)thresh, dhdw.as<double>());
     HC(hipGetLastError());
     HC(hipMemcpyAsync(hdw_out, dhdw.p, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -107,18 +196,19 @@ extern "C" int ldw_hamming_weights(ldw_ctx *c, int32_t thresh, double *hdw_out, 
         ldw::DevBuf s32;
         if ((rc = s32.reserve((size_t)N * N * 4))) return done(rc);
         dim3 g2((unsigned)((N + 255) / 256), (unsigned)N);
-        hipLaunchKernelGGL(k_shared_i32, g2, dim3(256), 0, c->stream, Gh.as<int64_t>(), Rp, N, s32.as<int32_t>());
+        hipLaunchKernelGGL(k_shared_i32, g2, dim3(256), 0, c->stream, Gh.as<int64_t>(), Rp, scnt.as<int32_t>(), N, L, s32.as<int32_t>());
         he = hipMemcpyAsync(shared_out, s32.p, (size_t)N * N * 4, hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         s32.release();
         if (he != hipSuccess) return done(ldw::hip_fail(he, "shared copy", __FILE__, __LINE__));
     }
     HC(hipStreamSynchronize(c->stream));
-    float t = 0;
+    float t = 0, tg = 0;
     HC(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
-    c->last_ms[0] = t;
+    HC(hipEventElapsedTime(&tg, c->ev[2], c->ev[1]));
+    c->last_ms[0] = tg;          // the GEMM alone
     c->last_ms[1] = c->last_ms[2] = 0;
-    c->last_ms[3] = t;
+    c->last_ms[3] = t;           // counts + column bits + transpose + GEMM
 #undef HC
     return done(LDW_OK);
 }

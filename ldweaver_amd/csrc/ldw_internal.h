@@ -128,13 +128,11 @@ struct ldw_ctx {
 namespace ldw {
 // launchers implemented in the .hip files (all asynchronous on ctx->stream)
 int ensure_rows(ldw_ctx *ctx);
-int launch_gemm(ldw_ctx *ctx, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f, int RFpad,
-                int64_t *G, int nlimbs, const int8_t *digits, const uint8_t *Mbase, int64_t Kpad,
-                int lower_only, int accumulate);
 int launch_hist(ldw_ctx *ctx, const int32_t *idx_f, int nf, const int32_t *idx_t, int nt, const int64_t *pfix_state,
                 int quirk, int lower_only, double *MI);
-int launch_gemm_bits(ldw_ctx *ctx, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f, int RFpad, int64_t *G,
-                     int nlimbs, const int8_t *digits, int lower_only);
+// G[t][f] = sum_k [row t has bit k][row f has bit k] * sum_j digits[j][k] 256^j over the bit matrix Mbits[rows][KW words]
+int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f,
+                     int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only);
 int fill_rows_bits(ldw_ctx *ctx, const int32_t *d_rowinfo, int64_t R);
 int check_gpu(ldw_ctx *ctx);
 }  // namespace ldw

@@ -1,7 +1,7 @@
 // MI epilogue, link selection and the block drivers (twins of perform_MI_computation_ACGTN,
 // R/computePairwiseMI.R:167-386, and of the block loop of perform_MI_computation, :103-116).
 //
-// Per block:  GEMM (ldw_gemm.hip) -> k_mi_epilogue: one thread per SNP pair turns the fixed-point joint
+// Per block:  GEMM (ldw_gemm_bits.hip) -> k_mi_epilogue: one thread per SNP pair turns the fixed-point joint
 // sums into MI (src/computeMI.cpp:19), writes the dense MI block, scatters the short-range links straight
 // to their final rows and histograms the long-range MI values in LDS -> k_pick_bucket: ranks of the two
 // order statistics of quantile type 7 and the histogram bucket holding them -> k_lr_gather: every
@@ -871,7 +871,7 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
     if (!epilogue_only) {
         if (int rc = c->G.reserve((size_t)RFpad * RTpad * 8)) return rc;
         LDW_HIP(hipEventRecord(ev[0], c->stream));
-        if (int rc = launch_gemm_bits(c, D.rl_t, RTpad, D.rl_f, RFpad, c->G.as<int64_t>(), c->nlimbs,
+        if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, c->G.as<int64_t>(), c->nlimbs,
                                       c->digits.as<int8_t>(), E.lower_only))
             return rc;
         LDW_HIP(hipEventRecord(ev[1], c->stream));
@@ -1238,7 +1238,7 @@ int ldw_joint_tables(ldw_ctx *c, const int32_t *pair_a, const int32_t *pair_b, i
         for (int pass = 0; pass < 2 && rc == LDW_OK; ++pass) {
             int64_t *host_out = pass == 0 ? counts_out : fixed_out;
             if (!host_out) continue;
-            rc = launch_gemm_bits(c, c->rowlist_t.as<int32_t>(), RTpad, c->rowlist_f.as<int32_t>(), RFpad, c->G.as<int64_t>(),
+            rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, c->rowlist_t.as<int32_t>(), RTpad, c->rowlist_f.as<int32_t>(), RFpad, c->G.as<int64_t>(),
                                   pass == 0 ? 1 : c->nlimbs, pass == 0 ? d_ones.as<int8_t>() : c->digits.as<int8_t>(), 0);
             if (rc) break;
             hipLaunchKernelGGL(k_tables, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->G.as<int64_t>(), RFpad,
