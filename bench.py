@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
                                                       "smoke-testing the N > 1 path on a single GPU)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run the timed region with the GEMM/epilogue stream overlap off too (kernel-exclusive times everywhere; "
+                         "the command profiles/*_serial_kernel_stats.csv was collected with)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="SNPs per side of the CPU-baseline sample block (0 = auto)")
     return ap.parse_args()
 
@@ -97,6 +100,7 @@ def main():
     torch.cuda.set_stream(stream)
     eng = Engine(local_rank, stream=stream.cuda_stream)
     eng.set_engine(LL.ENGINE_HIST if args.engine == "hist" else LL.ENGINE_MFMA)
+    eng.set_overlap(not args.no_overlap)
     eng.set_alignment(states)
     counts = eng.state_counts()
     uqe = (counts > 0).T.astype(np.float64)
@@ -164,12 +168,31 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # Kernel-exclusive stage times for the roofline: in the timed region the GEMM of block b+1 runs on a second stream
+    # beside the epilogue / selection of block b, so HIP-event brackets of one kernel also contain its neighbours.  Replay
+    # the same step with the overlap off (same kernels, same inputs, back to back on one stream) and bracket there.
+    tim_overlapped = dict(tim)
+    n_replay = 0
+    if rank == 0 and len(my_blocks):
+        eng.set_overlap(False)
+        for k in tim:
+            tim[k] = 0.0
+        n_replay = min(args.steps, 3)
+        t_r0 = time.perf_counter()
+        for _ in range(n_replay):
+            eng.mi_all_pairs(my_blocks, sr_dist, lr_retain, approx)
+            for k, v in eng.last_timing().items():
+                tim[k] += v
+        torch.cuda.synchronize()
+        serial_ms_per_step = (time.perf_counter() - t_r0) / n_replay * 1e3
+        eng.set_overlap(not args.no_overlap)
+
     if rank == 0:
         K = args.steps
         ms_per_step = dt / K * 1e3
         value = pairs * K / dt
         # ---- roofline of the dominant kernel (live HIP-event times accumulated by the library on this stream) ----
-        n_launch = max(1, len(my_blocks) * K)
+        n_launch = max(1, len(my_blocks) * max(1, n_replay))
         stage = max(("gemm_ms", "epilogue_ms", "select_ms"), key=lambda k: tim[k])
         my_pairs = 0
         for fs, fe, ts, te in my_blocks.tolist():
@@ -186,11 +209,14 @@ def main():
         Npad = (N + 127) // 128 * 128
         J = args.nlimbs or 5
         exec_ops = 0.0
-        for fs, fe, ts, te in my_blocks.tolist():
-            tf = -(-int(crow[fe] - crow[fs - 1]) // 128)
+        for fs, fe, ts, te in my_blocks.tolist():   # workgroup tile: 128 to-side rows x 64 from-side rows
+            tf = 2 * -(-int(crow[fe] - crow[fs - 1]) // 128)
             tt = -(-int(crow[te] - crow[ts - 1]) // 128)
-            tiles = tf * (tf + 1) // 2 if (fs == ts and fe == te) else tf * tt
-            exec_ops += 2.0 * tiles * 128 * 128 * Npad * J
+            if fs == ts and fe == te:   # tiles entirely above the diagonal are skipped
+                tiles = sum(tf - max(0, 2 * by - 1) for by in range(tt))
+            else:
+                tiles = tf * tt
+            exec_ops += 2.0 * tiles * 128 * 64 * Npad * J
         exec_per_launch = exec_ops / nb_mine
         i8_peak = 5000.0  # TOP/s dense (MI355X_MICROARCH.md: i8 = 2 x bf16 per clock, bf16 ~2.5 PF dense)
         achieved = alg_flops_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms else None
@@ -200,7 +226,12 @@ def main():
                     executed_TOPs=exec_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms else None,
                     note="achieved = ALGORITHMIC 50*N flops/pair (SURVEY 8d) x pairs per launch / avg launch time (HIP events) of the "
                          "co-occurrence GEMM; the kernel EXECUTES fewer ops (one indicator row per minor state, 5 int8 limbs): "
-                         "executed_TOPs / peak = executed_frac is the matrix-core utilisation")
+                         "executed_TOPs / peak = executed_frac is the matrix-core utilisation.  Launch times are kernel-exclusive: "
+                         "bracketed in a replay of the timed step with the GEMM/epilogue stream overlap switched off "
+                         "(ldw_set_overlap(0)); `overlapped_*` are the brackets inside the timed region, where the GEMM shares "
+                         "the GPU with the previous block's epilogue and selection",
+                    measured_in=f"{n_replay} serialized replay step(s) after the timed region, {serial_ms_per_step:.2f} ms/step",
+                    overlapped_avg_launch_ms=tim_overlapped["gemm_ms"] / max(1, len(my_blocks) * K))
         roof["executed_frac"] = roof["executed_TOPs"] / i8_peak if roof["executed_TOPs"] else None
         # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (rocprofv3 cannot run inside
         # the bench); only quoted for the configuration they were collected on
@@ -221,7 +252,8 @@ def main():
                                arithmetic="joint sums: int8 MFMA -> exact int64 fixed point; MI epilogue: f64",
                                parallelism=f"pair-space blocks over {world} GPU(s)"),
                    roofline=roof,
-                   stages_ms_per_step={k: v / K for k, v in tim.items()},
+                   stages_ms_per_step={k: v / max(1, n_replay) for k, v in tim.items()},
+                   stages_ms_per_step_overlapped={k: v / K for k, v in tim_overlapped.items()},
                    links=result, counters=eng.counters(), hamming_weights_s=hamming_s, hamming_gemm_ms=hamming_kernel_ms, setup_s=setup_s)
         if not args.no_cpu_baseline:
             sample = args.cpu_sample or max(200, min(2000, L // 2))   # ~10-30 s of host work at N = 5000

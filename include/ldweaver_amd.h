@@ -150,6 +150,11 @@ int ldw_mi_block_links(ldw_ctx *ctx, const int32_t *from_idx, int64_t nf, const 
                        const ldw_mi_params *p);
 int ldw_links_end(ldw_ctx *ctx);
 /* which: 0 = short-range, 1 = long-range (after the per-block quantile filter). */
+/* on (default): the co-occurrence GEMM of block b+1 runs on a second stream beside the epilogue and link selection
+ * of block b (~5 % faster end to end).  off: all kernels of all blocks run back to back on the context's stream, so
+ * that the per-stage times of ldw_ctx_last_timing are exclusive kernel times (what bench.py's roofline uses).
+ * Results are identical either way. */
+int ldw_set_overlap(ldw_ctx *ctx, int on);
 int ldw_links_count(ldw_ctx *ctx, int which, int64_t *n_out);
 /* a_out/b_out: 0-based SNP index of the from-side (pos2) and to-side (pos1) SNP; MI_out. capacity in
  * rows; on_device selects the destination space.  block_row_offsets_out[nblocks+1] (host, may be NULL)

@@ -276,6 +276,10 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     if (c->ev_pick) (void)hipEventDestroy(c->ev_pick);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->gemm_stream) (void)hipStreamDestroy(c->gemm_stream);
+    for (auto &e : c->ev_gemm)
+        if (e) (void)hipEventDestroy(e);
+    c->G2.release();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LDW_OK;

@@ -222,7 +222,8 @@ __global__ __launch_bounds__(256) void k_fill_rows_bits(const uint8_t *__restric
 }
 
 int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f,
-                     int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only) {
+                     int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only, hipStream_t stream) {
+    if (!stream) stream = ctx->stream;
     const int64_t Kpad = KW * 64;
     LDW_REQUIRE(RTpad % TILE == 0 && RFpad % TILE == 0 && KW > 0 && KW % 2 == 0 && Kpad == KW * 64, LDW_ERR_ARG,
                 "launch_gemm_bits: padding violated (RT %d RF %d KW %lld)", RTpad, RFpad, (long long)KW);
@@ -235,7 +236,7 @@ int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int3
         const int shift = 8 * done, accum = done > 0;
 #define LDW_LAUNCH_B(JJ)                                                                                        \
     case JJ:                                                                                                    \
-        hipLaunchKernelGGL(gemm_bits_kernel<JJ>, grid, block, 0, ctx->stream, Mbits, KW,                           \
+        hipLaunchKernelGGL(gemm_bits_kernel<JJ>, grid, block, 0, stream, Mbits, KW,                                 \
                            rowlist_t, rowlist_f, dg, Kpad, G, RFpad, lower_only, shift, accum);                 \
         break;
         switch (J) {

@@ -93,7 +93,7 @@ struct ldw_ctx {
     std::vector<int32_t> h_counts;
 
     // ---- per-block workspaces ----
-    ldw::DevBuf G;               // int64 [RTpad][RFpad]
+    ldw::DevBuf G, G2;           // int64 [RTpad][RFpad] fixed-point joint sums, one per pipeline slot
     ldw::DevBuf MIblk;           // double [nf*nt]
     ldw::DevBuf rowlist_f, rowlist_t, idx_f, idx_t, lrow_f, lrow_t, perm_f;
     ldw::DevBuf hist, colcnt, cand_key, cand_val, cand_key2, cand_val2, scratch, small;
@@ -111,7 +111,9 @@ struct ldw_ctx {
     double srm_sr_dist = 0;
 
     // ---- pipelined block staging: host prep of block i+1 overlaps the GPU work of block i ----
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr, gemm_stream = nullptr;
+    hipEvent_t ev_gemm[2] = {nullptr, nullptr};
+    bool overlap = true;                 // GEMM of block b+1 on its own stream beside the epilogue/selection of block b
     void *pin[2] = {nullptr, nullptr};   // pinned host staging, one packed buffer per slot
     size_t pin_cap[2] = {0, 0};
     ldw::DevBuf dstage[2];               // device image of the packed buffer
@@ -132,7 +134,7 @@ int launch_hist(ldw_ctx *ctx, const int32_t *idx_f, int nf, const int32_t *idx_t
                 int quirk, int lower_only, double *MI);
 // G[t][f] = sum_k [row t has bit k][row f has bit k] * sum_j digits[j][k] 256^j over the bit matrix Mbits[rows][KW words]
 int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f,
-                     int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only);
+                     int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only, hipStream_t stream = nullptr);
 int fill_rows_bits(ldw_ctx *ctx, const int32_t *d_rowinfo, int64_t R);
 int check_gpu(ldw_ctx *ctx);
 }  // namespace ldw

@@ -846,8 +846,24 @@ struct DevPtrs {
 // GEMM + epilogue (or the histogram engine) of one block into ctx->MIblk; with E.cols set, the short-range
 // scatter and the long-range histogram ride along.  ev[0..2] are recorded before the GEMM, between the two
 // kernels and after the epilogue.  Everything is asynchronous on ctx->stream.
+// stage events per block: [0] GEMM start, [1] GEMM end (GEMM stream); [4] epilogue start, [2] epilogue end, [3] selection
+// end (main stream).  The GEMM of block b+1 runs beside the epilogue and selection of block b, so the stage times overlap.
+constexpr int EVB = 5;
+// which: 1 = GEMM only (on gstream, into Gbuf), 2 = epilogue only, 3 = both
 int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E,
-                    hipEvent_t *ev, bool epilogue_only = false) {
+                    hipEvent_t *ev, int which = 3, ldw::DevBuf *Gb = nullptr, hipStream_t gstream = nullptr) {
+    ldw::DevBuf &Gbuf = Gb ? *Gb : c->G;
+    if (!gstream) gstream = c->stream;
+    if (which == 1) {   // the GEMM of a block, possibly on its own stream so that it overlaps the previous block's tail
+        if (int rc = Gbuf.reserve((size_t)RFpad * RTpad * 8)) return rc;
+        LDW_HIP(hipEventRecord(ev[0], gstream));
+        if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, Gbuf.as<int64_t>(), c->nlimbs,
+                                      c->digits.as<int8_t>(), E.lower_only, gstream))
+            return rc;
+        LDW_HIP(hipEventRecord(ev[1], gstream));
+        return LDW_OK;
+    }
+    const bool epilogue_only = which == 2;
     if (int rc = c->MIblk.reserve((size_t)nf * nt * 8)) return rc;
     if (int rc = c->hist.reserve((size_t)NBINS * 8)) return rc;
     E.MI = c->MIblk.as<double>();
@@ -869,15 +885,15 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
         return LDW_OK;
     }
     if (!epilogue_only) {
-        if (int rc = c->G.reserve((size_t)RFpad * RTpad * 8)) return rc;
+        if (int rc = Gbuf.reserve((size_t)RFpad * RTpad * 8)) return rc;
         LDW_HIP(hipEventRecord(ev[0], c->stream));
-        if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, c->G.as<int64_t>(), c->nlimbs,
-                                      c->digits.as<int8_t>(), E.lower_only))
+        if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, Gbuf.as<int64_t>(), c->nlimbs,
+                                      c->digits.as<int8_t>(), E.lower_only, c->stream))
             return rc;
         LDW_HIP(hipEventRecord(ev[1], c->stream));
     }
     EpiArgs A;
-    A.G = c->G.as<int64_t>();
+    A.G = Gbuf.as<int64_t>();
     A.RFpad = RFpad;
     A.idx_f = D.idx_f;
     A.lrow_f = D.lrow_f;
@@ -892,9 +908,10 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
     A.scale = std::ldexp(1.0, -c->frac_bits);
     A.quirk = quirk;
     A.E = E;
+    if (which == 2) LDW_HIP(hipEventRecord(ev[4], c->stream));
     hipLaunchKernelGGL(k_mi_epilogue, egrid, dim3(256), 0, c->stream, A, D.perm, ghist);
     LDW_HIP(hipGetLastError());
-    if (!epilogue_only) LDW_HIP(hipEventRecord(ev[2], c->stream));
+    if (which != 2 || c->engine != LDW_ENGINE_HIST) LDW_HIP(hipEventRecord(ev[2], c->stream));
     return LDW_OK;
 }
 
@@ -1035,17 +1052,40 @@ int launch_gather(ldw_ctx *c, const HostBlock &hb, const EmitArgs &E, const Smal
     return LDW_OK;
 }
 
-int submit_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
+// First half of a block: upload its index structures and run the co-occurrence GEMM into this slot's G buffer on
+// the GEMM stream.  Nothing here touches what the previous block's epilogue / selection still uses, so the GEMM of
+// block b+1 overlaps the tail of block b (epilogue wind-down, the launch-bound selection kernels, the host round trip).
+int submit_gemm(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p) {
     const int s = hb.slot;
     if (int rc = c->dstage[s].reserve(hb.total)) return rc;
-    // the device image of this slot was last read by the block two steps back
+    // the device image and the G buffer of this slot were last read by the block two steps back
     if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_done[s], 0));
     LDW_HIP(hipMemcpyAsync(c->dstage[s].p, c->pin[s], hb.total, hipMemcpyHostToDevice, c->copy_stream));
     LDW_HIP(hipEventRecord(c->ev_up[s], c->copy_stream));
-    LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_up[s], 0));
     const char *d = c->dstage[s].as<char>();
     auto I = [&](size_t off) { return reinterpret_cast<const int32_t *>(d + off); };
-    DevPtrs D{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm)};
+    hb.D = DevPtrs{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm)};
+    if (c->engine != LDW_ENGINE_MFMA) return LDW_OK;
+    hipStream_t gs = c->overlap ? c->gemm_stream : c->stream;   // overlap off: the stages of all blocks run back to back
+    LDW_HIP(hipStreamWaitEvent(gs, c->ev_up[s], 0));
+    if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(gs, c->ev_done[s], 0));
+    EmitArgs E;
+    memset(&E, 0, sizeof(E));
+    E.lower_only = hb.diag ? 1 : 0;
+    if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, &c->ev_pool[(size_t)hb.blk_no * EVB], 1,
+                                 s ? &c->G2 : &c->G, gs))
+        return rc;
+    LDW_HIP(hipEventRecord(c->ev_gemm[s], gs));
+    return LDW_OK;
+}
+
+// Second half: epilogue, histogram pick and the copy-back of the pick on the main stream.
+int submit_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
+    const int s = hb.slot;
+    LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_up[s], 0));
+    if (c->engine == LDW_ENGINE_MFMA) LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_gemm[s], 0));
+    const char *d = c->dstage[s].as<char>();
+    const DevPtrs D = hb.D;
     const bool do_lr = !p->sr_only;
     const int64_t sr_add = p->keep_sr ? hb.n_sr_blk : 0;
     if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr)) return rc;
@@ -1077,11 +1117,12 @@ int submit_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
     E.n_cand = &sl.pick->n_cand;
     E.ckey = c->cand_key.as<uint64_t>();
     E.cval = c->cand_val.as<uint64_t>();
-    hb.D = D;
     hb.E = E;
     LDW_HIP(hipMemsetAsync(sl.pick, 0, sizeof(ldw::PickOut), c->stream));
-    hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * 4];
-    if (int rc = launch_block_mi(c, D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, ev)) return rc;
+    hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
+    if (int rc = launch_block_mi(c, D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, ev, c->engine == LDW_ENGINE_MFMA ? 2 : 3,
+                                 s ? &c->G2 : &c->G))
+        return rc;
     c->n_sr += sr_add;
     if (do_lr) {
         hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, c->stream, c->hist.as<unsigned long long>(),
@@ -1111,8 +1152,8 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
         E.keep_sr = 0;
         LDW_HIP(hipMemsetAsync(c->hist.p, 0, (size_t)NBINS * 8, c->stream));
         LDW_HIP(hipMemsetAsync(sl.pick, 0, sizeof(ldw::PickOut), c->stream));
-        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E,
-                                     &c->ev_pool[(size_t)hb.blk_no * 4], true))
+        hipEvent_t dummy[5] = {c->ev[3], c->ev[3], c->ev[4], c->ev[3], c->ev[5]};   // keep the block's stage events as they are
+        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, dummy, 2, hb.slot ? &c->G2 : &c->G))
             return rc;
         hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, c->stream, c->hist.as<unsigned long long>(),
                            p->lr_retain_links, p->lr_links_approx, -1, 0LL, sl.pick);
@@ -1171,7 +1212,7 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
     hipLaunchKernelGGL(k_block_done, dim3(1), dim3(64), 0, c->stream, sl.pick, sl.lr_count, hb.n_sr_blk,
                        sl.stats_i + hb.blk_no * 3, sl.stats_d + hb.blk_no);
     LDW_HIP(hipGetLastError());
-    LDW_HIP(hipEventRecord(c->ev_pool[(size_t)hb.blk_no * 4 + 3], c->stream));
+    LDW_HIP(hipEventRecord(c->ev_pool[(size_t)hb.blk_no * EVB + 3], c->stream));
     LDW_HIP(hipEventRecord(c->ev_done[hb.slot], c->stream));
     c->done_recorded[hb.slot] = true;
     return LDW_OK;
@@ -1269,8 +1310,13 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
         }
         LDW_HIP(hipEventCreateWithFlags(&c->ev_pick, hipEventDisableTiming));
         LDW_HIP(hipHostMalloc(&c->pin_pick, sizeof(ldw::PickOut) + 64, hipHostMallocDefault));
+        LDW_HIP(hipStreamCreateWithFlags(&c->gemm_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) LDW_HIP(hipEventCreateWithFlags(&c->ev_gemm[k], hipEventDisableTiming));
     }
-    while ((int64_t)c->ev_pool.size() < nblocks_capacity * 4) {
+    // everything queued on the main stream so far (row map, weights) must be visible to the GEMM stream
+    LDW_HIP(hipEventRecord(c->ev_up[0], c->stream));
+    LDW_HIP(hipStreamWaitEvent(c->gemm_stream, c->ev_up[0], 0));
+    while ((int64_t)c->ev_pool.size() < nblocks_capacity * EVB) {
         hipEvent_t e;
         LDW_HIP(hipEventCreate(&e));
         c->ev_pool.push_back(e);
@@ -1303,6 +1349,7 @@ int ldw_mi_block_links(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const in
     links_layout(c, sl);
     HostBlock hb;
     if (int rc = prep_block(c, from_idx, nf, to_idx, nt, p, (int)(c->blk_cursor & 1), c->blk_cursor, hb)) return rc;
+    if (int rc = submit_gemm(c, hb, p)) return rc;
     if (int rc = submit_block(c, hb, p, sl)) return rc;
     if (int rc = finish_block(c, hb, p, sl)) return rc;
     ++c->blk_cursor;
@@ -1332,9 +1379,9 @@ int ldw_links_end(ldw_ctx *c) {
         c->stats[b].n_sr = si[b * 3 + 2];
         c->stats[b].disc_thresh = sd[b];
         float t01 = 0, t12 = 0, t23 = 0;
-        hipEvent_t *ev = &c->ev_pool[(size_t)b * 4];
+        hipEvent_t *ev = &c->ev_pool[(size_t)b * EVB];
         LDW_HIP(hipEventElapsedTime(&t01, ev[0], ev[1]));
-        LDW_HIP(hipEventElapsedTime(&t12, ev[1], ev[2]));
+        LDW_HIP(hipEventElapsedTime(&t12, ev[c->engine == LDW_ENGINE_MFMA ? 4 : 1], ev[2]));
         LDW_HIP(hipEventElapsedTime(&t23, ev[2], ev[3]));
         c->last_ms[0] += t01;
         c->last_ms[1] += t12;
@@ -1382,18 +1429,29 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     HostBlock hb[2];
     if (int rc = fill(0)) return rc;
     if (int rc = prep_block(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, 0, 0, hb[0])) return rc;
+    if (int rc = submit_gemm(c, hb[0], p)) return rc;
     for (int64_t b = 0; b < nblocks; ++b) {
         const int s = (int)(b & 1);
-        if (int rc = submit_block(c, hb[s], p, sl)) return rc;
+        if (int rc = submit_block(c, hb[s], p, sl)) return rc;          // epilogue + pick of block b (main stream)
         if (b + 1 < nblocks) {
             if (int rc = fill(b + 1)) return rc;
             if (int rc = prep_block(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, s ^ 1, b + 1, hb[s ^ 1]))
                 return rc;
+            if (c->overlap)
+                if (int rc = submit_gemm(c, hb[s ^ 1], p)) return rc;   // GEMM of block b+1 (GEMM stream) runs beside them
         }
-        if (int rc = finish_block(c, hb[s], p, sl)) return rc;
+        if (int rc = finish_block(c, hb[s], p, sl)) return rc;          // round trip + selection of block b
+        if (!c->overlap && b + 1 < nblocks)
+            if (int rc = submit_gemm(c, hb[s ^ 1], p)) return rc;       // overlap off: strictly one block after the other
         ++c->blk_cursor;
     }
     return ldw_links_end(c);
+}
+
+int ldw_set_overlap(ldw_ctx *c, int on) {
+    LDW_REQUIRE(c, LDW_ERR_ARG, "null context");
+    c->overlap = on != 0;
+    return LDW_OK;
 }
 
 int ldw_links_count(ldw_ctx *c, int which, int64_t *n_out) {

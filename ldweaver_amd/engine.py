@@ -56,6 +56,10 @@ class Engine:
         L.check(L.lib().ldw_ctx_counters(self._ctx, L.ptr(v)))
         return dict(spec_misses=int(v[0]))
 
+    def set_overlap(self, on: bool):
+        """GEMM of the next block beside the epilogue/selection of the current one (default on); off = exclusive stage times."""
+        L.check(L.lib().ldw_set_overlap(self._ctx, int(bool(on))))
+
     def set_engine(self, engine: int):
         L.check(L.lib().ldw_set_engine(self._ctx, int(engine)))
 
