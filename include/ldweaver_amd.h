@@ -62,8 +62,9 @@ int ldw_ctx_sync(ldw_ctx *ctx);
  * HIP events on the context's stream: [0] gemm, [1] epilogue, [2] selection, [3] total */
 int ldw_ctx_last_timing(ldw_ctx *ctx, double ms_out[4]);
 
-/* diagnostics: out[0] = blocks whose speculative long-range gather had to fall back to the dense pass since the
- * context was created, out[1..3] reserved */
+/* diagnostics since the context was created: out[0] = blocks whose speculative long-range gather had to fall back to
+ * the dense pass, out[1] = blocks run by the fused GEMM + epilogue kernel, out[2] = blocks run by the two-kernel path,
+ * out[3] = pairs the fp32 screen would have lost (counted in ldw_set_screen mode 2 only; must stay 0) */
 int ldw_ctx_counters(ldw_ctx *ctx, int64_t out[4]);
 
 /* ---- (1) .ACGTN2num  — src/ACGTN2num_parallel.cpp:10-43, R/RcppExports.R:4-6 ------------ */
@@ -155,6 +156,18 @@ int ldw_links_end(ldw_ctx *ctx);
  * that the per-stage times of ldw_ctx_last_timing are exclusive kernel times (what bench.py's roofline uses).
  * Results are identical either way. */
 int ldw_set_overlap(ldw_ctx *ctx, int on);
+/* on (default): blocks for which a histogram-bucket guess exists (every block but the first of a call sequence) run the
+ * co-occurrence GEMM and the MI epilogue as ONE kernel: the joint sums stay in LDS, the epilogue of one workgroup
+ * overlaps the MFMA loop of its neighbour on the CU.  off: always the GEMM -> G in HBM -> epilogue pair of kernels.
+ * Link tables are identical either way up to the rounding of MI (<= 1e-15: on diagonal blocks the fused kernel may
+ * meet a pair in mirrored roles). */
+int ldw_set_fused(ldw_ctx *ctx, int on);
+/* fp32 screen in front of the fp64 MI evaluation, in blocks that run the speculative selection: a long-range pair
+ * only matters if its MI reaches the guessed histogram bucket, so MI is first bounded in fp32 (v_log_f32, proven
+ * error < 1.3e-5 nats, margin 2e-4) and the exact value is computed for the waves that hold a pair which may pass, or a
+ * short-range pair.  Every MI that is emitted is the exact one, so the link tables do not depend on the mode.
+ * 0 = off, 1 = on (default), 2 = verify: evaluate everything both ways and count lost pairs in ldw_ctx_counters[3]. */
+int ldw_set_screen(ldw_ctx *ctx, int mode);
 int ldw_links_count(ldw_ctx *ctx, int which, int64_t *n_out);
 /* a_out/b_out: 0-based SNP index of the from-side (pos2) and to-side (pos1) SNP; MI_out. capacity in
  * rows; on_device selects the destination space.  block_row_offsets_out[nblocks+1] (host, may be NULL)

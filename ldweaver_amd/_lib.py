@@ -63,6 +63,8 @@ _SIGS = {
     "ldw_mi_block_links": (C.c_int, [_p, _p, _i64, _p, _i64, C.POINTER(MIParams)]),
     "ldw_links_end": (C.c_int, [_p]),
     "ldw_set_overlap": (C.c_int, [_p, C.c_int]),
+    "ldw_set_fused": (C.c_int, [_p, C.c_int]),
+    "ldw_set_screen": (C.c_int, [_p, C.c_int]),
     "ldw_links_count": (C.c_int, [_p, C.c_int, C.POINTER(_i64)]),
     "ldw_links_fetch": (C.c_int, [_p, C.c_int, _p, _p, _p, _i64, C.c_int]),
     "ldw_block_stats": (C.c_int, [_p, _i64, _p, _p, _p, _p]),

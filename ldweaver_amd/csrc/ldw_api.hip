@@ -257,8 +257,8 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     ldw::DevBuf *bufs[] = {&c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
-                           &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->hist, &c->colcnt, &c->cand_key,
-                           &c->cand_val, &c->cand_key2, &c->cand_val2, &c->scratch, &c->small, &c->sr_a, &c->sr_b,
+                           &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->hist[0], &c->hist[1], &c->colcnt, &c->cand_key[0], &c->cand_key[1],
+                           &c->cand_val[0], &c->cand_val[1], &c->cand_key2, &c->cand_val2, &c->scratch, &c->small, &c->sr_a, &c->sr_b,
                            &c->sr_mi, &c->lr_a, &c->lr_b, &c->lr_mi, &c->srm_pack, &c->srm_key, &c->srm_pack2, &c->srm_key2, &c->srm_pay, &c->srm_pay2, &c->srm_off,
                            &c->srm_q, &c->srm_n, &c->srm_md, &c->srm_part, &c->srm_shape, &c->srm_cnt, &c->red_row, &c->red_meta,
                            &c->red_srp, &c->pool_a, &c->pool_b, &c->pool_mi, &c->ar_key, &c->ar_val, &c->ar_key2, &c->ar_val2,
@@ -272,8 +272,12 @@ int ldw_ctx_destroy(ldw_ctx *c) {
         if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]);
         if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
     }
-    if (c->pin_pick) (void)hipHostFree(c->pin_pick);
-    if (c->ev_pick) (void)hipEventDestroy(c->ev_pick);
+    for (int k = 0; k < 2; ++k) {
+        if (c->pin_pick[k]) (void)hipHostFree(c->pin_pick[k]);
+        if (c->ev_pick[k]) (void)hipEventDestroy(c->ev_pick[k]);
+    }
+    if (c->pin_lrc) (void)hipHostFree(c->pin_lrc);
+    if (c->ev_lrc) (void)hipEventDestroy(c->ev_lrc);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->gemm_stream) (void)hipStreamDestroy(c->gemm_stream);
@@ -314,7 +318,9 @@ int ldw_ctx_last_timing(ldw_ctx *c, double ms_out[4]) {
 int ldw_ctx_counters(ldw_ctx *c, int64_t out[4]) {
     LDW_REQUIRE(c && out, LDW_ERR_ARG, "ldw_ctx_counters: null argument");
     out[0] = c->spec_misses;
-    out[1] = out[2] = out[3] = 0;
+    out[1] = c->fused_blocks;
+    out[2] = c->unfused_blocks;
+    out[3] = c->screen_violations;
     return LDW_OK;
 }
 
@@ -654,6 +660,8 @@ int ensure_rows(ldw_ctx *c) {
     }
     LDW_HIP(hipStreamSynchronize(c->stream));
     c->rows_ready = true;
+    c->spec_B_next[0] = c->spec_B_next[1] = -1;   // bucket guesses of an earlier alignment / weighting say nothing about this one
+    c->spec_seen[0] = c->spec_seen[1] = false;
     return LDW_OK;
 }
 

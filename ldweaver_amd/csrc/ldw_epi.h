@@ -1,0 +1,433 @@
+// Device-side pieces of the MI epilogue shared by k_mi_epilogue (ldw_mi.hip) and the fused GEMM + epilogue kernel
+// (ldw_fused.hip): histogram buckets, short-range interval tests, the fp64 log helpers, the per-pair MI
+// (src/computeMI.cpp:19 cell by cell) and the emission of one finished pair.
+#pragma once
+#include "ldw_internal.h"
+#include "ldw_dev.h"
+
+namespace ldw {
+
+// ------------------------------------------------------------------------------------------------
+// helpers shared by host and device
+// ------------------------------------------------------------------------------------------------
+// Histogram bucket of an MI value: monotone non-decreasing in mi, 128 buckets per octave (0.5 % wide) from 2^-20
+// up, taken straight from the IEEE-754 bits (exponent + 7 mantissa bits) — no floating-point arithmetic.  Values
+// below 2^-20 (and negatives, which quirk Q1 can produce) fall in bucket 0.
+constexpr int BUCKET_OFF = (1023 - 20) << 7;
+__host__ __device__ __forceinline__ int mi_bucket(double mi) {
+    long long u;
+    memcpy(&u, &mi, 8);
+    if (u <= 0) return 0;  // -x, -0, +0
+    const int b = (int)(u >> 45) - BUCKET_OFF;
+    return b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
+}
+// lower edge of bucket B (B >= 1)
+__host__ __device__ __forceinline__ double bucket_lo(int B) {
+    const long long u = (long long)(B + BUCKET_OFF) << 45;
+    double v;
+    memcpy(&v, &u, 8);
+    return v;
+}
+
+// Short-range partners of one to-side SNP: up to three disjoint, ascending index intervals [s,e) of the
+// from-side list, plus the first row of its upper (a_loc < b_loc) and lower (a_loc > b_loc) segment in
+// the short-range table (relative to the block's base row).
+struct ColInfo {
+    int32_t s[3], e[3];
+    int32_t pad[2];
+    int64_t off_u, off_l;
+};
+
+__host__ __device__ __forceinline__ bool col_is_sr(const ColInfo &c, int a) {
+    return (a >= c.s[0] && a < c.e[0]) || (a >= c.s[1] && a < c.e[1]) || (a >= c.s[2] && a < c.e[2]);
+}
+// number of short-range partners in [lo, hi)
+__host__ __device__ __forceinline__ int col_count(const ColInfo &c, int lo, int hi) {
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = c.s[k] > lo ? c.s[k] : lo, b = c.e[k] < hi ? c.e[k] : hi;
+        n += b > a ? b - a : 0;
+    }
+    return n;
+}
+
+// which segment a pair belongs to: 0 = upper (a<b, off-diagonal blocks only), 1 = lower (a>b), -1 = not a pair
+__host__ __device__ __forceinline__ int pair_seg(int a_loc, int b_loc, int lower_only) {
+    if (a_loc == b_loc) return -1;
+    if (a_loc > b_loc) return 1;
+    return lower_only ? -1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp64 helpers of the epilogue: no IEEE division, no libm call.  Accuracy ~2e-15; the
+// epilogue is not bit-matched to the reference (tolerance 1e-6 on MI), see DESIGN.md.
+// ------------------------------------------------------------------------------------------------
+// v_rcp_f64 is good to 4.5e-8 (measured on gfx950); one Newton step brings it to 2e-15
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// exact conversion of an integer 0 <= n < 2^52 to double (two integer ops and one add instead of the
+// multi-instruction int64 -> f64 sequence)
+__device__ __forceinline__ double u52_to_double(int64_t n) {
+    return __longlong_as_double(n | 0x4330000000000000LL) - 4503599627370496.0;
+}
+
+// log(N / D) for positive, finite, normal doubles with ONE reciprocal: D is rescaled by a power of two so that
+// N / D' lies in [1/sqrt2, sqrt2]; then log(N/D') = 2 atanh(s), s = (N - D')/(N + D'), |s| <= 0.1716, odd series
+// to s^17 (absolute error < 1e-15), and log(N/D) = k ln2 + log(N/D').
+__device__ __forceinline__ double fast_log_ratio(double N, double D) {
+    const int hn = __double2hiint(N), hd = __double2hiint(D);
+    int k = ((hn >> 20) & 0x7FF) - ((hd >> 20) & 0x7FF);
+    double Dp = __hiloint2double(hd + (k << 20), __double2loint(D));   // D * 2^k: same exponent as N
+    // N / Dp is in (1/2, 2): fold it into [1/sqrt2, sqrt2]
+    const bool big = N > Dp * 1.4142135623730951, small = N * 1.4142135623730951 < Dp;
+    const int adj = big ? 1 : (small ? -1 : 0);
+    Dp = __hiloint2double(__double2hiint(Dp) + (adj << 20), __double2loint(Dp));
+    k += adj;
+    const double s = (N - Dp) * fast_rcp(N + Dp);
+    const double z = s * s;
+    double p = 1.0 / 17.0;           // truncation z^9/19 <= 9e-16 relative to 2s
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    p = p * z;  // atanh(s)/s - 1
+    const double lm = fma(s + s, p, s + s);
+    return fma((double)k, 0.693147180559945309417, lm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// what happens to one finished pair: dense store, short-range scatter, long-range histogram
+// ------------------------------------------------------------------------------------------------
+struct EmitArgs {
+    double *MI;            // dense block, column-major nf x nt
+    const ColInfo *cols;   // null: dense store only (ldw_mi_block)
+    int nf, lower_only, keep_sr, do_lr;
+    int write_dense;       // store the dense MI block (needed by k_lr_gather; off when the gather is speculative)
+    int spec_B;            // >= 0: append long-range pairs with bucket >= spec_B to the candidate list right here,
+                           //       and histogram ONLY those (the pairs below are counted analytically)
+    int any_sr;            // 0: no pair of this block is short-range (skip the interval tests)
+    double spec_lo;        // lower edge of bucket spec_B minus a guard: cheap reject before the bucket arithmetic
+    int64_t sr_base;
+    int32_t *sr_a, *sr_b;
+    double *sr_mi;
+    unsigned long long *n_cand;
+    uint64_t *ckey, *cval;
+    // fp32 screen of the epilogue (speculative mode only): 0 off, 1 on, 2 verify
+    int scr_mode, scr_shift;             // fixed-point sums are cut to their top 31 bits: n >> scr_shift
+    float scr_scale;                     // 2^scr_shift * 2^-frac_bits
+    unsigned long long *scr_viol;        // verify mode: pairs the screen would have lost
+};
+
+__device__ __forceinline__ void emit_pair(const EmitArgs &E, const ColInfo &c, int a_loc, int b_loc, int sa, int sb,
+                                          double mi, unsigned int *sh_hist) {
+    if (E.write_dense) E.MI[(int64_t)a_loc + (int64_t)b_loc * E.nf] = mi;
+    if (!E.cols) return;
+    const int seg = pair_seg(a_loc, b_loc, E.lower_only);
+    if (seg < 0) return;
+    if (E.any_sr && col_is_sr(c, a_loc)) {
+        if (E.keep_sr) {
+            const int64_t dst = E.sr_base + (seg == 0 ? c.off_u + col_count(c, 0, a_loc) : c.off_l + col_count(c, b_loc + 1, a_loc));
+            E.sr_a[dst] = sa;
+            E.sr_b[dst] = sb;
+            E.sr_mi[dst] = mi;
+        }
+    } else if (E.do_lr) {
+        if (E.spec_B >= 0) {
+            // speculative mode: only the (rare) pairs at or above the guessed bucket are histogrammed and appended
+            if (mi >= E.spec_lo) {
+                const int bk = mi_bucket(mi);
+                if (bk >= E.spec_B) {
+                    atomicAdd(&sh_hist[bk], 1u);
+                    const unsigned long long p = atomicAdd(E.n_cand, 1ull);
+                    E.ckey[p] = f64_key(mi);
+                    E.cval[p] = ((uint64_t)seg << 62) | ((uint64_t)a_loc + (uint64_t)b_loc * (uint64_t)E.nf);
+                }
+            }
+        } else {
+            atomicAdd(&sh_hist[mi_bucket(mi)], 1u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MI epilogue: one thread per SNP pair; a wave = 64 consecutive from-side SNPs at one to-side SNP and walks
+// EPI_COLS/4 consecutive to-side SNPs, so everything indexed by the to-side SNP is wave-uniform.
+// ------------------------------------------------------------------------------------------------
+constexpr int EPI_COLS = 128;  // to-side SNPs per workgroup (4 waves x 32)
+
+struct EpiArgs {
+    const int64_t *G;
+    int RFpad;
+    const int32_t *idx_f, *lrow_f, *idx_t, *lrow_t;
+    int nf, nt;
+    const uint32_t *slot_meta;
+    const int64_t *slot_pfix;
+    const double *r;
+    double neff, scale;
+    int quirk;
+    EmitArgs E;
+};
+
+// arguments of the fused GEMM + epilogue kernel (ldw_fused.hip); A.G is unused there
+struct FusedArgs {
+    const uint64_t *Mbits;
+    int64_t KW, Kpad;
+    const int32_t *rowlist_t, *rowlist_f;
+    const int8_t *digits;
+    const int32_t *pos_f, *pos_t;   // local SNP index starting at each row position of the padded row lists, -1 elsewhere
+    const uint8_t *cls_f, *cls_t;   // slot-count class (1, 2, 4) of every 32-row group of the row lists
+    unsigned long long *ghist;      // NBINS counters of the long-range candidates
+    int dbg;                        // experiments only (env LDW_FUSED_DEBUG): 1 = skip the epilogue
+    EpiArgs A;
+};
+int launch_fused(ldw_ctx *ctx, const FusedArgs &F, int RFpad, int RTpad, int nlimbs, hipStream_t stream);
+
+// everything the epilogue needs about one to-side SNP, staged in LDS once per workgroup so that the
+// per-pair loop has no dependent global loads except its G entries
+struct ColMeta {
+    int32_t sb;
+    uint32_t mb;
+    int32_t rb0, pad;
+    double rb;      // r of the to-side SNP
+    double rq;      // Q1 on square blocks: r[idx_f[b_loc]]
+    double pYd[5];
+    int64_t pb[5];
+    float pYf[5];
+    int32_t pad2;
+    ColInfo ci;
+};
+
+// per-lane constants of the from-side SNP
+struct RowSide {
+    int sa, na;
+    uint32_t ma;
+    int64_t ra0;
+    double ra, rta;  // rta: Q1 on square blocks, r[idx_t[a_loc]]
+    int64_t pa[5];
+    double pXd[5];
+    float pXf[5];
+};
+
+// MI of one pair.  NAM / NB bound the unrolled slot loops (na <= NAM for every lane of the wave, nb <= NB);
+// the run-time slot counts still mask the individual cells.
+// Gp points at the pair's first joint sum G(slot 0 of a, slot 0 of b); slot i of the from-side SNP and slot j of the
+// to-side SNP are at Gp[i * si + j * sj] (global G block: si = 1, sj = RFpad, or transposed on the mirrored half of a
+// diagonal block; LDS tile of the fused kernel: si = 1, sj = its padded row stride).
+template <int NAM, int NB>
+__device__ __forceinline__ double pair_mi(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc,
+                                          bool square, const int64_t *Gp, int64_t si, int64_t sj) {
+    const int na = R.na, nb = M.mb & 7;
+    const uint32_t ma = R.ma, mb = M.mb;
+    // joint sums of the row slots (from G), their row / column sums
+    int64_t g[NAM][NB], rs[NAM], cs[NB];
+#pragma unroll
+    for (int i = 0; i < NAM; ++i) rs[i] = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) cs[j] = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int i = 0; i < NAM; ++i) {
+            int64_t v = 0;
+            if (i < na && j < nb) v = Gp[i * si + j * sj];
+            g[i][j] = v;
+            rs[i] += v;
+            cs[j] += v;
+        }
+    int64_t pa_drop = 0;
+#pragma unroll
+    for (int i = 0; i <= NAM; ++i)
+        if (i == na) pa_drop = R.pa[i];
+    int64_t dd = pa_drop;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        if (j < nb) dd -= M.pb[j] - cs[j];
+
+    const double ra = R.ra, rb = M.rb;
+    const double den = A.neff + (ra * rb) * 0.5;  // R/computePairwiseMI.R:260
+    double RXY;
+    if (A.quirk == LDW_QUIRK_REFERENCE) {
+        // rft is nt x nf but read by the linear index c = a + b*nf of the nf x nt matrix (Q1):
+        // 0.25 * rf[c / nt] * rt[c % nt]; on square blocks c / nt = b_loc and c % nt = a_loc
+        if (square) {
+            RXY = (M.rq * R.rta) * 0.25;
+        } else {
+            const uint32_t c = (uint32_t)a_loc + (uint32_t)b_loc * (uint32_t)A.nf;
+            const uint32_t q = c / (uint32_t)A.nt;
+            RXY = (A.r[A.idx_f[q]] * A.r[A.idx_t[c - q * (uint32_t)A.nt]]) * 0.25;
+        }
+    } else {
+        RXY = (ra * rb) * 0.25;
+    }
+    const double rX = 0.5 * ra, rY = 0.5 * rb;
+
+    // sum over cells of pxy * log(pxy / (pX pY + RXY + pX rX + pY rY) * den), divided by den at the end
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i <= NAM; ++i) {
+        if (i <= na && ((ma >> (3 + i)) & 1)) {
+            const double pX = R.pXd[i];
+            const double pXr = fma(pX, rX, RXY);
+#pragma unroll
+            for (int j = 0; j <= NB; ++j) {
+                if (j <= nb && ((mb >> (3 + j)) & 1)) {
+                    int64_t nfix;
+                    if (i < NAM && j < NB && i < na && j < nb) nfix = g[i < NAM ? i : 0][j < NB ? j : 0];
+                    else if (i < NAM && i < na) nfix = R.pa[i] - rs[i < NAM ? i : 0];   // j == nb
+                    else if (j < NB && j < nb) nfix = M.pb[j] - cs[j < NB ? j : 0];     // i == na
+                    else nfix = dd;
+                    const double pY = M.pYd[j];
+                    const double pxy = fma(u52_to_double(nfix), A.scale, 0.5);
+                    const double d = fma(pY, rY, fma(pX, pY, pXr));
+                    acc = fma(pxy, fast_log_ratio(pxy * den, d), acc);
+                }
+            }
+        }
+    }
+    return acc * fast_rcp(den);
+}
+
+// Straight-line variant for the common case: every lane has exactly NA row slots, the column has exactly NB,
+// and every slot of both SNPs is flagged in uqe — no per-cell predication, every index static.
+// The joint table in fixed point: rows = slots of the from-side SNP (the last one is the dropped state), columns = slots
+// of the to-side SNP; the cells without an indicator row follow from the marginals by exact integer subtraction.
+template <int NA, int NB>
+struct FullCells {
+    int64_t n[NA + 1][NB + 1];
+};
+
+template <int NA, int NB>
+__device__ __forceinline__ void full_cells(const RowSide &R, const ColMeta &M, const int64_t *Gp, int64_t si, int64_t sj,
+                                           FullCells<NA, NB> &C) {
+    int64_t rs[NA > 0 ? NA : 1], cs[NB > 0 ? NB : 1];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) rs[i] = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) cs[j] = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int64_t v = Gp[i * si + j * sj];
+            C.n[i][j] = v;
+            rs[i] += v;
+            cs[j] += v;
+        }
+    int64_t dd = R.pa[NA];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        C.n[NA][j] = M.pb[j] - cs[j];
+        dd -= C.n[NA][j];
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) C.n[i][NB] = R.pa[i] - rs[i];
+    C.n[NA][NB] = dd;
+}
+
+// RXY of src/computeMI.cpp:19 as the reference reads it (quirk Q1) or as intended
+__device__ __forceinline__ double pair_rxy(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc, bool square) {
+    if (A.quirk == LDW_QUIRK_REFERENCE) {
+        if (square) return (M.rq * R.rta) * 0.25;
+        const uint32_t c = (uint32_t)a_loc + (uint32_t)b_loc * (uint32_t)A.nf;
+        const uint32_t q = c / (uint32_t)A.nt;
+        return (A.r[A.idx_f[q]] * A.r[A.idx_t[c - q * (uint32_t)A.nt]]) * 0.25;
+    }
+    return (R.ra * M.rb) * 0.25;
+}
+
+template <int NA, int NB>
+__device__ __forceinline__ double full_cells_mi(const EpiArgs &A, const RowSide &R, const ColMeta &M, double RXY,
+                                                const FullCells<NA, NB> &C) {
+    const double ra = R.ra, rb = M.rb;
+    const double den = A.neff + (ra * rb) * 0.5;
+    const double rX = 0.5 * ra, rY = 0.5 * rb;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i <= NA; ++i) {
+        const double pX = R.pXd[i];
+        const double pXr = fma(pX, rX, RXY);
+#pragma unroll
+        for (int j = 0; j <= NB; ++j) {
+            const double pY = M.pYd[j];
+            const double pxy = fma(u52_to_double(C.n[i][j]), A.scale, 0.5);
+            const double d = fma(pY, rY, fma(pX, pY, pXr));
+            acc = fma(pxy, fast_log_ratio(pxy * den, d), acc);
+        }
+    }
+    return acc * fast_rcp(den);
+}
+
+// The same sum in fp32 with v_log_f32, an order of magnitude cheaper than the fp64 evaluation: a SCREEN.  In the
+// speculative selection mode a long-range pair matters only if its MI reaches the guessed bucket, which one pair in
+// a thousand does; the screen decides that for the rest within SCREEN_EPS and the exact evaluation runs only for
+// waves that hold a pair which passes (or a short-range pair).  Error budget, in nats: every cell contributes
+// (pxy/den) * (log2 u - log2 v) * ln2 with sum(pxy/den) = 1; v_log_f32 is good to 1 ulp of a result below 64 in
+// magnitude (2^-18 = 3.8e-6), the operands carry <= 3 roundings of 2^-24 each and the top 31 bits of the fixed-point
+// sum (<= 1e-7 on log2): |error| < 1.3e-5 ; SCREEN_EPS = 2e-4 leaves a factor of 15.  ldw_set_screen(ctx, 2) evaluates
+// every pair both ways and counts the pairs the screen would have lost (tests assert zero).
+constexpr float SCREEN_EPS = 2e-4f;
+
+template <int NA, int NB>
+__device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSide &R, const ColMeta &M, double RXY,
+                                                   const FullCells<NA, NB> &C) {
+    const float ra = (float)R.ra, rb = (float)M.rb;
+    const float den = (float)A.neff + (ra * rb) * 0.5f;
+    const float rX = 0.5f * ra, rY = 0.5f * rb, rxy = (float)RXY;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i <= NA; ++i) {
+        const float pX = R.pXf[i];
+        const float pXr = fmaf(pX, rX, rxy);
+#pragma unroll
+        for (int j = 0; j <= NB; ++j) {
+            const float pY = M.pYf[j];
+            const float pxy = fmaf((float)(uint32_t)(C.n[i][j] >> A.E.scr_shift), A.E.scr_scale, 0.5f);
+            const float d = fmaf(pY, rY, fmaf(pX, pY, pXr));
+            acc = fmaf(pxy, __builtin_amdgcn_logf(pxy * den) - __builtin_amdgcn_logf(d), acc);
+        }
+    }
+    return acc * (0.6931471805599453f * __builtin_amdgcn_rcpf(den));
+}
+
+template <int NA, int NB>
+__device__ __forceinline__ double pair_mi_full(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc,
+                                               bool square, const int64_t *Gp, int64_t si, int64_t sj) {
+    FullCells<NA, NB> C;
+    full_cells<NA, NB>(R, M, Gp, si, sj, C);
+    return full_cells_mi<NA, NB>(A, R, M, pair_rxy(A, R, M, a_loc, b_loc, square), C);
+}
+
+// Screen, then the exact value if some lane of the wave needs it.  `want(mi_upper)` tells whether a lane whose MI is at
+// most mi_upper still has to be evaluated exactly; returns false when no lane of the wave does (mi is then not set).
+// scr_mode: 0 = no screen, 1 = screen, 2 = screen + exact for every lane, lanes the screen would have lost are counted.
+template <int NA, int NB, class Want>
+__device__ __forceinline__ bool pair_mi_full_screened(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc,
+                                                      bool square, const int64_t *Gp, int64_t si, int64_t sj, bool lane_on,
+                                                      Want want, double &mi, bool &need) {
+    FullCells<NA, NB> C;
+    full_cells<NA, NB>(R, M, Gp, si, sj, C);
+    const double RXY = pair_rxy(A, R, M, a_loc, b_loc, square);
+    need = lane_on;
+    if (A.E.scr_mode) {
+        const float ub = full_cells_screen<NA, NB>(A, R, M, RXY, C) + SCREEN_EPS;
+        need = lane_on && want(ub);
+        if (A.E.scr_mode == 3) return false;   // experiment: screen cost alone
+        if (A.E.scr_mode == 1 && __ballot(need) == 0ull) return false;
+    }
+    mi = full_cells_mi<NA, NB>(A, R, M, RXY, C);
+    if (A.E.scr_mode == 2) {
+        if (lane_on && !need && want((float)mi)) atomicAdd(A.E.scr_viol, 1ull);
+        need = lane_on;
+    }
+    return true;
+}
+
+}  // namespace ldw

@@ -21,29 +21,14 @@
 //
 // Tiling: 128 (to side) x 64 (from side) rows per workgroup, 4 waves (2 x 2), 64 x 32 per wave = 2 MFMA tiles x J limbs.
 #include "ldw_internal.h"
+#include "ldw_gemm_tile.h"
 
 namespace ldw {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-
-constexpr int BW_CHUNK = 16;        // 64-bit words of K per LDS chunk (1024 sequences)
-constexpr int BROW = BW_CHUNK + 1;  // padded LDS row stride in words: odd, so 32 rows hit 32 distinct 8-B bank pairs
-
-__device__ __forceinline__ v4i expand01(uint32_t b16) {
-    v4i r;
-    r[0] = (int)(__umul24(b16 & 0xFu, 0x204081u) & 0x01010101u);
-    r[1] = (int)(__umul24((b16 >> 4) & 0xFu, 0x204081u) & 0x01010101u);
-    r[2] = (int)(__umul24((b16 >> 8) & 0xFu, 0x204081u) & 0x01010101u);
-    r[3] = (int)(__umul24((b16 >> 12) & 0xFu, 0x204081u) & 0x01010101u);
-    return r;
-}
 
 // 256-thread workgroups (4 waves, 2 x 2), tile 128 (to side) x 64 (from side), 64 x 32 per wave.  Two workgroups are
 // resident per CU (256 VGPRs per wave, 66.5 KB LDS each), so the prologue (LUT build, first chunk), the per-chunk
 // barrier and the Horner/store tail of one overlap the MFMA loop of the other: 5 % faster than one 512-thread
 // workgroup of 128 x 128 with the same wave tile.
-constexpr int TILE_F4 = 64;
 template <int J>
 __global__ __launch_bounds__(256, 2) void gemm_bits_kernel(const uint64_t *__restrict__ Mbits, int64_t KW,
                                                               const int32_t *__restrict__ rowlist_t,
@@ -54,132 +39,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bits_kernel(const uint64_t *__res
     const int bx = blockIdx.x, by = blockIdx.y;  // bx: from-side tile of 64 rows, by: to-side tile of 128 rows
     if (lower_only && bx * TILE_F4 + TILE_F4 - 1 < by * TILE) return;
 
-    __shared__ __attribute__((aligned(16))) uint64_t sT[2][TILE * BROW];
-    __shared__ __attribute__((aligned(16))) uint64_t sF[2][TILE_F4 * BROW];
-    __shared__ __attribute__((aligned(16))) int8_t sD[2][J * BW_CHUNK * 64];
-    __shared__ uint64_t lut01[256], lutFF[256];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // staging: to side 128 rows x 8 word pairs = 1024 pieces (4 per thread), from side 64 x 8 = 512 (2 per thread)
-    const uint64_t *gT[4], *gF[2];
-    int woT[4], woF[2], wpT[4], wpF[2];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int idx = tid + 256 * p;
-        const int row = idx >> 3;
-        wpT[p] = idx & 7;
-        gT[p] = Mbits + (int64_t)rowlist_t[by * TILE + row] * KW + 2 * wpT[p];
-        woT[p] = row * BROW + 2 * wpT[p];
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int idx = tid + 256 * p;
-        const int row = idx >> 3;
-        wpF[p] = idx & 7;
-        gF[p] = Mbits + (int64_t)rowlist_f[bx * TILE_F4 + row] * KW + 2 * wpF[p];
-        woF[p] = row * BROW + 2 * wpF[p];
-    }
-    // digits of a chunk: J*64 pieces of 16 B over 256 threads
-    constexpr int DP = (J * 64 + 255) / 256;
-    const int8_t *gD[DP];
-    int dOfs[DP], dq[DP];
-    bool dOn[DP];
-#pragma unroll
-    for (int p = 0; p < DP; ++p) {
-        const int idx = tid + 256 * p;
-        dOn[p] = idx < J * 64;
-        const int dj = idx >> 6;
-        dq[p] = idx & 63;
-        gD[p] = digits + (int64_t)(dOn[p] ? dj : 0) * Kpad + dq[p] * 16;
-        dOfs[p] = dj * (BW_CHUNK * 64) + dq[p] * 16;
-    }
-
-    v16i acc[J][2];
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][m][e] = 0;
-
-    const int nchunk = (int)((KW + BW_CHUNK - 1) / BW_CHUNK);
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    u64x2 rT[4], rF[2];
-    v4i rD[DP];
-
-    auto load_chunk = [&](int c) {
-        const int64_t w0 = (int64_t)c * BW_CHUNK;
-        const int cw = (int)((KW - w0) < BW_CHUNK ? (KW - w0) : BW_CHUNK);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) rT[p] = (2 * wpT[p] < cw) ? *reinterpret_cast<const u64x2 *>(gT[p] + w0) : u64x2{0ull, 0ull};
-#pragma unroll
-        for (int p = 0; p < 2; ++p) rF[p] = (2 * wpF[p] < cw) ? *reinterpret_cast<const u64x2 *>(gF[p] + w0) : u64x2{0ull, 0ull};
-#pragma unroll
-        for (int p = 0; p < DP; ++p)
-            rD[p] = (dOn[p] && dq[p] * 16 < cw * 64) ? *reinterpret_cast<const v4i *>(gD[p] + w0 * 64) : v4i{0, 0, 0, 0};
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            sT[buf][woT[p]] = rT[p][0];
-            sT[buf][woT[p] + 1] = rT[p][1];
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            sF[buf][woF[p]] = rF[p][0];
-            sF[buf][woF[p] + 1] = rF[p][1];
-        }
-#pragma unroll
-        for (int p = 0; p < DP; ++p)
-            if (dOn[p]) *reinterpret_cast<v4i *>(&sD[buf][dOfs[p]]) = rD[p];
-    };
-
-    {
-        const v4i lo = expand01((uint32_t)tid & 0xFFu);
-        const uint64_t e01 = (uint64_t)(uint32_t)lo[0] | ((uint64_t)(uint32_t)lo[1] << 32);
-        lut01[tid] = e01;
-        lutFF[tid] = (e01 << 8) - e01;
-    }
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-
-    const int frow = lane & 31;
-    const int fh = lane >> 5;
-    const int a0o = (wm * 64 + frow) * BROW + fh, a1o = a0o + 32 * BROW, bo = (wn * 32 + frow) * BROW + fh;
-
-    for (int c = 0; c < nchunk; ++c) {
-        const int cur = c & 1;
-        if (c + 1 < nchunk) load_chunk(c + 1);
-        const int64_t w0 = (int64_t)c * BW_CHUNK;
-        const int nmac = (int)(((KW - w0) < BW_CHUNK ? (KW - w0) : BW_CHUNK) >> 1);
-        for (int m = 0; m < nmac; ++m) {
-            const uint64_t a0w = sT[cur][a0o + 2 * m], a1w = sT[cur][a1o + 2 * m], bw = sF[cur][bo + 2 * m];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
-                const u64x2v a0q = {lut01[(a0w >> (16 * kk)) & 0xFFu], lut01[(a0w >> (16 * kk + 8)) & 0xFFu]};
-                const u64x2v a1q = {lut01[(a1w >> (16 * kk)) & 0xFFu], lut01[(a1w >> (16 * kk + 8)) & 0xFFu]};
-                const u64x2v bq = {lutFF[(bw >> (16 * kk)) & 0xFFu], lutFF[(bw >> (16 * kk + 8)) & 0xFFu]};
-                const v4i a0 = __builtin_bit_cast(v4i, a0q), a1 = __builtin_bit_cast(v4i, a1q);
-                const v4i bmask = __builtin_bit_cast(v4i, bq);
-                const int doff = (2 * m + fh) * 64 + kk * 16;
-#pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    const v4i d = *reinterpret_cast<const v4i *>(&sD[cur][j * (BW_CHUNK * 64) + doff]);
-                    const v4i bm = bmask & d;
-                    acc[j][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bm, acc[j][0], 0, 0, 0);
-                    acc[j][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bm, acc[j][1], 0, 0, 0);
-                }
-            }
-        }
-        if (c + 1 < nchunk) store_chunk(cur ^ 1);
-        __syncthreads();
-    }
+    __shared__ GemmSmem<J> S;
+#include "ldw_gemm_kloop.inc"
 
     const int fcol = bx * TILE_F4 + wn * 32 + frow;
 #pragma unroll

@@ -96,7 +96,8 @@ struct ldw_ctx {
     ldw::DevBuf G, G2;           // int64 [RTpad][RFpad] fixed-point joint sums, one per pipeline slot
     ldw::DevBuf MIblk;           // double [nf*nt]
     ldw::DevBuf rowlist_f, rowlist_t, idx_f, idx_t, lrow_f, lrow_t, perm_f;
-    ldw::DevBuf hist, colcnt, cand_key, cand_val, cand_key2, cand_val2, scratch, small;
+    ldw::DevBuf hist[2], cand_key[2], cand_val[2];   // per pipeline slot: histogram of the lr candidates, candidate list
+    ldw::DevBuf colcnt, cand_key2, cand_val2, scratch, small;
 
     // ---- link tables (device resident) ----
     ldw::DevBuf sr_a, sr_b, sr_mi, lr_a, lr_b, lr_mi;
@@ -119,11 +120,17 @@ struct ldw_ctx {
     ldw::DevBuf dstage[2];               // device image of the packed buffer
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool done_recorded[2] = {false, false};
-    void *pin_pick = nullptr;            // pinned landing zone of the per-block PickOut
-    hipEvent_t ev_pick = nullptr;
+    void *pin_pick[2] = {nullptr, nullptr};   // pinned landing zone of the per-block PickOut, one per slot
+    hipEvent_t ev_pick[2] = {nullptr, nullptr};
+    void *pin_lrc = nullptr;             // pinned copy of the running long-range row count
+    hipEvent_t ev_lrc = nullptr;
+    bool lrc_recorded = false;
+    bool fused = true;                   // GEMM + epilogue in one kernel whenever a bucket guess exists (ldw_fused.hip)
+    bool spec_seen[2] = {false, false};  // a block of this kind (off-diagonal, diagonal) has set its own guess
     std::vector<hipEvent_t> ev_pool;     // 4 timing events per block
     int spec_B_next[2] = {-1, -1};       // bucket guess for the speculative long-range gather: [off-diagonal, diagonal]
-    int64_t spec_misses = 0;
+    int64_t spec_misses = 0, fused_blocks = 0, unfused_blocks = 0, screen_violations = 0;
+    int screen = 1;                      // fp32 screen in front of the fp64 MI evaluation (0 off, 1 on, 2 verify)
     std::vector<ldw::BlockStat> stats;
 };
 

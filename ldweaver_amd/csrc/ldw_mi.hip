@@ -16,334 +16,11 @@
 
 #include "ldw_internal.h"
 #include "ldw_dev.h"
+#include "ldw_epi.h"
 
 using namespace ldw;
 
 namespace ldw {
-
-// ------------------------------------------------------------------------------------------------
-// helpers shared by host and device
-// ------------------------------------------------------------------------------------------------
-// Histogram bucket of an MI value: monotone non-decreasing in mi, 128 buckets per octave (0.5 % wide) from 2^-20
-// up, taken straight from the IEEE-754 bits (exponent + 7 mantissa bits) — no floating-point arithmetic.  Values
-// below 2^-20 (and negatives, which quirk Q1 can produce) fall in bucket 0.
-constexpr int BUCKET_OFF = (1023 - 20) << 7;
-__host__ __device__ __forceinline__ int mi_bucket(double mi) {
-    long long u;
-    memcpy(&u, &mi, 8);
-    if (u <= 0) return 0;  // -x, -0, +0
-    const int b = (int)(u >> 45) - BUCKET_OFF;
-    return b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
-}
-// lower edge of bucket B (B >= 1)
-__host__ __device__ __forceinline__ double bucket_lo(int B) {
-    const long long u = (long long)(B + BUCKET_OFF) << 45;
-    double v;
-    memcpy(&v, &u, 8);
-    return v;
-}
-
-// Short-range partners of one to-side SNP: up to three disjoint, ascending index intervals [s,e) of the
-// from-side list, plus the first row of its upper (a_loc < b_loc) and lower (a_loc > b_loc) segment in
-// the short-range table (relative to the block's base row).
-struct ColInfo {
-    int32_t s[3], e[3];
-    int32_t pad[2];
-    int64_t off_u, off_l;
-};
-
-__host__ __device__ __forceinline__ bool col_is_sr(const ColInfo &c, int a) {
-    return (a >= c.s[0] && a < c.e[0]) || (a >= c.s[1] && a < c.e[1]) || (a >= c.s[2] && a < c.e[2]);
-}
-// number of short-range partners in [lo, hi)
-__host__ __device__ __forceinline__ int col_count(const ColInfo &c, int lo, int hi) {
-    int n = 0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int a = c.s[k] > lo ? c.s[k] : lo, b = c.e[k] < hi ? c.e[k] : hi;
-        n += b > a ? b - a : 0;
-    }
-    return n;
-}
-
-// which segment a pair belongs to: 0 = upper (a<b, off-diagonal blocks only), 1 = lower (a>b), -1 = not a pair
-__host__ __device__ __forceinline__ int pair_seg(int a_loc, int b_loc, int lower_only) {
-    if (a_loc == b_loc) return -1;
-    if (a_loc > b_loc) return 1;
-    return lower_only ? -1 : 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// fp64 helpers of the epilogue: no IEEE division, no libm call.  Accuracy ~2e-15; the
-// epilogue is not bit-matched to the reference (tolerance 1e-6 on MI), see DESIGN.md.
-// ------------------------------------------------------------------------------------------------
-// v_rcp_f64 is good to 4.5e-8 (measured on gfx950); one Newton step brings it to 2e-15
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
-
-// exact conversion of an integer 0 <= n < 2^52 to double (two integer ops and one add instead of the
-// multi-instruction int64 -> f64 sequence)
-__device__ __forceinline__ double u52_to_double(int64_t n) {
-    return __longlong_as_double(n | 0x4330000000000000LL) - 4503599627370496.0;
-}
-
-// log(N / D) for positive, finite, normal doubles with ONE reciprocal: D is rescaled by a power of two so that
-// N / D' lies in [1/sqrt2, sqrt2]; then log(N/D') = 2 atanh(s), s = (N - D')/(N + D'), |s| <= 0.1716, odd series
-// to s^17 (absolute error < 1e-15), and log(N/D) = k ln2 + log(N/D').
-__device__ __forceinline__ double fast_log_ratio(double N, double D) {
-    const int hn = __double2hiint(N), hd = __double2hiint(D);
-    int k = ((hn >> 20) & 0x7FF) - ((hd >> 20) & 0x7FF);
-    double Dp = __hiloint2double(hd + (k << 20), __double2loint(D));   // D * 2^k: same exponent as N
-    // N / Dp is in (1/2, 2): fold it into [1/sqrt2, sqrt2]
-    const bool big = N > Dp * 1.4142135623730951, small = N * 1.4142135623730951 < Dp;
-    const int adj = big ? 1 : (small ? -1 : 0);
-    Dp = __hiloint2double(__double2hiint(Dp) + (adj << 20), __double2loint(Dp));
-    k += adj;
-    const double s = (N - Dp) * fast_rcp(N + Dp);
-    const double z = s * s;
-    double p = 1.0 / 17.0;           // truncation z^9/19 <= 9e-16 relative to 2s
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
-    p = p * z;  // atanh(s)/s - 1
-    const double lm = fma(s + s, p, s + s);
-    return fma((double)k, 0.693147180559945309417, lm);
-}
-
-// ------------------------------------------------------------------------------------------------
-// what happens to one finished pair: dense store, short-range scatter, long-range histogram
-// ------------------------------------------------------------------------------------------------
-struct EmitArgs {
-    double *MI;            // dense block, column-major nf x nt
-    const ColInfo *cols;   // null: dense store only (ldw_mi_block)
-    int nf, lower_only, keep_sr, do_lr;
-    int write_dense;       // store the dense MI block (needed by k_lr_gather; off when the gather is speculative)
-    int spec_B;            // >= 0: append long-range pairs with bucket >= spec_B to the candidate list right here,
-                           //       and histogram ONLY those (the pairs below are counted analytically)
-    int any_sr;            // 0: no pair of this block is short-range (skip the interval tests)
-    double spec_lo;        // lower edge of bucket spec_B minus a guard: cheap reject before the bucket arithmetic
-    int64_t sr_base;
-    int32_t *sr_a, *sr_b;
-    double *sr_mi;
-    unsigned long long *n_cand;
-    uint64_t *ckey, *cval;
-};
-
-__device__ __forceinline__ void emit_pair(const EmitArgs &E, const ColInfo &c, int a_loc, int b_loc, int sa, int sb,
-                                          double mi, unsigned int *sh_hist) {
-    if (E.write_dense) E.MI[(int64_t)a_loc + (int64_t)b_loc * E.nf] = mi;
-    if (!E.cols) return;
-    const int seg = pair_seg(a_loc, b_loc, E.lower_only);
-    if (seg < 0) return;
-    if (E.any_sr && col_is_sr(c, a_loc)) {
-        if (E.keep_sr) {
-            const int64_t dst = E.sr_base + (seg == 0 ? c.off_u + col_count(c, 0, a_loc) : c.off_l + col_count(c, b_loc + 1, a_loc));
-            E.sr_a[dst] = sa;
-            E.sr_b[dst] = sb;
-            E.sr_mi[dst] = mi;
-        }
-    } else if (E.do_lr) {
-        if (E.spec_B >= 0) {
-            // speculative mode: only the (rare) pairs at or above the guessed bucket are histogrammed and appended
-            if (mi >= E.spec_lo) {
-                const int bk = mi_bucket(mi);
-                if (bk >= E.spec_B) {
-                    atomicAdd(&sh_hist[bk], 1u);
-                    const unsigned long long p = atomicAdd(E.n_cand, 1ull);
-                    E.ckey[p] = f64_key(mi);
-                    E.cval[p] = ((uint64_t)seg << 62) | ((uint64_t)a_loc + (uint64_t)b_loc * (uint64_t)E.nf);
-                }
-            }
-        } else {
-            atomicAdd(&sh_hist[mi_bucket(mi)], 1u);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// MI epilogue: one thread per SNP pair; a wave = 64 consecutive from-side SNPs at one to-side SNP and walks
-// EPI_COLS/4 consecutive to-side SNPs, so everything indexed by the to-side SNP is wave-uniform.
-// ------------------------------------------------------------------------------------------------
-constexpr int EPI_COLS = 128;  // to-side SNPs per workgroup (4 waves x 32)
-
-struct EpiArgs {
-    const int64_t *G;
-    int RFpad;
-    const int32_t *idx_f, *lrow_f, *idx_t, *lrow_t;
-    int nf, nt;
-    const uint32_t *slot_meta;
-    const int64_t *slot_pfix;
-    const double *r;
-    double neff, scale;
-    int quirk;
-    EmitArgs E;
-};
-
-// everything the epilogue needs about one to-side SNP, staged in LDS once per workgroup so that the
-// per-pair loop has no dependent global loads except its G entries
-struct ColMeta {
-    int32_t sb;
-    uint32_t mb;
-    int32_t rb0, pad;
-    double rb;      // r of the to-side SNP
-    double rq;      // Q1 on square blocks: r[idx_f[b_loc]]
-    double pYd[5];
-    int64_t pb[5];
-    ColInfo ci;
-};
-
-// per-lane constants of the from-side SNP
-struct RowSide {
-    int sa, na;
-    uint32_t ma;
-    int64_t ra0;
-    double ra, rta;  // rta: Q1 on square blocks, r[idx_t[a_loc]]
-    int64_t pa[5];
-    double pXd[5];
-};
-
-// MI of one pair.  NAM / NB bound the unrolled slot loops (na <= NAM for every lane of the wave, nb <= NB);
-// the run-time slot counts still mask the individual cells.
-template <int NAM, int NB>
-__device__ __forceinline__ double pair_mi(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc,
-                                          bool square) {
-    const int na = R.na, nb = M.mb & 7;
-    const uint32_t ma = R.ma, mb = M.mb;
-    // joint sums of the row slots (from G), their row / column sums
-    int64_t g[NAM][NB], rs[NAM], cs[NB];
-#pragma unroll
-    for (int i = 0; i < NAM; ++i) rs[i] = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) cs[j] = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int i = 0; i < NAM; ++i) {
-            int64_t v = 0;
-            if (i < na && j < nb) v = A.G[((int64_t)M.rb0 + j) * A.RFpad + R.ra0 + i];
-            g[i][j] = v;
-            rs[i] += v;
-            cs[j] += v;
-        }
-    int64_t pa_drop = 0;
-#pragma unroll
-    for (int i = 0; i <= NAM; ++i)
-        if (i == na) pa_drop = R.pa[i];
-    int64_t dd = pa_drop;
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-        if (j < nb) dd -= M.pb[j] - cs[j];
-
-    const double ra = R.ra, rb = M.rb;
-    const double den = A.neff + (ra * rb) * 0.5;  // R/computePairwiseMI.R:260
-    double RXY;
-    if (A.quirk == LDW_QUIRK_REFERENCE) {
-        // rft is nt x nf but read by the linear index c = a + b*nf of the nf x nt matrix (Q1):
-        // 0.25 * rf[c / nt] * rt[c % nt]; on square blocks c / nt = b_loc and c % nt = a_loc
-        if (square) {
-            RXY = (M.rq * R.rta) * 0.25;
-        } else {
-            const uint32_t c = (uint32_t)a_loc + (uint32_t)b_loc * (uint32_t)A.nf;
-            const uint32_t q = c / (uint32_t)A.nt;
-            RXY = (A.r[A.idx_f[q]] * A.r[A.idx_t[c - q * (uint32_t)A.nt]]) * 0.25;
-        }
-    } else {
-        RXY = (ra * rb) * 0.25;
-    }
-    const double rX = 0.5 * ra, rY = 0.5 * rb;
-
-    // sum over cells of pxy * log(pxy / (pX pY + RXY + pX rX + pY rY) * den), divided by den at the end
-    double acc = 0.0;
-#pragma unroll
-    for (int i = 0; i <= NAM; ++i) {
-        if (i <= na && ((ma >> (3 + i)) & 1)) {
-            const double pX = R.pXd[i];
-            const double pXr = fma(pX, rX, RXY);
-#pragma unroll
-            for (int j = 0; j <= NB; ++j) {
-                if (j <= nb && ((mb >> (3 + j)) & 1)) {
-                    int64_t nfix;
-                    if (i < NAM && j < NB && i < na && j < nb) nfix = g[i < NAM ? i : 0][j < NB ? j : 0];
-                    else if (i < NAM && i < na) nfix = R.pa[i] - rs[i < NAM ? i : 0];   // j == nb
-                    else if (j < NB && j < nb) nfix = M.pb[j] - cs[j < NB ? j : 0];     // i == na
-                    else nfix = dd;
-                    const double pY = M.pYd[j];
-                    const double pxy = fma(u52_to_double(nfix), A.scale, 0.5);
-                    const double d = fma(pY, rY, fma(pX, pY, pXr));
-                    acc = fma(pxy, fast_log_ratio(pxy * den, d), acc);
-                }
-            }
-        }
-    }
-    return acc * fast_rcp(den);
-}
-
-// Straight-line variant for the common case: every lane has exactly NA row slots, the column has exactly NB,
-// and every slot of both SNPs is flagged in uqe — no per-cell predication, every index static.
-template <int NA, int NB>
-__device__ __forceinline__ double pair_mi_full(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc,
-                                               bool square) {
-    int64_t g[NA > 0 ? NA : 1][NB > 0 ? NB : 1], rs[NA > 0 ? NA : 1], cs[NB > 0 ? NB : 1];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) rs[i] = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) cs[j] = 0;
-    const int64_t base = (int64_t)M.rb0 * A.RFpad + R.ra0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int64_t v = A.G[base + (int64_t)j * A.RFpad + i];
-            g[i][j] = v;
-            rs[i] += v;
-            cs[j] += v;
-        }
-    int64_t dd = R.pa[NA];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) dd -= M.pb[j] - cs[j];
-
-    const double ra = R.ra, rb = M.rb;
-    const double den = A.neff + (ra * rb) * 0.5;
-    double RXY;
-    if (A.quirk == LDW_QUIRK_REFERENCE) {
-        if (square) {
-            RXY = (M.rq * R.rta) * 0.25;
-        } else {
-            const uint32_t c = (uint32_t)a_loc + (uint32_t)b_loc * (uint32_t)A.nf;
-            const uint32_t q = c / (uint32_t)A.nt;
-            RXY = (A.r[A.idx_f[q]] * A.r[A.idx_t[c - q * (uint32_t)A.nt]]) * 0.25;
-        }
-    } else {
-        RXY = (ra * rb) * 0.25;
-    }
-    const double rX = 0.5 * ra, rY = 0.5 * rb;
-    double acc = 0.0;
-#pragma unroll
-    for (int i = 0; i <= NA; ++i) {
-        const double pX = R.pXd[i];
-        const double pXr = fma(pX, rX, RXY);
-#pragma unroll
-        for (int j = 0; j <= NB; ++j) {
-            int64_t nfix;
-            if (i < NA && j < NB) nfix = g[i < NA ? i : 0][j < NB ? j : 0];
-            else if (i < NA) nfix = R.pa[i] - rs[i < NA ? i : 0];
-            else if (j < NB) nfix = M.pb[j] - cs[j < NB ? j : 0];
-            else nfix = dd;
-            const double pY = M.pYd[j];
-            const double pxy = fma(u52_to_double(nfix), A.scale, 0.5);
-            const double d = fma(pY, rY, fma(pX, pY, pXr));
-            acc = fma(pxy, fast_log_ratio(pxy * den, d), acc);
-        }
-    }
-    return acc * fast_rcp(den);
-}
 
 __global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *__restrict__ perm_f,
                                                      unsigned long long *__restrict__ ghist) {
@@ -367,7 +44,9 @@ __global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *_
             for (int j = 0; j < 5; ++j) {
                 m.pb[j] = A.slot_pfix[(int64_t)m.sb * 5 + j];
                 m.pYd[j] = (double)m.pb[j] * A.scale;
+                m.pYf[j] = (float)m.pYd[j];
             }
+            m.pad2 = 0;
             if (A.E.cols) m.ci = A.E.cols[b_loc];
             cm[threadIdx.x] = m;
         }
@@ -390,6 +69,7 @@ __global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *_
     for (int i = 0; i < 5; ++i) {
         R.pa[i] = A.slot_pfix[(int64_t)R.sa * 5 + i];
         R.pXd[i] = (double)R.pa[i] * A.scale;
+        R.pXf[i] = (float)R.pXd[i];
     }
     const int na_max = (__ballot(R.na > 2) != 0ull) ? 4 : ((__ballot(R.na > 1) != 0ull) ? 2 : 1);
     // wave-uniform: every active lane has the same slot count (1 or 2) and all its slots flagged in uqe
@@ -408,23 +88,36 @@ __global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *_
         if (A.E.lower_only && a_loc <= b_loc) continue;
         const ColMeta &M = cm[cl];
         const int nb = __builtin_amdgcn_readfirstlane((int)(M.mb & 7));
+        // Row lists are ordered by slot-count class, not by SNP index, so on a diagonal block (symmetric G, tiles above
+        // the diagonal of ROW positions skipped by the GEMM) the entry of a pair may only exist transposed.
+        const bool tr = A.E.lower_only && R.ra0 < (int64_t)M.rb0;
+        const int64_t si = tr ? (int64_t)A.RFpad : 1, sj = tr ? 1 : (int64_t)A.RFpad;
+        const int64_t *Gp = A.G + (tr ? R.ra0 * A.RFpad + M.rb0 : (int64_t)M.rb0 * A.RFpad + R.ra0);
         double mi;
         const bool b_full = ((M.mb >> 3) & ((2u << nb) - 1u)) == ((2u << nb) - 1u);
         if (wave_full && b_full && (nb == 1 || nb == 2)) {
-            if (na0 == 1) mi = nb == 1 ? pair_mi_full<1, 1>(A, R, M, a_loc, b_loc, square) : pair_mi_full<1, 2>(A, R, M, a_loc, b_loc, square);
-            else mi = nb == 1 ? pair_mi_full<2, 1>(A, R, M, a_loc, b_loc, square) : pair_mi_full<2, 2>(A, R, M, a_loc, b_loc, square);
+            // fp32 screen first (speculative mode): the exact value is computed only if some lane of the wave holds a
+            // short-range pair or a long-range pair that may reach the guessed bucket
+            const bool is_sr = A.E.scr_mode && A.E.any_sr && col_is_sr(M.ci, a_loc);
+            auto want = [&](double ub) { return is_sr ? A.E.keep_sr != 0 : (A.E.do_lr && ub >= A.E.spec_lo); };
+            bool need, ran;
+            if (na0 == 1) ran = nb == 1 ? pair_mi_full_screened<1, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj, true, want, mi, need)
+                                        : pair_mi_full_screened<1, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj, true, want, mi, need);
+            else ran = nb == 1 ? pair_mi_full_screened<2, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj, true, want, mi, need)
+                               : pair_mi_full_screened<2, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj, true, want, mi, need);
+            if (!ran || !need) continue;
         } else if (na_max == 1) {
-            if (nb <= 1) mi = pair_mi<1, 1>(A, R, M, a_loc, b_loc, square);
-            else if (nb == 2) mi = pair_mi<1, 2>(A, R, M, a_loc, b_loc, square);
-            else mi = pair_mi<1, 4>(A, R, M, a_loc, b_loc, square);
+            if (nb <= 1) mi = pair_mi<1, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+            else if (nb == 2) mi = pair_mi<1, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+            else mi = pair_mi<1, 4>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
         } else if (na_max == 2) {
-            if (nb <= 1) mi = pair_mi<2, 1>(A, R, M, a_loc, b_loc, square);
-            else if (nb == 2) mi = pair_mi<2, 2>(A, R, M, a_loc, b_loc, square);
-            else mi = pair_mi<2, 4>(A, R, M, a_loc, b_loc, square);
+            if (nb <= 1) mi = pair_mi<2, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+            else if (nb == 2) mi = pair_mi<2, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+            else mi = pair_mi<2, 4>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
         } else {
-            if (nb <= 1) mi = pair_mi<4, 1>(A, R, M, a_loc, b_loc, square);
-            else if (nb == 2) mi = pair_mi<4, 2>(A, R, M, a_loc, b_loc, square);
-            else mi = pair_mi<4, 4>(A, R, M, a_loc, b_loc, square);
+            if (nb <= 1) mi = pair_mi<4, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+            else if (nb == 2) mi = pair_mi<4, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+            else mi = pair_mi<4, 4>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
         }
         emit_pair(A.E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, sh_hist);
     }
@@ -716,22 +409,49 @@ int upload_i32(ldw_ctx *c, ldw::DevBuf &buf, const std::vector<int32_t> &v) {
     return LDW_OK;
 }
 
-// row lists / local row offsets of one side
-int build_side(ldw_ctx *c, const int32_t *idx, int64_t n, std::vector<int32_t> &rowlist, std::vector<int32_t> &lrow,
-               int &Rpad) {
-    lrow.resize((size_t)n);
-    rowlist.clear();
-    for (int64_t k = 0; k < n; ++k) {
-        const int32_t a = idx[k];
-        LDW_REQUIRE(a >= 0 && a < c->L, LDW_ERR_ARG, "SNP index %d out of range 0..%lld", a, (long long)c->L - 1);
-        lrow[k] = (int32_t)rowlist.size();
-        for (int32_t rr = c->h_row0[a]; rr < c->h_row0[a + 1]; ++rr) rowlist.push_back(rr);
+// Row list of one side of a block.  SNPs are grouped by slot-count CLASS — 1, 2 or 4 indicator rows after padding
+// (0 -> 1, 3 -> 4 with rows of zeros) — in their list order within a class, and every class starts on a 32-row
+// boundary: a 32 x 32 MFMA tile then holds whole SNPs of one class on either side and no SNP straddles the 64 x 32
+// sub-tile of a wave, which is what lets the fused kernel (ldw_fused.hip) run the epilogue on chip.  lrow[k] = row
+// position of SNP k's first row; pos[p] = k at that position, -1 elsewhere; cls[g] = class of 32-row group g.
+struct SideLists {
+    std::vector<int32_t> rowlist, lrow, pos;
+    std::vector<uint8_t> cls;
+    int Rpad = 0;
+};
+
+int build_side(ldw_ctx *c, const int32_t *idx, int64_t n, SideLists &S) {
+    S.lrow.assign((size_t)n, 0);
+    S.rowlist.clear();
+    S.pos.clear();
+    S.cls.clear();
+    const int32_t zero_row = (int32_t)c->R;   // rows R .. R+TILE-1 of Mbits are zero
+    for (int cl : {1, 2, 4}) {
+        for (int64_t k = 0; k < n; ++k) {
+            const int32_t a = idx[k];
+            if (cl == 1) LDW_REQUIRE(a >= 0 && a < c->L, LDW_ERR_ARG, "SNP index %d out of range 0..%lld", a, (long long)c->L - 1);
+            const int nr = c->h_row0[a + 1] - c->h_row0[a];
+            const int mine = nr <= 1 ? 1 : (nr == 2 ? 2 : 4);
+            if (mine != cl) continue;
+            S.lrow[k] = (int32_t)S.rowlist.size();
+            for (int q = 0; q < cl; ++q) {
+                S.rowlist.push_back(q < nr ? c->h_row0[a] + q : zero_row);
+                S.pos.push_back(q == 0 ? (int32_t)k : -1);
+            }
+        }
+        while (S.rowlist.size() % 32) {
+            S.rowlist.push_back(zero_row);
+            S.pos.push_back(-1);
+        }
+        S.cls.resize(S.rowlist.size() / 32, (uint8_t)cl);
     }
-    int64_t rp = ((int64_t)rowlist.size() + TILE - 1) / TILE * TILE;
+    int64_t rp = ((int64_t)S.rowlist.size() + TILE - 1) / TILE * TILE;
     if (rp == 0) rp = TILE;
     LDW_REQUIRE(rp < 2000000000LL, LDW_ERR_ARG, "block too large");
-    rowlist.resize((size_t)rp, (int32_t)c->R);  // padding rows point at the zero rows behind M
-    Rpad = (int)rp;
+    S.rowlist.resize((size_t)rp, zero_row);
+    S.pos.resize((size_t)rp, -1);
+    S.cls.resize((size_t)rp / 32, (uint8_t)1);
+    S.Rpad = (int)rp;
     return LDW_OK;
 }
 
@@ -840,18 +560,37 @@ bool same_list(const int32_t *a, int64_t na, const int32_t *b, int64_t nb) {
 
 // device pointers of one block's index structures
 struct DevPtrs {
-    const int32_t *idx_f, *idx_t, *rl_f, *rl_t, *lrow_f, *lrow_t, *perm;
+    const int32_t *idx_f, *idx_t, *rl_f, *rl_t, *lrow_f, *lrow_t, *perm, *pos_f, *pos_t;
+    const uint8_t *cls_f, *cls_t;
 };
 
+void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int quirk, const EmitArgs &E, const int64_t *G,
+                   EpiArgs &A) {
+    A.G = G;
+    A.RFpad = RFpad;
+    A.idx_f = D.idx_f;
+    A.lrow_f = D.lrow_f;
+    A.idx_t = D.idx_t;
+    A.lrow_t = D.lrow_t;
+    A.nf = (int)nf;
+    A.nt = (int)nt;
+    A.slot_meta = c->slot_meta.as<uint32_t>();
+    A.slot_pfix = c->slot_pfix.as<int64_t>();
+    A.r = c->r.as<double>();
+    A.neff = c->neff;
+    A.scale = std::ldexp(1.0, -c->frac_bits);
+    A.quirk = quirk;
+    A.E = E;
+}
+
 // GEMM + epilogue (or the histogram engine) of one block into ctx->MIblk; with E.cols set, the short-range
-// scatter and the long-range histogram ride along.  ev[0..2] are recorded before the GEMM, between the two
-// kernels and after the epilogue.  Everything is asynchronous on ctx->stream.
+// scatter and the long-range histogram ride along.  Everything is asynchronous.
 // stage events per block: [0] GEMM start, [1] GEMM end (GEMM stream); [4] epilogue start, [2] epilogue end, [3] selection
 // end (main stream).  The GEMM of block b+1 runs beside the epilogue and selection of block b, so the stage times overlap.
 constexpr int EVB = 5;
 // which: 1 = GEMM only (on gstream, into Gbuf), 2 = epilogue only, 3 = both
 int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E,
-                    hipEvent_t *ev, int which = 3, ldw::DevBuf *Gb = nullptr, hipStream_t gstream = nullptr) {
+                    hipEvent_t *ev, int which, ldw::DevBuf *Gb, hipStream_t gstream, unsigned long long *ghist) {
     ldw::DevBuf &Gbuf = Gb ? *Gb : c->G;
     if (!gstream) gstream = c->stream;
     if (which == 1) {   // the GEMM of a block, possibly on its own stream so that it overlaps the previous block's tail
@@ -865,12 +604,10 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
     }
     const bool epilogue_only = which == 2;
     if (int rc = c->MIblk.reserve((size_t)nf * nt * 8)) return rc;
-    if (int rc = c->hist.reserve((size_t)NBINS * 8)) return rc;
     E.MI = c->MIblk.as<double>();
     E.nf = (int)nf;
     dim3 egrid((unsigned)((nf + 63) / 64), (unsigned)((nt + EPI_COLS - 1) / EPI_COLS));
     LDW_REQUIRE(egrid.y <= 65535u, LDW_ERR_ARG, "nt too large for the epilogue grid");
-    unsigned long long *ghist = c->hist.as<unsigned long long>();
     if (c->engine == LDW_ENGINE_HIST) {
         LDW_HIP(hipEventRecord(ev[0], c->stream));
         LDW_HIP(hipEventRecord(ev[1], c->stream));
@@ -893,21 +630,7 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
         LDW_HIP(hipEventRecord(ev[1], c->stream));
     }
     EpiArgs A;
-    A.G = Gbuf.as<int64_t>();
-    A.RFpad = RFpad;
-    A.idx_f = D.idx_f;
-    A.lrow_f = D.lrow_f;
-    A.idx_t = D.idx_t;
-    A.lrow_t = D.lrow_t;
-    A.nf = (int)nf;
-    A.nt = (int)nt;
-    A.slot_meta = c->slot_meta.as<uint32_t>();
-    A.slot_pfix = c->slot_pfix.as<int64_t>();
-    A.r = c->r.as<double>();
-    A.neff = c->neff;
-    A.scale = std::ldexp(1.0, -c->frac_bits);
-    A.quirk = quirk;
-    A.E = E;
+    fill_epi_args(c, D, nf, nt, RFpad, quirk, E, Gbuf.as<int64_t>(), A);
     if (which == 2) LDW_HIP(hipEventRecord(ev[4], c->stream));
     hipLaunchKernelGGL(k_mi_epilogue, egrid, dim3(256), 0, c->stream, A, D.perm, ghist);
     LDW_HIP(hipGetLastError());
@@ -929,30 +652,37 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     if (int rc = ensure_rows(c)) return rc;
     LDW_REQUIRE(nf > 0 && nt > 0, LDW_ERR_ARG, "empty block (nf=%lld nt=%lld)", (long long)nf, (long long)nt);
     LDW_REQUIRE(nf <= 1000000 && nt <= 1000000, LDW_ERR_ARG, "block side too long");
-    std::vector<int32_t> vf(from_idx, from_idx + nf), vt(to_idx, to_idx + nt), rl_f, rl_t, lr_f, lr_t, perm((size_t)nf);
-    int RFpad = 0, RTpad = 0;
-    if (int rc = build_side(c, from_idx, nf, rl_f, lr_f, RFpad)) return rc;
-    if (int rc = build_side(c, to_idx, nt, rl_t, lr_t, RTpad)) return rc;
+    std::vector<int32_t> vf(from_idx, from_idx + nf), vt(to_idx, to_idx + nt), perm((size_t)nf);
+    SideLists SF, ST;
+    if (int rc = build_side(c, from_idx, nf, SF)) return rc;
+    if (int rc = build_side(c, to_idx, nt, ST)) return rc;
     build_perm(c, from_idx, nf, perm.data());
     if (int rc = upload_i32(c, c->idx_f, vf)) return rc;
     if (int rc = upload_i32(c, c->idx_t, vt)) return rc;
-    if (int rc = upload_i32(c, c->rowlist_f, rl_f)) return rc;
-    if (int rc = upload_i32(c, c->rowlist_t, rl_t)) return rc;
-    if (int rc = upload_i32(c, c->lrow_f, lr_f)) return rc;
-    if (int rc = upload_i32(c, c->lrow_t, lr_t)) return rc;
+    if (int rc = upload_i32(c, c->rowlist_f, SF.rowlist)) return rc;
+    if (int rc = upload_i32(c, c->rowlist_t, ST.rowlist)) return rc;
+    if (int rc = upload_i32(c, c->lrow_f, SF.lrow)) return rc;
+    if (int rc = upload_i32(c, c->lrow_t, ST.lrow)) return rc;
     if (int rc = upload_i32(c, c->perm_f, perm)) return rc;
+    if (int rc = c->hist[0].reserve((size_t)NBINS * 8)) return rc;
     LDW_HIP(hipStreamSynchronize(c->stream));  // pageable H2D copies are complete only after a sync
     DevPtrs D{c->idx_f.as<int32_t>(), c->idx_t.as<int32_t>(), c->rowlist_f.as<int32_t>(), c->rowlist_t.as<int32_t>(),
-              c->lrow_f.as<int32_t>(), c->lrow_t.as<int32_t>(), c->perm_f.as<int32_t>()};
+              c->lrow_f.as<int32_t>(), c->lrow_t.as<int32_t>(), c->perm_f.as<int32_t>(), nullptr, nullptr, nullptr, nullptr};
     E.write_dense = 1;
     E.spec_B = -1;
-    return launch_block_mi(c, D, nf, nt, RFpad, RTpad, quirk, E, c->ev);
+    // a symmetric block (same list on both sides) may be asked for in full: the GEMM then computes every tile
+    return launch_block_mi(c, D, nf, nt, SF.Rpad, ST.Rpad, quirk, E, c->ev, 3, nullptr, nullptr, c->hist[0].as<unsigned long long>());
 }
 
 int ensure_links_capacity(ldw_ctx *c, int64_t sr_rows, int64_t lr_rows) {
+    // the fused kernels of earlier blocks write the short-range table on the GEMM stream: a reallocation (rare: the
+    // all-pairs driver sizes the table up front) waits for them and is complete before anything else is queued
+    const bool grow_sr = (size_t)sr_rows * 8 > c->sr_mi.cap || (size_t)sr_rows * 4 > c->sr_a.cap || (size_t)sr_rows * 4 > c->sr_b.cap;
+    if (grow_sr && c->gemm_stream) LDW_HIP(hipStreamSynchronize(c->gemm_stream));
     if (int rc = c->sr_a.reserve_keep((size_t)sr_rows * 4, (size_t)c->n_sr * 4, c->stream)) return rc;
     if (int rc = c->sr_b.reserve_keep((size_t)sr_rows * 4, (size_t)c->n_sr * 4, c->stream)) return rc;
     if (int rc = c->sr_mi.reserve_keep((size_t)sr_rows * 8, (size_t)c->n_sr * 8, c->stream)) return rc;
+    if (grow_sr) LDW_HIP(hipStreamSynchronize(c->stream));
     if (int rc = c->lr_a.reserve_keep((size_t)lr_rows * 4, (size_t)c->n_lr * 4, c->stream)) return rc;
     if (int rc = c->lr_b.reserve_keep((size_t)lr_rows * 4, (size_t)c->n_lr * 4, c->stream)) return rc;
     if (int rc = c->lr_mi.reserve_keep((size_t)lr_rows * 8, (size_t)c->n_lr * 8, c->stream)) return rc;
@@ -962,28 +692,34 @@ int ensure_links_capacity(ldw_ctx *c, int64_t sr_rows, int64_t lr_rows) {
 // layout of ctx->small during link selection
 struct SmallLayout {
     int64_t *lr_count;   // running number of kept long-range rows (device side)
-    ldw::PickOut *pick;
+    ldw::PickOut *pick[2];   // one per pipeline slot
     int64_t *stats_i;    // [capacity][3]
     double *stats_d;     // [capacity]
 };
 
+constexpr size_t PICK_STRIDE = ((sizeof(ldw::PickOut) + 63) / 64) * 64;
+
 void links_layout(ldw_ctx *c, SmallLayout &sl) {
     char *base = c->small.as<char>();
     sl.lr_count = reinterpret_cast<int64_t *>(base);
-    sl.pick = reinterpret_cast<ldw::PickOut *>(base + 64);
-    sl.stats_i = reinterpret_cast<int64_t *>(base + 64 + ((sizeof(ldw::PickOut) + 63) / 64) * 64);
+    sl.pick[0] = reinterpret_cast<ldw::PickOut *>(base + 64);
+    sl.pick[1] = reinterpret_cast<ldw::PickOut *>(base + 64 + PICK_STRIDE);
+    sl.stats_i = reinterpret_cast<int64_t *>(base + 64 + 2 * PICK_STRIDE);
     sl.stats_d = reinterpret_cast<double *>(sl.stats_i + c->blk_capacity * 3);
 }
 
-// ---- one block of the link loop in three phases so that the host work of block i+1 overlaps the GPU work of
-// ---- block i:  prep (pure host, into pinned memory)  ->  submit (upload + kernels up to the candidate gather)
-// ---- ->  finish (the one host round trip: candidate count, then sorts / threshold / append)
+// ---- one block of the link loop in phases so that the host work of block i+1 and (fused path) its whole kernel
+// ---- overlap the selection of block i:
+// ----   prep     pure host, into pinned memory
+// ----   submit_a upload; unfused: the GEMM on the GEMM stream | fused: GEMM + epilogue + bucket pick + copy-back of the pick
+// ----   submit_b unfused: epilogue + bucket pick + copy-back on the main stream | fused: nothing
+// ----   finish   the one host round trip (candidate count), then sorts / threshold / append on the main stream
 struct HostBlock {
     int64_t nf = 0, nt = 0, n_sr_blk = 0, n_lr_total = 0, blk_no = 0;
     int RFpad = 0, RTpad = 0, slot = 0;
-    bool diag = false;
-    size_t o_idx_f = 0, o_idx_t = 0, o_rl_f = 0, o_rl_t = 0, o_lrow_f = 0, o_lrow_t = 0, o_perm = 0, o_cols = 0, total = 0;
-    // set by submit_block, used by the fallback of finish_block
+    bool diag = false, fused = false, submitted = false;
+    size_t o_idx_f = 0, o_idx_t = 0, o_rl_f = 0, o_rl_t = 0, o_lrow_f = 0, o_lrow_t = 0, o_perm = 0, o_cols = 0, o_pos_f = 0,
+           o_pos_t = 0, o_cls_f = 0, o_cls_t = 0, total = 0;
     DevPtrs D{};
     EmitArgs E{};
     int spec_B = -1;
@@ -998,14 +734,17 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
         LDW_REQUIRE(from_idx[k] >= 0 && from_idx[k] < c->L, LDW_ERR_ARG, "SNP index %d out of range", from_idx[k]);
     for (int64_t k = 0; k < nt; ++k)
         LDW_REQUIRE(to_idx[k] >= 0 && to_idx[k] < c->L, LDW_ERR_ARG, "SNP index %d out of range", to_idx[k]);
+    hb = HostBlock();
     hb.nf = nf;
     hb.nt = nt;
     hb.slot = slot;
     hb.blk_no = blk_no;
     hb.diag = same_list(from_idx, nf, to_idx, nt);
-    std::vector<int32_t> rl_f, rl_t, lr_f, lr_t;
-    if (int rc = build_side(c, from_idx, nf, rl_f, lr_f, hb.RFpad)) return rc;
-    if (int rc = build_side(c, to_idx, nt, rl_t, lr_t, hb.RTpad)) return rc;
+    SideLists SF, ST;
+    if (int rc = build_side(c, from_idx, nf, SF)) return rc;
+    if (int rc = build_side(c, to_idx, nt, ST)) return rc;
+    hb.RFpad = SF.Rpad;
+    hb.RTpad = ST.Rpad;
     std::vector<ColInfo> cols;
     if (int rc = build_cols(c, from_idx, nf, to_idx, nt, hb.diag, p->sr_dist, cols, hb.n_sr_blk)) return rc;
     hb.n_lr_total = (hb.diag ? nf * (nf - 1) / 2 : nf * nt - std::min(nf, nt)) - hb.n_sr_blk;
@@ -1013,12 +752,16 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     size_t o = 0;
     hb.o_idx_f = o; o = al(o + (size_t)nf * 4);
     hb.o_idx_t = o; o = al(o + (size_t)nt * 4);
-    hb.o_rl_f = o; o = al(o + rl_f.size() * 4);
-    hb.o_rl_t = o; o = al(o + rl_t.size() * 4);
+    hb.o_rl_f = o; o = al(o + SF.rowlist.size() * 4);
+    hb.o_rl_t = o; o = al(o + ST.rowlist.size() * 4);
     hb.o_lrow_f = o; o = al(o + (size_t)nf * 4);
     hb.o_lrow_t = o; o = al(o + (size_t)nt * 4);
     hb.o_perm = o; o = al(o + (size_t)nf * 4);
     hb.o_cols = o; o = al(o + cols.size() * sizeof(ColInfo));
+    hb.o_pos_f = o; o = al(o + SF.pos.size() * 4);
+    hb.o_pos_t = o; o = al(o + ST.pos.size() * 4);
+    hb.o_cls_f = o; o = al(o + SF.cls.size());
+    hb.o_cls_t = o; o = al(o + ST.cls.size());
     hb.total = o;
     if (c->pin_cap[slot] < o) {
         if (c->pin[slot]) LDW_HIP(hipHostFree(c->pin[slot]));
@@ -1030,12 +773,16 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     char *b = static_cast<char *>(c->pin[slot]);
     memcpy(b + hb.o_idx_f, from_idx, (size_t)nf * 4);
     memcpy(b + hb.o_idx_t, to_idx, (size_t)nt * 4);
-    memcpy(b + hb.o_rl_f, rl_f.data(), rl_f.size() * 4);
-    memcpy(b + hb.o_rl_t, rl_t.data(), rl_t.size() * 4);
-    memcpy(b + hb.o_lrow_f, lr_f.data(), (size_t)nf * 4);
-    memcpy(b + hb.o_lrow_t, lr_t.data(), (size_t)nt * 4);
+    memcpy(b + hb.o_rl_f, SF.rowlist.data(), SF.rowlist.size() * 4);
+    memcpy(b + hb.o_rl_t, ST.rowlist.data(), ST.rowlist.size() * 4);
+    memcpy(b + hb.o_lrow_f, SF.lrow.data(), (size_t)nf * 4);
+    memcpy(b + hb.o_lrow_t, ST.lrow.data(), (size_t)nt * 4);
     build_perm(c, from_idx, nf, reinterpret_cast<int32_t *>(b + hb.o_perm));
     memcpy(b + hb.o_cols, cols.data(), cols.size() * sizeof(ColInfo));
+    memcpy(b + hb.o_pos_f, SF.pos.data(), SF.pos.size() * 4);
+    memcpy(b + hb.o_pos_t, ST.pos.data(), ST.pos.size() * 4);
+    memcpy(b + hb.o_cls_f, SF.cls.data(), SF.cls.size());
+    memcpy(b + hb.o_cls_t, ST.cls.data(), ST.cls.size());
     return LDW_OK;
 }
 
@@ -1046,54 +793,21 @@ int launch_gather(ldw_ctx *c, const HostBlock &hb, const EmitArgs &E, const Smal
     S.nf = (int)hb.nf;
     S.nt = (int)hb.nt;
     S.lower_only = E.lower_only;
-    hipLaunchKernelGGL(k_lr_gather, dim3((unsigned)((hb.nt + 15) / 16)), dim3(256), 0, c->stream, S, sl.pick,
-                       c->cand_key.as<uint64_t>(), c->cand_val.as<uint64_t>());
+    hipLaunchKernelGGL(k_lr_gather, dim3((unsigned)((hb.nt + 15) / 16)), dim3(256), 0, c->stream, S, sl.pick[hb.slot],
+                       c->cand_key[hb.slot].as<uint64_t>(), c->cand_val[hb.slot].as<uint64_t>());
     LDW_HIP(hipGetLastError());
     return LDW_OK;
 }
 
-// First half of a block: upload its index structures and run the co-occurrence GEMM into this slot's G buffer on
-// the GEMM stream.  Nothing here touches what the previous block's epilogue / selection still uses, so the GEMM of
-// block b+1 overlaps the tail of block b (epilogue wind-down, the launch-bound selection kernels, the host round trip).
-int submit_gemm(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p) {
+// what the emission of a block's pairs needs (short-range table, candidate list of this slot)
+int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl, int spec_B) {
     const int s = hb.slot;
-    if (int rc = c->dstage[s].reserve(hb.total)) return rc;
-    // the device image and the G buffer of this slot were last read by the block two steps back
-    if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_done[s], 0));
-    LDW_HIP(hipMemcpyAsync(c->dstage[s].p, c->pin[s], hb.total, hipMemcpyHostToDevice, c->copy_stream));
-    LDW_HIP(hipEventRecord(c->ev_up[s], c->copy_stream));
-    const char *d = c->dstage[s].as<char>();
-    auto I = [&](size_t off) { return reinterpret_cast<const int32_t *>(d + off); };
-    hb.D = DevPtrs{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm)};
-    if (c->engine != LDW_ENGINE_MFMA) return LDW_OK;
-    hipStream_t gs = c->overlap ? c->gemm_stream : c->stream;   // overlap off: the stages of all blocks run back to back
-    LDW_HIP(hipStreamWaitEvent(gs, c->ev_up[s], 0));
-    if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(gs, c->ev_done[s], 0));
-    EmitArgs E;
-    memset(&E, 0, sizeof(E));
-    E.lower_only = hb.diag ? 1 : 0;
-    if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, &c->ev_pool[(size_t)hb.blk_no * EVB], 1,
-                                 s ? &c->G2 : &c->G, gs))
-        return rc;
-    LDW_HIP(hipEventRecord(c->ev_gemm[s], gs));
-    return LDW_OK;
-}
-
-// Second half: epilogue, histogram pick and the copy-back of the pick on the main stream.
-int submit_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
-    const int s = hb.slot;
-    LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_up[s], 0));
-    if (c->engine == LDW_ENGINE_MFMA) LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_gemm[s], 0));
-    const char *d = c->dstage[s].as<char>();
-    const DevPtrs D = hb.D;
     const bool do_lr = !p->sr_only;
-    const int64_t sr_add = p->keep_sr ? hb.n_sr_blk : 0;
-    if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr)) return rc;
-    if (int rc = c->hist.reserve((size_t)NBINS * 8)) return rc;
-    LDW_HIP(hipMemsetAsync(c->hist.p, 0, (size_t)NBINS * 8, c->stream));
+    const char *d = c->dstage[s].as<char>();
     EmitArgs E;
     memset(&E, 0, sizeof(E));
     E.cols = reinterpret_cast<const ColInfo *>(d + hb.o_cols);
+    E.nf = (int)hb.nf;
     E.lower_only = hb.diag ? 1 : 0;
     E.keep_sr = p->keep_sr ? 1 : 0;
     E.do_lr = do_lr ? 1 : 0;
@@ -1101,121 +815,237 @@ int submit_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
     E.sr_a = c->sr_a.as<int32_t>();
     E.sr_b = c->sr_b.as<int32_t>();
     E.sr_mi = c->sr_mi.as<double>();
-    // Long-range candidates: with a bucket guess from the previous block the epilogue appends them itself and the
+    // Long-range candidates: with a bucket guess from an earlier block the epilogue appends them itself and the
     // dense MI block is neither written nor re-read; without one (first block, histogram engine) the dense block
     // is written and k_lr_gather collects them once the true bucket is known.
-    hb.spec_B = (do_lr && c->engine == LDW_ENGINE_MFMA) ? c->spec_B_next[hb.diag ? 1 : 0] : -1;
+    hb.spec_B = spec_B;
     const size_t cap = (size_t)hb.nf * hb.nt;  // worst case: every pair of the block
     if (do_lr) {
-        if (int rc = c->cand_key.reserve(cap * 8)) return rc;
-        if (int rc = c->cand_val.reserve(cap * 8)) return rc;
+        if (int rc = c->cand_key[s].reserve(cap * 8)) return rc;
+        if (int rc = c->cand_val[s].reserve(cap * 8)) return rc;
     }
     E.write_dense = hb.spec_B < 0 ? 1 : 0;
     E.spec_B = hb.spec_B;
     E.spec_lo = hb.spec_B > 0 ? bucket_lo(hb.spec_B) : -1e300;
     E.any_sr = hb.n_sr_blk > 0 ? 1 : 0;
-    E.n_cand = &sl.pick->n_cand;
-    E.ckey = c->cand_key.as<uint64_t>();
-    E.cval = c->cand_val.as<uint64_t>();
+    E.n_cand = &sl.pick[s]->n_cand;
+    E.ckey = c->cand_key[s].as<uint64_t>();
+    E.cval = c->cand_val[s].as<uint64_t>();
+    // fp32 screen: only where a pair can be dismissed at all (speculative mode with a positive lower edge)
+    E.scr_mode = (hb.spec_B > 0 || !do_lr) && !E.write_dense ? c->screen : 0;
+    int bits = 0;
+    while (bits < 62 && (c->total_fixed >> bits) != 0) ++bits;
+    E.scr_shift = bits > 31 ? bits - 31 : 0;
+    E.scr_scale = (float)std::ldexp(1.0, E.scr_shift - c->frac_bits);
+    E.scr_viol = reinterpret_cast<unsigned long long *>(sl.lr_count + 1);
     hb.E = E;
-    LDW_HIP(hipMemsetAsync(sl.pick, 0, sizeof(ldw::PickOut), c->stream));
+    return LDW_OK;
+}
+
+// bucket pick + copy-back of the pick of slot s on `st`
+int launch_pick(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl, hipStream_t st) {
+    const int s = hb.slot;
+    if (!p->sr_only) {
+        hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, st, c->hist[s].as<unsigned long long>(), p->lr_retain_links,
+                           p->lr_links_approx, hb.spec_B, (long long)hb.n_lr_total, sl.pick[s]);
+        LDW_HIP(hipGetLastError());
+    }
+    return LDW_OK;
+}
+
+// First phase: upload the block's index structures, then
+//   unfused: the co-occurrence GEMM into this slot's G buffer on the GEMM stream.  Nothing there touches what the
+//            previous block's epilogue / selection still uses, so it overlaps the tail of block b;
+//   fused:   GEMM + epilogue in one kernel, the bucket pick and the copy-back of the pick, all on the GEMM stream:
+//            the whole block overlaps the selection (sorts, host round trip) of the previous one.
+int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
+    const int s = hb.slot;
+    if (int rc = c->dstage[s].reserve(hb.total)) return rc;
+    // the device image and the per-slot buffers (G, histogram, pick, candidates) were last used by the block two steps back
+    if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_done[s], 0));
+    LDW_HIP(hipMemcpyAsync(c->dstage[s].p, c->pin[s], hb.total, hipMemcpyHostToDevice, c->copy_stream));
+    LDW_HIP(hipEventRecord(c->ev_up[s], c->copy_stream));
+    const char *d = c->dstage[s].as<char>();
+    auto I = [&](size_t off) { return reinterpret_cast<const int32_t *>(d + off); };
+    auto B = [&](size_t off) { return reinterpret_cast<const uint8_t *>(d + off); };
+    hb.D = DevPtrs{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm),
+                   I(hb.o_pos_f), I(hb.o_pos_t), B(hb.o_cls_f), B(hb.o_cls_t)};
+    hb.submitted = true;
+    if (c->engine != LDW_ENGINE_MFMA) return LDW_OK;
+    hipStream_t gs = c->overlap ? c->gemm_stream : c->stream;   // overlap off: the stages of all blocks run back to back
+    LDW_HIP(hipStreamWaitEvent(gs, c->ev_up[s], 0));
+    if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(gs, c->ev_done[s], 0));
     hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
-    if (int rc = launch_block_mi(c, D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, ev, c->engine == LDW_ENGINE_MFMA ? 2 : 3,
-                                 s ? &c->G2 : &c->G))
+    const bool do_lr = !p->sr_only;
+    const int guess = do_lr ? c->spec_B_next[hb.diag ? 1 : 0] : 0;
+    hb.fused = c->fused && c->nlimbs <= 5 && (!do_lr || guess >= 0);
+    ++(hb.fused ? c->fused_blocks : c->unfused_blocks);
+    if (!hb.fused) {
+        EmitArgs E;
+        memset(&E, 0, sizeof(E));
+        E.lower_only = hb.diag ? 1 : 0;
+        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, ev, 1, s ? &c->G2 : &c->G, gs, nullptr))
+            return rc;
+        LDW_HIP(hipEventRecord(c->ev_gemm[s], gs));
+        return LDW_OK;
+    }
+    const int64_t sr_add = p->keep_sr ? hb.n_sr_blk : 0;
+    if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr)) return rc;
+    if (int rc = c->hist[s].reserve((size_t)NBINS * 8)) return rc;
+    if (int rc = make_emit_args(c, hb, p, sl, do_lr ? guess : -1)) return rc;
+    c->n_sr += sr_add;
+    LDW_HIP(hipMemsetAsync(c->hist[s].p, 0, (size_t)NBINS * 8, gs));
+    LDW_HIP(hipMemsetAsync(sl.pick[s], 0, sizeof(ldw::PickOut), gs));
+    FusedArgs F;
+    F.Mbits = c->Mbits.as<uint64_t>();
+    F.KW = c->KW;
+    F.Kpad = c->KW * 64;
+    F.rowlist_t = hb.D.rl_t;
+    F.rowlist_f = hb.D.rl_f;
+    F.digits = c->digits.as<int8_t>();
+    F.pos_f = hb.D.pos_f;
+    F.pos_t = hb.D.pos_t;
+    F.cls_f = hb.D.cls_f;
+    F.cls_t = hb.D.cls_t;
+    F.ghist = c->hist[s].as<unsigned long long>();
+    {
+        const char *e = getenv("LDW_FUSED_DEBUG");
+        F.dbg = e ? atoi(e) : 0;
+        if (F.dbg == 2) F.KW = 2;   // K loop of one short chunk: what is left is the epilogue
+    }
+    fill_epi_args(c, hb.D, hb.nf, hb.nt, hb.RFpad, p->quirk_mode, hb.E, nullptr, F.A);
+    LDW_HIP(hipEventRecord(ev[0], gs));
+    if (int rc = launch_fused(c, F, hb.RFpad, hb.RTpad, c->nlimbs, gs)) return rc;
+    LDW_HIP(hipEventRecord(ev[1], gs));
+    LDW_HIP(hipEventRecord(ev[4], gs));
+    LDW_HIP(hipEventRecord(ev[2], gs));
+    if (int rc = launch_pick(c, hb, p, sl, gs)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->pin_pick[s], sl.pick[s], sizeof(ldw::PickOut), hipMemcpyDeviceToHost, gs));
+    LDW_HIP(hipEventRecord(c->ev_pick[s], gs));
+    LDW_HIP(hipEventRecord(c->ev_gemm[s], gs));
+    return LDW_OK;
+}
+
+// Second phase (unfused path only): epilogue, histogram pick and the copy-back of the pick on the main stream.
+int submit_b(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
+    if (hb.fused) return LDW_OK;
+    const int s = hb.slot;
+    LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_up[s], 0));
+    if (c->engine == LDW_ENGINE_MFMA) LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_gemm[s], 0));
+    const bool do_lr = !p->sr_only;
+    const int64_t sr_add = p->keep_sr ? hb.n_sr_blk : 0;
+    if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr)) return rc;
+    if (int rc = c->hist[s].reserve((size_t)NBINS * 8)) return rc;
+    LDW_HIP(hipMemsetAsync(c->hist[s].p, 0, (size_t)NBINS * 8, c->stream));
+    if (int rc = make_emit_args(c, hb, p, sl, (do_lr && c->engine == LDW_ENGINE_MFMA) ? c->spec_B_next[hb.diag ? 1 : 0] : -1)) return rc;
+    LDW_HIP(hipMemsetAsync(sl.pick[s], 0, sizeof(ldw::PickOut), c->stream));
+    hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
+    if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, c->engine == LDW_ENGINE_MFMA ? 2 : 3,
+                                 s ? &c->G2 : &c->G, nullptr, c->hist[s].as<unsigned long long>()))
         return rc;
     c->n_sr += sr_add;
-    if (do_lr) {
-        hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, c->stream, c->hist.as<unsigned long long>(),
-                           p->lr_retain_links, p->lr_links_approx, hb.spec_B, (long long)hb.n_lr_total, sl.pick);
-        LDW_HIP(hipGetLastError());
-        if (hb.spec_B < 0)
-            if (int rc = launch_gather(c, hb, E, sl)) return rc;
-    }
-    LDW_HIP(hipMemcpyAsync(c->pin_pick, sl.pick, sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
-    // exact number of long-range rows kept by all EARLIER blocks (this block's append has not run yet)
-    LDW_HIP(hipMemcpyAsync(static_cast<char *>(c->pin_pick) + sizeof(ldw::PickOut), sl.lr_count, 8, hipMemcpyDeviceToHost, c->stream));
-    LDW_HIP(hipEventRecord(c->ev_pick, c->stream));
+    if (int rc = launch_pick(c, hb, p, sl, c->stream)) return rc;
+    if (do_lr && hb.spec_B < 0)
+        if (int rc = launch_gather(c, hb, hb.E, sl)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->pin_pick[s], sl.pick[s], sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipEventRecord(c->ev_pick[s], c->stream));
     return LDW_OK;
 }
 
 int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
     const bool do_lr = !p->sr_only;
+    const int s = hb.slot;
     // ---- the one host round trip of the block: the candidate count sizes the sorts ----
-    LDW_HIP(hipEventSynchronize(c->ev_pick));
-    ldw::PickOut *hp = static_cast<ldw::PickOut *>(c->pin_pick);
+    LDW_HIP(hipEventSynchronize(c->ev_pick[s]));
+    if (hb.fused) LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_gemm[s], 0));   // selection runs on the main stream
+    ldw::PickOut *hp = static_cast<ldw::PickOut *>(c->pin_pick[s]);
     if (do_lr && hb.spec_B >= 0 && hp->n > 0 && !hp->spec_ok) {
-        // the bucket guess was above the true bucket: redo the epilogue non-speculatively (G is still intact, the
-        // short-range rows are already final): full histogram, dense store, then pick and gather with the true bucket
+        // the bucket guess was above the true bucket: redo the epilogue non-speculatively (the short-range rows are
+        // already final): full histogram, dense store, then pick and gather with the true bucket.  The unfused path
+        // still has G; the fused one has to run the GEMM again.
         EmitArgs E = hb.E;
         E.write_dense = 1;
         E.spec_B = -1;
         E.keep_sr = 0;
-        LDW_HIP(hipMemsetAsync(c->hist.p, 0, (size_t)NBINS * 8, c->stream));
-        LDW_HIP(hipMemsetAsync(sl.pick, 0, sizeof(ldw::PickOut), c->stream));
+        E.scr_mode = 0;   // every pair goes into the histogram
+        hb.spec_B = -1;
+        LDW_HIP(hipMemsetAsync(c->hist[s].p, 0, (size_t)NBINS * 8, c->stream));
+        LDW_HIP(hipMemsetAsync(sl.pick[s], 0, sizeof(ldw::PickOut), c->stream));
         hipEvent_t dummy[5] = {c->ev[3], c->ev[3], c->ev[4], c->ev[3], c->ev[5]};   // keep the block's stage events as they are
-        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, dummy, 2, hb.slot ? &c->G2 : &c->G))
+        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, dummy, hb.fused ? 3 : 2, s ? &c->G2 : &c->G,
+                                     nullptr, c->hist[s].as<unsigned long long>()))
             return rc;
-        hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, c->stream, c->hist.as<unsigned long long>(),
-                           p->lr_retain_links, p->lr_links_approx, -1, 0LL, sl.pick);
-        LDW_HIP(hipGetLastError());
+        if (int rc = launch_pick(c, hb, p, sl, c->stream)) return rc;
         if (int rc = launch_gather(c, hb, E, sl)) return rc;
-        LDW_HIP(hipMemcpyAsync(c->pin_pick, sl.pick, sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipMemcpyAsync(c->pin_pick[s], sl.pick[s], sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
         LDW_HIP(hipStreamSynchronize(c->stream));
         ++c->spec_misses;
     }
-    if (do_lr && hp->n > 0) {  // next block's guess: a little below this block's bucket
-        // buckets are 0.5 % wide: guess ~5 % below the threshold of the last block of the same kind (diagonal blocks
-        // lose their closest pairs to the short-range table and sit ~8 % lower than off-diagonal ones)
-        const int margin = 10;
-        c->spec_B_next[hb.diag ? 1 : 0] = hp->B_true - margin > 0 ? hp->B_true - margin : 0;
+    if (do_lr && hp->n > 0) {  // guesses for later blocks: a little below this block's bucket
+        // buckets are 0.5 % wide: guess ~5 % below the threshold of the last block of the same kind.  Diagonal blocks
+        // lose their closest pairs to the short-range table and sit ~8 % (16 buckets) lower than off-diagonal ones:
+        // until a block of the other kind has been seen, its guess is derived from this one with a wider margin.
+        const int margin = 10, kind = hb.diag ? 1 : 0, other = kind ^ 1;
+        c->spec_B_next[kind] = hp->B_true - margin > 0 ? hp->B_true - margin : 0;
+        c->spec_seen[kind] = true;
+        if (!c->spec_seen[other]) {
+            const int g = hb.diag ? hp->B_true - margin : hp->B_true - 16 - 2 * margin;
+            c->spec_B_next[other] = g > 0 ? g : 0;
+        }
     }
     const int64_t m = do_lr ? (int64_t)hp->n_cand : 0;
-    {   // tighten the upper bound on the long-range row count: exact up to the previous block + this block's candidates
-        int64_t exact_before = 0;
-        memcpy(&exact_before, static_cast<char *>(c->pin_pick) + sizeof(ldw::PickOut), 8);
-        c->n_lr = exact_before;
+    if (c->lrc_recorded) {   // exact number of long-range rows kept by all EARLIER blocks
+        LDW_HIP(hipEventSynchronize(c->ev_lrc));
+        memcpy(&c->n_lr, c->pin_lrc, 8);
     }
     const int64_t nf = hb.nf;
-    const char *d = c->dstage[hb.slot].as<char>();
+    const char *d = c->dstage[s].as<char>();
     const int32_t *idx_f = reinterpret_cast<const int32_t *>(d + hb.o_idx_f), *idx_t = reinterpret_cast<const int32_t *>(d + hb.o_idx_t);
+    uint64_t *ck = c->cand_key[s].as<uint64_t>(), *cv = c->cand_val[s].as<uint64_t>();
     if (do_lr && m > 0) {
         LDW_REQUIRE(m < 2147483647LL, LDW_ERR_SIZE, "too many quantile candidates (%lld)", (long long)m);
         if (int rc = ensure_links_capacity(c, c->n_sr, c->n_lr + m)) return rc;
         if (int rc = c->cand_key2.reserve((size_t)m * 8)) return rc;
         if (int rc = c->cand_val2.reserve((size_t)m * 8)) return rc;
         size_t tmp_bytes = 0;
-        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->cand_key.as<uint64_t>(),
-                                                   c->cand_key2.as<uint64_t>(), c->cand_val.as<uint64_t>(),
+        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
                                                    c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
         if (int rc = c->scratch.reserve(tmp_bytes)) return rc;
-        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tmp_bytes, c->cand_key.as<uint64_t>(),
-                                                   c->cand_key2.as<uint64_t>(), c->cand_val.as<uint64_t>(),
+        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
                                                    c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
-        hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, c->cand_key2.as<uint64_t>(), sl.pick);
+        hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, c->cand_key2.as<uint64_t>(), sl.pick[s]);
         LDW_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_lr_mark, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), sl.pick,
-                           c->cand_key.as<uint64_t>(), c->cand_val.as<uint64_t>(), (long long)m);
+                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), sl.pick[s], ck, cv, (long long)m);
         LDW_HIP(hipGetLastError());
-        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tmp_bytes, c->cand_key.as<uint64_t>(),
-                                                   c->cand_key2.as<uint64_t>(), c->cand_val.as<uint64_t>(),
+        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
                                                    c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
         hipLaunchKernelGGL(k_lr_append, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), sl.pick, idx_f, idx_t, (int)nf,
+                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), sl.pick[s], idx_f, idx_t, (int)nf,
                            sl.lr_count, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), c->lr_mi.as<double>());
         LDW_HIP(hipGetLastError());
         c->n_lr += m;  // upper bound; the exact value is *lr_count
     } else if (do_lr) {
-        hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, c->cand_key.as<uint64_t>(), sl.pick);
+        hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, ck, sl.pick[s]);
         LDW_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_block_done, dim3(1), dim3(64), 0, c->stream, sl.pick, sl.lr_count, hb.n_sr_blk,
+    hipLaunchKernelGGL(k_block_done, dim3(1), dim3(64), 0, c->stream, sl.pick[s], sl.lr_count, hb.n_sr_blk,
                        sl.stats_i + hb.blk_no * 3, sl.stats_d + hb.blk_no);
     LDW_HIP(hipGetLastError());
+    LDW_HIP(hipMemcpyAsync(c->pin_lrc, sl.lr_count, 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipEventRecord(c->ev_lrc, c->stream));
+    c->lrc_recorded = true;
     LDW_HIP(hipEventRecord(c->ev_pool[(size_t)hb.blk_no * EVB + 3], c->stream));
-    LDW_HIP(hipEventRecord(c->ev_done[hb.slot], c->stream));
-    c->done_recorded[hb.slot] = true;
+    LDW_HIP(hipEventRecord(c->ev_done[s], c->stream));
+    c->done_recorded[s] = true;
     return LDW_OK;
+}
+
+// whether the next block can be submitted before the current one is finished: the fused path needs a bucket guess
+bool can_submit_early(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p) {
+    if (!c->overlap) return false;
+    if (c->engine != LDW_ENGINE_MFMA || !c->fused || c->nlimbs > 5 || p->sr_only) return true;
+    return c->spec_B_next[hb.diag ? 1 : 0] >= 0;
 }
 
 }  // namespace
@@ -1265,12 +1095,12 @@ int ldw_joint_tables(ldw_ctx *c, const int32_t *pair_a, const int32_t *pair_b, i
                        c->counts.as<int32_t>(), c->slot_meta.as<uint32_t>(), c->L, d_cmarg.as<int64_t>());
     for (int64_t p0 = 0; p0 < np && rc == LDW_OK; p0 += CH) {
         const int64_t n = std::min(CH, np - p0);
-        std::vector<int32_t> rl_f, rl_t, lr_f, lr_t;
-        int RFpad = 0, RTpad = 0;
-        if ((rc = build_side(c, pair_a + p0, n, rl_f, lr_f, RFpad))) break;
-        if ((rc = build_side(c, pair_b + p0, n, rl_t, lr_t, RTpad))) break;
-        if ((rc = upload_i32(c, c->rowlist_f, rl_f)) || (rc = upload_i32(c, c->rowlist_t, rl_t)) ||
-            (rc = upload_i32(c, c->lrow_f, lr_f)) || (rc = upload_i32(c, c->lrow_t, lr_t)))
+        SideLists SF, ST;
+        if ((rc = build_side(c, pair_a + p0, n, SF))) break;
+        if ((rc = build_side(c, pair_b + p0, n, ST))) break;
+        const int RFpad = SF.Rpad, RTpad = ST.Rpad;
+        if ((rc = upload_i32(c, c->rowlist_f, SF.rowlist)) || (rc = upload_i32(c, c->rowlist_t, ST.rowlist)) ||
+            (rc = upload_i32(c, c->lrow_f, SF.lrow)) || (rc = upload_i32(c, c->lrow_t, ST.lrow)))
             break;
         std::vector<int32_t> vf(pair_a + p0, pair_a + p0 + n), vt(pair_b + p0, pair_b + p0 + n);
         if ((rc = upload_i32(c, c->idx_f, vf)) || (rc = upload_i32(c, c->idx_t, vt))) break;
@@ -1299,7 +1129,7 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(nblocks_capacity > 0, LDW_ERR_ARG, "ldw_links_begin: capacity must be positive");
     if (int rc = ensure_rows(c)) return rc;  // uses ctx->small for staging; link bookkeeping takes it over below
-    const size_t need = 64 + ((sizeof(ldw::PickOut) + 63) / 64) * 64 + (size_t)nblocks_capacity * 32 + 64;
+    const size_t need = 64 + 2 * PICK_STRIDE + (size_t)nblocks_capacity * 32 + 64;
     if (int rc = c->small.reserve(need)) return rc;
     LDW_HIP(hipMemsetAsync(c->small.p, 0, need, c->stream));
     if (!c->copy_stream) {
@@ -1308,8 +1138,12 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
             LDW_HIP(hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming));
             LDW_HIP(hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
         }
-        LDW_HIP(hipEventCreateWithFlags(&c->ev_pick, hipEventDisableTiming));
-        LDW_HIP(hipHostMalloc(&c->pin_pick, sizeof(ldw::PickOut) + 64, hipHostMallocDefault));
+        for (int k = 0; k < 2; ++k) {
+            LDW_HIP(hipEventCreateWithFlags(&c->ev_pick[k], hipEventDisableTiming));
+            LDW_HIP(hipHostMalloc(&c->pin_pick[k], sizeof(ldw::PickOut) + 64, hipHostMallocDefault));
+        }
+        LDW_HIP(hipEventCreateWithFlags(&c->ev_lrc, hipEventDisableTiming));
+        LDW_HIP(hipHostMalloc(&c->pin_lrc, 64, hipHostMallocDefault));
         LDW_HIP(hipStreamCreateWithFlags(&c->gemm_stream, hipStreamNonBlocking));
         for (int k = 0; k < 2; ++k) LDW_HIP(hipEventCreateWithFlags(&c->ev_gemm[k], hipEventDisableTiming));
     }
@@ -1322,6 +1156,7 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
         c->ev_pool.push_back(e);
     }
     c->done_recorded[0] = c->done_recorded[1] = false;
+    c->lrc_recorded = false;
     c->n_sr = 0;
     c->n_lr = 0;
     c->stats.clear();
@@ -1349,8 +1184,8 @@ int ldw_mi_block_links(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const in
     links_layout(c, sl);
     HostBlock hb;
     if (int rc = prep_block(c, from_idx, nf, to_idx, nt, p, (int)(c->blk_cursor & 1), c->blk_cursor, hb)) return rc;
-    if (int rc = submit_gemm(c, hb, p)) return rc;
-    if (int rc = submit_block(c, hb, p, sl)) return rc;
+    if (int rc = submit_a(c, hb, p, sl)) return rc;
+    if (int rc = submit_b(c, hb, p, sl)) return rc;
     if (int rc = finish_block(c, hb, p, sl)) return rc;
     ++c->blk_cursor;
     return LDW_OK;
@@ -1365,13 +1200,16 @@ int ldw_links_end(ldw_ctx *c) {
     int64_t h_lr = 0;
     std::vector<int64_t> si((size_t)nb * 3 + 1);
     std::vector<double> sd((size_t)nb + 1);
+    int64_t h_viol = 0;
     LDW_HIP(hipMemcpyAsync(&h_lr, sl.lr_count, 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(&h_viol, sl.lr_count + 1, 8, hipMemcpyDeviceToHost, c->stream));
     if (nb > 0) {
         LDW_HIP(hipMemcpyAsync(si.data(), sl.stats_i, (size_t)nb * 24, hipMemcpyDeviceToHost, c->stream));
         LDW_HIP(hipMemcpyAsync(sd.data(), sl.stats_d, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
     }
     LDW_HIP(hipStreamSynchronize(c->stream));
     c->n_lr = h_lr;
+    c->screen_violations += h_viol;
     c->stats.resize((size_t)nb);
     for (int64_t b = 0; b < nb; ++b) {
         c->stats[b].n_lr_total = si[b * 3 + 0];
@@ -1425,24 +1263,25 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         }
         if (int rc = ensure_links_capacity(c, total_sr, 0)) return rc;
     }
-    // software pipeline: while the GPU works on block b, the host prepares block b+1
+    // software pipeline: while the GPU works on block b, the host prepares block b+1 and — as soon as a bucket guess
+    // for its kind exists — submits it, so that its kernels run beside the selection of block b
     HostBlock hb[2];
     if (int rc = fill(0)) return rc;
     if (int rc = prep_block(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, 0, 0, hb[0])) return rc;
-    if (int rc = submit_gemm(c, hb[0], p)) return rc;
+    if (int rc = submit_a(c, hb[0], p, sl)) return rc;
     for (int64_t b = 0; b < nblocks; ++b) {
         const int s = (int)(b & 1);
-        if (int rc = submit_block(c, hb[s], p, sl)) return rc;          // epilogue + pick of block b (main stream)
+        if (int rc = submit_b(c, hb[s], p, sl)) return rc;              // unfused: epilogue + pick of block b (main stream)
         if (b + 1 < nblocks) {
             if (int rc = fill(b + 1)) return rc;
             if (int rc = prep_block(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, s ^ 1, b + 1, hb[s ^ 1]))
                 return rc;
-            if (c->overlap)
-                if (int rc = submit_gemm(c, hb[s ^ 1], p)) return rc;   // GEMM of block b+1 (GEMM stream) runs beside them
+            if (can_submit_early(c, hb[s ^ 1], p))
+                if (int rc = submit_a(c, hb[s ^ 1], p, sl)) return rc;   // block b+1 (GEMM stream) runs beside them
         }
         if (int rc = finish_block(c, hb[s], p, sl)) return rc;          // round trip + selection of block b
-        if (!c->overlap && b + 1 < nblocks)
-            if (int rc = submit_gemm(c, hb[s ^ 1], p)) return rc;       // overlap off: strictly one block after the other
+        if (b + 1 < nblocks && !hb[s ^ 1].submitted)
+            if (int rc = submit_a(c, hb[s ^ 1], p, sl)) return rc;       // overlap off / no guess yet: one block after the other
         ++c->blk_cursor;
     }
     return ldw_links_end(c);
@@ -1451,6 +1290,18 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
 int ldw_set_overlap(ldw_ctx *c, int on) {
     LDW_REQUIRE(c, LDW_ERR_ARG, "null context");
     c->overlap = on != 0;
+    return LDW_OK;
+}
+
+int ldw_set_screen(ldw_ctx *c, int mode) {
+    LDW_REQUIRE(c && mode >= 0 && mode <= 3, LDW_ERR_ARG, "ldw_set_screen: mode must be 0, 1 or 2");
+    c->screen = mode;
+    return LDW_OK;
+}
+
+int ldw_set_fused(ldw_ctx *c, int on) {
+    LDW_REQUIRE(c, LDW_ERR_ARG, "null context");
+    c->fused = on != 0;
     return LDW_OK;
 }
 

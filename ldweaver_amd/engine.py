@@ -54,11 +54,19 @@ class Engine:
     def counters(self):
         v = np.zeros(4, dtype=np.int64)
         L.check(L.lib().ldw_ctx_counters(self._ctx, L.ptr(v)))
-        return dict(spec_misses=int(v[0]))
+        return dict(spec_misses=int(v[0]), fused_blocks=int(v[1]), unfused_blocks=int(v[2]), screen_violations=int(v[3]))
 
     def set_overlap(self, on: bool):
         """GEMM of the next block beside the epilogue/selection of the current one (default on); off = exclusive stage times."""
         L.check(L.lib().ldw_set_overlap(self._ctx, int(bool(on))))
+
+    def set_fused(self, on: bool):
+        """GEMM + MI epilogue as one kernel for every block with a bucket guess (default on); off = the two-kernel path."""
+        L.check(L.lib().ldw_set_fused(self._ctx, int(bool(on))))
+
+    def set_screen(self, mode: int):
+        """fp32 screen before the fp64 MI evaluation in speculative blocks: 0 off, 1 on (default), 2 verify."""
+        L.check(L.lib().ldw_set_screen(self._ctx, int(mode)))
 
     def set_engine(self, engine: int):
         L.check(L.lib().ldw_set_engine(self._ctx, int(engine)))

@@ -463,3 +463,103 @@ def test_speculative_gather_and_fallback(engine, synth):
         off += n
     assert off == len(mi)
     assert st["n_lr_kept"][2] == st["n_lr_total"][2] > 10 * st["n_lr_kept"][1]   # block 3 kept everything
+
+
+def _lr_blocks(links, stats):
+    """Split a long-range table into per-block dicts {(a, b): MI}."""
+    a, b, mi = links
+    out, off = [], 0
+    for n in stats["n_lr_kept"].tolist():
+        out.append(dict(zip(zip(a[off:off + n].tolist(), b[off:off + n].tolist()), mi[off:off + n].tolist())))
+        off += n
+    assert off == len(mi)
+    return out
+
+
+def _same_up_to_threshold_ties(d0, d1, thr, tol):
+    """Two retained sets of one block agree except for pairs whose MI sits on the quantile threshold itself: pairs
+    with equivalent joint tables tie there, and which side of `>=` a tie lands on depends on the last bit of an fp64
+    sum whose order is not the reference's either (the epilogue is not bit-matched)."""
+    for k in set(d0) ^ set(d1):
+        v = d0.get(k, d1.get(k))
+        assert abs(v - thr) < tol, (k, v, thr)
+    for k in set(d0) & set(d1):
+        assert abs(d0[k] - d1[k]) < tol, (k, d0[k], d1[k])
+
+
+@pytest.mark.parametrize("nlimbs", [0, 1, 3])
+def test_fused_kernel_matches_two_kernel_path(engine, synth, nlimbs):
+    """The fused GEMM + epilogue kernel (ldw_fused.hip) against the GEMM -> G -> epilogue pair on the same blocks:
+    diagonal, square off-diagonal and ragged (non-square, Q1-scrambled) blocks, SNPs of every slot-count class.
+    The sr tables must hold the same rows in the same order, the lr tables the same rows up to ties AT the block's
+    threshold; MI may differ by rounding only (a diagonal block can meet a pair in mirrored roles)."""
+    d = dict(synth)
+    if nlimbs == 1:
+        d["hdw"] = np.ones_like(synth["hdw"])
+    _setup(engine, d, nlimbs)
+    POS, g = synth["POS"], synth["g"]
+    approx = orc.lr_links_approx(POS, g, 20000.0)
+    blocks = np.array(orc.make_blocks(512, 150), dtype=np.int32)     # 4 x 4 grid: 150, 150, 150, 62 -> 10 block pairs
+    out = {}
+    for fused in (False, True):
+        engine.set_fused(fused)
+        c0 = engine.counters()
+        for _ in range(2):     # the second pass starts with bucket guesses: every block of it can run fused
+            engine.mi_all_pairs(blocks, 20000.0, 3000.0, approx)
+        c1 = engine.counters()
+        out[fused] = (engine.links(0), engine.links(1), engine.block_stats(), c1["fused_blocks"] - c0["fused_blocks"])
+    engine.set_fused(True)
+    assert out[False][3] == 0 and out[True][3] >= len(blocks) + len(blocks) - 2, (out[False][3], out[True][3])
+    (a0, b0, m0), (a1, b1, m1) = out[False][0], out[True][0]
+    assert len(m0) == len(m1) > 0 and np.array_equal(a0, a1) and np.array_equal(b0, b1)
+    assert np.abs(m0 - m1).max() < 1e-13
+    for k in ("n_lr_total", "n_sr"):
+        assert np.array_equal(out[False][2][k], out[True][2][k])
+    lr0, lr1 = _lr_blocks(out[False][1], out[False][2]), _lr_blocks(out[True][1], out[True][2])
+    for bi in range(len(blocks)):
+        _same_up_to_threshold_ties(lr0[bi], lr1[bi], out[True][2]["disc_thresh"][bi], 1e-13)
+    if nlimbs == 3:      # 24-bit weights: MI is only good to 1e-4, the selection near the threshold may differ from the oracle's
+        return
+    # and against the oracle, block by block (lr part)
+    for bi, (fs, fe, ts, te) in enumerate(blocks.tolist()):
+        fi, ti = np.arange(fs - 1, fe), np.arange(ts - 1, te)
+        Mb = c_oracle.mi_block(d["states"], d["hdw"], d["r"], d["uqe"], fi, ti)
+        bl = orc.block_links(Mb, fi, ti, POS, d["paint"], g, 20000.0, 3000.0, approx)
+        ref = dict(zip(zip(bl.lr["a"].tolist(), bl.lr["b"].tolist()), bl.lr["MI"].tolist()))
+        assert abs(out[True][2]["disc_thresh"][bi] - bl.disc_thresh) < MI_TIGHT
+        _same_up_to_threshold_ties(ref, lr1[bi], bl.disc_thresh, MI_TIGHT)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_fp32_screen_loses_nothing(engine, synth, fused):
+    """The fp32 screen in front of the fp64 MI evaluation (speculative blocks) must never dismiss a pair that the exact
+    value would have emitted: mode 2 evaluates every pair both ways and counts such pairs; and since every emitted MI
+    is the exact one, the link tables with the screen on are bit-identical to those with the screen off."""
+    syn = synth_alignment(3000, 700, seed=11)
+    st = syn["states"]
+    uqe, r = orc.uqe_r(st)
+    engine.set_alignment(st)
+    hdw = engine.hamming_weights(300)
+    d = dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=syn["POS"], paint=syn["paint"], g=float(syn["g"]))
+    _setup(engine, d)
+    approx = MIH.lr_links_approx(syn["POS"], float(syn["g"]), 20000.0)
+    blocks = MIH.make_blocks(3000, 1000)     # 6 block pairs, 3 of them diagonal
+    engine.set_fused(fused)
+    out = {}
+    for mode in (0, 1, 2):
+        engine.set_screen(mode)
+        c0 = engine.counters()
+        for _ in range(2):
+            engine.mi_all_pairs(blocks, 20000.0, 20000.0, approx)
+        c1 = engine.counters()
+        out[mode] = (engine.links(0), engine.links(1), c1["screen_violations"] - c0["screen_violations"],
+                     c1["spec_misses"] - c0["spec_misses"])
+    engine.set_screen(1)
+    engine.set_fused(True)
+    assert out[2][2] == 0, f"the screen would have lost {out[2][2]} pairs"
+    assert out[1][3] == 0 and out[0][3] == 0     # the second pass runs speculatively, i.e. with the screen
+    for which in (0, 1):
+        for mode in (1, 2):
+            for x, y in zip(out[0][which], out[mode][which]):
+                assert np.array_equal(x, y), (which, mode)
+    assert len(out[0][1][2]) > 15000 and len(out[0][0][2]) > 0

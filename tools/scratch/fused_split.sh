@@ -1,0 +1,11 @@
+#!/bin/bash
+# experiment: time split of the fused kernel (K loop only / epilogue only / both / two-kernel path)
+for mode in 0 1 2; do
+  echo "== LDW_FUSED_DEBUG=$mode"
+  LDW_FUSED_DEBUG=$mode timeout -k 10 300 python bench.py --no-cpu-baseline --steps 2 2>/dev/null | python3 -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('ms/step', round(d['ms_per_step'],1), 'stages', {k: round(v,1) for k,v in d['stages_ms_per_step'].items()}, d['counters'], d['links'])
+"
+done
