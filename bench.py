@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the timed region with the GEMM/epilogue stream overlap off too (kernel-exclusive times everywhere; "
                          "the command profiles/*_serial_kernel_stats.csv was collected with)")
-    ap.add_argument("--no-fused", action="store_true", help="always the two-kernel path GEMM -> G -> epilogue (ldw_set_fused(0))")
+    ap.add_argument("--fused", action="store_true", help="GEMM + MI epilogue as one kernel (ldw_set_fused(1)); default is GEMM -> G -> "
+                                                         "k_mi_screen -> k_mi_units, which is faster (DESIGN.md 5.2)")
     ap.add_argument("--screen", type=int, default=1, help="fp32 screen before the fp64 MI evaluation: 0 off, 1 on, 2 verify")
     ap.add_argument("--cpu-sample", type=int, default=0, help="SNPs per side of the CPU-baseline sample block (0 = auto)")
     return ap.parse_args()
@@ -103,7 +104,7 @@ def main():
     eng = Engine(local_rank, stream=stream.cuda_stream)
     eng.set_engine(LL.ENGINE_HIST if args.engine == "hist" else LL.ENGINE_MFMA)
     eng.set_overlap(not args.no_overlap)
-    eng.set_fused(not args.no_fused)
+    eng.set_fused(args.fused)
     eng.set_screen(args.screen)
     eng.set_alignment(states)
     counts = eng.state_counts()

@@ -156,11 +156,11 @@ int ldw_links_end(ldw_ctx *ctx);
  * that the per-stage times of ldw_ctx_last_timing are exclusive kernel times (what bench.py's roofline uses).
  * Results are identical either way. */
 int ldw_set_overlap(ldw_ctx *ctx, int on);
-/* on (default): blocks for which a histogram-bucket guess exists (every block but the first of a call sequence) run the
- * co-occurrence GEMM and the MI epilogue as ONE kernel: the joint sums stay in LDS, the epilogue of one workgroup
- * overlaps the MFMA loop of its neighbour on the CU.  off: always the GEMM -> G in HBM -> epilogue pair of kernels.
- * Link tables are identical either way up to the rounding of MI (<= 1e-15: on diagonal blocks the fused kernel may
- * meet a pair in mirrored roles). */
+/* on: blocks for which a histogram-bucket guess exists (every block but the first of a call sequence) run the
+ * co-occurrence GEMM and the MI epilogue as ONE kernel: the joint sums stay in LDS.  off (default): GEMM -> G in HBM ->
+ * k_mi_screen -> k_mi_units; measured faster on C4 (122 vs 132 ms per step) because the epilogue hides its latencies
+ * with occupancy the fused kernel cannot have.  Link tables are identical either way up to the rounding of MI (<= 1e-15:
+ * on diagonal blocks the fused kernel may meet a pair in mirrored roles). */
 int ldw_set_fused(ldw_ctx *ctx, int on);
 /* fp32 screen in front of the fp64 MI evaluation, in blocks that run the speculative selection: a long-range pair
  * only matters if its MI reaches the guessed histogram bucket, so MI is first bounded in fp32 (v_log_f32, proven

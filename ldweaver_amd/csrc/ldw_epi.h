@@ -157,6 +157,32 @@ __device__ __forceinline__ void emit_pair(const EmitArgs &E, const ColInfo &c, i
     }
 }
 
+// emission in the speculative selection mode without a dense block or an LDS histogram (fused kernel, k_mi_units):
+// candidates are rare, their bucket counts go straight to the global histogram
+__device__ __forceinline__ void emit_pair_spec(const EmitArgs &E, const ColInfo &c, int a_loc, int b_loc, int sa, int sb, double mi,
+                                           unsigned long long *__restrict__ ghist) {
+    const int seg = pair_seg(a_loc, b_loc, E.lower_only);
+    if (seg < 0) return;
+    if (E.any_sr && col_is_sr(c, a_loc)) {
+        if (E.keep_sr) {
+            const int64_t dst = E.sr_base + (seg == 0 ? c.off_u + col_count(c, 0, a_loc) : c.off_l + col_count(c, b_loc + 1, a_loc));
+            E.sr_a[dst] = sa;
+            E.sr_b[dst] = sb;
+            E.sr_mi[dst] = mi;
+        }
+    } else if (E.do_lr) {
+        if (mi >= E.spec_lo) {
+            const int bk = mi_bucket(mi);
+            if (bk >= E.spec_B) {
+                atomicAdd(&ghist[bk], 1ull);
+                const unsigned long long p = atomicAdd(E.n_cand, 1ull);
+                E.ckey[p] = f64_key(mi);
+                E.cval[p] = ((uint64_t)seg << 62) | ((uint64_t)a_loc + (uint64_t)b_loc * (uint64_t)E.nf);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // MI epilogue: one thread per SNP pair; a wave = 64 consecutive from-side SNPs at one to-side SNP and walks
 // EPI_COLS/4 consecutive to-side SNPs, so everything indexed by the to-side SNP is wave-uniform.
@@ -185,7 +211,6 @@ struct FusedArgs {
     const int32_t *pos_f, *pos_t;   // local SNP index starting at each row position of the padded row lists, -1 elsewhere
     const uint8_t *cls_f, *cls_t;   // slot-count class (1, 2, 4) of every 32-row group of the row lists
     unsigned long long *ghist;      // NBINS counters of the long-range candidates
-    int dbg;                        // experiments only (env LDW_FUSED_DEBUG): 1 = skip the epilogue
     EpiArgs A;
 };
 int launch_fused(ldw_ctx *ctx, const FusedArgs &F, int RFpad, int RTpad, int nlimbs, hipStream_t stream);
@@ -195,7 +220,7 @@ int launch_fused(ldw_ctx *ctx, const FusedArgs &F, int RFpad, int RTpad, int nli
 struct ColMeta {
     int32_t sb;
     uint32_t mb;
-    int32_t rb0, pad;
+    int32_t rb0, bl;   // first row position in the to-side row list; local index of the SNP in the to-side list
     double rb;      // r of the to-side SNP
     double rq;      // Q1 on square blocks: r[idx_f[b_loc]]
     double pYd[5];
@@ -403,31 +428,6 @@ __device__ __forceinline__ double pair_mi_full(const EpiArgs &A, const RowSide &
     FullCells<NA, NB> C;
     full_cells<NA, NB>(R, M, Gp, si, sj, C);
     return full_cells_mi<NA, NB>(A, R, M, pair_rxy(A, R, M, a_loc, b_loc, square), C);
-}
-
-// Screen, then the exact value if some lane of the wave needs it.  `want(mi_upper)` tells whether a lane whose MI is at
-// most mi_upper still has to be evaluated exactly; returns false when no lane of the wave does (mi is then not set).
-// scr_mode: 0 = no screen, 1 = screen, 2 = screen + exact for every lane, lanes the screen would have lost are counted.
-template <int NA, int NB, class Want>
-__device__ __forceinline__ bool pair_mi_full_screened(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc,
-                                                      bool square, const int64_t *Gp, int64_t si, int64_t sj, bool lane_on,
-                                                      Want want, double &mi, bool &need) {
-    FullCells<NA, NB> C;
-    full_cells<NA, NB>(R, M, Gp, si, sj, C);
-    const double RXY = pair_rxy(A, R, M, a_loc, b_loc, square);
-    need = lane_on;
-    if (A.E.scr_mode) {
-        const float ub = full_cells_screen<NA, NB>(A, R, M, RXY, C) + SCREEN_EPS;
-        need = lane_on && want(ub);
-        if (A.E.scr_mode == 3) return false;   // experiment: screen cost alone
-        if (A.E.scr_mode == 1 && __ballot(need) == 0ull) return false;
-    }
-    mi = full_cells_mi<NA, NB>(A, R, M, RXY, C);
-    if (A.E.scr_mode == 2) {
-        if (lane_on && !need && want((float)mi)) atomicAdd(A.E.scr_viol, 1ull);
-        need = lane_on;
-    }
-    return true;
 }
 
 }  // namespace ldw

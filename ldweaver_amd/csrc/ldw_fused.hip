@@ -48,30 +48,6 @@ union FusedSmem {
     int64_t g[4][64 * GS];
 };
 
-__device__ __forceinline__ void emit_fused(const EmitArgs &E, const ColInfo &c, int a_loc, int b_loc, int sa, int sb, double mi,
-                                           unsigned long long *__restrict__ ghist) {
-    const int seg = pair_seg(a_loc, b_loc, E.lower_only);
-    if (seg < 0) return;
-    if (E.any_sr && col_is_sr(c, a_loc)) {
-        if (E.keep_sr) {
-            const int64_t dst = E.sr_base + (seg == 0 ? c.off_u + col_count(c, 0, a_loc) : c.off_l + col_count(c, b_loc + 1, a_loc));
-            E.sr_a[dst] = sa;
-            E.sr_b[dst] = sb;
-            E.sr_mi[dst] = mi;
-        }
-    } else if (E.do_lr) {
-        if (mi >= E.spec_lo) {
-            const int bk = mi_bucket(mi);
-            if (bk >= E.spec_B) {
-                atomicAdd(&ghist[bk], 1ull);
-                const unsigned long long p = atomicAdd(E.n_cand, 1ull);
-                E.ckey[p] = f64_key(mi);
-                E.cval[p] = ((uint64_t)seg << 62) | ((uint64_t)a_loc + (uint64_t)b_loc * (uint64_t)E.nf);
-            }
-        }
-    }
-}
-
 __device__ __forceinline__ void load_from(const FromMeta &fmeta, double scale, RowSide &R, int &a_loc) {
     a_loc = __builtin_amdgcn_readfirstlane(fmeta.a_loc);
     R.sa = __builtin_amdgcn_readfirstlane(fmeta.sa);
@@ -129,7 +105,6 @@ __device__ __forceinline__ bool fused_group(const EpiArgs &A, const FromMeta *fg
         need[u] = act[u] && (is_sr[u] ? keep_sr : (do_lr && ms >= lo));
         any = any || need[u];
     }
-    if (A.E.scr_mode == 3) return true;   // experiment: screen cost alone
     if (A.E.scr_mode == 1 && __ballot(any) == 0ull) return true;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -143,9 +118,9 @@ __device__ __forceinline__ bool fused_group(const EpiArgs &A, const FromMeta *fg
         if (need[u]) {
             if (lower_only && a_loc[u] < b_loc) {   // diagonal block, pair met in mirrored roles (row order is by class, not by index)
                 const ColInfo ci = A.E.cols[a_loc[u]];
-                emit_fused(A.E, ci, b_loc, a_loc[u], M.sb, R[u].sa, mi, ghist);
+                emit_pair_spec(A.E, ci, b_loc, a_loc[u], M.sb, R[u].sa, mi, ghist);
             } else {
-                emit_fused(A.E, M.ci, a_loc[u], b_loc, R[u].sa, M.sb, mi, ghist);
+                emit_pair_spec(A.E, M.ci, a_loc[u], b_loc, R[u].sa, M.sb, mi, ghist);
             }
         }
     }
@@ -207,7 +182,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mi_fused_kernel(FusedArgs F) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    if (F.dbg == 1) return;
     // ---- epilogue of the wave's sub-tile: lane = to-side SNP, loop = from-side SNP ----
     const EpiArgs &A = F.A;
     const int half = lane >> 5, l32 = lane & 31;
@@ -224,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mi_fused_kernel(FusedArgs F) {
     M.sb = A.idx_t[b_loc];
     M.mb = A.slot_meta[M.sb];
     M.rb0 = 0;
-    M.pad = 0;
+    M.bl = b_loc;
     M.rb = A.r[M.sb];
     M.rq = square ? A.r[A.idx_f[b_loc]] : 0.0;
 #pragma unroll
@@ -275,9 +249,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mi_fused_kernel(FusedArgs F) {
             if (act) {
                 if (lower_only && a_loc < b_loc) {   // diagonal block, pair met in mirrored roles (row order is by class, not by index)
                     const ColInfo ci = A.E.cols[a_loc];
-                    emit_fused(A.E, ci, b_loc, a_loc, M.sb, R.sa, mi, F.ghist);
+                    emit_pair_spec(A.E, ci, b_loc, a_loc, M.sb, R.sa, mi, F.ghist);
                 } else {
-                    emit_fused(A.E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, F.ghist);
+                    emit_pair_spec(A.E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, F.ghist);
                 }
             }
         }

@@ -95,7 +95,8 @@ struct ldw_ctx {
     // ---- per-block workspaces ----
     ldw::DevBuf G, G2;           // int64 [RTpad][RFpad] fixed-point joint sums, one per pipeline slot
     ldw::DevBuf MIblk;           // double [nf*nt]
-    ldw::DevBuf rowlist_f, rowlist_t, idx_f, idx_t, lrow_f, lrow_t, perm_f;
+    ldw::DevBuf rowlist_f, rowlist_t, idx_f, idx_t, lrow_f, lrow_t, perm_f, perm_t;
+    ldw::DevBuf scr_units;       // uint32 count (64-B slot) + list of the block's units the fp32 screen wants evaluated exactly
     ldw::DevBuf hist[2], cand_key[2], cand_val[2];   // per pipeline slot: histogram of the lr candidates, candidate list
     ldw::DevBuf colcnt, cand_key2, cand_val2, scratch, small;
 
@@ -125,7 +126,8 @@ struct ldw_ctx {
     void *pin_lrc = nullptr;             // pinned copy of the running long-range row count
     hipEvent_t ev_lrc = nullptr;
     bool lrc_recorded = false;
-    bool fused = true;                   // GEMM + epilogue in one kernel whenever a bucket guess exists (ldw_fused.hip)
+    bool fused = false;                  // GEMM + epilogue in one kernel whenever a bucket guess exists (ldw_fused.hip); off:
+                                         // GEMM -> k_mi_screen -> k_mi_units, which measures 7 % faster on C4
     bool spec_seen[2] = {false, false};  // a block of this kind (off-diagonal, diagonal) has set its own guess
     std::vector<hipEvent_t> ev_pool;     // 4 timing events per block
     int spec_B_next[2] = {-1, -1};       // bucket guess for the speculative long-range gather: [off-diagonal, diagonal]

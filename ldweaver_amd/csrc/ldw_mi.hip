@@ -22,22 +22,18 @@ using namespace ldw;
 
 namespace ldw {
 
-__global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *__restrict__ perm_f,
-                                                     unsigned long long *__restrict__ ghist) {
-    __shared__ unsigned int sh_hist[NBINS];
-    __shared__ ColMeta cm[EPI_COLS];
-    const bool use_hist = A.E.cols && A.E.do_lr;
-    if (use_hist)
-        for (int i = threadIdx.x; i < NBINS; i += 256) sh_hist[i] = 0;
-    const bool square = A.nf == A.nt;
+// ---- pieces shared by k_mi_screen and k_mi_epilogue: both walk the block in the same units, one unit = the 64
+// ---- from-side SNPs of a wave (perm_f order) x one to-side SNP (perm_t order); both orders group equal slot counts.
+__device__ __forceinline__ void stage_cols(const EpiArgs &A, const int32_t *__restrict__ perm_t, bool square, ColMeta *cm) {
     if (threadIdx.x < EPI_COLS) {
-        const int b_loc = blockIdx.y * EPI_COLS + threadIdx.x;
-        if (b_loc < A.nt) {
+        const int q = blockIdx.y * EPI_COLS + threadIdx.x;
+        if (q < A.nt) {
+            const int b_loc = perm_t[q];
             ColMeta m;
             m.sb = A.idx_t[b_loc];
             m.mb = A.slot_meta[m.sb];
             m.rb0 = A.lrow_t[b_loc];
-            m.pad = 0;
+            m.bl = b_loc;
             m.rb = A.r[m.sb];
             m.rq = square ? A.r[A.idx_f[b_loc]] : 0.0;
 #pragma unroll
@@ -51,14 +47,33 @@ __global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *_
             cm[threadIdx.x] = m;
         }
     }
-    __syncthreads();
+}
 
-    // lanes walk the from-side SNPs in an order that groups equal slot counts, so that a wave runs the same cells
-    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int wave = threadIdx.x >> 6;
+// the same for ONE column slot q, executed by every lane of a wave with uniform addresses (k_mi_units)
+__device__ __forceinline__ void load_col(const EpiArgs &A, const int32_t *__restrict__ perm_t, bool square, int q, ColMeta &m) {
+    const int b_loc = perm_t[q];
+    m.sb = A.idx_t[b_loc];
+    m.mb = A.slot_meta[m.sb];
+    m.rb0 = A.lrow_t[b_loc];
+    m.bl = b_loc;
+    m.rb = A.r[m.sb];
+    m.rq = square ? A.r[A.idx_f[b_loc]] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        m.pb[j] = A.slot_pfix[(int64_t)m.sb * 5 + j];
+        m.pYd[j] = (double)m.pb[j] * A.scale;
+        m.pYf[j] = (float)m.pYd[j];
+    }
+    m.pad2 = 0;
+    m.ci = A.E.cols[b_loc];
+}
+
+// per-lane constants of the from-side SNP; returns whether the lane holds one
+__device__ __forceinline__ bool load_row_side(const EpiArgs &A, const int32_t *__restrict__ perm_f, bool square, int tile, RowSide &R,
+                                              int &a_loc) {
+    const int t = tile * 64 + (threadIdx.x & 63);
     const bool a_ok = t < A.nf;
-    const int a_loc = perm_f[a_ok ? t : A.nf - 1];
-    RowSide R;
+    a_loc = perm_f[a_ok ? t : A.nf - 1];
     R.sa = A.idx_f[a_loc];
     R.ma = A.slot_meta[R.sa];
     R.na = a_ok ? (int)(R.ma & 7) : 0;
@@ -71,60 +86,262 @@ __global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *_
         R.pXd[i] = (double)R.pa[i] * A.scale;
         R.pXf[i] = (float)R.pXd[i];
     }
-    const int na_max = (__ballot(R.na > 2) != 0ull) ? 4 : ((__ballot(R.na > 1) != 0ull) ? 2 : 1);
-    // wave-uniform: every active lane has the same slot count (1 or 2) and all its slots flagged in uqe
-    const int na0 = __builtin_amdgcn_readfirstlane(R.na);
+    return a_ok;
+}
+
+// every active lane of the wave has the same slot count na0 (1 or 2) and all of its slots flagged in uqe
+__device__ __forceinline__ bool wave_is_full(const RowSide &R, bool a_ok, int &na0) {
+    na0 = __builtin_amdgcn_readfirstlane(R.na);
     const bool a_full = a_ok && R.na == na0 && (((R.ma >> 3) & ((2u << na0) - 1u)) == ((2u << na0) - 1u));
-    const bool wave_full = (na0 == 1 || na0 == 2) && __ballot(!a_full) == 0ull;
+    return (na0 == 1 || na0 == 2) && __ballot(!a_full) == 0ull;
+}
+__device__ __forceinline__ bool col_is_fast(uint32_t mb) {
+    const int nb = (int)(mb & 7);
+    return (nb == 1 || nb == 2) && (((mb >> 3) & ((2u << nb) - 1u)) == ((2u << nb) - 1u));
+}
+
+// Row lists are ordered by slot-count class, not by SNP index, so on a diagonal block (symmetric G, tiles above
+// the diagonal of ROW positions skipped by the GEMM) the entry of a pair may only exist transposed.
+__device__ __forceinline__ const int64_t *g_entry(const EpiArgs &A, const RowSide &R, const ColMeta &M, int64_t &si, int64_t &sj) {
+    const bool tr = A.E.lower_only && R.ra0 < (int64_t)M.rb0;
+    si = tr ? (int64_t)A.RFpad : 1;
+    sj = tr ? 1 : (int64_t)A.RFpad;
+    return A.G + (tr ? R.ra0 * A.RFpad + M.rb0 : (int64_t)M.rb0 * A.RFpad + R.ra0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_mi_screen: the fp32 screen of the two-kernel path (speculative selection mode).  A long-range pair only matters if
+// its MI reaches the guessed histogram bucket, which about one pair in a thousand does; this kernel bounds MI in fp32
+// (full_cells_screen, ldw_epi.h) for every unit whose SNPs have 1 or 2 fully flagged slots and writes ONE byte per
+// unit: does any of its 64 pairs need the exact value (short-range pair, or upper bound >= the bucket's lower edge)?
+// k_mi_epilogue then evaluates only the flagged units (and the units this kernel does not handle).  The kernel is kept
+// free of the fp64 path on purpose: ~70 VGPRs instead of 145, so 6-7 waves per SIMD hide the latency of the G loads
+// that bound the one-kernel epilogue (one 512-B load in flight per wave, 3 waves per SIMD: 1.3 TB/s), and U columns per
+// iteration put U independent loads in flight per wave.
+// ------------------------------------------------------------------------------------------------
+template <int NA, int NB, int U>
+__device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc, bool a_ok,
+                                                    bool rxy_q1, float lo) {
+    FullCells<NA, NB> C[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        int64_t si, sj;
+        const int64_t *Gp = g_entry(A, R, cmu[u], si, sj);
+        full_cells<NA, NB>(R, cmu[u], Gp, si, sj, C[u]);
+    }
+    const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0, do_lr = A.E.do_lr != 0;
+    unsigned int bits = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const ColMeta &M = cmu[u];
+        const int b_loc = M.bl;
+        const bool act = a_ok && (A.E.lower_only ? a_loc > b_loc : a_loc != b_loc);
+        const double rxy = (rxy_q1 ? M.rq * R.rta : R.ra * M.rb) * 0.25;
+        const float ms = full_cells_screen<NA, NB>(A, R, M, rxy, C[u]);
+        const bool is_sr = test_sr && col_is_sr(M.ci, a_loc);
+        const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
+        if (__ballot(need) != 0ull) bits |= 1u << u;
+    }
+    return bits;
+}
+
+// U columns at once for biallelic x biallelic units (4 cells each, the bulk of the work); wider tables go two (or one)
+// at a time, which keeps the kernel near 64 VGPRs
+template <int NA, int U>
+__device__ __forceinline__ unsigned int screen_cols_nb(int nb, const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc,
+                                                       bool a_ok, bool rxy_q1, float lo) {
+    if (NA == 1 && nb == 1) return screen_cols<NA, 1, U>(A, R, cmu, a_loc, a_ok, rxy_q1, lo);
+    constexpr int V = U >= 2 && NA == 1 ? 2 : 1;
+    unsigned int bits = 0;
+    for (int u = 0; u < U; u += V) {
+        const unsigned int b = nb == 1 ? screen_cols<NA, 1, V>(A, R, cmu + u, a_loc, a_ok, rxy_q1, lo)
+                                       : screen_cols<NA, 2, V>(A, R, cmu + u, a_loc, a_ok, rxy_q1, lo);
+        bits |= b << u;
+    }
+    return bits;
+}
+
+// unit list entry: from-tile * nt + column slot; bit 31: verify mode only, a unit the screen dismissed
+constexpr uint32_t UNIT_DISMISSED = 0x80000000u;
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mi_screen(EpiArgs A, const int32_t *__restrict__ perm_f,
+                                                                                            const int32_t *__restrict__ perm_t,
+                                                                                            uint32_t *__restrict__ units,
+                                                                                            unsigned int *__restrict__ n_units) {
+    __shared__ ColMeta cm[EPI_COLS];
+    const bool square = A.nf == A.nt;
+    stage_cols(A, perm_t, square, cm);
+    __syncthreads();
+    RowSide R;
+    int a_loc, na0;
+    const bool a_ok = load_row_side(A, perm_f, square, blockIdx.x, R, a_loc);
+    const bool wave_full = wave_is_full(R, a_ok, na0);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c_first = wave * (EPI_COLS / 4);
+    const int q_base = blockIdx.y * EPI_COLS + c_first;
+    int n_it = A.nt - q_base;
+    n_it = n_it > EPI_COLS / 4 ? EPI_COLS / 4 : n_it;
+    if (n_it <= 0) return;
+    const bool rxy_q1 = A.quirk == LDW_QUIRK_REFERENCE;
+    const float lo = (float)A.E.spec_lo - SCREEN_EPS;
+    // wanted: units that need the fp64 kernel; handled: units this kernel could judge (the others are wanted by default)
+    unsigned int wanted = 0, handled = 0;
+    constexpr int U = 4;
+    if (wave_full) {
+        for (int it = 0; it < n_it; it += U) {
+            const ColMeta *cmu = &cm[c_first + it];
+            // the U columns of a group share one code path if they have the same slot count (the rule away from class borders)
+            bool same = it + U <= n_it;
+            const uint32_t mb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmu[0].mb);
+            if (same) {
+#pragma unroll
+                for (int u = 1; u < U; ++u) {
+                    const uint32_t mbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmu[u].mb);
+                    same = same && (mbu & 7) == (mb0 & 7) && col_is_fast(mbu);
+                }
+                same = same && col_is_fast(mb0);
+            }
+            if (same) {
+                const unsigned int b = na0 == 1 ? screen_cols_nb<1, U>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, rxy_q1, lo)
+                                                : screen_cols_nb<2, U>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, rxy_q1, lo);
+                wanted |= b << it;
+                handled |= ((1u << U) - 1u) << it;
+            } else {
+                for (int u = 0; u < U && it + u < n_it; ++u) {
+                    const uint32_t mbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmu[u].mb);
+                    if (!col_is_fast(mbu)) continue;
+                    const unsigned int b = na0 == 1 ? screen_cols_nb<1, 1>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, rxy_q1, lo)
+                                                    : screen_cols_nb<2, 1>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, rxy_q1, lo);
+                    wanted |= b << (it + u);
+                    handled |= 1u << (it + u);
+                }
+            }
+        }
+    }
+    const unsigned int all = n_it >= 32 ? 0xFFFFFFFFu : ((1u << n_it) - 1u);
+    wanted = (wanted | ~handled) & all;
+    const unsigned int listed = A.E.scr_mode == 2 ? all : wanted;   // verify mode: the dismissed units are listed too, marked
+    if (listed == 0) return;
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(n_units, (unsigned int)__popc(listed));
+    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+    if (lane < 32 && ((listed >> lane) & 1u)) {
+        const uint32_t u = (uint32_t)blockIdx.x * (uint32_t)A.nt + (uint32_t)(q_base + lane);
+        units[base + __popc(listed & ((1u << lane) - 1u))] = ((wanted >> lane) & 1u) ? u : (u | UNIT_DISMISSED);
+    }
+}
+
+// would this pair leave a trace (short-range row or long-range candidate)?  Verify mode of the screen only.
+__device__ __forceinline__ bool would_emit(const EmitArgs &E, const ColInfo &c, int a_loc, int b_loc, double mi) {
+    if (pair_seg(a_loc, b_loc, E.lower_only) < 0) return false;
+    if (E.any_sr && col_is_sr(c, a_loc)) return E.keep_sr != 0;
+    return E.do_lr && mi >= E.spec_lo && mi_bucket(mi) >= E.spec_B;
+}
+
+// MI of one pair by the variant that fits the slot counts (wave-uniform choice)
+__device__ __forceinline__ double unit_pair_mi(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc, bool square,
+                                               bool fast, int na0, int na_max, int nb) {
+    int64_t si, sj;
+    const int64_t *Gp = g_entry(A, R, M, si, sj);
+    if (fast) {
+        if (na0 == 1) return nb == 1 ? pair_mi_full<1, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj) : pair_mi_full<1, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+        return nb == 1 ? pair_mi_full<2, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj) : pair_mi_full<2, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+    }
+    if (na_max == 1) {
+        if (nb <= 1) return pair_mi<1, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+        if (nb == 2) return pair_mi<1, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+        return pair_mi<1, 4>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+    }
+    if (na_max == 2) {
+        if (nb <= 1) return pair_mi<2, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+        if (nb == 2) return pair_mi<2, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+        return pair_mi<2, 4>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+    }
+    if (nb <= 1) return pair_mi<4, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+    if (nb == 2) return pair_mi<4, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+    return pair_mi<4, 4>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_mi_epilogue: fp64 MI of every pair of the block, emission of the pairs (dense MI block, short-range rows, LDS
+// histogram / speculative candidates).  The path of blocks without a bucket guess and of ldw_mi_block.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
+                                                     unsigned long long *__restrict__ ghist) {
+    __shared__ unsigned int sh_hist[NBINS];
+    __shared__ ColMeta cm[EPI_COLS];
+    const bool use_hist = A.E.cols && A.E.do_lr;
+    if (use_hist)
+        for (int i = threadIdx.x; i < NBINS; i += 256) sh_hist[i] = 0;
+    const bool square = A.nf == A.nt;
+    stage_cols(A, perm_t, square, cm);
+    __syncthreads();
+
+    // lanes walk the from-side SNPs in an order that groups equal slot counts, so that a wave runs the same cells
+    const int wave = threadIdx.x >> 6;
+    RowSide R;
+    int a_loc, na0;
+    const bool a_ok = load_row_side(A, perm_f, square, blockIdx.x, R, a_loc);
+    const int na_max = (__ballot(R.na > 2) != 0ull) ? 4 : ((__ballot(R.na > 1) != 0ull) ? 2 : 1);
+    const bool wave_full = wave_is_full(R, a_ok, na0);
 
     const int c_first = wave * (EPI_COLS / 4);
-    const int b_base = blockIdx.y * EPI_COLS;
-    int n_it = A.nt - (b_base + c_first);
+    const int q_base = blockIdx.y * EPI_COLS + c_first;
+    int n_it = A.nt - q_base;
     n_it = n_it > EPI_COLS / 4 ? EPI_COLS / 4 : n_it;
     for (int it = 0; it < n_it; ++it) {
-        const int cl = c_first + it;
-        const int b_loc = b_base + cl;
+        const ColMeta &M = cm[c_first + it];
+        const uint32_t mbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.mb);
+        const int b_loc = M.bl;
         if (!a_ok) continue;
         if (A.E.lower_only && a_loc <= b_loc) continue;
-        const ColMeta &M = cm[cl];
-        const int nb = __builtin_amdgcn_readfirstlane((int)(M.mb & 7));
-        // Row lists are ordered by slot-count class, not by SNP index, so on a diagonal block (symmetric G, tiles above
-        // the diagonal of ROW positions skipped by the GEMM) the entry of a pair may only exist transposed.
-        const bool tr = A.E.lower_only && R.ra0 < (int64_t)M.rb0;
-        const int64_t si = tr ? (int64_t)A.RFpad : 1, sj = tr ? 1 : (int64_t)A.RFpad;
-        const int64_t *Gp = A.G + (tr ? R.ra0 * A.RFpad + M.rb0 : (int64_t)M.rb0 * A.RFpad + R.ra0);
-        double mi;
-        const bool b_full = ((M.mb >> 3) & ((2u << nb) - 1u)) == ((2u << nb) - 1u);
-        if (wave_full && b_full && (nb == 1 || nb == 2)) {
-            // fp32 screen first (speculative mode): the exact value is computed only if some lane of the wave holds a
-            // short-range pair or a long-range pair that may reach the guessed bucket
-            const bool is_sr = A.E.scr_mode && A.E.any_sr && col_is_sr(M.ci, a_loc);
-            auto want = [&](double ub) { return is_sr ? A.E.keep_sr != 0 : (A.E.do_lr && ub >= A.E.spec_lo); };
-            bool need, ran;
-            if (na0 == 1) ran = nb == 1 ? pair_mi_full_screened<1, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj, true, want, mi, need)
-                                        : pair_mi_full_screened<1, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj, true, want, mi, need);
-            else ran = nb == 1 ? pair_mi_full_screened<2, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj, true, want, mi, need)
-                               : pair_mi_full_screened<2, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj, true, want, mi, need);
-            if (!ran || !need) continue;
-        } else if (na_max == 1) {
-            if (nb <= 1) mi = pair_mi<1, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-            else if (nb == 2) mi = pair_mi<1, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-            else mi = pair_mi<1, 4>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-        } else if (na_max == 2) {
-            if (nb <= 1) mi = pair_mi<2, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-            else if (nb == 2) mi = pair_mi<2, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-            else mi = pair_mi<2, 4>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-        } else {
-            if (nb <= 1) mi = pair_mi<4, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-            else if (nb == 2) mi = pair_mi<4, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-            else mi = pair_mi<4, 4>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-        }
+        const double mi = unit_pair_mi(A, R, M, a_loc, b_loc, square, wave_full && col_is_fast(mbu), na0, na_max, (int)(mbu & 7));
         emit_pair(A.E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, sh_hist);
     }
     if (use_hist) {
         __syncthreads();
         for (int i = threadIdx.x; i < NBINS; i += 256)
             if (sh_hist[i]) atomicAdd(&ghist[i], (unsigned long long)sh_hist[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_mi_units: the fp64 evaluation of the units listed by k_mi_screen (speculative selection mode): one wave per unit,
+// grid-stride over the list.  A few per cent of the block's units are listed, so what counts is latency (the SNP
+// constants of both sides are fetched per unit) — hidden by the number of waves in flight — not throughput.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mi_units(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
+                                                  const uint32_t *__restrict__ units, const unsigned int *__restrict__ n_units,
+                                                  unsigned long long *__restrict__ ghist) {
+    const bool square = A.nf == A.nt;
+    const unsigned int n = *n_units;
+    const unsigned int stride = gridDim.x * 4u;
+    int cur_tile = -1, a_loc = 0, na0 = 0, na_max = 1;
+    bool a_ok = false, wave_full = false;
+    RowSide R;
+    for (unsigned int i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n; i += stride) {
+        const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)units[i]);
+        const bool dismissed = (u & UNIT_DISMISSED) != 0;
+        const uint32_t v = u & ~UNIT_DISMISSED;
+        const int tile = (int)(v / (uint32_t)A.nt), q = (int)(v - (uint32_t)tile * (uint32_t)A.nt);
+        if (tile != cur_tile) {
+            a_ok = load_row_side(A, perm_f, square, tile, R, a_loc);
+            na_max = (__ballot(R.na > 2) != 0ull) ? 4 : ((__ballot(R.na > 1) != 0ull) ? 2 : 1);
+            wave_full = wave_is_full(R, a_ok, na0);
+            cur_tile = tile;
+        }
+        ColMeta M;
+        load_col(A, perm_t, square, q, M);
+        const uint32_t mbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.mb);
+        const int b_loc = M.bl;
+        if (!a_ok) continue;
+        if (A.E.lower_only && a_loc <= b_loc) continue;
+        const double mi = unit_pair_mi(A, R, M, a_loc, b_loc, square, wave_full && col_is_fast(mbu), na0, na_max, (int)(mbu & 7));
+        if (dismissed) {   // verify mode: a pair of a dismissed unit that would have been emitted was lost by the screen
+            if (would_emit(A.E, M.ci, a_loc, b_loc, mi)) atomicAdd(A.E.scr_viol, 1ull);
+            continue;
+        }
+        emit_pair_spec(A.E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, ghist);
     }
 }
 
@@ -560,7 +777,7 @@ bool same_list(const int32_t *a, int64_t na, const int32_t *b, int64_t nb) {
 
 // device pointers of one block's index structures
 struct DevPtrs {
-    const int32_t *idx_f, *idx_t, *rl_f, *rl_t, *lrow_f, *lrow_t, *perm, *pos_f, *pos_t;
+    const int32_t *idx_f, *idx_t, *rl_f, *rl_t, *lrow_f, *lrow_t, *perm, *perm_t, *pos_f, *pos_t;
     const uint8_t *cls_f, *cls_t;
 };
 
@@ -632,8 +849,21 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
     EpiArgs A;
     fill_epi_args(c, D, nf, nt, RFpad, quirk, E, Gbuf.as<int64_t>(), A);
     if (which == 2) LDW_HIP(hipEventRecord(ev[4], c->stream));
-    hipLaunchKernelGGL(k_mi_epilogue, egrid, dim3(256), 0, c->stream, A, D.perm, ghist);
-    LDW_HIP(hipGetLastError());
+    if (A.E.scr_mode && A.E.cols && !A.E.write_dense && (nf == nt || quirk == LDW_QUIRK_INTENDED)) {
+        // speculative mode: the lean fp32 screen lists the units that need the exact value, k_mi_units evaluates those
+        const size_t n_units_max = (size_t)egrid.x * (size_t)nt;
+        if (int rc = c->scr_units.reserve(n_units_max * 4 + 64)) return rc;
+        unsigned int *n_units = c->scr_units.as<unsigned int>();
+        uint32_t *units = c->scr_units.as<uint32_t>() + 16;
+        LDW_HIP(hipMemsetAsync(n_units, 0, 4, c->stream));
+        hipLaunchKernelGGL(k_mi_screen, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units);
+        LDW_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_mi_units, dim3(2048), dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, ghist);
+        LDW_HIP(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_mi_epilogue, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, ghist);
+        LDW_HIP(hipGetLastError());
+    }
     if (which != 2 || c->engine != LDW_ENGINE_HIST) LDW_HIP(hipEventRecord(ev[2], c->stream));
     return LDW_OK;
 }
@@ -652,11 +882,13 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     if (int rc = ensure_rows(c)) return rc;
     LDW_REQUIRE(nf > 0 && nt > 0, LDW_ERR_ARG, "empty block (nf=%lld nt=%lld)", (long long)nf, (long long)nt);
     LDW_REQUIRE(nf <= 1000000 && nt <= 1000000, LDW_ERR_ARG, "block side too long");
-    std::vector<int32_t> vf(from_idx, from_idx + nf), vt(to_idx, to_idx + nt), perm((size_t)nf);
+    std::vector<int32_t> vf(from_idx, from_idx + nf), vt(to_idx, to_idx + nt), perm((size_t)nf), perm_t((size_t)nt);
     SideLists SF, ST;
     if (int rc = build_side(c, from_idx, nf, SF)) return rc;
     if (int rc = build_side(c, to_idx, nt, ST)) return rc;
     build_perm(c, from_idx, nf, perm.data());
+    build_perm(c, to_idx, nt, perm_t.data());
+    if (int rc = upload_i32(c, c->perm_t, perm_t)) return rc;
     if (int rc = upload_i32(c, c->idx_f, vf)) return rc;
     if (int rc = upload_i32(c, c->idx_t, vt)) return rc;
     if (int rc = upload_i32(c, c->rowlist_f, SF.rowlist)) return rc;
@@ -667,7 +899,8 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     if (int rc = c->hist[0].reserve((size_t)NBINS * 8)) return rc;
     LDW_HIP(hipStreamSynchronize(c->stream));  // pageable H2D copies are complete only after a sync
     DevPtrs D{c->idx_f.as<int32_t>(), c->idx_t.as<int32_t>(), c->rowlist_f.as<int32_t>(), c->rowlist_t.as<int32_t>(),
-              c->lrow_f.as<int32_t>(), c->lrow_t.as<int32_t>(), c->perm_f.as<int32_t>(), nullptr, nullptr, nullptr, nullptr};
+              c->lrow_f.as<int32_t>(), c->lrow_t.as<int32_t>(), c->perm_f.as<int32_t>(), c->perm_t.as<int32_t>(), nullptr, nullptr,
+              nullptr, nullptr};
     E.write_dense = 1;
     E.spec_B = -1;
     // a symmetric block (same list on both sides) may be asked for in full: the GEMM then computes every tile
@@ -718,7 +951,7 @@ struct HostBlock {
     int64_t nf = 0, nt = 0, n_sr_blk = 0, n_lr_total = 0, blk_no = 0;
     int RFpad = 0, RTpad = 0, slot = 0;
     bool diag = false, fused = false, submitted = false;
-    size_t o_idx_f = 0, o_idx_t = 0, o_rl_f = 0, o_rl_t = 0, o_lrow_f = 0, o_lrow_t = 0, o_perm = 0, o_cols = 0, o_pos_f = 0,
+    size_t o_idx_f = 0, o_idx_t = 0, o_rl_f = 0, o_rl_t = 0, o_lrow_f = 0, o_lrow_t = 0, o_perm = 0, o_perm_t = 0, o_cols = 0, o_pos_f = 0,
            o_pos_t = 0, o_cls_f = 0, o_cls_t = 0, total = 0;
     DevPtrs D{};
     EmitArgs E{};
@@ -757,6 +990,7 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     hb.o_lrow_f = o; o = al(o + (size_t)nf * 4);
     hb.o_lrow_t = o; o = al(o + (size_t)nt * 4);
     hb.o_perm = o; o = al(o + (size_t)nf * 4);
+    hb.o_perm_t = o; o = al(o + (size_t)nt * 4);
     hb.o_cols = o; o = al(o + cols.size() * sizeof(ColInfo));
     hb.o_pos_f = o; o = al(o + SF.pos.size() * 4);
     hb.o_pos_t = o; o = al(o + ST.pos.size() * 4);
@@ -778,6 +1012,7 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     memcpy(b + hb.o_lrow_f, SF.lrow.data(), (size_t)nf * 4);
     memcpy(b + hb.o_lrow_t, ST.lrow.data(), (size_t)nt * 4);
     build_perm(c, from_idx, nf, reinterpret_cast<int32_t *>(b + hb.o_perm));
+    build_perm(c, to_idx, nt, reinterpret_cast<int32_t *>(b + hb.o_perm_t));
     memcpy(b + hb.o_cols, cols.data(), cols.size() * sizeof(ColInfo));
     memcpy(b + hb.o_pos_f, SF.pos.data(), SF.pos.size() * 4);
     memcpy(b + hb.o_pos_t, ST.pos.data(), ST.pos.size() * 4);
@@ -868,7 +1103,7 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     const char *d = c->dstage[s].as<char>();
     auto I = [&](size_t off) { return reinterpret_cast<const int32_t *>(d + off); };
     auto B = [&](size_t off) { return reinterpret_cast<const uint8_t *>(d + off); };
-    hb.D = DevPtrs{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm),
+    hb.D = DevPtrs{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm), I(hb.o_perm_t),
                    I(hb.o_pos_f), I(hb.o_pos_t), B(hb.o_cls_f), B(hb.o_cls_t)};
     hb.submitted = true;
     if (c->engine != LDW_ENGINE_MFMA) return LDW_OK;
@@ -908,11 +1143,6 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     F.cls_f = hb.D.cls_f;
     F.cls_t = hb.D.cls_t;
     F.ghist = c->hist[s].as<unsigned long long>();
-    {
-        const char *e = getenv("LDW_FUSED_DEBUG");
-        F.dbg = e ? atoi(e) : 0;
-        if (F.dbg == 2) F.KW = 2;   // K loop of one short chunk: what is left is the epilogue
-    }
     fill_epi_args(c, hb.D, hb.nf, hb.nt, hb.RFpad, p->quirk_mode, hb.E, nullptr, F.A);
     LDW_HIP(hipEventRecord(ev[0], gs));
     if (int rc = launch_fused(c, F, hb.RFpad, hb.RTpad, c->nlimbs, gs)) return rc;
@@ -1294,7 +1524,7 @@ int ldw_set_overlap(ldw_ctx *c, int on) {
 }
 
 int ldw_set_screen(ldw_ctx *c, int mode) {
-    LDW_REQUIRE(c && mode >= 0 && mode <= 3, LDW_ERR_ARG, "ldw_set_screen: mode must be 0, 1 or 2");
+    LDW_REQUIRE(c && mode >= 0 && mode <= 2, LDW_ERR_ARG, "ldw_set_screen: mode must be 0, 1 or 2");
     c->screen = mode;
     return LDW_OK;
 }

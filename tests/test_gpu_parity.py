@@ -508,7 +508,7 @@ def test_fused_kernel_matches_two_kernel_path(engine, synth, nlimbs):
             engine.mi_all_pairs(blocks, 20000.0, 3000.0, approx)
         c1 = engine.counters()
         out[fused] = (engine.links(0), engine.links(1), engine.block_stats(), c1["fused_blocks"] - c0["fused_blocks"])
-    engine.set_fused(True)
+    engine.set_fused(False)
     assert out[False][3] == 0 and out[True][3] >= len(blocks) + len(blocks) - 2, (out[False][3], out[True][3])
     (a0, b0, m0), (a1, b1, m1) = out[False][0], out[True][0]
     assert len(m0) == len(m1) > 0 and np.array_equal(a0, a1) and np.array_equal(b0, b1)
@@ -555,7 +555,7 @@ def test_fp32_screen_loses_nothing(engine, synth, fused):
         out[mode] = (engine.links(0), engine.links(1), c1["screen_violations"] - c0["screen_violations"],
                      c1["spec_misses"] - c0["spec_misses"])
     engine.set_screen(1)
-    engine.set_fused(True)
+    engine.set_fused(False)
     assert out[2][2] == 0, f"the screen would have lost {out[2][2]} pairs"
     assert out[1][3] == 0 and out[0][3] == 0     # the second pass runs speculatively, i.e. with the screen
     for which in (0, 1):

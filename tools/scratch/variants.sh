@@ -1,7 +1,7 @@
 #!/bin/bash
-for v in "--screen 1" "--screen 3"; do
+for v in "--no-fused --screen 1" "--screen 1"; do
   echo "== $v"
-  timeout -k 10 300 python bench.py --no-cpu-baseline --steps 2 $v 2>/dev/null | python3 -c "
+  timeout -k 10 300 python bench.py --no-cpu-baseline --steps 3 $v 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
