@@ -225,7 +225,8 @@ def main():
         exec_per_launch = exec_ops / nb_mine
         i8_peak = 5000.0  # TOP/s dense (MI355X_MICROARCH.md: i8 = 2 x bf16 per clock, bf16 ~2.5 PF dense)
         achieved = alg_flops_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms else None
-        roof = dict(bound="mfma", kernel=f"gemm_bits_kernel<{J}>", achieved=achieved, peak=i8_peak, unit="TFLOP/s",
+        kname = f"gemm_mi_fused_kernel<{J}>" if args.fused else f"gemm_bits_kernel<{J}>"
+        roof = dict(bound="mfma", kernel=kname, achieved=achieved, peak=i8_peak, unit="TFLOP/s",
                     frac=achieved / i8_peak if achieved else None, traffic=None,
                     avg_launch_ms=gemm_avg_ms, launches=n_launch,
                     executed_TOPs=exec_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms else None,
@@ -240,11 +241,14 @@ def main():
         roof["executed_frac"] = roof["executed_TOPs"] / i8_peak if roof["executed_TOPs"] else None
         # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (rocprofv3 cannot run inside
         # the bench); only quoted for the configuration they were collected on
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and (L, N, world, J) == (100_000, 5_000, 1, 5):
+        tpath = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
+        if os.path.exists(tpath) and (L, N, world, J) == (100_000, 5_000, 1, 5) and not args.fused:
             roof["traffic"] = json.load(open(tpath)).get("gemm_bits_kernel<5>", {}).get("hbm_bytes_per_launch_corrected")
-            roof["traffic_source"] = "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+            roof["traffic_source"] = "profiles/r01f_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
         roof["epilogue_avg_launch_ms"] = epi_avg_ms
+        roof["epilogue_kernels"] = ("inside the fused kernel" if args.fused else
+                                    "k_mi_screen (fp32 screen, lists the units that need the exact value) + k_mi_units (fp64, listed units)"
+                                    if args.screen else "k_mi_epilogue (fp64, every pair)")
         roof["dominant_stage"] = stage
         roof["hbm_alg_GBps_whole_step"] = (L * N + 8.0 * pairs) / (dt / K) / 1e9
         roof["hbm_frac_whole_step"] = roof["hbm_alg_GBps_whole_step"] / 8000.0
@@ -254,7 +258,8 @@ def main():
                    config=dict(workload=f"synthetic {L} SNPs x {N} seqs, all {nblocks} block pairs of make_blocks(max_blk_sz={args.max_blk_sz}), "
                                         f"sr_dist=20000, lr_retain_links=1e6, sr+lr link tables on rank 0",
                                L=L, N=N, pairs=int(pairs), engine=args.engine, nlimbs=args.nlimbs or 5,
-                               arithmetic="joint sums: int8 MFMA -> exact int64 fixed point; MI epilogue: f64",
+                               arithmetic="joint sums: int8 MFMA -> exact int64 fixed point; MI: fp32 screen, f64 for every emitted value",
+                               fused=bool(args.fused), screen=args.screen,
                                parallelism=f"pair-space blocks over {world} GPU(s)"),
                    roofline=roof,
                    stages_ms_per_step={k: v / max(1, n_replay) for k, v in tim.items()},
