@@ -215,8 +215,28 @@ int ldw_sr_reduced_fetch(ldw_ctx *ctx, int64_t capacity, int64_t *row_out, int32
                          double *srp_out);
 int ldw_sr_pool_fetch(ldw_ctx *ctx, int64_t capacity, int32_t *a_out, int32_t *b_out, double *MI_out);
 /* runARACNE (R/io_functions.R:101-164) for the kept links against the pool, both device resident;
- * flags_out[i] belongs to row_out[i] of ldw_sr_reduced_fetch. */
+ * flags_out[i] belongs to row_out[i] of ldw_sr_reduced_fetch (after ldw_sr_pvalues) or ldw_lr_reduced_fetch (after
+ * ldw_lr_tukey). */
 int ldw_aracne_device(ldw_ctx *ctx, int64_t capacity, uint8_t *flags_out);
+
+/* ---- (8) consumers of the link tables, on the device-resident tables ------------------ */
+/* Numeric core of analyse_long_range_links (R/lr_analyser.R:72-111): q13_out = quantile(MI, c(.25,.75)) (type 7) of the
+ * long-range table, thresholds_out = q3 + (1.5, 3) IQR — or, when fewer than min_links (reference: 5000) links exceed
+ * min(thresholds) although the table has that many rows, quantile(MI, 1 - c(4000, 5000)/n) (*fallback_out = 1, the
+ * reference's warning).  Leaves on the device: the outlier links lr[MI > min(thresholds)] (n_red, table order) and the
+ * ARACNE pool rbind(lr, sr)[MI > min(thresholds)] (n_pool).  Then ldw_lr_reduced_fetch / ldw_aracne_device. */
+int ldw_lr_tukey(ldw_ctx *ctx, int64_t min_links, double q13_out[2], double thresholds_out[2], int *fallback_out,
+                 int64_t *n_red_out, int64_t *n_pool_out);
+/* the outlier links: row in the lr table (ldw_links_fetch order) and that row's (a, b, MI) */
+int ldw_lr_reduced_fetch(ldw_ctx *ctx, int64_t capacity, int64_t *row_out, int32_t *a_out, int32_t *b_out, double *MI_out);
+/* Numeric core of genomewide_LDMap (R/LDSummaryPlot.R:55-106): pos_vec = sorted unique positions of all links (kept
+ * if from < pos < to when a window is given; from = to = 0: genome-wide), symmetric sparse MI matrix over their ranks,
+ * block sums with the kernel of .mat(n, reducer) (:176-178), / reducer^2, log10(. + 1e-5), rescaled to [0, 1] (:157-163).
+ * reducer = 0: round(length(pos_vec) / 1e3) like the reference.  htm_out: B x B doubles, B = n_pos / reducer (integer
+ * division), symmetric; htm_out = NULL only returns the sizes.  reducer <= 1 (the reference's unreduced dense plot) is
+ * refused with LDW_ERR_ARG. */
+int ldw_ldmap(ldw_ctx *ctx, int32_t reducer, int32_t from, int32_t to, int64_t *n_pos_out, int32_t *reducer_out, int32_t *B_out,
+              double *htm_out, int64_t capacity);
 
 /* ---- small native helpers kept for finest-grain A/B parity (host memory) -------------------- */
 /* .compareToRow src/computeMI.cpp:25-41: ret[j] = any(x[j,] in y); x is nr x nc column-major */

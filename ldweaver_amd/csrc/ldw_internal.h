@@ -109,6 +109,7 @@ struct ldw_ctx {
     ldw::DevBuf srm_pack, srm_key, srm_pack2, srm_key2, srm_pay, srm_pay2, srm_off, srm_q, srm_n, srm_md, srm_part, srm_shape, srm_cnt;
     ldw::DevBuf red_row, red_meta, red_srp, pool_a, pool_b, pool_mi, ar_key, ar_val, ar_key2, ar_val2, ar_off, ar_flags;
     int64_t n_red = 0, n_pool = 0;
+    bool red_from_lr = false;    // red_row indexes the long-range table (ldw_lr_tukey) instead of the short-range one
     int srm_S = 0, srm_nclust = 0;   // geometry of the last ldw_sr_len_quantiles call
     double srm_sr_dist = 0;
 

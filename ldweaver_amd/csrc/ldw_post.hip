@@ -1,0 +1,318 @@
+// Consumers of the link tables (SURVEY.md §8 f rank 4), on the device-resident tables left by ldw_mi_all_pairs:
+//
+//   ldw_lr_tukey  : numeric core of analyse_long_range_links (R/lr_analyser.R:72-108): Tukey outlier thresholds
+//                   q3 + (1.5, 3) IQR of the long-range MI values (stats::quantile type 7), the "top ~5000" fallback
+//                   (:97-102), the outlier links lr[MI > min(thresholds)] and the ARACNE pool rbind(lr, sr)[MI > min(thresholds)]
+//                   (:106-111); ldw_aracne_device then marks the indirect links.
+//   ldw_ldmap     : numeric core of genomewide_LDMap (R/LDSummaryPlot.R:55-106): positions that occur in any link are
+//                   ranked, the symmetric sparse MI matrix over those ranks is block-summed with the kernel of .mat()
+//                   (:176-178: block k = ranks [k r, (k+1) r), the remainder beyond floor(n / r) r is dropped), divided by r^2,
+//                   log10(. + 1e-5), rescaled to [0, 1] (:157-163).
+//
+// Both are HBM-bound row streaming over (a, b, MI) tables: 16 B per link and pass.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <hipcub/hipcub.hpp>
+#include <vector>
+
+#include "ldw_internal.h"
+#include "ldw_dev.h"
+
+using namespace ldw;
+
+namespace ldw {
+
+__global__ __launch_bounds__(256) void k_mi_keys(const double *__restrict__ mi, int64_t n, uint64_t *__restrict__ key) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) key[i] = f64_key(mi[i]);
+}
+
+// rows with MI > thr: kept rows of `which == 0` go to red_row (in table order: one workgroup-wide ordered append per
+// 256-row segment keeps the order deterministic after a prefix over segment counts), all of them to the pool
+__global__ __launch_bounds__(256) void k_count_gt(const double *__restrict__ mi, int64_t n, double thr, int64_t *__restrict__ seg_cnt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool keep = i < n && mi[i] > thr;
+    const unsigned long long b = __ballot(keep);
+    __shared__ int wcnt[4];
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) seg_cnt[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+__global__ __launch_bounds__(256) void k_select_gt(const int32_t *__restrict__ a, const int32_t *__restrict__ b, const double *__restrict__ mi,
+                                                   int64_t n, double thr, const int64_t *__restrict__ seg_off, int64_t pool_base,
+                                                   int64_t *__restrict__ red_row, int32_t *__restrict__ pool_a,
+                                                   int32_t *__restrict__ pool_b, double *__restrict__ pool_mi) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool keep = i < n && mi[i] > thr;
+    const unsigned long long bal = __ballot(keep);
+    __shared__ int wcnt[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    if (!keep) return;
+    int64_t dst = seg_off[blockIdx.x];
+    for (int w = 0; w < wave; ++w) dst += wcnt[w];
+    dst += __popcll(bal & ((1ull << lane) - 1ull));
+    if (red_row) red_row[dst] = i;
+    pool_a[pool_base + dst] = a[i];
+    pool_b[pool_base + dst] = b[i];
+    pool_mi[pool_base + dst] = mi[i];
+}
+
+// ---- LD map ----
+__global__ __launch_bounds__(256) void k_mark_used(const int32_t *__restrict__ a, const int32_t *__restrict__ b, int64_t n,
+                                                   const int32_t *__restrict__ POS, int from, int to, int windowed, int32_t *__restrict__ used) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int32_t x = a[i], y = b[i];
+        // positions of ALL links define pos_vec; the window then keeps from < pos < to (R/LDSummaryPlot.R:57-62)
+        if (!windowed || (POS[x] > from && POS[x] < to)) used[x] = 1;
+        if (!windowed || (POS[y] > from && POS[y] < to)) used[y] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ldmap_add(const int32_t *__restrict__ a, const int32_t *__restrict__ b, const double *__restrict__ mi,
+                                                   int64_t n, const int32_t *__restrict__ POS, int from, int to, int windowed,
+                                                   const int32_t *__restrict__ used, const int32_t *__restrict__ rank, int r, int B,
+                                                   double *__restrict__ red) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int32_t x = a[i], y = b[i];
+        if (windowed && !(POS[x] >= from && POS[x] <= to && POS[y] >= from && POS[y] <= to)) continue;   // :66-67
+        if (!used[x] || !used[y]) continue;   // a window edge position: no level in pos_vec
+        const int bi = rank[x] / r, bj = rank[y] / r;
+        if (bi >= B || bj >= B) continue;     // ranks beyond floor(n / r) * r fall outside every column of .mat()
+        // i, j and j, i (:78-80): a pair inside one block counts twice.  Only the upper triangle is accumulated (the
+        // mirror cell gets the same value afterwards), so the map is exactly symmetric whatever order the atomics land in.
+        const double v = mi[i];
+        const int lo = bi < bj ? bi : bj, hi = bi < bj ? bj : bi;
+        atomicAdd(&red[(int64_t)lo * B + hi], lo == hi ? v + v : v);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ldmap_log(const double *__restrict__ red, int B, double inv_r2, double *__restrict__ out,
+                                                   double *__restrict__ mm) {
+    __shared__ double smin[256], smax[256];
+    double lo = 1e300, hi = -1e300;
+    const int64_t n = (int64_t)B * B;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / B, col = i - row * B;
+        const double s = red[row <= col ? row * B + col : col * B + row];
+        const double v = log10(s * inv_r2 + 1e-5);
+        out[i] = v;
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+    smin[threadIdx.x] = lo;
+    smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + s]);
+            smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        mm[2 * blockIdx.x] = smin[0];
+        mm[2 * blockIdx.x + 1] = smax[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ldmap_rescale(double *__restrict__ red, int64_t n, double mn, double inv_rn) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) red[i] = (red[i] - mn) * inv_rn;
+}
+
+static int links_ready(ldw_ctx *c, const char *who) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(c->have_meta, LDW_ERR_STATE, "%s: ldw_set_snp_meta has not been called", who);
+    LDW_REQUIRE(c->blk_capacity == 0, LDW_ERR_STATE, "%s: a link pass is still open (ldw_links_end)", who);
+    return LDW_OK;
+}
+
+// stats::quantile type 7 exactly as R evaluates it: index = 1 + (n - 1) p, lo = floor(index), hi = ceiling(index),
+// qs = x[lo]; if (index > lo && x[hi] != qs) qs = (1 - h) qs + h x[hi], h = index - lo   (1-based ranks)
+struct Q7 {
+    double index;
+    int64_t lo, hi;
+};
+static Q7 q7_ranks(int64_t n, double p) {
+    Q7 q;
+    q.index = 1.0 + (double)(n - 1 > 0 ? n - 1 : 0) * p;
+    q.lo = (int64_t)std::floor(q.index);
+    q.hi = (int64_t)std::ceil(q.index);
+    return q;
+}
+static double q7_value(const Q7 &q, double xlo, double xhi) {
+    double qs = xlo;
+    if (q.index > (double)q.lo && xhi != qs) {
+        const double h = q.index - (double)q.lo;
+        qs = (1.0 - h) * qs + h * xhi;
+    }
+    return qs;
+}
+
+}  // namespace ldw
+
+extern "C" {
+
+int ldw_lr_tukey(ldw_ctx *c, int64_t min_links, double q13_out[2], double thresholds_out[2], int *fallback_out, int64_t *n_red_out,
+                 int64_t *n_pool_out) {
+    if (int rc = links_ready(c, "ldw_lr_tukey")) return rc;
+    LDW_REQUIRE(q13_out && thresholds_out && fallback_out && n_red_out && n_pool_out, LDW_ERR_ARG, "ldw_lr_tukey: null argument");
+    const int64_t n = c->n_lr, ns = c->n_sr;
+    LDW_REQUIRE(n > 0, LDW_ERR_STATE, "ldw_lr_tukey: the long-range table is empty");
+    LDW_REQUIRE(n < 2147483647LL, LDW_ERR_SIZE, "ldw_lr_tukey: too many long-range links");
+    // ---- sorted MI keys -> order statistics ----
+    if (int rc = c->ar_key.reserve((size_t)n * 8)) return rc;
+    if (int rc = c->ar_key2.reserve((size_t)n * 8)) return rc;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_mi_keys, dim3(grid), dim3(256), 0, c->stream, c->lr_mi.as<double>(), n, c->ar_key.as<uint64_t>());
+    size_t tb = 0;
+    LDW_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, c->ar_key.as<uint64_t>(), c->ar_key2.as<uint64_t>(), (int)n, 0, 64, c->stream));
+    if (int rc = c->scratch.reserve(tb)) return rc;
+    tb = c->scratch.cap;
+    LDW_HIP(hipcub::DeviceRadixSort::SortKeys(c->scratch.p, tb, c->ar_key.as<uint64_t>(), c->ar_key2.as<uint64_t>(), (int)n, 0, 64, c->stream));
+    auto order_stats = [&](double p, double &q) -> int {
+        const Q7 r = q7_ranks(n, p);
+        uint64_t k[2];
+        LDW_HIP(hipMemcpyAsync(&k[0], c->ar_key2.as<uint64_t>() + (r.lo - 1), 8, hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipMemcpyAsync(&k[1], c->ar_key2.as<uint64_t>() + (r.hi - 1), 8, hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+        q = q7_value(r, key_f64(k[0]), key_f64(k[1]));
+        return LDW_OK;
+    };
+    double q1 = 0, q3 = 0;
+    if (int rc = order_stats(0.25, q1)) return rc;
+    if (int rc = order_stats(0.75, q3)) return rc;
+    q13_out[0] = q1;
+    q13_out[1] = q3;
+    const double iqr = q3 - q1;
+    double thr[2] = {q3 + 1.5 * iqr, q3 + 3.0 * iqr};
+    // ---- rows above min(thresholds): count per 256-row segment, prefix, ordered select ----
+    const int64_t nseg_l = (n + 255) / 256, nseg_s = (ns + 255) / 256;
+    if (int rc = c->ar_off.reserve((size_t)(nseg_l + nseg_s + 2) * 8 * 2)) return rc;
+    int64_t *cnt_l = c->ar_off.as<int64_t>(), *off_l = cnt_l + nseg_l + 1, *cnt_s = off_l + nseg_l + 1, *off_s = cnt_s + nseg_s + 1;
+    auto count_pass = [&](double t, int64_t &n_red, int64_t &n_srp) -> int {
+        hipLaunchKernelGGL(k_count_gt, dim3((unsigned)nseg_l), dim3(256), 0, c->stream, c->lr_mi.as<double>(), n, t, cnt_l);
+        if (ns > 0) hipLaunchKernelGGL(k_count_gt, dim3((unsigned)nseg_s), dim3(256), 0, c->stream, c->sr_mi.as<double>(), ns, t, cnt_s);
+        LDW_HIP(hipGetLastError());
+        size_t sb = 0;
+        LDW_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, cnt_l, off_l, (int)nseg_l, c->stream));
+        if (int rc = c->scratch.reserve(sb)) return rc;
+        sb = c->scratch.cap;
+        LDW_HIP(hipcub::DeviceScan::ExclusiveSum(c->scratch.p, sb, cnt_l, off_l, (int)nseg_l, c->stream));
+        if (ns > 0) LDW_HIP(hipcub::DeviceScan::ExclusiveSum(c->scratch.p, sb, cnt_s, off_s, (int)nseg_s, c->stream));
+        int64_t last[4] = {0, 0, 0, 0};
+        LDW_HIP(hipMemcpyAsync(&last[0], off_l + nseg_l - 1, 8, hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipMemcpyAsync(&last[1], cnt_l + nseg_l - 1, 8, hipMemcpyDeviceToHost, c->stream));
+        if (ns > 0) {
+            LDW_HIP(hipMemcpyAsync(&last[2], off_s + nseg_s - 1, 8, hipMemcpyDeviceToHost, c->stream));
+            LDW_HIP(hipMemcpyAsync(&last[3], cnt_s + nseg_s - 1, 8, hipMemcpyDeviceToHost, c->stream));
+        }
+        LDW_HIP(hipStreamSynchronize(c->stream));
+        n_red = last[0] + last[1];
+        n_srp = last[2] + last[3];
+        return LDW_OK;
+    };
+    int64_t n_red = 0, n_srp = 0;
+    if (int rc = count_pass(std::min(thr[0], thr[1]), n_red, n_srp)) return rc;
+    int fallback = 0;
+    if (n_red < min_links && n >= min_links) {   // R/lr_analyser.R:97-102: keep ~5000 top links instead
+        fallback = 1;
+        double t4 = 0, t5 = 0;
+        // with the reference's min_links = 5000 both probabilities are in [0, 1]; clamped for smaller caller-chosen values
+        if (int rc = order_stats(std::max(0.0, 1.0 - (1.0 / (double)n) * 4000.0), t4)) return rc;
+        if (int rc = order_stats(std::max(0.0, 1.0 - (1.0 / (double)n) * 5000.0), t5)) return rc;
+        thr[0] = t4;
+        thr[1] = t5;
+        if (int rc = count_pass(std::min(thr[0], thr[1]), n_red, n_srp)) return rc;
+    }
+    const double tmin = std::min(thr[0], thr[1]);
+    const int64_t n_pool = n_red + n_srp;
+    if (int rc = c->red_row.reserve((size_t)std::max<int64_t>(n_red, 1) * 8)) return rc;
+    if (int rc = c->pool_a.reserve((size_t)std::max<int64_t>(n_pool, 1) * 4)) return rc;
+    if (int rc = c->pool_b.reserve((size_t)std::max<int64_t>(n_pool, 1) * 4)) return rc;
+    if (int rc = c->pool_mi.reserve((size_t)std::max<int64_t>(n_pool, 1) * 8)) return rc;
+    hipLaunchKernelGGL(k_select_gt, dim3((unsigned)nseg_l), dim3(256), 0, c->stream, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(),
+                       c->lr_mi.as<double>(), n, tmin, off_l, (int64_t)0, c->red_row.as<int64_t>(), c->pool_a.as<int32_t>(),
+                       c->pool_b.as<int32_t>(), c->pool_mi.as<double>());
+    if (ns > 0)
+        hipLaunchKernelGGL(k_select_gt, dim3((unsigned)nseg_s), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(),
+                           c->sr_mi.as<double>(), ns, tmin, off_s, n_red, (int64_t *)nullptr, c->pool_a.as<int32_t>(),
+                           c->pool_b.as<int32_t>(), c->pool_mi.as<double>());
+    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    c->n_red = n_red;
+    c->n_pool = n_pool;
+    c->red_from_lr = true;
+    thresholds_out[0] = thr[0];
+    thresholds_out[1] = thr[1];
+    *fallback_out = fallback;
+    *n_red_out = n_red;
+    *n_pool_out = n_pool;
+    return LDW_OK;
+}
+
+int ldw_ldmap(ldw_ctx *c, int32_t reducer, int32_t from, int32_t to, int64_t *n_pos_out, int32_t *reducer_out, int32_t *B_out,
+              double *htm_out, int64_t capacity) {
+    if (int rc = links_ready(c, "ldw_ldmap")) return rc;
+    LDW_REQUIRE(n_pos_out && reducer_out && B_out, LDW_ERR_ARG, "ldw_ldmap: null argument");
+    const int windowed = (from != 0 || to != 0) ? 1 : 0;
+    LDW_REQUIRE(!windowed || (to > from && from >= 0), LDW_ERR_ARG, "ldw_ldmap: <to> must be greater than <from> and both positive");
+    LDW_REQUIRE(reducer >= 0, LDW_ERR_ARG, "ldw_ldmap: reducer must be >= 0 (0 = default)");
+    const int64_t L = c->L, nl = c->n_lr, ns = c->n_sr;
+    LDW_REQUIRE(nl + ns > 0, LDW_ERR_STATE, "ldw_ldmap: no links");
+    // ---- pos_vec: which SNPs occur in a link, and their rank ----
+    if (int rc = c->srm_cnt.reserve((size_t)(L + 1) * 4 * 2)) return rc;
+    int32_t *used = c->srm_cnt.as<int32_t>(), *rank = used + L + 1;
+    LDW_HIP(hipMemsetAsync(used, 0, (size_t)(L + 1) * 4, c->stream));
+    const int32_t *POS = c->POS.as<int32_t>();
+    auto grid_of = [](int64_t n) { return dim3((unsigned)std::min<int64_t>((n + 255) / 256, 16384)); };
+    if (nl > 0) hipLaunchKernelGGL(k_mark_used, grid_of(nl), dim3(256), 0, c->stream, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), nl, POS, from, to, windowed, used);
+    if (ns > 0) hipLaunchKernelGGL(k_mark_used, grid_of(ns), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), ns, POS, from, to, windowed, used);
+    LDW_HIP(hipGetLastError());
+    size_t sb = 0;
+    LDW_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, used, rank, (int)(L + 1), c->stream));
+    if (int rc = c->scratch.reserve(sb)) return rc;
+    sb = c->scratch.cap;
+    LDW_HIP(hipcub::DeviceScan::ExclusiveSum(c->scratch.p, sb, used, rank, (int)(L + 1), c->stream));
+    int32_t n_pos = 0;
+    LDW_HIP(hipMemcpyAsync(&n_pos, rank + L, 4, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    // reducer = round(length(pos_vec) / 1e3) by default (:83-87); R's round() is half-to-even
+    int32_t r = reducer > 0 ? reducer : (int32_t)std::nearbyint((double)n_pos / 1e3);
+    *n_pos_out = n_pos;
+    *reducer_out = r;
+    LDW_REQUIRE(r > 1, LDW_ERR_ARG, "ldw_ldmap: reducer %d <= 1: the reference plots the dense %d x %d matrix unreduced, which this entry "
+                "point does not materialise (choose a reducer > 1)", r, n_pos, n_pos);
+    const int32_t B = n_pos / r;
+    *B_out = B;
+    LDW_REQUIRE(B > 0, LDW_ERR_ARG, "ldw_ldmap: reducer %d larger than the %d positions", r, n_pos);
+    if (!htm_out) return LDW_OK;   // size query
+    LDW_REQUIRE(capacity >= (int64_t)B * B, LDW_ERR_SIZE, "ldw_ldmap: capacity %lld < %lld", (long long)capacity, (long long)B * B);
+    const int64_t nb = (int64_t)B * B;
+    const int rgrid = (int)std::min<int64_t>((nb + 255) / 256, 1024);
+    if (int rc = c->srm_q.reserve((size_t)nb * 16 + (size_t)rgrid * 16)) return rc;
+    double *red = c->srm_q.as<double>(), *htm = red + nb, *mm = htm + nb;
+    LDW_HIP(hipMemsetAsync(red, 0, (size_t)nb * 8, c->stream));
+    if (nl > 0) hipLaunchKernelGGL(k_ldmap_add, grid_of(nl), dim3(256), 0, c->stream, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), c->lr_mi.as<double>(), nl, POS, from, to, windowed, used, rank, r, B, red);
+    if (ns > 0) hipLaunchKernelGGL(k_ldmap_add, grid_of(ns), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), c->sr_mi.as<double>(), ns, POS, from, to, windowed, used, rank, r, B, red);
+    hipLaunchKernelGGL(k_ldmap_log, dim3(rgrid), dim3(256), 0, c->stream, red, (int)B, 1.0 / ((double)r * (double)r), htm, mm);
+    LDW_HIP(hipGetLastError());
+    std::vector<double> hmm((size_t)rgrid * 2);
+    LDW_HIP(hipMemcpyAsync(hmm.data(), mm, hmm.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    double mn = hmm[0], mx = hmm[1];
+    for (int i = 1; i < rgrid; ++i) {
+        mn = std::min(mn, hmm[2 * i]);
+        mx = std::max(mx, hmm[2 * i + 1]);
+    }
+    const double rn = mx - mn;   // 0 -> NaN everywhere, like .rescale01
+    hipLaunchKernelGGL(k_ldmap_rescale, dim3(rgrid), dim3(256), 0, c->stream, htm, nb, mn, 1.0 / rn);
+    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipMemcpyAsync(htm_out, htm, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
+
+}  // extern "C"

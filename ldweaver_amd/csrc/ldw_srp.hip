@@ -557,6 +557,7 @@ int ldw_sr_pvalues(ldw_ctx *c, int nclust, int32_t S, const double *mean_dist, c
                     "ldw_sr_pvalues: cluster %d has an invalid beta shape", k + 1);
     const int64_t n = c->n_sr;
     c->n_red = c->n_pool = 0;
+    c->red_from_lr = false;
     *n_red_out = *n_pool_out = 0;
     if (min_mi_out) *min_mi_out = std::nan("");
     if (n == 0) return LDW_OK;
@@ -623,6 +624,7 @@ int ldw_sr_reduced_fetch(ldw_ctx *c, int64_t capacity, int64_t *row_out, int32_t
     if (n == 0) return LDW_OK;
     LDW_REQUIRE(row_out && a_out && b_out && MI_out && clust_c_out && first_clust_out && dup_out && srp_out, LDW_ERR_ARG,
                 "ldw_sr_reduced_fetch: null output");
+    LDW_REQUIRE(!c->red_from_lr, LDW_ERR_STATE, "ldw_sr_reduced_fetch: the reduced set is the long-range one (ldw_lr_tukey ran last)");
     std::vector<uint32_t> meta((size_t)n);
     if (int rc = c->scratch.reserve((size_t)n * 16)) return rc;
     double *gmi = c->scratch.as<double>();
@@ -658,13 +660,35 @@ int ldw_sr_pool_fetch(ldw_ctx *c, int64_t capacity, int32_t *a_out, int32_t *b_o
     return LDW_OK;
 }
 
+// rows of the long-range table kept by ldw_lr_tukey, in table order
+int ldw_lr_reduced_fetch(ldw_ctx *c, int64_t capacity, int64_t *row_out, int32_t *a_out, int32_t *b_out, double *MI_out) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(c->red_from_lr, LDW_ERR_STATE, "ldw_lr_reduced_fetch: call ldw_lr_tukey first");
+    const int64_t n = c->n_red;
+    LDW_REQUIRE(capacity >= n, LDW_ERR_SIZE, "ldw_lr_reduced_fetch: capacity %lld < %lld rows", (long long)capacity, (long long)n);
+    if (n == 0) return LDW_OK;
+    LDW_REQUIRE(row_out && a_out && b_out && MI_out, LDW_ERR_ARG, "ldw_lr_reduced_fetch: null output");
+    if (int rc = c->scratch.reserve((size_t)n * 16)) return rc;
+    double *gmi = c->scratch.as<double>();
+    int32_t *ga = reinterpret_cast<int32_t *>(gmi + n), *gb = ga + n;
+    hipLaunchKernelGGL(k_red_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->red_row.as<int64_t>(), n,
+                       c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), c->lr_mi.as<double>(), ga, gb, gmi);
+    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipMemcpyAsync(a_out, ga, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(b_out, gb, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(MI_out, gmi, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(row_out, c->red_row.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
+
 int ldw_aracne_device(ldw_ctx *c, int64_t capacity, uint8_t *flags_out) {
     if (int rc = check_gpu(c)) return rc;
     const int64_t nr = c->n_red, np = c->n_pool;
     LDW_REQUIRE(capacity >= nr, LDW_ERR_SIZE, "ldw_aracne_device: capacity %lld < %lld links", (long long)capacity, (long long)nr);
     if (nr == 0) return LDW_OK;
     LDW_REQUIRE(flags_out, LDW_ERR_ARG, "ldw_aracne_device: null output");
-    LDW_REQUIRE(np > 0, LDW_ERR_STATE, "ldw_aracne_device: no pool (call ldw_sr_pvalues first)");
+    LDW_REQUIRE(np > 0, LDW_ERR_STATE, "ldw_aracne_device: no pool (call ldw_sr_pvalues or ldw_lr_tukey first)");
     const int64_t n2 = 2 * np, L = c->L;
     if (int rc = c->ar_key.reserve((size_t)n2 * 8)) return rc;
     if (int rc = c->ar_key2.reserve((size_t)n2 * 8)) return rc;
@@ -684,8 +708,11 @@ int ldw_aracne_device(ldw_ctx *c, int64_t capacity, uint8_t *flags_out) {
                                                c->ar_val.as<double>(), c->ar_val2.as<double>(), n2, 0, 64, c->stream));
     hipLaunchKernelGGL(k_ar_offsets, dim3((unsigned)((L + 1 + 255) / 256)), dim3(256), 0, c->stream, c->ar_key2.as<uint64_t>(), n2, L,
                        c->ar_off.as<int64_t>());
+    // the links to check are rows of the short-range table (after ldw_sr_pvalues) or of the long-range one (after ldw_lr_tukey)
+    const int32_t *ta = (c->red_from_lr ? c->lr_a : c->sr_a).as<int32_t>(), *tb2 = (c->red_from_lr ? c->lr_b : c->sr_b).as<int32_t>();
+    const double *tmi = (c->red_from_lr ? c->lr_mi : c->sr_mi).as<double>();
     hipLaunchKernelGGL(k_ar_check, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, c->stream, c->red_row.as<int64_t>(), nr,
-                       c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), c->sr_mi.as<double>(), c->ar_key2.as<uint64_t>(),
+                       ta, tb2, tmi, c->ar_key2.as<uint64_t>(),
                        c->ar_val2.as<double>(), c->ar_off.as<int64_t>(), c->ar_flags.as<uint8_t>());
     LDW_HIP(hipGetLastError());
     LDW_HIP(hipMemcpyAsync(flags_out, c->ar_flags.p, (size_t)nr, hipMemcpyDeviceToHost, c->stream));

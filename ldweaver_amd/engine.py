@@ -274,6 +274,35 @@ class Engine:
         L.check(L.lib().ldw_aracne_device(self._ctx, self._n_red, L.ptr(out)))
         return out.astype(bool)
 
+    # -- consumers of the link tables ---------------------------
+    def lr_tukey(self, min_links: int = 5000):
+        """Tukey thresholds of the long-range table, outlier links and ARACNE pool left on the device
+        (analyse_long_range_links, R/lr_analyser.R:72-111)."""
+        q13, thr = np.zeros(2), np.zeros(2)
+        fb = C.c_int(0)
+        nr, npool = C.c_int64(0), C.c_int64(0)
+        L.check(L.lib().ldw_lr_tukey(self._ctx, int(min_links), L.ptr(q13), L.ptr(thr), C.byref(fb), C.byref(nr), C.byref(npool)))
+        self._n_red, self._n_pool = nr.value, npool.value
+        return dict(q13=q13, thresholds=thr, fallback=bool(fb.value), n_red=nr.value, n_pool=npool.value)
+
+    def lr_reduced(self):
+        n = self._n_red
+        row = np.empty(n, dtype=np.int64)
+        a = np.empty(n, dtype=np.int32)
+        b = np.empty(n, dtype=np.int32)
+        mi = np.empty(n, dtype=np.float64)
+        L.check(L.lib().ldw_lr_reduced_fetch(self._ctx, n, L.ptr(row), L.ptr(a), L.ptr(b), L.ptr(mi)))
+        return dict(row=row, a=a, b=b, MI=mi)
+
+    def ldmap(self, reducer: int = 0, from_: int = 0, to: int = 0):
+        """Block-summed, log-scaled, 0..1-rescaled LD map of all links (genomewide_LDMap, R/LDSummaryPlot.R:55-106).
+        Returns (htm [B, B], n_pos, reducer)."""
+        n_pos, r, B = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        L.check(L.lib().ldw_ldmap(self._ctx, int(reducer), int(from_), int(to), C.byref(n_pos), C.byref(r), C.byref(B), None, 0))
+        htm = np.empty((B.value, B.value), dtype=np.float64)
+        L.check(L.lib().ldw_ldmap(self._ctx, int(reducer), int(from_), int(to), C.byref(n_pos), C.byref(r), C.byref(B), L.ptr(htm), htm.size))
+        return htm, n_pos.value, r.value
+
     # -- element-wise twins ------------------------------------------------------
     def acgtn2num(self, nv: np.ndarray, ref_chars) -> None:
         """In-place twin of .ACGTN2num: nv is a Fortran-ordered (5, L) float64 matrix."""

@@ -1,0 +1,55 @@
+"""Consumers of the link tables (SURVEY.md §8 f rank 4): the numeric cores of ``analyse_long_range_links``
+(R/lr_analyser.R:29-190) and ``genomewide_LDMap`` (R/LDSummaryPlot.R:25-125) on the device-resident tables of the
+engine.  Plots, SnpEff annotation and the tanglegram are out of scope (SURVEY.md §8 f)."""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import pandas as pd
+
+from .rcompat import circ_len
+
+
+def analyse_long_range_links(eng, snp_dat, cds_var=None, are_lrlinks_ordered: bool = False, min_links: int = 5000) -> dict:
+    """Tukey outlier analysis + ARACNE of the long-range links the engine holds after ``perform_MI_computation`` /
+    ``mi_all_pairs`` (the reference reads them back from lr_links.tsv / sr_links.tsv).  Returns the reference's
+    ``lr_links_red`` (pos1 pos2 [clust1 clust2] len MI ARACNE, descending MI unless ``are_lrlinks_ordered``) plus the
+    thresholds.  Everything O(#links) runs on the device (ldw_lr_tukey, ldw_aracne_device)."""
+    info = eng.lr_tukey(min_links)
+    if info["fallback"]:   # R/lr_analyser.R:96
+        warnings.warn("Not enough lr links pass the Tukey criteria, ~5000 top links were retained instead")
+    red = eng.lr_reduced()
+    flags = eng.aracne_device()
+    POS = np.asarray(snp_dat.POS)
+    a, b = red["a"], red["b"]
+    pos1, pos2 = POS[b].astype(np.int64), POS[a].astype(np.int64)     # to side = pos1, from side = pos2 (R/computePairwiseMI.R:319-320)
+    cols = dict(pos1=pos1, pos2=pos2)
+    if cds_var is not None:
+        paint = np.asarray(cds_var.paint)
+        cols.update(clust1=paint[b], clust2=paint[a])
+    cols.update(len=circ_len(pos1.astype(float), pos2.astype(float), float(snp_dat.g)), MI=red["MI"], ARACNE=flags.astype(int))
+    df = pd.DataFrame(cols)
+    if not are_lrlinks_ordered:    # :115-117
+        df = df.iloc[np.argsort(-df["MI"].to_numpy(), kind="stable")].reset_index(drop=True)
+    return dict(lr_links_red=df, q13=info["q13"], thresholds=info["thresholds"], fallback=info["fallback"], n_pool=info["n_pool"])
+
+
+def genomewide_LDMap(eng, snp_dat, reducer=None, from_=None, to=None) -> dict:
+    """Numeric core of ``genomewide_LDMap``: the reduced, log10-scaled, 0..1-rescaled LD matrix ``htm`` with its row /
+    column labels (the reference's ``nms``: pos_vec[seq(1, n, by = reducer - 1)][1:B], R/LDSummaryPlot.R:95-96)."""
+    if reducer is not None and reducer < 0:     # :30-35
+        warnings.warn("<reducer> for genomewide_LDMap should be >0, set to default")
+        reducer = None
+    if (from_ is None) != (to is None):         # :37-38
+        raise ValueError("If <from> is provided, <to> must be provided as well!" if to is None else
+                         "If <to> is provided, <from> must be provided as well!")
+    if from_ is not None:                       # :43-47
+        if to <= from_:
+            raise ValueError("<to> must be greater than <from>!")
+        if from_ < 0 or to < 0:
+            raise ValueError("<from> and <to> must be positive values")
+        from_, to = int(round(from_)), int(round(to))
+    r = 0 if reducer is None else int(np.round(reducer))
+    htm, n_pos, r = eng.ldmap(r, from_ or 0, to or 0)
+    return dict(htm=htm, n_pos=n_pos, reducer=r)

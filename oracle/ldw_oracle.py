@@ -760,3 +760,81 @@ def perform_mi_computation(states, POS, g, r, uqe, hdw, paint, nclust, sr_dist=2
         red = {k: v[o] for k, v in red.items()}
     res.sr_links_red = red
     return res
+
+
+# --------------------------------------------------------------------------
+# §8 f rank 4  analyse_long_range_links (numeric core)      R/lr_analyser.R:72-118
+# --------------------------------------------------------------------------
+def analyse_long_range_links(lr: dict, sr: dict, min_links: int = 5000, are_lrlinks_ordered: bool = False) -> dict:
+    """lr / sr: dicts of arrays pos1, pos2, MI (lr may carry more columns of the same length).  Returns the outlier
+    links (rows of lr, re-ordered like the reference: descending MI unless are_lrlinks_ordered), their ARACNE flags,
+    the Tukey quantiles / thresholds and whether the "~5000 top links" fallback (:97-102) was taken."""
+    mi = np.asarray(lr["MI"], dtype=np.float64)
+    q13 = np.array([quantile7(mi, 0.25), quantile7(mi, 0.75)])                     # :72
+    iqr = q13[1] - q13[0]                                                           # :73
+    thresholds = q13[1] + np.array([1.5, 3.0]) * iqr                                # :74
+    keep = mi > thresholds.min()                                                    # :91
+    fallback = False
+    if keep.sum() < min_links and len(mi) >= min_links:                             # :94
+        fallback = True
+        # :97; the reference only gets here with >= 5000 rows, where both probabilities are in [0, 1]; a caller-chosen
+        # min_links below 5000 may not be, so they are clamped at 0
+        thresholds = np.array([quantile7(mi, max(0.0, 1 - (1 / len(mi)) * 4000)), quantile7(mi, max(0.0, 1 - (1 / len(mi)) * 5000))])
+        keep = mi > thresholds.min()                                                # :98
+    rows = np.nonzero(keep)[0]
+    red = {k: np.asarray(v)[rows] for k, v in lr.items()}
+    # ARACNE pool: rbind(lr, sr)[MI > min(thresholds)]                              :106-109
+    cp1 = np.concatenate([np.asarray(lr["pos1"], dtype=np.float64), np.asarray(sr["pos1"], dtype=np.float64)])
+    cp2 = np.concatenate([np.asarray(lr["pos2"], dtype=np.float64), np.asarray(sr["pos2"], dtype=np.float64)])
+    cmi = np.concatenate([mi, np.asarray(sr["MI"], dtype=np.float64)])
+    m = cmi > thresholds.min()
+    aracne = run_aracne(np.asarray(red["pos1"], dtype=np.float64), np.asarray(red["pos2"], dtype=np.float64), red["MI"],
+                        cp1[m], cp2[m], cmi[m])                                      # :111
+    if not are_lrlinks_ordered:                                                     # :115-117: order(MI, decreasing = T), stable
+        o = np.argsort(-np.asarray(red["MI"], dtype=np.float64), kind="stable")
+        red = {k: v[o] for k, v in red.items()}
+        aracne, rows = aracne[o], rows[o]
+    return dict(red=red, rows=rows, ARACNE=aracne, q13=q13, thresholds=thresholds, fallback=fallback, n_pool=int(m.sum()))
+
+
+# --------------------------------------------------------------------------
+# §8 f rank 4  genomewide_LDMap (numeric core)              R/LDSummaryPlot.R:55-106, .mat :176-178, .rescale01 :157-163
+# --------------------------------------------------------------------------
+def ld_map(lr: dict, sr: dict, reducer=None, from_=None, to=None) -> dict:
+    """Returns htm (B x B, rescaled to [0, 1]), pos_vec, reducer.  reducer <= 1 (the reference's unreduced branch) is
+    not restated."""
+    p_all = np.concatenate([np.asarray(lr["pos1"]), np.asarray(lr["pos2"]), np.asarray(sr["pos1"]), np.asarray(sr["pos2"])]).astype(np.int64)
+    pos_vec = np.unique(p_all)                                                      # :56 / :59 sort(unique(...))
+    L1, L2, S1, S2 = (np.asarray(lr["pos1"]).astype(np.int64), np.asarray(lr["pos2"]).astype(np.int64),
+                      np.asarray(sr["pos1"]).astype(np.int64), np.asarray(sr["pos2"]).astype(np.int64))
+    LM, SM = np.asarray(lr["MI"], dtype=np.float64), np.asarray(sr["MI"], dtype=np.float64)
+    if from_ is not None:
+        pos_vec = pos_vec[(pos_vec < to) & (pos_vec > from_)]                       # :62
+        kl = (L1 >= from_) & (L1 <= to) & (L2 >= from_) & (L2 <= to)                # :66
+        ks = (S1 >= from_) & (S1 <= to) & (S2 >= from_) & (S2 <= to)                # :67
+        L1, L2, LM, S1, S2, SM = L1[kl], L2[kl], LM[kl], S1[ks], S2[ks], SM[ks]
+    n = len(pos_vec)
+    def idx(p):                                                                     # as.numeric(factor(p, levels = pos_vec)) - 1, NA -> -1
+        i = np.searchsorted(pos_vec, p)
+        ok = (i < n) & (pos_vec[np.minimum(i, n - 1)] == p)
+        return np.where(ok, i, -1)
+    i = np.concatenate([idx(L1), idx(L2), idx(S1), idx(S2)])                        # :78
+    j = np.concatenate([idx(L2), idx(L1), idx(S2), idx(S1)])                        # :79
+    x = np.concatenate([LM, LM, SM, SM])                                            # :80
+    ok = (i >= 0) & (j >= 0)       # a link touching a window edge has no level in pos_vec (the reference would stop there)
+    i, j, x = i[ok], j[ok], x[ok]
+    r = int(np.round(n / 1e3)) if reducer is None else int(np.round(reducer))       # :83-87 (np.round = half-to-even like R)
+    if r <= 1:
+        raise ValueError("reducer <= 1: unreduced branch not restated")
+    B = n // r                                                                      # matrix(..., n, n/r): ncol truncates
+    # .mat(n, r): column k is 1 on rows [k r, (k+1) r) — recycling c(rep(1, r), rep(0, n)) down n-row columns shifts the
+    # run of ones by r per column; rows beyond B r belong to no column
+    bi, bj = i // r, j // r
+    keep = (bi < B) & (bj < B)
+    red = np.zeros((B, B))
+    np.add.at(red, (bi[keep], bj[keep]), x[keep])                                   # crossprod(x, crossprod(sprs, x)) :93
+    htm = red / r ** 2                                                              # :94
+    htm = np.log10(htm + 1e-5)                                                      # :108
+    mv = htm.min()
+    htm = (htm - mv) / (htm.max() - mv)                                             # :109 .rescale01
+    return dict(htm=htm, pos_vec=pos_vec, reducer=r)

@@ -103,3 +103,21 @@ mergeNsort_sr_links_device <- function(snp.dat, cds_var, sr_dist, srp_cutoff, ru
                    ARACNE = r[[9]])
   df[order(r[[7]], ifelse(r[[7]], r[[6]], r[[5]]), r[[1]]), ]                    # reference row order (:470-486)
 }
+
+# Numeric core of analyse_long_range_links (R/lr_analyser.R:72-118) on the tables the device holds after
+# perform_MI_computation(): lr_links_red with its ARACNE column, in the reference's order.
+analyse_long_range_links_device <- function(snp.dat, cds_var, are_lrlinks_ordered = F) {
+  r <- .Call("ldwamd_lr_tukey_aracne", 5000)
+  if (r[[8]]) warning("Not enough lr links pass the Tukey criteria, ~5000 top links were retained instead")
+  pos2 <- as.numeric(snp.dat$POS[r[[2]] + 1]); pos1 <- as.numeric(snp.dat$POS[r[[3]] + 1])
+  df <- data.frame(pos1 = pos1, pos2 = pos2, clust1 = cds_var$paint[r[[3]] + 1], clust2 = cds_var$paint[r[[2]] + 1],
+                   len = 0.5 * snp.dat$g - abs((pos1 - pos2) %% snp.dat$g - 0.5 * snp.dat$g), MI = r[[4]], ARACNE = r[[5]])
+  if (!are_lrlinks_ordered) { df <- df[order(df$MI, decreasing = T), ]; rownames(df) <- NULL }
+  list(lr_links_red = df, thresholds = r[[7]])
+}
+
+# Numeric core of genomewide_LDMap (R/LDSummaryPlot.R:55-109): the matrix heatmap3 is given.
+genomewide_LDMap_device <- function(reducer = NULL, from = NULL, to = NULL) {
+  .Call("ldwamd_ldmap", if (is.null(reducer)) 0L else as.integer(round(reducer)), if (is.null(from)) 0L else as.integer(round(from)),
+        if (is.null(to)) 0L else as.integer(round(to)))
+}

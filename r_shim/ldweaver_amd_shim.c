@@ -155,7 +155,53 @@ SEXP ldwamd_sr_pvalues_aracne(SEXP nclust, SEXP mean_dist, SEXP shape, SEXP srp_
     return res;
 }
 
+/* analyse_long_range_links (R/lr_analyser.R:72-111) on the device-resident tables:
+ * list(row, a, b, MI, ARACNE, q13, thresholds, fallback) with the outlier links in lr-table order. */
+SEXP ldwamd_lr_tukey_aracne(SEXP min_links) {
+    ldw_ctx *c = ctx_or_stop();
+    double q13[2], thr[2];
+    int fallback = 0;
+    int64_t n_red = 0, n_pool = 0;
+    CHK(ldw_lr_tukey(c, (int64_t)asReal(min_links), q13, thr, &fallback, &n_red, &n_pool));
+    const R_xlen_t n = (R_xlen_t)n_red;
+    SEXP res = PROTECT(allocVector(VECSXP, 8));
+    SEXP row = PROTECT(allocVector(REALSXP, n)), a = PROTECT(allocVector(INTSXP, n)), b = PROTECT(allocVector(INTSXP, n));
+    SEXP mi = PROTECT(allocVector(REALSXP, n)), ar = PROTECT(allocVector(REALSXP, n));
+    SEXP q = PROTECT(allocVector(REALSXP, 2)), t = PROTECT(allocVector(REALSXP, 2)), fb = PROTECT(ScalarLogical(fallback));
+    int64_t *r64 = (int64_t *)R_alloc((size_t)n + 1, sizeof(int64_t));
+    unsigned char *f8 = (unsigned char *)R_alloc((size_t)n + 1, 1);
+    CHK(ldw_lr_reduced_fetch(c, n_red, r64, INTEGER(a), INTEGER(b), REAL(mi)));
+    memset(f8, 1, (size_t)n + 1);
+    if (n > 0) CHK(ldw_aracne_device(c, n_red, f8));
+    for (R_xlen_t i = 0; i < n; ++i) {
+        REAL(row)[i] = (double)r64[i] + 1;
+        REAL(ar)[i] = f8[i];
+    }
+    REAL(q)[0] = q13[0]; REAL(q)[1] = q13[1]; REAL(t)[0] = thr[0]; REAL(t)[1] = thr[1];
+    SEXP parts[8] = {row, a, b, mi, ar, q, t, fb};
+    for (int k = 0; k < 8; ++k) SET_VECTOR_ELT(res, k, parts[k]);
+    UNPROTECT(9);
+    return res;
+}
+
+/* genomewide_LDMap (R/LDSummaryPlot.R:55-109): the reduced, log10-scaled, rescaled B x B matrix `htm`;
+ * attributes n_pos, reducer.  reducer = 0: the reference's default; from = to = 0: genome-wide. */
+SEXP ldwamd_ldmap(SEXP reducer, SEXP from, SEXP to) {
+    ldw_ctx *c = ctx_or_stop();
+    int64_t n_pos = 0;
+    int32_t r = 0, B = 0;
+    CHK(ldw_ldmap(c, asInteger(reducer), asInteger(from), asInteger(to), &n_pos, &r, &B, NULL, 0));
+    SEXP htm = PROTECT(allocMatrix(REALSXP, B, B));
+    CHK(ldw_ldmap(c, asInteger(reducer), asInteger(from), asInteger(to), &n_pos, &r, &B, REAL(htm), (int64_t)B * B));
+    setAttrib(htm, install("n_pos"), ScalarReal((double)n_pos));
+    setAttrib(htm, install("reducer"), ScalarInteger(r));
+    UNPROTECT(1);
+    return htm;
+}
+
 static const R_CallMethodDef CallEntries[] = {
+    {"ldwamd_lr_tukey_aracne", (DL_FUNC)&ldwamd_lr_tukey_aracne, 1},
+    {"ldwamd_ldmap", (DL_FUNC)&ldwamd_ldmap, 3},
     {"ldwamd_sr_len_quantiles", (DL_FUNC)&ldwamd_sr_len_quantiles, 3},
     {"ldwamd_sr_excess_stats", (DL_FUNC)&ldwamd_sr_excess_stats, 2},
     {"ldwamd_sr_pvalues_aracne", (DL_FUNC)&ldwamd_sr_pvalues_aracne, 5},

@@ -563,3 +563,60 @@ def test_fp32_screen_loses_nothing(engine, synth, fused):
             for x, y in zip(out[0][which], out[mode][which]):
                 assert np.array_equal(x, y), (which, mode)
     assert len(out[0][1][2]) > 15000 and len(out[0][0][2]) > 0
+
+
+def _tables_as_dicts(engine, POS):
+    out = []
+    for which in (1, 0):
+        a, b, mi = engine.links(which)
+        out.append(dict(pos1=POS[b].astype(np.int64), pos2=POS[a].astype(np.int64), MI=mi, a=a, b=b))
+    return out   # lr, sr
+
+
+@pytest.mark.parametrize("min_links", [5000, 300])
+def test_lr_tukey_and_aracne_match_oracle(engine, synth, min_links):
+    """analyse_long_range_links' numeric core on the device-resident tables (quantiles type 7,
+    Tukey thresholds, the top-links fallback, outlier set, ARACNE against rbind(lr, sr)[MI > thr]) vs the oracle."""
+    _setup(engine, synth)
+    POS, g = synth["POS"], synth["g"]
+    approx = orc.lr_links_approx(POS, g, 20000.0)
+    engine.mi_all_pairs(np.array(orc.make_blocks(512, 200), dtype=np.int32), 20000.0, 6000.0, approx)
+    lr, sr = _tables_as_dicts(engine, POS)
+    assert len(lr["MI"]) >= 5000
+    ref = orc.analyse_long_range_links({k: lr[k] for k in ("pos1", "pos2", "MI")}, sr, min_links=min_links)
+    info = engine.lr_tukey(min_links)
+    assert info["fallback"] == ref["fallback"] == (min_links == 5000)
+    assert np.array_equal(info["q13"], ref["q13"]) and np.array_equal(info["thresholds"], ref["thresholds"])   # same order statistics, same arithmetic
+    assert info["n_red"] == len(ref["rows"]) > 0 and info["n_pool"] == ref["n_pool"]
+    red = engine.lr_reduced()
+    flags = engine.aracne_device()
+    o = np.argsort(-red["MI"], kind="stable")
+    assert np.array_equal(red["row"][o], ref["rows"])
+    assert np.array_equal(flags[o], ref["ARACNE"])
+    assert 0 < flags.sum() < len(flags)          # both outcomes occur
+    # the host mirror with the reference's column layout
+    from ldweaver_amd import lr as LR
+    sd = SnpDat(states=synth["states"], POS=POS, g=g, uqe=synth["uqe"], r=synth["r"])
+    with pytest.warns(UserWarning) if ref["fallback"] else np.errstate():
+        out = LR.analyse_long_range_links(engine, sd, CdsVar(paint=synth["paint"], nclust=3), min_links=min_links)
+    df = out["lr_links_red"]
+    assert list(df.columns) == ["pos1", "pos2", "clust1", "clust2", "len", "MI", "ARACNE"]
+    assert np.array_equal(df["pos1"].to_numpy(), ref["red"]["pos1"]) and np.array_equal(df["ARACNE"].to_numpy().astype(bool), ref["ARACNE"])
+
+
+def test_ldmap_matches_oracle(engine, synth):
+    """genomewide_LDMap's numeric core (rank of positions, block sums with the .mat kernel, log10, rescale) vs the
+    oracle; genome-wide with an explicit reducer and windowed with the default one refused / accepted like the reference."""
+    _setup(engine, synth)
+    POS, g = synth["POS"], synth["g"]
+    approx = orc.lr_links_approx(POS, g, 20000.0)
+    engine.mi_all_pairs(np.array(orc.make_blocks(512, 200), dtype=np.int32), 20000.0, 6000.0, approx)
+    lr, sr = _tables_as_dicts(engine, POS)
+    for reducer, win in ((7, None), (16, None), (5, (int(POS[40]), int(POS[400])))):
+        ref = orc.ld_map(lr, sr, reducer=reducer, from_=win[0] if win else None, to=win[1] if win else None)
+        htm, n_pos, r = engine.ldmap(reducer, *(win or (0, 0)))
+        assert n_pos == len(ref["pos_vec"]) and r == ref["reducer"] and htm.shape == ref["htm"].shape
+        assert np.abs(htm - ref["htm"]).max() < 1e-12      # fp64 atomics: summation order differs
+        assert htm.min() == 0.0 and htm.max() == 1.0 and np.array_equal(htm, htm.T)
+    with pytest.raises(RuntimeError):
+        engine.ldmap(0)          # default reducer round(512 / 1000) = 1 <= 1: the unreduced branch is refused

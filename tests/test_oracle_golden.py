@@ -111,3 +111,32 @@ def test_aracne_helpers():
     # triangle X-Z weakest -> indirect
     p1 = np.array([10., 10., 20.]); p2 = np.array([20., 30., 30.]); mi = np.array([0.1, 0.5, 0.4])
     assert list(orc.run_aracne(p1, p2, mi, p1, p2, mi)) == [False, True, True]
+
+
+def test_lr_postprocessing_oracle_small_cases():
+    """Hand-checkable cases of the rank-4 restatements: Tukey thresholds / fallback, and the .mat block kernel."""
+    rng = np.random.default_rng(3)
+    n = 40
+    mi = np.concatenate([rng.uniform(0.0, 0.1, n - 4), [0.5, 0.6, 0.7, 0.8]])
+    p1 = np.arange(1, n + 1) * 10
+    p2 = p1 + 100000
+    lr = dict(pos1=p1, pos2=p2, MI=mi)
+    sr = dict(pos1=np.array([10, 20]), pos2=np.array([15, 25]), MI=np.array([0.9, 0.01]))
+    out = orc.analyse_long_range_links(lr, sr, min_links=5000)
+    q1, q3 = np.quantile(mi, [0.25, 0.75])           # numpy's default is type 7 too
+    assert np.allclose(out["q13"], [q1, q3], rtol=0, atol=1e-15) and not out["fallback"]
+    assert np.allclose(out["thresholds"], q3 + np.array([1.5, 3.0]) * (q3 - q1))
+    assert set(out["rows"]) == {36, 37, 38, 39} and list(out["red"]["MI"]) == [0.8, 0.7, 0.6, 0.5]
+    assert out["ARACNE"].all()                        # no common neighbours anywhere
+    assert out["n_pool"] == 5                         # 4 outliers + the sr link with MI 0.9
+    # fallback: table of >= min_links rows of which too few pass
+    out = orc.analyse_long_range_links(lr, sr, min_links=30)
+    assert out["fallback"] and out["thresholds"][1] <= out["thresholds"][0]
+    # block kernel of .mat(n, r): n = 7 positions, r = 3 -> B = 2 columns, the 7th position belongs to none
+    lr = dict(pos1=np.array([1, 2, 7]), pos2=np.array([4, 3, 1]), MI=np.array([1.0, 2.0, 4.0]))
+    sr = dict(pos1=np.array([5]), pos2=np.array([6]), MI=np.array([8.0]))
+    m = orc.ld_map(lr, sr, reducer=3)
+    assert list(m["pos_vec"]) == [1, 2, 3, 4, 5, 6, 7] and m["htm"].shape == (2, 2)
+    raw = np.array([[2 * 2.0, 1.0], [1.0, 2 * 8.0]]) / 9.0      # (2,3) inside block 0 twice, (1,4) across, (5,6) inside block 1; (7,1) dropped
+    lg = np.log10(raw + 1e-5)
+    assert np.allclose(m["htm"], (lg - lg.min()) / (lg.max() - lg.min()))
