@@ -66,6 +66,8 @@ int ldw_ctx_last_timing(ldw_ctx *ctx, double ms_out[4]);
  * the dense pass, out[1] = blocks run by the fused GEMM + epilogue kernel, out[2] = blocks run by the two-kernel path,
  * out[3] = pairs the fp32 screen would have lost (counted in ldw_set_screen mode 2 only; must stay 0) */
 int ldw_ctx_counters(ldw_ctx *ctx, int64_t out[4]);
+/* the same four, then out[4] = blocks run in the mixed-precision path (ldw_set_mixed), out[5..7] reserved */
+int ldw_ctx_counters2(ldw_ctx *ctx, int64_t out[8]);
 
 /* ---- (1) .ACGTN2num  — src/ACGTN2num_parallel.cpp:10-43, R/RcppExports.R:4-6 ------------ */
 /* nv: 5 x L doubles, column-major, mutated IN PLACE (host memory, as R hands it over);
@@ -162,6 +164,12 @@ int ldw_set_overlap(ldw_ctx *ctx, int on);
  * with occupancy the fused kernel cannot have.  Link tables are identical either way up to the rounding of MI (<= 1e-15:
  * on diagonal blocks the fused kernel may meet a pair in mirrored roles). */
 int ldw_set_fused(ldw_ctx *ctx, int on);
+/* Mixed precision (default on; 5 weight limbs, two-kernel path, speculative blocks): the block-wide co-occurrence GEMM runs
+ * with the 3 HIGH limbs of the fixed-point weights only — all the fp32 screen needs; its margin is widened by a rigorous
+ * bound of what the low limbs can add — and the exact joint sums of the units the screen lists (3-4 % of an off-diagonal
+ * block, the short-range band of a diagonal one) get their 2 low limbs from a gathered GEMM over just those rows:
+ * sum = (high << 16) + low, the same integers as the 5-limb GEMM.  Every MI that is emitted is computed from exact sums. */
+int ldw_set_mixed(ldw_ctx *ctx, int on);
 /* fp32 screen in front of the fp64 MI evaluation, in blocks that run the speculative selection: a long-range pair
  * only matters if its MI reaches the guessed histogram bucket, so MI is first bounded in fp32 (v_log_f32, proven
  * error < 1.3e-5 nats, margin 2e-4) and the exact value is computed for the waves that hold a pair which may pass, or a

@@ -64,6 +64,8 @@ _SIGS = {
     "ldw_links_end": (C.c_int, [_p]),
     "ldw_set_overlap": (C.c_int, [_p, C.c_int]),
     "ldw_set_fused": (C.c_int, [_p, C.c_int]),
+    "ldw_set_mixed": (C.c_int, [_p, C.c_int]),
+    "ldw_ctx_counters2": (C.c_int, [_p, _p]),
     "ldw_set_screen": (C.c_int, [_p, C.c_int]),
     "ldw_links_count": (C.c_int, [_p, C.c_int, C.POINTER(_i64)]),
     "ldw_links_fetch": (C.c_int, [_p, C.c_int, _p, _p, _p, _i64, C.c_int]),

@@ -257,7 +257,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     ldw::DevBuf *bufs[] = {&c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
-                           &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->perm_t, &c->scr_units, &c->hist[0], &c->hist[1], &c->colcnt, &c->cand_key[0], &c->cand_key[1],
+                           &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->perm_t, &c->scr_units, &c->slot_pfix_hi, &c->glo, &c->lo_rows, &c->lo_meta, &c->hist[0], &c->hist[1], &c->colcnt, &c->cand_key[0], &c->cand_key[1],
                            &c->cand_val[0], &c->cand_val[1], &c->cand_key2, &c->cand_val2, &c->scratch, &c->small, &c->sr_a, &c->sr_b,
                            &c->sr_mi, &c->lr_a, &c->lr_b, &c->lr_mi, &c->srm_pack, &c->srm_key, &c->srm_pack2, &c->srm_key2, &c->srm_pay, &c->srm_pay2, &c->srm_off,
                            &c->srm_q, &c->srm_n, &c->srm_md, &c->srm_part, &c->srm_shape, &c->srm_cnt, &c->red_row, &c->red_meta,
@@ -312,6 +312,17 @@ int ldw_ctx_sync(ldw_ctx *c) {
 int ldw_ctx_last_timing(ldw_ctx *c, double ms_out[4]) {
     LDW_REQUIRE(c && ms_out, LDW_ERR_ARG, "ldw_ctx_last_timing: null argument");
     for (int i = 0; i < 4; ++i) ms_out[i] = c->last_ms[i];
+    return LDW_OK;
+}
+
+int ldw_ctx_counters2(ldw_ctx *c, int64_t out[8]) {
+    LDW_REQUIRE(c && out, LDW_ERR_ARG, "ldw_ctx_counters2: null argument");
+    out[0] = c->spec_misses;
+    out[1] = c->fused_blocks;
+    out[2] = c->unfused_blocks;
+    out[3] = c->screen_violations;
+    out[4] = c->mixed_blocks;
+    out[5] = out[6] = out[7] = 0;
     return LDW_OK;
 }
 
@@ -539,6 +550,21 @@ int ldw_set_weights(ldw_ctx *c, const double *hdw, int64_t N, int nlimbs) {
         LDW_REQUIRE(rem == 0, LDW_ERR_ARG, "ldw_set_weights: internal: weight %g does not fit %d limbs at F=%d", v[s], nlimbs, F);
     }
     c->total_fixed = total;
+    // Mixed-precision path (5 limbs only): the block-wide GEMM carries the 3 high limbs, V = V_hi * 2^16 + V_lo.
+    // lo_abs_sum = sum |V_lo| 2^-F bounds what the low limbs can add to any joint sum.
+    c->h_vfixed_hi.assign((size_t)c->Npad, 0);
+    c->total_fixed_hi = 0;
+    c->lo_abs_sum = 0;
+    if (nlimbs == 5) {
+        long double lo_abs = 0;
+        for (int64_t s = 0; s < N; ++s) {
+            const int64_t lo = (int64_t)dig[s] + 256 * (int64_t)dig[(size_t)c->Npad + s];
+            c->h_vfixed_hi[s] = (c->h_vfixed[s] - lo) / 65536;   // exact: the remainder is what limbs 2..4 encode
+            c->total_fixed_hi += c->h_vfixed_hi[s];
+            lo_abs += (long double)(lo < 0 ? -lo : lo);
+        }
+        c->lo_abs_sum = (double)(lo_abs * (long double)std::ldexp(1.0, -F));
+    }
     if (int rc = c->digits.reserve(dig.size())) return rc;
     if (int rc = c->vfixed.reserve((size_t)c->Npad * 8)) return rc;
     LDW_HIP(hipMemcpyAsync(c->digits.p, dig.data(), dig.size(), hipMemcpyHostToDevice, c->stream));
@@ -651,6 +677,30 @@ int ensure_rows(ldw_ctx *c) {
     LDW_HIP(hipMemcpyAsync(c->row0.p, c->h_row0.data(), (size_t)(L + 1) * 4, hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipMemcpyAsync(c->slot_meta.p, meta.data(), (size_t)L * 4, hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipMemcpyAsync(c->slot_pfix.p, spf.data(), (size_t)L * 40, hipMemcpyHostToDevice, c->stream));
+    if (c->nlimbs == 5) {   // marginals of the high-limb weights, by slot, for the screen of the mixed-precision path
+        ldw::DevBuf d_vhi, d_phi, d_cnt2;
+        int rc = LDW_OK;
+        if ((rc = d_vhi.reserve((size_t)Npad * 8)) || (rc = d_phi.reserve((size_t)L * 40)) || (rc = d_cnt2.reserve((size_t)L * 20)) ||
+            (rc = c->slot_pfix_hi.reserve((size_t)L * 40))) {
+            d_vhi.release(); d_phi.release(); d_cnt2.release();
+            return rc;
+        }
+        hipError_t he = hipMemcpyAsync(d_vhi.p, c->h_vfixed_hi.data(), (size_t)Npad * 8, hipMemcpyHostToDevice, c->stream);
+        hipLaunchKernelGGL(k_counts_marginals, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, c->stream, c->states.as<uint8_t>(), L, Npad,
+                           d_vhi.as<int64_t>(), d_cnt2.as<int32_t>(), d_phi.as<int64_t>());
+        std::vector<int64_t> phs((size_t)L * 5), sph((size_t)L * 5, 0);
+        if (he == hipSuccess) he = hipMemcpyAsync(phs.data(), d_phi.p, (size_t)L * 40, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        d_vhi.release(); d_phi.release(); d_cnt2.release();
+        if (he != hipSuccess) return ldw::hip_fail(he, "high-limb marginals", __FILE__, __LINE__);
+        for (int64_t a = 0; a < L; ++a) {
+            const uint32_t m = meta[a];
+            const int n = (int)(m & 7);
+            for (int i = 0; i <= n; ++i) sph[a * 5 + i] = phs[a * 5 + ((m >> (8 + 3 * i)) & 7)];
+        }
+        LDW_HIP(hipMemcpyAsync(c->slot_pfix_hi.p, sph.data(), (size_t)L * 40, hipMemcpyHostToDevice, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+    }
     // rows R .. R+TILE-1 stay zero: tile padding of the row lists points at row R
     LDW_HIP(hipMemsetAsync(c->Mbits.as<uint64_t>() + (size_t)R * c->KW, 0, (size_t)TILE * c->KW * 8, c->stream));
     if (R > 0) {

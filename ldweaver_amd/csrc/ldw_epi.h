@@ -123,6 +123,7 @@ struct EmitArgs {
     // fp32 screen of the epilogue (speculative mode only): 0 off, 1 on, 2 verify
     int scr_mode, scr_shift;             // fixed-point sums are cut to their top 31 bits: n >> scr_shift
     float scr_scale;                     // 2^scr_shift * 2^-frac_bits
+    float scr_eps;                       // margin of the screen: SCREEN_EPS (+ the bound of the low limbs in the mixed path)
     unsigned long long *scr_viol;        // verify mode: pairs the screen would have lost
 };
 
@@ -189,9 +190,28 @@ __device__ __forceinline__ void emit_pair_spec(const EmitArgs &E, const ColInfo 
 // ------------------------------------------------------------------------------------------------
 constexpr int EPI_COLS = 128;  // to-side SNPs per workgroup (4 waves x 32)
 
+// Mixed-precision path: geometry of the per-tile unit lists and of the low-limb joint sums of one block.
+// A from-TILE is the 64 from-side SNPs of one epilogue wave (perm_f order); the to-side SNPs are split by row-slot class
+// lc = 0, 1, 2 (1, 2, 4 indicator-row slots).  Units listed by k_mi_screen go to tl[tile * nt + uoff[lc] + k]; the
+// gathered GEMM then gives unit k of (tile, lc) the low-limb rows rowbase[lc] + k * c .. + c of that tile, each
+// 64 * cmax_f[tile] ints long (from-side SNP `lane`, slot i at lane * cmax + i), starting at glo + tile_base[tile].
+struct LoGeom {
+    int32_t n_lc[3], uoff[3], rowbase[3];
+    int32_t RTlo, ntiles, on;          // low-limb rows per tile (sum of the classes' rows padded to 128); on: path active
+    const int32_t *cmax_f;             // [ntiles] widest row-slot class among the tile's SNPs
+    const int64_t *tile_base;          // [ntiles] offset of the tile's low-limb block in glo (ints)
+    unsigned int *cnt;                 // [ntiles * 3] listed units per (tile, class)
+    uint32_t *tl;                      // [ntiles * nt] per-tile lists of column slots q
+    int32_t *glo;                      // low-limb joint sums
+    const int64_t *slot_pfix_hi;       // [L][5] marginals of the high-limb weights by slot
+    int hi_shift;                      // G holds sums of V_hi = (V - V_lo) / 2^hi_shift
+};
+__host__ __device__ __forceinline__ int lo_class(int nrows) { return nrows <= 1 ? 0 : (nrows == 2 ? 1 : 2); }
+
 struct EpiArgs {
     const int64_t *G;
     int RFpad;
+    LoGeom lo;
     const int32_t *idx_f, *lrow_f, *idx_t, *lrow_t;
     int nf, nt;
     const uint32_t *slot_meta;
@@ -214,6 +234,18 @@ struct FusedArgs {
     EpiArgs A;
 };
 int launch_fused(ldw_ctx *ctx, const FusedArgs &F, int RFpad, int RTpad, int nlimbs, hipStream_t stream);
+// arguments of the gathered low-limb GEMM (ldw_gemm_bits.hip)
+struct LoGemmArgs {
+    const uint64_t *Mbits;
+    int64_t KW, Kpad;
+    const int8_t *digits_lo;   // limbs 0 and 1
+    const int32_t *perm_f, *idx_f, *perm_t, *idx_t, *row0;
+    int32_t zero_row, nf, nt;
+    const int32_t *tf_list;    // (tile, fs) pairs: the 64-slot from-side sub-tiles that exist (fs < cmax_f[tile])
+    LoGeom lo;
+};
+
+int launch_gemm_lo_units(ldw_ctx *ctx, const LoGemmArgs &P, int n_tf, hipStream_t stream);
 
 // everything the epilogue needs about one to-side SNP, staged in LDS once per workgroup so that the
 // per-pair loop has no dependent global loads except its G entries
@@ -243,12 +275,27 @@ struct RowSide {
 
 // MI of one pair.  NAM / NB bound the unrolled slot loops (na <= NAM for every lane of the wave, nb <= NB);
 // the run-time slot counts still mask the individual cells.
-// Gp points at the pair's first joint sum G(slot 0 of a, slot 0 of b); slot i of the from-side SNP and slot j of the
-// to-side SNP are at Gp[i * si + j * sj] (global G block: si = 1, sj = RFpad, or transposed on the mirrored half of a
-// diagonal block; LDS tile of the fused kernel: si = 1, sj = its padded row stride).
+// Where the joint sums of one pair live.  g points at G(slot 0 of a, slot 0 of b); slot i of the from-side SNP and slot j of
+// the to-side SNP are at g[i * si + j * sj] (global G block: si = 1, sj = RFpad, or transposed on the mirrored half of a
+// diagonal block; LDS tile of the fused kernel: si = 1, sj = its padded row stride).  In the mixed-precision path the
+// block-wide GEMM only carries the HIGH limbs of the weights (g, to be shifted left by `shift` bits) and the low limbs of
+// the listed units come from the gathered GEMM (l, int32, own strides): sum = (g << shift) + l.
+struct GAcc {
+    const int64_t *g;
+    int64_t si, sj;
+    const int32_t *l;
+    int64_t li, lj;
+    int shift;
+    __device__ __forceinline__ int64_t at(int i, int j) const {
+        const int64_t v = g[i * si + j * sj];
+        return l ? (v << shift) + (int64_t)l[i * li + j * lj] : v;
+    }
+};
+__device__ __forceinline__ GAcc gacc_plain(const int64_t *g, int64_t si, int64_t sj) { return GAcc{g, si, sj, nullptr, 0, 0, 0}; }
+
 template <int NAM, int NB>
 __device__ __forceinline__ double pair_mi(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc,
-                                          bool square, const int64_t *Gp, int64_t si, int64_t sj) {
+                                          bool square, const GAcc &Ga) {
     const int na = R.na, nb = M.mb & 7;
     const uint32_t ma = R.ma, mb = M.mb;
     // joint sums of the row slots (from G), their row / column sums
@@ -262,7 +309,7 @@ __device__ __forceinline__ double pair_mi(const EpiArgs &A, const RowSide &R, co
 #pragma unroll
         for (int i = 0; i < NAM; ++i) {
             int64_t v = 0;
-            if (i < na && j < nb) v = Gp[i * si + j * sj];
+            if (i < na && j < nb) v = Ga.at(i, j);
             g[i][j] = v;
             rs[i] += v;
             cs[j] += v;
@@ -330,8 +377,7 @@ struct FullCells {
 };
 
 template <int NA, int NB>
-__device__ __forceinline__ void full_cells(const RowSide &R, const ColMeta &M, const int64_t *Gp, int64_t si, int64_t sj,
-                                           FullCells<NA, NB> &C) {
+__device__ __forceinline__ void full_cells(const RowSide &R, const ColMeta &M, const GAcc &Ga, FullCells<NA, NB> &C) {
     int64_t rs[NA > 0 ? NA : 1], cs[NB > 0 ? NB : 1];
 #pragma unroll
     for (int i = 0; i < NA; ++i) rs[i] = 0;
@@ -341,7 +387,7 @@ __device__ __forceinline__ void full_cells(const RowSide &R, const ColMeta &M, c
     for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int64_t v = Gp[i * si + j * sj];
+            const int64_t v = Ga.at(i, j);
             C.n[i][j] = v;
             rs[i] += v;
             cs[j] += v;
@@ -424,9 +470,9 @@ __device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSi
 
 template <int NA, int NB>
 __device__ __forceinline__ double pair_mi_full(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc,
-                                               bool square, const int64_t *Gp, int64_t si, int64_t sj) {
+                                               bool square, const GAcc &Ga) {
     FullCells<NA, NB> C;
-    full_cells<NA, NB>(R, M, Gp, si, sj, C);
+    full_cells<NA, NB>(R, M, Ga, C);
     return full_cells_mi<NA, NB>(A, R, M, pair_rxy(A, R, M, a_loc, b_loc, square), C);
 }
 

@@ -94,11 +94,11 @@ __device__ __forceinline__ bool fused_group(const EpiArgs &A, const FromMeta *fg
     bool act[U], need[U], is_sr[U];
     bool any = false;
     const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0, do_lr = A.E.do_lr != 0;
-    const float lo = (float)A.E.spec_lo - SCREEN_EPS;   // rounding of the difference is far inside the margin
+    const float lo = (float)A.E.spec_lo - A.E.scr_eps;   // rounding of the difference is far inside the margin
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         act[u] = t_ok && a_loc[u] >= 0 && (lower_only ? fpos0 + u * NA > tpos : a_loc[u] != b_loc);
-        full_cells<NA, NB>(R[u], M, gl0 + u * NA, 1, GS, C[u]);
+        full_cells<NA, NB>(R[u], M, gacc_plain(gl0 + u * NA, 1, GS), C[u]);
         rxy[u] = (rxy_q1 ? M.rq * R[u].rta : R[u].ra * M.rb) * 0.25;
         is_sr[u] = test_sr && col_is_sr(M.ci, a_loc[u]);
         const float ms = full_cells_screen<NA, NB>(A, R[u], M, rxy[u], C[u]);
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mi_fused_kernel(FusedArgs F) {
             const int fpos = bx * TILE_F4 + wv * 32 + fin;
             const bool act = t_ok && (lower_only ? fpos > tpos : a_loc != b_loc);
             if (__ballot(act) == 0ull) continue;
-            const double mi = pair_mi<4, 4>(A, R, M, a_loc, b_loc, square, gl + fin, 1, GS);
+            const double mi = pair_mi<4, 4>(A, R, M, a_loc, b_loc, square, gacc_plain(gl + fin, 1, GS));
             if (act) {
                 if (lower_only && a_loc < b_loc) {   // diagonal block, pair met in mirrored roles (row order is by class, not by index)
                     const ColInfo ci = A.E.cols[a_loc];

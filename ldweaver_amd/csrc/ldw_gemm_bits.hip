@@ -21,6 +21,8 @@
 //
 // Tiling: 128 (to side) x 64 (from side) rows per workgroup, 4 waves (2 x 2), 64 x 32 per wave = 2 MFMA tiles x J limbs.
 #include "ldw_internal.h"
+#include "ldw_dev.h"
+#include "ldw_epi.h"
 #include "ldw_gemm_tile.h"
 
 namespace ldw {
@@ -56,6 +58,90 @@ __global__ __launch_bounds__(256, 2) void gemm_bits_kernel(const uint64_t *__res
             *dst = accumulate ? (*dst + val) : val;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gathered low-limb GEMM of the mixed-precision path.  The block-wide GEMM runs with the 3 high limbs of the weights
+// only (all the fp32 screen needs: C4 1.14 instead of 1.73 ms per block); the exact joint sums of the few units the
+// screen lists (3-4 % of an off-diagonal block, the short-range band of a diagonal one) get their 2 low limbs here.
+// Workgroup (chunk, tile, fs): 128 low-limb rows of one from-tile — the indicator rows of up to 128 / c listed to-side
+// SNPs of one row-slot class c, read off the tile's unit list — against 64 of the tile's 64 * cmax from-side row slots.
+// Same K loop, J = 2, row lists built in LDS.  Output: int32 (|sum| <= N * 2^15).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_lo_units_kernel(LoGemmArgs P) {
+    // workgroup (x, y): y -> (tile, fs) through the host-built list of the 64-slot from-side sub-tiles that exist;
+    // x strides over the chunks of 128 low-limb rows that the tile's unit lists actually fill, class by class
+    const int tile = P.tf_list[2 * blockIdx.y], fs = P.tf_list[2 * blockIdx.y + 1];
+    const int cmax = P.lo.cmax_f[tile];
+    __shared__ GemmSmem<2> S;
+    __shared__ int32_t lrows[TILE + TILE_F4];
+    // chunk i of the tile (counted through the classes) goes to workgroup x = (i + y) mod gridDim.x: consecutive workgroup
+    // ids land on different XCDs, and most tiles fill only a few chunks — without the rotation by y all of them would
+    // sit on the first XCDs
+    int seq = (int)(blockIdx.y % gridDim.x);
+    for (int lc = 0; lc < 3; ++lc) {
+        const int cnt = (int)P.lo.cnt[tile * 3 + lc];
+        const int nch = (((cnt << lc) + TILE - 1) / TILE);
+        for (int ch = 0; ch < nch; ++ch, ++seq) {
+            if (seq % (int)gridDim.x != (int)blockIdx.x) continue;
+            const int k0 = (ch * TILE) >> lc;            // first unit of this chunk
+            const int r0 = P.lo.rowbase[lc] + ch * TILE; // its first low-limb row
+            __syncthreads();                             // the previous chunk's row lists and operand tiles are done with
+            {
+                const int t0 = threadIdx.x;
+                if (t0 < TILE) {
+                    const int kk = k0 + (t0 >> lc), j = t0 & ((1 << lc) - 1);
+                    int32_t row = P.zero_row;
+                    if (kk < cnt) {
+                        const int q = (int)P.lo.tl[(int64_t)tile * P.nt + P.lo.uoff[lc] + kk];
+                        const int snp = P.idx_t[P.perm_t[q]];
+                        if (j < P.row0[snp + 1] - P.row0[snp]) row = P.row0[snp] + j;
+                    }
+                    lrows[t0] = row;
+                } else if (t0 < TILE + TILE_F4) {
+                    const int p = fs * TILE_F4 + (t0 - TILE);
+                    const int ln = p / cmax, i = p - ln * cmax;
+                    const int pf = P.perm_f[tile * 64 + ln];
+                    int32_t row = P.zero_row;
+                    if (pf >= 0) {
+                        const int snp = P.idx_f[pf];
+                        if (i < P.row0[snp + 1] - P.row0[snp]) row = P.row0[snp] + i;
+                    }
+                    lrows[t0] = row;
+                }
+            }
+            __syncthreads();
+            constexpr int J = 2;
+            const uint64_t *__restrict__ Mbits = P.Mbits;
+            const int64_t KW = P.KW, Kpad = P.Kpad;
+            const int32_t *rowlist_t = lrows;
+            const int32_t *rowlist_f = lrows + TILE;
+            const int8_t *__restrict__ digits = P.digits_lo;
+            const int bx = 0, by = 0;
+#include "ldw_gemm_kloop.inc"
+
+            const int64_t ld = (int64_t)TILE_F4 * cmax;
+            int32_t *out = P.lo.glo + P.lo.tile_base[tile] + (int64_t)r0 * ld + fs * TILE_F4 + wn * 32 + frow;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int trow = wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    out[(int64_t)trow * ld] = acc[1][m][e] * 256 + acc[0][m][e];
+                }
+            }
+        }
+    }
+}
+
+int launch_gemm_lo_units(ldw_ctx *ctx, const LoGemmArgs &P, int n_tf, hipStream_t stream) {
+    LDW_REQUIRE(n_tf > 0 && n_tf <= 65535 && P.KW > 0 && P.KW % 2 == 0 && P.tf_list, LDW_ERR_ARG, "launch_gemm_lo_units: bad geometry");
+    // 32 workgroups per sub-tile stride over its chunks: the lists of an off-diagonal block fill ~5 chunks per tile, the
+    // short-range band of a diagonal block a few dozen, and the one tile of SNPs with >= 3 minor states (generic code,
+    // every unit listed) ~90 per sub-tile — that tile is the critical path
+    hipLaunchKernelGGL(gemm_lo_units_kernel, dim3(32, (unsigned)n_tf), dim3(256), 0, stream, P);
+    LDW_HIP(hipGetLastError());
+    return LDW_OK;
 }
 
 // bit rows: Mbits[row][w] bit i = (states[snp(row)][64 w + i] == state(row)); one thread per word

@@ -71,6 +71,11 @@ struct ldw_ctx {
     ldw::DevBuf digits;         // int8 [nlimbs][Npad] balanced base-256 digits of V_s
     ldw::DevBuf vfixed;         // int64 [Npad] quantised weights V_s (0 in the padding)
     std::vector<int64_t> h_vfixed;
+    // mixed-precision path (nlimbs == 5): V = V_hi * 2^16 + V_lo, V_hi = limbs 2..4
+    std::vector<int64_t> h_vfixed_hi;
+    int64_t total_fixed_hi = 0;
+    double lo_abs_sum = 0;      // sum_s |V_lo,s| * 2^-F: bound of the low limbs' contribution to any joint sum
+    int mixed = 1;              // 1: high-limb GEMM + gathered low-limb GEMM for the listed units in speculative blocks
 
     // ---- per-SNP meta ----
     bool have_meta = false;
@@ -87,6 +92,10 @@ struct ldw_ctx {
     ldw::DevBuf row0;            // int32 [L+1]: first row of each SNP
     ldw::DevBuf slot_meta;       // uint32 [L]: nrows (3 bits) | uq-by-slot (5 bits <<3) | slot states (5 x 3 bits << 8)
     ldw::DevBuf slot_pfix;       // int64 [L][5]: fixed-point marginal of the state in each slot
+    ldw::DevBuf slot_pfix_hi;    // the same for the high-limb weights V_hi (nlimbs == 5)
+    ldw::DevBuf glo;             // int32: low-limb joint sums of the listed units (gathered GEMM)
+    ldw::DevBuf lo_rows;         // int32 row lists of the gathered GEMM's workgroups
+    ldw::DevBuf lo_meta;         // per-block geometry of the unit lists (device copy)
     ldw::DevBuf counts;          // int32 [L][5] per-SNP state counts
     ldw::DevBuf pfix_state;      // int64 [L][5]: fixed-point marginal of each state (histogram engine)
     std::vector<int32_t> h_row0;
@@ -132,7 +141,7 @@ struct ldw_ctx {
     bool spec_seen[2] = {false, false};  // a block of this kind (off-diagonal, diagonal) has set its own guess
     std::vector<hipEvent_t> ev_pool;     // 4 timing events per block
     int spec_B_next[2] = {-1, -1};       // bucket guess for the speculative long-range gather: [off-diagonal, diagonal]
-    int64_t spec_misses = 0, fused_blocks = 0, unfused_blocks = 0, screen_violations = 0;
+    int64_t spec_misses = 0, fused_blocks = 0, unfused_blocks = 0, screen_violations = 0, mixed_blocks = 0;
     int screen = 1;                      // fp32 screen in front of the fp64 MI evaluation (0 off, 1 on, 2 verify)
     std::vector<ldw::BlockStat> stats;
 };

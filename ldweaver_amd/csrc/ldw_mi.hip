@@ -24,7 +24,10 @@ namespace ldw {
 
 // ---- pieces shared by k_mi_screen and k_mi_epilogue: both walk the block in the same units, one unit = the 64
 // ---- from-side SNPs of a wave (perm_f order) x one to-side SNP (perm_t order); both orders group equal slot counts.
-__device__ __forceinline__ void stage_cols(const EpiArgs &A, const int32_t *__restrict__ perm_t, bool square, ColMeta *cm) {
+// hi_cells (mixed-precision screen): the integer marginals pb / pa that the joint-table cells are derived from are those of
+// the high-limb weights, consistent with the high-limb G; the floating-point marginals stay the exact ones.
+__device__ __forceinline__ void stage_cols(const EpiArgs &A, const int32_t *__restrict__ perm_t, bool square, ColMeta *cm,
+                                           bool hi_cells = false) {
     if (threadIdx.x < EPI_COLS) {
         const int q = blockIdx.y * EPI_COLS + threadIdx.x;
         if (q < A.nt) {
@@ -41,6 +44,7 @@ __device__ __forceinline__ void stage_cols(const EpiArgs &A, const int32_t *__re
                 m.pb[j] = A.slot_pfix[(int64_t)m.sb * 5 + j];
                 m.pYd[j] = (double)m.pb[j] * A.scale;
                 m.pYf[j] = (float)m.pYd[j];
+                if (hi_cells) m.pb[j] = A.lo.slot_pfix_hi[(int64_t)m.sb * 5 + j];
             }
             m.pad2 = 0;
             if (A.E.cols) m.ci = A.E.cols[b_loc];
@@ -70,10 +74,11 @@ __device__ __forceinline__ void load_col(const EpiArgs &A, const int32_t *__rest
 
 // per-lane constants of the from-side SNP; returns whether the lane holds one
 __device__ __forceinline__ bool load_row_side(const EpiArgs &A, const int32_t *__restrict__ perm_f, bool square, int tile, RowSide &R,
-                                              int &a_loc) {
-    const int t = tile * 64 + (threadIdx.x & 63);
-    const bool a_ok = t < A.nf;
-    a_loc = perm_f[a_ok ? t : A.nf - 1];
+                                              int &a_loc, bool hi_cells = false) {
+    // perm_f is padded with -1 so that every tile of 64 holds SNPs of ONE slot-count class (build_perm_tiles)
+    const int pf = perm_f[tile * 64 + (threadIdx.x & 63)];
+    const bool a_ok = pf >= 0;
+    a_loc = a_ok ? pf : 0;
     R.sa = A.idx_f[a_loc];
     R.ma = A.slot_meta[R.sa];
     R.na = a_ok ? (int)(R.ma & 7) : 0;
@@ -85,6 +90,7 @@ __device__ __forceinline__ bool load_row_side(const EpiArgs &A, const int32_t *_
         R.pa[i] = A.slot_pfix[(int64_t)R.sa * 5 + i];
         R.pXd[i] = (double)R.pa[i] * A.scale;
         R.pXf[i] = (float)R.pXd[i];
+        if (hi_cells) R.pa[i] = A.lo.slot_pfix_hi[(int64_t)R.sa * 5 + i];
     }
     return a_ok;
 }
@@ -102,11 +108,10 @@ __device__ __forceinline__ bool col_is_fast(uint32_t mb) {
 
 // Row lists are ordered by slot-count class, not by SNP index, so on a diagonal block (symmetric G, tiles above
 // the diagonal of ROW positions skipped by the GEMM) the entry of a pair may only exist transposed.
-__device__ __forceinline__ const int64_t *g_entry(const EpiArgs &A, const RowSide &R, const ColMeta &M, int64_t &si, int64_t &sj) {
+__device__ __forceinline__ GAcc g_entry(const EpiArgs &A, const RowSide &R, const ColMeta &M) {
     const bool tr = A.E.lower_only && R.ra0 < (int64_t)M.rb0;
-    si = tr ? (int64_t)A.RFpad : 1;
-    sj = tr ? 1 : (int64_t)A.RFpad;
-    return A.G + (tr ? R.ra0 * A.RFpad + M.rb0 : (int64_t)M.rb0 * A.RFpad + R.ra0);
+    return gacc_plain(A.G + (tr ? R.ra0 * A.RFpad + M.rb0 : (int64_t)M.rb0 * A.RFpad + R.ra0), tr ? (int64_t)A.RFpad : 1,
+                      tr ? 1 : (int64_t)A.RFpad);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -125,9 +130,7 @@ __device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowS
     FullCells<NA, NB> C[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        int64_t si, sj;
-        const int64_t *Gp = g_entry(A, R, cmu[u], si, sj);
-        full_cells<NA, NB>(R, cmu[u], Gp, si, sj, C[u]);
+        full_cells<NA, NB>(R, cmu[u], g_entry(A, R, cmu[u]), C[u]);
     }
     const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0, do_lr = A.E.do_lr != 0;
     unsigned int bits = 0;
@@ -161,20 +164,22 @@ __device__ __forceinline__ unsigned int screen_cols_nb(int nb, const EpiArgs &A,
     return bits;
 }
 
-// unit list entry: from-tile * nt + column slot; bit 31: verify mode only, a unit the screen dismissed
-constexpr uint32_t UNIT_DISMISSED = 0x80000000u;
+// unit list entry (64 bits): from-tile * nt + column slot (bits 0-30), index k of the unit in its (tile, class) list (bits
+// 31-50) and the class (bits 51-52) in the mixed-precision path; bit 63: verify mode only, a unit the screen dismissed
+constexpr uint64_t UNIT_DISMISSED = 0x8000000000000000ull;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mi_screen(EpiArgs A, const int32_t *__restrict__ perm_f,
                                                                                             const int32_t *__restrict__ perm_t,
-                                                                                            uint32_t *__restrict__ units,
+                                                                                            uint64_t *__restrict__ units,
                                                                                             unsigned int *__restrict__ n_units) {
     __shared__ ColMeta cm[EPI_COLS];
     const bool square = A.nf == A.nt;
-    stage_cols(A, perm_t, square, cm);
+    const bool mixed = A.lo.on != 0;
+    stage_cols(A, perm_t, square, cm, mixed);
     __syncthreads();
     RowSide R;
     int a_loc, na0;
-    const bool a_ok = load_row_side(A, perm_f, square, blockIdx.x, R, a_loc);
+    const bool a_ok = load_row_side(A, perm_f, square, blockIdx.x, R, a_loc, mixed);
     const bool wave_full = wave_is_full(R, a_ok, na0);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c_first = wave * (EPI_COLS / 4);
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     n_it = n_it > EPI_COLS / 4 ? EPI_COLS / 4 : n_it;
     if (n_it <= 0) return;
     const bool rxy_q1 = A.quirk == LDW_QUIRK_REFERENCE;
-    const float lo = (float)A.E.spec_lo - SCREEN_EPS;
+    const float lo = (float)A.E.spec_lo - A.E.scr_eps;
     // wanted: units that need the fp64 kernel; handled: units this kernel could judge (the others are wanted by default)
     unsigned int wanted = 0, handled = 0;
     constexpr int U = 4;
@@ -222,11 +227,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     wanted = (wanted | ~handled) & all;
     const unsigned int listed = A.E.scr_mode == 2 ? all : wanted;   // verify mode: the dismissed units are listed too, marked
     if (listed == 0) return;
+    const bool mine = lane < 32 && ((listed >> lane) & 1u);
+    // mixed-precision path: the unit also joins the list of its (tile, row-slot class), which is what the gathered
+    // low-limb GEMM walks; its index k there tells k_mi_units where the low limbs of its joint sums are
+    uint64_t kfield = 0;
+    if (mixed) {
+        const int my_lc = lane < n_it ? lo_class((int)(cm[c_first + (lane < 32 ? lane : 0)].mb & 7)) : 0;
+#pragma unroll
+        for (int lc = 0; lc < 3; ++lc) {
+            const unsigned int m = (unsigned int)__ballot(mine && my_lc == lc);
+            if (m == 0) continue;
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(&A.lo.cnt[blockIdx.x * 3 + lc], (unsigned int)__popc(m));
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            if (mine && my_lc == lc) {
+                const unsigned int k = base + __popc(m & ((1u << lane) - 1u));
+                A.lo.tl[(int64_t)blockIdx.x * A.nt + A.lo.uoff[lc] + k] = (uint32_t)(q_base + lane);
+                kfield = ((uint64_t)k << 31) | ((uint64_t)lc << 51);
+            }
+        }
+    }
     unsigned int base = 0;
     if (lane == 0) base = atomicAdd(n_units, (unsigned int)__popc(listed));
     base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-    if (lane < 32 && ((listed >> lane) & 1u)) {
-        const uint32_t u = (uint32_t)blockIdx.x * (uint32_t)A.nt + (uint32_t)(q_base + lane);
+    if (mine) {
+        const uint64_t u = (uint64_t)((uint32_t)blockIdx.x * (uint32_t)A.nt + (uint32_t)(q_base + lane)) | kfield;
         units[base + __popc(listed & ((1u << lane) - 1u))] = ((wanted >> lane) & 1u) ? u : (u | UNIT_DISMISSED);
     }
 }
@@ -240,26 +265,24 @@ __device__ __forceinline__ bool would_emit(const EmitArgs &E, const ColInfo &c, 
 
 // MI of one pair by the variant that fits the slot counts (wave-uniform choice)
 __device__ __forceinline__ double unit_pair_mi(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc, bool square,
-                                               bool fast, int na0, int na_max, int nb) {
-    int64_t si, sj;
-    const int64_t *Gp = g_entry(A, R, M, si, sj);
+                                               bool fast, int na0, int na_max, int nb, const GAcc &Ga) {
     if (fast) {
-        if (na0 == 1) return nb == 1 ? pair_mi_full<1, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj) : pair_mi_full<1, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-        return nb == 1 ? pair_mi_full<2, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj) : pair_mi_full<2, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+        if (na0 == 1) return nb == 1 ? pair_mi_full<1, 1>(A, R, M, a_loc, b_loc, square, Ga) : pair_mi_full<1, 2>(A, R, M, a_loc, b_loc, square, Ga);
+        return nb == 1 ? pair_mi_full<2, 1>(A, R, M, a_loc, b_loc, square, Ga) : pair_mi_full<2, 2>(A, R, M, a_loc, b_loc, square, Ga);
     }
     if (na_max == 1) {
-        if (nb <= 1) return pair_mi<1, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-        if (nb == 2) return pair_mi<1, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-        return pair_mi<1, 4>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+        if (nb <= 1) return pair_mi<1, 1>(A, R, M, a_loc, b_loc, square, Ga);
+        if (nb == 2) return pair_mi<1, 2>(A, R, M, a_loc, b_loc, square, Ga);
+        return pair_mi<1, 4>(A, R, M, a_loc, b_loc, square, Ga);
     }
     if (na_max == 2) {
-        if (nb <= 1) return pair_mi<2, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-        if (nb == 2) return pair_mi<2, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-        return pair_mi<2, 4>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+        if (nb <= 1) return pair_mi<2, 1>(A, R, M, a_loc, b_loc, square, Ga);
+        if (nb == 2) return pair_mi<2, 2>(A, R, M, a_loc, b_loc, square, Ga);
+        return pair_mi<2, 4>(A, R, M, a_loc, b_loc, square, Ga);
     }
-    if (nb <= 1) return pair_mi<4, 1>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-    if (nb == 2) return pair_mi<4, 2>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
-    return pair_mi<4, 4>(A, R, M, a_loc, b_loc, square, Gp, si, sj);
+    if (nb <= 1) return pair_mi<4, 1>(A, R, M, a_loc, b_loc, square, Ga);
+    if (nb == 2) return pair_mi<4, 2>(A, R, M, a_loc, b_loc, square, Ga);
+    return pair_mi<4, 4>(A, R, M, a_loc, b_loc, square, Ga);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -295,7 +318,7 @@ __global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *_
         const int b_loc = M.bl;
         if (!a_ok) continue;
         if (A.E.lower_only && a_loc <= b_loc) continue;
-        const double mi = unit_pair_mi(A, R, M, a_loc, b_loc, square, wave_full && col_is_fast(mbu), na0, na_max, (int)(mbu & 7));
+        const double mi = unit_pair_mi(A, R, M, a_loc, b_loc, square, wave_full && col_is_fast(mbu), na0, na_max, (int)(mbu & 7), g_entry(A, R, M));
         emit_pair(A.E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, sh_hist);
     }
     if (use_hist) {
@@ -311,7 +334,7 @@ __global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *_
 // constants of both sides are fetched per unit) — hidden by the number of waves in flight — not throughput.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mi_units(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
-                                                  const uint32_t *__restrict__ units, const unsigned int *__restrict__ n_units,
+                                                  const uint64_t *__restrict__ units, const unsigned int *__restrict__ n_units,
                                                   unsigned long long *__restrict__ ghist) {
     const bool square = A.nf == A.nt;
     const unsigned int n = *n_units;
@@ -320,9 +343,11 @@ __global__ __launch_bounds__(256) void k_mi_units(EpiArgs A, const int32_t *__re
     bool a_ok = false, wave_full = false;
     RowSide R;
     for (unsigned int i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n; i += stride) {
-        const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)units[i]);
-        const bool dismissed = (u & UNIT_DISMISSED) != 0;
-        const uint32_t v = u & ~UNIT_DISMISSED;
+        const uint64_t u = units[i];
+        const uint32_t ulo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+        const uint32_t uhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+        const bool dismissed = (uhi & 0x80000000u) != 0;
+        const uint32_t v = ulo & 0x7FFFFFFFu;
         const int tile = (int)(v / (uint32_t)A.nt), q = (int)(v - (uint32_t)tile * (uint32_t)A.nt);
         if (tile != cur_tile) {
             a_ok = load_row_side(A, perm_f, square, tile, R, a_loc);
@@ -336,7 +361,17 @@ __global__ __launch_bounds__(256) void k_mi_units(EpiArgs A, const int32_t *__re
         const int b_loc = M.bl;
         if (!a_ok) continue;
         if (A.E.lower_only && a_loc <= b_loc) continue;
-        const double mi = unit_pair_mi(A, R, M, a_loc, b_loc, square, wave_full && col_is_fast(mbu), na0, na_max, (int)(mbu & 7));
+        GAcc Ga = g_entry(A, R, M);
+        if (A.lo.on) {   // G holds the high limbs only: the low limbs of this unit's joint sums come from the gathered GEMM
+            const int k = (int)(((ulo >> 31) | (uhi << 1)) & 0xFFFFFu), lc = (int)((uhi >> 19) & 3u);
+            const int cmax = A.lo.cmax_f[tile];
+            const int64_t ld = 64 * (int64_t)cmax;
+            Ga.l = A.lo.glo + A.lo.tile_base[tile] + ((int64_t)A.lo.rowbase[lc] + ((int64_t)k << lc)) * ld + (int64_t)(threadIdx.x & 63) * cmax;
+            Ga.li = 1;
+            Ga.lj = ld;
+            Ga.shift = A.lo.hi_shift;
+        }
+        const double mi = unit_pair_mi(A, R, M, a_loc, b_loc, square, wave_full && col_is_fast(mbu), na0, na_max, (int)(mbu & 7), Ga);
         if (dismissed) {   // verify mode: a pair of a dismissed unit that would have been emitted was lost by the screen
             if (would_emit(A.E, M.ci, a_loc, b_loc, mi)) atomicAdd(A.E.scr_viol, 1ull);
             continue;
@@ -779,6 +814,17 @@ bool same_list(const int32_t *a, int64_t na, const int32_t *b, int64_t nb) {
 struct DevPtrs {
     const int32_t *idx_f, *idx_t, *rl_f, *rl_t, *lrow_f, *lrow_t, *perm, *perm_t, *pos_f, *pos_t;
     const uint8_t *cls_f, *cls_t;
+    const int32_t *cmax_f;      // mixed-precision path: per from-tile widest row-slot class, offsets of the low-limb blocks
+    const int64_t *tile_base;
+    const int32_t *tf_list;     // (tile, fs) pairs of the gathered GEMM's grid
+    int nf_tiles;               // tiles of 64 in the padded from-side order perm
+};
+
+// host half of LoGeom
+struct LoHost {
+    int32_t n_lc[3] = {0, 0, 0}, uoff[3] = {0, 0, 0}, rowbase[3] = {0, 0, 0};
+    int32_t RTlo = 0, ntiles = 0, n_tf = 0;
+    int64_t glo_total = 0;
 };
 
 void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int quirk, const EmitArgs &E, const int64_t *G,
@@ -798,6 +844,7 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
     A.scale = std::ldexp(1.0, -c->frac_bits);
     A.quirk = quirk;
     A.E = E;
+    memset(&A.lo, 0, sizeof(A.lo));
 }
 
 // GEMM + epilogue (or the histogram engine) of one block into ctx->MIblk; with E.cols set, the short-range
@@ -806,15 +853,19 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
 // end (main stream).  The GEMM of block b+1 runs beside the epilogue and selection of block b, so the stage times overlap.
 constexpr int EVB = 5;
 // which: 1 = GEMM only (on gstream, into Gbuf), 2 = epilogue only, 3 = both
+constexpr int HI_LIMBS = 3, LO_LIMBS = 2;   // mixed-precision split of the 5 weight limbs
 int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E,
-                    hipEvent_t *ev, int which, ldw::DevBuf *Gb, hipStream_t gstream, unsigned long long *ghist) {
+                    hipEvent_t *ev, int which, ldw::DevBuf *Gb, hipStream_t gstream, unsigned long long *ghist,
+                    const LoHost *mixed = nullptr) {
     ldw::DevBuf &Gbuf = Gb ? *Gb : c->G;
     if (!gstream) gstream = c->stream;
     if (which == 1) {   // the GEMM of a block, possibly on its own stream so that it overlaps the previous block's tail
         if (int rc = Gbuf.reserve((size_t)RFpad * RTpad * 8)) return rc;
         LDW_HIP(hipEventRecord(ev[0], gstream));
-        if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, Gbuf.as<int64_t>(), c->nlimbs,
-                                      c->digits.as<int8_t>(), E.lower_only, gstream))
+        // mixed-precision path: the block-wide GEMM carries the high limbs only
+        if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, Gbuf.as<int64_t>(),
+                                      mixed ? HI_LIMBS : c->nlimbs, c->digits.as<int8_t>() + (mixed ? (int64_t)LO_LIMBS * c->KW * 64 : 0),
+                                      E.lower_only, gstream))
             return rc;
         LDW_HIP(hipEventRecord(ev[1], gstream));
         return LDW_OK;
@@ -823,7 +874,7 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
     if (int rc = c->MIblk.reserve((size_t)nf * nt * 8)) return rc;
     E.MI = c->MIblk.as<double>();
     E.nf = (int)nf;
-    dim3 egrid((unsigned)((nf + 63) / 64), (unsigned)((nt + EPI_COLS - 1) / EPI_COLS));
+    dim3 egrid((unsigned)(D.nf_tiles > 0 ? D.nf_tiles : (nf + 63) / 64), (unsigned)((nt + EPI_COLS - 1) / EPI_COLS));
     LDW_REQUIRE(egrid.y <= 65535u, LDW_ERR_ARG, "nt too large for the epilogue grid");
     if (c->engine == LDW_ENGINE_HIST) {
         LDW_HIP(hipEventRecord(ev[0], c->stream));
@@ -852,12 +903,52 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
     if (A.E.scr_mode && A.E.cols && !A.E.write_dense && (nf == nt || quirk == LDW_QUIRK_INTENDED)) {
         // speculative mode: the lean fp32 screen lists the units that need the exact value, k_mi_units evaluates those
         const size_t n_units_max = (size_t)egrid.x * (size_t)nt;
-        if (int rc = c->scr_units.reserve(n_units_max * 4 + 64)) return rc;
-        unsigned int *n_units = c->scr_units.as<unsigned int>();
-        uint32_t *units = c->scr_units.as<uint32_t>() + 16;
-        LDW_HIP(hipMemsetAsync(n_units, 0, 4, c->stream));
+        const size_t o_cnt = 64, o_flat = o_cnt + ((size_t)egrid.x * 12 + 63) / 64 * 64, o_tl = o_flat + n_units_max * 8;
+        if (int rc = c->scr_units.reserve(o_tl + n_units_max * 4 + 64)) return rc;
+        char *ub = c->scr_units.as<char>();
+        unsigned int *n_units = reinterpret_cast<unsigned int *>(ub);
+        uint64_t *units = reinterpret_cast<uint64_t *>(ub + o_flat);
+        LDW_HIP(hipMemsetAsync(ub, 0, o_flat, c->stream));   // the unit counter and the per-(tile, class) counters
+        if (mixed) {
+            LDW_REQUIRE(mixed->ntiles == (int)egrid.x, LDW_ERR_STATE, "mixed-precision geometry does not match the epilogue grid");
+            if (int rc = c->glo.reserve((size_t)mixed->glo_total * 4 + 64)) return rc;
+            LoGeom &lo = A.lo;
+            for (int k = 0; k < 3; ++k) {
+                lo.n_lc[k] = mixed->n_lc[k];
+                lo.uoff[k] = mixed->uoff[k];
+                lo.rowbase[k] = mixed->rowbase[k];
+            }
+            lo.RTlo = mixed->RTlo;
+            lo.ntiles = mixed->ntiles;
+            lo.on = 1;
+            lo.cmax_f = D.cmax_f;
+            lo.tile_base = D.tile_base;
+            lo.cnt = reinterpret_cast<unsigned int *>(ub + o_cnt);
+            lo.tl = reinterpret_cast<uint32_t *>(ub + o_tl);
+            lo.glo = c->glo.as<int32_t>();
+            lo.slot_pfix_hi = c->slot_pfix_hi.as<int64_t>();
+            lo.hi_shift = 8 * LO_LIMBS;
+        }
         hipLaunchKernelGGL(k_mi_screen, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units);
         LDW_HIP(hipGetLastError());
+        if (mixed) {   // low limbs of the listed units
+            LoGemmArgs P;
+            P.Mbits = c->Mbits.as<uint64_t>();
+            P.KW = c->KW;
+            P.Kpad = c->KW * 64;
+            P.digits_lo = c->digits.as<int8_t>();
+            P.perm_f = D.perm;
+            P.idx_f = D.idx_f;
+            P.perm_t = D.perm_t;
+            P.idx_t = D.idx_t;
+            P.row0 = c->row0.as<int32_t>();
+            P.zero_row = (int32_t)c->R;
+            P.nf = (int32_t)nf;
+            P.nt = (int32_t)nt;
+            P.tf_list = D.tf_list;
+            P.lo = A.lo;
+            if (int rc = launch_gemm_lo_units(c, P, mixed->n_tf, c->stream)) return rc;
+        }
         hipLaunchKernelGGL(k_mi_units, dim3(2048), dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, ghist);
         LDW_HIP(hipGetLastError());
     } else {
@@ -869,6 +960,20 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
 }
 
 // lane order of the epilogue: from-side SNPs grouped by their number of indicator rows (1, 2, 3, 4, 0)
+// The same for the from side of the epilogue kernels, which walk it in tiles of 64 (one wave): every class is padded
+// with -1 to a multiple of 64, so no tile mixes slot counts — a mixed tile cannot take the straight-line code and
+// would have all of its units listed for the fp64 kernel (and for the gathered low-limb GEMM).
+void build_perm_tiles(ldw_ctx *c, const int32_t *from_idx, int64_t nf, std::vector<int32_t> &perm) {
+    perm.clear();
+    for (int want : {1, 2, 3, 4, 0}) {
+        for (int64_t k = 0; k < nf; ++k)
+            if (c->h_row0[from_idx[k] + 1] - c->h_row0[from_idx[k]] == want) perm.push_back((int32_t)k);
+        if (want != 3)   // 3 and 4 rows share the generic code anyway
+            while (perm.size() % 64) perm.push_back(-1);
+    }
+    if (perm.empty()) perm.assign(64, -1);
+}
+
 void build_perm(ldw_ctx *c, const int32_t *from_idx, int64_t nf, int32_t *perm) {
     int64_t w = 0;
     for (int want : {1, 2, 3, 4, 0})
@@ -882,11 +987,11 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     if (int rc = ensure_rows(c)) return rc;
     LDW_REQUIRE(nf > 0 && nt > 0, LDW_ERR_ARG, "empty block (nf=%lld nt=%lld)", (long long)nf, (long long)nt);
     LDW_REQUIRE(nf <= 1000000 && nt <= 1000000, LDW_ERR_ARG, "block side too long");
-    std::vector<int32_t> vf(from_idx, from_idx + nf), vt(to_idx, to_idx + nt), perm((size_t)nf), perm_t((size_t)nt);
+    std::vector<int32_t> vf(from_idx, from_idx + nf), vt(to_idx, to_idx + nt), perm, perm_t((size_t)nt);
     SideLists SF, ST;
     if (int rc = build_side(c, from_idx, nf, SF)) return rc;
     if (int rc = build_side(c, to_idx, nt, ST)) return rc;
-    build_perm(c, from_idx, nf, perm.data());
+    build_perm_tiles(c, from_idx, nf, perm);
     build_perm(c, to_idx, nt, perm_t.data());
     if (int rc = upload_i32(c, c->perm_t, perm_t)) return rc;
     if (int rc = upload_i32(c, c->idx_f, vf)) return rc;
@@ -900,7 +1005,7 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     LDW_HIP(hipStreamSynchronize(c->stream));  // pageable H2D copies are complete only after a sync
     DevPtrs D{c->idx_f.as<int32_t>(), c->idx_t.as<int32_t>(), c->rowlist_f.as<int32_t>(), c->rowlist_t.as<int32_t>(),
               c->lrow_f.as<int32_t>(), c->lrow_t.as<int32_t>(), c->perm_f.as<int32_t>(), c->perm_t.as<int32_t>(), nullptr, nullptr,
-              nullptr, nullptr};
+              nullptr, nullptr, nullptr, nullptr, nullptr, (int)(perm.size() / 64)};
     E.write_dense = 1;
     E.spec_B = -1;
     // a symmetric block (same list on both sides) may be asked for in full: the GEMM then computes every tile
@@ -951,6 +1056,11 @@ struct HostBlock {
     int64_t nf = 0, nt = 0, n_sr_blk = 0, n_lr_total = 0, blk_no = 0;
     int RFpad = 0, RTpad = 0, slot = 0;
     bool diag = false, fused = false, submitted = false;
+    int nf_tiles = 0;          // tiles of 64 in the padded from-side order
+    bool mixed = false;        // high-limb GEMM + gathered low limbs (decided with the bucket guess at submit_a)
+    int guess = -1;            // bucket guess the block was submitted with
+    LoHost lo;
+    size_t o_cmax = 0, o_tbase = 0, o_tf = 0;
     size_t o_idx_f = 0, o_idx_t = 0, o_rl_f = 0, o_rl_t = 0, o_lrow_f = 0, o_lrow_t = 0, o_perm = 0, o_perm_t = 0, o_cols = 0, o_pos_f = 0,
            o_pos_t = 0, o_cls_f = 0, o_cls_t = 0, total = 0;
     DevPtrs D{};
@@ -989,13 +1099,57 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     hb.o_rl_t = o; o = al(o + ST.rowlist.size() * 4);
     hb.o_lrow_f = o; o = al(o + (size_t)nf * 4);
     hb.o_lrow_t = o; o = al(o + (size_t)nt * 4);
-    hb.o_perm = o; o = al(o + (size_t)nf * 4);
+    std::vector<int32_t> pf;
+    build_perm_tiles(c, from_idx, nf, pf);
+    hb.nf_tiles = (int)(pf.size() / 64);
+    hb.o_perm = o; o = al(o + pf.size() * 4);
     hb.o_perm_t = o; o = al(o + (size_t)nt * 4);
     hb.o_cols = o; o = al(o + cols.size() * sizeof(ColInfo));
     hb.o_pos_f = o; o = al(o + SF.pos.size() * 4);
     hb.o_pos_t = o; o = al(o + ST.pos.size() * 4);
     hb.o_cls_f = o; o = al(o + SF.cls.size());
     hb.o_cls_t = o; o = al(o + ST.cls.size());
+    // mixed-precision path: row-slot classes of the to side, widest class per from-tile, low-limb block offsets
+    std::vector<int32_t> cmax((size_t)hb.nf_tiles, 1);
+    std::vector<int64_t> tbase(cmax.size(), 0);
+    {
+        LoHost &lo = hb.lo;
+        lo = LoHost();
+        for (int64_t k = 0; k < nt; ++k) ++lo.n_lc[lo_class(c->h_row0[to_idx[k] + 1] - c->h_row0[to_idx[k]])];
+        int32_t uo = 0, rb = 0;
+        for (int lc = 0; lc < 3; ++lc) {
+            lo.uoff[lc] = uo;
+            lo.rowbase[lc] = rb;
+            uo += lo.n_lc[lc];
+            rb += (int32_t)((((int64_t)lo.n_lc[lc] << lc) + TILE - 1) / TILE * TILE);
+        }
+        lo.RTlo = rb;
+        lo.ntiles = (int32_t)cmax.size();
+        for (size_t t = 0; t < pf.size(); ++t) {
+            if (pf[t] < 0) continue;
+            const int32_t a = from_idx[pf[t]];
+            const int cls = 1 << lo_class(c->h_row0[a + 1] - c->h_row0[a]);
+            if (cls > cmax[t / 64]) cmax[t / 64] = cls;
+        }
+        int64_t tb = 0;
+        for (size_t t = 0; t < cmax.size(); ++t) {
+            tbase[t] = tb;
+            tb += (int64_t)lo.RTlo * 64 * cmax[t];
+        }
+        lo.glo_total = tb;
+    }
+    std::vector<int32_t> tf;
+    // last tiles first: the tile of the SNPs with >= 3 minor states (generic code, every unit listed, cmax 4) is the
+    // critical path of the gathered GEMM and must not start last
+    for (size_t t = cmax.size(); t-- > 0;)
+        for (int fs = 0; fs < cmax[t]; ++fs) {
+            tf.push_back((int32_t)t);
+            tf.push_back(fs);
+        }
+    hb.lo.n_tf = (int32_t)(tf.size() / 2);
+    hb.o_cmax = o; o = al(o + cmax.size() * 4);
+    hb.o_tbase = o; o = al(o + tbase.size() * 8);
+    hb.o_tf = o; o = al(o + tf.size() * 4);
     hb.total = o;
     if (c->pin_cap[slot] < o) {
         if (c->pin[slot]) LDW_HIP(hipHostFree(c->pin[slot]));
@@ -1011,13 +1165,16 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     memcpy(b + hb.o_rl_t, ST.rowlist.data(), ST.rowlist.size() * 4);
     memcpy(b + hb.o_lrow_f, SF.lrow.data(), (size_t)nf * 4);
     memcpy(b + hb.o_lrow_t, ST.lrow.data(), (size_t)nt * 4);
-    build_perm(c, from_idx, nf, reinterpret_cast<int32_t *>(b + hb.o_perm));
+    memcpy(b + hb.o_perm, pf.data(), pf.size() * 4);
     build_perm(c, to_idx, nt, reinterpret_cast<int32_t *>(b + hb.o_perm_t));
     memcpy(b + hb.o_cols, cols.data(), cols.size() * sizeof(ColInfo));
     memcpy(b + hb.o_pos_f, SF.pos.data(), SF.pos.size() * 4);
     memcpy(b + hb.o_pos_t, ST.pos.data(), ST.pos.size() * 4);
     memcpy(b + hb.o_cls_f, SF.cls.data(), SF.cls.size());
     memcpy(b + hb.o_cls_t, ST.cls.data(), ST.cls.size());
+    memcpy(b + hb.o_cmax, cmax.data(), cmax.size() * 4);
+    memcpy(b + hb.o_tbase, tbase.data(), tbase.size() * 8);
+    memcpy(b + hb.o_tf, tf.data(), tf.size() * 4);
     return LDW_OK;
 }
 
@@ -1032,6 +1189,14 @@ int launch_gather(ldw_ctx *c, const HostBlock &hb, const EmitArgs &E, const Smal
                        c->cand_key[hb.slot].as<uint64_t>(), c->cand_val[hb.slot].as<uint64_t>());
     LDW_HIP(hipGetLastError());
     return LDW_OK;
+}
+
+// Bound of |MI(exact sums) - MI(high-limb sums)| in nats.  Every cell of a joint table — indicator-row cell or derived by
+// subtraction from the high-limb marginals — misses exactly the low limbs of ITS sequences, so sum_cells |dp| <= lo_abs_sum;
+// dMI <= (1/den) sum_cells |dp| (|ln(pxy den / d)| + 1) with 0.5 <= pxy <= den, 0.25 <= d <= den^2, den >= neff.
+double lo_bound(const ldw_ctx *c) {
+    const double den = c->neff > 1.0 ? c->neff : 1.0;
+    return c->lo_abs_sum * (2.0 * std::log(den + 12.5) + 3.0) / den;
 }
 
 // what the emission of a block's pairs needs (short-range table, candidate list of this slot)
@@ -1068,10 +1233,14 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
     E.cval = c->cand_val[s].as<uint64_t>();
     // fp32 screen: only where a pair can be dismissed at all (speculative mode with a positive lower edge)
     E.scr_mode = (hb.spec_B > 0 || !do_lr) && !E.write_dense ? c->screen : 0;
+    // the screen reads the top 31 bits of a joint sum; in the mixed-precision path the sums are those of the high-limb
+    // weights (units of 2^(16 - F)) and the margin also covers what the low limbs can add (lo_bound)
+    const int64_t tot = hb.mixed ? c->total_fixed_hi : c->total_fixed;
     int bits = 0;
-    while (bits < 62 && (c->total_fixed >> bits) != 0) ++bits;
+    while (bits < 62 && (tot >> bits) != 0) ++bits;
     E.scr_shift = bits > 31 ? bits - 31 : 0;
-    E.scr_scale = (float)std::ldexp(1.0, E.scr_shift - c->frac_bits);
+    E.scr_scale = (float)std::ldexp(1.0, E.scr_shift - c->frac_bits + (hb.mixed ? 8 * LO_LIMBS : 0));
+    E.scr_eps = SCREEN_EPS + (hb.mixed ? (float)lo_bound(c) : 0.0f);
     E.scr_viol = reinterpret_cast<unsigned long long *>(sl.lr_count + 1);
     hb.E = E;
     return LDW_OK;
@@ -1104,7 +1273,8 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     auto I = [&](size_t off) { return reinterpret_cast<const int32_t *>(d + off); };
     auto B = [&](size_t off) { return reinterpret_cast<const uint8_t *>(d + off); };
     hb.D = DevPtrs{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm), I(hb.o_perm_t),
-                   I(hb.o_pos_f), I(hb.o_pos_t), B(hb.o_cls_f), B(hb.o_cls_t)};
+                   I(hb.o_pos_f), I(hb.o_pos_t), B(hb.o_cls_f), B(hb.o_cls_t), I(hb.o_cmax),
+                   reinterpret_cast<const int64_t *>(d + hb.o_tbase), I(hb.o_tf), hb.nf_tiles};
     hb.submitted = true;
     if (c->engine != LDW_ENGINE_MFMA) return LDW_OK;
     hipStream_t gs = c->overlap ? c->gemm_stream : c->stream;   // overlap off: the stages of all blocks run back to back
@@ -1115,11 +1285,18 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     const int guess = do_lr ? c->spec_B_next[hb.diag ? 1 : 0] : 0;
     hb.fused = c->fused && c->nlimbs <= 5 && (!do_lr || guess >= 0);
     ++(hb.fused ? c->fused_blocks : c->unfused_blocks);
+    hb.guess = guess;
     if (!hb.fused) {
+        // mixed precision: with a bucket guess the block will run the screen, which only needs the high limbs; the low
+        // limbs follow for the listed units only.  The guess is frozen here because the GEMM commits to it.
+        hb.mixed = c->mixed && c->screen && c->nlimbs == HI_LIMBS + LO_LIMBS && do_lr && guess > 0 &&
+                   (hb.nf == hb.nt || p->quirk_mode == LDW_QUIRK_INTENDED) && lo_bound(c) < 1e-3;
+        if (hb.mixed) ++c->mixed_blocks;
         EmitArgs E;
         memset(&E, 0, sizeof(E));
         E.lower_only = hb.diag ? 1 : 0;
-        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, ev, 1, s ? &c->G2 : &c->G, gs, nullptr))
+        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, ev, 1, s ? &c->G2 : &c->G, gs, nullptr,
+                                     hb.mixed ? &hb.lo : nullptr))
             return rc;
         LDW_HIP(hipEventRecord(c->ev_gemm[s], gs));
         return LDW_OK;
@@ -1167,11 +1344,12 @@ int submit_b(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr)) return rc;
     if (int rc = c->hist[s].reserve((size_t)NBINS * 8)) return rc;
     LDW_HIP(hipMemsetAsync(c->hist[s].p, 0, (size_t)NBINS * 8, c->stream));
-    if (int rc = make_emit_args(c, hb, p, sl, (do_lr && c->engine == LDW_ENGINE_MFMA) ? c->spec_B_next[hb.diag ? 1 : 0] : -1)) return rc;
+    if (int rc = make_emit_args(c, hb, p, sl, hb.mixed ? hb.guess : ((do_lr && c->engine == LDW_ENGINE_MFMA) ? c->spec_B_next[hb.diag ? 1 : 0] : -1)))
+        return rc;
     LDW_HIP(hipMemsetAsync(sl.pick[s], 0, sizeof(ldw::PickOut), c->stream));
     hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
     if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, c->engine == LDW_ENGINE_MFMA ? 2 : 3,
-                                 s ? &c->G2 : &c->G, nullptr, c->hist[s].as<unsigned long long>()))
+                                 s ? &c->G2 : &c->G, nullptr, c->hist[s].as<unsigned long long>(), hb.mixed ? &hb.lo : nullptr))
         return rc;
     c->n_sr += sr_add;
     if (int rc = launch_pick(c, hb, p, sl, c->stream)) return rc;
@@ -1191,8 +1369,8 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
     ldw::PickOut *hp = static_cast<ldw::PickOut *>(c->pin_pick[s]);
     if (do_lr && hb.spec_B >= 0 && hp->n > 0 && !hp->spec_ok) {
         // the bucket guess was above the true bucket: redo the epilogue non-speculatively (the short-range rows are
-        // already final): full histogram, dense store, then pick and gather with the true bucket.  The unfused path
-        // still has G; the fused one has to run the GEMM again.
+        // already final): full histogram, dense store, then pick and gather with the true bucket.  The plain two-kernel
+        // path still has G; the fused and the mixed-precision ones have to run the (full) GEMM again.
         EmitArgs E = hb.E;
         E.write_dense = 1;
         E.spec_B = -1;
@@ -1202,8 +1380,8 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
         LDW_HIP(hipMemsetAsync(c->hist[s].p, 0, (size_t)NBINS * 8, c->stream));
         LDW_HIP(hipMemsetAsync(sl.pick[s], 0, sizeof(ldw::PickOut), c->stream));
         hipEvent_t dummy[5] = {c->ev[3], c->ev[3], c->ev[4], c->ev[3], c->ev[5]};   // keep the block's stage events as they are
-        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, dummy, hb.fused ? 3 : 2, s ? &c->G2 : &c->G,
-                                     nullptr, c->hist[s].as<unsigned long long>()))
+        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, dummy, (hb.fused || hb.mixed) ? 3 : 2,
+                                     s ? &c->G2 : &c->G, nullptr, c->hist[s].as<unsigned long long>()))
             return rc;
         if (int rc = launch_pick(c, hb, p, sl, c->stream)) return rc;
         if (int rc = launch_gather(c, hb, E, sl)) return rc;
@@ -1526,6 +1704,12 @@ int ldw_set_overlap(ldw_ctx *c, int on) {
 int ldw_set_screen(ldw_ctx *c, int mode) {
     LDW_REQUIRE(c && mode >= 0 && mode <= 2, LDW_ERR_ARG, "ldw_set_screen: mode must be 0, 1 or 2");
     c->screen = mode;
+    return LDW_OK;
+}
+
+int ldw_set_mixed(ldw_ctx *c, int on) {
+    LDW_REQUIRE(c, LDW_ERR_ARG, "null context");
+    c->mixed = on != 0;
     return LDW_OK;
 }
 

@@ -52,9 +52,10 @@ class Engine:
         return dict(gemm_ms=t[0], epilogue_ms=t[1], select_ms=t[2], total_ms=t[3])
 
     def counters(self):
-        v = np.zeros(4, dtype=np.int64)
-        L.check(L.lib().ldw_ctx_counters(self._ctx, L.ptr(v)))
-        return dict(spec_misses=int(v[0]), fused_blocks=int(v[1]), unfused_blocks=int(v[2]), screen_violations=int(v[3]))
+        v = np.zeros(8, dtype=np.int64)
+        L.check(L.lib().ldw_ctx_counters2(self._ctx, L.ptr(v)))
+        return dict(spec_misses=int(v[0]), fused_blocks=int(v[1]), unfused_blocks=int(v[2]), screen_violations=int(v[3]),
+                    mixed_blocks=int(v[4]))
 
     def set_overlap(self, on: bool):
         """GEMM of the next block beside the epilogue/selection of the current one (default on); off = exclusive stage times."""
@@ -63,6 +64,10 @@ class Engine:
     def set_fused(self, on: bool):
         """GEMM + MI epilogue as one kernel for every block with a bucket guess (default on); off = the two-kernel path."""
         L.check(L.lib().ldw_set_fused(self._ctx, int(bool(on))))
+
+    def set_mixed(self, on: bool):
+        """High-limb block GEMM + gathered low-limb GEMM for the listed units in speculative blocks (default on)."""
+        L.check(L.lib().ldw_set_mixed(self._ctx, int(bool(on))))
 
     def set_screen(self, mode: int):
         """fp32 screen before the fp64 MI evaluation in speculative blocks: 0 off, 1 on (default), 2 verify."""

@@ -620,3 +620,36 @@ def test_ldmap_matches_oracle(engine, synth):
         assert htm.min() == 0.0 and htm.max() == 1.0 and np.array_equal(htm, htm.T)
     with pytest.raises(RuntimeError):
         engine.ldmap(0)          # default reducer round(512 / 1000) = 1 <= 1: the unreduced branch is refused
+
+
+def test_mixed_precision_gemm_is_exact(engine, synth):
+    """Mixed-precision path: block-wide GEMM with the 3 high weight limbs, low limbs from the gathered GEMM for the units
+    the screen lists.  The joint sums it feeds the fp64 evaluation are the same integers as the 5-limb GEMM's, so the
+    link tables must be BIT-identical to the plain path; the widened screen must lose nothing (verify mode)."""
+    syn = synth_alignment(3000, 700, seed=5)
+    st = syn["states"]
+    uqe, r = orc.uqe_r(st)
+    engine.set_alignment(st)
+    hdw = engine.hamming_weights(300)
+    d = dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=syn["POS"], paint=syn["paint"], g=float(syn["g"]))
+    _setup(engine, d)
+    approx = MIH.lr_links_approx(syn["POS"], float(syn["g"]), 20000.0)
+    blocks = MIH.make_blocks(3000, 1000)
+    out = {}
+    for mixed, scr in ((False, 1), (True, 1), (True, 2)):
+        engine.set_mixed(mixed)
+        engine.set_screen(scr)
+        c0 = engine.counters()
+        for _ in range(2):
+            engine.mi_all_pairs(blocks, 20000.0, 20000.0, approx)
+        c1 = engine.counters()
+        out[(mixed, scr)] = (engine.links(0), engine.links(1), {k: c1[k] - c0[k] for k in c1})
+    engine.set_mixed(True)
+    engine.set_screen(1)
+    assert out[(False, 1)][2]["mixed_blocks"] == 0 and out[(True, 1)][2]["mixed_blocks"] >= len(blocks)
+    assert out[(True, 2)][2]["screen_violations"] == 0
+    for which in (0, 1):
+        for key in ((True, 1), (True, 2)):
+            for x, y in zip(out[(False, 1)][which], out[key][which]):
+                assert np.array_equal(x, y), (which, key)
+    assert len(out[(True, 1)][1][2]) > 15000
