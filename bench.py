@@ -215,6 +215,8 @@ def main():
         crow = np.concatenate([[0], np.cumsum(nrow)])
         Npad = (N + 127) // 128 * 128
         J = args.nlimbs or 5
+        mixed = (J == 5) and not args.no_mixed and not args.fused and args.screen > 0
+        J_block = 3 if mixed else J     # limbs of the block-wide GEMM (mixed precision: 3 high limbs; the 2 low limbs only for listed units)
         exec_ops = 0.0
         for fs, fe, ts, te in my_blocks.tolist():   # workgroup tile: 128 to-side rows x 64 from-side rows
             tf = 2 * -(-int(crow[fe] - crow[fs - 1]) // 128)
@@ -223,17 +225,18 @@ def main():
                 tiles = sum(tf - max(0, 2 * by - 1) for by in range(tt))
             else:
                 tiles = tf * tt
-            exec_ops += 2.0 * tiles * 128 * 64 * Npad * J
+            exec_ops += 2.0 * tiles * 128 * 64 * Npad * J_block
         exec_per_launch = exec_ops / nb_mine
         i8_peak = 5000.0  # TOP/s dense (MI355X_MICROARCH.md: i8 = 2 x bf16 per clock, bf16 ~2.5 PF dense)
         achieved = alg_flops_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms else None
-        kname = f"gemm_mi_fused_kernel<{J}>" if args.fused else f"gemm_bits_kernel<{J}>"
+        kname = f"gemm_mi_fused_kernel<{J}>" if args.fused else f"gemm_bits_kernel<{J_block}>"
         roof = dict(bound="mfma", kernel=kname, achieved=achieved, peak=i8_peak, unit="TFLOP/s",
                     frac=achieved / i8_peak if achieved else None, traffic=None,
                     avg_launch_ms=gemm_avg_ms, launches=n_launch,
                     executed_TOPs=exec_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms else None,
                     note="achieved = ALGORITHMIC 50*N flops/pair (SURVEY 8d) x pairs per launch / avg launch time (HIP events) of the "
-                         "co-occurrence GEMM; the kernel EXECUTES fewer ops (one indicator row per minor state, 5 int8 limbs): "
+                         f"co-occurrence GEMM; the kernel EXECUTES fewer ops (one indicator row per minor state, {J_block} int8 limbs"
+                         + (" — the 3 high limbs of 5; the 2 low limbs are computed by gemm_lo_units_kernel for the ~4 % of units the screen lists" if mixed else "") + "): "
                          "executed_TOPs / peak = executed_frac is the matrix-core utilisation.  Launch times are kernel-exclusive: "
                          "bracketed in a replay of the timed step with the GEMM/epilogue stream overlap switched off "
                          "(ldw_set_overlap(0)); `overlapped_*` are the brackets inside the timed region, where the GEMM shares "
@@ -243,13 +246,14 @@ def main():
         roof["executed_frac"] = roof["executed_TOPs"] / i8_peak if roof["executed_TOPs"] else None
         # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (rocprofv3 cannot run inside
         # the bench); only quoted for the configuration they were collected on
-        tpath = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
         if os.path.exists(tpath) and (L, N, world, J) == (100_000, 5_000, 1, 5) and not args.fused:
-            roof["traffic"] = json.load(open(tpath)).get("gemm_bits_kernel<5>", {}).get("hbm_bytes_per_launch_corrected")
-            roof["traffic_source"] = "profiles/r01f_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+            roof["traffic"] = json.load(open(tpath)).get(kname, {}).get("hbm_bytes_per_launch_corrected")
+            roof["traffic_source"] = "profiles/r01g_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
         roof["epilogue_avg_launch_ms"] = epi_avg_ms
         roof["epilogue_kernels"] = ("inside the fused kernel" if args.fused else
-                                    "k_mi_screen (fp32 screen, lists the units that need the exact value) + k_mi_units (fp64, listed units)"
+                                    "k_mi_screen (fp32 screen, lists the units that need the exact value) + gemm_lo_units_kernel (low limbs of "
+                                    "the listed units, mixed precision) + k_mi_units (fp64, listed units)"
                                     if args.screen else "k_mi_epilogue (fp64, every pair)")
         roof["dominant_stage"] = stage
         roof["hbm_alg_GBps_whole_step"] = (L * N + 8.0 * pairs) / (dt / K) / 1e9
@@ -261,7 +265,7 @@ def main():
                                         f"sr_dist=20000, lr_retain_links=1e6, sr+lr link tables on rank 0",
                                L=L, N=N, pairs=int(pairs), engine=args.engine, nlimbs=args.nlimbs or 5,
                                arithmetic="joint sums: int8 MFMA -> exact int64 fixed point; MI: fp32 screen, f64 for every emitted value",
-                               fused=bool(args.fused), screen=args.screen,
+                               fused=bool(args.fused), screen=args.screen, mixed_precision=bool(mixed),
                                parallelism=f"pair-space blocks over {world} GPU(s)"),
                    roofline=roof,
                    stages_ms_per_step={k: v / max(1, n_replay) for k, v in tim.items()},
