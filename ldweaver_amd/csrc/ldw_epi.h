@@ -219,6 +219,9 @@ struct EpiArgs {
     const double *r;
     double neff, scale;
     int quirk;
+    // Both epilogue orders end with the SNPs that have >= 3 minor states or none: from-tiles >= gen_t0 and column slots
+    // >= gen_q0 are the domain of k_mi_screen_generic, the rest that of k_mi_screen
+    int gen_t0, gen_q0;
     EmitArgs E;
 };
 
@@ -463,6 +466,63 @@ __device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSi
             const float pxy = fmaf((float)(uint32_t)(C.n[i][j] >> A.E.scr_shift), A.E.scr_scale, 0.5f);
             const float d = fmaf(pY, rY, fmaf(pX, pY, pXr));
             acc = fmaf(pxy, __builtin_amdgcn_logf(pxy * den) - __builtin_amdgcn_logf(d), acc);
+        }
+    }
+    return acc * (0.6931471805599453f * __builtin_amdgcn_rcpf(den));
+}
+
+// The screen for ANY slot counts (SNPs with >= 3 minor states, or none, on either side): the predicated cell loop of
+// pair_mi<4, 4> in fp32.  Same error budget as full_cells_screen (up to 25 cells instead of 9: the log terms are still
+// weighted by pxy / den, which sum to 1).
+__device__ __forceinline__ float pair_screen_generic(const EpiArgs &A, const RowSide &R, const ColMeta &M, double RXY, const GAcc &Ga) {
+    const int na = R.na, nb = M.mb & 7;
+    const uint32_t ma = R.ma, mb = M.mb;
+    int64_t g[4][4], rs[4], cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rs[i] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cs[j] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t v = 0;
+            if (i < na && j < nb) v = Ga.at(i, j);
+            g[i][j] = v;
+            rs[i] += v;
+            cs[j] += v;
+        }
+    int64_t pa_drop = 0;
+#pragma unroll
+    for (int i = 0; i <= 4; ++i)
+        if (i == na) pa_drop = R.pa[i];
+    int64_t dd = pa_drop;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < nb) dd -= M.pb[j] - cs[j];
+    const float ra = (float)R.ra, rb = (float)M.rb;
+    const float den = (float)A.neff + (ra * rb) * 0.5f;
+    const float rX = 0.5f * ra, rY = 0.5f * rb, rxy = (float)RXY;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i <= 4; ++i) {
+        if (i <= na && ((ma >> (3 + i)) & 1)) {
+            const float pX = R.pXf[i];
+            const float pXr = fmaf(pX, rX, rxy);
+#pragma unroll
+            for (int j = 0; j <= 4; ++j) {
+                if (j <= nb && ((mb >> (3 + j)) & 1)) {
+                    int64_t nfix;
+                    if (i < 4 && j < 4 && i < na && j < nb) nfix = g[i < 4 ? i : 0][j < 4 ? j : 0];
+                    else if (i < 4 && i < na) nfix = R.pa[i] - rs[i < 4 ? i : 0];
+                    else if (j < 4 && j < nb) nfix = M.pb[j] - cs[j < 4 ? j : 0];
+                    else nfix = dd;
+                    const float pY = M.pYf[j];
+                    const float pxy = fmaf((float)(uint32_t)(nfix >> A.E.scr_shift), A.E.scr_scale, 0.5f);
+                    const float d = fmaf(pY, rY, fmaf(pX, pY, pXr));
+                    acc = fmaf(pxy, __builtin_amdgcn_logf(pxy * den) - __builtin_amdgcn_logf(d), acc);
+                }
+            }
         }
     }
     return acc * (0.6931471805599453f * __builtin_amdgcn_rcpf(den));

@@ -54,7 +54,8 @@ __device__ __forceinline__ void stage_cols(const EpiArgs &A, const int32_t *__re
 }
 
 // the same for ONE column slot q, executed by every lane of a wave with uniform addresses (k_mi_units)
-__device__ __forceinline__ void load_col(const EpiArgs &A, const int32_t *__restrict__ perm_t, bool square, int q, ColMeta &m) {
+__device__ __forceinline__ void load_col(const EpiArgs &A, const int32_t *__restrict__ perm_t, bool square, int q, ColMeta &m,
+                                         bool hi_cells = false) {
     const int b_loc = perm_t[q];
     m.sb = A.idx_t[b_loc];
     m.mb = A.slot_meta[m.sb];
@@ -67,6 +68,7 @@ __device__ __forceinline__ void load_col(const EpiArgs &A, const int32_t *__rest
         m.pb[j] = A.slot_pfix[(int64_t)m.sb * 5 + j];
         m.pYd[j] = (double)m.pb[j] * A.scale;
         m.pYf[j] = (float)m.pYd[j];
+        if (hi_cells) m.pb[j] = A.lo.slot_pfix_hi[(int64_t)m.sb * 5 + j];
     }
     m.pad2 = 0;
     m.ci = A.E.cols[b_loc];
@@ -168,6 +170,44 @@ __device__ __forceinline__ unsigned int screen_cols_nb(int nb, const EpiArgs &A,
 // 31-50) and the class (bits 51-52) in the mixed-precision path; bit 63: verify mode only, a unit the screen dismissed
 constexpr uint64_t UNIT_DISMISSED = 0x8000000000000000ull;
 
+// Append the wanted units of a wave (bit k = column slot q_base + k of from-tile `tile`) to the flat list and, in the
+// mixed-precision path, to the list of their (tile, row-slot class), which is what the gathered low-limb GEMM walks; the
+// index k there tells k_mi_units where the low limbs of the unit's joint sums are.  In verify mode every unit of `all` is
+// listed, the unwanted ones marked.
+__device__ __forceinline__ void list_wave_units(const EpiArgs &A, const ColMeta *cm, int c_first, int q_base, int n_it, unsigned int all,
+                                                unsigned int wanted, uint64_t *__restrict__ units, unsigned int *__restrict__ n_units,
+                                                int tile = -1) {
+    if (tile < 0) tile = (int)blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned int listed = A.E.scr_mode == 2 ? all : wanted;
+    if (listed == 0) return;
+    const bool mine = lane < 32 && ((listed >> lane) & 1u);
+    uint64_t kfield = 0;
+    if (A.lo.on) {
+        const int my_lc = lane < n_it ? lo_class((int)(cm[c_first + (lane < 32 ? lane : 0)].mb & 7)) : 0;
+#pragma unroll
+        for (int lc = 0; lc < 3; ++lc) {
+            const unsigned int m = (unsigned int)__ballot(mine && my_lc == lc);
+            if (m == 0) continue;
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(&A.lo.cnt[tile * 3 + lc], (unsigned int)__popc(m));
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            if (mine && my_lc == lc) {
+                const unsigned int k = base + __popc(m & ((1u << lane) - 1u));
+                A.lo.tl[(int64_t)tile * A.nt + A.lo.uoff[lc] + k] = (uint32_t)(q_base + lane);
+                kfield = ((uint64_t)k << 31) | ((uint64_t)lc << 51);
+            }
+        }
+    }
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(n_units, (unsigned int)__popc(listed));
+    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+    if (mine) {
+        const uint64_t u = (uint64_t)((uint32_t)tile * (uint32_t)A.nt + (uint32_t)(q_base + lane)) | kfield;
+        units[base + __popc(listed & ((1u << lane) - 1u))] = ((wanted >> lane) & 1u) ? u : (u | UNIT_DISMISSED);
+    }
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mi_screen(EpiArgs A, const int32_t *__restrict__ perm_f,
                                                                                             const int32_t *__restrict__ perm_t,
                                                                                             uint64_t *__restrict__ units,
@@ -192,6 +232,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // wanted: units that need the fp64 kernel; handled: units this kernel could judge (the others are wanted by default)
     unsigned int wanted = 0, handled = 0;
     constexpr int U = 4;
+    // from-tiles >= gen_t0 and column slots >= gen_q0 (SNPs with >= 3 minor states, or none) belong to k_mi_screen_generic
+    if ((int)blockIdx.x >= A.gen_t0 || q_base >= A.gen_q0) return;
+    if (q_base + n_it > A.gen_q0) n_it = A.gen_q0 - q_base;
     if (wave_full) {
         for (int it = 0; it < n_it; it += U) {
             const ColMeta *cmu = &cm[c_first + it];
@@ -225,35 +268,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     const unsigned int all = n_it >= 32 ? 0xFFFFFFFFu : ((1u << n_it) - 1u);
     wanted = (wanted | ~handled) & all;
-    const unsigned int listed = A.E.scr_mode == 2 ? all : wanted;   // verify mode: the dismissed units are listed too, marked
-    if (listed == 0) return;
-    const bool mine = lane < 32 && ((listed >> lane) & 1u);
-    // mixed-precision path: the unit also joins the list of its (tile, row-slot class), which is what the gathered
-    // low-limb GEMM walks; its index k there tells k_mi_units where the low limbs of its joint sums are
-    uint64_t kfield = 0;
-    if (mixed) {
-        const int my_lc = lane < n_it ? lo_class((int)(cm[c_first + (lane < 32 ? lane : 0)].mb & 7)) : 0;
-#pragma unroll
-        for (int lc = 0; lc < 3; ++lc) {
-            const unsigned int m = (unsigned int)__ballot(mine && my_lc == lc);
-            if (m == 0) continue;
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(&A.lo.cnt[blockIdx.x * 3 + lc], (unsigned int)__popc(m));
-            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-            if (mine && my_lc == lc) {
-                const unsigned int k = base + __popc(m & ((1u << lane) - 1u));
-                A.lo.tl[(int64_t)blockIdx.x * A.nt + A.lo.uoff[lc] + k] = (uint32_t)(q_base + lane);
-                kfield = ((uint64_t)k << 31) | ((uint64_t)lc << 51);
-            }
+    list_wave_units(A, cm, c_first, q_base, n_it, all, wanted, units, n_units);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_mi_screen_generic: the fp32 screen for the units k_mi_screen leaves out — a from-tile or a column whose SNPs have >= 3
+// minor states (or none).  Those are 1-2 % of the units, but unscreened they were a quarter of the fp64 kernel's list,
+// its slowest entries (predicated code), and a third of the gathered low-limb GEMM.  Launched over the generic
+// from-tiles x all columns and over the other tiles x the generic columns.
+// ------------------------------------------------------------------------------------------------
+constexpr int GEN_COLS = 16;   // column slots per workgroup of k_mi_screen_generic: 4 per wave — the kernel is a chain of
+                               // dependent loads per column with nothing else to hide them, so the chains are kept short
+__global__ __launch_bounds__(256) void k_mi_screen_generic(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
+                                                           uint64_t *__restrict__ units, unsigned int *__restrict__ n_units, int tile0,
+                                                           int q0) {
+    __shared__ ColMeta cm[GEN_COLS];
+    const bool square = A.nf == A.nt;
+    const bool mixed = A.lo.on != 0;
+    const int tile = tile0 + (int)blockIdx.x, qb = q0 + (int)blockIdx.y * GEN_COLS;
+    if (threadIdx.x < GEN_COLS) {
+        const int q = qb + (int)threadIdx.x;
+        if (q < A.nt) {
+            ColMeta m;
+            load_col(A, perm_t, square, q, m, mixed);
+            cm[threadIdx.x] = m;
         }
     }
-    unsigned int base = 0;
-    if (lane == 0) base = atomicAdd(n_units, (unsigned int)__popc(listed));
-    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-    if (mine) {
-        const uint64_t u = (uint64_t)((uint32_t)blockIdx.x * (uint32_t)A.nt + (uint32_t)(q_base + lane)) | kfield;
-        units[base + __popc(listed & ((1u << lane) - 1u))] = ((wanted >> lane) & 1u) ? u : (u | UNIT_DISMISSED);
+    __syncthreads();
+    RowSide R;
+    int a_loc;
+    const bool a_ok = load_row_side(A, perm_f, square, tile, R, a_loc, mixed);
+    const int wave = threadIdx.x >> 6;
+    const int c_first = wave * (GEN_COLS / 4);
+    const int q_base = qb + c_first;
+    int n_it = A.nt - q_base;
+    n_it = n_it > GEN_COLS / 4 ? GEN_COLS / 4 : n_it;
+    if (n_it <= 0) return;
+    const bool rxy_q1 = A.quirk == LDW_QUIRK_REFERENCE;
+    const float lo = (float)A.E.spec_lo - A.E.scr_eps;
+    const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0, do_lr = A.E.do_lr != 0;
+    unsigned int wanted = 0, mine = 0;   // mine: the units of this wave that belong to this kernel
+    for (int it = 0; it < n_it; ++it) {
+        // the same split as k_mi_screen's: its domain is tile < gen_t0 and q < gen_q0, where it takes the fast units and
+        // lists the others unscreened (unflagged slots); everything outside that domain is screened here
+        if (tile < A.gen_t0 && q_base + it < A.gen_q0) continue;
+        const ColMeta &M = cm[c_first + it];
+        mine |= 1u << it;
+        const int b_loc = M.bl;
+        const bool act = a_ok && (A.E.lower_only ? a_loc > b_loc : a_loc != b_loc);
+        const double rxy = (rxy_q1 ? M.rq * R.rta : R.ra * M.rb) * 0.25;
+        const float ms = pair_screen_generic(A, R, M, rxy, g_entry(A, R, M));
+        const bool is_sr = test_sr && col_is_sr(M.ci, a_loc);
+        const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
+        if (__ballot(need) != 0ull) wanted |= 1u << it;
     }
+    list_wave_units(A, cm, c_first, q_base, n_it, mine, wanted & mine, units, n_units, tile);
 }
 
 // would this pair leave a trace (short-range row or long-range candidate)?  Verify mode of the screen only.
@@ -818,6 +887,7 @@ struct DevPtrs {
     const int64_t *tile_base;
     const int32_t *tf_list;     // (tile, fs) pairs of the gathered GEMM's grid
     int nf_tiles;               // tiles of 64 in the padded from-side order perm
+    int gen_t0, gen_q0;         // first from-tile / column slot of the SNPs with >= 3 minor states or none (k_mi_screen_generic)
 };
 
 // host half of LoGeom
@@ -843,6 +913,8 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
     A.neff = c->neff;
     A.scale = std::ldexp(1.0, -c->frac_bits);
     A.quirk = quirk;
+    A.gen_t0 = D.gen_t0;
+    A.gen_q0 = D.gen_q0;
     A.E = E;
     memset(&A.lo, 0, sizeof(A.lo));
 }
@@ -931,6 +1003,17 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
         }
         hipLaunchKernelGGL(k_mi_screen, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units);
         LDW_HIP(hipGetLastError());
+        {   // the units outside k_mi_screen's domain: generic from-tiles x all columns, the other tiles x the generic columns
+            const int gt0 = std::min<int>(A.gen_t0, (int)egrid.x);
+            const int q0 = std::min<int>(A.gen_q0, (int)nt) / GEN_COLS * GEN_COLS;
+            if (gt0 < (int)egrid.x)
+                hipLaunchKernelGGL(k_mi_screen_generic, dim3(egrid.x - gt0, (unsigned)((nt + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A,
+                                   D.perm, D.perm_t, units, n_units, gt0, 0);
+            if (gt0 > 0 && A.gen_q0 < (int)nt)
+                hipLaunchKernelGGL(k_mi_screen_generic, dim3(gt0, (unsigned)((nt - q0 + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A,
+                                   D.perm, D.perm_t, units, n_units, 0, q0);
+            LDW_HIP(hipGetLastError());
+        }
         if (mixed) {   // low limbs of the listed units
             LoGemmArgs P;
             P.Mbits = c->Mbits.as<uint64_t>();
@@ -1005,7 +1088,7 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     LDW_HIP(hipStreamSynchronize(c->stream));  // pageable H2D copies are complete only after a sync
     DevPtrs D{c->idx_f.as<int32_t>(), c->idx_t.as<int32_t>(), c->rowlist_f.as<int32_t>(), c->rowlist_t.as<int32_t>(),
               c->lrow_f.as<int32_t>(), c->lrow_t.as<int32_t>(), c->perm_f.as<int32_t>(), c->perm_t.as<int32_t>(), nullptr, nullptr,
-              nullptr, nullptr, nullptr, nullptr, nullptr, (int)(perm.size() / 64)};
+              nullptr, nullptr, nullptr, nullptr, nullptr, (int)(perm.size() / 64), 0x7FFFFFFF, 0x7FFFFFFF};
     E.write_dense = 1;
     E.spec_B = -1;
     // a symmetric block (same list on both sides) may be asked for in full: the GEMM then computes every tile
@@ -1057,6 +1140,7 @@ struct HostBlock {
     int RFpad = 0, RTpad = 0, slot = 0;
     bool diag = false, fused = false, submitted = false;
     int nf_tiles = 0;          // tiles of 64 in the padded from-side order
+    int gen_t0 = 0, gen_q0 = 0;
     bool mixed = false;        // high-limb GEMM + gathered low limbs (decided with the bucket guess at submit_a)
     int guess = -1;            // bucket guess the block was submitted with
     LoHost lo;
@@ -1102,6 +1186,22 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     std::vector<int32_t> pf;
     build_perm_tiles(c, from_idx, nf, pf);
     hb.nf_tiles = (int)(pf.size() / 64);
+    {   // where the SNPs with 1 or 2 indicator rows end in either order
+        int64_t n12f = 0, n1 = 0, n2 = 0;
+        for (int64_t k = 0; k < nf; ++k) {
+            const int nr = c->h_row0[from_idx[k] + 1] - c->h_row0[from_idx[k]];
+            n1 += nr == 1;
+            n2 += nr == 2;
+        }
+        n12f = (n1 + 63) / 64 + (n2 + 63) / 64;   // build_perm_tiles pads each of the two classes to whole tiles
+        hb.gen_t0 = (int)n12f;
+        int64_t q12 = 0;
+        for (int64_t k = 0; k < nt; ++k) {
+            const int nr = c->h_row0[to_idx[k] + 1] - c->h_row0[to_idx[k]];
+            q12 += nr == 1 || nr == 2;
+        }
+        hb.gen_q0 = (int)q12;
+    }
     hb.o_perm = o; o = al(o + pf.size() * 4);
     hb.o_perm_t = o; o = al(o + (size_t)nt * 4);
     hb.o_cols = o; o = al(o + cols.size() * sizeof(ColInfo));
@@ -1274,7 +1374,7 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     auto B = [&](size_t off) { return reinterpret_cast<const uint8_t *>(d + off); };
     hb.D = DevPtrs{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm), I(hb.o_perm_t),
                    I(hb.o_pos_f), I(hb.o_pos_t), B(hb.o_cls_f), B(hb.o_cls_t), I(hb.o_cmax),
-                   reinterpret_cast<const int64_t *>(d + hb.o_tbase), I(hb.o_tf), hb.nf_tiles};
+                   reinterpret_cast<const int64_t *>(d + hb.o_tbase), I(hb.o_tf), hb.nf_tiles, hb.gen_t0, hb.gen_q0};
     hb.submitted = true;
     if (c->engine != LDW_ENGINE_MFMA) return LDW_OK;
     hipStream_t gs = c->overlap ? c->gemm_stream : c->stream;   // overlap off: the stages of all blocks run back to back
