@@ -208,7 +208,7 @@ __device__ __forceinline__ void list_wave_units(const EpiArgs &A, const ColMeta 
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mi_screen(EpiArgs A, const int32_t *__restrict__ perm_f,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_mi_screen(EpiArgs A, const int32_t *__restrict__ perm_f,
                                                                                             const int32_t *__restrict__ perm_t,
                                                                                             uint64_t *__restrict__ units,
                                                                                             unsigned int *__restrict__ n_units) {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     int a_loc, na0;
     const bool a_ok = load_row_side(A, perm_f, square, blockIdx.x, R, a_loc, mixed);
     const bool wave_full = wave_is_full(R, a_ok, na0);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const int c_first = wave * (EPI_COLS / 4);
     const int q_base = blockIdx.y * EPI_COLS + c_first;
     int n_it = A.nt - q_base;
@@ -589,7 +589,6 @@ __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *_
     __syncthreads();
     const long long lo = s_lo;
     if (lo <= 0) return;
-    __shared__ int s_B;
     long long cum = part[t];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -597,7 +596,6 @@ __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *_
             out->B = t * PER + k;
             out->B_true = t * PER + k;
             out->n_below = cum;
-            s_B = t * PER + k;
         }
         cum += loc[k];
     }
