@@ -182,6 +182,10 @@ int ldw_links_count(ldw_ctx *ctx, int which, int64_t *n_out);
  * gives each processed block's first row. */
 int ldw_links_fetch(ldw_ctx *ctx, int which, int32_t *a_out, int32_t *b_out, double *MI_out,
                     int64_t capacity, int on_device);
+/* Replace the context's short-range (which = 0) or long-range (1) table by caller data (host or device memory): how the
+ * rank that received the other ranks' tables in the multi-GPU gather hands the assembled table to the short-range model,
+ * ARACNE and the post-processing entry points below, which work on the context's tables. */
+int ldw_links_import(ldw_ctx *ctx, int which, const int32_t *a, const int32_t *b, const double *MI, int64_t n, int on_device);
 /* per-block diagnostics of the last ldw_mi_all_pairs call: n_lr_total, n_lr_kept, n_sr, and the
  * quantile threshold (NaN when no lr links); arrays of length nblocks (may be NULL). */
 int ldw_block_stats(ldw_ctx *ctx, int64_t nblocks, int64_t *n_lr_total, int64_t *n_lr_kept,

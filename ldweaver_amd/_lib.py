@@ -70,6 +70,7 @@ _SIGS = {
     "ldw_links_count": (C.c_int, [_p, C.c_int, C.POINTER(_i64)]),
     "ldw_links_fetch": (C.c_int, [_p, C.c_int, _p, _p, _p, _i64, C.c_int]),
     "ldw_block_stats": (C.c_int, [_p, _i64, _p, _p, _p, _p]),
+    "ldw_links_import": (C.c_int, [_p, C.c_int, _p, _p, _p, _i64, C.c_int]),
     "ldw_aracne": (C.c_int, [_p, _p, _p, _p, _i64, _p, _p, _p, _i64, _p]),
     "ldw_sr_len_quantiles": (C.c_int, [_p, C.c_int, C.c_double, C.c_double, C.c_int32, _p, _p, _p]),
     "ldw_sr_excess_stats": (C.c_int, [_p, C.c_int, C.c_int32, _p, _p]),

@@ -1840,6 +1840,28 @@ int ldw_links_fetch(ldw_ctx *c, int which, int32_t *a_out, int32_t *b_out, doubl
     return LDW_OK;
 }
 
+int ldw_links_import(ldw_ctx *c, int which, const int32_t *a, const int32_t *b, const double *MI, int64_t n, int on_device) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(which == 0 || which == 1, LDW_ERR_ARG, "ldw_links_import: which must be 0 (sr) or 1 (lr)");
+    LDW_REQUIRE(n >= 0 && (n == 0 || (a && b && MI)), LDW_ERR_ARG, "ldw_links_import: bad argument");
+    LDW_REQUIRE(c->blk_capacity == 0, LDW_ERR_STATE, "ldw_links_import: a link pass is still open (ldw_links_end)");
+    if (c->gemm_stream) LDW_HIP(hipStreamSynchronize(c->gemm_stream));
+    ldw::DevBuf &A = which == 0 ? c->sr_a : c->lr_a, &B = which == 0 ? c->sr_b : c->lr_b, &M = which == 0 ? c->sr_mi : c->lr_mi;
+    if (int rc = A.reserve((size_t)std::max<int64_t>(n, 1) * 4)) return rc;
+    if (int rc = B.reserve((size_t)std::max<int64_t>(n, 1) * 4)) return rc;
+    if (int rc = M.reserve((size_t)std::max<int64_t>(n, 1) * 8)) return rc;
+    if (n > 0) {
+        const hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        LDW_HIP(hipMemcpyAsync(A.p, a, (size_t)n * 4, k, c->stream));
+        LDW_HIP(hipMemcpyAsync(B.p, b, (size_t)n * 4, k, c->stream));
+        LDW_HIP(hipMemcpyAsync(M.p, MI, (size_t)n * 8, k, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+    }
+    (which == 0 ? c->n_sr : c->n_lr) = n;
+    c->n_red = c->n_pool = 0;   // whatever was derived from the old table is stale
+    return LDW_OK;
+}
+
 int ldw_block_stats(ldw_ctx *c, int64_t nblocks, int64_t *n_lr_total, int64_t *n_lr_kept, int64_t *n_sr,
                     double *disc_thresh) {
     LDW_REQUIRE(c, LDW_ERR_ARG, "null context");

@@ -119,3 +119,22 @@ def gather_link_tables(local: dict, my_blocks: np.ndarray, counts: dict, nblocks
                 cursor[rk] = c0 + n
         out[k] = tuple((torch.cat(s) if s else per_rank[0][k][j][:0]).to(out_dev) for j, s in enumerate(segs))
     return out
+
+
+def gather_block_stats(my_stats: dict, my_blocks: np.ndarray, nblocks: int, group=None) -> dict:
+    """Per-block diagnostics (Engine.block_stats) of all ranks in make_blocks order, on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    keys = ("n_lr_total", "n_lr_kept", "n_sr", "disc_thresh")
+    tab = torch.zeros((nblocks, 4), dtype=torch.float64)
+    if len(my_blocks):
+        idx = torch.as_tensor(np.asarray(my_blocks), dtype=torch.int64)
+        for j, k in enumerate(keys):
+            v = np.asarray(my_stats[k], dtype=np.float64)
+            tab[idx, j] = torch.as_tensor(np.where(np.isnan(v), 0.0, v))   # NaN threshold (no lr links) travels as 0
+    if world > 1:
+        t = tab.cuda() if dist.get_backend(group) == "nccl" else tab
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)   # blocks are disjoint: a sum is a gather here
+        tab = t.cpu()
+    a = tab.numpy()
+    return dict(n_lr_total=a[:, 0].astype(np.int64), n_lr_kept=a[:, 1].astype(np.int64), n_sr=a[:, 2].astype(np.int64),
+                disc_thresh=a[:, 3].copy())

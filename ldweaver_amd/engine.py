@@ -215,6 +215,17 @@ class Engine:
         L.check(L.lib().ldw_links_fetch(self._ctx, which, L.ptr(a), L.ptr(b), L.ptr(mi), n, 0))
         return a, b, mi
 
+    def links_import(self, which: int, a, b, mi):
+        """Replace the context's sr (0) / lr (1) table, e.g. by the table assembled from all ranks (dist.gather_link_tables)."""
+        if _is_torch(a):
+            a, b, mi = a.contiguous(), b.contiguous(), mi.contiguous()
+            assert a.dtype.__str__() == "torch.int32" and mi.dtype.__str__() == "torch.float64" and len(a) == len(b) == len(mi)
+            on_dev = int(a.is_cuda)
+        else:
+            a, b, mi = np.ascontiguousarray(a, dtype=np.int32), np.ascontiguousarray(b, dtype=np.int32), np.ascontiguousarray(mi, dtype=np.float64)
+            on_dev = 0
+        L.check(L.lib().ldw_links_import(self._ctx, int(which), L.ptr(a), L.ptr(b), L.ptr(mi), len(mi), on_dev))
+
     def block_stats(self):
         nb = self._nblocks
         t = np.empty(nb, dtype=np.int64)

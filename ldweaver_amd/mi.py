@@ -127,9 +127,15 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
                            runARACNE=True, perform_SR_analysis_only=False, order_links=True, mega_dset=False, *,
                            engine: Engine | None = None, alignment_resident: bool = False,
                            quirk_mode: int = L.QUIRK_REFERENCE, nlimbs: int = 0, verbose: bool = True,
-                           return_aux: bool = False, sr_model: str = "device"):
+                           return_aux: bool = False, sr_model: str = "device", group=None):
     """Returns the short-range link data.frame (clust_c,pos1,pos2,clust1,clust2,len,MI,srp_max,ARACNE);
-    long-range links are appended to ``lr_save_path`` and the returned frame to ``sr_save_path``."""
+    long-range links are appended to ``lr_save_path`` and the returned frame to ``sr_save_path``.
+
+    Multi-GPU: when ``torch.distributed`` is initialised with more than one rank (one process per GPU, every rank calling
+    this function with the same arguments and its own ``engine``), the block pairs of ``make_blocks`` are dealt over the
+    ranks, every rank computes its share on its GPU, ONE variable-length gather assembles the link tables on rank 0
+    (``dist.gather_link_tables``), rank 0 adopts them (``ldw_links_import``) and runs the short-range model / ARACNE on
+    them and writes the files; the other ranks return None."""
     t000 = time.time()
     say = print if verbose else (lambda *a, **k: None)
     if lr_save_path is None:
@@ -156,7 +162,36 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
         eng.set_snp_meta(snp_dat.r, snp_dat.uqe, POS, paint, g)
         kw = dict(sr_dist=sr_dist, lr_retain_links=lr_retain_links, lr_links_approx=approx or 1.0,
                   sr_only=perform_SR_analysis_only, quirk=quirk_mode)
-        if not perform_SR_analysis_only:
+        world, rank = 1, 0
+        try:
+            import torch.distributed as tdist
+            if tdist.is_available() and tdist.is_initialized():
+                world, rank = tdist.get_world_size(group), tdist.get_rank(group)
+        except ImportError:
+            pass
+        if world > 1:
+            if perform_SR_analysis_only:
+                raise NotImplementedError("perform_SR_analysis_only is not sharded over ranks")
+            from .dist import deal_blocks, gather_block_stats, gather_link_tables
+            mine = deal_blocks(blocks, world)[rank]
+            if len(mine):
+                eng.mi_all_pairs(blocks[mine], **kw)
+                my_stats = eng.block_stats()
+                local = {"sr": eng.links(0, device_tensors=True), "lr": eng.links(1, device_tensors=True)}
+            else:
+                import torch
+                dev = torch.device("cuda", eng.device)
+                e = lambda dt: torch.empty(0, dtype=dt, device=dev)
+                local = {k: (e(torch.int32), e(torch.int32), e(torch.float64)) for k in ("sr", "lr")}
+                my_stats = {k: np.zeros(0, dtype=np.float64 if k == "disc_thresh" else np.int64)
+                            for k in ("n_lr_total", "n_lr_kept", "n_sr", "disc_thresh")}
+            out = gather_link_tables(local, mine, {"sr": my_stats["n_sr"], "lr": my_stats["n_lr_kept"]}, len(blocks), group=group)
+            stats = gather_block_stats(my_stats, mine, len(blocks), group=group)
+            if rank != 0:
+                return None
+            eng.links_import(0, *out["sr"])
+            eng.links_import(1, *out["lr"])
+        elif not perform_SR_analysis_only:
             eng.mi_all_pairs(blocks, **kw)
         else:
             # drop sites that form no link < sr_dist with the other side (R/computePairwiseMI.R:179-189)
@@ -171,7 +206,8 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
                 eng.mi_block_links(fi, ti, **kw)
             eng.links_end()
         la, lb, lmi = eng.links(1)
-        stats = eng.block_stats()
+        if world == 1:
+            stats = eng.block_stats()
         if sr_model == "device":
             # mergeNsort_sr_links + runARACNE on the device-resident table; only the kept links come back
             redd, flags, model_aux = merge_n_sort_sr_links_device(eng, cds_var.nclust, sr_dist, srp_cutoff, POS, paint, g,

@@ -1,0 +1,37 @@
+"""Worker of tests/test_gpu_parity.py::test_perform_mi_computation_two_ranks: one rank of a torch.distributed (gloo) run of
+perform_MI_computation, every rank with its own engine (on the one GPU of the test box).  Rank 0 writes the files."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ldweaver_amd.engine import Engine  # noqa: E402
+from ldweaver_amd import mi as MIH  # noqa: E402
+from ldweaver_amd.snpdat import CdsVar, SnpDat  # noqa: E402
+
+
+def main():
+    outdir = sys.argv[1]
+    dist.init_process_group("gloo")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "snp_sample_states.npz"))
+    o = np.load(os.path.join(ROOT, "tests", "golden", "snp_sample_oracle.npz"))
+    sd = SnpDat.from_states(g["states"], g["POS"], float(o["g"]))
+    with Engine(0) as eng:
+        red = MIH.perform_MI_computation(sd, o["hdw"], CdsVar(paint=o["paint"], nclust=3), ncores=1,
+                                         lr_save_path=os.path.join(outdir, "lr_links.tsv"), sr_save_path=os.path.join(outdir, "sr_links.tsv"),
+                                         plt_folder=os.path.join(outdir, "PLOTS"), max_blk_sz=1000, lr_retain_links=1e5, engine=eng,
+                                         verbose=False, quirk_mode=1)   # LDW_QUIRK_INTENDED, like the single-process run of the test
+    if dist.get_rank() == 0:
+        assert red is not None
+        red.to_pickle(os.path.join(outdir, "red.pkl"))
+    else:
+        assert red is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -2,6 +2,7 @@
 inputs, against the committed golden fixtures, and — at BASELINE.json's sizes — through size-independent properties.
 Bars: integer / index work bit-exact; MI within 1e-6 (north_star), typically ~1e-12 (weight quantisation)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -653,3 +654,31 @@ def test_mixed_precision_gemm_is_exact(engine, synth):
             for x, y in zip(out[(False, 1)][which], out[key][which]):
                 assert np.array_equal(x, y), (which, key)
     assert len(out[(True, 1)][1][2]) > 15000
+
+
+def test_perform_mi_computation_two_ranks(engine, sample, tmp_path):
+    """SURVEY 8e end to end: perform_MI_computation under torch.distributed with 2 ranks (gloo, both engines on this box's
+    one GPU): blocks dealt over the ranks, one gather, rank 0 adopts the assembled tables (ldw_links_import) and runs the
+    short-range model + ARACNE on them.  Files and frame must equal the single-process run's."""
+    import subprocess
+    import pandas as pd
+    sd = SnpDat.from_states(sample["states"], sample["POS"], sample["g"])
+    one = tmp_path / "one"
+    two = tmp_path / "two"
+    one.mkdir()
+    two.mkdir()
+    red1 = MIH.perform_MI_computation(sd, sample["hdw"], CdsVar(paint=sample["paint"], nclust=3), ncores=1,
+                                      lr_save_path=str(one / "lr_links.tsv"), sr_save_path=str(one / "sr_links.tsv"),
+                                      plt_folder=str(one / "PLOTS"), max_blk_sz=1000, lr_retain_links=1e5, engine=engine, verbose=False,
+                                      quirk_mode=L.QUIRK_INTENDED)   # ragged blocks: Q1 scrambles RXY there, the srp fit has no solution
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(os.path.dirname(__file__), "dist_worker.py"), str(two)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (one / "lr_links.tsv").read_bytes() == (two / "lr_links.tsv").read_bytes()
+    red2 = pd.read_pickle(two / "red.pkl")
+    assert list(red1.columns) == list(red2.columns) and len(red1) == len(red2) > 0
+    for c in red1.columns:
+        a, b = red1[c].to_numpy(), red2[c].to_numpy()
+        assert np.array_equal(a, b) if a.dtype.kind in "iub" else np.allclose(a, b, rtol=0, atol=1e-9), c
