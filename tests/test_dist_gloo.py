@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ldweaver_amd.dist import deal_blocks, gather_link_tables
+from ldweaver_amd.dist import deal_blocks, gather_block_stats, gather_link_tables
 from ldweaver_amd.mi import make_blocks
 
 
@@ -31,6 +31,14 @@ def _worker(rank, world, port, q):
             cat = lambda j, dt: torch.as_tensor(np.concatenate([s[j] for s in segs]) if segs else np.zeros(0), dtype=dt)
             local[kind] = (cat(0, torch.int32), cat(1, torch.int32), cat(2, torch.float64))
         out = gather_link_tables(local, mine, counts, len(blocks))
+        # per-block diagnostics travel the same way: every rank ends up with all blocks' rows
+        fake = lambda bi: (1000 + bi, 10 + bi, 5 * bi, float("nan") if bi % 4 == 0 else 0.25 + bi)
+        st = {k: np.array([fake(int(bi))[j] for bi in mine], dtype=np.float64 if k == "disc_thresh" else np.int64)
+              for j, k in enumerate(("n_lr_total", "n_lr_kept", "n_sr", "disc_thresh"))}
+        allst = gather_block_stats(st, mine, len(blocks))
+        exp = [fake(bi) for bi in range(len(blocks))]
+        assert allst["n_lr_total"].tolist() == [e[0] for e in exp] and allst["n_sr"].tolist() == [e[2] for e in exp]
+        assert np.allclose(allst["disc_thresh"], [0.0 if np.isnan(e[3]) else e[3] for e in exp])
         if rank == 0:
             ok = True
             for kind in ("sr", "lr"):
