@@ -174,9 +174,12 @@ constexpr uint64_t UNIT_DISMISSED = 0x8000000000000000ull;
 // mixed-precision path, to the list of their (tile, row-slot class), which is what the gathered low-limb GEMM walks; the
 // index k there tells k_mi_units where the low limbs of the unit's joint sums are.  In verify mode every unit of `all` is
 // listed, the unwanted ones marked.
+// There are two flat lists: units whose SNPs have 1 or 2 fully flagged slots on both sides (bit set in `fastmask`) go to
+// list 0, which the straight-line kernel k_mi_units<true> walks; the others to list 1 (k_mi_units<false>, predicated code).
+// units / n_units point at list 0 / its counter; list 1 follows at units + list_stride / n_units + 1.
 __device__ __forceinline__ void list_wave_units(const EpiArgs &A, const ColMeta *cm, int c_first, int q_base, int n_it, unsigned int all,
-                                                unsigned int wanted, uint64_t *__restrict__ units, unsigned int *__restrict__ n_units,
-                                                int tile = -1) {
+                                                unsigned int wanted, unsigned int fastmask, uint64_t *__restrict__ units,
+                                                unsigned int *__restrict__ n_units, int64_t list_stride, int tile = -1) {
     if (tile < 0) tile = (int)blockIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned int listed = A.E.scr_mode == 2 ? all : wanted;
@@ -199,19 +202,25 @@ __device__ __forceinline__ void list_wave_units(const EpiArgs &A, const ColMeta 
             }
         }
     }
-    unsigned int base = 0;
-    if (lane == 0) base = atomicAdd(n_units, (unsigned int)__popc(listed));
-    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-    if (mine) {
-        const uint64_t u = (uint64_t)((uint32_t)tile * (uint32_t)A.nt + (uint32_t)(q_base + lane)) | kfield;
-        units[base + __popc(listed & ((1u << lane) - 1u))] = ((wanted >> lane) & 1u) ? u : (u | UNIT_DISMISSED);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const unsigned int m = listed & (which == 0 ? fastmask : ~fastmask);
+        if (m == 0) continue;
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(n_units + which, (unsigned int)__popc(m));
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        if (lane < 32 && ((m >> lane) & 1u)) {
+            const uint64_t u = (uint64_t)((uint32_t)tile * (uint32_t)A.nt + (uint32_t)(q_base + lane)) | kfield;
+            units[which * list_stride + base + __popc(m & ((1u << lane) - 1u))] = ((wanted >> lane) & 1u) ? u : (u | UNIT_DISMISSED);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_mi_screen(EpiArgs A, const int32_t *__restrict__ perm_f,
                                                                                             const int32_t *__restrict__ perm_t,
                                                                                             uint64_t *__restrict__ units,
-                                                                                            unsigned int *__restrict__ n_units) {
+                                                                                            unsigned int *__restrict__ n_units,
+                                                                                            int64_t list_stride) {
     __shared__ ColMeta cm[EPI_COLS];
     const bool square = A.nf == A.nt;
     const bool mixed = A.lo.on != 0;
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
     const unsigned int all = n_it >= 32 ? 0xFFFFFFFFu : ((1u << n_it) - 1u);
     wanted = (wanted | ~handled) & all;
-    list_wave_units(A, cm, c_first, q_base, n_it, all, wanted, units, n_units);
+    list_wave_units(A, cm, c_first, q_base, n_it, all, wanted, handled, units, n_units, list_stride);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -280,8 +289,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 constexpr int GEN_COLS = 16;   // column slots per workgroup of k_mi_screen_generic: 4 per wave — the kernel is a chain of
                                // dependent loads per column with nothing else to hide them, so the chains are kept short
 __global__ __launch_bounds__(256) void k_mi_screen_generic(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
-                                                           uint64_t *__restrict__ units, unsigned int *__restrict__ n_units, int tile0,
-                                                           int q0) {
+                                                           uint64_t *__restrict__ units, unsigned int *__restrict__ n_units,
+                                                           int64_t list_stride, int tile0, int q0) {
     __shared__ ColMeta cm[GEN_COLS];
     const bool square = A.nf == A.nt;
     const bool mixed = A.lo.on != 0;
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(256) void k_mi_screen_generic(EpiArgs A, const int3
         const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
         if (__ballot(need) != 0ull) wanted |= 1u << it;
     }
-    list_wave_units(A, cm, c_first, q_base, n_it, mine, wanted & mine, units, n_units, tile);
+    list_wave_units(A, cm, c_first, q_base, n_it, mine, wanted & mine, 0u, units, n_units, list_stride, tile);
 }
 
 // would this pair leave a trace (short-range row or long-range candidate)?  Verify mode of the screen only.
@@ -402,6 +411,9 @@ __global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *_
 // grid-stride over the list.  A few per cent of the block's units are listed, so what counts is latency (the SNP
 // constants of both sides are fetched per unit) — hidden by the number of waves in flight — not throughput.
 // ------------------------------------------------------------------------------------------------
+// FAST: list 0, straight-line variants only — half the registers of the predicated code, so that its waves fit on a CU beside
+// the two workgroups of the next block's GEMM (which runs on the other stream) instead of waiting for them to drain.
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_mi_units(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
                                                   const uint64_t *__restrict__ units, const unsigned int *__restrict__ n_units,
                                                   unsigned long long *__restrict__ ghist) {
@@ -440,7 +452,14 @@ __global__ __launch_bounds__(256) void k_mi_units(EpiArgs A, const int32_t *__re
             Ga.lj = ld;
             Ga.shift = A.lo.hi_shift;
         }
-        const double mi = unit_pair_mi(A, R, M, a_loc, b_loc, square, wave_full && col_is_fast(mbu), na0, na_max, (int)(mbu & 7), Ga);
+        double mi;
+        if (FAST) {
+            const int nb = (int)(mbu & 7);
+            if (na0 == 1) mi = nb == 1 ? pair_mi_full<1, 1>(A, R, M, a_loc, b_loc, square, Ga) : pair_mi_full<1, 2>(A, R, M, a_loc, b_loc, square, Ga);
+            else mi = nb == 1 ? pair_mi_full<2, 1>(A, R, M, a_loc, b_loc, square, Ga) : pair_mi_full<2, 2>(A, R, M, a_loc, b_loc, square, Ga);
+        } else {
+            mi = unit_pair_mi(A, R, M, a_loc, b_loc, square, wave_full && col_is_fast(mbu), na0, na_max, (int)(mbu & 7), Ga);
+        }
         if (dismissed) {   // verify mode: a pair of a dismissed unit that would have been emitted was lost by the screen
             if (would_emit(A.E, M.ci, a_loc, b_loc, mi)) atomicAdd(A.E.scr_viol, 1ull);
             continue;
@@ -973,7 +992,8 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
     if (A.E.scr_mode && A.E.cols && !A.E.write_dense && (nf == nt || quirk == LDW_QUIRK_INTENDED)) {
         // speculative mode: the lean fp32 screen lists the units that need the exact value, k_mi_units evaluates those
         const size_t n_units_max = (size_t)egrid.x * (size_t)nt;
-        const size_t o_cnt = 64, o_flat = o_cnt + ((size_t)egrid.x * 12 + 63) / 64 * 64, o_tl = o_flat + n_units_max * 8;
+        const size_t o_cnt = 64, o_flat = o_cnt + ((size_t)egrid.x * 12 + 63) / 64 * 64, o_tl = o_flat + 2 * n_units_max * 8;
+        const int64_t list_stride = (int64_t)n_units_max;   // two flat lists: straight-line units, the others
         if (int rc = c->scr_units.reserve(o_tl + n_units_max * 4 + 64)) return rc;
         char *ub = c->scr_units.as<char>();
         unsigned int *n_units = reinterpret_cast<unsigned int *>(ub);
@@ -999,17 +1019,17 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
             lo.slot_pfix_hi = c->slot_pfix_hi.as<int64_t>();
             lo.hi_shift = 8 * LO_LIMBS;
         }
-        hipLaunchKernelGGL(k_mi_screen, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units);
+        hipLaunchKernelGGL(k_mi_screen, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride);
         LDW_HIP(hipGetLastError());
         {   // the units outside k_mi_screen's domain: generic from-tiles x all columns, the other tiles x the generic columns
             const int gt0 = std::min<int>(A.gen_t0, (int)egrid.x);
             const int q0 = std::min<int>(A.gen_q0, (int)nt) / GEN_COLS * GEN_COLS;
             if (gt0 < (int)egrid.x)
                 hipLaunchKernelGGL(k_mi_screen_generic, dim3(egrid.x - gt0, (unsigned)((nt + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A,
-                                   D.perm, D.perm_t, units, n_units, gt0, 0);
+                                   D.perm, D.perm_t, units, n_units, list_stride, gt0, 0);
             if (gt0 > 0 && A.gen_q0 < (int)nt)
                 hipLaunchKernelGGL(k_mi_screen_generic, dim3(gt0, (unsigned)((nt - q0 + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A,
-                                   D.perm, D.perm_t, units, n_units, 0, q0);
+                                   D.perm, D.perm_t, units, n_units, list_stride, 0, q0);
             LDW_HIP(hipGetLastError());
         }
         if (mixed) {   // low limbs of the listed units
@@ -1030,7 +1050,8 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
             P.lo = A.lo;
             if (int rc = launch_gemm_lo_units(c, P, mixed->n_tf, c->stream)) return rc;
         }
-        hipLaunchKernelGGL(k_mi_units, dim3(2048), dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, ghist);
+        hipLaunchKernelGGL(k_mi_units<true>, dim3(2048), dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, ghist);
+        hipLaunchKernelGGL(k_mi_units<false>, dim3(512), dim3(256), 0, c->stream, A, D.perm, D.perm_t, units + list_stride, n_units + 1, ghist);
         LDW_HIP(hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_mi_epilogue, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, ghist);

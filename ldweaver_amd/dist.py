@@ -46,6 +46,10 @@ def gather_link_tables(local: dict, my_blocks: np.ndarray, counts: dict, nblocks
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world == 1:   # one rank owns every block, in make_blocks order already: nothing to move
+        if len(my_blocks) != nblocks:
+            raise RuntimeError("some blocks were processed by no rank")
+        return {k: tuple(local[k]) for k in ("sr", "lr")}
     out_dev = local["sr"][2].device
     # gloo cannot move GPU tensors point to point: stage through the host in that case (CPU tests, or a
     # multi-process run on one GPU); RCCL ("nccl") exchanges device memory directly over xGMI
