@@ -246,10 +246,10 @@ def main():
         roof["executed_frac"] = roof["executed_TOPs"] / i8_peak if roof["executed_TOPs"] else None
         # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (rocprofv3 cannot run inside
         # the bench); only quoted for the configuration they were collected on
-        tpath = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")
         if os.path.exists(tpath) and (L, N, world, J) == (100_000, 5_000, 1, 5) and not args.fused:
             roof["traffic"] = json.load(open(tpath)).get(kname, {}).get("hbm_bytes_per_launch_corrected")
-            roof["traffic_source"] = "profiles/r01g_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+            roof["traffic_source"] = "profiles/r01h_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
         roof["epilogue_avg_launch_ms"] = epi_avg_ms
         roof["epilogue_kernels"] = ("inside the fused kernel" if args.fused else
                                     "k_mi_screen (fp32 screen, lists the units that need the exact value) + gemm_lo_units_kernel (low limbs of "
