@@ -1409,7 +1409,8 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
         // mixed precision: with a bucket guess the block will run the screen, which only needs the high limbs; the low
         // limbs follow for the listed units only.  The guess is frozen here because the GEMM commits to it.
         hb.mixed = c->mixed && c->screen && c->nlimbs == HI_LIMBS + LO_LIMBS && do_lr && guess > 0 &&
-                   (hb.nf == hb.nt || p->quirk_mode == LDW_QUIRK_INTENDED) && lo_bound(c) < 1e-3;
+                   (hb.nf == hb.nt || p->quirk_mode == LDW_QUIRK_INTENDED) && lo_bound(c) < 1e-3 &&
+                   c->N <= 60000;   // the low-limb sums are int32: |sum| <= N * 2^15
         if (hb.mixed) ++c->mixed_blocks;
         EmitArgs E;
         memset(&E, 0, sizeof(E));
