@@ -682,3 +682,54 @@ def test_perform_mi_computation_two_ranks(engine, sample, tmp_path):
     for c in red1.columns:
         a, b = red1[c].to_numpy(), red2[c].to_numpy()
         assert np.array_equal(a, b) if a.dtype.kind in "iub" else np.allclose(a, b, rtol=0, atol=1e-9), c
+
+
+def test_screen_and_mixed_paths_on_multiallelic_alignment(engine):
+    """Stress for the generic screen (k_mi_screen_generic), the class-4 row slots of the gathered low-limb GEMM and the
+    predicated fp64 kernel: an alignment where a third of the SNPs have 3-5 states at sizeable frequencies, some are
+    monomorphic, and the weights are irregular.  Screen + mixed precision (default) against the plain path (5-limb GEMM, fp64
+    for every pair): link tables bit-identical; verify mode: nothing lost."""
+    rng = np.random.default_rng(77)
+    Ls, N = 2600, 640
+    st = np.zeros((Ls, N), dtype=np.uint8)
+    for a in range(Ls):
+        k = rng.integers(0, 10)
+        if k == 0:
+            st[a] = rng.integers(0, 5)                                   # monomorphic
+        elif k <= 3:
+            st[a] = rng.choice(5, size=N, p=rng.dirichlet(np.ones(5)))   # up to 5 states
+        else:
+            maj, mnr = rng.choice(5, size=2, replace=False)
+            st[a] = np.where(rng.random(N) < rng.uniform(0.05, 0.5), mnr, maj)
+        if a % 3 == 1:                                                   # LD with the previous SNP
+            keep = rng.random(N) < 0.9
+            st[a] = np.where(keep, st[a - 1], st[a])
+    uqe, r = orc.uqe_r(st)
+    POS = np.sort(rng.choice(np.arange(1, 400000), size=Ls, replace=False)).astype(np.int32)
+    hdw = 1.0 / rng.integers(1, 40, size=N).astype(np.float64)
+    d = dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=POS, paint=rng.integers(1, 4, Ls).astype(np.int32), g=400000.0)
+    _setup(engine, d)
+    approx = orc.lr_links_approx(POS, d["g"], 20000.0)
+    blocks = np.array(orc.make_blocks(Ls, 1000), dtype=np.int32)       # 1000, 1000, 600: ragged last column -> intended quirk mode
+    out = {}
+    for key, (mixed, scr) in dict(plain=(False, 0), fast=(True, 1), verify=(True, 2)).items():
+        engine.set_mixed(mixed)
+        engine.set_screen(scr)
+        c0 = engine.counters()
+        for _ in range(2):
+            engine.mi_all_pairs(blocks, 20000.0, 30000.0, approx, quirk=L.QUIRK_INTENDED)
+        c1 = engine.counters()
+        out[key] = (engine.links(0), engine.links(1), {k: c1[k] - c0[k] for k in c1})
+    engine.set_mixed(True)
+    engine.set_screen(1)
+    assert out["fast"][2]["mixed_blocks"] >= len(blocks) and out["verify"][2]["screen_violations"] == 0
+    for which in (0, 1):
+        for key in ("fast", "verify"):
+            for x, y in zip(out["plain"][which], out[key][which]):
+                assert np.array_equal(x, y), (which, key)
+    assert len(out["plain"][1][2]) > 20000 and len(out["plain"][0][2]) > 1000
+    # and the plain path itself against the oracle on one off-diagonal block
+    fi, ti = np.arange(0, 1000), np.arange(1000, 2000)
+    Mg = engine.mi_block(fi, ti, quirk=L.QUIRK_INTENDED)
+    Mo = np.array([[orc.mi_pair_direct(st, hdw, r, uqe, int(a), int(b)) for b in (1000, 1500, 1999)] for a in (0, 3, 500, 999)])
+    assert np.abs(Mg[np.ix_([0, 3, 500, 999], [0, 500, 999])] - Mo).max() < MI_TIGHT
