@@ -733,3 +733,69 @@ def test_screen_and_mixed_paths_on_multiallelic_alignment(engine):
     Mg = engine.mi_block(fi, ti, quirk=L.QUIRK_INTENDED)
     Mo = np.array([[orc.mi_pair_direct(st, hdw, r, uqe, int(a), int(b)) for b in (1000, 1500, 1999)] for a in (0, 3, 500, 999)])
     assert np.abs(Mg[np.ix_([0, 3, 500, 999], [0, 500, 999])] - Mo).max() < MI_TIGHT
+
+
+def test_c4_full_size_properties(engine):
+    """BASELINE config 4 at FULL size (100k SNPs x 5k sequences, 55 block pairs, the bench's workload) through
+    size-independent properties: every pair is accounted for exactly once, the long-range rows of every block are in the
+    reference's row order and above the block's threshold, ~lr_retain_links survive, sampled rows of both tables equal the
+    oracle's per-pair MI, and the default path (mixed precision + screen) equals the plain one bit for bit."""
+    import torch
+    Ls, N = 100_000, 5_000
+    syn = synth_alignment(Ls, N, seed=1988, device="cuda", as_numpy=False)
+    st_dev = syn["states"]
+    engine.set_alignment(st_dev)
+    cnt = engine.state_counts()
+    uqe = (cnt > 0).T.astype(np.float64)
+    r = uqe.sum(axis=1)
+    hdw = engine.hamming_weights(int(Ls * 0.1))
+    assert 0 < hdw.min() and hdw.max() <= 1.0
+    engine.set_weights(hdw)
+    POS, g = syn["POS"], float(syn["g"])
+    engine.set_snp_meta(r, uqe, POS, syn["paint"], g)
+    approx = MIH.lr_links_approx(POS, g, 20000.0)
+    blocks = MIH.make_blocks(Ls, 10000)
+    out = {}
+    for key, (mixed, scr) in dict(plain=(False, 0), fast=(True, 1)).items():
+        engine.set_mixed(mixed)
+        engine.set_screen(scr)
+        for _ in range(2):
+            engine.mi_all_pairs(blocks, 20000.0, 1e6, approx)
+        out[key] = (engine.links(0, device_tensors=True), engine.links(1), engine.block_stats())
+    engine.set_mixed(True)
+    engine.set_screen(1)
+    for x, y in zip(out["plain"][0], out["fast"][0]):
+        assert torch.equal(x, y)
+    for x, y in zip(out["plain"][1], out["fast"][1]):
+        assert np.array_equal(x, y)
+    sr, (la, lb, lmi), stt = out["fast"]
+    pairs = sum(nf * (nf - 1) // 2 if (fs, fe) == (ts, te) else nf * nt - min(nf, nt)
+                for fs, fe, ts, te in blocks.tolist() for nf, nt in [(fe - fs + 1, te - ts + 1)])
+    assert int(stt["n_sr"].sum() + stt["n_lr_total"].sum()) == pairs == 4_999_500_000
+    assert len(sr[2]) == int(stt["n_sr"].sum()) and len(lmi) == int(stt["n_lr_kept"].sum())
+    assert 0.95e6 < len(lmi) < 1.05e6          # prob = 1 - lr_retain_links / lr_links_approx keeps ~1e6 in total
+    off = 0
+    for bi, (fs, fe, ts, te) in enumerate(blocks.tolist()):
+        n = int(stt["n_lr_kept"][bi])
+        a, b, m = la[off:off + n] - (fs - 1), lb[off:off + n] - (ts - 1), lmi[off:off + n]
+        off += n
+        assert (m >= stt["disc_thresh"][bi]).all()
+        nf = fe - fs + 1
+        if (fs, fe) == (ts, te):
+            assert (a > b).all() and (np.diff(a.astype(np.int64) + b.astype(np.int64) * nf) > 0).all()
+        else:                                    # all upper-triangle rows (a < b), then all lower ones, each column-major
+            up = a < b
+            k = a.astype(np.int64) + b.astype(np.int64) * nf
+            nu = int(up.sum())
+            assert up[:nu].all() and not up[nu:].any() and (np.diff(k[:nu]) > 0).all() and (np.diff(k[nu:]) > 0).all() and (a != b).all()
+    # sampled rows against the oracle's per-pair MI (square blocks: Q1 reads RXY = r[from[b_loc]] * r[to[a_loc]] / 4)
+    rng = np.random.default_rng(9)
+    blk_of = lambda idx: idx // 10000
+    for tab_a, tab_b, tab_m in ((la, lb, lmi), tuple(t.cpu().numpy() for t in sr)):
+        for k in rng.integers(0, len(tab_m), 12):
+            a, b = int(tab_a[k]), int(tab_b[k])
+            rows = st_dev[[a, b]].cpu().numpy()
+            fa, tb = blk_of(a) * 10000, blk_of(b) * 10000
+            rxy = 0.25 * r[fa + (b - tb)] * r[tb + (a - fa)]
+            ref = orc.mi_pair_direct(rows, hdw, r[[a, b]], uqe[[a, b]], 0, 1, rxy)
+            assert abs(tab_m[k] - ref) < MI_TIGHT, (a, b, tab_m[k], ref)
