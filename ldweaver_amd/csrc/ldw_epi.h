@@ -222,6 +222,11 @@ struct EpiArgs {
     // Both epilogue orders end with the SNPs that have >= 3 minor states or none: from-tiles >= gen_t0 and column slots
     // >= gen_q0 are the domain of k_mi_screen_generic, the rest that of k_mi_screen
     int gen_t0, gen_q0;
+    // Ready-made per-block SNP constants (k_build_packs): what stage_cols / load_col / load_row_side otherwise derive through
+    // a chain of 3-4 dependent loads (permutation -> SNP index -> slot meta / marginals / r / intervals).  null: derive.
+    // The _hi copies carry the marginals of the high-limb weights in pb / pa (screen of the mixed-precision path).
+    const struct ColMeta *colpack, *colpack_hi;   // [nt], epilogue order perm_t
+    const struct RowPack *rowpack, *rowpack_hi;   // [64 * from-tiles], epilogue order perm_f (padded)
     EmitArgs E;
 };
 
@@ -274,6 +279,12 @@ struct RowSide {
     int64_t pa[5];
     double pXd[5];
     float pXf[5];
+};
+
+struct RowPack {
+    RowSide R;
+    int32_t a_loc;   // local index in the from-side list, -1: padding slot of the tile
+    int32_t pad;
 };
 
 // MI of one pair.  NAM / NB bound the unrolled slot loops (na <= NAM for every lane of the wave, nb <= NB);

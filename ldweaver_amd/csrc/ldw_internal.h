@@ -95,7 +95,7 @@ struct ldw_ctx {
     ldw::DevBuf slot_pfix_hi;    // the same for the high-limb weights V_hi (nlimbs == 5)
     ldw::DevBuf glo;             // int32: low-limb joint sums of the listed units (gathered GEMM)
     ldw::DevBuf lo_rows;         // int32 row lists of the gathered GEMM's workgroups
-    ldw::DevBuf lo_meta;         // per-block geometry of the unit lists (device copy)
+    ldw::DevBuf packs;           // per-block SNP constants in epilogue order (ColMeta / RowPack arrays, k_build_packs)
     ldw::DevBuf counts;          // int32 [L][5] per-SNP state counts
     ldw::DevBuf pfix_state;      // int64 [L][5]: fixed-point marginal of each state (histogram engine)
     std::vector<int32_t> h_row0;

@@ -30,7 +30,9 @@ __device__ __forceinline__ void stage_cols(const EpiArgs &A, const int32_t *__re
                                            bool hi_cells = false) {
     if (threadIdx.x < EPI_COLS) {
         const int q = blockIdx.y * EPI_COLS + threadIdx.x;
-        if (q < A.nt) {
+        if (q < A.nt && A.colpack) {
+            cm[threadIdx.x] = (hi_cells ? A.colpack_hi : A.colpack)[q];
+        } else if (q < A.nt) {
             const int b_loc = perm_t[q];
             ColMeta m;
             m.sb = A.idx_t[b_loc];
@@ -56,6 +58,10 @@ __device__ __forceinline__ void stage_cols(const EpiArgs &A, const int32_t *__re
 // the same for ONE column slot q, executed by every lane of a wave with uniform addresses (k_mi_units)
 __device__ __forceinline__ void load_col(const EpiArgs &A, const int32_t *__restrict__ perm_t, bool square, int q, ColMeta &m,
                                          bool hi_cells = false) {
+    if (A.colpack) {
+        m = (hi_cells ? A.colpack_hi : A.colpack)[q];
+        return;
+    }
     const int b_loc = perm_t[q];
     m.sb = A.idx_t[b_loc];
     m.mb = A.slot_meta[m.sb];
@@ -75,10 +81,10 @@ __device__ __forceinline__ void load_col(const EpiArgs &A, const int32_t *__rest
 }
 
 // per-lane constants of the from-side SNP; returns whether the lane holds one
-__device__ __forceinline__ bool load_row_side(const EpiArgs &A, const int32_t *__restrict__ perm_f, bool square, int tile, RowSide &R,
-                                              int &a_loc, bool hi_cells = false) {
+__device__ __forceinline__ bool load_row_side_at(const EpiArgs &A, const int32_t *__restrict__ perm_f, bool square, int t, RowSide &R,
+                                                 int &a_loc, bool hi_cells) {
     // perm_f is padded with -1 so that every tile of 64 holds SNPs of ONE slot-count class (build_perm_tiles)
-    const int pf = perm_f[tile * 64 + (threadIdx.x & 63)];
+    const int pf = perm_f[t];
     const bool a_ok = pf >= 0;
     a_loc = a_ok ? pf : 0;
     R.sa = A.idx_f[a_loc];
@@ -95,6 +101,49 @@ __device__ __forceinline__ bool load_row_side(const EpiArgs &A, const int32_t *_
         if (hi_cells) R.pa[i] = A.lo.slot_pfix_hi[(int64_t)R.sa * 5 + i];
     }
     return a_ok;
+}
+__device__ __forceinline__ bool load_row_side(const EpiArgs &A, const int32_t *__restrict__ perm_f, bool square, int tile, RowSide &R,
+                                              int &a_loc, bool hi_cells = false) {
+    const int t = tile * 64 + (threadIdx.x & 63);
+    if (A.rowpack) {
+        const RowPack &P = (hi_cells ? A.rowpack_hi : A.rowpack)[t];
+        R = P.R;
+        a_loc = P.a_loc < 0 ? 0 : P.a_loc;
+        return P.a_loc >= 0;
+    }
+    return load_row_side_at(A, perm_f, square, t, R, a_loc, hi_cells);
+}
+
+// Per-block SNP constants in epilogue order, once per block instead of once per workgroup (k_mi_screen) or per unit
+// (k_mi_units): thread i builds column slot i (i < nt) and from-side slot i (i < 64 * tiles); A.colpack / A.rowpack are null here.
+__global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
+                                                     int nf_slots, int with_hi, ColMeta *__restrict__ cp, ColMeta *__restrict__ cp_hi,
+                                                     RowPack *__restrict__ rp, RowPack *__restrict__ rp_hi) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool square = A.nf == A.nt;
+    if (i < A.nt) {
+        ColMeta m;
+        load_col(A, perm_t, square, i, m, false);
+        cp[i] = m;
+        if (with_hi) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) m.pb[j] = A.lo.slot_pfix_hi[(int64_t)m.sb * 5 + j];
+            cp_hi[i] = m;
+        }
+    }
+    if (i < nf_slots) {
+        RowPack P;
+        int a_loc;
+        const bool ok = load_row_side_at(A, perm_f, square, i, P.R, a_loc, false);
+        P.a_loc = ok ? a_loc : -1;
+        P.pad = 0;
+        rp[i] = P;
+        if (with_hi) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) P.R.pa[k] = A.lo.slot_pfix_hi[(int64_t)P.R.sa * 5 + k];
+            rp_hi[i] = P;
+        }
+    }
 }
 
 // every active lane of the wave has the same slot count na0 (1 or 2) and all of its slots flagged in uqe
@@ -932,6 +981,8 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
     A.quirk = quirk;
     A.gen_t0 = D.gen_t0;
     A.gen_q0 = D.gen_q0;
+    A.colpack = A.colpack_hi = nullptr;
+    A.rowpack = A.rowpack_hi = nullptr;
     A.E = E;
     memset(&A.lo, 0, sizeof(A.lo));
 }
@@ -1018,6 +1069,23 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
             lo.glo = c->glo.as<int32_t>();
             lo.slot_pfix_hi = c->slot_pfix_hi.as<int64_t>();
             lo.hi_shift = 8 * LO_LIMBS;
+        }
+        {   // per-block SNP constants in epilogue order (A.lo is final by now: the high-limb marginals are reachable)
+            const int nf_slots = (int)egrid.x * 64;
+            const size_t o_cph = ((size_t)nt * sizeof(ColMeta) + 255) / 256 * 256, o_rp = 2 * o_cph;
+            const size_t o_rph = o_rp + ((size_t)nf_slots * sizeof(RowPack) + 255) / 256 * 256;
+            if (int rc = c->packs.reserve(o_rph + (size_t)nf_slots * sizeof(RowPack) + 256)) return rc;
+            char *pb = c->packs.as<char>();
+            ColMeta *cp = reinterpret_cast<ColMeta *>(pb), *cph = reinterpret_cast<ColMeta *>(pb + o_cph);
+            RowPack *rp = reinterpret_cast<RowPack *>(pb + o_rp), *rph = reinterpret_cast<RowPack *>(pb + o_rph);
+            const int nthr = std::max<int>((int)nt, nf_slots);
+            hipLaunchKernelGGL(k_build_packs, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, A, D.perm, D.perm_t, nf_slots,
+                               mixed ? 1 : 0, cp, cph, rp, rph);
+            LDW_HIP(hipGetLastError());
+            A.colpack = cp;
+            A.colpack_hi = mixed ? cph : cp;
+            A.rowpack = rp;
+            A.rowpack_hi = mixed ? rph : rp;
         }
         hipLaunchKernelGGL(k_mi_screen, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride);
         LDW_HIP(hipGetLastError());
