@@ -44,6 +44,7 @@ def parse():
                                                          "k_mi_screen -> k_mi_units, which is faster (DESIGN.md 5.2)")
     ap.add_argument("--no-mixed", action="store_true", help="block-wide GEMM with all 5 limbs instead of 3 high limbs + gathered low limbs")
     ap.add_argument("--screen", type=int, default=1, help="fp32 screen before the fp64 MI evaluation: 0 off, 1 on, 2 verify")
+    ap.add_argument("--gather-phases", type=int, default=3, help="N > 1: phases of the link-table gather (1 = one gather after all blocks)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="SNPs per side of the CPU-baseline sample block (0 = auto)")
     return ap.parse_args()
 
@@ -71,7 +72,7 @@ def main():
     import torch
     import torch.distributed as dist
     from ldweaver_amd import _lib as LL
-    from ldweaver_amd.dist import deal_blocks, gather_link_tables
+    from ldweaver_amd.dist import deal_blocks, gather_begin, gather_end, gather_link_tables
     from ldweaver_amd.engine import Engine
     from ldweaver_amd.mi import lr_links_approx, make_blocks
     from ldweaver_amd.synth import synth_alignment
@@ -136,9 +137,10 @@ def main():
     tim = dict(gemm_ms=0.0, epilogue_ms=0.0, select_ms=0.0, total_ms=0.0)
     result = {}
 
-    def step(accumulate_timing):
-        if len(my_blocks):
-            eng.mi_all_pairs(my_blocks, sr_dist, lr_retain, approx)
+    def compute(sub, accumulate_timing):
+        """This rank's blocks `sub` (indices into blocks) -> its link tables of those blocks (device tensors) + row counts."""
+        if len(sub):
+            eng.mi_all_pairs(blocks[sub], sr_dist, lr_retain, approx)
             st = eng.block_stats()
             local = {"sr": eng.links(0, device_tensors=True), "lr": eng.links(1, device_tensors=True)}
             cnt = {"sr": st["n_sr"], "lr": st["n_lr_kept"]}
@@ -149,7 +151,23 @@ def main():
             e = lambda dt: torch.empty(0, dtype=dt, device=dev)
             local = {k: (e(torch.int32), e(torch.int32), e(torch.float64)) for k in ("sr", "lr")}
             cnt = {"sr": np.zeros(0, dtype=np.int64), "lr": np.zeros(0, dtype=np.int64)}
-        out = gather_link_tables(local, mine, cnt, nblocks)
+        return local, cnt
+
+    # N > 1: the gather runs in phases, so that the rows of the blocks a rank has finished travel over xGMI while it
+    # computes its next ones; only the last phase's transfer is exposed.  Every rank runs the same number of phases.
+    n_phase = 1 if world == 1 else max(1, min(args.gather_phases, -(-nblocks // world)))
+    my_phases = np.array_split(mine, n_phase)
+
+    def step(accumulate_timing):
+        if world == 1:
+            local, cnt = compute(mine, accumulate_timing)
+            out = gather_link_tables(local, mine, cnt, nblocks)
+        else:
+            started = []
+            for sub in my_phases:
+                local, cnt = compute(sub, accumulate_timing)
+                started.append(gather_begin(local, sub, cnt, nblocks))
+            out = gather_end(started, nblocks)
         if out is not None:
             result["n_sr"] = int(out["sr"][2].numel())
             result["n_lr"] = int(out["lr"][2].numel())

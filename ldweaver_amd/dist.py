@@ -5,7 +5,9 @@ given the replicated state matrix (<= 5 GB of 288 GB per GPU), and the long-rang
 (R/computePairwiseMI.R:352-358), so sharding by reference blocks reproduces the reference's retained set
 exactly.  There is no data-path collective; the only exchange is ONE variable-length gather of the link
 tables to rank 0: an all-gather of the per-block row counts followed by a grouped send/recv (RCCL has no
-gatherv; a 7 -> 1 gather uses every peer's own xGMI link to GPU 0 concurrently).
+gatherv; a 7 -> 1 gather uses every peer's own xGMI link to GPU 0 concurrently).  The gather can be started in PHASES
+(gather_begin per subset of a rank's blocks, gather_end once): the rows of the blocks that are done travel while the
+rank computes its next ones, so only the last phase's transfer is exposed.
 
 Works with backend "nccl" (= RCCL, GPU tensors) and "gloo" (CPU tensors, used by the CPU tests).
 """
@@ -36,29 +38,33 @@ def deal_blocks(blocks: np.ndarray, world: int) -> list:
     return [np.nonzero(owner == rk)[0] for rk in range(world)]
 
 
-def gather_link_tables(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int, group=None, dst: int = 0):
-    """Assemble the global link tables on rank ``dst`` in make_blocks order.
+class _Phase:
+    """One started gather: the count table of its blocks, the packed buffers and the outstanding transfers."""
+    __slots__ = ("tab", "owner", "rows", "bufs", "works", "mine", "out_dev", "rank", "world", "dst")
+
+
+def gather_begin(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int, group=None, dst: int = 0) -> _Phase:
+    """Start the gather of the link tables of a SUBSET of blocks (this rank's ``my_blocks``, any rank's may be empty) and
+    return without waiting for the transfers: the caller goes on computing its next blocks while the rows travel, and
+    hands all its phases to ``gather_end``.  Every rank must call it the same number of times (it contains a collective).
 
     local:   {"sr": (a, b, mi), "lr": (a, b, mi)} tensors of this rank (int32, int32, float64), rows grouped by
              block in the order of ``my_blocks``.
     counts:  {"sr": int64[len(my_blocks)], "lr": ...} rows per owned block.
-    Returns the same dict of global tensors on rank dst, None elsewhere.
     """
+    ph = _Phase()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    if world == 1:   # one rank owns every block, in make_blocks order already: nothing to move
-        if len(my_blocks) != nblocks:
-            raise RuntimeError("some blocks were processed by no rank")
-        return {k: tuple(local[k]) for k in ("sr", "lr")}
-    out_dev = local["sr"][2].device
+    ph.world, ph.rank, ph.dst = world, rank, dst
+    ph.out_dev = local["sr"][2].device
     # gloo cannot move GPU tensors point to point: stage through the host in that case (CPU tests, or a
     # multi-process run on one GPU); RCCL ("nccl") exchanges device memory directly over xGMI
-    via_host = world > 1 and dist.get_backend(group) == "gloo" and out_dev.type != "cpu"
+    via_host = world > 1 and dist.get_backend(group) == "gloo" and ph.out_dev.type != "cpu"
     if via_host:
         local = {k: tuple(t.cpu() for t in v) for k, v in local.items()}
     dev = local["sr"][2].device
     kinds = ("sr", "lr")
-    # 1) everyone learns every block's row counts and owner
+    # 1) everyone learns the row counts and owner of the blocks of this phase
     table = torch.zeros((nblocks, 3), dtype=torch.int64, device=dev)  # sr rows, lr rows, owner+1
     if len(my_blocks):
         idx = torch.as_tensor(np.asarray(my_blocks), dtype=torch.int64, device=dev)
@@ -68,61 +74,90 @@ def gather_link_tables(local: dict, my_blocks: np.ndarray, counts: dict, nblocks
     if world > 1:
         dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)  # blocks are disjoint: a sum is a gather here
     tab = table.cpu().numpy()
-    owner = tab[:, 2] - 1
-    if (owner < 0).any():
-        raise RuntimeError("some blocks were processed by no rank")
+    ph.tab, ph.owner = tab, tab[:, 2] - 1
 
     # 2) one packed byte buffer per rank: [sr_a | sr_b | sr_mi | lr_a | lr_b | lr_mi]
     def pack(tabs):
         parts = []
         for k in kinds:
-            a, b, mi = tabs[k]
-            parts += [a.contiguous().view(torch.uint8), b.contiguous().view(torch.uint8), mi.contiguous().view(torch.uint8)]
+            parts += [t.contiguous().view(torch.uint8) for t in tabs[k] if t.numel()]   # (an empty tensor may have stride 0)
         return torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8, device=dev)
 
-    rows = {k: np.array([tab[owner == rk, i].sum() for rk in range(world)]) for i, k in enumerate(kinds)}
-    nbytes = [int(16 * (rows["sr"][rk] + rows["lr"][rk])) for rk in range(world)]
-    mine = pack(local)
-    assert mine.numel() == nbytes[rank], (mine.numel(), nbytes[rank])
-    bufs = None
+    ph.rows = {k: np.array([tab[ph.owner == rk, i].sum() for rk in range(world)]) for i, k in enumerate(kinds)}
+    nbytes = [int(16 * (ph.rows["sr"][rk] + ph.rows["lr"][rk])) for rk in range(world)]
+    ph.mine = pack(local)
+    assert ph.mine.numel() == nbytes[rank], (ph.mine.numel(), nbytes[rank])
+    ph.bufs, ph.works = None, []
     if world > 1:
         if rank == dst:
-            bufs = [mine if rk == dst else torch.empty(nbytes[rk], dtype=torch.uint8, device=dev) for rk in range(world)]
-            ops = [dist.P2POp(dist.irecv, bufs[rk], rk, group) for rk in range(world) if rk != dst and nbytes[rk] > 0]
+            ph.bufs = [ph.mine if rk == dst else torch.empty(nbytes[rk], dtype=torch.uint8, device=dev) for rk in range(world)]
+            ops = [dist.P2POp(dist.irecv, ph.bufs[rk], rk, group) for rk in range(world) if rk != dst and nbytes[rk] > 0]
         else:
-            ops = [dist.P2POp(dist.isend, mine, dst, group)] if nbytes[rank] > 0 else []
+            ops = [dist.P2POp(dist.isend, ph.mine, dst, group)] if nbytes[rank] > 0 else []
         if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            ph.works = dist.batch_isend_irecv(ops)
     else:
-        bufs = [mine]
-    if rank != dst:
-        return None
+        ph.bufs = [ph.mine]
+    return ph
 
-    # 3) unpack and interleave the per-rank segments back into make_blocks order
-    out = {}
-    per_rank = []
-    for rk in range(world):
-        o, d = 0, {}
-        for k in kinds:
-            n = int(rows[k][rk])
-            a = bufs[rk][o:o + 4 * n].view(torch.int32); o += 4 * n
-            b = bufs[rk][o:o + 4 * n].view(torch.int32); o += 4 * n
-            mi = bufs[rk][o:o + 8 * n].view(torch.float64); o += 8 * n
-            d[k] = (a, b, mi)
-        per_rank.append(d)
-    for ki, k in enumerate(kinds):
-        cursor = [0] * world
-        segs = ([], [], [])
-        for bi in range(nblocks):
-            rk, n = int(owner[bi]), int(tab[bi, ki])
-            if n:
+
+def gather_end(phases: list, nblocks: int):
+    """Wait for the transfers of all phases and assemble the global link tables on the destination rank in make_blocks
+    order (None elsewhere)."""
+    for ph in phases:
+        for w in ph.works:
+            w.wait()
+    ph0 = phases[0]
+    if ph0.rank != ph0.dst:
+        return None
+    kinds = ("sr", "lr")
+    owned = np.zeros(nblocks, dtype=bool)
+    # per phase: unpack the per-rank buffers, then cut them into per-block segments
+    segs = {k: [[None, None, None] for _ in range(nblocks)] for k in kinds}
+    for ph in phases:
+        per_rank = []
+        for rk in range(ph.world):
+            o, d = 0, {}
+            for k in kinds:
+                n = int(ph.rows[k][rk])
+                a = ph.bufs[rk][o:o + 4 * n].view(torch.int32); o += 4 * n
+                b = ph.bufs[rk][o:o + 4 * n].view(torch.int32); o += 4 * n
+                mi = ph.bufs[rk][o:o + 8 * n].view(torch.float64); o += 8 * n
+                d[k] = (a, b, mi)
+            per_rank.append(d)
+        for ki, k in enumerate(kinds):
+            cursor = [0] * ph.world
+            for bi in range(nblocks):
+                rk = int(ph.owner[bi])
+                if rk < 0:
+                    continue
+                owned[bi] = True
+                n = int(ph.tab[bi, ki])
                 c0 = cursor[rk]
                 for j in range(3):
-                    segs[j].append(per_rank[rk][k][j][c0:c0 + n])
+                    segs[k][bi][j] = per_rank[rk][k][j][c0:c0 + n]
                 cursor[rk] = c0 + n
-        out[k] = tuple((torch.cat(s) if s else per_rank[0][k][j][:0]).to(out_dev) for j, s in enumerate(segs))
+    if not owned.all():
+        raise RuntimeError("some blocks were processed by no rank")
+    out = {}
+    for k in kinds:
+        cols = []
+        for j, dt in enumerate((torch.int32, torch.int32, torch.float64)):
+            parts = [segs[k][bi][j] for bi in range(nblocks) if segs[k][bi][j] is not None and len(segs[k][bi][j])]
+            cols.append((torch.cat(parts) if parts else torch.empty(0, dtype=dt)).to(ph0.out_dev))
+        out[k] = tuple(cols)
     return out
+
+
+def gather_link_tables(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int, group=None, dst: int = 0):
+    """Assemble the global link tables on rank ``dst`` in make_blocks order (one phase: see gather_begin / gather_end).
+    Returns the same dict of global tensors on rank dst, None elsewhere."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:   # one rank owns every block, in make_blocks order already: nothing to move
+        if len(my_blocks) != nblocks:
+            raise RuntimeError("some blocks were processed by no rank")
+        return {k: tuple(local[k]) for k in ("sr", "lr")}
+    return gather_end([gather_begin(local, my_blocks, counts, nblocks, group=group, dst=dst)], nblocks)
 
 
 def gather_block_stats(my_stats: dict, my_blocks: np.ndarray, nblocks: int, group=None) -> dict:

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ldweaver_amd.dist import deal_blocks, gather_block_stats, gather_link_tables
+from ldweaver_amd.dist import deal_blocks, gather_begin, gather_block_stats, gather_end, gather_link_tables
 from ldweaver_amd.mi import make_blocks
 
 
@@ -31,6 +31,25 @@ def _worker(rank, world, port, q):
             cat = lambda j, dt: torch.as_tensor(np.concatenate([s[j] for s in segs]) if segs else np.zeros(0), dtype=dt)
             local[kind] = (cat(0, torch.int32), cat(1, torch.int32), cat(2, torch.float64))
         out = gather_link_tables(local, mine, counts, len(blocks))
+        # the same tables through a gather in 3 phases (rows of finished blocks travel while the rank computes on): the
+        # chunks are ragged and one of rank 1's phases is empty
+        cuts = [0, 2, len(mine) if rank == 0 else 2, len(mine)]
+        phases = []
+        for p0, p1 in zip(cuts[:-1], cuts[1:]):
+            sub, lo, cn = mine[p0:p1], {}, {}
+            for kind in ("sr", "lr"):
+                segs = [_fake_block_links(int(bi), kind) for bi in sub]
+                cn[kind] = np.array([len(s[2]) for s in segs], dtype=np.int64)
+                cat = lambda j, dt: torch.as_tensor(np.concatenate([s[j] for s in segs]) if segs else np.zeros(0), dtype=dt)
+                lo[kind] = (cat(0, torch.int32), cat(1, torch.int32), cat(2, torch.float64))
+            phases.append(gather_begin(lo, sub, cn, len(blocks)))
+        out3 = gather_end(phases, len(blocks))
+        if rank == 0:
+            for kind in ("sr", "lr"):
+                for j in range(3):
+                    assert torch.equal(out3[kind][j], out[kind][j])
+        else:
+            assert out3 is None
         # per-block diagnostics travel the same way: every rank ends up with all blocks' rows
         fake = lambda bi: (1000 + bi, 10 + bi, 5 * bi, float("nan") if bi % 4 == 0 else 0.25 + bi)
         st = {k: np.array([fake(int(bi))[j] for bi in mine], dtype=np.float64 if k == "disc_thresh" else np.int64)
