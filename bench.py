@@ -155,7 +155,8 @@ def main():
 
     # N > 1: the gather runs in phases, so that the rows of the blocks a rank has finished travel over xGMI while it
     # computes its next ones; only the last phase's transfer is exposed.  Every rank runs the same number of phases.
-    n_phase = 1 if world == 1 else max(1, min(args.gather_phases, -(-nblocks // world)))
+    # (every phase is its own pass of the block pipeline, which costs a start-up / drain: at least 3 blocks per phase)
+    n_phase = 1 if world == 1 else max(1, min(args.gather_phases, (nblocks // world) // 3))
     my_phases = np.array_split(mine, n_phase)
 
     def step(accumulate_timing):
