@@ -1,14 +1,21 @@
 // MI epilogue, link selection and the block drivers (twins of perform_MI_computation_ACGTN,
 // R/computePairwiseMI.R:167-386, and of the block loop of perform_MI_computation, :103-116).
 //
-// Per block:  GEMM (ldw_gemm_bits.hip) -> k_mi_epilogue: one thread per SNP pair turns the fixed-point joint
-// sums into MI (src/computeMI.cpp:19), writes the dense MI block, scatters the short-range links straight
-// to their final rows and histograms the long-range MI values in LDS -> k_pick_bucket: ranks of the two
-// order statistics of quantile type 7 and the histogram bucket holding them -> k_lr_gather: every
-// long-range pair at or above that bucket -> two radix sorts (by MI, then by reference row order) with
-// k_lr_thresh in between -> k_lr_append.  The short-range test needs no arithmetic per pair: POS is
-// ascending, so the partners of a to-side SNP within sr_dist (circularly) are at most three index
-// intervals of the from-side list, found on the host by binary search (ColInfo).
+// First block of a call sequence (no histogram-bucket guess yet), speculation misses, ldw_mi_block:
+//   GEMM, 5 limbs (ldw_gemm_bits.hip) -> k_mi_epilogue: one thread per SNP pair turns the fixed-point joint sums into MI
+//   (src/computeMI.cpp:19), writes the dense MI block, scatters the short-range links straight to their final rows and
+//   histograms the long-range MI values in LDS -> k_pick_bucket: ranks of the two order statistics of quantile type 7
+//   and the histogram bucket holding them -> k_lr_gather: every long-range pair at or above that bucket.
+// Every other block (speculative: the guess is the previous same-kind block's bucket minus a margin):
+//   GEMM, 3 high limbs -> k_build_packs (per-block SNP constants in epilogue order) -> k_mi_screen / k_mi_screen_generic
+//   (fp32 upper bound of MI per pair; lists the units = 64 from-side SNPs x 1 to-side SNP that hold a short-range pair
+//   or a pair that may reach the guessed bucket) -> gemm_lo_units_kernel (the 2 low limbs of the listed units' joint sums)
+//   -> k_mi_units<true|false> (fp64 MI of the listed units, short-range rows to their final rows, candidates >= the
+//   guessed bucket appended and counted) -> k_pick_bucket (verifies the guess).
+// Then, either way: two radix sorts (by MI, then by reference row order) with k_lr_thresh in between -> k_lr_append.
+// The short-range test needs no arithmetic per pair: POS is ascending, so the partners of a to-side SNP within sr_dist
+// (circularly) are at most three index intervals of the from-side list, found on the host by binary search (ColInfo).
+// The fused alternative (GEMM + epilogue in one kernel, ldw_set_fused) lives in ldw_fused.hip.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
