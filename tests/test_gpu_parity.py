@@ -735,13 +735,14 @@ def test_screen_and_mixed_paths_on_multiallelic_alignment(engine):
     assert np.abs(Mg[np.ix_([0, 3, 500, 999], [0, 500, 999])] - Mo).max() < MI_TIGHT
 
 
-def test_c4_full_size_properties(engine):
-    """BASELINE config 4 at FULL size (100k SNPs x 5k sequences, 55 block pairs, the bench's workload) through
-    size-independent properties: every pair is accounted for exactly once, the long-range rows of every block are in the
+@pytest.mark.parametrize("Ls,N", [(100_000, 5_000), (85_000, 616)])
+def test_full_size_properties(engine, Ls, N):
+    """BASELINE config 4 at FULL size (100k SNPs x 5k sequences, 55 block pairs, the bench's workload) and the shape of
+    config 3 (616 genomes; the real alignment is not available offline, SURVEY 8c: synthetic of matching shape, ragged
+    last block column, N not a multiple of 64) through size-independent properties: every pair is accounted for exactly once, the long-range rows of every block are in the
     reference's row order and above the block's threshold, ~lr_retain_links survive, sampled rows of both tables equal the
     oracle's per-pair MI, and the default path (mixed precision + screen) equals the plain one bit for bit."""
     import torch
-    Ls, N = 100_000, 5_000
     syn = synth_alignment(Ls, N, seed=1988, device="cuda", as_numpy=False)
     st_dev = syn["states"]
     engine.set_alignment(st_dev)
@@ -771,7 +772,8 @@ def test_c4_full_size_properties(engine):
     sr, (la, lb, lmi), stt = out["fast"]
     pairs = sum(nf * (nf - 1) // 2 if (fs, fe) == (ts, te) else nf * nt - min(nf, nt)
                 for fs, fe, ts, te in blocks.tolist() for nf, nt in [(fe - fs + 1, te - ts + 1)])
-    assert int(stt["n_sr"].sum() + stt["n_lr_total"].sum()) == pairs == 4_999_500_000
+    assert int(stt["n_sr"].sum() + stt["n_lr_total"].sum()) == pairs
+    assert pairs == (4_999_500_000 if Ls == 100_000 else Ls * (Ls - 1) // 2 - sum(min(fe - fs, te - ts) + 1 for fs, fe, ts, te in blocks.tolist() if fs != ts))
     assert len(sr[2]) == int(stt["n_sr"].sum()) and len(lmi) == int(stt["n_lr_kept"].sum())
     assert 0.95e6 < len(lmi) < 1.05e6          # prob = 1 - lr_retain_links / lr_links_approx keeps ~1e6 in total
     off = 0
@@ -788,7 +790,7 @@ def test_c4_full_size_properties(engine):
             k = a.astype(np.int64) + b.astype(np.int64) * nf
             nu = int(up.sum())
             assert up[:nu].all() and not up[nu:].any() and (np.diff(k[:nu]) > 0).all() and (np.diff(k[nu:]) > 0).all() and (a != b).all()
-    # sampled rows against the oracle's per-pair MI (square blocks: Q1 reads RXY = r[from[b_loc]] * r[to[a_loc]] / 4)
+    # sampled rows against the oracle's per-pair MI with the RXY the reference reads (Q1: linear index of the nt x nf matrix)
     rng = np.random.default_rng(9)
     blk_of = lambda idx: idx // 10000
     for tab_a, tab_b, tab_m in ((la, lb, lmi), tuple(t.cpu().numpy() for t in sr)):
@@ -796,6 +798,7 @@ def test_c4_full_size_properties(engine):
             a, b = int(tab_a[k]), int(tab_b[k])
             rows = st_dev[[a, b]].cpu().numpy()
             fa, tb = blk_of(a) * 10000, blk_of(b) * 10000
-            rxy = 0.25 * r[fa + (b - tb)] * r[tb + (a - fa)]
+            nfb, ntb = min(10000, Ls - fa), min(10000, Ls - tb)
+            rxy = orc.q1_rxy(a - fa, b - tb, nfb, ntb, r[fa:fa + nfb], r[tb:tb + ntb])
             ref = orc.mi_pair_direct(rows, hdw, r[[a, b]], uqe[[a, b]], 0, 1, rxy)
             assert abs(tab_m[k] - ref) < MI_TIGHT, (a, b, tab_m[k], ref)
