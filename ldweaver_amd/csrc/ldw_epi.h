@@ -227,6 +227,7 @@ struct EpiArgs {
     // The _hi copies carry the marginals of the high-limb weights in pb / pa (screen of the mixed-precision path).
     const struct ColMeta *colpack, *colpack_hi;   // [nt], epilogue order perm_t
     const struct RowPack *rowpack, *rowpack_hi;   // [64 * from-tiles], epilogue order perm_f (padded)
+    const float *rloc_f, *rloc_t;                 // r of the from- / to-side SNPs by LOCAL index (quirk Q1 on ragged blocks)
     EmitArgs E;
 };
 

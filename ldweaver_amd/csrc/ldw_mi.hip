@@ -125,9 +125,12 @@ __device__ __forceinline__ bool load_row_side(const EpiArgs &A, const int32_t *_
 // (k_mi_units): thread i builds column slot i (i < nt) and from-side slot i (i < 64 * tiles); A.colpack / A.rowpack are null here.
 __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
                                                      int nf_slots, int with_hi, ColMeta *__restrict__ cp, ColMeta *__restrict__ cp_hi,
-                                                     RowPack *__restrict__ rp, RowPack *__restrict__ rp_hi) {
+                                                     RowPack *__restrict__ rp, RowPack *__restrict__ rp_hi, float *__restrict__ rloc_f,
+                                                     float *__restrict__ rloc_t) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool square = A.nf == A.nt;
+    if (i < A.nf) rloc_f[i] = (float)A.r[A.idx_f[i]];
+    if (i < A.nt) rloc_t[i] = (float)A.r[A.idx_t[i]];
     if (i < A.nt) {
         ColMeta m;
         load_col(A, perm_t, square, i, m, false);
@@ -172,6 +175,18 @@ __device__ __forceinline__ GAcc g_entry(const EpiArgs &A, const RowSide &R, cons
                       tr ? 1 : (int64_t)A.RFpad);
 }
 
+// RXY as the screens need it.  mode 0: intended (r_a r_b); 1: reference quirk Q1 on a square block (r[from[b_loc]] r[to[a_loc]],
+// both staged per SNP); 2: Q1 on a ragged block — the linear index c = a_loc + b_loc nf of the nf x nt matrix read as
+// nt x nf: r[from[c / nt]] r[to[c % nt]], looked up in the per-block local-order tables.
+__device__ __forceinline__ double screen_rxy(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc, int mode) {
+    if (mode == 2) {
+        const uint32_t c = (uint32_t)a_loc + (uint32_t)b_loc * (uint32_t)A.nf;
+        const uint32_t q = c / (uint32_t)A.nt;
+        return (double)(A.rloc_f[q] * A.rloc_t[c - q * (uint32_t)A.nt]) * 0.25;
+    }
+    return (mode == 1 ? M.rq * R.rta : R.ra * M.rb) * 0.25;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_mi_screen: the fp32 screen of the two-kernel path (speculative selection mode).  A long-range pair only matters if
 // its MI reaches the guessed histogram bucket, which about one pair in a thousand does; this kernel bounds MI in fp32
@@ -184,7 +199,7 @@ __device__ __forceinline__ GAcc g_entry(const EpiArgs &A, const RowSide &R, cons
 // ------------------------------------------------------------------------------------------------
 template <int NA, int NB, int U>
 __device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc, bool a_ok,
-                                                    bool rxy_q1, float lo) {
+                                                    int rxy_mode, float lo) {
     FullCells<NA, NB> C[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -197,7 +212,7 @@ __device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowS
         const ColMeta &M = cmu[u];
         const int b_loc = M.bl;
         const bool act = a_ok && (A.E.lower_only ? a_loc > b_loc : a_loc != b_loc);
-        const double rxy = (rxy_q1 ? M.rq * R.rta : R.ra * M.rb) * 0.25;
+        const double rxy = screen_rxy(A, R, M, a_loc, b_loc, rxy_mode);
         const float ms = full_cells_screen<NA, NB>(A, R, M, rxy, C[u]);
         const bool is_sr = test_sr && col_is_sr(M.ci, a_loc);
         const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
@@ -210,13 +225,13 @@ __device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowS
 // at a time, which keeps the kernel near 64 VGPRs
 template <int NA, int U>
 __device__ __forceinline__ unsigned int screen_cols_nb(int nb, const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc,
-                                                       bool a_ok, bool rxy_q1, float lo) {
-    if (NA == 1 && nb == 1) return screen_cols<NA, 1, U>(A, R, cmu, a_loc, a_ok, rxy_q1, lo);
+                                                       bool a_ok, int rxy_mode, float lo) {
+    if (NA == 1 && nb == 1) return screen_cols<NA, 1, U>(A, R, cmu, a_loc, a_ok, rxy_mode, lo);
     constexpr int V = U >= 2 && NA == 1 ? 2 : 1;
     unsigned int bits = 0;
     for (int u = 0; u < U; u += V) {
-        const unsigned int b = nb == 1 ? screen_cols<NA, 1, V>(A, R, cmu + u, a_loc, a_ok, rxy_q1, lo)
-                                       : screen_cols<NA, 2, V>(A, R, cmu + u, a_loc, a_ok, rxy_q1, lo);
+        const unsigned int b = nb == 1 ? screen_cols<NA, 1, V>(A, R, cmu + u, a_loc, a_ok, rxy_mode, lo)
+                                       : screen_cols<NA, 2, V>(A, R, cmu + u, a_loc, a_ok, rxy_mode, lo);
         bits |= b << u;
     }
     return bits;
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     int n_it = A.nt - q_base;
     n_it = n_it > EPI_COLS / 4 ? EPI_COLS / 4 : n_it;
     if (n_it <= 0) return;
-    const bool rxy_q1 = A.quirk == LDW_QUIRK_REFERENCE;
+    const int rxy_mode = A.quirk == LDW_QUIRK_REFERENCE ? (square ? 1 : 2) : 0;
     const float lo = (float)A.E.spec_lo - A.E.scr_eps;
     // wanted: units that need the fp64 kernel; handled: units this kernel could judge (the others are wanted by default)
     unsigned int wanted = 0, handled = 0;
@@ -315,16 +330,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 same = same && col_is_fast(mb0);
             }
             if (same) {
-                const unsigned int b = na0 == 1 ? screen_cols_nb<1, U>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, rxy_q1, lo)
-                                                : screen_cols_nb<2, U>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, rxy_q1, lo);
+                const unsigned int b = na0 == 1 ? screen_cols_nb<1, U>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, rxy_mode, lo)
+                                                : screen_cols_nb<2, U>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, rxy_mode, lo);
                 wanted |= b << it;
                 handled |= ((1u << U) - 1u) << it;
             } else {
                 for (int u = 0; u < U && it + u < n_it; ++u) {
                     const uint32_t mbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmu[u].mb);
                     if (!col_is_fast(mbu)) continue;
-                    const unsigned int b = na0 == 1 ? screen_cols_nb<1, 1>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, rxy_q1, lo)
-                                                    : screen_cols_nb<2, 1>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, rxy_q1, lo);
+                    const unsigned int b = na0 == 1 ? screen_cols_nb<1, 1>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, rxy_mode, lo)
+                                                    : screen_cols_nb<2, 1>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, rxy_mode, lo);
                     wanted |= b << (it + u);
                     handled |= 1u << (it + u);
                 }
@@ -369,7 +384,7 @@ __global__ __launch_bounds__(256) void k_mi_screen_generic(EpiArgs A, const int3
     int n_it = A.nt - q_base;
     n_it = n_it > GEN_COLS / 4 ? GEN_COLS / 4 : n_it;
     if (n_it <= 0) return;
-    const bool rxy_q1 = A.quirk == LDW_QUIRK_REFERENCE;
+    const int rxy_mode = A.quirk == LDW_QUIRK_REFERENCE ? (square ? 1 : 2) : 0;
     const float lo = (float)A.E.spec_lo - A.E.scr_eps;
     const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0, do_lr = A.E.do_lr != 0;
     unsigned int wanted = 0, mine = 0;   // mine: the units of this wave that belong to this kernel
@@ -381,7 +396,7 @@ __global__ __launch_bounds__(256) void k_mi_screen_generic(EpiArgs A, const int3
         mine |= 1u << it;
         const int b_loc = M.bl;
         const bool act = a_ok && (A.E.lower_only ? a_loc > b_loc : a_loc != b_loc);
-        const double rxy = (rxy_q1 ? M.rq * R.rta : R.ra * M.rb) * 0.25;
+        const double rxy = screen_rxy(A, R, M, a_loc, b_loc, rxy_mode);
         const float ms = pair_screen_generic(A, R, M, rxy, g_entry(A, R, M));
         const bool is_sr = test_sr && col_is_sr(M.ci, a_loc);
         const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
@@ -990,6 +1005,7 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
     A.gen_q0 = D.gen_q0;
     A.colpack = A.colpack_hi = nullptr;
     A.rowpack = A.rowpack_hi = nullptr;
+    A.rloc_f = A.rloc_t = nullptr;
     A.E = E;
     memset(&A.lo, 0, sizeof(A.lo));
 }
@@ -1047,7 +1063,7 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
     EpiArgs A;
     fill_epi_args(c, D, nf, nt, RFpad, quirk, E, Gbuf.as<int64_t>(), A);
     if (which == 2) LDW_HIP(hipEventRecord(ev[4], c->stream));
-    if (A.E.scr_mode && A.E.cols && !A.E.write_dense && (nf == nt || quirk == LDW_QUIRK_INTENDED)) {
+    if (A.E.scr_mode && A.E.cols && !A.E.write_dense) {
         // speculative mode: the lean fp32 screen lists the units that need the exact value, k_mi_units evaluates those
         const size_t n_units_max = (size_t)egrid.x * (size_t)nt;
         const size_t o_cnt = 64, o_flat = o_cnt + ((size_t)egrid.x * 12 + 63) / 64 * 64, o_tl = o_flat + 2 * n_units_max * 8;
@@ -1081,13 +1097,17 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
             const int nf_slots = (int)egrid.x * 64;
             const size_t o_cph = ((size_t)nt * sizeof(ColMeta) + 255) / 256 * 256, o_rp = 2 * o_cph;
             const size_t o_rph = o_rp + ((size_t)nf_slots * sizeof(RowPack) + 255) / 256 * 256;
-            if (int rc = c->packs.reserve(o_rph + (size_t)nf_slots * sizeof(RowPack) + 256)) return rc;
+            const size_t o_rf = o_rph + ((size_t)nf_slots * sizeof(RowPack) + 255) / 256 * 256, o_rt = o_rf + ((size_t)nf * 4 + 255) / 256 * 256;
+            if (int rc = c->packs.reserve(o_rt + (size_t)nt * 4 + 256)) return rc;
             char *pb = c->packs.as<char>();
             ColMeta *cp = reinterpret_cast<ColMeta *>(pb), *cph = reinterpret_cast<ColMeta *>(pb + o_cph);
             RowPack *rp = reinterpret_cast<RowPack *>(pb + o_rp), *rph = reinterpret_cast<RowPack *>(pb + o_rph);
+            float *rlf = reinterpret_cast<float *>(pb + o_rf), *rlt = reinterpret_cast<float *>(pb + o_rt);
             const int nthr = std::max<int>((int)nt, nf_slots);
             hipLaunchKernelGGL(k_build_packs, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, A, D.perm, D.perm_t, nf_slots,
-                               mixed ? 1 : 0, cp, cph, rp, rph);
+                               mixed ? 1 : 0, cp, cph, rp, rph, rlf, rlt);
+            A.rloc_f = rlf;
+            A.rloc_t = rlt;
             LDW_HIP(hipGetLastError());
             A.colpack = cp;
             A.colpack_hi = mixed ? cph : cp;
@@ -1483,8 +1503,7 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     if (!hb.fused) {
         // mixed precision: with a bucket guess the block will run the screen, which only needs the high limbs; the low
         // limbs follow for the listed units only.  The guess is frozen here because the GEMM commits to it.
-        hb.mixed = c->mixed && c->screen && c->nlimbs == HI_LIMBS + LO_LIMBS && do_lr && guess > 0 &&
-                   (hb.nf == hb.nt || p->quirk_mode == LDW_QUIRK_INTENDED) && lo_bound(c) < 1e-3 &&
+        hb.mixed = c->mixed && c->screen && c->nlimbs == HI_LIMBS + LO_LIMBS && do_lr && guess > 0 && lo_bound(c) < 1e-3 &&
                    c->N <= 60000;   // the low-limb sums are int32: |sum| <= N * 2^15
         if (hb.mixed) ++c->mixed_blocks;
         EmitArgs E;
