@@ -1438,7 +1438,7 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
         if (int rc = c->cand_key[s].reserve(cap * 8)) return rc;
         if (int rc = c->cand_val[s].reserve(cap * 8)) return rc;
     }
-    E.write_dense = hb.spec_B < 0 ? 1 : 0;
+    E.write_dense = (do_lr && hb.spec_B < 0) ? 1 : 0;   // the dense block only feeds k_lr_gather; SR-only passes take the screen path
     E.spec_B = hb.spec_B;
     E.spec_lo = hb.spec_B > 0 ? bucket_lo(hb.spec_B) : -1e300;
     E.any_sr = hb.n_sr_blk > 0 ? 1 : 0;
