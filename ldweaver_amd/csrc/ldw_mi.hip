@@ -197,23 +197,22 @@ __device__ __forceinline__ double screen_rxy(const EpiArgs &A, const RowSide &R,
 // that bound the one-kernel epilogue (one 512-B load in flight per wave, 3 waves per SIMD: 1.3 TB/s), and U columns per
 // iteration put U independent loads in flight per wave.
 // ------------------------------------------------------------------------------------------------
-template <int NA, int NB, int U>
-__device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc, bool a_ok,
-                                                    int rxy_mode, float lo) {
-    FullCells<NA, NB> C[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        full_cells<NA, NB>(R, cmu[u], g_entry(A, R, cmu[u]), C[u]);
-    }
+template <int NA, int NB, int U, int RM>
+__device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc, bool a_ok, float lo) {
     const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0, do_lr = A.E.do_lr != 0;
+    FullCells<NA, NB> C[U];
+    if (do_lr) {   // an SR-only pass needs no MI here at all: a unit is wanted iff it holds a short-range pair
+#pragma unroll
+        for (int u = 0; u < U; ++u) full_cells<NA, NB>(R, cmu[u], g_entry(A, R, cmu[u]), C[u]);
+    }
     unsigned int bits = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const ColMeta &M = cmu[u];
         const int b_loc = M.bl;
         const bool act = a_ok && (A.E.lower_only ? a_loc > b_loc : a_loc != b_loc);
-        const double rxy = screen_rxy(A, R, M, a_loc, b_loc, rxy_mode);
-        const float ms = full_cells_screen<NA, NB>(A, R, M, rxy, C[u]);
+        float ms = 0.0f;
+        if (do_lr) ms = full_cells_screen<NA, NB>(A, R, M, screen_rxy(A, R, M, a_loc, b_loc, RM), C[u]);
         const bool is_sr = test_sr && col_is_sr(M.ci, a_loc);
         const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
         if (__ballot(need) != 0ull) bits |= 1u << u;
@@ -223,15 +222,15 @@ __device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowS
 
 // U columns at once for biallelic x biallelic units (4 cells each, the bulk of the work); wider tables go two (or one)
 // at a time, which keeps the kernel near 64 VGPRs
-template <int NA, int U>
+template <int NA, int U, int RM>
 __device__ __forceinline__ unsigned int screen_cols_nb(int nb, const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc,
-                                                       bool a_ok, int rxy_mode, float lo) {
-    if (NA == 1 && nb == 1) return screen_cols<NA, 1, U>(A, R, cmu, a_loc, a_ok, rxy_mode, lo);
+                                                       bool a_ok, float lo) {
+    if (NA == 1 && nb == 1) return screen_cols<NA, 1, U, RM>(A, R, cmu, a_loc, a_ok, lo);
     constexpr int V = U >= 2 && NA == 1 ? 2 : 1;
     unsigned int bits = 0;
     for (int u = 0; u < U; u += V) {
-        const unsigned int b = nb == 1 ? screen_cols<NA, 1, V>(A, R, cmu + u, a_loc, a_ok, rxy_mode, lo)
-                                       : screen_cols<NA, 2, V>(A, R, cmu + u, a_loc, a_ok, rxy_mode, lo);
+        const unsigned int b = nb == 1 ? screen_cols<NA, 1, V, RM>(A, R, cmu + u, a_loc, a_ok, lo)
+                                       : screen_cols<NA, 2, V, RM>(A, R, cmu + u, a_loc, a_ok, lo);
         bits |= b << u;
     }
     return bits;
@@ -287,6 +286,9 @@ __device__ __forceinline__ void list_wave_units(const EpiArgs &A, const ColMeta 
     }
 }
 
+// RM: how RXY is read (screen_rxy) — a template parameter so that the common square-block code carries neither the
+// division nor the table look-ups of the ragged case
+template <int RM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_mi_screen(EpiArgs A, const int32_t *__restrict__ perm_f,
                                                                                             const int32_t *__restrict__ perm_t,
                                                                                             uint64_t *__restrict__ units,
@@ -307,7 +309,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     int n_it = A.nt - q_base;
     n_it = n_it > EPI_COLS / 4 ? EPI_COLS / 4 : n_it;
     if (n_it <= 0) return;
-    const int rxy_mode = A.quirk == LDW_QUIRK_REFERENCE ? (square ? 1 : 2) : 0;
     const float lo = (float)A.E.spec_lo - A.E.scr_eps;
     // wanted: units that need the fp64 kernel; handled: units this kernel could judge (the others are wanted by default)
     unsigned int wanted = 0, handled = 0;
@@ -330,16 +331,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 same = same && col_is_fast(mb0);
             }
             if (same) {
-                const unsigned int b = na0 == 1 ? screen_cols_nb<1, U>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, rxy_mode, lo)
-                                                : screen_cols_nb<2, U>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, rxy_mode, lo);
+                const unsigned int b = na0 == 1 ? screen_cols_nb<1, U, RM>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo)
+                                                : screen_cols_nb<2, U, RM>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo);
                 wanted |= b << it;
                 handled |= ((1u << U) - 1u) << it;
             } else {
                 for (int u = 0; u < U && it + u < n_it; ++u) {
                     const uint32_t mbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmu[u].mb);
                     if (!col_is_fast(mbu)) continue;
-                    const unsigned int b = na0 == 1 ? screen_cols_nb<1, 1>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, rxy_mode, lo)
-                                                    : screen_cols_nb<2, 1>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, rxy_mode, lo);
+                    const unsigned int b = na0 == 1 ? screen_cols_nb<1, 1, RM>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, lo)
+                                                    : screen_cols_nb<2, 1, RM>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, lo);
                     wanted |= b << (it + u);
                     handled |= 1u << (it + u);
                 }
@@ -1114,7 +1115,10 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
             A.rowpack = rp;
             A.rowpack_hi = mixed ? rph : rp;
         }
-        hipLaunchKernelGGL(k_mi_screen, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride);
+        const int rm = quirk == LDW_QUIRK_REFERENCE ? (nf == nt ? 1 : 2) : 0;
+        if (rm == 0) hipLaunchKernelGGL(k_mi_screen<0>, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride);
+        else if (rm == 1) hipLaunchKernelGGL(k_mi_screen<1>, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride);
+        else hipLaunchKernelGGL(k_mi_screen<2>, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride);
         LDW_HIP(hipGetLastError());
         {   // the units outside k_mi_screen's domain: generic from-tiles x all columns, the other tiles x the generic columns
             const int gt0 = std::min<int>(A.gen_t0, (int)egrid.x);
