@@ -105,6 +105,12 @@ int ldw_get_alignment(ldw_ctx *ctx, uint8_t *states_out);
 /* hdw_out[j] = 1 / (#{i : L - shared[i][j] < thresh} + 1), thresh = as.integer(L*threshold) computed by
  * the caller.  shared_out (N x N int32, may be NULL) receives the exact shared-state counts. */
 int ldw_hamming_weights(ldw_ctx *ctx, int32_t thresh, double *hdw_out, int32_t *shared_out);
+/* Sharded form: the N x N comparison is symmetric, so only pairs (t, f), t <= f, are computed; this entry
+ * point does the strip of 128-sequence row tiles [tile0, tile1) (tile1 <= ceil(N / 128) rounded to the padding) and
+ * returns counts_out[j] = the strip's contribution to #{i : L - shared[i][j] < thresh} for EVERY j in 0..N-1.  The strips
+ * of all ranks add up to the full count n_j (self included), hdw[j] = 1 / (n_j + 1): exact integers, so every rank
+ * derives bit-identical weights after one all-reduce of N counts. */
+int ldw_hamming_counts(ldw_ctx *ctx, int32_t thresh, int32_t tile0, int32_t tile1, int64_t *counts_out);
 
 /* ---- MI set-up ------------------------------------------------------------------------------ */
 /* Per-sequence weights hdw[N] (R/computePairwiseMI.R:77,89).  The engine uses v_s = fl(sqrt(hdw_s))^2

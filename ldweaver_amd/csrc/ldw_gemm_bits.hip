@@ -37,8 +37,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bits_kernel(const uint64_t *__res
                                                               const int32_t *__restrict__ rowlist_f,
                                                               const int8_t *__restrict__ digits, int64_t Kpad,
                                                               int64_t *__restrict__ G, int RFpad, int lower_only,
-                                                              int shift_bits, int accumulate) {
-    const int bx = blockIdx.x, by = blockIdx.y;  // bx: from-side tile of 64 rows, by: to-side tile of 128 rows
+                                                              int shift_bits, int accumulate, int by0) {
+    const int bx = blockIdx.x, by = blockIdx.y + by0;  // bx: from-side tile of 64 rows, by: to-side tile of 128 rows (grid.y may
+                                                       // cover a strip of them starting at by0: sharded Hamming weights)
     if (lower_only && bx * TILE_F4 + TILE_F4 - 1 < by * TILE) return;
 
     __shared__ GemmSmem<J> S;
@@ -169,13 +170,15 @@ __global__ __launch_bounds__(256) void k_fill_rows_bits(const uint8_t *__restric
 }
 
 int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f,
-                     int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only, hipStream_t stream) {
+                     int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only, hipStream_t stream, int by0, int by1) {
     if (!stream) stream = ctx->stream;
     const int64_t Kpad = KW * 64;
     LDW_REQUIRE(RTpad % TILE == 0 && RFpad % TILE == 0 && KW > 0 && KW % 2 == 0 && Kpad == KW * 64, LDW_ERR_ARG,
                 "launch_gemm_bits: padding violated (RT %d RF %d KW %lld)", RTpad, RFpad, (long long)KW);
     LDW_REQUIRE(nlimbs >= 1 && nlimbs <= 6, LDW_ERR_ARG, "launch_gemm_bits: nlimbs %d out of range", nlimbs);
-    dim3 grid(RFpad / TILE_F4, RTpad / TILE), block(256);
+    if (by1 < 0) by1 = RTpad / TILE;
+    LDW_REQUIRE(by0 >= 0 && by0 < by1 && by1 <= RTpad / TILE, LDW_ERR_ARG, "launch_gemm_bits: bad tile-row range %d..%d", by0, by1);
+    dim3 grid(RFpad / TILE_F4, by1 - by0), block(256);
     int done = 0;
     while (done < nlimbs) {  // up to 5 limbs share one pass over K; 6 limbs run as 3 + 3
         const int J = (nlimbs == 6) ? 3 : nlimbs;
@@ -184,7 +187,7 @@ int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int3
 #define LDW_LAUNCH_B(JJ)                                                                                        \
     case JJ:                                                                                                    \
         hipLaunchKernelGGL(gemm_bits_kernel<JJ>, grid, block, 0, stream, Mbits, KW,                                 \
-                           rowlist_t, rowlist_f, dg, Kpad, G, RFpad, lower_only, shift, accum);                 \
+                           rowlist_t, rowlist_f, dg, Kpad, G, RFpad, lower_only, shift, accum, by0);            \
         break;
         switch (J) {
             LDW_LAUNCH_B(1)

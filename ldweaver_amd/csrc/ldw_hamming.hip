@@ -99,6 +99,25 @@ __global__ __launch_bounds__(256) void k_hdw(const int64_t *__restrict__ G, int 
     if (lane == 0) hdw[j] = 1.0 / ((double)n + 1.0);
 }
 
+// Sharded variant: the workgroup rows t of a strip of the lower-triangular G against every f >= t.  Each unordered pair
+// {t, f} lives in exactly one strip (the one that holds min(t, f)), so the strips' counts add up to k_hdw's n.
+__global__ __launch_bounds__(256) void k_hdw_strip(const int64_t *__restrict__ G, int ld, const int32_t *__restrict__ cnt, int64_t N, int64_t L,
+                                                   int thresh, int64_t t0, int64_t t1, int32_t *__restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = t0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= t1 || t >= N) return;
+    int n = 0;
+    for (int64_t f = t + lane; f < N; f += 64) {
+        if ((L - shared_ij(G, ld, cnt, L, t, f)) < (int64_t)thresh) {
+            ++n;
+            if (f != t) atomicAdd(&counts[f], 1);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
+    if (lane == 0 && n) atomicAdd(&counts[t], n);
+}
+
 __global__ void k_shared_i32(const int64_t *__restrict__ G, int ld, const int32_t *__restrict__ cnt, int64_t N, int64_t L,
                              int32_t *__restrict__ out) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, j = blockIdx.y;
@@ -107,12 +126,16 @@ __global__ void k_shared_i32(const int64_t *__restrict__ G, int ld, const int32_
 
 }  // namespace ldw
 
-extern "C" int ldw_hamming_weights(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *shared_out) {
+// tile0 < 0: the whole matrix -> hdw_out (and shared_out); else the strip of 128-sequence row tiles [tile0, tile1) -> counts_out
+static int hamming_impl(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *shared_out, int tile0, int tile1, int64_t *counts_out) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(c->L > 0, LDW_ERR_STATE, "ldw_hamming_weights: set the alignment first");
-    LDW_REQUIRE(hdw_out, LDW_ERR_ARG, "ldw_hamming_weights: hdw_out is null");
+    const bool strip = tile0 >= 0;
+    LDW_REQUIRE(strip ? counts_out != nullptr : hdw_out != nullptr, LDW_ERR_ARG, "ldw_hamming_weights: output is null");
     const int64_t L = c->L, N = c->N, Npad = c->Npad, KW = c->KW;
     const int Rp = (int)Npad;  // sequences padded to the GEMM tile (Npad is a multiple of 128)
+    LDW_REQUIRE(!strip || (tile0 < tile1 && tile1 <= Rp / ldw::TILE), LDW_ERR_ARG, "ldw_hamming_counts: tile range %d..%d outside 0..%d", tile0,
+                tile1, Rp / ldw::TILE);
     ldw::DevBuf info, Hb, T, dig, um, Gh, rl, scnt, dhdw;
     int rc = LDW_OK;
     auto done = [&](int code) {
@@ -185,9 +208,28 @@ extern "C" int ldw_hamming_weights(ldw_ctx *c, int32_t thresh, double *hdw_out, 
                        (int64_t)Rp, KWr, scnt.as<int32_t>());
     HC(hipGetLastError());
     HC(hipEventRecord(c->ev[2], c->stream));
-    if ((rc = launch_gemm_bits(c, T.as<uint64_t>(), KWr, rl.as<int32_t>(), Rp, rl.as<int32_t>(), Rp, Gh.as<int64_t>(), 1, dig.as<int8_t>(), 1)))
+    if ((rc = launch_gemm_bits(c, T.as<uint64_t>(), KWr, rl.as<int32_t>(), Rp, rl.as<int32_t>(), Rp, Gh.as<int64_t>(), 1, dig.as<int8_t>(), 1,
+                               nullptr, strip ? tile0 : 0, strip ? tile1 : -1)))
         return done(rc);
     HC(hipEventRecord(c->ev[1], c->stream));
+    if (strip) {
+        ldw::DevBuf dcnt;
+        if ((rc = dcnt.reserve((size_t)N * 4))) return done(rc);
+        const int64_t t0 = (int64_t)tile0 * ldw::TILE, t1 = std::min<int64_t>((int64_t)tile1 * ldw::TILE, N);
+        std::vector<int32_t> hcnt((size_t)N, 0);
+        he = hipMemsetAsync(dcnt.p, 0, (size_t)N * 4, c->stream);
+        if (he == hipSuccess && t1 > t0) {
+            hipLaunchKernelGGL(k_hdw_strip, dim3((unsigned)((t1 - t0 + 3) / 4)), dim3(256), 0, c->stream, Gh.as<int64_t>(), Rp, scnt.as<int32_t>(), N, L,
+                               (int)thresh, t0, t1, dcnt.as<int32_t>());
+            he = hipGetLastError();
+        }
+        if (he == hipSuccess) he = hipMemcpyAsync(hcnt.data(), dcnt.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        dcnt.release();
+        if (he != hipSuccess) return done(ldw::hip_fail(he, "strip counts", __FILE__, __LINE__));
+        for (int64_t i = 0; i < N; ++i) counts_out[i] = hcnt[(size_t)i];
+        return done(LDW_OK);
+    }
     hipLaunchKernelGGL(k_hdw, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream, Gh.as<int64_t>(), Rp, scnt.as<int32_t>(), N, L,
                        (int)thresh, dhdw.as<double>());
     HC(hipGetLastError());
@@ -211,4 +253,13 @@ extern "C" int ldw_hamming_weights(ldw_ctx *c, int32_t thresh, double *hdw_out, 
     c->last_ms[3] = t;           // counts + column bits + transpose + GEMM
 #undef HC
     return done(LDW_OK);
+}
+
+extern "C" int ldw_hamming_weights(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *shared_out) {
+    return hamming_impl(c, thresh, hdw_out, shared_out, -1, -1, nullptr);
+}
+
+extern "C" int ldw_hamming_counts(ldw_ctx *c, int32_t thresh, int32_t tile0, int32_t tile1, int64_t *counts_out) {
+    LDW_REQUIRE(tile0 >= 0, LDW_ERR_ARG, "ldw_hamming_counts: tile0 must be >= 0");
+    return hamming_impl(c, thresh, nullptr, nullptr, tile0, tile1, counts_out);
 }

@@ -153,7 +153,8 @@ int launch_hist(ldw_ctx *ctx, const int32_t *idx_f, int nf, const int32_t *idx_t
                 int quirk, int lower_only, double *MI);
 // G[t][f] = sum_k [row t has bit k][row f has bit k] * sum_j digits[j][k] 256^j over the bit matrix Mbits[rows][KW words]
 int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f,
-                     int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only, hipStream_t stream = nullptr);
+                     int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only, hipStream_t stream = nullptr, int by0 = 0,
+                     int by1 = -1);   // by0..by1: strip of 128-row to-side tiles to compute (default: all)
 int fill_rows_bits(ldw_ctx *ctx, const int32_t *d_rowinfo, int64_t R);
 int check_gpu(ldw_ctx *ctx);
 }  // namespace ldw

@@ -177,3 +177,31 @@ def gather_block_stats(my_stats: dict, my_blocks: np.ndarray, nblocks: int, grou
     a = tab.numpy()
     return dict(n_lr_total=a[:, 0].astype(np.int64), n_lr_kept=a[:, 1].astype(np.int64), n_sr=a[:, 2].astype(np.int64),
                 disc_thresh=a[:, 3].copy())
+
+
+def hamming_tile_strips(nseq: int, world: int) -> list:
+    """Row-tile strips [t0, t1) of the symmetric N x N sequence comparison for the ranks: only pairs (t, f), t <= f, are
+    computed, so tile row k costs ~(ntiles - k); the strips are cut at equal cumulative cost."""
+    ntiles = (nseq + 127) // 128
+    cost = np.arange(ntiles, 0, -1, dtype=np.float64)
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    cuts = [int(np.searchsorted(cum, cum[-1] * k / world, side="left")) for k in range(world + 1)]
+    cuts[0], cuts[-1] = 0, ntiles
+    return [(cuts[k], max(cuts[k], cuts[k + 1])) for k in range(world)]
+
+
+def hamming_weights_sharded(eng, thresh: int, group=None) -> np.ndarray:
+    """estimate_Hamming_distance_weights over the ranks of an initialised process group: every rank (its engine holding the
+    same alignment) counts its strip's neighbours (ldw_hamming_counts), ONE all-reduce of N integers, hdw = 1 / (n + 1)
+    on every rank — integers in, so the weights are bit-identical everywhere."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    t0, t1 = hamming_tile_strips(eng.N, world)[rank]
+    cnt = eng.hamming_counts(thresh, t0, t1) if t1 > t0 else np.zeros(eng.N, dtype=np.int64)
+    t = torch.as_tensor(cnt)
+    if world > 1:
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda(eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t = t.cpu()
+    return 1.0 / (t.numpy().astype(np.float64) + 1.0)

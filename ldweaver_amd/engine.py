@@ -134,6 +134,12 @@ class Engine:
         L.check(L.lib().ldw_hamming_weights(self._ctx, int(thresh), L.ptr(hdw), L.ptr(shared)))
         return (hdw, shared) if want_shared else hdw
 
+    def hamming_counts(self, thresh: int, tile0: int, tile1: int) -> np.ndarray:
+        """Contribution of the strip of 128-sequence row tiles [tile0, tile1) to the neighbour counts n_j (all j)."""
+        out = np.zeros(self.N, dtype=np.int64)
+        L.check(L.lib().ldw_hamming_counts(self._ctx, int(thresh), int(tile0), int(tile1), L.ptr(out)))
+        return out
+
     # -- MI --------------------------------------------------------------------
     def set_weights(self, hdw, nlimbs: int = 0):
         w = L.as_c(hdw, np.float64)

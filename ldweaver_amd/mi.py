@@ -71,7 +71,18 @@ def estimate_Hamming_distance_weights(snp_dat: SnpDat, threshold: float = 0.1, m
     try:
         if not alignment_resident:
             eng.set_alignment(snp_dat.states)
-        hdw = eng.hamming_weights(thresh)
+        world = 1
+        try:
+            import torch.distributed as tdist
+            if tdist.is_available() and tdist.is_initialized():
+                world = tdist.get_world_size()
+        except ImportError:
+            pass
+        if world > 1:   # one process per GPU: every rank counts a strip of the sequence x sequence comparison
+            from .dist import hamming_weights_sharded
+            hdw = hamming_weights_sharded(eng, thresh)
+        else:
+            hdw = eng.hamming_weights(thresh)
     finally:
         if own:
             eng.close()

@@ -20,6 +20,8 @@ def main():
     o = np.load(os.path.join(ROOT, "tests", "golden", "snp_sample_oracle.npz"))
     sd = SnpDat.from_states(g["states"], g["POS"], float(o["g"]))
     with Engine(0) as eng:
+        hdw = MIH.estimate_Hamming_distance_weights(sd, threshold=0.1, engine=eng)   # sharded over the two ranks
+        assert np.array_equal(hdw, o["hdw"]), "sharded Hamming weights differ from the golden ones"
         red = MIH.perform_MI_computation(sd, o["hdw"], CdsVar(paint=o["paint"], nclust=3), ncores=1,
                                          lr_save_path=os.path.join(outdir, "lr_links.tsv"), sr_save_path=os.path.join(outdir, "sr_links.tsv"),
                                          plt_folder=os.path.join(outdir, "PLOTS"), max_blk_sz=1000, lr_retain_links=1e5, engine=eng,

@@ -802,3 +802,24 @@ def test_full_size_properties(engine, Ls, N):
             rxy = orc.q1_rxy(a - fa, b - tb, nfb, ntb, r[fa:fa + nfb], r[tb:tb + ntb])
             ref = orc.mi_pair_direct(rows, hdw, r[[a, b]], uqe[[a, b]], 0, 1, rxy)
             assert abs(tab_m[k] - ref) < MI_TIGHT, (a, b, tab_m[k], ref)
+
+
+def test_hamming_counts_strips_add_up(engine, sample, synth):
+    """Sharded Hamming weights: the neighbour counts of any partition of the 128-sequence row tiles into strips
+    add up to the full count, i.e. 1 / (sum + 1) is bit-identical to ldw_hamming_weights (and to the oracle)."""
+    from ldweaver_amd.dist import hamming_tile_strips
+    for d in (sample, synth):
+        engine.set_alignment(d["states"])
+        N = d["states"].shape[1]
+        thr = int(d["states"].shape[0] * 0.1)
+        hdw = engine.hamming_weights(thr)
+        assert np.array_equal(hdw, orc.hamming_weights(d["states"], 0.1))
+        ntiles = (N + 127) // 128
+        for world in (1, 2, 3, 8):
+            strips = hamming_tile_strips(N, world)
+            assert strips[0][0] == 0 and strips[-1][1] == ntiles and all(a[1] == b[0] for a, b in zip(strips[:-1], strips[1:]))
+            tot = np.zeros(N, dtype=np.int64)
+            for t0, t1 in strips:
+                if t1 > t0:
+                    tot += engine.hamming_counts(thr, t0, t1)
+            assert np.array_equal(1.0 / (tot + 1.0), hdw), world
