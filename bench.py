@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--fused", action="store_true", help="GEMM + MI epilogue as one kernel (ldw_set_fused(1)); default is GEMM -> G -> "
                                                          "k_mi_screen -> k_mi_units, which is faster (DESIGN.md 5.2)")
     ap.add_argument("--no-mixed", action="store_true", help="block-wide GEMM with all 5 limbs instead of 3 high limbs + gathered low limbs")
+    ap.add_argument("--path", type=int, default=0, help="block-wide pass of the speculative blocks: 0 auto, 1 limb GEMM paths, 2 approximate GEMM + popcount sums")
     ap.add_argument("--screen", type=int, default=1, help="fp32 screen before the fp64 MI evaluation: 0 off, 1 on, 2 verify")
     ap.add_argument("--gather-phases", type=int, default=3, help="N > 1: phases of the link-table gather (1 = one gather after all blocks)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="SNPs per side of the CPU-baseline sample block (0 = auto)")
@@ -109,6 +110,7 @@ def main():
     eng.set_fused(args.fused)
     eng.set_screen(args.screen)
     eng.set_mixed(not args.no_mixed)
+    eng.set_path(args.path)
     eng.set_alignment(states)
     counts = eng.state_counts()
     uqe = (counts > 0).T.astype(np.float64)

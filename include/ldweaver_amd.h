@@ -66,7 +66,8 @@ int ldw_ctx_last_timing(ldw_ctx *ctx, double ms_out[4]);
  * the dense pass, out[1] = blocks run by the fused GEMM + epilogue kernel, out[2] = blocks run by the two-kernel path,
  * out[3] = pairs the fp32 screen would have lost (counted in ldw_set_screen mode 2 only; must stay 0) */
 int ldw_ctx_counters(ldw_ctx *ctx, int64_t out[4]);
-/* the same four, then out[4] = blocks run in the mixed-precision path (ldw_set_mixed), out[5..7] reserved */
+/* the same four, then out[4] = blocks run in the mixed-precision path (ldw_set_mixed), out[5] = blocks run in the
+ * approximate-GEMM path (ldw_set_path), out[6] = units its approximate screen listed, out[7] = units kept by the exact re-screen */
 int ldw_ctx_counters2(ldw_ctx *ctx, int64_t out[8]);
 
 /* ---- (1) .ACGTN2num  — src/ACGTN2num_parallel.cpp:10-43, R/RcppExports.R:4-6 ------------ */
@@ -176,6 +177,17 @@ int ldw_set_fused(ldw_ctx *ctx, int on);
  * block, the short-range band of a diagonal one) get their 2 low limbs from a gathered GEMM over just those rows:
  * sum = (high << 16) + low, the same integers as the 5-limb GEMM.  Every MI that is emitted is computed from exact sums. */
 int ldw_set_mixed(ldw_ctx *ctx, int on);
+/* Which block-wide pass feeds the screen of the speculative blocks (every block but the first of a call sequence):
+ * 0 (default) = the approximate-GEMM path when the weights allow it — ONE int8 MFMA pass with dual-digit block-floating-
+ *     point weights (V ~ a b 2^e, rigorous relative error bound in the screen's margin), exact joint sums of the listed
+ *     units by class-wise popcounts over the weight classes (sequences of equal weight are contiguous in the bit rows),
+ *     exact re-screen, fp64 — else the limb paths; 1 = the limb paths of ldw_set_mixed only; 2 = the approximate path or
+ *     LDW_ERR_STATE at block time when the weights do not allow it (too many distinct weights, > 30k sequences).
+ * Every MI that is emitted is computed from the exact fixed-point sums either way: the link tables do not depend on it. */
+int ldw_set_path(ldw_ctx *ctx, int mode);
+/* diagnostics of the approximate path after ldw_set_weights: out[0] = usable (0/1), out[1] = max relative error delta of the
+ * dual-digit weights, out[2] = weight classes, out[3] = popcount segments, out[4] = exponent transitions, out[5] = e_last */
+int ldw_apx_info(ldw_ctx *ctx, double out[6]);
 /* fp32 screen in front of the fp64 MI evaluation, in blocks that run the speculative selection: a long-range pair
  * only matters if its MI reaches the guessed histogram bucket, so MI is first bounded in fp32 (v_log_f32, proven
  * error < 1.3e-5 nats, margin 2e-4) and the exact value is computed for the waves that hold a pair which may pass, or a

@@ -68,6 +68,8 @@ _SIGS = {
     "ldw_set_mixed": (C.c_int, [_p, C.c_int]),
     "ldw_ctx_counters2": (C.c_int, [_p, _p]),
     "ldw_set_screen": (C.c_int, [_p, C.c_int]),
+    "ldw_set_path": (C.c_int, [_p, C.c_int]),
+    "ldw_apx_info": (C.c_int, [_p, _p]),
     "ldw_links_count": (C.c_int, [_p, C.c_int, C.POINTER(_i64)]),
     "ldw_links_fetch": (C.c_int, [_p, C.c_int, _p, _p, _p, _i64, C.c_int]),
     "ldw_block_stats": (C.c_int, [_p, _i64, _p, _p, _p, _p]),

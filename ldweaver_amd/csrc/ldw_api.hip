@@ -1,4 +1,5 @@
 // Context, residency, set-up kernels and the small element-wise twins of libldweaver_amd.so.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -262,7 +263,8 @@ int ldw_ctx_destroy(ldw_ctx *c) {
                            &c->sr_mi, &c->lr_a, &c->lr_b, &c->lr_mi, &c->srm_pack, &c->srm_key, &c->srm_pack2, &c->srm_key2, &c->srm_pay, &c->srm_pay2, &c->srm_off,
                            &c->srm_q, &c->srm_n, &c->srm_md, &c->srm_part, &c->srm_shape, &c->srm_cnt, &c->red_row, &c->red_meta,
                            &c->red_srp, &c->pool_a, &c->pool_b, &c->pool_mi, &c->ar_key, &c->ar_val, &c->ar_key2, &c->ar_val2,
-                           &c->ar_off, &c->ar_flags};
+                           &c->ar_off, &c->ar_flags, &c->seq_perm, &c->dig_a, &c->dig_b, &c->apx_shift, &c->slot_papx, &c->pop_segs, &c->pop_wbeg,
+                           &c->panel[0][0], &c->panel[0][1], &c->panel[1][0], &c->panel[1][1], &c->Gapx[0], &c->Gapx[1], &c->cs, &c->pair_sums, &c->pairs[0], &c->pairs[1], &c->apx_units[0], &c->apx_units[1], &c->apx_packs[0], &c->apx_packs[1]};
     for (auto *b : bufs) b->release();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -322,7 +324,9 @@ int ldw_ctx_counters2(ldw_ctx *c, int64_t out[8]) {
     out[2] = c->unfused_blocks;
     out[3] = c->screen_violations;
     out[4] = c->mixed_blocks;
-    out[5] = out[6] = out[7] = 0;
+    out[5] = c->apx_blocks;
+    out[6] = c->apx_units_listed;
+    out[7] = c->apx_units_kept;
     return LDW_OK;
 }
 
@@ -332,6 +336,23 @@ int ldw_ctx_counters(ldw_ctx *c, int64_t out[4]) {
     out[1] = c->fused_blocks;
     out[2] = c->unfused_blocks;
     out[3] = c->screen_violations;
+    return LDW_OK;
+}
+
+int ldw_set_path(ldw_ctx *c, int mode) {
+    LDW_REQUIRE(c && mode >= 0 && mode <= 2, LDW_ERR_ARG, "ldw_set_path: mode must be 0 (auto), 1 (limb GEMM paths) or 2 (approximate GEMM path)");
+    c->path_mode = mode;
+    return LDW_OK;
+}
+
+int ldw_apx_info(ldw_ctx *c, double out[6]) {
+    LDW_REQUIRE(c && out, LDW_ERR_ARG, "ldw_apx_info: null argument");
+    out[0] = c->apx_ok ? 1.0 : 0.0;
+    out[1] = c->apx_delta;
+    out[2] = (double)c->n_classes;
+    out[3] = (double)c->n_pop_segs;
+    out[4] = (double)c->apx_transitions;
+    out[5] = (double)c->apx_e_last;
     return LDW_OK;
 }
 
@@ -535,7 +556,7 @@ int ldw_set_weights(ldw_ctx *c, const double *hdw, int64_t N, int nlimbs) {
     c->frac_bits = F;
     c->neff = (double)neff;
     c->h_vfixed.assign((size_t)c->Npad, 0);
-    std::vector<int8_t> dig((size_t)nlimbs * c->Npad, 0);
+    std::vector<int8_t> dseq((size_t)nlimbs * c->Npad, 0);   // digits by sequence
     int64_t total = 0;
     for (int64_t s = 0; s < N; ++s) {
         int64_t V = (int64_t)std::llround(std::ldexp(v[s], F));
@@ -544,7 +565,7 @@ int ldw_set_weights(ldw_ctx *c, const double *hdw, int64_t N, int nlimbs) {
         int64_t rem = V;
         for (int j = 0; j < nlimbs; ++j) {
             int64_t d = ((rem + 128) & 255) - 128;  // balanced digit in [-128, 127]
-            dig[(size_t)j * c->Npad + s] = (int8_t)d;
+            dseq[(size_t)j * c->Npad + s] = (int8_t)d;
             rem = (rem - d) / 256;
         }
         LDW_REQUIRE(rem == 0, LDW_ERR_ARG, "ldw_set_weights: internal: weight %g does not fit %d limbs at F=%d", v[s], nlimbs, F);
@@ -558,13 +579,29 @@ int ldw_set_weights(ldw_ctx *c, const double *hdw, int64_t N, int nlimbs) {
     if (nlimbs == 5) {
         long double lo_abs = 0;
         for (int64_t s = 0; s < N; ++s) {
-            const int64_t lo = (int64_t)dig[s] + 256 * (int64_t)dig[(size_t)c->Npad + s];
+            const int64_t lo = (int64_t)dseq[s] + 256 * (int64_t)dseq[(size_t)c->Npad + s];
             c->h_vfixed_hi[s] = (c->h_vfixed[s] - lo) / 65536;   // exact: the remainder is what limbs 2..4 encode
             c->total_fixed_hi += c->h_vfixed_hi[s];
             lo_abs += (long double)(lo < 0 ? -lo : lo);
         }
         c->lo_abs_sum = (double)(lo_abs * (long double)std::ldexp(1.0, -F));
     }
+    // Position order of the bit rows: ascending weight (ties by sequence), padding last.  A sum over sequences does not
+    // care about their order; this one makes the sequences of one weight CLASS contiguous (class-wise popcounts of the
+    // approximate-GEMM path) and lets consecutive 128-position macro steps share a block exponent.
+    {
+        std::vector<int32_t> order((size_t)N);
+        for (int64_t s = 0; s < N; ++s) order[(size_t)s] = (int32_t)s;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return c->h_vfixed[x] < c->h_vfixed[y]; });
+        c->h_seq_perm.assign((size_t)c->Npad, -1);
+        for (int64_t q = 0; q < N; ++q) c->h_seq_perm[(size_t)q] = order[(size_t)q];
+    }
+    std::vector<int8_t> dig((size_t)nlimbs * c->Npad, 0);   // digits by position
+    for (int j = 0; j < nlimbs; ++j)
+        for (int64_t q = 0; q < N; ++q) dig[(size_t)j * c->Npad + q] = dseq[(size_t)j * c->Npad + c->h_seq_perm[(size_t)q]];
+    if (int rc = c->seq_perm.reserve((size_t)c->Npad * 4)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->seq_perm.p, c->h_seq_perm.data(), (size_t)c->Npad * 4, hipMemcpyHostToDevice, c->stream));
+    if (int rc = prepare_apx_weights(c)) return rc;
     if (int rc = c->digits.reserve(dig.size())) return rc;
     if (int rc = c->vfixed.reserve((size_t)c->Npad * 8)) return rc;
     LDW_HIP(hipMemcpyAsync(c->digits.p, dig.data(), dig.size(), hipMemcpyHostToDevice, c->stream));
@@ -699,6 +736,30 @@ int ensure_rows(ldw_ctx *c) {
             for (int i = 0; i <= n; ++i) sph[a * 5 + i] = phs[a * 5 + ((m >> (8 + 3 * i)) & 7)];
         }
         LDW_HIP(hipMemcpyAsync(c->slot_pfix_hi.p, sph.data(), (size_t)L * 40, hipMemcpyHostToDevice, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (c->apx_ok) {   // marginals of the approximate weights V' = a b 2^e by slot, in the accumulators' final unit 2^e_last (floor)
+        ldw::DevBuf d_v, d_p, d_cnt2;
+        int rc = LDW_OK;
+        if ((rc = d_v.reserve((size_t)Npad * 8)) || (rc = d_p.reserve((size_t)L * 40)) || (rc = d_cnt2.reserve((size_t)L * 20)) ||
+            (rc = c->slot_papx.reserve((size_t)L * 40))) {
+            d_v.release(); d_p.release(); d_cnt2.release();
+            return rc;
+        }
+        hipError_t he = hipMemcpyAsync(d_v.p, c->h_vapx.data(), (size_t)Npad * 8, hipMemcpyHostToDevice, c->stream);
+        hipLaunchKernelGGL(k_counts_marginals, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, c->stream, c->states.as<uint8_t>(), L, Npad,
+                           d_v.as<int64_t>(), d_cnt2.as<int32_t>(), d_p.as<int64_t>());
+        std::vector<int64_t> pas((size_t)L * 5), spa((size_t)L * 5, 0);
+        if (he == hipSuccess) he = hipMemcpyAsync(pas.data(), d_p.p, (size_t)L * 40, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        d_v.release(); d_p.release(); d_cnt2.release();
+        if (he != hipSuccess) return ldw::hip_fail(he, "approximate-weight marginals", __FILE__, __LINE__);
+        for (int64_t a = 0; a < L; ++a) {
+            const uint32_t m = meta[a];
+            const int n = (int)(m & 7);
+            for (int i = 0; i <= n; ++i) spa[a * 5 + i] = pas[a * 5 + ((m >> (8 + 3 * i)) & 7)] >> c->apx_e_last;
+        }
+        LDW_HIP(hipMemcpyAsync(c->slot_papx.p, spa.data(), (size_t)L * 40, hipMemcpyHostToDevice, c->stream));
         LDW_HIP(hipStreamSynchronize(c->stream));
     }
     // rows R .. R+TILE-1 stay zero: tile padding of the row lists points at row R

@@ -1,0 +1,670 @@
+// Approximate-GEMM path of the speculative blocks: see ldw_apx.h for the formulation.
+//   prepare_apx_weights  host: dual digits a, b and block exponents of the weights, popcount segments of the weight classes
+//   k_pack_panel         per block side: bit rows of the row list, transposed to [macro step][row][2 words]
+//   gemm_apx_kernel      one int8 MFMA pass, both operands masked digits -> int32 approximate joint sums (screen input)
+//   k_units_pop<CF, CT>  exact joint sums of the listed units by class-wise popcounts, exact fp32 re-screen, compaction
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "ldw_apx.h"
+#include "ldw_dev.h"
+
+using namespace ldw;
+
+namespace ldw {
+
+// ------------------------------------------------------------------------------------------------
+// host: weights -> (a, b, e) and popcount segments
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int64_t APX_PROD_CAP = 12000;
+struct ProdTable {
+    std::vector<int32_t> val;
+    std::vector<uint8_t> a, b;
+    ProdTable() {
+        std::vector<std::pair<int32_t, std::pair<uint8_t, uint8_t>>> all;
+        for (int x = 0; x <= 127; ++x)
+            for (int y = x; y <= 127; ++y) all.push_back({x * y, {(uint8_t)x, (uint8_t)y}});
+        std::sort(all.begin(), all.end());
+        for (auto &e : all)
+            if (val.empty() || val.back() != e.first) {
+                val.push_back(e.first);
+                a.push_back(e.second.first);
+                b.push_back(e.second.second);
+            }
+    }
+    // index of the product nearest to t (0 <= t <= 16129)
+    size_t nearest(double t) const {
+        size_t hi = std::lower_bound(val.begin(), val.end(), (int32_t)std::ceil(t)) - val.begin();
+        if (hi >= val.size()) hi = val.size() - 1;
+        size_t lo = hi > 0 ? hi - 1 : 0;
+        return (t - (double)val[lo]) <= ((double)val[hi] - t) ? lo : hi;
+    }
+};
+}  // namespace
+
+int prepare_apx_weights(ldw_ctx *c) {
+    static const ProdTable PT;
+    const int64_t N = c->N, Npad = c->Npad;
+    const int M2 = (int)(Npad / 128);
+    c->apx_ok = false;
+    std::vector<int64_t> Vp((size_t)Npad, 0);
+    for (int64_t p = 0; p < N; ++p) Vp[(size_t)p] = c->h_vfixed[(size_t)c->h_seq_perm[(size_t)p]];
+    // block exponents: smallest non-decreasing e(m) with ceil(Vmax(m) / 2^e) <= APX_PROD_CAP.  Products of two 7-bit digits
+    // are dense up to ~12000 (worst relative half-gap 1.0e-3 over [6000, 12000], 1.2e-3 over [3000, 12000]) and sparse
+    // above (15750 -> 15875: 4e-3), so the largest weight of a macro step is mapped below the sparse region
+    std::vector<int32_t> em((size_t)M2, 0), sh((size_t)M2, 0);
+    int e_prev = 0, transitions = 0;
+    for (int m = 0; m < M2; ++m) {
+        int64_t vmax = 0;
+        for (int q = 0; q < 128; ++q) vmax = std::max(vmax, Vp[(size_t)m * 128 + q]);
+        int e = e_prev;
+        while (e < 62 && ((vmax + ((int64_t)1 << e) - 1) >> e) > APX_PROD_CAP) ++e;
+        em[(size_t)m] = e;
+        if (m > 0 && e > e_prev) {
+            sh[(size_t)m] = std::min(e - e_prev, 31);
+            ++transitions;
+        }
+        e_prev = e;
+    }
+    std::vector<uint8_t> da((size_t)Npad, 0), db((size_t)Npad, 0);
+    c->h_vapx.assign((size_t)Npad, 0);
+    double delta = 0;
+    for (int64_t p = 0; p < N; ++p) {
+        const int64_t V = Vp[(size_t)p];
+        if (V <= 0) continue;
+        const int e = em[(size_t)(p / 128)];
+        const size_t k = PT.nearest(std::ldexp((double)V, -e));
+        da[(size_t)p] = PT.a[k];
+        db[(size_t)p] = PT.b[k];
+        const int64_t Va = (int64_t)PT.val[k] << e;
+        c->h_vapx[(size_t)c->h_seq_perm[(size_t)p]] = Va;
+        delta = std::max(delta, std::fabs((double)(Va - V)) / (double)V);
+    }
+    c->apx_delta = delta;
+    c->apx_e_last = M2 > 0 ? em[(size_t)M2 - 1] : 0;
+    c->apx_transitions = transitions;
+    // weight classes = runs of equal V along the positions; segments = (32-bit word, class) intersections
+    std::vector<PopSeg> segs;
+    std::vector<int32_t> wbeg((size_t)(Npad / 32) + 1, 0);
+    std::vector<std::vector<PopSeg>> per_word((size_t)(Npad / 32));
+    int n_classes = 0;
+    for (int64_t p0 = 0; p0 < N;) {
+        int64_t p1 = p0 + 1;
+        while (p1 < N && Vp[(size_t)p1] == Vp[(size_t)p0]) ++p1;
+        if (Vp[(size_t)p0] > 0) {
+            ++n_classes;
+            for (int64_t w = p0 / 32; w <= (p1 - 1) / 32; ++w) {
+                const int64_t lo = std::max<int64_t>(p0, w * 32) - w * 32, hi = std::min<int64_t>(p1, w * 32 + 32) - w * 32;   // bits [lo, hi)
+                const uint32_t mask = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+                per_word[(size_t)w].push_back(PopSeg{mask, w == (p1 - 1) / 32 ? 1u : 0u, Vp[(size_t)p0]});
+            }
+        }
+        p0 = p1;
+    }
+    for (size_t w = 0; w < per_word.size(); ++w) {
+        wbeg[w] = (int32_t)segs.size();
+        // bit 31: the word is ONE full segment that does not end its class (k_units_pop reads no segment record for it)
+        if (per_word[w].size() == 1 && per_word[w][0].mask == 0xFFFFFFFFu && !per_word[w][0].flush) wbeg[w] |= (int32_t)0x80000000;
+        for (auto &s : per_word[w]) segs.push_back(s);
+    }
+    wbeg[per_word.size()] = (int32_t)segs.size();
+    c->n_pop_segs = (int)segs.size();
+    c->n_classes = n_classes;
+    if (segs.empty()) segs.push_back(PopSeg{0, 0, 0});
+    if (int rc = c->dig_a.reserve((size_t)Npad)) return rc;
+    if (int rc = c->dig_b.reserve((size_t)Npad)) return rc;
+    if (int rc = c->apx_shift.reserve((size_t)std::max(M2, 1) * 4)) return rc;
+    if (int rc = c->pop_segs.reserve(segs.size() * sizeof(PopSeg))) return rc;
+    if (int rc = c->pop_wbeg.reserve(wbeg.size() * 4)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->dig_a.p, da.data(), (size_t)Npad, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemcpyAsync(c->dig_b.p, db.data(), (size_t)Npad, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemcpyAsync(c->apx_shift.p, sh.data(), (size_t)M2 * 4, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemcpyAsync(c->pop_segs.p, segs.data(), segs.size() * sizeof(PopSeg), hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemcpyAsync(c->pop_wbeg.p, wbeg.data(), wbeg.size() * 4, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    // The path pays when (i) the approximation is tight enough for the screen to dismiss almost everything (its margin
+    // grows with delta), (ii) the classes are long enough for the popcounts to beat a gathered limb GEMM (one 64-bit
+    // multiply-add per class and sum against two VALU instructions per 32 sequences), (iii) the digit arrays fit in LDS.
+    c->apx_ok = delta <= 4e-3 && n_classes * 8 <= Npad && Npad <= 30720 && M2 > 0 && segs.size() * sizeof(PopSeg) + (size_t)Npad / 8 + 64 <= 60000;
+    return LDW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pack_panel: panel[m][r][h] = Mbits[rowlist[r]][2 m + h].  Both consumers read one macro step (128 positions) of many
+// consecutive rows at a time; in this layout that is one contiguous run (16 B per row).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_panel(const uint64_t *__restrict__ Mbits, int64_t KW, const int32_t *__restrict__ rowlist,
+                                                    int Rpad, int M2, uint64_t *__restrict__ panel) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const int r = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (r >= Rpad) return;
+    const u64x2 *src = reinterpret_cast<const u64x2 *>(Mbits + (int64_t)rowlist[r] * KW);
+    u64x2 *dst = reinterpret_cast<u64x2 *>(panel);
+    for (int m = threadIdx.x >> 6; m < M2; m += 4) dst[(int64_t)m * Rpad + r] = src[m];
+}
+
+int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_panel, dim3((unsigned)((Rpad + 63) / 64)), dim3(256), 0, st, c->Mbits.as<uint64_t>(), c->KW, rowlist, Rpad,
+                       (int)(c->KW / 2), panel);
+    LDW_HIP(hipGetLastError());
+    return LDW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_apx_kernel<MT, NT>: G'[t][f] = sum_p [row t has bit p][row f has bit p] a_p b_p 2^(e(p) - e_last), truncated at the
+// exponent transitions (each loses < 1 unit).  256 threads = 4 independent waves (2 x 2), each with a tile of MT x NT MFMA
+// tiles of 32 x 32 x 32 int8 (default 4 x 2 = 128 to-side x 64 from-side rows: 128 accumulator registers, everything in
+// VGPRs so that the shift at an exponent transition is plain VALU, two waves per SIMD; with 4 x 4 tiles the accumulators
+// have to live in AGPRs and hipcc 7.2 spills around the shift).  No LDS staging of the operand bits and no barrier in the
+// K loop: every lane reads the 64-bit word of ITS row and lane half straight from the packed panel (consecutive rows are
+// consecutive 16-B pieces: coalesced), one macro step ahead; LDS only holds the 0xFF expansion table and the two digit
+// arrays.  Per MFMA k-step (32 positions) a lane expands 16 bits of each of its MT + NT rows through the table (2 look-ups
+// each) and masks them with the 16 digits of its lane half: 6 (MT + NT) VALU + 2 (MT + NT) ds_read_b64 for MT NT MFMAs.
+// ------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint64_t *lutFF = reinterpret_cast<uint64_t *>(smem);           // [256]: byte of bits -> 8 bytes of 0xFF / 0x00
+    uint8_t *sA = smem + 2048, *sB = sA + (size_t)P.M2 * 128;       // digits by position
+    const int tid = threadIdx.x;
+    {
+        uint64_t e = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e |= ((tid >> k) & 1) ? (0xFFull << (8 * k)) : 0ull;
+        lutFF[tid] = e;
+        const int n16 = P.M2 * 8;   // 16-byte pieces per digit array
+        for (int i = tid; i < n16; i += 256) {
+            reinterpret_cast<uint4 *>(sA)[i] = reinterpret_cast<const uint4 *>(P.dig_a)[i];
+            reinterpret_cast<uint4 *>(sB)[i] = reinterpret_cast<const uint4 *>(P.dig_b)[i];
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ty = 2 * blockIdx.y + (wave >> 1), tx = 2 * blockIdx.x + (wave & 1);
+    constexpr int TH = 32 * MT, TWd = 32 * NT;
+    if (ty * TH >= P.RTpad || tx * TWd >= P.RFpad) return;
+    if (P.lower_only && tx * TWd + TWd - 1 < ty * TH) return;
+    const int frow = lane & 31, fh = lane >> 5;
+    const uint64_t *pa[MT], *pb[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) pa[i] = P.panel_t + ((int64_t)(ty * TH + 32 * i + frow) * 2 + fh);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) pb[i] = P.panel_f + ((int64_t)(tx * TWd + 32 * i + frow) * 2 + fh);
+    const int64_t sta = (int64_t)P.RTpad * 2, stb = (int64_t)P.RFpad * 2;
+    v16i acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+    uint64_t wa[MT], wb[NT], na[MT], nb[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) na[i] = pa[i][0];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) nb[i] = pb[i][0];
+    for (int m = 0; m < P.M2; ++m) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) wa[i] = na[i];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) wb[i] = nb[i];
+        if (m + 1 < P.M2) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) na[i] = pa[i][(int64_t)(m + 1) * sta];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) nb[i] = pb[i][(int64_t)(m + 1) * stb];
+        }
+        const int sh = P.shift[m];
+        if (sh) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = (int)((unsigned)acc[i][j][e] >> sh);
+        }
+        const uint8_t *dA = sA + m * 128 + fh * 64, *dB = sB + m * 128 + fh * 64;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const v4i da = *reinterpret_cast<const v4i *>(dA + 16 * kk);
+            const v4i db = *reinterpret_cast<const v4i *>(dB + 16 * kk);
+            v4i fa[MT], fb[NT];
+            typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const u64x2v qa = {lutFF[(wa[i] >> (16 * kk)) & 0xFFu], lutFF[(wa[i] >> (16 * kk + 8)) & 0xFFu]};
+                fa[i] = __builtin_bit_cast(v4i, qa) & da;
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const u64x2v qb = {lutFF[(wb[i] >> (16 * kk)) & 0xFFu], lutFF[(wb[i] >> (16 * kk + 8)) & 0xFFu]};
+                fb[i] = __builtin_bit_cast(v4i, qb) & db;
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int fcol = tx * TWd + 32 * j + frow;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int trow = ty * TH + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                P.G[(int64_t)trow * P.RFpad + fcol] = acc[i][j][e];
+            }
+        }
+}
+int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
+    LDW_REQUIRE(P.RTpad % APX_TW == 0 && P.RFpad % APX_TW == 0 && P.M2 > 0, LDW_ERR_ARG, "launch_gemm_apx: padding violated (RT %d RF %d M2 %d)", P.RTpad,
+                P.RFpad, P.M2);
+    const size_t lds = 2048 + (size_t)P.M2 * 256;
+    LDW_REQUIRE(lds <= 65536, LDW_ERR_ARG, "launch_gemm_apx: %d positions do not fit the LDS digit arrays", P.M2 * 128);
+    static const int tile = [] {
+        const char *e = getenv("LDW_APX_TILE");   // tuning: wave tile in MFMA tiles, to side x from side (default 4 x 2)
+        return e ? atoi(e) : 42;
+    }();
+#define LDW_APX_LAUNCH(MTv, NTv)                                                                                              \
+    {                                                                                                                         \
+        const int ntx = P.RFpad / (32 * NTv), nty = P.RTpad / (32 * MTv);                                                     \
+        hipLaunchKernelGGL((gemm_apx_kernel<MTv, NTv>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P); \
+    }
+    if (tile == 22) LDW_APX_LAUNCH(2, 2)
+    else if (tile == 24) LDW_APX_LAUNCH(2, 4)
+    else LDW_APX_LAUNCH(4, 2)
+#undef LDW_APX_LAUNCH
+    LDW_HIP(hipGetLastError());
+    return LDW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_units_pop<CF, CT>: exact joint sums of the units listed by the approximate screen.
+// Work item = (from-tile, batch of T = 8 / CT listed to-side SNPs of row-slot class CT): lane = from-side SNP of the tile
+// (CF row slots, its bit words come from the packed panel, coalesced), the to-side rows are wave-uniform (scalar loads from
+// the row-major bit matrix).  Per 32-bit word and (to row, from slot): v_and + v_bcnt accumulate the class count; at the
+// end of a class: sum64 += count * V_class.  The sums are the integers the 5-limb GEMM produces.  Then, per unit: the exact
+// fp32 screen (margin SCREEN_EPS) decides whether any of its 64 pairs needs the fp64 value; kept units are appended to the
+// final list of their code path and their sums stored for k_mi_units.
+// ------------------------------------------------------------------------------------------------
+template <int NA, int NB>
+__device__ __forceinline__ void cells_from_sums(const RowSide &R, const ColMeta &M, const int64_t (&s)[NB][NA], FullCells<NA, NB> &C) {
+    int64_t rs[NA], cs[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) rs[i] = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) cs[j] = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            C.n[i][j] = s[j][i];
+            rs[i] += s[j][i];
+            cs[j] += s[j][i];
+        }
+    int64_t dd = R.pa[NA];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        C.n[NA][j] = M.pb[j] - cs[j];
+        dd -= C.n[NA][j];
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) C.n[i][NB] = R.pa[i] - rs[i];
+    C.n[NA][NB] = dd;
+}
+
+template <int CF, int CT>
+__global__ __launch_bounds__(256) void k_units_pop(PopArgs P) {
+    constexpr int T = 8 / CT;
+    constexpr int LC = CT == 1 ? 0 : (CT == 2 ? 1 : 2);
+    constexpr bool FASTV = CF <= 2 && CT <= 2;
+    // LDS copy of the segment tables: wbeg (bit 31: the word is ONE full segment that does not end its class, the common case:
+    // no segment record is read for it) and the segment records
+    extern __shared__ __attribute__((aligned(16))) uint8_t pop_smem[];
+    int32_t *s_wbeg = reinterpret_cast<int32_t *>(pop_smem);
+    PopSeg *s_segs = reinterpret_cast<PopSeg *>(pop_smem + (((size_t)P.M2 * 4 + 4) * 4 + 15) / 16 * 16);
+    const int tile = blockIdx.x;
+    const bool mine = P.cmax_f[tile] == CF;
+    const unsigned int cnt = mine ? P.A.lo.cnt[tile * 3 + LC] : 0u;
+    const unsigned int nbatch = (cnt + T - 1) / T;
+    if (blockIdx.y * 4u >= nbatch) return;   // the whole workgroup has nothing to do
+    for (int i = threadIdx.x; i < P.M2 * 4 + 1; i += 256) s_wbeg[i] = P.wbeg[i];
+    for (int i = threadIdx.x; i < P.nseg; i += 256) s_segs[i] = P.segs[i];
+    __syncthreads();
+    EpiArgs A = P.A;
+    A.E.scr_shift = P.x_shift;   // the re-screen reads EXACT sums
+    A.E.scr_scale = P.x_scale;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (blockIdx.y * 4u + wave >= nbatch) return;
+    const bool square = A.nf == A.nt;
+    RowSide R;
+    int a_loc, na0;
+    const bool a_ok = load_row_side(A, nullptr, square, tile, R, a_loc);
+    const bool wave_full = FASTV && wave_is_full(R, a_ok, na0) && na0 == CF;
+    const int rxy_mode = A.quirk == LDW_QUIRK_REFERENCE ? (square ? 1 : 2) : 0;
+    const float lo = (float)A.E.spec_lo - SCREEN_EPS;
+    const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0, do_lr = A.E.do_lr != 0;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *pf = reinterpret_cast<const u32x4 *>(P.panel_f) + (a_ok ? R.ra0 : 0);
+
+    for (unsigned int b = blockIdx.y * 4u + wave; b < nbatch; b += gridDim.y * 4u) {
+        // the batch's units: column slot q (bit 31: dismissed by the approximate screen, verify mode), rows of the to-side SNP
+        uint32_t qv[T];
+        // the 8 to-side rows of the batch (T units x CT row slots) x the 4 words of a macro step = 32 dwords: lane l < 32 loads
+        // word l & 3 of row l >> 2 with ONE load per macro step; v_readlane hands them to the whole wave as scalars
+        const uint32_t *my_trow = reinterpret_cast<const uint32_t *>(P.Mbits + (int64_t)P.zero_row * P.KW);
+#pragma unroll
+        for (int u = 0; u < T; ++u) {
+            const unsigned int k = b * T + u;
+            const uint32_t e = k < cnt ? A.lo.tl[(int64_t)tile * A.nt + A.lo.uoff[LC] + k] : 0xFFFFFFFFu;
+            qv[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+            int32_t r0 = P.zero_row, nr = 0;
+            if (qv[u] != 0xFFFFFFFFu) {
+                const int snp = P.idx_t[P.perm_t[qv[u] & 0x7FFFFFFFu]];
+                r0 = P.row0[snp];
+                nr = P.row0[snp + 1] - r0;
+            }
+            r0 = __builtin_amdgcn_readfirstlane(r0);
+            nr = __builtin_amdgcn_readfirstlane(nr);
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+                if (((lane >> 2) & 7) == u * CT + j) my_trow = reinterpret_cast<const uint32_t *>(P.Mbits + (int64_t)(j < nr ? r0 + j : P.zero_row) * P.KW);
+        }
+        my_trow += lane & 3;
+        unsigned int c32[T][CT][CF];
+        int64_t s64[T][CT][CF];
+#pragma unroll
+        for (int u = 0; u < T; ++u)
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int i = 0; i < CF; ++i) {
+                    c32[u][j][i] = 0;
+                    s64[u][j][i] = 0;
+                }
+        u32x4 fn[CF];   // next macro step's words, loaded while the current one is counted
+        uint32_t tnw;
+#pragma unroll
+        for (int i = 0; i < CF; ++i) fn[i] = pf[i];
+        tnw = my_trow[0];
+        const int M2run = (P.debug & 1) ? 1 : P.M2;
+        for (int m = 0; m < M2run; ++m) {
+            u32x4 f[CF];
+            uint32_t t[T][CT][4];
+#pragma unroll
+            for (int i = 0; i < CF; ++i) f[i] = fn[i];
+#pragma unroll
+            for (int u = 0; u < T; ++u)
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[u][j][k] = (uint32_t)__builtin_amdgcn_readlane((int)tnw, (u * CT + j) * 4 + k);
+            if (m + 1 < P.M2) {
+#pragma unroll
+                for (int i = 0; i < CF; ++i) fn[i] = pf[(int64_t)(m + 1) * P.RFpad + i];
+                tnw = my_trow[(m + 1) * 4];
+            }
+            int wb[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) wb[k] = __builtin_amdgcn_readfirstlane(s_wbeg[4 * m + k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (wb[k] < 0) {   // one full segment inside a class
+#pragma unroll
+                    for (int u = 0; u < T; ++u)
+#pragma unroll
+                        for (int j = 0; j < CT; ++j)
+#pragma unroll
+                            for (int i = 0; i < CF; ++i) c32[u][j][i] += __popc(f[i][k] & t[u][j][k]);
+                    continue;
+                }
+                const int s1 = wb[k + 1] & 0x7FFFFFFF;
+                for (int s = wb[k]; s < s1; ++s) {
+                    const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segs[s].mask);
+                    const uint32_t flush = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segs[s].flush);
+                    uint32_t fm[CF];
+#pragma unroll
+                    for (int i = 0; i < CF; ++i) fm[i] = f[i][k] & mask;
+#pragma unroll
+                    for (int u = 0; u < T; ++u)
+#pragma unroll
+                        for (int j = 0; j < CT; ++j)
+#pragma unroll
+                            for (int i = 0; i < CF; ++i) c32[u][j][i] += __popc(fm[i] & t[u][j][k]);
+                    if (flush) {
+                        const int64_t V = s_segs[s].V;
+                        const uint32_t vlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)V);
+                        const uint32_t vhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)V >> 32));
+                        const uint64_t Vu = ((uint64_t)vhi << 32) | vlo;
+#pragma unroll
+                        for (int u = 0; u < T; ++u)
+#pragma unroll
+                            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                                for (int i = 0; i < CF; ++i) {
+                                    s64[u][j][i] += (int64_t)((uint64_t)c32[u][j][i] * Vu);
+                                    c32[u][j][i] = 0;
+                                }
+                    }
+                }
+            }
+        }
+        // per unit: exact re-screen, compaction
+#pragma unroll
+        for (int u = 0; u < T; ++u) {
+            if (qv[u] == 0xFFFFFFFFu || (P.debug & 2)) continue;
+            const bool dismissed_in = (qv[u] & 0x80000000u) != 0;
+            const int q = (int)(qv[u] & 0x7FFFFFFFu);
+            const ColMeta &M = A.colpack[q];
+            const uint32_t mbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.mb);
+            const int b_loc = __builtin_amdgcn_readfirstlane(M.bl);
+            const bool fast = wave_full && col_is_fast(mbu) && (int)(mbu & 7) == CT;
+            bool keep = true;
+            if constexpr (FASTV) {
+                if (fast && A.E.scr_mode) {
+                    FullCells<CF, CT> C;
+                    cells_from_sums<CF, CT>(R, M, s64[u], C);
+                    const bool act = a_ok && (A.E.lower_only ? a_loc > b_loc : a_loc != b_loc);
+                    float ms = 0.0f;
+                    if (do_lr) ms = full_cells_screen<CF, CT>(A, R, M, screen_rxy(A, R, M, a_loc, b_loc, rxy_mode), C);
+                    const bool is_sr = test_sr && col_is_sr(M.ci, a_loc);
+                    const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
+                    keep = __ballot(need) != 0ull;
+                }
+            }
+            // Result, written back into the unit's list entry: dropped (the exact sums rule the unit out), predicated code
+            // (k_mi_units_tl<false>), dismissed (verify mode: evaluated anyway, must not produce anything).  The sums go to the
+            // slot of the unit's list position: no counter, no compaction (4 of 5 listed units are kept).
+            const bool dismissed = dismissed_in || !keep;
+            const unsigned int kpos = b * T + u;
+            uint32_t ent = (uint32_t)q | (fast ? 0u : UNIT_TL_GENERIC);
+            if (dismissed) ent |= A.E.scr_mode == 2 ? UNIT_TL_DISMISSED : UNIT_TL_DROPPED;
+            if (lane == 0) A.lo.tl[(int64_t)tile * A.nt + A.lo.uoff[LC] + kpos] = ent;
+            if (dismissed && A.E.scr_mode != 2) continue;
+            int64_t *dst = P.cs + P.cs_base[tile * 3 + LC] + (int64_t)kpos * (64 * CF * CT) + lane;
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int i = 0; i < CF; ++i) dst[(j * CF + i) * 64] = s64[u][j][i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The long-range candidates listed pair by pair (units without a short-range pair), in two kernels:
+//   k_pair_sums<CA, CB>  one WAVE per pair, lane = 32-bit word of the bit rows (coalesced 256-B reads of the pair's CA + CB rows
+//                        from the row-major bit matrix).  sum_s V_s x_s y_s = sum_words sum_segments V_class popcount(x & y & mask):
+//                        every lane multiplies the popcounts of ITS words by the class weight at once (one 64-bit multiply-add
+//                        per segment) and a wave reduction adds the lanes up: no per-class flush, no serial walk over the row.
+//                        The CA * CB exact sums of pair i of list `sub` go to sums[(sub * cap + i) * 16 + j * 4 + i].
+//   k_pair_mi<NA, NB>    one LANE per pair: the sums -> fp64 MI -> emission (candidate list + histogram).
+// One pair in a few thousand gets here.
+// ------------------------------------------------------------------------------------------------
+struct PairArgs {
+    const uint64_t *Mbits;
+    int64_t KW;
+    int nwords, path;            // 32-bit words per row
+    const PopSeg *segs;
+    const int32_t *wbeg, *row0;
+    int32_t zero_row;
+    int64_t *sums;
+    EpiArgs A;
+    unsigned long long *ghist;
+};
+
+template <int CA, int CB>
+__device__ __forceinline__ void pair_sums_body(const PairArgs &P, int path) {
+    const EpiArgs &A = P.A;
+    const int sub = path * PAIR_SHARDS + (int)blockIdx.y;
+    unsigned int n = A.pl_n[sub];
+    n = n > A.pl_cap ? A.pl_cap : n;
+    const int lane = threadIdx.x & 63;
+    const uint64_t *list = A.pl_pairs + (int64_t)sub * A.pl_cap;
+    for (unsigned int idx = blockIdx.x * 4u + (threadIdx.x >> 6); idx < n; idx += gridDim.x * 4u) {
+        const uint64_t e = list[idx];
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(e >> 32));
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)e);
+        const int sa = __builtin_amdgcn_readfirstlane(A.rowpack[t].R.sa), sb = __builtin_amdgcn_readfirstlane(A.colpack[q].sb);
+        const int r0a = __builtin_amdgcn_readfirstlane(P.row0[sa]), na = __builtin_amdgcn_readfirstlane(P.row0[sa + 1]) - r0a;
+        const int r0b = __builtin_amdgcn_readfirstlane(P.row0[sb]), nb = __builtin_amdgcn_readfirstlane(P.row0[sb + 1]) - r0b;
+        const uint32_t *fr[CA], *tr[CB];
+#pragma unroll
+        for (int i = 0; i < CA; ++i) fr[i] = reinterpret_cast<const uint32_t *>(P.Mbits + (int64_t)(i < na ? r0a + i : P.zero_row) * P.KW);
+#pragma unroll
+        for (int j = 0; j < CB; ++j) tr[j] = reinterpret_cast<const uint32_t *>(P.Mbits + (int64_t)(j < nb ? r0b + j : P.zero_row) * P.KW);
+        int64_t s[CB][CA];
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int i = 0; i < CA; ++i) s[j][i] = 0;
+        for (int w = lane; w < P.nwords; w += 64) {
+            uint32_t f[CA], tt[CB];
+#pragma unroll
+            for (int i = 0; i < CA; ++i) f[i] = fr[i][w];
+#pragma unroll
+            for (int j = 0; j < CB; ++j) tt[j] = tr[j][w];
+            const int s0 = P.wbeg[w] & 0x7FFFFFFF, s1 = P.wbeg[w + 1] & 0x7FFFFFFF;
+            for (int sg = s0; sg < s1; ++sg) {
+                const PopSeg seg = P.segs[sg];
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int i = 0; i < CA; ++i) s[j][i] += (int64_t)((uint64_t)__popc(f[i] & tt[j] & seg.mask) * (uint64_t)seg.V);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int i = 0; i < CA; ++i) {
+                int64_t v = s[j][i];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if (lane == 0) P.sums[((int64_t)sub * A.pl_cap + idx) * 16 + j * 4 + i] = v;
+            }
+    }
+}
+
+// all five lists in one launch: blockIdx.z = path
+__global__ __launch_bounds__(256) void k_pair_sums(PairArgs P) {
+    switch (blockIdx.z) {
+        case 0: pair_sums_body<1, 1>(P, 0); break;
+        case 1: pair_sums_body<2, 1>(P, 1); break;
+        case 2: pair_sums_body<1, 2>(P, 2); break;
+        case 3: pair_sums_body<2, 2>(P, 3); break;
+        default: pair_sums_body<4, 4>(P, 4); break;
+    }
+}
+
+template <int NA, int NB>   // NA = 0: any slot counts (predicated code)
+__device__ __forceinline__ void pair_mi_body(const PairArgs &P, int path) {
+    constexpr bool GEN = NA == 0;
+    const EpiArgs &A = P.A;
+    const int sub = path * PAIR_SHARDS + (int)blockIdx.y;
+    unsigned int n = A.pl_n[sub];
+    n = n > A.pl_cap ? A.pl_cap : n;
+    const bool square = A.nf == A.nt;
+    const uint64_t *list = A.pl_pairs + (int64_t)sub * A.pl_cap;
+    for (unsigned int idx = blockIdx.x * 256u + threadIdx.x; idx < n; idx += gridDim.x * 256u) {
+        const uint64_t e = list[idx];
+        const uint32_t t = (uint32_t)(e >> 32), q = (uint32_t)e;
+        const RowPack &RP = A.rowpack[t];
+        if (RP.a_loc < 0) continue;
+        const RowSide R = RP.R;
+        const int a_loc = RP.a_loc;
+        const ColMeta M = A.colpack[q];
+        const int b_loc = M.bl;
+        const int64_t *sp = P.sums + ((int64_t)sub * A.pl_cap + idx) * 16;
+        double mi;
+        if constexpr (GEN) {
+            mi = pair_mi<4, 4>(A, R, M, a_loc, b_loc, square, gacc_plain(sp, 1, 4));
+        } else {
+            mi = pair_mi_full<NA, NB>(A, R, M, a_loc, b_loc, square, gacc_plain(sp, 1, 4));
+        }
+        emit_pair_spec(A.E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, P.ghist);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pair_mi(PairArgs P) {
+    switch (blockIdx.z) {
+        case 0: pair_mi_body<1, 1>(P, 0); break;
+        case 1: pair_mi_body<2, 1>(P, 1); break;
+        case 2: pair_mi_body<1, 2>(P, 2); break;
+        case 3: pair_mi_body<2, 2>(P, 3); break;
+        default: pair_mi_body<0, 0>(P, 4); break;
+    }
+}
+
+int launch_pairs_exact(ldw_ctx *c, const EpiArgs &A, unsigned long long *ghist, int64_t *sums, hipStream_t st) {
+    PairArgs P;
+    memset(&P, 0, sizeof(P));
+    P.Mbits = c->Mbits.as<uint64_t>();
+    P.KW = c->KW;
+    P.nwords = (int)(c->KW * 2);
+    P.segs = c->pop_segs.as<PopSeg>();
+    P.wbeg = c->pop_wbeg.as<int32_t>();
+    P.row0 = c->row0.as<int32_t>();
+    P.zero_row = (int32_t)c->R;
+    P.sums = sums;
+    P.A = A;
+    P.ghist = ghist;
+    // 1024 waves per list stride over its pairs (one wave per pair), then one lane per pair for the fp64 value
+    hipLaunchKernelGGL(k_pair_sums, dim3(256, PAIR_SHARDS, PAIR_PATHS), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_pair_mi, dim3(16, PAIR_SHARDS, PAIR_PATHS), dim3(256), 0, st, P);
+    LDW_HIP(hipGetLastError());
+    return LDW_OK;
+}
+
+int launch_units_pop(ldw_ctx *c, const PopArgs &P, int nf_tiles, const int n_tiles_cf[3], hipStream_t st) {
+    LDW_REQUIRE(nf_tiles > 0, LDW_ERR_ARG, "launch_units_pop: no from-tiles");
+    // 32 workgroups of 4 waves stride over a tile's batches (most tiles list a few hundred units per class, the short-range
+    // band of a diagonal block a few thousand; workgroups without a batch leave at once)
+    const dim3 grid((unsigned)nf_tiles, 32), block(256);
+    static const int dbg = [] { const char *e = getenv("LDW_POP_DEBUG"); return e ? atoi(e) : 0; }();
+    const_cast<PopArgs &>(P).debug = dbg;
+    const size_t lds = (((size_t)P.M2 * 4 + 4) * 4 + 15) / 16 * 16 + (size_t)P.nseg * sizeof(PopSeg);
+    LDW_REQUIRE(lds <= 65536, LDW_ERR_ARG, "launch_units_pop: %d segments do not fit in LDS", P.nseg);
+#define LDW_POP(CFv, CTv, kf, kt)                                                                      \
+    if (n_tiles_cf[kf] > 0 && P.A.lo.n_lc[kt] > 0) hipLaunchKernelGGL((k_units_pop<CFv, CTv>), grid, block, lds, st, P);
+    LDW_POP(1, 1, 0, 0)
+    LDW_POP(2, 1, 1, 0)
+    LDW_POP(1, 2, 0, 1)
+    LDW_POP(2, 2, 1, 1)
+    LDW_POP(4, 1, 2, 0)
+    LDW_POP(4, 2, 2, 1)
+    LDW_POP(1, 4, 0, 2)
+    LDW_POP(2, 4, 1, 2)
+    LDW_POP(4, 4, 2, 2)
+#undef LDW_POP
+    LDW_HIP(hipGetLastError());
+    return LDW_OK;
+}
+
+}  // namespace ldw

@@ -125,6 +125,12 @@ struct EmitArgs {
     float scr_scale;                     // 2^scr_shift * 2^-frac_bits
     float scr_eps;                       // margin of the screen: SCREEN_EPS (+ the bound of the low limbs in the mixed path)
     unsigned long long *scr_viol;        // verify mode: pairs the screen would have lost
+    // approximate-GEMM path (ldw_apx.h): the joint sums the screen reads are int32 sums of the approximate weights
+    // V' = a b 2^e in units of 2^e_last, each within a relative apx_delta of the exact sum plus a few truncated units
+    int apx;                             // 1: G is int32 [RTpad][RFpad]
+    int apx_EG;                          // exponent transitions of the K loop: a GEMM entry lost < apx_EG units
+    float apx_dfac;                      // 1.01 delta / (1 - delta)
+    float apx_s1;                        // 2^(e_last - F) (2 ln(neff + 12.5) + 3.1) / (1 - delta): what one lost unit can add to den * MI
 };
 
 __device__ __forceinline__ void emit_pair(const EmitArgs &E, const ColInfo &c, int a_loc, int b_loc, int sa, int sb,
@@ -210,7 +216,7 @@ __host__ __device__ __forceinline__ int lo_class(int nrows) { return nrows <= 1 
 
 struct EpiArgs {
     const int64_t *G;
-    int RFpad;
+    int RFpad, RTpad;
     LoGeom lo;
     const int32_t *idx_f, *lrow_f, *idx_t, *lrow_t;
     int nf, nt;
@@ -228,8 +234,16 @@ struct EpiArgs {
     const struct ColMeta *colpack, *colpack_hi;   // [nt], epilogue order perm_t
     const struct RowPack *rowpack, *rowpack_hi;   // [64 * from-tiles], epilogue order perm_f (padded)
     const float *rloc_f, *rloc_t;                 // r of the from- / to-side SNPs by LOCAL index (quirk Q1 on ragged blocks)
+    // approximate-GEMM path: long-range candidates of units WITHOUT a short-range pair are listed pair by pair (one in a
+    // thousand pairs passes the screen: evaluating the whole unit of 64 for it wastes 98 %): PAIR_PATHS x PAIR_SHARDS lists of
+    // pl_cap entries (from-slot index << 32 | column slot), list = path * PAIR_SHARDS + (workgroup & 7)
+    uint64_t *pl_pairs;
+    unsigned int *pl_n;
+    uint32_t pl_cap;
     EmitArgs E;
 };
+constexpr int PAIR_PATHS = 5;    // (NA, NB) = (1,1) (2,1) (1,2) (2,2) straight-line code, 4 = predicated
+constexpr int PAIR_SHARDS = 8;
 
 // arguments of the fused GEMM + epilogue kernel (ldw_fused.hip); A.G is unused there
 struct FusedArgs {
@@ -301,12 +315,14 @@ struct GAcc {
     const int32_t *l;
     int64_t li, lj;
     int shift;
+    int w32;   // g addresses int32 entries (approximate-GEMM path)
     __device__ __forceinline__ int64_t at(int i, int j) const {
+        if (w32) return (int64_t)reinterpret_cast<const int32_t *>(g)[i * si + j * sj];
         const int64_t v = g[i * si + j * sj];
         return l ? (v << shift) + (int64_t)l[i * li + j * lj] : v;
     }
 };
-__device__ __forceinline__ GAcc gacc_plain(const int64_t *g, int64_t si, int64_t sj) { return GAcc{g, si, sj, nullptr, 0, 0, 0}; }
+__device__ __forceinline__ GAcc gacc_plain(const int64_t *g, int64_t si, int64_t sj) { return GAcc{g, si, sj, nullptr, 0, 0, 0, 0}; }
 
 template <int NAM, int NB>
 __device__ __forceinline__ double pair_mi(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc,
@@ -461,13 +477,19 @@ __device__ __forceinline__ double full_cells_mi(const EpiArgs &A, const RowSide 
 // every pair both ways and counts the pairs the screen would have lost (tests assert zero).
 constexpr float SCREEN_EPS = 2e-4f;
 
-template <int NA, int NB>
+// APX (approximate-GEMM path): the cells are int32 sums of the approximate weights V' (units of 2^e_last) and the value
+// returned is an UPPER BOUND of the MI of the exact sums.  With x = pxy of the exact sums and x' the one evaluated here:
+// |x - x'| <= (delta x' + eta) / (1 - delta), eta = lost units * 2^(e_last - F) (truncations at the exponent transitions,
+// floor of the marginals; every cell derived by subtraction inherits those of its terms), and f(x) = x ln(x den / d) has
+// f' = ln(x den / d) + 1, so  den MI <= sum f(x') + delta/(1-delta) sum x' (|ln(x' den / d)| + 1 + c) + eta/(1-delta) sum (|ln| + 1 + c)
+// with c = 2 (delta + 2 eta) / (1 - delta) < 0.02 and |ln| + 1 <= 2 ln(neff + 12.5) + 3 in the last sum (lo_bound, ldw_mi.hip).
+template <int NA, int NB, bool APX = false>
 __device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSide &R, const ColMeta &M, double RXY,
                                                    const FullCells<NA, NB> &C) {
     const float ra = (float)R.ra, rb = (float)M.rb;
     const float den = (float)A.neff + (ra * rb) * 0.5f;
     const float rX = 0.5f * ra, rY = 0.5f * rb, rxy = (float)RXY;
-    float acc = 0.0f;
+    float acc = 0.0f, acc_abs = 0.0f, xsum = 0.0f;
 #pragma unroll
     for (int i = 0; i <= NA; ++i) {
         const float pX = R.pXf[i];
@@ -475,10 +497,27 @@ __device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSi
 #pragma unroll
         for (int j = 0; j <= NB; ++j) {
             const float pY = M.pYf[j];
-            const float pxy = fmaf((float)(uint32_t)(C.n[i][j] >> A.E.scr_shift), A.E.scr_scale, 0.5f);
+            float pxy;
+            if (APX) {
+                const int n = (int)C.n[i][j];
+                pxy = fmaf((float)(n < 0 ? 0 : n), A.E.scr_scale, 0.5f);
+            } else {
+                pxy = fmaf((float)(uint32_t)(C.n[i][j] >> A.E.scr_shift), A.E.scr_scale, 0.5f);
+            }
             const float d = fmaf(pY, rY, fmaf(pX, pY, pXr));
-            acc = fmaf(pxy, __builtin_amdgcn_logf(pxy * den) - __builtin_amdgcn_logf(d), acc);
+            const float lt = __builtin_amdgcn_logf(pxy * den) - __builtin_amdgcn_logf(d);
+            acc = fmaf(pxy, lt, acc);
+            if (APX) {
+                acc_abs = fmaf(pxy, fabsf(lt), acc_abs);
+                xsum += pxy;
+            }
         }
+    }
+    if (APX) {
+        constexpr float lost = (float)((NA + 1) * (NB + 1)) * (float)(NA + NB + 1);
+        constexpr float lost_g = (float)((NA + 1) * (NB + 1) * NA * NB);
+        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + (lost + lost_g * (float)A.E.apx_EG) * A.E.apx_s1;
+        return fmaf(acc, 0.6931471805599453f, extra) * __builtin_amdgcn_rcpf(den);
     }
     return acc * (0.6931471805599453f * __builtin_amdgcn_rcpf(den));
 }
@@ -486,6 +525,7 @@ __device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSi
 // The screen for ANY slot counts (SNPs with >= 3 minor states, or none, on either side): the predicated cell loop of
 // pair_mi<4, 4> in fp32.  Same error budget as full_cells_screen (up to 25 cells instead of 9: the log terms are still
 // weighted by pxy / den, which sum to 1).
+template <bool APX = false>
 __device__ __forceinline__ float pair_screen_generic(const EpiArgs &A, const RowSide &R, const ColMeta &M, double RXY, const GAcc &Ga) {
     const int na = R.na, nb = M.mb & 7;
     const uint32_t ma = R.ma, mb = M.mb;
@@ -515,7 +555,7 @@ __device__ __forceinline__ float pair_screen_generic(const EpiArgs &A, const Row
     const float ra = (float)R.ra, rb = (float)M.rb;
     const float den = (float)A.neff + (ra * rb) * 0.5f;
     const float rX = 0.5f * ra, rY = 0.5f * rb, rxy = (float)RXY;
-    float acc = 0.0f;
+    float acc = 0.0f, acc_abs = 0.0f, xsum = 0.0f;
 #pragma unroll
     for (int i = 0; i <= 4; ++i) {
         if (i <= na && ((ma >> (3 + i)) & 1)) {
@@ -530,12 +570,23 @@ __device__ __forceinline__ float pair_screen_generic(const EpiArgs &A, const Row
                     else if (j < 4 && j < nb) nfix = M.pb[j] - cs[j < 4 ? j : 0];
                     else nfix = dd;
                     const float pY = M.pYf[j];
-                    const float pxy = fmaf((float)(uint32_t)(nfix >> A.E.scr_shift), A.E.scr_scale, 0.5f);
+                    float pxy;
+                    if (APX) pxy = fmaf((float)(nfix < 0 ? 0 : (int)nfix), A.E.scr_scale, 0.5f);
+                    else pxy = fmaf((float)(uint32_t)(nfix >> A.E.scr_shift), A.E.scr_scale, 0.5f);
                     const float d = fmaf(pY, rY, fmaf(pX, pY, pXr));
-                    acc = fmaf(pxy, __builtin_amdgcn_logf(pxy * den) - __builtin_amdgcn_logf(d), acc);
+                    const float lt = __builtin_amdgcn_logf(pxy * den) - __builtin_amdgcn_logf(d);
+                    acc = fmaf(pxy, lt, acc);
+                    if (APX) {
+                        acc_abs = fmaf(pxy, fabsf(lt), acc_abs);
+                        xsum += pxy;
+                    }
                 }
             }
         }
+    }
+    if (APX) {   // see full_cells_screen: up to 25 cells, each may have lost 9 + 16 apx_EG units
+        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + 25.0f * (9.0f + 16.0f * (float)A.E.apx_EG) * A.E.apx_s1;
+        return fmaf(acc, 0.6931471805599453f, extra) * __builtin_amdgcn_rcpf(den);
     }
     return acc * (0.6931471805599453f * __builtin_amdgcn_rcpf(den));
 }
@@ -547,5 +598,149 @@ __device__ __forceinline__ double pair_mi_full(const EpiArgs &A, const RowSide &
     full_cells<NA, NB>(R, M, Ga, C);
     return full_cells_mi<NA, NB>(A, R, M, pair_rxy(A, R, M, a_loc, b_loc, square), C);
 }
+
+// ------------------------------------------------------------------------------------------------
+// pieces shared by the screen / epilogue / unit kernels (ldw_mi.hip, ldw_apx.hip): all of them walk a block in the same
+// units, one unit = the 64 from-side SNPs of a wave (perm_f order) x one to-side SNP (perm_t order); both orders group
+// equal slot counts.
+// ------------------------------------------------------------------------------------------------
+// hi_cells (mixed-precision screen): the integer marginals pb / pa that the joint-table cells are derived from are those of
+// the high-limb weights, consistent with the high-limb G; the floating-point marginals stay the exact ones.
+__device__ __forceinline__ void stage_cols(const EpiArgs &A, const int32_t *__restrict__ perm_t, bool square, ColMeta *cm,
+                                           bool hi_cells = false) {
+    if (threadIdx.x < EPI_COLS) {
+        const int q = blockIdx.y * EPI_COLS + threadIdx.x;
+        if (q < A.nt && A.colpack) {
+            cm[threadIdx.x] = (hi_cells ? A.colpack_hi : A.colpack)[q];
+        } else if (q < A.nt) {
+            const int b_loc = perm_t[q];
+            ColMeta m;
+            m.sb = A.idx_t[b_loc];
+            m.mb = A.slot_meta[m.sb];
+            m.rb0 = A.lrow_t[b_loc];
+            m.bl = b_loc;
+            m.rb = A.r[m.sb];
+            m.rq = square ? A.r[A.idx_f[b_loc]] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                m.pb[j] = A.slot_pfix[(int64_t)m.sb * 5 + j];
+                m.pYd[j] = (double)m.pb[j] * A.scale;
+                m.pYf[j] = (float)m.pYd[j];
+                if (hi_cells) m.pb[j] = A.lo.slot_pfix_hi[(int64_t)m.sb * 5 + j];
+            }
+            m.pad2 = 0;
+            if (A.E.cols) m.ci = A.E.cols[b_loc];
+            cm[threadIdx.x] = m;
+        }
+    }
+}
+
+// the same for ONE column slot q, executed by every lane of a wave with uniform addresses (k_mi_units)
+__device__ __forceinline__ void load_col(const EpiArgs &A, const int32_t *__restrict__ perm_t, bool square, int q, ColMeta &m,
+                                         bool hi_cells = false) {
+    if (A.colpack) {
+        m = (hi_cells ? A.colpack_hi : A.colpack)[q];
+        return;
+    }
+    const int b_loc = perm_t[q];
+    m.sb = A.idx_t[b_loc];
+    m.mb = A.slot_meta[m.sb];
+    m.rb0 = A.lrow_t[b_loc];
+    m.bl = b_loc;
+    m.rb = A.r[m.sb];
+    m.rq = square ? A.r[A.idx_f[b_loc]] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        m.pb[j] = A.slot_pfix[(int64_t)m.sb * 5 + j];
+        m.pYd[j] = (double)m.pb[j] * A.scale;
+        m.pYf[j] = (float)m.pYd[j];
+        if (hi_cells) m.pb[j] = A.lo.slot_pfix_hi[(int64_t)m.sb * 5 + j];
+    }
+    m.pad2 = 0;
+    m.ci = A.E.cols[b_loc];
+}
+
+// per-lane constants of the from-side SNP; returns whether the lane holds one
+__device__ __forceinline__ bool load_row_side_at(const EpiArgs &A, const int32_t *__restrict__ perm_f, bool square, int t, RowSide &R,
+                                                 int &a_loc, bool hi_cells) {
+    // perm_f is padded with -1 so that every tile of 64 holds SNPs of ONE slot-count class (build_perm_tiles)
+    const int pf = perm_f[t];
+    const bool a_ok = pf >= 0;
+    a_loc = a_ok ? pf : 0;
+    R.sa = A.idx_f[a_loc];
+    R.ma = A.slot_meta[R.sa];
+    R.na = a_ok ? (int)(R.ma & 7) : 0;
+    R.ra0 = A.lrow_f[a_loc];
+    R.ra = A.r[R.sa];
+    R.rta = (square && a_ok) ? A.r[A.idx_t[a_loc]] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        R.pa[i] = A.slot_pfix[(int64_t)R.sa * 5 + i];
+        R.pXd[i] = (double)R.pa[i] * A.scale;
+        R.pXf[i] = (float)R.pXd[i];
+        if (hi_cells) R.pa[i] = A.lo.slot_pfix_hi[(int64_t)R.sa * 5 + i];
+    }
+    return a_ok;
+}
+__device__ __forceinline__ bool load_row_side(const EpiArgs &A, const int32_t *__restrict__ perm_f, bool square, int tile, RowSide &R,
+                                              int &a_loc, bool hi_cells = false) {
+    const int t = tile * 64 + (threadIdx.x & 63);
+    if (A.rowpack) {
+        const RowPack &P = (hi_cells ? A.rowpack_hi : A.rowpack)[t];
+        R = P.R;
+        a_loc = P.a_loc < 0 ? 0 : P.a_loc;
+        return P.a_loc >= 0;
+    }
+    return load_row_side_at(A, perm_f, square, t, R, a_loc, hi_cells);
+}
+
+// every SNP of the wave's tile has the same slot count na0 (1 or 2) and all of its slots flagged in uqe.  The padding lanes
+// of a partly filled tile (the last one of a class) do not count: they run the same straight-line code on the constants of
+// SNP 0 and every use of their result is masked by a_ok — excluding such tiles left ALL of their units unscreened.
+__device__ __forceinline__ bool wave_is_full(const RowSide &R, bool a_ok, int &na0) {
+    const unsigned long long okm = __ballot(a_ok);
+    if (okm == 0ull) {
+        na0 = 0;
+        return false;
+    }
+    na0 = __builtin_amdgcn_readlane(R.na, __builtin_ctzll(okm));
+    const bool a_full = !a_ok || (R.na == na0 && (((R.ma >> 3) & ((2u << na0) - 1u)) == ((2u << na0) - 1u)));
+    return (na0 == 1 || na0 == 2) && __ballot(!a_full) == 0ull;
+}
+__device__ __forceinline__ bool col_is_fast(uint32_t mb) {
+    const int nb = (int)(mb & 7);
+    return (nb == 1 || nb == 2) && (((mb >> 3) & ((2u << nb) - 1u)) == ((2u << nb) - 1u));
+}
+
+// Row lists are ordered by slot-count class, not by SNP index, so on a diagonal block (symmetric G, tiles above
+// the diagonal of ROW positions skipped by the GEMM) the entry of a pair may only exist transposed.
+__device__ __forceinline__ GAcc g_entry(const EpiArgs &A, const RowSide &R, const ColMeta &M) {
+    const bool tr = A.E.lower_only && R.ra0 < (int64_t)M.rb0;
+    const int64_t off = tr ? R.ra0 * A.RFpad + M.rb0 : (int64_t)M.rb0 * A.RFpad + R.ra0;
+    if (A.E.apx) {
+        GAcc g = gacc_plain(reinterpret_cast<const int64_t *>(reinterpret_cast<const int32_t *>(A.G) + off), tr ? (int64_t)A.RFpad : 1,
+                            tr ? 1 : (int64_t)A.RFpad);
+        g.w32 = 1;
+        return g;
+    }
+    return gacc_plain(A.G + off, tr ? (int64_t)A.RFpad : 1, tr ? 1 : (int64_t)A.RFpad);
+}
+
+// RXY as the screens need it.  mode 0: intended (r_a r_b); 1: reference quirk Q1 on a square block (r[from[b_loc]] r[to[a_loc]],
+// both staged per SNP); 2: Q1 on a ragged block — the linear index c = a_loc + b_loc nf of the nf x nt matrix read as
+// nt x nf: r[from[c / nt]] r[to[c % nt]], looked up in the per-block local-order tables.
+__device__ __forceinline__ double screen_rxy(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc, int mode) {
+    if (mode == 2) {
+        const uint32_t c = (uint32_t)a_loc + (uint32_t)b_loc * (uint32_t)A.nf;
+        const uint32_t q = c / (uint32_t)A.nt;
+        return (double)(A.rloc_f[q] * A.rloc_t[c - q * (uint32_t)A.nt]) * 0.25;
+    }
+    return (mode == 1 ? M.rq * R.rta : R.ra * M.rb) * 0.25;
+}
+
+// unit list entry (64 bits): from-tile * nt + column slot (bits 0-30), index k of the unit in its (tile, class) list (bits
+// 31-50) and the class (bits 51-52) in the mixed-precision path; bit 63: verify mode only, a unit the screen dismissed
+constexpr uint64_t UNIT_DISMISSED = 0x8000000000000000ull;
+
 
 }  // namespace ldw

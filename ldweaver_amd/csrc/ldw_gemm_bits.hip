@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lo_units_kernel(LoGemmArgs P) {
                     const int kk = k0 + (t0 >> lc), j = t0 & ((1 << lc) - 1);
                     int32_t row = P.zero_row;
                     if (kk < cnt) {
-                        const int q = (int)P.lo.tl[(int64_t)tile * P.nt + P.lo.uoff[lc] + kk];
+                        const int q = (int)(P.lo.tl[(int64_t)tile * P.nt + P.lo.uoff[lc] + kk] & 0x7FFFFFFFu);
                         const int snp = P.idx_t[P.perm_t[q]];
                         if (j < P.row0[snp + 1] - P.row0[snp]) row = P.row0[snp] + j;
                     }
@@ -145,25 +145,31 @@ int launch_gemm_lo_units(ldw_ctx *ctx, const LoGemmArgs &P, int n_tf, hipStream_
     return LDW_OK;
 }
 
-// bit rows: Mbits[row][w] bit i = (states[snp(row)][64 w + i] == state(row)); one thread per word
+// bit rows: Mbits[row][w] bit i = (states[snp(row)][seq_perm[64 w + i]] == state(row)); one workgroup per row, the state
+// row staged in LDS (the positions of a word are scattered over the row: weight order, ldw_set_weights)
 __global__ __launch_bounds__(256) void k_fill_rows_bits(const uint8_t *__restrict__ states, int64_t Npad,
                                                         const int32_t *__restrict__ rowinfo, int64_t KW,
+                                                        const int32_t *__restrict__ seq_perm, int use_lds,
                                                         uint64_t *__restrict__ Mbits) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t srow[];
     const int64_t row = blockIdx.x;
     const int32_t info = rowinfo[row];
     const int64_t snp = info >> 3;
     const uint32_t st = (uint32_t)(info & 7);
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(states + snp * Npad);
+    const uint8_t *src = states + snp * Npad;
+    if (use_lds) {
+        for (int64_t i = threadIdx.x; i < Npad / 16; i += blockDim.x)
+            reinterpret_cast<uint4 *>(srow)[i] = reinterpret_cast<const uint4 *>(src)[i];
+        __syncthreads();
+    }
     for (int64_t w = threadIdx.x; w < KW; w += blockDim.x) {
         uint64_t bits = 0;
-        if (w * 64 < Npad) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const uint32_t x = src[w * 16 + q];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    bits |= (uint64_t)(((x >> (8 * k)) & 0xFFu) == st) << (4 * q + k);
-            }
+        const int32_t *sp = seq_perm + w * 64;
+#pragma unroll 8
+        for (int q = 0; q < 64; ++q) {
+            const int32_t s = sp[q];
+            const uint32_t x = s < 0 ? 255u : (use_lds ? (uint32_t)srow[s] : (uint32_t)src[s]);
+            bits |= (uint64_t)(x == st) << q;
         }
         Mbits[row * KW + w] = bits;
     }
@@ -204,8 +210,10 @@ int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int3
 }
 
 int fill_rows_bits(ldw_ctx *c, const int32_t *d_rowinfo, int64_t R) {
-    hipLaunchKernelGGL(k_fill_rows_bits, dim3((unsigned)R), dim3(256), 0, c->stream, c->states.as<uint8_t>(), c->Npad,
-                       d_rowinfo, c->KW, c->Mbits.as<uint64_t>());
+    LDW_REQUIRE(c->seq_perm.p && (int64_t)c->h_seq_perm.size() == c->Npad, LDW_ERR_STATE, "fill_rows_bits: no sequence order (set the weights first)");
+    const int use_lds = c->Npad <= 61440 ? 1 : 0;   // the default dynamic-LDS limit is 64 KB
+    hipLaunchKernelGGL(k_fill_rows_bits, dim3((unsigned)R), dim3(256), use_lds ? (size_t)c->Npad : 0, c->stream, c->states.as<uint8_t>(), c->Npad,
+                       d_rowinfo, c->KW, c->seq_perm.as<int32_t>(), use_lds, c->Mbits.as<uint64_t>());
     LDW_HIP(hipGetLastError());
     return LDW_OK;
 }

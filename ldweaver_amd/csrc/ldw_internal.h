@@ -77,6 +77,31 @@ struct ldw_ctx {
     double lo_abs_sum = 0;      // sum_s |V_lo,s| * 2^-F: bound of the low limbs' contribution to any joint sum
     int mixed = 1;              // 1: high-limb GEMM + gathered low-limb GEMM for the listed units in speculative blocks
 
+    // ---- sequence order of the bit rows: position p of a row = sequence seq_perm[p]; positions ascend in weight, so
+    // ---- sequences of equal weight (a weight CLASS) are contiguous.  digits / dig_a / dig_b are indexed by position.
+    std::vector<int32_t> h_seq_perm;   // [Npad], -1 in the padding
+    ldw::DevBuf seq_perm;
+    // ---- approximate-GEMM path (ldw_apx.hip): V_p ~ a_p * b_p * 2^e(macro step of p), one int8 MFMA pass with both
+    // ---- operands masked by a digit; exact joint sums of the listed units by class-wise popcounts
+    int path_mode = 0;                 // ldw_set_path: 0 auto, 1 mixed/plain path, 2 force the approximate path
+    bool apx_ok = false;               // the weights allow the approximate path (precision and class structure)
+    ldw::DevBuf dig_a, dig_b;          // uint8 [Npad]
+    ldw::DevBuf apx_shift;             // int32 [KW / 2]: right shift of the accumulators before macro step m (128 positions)
+    int apx_e_last = 0;                // accumulators end in units of 2^apx_e_last (fixed-point units of V)
+    int apx_transitions = 0;           // macro steps with a shift: each loses < 1 unit of a joint sum
+    double apx_delta = 0;              // max_p |V'_p - V_p| / V_p
+    std::vector<int64_t> h_vapx;       // [Npad] by SEQUENCE: V'_s = a b 2^e (exact integer)
+    ldw::DevBuf slot_papx;             // int64 [L][5] by slot: floor(marginal of V' / 2^apx_e_last)
+    ldw::DevBuf pop_segs, pop_wbeg;    // popcount segments (PopSeg) and first segment of every 32-bit word (+1)
+    int n_pop_segs = 0, n_classes = 0;
+    ldw::DevBuf panel[2][2];           // [slot][from, to]: packed bit panels of a block's row lists, [KW/2][Rpad][2] u64
+    ldw::DevBuf Gapx[2];               // int32 [RTpad][RFpad] approximate joint sums, one per pipeline slot
+    ldw::DevBuf cs;                    // int64 exact joint sums of the units that survive the exact re-screen
+    ldw::DevBuf pair_sums;             // exact joint sums of the listed pairs (16 per pair)
+    ldw::DevBuf pairs[2];              // per pipeline slot: pair lists of the approximate screen (counters + PAIR_PATHS x PAIR_SHARDS lists)
+    ldw::DevBuf apx_units[2], apx_packs[2];   // per slot: per-(tile, class) unit lists + counters; per-block SNP constants
+    int64_t apx_blocks = 0, apx_units_listed = 0, apx_units_kept = 0;
+
     // ---- per-SNP meta ----
     bool have_meta = false;
     double g = 0;
@@ -156,5 +181,6 @@ int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int3
                      int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only, hipStream_t stream = nullptr, int by0 = 0,
                      int by1 = -1);   // by0..by1: strip of 128-row to-side tiles to compute (default: all)
 int fill_rows_bits(ldw_ctx *ctx, const int32_t *d_rowinfo, int64_t R);
+int prepare_apx_weights(ldw_ctx *ctx);   // ldw_apx.hip: dual digits, exponents, popcount segments from h_vfixed / h_seq_perm
 int check_gpu(ldw_ctx *ctx);
 }  // namespace ldw

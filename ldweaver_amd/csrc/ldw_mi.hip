@@ -24,102 +24,11 @@
 #include "ldw_internal.h"
 #include "ldw_dev.h"
 #include "ldw_epi.h"
+#include "ldw_apx.h"
 
 using namespace ldw;
 
 namespace ldw {
-
-// ---- pieces shared by k_mi_screen and k_mi_epilogue: both walk the block in the same units, one unit = the 64
-// ---- from-side SNPs of a wave (perm_f order) x one to-side SNP (perm_t order); both orders group equal slot counts.
-// hi_cells (mixed-precision screen): the integer marginals pb / pa that the joint-table cells are derived from are those of
-// the high-limb weights, consistent with the high-limb G; the floating-point marginals stay the exact ones.
-__device__ __forceinline__ void stage_cols(const EpiArgs &A, const int32_t *__restrict__ perm_t, bool square, ColMeta *cm,
-                                           bool hi_cells = false) {
-    if (threadIdx.x < EPI_COLS) {
-        const int q = blockIdx.y * EPI_COLS + threadIdx.x;
-        if (q < A.nt && A.colpack) {
-            cm[threadIdx.x] = (hi_cells ? A.colpack_hi : A.colpack)[q];
-        } else if (q < A.nt) {
-            const int b_loc = perm_t[q];
-            ColMeta m;
-            m.sb = A.idx_t[b_loc];
-            m.mb = A.slot_meta[m.sb];
-            m.rb0 = A.lrow_t[b_loc];
-            m.bl = b_loc;
-            m.rb = A.r[m.sb];
-            m.rq = square ? A.r[A.idx_f[b_loc]] : 0.0;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                m.pb[j] = A.slot_pfix[(int64_t)m.sb * 5 + j];
-                m.pYd[j] = (double)m.pb[j] * A.scale;
-                m.pYf[j] = (float)m.pYd[j];
-                if (hi_cells) m.pb[j] = A.lo.slot_pfix_hi[(int64_t)m.sb * 5 + j];
-            }
-            m.pad2 = 0;
-            if (A.E.cols) m.ci = A.E.cols[b_loc];
-            cm[threadIdx.x] = m;
-        }
-    }
-}
-
-// the same for ONE column slot q, executed by every lane of a wave with uniform addresses (k_mi_units)
-__device__ __forceinline__ void load_col(const EpiArgs &A, const int32_t *__restrict__ perm_t, bool square, int q, ColMeta &m,
-                                         bool hi_cells = false) {
-    if (A.colpack) {
-        m = (hi_cells ? A.colpack_hi : A.colpack)[q];
-        return;
-    }
-    const int b_loc = perm_t[q];
-    m.sb = A.idx_t[b_loc];
-    m.mb = A.slot_meta[m.sb];
-    m.rb0 = A.lrow_t[b_loc];
-    m.bl = b_loc;
-    m.rb = A.r[m.sb];
-    m.rq = square ? A.r[A.idx_f[b_loc]] : 0.0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        m.pb[j] = A.slot_pfix[(int64_t)m.sb * 5 + j];
-        m.pYd[j] = (double)m.pb[j] * A.scale;
-        m.pYf[j] = (float)m.pYd[j];
-        if (hi_cells) m.pb[j] = A.lo.slot_pfix_hi[(int64_t)m.sb * 5 + j];
-    }
-    m.pad2 = 0;
-    m.ci = A.E.cols[b_loc];
-}
-
-// per-lane constants of the from-side SNP; returns whether the lane holds one
-__device__ __forceinline__ bool load_row_side_at(const EpiArgs &A, const int32_t *__restrict__ perm_f, bool square, int t, RowSide &R,
-                                                 int &a_loc, bool hi_cells) {
-    // perm_f is padded with -1 so that every tile of 64 holds SNPs of ONE slot-count class (build_perm_tiles)
-    const int pf = perm_f[t];
-    const bool a_ok = pf >= 0;
-    a_loc = a_ok ? pf : 0;
-    R.sa = A.idx_f[a_loc];
-    R.ma = A.slot_meta[R.sa];
-    R.na = a_ok ? (int)(R.ma & 7) : 0;
-    R.ra0 = A.lrow_f[a_loc];
-    R.ra = A.r[R.sa];
-    R.rta = (square && a_ok) ? A.r[A.idx_t[a_loc]] : 0.0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        R.pa[i] = A.slot_pfix[(int64_t)R.sa * 5 + i];
-        R.pXd[i] = (double)R.pa[i] * A.scale;
-        R.pXf[i] = (float)R.pXd[i];
-        if (hi_cells) R.pa[i] = A.lo.slot_pfix_hi[(int64_t)R.sa * 5 + i];
-    }
-    return a_ok;
-}
-__device__ __forceinline__ bool load_row_side(const EpiArgs &A, const int32_t *__restrict__ perm_f, bool square, int tile, RowSide &R,
-                                              int &a_loc, bool hi_cells = false) {
-    const int t = tile * 64 + (threadIdx.x & 63);
-    if (A.rowpack) {
-        const RowPack &P = (hi_cells ? A.rowpack_hi : A.rowpack)[t];
-        R = P.R;
-        a_loc = P.a_loc < 0 ? 0 : P.a_loc;
-        return P.a_loc >= 0;
-    }
-    return load_row_side_at(A, perm_f, square, t, R, a_loc, hi_cells);
-}
 
 // Per-block SNP constants in epilogue order, once per block instead of once per workgroup (k_mi_screen) or per unit
 // (k_mi_units): thread i builds column slot i (i < nt) and from-side slot i (i < 64 * tiles); A.colpack / A.rowpack are null here.
@@ -156,37 +65,6 @@ __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *_
     }
 }
 
-// every active lane of the wave has the same slot count na0 (1 or 2) and all of its slots flagged in uqe
-__device__ __forceinline__ bool wave_is_full(const RowSide &R, bool a_ok, int &na0) {
-    na0 = __builtin_amdgcn_readfirstlane(R.na);
-    const bool a_full = a_ok && R.na == na0 && (((R.ma >> 3) & ((2u << na0) - 1u)) == ((2u << na0) - 1u));
-    return (na0 == 1 || na0 == 2) && __ballot(!a_full) == 0ull;
-}
-__device__ __forceinline__ bool col_is_fast(uint32_t mb) {
-    const int nb = (int)(mb & 7);
-    return (nb == 1 || nb == 2) && (((mb >> 3) & ((2u << nb) - 1u)) == ((2u << nb) - 1u));
-}
-
-// Row lists are ordered by slot-count class, not by SNP index, so on a diagonal block (symmetric G, tiles above
-// the diagonal of ROW positions skipped by the GEMM) the entry of a pair may only exist transposed.
-__device__ __forceinline__ GAcc g_entry(const EpiArgs &A, const RowSide &R, const ColMeta &M) {
-    const bool tr = A.E.lower_only && R.ra0 < (int64_t)M.rb0;
-    return gacc_plain(A.G + (tr ? R.ra0 * A.RFpad + M.rb0 : (int64_t)M.rb0 * A.RFpad + R.ra0), tr ? (int64_t)A.RFpad : 1,
-                      tr ? 1 : (int64_t)A.RFpad);
-}
-
-// RXY as the screens need it.  mode 0: intended (r_a r_b); 1: reference quirk Q1 on a square block (r[from[b_loc]] r[to[a_loc]],
-// both staged per SNP); 2: Q1 on a ragged block — the linear index c = a_loc + b_loc nf of the nf x nt matrix read as
-// nt x nf: r[from[c / nt]] r[to[c % nt]], looked up in the per-block local-order tables.
-__device__ __forceinline__ double screen_rxy(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc, int mode) {
-    if (mode == 2) {
-        const uint32_t c = (uint32_t)a_loc + (uint32_t)b_loc * (uint32_t)A.nf;
-        const uint32_t q = c / (uint32_t)A.nt;
-        return (double)(A.rloc_f[q] * A.rloc_t[c - q * (uint32_t)A.nt]) * 0.25;
-    }
-    return (mode == 1 ? M.rq * R.rta : R.ra * M.rb) * 0.25;
-}
-
 // ------------------------------------------------------------------------------------------------
 // k_mi_screen: the fp32 screen of the two-kernel path (speculative selection mode).  A long-range pair only matters if
 // its MI reaches the guessed histogram bucket, which about one pair in a thousand does; this kernel bounds MI in fp32
@@ -197,8 +75,21 @@ __device__ __forceinline__ double screen_rxy(const EpiArgs &A, const RowSide &R,
 // that bound the one-kernel epilogue (one 512-B load in flight per wave, 3 waves per SIMD: 1.3 TB/s), and U columns per
 // iteration put U independent loads in flight per wave.
 // ------------------------------------------------------------------------------------------------
-template <int NA, int NB, int U, int RM>
-__device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc, bool a_ok, float lo) {
+// long-range candidates of one column of one wave -> pair list `path` (approximate-GEMM path)
+__device__ __forceinline__ void append_pairs(const EpiArgs &A, int path, unsigned long long m, bool mine, uint32_t t, uint32_t q) {
+    const int lane = threadIdx.x & 63;
+    const int sub = path * PAIR_SHARDS + (int)(blockIdx.x & (PAIR_SHARDS - 1));
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(A.pl_n + sub, (unsigned int)__popcll(m));
+    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+    if (mine) {
+        const unsigned int pos = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < A.pl_cap) A.pl_pairs[(int64_t)sub * A.pl_cap + pos] = ((uint64_t)t << 32) | (uint64_t)q;   // overflow: k_pick_bucket sees the counter
+    }
+}
+
+template <int NA, int NB, int U, int RM, bool APX>
+__device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc, bool a_ok, float lo, int q0) {
     const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0, do_lr = A.E.do_lr != 0;
     FullCells<NA, NB> C[U];
     if (do_lr) {   // an SR-only pass needs no MI here at all: a unit is wanted iff it holds a short-range pair
@@ -212,33 +103,40 @@ __device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowS
         const int b_loc = M.bl;
         const bool act = a_ok && (A.E.lower_only ? a_loc > b_loc : a_loc != b_loc);
         float ms = 0.0f;
-        if (do_lr) ms = full_cells_screen<NA, NB>(A, R, M, screen_rxy(A, R, M, a_loc, b_loc, RM), C[u]);
+        if (do_lr) ms = full_cells_screen<NA, NB, APX>(A, R, M, screen_rxy(A, R, M, a_loc, b_loc, RM), C[u]);
         const bool is_sr = test_sr && col_is_sr(M.ci, a_loc);
-        const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
-        if (__ballot(need) != 0ull) bits |= 1u << u;
+        if (APX && A.pl_pairs) {
+            // a unit with a short-range pair is evaluated whole (its band is dense); otherwise only the candidates themselves
+            const bool need_lr = act && !is_sr && do_lr && ms >= lo;
+            if (__ballot(act && is_sr && keep_sr) != 0ull) {
+                bits |= 1u << u;
+            } else {
+                const unsigned long long m = __ballot(need_lr);
+                if (m != 0ull) append_pairs(A, (NA - 1) + 2 * (NB - 1), m, need_lr, (uint32_t)(blockIdx.x * 64 + (threadIdx.x & 63)), (uint32_t)(q0 + u));
+            }
+        } else {
+            const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
+            if (__ballot(need) != 0ull) bits |= 1u << u;
+        }
     }
     return bits;
 }
 
 // U columns at once for biallelic x biallelic units (4 cells each, the bulk of the work); wider tables go two (or one)
 // at a time, which keeps the kernel near 64 VGPRs
-template <int NA, int U, int RM>
+template <int NA, int U, int RM, bool APX>
 __device__ __forceinline__ unsigned int screen_cols_nb(int nb, const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc,
-                                                       bool a_ok, float lo) {
-    if (NA == 1 && nb == 1) return screen_cols<NA, 1, U, RM>(A, R, cmu, a_loc, a_ok, lo);
+                                                       bool a_ok, float lo, int q0) {
+    if (NA == 1 && nb == 1) return screen_cols<NA, 1, U, RM, APX>(A, R, cmu, a_loc, a_ok, lo, q0);
     constexpr int V = U >= 2 && NA == 1 ? 2 : 1;
     unsigned int bits = 0;
     for (int u = 0; u < U; u += V) {
-        const unsigned int b = nb == 1 ? screen_cols<NA, 1, V, RM>(A, R, cmu + u, a_loc, a_ok, lo)
-                                       : screen_cols<NA, 2, V, RM>(A, R, cmu + u, a_loc, a_ok, lo);
+        const unsigned int b = nb == 1 ? screen_cols<NA, 1, V, RM, APX>(A, R, cmu + u, a_loc, a_ok, lo, q0 + u)
+                                       : screen_cols<NA, 2, V, RM, APX>(A, R, cmu + u, a_loc, a_ok, lo, q0 + u);
         bits |= b << u;
     }
     return bits;
 }
-
-// unit list entry (64 bits): from-tile * nt + column slot (bits 0-30), index k of the unit in its (tile, class) list (bits
-// 31-50) and the class (bits 51-52) in the mixed-precision path; bit 63: verify mode only, a unit the screen dismissed
-constexpr uint64_t UNIT_DISMISSED = 0x8000000000000000ull;
 
 // Append the wanted units of a wave (bit k = column slot q_base + k of from-tile `tile`) to the flat list and, in the
 // mixed-precision path, to the list of their (tile, row-slot class), which is what the gathered low-limb GEMM walks; the
@@ -267,11 +165,13 @@ __device__ __forceinline__ void list_wave_units(const EpiArgs &A, const ColMeta 
             base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
             if (mine && my_lc == lc) {
                 const unsigned int k = base + __popc(m & ((1u << lane) - 1u));
-                A.lo.tl[(int64_t)tile * A.nt + A.lo.uoff[lc] + k] = (uint32_t)(q_base + lane);
+                // bit 31 (verify mode only): a unit the screen dismissed
+                A.lo.tl[(int64_t)tile * A.nt + A.lo.uoff[lc] + k] = (uint32_t)(q_base + lane) | (((wanted >> lane) & 1u) ? 0u : 0x80000000u);
                 kfield = ((uint64_t)k << 31) | ((uint64_t)lc << 51);
             }
         }
     }
+    if (!units) return;   // approximate path: only the per-(tile, class) lists are read (k_units_pop builds the final flat lists)
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
         const unsigned int m = listed & (which == 0 ? fastmask : ~fastmask);
@@ -288,7 +188,7 @@ __device__ __forceinline__ void list_wave_units(const EpiArgs &A, const ColMeta 
 
 // RM: how RXY is read (screen_rxy) — a template parameter so that the common square-block code carries neither the
 // division nor the table look-ups of the ragged case
-template <int RM>
+template <int RM, bool APX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_mi_screen(EpiArgs A, const int32_t *__restrict__ perm_f,
                                                                                             const int32_t *__restrict__ perm_t,
                                                                                             uint64_t *__restrict__ units,
@@ -331,16 +231,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 same = same && col_is_fast(mb0);
             }
             if (same) {
-                const unsigned int b = na0 == 1 ? screen_cols_nb<1, U, RM>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo)
-                                                : screen_cols_nb<2, U, RM>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo);
+                const unsigned int b = na0 == 1 ? screen_cols_nb<1, U, RM, APX>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo, q_base + it)
+                                                : screen_cols_nb<2, U, RM, APX>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo, q_base + it);
                 wanted |= b << it;
                 handled |= ((1u << U) - 1u) << it;
             } else {
                 for (int u = 0; u < U && it + u < n_it; ++u) {
                     const uint32_t mbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmu[u].mb);
                     if (!col_is_fast(mbu)) continue;
-                    const unsigned int b = na0 == 1 ? screen_cols_nb<1, 1, RM>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, lo)
-                                                    : screen_cols_nb<2, 1, RM>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, lo);
+                    const unsigned int b = na0 == 1 ? screen_cols_nb<1, 1, RM, APX>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, lo, q_base + it + u)
+                                                    : screen_cols_nb<2, 1, RM, APX>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, lo, q_base + it + u);
                     wanted |= b << (it + u);
                     handled |= 1u << (it + u);
                 }
@@ -360,6 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 // ------------------------------------------------------------------------------------------------
 constexpr int GEN_COLS = 16;   // column slots per workgroup of k_mi_screen_generic: 4 per wave — the kernel is a chain of
                                // dependent loads per column with nothing else to hide them, so the chains are kept short
+template <bool APX>
 __global__ __launch_bounds__(256) void k_mi_screen_generic(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
                                                            uint64_t *__restrict__ units, unsigned int *__restrict__ n_units,
                                                            int64_t list_stride, int tile0, int q0) {
@@ -398,10 +299,20 @@ __global__ __launch_bounds__(256) void k_mi_screen_generic(EpiArgs A, const int3
         const int b_loc = M.bl;
         const bool act = a_ok && (A.E.lower_only ? a_loc > b_loc : a_loc != b_loc);
         const double rxy = screen_rxy(A, R, M, a_loc, b_loc, rxy_mode);
-        const float ms = pair_screen_generic(A, R, M, rxy, g_entry(A, R, M));
+        const float ms = do_lr ? pair_screen_generic<APX>(A, R, M, rxy, g_entry(A, R, M)) : 0.0f;
         const bool is_sr = test_sr && col_is_sr(M.ci, a_loc);
-        const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
-        if (__ballot(need) != 0ull) wanted |= 1u << it;
+        if (APX && A.pl_pairs) {
+            const bool need_lr = act && !is_sr && do_lr && ms >= lo;
+            if (__ballot(act && is_sr && keep_sr) != 0ull) {
+                wanted |= 1u << it;
+            } else {
+                const unsigned long long m = __ballot(need_lr);
+                if (m != 0ull) append_pairs(A, 4, m, need_lr, (uint32_t)(tile * 64 + (threadIdx.x & 63)), (uint32_t)(q_base + it));
+            }
+        } else {
+            const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
+            if (__ballot(need) != 0ull) wanted |= 1u << it;
+        }
     }
     list_wave_units(A, cm, c_first, q_base, n_it, mine, wanted & mine, 0u, units, n_units, list_stride, tile);
 }
@@ -485,12 +396,19 @@ __global__ __launch_bounds__(256) void k_mi_epilogue(EpiArgs A, const int32_t *_
 // ------------------------------------------------------------------------------------------------
 // FAST: list 0, straight-line variants only — half the registers of the predicated code, so that its waves fit on a CU beside
 // the two workgroups of the next block's GEMM (which runs on the other stream) instead of waiting for them to drain.
+// Where a launch of k_mi_units finds its units: up to 4 flat lists (blockIdx.y)
+struct UnitLists {
+    const uint64_t *units[4];
+    const unsigned int *n[4];
+};
+
 template <bool FAST>
 __global__ __launch_bounds__(256) void k_mi_units(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
-                                                  const uint64_t *__restrict__ units, const unsigned int *__restrict__ n_units,
-                                                  unsigned long long *__restrict__ ghist) {
+                                                  UnitLists UL, unsigned long long *__restrict__ ghist) {
     const bool square = A.nf == A.nt;
-    const unsigned int n = *n_units;
+    const int y = blockIdx.y;
+    const uint64_t *__restrict__ units = UL.units[y];
+    const unsigned int n = *UL.n[y];
     const unsigned int stride = gridDim.x * 4u;
     int cur_tile = -1, a_loc = 0, na0 = 0, na_max = 1;
     bool a_ok = false, wave_full = false;
@@ -537,6 +455,77 @@ __global__ __launch_bounds__(256) void k_mi_units(EpiArgs A, const int32_t *__re
             continue;
         }
         emit_pair_spec(A.E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, ghist);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_mi_units_tl: the same fp64 evaluation for the approximate-GEMM path, straight off the per-(from-tile, to-class) lists:
+// k_units_pop has left its verdict in every entry (ldw_apx.h) and the exact joint sums of unit k of list (tile, lc) at the
+// slot of its list position.  Workgroup = (tile, lc, z); its 4 waves stride over the list.  FAST: lists whose from-tile and
+// to-class take the straight-line code, entries without the GENERIC flag; the other instance takes the rest.
+// ------------------------------------------------------------------------------------------------
+template <bool FAST>
+__global__ __launch_bounds__(256) void k_mi_units_tl(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
+                                                     const int64_t *__restrict__ cs, const int64_t *__restrict__ cs_base,
+                                                     unsigned long long *__restrict__ ghist, unsigned long long *__restrict__ n_kept) {
+    const int tile = blockIdx.x, lc = blockIdx.y;
+    const unsigned int cnt = A.lo.cnt[tile * 3 + lc];
+    if (blockIdx.z * 4u >= cnt) return;
+    const int cmax = A.lo.cmax_f[tile];
+    const bool fast_list = cmax <= 2 && lc <= 1;
+    if (FAST && !fast_list) return;
+    const bool square = A.nf == A.nt;
+    RowSide R;
+    int a_loc, na0;
+    const bool a_ok = load_row_side(A, perm_f, square, tile, R, a_loc);
+    const int na_max = (__ballot(R.na > 2) != 0ull) ? 4 : ((__ballot(R.na > 1) != 0ull) ? 2 : 1);
+    const bool wave_full = wave_is_full(R, a_ok, na0);
+    const int64_t ustride = 64 * (int64_t)cmax << lc;
+    const int64_t *csl = cs + cs_base[tile * 3 + lc] + (threadIdx.x & 63);
+    const uint32_t *tl = A.lo.tl + (int64_t)tile * A.nt + A.lo.uoff[lc];
+    unsigned int kept = 0;
+    for (unsigned int k = blockIdx.z * 4u + (threadIdx.x >> 6); k < cnt; k += gridDim.z * 4u) {
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tl[k]);
+        if (e & UNIT_TL_DROPPED) continue;
+        if (FAST == ((e & UNIT_TL_GENERIC) != 0)) continue;   // the other instance's unit
+        ++kept;
+        const bool dismissed = (e & UNIT_TL_DISMISSED) != 0;
+        const int q = (int)(e & UNIT_TL_Q);
+        ColMeta M;
+        load_col(A, perm_t, square, q, M);
+        const uint32_t mbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.mb);
+        const int b_loc = M.bl;
+        if (!a_ok) continue;
+        if (A.E.lower_only && a_loc <= b_loc) continue;
+        const GAcc Ga = gacc_plain(csl + (int64_t)k * ustride, 64, 64 * (int64_t)cmax);
+        double mi;
+        if (FAST) {
+            const int nb = (int)(mbu & 7);
+            if (na0 == 1) mi = nb == 1 ? pair_mi_full<1, 1>(A, R, M, a_loc, b_loc, square, Ga) : pair_mi_full<1, 2>(A, R, M, a_loc, b_loc, square, Ga);
+            else mi = nb == 1 ? pair_mi_full<2, 1>(A, R, M, a_loc, b_loc, square, Ga) : pair_mi_full<2, 2>(A, R, M, a_loc, b_loc, square, Ga);
+        } else {
+            mi = unit_pair_mi(A, R, M, a_loc, b_loc, square, wave_full && col_is_fast(mbu), na0, na_max, (int)(mbu & 7), Ga);
+        }
+        if (dismissed) {   // verify mode: a pair of a dismissed unit that would have been emitted was lost by a screen
+            if (would_emit(A.E, M.ci, a_loc, b_loc, mi)) atomicAdd(A.E.scr_viol, 1ull);
+            continue;
+        }
+        emit_pair_spec(A.E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, ghist);
+    }
+    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(n_kept, (unsigned long long)kept);   // diagnostics
+}
+
+// totals of the approximate path's unit lists (diagnostics: ldw_ctx_counters2)
+__global__ void k_apx_stats(const unsigned int *__restrict__ cnt, int n_cnt, unsigned long long *__restrict__ acc) {
+    __shared__ unsigned long long part[256];
+    unsigned long long s = 0;
+    for (int i = threadIdx.x; i < n_cnt; i += 256) s += cnt[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < 256; ++i) t += part[i];
+        acc[0] += t;
     }
 }
 
@@ -635,7 +624,7 @@ struct PickOut {
 // pair count known to the host, and everything below spec_B is lumped into one virtual bucket.
 __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *__restrict__ hist, double lr_retain,
                                                      double lr_approx, int spec_B, long long n_total,
-                                                     PickOut *__restrict__ out) {
+                                                     PickOut *__restrict__ out, const unsigned int *__restrict__ pl_n, unsigned int pl_cap) {
     __shared__ long long part[256];
     __shared__ long long s_lo;
     constexpr int PER = NBINS / 256;
@@ -701,7 +690,11 @@ __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *_
             if (t * PER + k == spec_B) {
                 out->B = spec_B;
                 out->n_below = cum;
-                out->spec_ok = 1;
+                // a pair list of the approximate path that overflowed lost candidates: treat like a guess that was too high
+                bool over = false;
+                if (pl_n)
+                    for (int i = 0; i < PAIR_PATHS * PAIR_SHARDS; ++i) over = over || pl_n[i] > pl_cap;
+                out->spec_ok = over ? 0 : 1;
             }
             cum += loc[k];
         }
@@ -975,6 +968,7 @@ struct DevPtrs {
     const int32_t *cmax_f;      // mixed-precision path: per from-tile widest row-slot class, offsets of the low-limb blocks
     const int64_t *tile_base;
     const int32_t *tf_list;     // (tile, fs) pairs of the gathered GEMM's grid
+    const int64_t *cs_base;     // approximate path: [tiles * 3] start of the exact sums of list (tile, lc)
     int nf_tiles;               // tiles of 64 in the padded from-side order perm
     int gen_t0, gen_q0;         // first from-tile / column slot of the SNPs with >= 3 minor states or none (k_mi_screen_generic)
 };
@@ -984,12 +978,16 @@ struct LoHost {
     int32_t n_lc[3] = {0, 0, 0}, uoff[3] = {0, 0, 0}, rowbase[3] = {0, 0, 0};
     int32_t RTlo = 0, ntiles = 0, n_tf = 0;
     int64_t glo_total = 0;
+    int32_t n_tiles_cf[3] = {0, 0, 0};   // from-tiles whose widest row-slot class is 1, 2, 4
+    int64_t cs_total = 0;                // int64 entries of the approximate path's exact-sum slots
+    int apx = 0, slot = 0, diag = 0;     // approximate-GEMM path (ldw_apx.h) instead of the high-limb GEMM + gathered low limbs
 };
 
 void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int quirk, const EmitArgs &E, const int64_t *G,
                    EpiArgs &A) {
     A.G = G;
     A.RFpad = RFpad;
+    A.RTpad = 0;
     A.idx_f = D.idx_f;
     A.lrow_f = D.lrow_f;
     A.idx_t = D.idx_t;
@@ -1007,6 +1005,9 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
     A.colpack = A.colpack_hi = nullptr;
     A.rowpack = A.rowpack_hi = nullptr;
     A.rloc_f = A.rloc_t = nullptr;
+    A.pl_pairs = nullptr;
+    A.pl_n = nullptr;
+    A.pl_cap = 0;
     A.E = E;
     memset(&A.lo, 0, sizeof(A.lo));
 }
@@ -1015,9 +1016,10 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
 // scatter and the long-range histogram ride along.  Everything is asynchronous.
 // stage events per block: [0] GEMM start, [1] GEMM end (GEMM stream); [4] epilogue start, [2] epilogue end, [3] selection
 // end (main stream).  The GEMM of block b+1 runs beside the epilogue and selection of block b, so the stage times overlap.
-constexpr int EVB = 5;
+constexpr int EVB = 6;
 // which: 1 = GEMM only (on gstream, into Gbuf), 2 = epilogue only, 3 = both
 constexpr int HI_LIMBS = 3, LO_LIMBS = 2;   // mixed-precision split of the 5 weight limbs
+constexpr size_t PAIR_CAP = 1u << 18;       // entries per pair list of the approximate path (PAIR_PATHS x PAIR_SHARDS lists)
 int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E,
                     hipEvent_t *ev, int which, ldw::DevBuf *Gb, hipStream_t gstream, unsigned long long *ghist,
                     const LoHost *mixed = nullptr) {
@@ -1032,6 +1034,7 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
                                       E.lower_only, gstream))
             return rc;
         LDW_HIP(hipEventRecord(ev[1], gstream));
+        LDW_HIP(hipEventRecord(ev[5], gstream));
         return LDW_OK;
     }
     const bool epilogue_only = which == 2;
@@ -1116,18 +1119,18 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
             A.rowpack_hi = mixed ? rph : rp;
         }
         const int rm = quirk == LDW_QUIRK_REFERENCE ? (nf == nt ? 1 : 2) : 0;
-        if (rm == 0) hipLaunchKernelGGL(k_mi_screen<0>, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride);
-        else if (rm == 1) hipLaunchKernelGGL(k_mi_screen<1>, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride);
-        else hipLaunchKernelGGL(k_mi_screen<2>, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride);
+        if (rm == 0) hipLaunchKernelGGL((k_mi_screen<0, false>), egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride);
+        else if (rm == 1) hipLaunchKernelGGL((k_mi_screen<1, false>), egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride);
+        else hipLaunchKernelGGL((k_mi_screen<2, false>), egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride);
         LDW_HIP(hipGetLastError());
         {   // the units outside k_mi_screen's domain: generic from-tiles x all columns, the other tiles x the generic columns
             const int gt0 = std::min<int>(A.gen_t0, (int)egrid.x);
             const int q0 = std::min<int>(A.gen_q0, (int)nt) / GEN_COLS * GEN_COLS;
             if (gt0 < (int)egrid.x)
-                hipLaunchKernelGGL(k_mi_screen_generic, dim3(egrid.x - gt0, (unsigned)((nt + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A,
+                hipLaunchKernelGGL(k_mi_screen_generic<false>, dim3(egrid.x - gt0, (unsigned)((nt + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A,
                                    D.perm, D.perm_t, units, n_units, list_stride, gt0, 0);
             if (gt0 > 0 && A.gen_q0 < (int)nt)
-                hipLaunchKernelGGL(k_mi_screen_generic, dim3(gt0, (unsigned)((nt - q0 + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A,
+                hipLaunchKernelGGL(k_mi_screen_generic<false>, dim3(gt0, (unsigned)((nt - q0 + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A,
                                    D.perm, D.perm_t, units, n_units, list_stride, 0, q0);
             LDW_HIP(hipGetLastError());
         }
@@ -1149,14 +1152,189 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
             P.lo = A.lo;
             if (int rc = launch_gemm_lo_units(c, P, mixed->n_tf, c->stream)) return rc;
         }
-        hipLaunchKernelGGL(k_mi_units<true>, dim3(2048), dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, ghist);
-        hipLaunchKernelGGL(k_mi_units<false>, dim3(512), dim3(256), 0, c->stream, A, D.perm, D.perm_t, units + list_stride, n_units + 1, ghist);
+        UnitLists UL;
+        memset(&UL, 0, sizeof(UL));
+        UL.units[0] = units;
+        UL.n[0] = n_units;
+        hipLaunchKernelGGL(k_mi_units<true>, dim3(2048, 1), dim3(256), 0, c->stream, A, D.perm, D.perm_t, UL, ghist);
+        UnitLists UG;
+        memset(&UG, 0, sizeof(UG));
+        UG.units[0] = units + list_stride;
+        UG.n[0] = n_units + 1;
+        hipLaunchKernelGGL(k_mi_units<false>, dim3(512, 1), dim3(256), 0, c->stream, A, D.perm, D.perm_t, UG, ghist);
         LDW_HIP(hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_mi_epilogue, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, ghist);
         LDW_HIP(hipGetLastError());
     }
     if (which != 2 || c->engine != LDW_ENGINE_HIST) LDW_HIP(hipEventRecord(ev[2], c->stream));
+    return LDW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One block in the approximate-GEMM path (ldw_apx.h), in two phases so that the block-wide work of block b+1 runs beside
+// the tail of block b:
+//   phase 1 (stream gs): pack the bit panels of both row lists, the dual-digit int8 pass into the int32 block (not for an
+//            SR-only pass: it screens without MI), per-block SNP constants, the approximate screens -> unit lists (units
+//            with a short-range pair) and pair lists (the other long-range candidates);
+//   phase 2 (main stream): exact sums + fp64 MI + emission of the listed pairs (k_pairs_exact) and of the listed units
+//            (k_units_pop -> k_mi_units_tl).
+// Everything phase 1 writes is per pipeline slot; both phases derive the same pointers from the slot's buffers.
+// Events: ev[0] / ev[1] around the packing + GEMM, ev[5] after the screens (gs); ev[4] / ev[2] around phase 2.
+// ------------------------------------------------------------------------------------------------
+int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E, hipEvent_t *ev, int phase,
+                     hipStream_t gs, unsigned long long *ghist, const LoHost *lo_h) {
+    const int s = lo_h->slot;
+    E.nf = (int)nf;
+    E.MI = nullptr;
+    dim3 egrid((unsigned)(D.nf_tiles > 0 ? D.nf_tiles : (nf + 63) / 64), (unsigned)((nt + EPI_COLS - 1) / EPI_COLS));
+    LDW_REQUIRE(egrid.y <= 65535u, LDW_ERR_ARG, "nt too large for the epilogue grid");
+    LDW_REQUIRE(lo_h->ntiles == (int)egrid.x, LDW_ERR_STATE, "unit-list geometry does not match the epilogue grid");
+    LDW_REQUIRE(E.scr_mode && E.cols && !E.write_dense, LDW_ERR_STATE, "the approximate path needs the screen");
+    const size_t n_units_max = (size_t)egrid.x * (size_t)nt;
+    const size_t o_cnt = 64, o_tl = o_cnt + ((size_t)egrid.x * 12 + 63) / 64 * 64;
+    const int nf_slots = (int)egrid.x * 64;
+    const size_t o_cph = ((size_t)nt * sizeof(ColMeta) + 255) / 256 * 256, o_rp = 2 * o_cph;
+    const size_t o_rph = o_rp + ((size_t)nf_slots * sizeof(RowPack) + 255) / 256 * 256;
+    const size_t o_rf = o_rph + ((size_t)nf_slots * sizeof(RowPack) + 255) / 256 * 256, o_rt = o_rf + ((size_t)nf * 4 + 255) / 256 * 256;
+    const size_t o_pairs = 256;
+    const bool use_pairs = E.scr_mode == 1 && E.do_lr;   // verify mode keeps whole units: it must see the dismissed ones
+    if (phase == 1) {
+        if (int rc = c->panel[s][0].reserve((size_t)RFpad * c->KW * 8)) return rc;
+        if (!lo_h->diag)
+            if (int rc = c->panel[s][1].reserve((size_t)RTpad * c->KW * 8)) return rc;
+        if (E.do_lr)
+            if (int rc = c->Gapx[s].reserve((size_t)RFpad * RTpad * 4)) return rc;
+        if (int rc = c->apx_units[s].reserve(o_tl + n_units_max * 4 + 64)) return rc;
+        if (int rc = c->apx_packs[s].reserve(o_rt + (size_t)nt * 4 + 256)) return rc;
+        if (use_pairs)
+            if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * PAIR_CAP * 8)) return rc;
+    }
+    EpiArgs A;
+    fill_epi_args(c, D, nf, nt, RFpad, quirk, E, reinterpret_cast<const int64_t *>(c->Gapx[s].p), A);
+    A.RTpad = RTpad;
+    char *ub = c->apx_units[s].as<char>();
+    {
+        LoGeom &lo = A.lo;
+        for (int k = 0; k < 3; ++k) {
+            lo.n_lc[k] = lo_h->n_lc[k];
+            lo.uoff[k] = lo_h->uoff[k];
+            lo.rowbase[k] = lo_h->rowbase[k];
+        }
+        lo.RTlo = lo_h->RTlo;
+        lo.ntiles = lo_h->ntiles;
+        lo.on = 1;
+        lo.cmax_f = D.cmax_f;
+        lo.tile_base = D.tile_base;
+        lo.cnt = reinterpret_cast<unsigned int *>(ub + o_cnt);
+        lo.tl = reinterpret_cast<uint32_t *>(ub + o_tl);
+        lo.glo = nullptr;
+        lo.slot_pfix_hi = c->slot_papx.as<int64_t>();   // the screen derives its cells from the marginals of the approximate weights
+        lo.hi_shift = 0;
+    }
+    char *pb = c->apx_packs[s].as<char>();
+    ColMeta *cp = reinterpret_cast<ColMeta *>(pb), *cph = reinterpret_cast<ColMeta *>(pb + o_cph);
+    RowPack *rp = reinterpret_cast<RowPack *>(pb + o_rp), *rph = reinterpret_cast<RowPack *>(pb + o_rph);
+    float *rlf = reinterpret_cast<float *>(pb + o_rf), *rlt = reinterpret_cast<float *>(pb + o_rt);
+    if (use_pairs) {
+        A.pl_n = c->pairs[s].as<unsigned int>();
+        A.pl_pairs = reinterpret_cast<uint64_t *>(c->pairs[s].as<char>() + o_pairs);
+        A.pl_cap = (uint32_t)PAIR_CAP;
+    }
+    if (phase == 1) {
+        LDW_HIP(hipEventRecord(ev[0], gs));
+        if (int rc = launch_pack_panel(c, D.rl_f, RFpad, c->panel[s][0].as<uint64_t>(), gs)) return rc;
+        if (!lo_h->diag)
+            if (int rc = launch_pack_panel(c, D.rl_t, RTpad, c->panel[s][1].as<uint64_t>(), gs)) return rc;
+        if (E.do_lr) {
+            ApxGemmArgs P;
+            P.panel_f = c->panel[s][0].as<uint64_t>();
+            P.panel_t = lo_h->diag ? P.panel_f : c->panel[s][1].as<uint64_t>();
+            P.RTpad = RTpad;
+            P.RFpad = RFpad;
+            P.M2 = (int)(c->KW / 2);
+            P.dig_a = c->dig_a.as<uint8_t>();
+            P.dig_b = c->dig_b.as<uint8_t>();
+            P.shift = c->apx_shift.as<int32_t>();
+            P.G = c->Gapx[s].as<int32_t>();
+            P.lower_only = E.lower_only;
+            if (int rc = launch_gemm_apx(c, P, gs)) return rc;
+        }
+        LDW_HIP(hipEventRecord(ev[1], gs));
+        LDW_HIP(hipMemsetAsync(ub, 0, o_tl, gs));   // the per-(tile, class) unit counters
+        if (use_pairs) LDW_HIP(hipMemsetAsync(c->pairs[s].p, 0, o_pairs, gs));
+        const int nthr = std::max<int>((int)nt, nf_slots);
+        hipLaunchKernelGGL(k_build_packs, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, gs, A, D.perm, D.perm_t, nf_slots, 1, cp, cph, rp, rph,
+                           rlf, rlt);
+        LDW_HIP(hipGetLastError());
+    }
+    A.rloc_f = rlf;
+    A.rloc_t = rlt;
+    A.colpack = cp;
+    A.colpack_hi = cph;
+    A.rowpack = rp;
+    A.rowpack_hi = rph;
+    if (phase == 1) {
+        const int rm = quirk == LDW_QUIRK_REFERENCE ? (nf == nt ? 1 : 2) : 0;
+        uint64_t *no_flat = nullptr;   // only the per-(tile, class) lists are read
+        unsigned int *no_cnt = nullptr;
+#define LDW_SCREEN(RMv) hipLaunchKernelGGL((k_mi_screen<RMv, true>), egrid, dim3(256), 0, gs, A, D.perm, D.perm_t, no_flat, no_cnt, (int64_t)0)
+        if (rm == 0) LDW_SCREEN(0); else if (rm == 1) LDW_SCREEN(1); else LDW_SCREEN(2);
+#undef LDW_SCREEN
+        LDW_HIP(hipGetLastError());
+        // the units outside k_mi_screen's domain: generic from-tiles x all columns, the other tiles x the generic columns
+        const int gt0 = std::min<int>(A.gen_t0, (int)egrid.x);
+        const int q0 = std::min<int>(A.gen_q0, (int)nt) / GEN_COLS * GEN_COLS;
+        if (gt0 < (int)egrid.x)
+            hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3(egrid.x - gt0, (unsigned)((nt + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, gs, A, D.perm,
+                               D.perm_t, no_flat, no_cnt, (int64_t)0, gt0, 0);
+        if (gt0 > 0 && A.gen_q0 < (int)nt)
+            hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3(gt0, (unsigned)((nt - q0 + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, gs, A, D.perm, D.perm_t,
+                               no_flat, no_cnt, (int64_t)0, 0, q0);
+        LDW_HIP(hipGetLastError());
+        LDW_HIP(hipEventRecord(ev[5], gs));
+        return LDW_OK;
+    }
+    // ---- phase 2 ----
+    LDW_HIP(hipEventRecord(ev[4], c->stream));
+    if (use_pairs) {
+        if (int rc = c->pair_sums.reserve((size_t)PAIR_PATHS * PAIR_SHARDS * PAIR_CAP * 16 * 8)) return rc;
+        if (int rc = launch_pairs_exact(c, A, ghist, c->pair_sums.as<int64_t>(), c->stream)) return rc;
+    }
+    unsigned long long *acc = A.E.scr_viol + 1;   // [0] units listed, [1] units kept
+    if (A.E.any_sr || !use_pairs) {   // without a short-range pair in the block (and outside verify mode) no unit is listed at all
+        PopArgs P;
+        memset(&P, 0, sizeof(P));
+        P.Mbits = c->Mbits.as<uint64_t>();
+        P.KW = c->KW;
+        P.panel_f = c->panel[s][0].as<uint64_t>();
+        P.RFpad = RFpad;
+        P.M2 = (int)(c->KW / 2);
+        P.segs = c->pop_segs.as<PopSeg>();
+        P.wbeg = c->pop_wbeg.as<int32_t>();
+        P.perm_t = D.perm_t;
+        P.idx_t = D.idx_t;
+        P.row0 = c->row0.as<int32_t>();
+        P.cmax_f = D.cmax_f;
+        P.zero_row = (int32_t)c->R;
+        P.nseg = c->n_pop_segs;
+        {   // what the screen of the limb paths uses for the exact sums: their top 31 bits
+            int bits = 0;
+            while (bits < 62 && (c->total_fixed >> bits) != 0) ++bits;
+            P.x_shift = bits > 31 ? bits - 31 : 0;
+            P.x_scale = (float)std::ldexp(1.0, P.x_shift - c->frac_bits);
+        }
+        P.A = A;
+        if (int rc = c->cs.reserve((size_t)lo_h->cs_total * 8 + 64)) return rc;
+        P.cs = c->cs.as<int64_t>();
+        P.cs_base = D.cs_base;
+        if (int rc = launch_units_pop(c, P, (int)egrid.x, lo_h->n_tiles_cf, c->stream)) return rc;
+        hipLaunchKernelGGL(k_mi_units_tl<true>, dim3(egrid.x, 2, 16), dim3(256), 0, c->stream, A, D.perm, D.perm_t, P.cs, D.cs_base, ghist, acc + 1);
+        hipLaunchKernelGGL(k_mi_units_tl<false>, dim3(egrid.x, 3, 16), dim3(256), 0, c->stream, A, D.perm, D.perm_t, P.cs, D.cs_base, ghist, acc + 1);
+        hipLaunchKernelGGL(k_apx_stats, dim3(1), dim3(256), 0, c->stream, A.lo.cnt, (int)egrid.x * 3, acc);
+        LDW_HIP(hipGetLastError());
+    }
+    LDW_HIP(hipEventRecord(ev[2], c->stream));
     return LDW_OK;
 }
 
@@ -1206,7 +1384,7 @@ int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t 
     LDW_HIP(hipStreamSynchronize(c->stream));  // pageable H2D copies are complete only after a sync
     DevPtrs D{c->idx_f.as<int32_t>(), c->idx_t.as<int32_t>(), c->rowlist_f.as<int32_t>(), c->rowlist_t.as<int32_t>(),
               c->lrow_f.as<int32_t>(), c->lrow_t.as<int32_t>(), c->perm_f.as<int32_t>(), c->perm_t.as<int32_t>(), nullptr, nullptr,
-              nullptr, nullptr, nullptr, nullptr, nullptr, (int)(perm.size() / 64), 0x7FFFFFFF, 0x7FFFFFFF};
+              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (int)(perm.size() / 64), 0x7FFFFFFF, 0x7FFFFFFF};
     E.write_dense = 1;
     E.spec_B = -1;
     // a symmetric block (same list on both sides) may be asked for in full: the GEMM then computes every tile
@@ -1260,9 +1438,10 @@ struct HostBlock {
     int nf_tiles = 0;          // tiles of 64 in the padded from-side order
     int gen_t0 = 0, gen_q0 = 0;
     bool mixed = false;        // high-limb GEMM + gathered low limbs (decided with the bucket guess at submit_a)
+    bool apx = false;          // approximate GEMM + exact popcount sums of the listed units (ldw_apx.h); implies the lo geometry
     int guess = -1;            // bucket guess the block was submitted with
     LoHost lo;
-    size_t o_cmax = 0, o_tbase = 0, o_tf = 0;
+    size_t o_cmax = 0, o_tbase = 0, o_tf = 0, o_csb = 0;
     size_t o_idx_f = 0, o_idx_t = 0, o_rl_f = 0, o_rl_t = 0, o_lrow_f = 0, o_lrow_t = 0, o_perm = 0, o_perm_t = 0, o_cols = 0, o_pos_f = 0,
            o_pos_t = 0, o_cls_f = 0, o_cls_t = 0, total = 0;
     DevPtrs D{};
@@ -1353,7 +1532,10 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
         for (size_t t = 0; t < cmax.size(); ++t) {
             tbase[t] = tb;
             tb += (int64_t)lo.RTlo * 64 * cmax[t];
+            ++lo.n_tiles_cf[cmax[t] == 1 ? 0 : (cmax[t] == 2 ? 1 : 2)];
         }
+        lo.slot = slot;
+        lo.diag = hb.diag ? 1 : 0;
         lo.glo_total = tb;
     }
     std::vector<int32_t> tf;
@@ -1365,9 +1547,21 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
             tf.push_back(fs);
         }
     hb.lo.n_tf = (int32_t)(tf.size() / 2);
+    // exact-sum slots of the approximate path: list (tile, lc) holds up to n_lc[lc] units of 64 * cmax[tile] * (1 << lc) sums
+    std::vector<int64_t> csb(cmax.size() * 3, 0);
+    {
+        int64_t off = 0;
+        for (size_t t = 0; t < cmax.size(); ++t)
+            for (int lc = 0; lc < 3; ++lc) {
+                csb[t * 3 + lc] = off;
+                off += (int64_t)hb.lo.n_lc[lc] * 64 * cmax[t] * (1 << lc);
+            }
+        hb.lo.cs_total = off;
+    }
     hb.o_cmax = o; o = al(o + cmax.size() * 4);
     hb.o_tbase = o; o = al(o + tbase.size() * 8);
     hb.o_tf = o; o = al(o + tf.size() * 4);
+    hb.o_csb = o; o = al(o + csb.size() * 8);
     hb.total = o;
     if (c->pin_cap[slot] < o) {
         if (c->pin[slot]) LDW_HIP(hipHostFree(c->pin[slot]));
@@ -1393,6 +1587,7 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     memcpy(b + hb.o_cmax, cmax.data(), cmax.size() * 4);
     memcpy(b + hb.o_tbase, tbase.data(), tbase.size() * 8);
     memcpy(b + hb.o_tf, tf.data(), tf.size() * 4);
+    memcpy(b + hb.o_csb, csb.data(), csb.size() * 8);
     return LDW_OK;
 }
 
@@ -1459,6 +1654,18 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
     E.scr_shift = bits > 31 ? bits - 31 : 0;
     E.scr_scale = (float)std::ldexp(1.0, E.scr_shift - c->frac_bits + (hb.mixed ? 8 * LO_LIMBS : 0));
     E.scr_eps = SCREEN_EPS + (hb.mixed ? (float)lo_bound(c) : 0.0f);
+    if (hb.apx) {
+        // the screen reads int32 sums of the approximate weights in units of 2^e_last; its bound of the exact MI carries the
+        // relative error delta of the weights and the units lost to truncation (full_cells_screen<.., APX>)
+        const double den = c->neff > 1.0 ? c->neff : 1.0;
+        E.apx = 1;
+        E.apx_EG = c->apx_transitions;
+        E.apx_dfac = (float)(1.01 * c->apx_delta / (1.0 - c->apx_delta));
+        E.apx_s1 = (float)(std::ldexp(1.0, c->apx_e_last - c->frac_bits) * (2.0 * std::log(den + 12.5) + 3.1) / (1.0 - c->apx_delta) * 1.01);
+        E.scr_shift = 0;
+        E.scr_scale = (float)std::ldexp(1.0, c->apx_e_last - c->frac_bits);
+        E.scr_eps = SCREEN_EPS;
+    }
     E.scr_viol = reinterpret_cast<unsigned long long *>(sl.lr_count + 1);
     hb.E = E;
     return LDW_OK;
@@ -1468,8 +1675,10 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
 int launch_pick(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl, hipStream_t st) {
     const int s = hb.slot;
     if (!p->sr_only) {
+        const bool pl = hb.apx && c->screen == 1;
         hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, st, c->hist[s].as<unsigned long long>(), p->lr_retain_links,
-                           p->lr_links_approx, hb.spec_B, (long long)hb.n_lr_total, sl.pick[s]);
+                           p->lr_links_approx, hb.spec_B, (long long)hb.n_lr_total, sl.pick[s],
+                           pl ? reinterpret_cast<const unsigned int *>(c->pairs[s].p) : nullptr, (unsigned int)PAIR_CAP);
         LDW_HIP(hipGetLastError());
     }
     return LDW_OK;
@@ -1492,7 +1701,8 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     auto B = [&](size_t off) { return reinterpret_cast<const uint8_t *>(d + off); };
     hb.D = DevPtrs{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm), I(hb.o_perm_t),
                    I(hb.o_pos_f), I(hb.o_pos_t), B(hb.o_cls_f), B(hb.o_cls_t), I(hb.o_cmax),
-                   reinterpret_cast<const int64_t *>(d + hb.o_tbase), I(hb.o_tf), hb.nf_tiles, hb.gen_t0, hb.gen_q0};
+                   reinterpret_cast<const int64_t *>(d + hb.o_tbase), I(hb.o_tf), reinterpret_cast<const int64_t *>(d + hb.o_csb), hb.nf_tiles, hb.gen_t0,
+                   hb.gen_q0};
     hb.submitted = true;
     if (c->engine != LDW_ENGINE_MFMA) return LDW_OK;
     hipStream_t gs = c->overlap ? c->gemm_stream : c->stream;   // overlap off: the stages of all blocks run back to back
@@ -1509,10 +1719,30 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
         // limbs follow for the listed units only.  The guess is frozen here because the GEMM commits to it.
         hb.mixed = c->mixed && c->screen && c->nlimbs == HI_LIMBS + LO_LIMBS && do_lr && guess > 0 && lo_bound(c) < 1e-3 &&
                    c->N <= 60000;   // the low-limb sums are int32: |sum| <= N * 2^15
+        // approximate GEMM + class-wise popcounts: any block that takes the screen path (a bucket guess exists, or the pass
+        // is SR-only and needs no MI to screen at all)
+        hb.apx = c->path_mode != 1 && c->apx_ok && c->screen && (do_lr ? guess > 0 : true) && hb.nt < (1 << 29);
+        LDW_REQUIRE(c->path_mode != 2 || hb.apx || (do_lr && guess <= 0), LDW_ERR_STATE,
+                    "ldw_set_path(2): the approximate path is not available (delta %.3g, %d weight classes, %lld sequences, screen %d)", c->apx_delta,
+                    c->n_classes, (long long)c->N, c->screen);
+        if (hb.apx) {
+            hb.mixed = false;
+            hb.lo.apx = 1;
+            ++c->apx_blocks;
+        }
         if (hb.mixed) ++c->mixed_blocks;
+        if (hb.apx) {
+            // phase 1 of the approximate path: panels, GEMM, SNP constants and the screens, all beside the previous block's tail.
+            // The emission constants of phase 2 (table pointers, row base) are refreshed in submit_b.
+            if (int rc = make_emit_args(c, hb, p, sl, do_lr ? guess : -1)) return rc;
+            if (int rc = launch_block_apx(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, 1, gs, nullptr, &hb.lo)) return rc;
+            LDW_HIP(hipEventRecord(c->ev_gemm[s], gs));
+            return LDW_OK;
+        }
         EmitArgs E;
         memset(&E, 0, sizeof(E));
         E.lower_only = hb.diag ? 1 : 0;
+        E.do_lr = do_lr ? 1 : 0;
         if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, ev, 1, s ? &c->G2 : &c->G, gs, nullptr,
                                      hb.mixed ? &hb.lo : nullptr))
             return rc;
@@ -1562,12 +1792,15 @@ int submit_b(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr)) return rc;
     if (int rc = c->hist[s].reserve((size_t)NBINS * 8)) return rc;
     LDW_HIP(hipMemsetAsync(c->hist[s].p, 0, (size_t)NBINS * 8, c->stream));
-    if (int rc = make_emit_args(c, hb, p, sl, hb.mixed ? hb.guess : ((do_lr && c->engine == LDW_ENGINE_MFMA) ? c->spec_B_next[hb.diag ? 1 : 0] : -1)))
+    if (int rc = make_emit_args(c, hb, p, sl, (hb.mixed || hb.apx) ? (do_lr ? hb.guess : -1) : ((do_lr && c->engine == LDW_ENGINE_MFMA) ? c->spec_B_next[hb.diag ? 1 : 0] : -1)))
         return rc;
     LDW_HIP(hipMemsetAsync(sl.pick[s], 0, sizeof(ldw::PickOut), c->stream));
     hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
-    if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, c->engine == LDW_ENGINE_MFMA ? 2 : 3,
-                                 s ? &c->G2 : &c->G, nullptr, c->hist[s].as<unsigned long long>(), hb.mixed ? &hb.lo : nullptr))
+    if (hb.apx) {
+        if (int rc = launch_block_apx(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, 2, nullptr, c->hist[s].as<unsigned long long>(), &hb.lo))
+            return rc;
+    } else if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, c->engine == LDW_ENGINE_MFMA ? 2 : 3,
+                                        s ? &c->G2 : &c->G, nullptr, c->hist[s].as<unsigned long long>(), hb.mixed ? &hb.lo : nullptr))
         return rc;
     c->n_sr += sr_add;
     if (int rc = launch_pick(c, hb, p, sl, c->stream)) return rc;
@@ -1597,8 +1830,9 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
         hb.spec_B = -1;
         LDW_HIP(hipMemsetAsync(c->hist[s].p, 0, (size_t)NBINS * 8, c->stream));
         LDW_HIP(hipMemsetAsync(sl.pick[s], 0, sizeof(ldw::PickOut), c->stream));
-        hipEvent_t dummy[5] = {c->ev[3], c->ev[3], c->ev[4], c->ev[3], c->ev[5]};   // keep the block's stage events as they are
-        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, dummy, (hb.fused || hb.mixed) ? 3 : 2,
+        hipEvent_t dummy[6] = {c->ev[3], c->ev[3], c->ev[4], c->ev[3], c->ev[5], c->ev[3]};   // keep the block's stage events as they are
+        E.apx = 0;
+        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, dummy, (hb.fused || hb.mixed || hb.apx) ? 3 : 2,
                                      s ? &c->G2 : &c->G, nullptr, c->hist[s].as<unsigned long long>()))
             return rc;
         if (int rc = launch_pick(c, hb, p, sl, c->stream)) return rc;
@@ -1770,7 +2004,14 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
         }
         LDW_HIP(hipEventCreateWithFlags(&c->ev_lrc, hipEventDisableTiming));
         LDW_HIP(hipHostMalloc(&c->pin_lrc, 64, hipHostMallocDefault));
-        LDW_HIP(hipStreamCreateWithFlags(&c->gemm_stream, hipStreamNonBlocking));
+        {   // the block-wide kernels (GEMM, screens) fill the chip; the tail of the previous block on the main stream is a chain of
+            // small latency-bound kernels that should be dispatched as soon as they are ready: lowest priority for this stream
+            int lo_p = 0, hi_p = 0;
+            LDW_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+            static const bool prio = getenv("LDW_NO_STREAM_PRIO") == nullptr;
+            if (prio) LDW_HIP(hipStreamCreateWithPriority(&c->gemm_stream, hipStreamNonBlocking, lo_p));
+            else LDW_HIP(hipStreamCreateWithFlags(&c->gemm_stream, hipStreamNonBlocking));
+        }
         for (int k = 0; k < 2; ++k) LDW_HIP(hipEventCreateWithFlags(&c->ev_gemm[k], hipEventDisableTiming));
     }
     // everything queued on the main stream so far (row map, weights) must be visible to the GEMM stream
@@ -1826,9 +2067,10 @@ int ldw_links_end(ldw_ctx *c) {
     int64_t h_lr = 0;
     std::vector<int64_t> si((size_t)nb * 3 + 1);
     std::vector<double> sd((size_t)nb + 1);
-    int64_t h_viol = 0;
+    int64_t h_viol = 0, h_apx[2] = {0, 0};
     LDW_HIP(hipMemcpyAsync(&h_lr, sl.lr_count, 8, hipMemcpyDeviceToHost, c->stream));
     LDW_HIP(hipMemcpyAsync(&h_viol, sl.lr_count + 1, 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(h_apx, sl.lr_count + 2, 16, hipMemcpyDeviceToHost, c->stream));
     if (nb > 0) {
         LDW_HIP(hipMemcpyAsync(si.data(), sl.stats_i, (size_t)nb * 24, hipMemcpyDeviceToHost, c->stream));
         LDW_HIP(hipMemcpyAsync(sd.data(), sl.stats_d, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1836,6 +2078,8 @@ int ldw_links_end(ldw_ctx *c) {
     LDW_HIP(hipStreamSynchronize(c->stream));
     c->n_lr = h_lr;
     c->screen_violations += h_viol;
+    c->apx_units_listed += h_apx[0];
+    c->apx_units_kept += h_apx[1];
     c->stats.resize((size_t)nb);
     for (int64_t b = 0; b < nb; ++b) {
         c->stats[b].n_lr_total = si[b * 3 + 0];
@@ -1846,6 +2090,10 @@ int ldw_links_end(ldw_ctx *c) {
         hipEvent_t *ev = &c->ev_pool[(size_t)b * EVB];
         LDW_HIP(hipEventElapsedTime(&t01, ev[0], ev[1]));
         LDW_HIP(hipEventElapsedTime(&t12, ev[c->engine == LDW_ENGINE_MFMA ? 4 : 1], ev[2]));
+        if (c->engine == LDW_ENGINE_MFMA && !c->fused) {   // the screens of the approximate path run behind the GEMM on its stream
+            float t15 = 0;
+            if (hipEventElapsedTime(&t15, ev[1], ev[5]) == hipSuccess) t12 += t15;
+        }
         LDW_HIP(hipEventElapsedTime(&t23, ev[2], ev[3]));
         c->last_ms[0] += t01;
         c->last_ms[1] += t12;

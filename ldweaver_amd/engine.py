@@ -55,7 +55,7 @@ class Engine:
         v = np.zeros(8, dtype=np.int64)
         L.check(L.lib().ldw_ctx_counters2(self._ctx, L.ptr(v)))
         return dict(spec_misses=int(v[0]), fused_blocks=int(v[1]), unfused_blocks=int(v[2]), screen_violations=int(v[3]),
-                    mixed_blocks=int(v[4]))
+                    mixed_blocks=int(v[4]), apx_blocks=int(v[5]), apx_units_listed=int(v[6]), apx_units_kept=int(v[7]))
 
     def set_overlap(self, on: bool):
         """GEMM of the next block beside the epilogue/selection of the current one (default on); off = exclusive stage times."""
@@ -68,6 +68,17 @@ class Engine:
     def set_mixed(self, on: bool):
         """High-limb block GEMM + gathered low-limb GEMM for the listed units in speculative blocks (default on)."""
         L.check(L.lib().ldw_set_mixed(self._ctx, int(bool(on))))
+
+    def set_path(self, mode: int):
+        """Block-wide pass of the speculative blocks: 0 auto (default), 1 limb GEMM paths only, 2 approximate-GEMM path
+        (one dual-digit int8 pass + exact class-wise popcount sums of the listed units) or an error."""
+        L.check(L.lib().ldw_set_path(self._ctx, int(mode)))
+
+    def apx_info(self):
+        """Diagnostics of the approximate path for the current weights (after set_weights)."""
+        v = np.zeros(6)
+        L.check(L.lib().ldw_apx_info(self._ctx, L.ptr(v)))
+        return dict(usable=bool(v[0]), delta=float(v[1]), classes=int(v[2]), segments=int(v[3]), transitions=int(v[4]), e_last=int(v[5]))
 
     def set_screen(self, mode: int):
         """fp32 screen before the fp64 MI evaluation in speculative blocks: 0 off, 1 on (default), 2 verify."""

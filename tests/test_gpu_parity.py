@@ -637,6 +637,7 @@ def test_mixed_precision_gemm_is_exact(engine, synth):
     approx = MIH.lr_links_approx(syn["POS"], float(syn["g"]), 20000.0)
     blocks = MIH.make_blocks(3000, 1000)
     out = {}
+    engine.set_path(1)     # the limb paths (auto would take the approximate-GEMM path on these weights)
     for mixed, scr in ((False, 1), (True, 1), (True, 2)):
         engine.set_mixed(mixed)
         engine.set_screen(scr)
@@ -647,6 +648,7 @@ def test_mixed_precision_gemm_is_exact(engine, synth):
         out[(mixed, scr)] = (engine.links(0), engine.links(1), {k: c1[k] - c0[k] for k in c1})
     engine.set_mixed(True)
     engine.set_screen(1)
+    engine.set_path(0)
     assert out[(False, 1)][2]["mixed_blocks"] == 0 and out[(True, 1)][2]["mixed_blocks"] >= len(blocks)
     assert out[(True, 2)][2]["screen_violations"] == 0
     for which in (0, 1):
@@ -712,9 +714,11 @@ def test_screen_and_mixed_paths_on_multiallelic_alignment(engine):
     approx = orc.lr_links_approx(POS, d["g"], 20000.0)
     blocks = np.array(orc.make_blocks(Ls, 1000), dtype=np.int32)       # 1000, 1000, 600: ragged last column -> intended quirk mode
     out = {}
-    for key, (mixed, scr) in dict(plain=(False, 0), fast=(True, 1), verify=(True, 2)).items():
+    assert engine.apx_info()["usable"]
+    for key, (mixed, scr, path) in dict(plain=(False, 0, 1), fast=(True, 1, 1), verify=(True, 2, 1), apx=(True, 1, 2), apx_verify=(True, 2, 2)).items():
         engine.set_mixed(mixed)
         engine.set_screen(scr)
+        engine.set_path(path)
         c0 = engine.counters()
         for _ in range(2):
             engine.mi_all_pairs(blocks, 20000.0, 30000.0, approx, quirk=L.QUIRK_INTENDED)
@@ -722,9 +726,12 @@ def test_screen_and_mixed_paths_on_multiallelic_alignment(engine):
         out[key] = (engine.links(0), engine.links(1), {k: c1[k] - c0[k] for k in c1})
     engine.set_mixed(True)
     engine.set_screen(1)
+    engine.set_path(0)
     assert out["fast"][2]["mixed_blocks"] >= len(blocks) and out["verify"][2]["screen_violations"] == 0
+    assert out["apx"][2]["apx_blocks"] >= len(blocks) and out["apx"][2]["mixed_blocks"] == 0 and out["apx_verify"][2]["screen_violations"] == 0
+    assert 0 < out["apx"][2]["apx_units_kept"] <= out["apx"][2]["apx_units_listed"]
     for which in (0, 1):
-        for key in ("fast", "verify"):
+        for key in ("fast", "verify", "apx", "apx_verify"):
             for x, y in zip(out["plain"][which], out[key][which]):
                 assert np.array_equal(x, y), (which, key)
     assert len(out["plain"][1][2]) > 20000 and len(out["plain"][0][2]) > 1000
@@ -757,19 +764,28 @@ def test_full_size_properties(engine, Ls, N):
     approx = MIH.lr_links_approx(POS, g, 20000.0)
     blocks = MIH.make_blocks(Ls, 10000)
     out = {}
-    for key, (mixed, scr) in dict(plain=(False, 0), fast=(True, 1)).items():
+    info = engine.apx_info()
+    variants = dict(plain=(False, 0, 1), mixed=(True, 1, 1), fast=(True, 1, 0))   # fast = the default configuration
+    for key, (mixed, scr, path) in variants.items():
         engine.set_mixed(mixed)
         engine.set_screen(scr)
+        engine.set_path(path)
+        c0 = engine.counters()
         for _ in range(2):
             engine.mi_all_pairs(blocks, 20000.0, 1e6, approx)
-        out[key] = (engine.links(0, device_tensors=True), engine.links(1), engine.block_stats())
+        c1 = engine.counters()
+        out[key] = (engine.links(0, device_tensors=True), engine.links(1), engine.block_stats(), {k: c1[k] - c0[k] for k in c1})
     engine.set_mixed(True)
     engine.set_screen(1)
-    for x, y in zip(out["plain"][0], out["fast"][0]):
-        assert torch.equal(x, y)
-    for x, y in zip(out["plain"][1], out["fast"][1]):
-        assert np.array_equal(x, y)
-    sr, (la, lb, lmi), stt = out["fast"]
+    engine.set_path(0)
+    if Ls == 100_000:   # few weight classes (clonal groups): the default is the approximate-GEMM path
+        assert info["usable"] and out["fast"][3]["apx_blocks"] >= len(blocks) and out["fast"][3]["spec_misses"] <= 2
+    for key in ("mixed", "fast"):
+        for x, y in zip(out["plain"][0], out[key][0]):
+            assert torch.equal(x, y), key
+        for x, y in zip(out["plain"][1], out[key][1]):
+            assert np.array_equal(x, y), key
+    sr, (la, lb, lmi), stt, _ = out["fast"]
     pairs = sum(nf * (nf - 1) // 2 if (fs, fe) == (ts, te) else nf * nt - min(nf, nt)
                 for fs, fe, ts, te in blocks.tolist() for nf, nt in [(fe - fs + 1, te - ts + 1)])
     assert int(stt["n_sr"].sum() + stt["n_lr_total"].sum()) == pairs
@@ -823,3 +839,108 @@ def test_hamming_counts_strips_add_up(engine, sample, synth):
                 if t1 > t0:
                     tot += engine.hamming_counts(thr, t0, t1)
             assert np.array_equal(1.0 / (tot + 1.0), hdw), world
+
+
+def test_apx_path_is_exact(engine):
+    """Approximate-GEMM path (ldw_set_path 2): ONE dual-digit int8 pass feeds the screen, the listed units get their exact
+    joint sums from class-wise popcounts.  Those sums are the integers the 5-limb GEMM produces, so the link tables must be
+    BIT-identical to the plain path (5 limbs, fp64 for every pair) — ragged last block column (Q1 scramble), both quirk
+    modes, diagonal and off-diagonal blocks; verify mode evaluates every unit both ways: nothing lost by either screen."""
+    syn = synth_alignment(3300, 900, seed=11)
+    st = syn["states"]
+    uqe, r = orc.uqe_r(st)
+    engine.set_alignment(st)
+    hdw = engine.hamming_weights(330)
+    d = dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=syn["POS"], paint=syn["paint"], g=float(syn["g"]))
+    _setup(engine, d)
+    info = engine.apx_info()
+    assert info["usable"] and info["delta"] < 4e-3 and info["classes"] <= 900 // 8, info
+    approx = MIH.lr_links_approx(syn["POS"], float(syn["g"]), 20000.0)
+    blocks = MIH.make_blocks(3300, 1000)     # 1000, 1000, 1000, 300: ragged last column
+    for quirk in (L.QUIRK_REFERENCE, L.QUIRK_INTENDED):
+        out = {}
+        for key, (scr, path, mixed) in dict(plain=(0, 1, False), apx=(1, 2, True), verify=(2, 2, True)).items():
+            engine.set_mixed(mixed)
+            engine.set_screen(scr)
+            engine.set_path(path)
+            c0 = engine.counters()
+            for _ in range(2):
+                engine.mi_all_pairs(blocks, 20000.0, 25000.0, approx, quirk=quirk)
+            c1 = engine.counters()
+            out[key] = (engine.links(0), engine.links(1), {k: c1[k] - c0[k] for k in c1})
+        engine.set_mixed(True)
+        engine.set_screen(1)
+        engine.set_path(0)
+        assert out["apx"][2]["apx_blocks"] >= len(blocks) and out["apx"][2]["mixed_blocks"] == 0
+        assert out["verify"][2]["screen_violations"] == 0
+        for which in (0, 1):
+            for key in ("apx", "verify"):
+                for x, y in zip(out["plain"][which], out[key][which]):
+                    assert np.array_equal(x, y), (quirk, which, key)
+        assert len(out["plain"][1][2]) > 15000 and len(out["plain"][0][2]) > 1000
+        lst, kept = out["apx"][2]["apx_units_listed"], out["apx"][2]["apx_units_kept"]
+        assert 0 < kept <= lst
+
+
+def test_apx_path_sr_only(engine):
+    """SR-only passes need no block-wide GEMM at all in the approximate path (the screen lists the units that hold a
+    short-range pair; their sums come from the popcounts): same table as the limb path, bit for bit."""
+    syn = synth_alignment(2400, 800, seed=21)
+    st = syn["states"]
+    uqe, r = orc.uqe_r(st)
+    engine.set_alignment(st)
+    hdw = engine.hamming_weights(240)
+    POS, g, sr_dist = syn["POS"], float(syn["g"]), 4000.0
+    _setup(engine, dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=POS, paint=syn["paint"], g=g))
+    assert engine.apx_info()["usable"]
+    blocks = orc.make_blocks(2400, 1000)
+    POSf = POS.astype(float)
+    res = {}
+    for path in (1, 2):
+        engine.set_path(path)
+        c0 = engine.counters()
+        engine.links_begin(len(blocks))
+        for fs, fe, ts, te in blocks:
+            fi, ti = np.arange(fs - 1, fe), np.arange(ts - 1, te)
+            ln = np.abs(orc.circ_len(POSf[ti][None, :], POSf[fi][:, None], g))
+            fi, ti = fi[(ln < sr_dist).any(axis=1)], ti[(ln < sr_dist).any(axis=0)]
+            if len(fi) and len(ti):
+                engine.mi_block_links(fi, ti, sr_dist=sr_dist, sr_only=True)
+        engine.links_end()
+        c1 = engine.counters()
+        res[path] = engine.links(0)
+        assert engine.links_count(1) == 0
+        assert (c1["apx_blocks"] > c0["apx_blocks"]) == (path == 2)
+    engine.set_path(0)
+    assert len(res[1][2]) > 1000
+    for x, y in zip(res[1], res[2]):
+        assert np.array_equal(x, y)
+    # a few rows against the oracle's per-pair MI (non-square SR-only blocks: the reference reads a scrambled RXY, so use
+    # rows of the diagonal blocks, where Q1 is harmless)
+    a, b, mi = res[2]
+    sel = np.flatnonzero((a // 1000) == (b // 1000))[:: max(1, len(a) // 40)][:12]
+    for k in sel:
+        ref = orc.mi_pair_direct(st, hdw, r, uqe, int(a[k]), int(b[k]))
+        assert abs(mi[k] - ref) < MI_TIGHT
+
+
+def test_apx_path_falls_back_on_irregular_weights(engine, synth):
+    """Weights without class structure (every sequence its own value): the approximate path is not usable, auto mode takes
+    the limb path, forcing it is refused."""
+    d = dict(synth)
+    rng = np.random.default_rng(3)
+    d["hdw"] = rng.uniform(0.01, 1.0, len(synth["hdw"]))
+    _setup(engine, d)
+    assert not engine.apx_info()["usable"]
+    blocks = MIH.make_blocks(512, 200)
+    approx = MIH.lr_links_approx(d["POS"], d["g"], 3000.0)
+    c0 = engine.counters()
+    engine.mi_all_pairs(blocks, 3000.0, 5000.0, approx)
+    c1 = engine.counters()
+    assert c1["apx_blocks"] == c0["apx_blocks"] and c1["mixed_blocks"] > c0["mixed_blocks"]
+    engine.set_path(2)
+    try:
+        with pytest.raises(L.LdwError):
+            engine.mi_all_pairs(blocks, 3000.0, 5000.0, approx)
+    finally:
+        engine.set_path(0)

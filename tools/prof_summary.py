@@ -11,7 +11,7 @@ w = csv.writer(sys.stdout)
 w.writerow(["kernel", "calls", "total_ms", "avg_us", "pct", "min_us", "max_us"])
 for r in rows[:top]:
     name = r["Name"]
-    m = re.search(r"(ldw::\w+(<\d+>)?)", name)
+    m = re.search(r"(ldw::\w+(<[\w, ]+>)?)", name)
     if m:
         short = m.group(1)
     else:
