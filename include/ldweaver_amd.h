@@ -67,7 +67,8 @@ int ldw_ctx_last_timing(ldw_ctx *ctx, double ms_out[4]);
  * out[3] = pairs the fp32 screen would have lost (counted in ldw_set_screen mode 2 only; must stay 0) */
 int ldw_ctx_counters(ldw_ctx *ctx, int64_t out[4]);
 /* the same four, then out[4] = blocks run in the mixed-precision path (ldw_set_mixed), out[5] = blocks run in the
- * approximate-GEMM path (ldw_set_path), out[6] = units its approximate screen listed, out[7] = units kept by the exact re-screen */
+ * approximate-GEMM path (ldw_set_path), out[6] = units its screen listed (they hold a short-range pair), out[7] = long-range candidate
+ * pairs its screen listed */
 int ldw_ctx_counters2(ldw_ctx *ctx, int64_t out[8]);
 
 /* ---- (1) .ACGTN2num  — src/ACGTN2num_parallel.cpp:10-43, R/RcppExports.R:4-6 ------------ */

@@ -264,7 +264,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
                            &c->srm_q, &c->srm_n, &c->srm_md, &c->srm_part, &c->srm_shape, &c->srm_cnt, &c->red_row, &c->red_meta,
                            &c->red_srp, &c->pool_a, &c->pool_b, &c->pool_mi, &c->ar_key, &c->ar_val, &c->ar_key2, &c->ar_val2,
                            &c->ar_off, &c->ar_flags, &c->seq_perm, &c->dig_a, &c->dig_b, &c->apx_shift, &c->slot_papx, &c->pop_segs, &c->pop_wbeg,
-                           &c->panel[0][0], &c->panel[0][1], &c->panel[1][0], &c->panel[1][1], &c->Gapx[0], &c->Gapx[1], &c->cs, &c->pair_sums, &c->pairs[0], &c->pairs[1], &c->apx_units[0], &c->apx_units[1], &c->apx_packs[0], &c->apx_packs[1]};
+                           &c->panel[0][0], &c->panel[0][1], &c->panel[1][0], &c->panel[1][1], &c->Gapx[0], &c->Gapx[1], &c->pair_sums, &c->pairs[0], &c->pairs[1], &c->apx_units[0], &c->apx_units[1], &c->apx_packs[0], &c->apx_packs[1]};
     for (auto *b : bufs) b->release();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -326,7 +326,7 @@ int ldw_ctx_counters2(ldw_ctx *c, int64_t out[8]) {
     out[4] = c->mixed_blocks;
     out[5] = c->apx_blocks;
     out[6] = c->apx_units_listed;
-    out[7] = c->apx_units_kept;
+    out[7] = c->apx_pairs_listed;
     return LDW_OK;
 }
 
@@ -706,6 +706,7 @@ int ensure_rows(ldw_ctx *c) {
         c->h_row0[a + 1] = c->h_row0[a] + nrows;
     }
     c->R = c->h_row0[L];
+    c->h_slot_meta = meta;
     const int64_t R = c->R;
     if (int rc = c->row0.reserve((size_t)(L + 1) * 4)) return rc;
     if (int rc = c->slot_meta.reserve((size_t)L * 4)) return rc;

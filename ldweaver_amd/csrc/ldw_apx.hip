@@ -2,7 +2,7 @@
 //   prepare_apx_weights  host: dual digits a, b and block exponents of the weights, popcount segments of the weight classes
 //   k_pack_panel         per block side: bit rows of the row list, transposed to [macro step][row][2 words]
 //   gemm_apx_kernel      one int8 MFMA pass, both operands masked digits -> int32 approximate joint sums (screen input)
-//   k_units_pop<CF, CT>  exact joint sums of the listed units by class-wise popcounts, exact fp32 re-screen, compaction
+//   k_pair_sums / k_pair_mi  exact joint sums of the listed candidate pairs by class-wise popcounts, fp64 MI, emission
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -86,6 +86,10 @@ int prepare_apx_weights(ldw_ctx *c) {
     c->apx_delta = delta;
     c->apx_e_last = M2 > 0 ? em[(size_t)M2 - 1] : 0;
     c->apx_transitions = transitions;
+    // units of 2^e_last a GEMM entry can have lost to the truncations: < 1 unit of 2^e(m) at every transition into macro step m
+    c->apx_lost_units = 0;
+    for (int m = 1; m < M2; ++m)
+        if (sh[(size_t)m] > 0) c->apx_lost_units += std::ldexp(1.0, em[(size_t)m] - c->apx_e_last);
     // weight classes = runs of equal V along the positions; segments = (32-bit word, class) intersections
     std::vector<PopSeg> segs;
     std::vector<int32_t> wbeg((size_t)(Npad / 32) + 1, 0);
@@ -125,10 +129,10 @@ int prepare_apx_weights(ldw_ctx *c) {
     LDW_HIP(hipMemcpyAsync(c->pop_segs.p, segs.data(), segs.size() * sizeof(PopSeg), hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipMemcpyAsync(c->pop_wbeg.p, wbeg.data(), wbeg.size() * 4, hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipStreamSynchronize(c->stream));
-    // The path pays when (i) the approximation is tight enough for the screen to dismiss almost everything (its margin
-    // grows with delta), (ii) the classes are long enough for the popcounts to beat a gathered limb GEMM (one 64-bit
-    // multiply-add per class and sum against two VALU instructions per 32 sequences), (iii) the digit arrays fit in LDS.
-    c->apx_ok = delta <= 4e-3 && n_classes * 8 <= Npad && Npad <= 30720 && M2 > 0 && segs.size() * sizeof(PopSeg) + (size_t)Npad / 8 + 64 <= 60000;
+    // The path pays when the approximation is tight enough for the screen to dismiss almost everything (its margin grows with
+    // delta); the digit arrays of the GEMM must fit in LDS.  Any weights qualify: with many distinct values the popcount sums of
+    // the listed pairs walk more segments per word, which is still cheap for the few pairs that are listed.
+    c->apx_ok = delta <= 4e-3 && Npad <= 30720 && M2 > 0 && segs.size() * sizeof(PopSeg) + (size_t)Npad / 8 + 64 <= 60000;   // k_pair_sums keeps the segment tables in LDS
     return LDW_OK;
 }
 
@@ -287,218 +291,6 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_units_pop<CF, CT>: exact joint sums of the units listed by the approximate screen.
-// Work item = (from-tile, batch of T = 8 / CT listed to-side SNPs of row-slot class CT): lane = from-side SNP of the tile
-// (CF row slots, its bit words come from the packed panel, coalesced), the to-side rows are wave-uniform (scalar loads from
-// the row-major bit matrix).  Per 32-bit word and (to row, from slot): v_and + v_bcnt accumulate the class count; at the
-// end of a class: sum64 += count * V_class.  The sums are the integers the 5-limb GEMM produces.  Then, per unit: the exact
-// fp32 screen (margin SCREEN_EPS) decides whether any of its 64 pairs needs the fp64 value; kept units are appended to the
-// final list of their code path and their sums stored for k_mi_units.
-// ------------------------------------------------------------------------------------------------
-template <int NA, int NB>
-__device__ __forceinline__ void cells_from_sums(const RowSide &R, const ColMeta &M, const int64_t (&s)[NB][NA], FullCells<NA, NB> &C) {
-    int64_t rs[NA], cs[NB];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) rs[i] = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) cs[j] = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            C.n[i][j] = s[j][i];
-            rs[i] += s[j][i];
-            cs[j] += s[j][i];
-        }
-    int64_t dd = R.pa[NA];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        C.n[NA][j] = M.pb[j] - cs[j];
-        dd -= C.n[NA][j];
-    }
-#pragma unroll
-    for (int i = 0; i < NA; ++i) C.n[i][NB] = R.pa[i] - rs[i];
-    C.n[NA][NB] = dd;
-}
-
-template <int CF, int CT>
-__global__ __launch_bounds__(256) void k_units_pop(PopArgs P) {
-    constexpr int T = 8 / CT;
-    constexpr int LC = CT == 1 ? 0 : (CT == 2 ? 1 : 2);
-    constexpr bool FASTV = CF <= 2 && CT <= 2;
-    // LDS copy of the segment tables: wbeg (bit 31: the word is ONE full segment that does not end its class, the common case:
-    // no segment record is read for it) and the segment records
-    extern __shared__ __attribute__((aligned(16))) uint8_t pop_smem[];
-    int32_t *s_wbeg = reinterpret_cast<int32_t *>(pop_smem);
-    PopSeg *s_segs = reinterpret_cast<PopSeg *>(pop_smem + (((size_t)P.M2 * 4 + 4) * 4 + 15) / 16 * 16);
-    const int tile = blockIdx.x;
-    const bool mine = P.cmax_f[tile] == CF;
-    const unsigned int cnt = mine ? P.A.lo.cnt[tile * 3 + LC] : 0u;
-    const unsigned int nbatch = (cnt + T - 1) / T;
-    if (blockIdx.y * 4u >= nbatch) return;   // the whole workgroup has nothing to do
-    for (int i = threadIdx.x; i < P.M2 * 4 + 1; i += 256) s_wbeg[i] = P.wbeg[i];
-    for (int i = threadIdx.x; i < P.nseg; i += 256) s_segs[i] = P.segs[i];
-    __syncthreads();
-    EpiArgs A = P.A;
-    A.E.scr_shift = P.x_shift;   // the re-screen reads EXACT sums
-    A.E.scr_scale = P.x_scale;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (blockIdx.y * 4u + wave >= nbatch) return;
-    const bool square = A.nf == A.nt;
-    RowSide R;
-    int a_loc, na0;
-    const bool a_ok = load_row_side(A, nullptr, square, tile, R, a_loc);
-    const bool wave_full = FASTV && wave_is_full(R, a_ok, na0) && na0 == CF;
-    const int rxy_mode = A.quirk == LDW_QUIRK_REFERENCE ? (square ? 1 : 2) : 0;
-    const float lo = (float)A.E.spec_lo - SCREEN_EPS;
-    const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0, do_lr = A.E.do_lr != 0;
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 *pf = reinterpret_cast<const u32x4 *>(P.panel_f) + (a_ok ? R.ra0 : 0);
-
-    for (unsigned int b = blockIdx.y * 4u + wave; b < nbatch; b += gridDim.y * 4u) {
-        // the batch's units: column slot q (bit 31: dismissed by the approximate screen, verify mode), rows of the to-side SNP
-        uint32_t qv[T];
-        // the 8 to-side rows of the batch (T units x CT row slots) x the 4 words of a macro step = 32 dwords: lane l < 32 loads
-        // word l & 3 of row l >> 2 with ONE load per macro step; v_readlane hands them to the whole wave as scalars
-        const uint32_t *my_trow = reinterpret_cast<const uint32_t *>(P.Mbits + (int64_t)P.zero_row * P.KW);
-#pragma unroll
-        for (int u = 0; u < T; ++u) {
-            const unsigned int k = b * T + u;
-            const uint32_t e = k < cnt ? A.lo.tl[(int64_t)tile * A.nt + A.lo.uoff[LC] + k] : 0xFFFFFFFFu;
-            qv[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
-            int32_t r0 = P.zero_row, nr = 0;
-            if (qv[u] != 0xFFFFFFFFu) {
-                const int snp = P.idx_t[P.perm_t[qv[u] & 0x7FFFFFFFu]];
-                r0 = P.row0[snp];
-                nr = P.row0[snp + 1] - r0;
-            }
-            r0 = __builtin_amdgcn_readfirstlane(r0);
-            nr = __builtin_amdgcn_readfirstlane(nr);
-#pragma unroll
-            for (int j = 0; j < CT; ++j)
-                if (((lane >> 2) & 7) == u * CT + j) my_trow = reinterpret_cast<const uint32_t *>(P.Mbits + (int64_t)(j < nr ? r0 + j : P.zero_row) * P.KW);
-        }
-        my_trow += lane & 3;
-        unsigned int c32[T][CT][CF];
-        int64_t s64[T][CT][CF];
-#pragma unroll
-        for (int u = 0; u < T; ++u)
-#pragma unroll
-            for (int j = 0; j < CT; ++j)
-#pragma unroll
-                for (int i = 0; i < CF; ++i) {
-                    c32[u][j][i] = 0;
-                    s64[u][j][i] = 0;
-                }
-        u32x4 fn[CF];   // next macro step's words, loaded while the current one is counted
-        uint32_t tnw;
-#pragma unroll
-        for (int i = 0; i < CF; ++i) fn[i] = pf[i];
-        tnw = my_trow[0];
-        const int M2run = (P.debug & 1) ? 1 : P.M2;
-        for (int m = 0; m < M2run; ++m) {
-            u32x4 f[CF];
-            uint32_t t[T][CT][4];
-#pragma unroll
-            for (int i = 0; i < CF; ++i) f[i] = fn[i];
-#pragma unroll
-            for (int u = 0; u < T; ++u)
-#pragma unroll
-                for (int j = 0; j < CT; ++j)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) t[u][j][k] = (uint32_t)__builtin_amdgcn_readlane((int)tnw, (u * CT + j) * 4 + k);
-            if (m + 1 < P.M2) {
-#pragma unroll
-                for (int i = 0; i < CF; ++i) fn[i] = pf[(int64_t)(m + 1) * P.RFpad + i];
-                tnw = my_trow[(m + 1) * 4];
-            }
-            int wb[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) wb[k] = __builtin_amdgcn_readfirstlane(s_wbeg[4 * m + k]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (wb[k] < 0) {   // one full segment inside a class
-#pragma unroll
-                    for (int u = 0; u < T; ++u)
-#pragma unroll
-                        for (int j = 0; j < CT; ++j)
-#pragma unroll
-                            for (int i = 0; i < CF; ++i) c32[u][j][i] += __popc(f[i][k] & t[u][j][k]);
-                    continue;
-                }
-                const int s1 = wb[k + 1] & 0x7FFFFFFF;
-                for (int s = wb[k]; s < s1; ++s) {
-                    const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segs[s].mask);
-                    const uint32_t flush = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segs[s].flush);
-                    uint32_t fm[CF];
-#pragma unroll
-                    for (int i = 0; i < CF; ++i) fm[i] = f[i][k] & mask;
-#pragma unroll
-                    for (int u = 0; u < T; ++u)
-#pragma unroll
-                        for (int j = 0; j < CT; ++j)
-#pragma unroll
-                            for (int i = 0; i < CF; ++i) c32[u][j][i] += __popc(fm[i] & t[u][j][k]);
-                    if (flush) {
-                        const int64_t V = s_segs[s].V;
-                        const uint32_t vlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)V);
-                        const uint32_t vhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)V >> 32));
-                        const uint64_t Vu = ((uint64_t)vhi << 32) | vlo;
-#pragma unroll
-                        for (int u = 0; u < T; ++u)
-#pragma unroll
-                            for (int j = 0; j < CT; ++j)
-#pragma unroll
-                                for (int i = 0; i < CF; ++i) {
-                                    s64[u][j][i] += (int64_t)((uint64_t)c32[u][j][i] * Vu);
-                                    c32[u][j][i] = 0;
-                                }
-                    }
-                }
-            }
-        }
-        // per unit: exact re-screen, compaction
-#pragma unroll
-        for (int u = 0; u < T; ++u) {
-            if (qv[u] == 0xFFFFFFFFu || (P.debug & 2)) continue;
-            const bool dismissed_in = (qv[u] & 0x80000000u) != 0;
-            const int q = (int)(qv[u] & 0x7FFFFFFFu);
-            const ColMeta &M = A.colpack[q];
-            const uint32_t mbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.mb);
-            const int b_loc = __builtin_amdgcn_readfirstlane(M.bl);
-            const bool fast = wave_full && col_is_fast(mbu) && (int)(mbu & 7) == CT;
-            bool keep = true;
-            if constexpr (FASTV) {
-                if (fast && A.E.scr_mode) {
-                    FullCells<CF, CT> C;
-                    cells_from_sums<CF, CT>(R, M, s64[u], C);
-                    const bool act = a_ok && (A.E.lower_only ? a_loc > b_loc : a_loc != b_loc);
-                    float ms = 0.0f;
-                    if (do_lr) ms = full_cells_screen<CF, CT>(A, R, M, screen_rxy(A, R, M, a_loc, b_loc, rxy_mode), C);
-                    const bool is_sr = test_sr && col_is_sr(M.ci, a_loc);
-                    const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
-                    keep = __ballot(need) != 0ull;
-                }
-            }
-            // Result, written back into the unit's list entry: dropped (the exact sums rule the unit out), predicated code
-            // (k_mi_units_tl<false>), dismissed (verify mode: evaluated anyway, must not produce anything).  The sums go to the
-            // slot of the unit's list position: no counter, no compaction (4 of 5 listed units are kept).
-            const bool dismissed = dismissed_in || !keep;
-            const unsigned int kpos = b * T + u;
-            uint32_t ent = (uint32_t)q | (fast ? 0u : UNIT_TL_GENERIC);
-            if (dismissed) ent |= A.E.scr_mode == 2 ? UNIT_TL_DISMISSED : UNIT_TL_DROPPED;
-            if (lane == 0) A.lo.tl[(int64_t)tile * A.nt + A.lo.uoff[LC] + kpos] = ent;
-            if (dismissed && A.E.scr_mode != 2) continue;
-            int64_t *dst = P.cs + P.cs_base[tile * 3 + LC] + (int64_t)kpos * (64 * CF * CT) + lane;
-#pragma unroll
-            for (int j = 0; j < CT; ++j)
-#pragma unroll
-                for (int i = 0; i < CF; ++i) dst[(j * CF + i) * 64] = s64[u][j][i];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // The long-range candidates listed pair by pair (units without a short-range pair), in two kernels:
 //   k_pair_sums<CA, CB>  one WAVE per pair, lane = 32-bit word of the bit rows (coalesced 256-B reads of the pair's CA + CB rows
 //                        from the row-major bit matrix).  sum_s V_s x_s y_s = sum_words sum_segments V_class popcount(x & y & mask):
@@ -511,7 +303,7 @@ __global__ __launch_bounds__(256) void k_units_pop(PopArgs P) {
 struct PairArgs {
     const uint64_t *Mbits;
     int64_t KW;
-    int nwords, path;            // 32-bit words per row
+    int nwords, path, nseg;      // 32-bit words per row; segment records
     const PopSeg *segs;
     const int32_t *wbeg, *row0;
     int32_t zero_row;
@@ -521,20 +313,39 @@ struct PairArgs {
 };
 
 template <int CA, int CB>
-__device__ __forceinline__ void pair_sums_body(const PairArgs &P, int path) {
+__device__ __forceinline__ void pair_sums_body(const PairArgs &P, int path, const int32_t *s_wbeg, const PopSeg *s_segs) {
     const EpiArgs &A = P.A;
     const int sub = path * PAIR_SHARDS + (int)blockIdx.y;
     unsigned int n = A.pl_n[sub];
     n = n > A.pl_cap ? A.pl_cap : n;
     const int lane = threadIdx.x & 63;
-    const uint64_t *list = A.pl_pairs + (int64_t)sub * A.pl_cap;
+    const PairEnt *list = A.pl_pairs + (int64_t)sub * A.pl_cap;
+    // the segments of THIS lane's first words are the same for every pair: keep two per word in registers (a word holds more
+    // than two only where several tiny weight classes meet: those go through the table)
+    constexpr int KW = 3, KS = 2;
+    uint32_t smask[KW][KS];
+    int64_t sV[KW][KS];
+    bool more[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int w = lane + 64 * k;
+        int s0 = 0, s1 = 0;
+        if (w < P.nwords) {
+            s0 = s_wbeg[w] & 0x7FFFFFFF;
+            s1 = s_wbeg[w + 1] & 0x7FFFFFFF;
+        }
+        more[k] = s1 - s0 > KS;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            const bool on = s0 + q < s1 && !more[k];
+            smask[k][q] = on ? s_segs[s0 + q].mask : 0u;
+            sV[k][q] = on ? s_segs[s0 + q].V : 0;
+        }
+    }
     for (unsigned int idx = blockIdx.x * 4u + (threadIdx.x >> 6); idx < n; idx += gridDim.x * 4u) {
-        const uint64_t e = list[idx];
-        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(e >> 32));
-        const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)e);
-        const int sa = __builtin_amdgcn_readfirstlane(A.rowpack[t].R.sa), sb = __builtin_amdgcn_readfirstlane(A.colpack[q].sb);
-        const int r0a = __builtin_amdgcn_readfirstlane(P.row0[sa]), na = __builtin_amdgcn_readfirstlane(P.row0[sa + 1]) - r0a;
-        const int r0b = __builtin_amdgcn_readfirstlane(P.row0[sb]), nb = __builtin_amdgcn_readfirstlane(P.row0[sb + 1]) - r0b;
+        const PairEnt e = list[idx];
+        const uint32_t era = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.ra), erb = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.rb);
+        const int r0a = (int)(era & 0x1FFFFFFFu), na = (int)(era >> 29), r0b = (int)(erb & 0x1FFFFFFFu), nb = (int)(erb >> 29);
         const uint32_t *fr[CA], *tr[CB];
 #pragma unroll
         for (int i = 0; i < CA; ++i) fr[i] = reinterpret_cast<const uint32_t *>(P.Mbits + (int64_t)(i < na ? r0a + i : P.zero_row) * P.KW);
@@ -545,19 +356,51 @@ __device__ __forceinline__ void pair_sums_body(const PairArgs &P, int path) {
         for (int j = 0; j < CB; ++j)
 #pragma unroll
             for (int i = 0; i < CA; ++i) s[j][i] = 0;
-        for (int w = lane; w < P.nwords; w += 64) {
-            uint32_t f[CA], tt[CB];
+        // the first KW * 64 words: all loads of the pair are issued at once, the segments come from registers
+        uint32_t f[KW][CA], tt[KW][CB];
 #pragma unroll
-            for (int i = 0; i < CA; ++i) f[i] = fr[i][w];
+        for (int k = 0; k < KW; ++k) {
+            const int w = lane + 64 * k;
+            const bool in = w < P.nwords;
 #pragma unroll
-            for (int j = 0; j < CB; ++j) tt[j] = tr[j][w];
-            const int s0 = P.wbeg[w] & 0x7FFFFFFF, s1 = P.wbeg[w + 1] & 0x7FFFFFFF;
+            for (int i = 0; i < CA; ++i) f[k][i] = in ? fr[i][w] : 0u;
+#pragma unroll
+            for (int j = 0; j < CB; ++j) tt[k][j] = in ? tr[j][w] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            if (more[k]) {
+                const int w = lane + 64 * k;
+                const int s0 = s_wbeg[w] & 0x7FFFFFFF, s1 = s_wbeg[w + 1] & 0x7FFFFFFF;
+                for (int sg = s0; sg < s1; ++sg) {
+                    const PopSeg seg = s_segs[sg];
+#pragma unroll
+                    for (int j = 0; j < CB; ++j)
+#pragma unroll
+                        for (int i = 0; i < CA; ++i) s[j][i] += (int64_t)((uint64_t)__popc(f[k][i] & tt[k][j] & seg.mask) * (uint64_t)seg.V);
+                }
+            } else {
+#pragma unroll
+                for (int q2 = 0; q2 < KS; ++q2)
+#pragma unroll
+                    for (int j = 0; j < CB; ++j)
+#pragma unroll
+                        for (int i = 0; i < CA; ++i) s[j][i] += (int64_t)((uint64_t)__popc(f[k][i] & tt[k][j] & smask[k][q2]) * (uint64_t)sV[k][q2]);
+            }
+        }
+        for (int w = lane + 64 * KW; w < P.nwords; w += 64) {   // longer rows (more than 6144 sequences): the rest through the table
+            uint32_t f2[CA], t2[CB];
+#pragma unroll
+            for (int i = 0; i < CA; ++i) f2[i] = fr[i][w];
+#pragma unroll
+            for (int j = 0; j < CB; ++j) t2[j] = tr[j][w];
+            const int s0 = s_wbeg[w] & 0x7FFFFFFF, s1 = s_wbeg[w + 1] & 0x7FFFFFFF;
             for (int sg = s0; sg < s1; ++sg) {
-                const PopSeg seg = P.segs[sg];
+                const PopSeg seg = s_segs[sg];
 #pragma unroll
                 for (int j = 0; j < CB; ++j)
 #pragma unroll
-                    for (int i = 0; i < CA; ++i) s[j][i] += (int64_t)((uint64_t)__popc(f[i] & tt[j] & seg.mask) * (uint64_t)seg.V);
+                    for (int i = 0; i < CA; ++i) s[j][i] += (int64_t)((uint64_t)__popc(f2[i] & t2[j] & seg.mask) * (uint64_t)seg.V);
             }
         }
 #pragma unroll
@@ -572,14 +415,27 @@ __device__ __forceinline__ void pair_sums_body(const PairArgs &P, int path) {
     }
 }
 
-// all five lists in one launch: blockIdx.z = path
+// the four straight-line lists in one launch (blockIdx.z = path), the predicated one (16 sums per pair: many more registers)
+// in another.  The segment tables are staged in LDS once per workgroup.
+template <bool GEN>
 __global__ __launch_bounds__(256) void k_pair_sums(PairArgs P) {
-    switch (blockIdx.z) {
-        case 0: pair_sums_body<1, 1>(P, 0); break;
-        case 1: pair_sums_body<2, 1>(P, 1); break;
-        case 2: pair_sums_body<1, 2>(P, 2); break;
-        case 3: pair_sums_body<2, 2>(P, 3); break;
-        default: pair_sums_body<4, 4>(P, 4); break;
+    extern __shared__ __attribute__((aligned(16))) uint8_t pop_smem[];
+    int32_t *s_wbeg = reinterpret_cast<int32_t *>(pop_smem);
+    PopSeg *s_segs = reinterpret_cast<PopSeg *>(pop_smem + (((size_t)P.nwords + 4) * 4 + 15) / 16 * 16);
+    const int path = GEN ? 4 : (int)blockIdx.z;
+    if (blockIdx.x * 4u >= P.A.pl_n[path * PAIR_SHARDS + (int)blockIdx.y]) return;   // nothing for this workgroup
+    for (int i = threadIdx.x; i < P.nwords + 1; i += 256) s_wbeg[i] = P.wbeg[i];
+    for (int i = threadIdx.x; i < P.nseg; i += 256) s_segs[i] = P.segs[i];
+    __syncthreads();
+    if constexpr (GEN) {
+        pair_sums_body<4, 4>(P, 4, s_wbeg, s_segs);
+    } else {
+        switch (path) {
+            case 0: pair_sums_body<1, 1>(P, 0, s_wbeg, s_segs); break;
+            case 1: pair_sums_body<2, 1>(P, 1, s_wbeg, s_segs); break;
+            case 2: pair_sums_body<1, 2>(P, 2, s_wbeg, s_segs); break;
+            default: pair_sums_body<2, 2>(P, 3, s_wbeg, s_segs); break;
+        }
     }
 }
 
@@ -591,10 +447,9 @@ __device__ __forceinline__ void pair_mi_body(const PairArgs &P, int path) {
     unsigned int n = A.pl_n[sub];
     n = n > A.pl_cap ? A.pl_cap : n;
     const bool square = A.nf == A.nt;
-    const uint64_t *list = A.pl_pairs + (int64_t)sub * A.pl_cap;
+    const PairEnt *list = A.pl_pairs + (int64_t)sub * A.pl_cap;
     for (unsigned int idx = blockIdx.x * 256u + threadIdx.x; idx < n; idx += gridDim.x * 256u) {
-        const uint64_t e = list[idx];
-        const uint32_t t = (uint32_t)(e >> 32), q = (uint32_t)e;
+        const uint32_t t = list[idx].t, q = list[idx].q;
         const RowPack &RP = A.rowpack[t];
         if (RP.a_loc < 0) continue;
         const RowSide R = RP.R;
@@ -628,6 +483,7 @@ int launch_pairs_exact(ldw_ctx *c, const EpiArgs &A, unsigned long long *ghist, 
     P.Mbits = c->Mbits.as<uint64_t>();
     P.KW = c->KW;
     P.nwords = (int)(c->KW * 2);
+    P.nseg = c->n_pop_segs;
     P.segs = c->pop_segs.as<PopSeg>();
     P.wbeg = c->pop_wbeg.as<int32_t>();
     P.row0 = c->row0.as<int32_t>();
@@ -636,33 +492,11 @@ int launch_pairs_exact(ldw_ctx *c, const EpiArgs &A, unsigned long long *ghist, 
     P.A = A;
     P.ghist = ghist;
     // 1024 waves per list stride over its pairs (one wave per pair), then one lane per pair for the fp64 value
-    hipLaunchKernelGGL(k_pair_sums, dim3(256, PAIR_SHARDS, PAIR_PATHS), dim3(256), 0, st, P);
+    const size_t lds = (((size_t)P.nwords + 4) * 4 + 15) / 16 * 16 + (size_t)P.nseg * sizeof(PopSeg);
+    LDW_REQUIRE(lds <= 65536, LDW_ERR_ARG, "launch_pairs_exact: %d weight segments do not fit in LDS", P.nseg);
+    hipLaunchKernelGGL(k_pair_sums<false>, dim3(256, PAIR_SHARDS, 4), dim3(256), lds, st, P);
+    hipLaunchKernelGGL(k_pair_sums<true>, dim3(256, PAIR_SHARDS, 1), dim3(256), lds, st, P);
     hipLaunchKernelGGL(k_pair_mi, dim3(16, PAIR_SHARDS, PAIR_PATHS), dim3(256), 0, st, P);
-    LDW_HIP(hipGetLastError());
-    return LDW_OK;
-}
-
-int launch_units_pop(ldw_ctx *c, const PopArgs &P, int nf_tiles, const int n_tiles_cf[3], hipStream_t st) {
-    LDW_REQUIRE(nf_tiles > 0, LDW_ERR_ARG, "launch_units_pop: no from-tiles");
-    // 32 workgroups of 4 waves stride over a tile's batches (most tiles list a few hundred units per class, the short-range
-    // band of a diagonal block a few thousand; workgroups without a batch leave at once)
-    const dim3 grid((unsigned)nf_tiles, 32), block(256);
-    static const int dbg = [] { const char *e = getenv("LDW_POP_DEBUG"); return e ? atoi(e) : 0; }();
-    const_cast<PopArgs &>(P).debug = dbg;
-    const size_t lds = (((size_t)P.M2 * 4 + 4) * 4 + 15) / 16 * 16 + (size_t)P.nseg * sizeof(PopSeg);
-    LDW_REQUIRE(lds <= 65536, LDW_ERR_ARG, "launch_units_pop: %d segments do not fit in LDS", P.nseg);
-#define LDW_POP(CFv, CTv, kf, kt)                                                                      \
-    if (n_tiles_cf[kf] > 0 && P.A.lo.n_lc[kt] > 0) hipLaunchKernelGGL((k_units_pop<CFv, CTv>), grid, block, lds, st, P);
-    LDW_POP(1, 1, 0, 0)
-    LDW_POP(2, 1, 1, 0)
-    LDW_POP(1, 2, 0, 1)
-    LDW_POP(2, 2, 1, 1)
-    LDW_POP(4, 1, 2, 0)
-    LDW_POP(4, 2, 2, 1)
-    LDW_POP(1, 4, 0, 2)
-    LDW_POP(2, 4, 1, 2)
-    LDW_POP(4, 4, 2, 2)
-#undef LDW_POP
     LDW_HIP(hipGetLastError());
     return LDW_OK;
 }

@@ -128,7 +128,7 @@ struct EmitArgs {
     // approximate-GEMM path (ldw_apx.h): the joint sums the screen reads are int32 sums of the approximate weights
     // V' = a b 2^e in units of 2^e_last, each within a relative apx_delta of the exact sum plus a few truncated units
     int apx;                             // 1: G is int32 [RTpad][RFpad]
-    int apx_EG;                          // exponent transitions of the K loop: a GEMM entry lost < apx_EG units
+    float apx_EG;                        // units of 2^e_last a GEMM entry can have lost at the exponent transitions of the K loop
     float apx_dfac;                      // 1.01 delta / (1 - delta)
     float apx_s1;                        // 2^(e_last - F) (2 ln(neff + 12.5) + 3.1) / (1 - delta): what one lost unit can add to den * MI
 };
@@ -214,6 +214,7 @@ struct LoGeom {
 };
 __host__ __device__ __forceinline__ int lo_class(int nrows) { return nrows <= 1 ? 0 : (nrows == 2 ? 1 : 2); }
 
+struct PairEnt;
 struct EpiArgs {
     const int64_t *G;
     int RFpad, RTpad;
@@ -237,10 +238,15 @@ struct EpiArgs {
     // approximate-GEMM path: long-range candidates of units WITHOUT a short-range pair are listed pair by pair (one in a
     // thousand pairs passes the screen: evaluating the whole unit of 64 for it wastes 98 %): PAIR_PATHS x PAIR_SHARDS lists of
     // pl_cap entries (from-slot index << 32 | column slot), list = path * PAIR_SHARDS + (workgroup & 7)
-    uint64_t *pl_pairs;
+    struct PairEnt *pl_pairs;
     unsigned int *pl_n;
     uint32_t pl_cap;
+    const int32_t *row0;      // first bit row of every SNP (pair entries carry the rows, so that k_pair_sums starts loading at once)
     EmitArgs E;
+};
+// a listed candidate pair: from-slot index (64 * tile + lane), column slot, first bit row | row count << 29 of both SNPs
+struct PairEnt {
+    uint32_t t, q, ra, rb;
 };
 constexpr int PAIR_PATHS = 5;    // (NA, NB) = (1,1) (2,1) (1,2) (2,2) straight-line code, 4 = predicated
 constexpr int PAIR_SHARDS = 8;
@@ -516,7 +522,7 @@ __device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSi
     if (APX) {
         constexpr float lost = (float)((NA + 1) * (NB + 1)) * (float)(NA + NB + 1);
         constexpr float lost_g = (float)((NA + 1) * (NB + 1) * NA * NB);
-        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + (lost + lost_g * (float)A.E.apx_EG) * A.E.apx_s1;
+        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + (lost + lost_g * A.E.apx_EG) * A.E.apx_s1;
         return fmaf(acc, 0.6931471805599453f, extra) * __builtin_amdgcn_rcpf(den);
     }
     return acc * (0.6931471805599453f * __builtin_amdgcn_rcpf(den));
@@ -585,7 +591,7 @@ __device__ __forceinline__ float pair_screen_generic(const EpiArgs &A, const Row
         }
     }
     if (APX) {   // see full_cells_screen: up to 25 cells, each may have lost 9 + 16 apx_EG units
-        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + 25.0f * (9.0f + 16.0f * (float)A.E.apx_EG) * A.E.apx_s1;
+        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + 25.0f * (9.0f + 16.0f * A.E.apx_EG) * A.E.apx_s1;
         return fmaf(acc, 0.6931471805599453f, extra) * __builtin_amdgcn_rcpf(den);
     }
     return acc * (0.6931471805599453f * __builtin_amdgcn_rcpf(den));

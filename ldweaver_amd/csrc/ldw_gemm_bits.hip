@@ -37,10 +37,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bits_kernel(const uint64_t *__res
                                                               const int32_t *__restrict__ rowlist_f,
                                                               const int8_t *__restrict__ digits, int64_t Kpad,
                                                               int64_t *__restrict__ G, int RFpad, int lower_only,
-                                                              int shift_bits, int accumulate, int by0) {
+                                                              int shift_bits, int accumulate, int by0,
+                                                              const uint8_t *__restrict__ tile_mask) {
     const int bx = blockIdx.x, by = blockIdx.y + by0;  // bx: from-side tile of 64 rows, by: to-side tile of 128 rows (grid.y may
                                                        // cover a strip of them starting at by0: sharded Hamming weights)
     if (lower_only && bx * TILE_F4 + TILE_F4 - 1 < by * TILE) return;
+    // tile_mask[by][bx] == 0: nobody reads this tile (approximate path: only the tiles that hold a short-range pair are needed)
+    if (tile_mask && tile_mask[by * (RFpad / TILE_F4) + bx] == 0) return;
 
     __shared__ GemmSmem<J> S;
 #include "ldw_gemm_kloop.inc"
@@ -176,7 +179,8 @@ __global__ __launch_bounds__(256) void k_fill_rows_bits(const uint8_t *__restric
 }
 
 int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f,
-                     int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only, hipStream_t stream, int by0, int by1) {
+                     int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only, hipStream_t stream, int by0, int by1,
+                     const uint8_t *tile_mask) {
     if (!stream) stream = ctx->stream;
     const int64_t Kpad = KW * 64;
     LDW_REQUIRE(RTpad % TILE == 0 && RFpad % TILE == 0 && KW > 0 && KW % 2 == 0 && Kpad == KW * 64, LDW_ERR_ARG,
@@ -193,7 +197,7 @@ int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int3
 #define LDW_LAUNCH_B(JJ)                                                                                        \
     case JJ:                                                                                                    \
         hipLaunchKernelGGL(gemm_bits_kernel<JJ>, grid, block, 0, stream, Mbits, KW,                                 \
-                           rowlist_t, rowlist_f, dg, Kpad, G, RFpad, lower_only, shift, accum, by0);            \
+                           rowlist_t, rowlist_f, dg, Kpad, G, RFpad, lower_only, shift, accum, by0, tile_mask); \
         break;
         switch (J) {
             LDW_LAUNCH_B(1)

@@ -88,7 +88,8 @@ struct ldw_ctx {
     ldw::DevBuf dig_a, dig_b;          // uint8 [Npad]
     ldw::DevBuf apx_shift;             // int32 [KW / 2]: right shift of the accumulators before macro step m (128 positions)
     int apx_e_last = 0;                // accumulators end in units of 2^apx_e_last (fixed-point units of V)
-    int apx_transitions = 0;           // macro steps with a shift: each loses < 1 unit of a joint sum
+    int apx_transitions = 0;           // macro steps with a shift: each loses < 1 unit (of ITS exponent) of a joint sum
+    double apx_lost_units = 0;         // what that adds up to in units of 2^apx_e_last (< 2: the exponents ascend)
     double apx_delta = 0;              // max_p |V'_p - V_p| / V_p
     std::vector<int64_t> h_vapx;       // [Npad] by SEQUENCE: V'_s = a b 2^e (exact integer)
     ldw::DevBuf slot_papx;             // int64 [L][5] by slot: floor(marginal of V' / 2^apx_e_last)
@@ -96,11 +97,10 @@ struct ldw_ctx {
     int n_pop_segs = 0, n_classes = 0;
     ldw::DevBuf panel[2][2];           // [slot][from, to]: packed bit panels of a block's row lists, [KW/2][Rpad][2] u64
     ldw::DevBuf Gapx[2];               // int32 [RTpad][RFpad] approximate joint sums, one per pipeline slot
-    ldw::DevBuf cs;                    // int64 exact joint sums of the units that survive the exact re-screen
     ldw::DevBuf pair_sums;             // exact joint sums of the listed pairs (16 per pair)
     ldw::DevBuf pairs[2];              // per pipeline slot: pair lists of the approximate screen (counters + PAIR_PATHS x PAIR_SHARDS lists)
     ldw::DevBuf apx_units[2], apx_packs[2];   // per slot: per-(tile, class) unit lists + counters; per-block SNP constants
-    int64_t apx_blocks = 0, apx_units_listed = 0, apx_units_kept = 0;
+    int64_t apx_blocks = 0, apx_units_listed = 0, apx_pairs_listed = 0;
 
     // ---- per-SNP meta ----
     bool have_meta = false;
@@ -124,6 +124,7 @@ struct ldw_ctx {
     ldw::DevBuf counts;          // int32 [L][5] per-SNP state counts
     ldw::DevBuf pfix_state;      // int64 [L][5]: fixed-point marginal of each state (histogram engine)
     std::vector<int32_t> h_row0;
+    std::vector<uint32_t> h_slot_meta;
     std::vector<int32_t> h_counts;
 
     // ---- per-block workspaces ----
@@ -179,7 +180,8 @@ int launch_hist(ldw_ctx *ctx, const int32_t *idx_f, int nf, const int32_t *idx_t
 // G[t][f] = sum_k [row t has bit k][row f has bit k] * sum_j digits[j][k] 256^j over the bit matrix Mbits[rows][KW words]
 int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f,
                      int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only, hipStream_t stream = nullptr, int by0 = 0,
-                     int by1 = -1);   // by0..by1: strip of 128-row to-side tiles to compute (default: all)
+                     int by1 = -1,    // by0..by1: strip of 128-row to-side tiles to compute (default: all)
+                     const uint8_t *tile_mask = nullptr);   // [RTpad / 128][RFpad / 64]: 0 = skip the tile (default: all tiles)
 int fill_rows_bits(ldw_ctx *ctx, const int32_t *d_rowinfo, int64_t R);
 int prepare_apx_weights(ldw_ctx *ctx);   // ldw_apx.hip: dual digits, exponents, popcount segments from h_vfixed / h_seq_perm
 int check_gpu(ldw_ctx *ctx);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *_
 // iteration put U independent loads in flight per wave.
 // ------------------------------------------------------------------------------------------------
 // long-range candidates of one column of one wave -> pair list `path` (approximate-GEMM path)
-__device__ __forceinline__ void append_pairs(const EpiArgs &A, int path, unsigned long long m, bool mine, uint32_t t, uint32_t q) {
+__device__ __forceinline__ void append_pairs(const EpiArgs &A, int path, unsigned long long m, bool mine, uint32_t t, uint32_t q, int sa, int sb) {
     const int lane = threadIdx.x & 63;
     const int sub = path * PAIR_SHARDS + (int)(blockIdx.x & (PAIR_SHARDS - 1));
     unsigned int base = 0;
@@ -84,7 +84,15 @@ __device__ __forceinline__ void append_pairs(const EpiArgs &A, int path, unsigne
     base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
     if (mine) {
         const unsigned int pos = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-        if (pos < A.pl_cap) A.pl_pairs[(int64_t)sub * A.pl_cap + pos] = ((uint64_t)t << 32) | (uint64_t)q;   // overflow: k_pick_bucket sees the counter
+        if (pos < A.pl_cap) {   // overflow: k_pick_bucket sees the counter
+            const int32_t r0a = A.row0[sa], r0b = A.row0[sb];
+            PairEnt e;
+            e.t = t;
+            e.q = q;
+            e.ra = (uint32_t)r0a | ((uint32_t)(A.row0[sa + 1] - r0a) << 29);
+            e.rb = (uint32_t)r0b | ((uint32_t)(A.row0[sb + 1] - r0b) << 29);
+            A.pl_pairs[(int64_t)sub * A.pl_cap + pos] = e;
+        }
     }
 }
 
@@ -112,7 +120,7 @@ __device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowS
                 bits |= 1u << u;
             } else {
                 const unsigned long long m = __ballot(need_lr);
-                if (m != 0ull) append_pairs(A, (NA - 1) + 2 * (NB - 1), m, need_lr, (uint32_t)(blockIdx.x * 64 + (threadIdx.x & 63)), (uint32_t)(q0 + u));
+                if (m != 0ull) append_pairs(A, (NA - 1) + 2 * (NB - 1), m, need_lr, (uint32_t)(blockIdx.x * 64 + (threadIdx.x & 63)), (uint32_t)(q0 + u), R.sa, M.sb);
             }
         } else {
             const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                                                             int64_t list_stride) {
     __shared__ ColMeta cm[EPI_COLS];
     const bool square = A.nf == A.nt;
-    const bool mixed = A.lo.on != 0;
+    const bool mixed = A.lo.on != 0 || APX;   // cells derived from the marginals of the weights the block-wide sums were taken with
     stage_cols(A, perm_t, square, cm, mixed);
     __syncthreads();
     RowSide R;
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(256) void k_mi_screen_generic(EpiArgs A, const int3
                                                            int64_t list_stride, int tile0, int q0) {
     __shared__ ColMeta cm[GEN_COLS];
     const bool square = A.nf == A.nt;
-    const bool mixed = A.lo.on != 0;
+    const bool mixed = A.lo.on != 0 || APX;
     const int tile = tile0 + (int)blockIdx.x, qb = q0 + (int)blockIdx.y * GEN_COLS;
     if (threadIdx.x < GEN_COLS) {
         const int q = qb + (int)threadIdx.x;
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(256) void k_mi_screen_generic(EpiArgs A, const int3
                 wanted |= 1u << it;
             } else {
                 const unsigned long long m = __ballot(need_lr);
-                if (m != 0ull) append_pairs(A, 4, m, need_lr, (uint32_t)(tile * 64 + (threadIdx.x & 63)), (uint32_t)(q_base + it));
+                if (m != 0ull) append_pairs(A, 4, m, need_lr, (uint32_t)(tile * 64 + (threadIdx.x & 63)), (uint32_t)(q_base + it), R.sa, M.sb);
             }
         } else {
             const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
@@ -458,75 +466,16 @@ __global__ __launch_bounds__(256) void k_mi_units(EpiArgs A, const int32_t *__re
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_mi_units_tl: the same fp64 evaluation for the approximate-GEMM path, straight off the per-(from-tile, to-class) lists:
-// k_units_pop has left its verdict in every entry (ldw_apx.h) and the exact joint sums of unit k of list (tile, lc) at the
-// slot of its list position.  Workgroup = (tile, lc, z); its 4 waves stride over the list.  FAST: lists whose from-tile and
-// to-class take the straight-line code, entries without the GENERIC flag; the other instance takes the rest.
-// ------------------------------------------------------------------------------------------------
-template <bool FAST>
-__global__ __launch_bounds__(256) void k_mi_units_tl(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
-                                                     const int64_t *__restrict__ cs, const int64_t *__restrict__ cs_base,
-                                                     unsigned long long *__restrict__ ghist, unsigned long long *__restrict__ n_kept) {
-    const int tile = blockIdx.x, lc = blockIdx.y;
-    const unsigned int cnt = A.lo.cnt[tile * 3 + lc];
-    if (blockIdx.z * 4u >= cnt) return;
-    const int cmax = A.lo.cmax_f[tile];
-    const bool fast_list = cmax <= 2 && lc <= 1;
-    if (FAST && !fast_list) return;
-    const bool square = A.nf == A.nt;
-    RowSide R;
-    int a_loc, na0;
-    const bool a_ok = load_row_side(A, perm_f, square, tile, R, a_loc);
-    const int na_max = (__ballot(R.na > 2) != 0ull) ? 4 : ((__ballot(R.na > 1) != 0ull) ? 2 : 1);
-    const bool wave_full = wave_is_full(R, a_ok, na0);
-    const int64_t ustride = 64 * (int64_t)cmax << lc;
-    const int64_t *csl = cs + cs_base[tile * 3 + lc] + (threadIdx.x & 63);
-    const uint32_t *tl = A.lo.tl + (int64_t)tile * A.nt + A.lo.uoff[lc];
-    unsigned int kept = 0;
-    for (unsigned int k = blockIdx.z * 4u + (threadIdx.x >> 6); k < cnt; k += gridDim.z * 4u) {
-        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tl[k]);
-        if (e & UNIT_TL_DROPPED) continue;
-        if (FAST == ((e & UNIT_TL_GENERIC) != 0)) continue;   // the other instance's unit
-        ++kept;
-        const bool dismissed = (e & UNIT_TL_DISMISSED) != 0;
-        const int q = (int)(e & UNIT_TL_Q);
-        ColMeta M;
-        load_col(A, perm_t, square, q, M);
-        const uint32_t mbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.mb);
-        const int b_loc = M.bl;
-        if (!a_ok) continue;
-        if (A.E.lower_only && a_loc <= b_loc) continue;
-        const GAcc Ga = gacc_plain(csl + (int64_t)k * ustride, 64, 64 * (int64_t)cmax);
-        double mi;
-        if (FAST) {
-            const int nb = (int)(mbu & 7);
-            if (na0 == 1) mi = nb == 1 ? pair_mi_full<1, 1>(A, R, M, a_loc, b_loc, square, Ga) : pair_mi_full<1, 2>(A, R, M, a_loc, b_loc, square, Ga);
-            else mi = nb == 1 ? pair_mi_full<2, 1>(A, R, M, a_loc, b_loc, square, Ga) : pair_mi_full<2, 2>(A, R, M, a_loc, b_loc, square, Ga);
-        } else {
-            mi = unit_pair_mi(A, R, M, a_loc, b_loc, square, wave_full && col_is_fast(mbu), na0, na_max, (int)(mbu & 7), Ga);
-        }
-        if (dismissed) {   // verify mode: a pair of a dismissed unit that would have been emitted was lost by a screen
-            if (would_emit(A.E, M.ci, a_loc, b_loc, mi)) atomicAdd(A.E.scr_viol, 1ull);
-            continue;
-        }
-        emit_pair_spec(A.E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, ghist);
-    }
-    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(n_kept, (unsigned long long)kept);   // diagnostics
-}
-
-// totals of the approximate path's unit lists (diagnostics: ldw_ctx_counters2)
-__global__ void k_apx_stats(const unsigned int *__restrict__ cnt, int n_cnt, unsigned long long *__restrict__ acc) {
-    __shared__ unsigned long long part[256];
-    unsigned long long s = 0;
-    for (int i = threadIdx.x; i < n_cnt; i += 256) s += cnt[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int i = 0; i < 256; ++i) t += part[i];
-        acc[0] += t;
-    }
+// totals of the approximate path's lists (diagnostics: ldw_ctx_counters2): units listed (they hold a short-range pair),
+// long-range candidate pairs listed
+__global__ void k_apx_stats(const unsigned int *__restrict__ n_units, const unsigned int *__restrict__ pl_n, unsigned int pl_cap,
+                            unsigned long long *__restrict__ acc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    acc[0] += (unsigned long long)n_units[0] + n_units[1];
+    unsigned long long k = 0;
+    if (pl_n)
+        for (int i = 0; i < PAIR_PATHS * PAIR_SHARDS; ++i) k += pl_n[i] > pl_cap ? pl_cap : pl_n[i];
+    acc[1] += k;
 }
 
 // the same emission for an MI block produced elsewhere (LDW_ENGINE_HIST)
@@ -968,7 +917,7 @@ struct DevPtrs {
     const int32_t *cmax_f;      // mixed-precision path: per from-tile widest row-slot class, offsets of the low-limb blocks
     const int64_t *tile_base;
     const int32_t *tf_list;     // (tile, fs) pairs of the gathered GEMM's grid
-    const int64_t *cs_base;     // approximate path: [tiles * 3] start of the exact sums of list (tile, lc)
+    const uint8_t *band_mask;   // approximate path: [RTpad / 128][RFpad / 64] exact-GEMM tiles that hold a short-range pair
     int nf_tiles;               // tiles of 64 in the padded from-side order perm
     int gen_t0, gen_q0;         // first from-tile / column slot of the SNPs with >= 3 minor states or none (k_mi_screen_generic)
 };
@@ -979,7 +928,7 @@ struct LoHost {
     int32_t RTlo = 0, ntiles = 0, n_tf = 0;
     int64_t glo_total = 0;
     int32_t n_tiles_cf[3] = {0, 0, 0};   // from-tiles whose widest row-slot class is 1, 2, 4
-    int64_t cs_total = 0;                // int64 entries of the approximate path's exact-sum slots
+    int band_full = 0;                   // the exact GEMM has to cover every tile (a SNP with unflagged slots: its units are not screened)
     int apx = 0, slot = 0, diag = 0;     // approximate-GEMM path (ldw_apx.h) instead of the high-limb GEMM + gathered low limbs
 };
 
@@ -1008,6 +957,7 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
     A.pl_pairs = nullptr;
     A.pl_n = nullptr;
     A.pl_cap = 0;
+    A.row0 = c->row0.as<int32_t>();
     A.E = E;
     memset(&A.lo, 0, sizeof(A.lo));
 }
@@ -1176,11 +1126,13 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
 // the tail of block b:
 //   phase 1 (stream gs): pack the bit panels of both row lists, the dual-digit int8 pass into the int32 block (not for an
 //            SR-only pass: it screens without MI), per-block SNP constants, the approximate screens -> unit lists (units
-//            with a short-range pair) and pair lists (the other long-range candidates);
-//   phase 2 (main stream): exact sums + fp64 MI + emission of the listed pairs (k_pairs_exact) and of the listed units
-//            (k_units_pop -> k_mi_units_tl).
+//            that hold a short-range pair) and pair lists (the other long-range candidates), and the EXACT 5-limb GEMM of
+//            the tiles that hold a short-range pair (band_mask: the short-range band is dense, a fifth of a diagonal block);
+//   phase 2 (main stream): exact sums + fp64 MI + emission of the listed pairs (k_pair_sums, k_pair_mi) and the fp64
+//            evaluation of the listed units from the exact tiles (k_mi_units).
 // Everything phase 1 writes is per pipeline slot; both phases derive the same pointers from the slot's buffers.
-// Events: ev[0] / ev[1] around the packing + GEMM, ev[5] after the screens (gs); ev[4] / ev[2] around phase 2.
+// Events: ev[0] / ev[1] around the packing + approximate GEMM, ev[5] after the screens and the band GEMM (gs); ev[4] / ev[2]
+// around phase 2.
 // ------------------------------------------------------------------------------------------------
 int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E, hipEvent_t *ev, int phase,
                      hipStream_t gs, unsigned long long *ghist, const LoHost *lo_h) {
@@ -1189,64 +1141,54 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     E.MI = nullptr;
     dim3 egrid((unsigned)(D.nf_tiles > 0 ? D.nf_tiles : (nf + 63) / 64), (unsigned)((nt + EPI_COLS - 1) / EPI_COLS));
     LDW_REQUIRE(egrid.y <= 65535u, LDW_ERR_ARG, "nt too large for the epilogue grid");
-    LDW_REQUIRE(lo_h->ntiles == (int)egrid.x, LDW_ERR_STATE, "unit-list geometry does not match the epilogue grid");
     LDW_REQUIRE(E.scr_mode && E.cols && !E.write_dense, LDW_ERR_STATE, "the approximate path needs the screen");
     const size_t n_units_max = (size_t)egrid.x * (size_t)nt;
-    const size_t o_cnt = 64, o_tl = o_cnt + ((size_t)egrid.x * 12 + 63) / 64 * 64;
+    const size_t o_flat = 64;
+    const int64_t list_stride = (int64_t)n_units_max;   // two flat lists: straight-line units, the others
     const int nf_slots = (int)egrid.x * 64;
     const size_t o_cph = ((size_t)nt * sizeof(ColMeta) + 255) / 256 * 256, o_rp = 2 * o_cph;
     const size_t o_rph = o_rp + ((size_t)nf_slots * sizeof(RowPack) + 255) / 256 * 256;
     const size_t o_rf = o_rph + ((size_t)nf_slots * sizeof(RowPack) + 255) / 256 * 256, o_rt = o_rf + ((size_t)nf * 4 + 255) / 256 * 256;
     const size_t o_pairs = 256;
     const bool use_pairs = E.scr_mode == 1 && E.do_lr;   // verify mode keeps whole units: it must see the dismissed ones
+    // units are evaluated from EXACT sums: the 5-limb GEMM of the tiles they live in (all tiles when any unit can be listed)
+    const bool need_exact = E.any_sr || !use_pairs || lo_h->band_full;
+    const uint8_t *band = (use_pairs && !lo_h->band_full) ? D.band_mask : nullptr;
+    ldw::DevBuf &Gx = s ? c->G2 : c->G;
     if (phase == 1) {
         if (int rc = c->panel[s][0].reserve((size_t)RFpad * c->KW * 8)) return rc;
         if (!lo_h->diag)
             if (int rc = c->panel[s][1].reserve((size_t)RTpad * c->KW * 8)) return rc;
         if (E.do_lr)
             if (int rc = c->Gapx[s].reserve((size_t)RFpad * RTpad * 4)) return rc;
-        if (int rc = c->apx_units[s].reserve(o_tl + n_units_max * 4 + 64)) return rc;
+        if (int rc = c->apx_units[s].reserve(o_flat + 2 * n_units_max * 8 + 64)) return rc;
         if (int rc = c->apx_packs[s].reserve(o_rt + (size_t)nt * 4 + 256)) return rc;
         if (use_pairs)
-            if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * PAIR_CAP * 8)) return rc;
+            if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * PAIR_CAP * sizeof(PairEnt))) return rc;
+        if (need_exact)
+            if (int rc = Gx.reserve((size_t)RFpad * RTpad * 8)) return rc;
     }
     EpiArgs A;
     fill_epi_args(c, D, nf, nt, RFpad, quirk, E, reinterpret_cast<const int64_t *>(c->Gapx[s].p), A);
-    A.RTpad = RTpad;
+    A.lo.slot_pfix_hi = c->slot_papx.as<int64_t>();   // the screen derives its cells from the marginals of the approximate weights
     char *ub = c->apx_units[s].as<char>();
-    {
-        LoGeom &lo = A.lo;
-        for (int k = 0; k < 3; ++k) {
-            lo.n_lc[k] = lo_h->n_lc[k];
-            lo.uoff[k] = lo_h->uoff[k];
-            lo.rowbase[k] = lo_h->rowbase[k];
-        }
-        lo.RTlo = lo_h->RTlo;
-        lo.ntiles = lo_h->ntiles;
-        lo.on = 1;
-        lo.cmax_f = D.cmax_f;
-        lo.tile_base = D.tile_base;
-        lo.cnt = reinterpret_cast<unsigned int *>(ub + o_cnt);
-        lo.tl = reinterpret_cast<uint32_t *>(ub + o_tl);
-        lo.glo = nullptr;
-        lo.slot_pfix_hi = c->slot_papx.as<int64_t>();   // the screen derives its cells from the marginals of the approximate weights
-        lo.hi_shift = 0;
-    }
+    unsigned int *n_units = reinterpret_cast<unsigned int *>(ub);
+    uint64_t *units = reinterpret_cast<uint64_t *>(ub + o_flat);
     char *pb = c->apx_packs[s].as<char>();
     ColMeta *cp = reinterpret_cast<ColMeta *>(pb), *cph = reinterpret_cast<ColMeta *>(pb + o_cph);
     RowPack *rp = reinterpret_cast<RowPack *>(pb + o_rp), *rph = reinterpret_cast<RowPack *>(pb + o_rph);
     float *rlf = reinterpret_cast<float *>(pb + o_rf), *rlt = reinterpret_cast<float *>(pb + o_rt);
     if (use_pairs) {
         A.pl_n = c->pairs[s].as<unsigned int>();
-        A.pl_pairs = reinterpret_cast<uint64_t *>(c->pairs[s].as<char>() + o_pairs);
+        A.pl_pairs = reinterpret_cast<PairEnt *>(c->pairs[s].as<char>() + o_pairs);
         A.pl_cap = (uint32_t)PAIR_CAP;
     }
     if (phase == 1) {
         LDW_HIP(hipEventRecord(ev[0], gs));
-        if (int rc = launch_pack_panel(c, D.rl_f, RFpad, c->panel[s][0].as<uint64_t>(), gs)) return rc;
-        if (!lo_h->diag)
-            if (int rc = launch_pack_panel(c, D.rl_t, RTpad, c->panel[s][1].as<uint64_t>(), gs)) return rc;
         if (E.do_lr) {
+            if (int rc = launch_pack_panel(c, D.rl_f, RFpad, c->panel[s][0].as<uint64_t>(), gs)) return rc;
+            if (!lo_h->diag)
+                if (int rc = launch_pack_panel(c, D.rl_t, RTpad, c->panel[s][1].as<uint64_t>(), gs)) return rc;
             ApxGemmArgs P;
             P.panel_f = c->panel[s][0].as<uint64_t>();
             P.panel_t = lo_h->diag ? P.panel_f : c->panel[s][1].as<uint64_t>();
@@ -1261,7 +1203,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             if (int rc = launch_gemm_apx(c, P, gs)) return rc;
         }
         LDW_HIP(hipEventRecord(ev[1], gs));
-        LDW_HIP(hipMemsetAsync(ub, 0, o_tl, gs));   // the per-(tile, class) unit counters
+        LDW_HIP(hipMemsetAsync(ub, 0, o_flat, gs));   // the unit counters
         if (use_pairs) LDW_HIP(hipMemsetAsync(c->pairs[s].p, 0, o_pairs, gs));
         const int nthr = std::max<int>((int)nt, nf_slots);
         hipLaunchKernelGGL(k_build_packs, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, gs, A, D.perm, D.perm_t, nf_slots, 1, cp, cph, rp, rph,
@@ -1276,9 +1218,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     A.rowpack_hi = rph;
     if (phase == 1) {
         const int rm = quirk == LDW_QUIRK_REFERENCE ? (nf == nt ? 1 : 2) : 0;
-        uint64_t *no_flat = nullptr;   // only the per-(tile, class) lists are read
-        unsigned int *no_cnt = nullptr;
-#define LDW_SCREEN(RMv) hipLaunchKernelGGL((k_mi_screen<RMv, true>), egrid, dim3(256), 0, gs, A, D.perm, D.perm_t, no_flat, no_cnt, (int64_t)0)
+#define LDW_SCREEN(RMv) hipLaunchKernelGGL((k_mi_screen<RMv, true>), egrid, dim3(256), 0, gs, A, D.perm, D.perm_t, units, n_units, list_stride)
         if (rm == 0) LDW_SCREEN(0); else if (rm == 1) LDW_SCREEN(1); else LDW_SCREEN(2);
 #undef LDW_SCREEN
         LDW_HIP(hipGetLastError());
@@ -1287,11 +1227,15 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         const int q0 = std::min<int>(A.gen_q0, (int)nt) / GEN_COLS * GEN_COLS;
         if (gt0 < (int)egrid.x)
             hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3(egrid.x - gt0, (unsigned)((nt + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, gs, A, D.perm,
-                               D.perm_t, no_flat, no_cnt, (int64_t)0, gt0, 0);
+                               D.perm_t, units, n_units, list_stride, gt0, 0);
         if (gt0 > 0 && A.gen_q0 < (int)nt)
             hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3(gt0, (unsigned)((nt - q0 + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, gs, A, D.perm, D.perm_t,
-                               no_flat, no_cnt, (int64_t)0, 0, q0);
+                               units, n_units, list_stride, 0, q0);
         LDW_HIP(hipGetLastError());
+        if (need_exact)
+            if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, Gx.as<int64_t>(), c->nlimbs, c->digits.as<int8_t>(),
+                                          E.lower_only, gs, 0, -1, band))
+                return rc;
         LDW_HIP(hipEventRecord(ev[5], gs));
         return LDW_OK;
     }
@@ -1301,39 +1245,24 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         if (int rc = c->pair_sums.reserve((size_t)PAIR_PATHS * PAIR_SHARDS * PAIR_CAP * 16 * 8)) return rc;
         if (int rc = launch_pairs_exact(c, A, ghist, c->pair_sums.as<int64_t>(), c->stream)) return rc;
     }
-    unsigned long long *acc = A.E.scr_viol + 1;   // [0] units listed, [1] units kept
-    if (A.E.any_sr || !use_pairs) {   // without a short-range pair in the block (and outside verify mode) no unit is listed at all
-        PopArgs P;
-        memset(&P, 0, sizeof(P));
-        P.Mbits = c->Mbits.as<uint64_t>();
-        P.KW = c->KW;
-        P.panel_f = c->panel[s][0].as<uint64_t>();
-        P.RFpad = RFpad;
-        P.M2 = (int)(c->KW / 2);
-        P.segs = c->pop_segs.as<PopSeg>();
-        P.wbeg = c->pop_wbeg.as<int32_t>();
-        P.perm_t = D.perm_t;
-        P.idx_t = D.idx_t;
-        P.row0 = c->row0.as<int32_t>();
-        P.cmax_f = D.cmax_f;
-        P.zero_row = (int32_t)c->R;
-        P.nseg = c->n_pop_segs;
-        {   // what the screen of the limb paths uses for the exact sums: their top 31 bits
-            int bits = 0;
-            while (bits < 62 && (c->total_fixed >> bits) != 0) ++bits;
-            P.x_shift = bits > 31 ? bits - 31 : 0;
-            P.x_scale = (float)std::ldexp(1.0, P.x_shift - c->frac_bits);
-        }
-        P.A = A;
-        if (int rc = c->cs.reserve((size_t)lo_h->cs_total * 8 + 64)) return rc;
-        P.cs = c->cs.as<int64_t>();
-        P.cs_base = D.cs_base;
-        if (int rc = launch_units_pop(c, P, (int)egrid.x, lo_h->n_tiles_cf, c->stream)) return rc;
-        hipLaunchKernelGGL(k_mi_units_tl<true>, dim3(egrid.x, 2, 16), dim3(256), 0, c->stream, A, D.perm, D.perm_t, P.cs, D.cs_base, ghist, acc + 1);
-        hipLaunchKernelGGL(k_mi_units_tl<false>, dim3(egrid.x, 3, 16), dim3(256), 0, c->stream, A, D.perm, D.perm_t, P.cs, D.cs_base, ghist, acc + 1);
-        hipLaunchKernelGGL(k_apx_stats, dim3(1), dim3(256), 0, c->stream, A.lo.cnt, (int)egrid.x * 3, acc);
-        LDW_HIP(hipGetLastError());
+    if (need_exact) {   // the listed units, from the exact tiles
+        EpiArgs Ax = A;
+        Ax.G = Gx.as<int64_t>();
+        Ax.E.apx = 0;
+        Ax.pl_pairs = nullptr;
+        UnitLists UL;
+        memset(&UL, 0, sizeof(UL));
+        UL.units[0] = units;
+        UL.n[0] = n_units;
+        hipLaunchKernelGGL(k_mi_units<true>, dim3(2048, 1), dim3(256), 0, c->stream, Ax, D.perm, D.perm_t, UL, ghist);
+        UnitLists UG;
+        memset(&UG, 0, sizeof(UG));
+        UG.units[0] = units + list_stride;
+        UG.n[0] = n_units + 1;
+        hipLaunchKernelGGL(k_mi_units<false>, dim3(512, 1), dim3(256), 0, c->stream, Ax, D.perm, D.perm_t, UG, ghist);
     }
+    hipLaunchKernelGGL(k_apx_stats, dim3(1), dim3(64), 0, c->stream, n_units, A.pl_n, A.pl_cap, A.E.scr_viol + 1);
+    LDW_HIP(hipGetLastError());
     LDW_HIP(hipEventRecord(ev[2], c->stream));
     return LDW_OK;
 }
@@ -1441,7 +1370,7 @@ struct HostBlock {
     bool apx = false;          // approximate GEMM + exact popcount sums of the listed units (ldw_apx.h); implies the lo geometry
     int guess = -1;            // bucket guess the block was submitted with
     LoHost lo;
-    size_t o_cmax = 0, o_tbase = 0, o_tf = 0, o_csb = 0;
+    size_t o_cmax = 0, o_tbase = 0, o_tf = 0, o_band = 0;
     size_t o_idx_f = 0, o_idx_t = 0, o_rl_f = 0, o_rl_t = 0, o_lrow_f = 0, o_lrow_t = 0, o_perm = 0, o_perm_t = 0, o_cols = 0, o_pos_f = 0,
            o_pos_t = 0, o_cls_f = 0, o_cls_t = 0, total = 0;
     DevPtrs D{};
@@ -1547,21 +1476,69 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
             tf.push_back(fs);
         }
     hb.lo.n_tf = (int32_t)(tf.size() / 2);
-    // exact-sum slots of the approximate path: list (tile, lc) holds up to n_lc[lc] units of 64 * cmax[tile] * (1 << lc) sums
-    std::vector<int64_t> csb(cmax.size() * 3, 0);
+    // approximate path: tiles of the exact GEMM (128 to-side x 64 from-side rows) that hold a short-range pair.  POS ascends along
+    // both lists and the row lists keep the list order within a slot-count class, so the partners of a to-side SNP are a
+    // contiguous row range per class
+    std::vector<uint8_t> band((size_t)(hb.RTpad / TILE) * (hb.RFpad / 64), 0);
     {
-        int64_t off = 0;
-        for (size_t t = 0; t < cmax.size(); ++t)
-            for (int lc = 0; lc < 3; ++lc) {
-                csb[t * 3 + lc] = off;
-                off += (int64_t)hb.lo.n_lc[lc] * 64 * cmax[t] * (1 << lc);
+        const int ntx = hb.RFpad / 64;
+        auto cls_of = [&](int32_t snp) { const int nr = c->h_row0[snp + 1] - c->h_row0[snp]; return nr <= 1 ? 0 : (nr == 2 ? 1 : 2); };
+        std::vector<int32_t> pre[3];
+        int32_t base[3] = {0, 0, 0};
+        for (int k = 0; k < 3; ++k) pre[k].assign((size_t)nf + 1, 0);
+        for (int64_t a = 0; a < nf; ++a) {
+            const int k = cls_of(from_idx[a]);
+            for (int q = 0; q < 3; ++q) pre[q][(size_t)a + 1] = pre[q][(size_t)a] + (q == k ? 1 : 0);
+            const uint32_t m = c->h_slot_meta[(size_t)from_idx[a]];
+            const int n = (int)(m & 7);
+            if ((n == 1 || n == 2) && (((m >> 3) & ((2u << n) - 1u)) != ((2u << n) - 1u))) hb.lo.band_full = 1;
+            if (n == 0) hb.lo.band_full = 1;   // SNPs without a row sit among the one-row SNPs in the row list but last in the tiles
+        }
+        for (int64_t b2 = 0; b2 < nt; ++b2) {
+            const uint32_t m = c->h_slot_meta[(size_t)to_idx[b2]];
+            const int n = (int)(m & 7);
+            if ((n == 1 || n == 2) && (((m >> 3) & ((2u << n) - 1u)) != ((2u << n) - 1u))) hb.lo.band_full = 1;
+        }
+        {   // first row of each class region of the from-side row list (build_side: classes 1, 2, 4 in this order, 32-row aligned)
+            int64_t rows = 0;
+            for (int k = 0; k < 3; ++k) {
+                base[k] = (int32_t)rows;
+                rows += (int64_t)pre[k][(size_t)nf] * (1 << k);
+                rows = (rows + 31) / 32 * 32;
             }
-        hb.lo.cs_total = off;
+        }
+        auto mark = [&](int64_t t0, int64_t t1, int64_t f0, int64_t f1) {
+            for (int64_t ty = t0 / TILE; ty <= (t1 - 1) / TILE; ++ty)
+                for (int64_t tx = f0 / 64; tx <= (f1 - 1) / 64; ++tx) band[(size_t)ty * ntx + tx] = 1;
+        };
+        if (hb.n_sr_blk > 0 && !hb.lo.band_full)
+            for (int64_t b2 = 0; b2 < nt; ++b2) {
+                const ColInfo &ci = cols[(size_t)b2];
+                const int64_t rb0 = ST.lrow[(size_t)b2], rb1 = rb0 + (1 << cls_of(to_idx[b2]));
+                for (int iv = 0; iv < 3; ++iv) {
+                    if (ci.e[iv] <= ci.s[iv]) continue;
+                    for (int k = 0; k < 3; ++k) {
+                        const int32_t n0 = pre[k][(size_t)ci.s[iv]], n1 = pre[k][(size_t)ci.e[iv]];
+                        if (n1 <= n0) continue;
+                        // a listed unit is evaluated whole: all 64 from-side SNPs of its epilogue tile (build_perm_tiles: 64 SNPs of
+                        // one class in list order = 64 << k consecutive rows), so the range grows to whole tiles; the tiles of the
+                        // SNPs with 3 and 4 rows are ordered differently from their rows: their whole class region is kept
+                        int64_t f0 = base[k] + (int64_t)(n0 / 64 * 64) * (1 << k), f1 = base[k] + (int64_t)((n1 + 63) / 64 * 64) * (1 << k);
+                        if (k == 2) {
+                            f0 = base[2];
+                            f1 = base[2] + (int64_t)pre[2][(size_t)nf] * 4;
+                        }
+                        if (f1 > hb.RFpad) f1 = hb.RFpad;
+                        mark(rb0, rb1, f0, f1);
+                        if (hb.diag) mark(f0, f1, rb0, rb1);   // a pair may be read in mirrored roles (g_entry)
+                    }
+                }
+            }
     }
     hb.o_cmax = o; o = al(o + cmax.size() * 4);
     hb.o_tbase = o; o = al(o + tbase.size() * 8);
     hb.o_tf = o; o = al(o + tf.size() * 4);
-    hb.o_csb = o; o = al(o + csb.size() * 8);
+    hb.o_band = o; o = al(o + band.size());
     hb.total = o;
     if (c->pin_cap[slot] < o) {
         if (c->pin[slot]) LDW_HIP(hipHostFree(c->pin[slot]));
@@ -1587,7 +1564,7 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     memcpy(b + hb.o_cmax, cmax.data(), cmax.size() * 4);
     memcpy(b + hb.o_tbase, tbase.data(), tbase.size() * 8);
     memcpy(b + hb.o_tf, tf.data(), tf.size() * 4);
-    memcpy(b + hb.o_csb, csb.data(), csb.size() * 8);
+    memcpy(b + hb.o_band, band.data(), band.size());
     return LDW_OK;
 }
 
@@ -1659,7 +1636,7 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
         // relative error delta of the weights and the units lost to truncation (full_cells_screen<.., APX>)
         const double den = c->neff > 1.0 ? c->neff : 1.0;
         E.apx = 1;
-        E.apx_EG = c->apx_transitions;
+        E.apx_EG = (float)(c->apx_lost_units * 1.001);
         E.apx_dfac = (float)(1.01 * c->apx_delta / (1.0 - c->apx_delta));
         E.apx_s1 = (float)(std::ldexp(1.0, c->apx_e_last - c->frac_bits) * (2.0 * std::log(den + 12.5) + 3.1) / (1.0 - c->apx_delta) * 1.01);
         E.scr_shift = 0;
@@ -1701,7 +1678,7 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     auto B = [&](size_t off) { return reinterpret_cast<const uint8_t *>(d + off); };
     hb.D = DevPtrs{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm), I(hb.o_perm_t),
                    I(hb.o_pos_f), I(hb.o_pos_t), B(hb.o_cls_f), B(hb.o_cls_t), I(hb.o_cmax),
-                   reinterpret_cast<const int64_t *>(d + hb.o_tbase), I(hb.o_tf), reinterpret_cast<const int64_t *>(d + hb.o_csb), hb.nf_tiles, hb.gen_t0,
+                   reinterpret_cast<const int64_t *>(d + hb.o_tbase), I(hb.o_tf), B(hb.o_band), hb.nf_tiles, hb.gen_t0,
                    hb.gen_q0};
     hb.submitted = true;
     if (c->engine != LDW_ENGINE_MFMA) return LDW_OK;
@@ -2079,7 +2056,7 @@ int ldw_links_end(ldw_ctx *c) {
     c->n_lr = h_lr;
     c->screen_violations += h_viol;
     c->apx_units_listed += h_apx[0];
-    c->apx_units_kept += h_apx[1];
+    c->apx_pairs_listed += h_apx[1];
     c->stats.resize((size_t)nb);
     for (int64_t b = 0; b < nb; ++b) {
         c->stats[b].n_lr_total = si[b * 3 + 0];

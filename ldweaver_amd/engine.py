@@ -55,7 +55,7 @@ class Engine:
         v = np.zeros(8, dtype=np.int64)
         L.check(L.lib().ldw_ctx_counters2(self._ctx, L.ptr(v)))
         return dict(spec_misses=int(v[0]), fused_blocks=int(v[1]), unfused_blocks=int(v[2]), screen_violations=int(v[3]),
-                    mixed_blocks=int(v[4]), apx_blocks=int(v[5]), apx_units_listed=int(v[6]), apx_units_kept=int(v[7]))
+                    mixed_blocks=int(v[4]), apx_blocks=int(v[5]), apx_units_listed=int(v[6]), apx_pairs_listed=int(v[7]))
 
     def set_overlap(self, on: bool):
         """GEMM of the next block beside the epilogue/selection of the current one (default on); off = exclusive stage times."""
