@@ -242,8 +242,17 @@ struct EpiArgs {
     unsigned int *pl_n;
     uint32_t pl_cap;
     const int32_t *row0;      // first bit row of every SNP (pair entries carry the rows, so that k_pair_sums starts loading at once)
+    // threshold table of the biallelic x biallelic pairs (k_build_tab11): entry [bin of the to-side minor marginal][bin of the
+    // from-side one] = (Lq, Hq): a joint sum n' with Lq < n' < Hq cannot reach tab_lo whatever the rest of the pair looks like
+    const int2 *tab11;
+    int tab_nb;               // bins per side (sqrt scale: bin = min(tab_nb - 1, floor(sqrt(p) tab_c)))
+    float tab_c;
     EmitArgs E;
 };
+__host__ __device__ __forceinline__ int tab_bin(float p, float c, int nb) {
+    const int b = (int)(sqrtf(p > 0.0f ? p : 0.0f) * c);
+    return b < nb - 1 ? b : nb - 1;
+}
 // a listed candidate pair: from-slot index (64 * tile + lane), column slot, first bit row | row count << 29 of both SNPs
 struct PairEnt {
     uint32_t t, q, ra, rb;
@@ -634,7 +643,7 @@ __device__ __forceinline__ void stage_cols(const EpiArgs &A, const int32_t *__re
                 m.pYf[j] = (float)m.pYd[j];
                 if (hi_cells) m.pb[j] = A.lo.slot_pfix_hi[(int64_t)m.sb * 5 + j];
             }
-            m.pad2 = 0;
+            m.pad2 = A.tab11 ? tab_bin(m.pYf[0], A.tab_c, A.tab_nb) : 0;
             if (A.E.cols) m.ci = A.E.cols[b_loc];
             cm[threadIdx.x] = m;
         }
@@ -662,7 +671,7 @@ __device__ __forceinline__ void load_col(const EpiArgs &A, const int32_t *__rest
         m.pYf[j] = (float)m.pYd[j];
         if (hi_cells) m.pb[j] = A.lo.slot_pfix_hi[(int64_t)m.sb * 5 + j];
     }
-    m.pad2 = 0;
+    m.pad2 = A.tab11 ? tab_bin(m.pYf[0], A.tab_c, A.tab_nb) : 0;   // bin of the minor-state marginal (threshold table)
     m.ci = A.E.cols[b_loc];
 }
 

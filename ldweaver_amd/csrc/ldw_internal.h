@@ -97,6 +97,11 @@ struct ldw_ctx {
     int n_pop_segs = 0, n_classes = 0;
     ldw::DevBuf panel[2][2];           // [slot][from, to]: packed bit panels of a block's row lists, [KW/2][Rpad][2] u64
     ldw::DevBuf Gapx[2];               // int32 [RTpad][RFpad] approximate joint sums, one per pipeline slot
+    ldw::DevBuf tab11;                 // threshold table of the biallelic pairs (k_build_tab11), int2 [nb][nb]
+    double tab11_lo = 0;               // MI level it was built for (0: none)
+    float tab11_c = 0;
+    int tab11_nb = 0;
+    bool tab11_on = true;              // LDW_NO_TAB11 switches the table off (A/B measurements)
     ldw::DevBuf pair_sums;             // exact joint sums of the listed pairs (16 per pair)
     ldw::DevBuf pairs[2];              // per pipeline slot: pair lists of the approximate screen (counters + PAIR_PATHS x PAIR_SHARDS lists)
     ldw::DevBuf apx_units[2], apx_packs[2];   // per slot: per-(tile, class) unit lists + counters; per-block SNP constants

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *_
         int a_loc;
         const bool ok = load_row_side_at(A, perm_f, square, i, P.R, a_loc, false);
         P.a_loc = ok ? a_loc : -1;
-        P.pad = 0;
+        P.pad = A.tab11 ? tab_bin(P.R.pXf[0], A.tab_c, A.tab_nb) : 0;   // bin of the minor-state marginal (threshold table)
         rp[i] = P;
         if (with_hi) {
 #pragma unroll
@@ -130,12 +130,119 @@ __device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowS
     return bits;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Threshold table of the biallelic x biallelic pairs (both SNPs: one indicator row, r = 2).  With the marginals fixed the
+// joint table has ONE free number, x = pxy of (minor, minor), and MI is convex in it with its minimum at independence: MI
+// reaches a level lo only for x <= L or x >= H.  L and H depend on the two minor marginals alone (RXY >= 1 with equality in the
+// intended mode, and MI falls as RXY grows: the table is built for RXY = 1), so they are tabulated once per weighting over
+// bins of the two marginals — conservatively: the largest L and the smallest H over the bin (sampled on a 3 x 3 grid, L and H
+// ascend with both marginals) — and shifted by everything the approximate sum n' may be off: H (1 - delta) - eta, L (1 + delta)
+// + eta, in units of the int32 block.  The screen then dismisses a pair with Lq < n' < Hq on two integer compares and runs the
+// 25-cell log evaluation only for the columns in which some lane fails that test (one pair in a few thousand does).
+// Every dismissal is still checked in verify mode (ldw_set_screen 2).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double mi11_exact(double x, double pa, double pb, double W, double den) {
+    const double A0 = pa + 1.0, A1 = W - pa + 1.0, B0 = pb + 1.0, B1 = W - pb + 1.0;
+    const double x01 = A0 - x, x10 = B0 - x, x11 = den - A0 - B0 + x;
+    if (!(x > 0.0 && x01 > 0.0 && x10 > 0.0 && x11 > 0.0)) return 1e30;
+    return (x * log(x * den / (A0 * B0)) + x01 * log(x01 * den / (A0 * B1)) + x10 * log(x10 * den / (A1 * B0)) + x11 * log(x11 * den / (A1 * B1))) / den;
+}
+
+__global__ __launch_bounds__(256) void k_build_tab11(double W, double lo, double delta, double eta, double sprime, int NB, float cbin, int2 *__restrict__ tab) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= NB * NB) return;
+    const int jb = id / NB, ia = id % NB;   // [bin of the to side][bin of the from side]
+    const double den = W + 2.0;
+    double Lmax = -1e30, Hmin = 1e30;
+    for (int sa = 0; sa < 3; ++sa)
+        for (int sb = 0; sb < 3; ++sb) {
+            // bin k covers sqrt(p) * cbin in [k, k + 1); the last bin is open-ended: sample it up to the total weight
+            const double ua = (ia + 0.5 * sa) / cbin, ub = (jb + 0.5 * sb) / cbin;
+            double pa = ua * ua, pb = ub * ub;
+            if (ia == NB - 1 && sa > 0) pa = sa == 1 ? 0.5 * (pa + W) : W;
+            if (jb == NB - 1 && sb > 0) pb = sb == 1 ? 0.5 * (pb + W) : W;
+            pa = pa > W ? W : pa;
+            pb = pb > W ? W : pb;
+            const double E = (pa + 1.0) * (pb + 1.0) / den;
+            double xlo = 0.5, xhi = (pa < pb ? pa : pb) + 0.5;
+            const double xmin_feas = (pa + 1.0) + (pb + 1.0) - den + 0.5;
+            if (xmin_feas > xlo) xlo = xmin_feas;
+            double H = 1e30, L = -1e30;
+            if (E < xhi && mi11_exact(xhi, pa, pb, W, den) >= lo) {
+                double a = E > xlo ? E : xlo, b = xhi;
+                for (int it = 0; it < 40; ++it) {
+                    const double m = 0.5 * (a + b);
+                    if (mi11_exact(m, pa, pb, W, den) < lo) a = m; else b = m;
+                }
+                H = a;   // MI(a) < lo: everything below a (and above E) is safe
+            }
+            if (E > xlo && mi11_exact(xlo, pa, pb, W, den) >= lo) {
+                double a = xlo, b = E < xhi ? E : xhi;
+                for (int it = 0; it < 40; ++it) {
+                    const double m = 0.5 * (a + b);
+                    if (mi11_exact(m, pa, pb, W, den) < lo) b = m; else a = m;
+                }
+                L = b;
+            }
+            Lmax = L > Lmax ? L : Lmax;
+            Hmin = H < Hmin ? H : Hmin;
+        }
+    // n' is at most eta / sprime units below the sum of the approximate weights, which is within delta of the exact sum
+    int2 e;
+    const double hq = (Hmin * (1.0 - delta) - eta - 0.5) / sprime, lq = (Lmax * (1.0 + delta) + eta - 0.5) / sprime;
+    e.y = Hmin > 1e29 ? 2147483647 : (hq < 0.0 ? 0 : (hq > 2147483000.0 ? 2147483647 : (int)floor(hq) - 1));
+    e.x = Lmax < -1e29 ? -1 : (lq < -1.0 ? -1 : (lq > 2147483000.0 ? 2147483646 : (int)ceil(lq) + 1));
+    tab[id] = e;
+}
+
+// biallelic x biallelic columns of the approximate screen through the threshold table
+template <int U, int RM>
+__device__ __forceinline__ unsigned int screen_cols_tab(const EpiArgs &A, const RowSide &R, int binA, const ColMeta *cmu, int a_loc, bool a_ok, float lo,
+                                                        int q0) {
+    const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0;
+    int n[U];
+    int2 th[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        n[u] = (int)g_entry(A, R, cmu[u]).at(0, 0);
+        th[u] = A.tab11[cmu[u].pad2 * A.tab_nb + binA];
+    }
+    unsigned int bits = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const ColMeta &M = cmu[u];
+        const int b_loc = M.bl;
+        const bool act = a_ok && (A.E.lower_only ? a_loc > b_loc : a_loc != b_loc);
+        const bool is_sr = test_sr && col_is_sr(M.ci, a_loc);
+        if (test_sr && __ballot(act && is_sr && keep_sr) != 0ull) {   // a unit with a short-range pair is evaluated whole
+            bits |= 1u << u;
+            continue;
+        }
+        const bool maybe = act && !is_sr && !(n[u] > th[u].x && n[u] < th[u].y);
+        if (__ballot(maybe) == 0ull) continue;
+        // some lane is beyond its thresholds: the full bound for this column
+        FullCells<1, 1> C;
+        const int64_t v = n[u];
+        C.n[0][0] = v;
+        C.n[1][0] = M.pb[0] - v;
+        C.n[0][1] = R.pa[0] - v;
+        C.n[1][1] = R.pa[1] - C.n[1][0];
+        const float ms = full_cells_screen<1, 1, true>(A, R, M, screen_rxy(A, R, M, a_loc, b_loc, RM), C);
+        const bool need_lr = maybe && ms >= lo;
+        const unsigned long long m = __ballot(need_lr);
+        if (m == 0ull) continue;
+        if (A.pl_pairs) append_pairs(A, 0, m, need_lr, (uint32_t)(blockIdx.x * 64 + (threadIdx.x & 63)), (uint32_t)(q0 + u), R.sa, M.sb);
+        else bits |= 1u << u;   // verify mode: whole units (the dismissed ones are evaluated too and must not produce anything)
+    }
+    return bits;
+}
+
 // U columns at once for biallelic x biallelic units (4 cells each, the bulk of the work); wider tables go two (or one)
 // at a time, which keeps the kernel near 64 VGPRs
 template <int NA, int U, int RM, bool APX>
 __device__ __forceinline__ unsigned int screen_cols_nb(int nb, const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc,
                                                        bool a_ok, float lo, int q0) {
-    if (NA == 1 && nb == 1) return screen_cols<NA, 1, U, RM, APX>(A, R, cmu, a_loc, a_ok, lo, q0);
+    if (NA == 1 && nb == 1) return screen_cols<NA, 1, U, RM, APX>(A, R, cmu, a_loc, a_ok, lo, q0);   // (the table path is taken by the caller)
     constexpr int V = U >= 2 && NA == 1 ? 2 : 1;
     unsigned int bits = 0;
     for (int u = 0; u < U; u += V) {
@@ -218,6 +325,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     n_it = n_it > EPI_COLS / 4 ? EPI_COLS / 4 : n_it;
     if (n_it <= 0) return;
     const float lo = (float)A.E.spec_lo - A.E.scr_eps;
+    // threshold-table path: every SNP of the tile biallelic with r = 2, long-range pass
+    int binA = 0;
+    bool use_tab = false;
+    if (APX && A.tab11 && A.rowpack && A.E.do_lr && wave_full && na0 == 1) {
+        binA = A.rowpack[blockIdx.x * 64 + (threadIdx.x & 63)].pad;
+        use_tab = __ballot(a_ok && R.ra != 2.0) == 0ull;
+    }
     // wanted: units that need the fp64 kernel; handled: units this kernel could judge (the others are wanted by default)
     unsigned int wanted = 0, handled = 0;
     constexpr int U = 4;
@@ -239,8 +353,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 same = same && col_is_fast(mb0);
             }
             if (same) {
-                const unsigned int b = na0 == 1 ? screen_cols_nb<1, U, RM, APX>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo, q_base + it)
-                                                : screen_cols_nb<2, U, RM, APX>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo, q_base + it);
+                unsigned int b;
+                bool tab_ok = false;
+                if (APX && use_tab && (mb0 & 7) == 1) {   // biallelic x biallelic with r = 2 on both sides: the threshold table
+                    tab_ok = true;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) tab_ok = tab_ok && cmu[u].rb == 2.0;
+                }
+                if (tab_ok) b = screen_cols_tab<U, RM>(A, R, binA, cmu, a_loc, a_ok, lo, q_base + it);
+                else
+                    b = na0 == 1 ? screen_cols_nb<1, U, RM, APX>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo, q_base + it)
+                                 : screen_cols_nb<2, U, RM, APX>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo, q_base + it);
                 wanted |= b << it;
                 handled |= ((1u << U) - 1u) << it;
             } else {
@@ -958,6 +1081,9 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
     A.pl_n = nullptr;
     A.pl_cap = 0;
     A.row0 = c->row0.as<int32_t>();
+    A.tab11 = nullptr;
+    A.tab_nb = 0;
+    A.tab_c = 0;
     A.E = E;
     memset(&A.lo, 0, sizeof(A.lo));
 }
@@ -1168,9 +1294,33 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         if (need_exact)
             if (int rc = Gx.reserve((size_t)RFpad * RTpad * 8)) return rc;
     }
+    if (phase == 1) {
+        if (E.do_lr && c->tab11_on) {
+            // threshold table of the biallelic pairs: valid for every block whose level is at least the level it was built
+            // for (a higher level only widens the true interval), so it is rebuilt only when a block's level falls below it
+            const double lo_blk = E.spec_lo - (double)E.scr_eps;
+            if (!(c->tab11_lo > 0) || lo_blk < c->tab11_lo || lo_blk > 1.5 * c->tab11_lo) {
+                constexpr int NBINS_T = 64;
+                if (int rc = c->tab11.reserve((size_t)NBINS_T * NBINS_T * 8)) return rc;
+                const double W = std::ldexp((double)c->total_fixed, -c->frac_bits);
+                c->tab11_lo = 0.93 * lo_blk;   // buckets are 0.5 % wide and the guesses drift by a few per cent between blocks
+                c->tab11_c = (float)(NBINS_T / std::sqrt(W + 1.0));
+                c->tab11_nb = NBINS_T;
+                const double sprime = std::ldexp(1.0, c->apx_e_last - c->frac_bits);
+                hipLaunchKernelGGL(k_build_tab11, dim3(NBINS_T * NBINS_T / 256), dim3(256), 0, gs, W, c->tab11_lo, c->apx_delta * 1.001,
+                                   (c->apx_lost_units + 1.0) * sprime, sprime, NBINS_T, c->tab11_c, c->tab11.as<int2>());
+                LDW_HIP(hipGetLastError());
+            }
+        }
+    }
     EpiArgs A;
     fill_epi_args(c, D, nf, nt, RFpad, quirk, E, reinterpret_cast<const int64_t *>(c->Gapx[s].p), A);
     A.lo.slot_pfix_hi = c->slot_papx.as<int64_t>();   // the screen derives its cells from the marginals of the approximate weights
+    if (E.do_lr && c->tab11_on && c->tab11.p && c->tab11_lo > 0 && E.spec_lo - (double)E.scr_eps >= c->tab11_lo) {
+        A.tab11 = c->tab11.as<int2>();
+        A.tab_nb = c->tab11_nb;
+        A.tab_c = c->tab11_c;
+    }
     char *ub = c->apx_units[s].as<char>();
     unsigned int *n_units = reinterpret_cast<unsigned int *>(ub);
     uint64_t *units = reinterpret_cast<uint64_t *>(ub + o_flat);
@@ -1222,25 +1372,25 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         if (rm == 0) LDW_SCREEN(0); else if (rm == 1) LDW_SCREEN(1); else LDW_SCREEN(2);
 #undef LDW_SCREEN
         LDW_HIP(hipGetLastError());
-        // the units outside k_mi_screen's domain: generic from-tiles x all columns, the other tiles x the generic columns
-        const int gt0 = std::min<int>(A.gen_t0, (int)egrid.x);
-        const int q0 = std::min<int>(A.gen_q0, (int)nt) / GEN_COLS * GEN_COLS;
-        if (gt0 < (int)egrid.x)
-            hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3(egrid.x - gt0, (unsigned)((nt + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, gs, A, D.perm,
-                               D.perm_t, units, n_units, list_stride, gt0, 0);
-        if (gt0 > 0 && A.gen_q0 < (int)nt)
-            hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3(gt0, (unsigned)((nt - q0 + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, gs, A, D.perm, D.perm_t,
-                               units, n_units, list_stride, 0, q0);
-        LDW_HIP(hipGetLastError());
-        if (need_exact)
-            if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, Gx.as<int64_t>(), c->nlimbs, c->digits.as<int8_t>(),
-                                          E.lower_only, gs, 0, -1, band))
-                return rc;
         LDW_HIP(hipEventRecord(ev[5], gs));
         return LDW_OK;
     }
     // ---- phase 2 ----
     LDW_HIP(hipEventRecord(ev[4], c->stream));
+    // the units outside k_mi_screen's domain: generic from-tiles x all columns, the other tiles x the generic columns
+    const int gt0 = std::min<int>(A.gen_t0, (int)egrid.x);
+    const int q0 = std::min<int>(A.gen_q0, (int)nt) / GEN_COLS * GEN_COLS;
+    if (gt0 < (int)egrid.x)
+        hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3(egrid.x - gt0, (unsigned)((nt + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A, D.perm,
+                           D.perm_t, units, n_units, list_stride, gt0, 0);
+    if (gt0 > 0 && A.gen_q0 < (int)nt)
+        hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3(gt0, (unsigned)((nt - q0 + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A, D.perm, D.perm_t,
+                           units, n_units, list_stride, 0, q0);
+    LDW_HIP(hipGetLastError());
+    if (need_exact)
+        if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, Gx.as<int64_t>(), c->nlimbs, c->digits.as<int8_t>(),
+                                      E.lower_only, c->stream, 0, -1, band))
+            return rc;
     if (use_pairs) {
         if (int rc = c->pair_sums.reserve((size_t)PAIR_PATHS * PAIR_SHARDS * PAIR_CAP * 16 * 8)) return rc;
         if (int rc = launch_pairs_exact(c, A, ghist, c->pair_sums.as<int64_t>(), c->stream)) return rc;
