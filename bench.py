@@ -11,6 +11,12 @@ tables assembled on rank 0 (BASELINE.json: synthetic 100k SNPs x 5k sequences, r
 matrix, weights and SNP meta data are resident in HBM before the timed region.  With N > 1 the block pairs are
 dealt over the ranks (total work fixed -> "strong" scaling) and gathered with one RCCL gatherv.
 Prints ONE JSON line on rank 0.
+
+Order of work (so that a coarse GPU-busy sampler sees the GPU section as one stretch at the end of the run): setup ->
+`cpu_baseline` on the host cores (rank 0, N = 1 only) -> W warm-up steps -> EXACTLY K timed steps -> (N = 1 only) the extra
+legs reported on the same line: `sustained` (the same step repeated until >= 10 s of GPU work have run), the kernel-exclusive
+replay behind `roofline`, `plain` (5-limb GEMM + fp64 MI of every pair: no screen, no mixed precision, no approximate GEMM)
+and `cold_first_pass_ms` (one pass without the histogram-bucket guesses that every warm step inherits from its predecessor).
 """
 import argparse
 import json
@@ -47,6 +53,8 @@ def parse():
     ap.add_argument("--screen", type=int, default=1, help="fp32 screen before the fp64 MI evaluation: 0 off, 1 on, 2 verify")
     ap.add_argument("--gather-phases", type=int, default=3, help="N > 1: phases of the link-table gather (1 = one gather after all blocks)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="SNPs per side of the CPU-baseline sample block (0 = auto)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the sustained / plain / cold legs after the timed region")
+    ap.add_argument("--sustain-s", type=float, default=10.0, help="N = 1: keep stepping after the timed region until this many seconds of steps have run")
     return ap.parse_args()
 
 
@@ -64,8 +72,9 @@ def cpu_baseline(states_np, hdw, r, uqe, N, sample):
     dt = time.time() - t0
     pairs = s * (s - 1) // 2 + s * s
     return dict(value=pairs / dt, unit="MI SNP-pairs/s", cores=cores, kind="port",
-                sample=f"one diagonal + one off-diagonal {s}x{s} block at N={N} (all 25 state pairs, dense x CSR + fused "
-                       f"Hadamard), {dt:.1f} s wall; extrapolates linearly in pairs")
+                sample=f"one diagonal + one off-diagonal {s}x{s} sub-block of the workload's first 10000-SNP block at N={N} (all 25 state "
+                       f"pairs, dense x CSR + fused Hadamard), {dt:.1f} s wall.  A whole 10000 x 10000 block is 25x the pairs (minutes on "
+                       f"these cores); the cost is linear in pairs at fixed N, so the sample rate extrapolates")
 
 
 def main():
@@ -131,6 +140,14 @@ def main():
     my_blocks = blocks[mine]
     setup_s = time.time() - t_setup
 
+    # ---- CPU baseline first: the GPU section below then runs as one stretch until the end of the process ----
+    cpu_base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sample = args.cpu_sample or max(200, min(2000, L // 2))   # ~10-30 s of host work at N = 5000
+        st_np = states[: 2 * sample].cpu().numpy()
+        cpu_base = cpu_baseline(st_np, hdw, r[: 2 * sample], uqe[: 2 * sample], N, sample)
+        del st_np
+
     pairs = 0
     for fs, fe, ts, te in blocks.tolist():
         nf, nt = fe - fs + 1, te - ts + 1
@@ -180,32 +197,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step(True)
-    ev1.record()
-    fence()
-    dt = time.perf_counter() - t0
+    def timed(n, accumulate=False):
+        """n steps bracketed by fences; wall seconds."""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(accumulate)
+        fence()
+        return time.perf_counter() - t0
+
+    first_pass_ms = None
+    for w in range(args.warmup):
+        t = timed(1)
+        if w == 0:
+            first_pass_ms = t * 1e3     # includes the one-off allocations of the context and has no bucket guesses
+    dt = timed(args.steps, accumulate=True)
     tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.backend == "gloo" else dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    counters_timed = eng.counters()
+    links_timed = dict(result)
 
-    # Kernel-exclusive stage times for the roofline: in the timed region the GEMM of block b+1 runs on a second stream
+    extra = rank == 0 and world == 1 and len(my_blocks) and not args.no_extra_legs
+    legs = {}
+    # ---- sustained: the same step until >= 10 s of steps have run (clock / thermal steady state; also what a coarse busy
+    # sampler can see) ----
+    if extra and args.sustain_s > 0:
+        done_s, n_s = dt, args.steps
+        t_chunk = 0.0
+        n_chunk = 0
+        while done_s + t_chunk < args.sustain_s:
+            k = max(1, min(20, int((args.sustain_s - done_s - t_chunk) / max(1e-3, dt / args.steps)) + 1))
+            t_chunk += timed(k)
+            n_chunk += k
+        if n_chunk:
+            legs["sustained"] = dict(steps=n_chunk, seconds=t_chunk, ms_per_step=t_chunk / n_chunk * 1e3, value=pairs * n_chunk / t_chunk,
+                                     note="further steps of the same workload right after the timed region")
+
+    # ---- kernel-exclusive stage times for the roofline: in the timed region the GEMM of block b+1 runs on a second stream
     # beside the epilogue / selection of block b, so HIP-event brackets of one kernel also contain its neighbours.  Replay
-    # the same step with the overlap off (same kernels, same inputs, back to back on one stream) and bracket there.
+    # the same step with the overlap off (same kernels, same inputs, back to back on one stream) and bracket there. ----
     tim_overlapped = dict(tim)
-    n_replay = 0
+    n_replay, gst, serial_ms_per_step, cnt_replay = 0, None, None, None
     if rank == 0 and len(my_blocks):
         eng.set_overlap(False)
         for k in tim:
             tim[k] = 0.0
         n_replay = min(args.steps, 3)
+        eng.gemm_stats(reset=True)
+        c0 = eng.counters()
         t_r0 = time.perf_counter()
         for _ in range(n_replay):
             eng.mi_all_pairs(my_blocks, sr_dist, lr_retain, approx)
@@ -213,89 +254,100 @@ def main():
                 tim[k] += v
         torch.cuda.synchronize()
         serial_ms_per_step = (time.perf_counter() - t_r0) / n_replay * 1e3
+        gst = eng.gemm_stats(reset=True)
+        c1 = eng.counters()
+        cnt_replay = {k: c1[k] - c0[k] for k in c1}
         eng.set_overlap(not args.no_overlap)
+
+    # ---- plain: no screen, no mixed precision, no approximate GEMM: 5-limb GEMM + fp64 MI of every pair ----
+    if extra and args.engine == "mfma":
+        eng.set_mixed(False)
+        eng.set_screen(0)
+        eng.set_path(1)
+        timed(1)
+        n_pl = 3
+        t_pl = timed(n_pl)
+        legs["plain"] = dict(ms_per_step=t_pl / n_pl * 1e3, value=pairs * n_pl / t_pl, steps=n_pl, links=dict(result),
+                             what="--no-mixed --screen 0 --path 1: gemm_bits_kernel<5> + k_mi_epilogue (fp64 MI of every pair), same link tables")
+        eng.set_mixed(not args.no_mixed)
+        eng.set_screen(args.screen)
+        eng.set_path(args.path)
+        # ---- cold: setting the weights again forgets the bucket guesses (buffers stay allocated): one pass as a real job runs it
+        eng.set_weights(hdw, args.nlimbs)
+        legs["cold_first_pass_ms"] = timed(1) * 1e3
+        legs["cold_links"] = dict(result)
+        legs["first_pass_incl_allocations_ms"] = first_pass_ms
 
     if rank == 0:
         K = args.steps
         ms_per_step = dt / K * 1e3
         value = pairs * K / dt
-        # ---- roofline of the dominant kernel (live HIP-event times accumulated by the library on this stream) ----
-        n_launch = max(1, len(my_blocks) * max(1, n_replay))
-        stage = max(("gemm_ms", "epilogue_ms", "select_ms"), key=lambda k: tim[k])
+        # ---- roofline of the dominant kernel: the block-wide co-occurrence GEMM (live HIP-event times of the replay) ----
         my_pairs = 0
         for fs, fe, ts, te in my_blocks.tolist():
             nf, nt = fe - fs + 1, te - ts + 1
             my_pairs += nf * (nf - 1) // 2 if (fs == ts and fe == te) else nf * nt - min(nf, nt)
-        gemm_avg_ms = tim["gemm_ms"] / n_launch
-        epi_avg_ms = tim["epilogue_ms"] / n_launch
         nb_mine = max(1, len(my_blocks))
-        alg_flops_per_launch = 50.0 * N * my_pairs / nb_mine       # 50*N MAC-flops per pair
-        # int8 ops the GEMM actually executes: 2 * (to-rows x from-rows, padded to 128) * Npad * limbs, tiles above
-        # the diagonal of a diagonal block skipped.  One indicator row per present state minus one per SNP.
-        nrow = np.maximum(r.astype(np.int64) - 1, 0)
-        crow = np.concatenate([[0], np.cumsum(nrow)])
-        Npad = (N + 127) // 128 * 128
         J = args.nlimbs or 5
-        mixed = (J == 5) and not args.no_mixed and not args.fused and args.screen > 0
-        J_block = 3 if mixed else J     # limbs of the block-wide GEMM (mixed precision: 3 high limbs; the 2 low limbs only for listed units)
-        exec_ops = 0.0
-        for fs, fe, ts, te in my_blocks.tolist():   # workgroup tile: 128 to-side rows x 64 from-side rows
-            tf = 2 * -(-int(crow[fe] - crow[fs - 1]) // 128)
-            tt = -(-int(crow[te] - crow[ts - 1]) // 128)
-            if fs == ts and fe == te:   # tiles entirely above the diagonal are skipped
-                tiles = sum(tf - max(0, 2 * by - 1) for by in range(tt))
-            else:
-                tiles = tf * tt
-            exec_ops += 2.0 * tiles * 128 * 64 * Npad * J_block
-        exec_per_launch = exec_ops / nb_mine
         i8_peak = 5000.0  # TOP/s dense (MI355X_MICROARCH.md: i8 = 2 x bf16 per clock, bf16 ~2.5 PF dense)
-        achieved = alg_flops_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms else None
-        kname = f"gemm_mi_fused_kernel<{J}>" if args.fused else f"gemm_bits_kernel<{J_block}>"
-        roof = dict(bound="mfma", kernel=kname, achieved=achieved, peak=i8_peak, unit="TFLOP/s",
-                    frac=achieved / i8_peak if achieved else None, traffic=None,
-                    avg_launch_ms=gemm_avg_ms, launches=n_launch,
-                    executed_TOPs=exec_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms else None,
-                    note="achieved = ALGORITHMIC 50*N flops/pair (SURVEY 8d) x pairs per launch / avg launch time (HIP events) of the "
-                         f"co-occurrence GEMM; the kernel EXECUTES fewer ops (one indicator row per minor state, {J_block} int8 limbs"
-                         + (" — the 3 high limbs of 5; the 2 low limbs are computed by gemm_lo_units_kernel for the ~4 % of units the screen lists" if mixed else "") + "): "
-                         "executed_TOPs / peak = executed_frac is the matrix-core utilisation.  Launch times are kernel-exclusive: "
-                         "bracketed in a replay of the timed step with the GEMM/epilogue stream overlap switched off "
-                         "(ldw_set_overlap(0)); `overlapped_*` are the brackets inside the timed region, where the GEMM shares "
-                         "the GPU with the previous block's epilogue and selection",
-                    measured_in=f"{n_replay} serialized replay step(s) after the timed region, {serial_ms_per_step:.2f} ms/step",
-                    overlapped_avg_launch_ms=tim_overlapped["gemm_ms"] / max(1, len(my_blocks) * K))
-        roof["executed_frac"] = roof["executed_TOPs"] / i8_peak if roof["executed_TOPs"] else None
-        # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (rocprofv3 cannot run inside
-        # the bench); only quoted for the configuration they were collected on
-        tpath = os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")
-        if os.path.exists(tpath) and (L, N, world, J) == (100_000, 5_000, 1, 5) and not args.fused:
-            roof["traffic"] = json.load(open(tpath)).get(kname, {}).get("hbm_bytes_per_launch_corrected")
-            roof["traffic_source"] = "profiles/r01h_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
-        roof["epilogue_avg_launch_ms"] = epi_avg_ms
-        roof["epilogue_kernels"] = ("inside the fused kernel" if args.fused else
-                                    "k_mi_screen (fp32 screen, lists the units that need the exact value) + gemm_lo_units_kernel (low limbs of "
-                                    "the listed units, mixed precision) + k_mi_units (fp64, listed units)"
-                                    if args.screen else "k_mi_epilogue (fp64, every pair)")
+        stage = max(("gemm_ms", "epilogue_ms", "select_ms"), key=lambda k: tim[k])
+        roof = dict(bound="mfma", peak=i8_peak, unit="TFLOP/s", traffic=None)
+        if gst and (gst["apx_launches"] + gst["bits_launches"]) > 0 and tim["gemm_ms"] > 0:
+            n_launch = gst["apx_launches"] + gst["bits_launches"]
+            apx = gst["apx_launches"] >= gst["bits_launches"]
+            mixed_blocks = cnt_replay.get("mixed_blocks", 0)
+            kname = "gemm_apx_kernel<4, 2>" if apx else (f"gemm_mi_fused_kernel<{J}>" if args.fused else
+                                                        f"gemm_bits_kernel<{3 if mixed_blocks else J}>")
+            avg_ms = tim["gemm_ms"] / n_launch
+            exec_per_launch = (gst["apx_ops"] + gst["bits_ops"]) / n_launch
+            alg_per_launch = 50.0 * N * my_pairs * n_replay / n_launch      # 50 * N MAC-flops per pair
+            achieved = exec_per_launch / (avg_ms * 1e-3) / 1e12
+            roof.update(kernel=kname, achieved=achieved, frac=achieved / i8_peak, avg_launch_ms=avg_ms, launches=n_launch,
+                        executed_ops_per_launch=exec_per_launch,
+                        alg_work_reduction=alg_per_launch / exec_per_launch,
+                        alg_TFLOPs=alg_per_launch / (avg_ms * 1e-3) / 1e12,
+                        launch_mix=dict(gemm_apx=gst["apx_launches"], gemm_bits_full=gst["bits_launches"], gemm_bits_band=gst["band_launches"]),
+                        overlapped_avg_launch_ms=tim_overlapped["gemm_ms"] / max(1, len(my_blocks) * K),
+                        measured_in=f"{n_replay} serialized replay step(s) after the timed region, {serial_ms_per_step:.2f} ms/step",
+                        note="achieved = int8 operations the kernel EXECUTES per launch (2 x rows x rows x positions of every wave tile "
+                             "that runs, counted by the library: ldw_gemm_stats) / its average launch time (HIP events around the kernel, "
+                             "overlap off) ; frac = achieved / 5 POP/s dense int8.  alg_work_reduction = SURVEY 8(d)'s algorithmic 50*N "
+                             "flops per pair x pairs per launch / executed operations: one indicator row per minor state instead of 5 one-hot "
+                             "planes, " + ("one dual-digit pass instead of 5 limbs (the exact sums of what the screen lists come from "
+                                           "k_pair_sums / the band GEMM)" if apx else f"{3 if mixed_blocks else J} int8 limbs") +
+                             ".  `overlapped_avg_launch_ms` is the bracket inside the timed region, where the GEMM shares the GPU with the "
+                             "previous block's screens and selection")
+            tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
+            if os.path.exists(tpath) and (L, N, world) == (100_000, 5_000, 1):   # the configuration the PMC passes were collected on
+                ent = json.load(open(tpath)).get(kname)
+                if ent:
+                    roof["traffic"] = ent.get("hbm_bytes_per_launch_corrected")
+                    roof["traffic_source"] = "profiles/r02_pmc_traffic.json (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, per launch)"
+        else:
+            roof.update(kernel="k_mi_hist" if args.engine == "hist" else None, achieved=None, frac=None)
         roof["dominant_stage"] = stage
         roof["hbm_alg_GBps_whole_step"] = (L * N + 8.0 * pairs) / (dt / K) / 1e9
         roof["hbm_frac_whole_step"] = roof["hbm_alg_GBps_whole_step"] / 8000.0
+        mixed = (J == 5) and not args.no_mixed and not args.fused and args.screen > 0
         out = dict(metric="MI SNP-pairs/sec", value=value, unit="pairs/s", n_gpus=world, steps=K, warmup=args.warmup,
                    ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="i8",
                    data="synthetic",
                    config=dict(workload=f"synthetic {L} SNPs x {N} seqs, all {nblocks} block pairs of make_blocks(max_blk_sz={args.max_blk_sz}), "
                                         f"sr_dist=20000, lr_retain_links=1e6, sr+lr link tables on rank 0",
                                L=L, N=N, pairs=int(pairs), engine=args.engine, nlimbs=args.nlimbs or 5,
-                               arithmetic="joint sums: int8 MFMA -> exact int64 fixed point; MI: fp32 screen, f64 for every emitted value",
-                               fused=bool(args.fused), screen=args.screen, mixed_precision=bool(mixed),
+                               arithmetic="screen: one dual-digit int8 MFMA pass (rigorous error bound) -> fp32 bound; every emitted MI: exact "
+                                          "int64 fixed-point joint sums -> f64",
+                               fused=bool(args.fused), screen=args.screen, mixed_precision=bool(mixed), path=args.path,
+                               approximate_gemm=eng.apx_info(),
                                parallelism=f"pair-space blocks over {world} GPU(s)"),
-                   roofline=roof,
-                   stages_ms_per_step={k: v / max(1, n_replay) for k, v in tim.items()},
+                   roofline=roof)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
+        out.update(legs)
+        out.update(stages_ms_per_step={k: v / max(1, n_replay) for k, v in tim.items()},
                    stages_ms_per_step_overlapped={k: v / K for k, v in tim_overlapped.items()},
-                   links=result, counters=eng.counters(), hamming_weights_s=hamming_s, hamming_gemm_ms=hamming_kernel_ms, setup_s=setup_s)
-        if not args.no_cpu_baseline:
-            sample = args.cpu_sample or max(200, min(2000, L // 2))   # ~10-30 s of host work at N = 5000
-            st_np = states[: 2 * sample].cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(st_np, hdw, r[: 2 * sample], uqe[: 2 * sample], N, sample)
+                   links=links_timed, counters=counters_timed, counters_replay=cnt_replay, hamming_weights_s=hamming_s,
+                   hamming_gemm_ms=hamming_kernel_ms, setup_s=setup_s)
         print(json.dumps(out))
     eng.close()
     if world > 1:

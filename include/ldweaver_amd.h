@@ -70,6 +70,11 @@ int ldw_ctx_counters(ldw_ctx *ctx, int64_t out[4]);
  * approximate-GEMM path (ldw_set_path), out[6] = units its screen listed (they hold a short-range pair), out[7] = long-range candidate
  * pairs its screen listed */
 int ldw_ctx_counters2(ldw_ctx *ctx, int64_t out[8]);
+/* Work the block-wide GEMMs of this context EXECUTED since the last reset (for the roofline: executed int8 operations /
+ * kernel time / peak): out[0] launches and out[1] int8 operations (2 x rows x rows x positions of the wave tiles that do not exit
+ * at once) of the approximate GEMM (gemm_apx_kernel), out[2] / out[3] the same for the unmasked limb GEMM (gemm_bits_kernel<J>,
+ * all J limbs), out[4] launches of the band-masked limb GEMM, out[5] reserved.  reset != 0 clears the counts. */
+int ldw_gemm_stats(ldw_ctx *ctx, double out[6], int reset);
 
 /* ---- (1) .ACGTN2num  — src/ACGTN2num_parallel.cpp:10-43, R/RcppExports.R:4-6 ------------ */
 /* nv: 5 x L doubles, column-major, mutated IN PLACE (host memory, as R hands it over);
@@ -254,9 +259,13 @@ int ldw_aracne_device(ldw_ctx *ctx, int64_t capacity, uint8_t *flags_out);
 /* Numeric core of analyse_long_range_links (R/lr_analyser.R:72-111): q13_out = quantile(MI, c(.25,.75)) (type 7) of the
  * long-range table, thresholds_out = q3 + (1.5, 3) IQR — or, when fewer than min_links (reference: 5000) links exceed
  * min(thresholds) although the table has that many rows, quantile(MI, 1 - c(4000, 5000)/n) (*fallback_out = 1, the
- * reference's warning).  Leaves on the device: the outlier links lr[MI > min(thresholds)] (n_red, table order) and the
- * ARACNE pool rbind(lr, sr)[MI > min(thresholds)] (n_pool).  Then ldw_lr_reduced_fetch / ldw_aracne_device. */
-int ldw_lr_tukey(ldw_ctx *ctx, int64_t min_links, double q13_out[2], double thresholds_out[2], int *fallback_out,
+ * reference's warning).  sr_a / sr_b / sr_mi (host, n_sr_rows >= 0 rows: 0-based from-side / to-side SNP index and MI) is the
+ * short-range table the reference reads back from sr_links.tsv (R/lr_analyser.R:67), i.e. the REDUCED set
+ * perform_MI_computation returned (srp_max > srp_cutoff, R/computePairwiseMI.R:122,140) — not the raw short-range table.
+ * Leaves on the device: the outlier links lr[MI > min(thresholds)] (n_red, table order) and the ARACNE pool
+ * rbind(lr, sr)[MI > min(thresholds)] (n_pool, R/lr_analyser.R:106-109).  Then ldw_lr_reduced_fetch / ldw_aracne_device. */
+int ldw_lr_tukey(ldw_ctx *ctx, int64_t min_links, const int32_t *sr_a, const int32_t *sr_b, const double *sr_mi,
+                 int64_t n_sr_rows, double q13_out[2], double thresholds_out[2], int *fallback_out,
                  int64_t *n_red_out, int64_t *n_pool_out);
 /* the outlier links: row in the lr table (ldw_links_fetch order) and that row's (a, b, MI) */
 int ldw_lr_reduced_fetch(ldw_ctx *ctx, int64_t capacity, int64_t *row_out, int32_t *a_out, int32_t *b_out, double *MI_out);

@@ -81,7 +81,8 @@ _SIGS = {
     "ldw_sr_reduced_fetch": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "ldw_sr_pool_fetch": (C.c_int, [_p, _i64, _p, _p, _p]),
     "ldw_aracne_device": (C.c_int, [_p, _i64, _p]),
-    "ldw_lr_tukey": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p]),
+    "ldw_gemm_stats": (C.c_int, [_p, _p, C.c_int]),
+    "ldw_lr_tukey": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, _p, _p]),
     "ldw_lr_reduced_fetch": (C.c_int, [_p, _i64, _p, _p, _p, _p]),
     "ldw_ldmap": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, _p, _p, _i64]),
     "ldw_compare_to_row": (C.c_int, [_p, _i64, _i64, _p, _i64, _p]),

@@ -357,6 +357,15 @@ int ldw_apx_info(ldw_ctx *c, double out[6]) {
     return LDW_OK;
 }
 
+int ldw_gemm_stats(ldw_ctx *c, double out[6], int reset) {
+    LDW_REQUIRE(c && out, LDW_ERR_ARG, "ldw_gemm_stats: null argument");
+    for (int k = 0; k < 6; ++k) {
+        out[k] = c->gemm_stat[k];
+        if (reset) c->gemm_stat[k] = 0;
+    }
+    return LDW_OK;
+}
+
 int ldw_set_engine(ldw_ctx *c, int engine) {
     LDW_REQUIRE(c, LDW_ERR_ARG, "null context");
     LDW_REQUIRE(engine == LDW_ENGINE_MFMA || engine == LDW_ENGINE_HIST, LDW_ERR_ARG, "unknown engine %d", engine);

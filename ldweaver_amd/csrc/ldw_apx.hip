@@ -287,6 +287,17 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     else LDW_APX_LAUNCH(4, 2)
 #undef LDW_APX_LAUNCH
     LDW_HIP(hipGetLastError());
+    {   // executed work (ldw_gemm_stats): waves that do not leave at once, each 2 * rows_t * rows_f * K int8 operations
+        const int MTv = tile == 22 || tile == 24 ? 2 : 4, NTv = tile == 24 ? 4 : 2, TH = 32 * MTv, TWd = 32 * NTv;
+        int64_t waves = 0;
+        for (int ty = 0; ty * TH < P.RTpad; ++ty) {
+            const int ntx = P.RFpad / TWd;
+            if (!P.lower_only) waves += ntx;
+            else for (int tx = 0; tx < ntx; ++tx) waves += (tx * TWd + TWd - 1 < ty * TH) ? 0 : 1;
+        }
+        c->gemm_stat[0] += 1;
+        c->gemm_stat[1] += 2.0 * (double)waves * TH * TWd * ((double)P.M2 * 128.0);
+    }
     return LDW_OK;
 }
 

@@ -210,6 +210,18 @@ int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int3
         LDW_HIP(hipGetLastError());
         done += J;
     }
+    if (!tile_mask) {   // executed work (ldw_gemm_stats): workgroup tiles that do not leave at once, all limbs
+        int64_t tiles = 0;
+        const int nbx = RFpad / TILE_F4;
+        for (int by = by0; by < by1; ++by) {
+            if (!lower_only) tiles += nbx;
+            else for (int bx = 0; bx < nbx; ++bx) tiles += (bx * TILE_F4 + TILE_F4 - 1 < by * TILE) ? 0 : 1;
+        }
+        ctx->gemm_stat[2] += 1;
+        ctx->gemm_stat[3] += 2.0 * (double)tiles * TILE * TILE_F4 * (double)Kpad * nlimbs;
+    } else {
+        ctx->gemm_stat[4] += 1;
+    }
     return LDW_OK;
 }
 

@@ -147,6 +147,7 @@ struct ldw_ctx {
 
     // ---- short-range model and ARACNE on the device-resident sr table (ldw_srp.hip) ----
     ldw::DevBuf srm_pack, srm_key, srm_pack2, srm_key2, srm_pay, srm_pay2, srm_off, srm_q, srm_n, srm_md, srm_part, srm_shape, srm_cnt;
+    double gemm_stat[6] = {0, 0, 0, 0, 0, 0};   // ldw_gemm_stats: launches and executed int8 ops of the block-wide GEMMs
     ldw::DevBuf red_row, red_meta, red_srp, pool_a, pool_b, pool_mi, ar_key, ar_val, ar_key2, ar_val2, ar_off, ar_flags;
     int64_t n_red = 0, n_pool = 0;
     bool red_from_lr = false;    // red_row indexes the long-range table (ldw_lr_tukey) instead of the short-range one

@@ -1334,11 +1334,13 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         A.pl_cap = (uint32_t)PAIR_CAP;
     }
     if (phase == 1) {
-        LDW_HIP(hipEventRecord(ev[0], gs));
         if (E.do_lr) {
             if (int rc = launch_pack_panel(c, D.rl_f, RFpad, c->panel[s][0].as<uint64_t>(), gs)) return rc;
             if (!lo_h->diag)
                 if (int rc = launch_pack_panel(c, D.rl_t, RTpad, c->panel[s][1].as<uint64_t>(), gs)) return rc;
+        }
+        LDW_HIP(hipEventRecord(ev[0], gs));   // ev[0] .. ev[1]: the approximate GEMM alone (its launch time is the roofline's)
+        if (E.do_lr) {
             ApxGemmArgs P;
             P.panel_f = c->panel[s][0].as<uint64_t>();
             P.panel_t = lo_h->diag ? P.panel_f : c->panel[s][1].as<uint64_t>();

@@ -155,11 +155,25 @@ static double q7_value(const Q7 &q, double xlo, double xhi) {
 
 extern "C" {
 
-int ldw_lr_tukey(ldw_ctx *c, int64_t min_links, double q13_out[2], double thresholds_out[2], int *fallback_out, int64_t *n_red_out,
-                 int64_t *n_pool_out) {
+int ldw_lr_tukey(ldw_ctx *c, int64_t min_links, const int32_t *sr_a, const int32_t *sr_b, const double *sr_mi, int64_t n_sr_rows,
+                 double q13_out[2], double thresholds_out[2], int *fallback_out, int64_t *n_red_out, int64_t *n_pool_out) {
     if (int rc = links_ready(c, "ldw_lr_tukey")) return rc;
     LDW_REQUIRE(q13_out && thresholds_out && fallback_out && n_red_out && n_pool_out, LDW_ERR_ARG, "ldw_lr_tukey: null argument");
-    const int64_t n = c->n_lr, ns = c->n_sr;
+    LDW_REQUIRE(n_sr_rows >= 0 && (n_sr_rows == 0 || (sr_a && sr_b && sr_mi)), LDW_ERR_ARG, "ldw_lr_tukey: bad short-range table");
+    // the short-range part of the ARACNE pool is what sr_links.tsv holds — the REDUCED set perform_MI_computation returned
+    // (srp_max > srp_cutoff, R/computePairwiseMI.R:122,140), not the engine's raw short-range table: the caller hands it in
+    const int64_t n = c->n_lr, ns = n_sr_rows;
+    if (ns > 0) {
+        if (int rc = c->ar_val.reserve((size_t)ns * 4)) return rc;
+        if (int rc = c->ar_val2.reserve((size_t)ns * 4)) return rc;
+        if (int rc = c->ar_flags.reserve((size_t)ns * 8)) return rc;
+        LDW_HIP(hipMemcpyAsync(c->ar_val.p, sr_a, (size_t)ns * 4, hipMemcpyHostToDevice, c->stream));
+        LDW_HIP(hipMemcpyAsync(c->ar_val2.p, sr_b, (size_t)ns * 4, hipMemcpyHostToDevice, c->stream));
+        LDW_HIP(hipMemcpyAsync(c->ar_flags.p, sr_mi, (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));   // pageable sources
+    }
+    const int32_t *d_sa = c->ar_val.as<int32_t>(), *d_sb = c->ar_val2.as<int32_t>();
+    const double *d_smi = c->ar_flags.as<double>();
     LDW_REQUIRE(n > 0, LDW_ERR_STATE, "ldw_lr_tukey: the long-range table is empty");
     LDW_REQUIRE(n < 2147483647LL, LDW_ERR_SIZE, "ldw_lr_tukey: too many long-range links");
     // ---- sorted MI keys -> order statistics ----
@@ -194,7 +208,7 @@ int ldw_lr_tukey(ldw_ctx *c, int64_t min_links, double q13_out[2], double thresh
     int64_t *cnt_l = c->ar_off.as<int64_t>(), *off_l = cnt_l + nseg_l + 1, *cnt_s = off_l + nseg_l + 1, *off_s = cnt_s + nseg_s + 1;
     auto count_pass = [&](double t, int64_t &n_red, int64_t &n_srp) -> int {
         hipLaunchKernelGGL(k_count_gt, dim3((unsigned)nseg_l), dim3(256), 0, c->stream, c->lr_mi.as<double>(), n, t, cnt_l);
-        if (ns > 0) hipLaunchKernelGGL(k_count_gt, dim3((unsigned)nseg_s), dim3(256), 0, c->stream, c->sr_mi.as<double>(), ns, t, cnt_s);
+        if (ns > 0) hipLaunchKernelGGL(k_count_gt, dim3((unsigned)nseg_s), dim3(256), 0, c->stream, d_smi, ns, t, cnt_s);
         LDW_HIP(hipGetLastError());
         size_t sb = 0;
         LDW_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, cnt_l, off_l, (int)nseg_l, c->stream));
@@ -237,8 +251,8 @@ int ldw_lr_tukey(ldw_ctx *c, int64_t min_links, double q13_out[2], double thresh
                        c->lr_mi.as<double>(), n, tmin, off_l, (int64_t)0, c->red_row.as<int64_t>(), c->pool_a.as<int32_t>(),
                        c->pool_b.as<int32_t>(), c->pool_mi.as<double>());
     if (ns > 0)
-        hipLaunchKernelGGL(k_select_gt, dim3((unsigned)nseg_s), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(),
-                           c->sr_mi.as<double>(), ns, tmin, off_s, n_red, (int64_t *)nullptr, c->pool_a.as<int32_t>(),
+        hipLaunchKernelGGL(k_select_gt, dim3((unsigned)nseg_s), dim3(256), 0, c->stream, d_sa, d_sb,
+                           d_smi, ns, tmin, off_s, n_red, (int64_t *)nullptr, c->pool_a.as<int32_t>(),
                            c->pool_b.as<int32_t>(), c->pool_mi.as<double>());
     LDW_HIP(hipGetLastError());
     LDW_HIP(hipStreamSynchronize(c->stream));

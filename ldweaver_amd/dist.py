@@ -10,12 +10,53 @@ gatherv; a 7 -> 1 gather uses every peer's own xGMI link to GPU 0 concurrently).
 rank computes its next ones, so only the last phase's transfer is exposed.
 
 Works with backend "nccl" (= RCCL, GPU tensors) and "gloo" (CPU tensors, used by the CPU tests).
+
+``force_collective`` (argument, or LDW_FORCE_COLLECTIVE=1): a group of ONE rank normally short-cuts every exchange; with the
+switch the collectives run anyway — the all-reduce on the device table and a loop-back isend/irecv pair of the packed
+byte buffer — so the whole RCCL path executes on a single GPU (tests/test_gpu_parity.py::test_rccl_single_rank_walk).
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+def _forced(flag) -> bool:
+    return bool(flag) if flag is not None else os.environ.get("LDW_FORCE_COLLECTIVE", "0") not in ("", "0")
+
+
+def _world_rank(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def _collective_device(group, fallback: torch.device) -> torch.device:
+    """Tensors of a collective live on the GPU under RCCL and on the host under gloo."""
+    if dist.get_backend(group) == "nccl":
+        return fallback if fallback.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def agree(ok: bool, group=None, what: str = "", force_collective=None) -> None:
+    """Error agreement: every rank reports whether its share succeeded (ONE all-reduce of a flag) BEFORE any rank enters a
+    gather, so that a rank that failed (out of memory, a refused argument) cannot leave the others blocked in a collective.
+    Raises RuntimeError on every rank when any rank failed; the failing rank chains its own exception to it."""
+    world, rank = _world_rank(group)
+    if world == 1 and not (_forced(force_collective) and dist.is_initialized()):
+        if not ok:
+            raise RuntimeError(f"{what or 'the computation'} failed")
+        return
+    dev = _collective_device(group, torch.device("cpu"))
+    flag = torch.zeros(world, dtype=torch.int32, device=dev)
+    flag[rank] = 0 if ok else 1
+    dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
+    bad = np.nonzero(flag.cpu().numpy())[0]
+    if len(bad):
+        raise RuntimeError(f"{what or 'the computation'} failed on rank(s) {bad.tolist()} (this is rank {rank})")
 
 
 def block_cost(blocks: np.ndarray) -> np.ndarray:
@@ -43,7 +84,8 @@ class _Phase:
     __slots__ = ("tab", "owner", "rows", "bufs", "works", "mine", "out_dev", "rank", "world", "dst")
 
 
-def gather_begin(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int, group=None, dst: int = 0) -> _Phase:
+def gather_begin(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int, group=None, dst: int = 0,
+                 force_collective=None) -> _Phase:
     """Start the gather of the link tables of a SUBSET of blocks (this rank's ``my_blocks``, any rank's may be empty) and
     return without waiting for the transfers: the caller goes on computing its next blocks while the rows travel, and
     hands all its phases to ``gather_end``.  Every rank must call it the same number of times (it contains a collective).
@@ -53,8 +95,8 @@ def gather_begin(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int,
     counts:  {"sr": int64[len(my_blocks)], "lr": ...} rows per owned block.
     """
     ph = _Phase()
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world, rank = _world_rank(group)
+    loopback = world == 1 and _forced(force_collective) and dist.is_initialized()
     ph.world, ph.rank, ph.dst = world, rank, dst
     ph.out_dev = local["sr"][2].device
     # gloo cannot move GPU tensors point to point: stage through the host in that case (CPU tests, or a
@@ -71,7 +113,7 @@ def gather_begin(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int,
         table[idx, 0] = torch.as_tensor(np.asarray(counts["sr"]), dtype=torch.int64, device=dev)
         table[idx, 1] = torch.as_tensor(np.asarray(counts["lr"]), dtype=torch.int64, device=dev)
         table[idx, 2] = rank + 1
-    if world > 1:
+    if world > 1 or loopback:
         dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)  # blocks are disjoint: a sum is a gather here
     tab = table.cpu().numpy()
     ph.tab, ph.owner = tab, tab[:, 2] - 1
@@ -96,6 +138,10 @@ def gather_begin(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int,
             ops = [dist.P2POp(dist.isend, ph.mine, dst, group)] if nbytes[rank] > 0 else []
         if ops:
             ph.works = dist.batch_isend_irecv(ops)
+    elif loopback and nbytes[0] > 0:
+        # one rank, collectives forced: the packed buffer travels rank 0 -> rank 0 through the same grouped isend / irecv
+        ph.bufs = [torch.empty(nbytes[0], dtype=torch.uint8, device=dev)]
+        ph.works = dist.batch_isend_irecv([dist.P2POp(dist.irecv, ph.bufs[0], rank, group), dist.P2POp(dist.isend, ph.mine, rank, group)])
     else:
         ph.bufs = [ph.mine]
     return ph
@@ -107,6 +153,8 @@ def gather_end(phases: list, nblocks: int):
     for ph in phases:
         for w in ph.works:
             w.wait()
+        if ph.works and ph.mine.is_cuda:   # RCCL: wait() only orders the current torch stream behind the transfer
+            torch.cuda.current_stream(ph.mine.device).synchronize()
     ph0 = phases[0]
     if ph0.rank != ph0.dst:
         return None
@@ -149,20 +197,23 @@ def gather_end(phases: list, nblocks: int):
     return out
 
 
-def gather_link_tables(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int, group=None, dst: int = 0):
+def gather_link_tables(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int, group=None, dst: int = 0,
+                       force_collective=None):
     """Assemble the global link tables on rank ``dst`` in make_blocks order (one phase: see gather_begin / gather_end).
     Returns the same dict of global tensors on rank dst, None elsewhere."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:   # one rank owns every block, in make_blocks order already: nothing to move
+    world, _ = _world_rank(group)
+    if world == 1 and not (_forced(force_collective) and dist.is_initialized()):
+        # one rank owns every block, in make_blocks order already: nothing to move
         if len(my_blocks) != nblocks:
             raise RuntimeError("some blocks were processed by no rank")
         return {k: tuple(local[k]) for k in ("sr", "lr")}
-    return gather_end([gather_begin(local, my_blocks, counts, nblocks, group=group, dst=dst)], nblocks)
+    return gather_end([gather_begin(local, my_blocks, counts, nblocks, group=group, dst=dst, force_collective=force_collective)], nblocks)
 
 
-def gather_block_stats(my_stats: dict, my_blocks: np.ndarray, nblocks: int, group=None) -> dict:
+def gather_block_stats(my_stats: dict, my_blocks: np.ndarray, nblocks: int, group=None, force_collective=None) -> dict:
     """Per-block diagnostics (Engine.block_stats) of all ranks in make_blocks order, on every rank."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    world, _ = _world_rank(group)
+    collective = world > 1 or (_forced(force_collective) and dist.is_initialized())
     keys = ("n_lr_total", "n_lr_kept", "n_sr", "disc_thresh")
     tab = torch.zeros((nblocks, 4), dtype=torch.float64)
     if len(my_blocks):
@@ -170,8 +221,8 @@ def gather_block_stats(my_stats: dict, my_blocks: np.ndarray, nblocks: int, grou
         for j, k in enumerate(keys):
             v = np.asarray(my_stats[k], dtype=np.float64)
             tab[idx, j] = torch.as_tensor(np.where(np.isnan(v), 0.0, v))   # NaN threshold (no lr links) travels as 0
-    if world > 1:
-        t = tab.cuda() if dist.get_backend(group) == "nccl" else tab
+    if collective:
+        t = tab.to(_collective_device(group, tab.device))
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)   # blocks are disjoint: a sum is a gather here
         tab = t.cpu()
     a = tab.numpy()
@@ -190,18 +241,24 @@ def hamming_tile_strips(nseq: int, world: int) -> list:
     return [(cuts[k], max(cuts[k], cuts[k + 1])) for k in range(world)]
 
 
-def hamming_weights_sharded(eng, thresh: int, group=None) -> np.ndarray:
+def hamming_weights_sharded(eng, thresh: int, group=None, force_collective=None) -> np.ndarray:
     """estimate_Hamming_distance_weights over the ranks of an initialised process group: every rank (its engine holding the
     same alignment) counts its strip's neighbours (ldw_hamming_counts), ONE all-reduce of N integers, hdw = 1 / (n + 1)
     on every rank — integers in, so the weights are bit-identical everywhere."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world, rank = _world_rank(group)
     t0, t1 = hamming_tile_strips(eng.N, world)[rank]
-    cnt = eng.hamming_counts(thresh, t0, t1) if t1 > t0 else np.zeros(eng.N, dtype=np.int64)
+    err = None
+    try:
+        cnt = eng.hamming_counts(thresh, t0, t1) if t1 > t0 else np.zeros(eng.N, dtype=np.int64)
+    except Exception as e:   # agree before the all-reduce: the other ranks must not wait for this one
+        err, cnt = e, np.zeros(eng.N, dtype=np.int64)
+    try:
+        agree(err is None, group, "the Hamming strip", force_collective)
+    except RuntimeError as e:
+        raise e from err
     t = torch.as_tensor(cnt)
-    if world > 1:
-        if dist.get_backend(group) == "nccl":
-            t = t.cuda(eng.device)
+    if world > 1 or (_forced(force_collective) and dist.is_initialized()):
+        t = t.to(_collective_device(group, torch.device("cuda", eng.device) if torch.cuda.is_available() else t.device))
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         t = t.cpu()
     return 1.0 / (t.numpy().astype(np.float64) + 1.0)

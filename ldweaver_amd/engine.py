@@ -51,6 +51,12 @@ class Engine:
         L.check(L.lib().ldw_ctx_last_timing(self._ctx, L.ptr(t)))
         return dict(gemm_ms=t[0], epilogue_ms=t[1], select_ms=t[2], total_ms=t[3])
 
+    def gemm_stats(self, reset: bool = False):
+        """Launches and EXECUTED int8 operations of the block-wide GEMMs since the last reset (ldw_gemm_stats)."""
+        v = np.zeros(6)
+        L.check(L.lib().ldw_gemm_stats(self._ctx, L.ptr(v), int(reset)))
+        return dict(apx_launches=int(v[0]), apx_ops=float(v[1]), bits_launches=int(v[2]), bits_ops=float(v[3]), band_launches=int(v[4]))
+
     def counters(self):
         v = np.zeros(8, dtype=np.int64)
         L.check(L.lib().ldw_ctx_counters2(self._ctx, L.ptr(v)))
@@ -238,6 +244,9 @@ class Engine:
             a, b, mi = a.contiguous(), b.contiguous(), mi.contiguous()
             assert a.dtype.__str__() == "torch.int32" and mi.dtype.__str__() == "torch.float64" and len(a) == len(b) == len(mi)
             on_dev = int(a.is_cuda)
+            if on_dev:   # the library copies on its own (non-blocking) stream: torch's producers (cat, RCCL receives) must be done
+                import torch
+                torch.cuda.synchronize(a.device)
         else:
             a, b, mi = np.ascontiguousarray(a, dtype=np.int32), np.ascontiguousarray(b, dtype=np.int32), np.ascontiguousarray(mi, dtype=np.float64)
             on_dev = 0
@@ -308,13 +317,22 @@ class Engine:
         return out.astype(bool)
 
     # -- consumers of the link tables ---------------------------
-    def lr_tukey(self, min_links: int = 5000):
+    def lr_tukey(self, min_links: int = 5000, sr=None):
         """Tukey thresholds of the long-range table, outlier links and ARACNE pool left on the device
-        (analyse_long_range_links, R/lr_analyser.R:72-111)."""
+        (analyse_long_range_links, R/lr_analyser.R:72-111).  ``sr`` = (a, b, MI) of the REDUCED short-range links — the rows of
+        sr_links.tsv, which is what the reference pools with the long-range links (R/lr_analyser.R:67,106-109); None: no rows."""
         q13, thr = np.zeros(2), np.zeros(2)
         fb = C.c_int(0)
         nr, npool = C.c_int64(0), C.c_int64(0)
-        L.check(L.lib().ldw_lr_tukey(self._ctx, int(min_links), L.ptr(q13), L.ptr(thr), C.byref(fb), C.byref(nr), C.byref(npool)))
+        if sr is None:
+            sa = sb = smi = None
+            ns = 0
+        else:
+            sa, sb, smi = L.as_c(sr[0], np.int32), L.as_c(sr[1], np.int32), L.as_c(sr[2], np.float64)
+            ns = len(smi)
+            assert len(sa) == len(sb) == ns
+        L.check(L.lib().ldw_lr_tukey(self._ctx, int(min_links), L.ptr(sa), L.ptr(sb), L.ptr(smi), ns, L.ptr(q13), L.ptr(thr),
+                                     C.byref(fb), C.byref(nr), C.byref(npool)))
         self._n_red, self._n_pool = nr.value, npool.value
         return dict(q13=q13, thresholds=thr, fallback=bool(fb.value), n_red=nr.value, n_pool=npool.value)
 

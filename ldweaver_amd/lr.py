@@ -11,12 +11,24 @@ import pandas as pd
 from .rcompat import circ_len
 
 
-def analyse_long_range_links(eng, snp_dat, cds_var=None, are_lrlinks_ordered: bool = False, min_links: int = 5000) -> dict:
+SR_TSV_COLS = ["clust_c", "pos1", "pos2", "clust1", "clust2", "len", "MI", "srp_max", "ARACNE"]   # R/computePairwiseMI.R:140
+
+
+def analyse_long_range_links(eng, snp_dat, sr_links, cds_var=None, are_lrlinks_ordered: bool = False, min_links: int = 5000) -> dict:
     """Tukey outlier analysis + ARACNE of the long-range links the engine holds after ``perform_MI_computation`` /
-    ``mi_all_pairs`` (the reference reads them back from lr_links.tsv / sr_links.tsv).  Returns the reference's
-    ``lr_links_red`` (pos1 pos2 [clust1 clust2] len MI ARACNE, descending MI unless ``are_lrlinks_ordered``) plus the
-    thresholds.  Everything O(#links) runs on the device (ldw_lr_tukey, ldw_aracne_device)."""
-    info = eng.lr_tukey(min_links)
+    ``mi_all_pairs`` (the reference reads them back from lr_links.tsv).  ``sr_links`` is the short-range part of the ARACNE
+    pool exactly as the reference has it: the contents of sr_links.tsv (R/lr_analyser.R:67), i.e. the REDUCED frame
+    ``perform_MI_computation`` returned (srp_max > srp_cutoff) — pass that frame (pos1, pos2, MI columns) or the path of the
+    tsv.  Returns the reference's ``lr_links_red`` (pos1 pos2 [clust1 clust2] len MI ARACNE, descending MI unless
+    ``are_lrlinks_ordered``) plus the thresholds.  Everything O(#links) runs on the device (ldw_lr_tukey, ldw_aracne_device)."""
+    if isinstance(sr_links, (str, bytes)) or hasattr(sr_links, "__fspath__"):
+        sr_links = pd.read_csv(sr_links, sep="\t", header=None, names=SR_TSV_COLS)
+    POS_ = np.asarray(snp_dat.POS)
+    p1, p2 = np.asarray(sr_links["pos1"]), np.asarray(sr_links["pos2"])
+    sb_, sa_ = np.searchsorted(POS_, p1), np.searchsorted(POS_, p2)      # pos1 = to side (b), pos2 = from side (a)
+    if len(p1) and not (np.array_equal(POS_[np.minimum(sb_, len(POS_) - 1)], p1) and np.array_equal(POS_[np.minimum(sa_, len(POS_) - 1)], p2)):
+        raise ValueError("sr_links holds positions that are not SNP positions of snp_dat")
+    info = eng.lr_tukey(min_links, sr=(sa_, sb_, np.asarray(sr_links["MI"], dtype=np.float64)))
     if info["fallback"]:   # R/lr_analyser.R:96
         warnings.warn("Not enough lr links pass the Tukey criteria, ~5000 top links were retained instead")
     red = eng.lr_reduced()

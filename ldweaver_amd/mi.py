@@ -43,7 +43,8 @@ def lr_links_approx(POS, g, sr_dist, seed: int = 1988) -> float:
     idx = rcompat.RRandom(seed).sample(nsnp, snp_subset) - 1
     total = 0
     gi, si = float(g), float(sr_dist)
-    if nsnp > 2000 and np.all(np.diff(POS) >= 0) and gi == int(gi) and np.all(POS == np.rint(POS)) and 2 * si < gi:
+    if (nsnp > 2000 and np.all(np.diff(POS) >= 0) and gi == int(gi) and np.all(POS == np.rint(POS)) and 2 * si < gi
+            and POS[0] >= 0 and POS[-1] <= gi):
         # POS ascending, everything integral: len > sr_dist  <=>  the partner is outside [x - sr, x + sr] and outside
         # the two wrap-around windows; count the complement with binary searches (identical result, O(k log n))
         x = POS[idx]
@@ -63,7 +64,7 @@ def lr_links_approx(POS, g, sr_dist, seed: int = 1988) -> float:
 # a-4 estimate_Hamming_distance_weights            R/performPopulationStuctureCorrection.R:20-81
 # ---------------------------------------------------------------------------------------------
 def estimate_Hamming_distance_weights(snp_dat: SnpDat, threshold: float = 0.1, mega_dset: bool = False,
-                                      engine: Engine | None = None, alignment_resident: bool = False) -> np.ndarray:
+                                      engine: Engine | None = None, alignment_resident: bool = False, group=None) -> np.ndarray:
     t0 = time.time()
     thresh = int(snp_dat.nsnp * threshold)  # as.integer() truncates
     own = engine is None
@@ -72,15 +73,18 @@ def estimate_Hamming_distance_weights(snp_dat: SnpDat, threshold: float = 0.1, m
         if not alignment_resident:
             eng.set_alignment(snp_dat.states)
         world = 1
+        forced = os.environ.get("LDW_FORCE_COLLECTIVE", "0") not in ("", "0")
         try:
             import torch.distributed as tdist
             if tdist.is_available() and tdist.is_initialized():
-                world = tdist.get_world_size()
+                world = tdist.get_world_size(group)
+            else:
+                forced = False
         except ImportError:
-            pass
-        if world > 1:   # one process per GPU: every rank counts a strip of the sequence x sequence comparison
+            forced = False
+        if world > 1 or forced:   # one process per GPU: every rank counts a strip of the sequence x sequence comparison
             from .dist import hamming_weights_sharded
-            hdw = hamming_weights_sharded(eng, thresh)
+            hdw = hamming_weights_sharded(eng, thresh, group=group)
         else:
             hdw = eng.hamming_weights(thresh)
     finally:
@@ -130,6 +134,51 @@ def links_frame(a, b, mi, POS, paint, g) -> pd.DataFrame:
                          "len": rcompat.circ_len(pos1, pos2, g), "MI": mi})
 
 
+def _run_blocks(eng: Engine, blocks: np.ndarray, mine, kw: dict, POS, g: float) -> dict:
+    """Compute the block pairs ``blocks[mine]`` (make_blocks order) into the engine's link tables and return their
+    per-block statistics, one entry per block of ``mine``.  ``kw['sr_only']``: sites that form no link < sr_dist with the
+    other side of their block are dropped first and blocks left empty are skipped (R/computePairwiseMI.R:179-189)."""
+    mine = np.asarray(mine, dtype=np.int64)
+    keys = ("n_lr_total", "n_lr_kept", "n_sr", "disc_thresh")
+    out = {k: (np.full(len(mine), np.nan) if k == "disc_thresh" else np.zeros(len(mine), dtype=np.int64)) for k in keys}
+    if not kw["sr_only"]:
+        if len(mine):
+            eng.mi_all_pairs(blocks[mine], **kw)
+            return eng.block_stats()
+        eng.links_begin(1)   # a rank without blocks still holds (empty) link tables
+        eng.links_end()
+        return out
+    eng.links_begin(max(1, len(mine)))
+    POSf = np.asarray(POS, dtype=np.float64)
+    done = []
+    for j, (fs, fe, ts, te) in enumerate(blocks[mine]):
+        fi, ti = np.arange(fs - 1, fe), np.arange(ts - 1, te)
+        near = _near_mask(POSf[fi], POSf[ti], g, kw["sr_dist"])
+        fi, ti = fi[near[0]], ti[near[1]]
+        if len(fi) == 0 or len(ti) == 0:
+            continue
+        eng.mi_block_links(fi, ti, **kw)
+        done.append(j)
+    eng.links_end()
+    st = eng.block_stats()
+    for k in keys:
+        out[k][done] = st[k]
+    return out
+
+
+def _near_mask(pf: np.ndarray, pt: np.ndarray, g: float, sr_dist: float):
+    """(keep_from, keep_to): sites with at least one partner on the other side at circular distance < sr_dist
+    (the kp_f / kp_t of R/computePairwiseMI.R:182-183), in strips so that the nf x nt distance matrix is never whole."""
+    kf = np.zeros(len(pf), dtype=bool)
+    kt = np.zeros(len(pt), dtype=bool)
+    step = max(1, 8_000_000 // max(1, len(pt)))
+    for lo in range(0, len(pf), step):
+        near = np.abs(rcompat.circ_len(pt[None, :], pf[lo:lo + step, None], g)) < sr_dist
+        kf[lo:lo + step] = near.any(axis=1)
+        kt |= near.any(axis=0)
+    return kf, kt
+
+
 # ---------------------------------------------------------------------------------------------
 # a-5 perform_MI_computation                                      R/computePairwiseMI.R:46-145
 # ---------------------------------------------------------------------------------------------
@@ -162,68 +211,63 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
     max_blk_sz = rcompat.round_thousands(max_blk_sz)
     blocks = make_blocks(snp_dat.nsnp, max_blk_sz)
     POS, g, paint = snp_dat.POS, float(snp_dat.g), np.asarray(cds_var.paint)
+    if np.any(np.diff(np.asarray(POS, dtype=np.float64)) < 0):
+        # the reference's parser emits SNPs in alignment order, so snp.dat$POS ascends; the device path relies on it (the
+        # short-range band of a block is a contiguous index range)
+        raise ValueError("snp.dat$POS must be in ascending order: sort the SNPs (states, POS, r, uqe, paint) by position first")
     approx = None if perform_SR_analysis_only else lr_links_approx(POS, g, sr_dist)
 
     own = engine is None
     eng = engine or Engine(0)
     try:
-        if not alignment_resident:   # pass alignment_resident=True when `engine` already holds snp_dat.states
-            eng.set_alignment(snp_dat.states)
-        eng.set_weights(hdw, nlimbs)
-        eng.set_snp_meta(snp_dat.r, snp_dat.uqe, POS, paint, g)
+        def setup():
+            if not alignment_resident:   # pass alignment_resident=True when `engine` already holds snp_dat.states
+                eng.set_alignment(snp_dat.states)
+            eng.set_weights(hdw, nlimbs)
+            eng.set_snp_meta(snp_dat.r, snp_dat.uqe, POS, paint, g)
+
         kw = dict(sr_dist=sr_dist, lr_retain_links=lr_retain_links, lr_links_approx=approx or 1.0,
                   sr_only=perform_SR_analysis_only, quirk=quirk_mode)
         world, rank = 1, 0
+        forced = os.environ.get("LDW_FORCE_COLLECTIVE", "0") not in ("", "0")
         try:
             import torch.distributed as tdist
             if tdist.is_available() and tdist.is_initialized():
                 world, rank = tdist.get_world_size(group), tdist.get_rank(group)
-        except ImportError:
-            pass
-        if world > 1:
-            if perform_SR_analysis_only:
-                raise NotImplementedError("perform_SR_analysis_only is not sharded over ranks")
-            from .dist import deal_blocks, gather_block_stats, gather_link_tables
-            mine = deal_blocks(blocks, world)[rank]
-            if len(mine):
-                eng.mi_all_pairs(blocks[mine], **kw)
-                my_stats = eng.block_stats()
-                local = {"sr": eng.links(0, device_tensors=True), "lr": eng.links(1, device_tensors=True)}
             else:
-                import torch
-                dev = torch.device("cuda", eng.device)
-                e = lambda dt: torch.empty(0, dtype=dt, device=dev)
-                local = {k: (e(torch.int32), e(torch.int32), e(torch.float64)) for k in ("sr", "lr")}
-                my_stats = {k: np.zeros(0, dtype=np.float64 if k == "disc_thresh" else np.int64)
-                            for k in ("n_lr_total", "n_lr_kept", "n_sr", "disc_thresh")}
+                forced = False
+        except ImportError:
+            forced = False
+        if world > 1 or forced:
+            from .dist import agree, deal_blocks, gather_block_stats, gather_link_tables
+            mine = deal_blocks(blocks, world)[rank]
+            err, my_stats, local = None, None, None
+            try:
+                setup()
+                my_stats = _run_blocks(eng, blocks, mine, kw, POS, g)
+                local = {"sr": eng.links(0, device_tensors=True), "lr": eng.links(1, device_tensors=True)}
+            except Exception as e:   # the other ranks must learn of it before they enter the gather
+                err = e
+            try:
+                agree(err is None, group, "perform_MI_computation")
+            except RuntimeError as e:
+                raise e from err
             out = gather_link_tables(local, mine, {"sr": my_stats["n_sr"], "lr": my_stats["n_lr_kept"]}, len(blocks), group=group)
             stats = gather_block_stats(my_stats, mine, len(blocks), group=group)
             if rank != 0:
                 return None
             eng.links_import(0, *out["sr"])
             eng.links_import(1, *out["lr"])
-        elif not perform_SR_analysis_only:
-            eng.mi_all_pairs(blocks, **kw)
         else:
-            # drop sites that form no link < sr_dist with the other side (R/computePairwiseMI.R:179-189)
-            eng.links_begin(len(blocks))
-            POSf = np.asarray(POS, dtype=np.float64)
-            for fs, fe, ts, te in blocks:
-                fi, ti = np.arange(fs - 1, fe), np.arange(ts - 1, te)
-                ln = np.abs(rcompat.circ_len(POSf[ti][None, :], POSf[fi][:, None], g))
-                fi, ti = fi[(ln < sr_dist).any(axis=1)], ti[(ln < sr_dist).any(axis=0)]
-                if len(fi) == 0 or len(ti) == 0:
-                    continue
-                eng.mi_block_links(fi, ti, **kw)
-            eng.links_end()
+            setup()
+            stats = _run_blocks(eng, blocks, np.arange(len(blocks)), kw, POS, g)
         la, lb, lmi = eng.links(1)
-        if world == 1:
-            stats = eng.block_stats()
         if sr_model == "device":
             # mergeNsort_sr_links + runARACNE on the device-resident table; only the kept links come back
             redd, flags, model_aux = merge_n_sort_sr_links_device(eng, cds_var.nclust, sr_dist, srp_cutoff, POS, paint, g,
                                                                   run_aracne=runARACNE)
             pool = eng.sr_pool() if return_aux else None
+            fit_data = model_aux["fit_data"]
             sa, sb, smi = redd["a"], redd["b"], redd["MI"]
         elif sr_model == "host":
             sa, sb, smi = eng.links(0)
@@ -251,10 +295,16 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
             red["ARACNE"] = flags.astype(np.float64)
     else:
         sr_links = [sr[(sr["clust1"] == ci) | (sr["clust2"] == ci)] for ci in range(1, cds_var.nclust + 1)]
-        red, chk = merge_n_sort_sr_links(sr_links, cds_var.nclust, sr_dist, srp_cutoff)
+        fit_data = []
+        red, chk = merge_n_sort_sr_links(sr_links, cds_var.nclust, sr_dist, srp_cutoff, fit_data=fit_data)
         if runARACNE:
             say(f"Running ARACNE on {len(red)} links... ")
             red["ARACNE"] = aracne(red["pos1"], red["pos2"], red["MI"], chk["pos1"], chk["pos2"], chk["MI"]).astype(np.float64)
+    # the data of c<i>_fit_data.rds (saveRDS(maxvls), R/computePairwiseMI.R:439) as a tsv with a header; the png is out of scope
+    for ci, fd in enumerate(fit_data):
+        with open(os.path.join(plt_folder, f"c{ci + 1}_fit_data.tsv"), "w") as fh:
+            fh.write("len\tmax\tfit\n")
+        append_table(os.path.join(plt_folder, f"c{ci + 1}_fit_data.tsv"), [fd["len"].to_numpy(), fd["max"].to_numpy(), fd["fit"].to_numpy()])
     if not runARACNE:
         warnings.warn("ARACNE not run, all values will be set to 1")
         red["ARACNE"] = 1.0
@@ -263,5 +313,5 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
     append_table(sr_save_path, [red[c].to_numpy() for c in ["clust_c"] + COLS + ["srp_max", "ARACNE"]])
     say(f"All done in {round((time.time() - t000) / 60, 2)} mins ")
     if return_aux:   # not part of the reference's return value: the ARACNE pool and per-block statistics
-        return red, dict(sr_links_ARACNE_check=chk, block_stats=stats, lr_links_approx=approx)
+        return red, dict(sr_links_ARACNE_check=chk, block_stats=stats, lr_links_approx=approx, fit_data=fit_data)
     return red

@@ -133,6 +133,7 @@ def merge_n_sort_sr_links_device(eng, nclust: int, sr_dist: float, srp_cutoff: f
     S = qlo.shape[1]
     md = np.full((nclust, S), np.nan)
     lens = np.arange(1, S + 1, dtype=np.float64)
+    fit_data = []                                       # the maxvls table saved as c<i>_fit_data.rds (:422-439): len, max, fit
     for ci in range(nclust):
         has = cnt[ci] > 0
         n = cnt[ci][has].astype(np.float64)
@@ -142,6 +143,7 @@ def merge_n_sort_sr_links_device(eng, nclust: int, sr_dist: float, srp_cutoff: f
         maxvls = np.where((h > 0) & (hi != lo), (1 - h) * lo + h * hi, lo)
         mean_dist = fit_decay(lens[has], maxvls)
         md[ci, :len(mean_dist)] = mean_dist             # looked up by the VALUE of len (Q5)
+        fit_data.append(pd.DataFrame({"len": lens[has], "max": maxvls, "fit": mean_dist}))
     stats = eng.sr_excess_stats(md)
     shape = np.empty((nclust, 3))
     for ci in range(nclust):
@@ -155,11 +157,12 @@ def merge_n_sort_sr_links_device(eng, nclust: int, sr_dist: float, srp_cutoff: f
     key_cl = np.where(red["dup"], red["first_clust"], red["clust_c"])
     order = np.lexsort((red["row"], key_cl, red["dup"]))
     return {k: v[order] for k, v in red.items()}, flags[order], dict(mean_dist=md, shape=shape, stats=stats, n_pool=n_pool,
-                                                                     min_mi=min_mi, counts=cnt)
+                                                                     min_mi=min_mi, counts=cnt, fit_data=fit_data)
 
 
-def merge_n_sort_sr_links(sr_links: list, nclust: int, sr_dist: float, srp_cutoff: float):
-    """sr_links: list (one per cluster) of DataFrames with COLS.  Returns (sr_links_red, sr_links_ARACNE_check)."""
+def merge_n_sort_sr_links(sr_links: list, nclust: int, sr_dist: float, srp_cutoff: float, fit_data: list | None = None):
+    """sr_links: list (one per cluster) of DataFrames with COLS.  Returns (sr_links_red, sr_links_ARACNE_check); the per-cluster
+    ``maxvls`` tables (len, max, fit — the reference's c<i>_fit_data.rds, :422-439) are appended to ``fit_data`` when given."""
     from scipy import stats
     if nclust != len(sr_links):
         raise ValueError("Cluster mismatch detected, stopping!")
@@ -170,6 +173,8 @@ def merge_n_sort_sr_links(sr_links: list, nclust: int, sr_dist: float, srp_cutof
         # per-length 95th percentile (type 7 == pandas' linear interpolation), sorted by len   (:422)
         maxvls = t.groupby("len", sort=True)["MI"].quantile(0.95)
         mean_dist = fit_decay(maxvls.index.to_numpy(dtype=np.float64), maxvls.to_numpy())   # fastLm (:428-429)
+        if fit_data is not None:
+            fit_data.append(pd.DataFrame({"len": maxvls.index.to_numpy(dtype=np.float64), "max": maxvls.to_numpy(), "fit": mean_dist}))
         li = t["len"].to_numpy().astype(np.int64)                                  # positional index (Q5)
         ok = (li >= 1) & (li <= len(mean_dist))
         md = np.full(len(li), np.nan)

@@ -572,9 +572,10 @@ def neg_log_beta_sf(x, a: float, b: float) -> np.ndarray:
     return out
 
 
-def merge_n_sort_sr_links(sr_links_by_clust, nclust: int, sr_dist: float, srp_cutoff: float):
+def merge_n_sort_sr_links(sr_links_by_clust, nclust: int, sr_dist: float, srp_cutoff: float, fit_data=None):
     """Returns (sr_links_red, sr_links_ARACNE_check) as dicts of columns
-    clust_c,pos1,pos2,clust1,clust2,len,MI,srp_max.  Plot/RDS side outputs (:439-440) are not produced.
+    clust_c,pos1,pos2,clust1,clust2,len,MI,srp_max.  The plot (:440) is not produced; the table saved as
+    c<i>_fit_data.rds (maxvls: len, max, fit; :422-439) is appended per cluster to ``fit_data`` when a list is given.
     Reproduces Q5 (``mean_dist[len]`` positional indexing, :448) and Q6 (natural-log srp, :453)."""
     from scipy import stats
     cols = ["pos1", "pos2", "clust1", "clust2", "len", "MI"]
@@ -593,6 +594,8 @@ def merge_n_sort_sr_links(sr_links_by_clust, nclust: int, sr_dist: float, srp_cu
         Xd = np.column_stack([np.log(ulen), np.ones(len(ulen))])
         coef, *_ = np.linalg.lstsq(Xd, np.log(mx), rcond=None)
         mean_dist = np.exp(Xd @ coef)                                # (:429)
+        if fit_data is not None:
+            fit_data.append(dict(len=ulen.astype(np.float64), max=mx, fit=mean_dist))   # saveRDS(maxvls) (:439)
         # diff_dat = MI - mean_dist[len]   positional index by VALUE of len (Q5, :448)
         li = t["len"].astype(np.int64)                                # R truncates toward zero
         ok = (li >= 1) & (li <= len(mean_dist))
@@ -712,6 +715,7 @@ class MIResult:
     sr_links_by_clust: list = field(default_factory=list)
     blocks: list = field(default_factory=list)
     lr_links_approx: float = float("nan")
+    fit_data: list = field(default_factory=list)      # per cluster: the maxvls table of c<i>_fit_data.rds (:439)
 
 
 def perform_mi_computation(states, POS, g, r, uqe, hdw, paint, nclust, sr_dist=20000,
@@ -749,7 +753,7 @@ def perform_mi_computation(states, POS, g, r, uqe, hdw, paint, nclust, sr_dist=2
                    lr_links_approx=approx if approx is not None else float("nan"))
     if not do_srp:
         return res
-    red, chk = merge_n_sort_sr_links(sr_by_clust, nclust, sr_dist, srp_cutoff)
+    red, chk = merge_n_sort_sr_links(sr_by_clust, nclust, sr_dist, srp_cutoff, fit_data=res.fit_data)
     if run_aracne_flag:
         red["ARACNE"] = run_aracne(red["pos1"], red["pos2"], red["MI"],
                                    chk["pos1"], chk["pos2"], chk["MI"]).astype(np.float64)

@@ -74,7 +74,7 @@ perform_MI_computation <- function(snp.dat, hdw, cds_var, ncores, lr_save_path =
 # (R/computePairwiseMI.R:400-495): the O(#links) work runs in HBM, R keeps fastLm and fitdist.  Same rows, order and
 # columns as the reference's sr_links_red; use it instead of the to_df(res[[1]]) / mergeNsort_sr_links lines of
 # perform_MI_computation above when the table is too large to bring into R (config 5: 2.25e9 rows).
-mergeNsort_sr_links_device <- function(snp.dat, cds_var, sr_dist, srp_cutoff, runARACNE = TRUE) {
+mergeNsort_sr_links_device <- function(snp.dat, cds_var, sr_dist, srp_cutoff, runARACNE = TRUE, plt_path = NULL) {
   nclust <- cds_var$nclust
   S <- ceiling(sr_dist) - 1
   q <- .Call("ldwamd_sr_len_quantiles", as.integer(nclust), sr_dist, 0.95)
@@ -87,6 +87,8 @@ mergeNsort_sr_links_device <- function(snp.dat, cds_var, sr_dist, srp_cutoff, ru
     mx <- ifelse(h > 0 & qhi[ci, has] != qlo[ci, has], (1 - h) * qlo[ci, has] + h * qhi[ci, has], qlo[ci, has])
     mod <- RcppArmadillo::fastLm(cbind(log(has), 1), log(mx))                    # :428
     md[ci, seq_along(has)] <- exp(fitted(mod))                                   # looked up by the VALUE of len (:448)
+    if (!is.null(plt_path))                                                      # the maxvls table of the reference (:422-439)
+      saveRDS(object = data.frame(len = has, max = mx, fit = md[ci, seq_along(has)]), file = file.path(plt_path, paste("c", ci, "_fit_data.rds", sep = "")))
   }
   st <- matrix(.Call("ldwamd_sr_excess_stats", as.integer(nclust), as.numeric(t(md))), ncol = 5, byrow = TRUE)
   shape <- t(sapply(1:nclust, function(ci) {
@@ -106,8 +108,10 @@ mergeNsort_sr_links_device <- function(snp.dat, cds_var, sr_dist, srp_cutoff, ru
 
 # Numeric core of analyse_long_range_links (R/lr_analyser.R:72-118) on the tables the device holds after
 # perform_MI_computation(): lr_links_red with its ARACNE column, in the reference's order.
-analyse_long_range_links_device <- function(snp.dat, cds_var, are_lrlinks_ordered = F) {
-  r <- .Call("ldwamd_lr_tukey_aracne", 5000)
+# sr_links: the reduced short-range links, i.e. what sr_links.tsv holds / perform_MI_computation() returned (R/lr_analyser.R:67)
+analyse_long_range_links_device <- function(snp.dat, cds_var, sr_links, are_lrlinks_ordered = F) {
+  r <- .Call("ldwamd_lr_tukey_aracne", 5000, as.integer(match(sr_links$pos2, snp.dat$POS) - 1L), as.integer(match(sr_links$pos1, snp.dat$POS) - 1L),
+             as.numeric(sr_links$MI))
   if (r[[8]]) warning("Not enough lr links pass the Tukey criteria, ~5000 top links were retained instead")
   pos2 <- as.numeric(snp.dat$POS[r[[2]] + 1]); pos1 <- as.numeric(snp.dat$POS[r[[3]] + 1])
   df <- data.frame(pos1 = pos1, pos2 = pos2, clust1 = cds_var$paint[r[[3]] + 1], clust2 = cds_var$paint[r[[2]] + 1],

@@ -157,12 +157,15 @@ SEXP ldwamd_sr_pvalues_aracne(SEXP nclust, SEXP mean_dist, SEXP shape, SEXP srp_
 
 /* analyse_long_range_links (R/lr_analyser.R:72-111) on the device-resident tables:
  * list(row, a, b, MI, ARACNE, q13, thresholds, fallback) with the outlier links in lr-table order. */
-SEXP ldwamd_lr_tukey_aracne(SEXP min_links) {
+SEXP ldwamd_lr_tukey_aracne(SEXP min_links, SEXP sr_a, SEXP sr_b, SEXP sr_mi) {
+    /* sr_a / sr_b (INTSXP, 0-based SNP index of pos2 / pos1) and sr_mi (REALSXP): the rows of sr_links.tsv (sr_links_red) */
     ldw_ctx *c = ctx_or_stop();
     double q13[2], thr[2];
     int fallback = 0;
     int64_t n_red = 0, n_pool = 0;
-    CHK(ldw_lr_tukey(c, (int64_t)asReal(min_links), q13, thr, &fallback, &n_red, &n_pool));
+    if (XLENGTH(sr_a) != XLENGTH(sr_mi) || XLENGTH(sr_b) != XLENGTH(sr_mi)) error("ldweaver_amd: ragged short-range table");
+    CHK(ldw_lr_tukey(c, (int64_t)asReal(min_links), INTEGER(sr_a), INTEGER(sr_b), REAL(sr_mi), (int64_t)XLENGTH(sr_mi), q13, thr,
+                     &fallback, &n_red, &n_pool));
     const R_xlen_t n = (R_xlen_t)n_red;
     SEXP res = PROTECT(allocVector(VECSXP, 8));
     SEXP row = PROTECT(allocVector(REALSXP, n)), a = PROTECT(allocVector(INTSXP, n)), b = PROTECT(allocVector(INTSXP, n));
@@ -199,8 +202,81 @@ SEXP ldwamd_ldmap(SEXP reducer, SEXP from, SEXP to) {
     return htm;
 }
 
+/* ---- native-level twins of the reference's own .Call table (src/RcppExports.cpp:154-160): same symbol names, arity, argument
+ * types and return values, so that LDWeaver's UNCHANGED R code (.fastHadamard R/computePairwiseMI.R:396, .compareToRow :374,
+ * .vecPosMatch / .compareTriplet / .fast_intersect R/io_functions.R:125-155, .ACGTN2num R/computePairwiseMI.R:256-259) binds to
+ * this library when the shim is built as the package's native library (or loaded in its place). ---- */
+
+/* void fastHadamard(MIt, den, uq_t, pxy_t, pxpy_t, RXY, pXrX, pYrY, ncores): MIt updated IN PLACE over the linear index
+ * (src/computeMI.cpp:11-21); ncores accepted and ignored */
+SEXP _LDWeaver_fastHadamard(SEXP MIt, SEXP den, SEXP uq_t, SEXP pxy_t, SEXP pxpy_t, SEXP RXY, SEXP pXrX, SEXP pYrY, SEXP ncores) {
+    const R_xlen_t n = XLENGTH(MIt);
+    SEXP ops[7] = {den, uq_t, pxy_t, pxpy_t, RXY, pXrX, pYrY};
+    for (int k = 0; k < 7; ++k)
+        if (TYPEOF(ops[k]) != REALSXP || XLENGTH(ops[k]) < n) error("ldweaver_amd: .fastHadamard operand %d is not a numeric matrix of MIt's size", k + 2);
+    if (TYPEOF(MIt) != REALSXP) error("ldweaver_amd: .fastHadamard: MIt must be a numeric matrix");
+    (void)ncores;
+    CHK(ldw_fast_hadamard(ctx_or_stop(), REAL(MIt), REAL(den), REAL(uq_t), REAL(pxy_t), REAL(pxpy_t), REAL(RXY), REAL(pXrX), REAL(pYrY),
+                          (int64_t)n, 0));
+    return R_NilValue;
+}
+
+/* void ACGTN2num(nv, cv, ncores) (src/ACGTN2num_parallel.cpp:10-43) */
+SEXP _LDWeaver_ACGTN2num(SEXP nv, SEXP cv, SEXP ncores) { return ldwamd_ACGTN2num(nv, cv, ncores); }
+
+/* LogicalVector compareToRow(NumericMatrix x, NumericVector y) (src/computeMI.cpp:25-41) */
+SEXP _LDWeaver_compareToRow(SEXP x, SEXP y) {
+    if (TYPEOF(x) != REALSXP || TYPEOF(y) != REALSXP) error("ldweaver_amd: .compareToRow takes a numeric matrix and a numeric vector");
+    SEXP dim = getAttrib(x, R_DimSymbol);
+    if (dim == R_NilValue || LENGTH(dim) != 2) error("ldweaver_amd: .compareToRow: x must be a matrix");
+    const int64_t nr = INTEGER(dim)[0], nc = INTEGER(dim)[1];
+    unsigned char *f8 = (unsigned char *)R_alloc((size_t)nr + 1, 1);
+    CHK(ldw_compare_to_row(REAL(x), nr, nc, REAL(y), (int64_t)XLENGTH(y), f8));
+    SEXP out = PROTECT(allocVector(LGLSXP, (R_xlen_t)nr));
+    for (int64_t j = 0; j < nr; ++j) LOGICAL(out)[j] = f8[j] ? TRUE : FALSE;
+    UNPROTECT(1);
+    return out;
+}
+
+/* NumericVector vecPosMatch(NumericVector x, NumericVector y) (src/computeMI.cpp:44-59) */
+SEXP _LDWeaver_vecPosMatch(SEXP x, SEXP y) {
+    if (TYPEOF(x) != REALSXP || TYPEOF(y) != REALSXP) error("ldweaver_amd: .vecPosMatch takes numeric vectors");
+    SEXP out = PROTECT(allocVector(REALSXP, XLENGTH(x)));
+    CHK(ldw_vec_pos_match(REAL(x), (int64_t)XLENGTH(x), REAL(y), (int64_t)XLENGTH(y), REAL(out)));
+    UNPROTECT(1);
+    return out;
+}
+
+/* bool compareTriplet(NumericVector MI0X, NumericVector MI0Z, double MI0) (src/computeMI.cpp:63-77) */
+SEXP _LDWeaver_compareTriplet(SEXP MI0X, SEXP MI0Z, SEXP MI0) {
+    if (TYPEOF(MI0X) != REALSXP || TYPEOF(MI0Z) != REALSXP || XLENGTH(MI0X) != XLENGTH(MI0Z)) error("ldweaver_amd: .compareTriplet: MI0X and MI0Z must be numeric vectors of one length");
+    int r = 0;
+    CHK(ldw_compare_triplet(REAL(MI0X), REAL(MI0Z), (int64_t)XLENGTH(MI0X), asReal(MI0), &r));
+    return ScalarLogical(r);
+}
+
+/* std::vector<int> fast_intersect(std::vector<int> A, std::vector<int> B) (src/fintersect.cpp:6-32); Rcpp coerces numeric input
+ * to int the same way (truncation) */
+SEXP _LDWeaver_fast_intersect(SEXP A, SEXP B) {
+    SEXP a = PROTECT(coerceVector(A, INTSXP)), b = PROTECT(coerceVector(B, INTSXP));
+    const int64_t na = XLENGTH(a), nb = XLENGTH(b), cap = na < nb ? na : nb;
+    int32_t *buf = (int32_t *)R_alloc((size_t)cap + 1, sizeof(int32_t));
+    int64_t n = 0;
+    CHK(ldw_fast_intersect(INTEGER(a), na, INTEGER(b), nb, buf, &n));
+    SEXP out = PROTECT(allocVector(INTSXP, (R_xlen_t)n));
+    if (n > 0) memcpy(INTEGER(out), buf, (size_t)n * sizeof(int32_t));
+    UNPROTECT(3);
+    return out;
+}
+
 static const R_CallMethodDef CallEntries[] = {
-    {"ldwamd_lr_tukey_aracne", (DL_FUNC)&ldwamd_lr_tukey_aracne, 1},
+    {"_LDWeaver_ACGTN2num", (DL_FUNC)&_LDWeaver_ACGTN2num, 3},
+    {"_LDWeaver_fastHadamard", (DL_FUNC)&_LDWeaver_fastHadamard, 9},
+    {"_LDWeaver_compareToRow", (DL_FUNC)&_LDWeaver_compareToRow, 2},
+    {"_LDWeaver_vecPosMatch", (DL_FUNC)&_LDWeaver_vecPosMatch, 2},
+    {"_LDWeaver_compareTriplet", (DL_FUNC)&_LDWeaver_compareTriplet, 3},
+    {"_LDWeaver_fast_intersect", (DL_FUNC)&_LDWeaver_fast_intersect, 2},
+    {"ldwamd_lr_tukey_aracne", (DL_FUNC)&ldwamd_lr_tukey_aracne, 4},
     {"ldwamd_ldmap", (DL_FUNC)&ldwamd_ldmap, 3},
     {"ldwamd_sr_len_quantiles", (DL_FUNC)&ldwamd_sr_len_quantiles, 3},
     {"ldwamd_sr_excess_stats", (DL_FUNC)&ldwamd_sr_excess_stats, 2},

@@ -104,8 +104,14 @@ def _toy_links(seed=0, n=4000):
 def test_srp_model_matches_oracle():
     df = _toy_links()
     by_clust = [df[(df.clust1 == ci) | (df.clust2 == ci)] for ci in (1, 2)]
-    red, chk = srp.merge_n_sort_sr_links(by_clust, 2, 20000, 1.0)
-    ored, ochk = orc.merge_n_sort_sr_links([{k: d[k].to_numpy() for k in srp.COLS} for d in by_clust], 2, 20000, 1.0)
+    fd, ofd = [], []
+    red, chk = srp.merge_n_sort_sr_links(by_clust, 2, 20000, 1.0, fit_data=fd)
+    ored, ochk = orc.merge_n_sort_sr_links([{k: d[k].to_numpy() for k in srp.COLS} for d in by_clust], 2, 20000, 1.0, fit_data=ofd)
+    assert len(fd) == len(ofd) == 2                      # the maxvls table of c<i>_fit_data.rds (R/computePairwiseMI.R:422-439)
+    for a, b in zip(fd, ofd):
+        assert list(a.columns) == ["len", "max", "fit"] and np.array_equal(a["len"].to_numpy(), b["len"])
+        np.testing.assert_allclose(a["max"].to_numpy(), b["max"], rtol=1e-12)
+        np.testing.assert_allclose(a["fit"].to_numpy(), b["fit"], rtol=1e-10)
     assert len(red) == len(ored["MI"]) > 10 and len(chk) == len(ochk["MI"])
     for k in ("clust_c", "pos1", "pos2", "clust1", "clust2", "len", "MI"):
         assert np.array_equal(red[k].to_numpy(dtype=float), np.asarray(ored[k], dtype=float)), k
@@ -172,3 +178,25 @@ def test_lr_links_approx_fast_path_equals_brute_force():
     for n, g, sr in ((5000, 2_221_315, 20000), (3000, 60_001, 20000), (2500, 50_000, 12000)):
         POS = np.sort(rng.choice(g, n, replace=False) + 1)
         assert MI.lr_links_approx(POS, g, sr) == orc.lr_links_approx(POS, g, sr)
+
+
+def test_near_mask_equals_the_references_site_filter():
+    """perform_SR_analysis_only's kp_f / kp_t (R/computePairwiseMI.R:182-183), computed in strips."""
+    rng = np.random.default_rng(5)
+    g, sr = 100000.0, 40.0
+    pf = np.sort(rng.integers(1, 100001, 900)).astype(np.float64)
+    pt = np.sort(rng.integers(1, 100001, 1100)).astype(np.float64)
+    kf, kt = MI._near_mask(pf, pt, g, sr)
+    ln = np.abs(orc.circ_len(pt[None, :], pf[:, None], g))
+    assert np.array_equal(kf, (ln < sr).any(axis=1)) and np.array_equal(kt, (ln < sr).any(axis=0))
+    assert 0 < kf.sum() < len(kf)
+
+
+def test_unsorted_positions_are_refused_with_a_clear_message(tmp_path):
+    from ldweaver_amd.snpdat import CdsVar, SnpDat
+    st = np.zeros((4, 8), dtype=np.uint8)
+    st[:, ::2] = 1
+    sd = SnpDat.from_states(st, np.array([10, 30, 20, 40]), 100.0)
+    with pytest.raises(ValueError, match="ascending"):
+        MI.perform_MI_computation(sd, np.ones(8), CdsVar(paint=np.ones(4, dtype=np.int32), nclust=1),
+                                   lr_save_path=str(tmp_path / "l"), sr_save_path=str(tmp_path / "s"), plt_folder=str(tmp_path / "p"))

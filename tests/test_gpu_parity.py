@@ -1,10 +1,12 @@
 """GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
 inputs, against the committed golden fixtures, and — at BASELINE.json's sizes — through size-independent properties.
 Bars: integer / index work bit-exact; MI within 1e-6 (north_star), typically ~1e-12 (weight quantisation)."""
+import json
 import os
 import sys
 
 import numpy as np
+import pandas as pd
 import pytest
 
 import c_oracle
@@ -273,6 +275,14 @@ def test_perform_mi_computation_end_to_end(engine, sample, tmp_path):
     assert len(first) == 6 and float(first[0]) == ref.lr_rows["pos1"][0] and abs(float(first[5]) - ref.lr_rows["MI"][0]) < 1e-9
     srl = open(sr_p).read().splitlines()
     assert len(srl) == len(red) and len(srl[0].split("\t")) == 9
+    # the maxvls table the reference saves as c<i>_fit_data.rds (len, 95th percentile of MI at that len, fitted decay; :422-439)
+    assert len(aux["fit_data"]) == len(ref.fit_data) == 3
+    for ci, (fd, ofd) in enumerate(zip(aux["fit_data"], ref.fit_data)):
+        assert np.array_equal(fd["len"].to_numpy(), ofd["len"]) and len(fd) > 100
+        assert np.abs(fd["max"].to_numpy() - ofd["max"]).max() < MI_TIGHT
+        assert np.abs(fd["fit"].to_numpy() / ofd["fit"] - 1).max() < 1e-8
+        tsv = pd.read_csv(tmp_path / "plots" / f"c{ci + 1}_fit_data.tsv", sep="\t")
+        assert list(tsv.columns) == ["len", "max", "fit"] and len(tsv) == len(fd)
 
 
 @pytest.mark.parametrize("max_blk_sz", [10000, 1000])
@@ -577,15 +587,21 @@ def _tables_as_dicts(engine, POS):
 @pytest.mark.parametrize("min_links", [5000, 300])
 def test_lr_tukey_and_aracne_match_oracle(engine, synth, min_links):
     """analyse_long_range_links' numeric core on the device-resident tables (quantiles type 7,
-    Tukey thresholds, the top-links fallback, outlier set, ARACNE against rbind(lr, sr)[MI > thr]) vs the oracle."""
+    Tukey thresholds, the top-links fallback, outlier set, ARACNE against rbind(lr, sr)[MI > thr]) vs the oracle.  The sr
+    part of the pool is what sr_links.tsv holds — the REDUCED short-range set (R/lr_analyser.R:67, R/computePairwiseMI.R:140),
+    here a strict subset of the engine's raw short-range table so that pooling the raw table would be noticed."""
     _setup(engine, synth)
     POS, g = synth["POS"], synth["g"]
     approx = orc.lr_links_approx(POS, g, 20000.0)
     engine.mi_all_pairs(np.array(orc.make_blocks(512, 200), dtype=np.int32), 20000.0, 6000.0, approx)
-    lr, sr = _tables_as_dicts(engine, POS)
+    lr, sr_all = _tables_as_dicts(engine, POS)
     assert len(lr["MI"]) >= 5000
+    keep = (np.arange(len(sr_all["MI"])) * 2654435761 % 7) < 3           # stands for srp_max > srp_cutoff
+    sr = {k: v[keep] for k, v in sr_all.items()}
     ref = orc.analyse_long_range_links({k: lr[k] for k in ("pos1", "pos2", "MI")}, sr, min_links=min_links)
-    info = engine.lr_tukey(min_links)
+    ref_all = orc.analyse_long_range_links({k: lr[k] for k in ("pos1", "pos2", "MI")}, sr_all, min_links=min_links)
+    assert ref_all["n_pool"] > ref["n_pool"]                             # the raw table would pool more rows
+    info = engine.lr_tukey(min_links, sr=(sr["a"], sr["b"], sr["MI"]))
     assert info["fallback"] == ref["fallback"] == (min_links == 5000)
     assert np.array_equal(info["q13"], ref["q13"]) and np.array_equal(info["thresholds"], ref["thresholds"])   # same order statistics, same arithmetic
     assert info["n_red"] == len(ref["rows"]) > 0 and info["n_pool"] == ref["n_pool"]
@@ -599,7 +615,8 @@ def test_lr_tukey_and_aracne_match_oracle(engine, synth, min_links):
     from ldweaver_amd import lr as LR
     sd = SnpDat(states=synth["states"], POS=POS, g=g, uqe=synth["uqe"], r=synth["r"])
     with pytest.warns(UserWarning) if ref["fallback"] else np.errstate():
-        out = LR.analyse_long_range_links(engine, sd, CdsVar(paint=synth["paint"], nclust=3), min_links=min_links)
+        out = LR.analyse_long_range_links(engine, sd, pd.DataFrame({k: sr[k] for k in ("pos1", "pos2", "MI")}),
+                                          CdsVar(paint=synth["paint"], nclust=3), min_links=min_links)
     df = out["lr_links_red"]
     assert list(df.columns) == ["pos1", "pos2", "clust1", "clust2", "len", "MI", "ARACNE"]
     assert np.array_equal(df["pos1"].to_numpy(), ref["red"]["pos1"]) and np.array_equal(df["ARACNE"].to_numpy().astype(bool), ref["ARACNE"])
@@ -679,11 +696,75 @@ def test_perform_mi_computation_two_ranks(engine, sample, tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert (one / "lr_links.tsv").read_bytes() == (two / "lr_links.tsv").read_bytes()
-    red2 = pd.read_pickle(two / "red.pkl")
+    _frames_equal(red1, pd.read_pickle(two / "red.pkl"))
+
+
+def _frames_equal(red1, red2):
     assert list(red1.columns) == list(red2.columns) and len(red1) == len(red2) > 0
     for c in red1.columns:
         a, b = red1[c].to_numpy(), red2[c].to_numpy()
         assert np.array_equal(a, b) if a.dtype.kind in "iub" else np.allclose(a, b, rtol=0, atol=1e-9), c
+
+
+def _torchrun(nproc, port, script, *args, timeout=300, env=None):
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(os.path.dirname(__file__), script), *map(str, args)]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_sr_only_two_ranks(engine, sample, tmp_path):
+    """perform_SR_analysis_only under 2 ranks (R/computePairwiseMI.R:179-189 per block, blocks dealt over the ranks, blocks
+    left without sites skipped on their owner): frame and sr file equal the single-process run's, no lr file is written."""
+    import pandas as pd
+    sd = SnpDat.from_states(sample["states"], sample["POS"], sample["g"])
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir()
+    two.mkdir()
+    red1 = MIH.perform_MI_computation(sd, sample["hdw"], CdsVar(paint=sample["paint"], nclust=3), ncores=1,
+                                      lr_save_path=str(one / "lr_links.tsv"), sr_save_path=str(one / "sr_links.tsv"),
+                                      plt_folder=str(one / "PLOTS"), max_blk_sz=1000, lr_retain_links=1e5, engine=engine, verbose=False,
+                                      perform_SR_analysis_only=True, sr_dist=3000, quirk_mode=L.QUIRK_INTENDED)
+    r = _torchrun(2, 29535, "dist_worker.py", two, "sr_only")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert not (one / "lr_links.tsv").exists() and not (two / "lr_links.tsv").exists()
+    assert (one / "sr_links.tsv").read_bytes() == (two / "sr_links.tsv").read_bytes()
+    _frames_equal(red1, pd.read_pickle(two / "red.pkl"))
+
+
+def test_failing_rank_is_agreed_on(tmp_path):
+    """One rank cannot compute its share: every rank raises (one all-reduce of a status flag before the gather) instead of
+    the healthy ranks waiting in a collective for ever."""
+    r = _torchrun(2, 29537, "dist_worker.py", tmp_path, "fail", timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m0, m1 = (tmp_path / "raised_0.txt").read_text(), (tmp_path / "raised_1.txt").read_text()
+    assert "failed on rank(s) [1]" in m0 and "failed on rank(s) [1]" in m1, (m0, m1)
+
+
+def test_rccl_single_rank_walk(engine, sample, tmp_path):
+    """The RCCL branch of every dist.py function on GPU tensors (backend "nccl", one rank, collectives forced) and
+    perform_MI_computation / estimate_Hamming_distance_weights on top of it: same files and frame as without torch.distributed."""
+    import subprocess
+    import pandas as pd
+    sd = SnpDat.from_states(sample["states"], sample["POS"], sample["g"])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "rccl_worker.py"), str(tmp_path)], env=env,
+                       capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.load(open(tmp_path / "report.json"))
+    assert rep["backend"] == "nccl" and rep["gather_rows"]["sr"] > 0
+    for tag, sr_only in (("full", False), ("sr", True)):
+        one = tmp_path / f"one_{tag}"
+        one.mkdir()
+        red1 = MIH.perform_MI_computation(sd, sample["hdw"], CdsVar(paint=sample["paint"], nclust=3), ncores=1,
+                                          lr_save_path=str(one / "lr.tsv"), sr_save_path=str(one / "sr.tsv"), plt_folder=str(one / "P"),
+                                          max_blk_sz=1000, lr_retain_links=1e5, engine=engine, verbose=False,
+                                          perform_SR_analysis_only=sr_only, sr_dist=(3000 if sr_only else 20000), quirk_mode=L.QUIRK_INTENDED)
+        _frames_equal(red1, pd.read_pickle(tmp_path / f"red_{tag}.pkl"))
+        assert (one / "sr.tsv").read_bytes() == (tmp_path / f"sr_{tag}.tsv").read_bytes()
+        if not sr_only:
+            assert (one / "lr.tsv").read_bytes() == (tmp_path / "lr_full.tsv").read_bytes()
 
 
 def test_screen_and_mixed_paths_on_multiallelic_alignment(engine):
@@ -742,22 +823,49 @@ def test_screen_and_mixed_paths_on_multiallelic_alignment(engine):
     assert np.abs(Mg[np.ix_([0, 3, 500, 999], [0, 500, 999])] - Mo).max() < MI_TIGHT
 
 
-@pytest.mark.parametrize("Ls,N", [(100_000, 5_000), (85_000, 616)])
-def test_full_size_properties(engine, Ls, N):
-    """BASELINE config 4 at FULL size (100k SNPs x 5k sequences, 55 block pairs, the bench's workload) and the shape of
-    config 3 (616 genomes; the real alignment is not available offline, SURVEY 8c: synthetic of matching shape, ragged
-    last block column, N not a multiple of 64) through size-independent properties: every pair is accounted for exactly once, the long-range rows of every block are in the
-    reference's row order and above the block's threshold, ~lr_retain_links survive, sampled rows of both tables equal the
-    oracle's per-pair MI, and the default path (mixed precision + screen) equals the plain one bit for bit."""
+def _table_digest(a, b, mi):
+    """Order-sensitive 64-bit digest of a device-resident link table (wrapping int64 arithmetic): equal tables, equal digest."""
     import torch
+    n = len(mi)
+    if n == 0:
+        return (0, 0, 0, 0)
+    acc = [0, 0, 0]
+    step = 1 << 27
+    for lo in range(0, n, step):
+        w = (torch.arange(lo, min(n, lo + step), device=mi.device, dtype=torch.int64) % 1000003) + 1
+        acc[0] += int((a[lo:lo + step].long() * w).sum())
+        acc[1] += int((b[lo:lo + step].long() * w).sum())
+        acc[2] += int((mi[lo:lo + step].view(torch.int64) * w).sum())
+    return (n,) + tuple(x & 0xFFFFFFFFFFFFFFFF for x in acc)
+
+
+@pytest.mark.parametrize("Ls,N", [(100_000, 5_000), (85_000, 616), (500_000, 10_000)])
+def test_full_size_properties(engine, Ls, N):
+    """BASELINE config 4 at FULL size (100k SNPs x 5k sequences, 55 block pairs, the bench's workload), the shape of
+    config 3 (616 genomes; the real alignment is not available offline, SURVEY 8c: synthetic of matching shape, ragged
+    last block column, N not a multiple of 64) and config 5 at FULL size (500k SNPs x 10k sequences on ONE GPU: 1275 block pairs, 1.25e11
+    pairs, a 2.25e9-row short-range table) through size-independent properties: every pair is accounted for exactly once, the
+    long-range rows of every block are in the reference's row order and above the block's threshold, ~lr_retain_links survive,
+    sampled rows of both tables equal the oracle's per-pair MI, sampled Hamming weights equal a direct count, and the default
+    path (screen + approximate / mixed-precision GEMM) equals the plain one (5-limb GEMM, fp64 for every pair) bit for bit.
+    Config 5 then runs the device short-range model + ARACNE on its table (invariants; a re-run is bit-identical)."""
+    import torch
+    big = Ls >= 500_000
     syn = synth_alignment(Ls, N, seed=1988, device="cuda", as_numpy=False)
     st_dev = syn["states"]
     engine.set_alignment(st_dev)
     cnt = engine.state_counts()
     uqe = (cnt > 0).T.astype(np.float64)
     r = uqe.sum(axis=1)
-    hdw = engine.hamming_weights(int(Ls * 0.1))
+    thresh = int(Ls * 0.1)
+    hdw = engine.hamming_weights(thresh)
     assert 0 < hdw.min() and hdw.max() <= 1.0
+    # Hamming weights against a direct count for sampled sequences (R/performPopulationStuctureCorrection.R:23,76)
+    for j in np.random.default_rng(3).integers(0, N, 6):
+        diff = torch.zeros(N, dtype=torch.int64, device=st_dev.device)
+        for lo in range(0, Ls, 50_000):
+            diff += (st_dev[lo:lo + 50_000] != st_dev[lo:lo + 50_000, int(j)][:, None]).sum(0)
+        assert hdw[j] == 1.0 / (int((diff < thresh).sum()) + 1.0), j
     engine.set_weights(hdw)
     POS, g = syn["POS"], float(syn["g"])
     engine.set_snp_meta(r, uqe, POS, syn["paint"], g)
@@ -765,31 +873,39 @@ def test_full_size_properties(engine, Ls, N):
     blocks = MIH.make_blocks(Ls, 10000)
     out = {}
     info = engine.apx_info()
-    variants = dict(plain=(False, 0, 1), mixed=(True, 1, 1), fast=(True, 1, 0))   # fast = the default configuration
+    variants = dict(plain=(False, 0, 1), mixed=(True, 1, 1), fast=(True, 1, 0))   # fast = the default configuration (last: its tables stay)
     for key, (mixed, scr, path) in variants.items():
         engine.set_mixed(mixed)
         engine.set_screen(scr)
         engine.set_path(path)
         c0 = engine.counters()
-        for _ in range(2):
+        for _ in range(1 if (big and key != "fast") else 2):
             engine.mi_all_pairs(blocks, 20000.0, 1e6, approx)
         c1 = engine.counters()
-        out[key] = (engine.links(0, device_tensors=True), engine.links(1), engine.block_stats(), {k: c1[k] - c0[k] for k in c1})
+        sr_t = engine.links(0, device_tensors=True)
+        out[key] = (None if big else sr_t, engine.links(1), engine.block_stats(), {k: c1[k] - c0[k] for k in c1}, _table_digest(*sr_t))
+        if big and key != "fast":
+            del sr_t
+            torch.cuda.empty_cache()
     engine.set_mixed(True)
     engine.set_screen(1)
     engine.set_path(0)
-    if Ls == 100_000:   # few weight classes (clonal groups): the default is the approximate-GEMM path
-        assert info["usable"] and out["fast"][3]["apx_blocks"] >= len(blocks) and out["fast"][3]["spec_misses"] <= 2
+    if Ls >= 100_000:   # few weight classes (clonal groups): the default is the approximate-GEMM path
+        assert info["usable"] and out["fast"][3]["apx_blocks"] >= len(blocks) and out["fast"][3]["spec_misses"] <= (2 if not big else 40)
     for key in ("mixed", "fast"):
-        for x, y in zip(out["plain"][0], out[key][0]):
-            assert torch.equal(x, y), key
+        assert out["plain"][4] == out[key][4], key
+        if not big:
+            for x, y in zip(out["plain"][0], out[key][0]):
+                assert torch.equal(x, y), key
         for x, y in zip(out["plain"][1], out[key][1]):
             assert np.array_equal(x, y), key
-    sr, (la, lb, lmi), stt, _ = out["fast"]
+    _, (la, lb, lmi), stt, _, _ = out["fast"]
+    sr = sr_t
     pairs = sum(nf * (nf - 1) // 2 if (fs, fe) == (ts, te) else nf * nt - min(nf, nt)
                 for fs, fe, ts, te in blocks.tolist() for nf, nt in [(fe - fs + 1, te - ts + 1)])
     assert int(stt["n_sr"].sum() + stt["n_lr_total"].sum()) == pairs
-    assert pairs == (4_999_500_000 if Ls == 100_000 else Ls * (Ls - 1) // 2 - sum(min(fe - fs, te - ts) + 1 for fs, fe, ts, te in blocks.tolist() if fs != ts))
+    assert pairs == ({100_000: 4_999_500_000, 500_000: 124_987_500_000}.get(Ls) or
+                     Ls * (Ls - 1) // 2 - sum(min(fe - fs, te - ts) + 1 for fs, fe, ts, te in blocks.tolist() if fs != ts))
     assert len(sr[2]) == int(stt["n_sr"].sum()) and len(lmi) == int(stt["n_lr_kept"].sum())
     assert 0.95e6 < len(lmi) < 1.05e6          # prob = 1 - lr_retain_links / lr_links_approx keeps ~1e6 in total
     off = 0
@@ -809,15 +925,81 @@ def test_full_size_properties(engine, Ls, N):
     # sampled rows against the oracle's per-pair MI with the RXY the reference reads (Q1: linear index of the nt x nf matrix)
     rng = np.random.default_rng(9)
     blk_of = lambda idx: idx // 10000
-    for tab_a, tab_b, tab_m in ((la, lb, lmi), tuple(t.cpu().numpy() for t in sr)):
+    for tab_a, tab_b, tab_m in ((la, lb, lmi), sr):
         for k in rng.integers(0, len(tab_m), 12):
-            a, b = int(tab_a[k]), int(tab_b[k])
+            a, b, mk = int(tab_a[k]), int(tab_b[k]), float(tab_m[k])
             rows = st_dev[[a, b]].cpu().numpy()
             fa, tb = blk_of(a) * 10000, blk_of(b) * 10000
             nfb, ntb = min(10000, Ls - fa), min(10000, Ls - tb)
             rxy = orc.q1_rxy(a - fa, b - tb, nfb, ntb, r[fa:fa + nfb], r[tb:tb + ntb])
             ref = orc.mi_pair_direct(rows, hdw, r[[a, b]], uqe[[a, b]], 0, 1, rxy)
-            assert abs(tab_m[k] - ref) < MI_TIGHT, (a, b, tab_m[k], ref)
+            assert abs(mk - ref) < MI_TIGHT, (a, b, mk, ref)
+    if not big:
+        return
+    # ---- config 5: the short-range model and ARACNE on the device-resident 2.25e9-row table ----
+    paint = np.asarray(syn["paint"])
+    S = int(np.ceil(20000.0)) - 1
+    pos_t, paint_t = torch.as_tensor(np.asarray(POS, dtype=np.int64), device=st_dev.device), torch.as_tensor(paint.astype(np.int64), device=st_dev.device)
+    want = torch.zeros((3, S + 1), dtype=torch.int64, device=st_dev.device)
+    n_sr = len(sr[2])
+    for lo in range(0, n_sr, 1 << 27):     # counts per (cluster, len) straight from the table: sum over clusters >= n_sr
+        a_, b_ = sr[0][lo:lo + (1 << 27)].long(), sr[1][lo:lo + (1 << 27)].long()
+        d = (pos_t[b_] - pos_t[a_]) % int(g)
+        ln = torch.minimum(d, int(g) - d)
+        ok = (ln > 0) & (ln < 20000)
+        for ci in (1, 2, 3):
+            m = ok & ((paint_t[a_] == ci) | (paint_t[b_] == ci))
+            want[ci - 1] += torch.bincount(ln[m], minlength=S + 1)[:S + 1]
+        del a_, b_, d, ln, ok, m
+    runs = []
+    for _ in range(2):
+        redd, flags, aux = srp_host.merge_n_sort_sr_links_device(engine, 3, 20000.0, 3.0, POS, paint, g, run_aracne=True)
+        runs.append((redd, flags, aux))
+    redd, flags, aux = runs[0]
+    assert np.array_equal(aux["counts"], want[:, 1:].cpu().numpy()) and int(aux["counts"].sum()) >= n_sr
+    assert set(np.unique(flags).tolist()) <= {False, True} and len(flags) == len(redd["MI"]) > 0
+    assert (redd["srp_max"] > 3.0).all() and aux["n_pool"] >= len(flags)
+    for k in redd:
+        assert np.array_equal(redd[k], runs[1][0][k]), k
+    assert np.array_equal(flags, runs[1][1])
+    # the kept rows are rows of the table
+    rows = torch.as_tensor(redd["row"][:1000], device=st_dev.device)
+    assert np.array_equal(sr[0][rows].cpu().numpy(), redd["a"][:1000]) and np.array_equal(sr[2][rows].cpu().numpy(), redd["MI"][:1000])
+
+
+def test_link_tables_regrow_mid_call(synth):
+    """DevBuf::reserve_keep (ldw_api.hip) under load: a FRESH context whose link tables start empty takes blocks one by one
+    (ldw_mi_block_links sizes the tables per block, so the short-range and long-range tables are reallocated — and their rows
+    copied — several times while earlier blocks' rows are already in them), then a larger all-pairs call after a smaller one
+    (stale row counts from the previous call).  Tables must equal those of the driver that sizes the short-range table up front."""
+    d = synth
+    POS, g = d["POS"], d["g"]
+    approx = orc.lr_links_approx(POS, g, 20000.0)
+    blocks = np.array(orc.make_blocks(512, 100), dtype=np.int32)     # 15 block pairs, ascending table sizes
+    with Engine(0) as ref:
+        _setup(ref, d)
+        ref.mi_all_pairs(blocks, 2000.0, 60000.0, approx, quirk=L.QUIRK_INTENDED)
+        want = (ref.links(0), ref.links(1))
+    with Engine(0) as eng:
+        _setup(eng, d)
+        eng.links_begin(len(blocks))
+        for fs, fe, ts, te in blocks:
+            eng.mi_block_links(np.arange(fs - 1, fe), np.arange(ts - 1, te), sr_dist=2000.0, lr_retain_links=60000.0, lr_links_approx=approx,
+                               quirk=L.QUIRK_INTENDED)
+        eng.links_end()
+        got = (eng.links(0), eng.links(1))
+        for w, g_ in zip(want, got):
+            assert len(w[2]) > 500
+            for x, y in zip(w, g_):
+                assert np.array_equal(x, y)
+        # a small call, then the large one in the same context: the tables grow again with the previous call's counts around
+        eng.mi_all_pairs(blocks[:2], 2000.0, 60000.0, approx, quirk=L.QUIRK_INTENDED)
+        small = eng.links_count(0)
+        eng.mi_all_pairs(blocks, 2000.0, 60000.0, approx, quirk=L.QUIRK_INTENDED)
+        assert 0 < small < eng.links_count(0)
+        for w, g_ in zip(want, (eng.links(0), eng.links(1))):
+            for x, y in zip(w, g_):
+                assert np.array_equal(x, y)
 
 
 def test_hamming_counts_strips_add_up(engine, sample, synth):

@@ -59,7 +59,7 @@ def run_matrix(base: str, combos=COMBOS, timeout: int = 900, log=print):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--base", default="--L 30000 --N 2000 --steps 2 --warmup 1 --no-cpu-baseline")
+    ap.add_argument("--base", default="--L 30000 --N 2000 --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs")
     ap.add_argument("--only", default=None, help="comma-separated indices into the combination list")
     ap.add_argument("--out", default=None)
     ap.add_argument("--timeout", type=int, default=900)
