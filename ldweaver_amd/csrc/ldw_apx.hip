@@ -507,7 +507,7 @@ int launch_pairs_exact(ldw_ctx *c, const EpiArgs &A, unsigned long long *ghist, 
     LDW_REQUIRE(lds <= 65536, LDW_ERR_ARG, "launch_pairs_exact: %d weight segments do not fit in LDS", P.nseg);
     hipLaunchKernelGGL(k_pair_sums<false>, dim3(256, PAIR_SHARDS, 4), dim3(256), lds, st, P);
     hipLaunchKernelGGL(k_pair_sums<true>, dim3(256, PAIR_SHARDS, 1), dim3(256), lds, st, P);
-    hipLaunchKernelGGL(k_pair_mi, dim3(16, PAIR_SHARDS, PAIR_PATHS), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_pair_mi, dim3(64, PAIR_SHARDS, PAIR_PATHS), dim3(256), 0, st, P);
     LDW_HIP(hipGetLastError());
     return LDW_OK;
 }

@@ -488,7 +488,7 @@ int ldw_sr_len_quantiles(ldw_ctx *c, int nclust, double sr_dist, double prob, in
                        c->sr_mi.as<double>(), n, c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, sr_dist, pack, key);
     // Two stable LSD sorts, both over the FULL width of their key type: by MI (u64 keys, tags as values), then by len
     // (u16 keys, {MI key, tag} as values) -> ordered by (len, MI).  rocPRIM 7.2's merge-sort path mis-sorts u32 keys on a
-    // partial bit range at mid sizes (tools/scratch/sorttest.hip), so no begin_bit/end_bit tricks here.
+    // partial bit range at mid sizes (reproduced standalone with hipcub::DeviceRadixSort::SortKeys), so no begin_bit/end_bit tricks here.
     if (int rc = c->srm_pay.reserve((size_t)n * sizeof(SrPay))) return rc;
     if (int rc = c->srm_pay2.reserve((size_t)n * sizeof(SrPay))) return rc;
     uint16_t *len16 = reinterpret_cast<uint16_t *>(pack), *len16b = len16 + n;   // pack is free after the first sort
