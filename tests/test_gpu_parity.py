@@ -224,6 +224,53 @@ def test_lr_quantile_filter_exact(engine, synth):
         assert off == len(mi)
 
 
+@pytest.mark.parametrize("variant", ["default", "plain", "limb_paths", "fused"])
+def test_threshold_ties_match_oracle_exactly(engine, sample, variant):
+    """Ties at a block's long-range threshold (R/computePairwiseMI.R:352-358: `MI >= quantile(MI, prob)`): the reference's
+    sample alignment is clonal — a third of its links sit in groups of pairs with identical joint tables, and several blocks'
+    thresholds fall INSIDE such a group.  The reference keeps or drops a group as one (bitwise-equal MI, `>=`); so must we:
+    the emitted fp64 MI is a pure function of the slot-ordered joint table (same cell order and arithmetic in every kernel
+    variant), hence the retained (a, b) set of every block equals the oracle's EXACTLY — no tolerance for threshold ties —
+    on every execution path, cold and warm."""
+    _setup(engine, sample)
+    POS, g = sample["POS"], sample["g"]
+    approx = orc.lr_links_approx(POS, g, 20000.0)
+    blocks = np.array(orc.make_blocks(1268, 300), dtype=np.int32)      # 5 x 5 grid, 15 block pairs, ragged last column
+    cfg = dict(default=(True, 1, 0, False), plain=(False, 0, 1, False), limb_paths=(True, 1, 1, False), fused=(True, 1, 1, True))[variant]
+    engine.set_mixed(cfg[0])
+    engine.set_screen(cfg[1])
+    engine.set_path(cfg[2])
+    engine.set_fused(cfg[3])
+    try:
+        runs = []
+        for _ in range(2):      # cold (no bucket guesses), then warm (speculative blocks: screen / approximate / fused paths)
+            engine.mi_all_pairs(blocks, 20000.0, 40000.0, approx)
+            runs.append((engine.links(1), engine.block_stats()))
+    finally:
+        engine.set_mixed(True)
+        engine.set_screen(1)
+        engine.set_path(0)
+        engine.set_fused(False)
+    tied_blocks = 0
+    for (a, b, mi), st in runs:
+        off = 0
+        for bi, (fs, fe, ts, te) in enumerate(blocks.tolist()):
+            fi, ti = np.arange(fs - 1, fe), np.arange(ts - 1, te)
+            Mb = c_oracle.mi_block(sample["states"], sample["hdw"], sample["r"], sample["uqe"], fi, ti)
+            bl = orc.block_links(Mb, fi, ti, POS, sample["paint"], g, 20000.0, 40000.0, approx)
+            n = len(bl.lr["MI"])
+            assert st["n_lr_kept"][bi] == n, (variant, bi, int(st["n_lr_kept"][bi]), n)
+            assert np.array_equal(a[off:off + n], bl.lr["a"]) and np.array_equal(b[off:off + n], bl.lr["b"]), (variant, bi)
+            if n and (bl.lr["MI"] == bl.lr["MI"].min()).sum() > 1 and (Mb == bl.lr["MI"].min()).sum() > 1:
+                tied_blocks += 1       # the smallest kept value is shared by several pairs: a tie group sits on the threshold
+                # (our groups can only be coarser than the reference's: equal slot-ordered tables give equal bits here, while the
+                # reference's fixed A,C,G,T,N summation order separates relabelled copies in the last bit)
+                assert (mi[off:off + n] == mi[off:off + n].min()).sum() >= (bl.lr["MI"] == bl.lr["MI"].min()).sum()
+            off += n
+        assert off == len(mi)
+    assert tied_blocks >= 4, tied_blocks
+
+
 def test_perform_mi_computation_end_to_end(engine, sample, tmp_path):
     """Drop-in entry point with the reference's signature: returned frame and both tsv files vs the oracle's a-5 loop
     (srp model: same optimiser on both sides; parity with R's fitdist is unpinned)."""
