@@ -139,6 +139,7 @@ struct ldw_ctx {
     ldw::DevBuf scr_units;       // uint32 count (64-B slot) + list of the block's units the fp32 screen wants evaluated exactly
     ldw::DevBuf hist[2], cand_key[2], cand_val[2];   // per pipeline slot: histogram of the lr candidates, candidate list
     ldw::DevBuf colcnt, cand_key2, cand_val2, scratch, small;
+    ldw::DevBuf sel_bitmap, sel_chunks, sel_prefix;   // fast selection (k_sel_thresh): bitmap, chunk and super-chunk (sel_prefix) counters, all-zero between blocks
 
     // ---- link tables (device resident) ----
     ldw::DevBuf sr_a, sr_b, sr_mi, lr_a, lr_b, lr_mi;

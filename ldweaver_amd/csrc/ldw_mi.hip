@@ -688,6 +688,7 @@ struct PickOut {
     long long n_kept;           // filled by k_lr_thresh
     double disc_thresh;
     long long kstart;
+    long long n_below_true;     // pairs in buckets below B_true
 };
 
 // prob and quantile ranks of R/computePairwiseMI.R:352-354 (stats::quantile type 7), then the bucket
@@ -748,6 +749,7 @@ __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *_
             out->B = t * PER + k;
             out->B_true = t * PER + k;
             out->n_below = cum;
+            out->n_below_true = cum;
         }
         cum += loc[k];
     }
@@ -859,6 +861,258 @@ __global__ void k_lr_append(const uint64_t *__restrict__ okey, const uint64_t *_
     out_a[dst] = idx_f[a_loc];
     out_b[dst] = idx_t[b_loc];
     out_mi[dst] = key_f64(oval[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Selection without a sort (the common case: <= 32768 candidates above the guessed bucket), four small launches:
+//   k_sel_thresh  ONE workgroup, every thread keeps 32 MI keys in registers.  The two order statistics of quantile type 7 by an
+//                 11-bit-digit RADIX SELECT (6 passes, an LDS histogram each; a wave first folds the lanes that share its first
+//                 lane's bin into one LDS atomic, because the top digits of the candidates nearly all coincide), the smallest key
+//                 above for x[hi], the threshold with R's own rule.
+//   k_sel_mark    one thread per candidate: every kept candidate sets its bit in a BITMAP over the block's row-order key space
+//                 (bit = segment * nf * nt + a + b * nf) and counts itself in its 1024-bit chunk and its 65536-bit super-chunk.
+//   k_sel_scatter one thread per candidate: rank = (super-chunks before, scanned per workgroup in LDS) + (chunks before, in the
+//                 super-chunk) + (bits before, in the chunk) = the row's position in the reference's row order
+//                 (R/computePairwiseMI.R:306-331: upper rows column-major, then lower) -> written straight to its final place.
+//   k_sel_clear   zeroes the bitmap words and counters that were touched (all three arrays stay all-zero between blocks).
+// Same results as the two radix sorts of the general path, which stays for blocks without a bucket guess, speculation misses,
+// more candidates and key spaces beyond 2^32 bits.
+// ------------------------------------------------------------------------------------------------
+constexpr int SEL_CHUNK_BITS = 1024, SEL_CHUNK_WORDS = SEL_CHUNK_BITS / 32, SEL_SUPER = 64;   // super-chunk = 64 chunks
+constexpr int SEL_DIGIT = 11, SEL_BINS = 1 << SEL_DIGIT;
+constexpr int SEL_MAX = 1 << 20;          // candidates the sort-free path takes
+constexpr int SEL_MAX_SUPER = 8192;       // super-chunks a scatter workgroup can scan in LDS: key spaces up to 2^29 bits
+
+__device__ __forceinline__ uint64_t sel_order_key(uint64_t cv, uint64_t space) {   // cv = seg << 62 | (a + b * nf)
+    return (cv >> 62) * space + (cv & 0x3FFFFFFFFFFFFFFFull);
+}
+
+constexpr int SEL_LIST = 6144;   // keys of the threshold's bucket a k_sel_thresh workgroup keeps in LDS (more: it re-reads the global list)
+
+__global__ __launch_bounds__(1024) void k_sel_thresh(const uint64_t *__restrict__ ckey, PickOut *__restrict__ pick) {
+    __shared__ uint64_t list[SEL_LIST];
+    __shared__ unsigned int hist[SEL_BINS];
+    __shared__ unsigned int wsum[16];
+    __shared__ unsigned int s_n;
+    __shared__ unsigned long long s_prefix, s_min, s_above;
+    __shared__ long long s_k, s_less, s_eq;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const PickOut o = *pick;
+    const long long m = (long long)o.n_cand;
+    if (o.n <= 0 || m <= 0 || o.B_true >= NBINS) {
+        if (t == 0) {
+            pick->n_kept = 0;
+            pick->kstart = -1;     // (as a key: above every candidate)
+        }
+        return;
+    }
+    // Phase A: the keys of the bucket that holds rank lo (the histogram that found it counts with the same mi_bucket) go to the
+    // LDS list; the smallest key of the buckets above is x[hi] when rank hi leaves the bucket.  8 loads in flight per thread.
+    if (t == 0) {
+        s_n = 0u;
+        s_above = ~0ull;
+        s_prefix = 0ull;
+        s_k = o.lo - o.n_below_true - 1;     // 0-based rank of x[lo] inside its bucket
+        s_less = 0;
+        s_eq = 0;
+    }
+    __syncthreads();
+    unsigned long long above = ~0ull;
+    for (long long base = 0; base < m; base += 8 * 1024) {
+        uint64_t k8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long i = base + (long long)j * 1024 + t;
+            k8[j] = i < m ? ckey[i] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long i = base + (long long)j * 1024 + t;
+            const int bk = i < m ? mi_bucket(key_f64(k8[j])) : -1;
+            if (bk > o.B_true && k8[j] < above) above = k8[j];
+            const bool in = bk == o.B_true;
+            const unsigned long long mk = __ballot(in);
+            if (mk == 0ull) continue;
+            unsigned int pos = 0;
+            if (lane == __builtin_ctzll(mk)) pos = atomicAdd(&s_n, (unsigned int)__popcll(mk));
+            pos = (unsigned int)__shfl((int)pos, __builtin_ctzll(mk)) + (unsigned int)__popcll(mk & ((1ull << lane) - 1ull));
+            if (in && pos < SEL_LIST) list[pos] = k8[j];
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long y = __shfl_xor(above, d);
+        above = y < above ? y : above;
+    }
+    if (lane == 0) atomicMin(&s_above, above);
+    __syncthreads();
+    const unsigned int n_in = s_n;
+    const bool in_lds = n_in <= SEL_LIST;
+    // visit every key of the bucket: the LDS list, or (huge tie groups) the global list once more
+    auto n_items = [&]() -> long long { return in_lds ? (long long)n_in : m; };
+    auto item = [&](long long i, uint64_t &k) -> bool {
+        if (in_lds) {
+            k = list[i];
+            return true;
+        }
+        k = ckey[i];
+        return mi_bucket(key_f64(k)) == o.B_true;
+    };
+    // Phase B: radix select of rank s_k among them, 11-bit digits from the top
+    uint64_t mask = 0ull;
+    const long long n_it = n_items();
+    for (int pass = 0; pass < 6; ++pass) {
+        const int shift = pass < 5 ? 64 - SEL_DIGIT * (pass + 1) : 0;     // 53, 42, 31, 20, 9, then the last 9 bits
+        const unsigned int dmask = pass < 5 ? (unsigned int)SEL_BINS - 1u : 511u;
+        for (int i = t; i < SEL_BINS; i += 1024) hist[i] = 0u;
+        __syncthreads();
+        const uint64_t prefix = s_prefix;
+        for (long long i0 = 0; i0 < n_it; i0 += 1024) {
+            const long long i = i0 + t;
+            uint64_t k = 0ull;
+            const bool in = i < n_it && item(i, k) && (k & mask) == prefix;
+            const unsigned int bin = (unsigned int)(k >> shift) & dmask;
+            const unsigned long long act = __ballot(in);
+            if (act == 0ull) continue;
+            const unsigned int b0 = (unsigned int)__shfl((int)bin, __builtin_ctzll(act));
+            const unsigned long long same = __ballot(in && bin == b0);      // the top digits nearly all coincide: one atomic for them
+            if (in && bin == b0) {
+                if (lane == __builtin_ctzll(same)) atomicAdd(&hist[b0], (unsigned int)__popcll(same));
+            } else if (in) {
+                atomicAdd(&hist[bin], 1u);
+            }
+        }
+        __syncthreads();
+        // the bin that holds rank s_k: every thread owns two adjacent bins
+        const unsigned int h0 = hist[2 * t], h1 = hist[2 * t + 1];
+        unsigned int x = h0 + h1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        unsigned int base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        const long long incl = (long long)base + x, excl = incl - (h0 + h1), k = s_k;
+        __syncthreads();
+        if (k >= excl && k < incl) {        // exactly one thread
+            const int b = (k < excl + h0) ? 0 : 1;
+            const long long before = excl + (b ? h0 : 0);
+            s_prefix = prefix | ((uint64_t)(2 * t + b) << shift);
+            s_k = k - before;
+            s_less += before;
+            s_eq = b ? h1 : h0;
+        }
+        __syncthreads();
+        mask |= (uint64_t)dmask << shift;
+    }
+    const uint64_t v_lo = s_prefix;                  // key of rank lo; s_less keys of the bucket are smaller, s_eq equal
+    uint64_t v_hi = v_lo;
+    const long long r_in = o.lo - o.n_below_true - 1;
+    if (o.hi > o.lo && r_in + 1 >= s_less + s_eq) {  // x[hi] is the smallest key above v_lo: in the bucket, or the first one above it
+        if (t == 0) s_min = s_above;
+        __syncthreads();
+        unsigned long long mn = ~0ull;
+        for (long long i0 = 0; i0 < n_it; i0 += 1024) {
+            const long long i = i0 + t;
+            uint64_t k = 0ull;
+            if (i < n_it && item(i, k) && k > v_lo && k < mn) mn = k;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const unsigned long long y = __shfl_xor(mn, d);
+            mn = y < mn ? y : mn;
+        }
+        if (lane == 0) atomicMin(&s_min, mn);
+        __syncthreads();
+        v_hi = s_min;
+    }
+    if (t == 0) {
+        const double xlo = key_f64(v_lo), xhi = key_f64(v_hi);
+        double qs = xlo;
+        if (o.index > (double)o.lo && xhi != qs) {   // stats::quantile type 7 (the interpolation is skipped on a tie)
+            const double h = o.index - (double)o.lo;
+            qs = (1.0 - h) * qs + h * xhi;
+        }
+        pick->disc_thresh = qs;
+        pick->n_kept = 0;                            // counted by k_sel_mark
+        pick->kstart = (long long)f64_key(qs);       // (reused: the threshold key, read by the kernels below)
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sel_mark(const uint64_t *__restrict__ ckey, const uint64_t *__restrict__ cval, PickOut *__restrict__ pick,
+                                                  uint64_t space, uint32_t *__restrict__ bitmap, uint32_t *__restrict__ chunk_cnt,
+                                                  uint32_t *__restrict__ super_cnt) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const bool keep = i < (long long)pick->n_cand && ckey[i] >= (uint64_t)pick->kstart;
+    if (keep) {
+        const uint64_t ok = sel_order_key(cval[i], space);
+        atomicOr(&bitmap[ok >> 5], 1u << (ok & 31));
+        atomicAdd(&chunk_cnt[ok / SEL_CHUNK_BITS], 1u);
+        atomicAdd(&super_cnt[ok / (SEL_CHUNK_BITS * SEL_SUPER)], 1u);
+    }
+    const unsigned long long mk = __ballot(keep);
+    if (mk != 0ull && (threadIdx.x & 63) == __builtin_ctzll(mk)) atomicAdd((unsigned long long *)&pick->n_kept, (unsigned long long)__popcll(mk));
+}
+
+__global__ __launch_bounds__(256) void k_sel_scatter(const uint64_t *__restrict__ ckey, const uint64_t *__restrict__ cval, const PickOut *__restrict__ pick,
+                                                     uint64_t space, const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ chunk_cnt,
+                                                     const uint32_t *__restrict__ super_cnt, int n_super, const int32_t *__restrict__ idx_f,
+                                                     const int32_t *__restrict__ idx_t, int nf, const int64_t *__restrict__ lr_count,
+                                                     int32_t *__restrict__ out_a, int32_t *__restrict__ out_b, double *__restrict__ out_mi) {
+    __shared__ unsigned int spre[SEL_MAX_SUPER];
+    __shared__ unsigned int wtot[4];
+    // exclusive scan of the super-chunk counters, per workgroup: strips of consecutive counters per thread
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (n_super + 255) / 256, s0 = t * per, s1 = s0 + per < n_super ? s0 + per : n_super;
+    unsigned int sum = 0;
+    for (int q = s0; q < s1; ++q) sum += super_cnt[q];
+    unsigned int x = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) wtot[wave] = x;
+    __syncthreads();
+    unsigned int run = x - sum;
+    for (int w = 0; w < wave; ++w) run += wtot[w];
+    for (int q = s0; q < s1; ++q) {
+        spre[q] = run;
+        run += super_cnt[q];
+    }
+    __syncthreads();
+    const long long i = blockIdx.x * (long long)blockDim.x + t;
+    if (i >= (long long)pick->n_cand) return;
+    const uint64_t k = ckey[i];
+    if (k < (uint64_t)pick->kstart) return;
+    const uint64_t cv = cval[i], ok = sel_order_key(cv, space);
+    const uint64_t chunk = ok / SEL_CHUNK_BITS, sup = chunk / SEL_SUPER, w_end = ok >> 5;
+    unsigned int rank = spre[sup];
+    for (uint64_t q = sup * SEL_SUPER; q < chunk; ++q) rank += chunk_cnt[q];
+    for (uint64_t w = chunk * SEL_CHUNK_WORDS; w < w_end; ++w) rank += __popc(bitmap[w]);
+    rank += __popc(bitmap[w_end] & ((1u << (ok & 31)) - 1u));
+    if ((long long)rank >= pick->n_kept) return;   // (cannot happen; never write past the rows reserved for this block)
+    const uint64_t c = cv & 0x3FFFFFFFFFFFFFFFull;
+    const int a_loc = (int)(c % (uint64_t)nf), b_loc = (int)(c / (uint64_t)nf);
+    const int64_t dst = *lr_count + rank;
+    out_a[dst] = idx_f[a_loc];
+    out_b[dst] = idx_t[b_loc];
+    out_mi[dst] = key_f64(k);
+}
+
+__global__ __launch_bounds__(256) void k_sel_clear(const uint64_t *__restrict__ ckey, const uint64_t *__restrict__ cval, const PickOut *__restrict__ pick,
+                                                   uint64_t space, uint32_t *__restrict__ bitmap, uint32_t *__restrict__ chunk_cnt,
+                                                   uint32_t *__restrict__ super_cnt) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= (long long)pick->n_cand) return;
+    if (ckey[i] < (uint64_t)pick->kstart) return;
+    const uint64_t ok = sel_order_key(cval[i], space);
+    bitmap[ok >> 5] = 0u;
+    chunk_cnt[ok / SEL_CHUNK_BITS] = 0u;
+    super_cnt[ok / (SEL_CHUNK_BITS * SEL_SUPER)] = 0u;
 }
 
 // running device-side counters and per-block stats
@@ -1991,7 +2245,33 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
     const char *d = c->dstage[s].as<char>();
     const int32_t *idx_f = reinterpret_cast<const int32_t *>(d + hb.o_idx_f), *idx_t = reinterpret_cast<const int32_t *>(d + hb.o_idx_t);
     uint64_t *ck = c->cand_key[s].as<uint64_t>(), *cv = c->cand_val[s].as<uint64_t>();
-    if (do_lr && m > 0) {
+    const uint64_t sel_space = (uint64_t)hb.nf * (uint64_t)hb.nt;
+    static const bool sel_fast_on = getenv("LDW_NO_FAST_SELECT") == nullptr;
+    const long long n_words = (long long)((2 * sel_space + 31) / 32) + 1, n_chunks = (long long)((2 * sel_space + SEL_CHUNK_BITS - 1) / SEL_CHUNK_BITS) + 1;
+    const long long n_super_ll = (n_chunks + SEL_SUPER - 1) / SEL_SUPER;
+    if (do_lr && m > 0 && sel_fast_on && m <= SEL_MAX && n_super_ll <= SEL_MAX_SUPER) {
+        // the common case: radix select + bitmap ranks, four small launches, no sort (k_sel_thresh)
+        if (int rc = ensure_links_capacity(c, c->n_sr, c->n_lr + m)) return rc;
+        const int n_super = (int)n_super_ll;
+        if ((size_t)n_words * 4 > c->sel_bitmap.cap || (size_t)n_chunks * 4 > c->sel_chunks.cap || (size_t)n_super * 4 > c->sel_prefix.cap) {
+            // first use / a larger block: fresh zeroes
+            if (int rc = c->sel_bitmap.reserve((size_t)n_words * 4)) return rc;
+            if (int rc = c->sel_chunks.reserve((size_t)n_chunks * 4)) return rc;
+            if (int rc = c->sel_prefix.reserve((size_t)SEL_MAX_SUPER * 4)) return rc;
+            LDW_HIP(hipMemsetAsync(c->sel_bitmap.p, 0, c->sel_bitmap.cap, c->stream));
+            LDW_HIP(hipMemsetAsync(c->sel_chunks.p, 0, c->sel_chunks.cap, c->stream));
+            LDW_HIP(hipMemsetAsync(c->sel_prefix.p, 0, c->sel_prefix.cap, c->stream));
+        }
+        uint32_t *bm = c->sel_bitmap.as<uint32_t>(), *cc = c->sel_chunks.as<uint32_t>(), *sc = c->sel_prefix.as<uint32_t>();
+        const unsigned gridm = (unsigned)((m + 255) / 256);
+        hipLaunchKernelGGL(k_sel_thresh, dim3(1), dim3(1024), 0, c->stream, ck, sl.pick[s]);
+        hipLaunchKernelGGL(k_sel_mark, dim3(gridm), dim3(256), 0, c->stream, ck, cv, sl.pick[s], sel_space, bm, cc, sc);
+        hipLaunchKernelGGL(k_sel_scatter, dim3(gridm), dim3(256), 0, c->stream, ck, cv, sl.pick[s], sel_space, bm, cc, sc, n_super, idx_f, idx_t, (int)nf,
+                           sl.lr_count, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), c->lr_mi.as<double>());
+        hipLaunchKernelGGL(k_sel_clear, dim3(gridm), dim3(256), 0, c->stream, ck, cv, sl.pick[s], sel_space, bm, cc, sc);
+        LDW_HIP(hipGetLastError());
+        c->n_lr += m;  // upper bound; the exact value is *lr_count
+    } else if (do_lr && m > 0) {
         LDW_REQUIRE(m < 2147483647LL, LDW_ERR_SIZE, "too many quantile candidates (%lld)", (long long)m);
         if (int rc = ensure_links_capacity(c, c->n_sr, c->n_lr + m)) return rc;
         if (int rc = c->cand_key2.reserve((size_t)m * 8)) return rc;
