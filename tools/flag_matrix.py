@@ -29,6 +29,7 @@ COMBOS = [
     "--path 2",
     "--path 2 --screen 2",
     "--path 2 --no-overlap",
+    "--engine hist",
 ]
 
 
