@@ -450,42 +450,88 @@ __global__ __launch_bounds__(256) void k_pair_sums(PairArgs P) {
     }
 }
 
+// Emission of the listed pairs.  Nearly all of them ARE candidates (they sit in the few buckets just above the guess), so one
+// returning atomic on the candidate counter plus one histogram atomic per pair made the kernel a queue at two or three
+// addresses of the L2 (100 us for 7e4 pairs; 14 us with the atomics compiled out): a wave bumps the counter ONCE for all its
+// candidates, and the bucket counts go through a workgroup-local window of PAIR_HWIN buckets in LDS, flushed at the end.
+constexpr int PAIR_HWIN = 128;
+
 template <int NA, int NB>   // NA = 0: any slot counts (predicated code)
-__device__ __forceinline__ void pair_mi_body(const PairArgs &P, int path) {
+__device__ __forceinline__ void pair_mi_body(const PairArgs &P, int path, unsigned int *s_hist) {
     constexpr bool GEN = NA == 0;
     const EpiArgs &A = P.A;
+    const EmitArgs &E = A.E;
     const int sub = path * PAIR_SHARDS + (int)blockIdx.y;
     unsigned int n = A.pl_n[sub];
     n = n > A.pl_cap ? A.pl_cap : n;
     const bool square = A.nf == A.nt;
     const PairEnt *list = A.pl_pairs + (int64_t)sub * A.pl_cap;
-    for (unsigned int idx = blockIdx.x * 256u + threadIdx.x; idx < n; idx += gridDim.x * 256u) {
-        const uint32_t t = list[idx].t, q = list[idx].q;
-        const RowPack &RP = A.rowpack[t];
-        if (RP.a_loc < 0) continue;
-        const RowSide R = RP.R;
-        const int a_loc = RP.a_loc;
-        const ColMeta M = A.colpack[q];
-        const int b_loc = M.bl;
-        const int64_t *sp = P.sums + ((int64_t)sub * A.pl_cap + idx) * 16;
-        double mi;
-        if constexpr (GEN) {
-            mi = pair_mi<4, 4>(A, R, M, a_loc, b_loc, square, gacc_plain(sp, 1, 4));
-        } else {
-            mi = pair_mi_full<NA, NB>(A, R, M, a_loc, b_loc, square, gacc_plain(sp, 1, 4));
+    const int lane = (int)(threadIdx.x & 63);
+    // wave-uniform trip count: every lane stays in the loop, so the ballots below see the whole wave
+    for (unsigned int base = blockIdx.x * 256u + (threadIdx.x & ~63u); base < n; base += gridDim.x * 256u) {
+        const unsigned int idx = base + (unsigned int)lane;
+        bool valid = idx < n;
+        uint32_t t = 0, q = 0;
+        if (valid) {
+            t = list[idx].t;
+            q = list[idx].q;
         }
-        emit_pair_spec(A.E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, P.ghist);
+        const RowPack &RP = A.rowpack[t];
+        valid = valid && RP.a_loc >= 0;
+        bool cand = false;
+        int bk = 0, seg = -1, a_loc = 0, b_loc = 0;
+        double mi = 0.0;
+        if (valid) {
+            const RowSide R = RP.R;
+            a_loc = RP.a_loc;
+            const ColMeta M = A.colpack[q];
+            b_loc = M.bl;
+            const int64_t *sp = P.sums + ((int64_t)sub * A.pl_cap + idx) * 16;
+            if constexpr (GEN) {
+                mi = pair_mi<4, 4>(A, R, M, a_loc, b_loc, square, gacc_plain(sp, 1, 4));
+            } else {
+                mi = pair_mi_full<NA, NB>(A, R, M, a_loc, b_loc, square, gacc_plain(sp, 1, 4));
+            }
+            seg = pair_seg(a_loc, b_loc, E.lower_only);
+            if (seg >= 0 && E.any_sr && col_is_sr(M.ci, a_loc)) {
+                emit_pair_spec(E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, P.ghist);   // (a short-range pair is never listed; kept for exactness)
+            } else if (seg >= 0 && E.do_lr && mi >= E.spec_lo) {
+                bk = mi_bucket(mi);
+                cand = bk >= E.spec_B;
+            }
+        }
+        const unsigned long long mk = __ballot(cand);
+        if (mk == 0ull) continue;
+        const int leader = __builtin_ctzll(mk);
+        unsigned long long pos = 0;
+        if (lane == leader) pos = atomicAdd(E.n_cand, (unsigned long long)__popcll(mk));
+        pos = __shfl(pos, leader);
+        if (cand) {
+            pos += (unsigned long long)__popcll(mk & ((1ull << lane) - 1ull));
+            E.ckey[pos] = f64_key(mi);
+            E.cval[pos] = ((uint64_t)seg << 62) | ((uint64_t)a_loc + (uint64_t)b_loc * (uint64_t)E.nf);
+            const int w = bk - (E.spec_B > 0 ? E.spec_B : 0);
+            if (w < PAIR_HWIN) atomicAdd(&s_hist[w], 1u);
+            else atomicAdd(&P.ghist[bk], 1ull);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void k_pair_mi(PairArgs P) {
+    __shared__ unsigned int s_hist[PAIR_HWIN];
+    if (threadIdx.x < PAIR_HWIN) s_hist[threadIdx.x] = 0u;
+    __syncthreads();
     switch (blockIdx.z) {
-        case 0: pair_mi_body<1, 1>(P, 0); break;
-        case 1: pair_mi_body<2, 1>(P, 1); break;
-        case 2: pair_mi_body<1, 2>(P, 2); break;
-        case 3: pair_mi_body<2, 2>(P, 3); break;
-        default: pair_mi_body<0, 0>(P, 4); break;
+        case 0: pair_mi_body<1, 1>(P, 0, s_hist); break;
+        case 1: pair_mi_body<2, 1>(P, 1, s_hist); break;
+        case 2: pair_mi_body<1, 2>(P, 2, s_hist); break;
+        case 3: pair_mi_body<2, 2>(P, 3, s_hist); break;
+        default: pair_mi_body<0, 0>(P, 4, s_hist); break;
     }
+    __syncthreads();
+    const int hb0 = P.A.E.spec_B > 0 ? P.A.E.spec_B : 0;
+    if (threadIdx.x < PAIR_HWIN && s_hist[threadIdx.x] != 0u && hb0 + (int)threadIdx.x < NBINS)
+        atomicAdd(&P.ghist[hb0 + threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
 }
 
 int launch_pairs_exact(ldw_ctx *c, const EpiArgs &A, unsigned long long *ghist, int64_t *sums, hipStream_t st) {

@@ -389,16 +389,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 // its slowest entries (predicated code), and a third of the gathered low-limb GEMM.  Launched over the generic
 // from-tiles x all columns and over the other tiles x the generic columns.
 // ------------------------------------------------------------------------------------------------
+struct GenRegions {      // k_mi_screen_generic's two rectangles: a = from-tiles [tile0_a, tile0_a + nt_a) x column groups [0, ncg_a);
+    int tile0_a, nt_a, ncg_a;   // b = from-tiles [0, nt_b) x ncg_b column groups from column slot q0_b
+    int nt_b, q0_b, ncg_b;
+};
 constexpr int GEN_COLS = 16;   // column slots per workgroup of k_mi_screen_generic: 4 per wave — the kernel is a chain of
                                // dependent loads per column with nothing else to hide them, so the chains are kept short
 template <bool APX>
 __global__ __launch_bounds__(256) void k_mi_screen_generic(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
                                                            uint64_t *__restrict__ units, unsigned int *__restrict__ n_units,
-                                                           int64_t list_stride, int tile0, int q0) {
+                                                           int64_t list_stride, GenRegions Rg) {
     __shared__ ColMeta cm[GEN_COLS];
     const bool square = A.nf == A.nt;
     const bool mixed = A.lo.on != 0 || APX;
-    const int tile = tile0 + (int)blockIdx.x, qb = q0 + (int)blockIdx.y * GEN_COLS;
+    // both regions in ONE launch (1-D grid): the generic from-tiles x all columns, then the other tiles x the generic columns
+    int bid = (int)blockIdx.x, tile, qb;
+    if (bid < Rg.nt_a * Rg.ncg_a) {
+        tile = Rg.tile0_a + bid % Rg.nt_a;
+        qb = (bid / Rg.nt_a) * GEN_COLS;
+    } else {
+        bid -= Rg.nt_a * Rg.ncg_a;
+        tile = bid % Rg.nt_b;
+        qb = Rg.q0_b + (bid / Rg.nt_b) * GEN_COLS;
+    }
     if (threadIdx.x < GEN_COLS) {
         const int q = qb + (int)threadIdx.x;
         if (q < A.nt) {
@@ -587,6 +600,19 @@ __global__ __launch_bounds__(256) void k_mi_units(EpiArgs A, const int32_t *__re
         }
         emit_pair_spec(A.E, M.ci, a_loc, b_loc, R.sa, M.sb, mi, ghist);
     }
+}
+
+// one launch instead of four or five hipMemsetAsync per block (each a 4-5 us kernel of its own plus a dispatch gap): zeroes up to
+// four small buffers, sizes in 16-byte pieces
+struct ZeroArgs {
+    uint4 *p[4];
+    unsigned int n16[4];
+};
+__global__ __launch_bounds__(256) void k_zero4(ZeroArgs Z) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < Z.n16[k]; i += gridDim.x * 256u) Z.p[k][i] = z;
 }
 
 // totals of the approximate path's lists (diagnostics: ldw_ctx_counters2): units listed (they hold a short-range pair),
@@ -1456,12 +1482,18 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
         {   // the units outside k_mi_screen's domain: generic from-tiles x all columns, the other tiles x the generic columns
             const int gt0 = std::min<int>(A.gen_t0, (int)egrid.x);
             const int q0 = std::min<int>(A.gen_q0, (int)nt) / GEN_COLS * GEN_COLS;
-            if (gt0 < (int)egrid.x)
-                hipLaunchKernelGGL(k_mi_screen_generic<false>, dim3(egrid.x - gt0, (unsigned)((nt + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A,
-                                   D.perm, D.perm_t, units, n_units, list_stride, gt0, 0);
-            if (gt0 > 0 && A.gen_q0 < (int)nt)
-                hipLaunchKernelGGL(k_mi_screen_generic<false>, dim3(gt0, (unsigned)((nt - q0 + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A,
-                                   D.perm, D.perm_t, units, n_units, list_stride, 0, q0);
+            {
+                GenRegions Rg;
+                Rg.tile0_a = gt0;
+                Rg.nt_a = (int)egrid.x - gt0;
+                Rg.ncg_a = Rg.nt_a > 0 ? (int)((nt + GEN_COLS - 1) / GEN_COLS) : 0;
+                Rg.nt_b = (gt0 > 0 && A.gen_q0 < (int)nt) ? gt0 : 0;
+                Rg.q0_b = q0;
+                Rg.ncg_b = Rg.nt_b > 0 ? (int)((nt - q0 + GEN_COLS - 1) / GEN_COLS) : 0;
+                const long long nblk = (long long)Rg.nt_a * Rg.ncg_a + (long long)Rg.nt_b * Rg.ncg_b;
+                if (nblk > 0)
+                    hipLaunchKernelGGL(k_mi_screen_generic<false>, dim3((unsigned)nblk), dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride, Rg);
+            }
             LDW_HIP(hipGetLastError());
         }
         if (mixed) {   // low limbs of the listed units
@@ -1515,7 +1547,8 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
 // around phase 2.
 // ------------------------------------------------------------------------------------------------
 int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E, hipEvent_t *ev, int phase,
-                     hipStream_t gs, unsigned long long *ghist, const LoHost *lo_h) {
+                     hipStream_t gs, unsigned long long *ghist, const LoHost *lo_h, void *zero_hist = nullptr, void *zero_pick = nullptr,
+                     size_t zero_pick_bytes = 0) {
     const int s = lo_h->slot;
     E.nf = (int)nf;
     E.MI = nullptr;
@@ -1609,8 +1642,23 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             if (int rc = launch_gemm_apx(c, P, gs)) return rc;
         }
         LDW_HIP(hipEventRecord(ev[1], gs));
-        LDW_HIP(hipMemsetAsync(ub, 0, o_flat, gs));   // the unit counters
-        if (use_pairs) LDW_HIP(hipMemsetAsync(c->pairs[s].p, 0, o_pairs, gs));
+        {   // the unit counters, the pair-list counters, this slot's histogram and pick record (submit_b skips its own memsets)
+            ZeroArgs Z;
+            memset(&Z, 0, sizeof(Z));
+            Z.p[0] = reinterpret_cast<uint4 *>(ub);
+            Z.n16[0] = (unsigned int)((o_flat + 15) / 16);
+            if (use_pairs) {
+                Z.p[1] = reinterpret_cast<uint4 *>(c->pairs[s].p);
+                Z.n16[1] = (unsigned int)((o_pairs + 15) / 16);
+            }
+            if (zero_hist) {
+                Z.p[2] = reinterpret_cast<uint4 *>(zero_hist);
+                Z.n16[2] = (unsigned int)(NBINS * 8 / 16);
+                Z.p[3] = reinterpret_cast<uint4 *>(zero_pick);
+                Z.n16[3] = (unsigned int)(zero_pick_bytes / 16);
+            }
+            hipLaunchKernelGGL(k_zero4, dim3(16), dim3(256), 0, gs, Z);
+        }
         const int nthr = std::max<int>((int)nt, nf_slots);
         hipLaunchKernelGGL(k_build_packs, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, gs, A, D.perm, D.perm_t, nf_slots, 1, cp, cph, rp, rph,
                            rlf, rlt);
@@ -1636,12 +1684,18 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     // the units outside k_mi_screen's domain: generic from-tiles x all columns, the other tiles x the generic columns
     const int gt0 = std::min<int>(A.gen_t0, (int)egrid.x);
     const int q0 = std::min<int>(A.gen_q0, (int)nt) / GEN_COLS * GEN_COLS;
-    if (gt0 < (int)egrid.x)
-        hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3(egrid.x - gt0, (unsigned)((nt + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A, D.perm,
-                           D.perm_t, units, n_units, list_stride, gt0, 0);
-    if (gt0 > 0 && A.gen_q0 < (int)nt)
-        hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3(gt0, (unsigned)((nt - q0 + GEN_COLS - 1) / GEN_COLS)), dim3(256), 0, c->stream, A, D.perm, D.perm_t,
-                           units, n_units, list_stride, 0, q0);
+    {
+        GenRegions Rg;
+        Rg.tile0_a = gt0;
+        Rg.nt_a = (int)egrid.x - gt0;
+        Rg.ncg_a = Rg.nt_a > 0 ? (int)((nt + GEN_COLS - 1) / GEN_COLS) : 0;
+        Rg.nt_b = (gt0 > 0 && A.gen_q0 < (int)nt) ? gt0 : 0;
+        Rg.q0_b = q0;
+        Rg.ncg_b = Rg.nt_b > 0 ? (int)((nt - q0 + GEN_COLS - 1) / GEN_COLS) : 0;
+        const long long nblk = (long long)Rg.nt_a * Rg.ncg_a + (long long)Rg.nt_b * Rg.ncg_b;
+        if (nblk > 0)
+            hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3((unsigned)nblk), dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride, Rg);
+    }
     LDW_HIP(hipGetLastError());
     if (need_exact)
         if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, Gx.as<int64_t>(), c->nlimbs, c->digits.as<int8_t>(),
@@ -2118,7 +2172,10 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
             // phase 1 of the approximate path: panels, GEMM, SNP constants and the screens, all beside the previous block's tail.
             // The emission constants of phase 2 (table pointers, row base) are refreshed in submit_b.
             if (int rc = make_emit_args(c, hb, p, sl, do_lr ? guess : -1)) return rc;
-            if (int rc = launch_block_apx(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, 1, gs, nullptr, &hb.lo)) return rc;
+            if (int rc = c->hist[s].reserve((size_t)NBINS * 8)) return rc;
+            if (int rc = launch_block_apx(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, 1, gs, nullptr, &hb.lo, c->hist[s].p, sl.pick[s],
+                                          PICK_STRIDE))
+                return rc;
             LDW_HIP(hipEventRecord(c->ev_gemm[s], gs));
             return LDW_OK;
         }
@@ -2174,10 +2231,10 @@ int submit_b(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     const int64_t sr_add = p->keep_sr ? hb.n_sr_blk : 0;
     if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr)) return rc;
     if (int rc = c->hist[s].reserve((size_t)NBINS * 8)) return rc;
-    LDW_HIP(hipMemsetAsync(c->hist[s].p, 0, (size_t)NBINS * 8, c->stream));
+    if (!hb.apx) LDW_HIP(hipMemsetAsync(c->hist[s].p, 0, (size_t)NBINS * 8, c->stream));   // (the approximate path zeroed both in its first phase: k_zero4)
     if (int rc = make_emit_args(c, hb, p, sl, (hb.mixed || hb.apx) ? (do_lr ? hb.guess : -1) : ((do_lr && c->engine == LDW_ENGINE_MFMA) ? c->spec_B_next[hb.diag ? 1 : 0] : -1)))
         return rc;
-    LDW_HIP(hipMemsetAsync(sl.pick[s], 0, sizeof(ldw::PickOut), c->stream));
+    if (!hb.apx) LDW_HIP(hipMemsetAsync(sl.pick[s], 0, sizeof(ldw::PickOut), c->stream));
     hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
     if (hb.apx) {
         if (int rc = launch_block_apx(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, 2, nullptr, c->hist[s].as<unsigned long long>(), &hb.lo))
