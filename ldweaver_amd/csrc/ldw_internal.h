@@ -164,6 +164,7 @@ struct ldw_ctx {
     ldw::DevBuf dstage[2];               // device image of the packed buffer
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool done_recorded[2] = {false, false};
+    bool up_recorded[2] = {false, false};    // ev_up[slot] has been recorded at least once
     void *pin_pick[2] = {nullptr, nullptr};   // pinned landing zone of the per-block PickOut, one per slot
     hipEvent_t ev_pick[2] = {nullptr, nullptr};
     void *pin_lrc = nullptr;             // pinned copy of the running long-range row count

@@ -17,6 +17,7 @@
 // (circularly) are at most three index intervals of the from-side list, found on the host by binary search (ColInfo).
 // The fused alternative (GEMM + epilogue in one kernel, ldw_set_fused) lives in ldw_fused.hip.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <hipcub/hipcub.hpp>
@@ -2133,6 +2134,7 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_done[s], 0));
     LDW_HIP(hipMemcpyAsync(c->dstage[s].p, c->pin[s], hb.total, hipMemcpyHostToDevice, c->copy_stream));
     LDW_HIP(hipEventRecord(c->ev_up[s], c->copy_stream));
+    c->up_recorded[s] = true;
     const char *d = c->dstage[s].as<char>();
     auto I = [&](size_t off) { return reinterpret_cast<const int32_t *>(d + off); };
     auto B = [&](size_t off) { return reinterpret_cast<const uint8_t *>(d + off); };
@@ -2603,27 +2605,48 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         }
         if (int rc = ensure_links_capacity(c, total_sr, 0)) return rc;
     }
-    // software pipeline: while the GPU works on block b, the host prepares block b+1 and — as soon as a bucket guess
-    // for its kind exists — submits it, so that its kernels run beside the selection of block b
-    HostBlock hb[2];
-    if (int rc = fill(0)) return rc;
-    if (int rc = prep_block(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, 0, 0, hb[0])) return rc;
+    // Software pipeline, three blocks deep on the host: block b's epilogue chain is submitted (main stream), then at once the
+    // block-wide pass of block b+1 (GEMM stream; prepared one iteration ago), THEN the host prepares block b+2 — about half
+    // a millisecond of list building for a 10k x 10k block — while the GPU works, and only then waits for block b's pick.
+    // (Preparing b+1 between submit_b(b) and submit_a(b+1), as the first version did, delivered the GEMM of b+1 to the GPU when
+    // the chain of b was already over: the two streams never ran side by side.)
+    HostBlock hb[3];
+    static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
+    double th[5] = {0, 0, 0, 0, 0};
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto prep = [&](int64_t b) -> int {
+        if (int rc = fill(b)) return rc;
+        const int slot = (int)(b & 1);
+        if (c->up_recorded[slot]) LDW_HIP(hipEventSynchronize(c->ev_up[slot]));   // the staging buffer of this slot has been uploaded
+        return prep_block(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, slot, b, hb[b % 3]);
+    };
+    if (int rc = prep(0)) return rc;
     if (int rc = submit_a(c, hb[0], p, sl)) return rc;
+    if (nblocks > 1)
+        if (int rc = prep(1)) return rc;
     for (int64_t b = 0; b < nblocks; ++b) {
-        const int s = (int)(b & 1);
-        if (int rc = submit_b(c, hb[s], p, sl)) return rc;              // unfused: epilogue + pick of block b (main stream)
-        if (b + 1 < nblocks) {
-            if (int rc = fill(b + 1)) return rc;
-            if (int rc = prep_block(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, s ^ 1, b + 1, hb[s ^ 1]))
-                return rc;
-            if (can_submit_early(c, hb[s ^ 1], p))
-                if (int rc = submit_a(c, hb[s ^ 1], p, sl)) return rc;   // block b+1 (GEMM stream) runs beside them
-        }
-        if (int rc = finish_block(c, hb[s], p, sl)) return rc;          // round trip + selection of block b
-        if (b + 1 < nblocks && !hb[s ^ 1].submitted)
-            if (int rc = submit_a(c, hb[s ^ 1], p, sl)) return rc;       // overlap off / no guess yet: one block after the other
+        HostBlock &cur = hb[b % 3], &nxt = hb[(b + 1) % 3];
+        double t0 = now();
+        if (int rc = submit_b(c, cur, p, sl)) return rc;                 // unfused: epilogue + pick of block b (main stream)
+        th[0] += now() - t0;
+        t0 = now();
+        if (b + 1 < nblocks && can_submit_early(c, nxt, p))
+            if (int rc = submit_a(c, nxt, p, sl)) return rc;              // block b+1 (GEMM stream) runs beside them
+        th[2] += now() - t0;
+        t0 = now();
+        if (b + 2 < nblocks)
+            if (int rc = prep(b + 2)) return rc;                          // host work, hidden behind the GPU
+        th[1] += now() - t0;
+        t0 = now();
+        if (int rc = finish_block(c, cur, p, sl)) return rc;             // round trip + selection of block b
+        th[3] += now() - t0;
+        if (b + 1 < nblocks && !nxt.submitted)
+            if (int rc = submit_a(c, nxt, p, sl)) return rc;              // overlap off / no guess yet: one block after the other
         ++c->blk_cursor;
     }
+    if (host_timing)
+        fprintf(stderr, "[ldw host us/block] submit_b %.1f  prep %.1f  submit_a %.1f  finish (incl. wait) %.1f  blocks %lld\n", th[0] / nblocks, th[1] / nblocks,
+                th[2] / nblocks, th[3] / nblocks, (long long)nblocks);
     return ldw_links_end(c);
 }
 
