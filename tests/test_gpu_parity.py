@@ -335,8 +335,8 @@ def test_perform_mi_computation_end_to_end(engine, sample, tmp_path):
 @pytest.mark.parametrize("max_blk_sz", [10000, 1000])
 def test_device_sr_model_matches_host_model(engine, sample, tmp_path, max_blk_sz):
     """mergeNsort_sr_links + runARACNE on the device-resident link table (csrc/ldw_srp.hip) against the host mirror
-    (pandas + the native ARACNE) on the same MI table: same rows in the same order, srp within 1e-9, same flags; and
-    each device reduction against numpy on the fetched table."""
+    (pandas + the native ARACNE) on the same MI table: same rows in the same order, srp within 1e-9, same flags; against
+    the oracle's model and ARACNE on that table; and each device reduction against numpy on the fetched table."""
     st = sample["states"]
     sd = SnpDat(states=st, POS=sample["POS"], g=sample["g"], uqe=sample["uqe"], r=sample["r"])
     cv = CdsVar(paint=sample["paint"], nclust=3)
@@ -368,6 +368,17 @@ def test_device_sr_model_matches_host_model(engine, sample, tmp_path, max_blk_sz
     a, b, mi = engine.links(0)
     POS, paint, g = sample["POS"].astype(float), sample["paint"], float(sample["g"])
     ln = orc.circ_len(POS[b], POS[a], g)
+    # ... and the device model against the ORACLE's mergeNsort_sr_links + runARACNE on that very table (single- and multi-block):
+    # same rows in the reference's row order, srp_max to 1e-6 (two different optimisers reach the beta MLE), same ARACNE flags
+    tab = dict(pos1=POS[b], pos2=POS[a], clust1=paint[b], clust2=paint[a], len=ln, MI=mi)
+    by_clust = [{k: v[(tab["clust1"] == ci) | (tab["clust2"] == ci)] for k, v in tab.items()} for ci in (1, 2, 3)]
+    ored, ochk = orc.merge_n_sort_sr_links(by_clust, 3, 20000, 2.0)
+    assert len(ored["MI"]) == len(rd)
+    for k in ("clust_c", "pos1", "pos2", "clust1", "clust2", "len", "MI"):
+        assert np.array_equal(np.asarray(ored[k], dtype=float), rd[k].to_numpy(dtype=float)), k
+    assert np.abs(ored["srp_max"] - rd["srp_max"].to_numpy()).max() < 1e-6 * max(1.0, float(np.abs(ored["srp_max"]).max()))
+    oflags = orc.run_aracne(ored["pos1"], ored["pos2"], ored["MI"], ochk["pos1"], ochk["pos2"], ochk["MI"])
+    assert np.array_equal(oflags.astype(float), rd["ARACNE"].to_numpy())
     qlo, qhi, cnt = engine.sr_len_quantiles(3, 20000, 0.95)
     assert qlo.shape == (3, 19999)
     for ci in (1, 2, 3):
