@@ -59,16 +59,21 @@ def agree(ok: bool, group=None, what: str = "", force_collective=None) -> None:
         raise RuntimeError(f"{what or 'the computation'} failed on rank(s) {bad.tolist()} (this is rank {rank})")
 
 
-def block_cost(blocks: np.ndarray) -> np.ndarray:
+def block_cost(blocks: np.ndarray, diag_factor: float = 2.0) -> np.ndarray:
+    """Relative GPU time of the block pairs.  An off-diagonal pair costs its nf * nt pairs.  A diagonal pair has half the pairs
+    (half the block-wide GEMM and screen) but holds the dense short-range band, whose units take the exact 5-limb GEMM of the
+    band's tiles (23 % of the tiles at C4) and the whole-unit fp64 kernel: measured on the C4 shape (rocprof, kernel-exclusive)
+    both kinds come to ~1.4 ms, i.e. ``diag_factor`` = 2 times a diagonal pair's own pair count."""
     b = np.asarray(blocks, dtype=np.int64).reshape(-1, 4)
     nf, nt = b[:, 1] - b[:, 0] + 1, b[:, 3] - b[:, 2] + 1
     diag = (b[:, 0] == b[:, 2]) & (b[:, 1] == b[:, 3])
-    return np.where(diag, nf * (nf - 1) // 2, nf * nt).astype(np.int64)
+    return np.where(diag, (nf * (nf - 1) // 2 * diag_factor).astype(np.int64), nf * nt).astype(np.int64)
 
 
-def deal_blocks(blocks: np.ndarray, world: int) -> list:
-    """Cost-weighted longest-processing-time deal; every rank keeps its blocks in make_blocks order."""
-    cost = block_cost(blocks)
+def deal_blocks(blocks: np.ndarray, world: int, cost: np.ndarray | None = None) -> list:
+    """Cost-weighted longest-processing-time deal (``cost``: per block, default ``block_cost``); every rank keeps its blocks in
+    make_blocks order."""
+    cost = block_cost(blocks) if cost is None else np.asarray(cost, dtype=np.int64)
     order = np.argsort(-cost, kind="stable")
     load = np.zeros(world, dtype=np.int64)
     owner = np.empty(len(cost), dtype=np.int64)
