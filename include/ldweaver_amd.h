@@ -191,6 +191,9 @@ int ldw_set_mixed(ldw_ctx *ctx, int on);
  *     LDW_ERR_STATE at block time when the weights do not allow it (too many distinct weights, > 30k sequences).
  * Every MI that is emitted is computed from the exact fixed-point sums either way: the link tables do not depend on it. */
 int ldw_set_path(ldw_ctx *ctx, int mode);
+/* Long-range selection of the speculative blocks: 0 (default) = without a sort where it applies (radix select of the threshold,
+ * bitmap ranks over the row-order key space: ldw_mi.hip k_sel_*), 1 = always the general path (two radix sorts).  Same tables. */
+int ldw_set_select(ldw_ctx *ctx, int mode);
 /* diagnostics of the approximate path after ldw_set_weights: out[0] = usable (0/1), out[1] = max relative error delta of the
  * dual-digit weights, out[2] = weight classes, out[3] = popcount segments, out[4] = exponent transitions, out[5] = e_last */
 int ldw_apx_info(ldw_ctx *ctx, double out[6]);

@@ -69,6 +69,7 @@ _SIGS = {
     "ldw_ctx_counters2": (C.c_int, [_p, _p]),
     "ldw_set_screen": (C.c_int, [_p, C.c_int]),
     "ldw_set_path": (C.c_int, [_p, C.c_int]),
+    "ldw_set_select": (C.c_int, [_p, C.c_int]),
     "ldw_apx_info": (C.c_int, [_p, _p]),
     "ldw_links_count": (C.c_int, [_p, C.c_int, C.POINTER(_i64)]),
     "ldw_links_fetch": (C.c_int, [_p, C.c_int, _p, _p, _p, _i64, C.c_int]),

@@ -340,6 +340,12 @@ int ldw_ctx_counters(ldw_ctx *c, int64_t out[4]) {
     return LDW_OK;
 }
 
+int ldw_set_select(ldw_ctx *c, int mode) {
+    LDW_REQUIRE(c && (mode == 0 || mode == 1), LDW_ERR_ARG, "ldw_set_select: mode must be 0 (auto) or 1 (radix sorts)");
+    c->select_mode = mode;
+    return LDW_OK;
+}
+
 int ldw_set_path(ldw_ctx *c, int mode) {
     LDW_REQUIRE(c && mode >= 0 && mode <= 2, LDW_ERR_ARG, "ldw_set_path: mode must be 0 (auto), 1 (limb GEMM paths) or 2 (approximate GEMM path)");
     c->path_mode = mode;

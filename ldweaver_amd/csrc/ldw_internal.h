@@ -84,6 +84,7 @@ struct ldw_ctx {
     // ---- approximate-GEMM path (ldw_apx.hip): V_p ~ a_p * b_p * 2^e(macro step of p), one int8 MFMA pass with both
     // ---- operands masked by a digit; exact joint sums of the listed units by class-wise popcounts
     int path_mode = 0;                 // ldw_set_path: 0 auto, 1 mixed/plain path, 2 force the approximate path
+    int select_mode = 0;               // ldw_set_select: 0 auto (sort-free selection where it applies), 1 always the two radix sorts
     bool apx_ok = false;               // the weights allow the approximate path (precision and class structure)
     ldw::DevBuf dig_a, dig_b;          // uint8 [Npad]
     ldw::DevBuf apx_shift;             // int32 [KW / 2]: right shift of the accumulators before macro step m (128 positions)

@@ -2308,7 +2308,7 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
     static const bool sel_fast_on = getenv("LDW_NO_FAST_SELECT") == nullptr;
     const long long n_words = (long long)((2 * sel_space + 31) / 32) + 1, n_chunks = (long long)((2 * sel_space + SEL_CHUNK_BITS - 1) / SEL_CHUNK_BITS) + 1;
     const long long n_super_ll = (n_chunks + SEL_SUPER - 1) / SEL_SUPER;
-    if (do_lr && m > 0 && sel_fast_on && m <= SEL_MAX && n_super_ll <= SEL_MAX_SUPER) {
+    if (do_lr && m > 0 && sel_fast_on && c->select_mode == 0 && m <= SEL_MAX && n_super_ll <= SEL_MAX_SUPER) {
         // the common case: radix select + bitmap ranks, four small launches, no sort (k_sel_thresh)
         if (int rc = ensure_links_capacity(c, c->n_sr, c->n_lr + m)) return rc;
         const int n_super = (int)n_super_ll;

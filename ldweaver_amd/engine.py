@@ -80,6 +80,10 @@ class Engine:
         (one dual-digit int8 pass + exact class-wise popcount sums of the listed units) or an error."""
         L.check(L.lib().ldw_set_path(self._ctx, int(mode)))
 
+    def set_select(self, mode: int):
+        """Long-range selection: 0 auto (sort-free where it applies), 1 always the two radix sorts.  Same tables."""
+        L.check(L.lib().ldw_set_select(self._ctx, int(mode)))
+
     def apx_info(self):
         """Diagnostics of the approximate path for the current weights (after set_weights)."""
         v = np.zeros(6)

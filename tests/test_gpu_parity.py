@@ -224,7 +224,7 @@ def test_lr_quantile_filter_exact(engine, synth):
         assert off == len(mi)
 
 
-@pytest.mark.parametrize("variant", ["default", "plain", "limb_paths", "fused"])
+@pytest.mark.parametrize("variant", ["default", "plain", "limb_paths", "fused", "sort_select"])
 def test_threshold_ties_match_oracle_exactly(engine, sample, variant):
     """Ties at a block's long-range threshold (R/computePairwiseMI.R:352-358: `MI >= quantile(MI, prob)`): the reference's
     sample alignment is clonal — a third of its links sit in groups of pairs with identical joint tables, and several blocks'
@@ -236,7 +236,9 @@ def test_threshold_ties_match_oracle_exactly(engine, sample, variant):
     POS, g = sample["POS"], sample["g"]
     approx = orc.lr_links_approx(POS, g, 20000.0)
     blocks = np.array(orc.make_blocks(1268, 300), dtype=np.int32)      # 5 x 5 grid, 15 block pairs, ragged last column
-    cfg = dict(default=(True, 1, 0, False), plain=(False, 0, 1, False), limb_paths=(True, 1, 1, False), fused=(True, 1, 1, True))[variant]
+    cfg = dict(default=(True, 1, 0, False), plain=(False, 0, 1, False), limb_paths=(True, 1, 1, False), fused=(True, 1, 1, True),
+               sort_select=(True, 1, 0, False))[variant]
+    engine.set_select(1 if variant == "sort_select" else 0)     # the general selection path (two radix sorts) against the sort-free one
     engine.set_mixed(cfg[0])
     engine.set_screen(cfg[1])
     engine.set_path(cfg[2])
@@ -251,6 +253,7 @@ def test_threshold_ties_match_oracle_exactly(engine, sample, variant):
         engine.set_screen(1)
         engine.set_path(0)
         engine.set_fused(False)
+        engine.set_select(0)
     tied_blocks = 0
     for (a, b, mi), st in runs:
         off = 0
