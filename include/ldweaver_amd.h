@@ -73,7 +73,8 @@ int ldw_ctx_counters2(ldw_ctx *ctx, int64_t out[8]);
 /* Work the block-wide GEMMs of this context EXECUTED since the last reset (for the roofline: executed int8 operations /
  * kernel time / peak): out[0] launches and out[1] int8 operations (2 x rows x rows x positions of the wave tiles that do not exit
  * at once) of the approximate GEMM (gemm_apx_kernel), out[2] / out[3] the same for the unmasked limb GEMM (gemm_bits_kernel<J>,
- * all J limbs), out[4] launches of the band-masked limb GEMM, out[5] reserved.  reset != 0 clears the counts. */
+ * all J limbs), out[4] launches of the band-masked limb GEMM, out[5] launches of the approximate GEMM that applied the threshold
+ * table in their epilogue (long-range-only blocks).  reset != 0 clears the counts. */
 int ldw_gemm_stats(ldw_ctx *ctx, double out[6], int reset);
 
 /* ---- (1) .ACGTN2num  — src/ACGTN2num_parallel.cpp:10-43, R/RcppExports.R:4-6 ------------ */

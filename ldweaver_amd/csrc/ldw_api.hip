@@ -260,7 +260,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     ldw::DevBuf *bufs[] = {&c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
                            &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->perm_t, &c->scr_units, &c->slot_pfix_hi, &c->glo, &c->lo_rows, &c->packs, &c->hist[0], &c->hist[1], &c->colcnt, &c->cand_key[0], &c->cand_key[1],
-                           &c->cand_val[0], &c->cand_val[1], &c->cand_key2, &c->cand_val2, &c->sel_bitmap, &c->sel_chunks, &c->sel_prefix, &c->scratch, &c->small, &c->sr_a, &c->sr_b,
+                           &c->cand_val[0], &c->cand_val[1], &c->cand_key2, &c->cand_val2, &c->sel_bitmap, &c->sel_chunks, &c->sel_prefix, &c->apx_bins[0], &c->apx_bins[1], &c->apx_clean[0], &c->apx_clean[1], &c->scratch, &c->small, &c->sr_a, &c->sr_b,
                            &c->sr_mi, &c->lr_a, &c->lr_b, &c->lr_mi, &c->srm_pack, &c->srm_key, &c->srm_pack2, &c->srm_key2, &c->srm_pay, &c->srm_pay2, &c->srm_off,
                            &c->srm_q, &c->srm_n, &c->srm_md, &c->srm_part, &c->srm_shape, &c->srm_cnt, &c->red_row, &c->red_meta,
                            &c->red_srp, &c->pool_a, &c->pool_b, &c->pool_mi, &c->ar_key, &c->ar_val, &c->ar_key2, &c->ar_val2,

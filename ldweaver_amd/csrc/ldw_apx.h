@@ -33,6 +33,15 @@ struct ApxGemmArgs {
     const int32_t *shift;                // [M2]
     int32_t *G;                          // [RTpad][RFpad]
     int lower_only;
+    // Threshold-table test in the epilogue (long-range-only blocks): bin_t / bin_f give every row of the two row lists its bin of
+    // the 64 x 64 table `tab` (255: not a biallelic r = 2 SNP's row).  A region of 32 to-rows x 64 from-rows in which every
+    // entry n' satisfies Lq < n' < Hq — what the screen would find for every one of its 2048 pairs — is flagged in
+    // clean[(trow / 32) * (RFpad / 64) + fcol / 64] and NOT stored: the screen skips it without reading anything.
+    int fuse;
+    const uint8_t *bin_t, *bin_f;
+    const int2 *tab;
+    int tab_nb;
+    uint8_t *clean;
 };
 
 int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st);

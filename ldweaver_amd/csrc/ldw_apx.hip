@@ -176,7 +176,10 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint64_t *lutFF = reinterpret_cast<uint64_t *>(smem);           // [256]: byte of bits -> 8 bytes of 0xFF / 0x00
     uint8_t *sA = smem + 2048, *sB = sA + (size_t)P.M2 * 128;       // digits by position
+    int2 *s_tab = reinterpret_cast<int2 *>(sB + (size_t)P.M2 * 128);  // threshold table (P.fuse)
     const int tid = threadIdx.x;
+    if (P.fuse)
+        for (int i = tid; i < P.tab_nb * P.tab_nb; i += 256) s_tab[i] = P.tab[i];
     {
         uint64_t e = 0;
 #pragma unroll
@@ -256,23 +259,61 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     }
+    int bf[NT];
+    uint8_t *s_bt = reinterpret_cast<uint8_t *>(s_tab + 64 * 64) + wave * 256;   // the to-side bins of this wave's rows (P.fuse)
+    if (P.fuse) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int j = 0; j < NT; ++j) bf[j] = (int)P.bin_f[tx * TWd + 32 * j + frow];
+        // one coalesced load of the wave tile's TH to-side bins, then LDS byte reads at static offsets (64 separate global byte
+        // loads per lane made the epilogue cost more than the screen saved)
+        for (int r = lane; r < TH; r += 64) s_bt[r] = P.bin_t[ty * TH + r];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0);   // (wave-private LDS: the writes of this wave are done before its reads)
+    }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int fcol = tx * TWd + 32 * j + frow;
+    for (int i = 0; i < MT; ++i) {
+        bool store = true;
+        if (P.fuse) {   // region = to-rows [ty TH + 32 i, + 32) x the wave's from-rows (NT * 32 = 64 when NT = 2)
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ok = ok && bf[j] != 255;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int trow = ty * TH + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                P.G[(int64_t)trow * P.RFpad + fcol] = acc[i][j][e];
+                const int bt = (int)s_bt[32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh];
+                ok = ok && bt != 255;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int2 th = s_tab[(bt & 63) * P.tab_nb + (bf[j] & 63)];
+                    const int n = acc[i][j][e];
+                    ok = ok && n > th.x && n < th.y;
+                }
+            }
+            const bool clean = __ballot(!ok) == 0ull;
+            if (lane == 0) {
+#pragma unroll
+                for (int h = 0; h < (NT * 32) / 64; ++h) P.clean[(int64_t)((ty * TH + 32 * i) / 32) * (P.RFpad / 64) + (tx * TWd) / 64 + h] = clean ? 1 : 0;
+            }
+            store = !clean;
+        }
+        if (store) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int fcol = tx * TWd + 32 * j + frow;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int trow = ty * TH + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    P.G[(int64_t)trow * P.RFpad + fcol] = acc[i][j][e];
+                }
             }
         }
+    }
 }
 int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     LDW_REQUIRE(P.RTpad % APX_TW == 0 && P.RFpad % APX_TW == 0 && P.M2 > 0, LDW_ERR_ARG, "launch_gemm_apx: padding violated (RT %d RF %d M2 %d)", P.RTpad,
                 P.RFpad, P.M2);
-    const size_t lds = 2048 + (size_t)P.M2 * 256;
+    const size_t lds = 2048 + (size_t)P.M2 * 256 + (P.fuse ? (size_t)P.tab_nb * P.tab_nb * 8 + 1024 : 0);
     LDW_REQUIRE(lds <= 65536, LDW_ERR_ARG, "launch_gemm_apx: %d positions do not fit the LDS digit arrays", P.M2 * 128);
+    LDW_REQUIRE(!P.fuse || (P.tab_nb == 64 && P.bin_t && P.bin_f && P.tab && P.clean && !P.lower_only), LDW_ERR_ARG, "launch_gemm_apx: bad table arguments");
     static const int tile = [] {
         const char *e = getenv("LDW_APX_TILE");   // tuning: wave tile in MFMA tiles, to side x from side (default 4 x 2)
         return e ? atoi(e) : 42;
@@ -282,13 +323,14 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
         const int ntx = P.RFpad / (32 * NTv), nty = P.RTpad / (32 * MTv);                                                     \
         hipLaunchKernelGGL((gemm_apx_kernel<MTv, NTv>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P); \
     }
-    if (tile == 22) LDW_APX_LAUNCH(2, 2)
-    else if (tile == 24) LDW_APX_LAUNCH(2, 4)
+    if (tile == 22 && !P.fuse) LDW_APX_LAUNCH(2, 2)          // (the table epilogue assumes 64 from-rows per wave: NT = 2)
+    else if (tile == 24 && !P.fuse) LDW_APX_LAUNCH(2, 4)
     else LDW_APX_LAUNCH(4, 2)
 #undef LDW_APX_LAUNCH
     LDW_HIP(hipGetLastError());
     {   // executed work (ldw_gemm_stats): waves that do not leave at once, each 2 * rows_t * rows_f * K int8 operations
-        const int MTv = tile == 22 || tile == 24 ? 2 : 4, NTv = tile == 24 ? 4 : 2, TH = 32 * MTv, TWd = 32 * NTv;
+        const int tl = P.fuse ? 42 : tile;
+        const int MTv = tl == 22 || tl == 24 ? 2 : 4, NTv = tl == 24 ? 4 : 2, TH = 32 * MTv, TWd = 32 * NTv;
         int64_t waves = 0;
         for (int ty = 0; ty * TH < P.RTpad; ++ty) {
             const int ntx = P.RFpad / TWd;
@@ -296,6 +338,7 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
             else for (int tx = 0; tx < ntx; ++tx) waves += (tx * TWd + TWd - 1 < ty * TH) ? 0 : 1;
         }
         c->gemm_stat[0] += 1;
+        if (P.fuse) c->gemm_stat[5] += 1;
         c->gemm_stat[1] += 2.0 * (double)waves * TH * TWd * ((double)P.M2 * 128.0);
     }
     return LDW_OK;

@@ -247,6 +247,10 @@ struct EpiArgs {
     const int2 *tab11;
     int tab_nb;               // bins per side (sqrt scale: bin = min(tab_nb - 1, floor(sqrt(p) tab_c)))
     float tab_c;
+    // regions of 32 column slots x one from-tile that the GEMM's epilogue found clean (every pair inside its table thresholds):
+    // clean[(q / 32) * clean_stride + tile]; null: no such information
+    const uint8_t *clean;
+    int clean_stride;
     EmitArgs E;
 };
 __host__ __device__ __forceinline__ int tab_bin(float p, float c, int nb) {

@@ -105,6 +105,7 @@ struct ldw_ctx {
     bool tab11_on = true;              // LDW_NO_TAB11 switches the table off (A/B measurements)
     ldw::DevBuf pair_sums;             // exact joint sums of the listed pairs (16 per pair)
     ldw::DevBuf pairs[2];              // per pipeline slot: pair lists of the approximate screen (counters + PAIR_PATHS x PAIR_SHARDS lists)
+    ldw::DevBuf apx_bins[2], apx_clean[2];    // per slot: threshold-table bin of every row of the two row lists; clean-region flags of the GEMM epilogue
     ldw::DevBuf apx_units[2], apx_packs[2];   // per slot: per-(tile, class) unit lists + counters; per-block SNP constants
     int64_t apx_blocks = 0, apx_units_listed = 0, apx_pairs_listed = 0;
 

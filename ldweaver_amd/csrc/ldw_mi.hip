@@ -36,15 +36,20 @@ namespace ldw {
 __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
                                                      int nf_slots, int with_hi, ColMeta *__restrict__ cp, ColMeta *__restrict__ cp_hi,
                                                      RowPack *__restrict__ rp, RowPack *__restrict__ rp_hi, float *__restrict__ rloc_f,
-                                                     float *__restrict__ rloc_t) {
+                                                     float *__restrict__ rloc_t, uint8_t *__restrict__ bin_t = nullptr,
+                                                     uint8_t *__restrict__ bin_f = nullptr, int RTpad = 0, int RFpad = 0) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool square = A.nf == A.nt;
+    // bins of the threshold table by ROW of the two row lists for the GEMM's epilogue test (only used when the host has checked
+    // that a one-row SNP's position in its row list equals its slot here: no SNP without a row in the block)
+    int my_bt = 255, my_bf = 255;
     if (i < A.nf) rloc_f[i] = (float)A.r[A.idx_f[i]];
     if (i < A.nt) rloc_t[i] = (float)A.r[A.idx_t[i]];
     if (i < A.nt) {
         ColMeta m;
         load_col(A, perm_t, square, i, m, false);
         cp[i] = m;
+        if ((m.mb & 7) == 1 && col_is_fast(m.mb) && m.rb == 2.0) my_bt = m.pad2 & 63;
         if (with_hi) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) m.pb[j] = A.lo.slot_pfix_hi[(int64_t)m.sb * 5 + j];
@@ -58,12 +63,15 @@ __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *_
         P.a_loc = ok ? a_loc : -1;
         P.pad = A.tab11 ? tab_bin(P.R.pXf[0], A.tab_c, A.tab_nb) : 0;   // bin of the minor-state marginal (threshold table)
         rp[i] = P;
+        if (ok && P.R.na == 1 && ((P.R.ma >> 3) & 3u) == 3u && P.R.ra == 2.0) my_bf = P.pad & 63;
         if (with_hi) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) P.R.pa[k] = A.lo.slot_pfix_hi[(int64_t)P.R.sa * 5 + k];
             rp_hi[i] = P;
         }
     }
+    if (bin_t && i < RTpad) bin_t[i] = (uint8_t)my_bt;
+    if (bin_f && i < RFpad) bin_f[i] = (uint8_t)my_bf;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -313,6 +321,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     __shared__ ColMeta cm[EPI_COLS];
     const bool square = A.nf == A.nt;
     const bool mixed = A.lo.on != 0 || APX;   // cells derived from the marginals of the weights the block-wide sums were taken with
+    if (APX && A.clean && A.E.scr_mode != 2 && (int)blockIdx.x < A.clean_stride && (int)blockIdx.x < A.gen_t0) {
+        // all four 32-column regions of this workgroup found clean by the GEMM's epilogue: nothing to stage, nothing to list
+        bool all_clean = true;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int qb = (int)blockIdx.y * EPI_COLS + w * (EPI_COLS / 4);
+            const bool whole = qb + EPI_COLS / 4 <= A.nt && qb + EPI_COLS / 4 <= A.gen_q0;
+            all_clean = all_clean && whole && A.clean[(int64_t)(qb / 32) * A.clean_stride + blockIdx.x] != 0;
+        }
+        if (all_clean) return;
+    }
     stage_cols(A, perm_t, square, cm, mixed);
     __syncthreads();
     RowSide R;
@@ -339,7 +358,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // from-tiles >= gen_t0 and column slots >= gen_q0 (SNPs with >= 3 minor states, or none) belong to k_mi_screen_generic
     if ((int)blockIdx.x >= A.gen_t0 || q_base >= A.gen_q0) return;
     if (q_base + n_it > A.gen_q0) n_it = A.gen_q0 - q_base;
-    if (wave_full) {
+    // a region the GEMM's epilogue found clean (every one of its 64 x 32 pairs inside the table thresholds — the very test the
+    // table path below would make) is dismissed without a single load
+    const bool region_clean = APX && A.clean && n_it == EPI_COLS / 4 && (int)blockIdx.x < A.clean_stride &&
+                              A.clean[(int64_t)(q_base / 32) * A.clean_stride + blockIdx.x] != 0;
+    if (region_clean) {
+        handled = 0xFFFFFFFFu;
+    } else if (wave_full) {
         for (int it = 0; it < n_it; it += U) {
             const ColMeta *cmu = &cm[c_first + it];
             // the U columns of a group share one code path if they have the same slot count (the rule away from class borders)
@@ -1334,6 +1359,8 @@ struct LoHost {
     int32_t n_tiles_cf[3] = {0, 0, 0};   // from-tiles whose widest row-slot class is 1, 2, 4
     int band_full = 0;                   // the exact GEMM has to cover every tile (a SNP with unflagged slots: its units are not screened)
     int apx = 0, slot = 0, diag = 0;     // approximate-GEMM path (ldw_apx.h) instead of the high-limb GEMM + gathered low limbs
+    int fuse_ok = 0;                     // rows of one-row SNPs sit at their slot index in both row lists (no SNP without a row): the
+                                         // GEMM's epilogue may apply the threshold table by row (ApxGemmArgs::fuse)
 };
 
 void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int quirk, const EmitArgs &E, const int64_t *G,
@@ -1363,6 +1390,8 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
     A.pl_cap = 0;
     A.row0 = c->row0.as<int32_t>();
     A.tab11 = nullptr;
+    A.clean = nullptr;
+    A.clean_stride = 0;
     A.tab_nb = 0;
     A.tab_c = 0;
     A.E = E;
@@ -1581,6 +1610,8 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * PAIR_CAP * sizeof(PairEnt))) return rc;
         if (need_exact)
             if (int rc = Gx.reserve((size_t)RFpad * RTpad * 8)) return rc;
+        if (int rc = c->apx_bins[s].reserve((size_t)RTpad + (size_t)RFpad + 64)) return rc;
+        if (int rc = c->apx_clean[s].reserve((size_t)(RTpad / 32) * (size_t)(RFpad / 64) + 64)) return rc;
     }
     if (phase == 1) {
         if (E.do_lr && c->tab11_on) {
@@ -1609,6 +1640,15 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         A.tab_nb = c->tab11_nb;
         A.tab_c = c->tab11_c;
     }
+    // long-range-only blocks: the GEMM applies the table itself and neither stores nor lets the screen read the regions that pass
+    static const bool fuse_on = getenv("LDW_NO_FUSE_TAB") == nullptr;
+    const bool fuse = fuse_on && lo_h->fuse_ok && A.tab11 && A.tab_nb == 64 && (use_pairs || c->screen == 2) && E.do_lr && !E.any_sr && !E.lower_only && RFpad % 64 == 0 &&   // (verify mode: the clean regions' units are listed as dismissed and checked in fp64)
+                      2048 + (size_t)(c->KW / 2) * 256 + 64 * 64 * 8 + 1024 <= 65536;   // (the table shares the GEMM's LDS with the digit arrays)
+    uint8_t *bin_t = c->apx_bins[s].as<uint8_t>(), *bin_f = bin_t + RTpad;
+    if (fuse) {
+        A.clean = c->apx_clean[s].as<uint8_t>();
+        A.clean_stride = RFpad / 64;
+    }
     char *ub = c->apx_units[s].as<char>();
     unsigned int *n_units = reinterpret_cast<unsigned int *>(ub);
     uint64_t *units = reinterpret_cast<uint64_t *>(ub + o_flat);
@@ -1627,22 +1667,6 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             if (!lo_h->diag)
                 if (int rc = launch_pack_panel(c, D.rl_t, RTpad, c->panel[s][1].as<uint64_t>(), gs)) return rc;
         }
-        LDW_HIP(hipEventRecord(ev[0], gs));   // ev[0] .. ev[1]: the approximate GEMM alone (its launch time is the roofline's)
-        if (E.do_lr) {
-            ApxGemmArgs P;
-            P.panel_f = c->panel[s][0].as<uint64_t>();
-            P.panel_t = lo_h->diag ? P.panel_f : c->panel[s][1].as<uint64_t>();
-            P.RTpad = RTpad;
-            P.RFpad = RFpad;
-            P.M2 = (int)(c->KW / 2);
-            P.dig_a = c->dig_a.as<uint8_t>();
-            P.dig_b = c->dig_b.as<uint8_t>();
-            P.shift = c->apx_shift.as<int32_t>();
-            P.G = c->Gapx[s].as<int32_t>();
-            P.lower_only = E.lower_only;
-            if (int rc = launch_gemm_apx(c, P, gs)) return rc;
-        }
-        LDW_HIP(hipEventRecord(ev[1], gs));
         {   // the unit counters, the pair-list counters, this slot's histogram and pick record (submit_b skips its own memsets)
             ZeroArgs Z;
             memset(&Z, 0, sizeof(Z));
@@ -1660,10 +1684,36 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             }
             hipLaunchKernelGGL(k_zero4, dim3(16), dim3(256), 0, gs, Z);
         }
-        const int nthr = std::max<int>((int)nt, nf_slots);
+        // the per-SNP constants in epilogue order — before the GEMM: its epilogue reads the table bins by row
+        const int nthr = std::max<int>(std::max<int>((int)nt, nf_slots), std::max<int>(RTpad, RFpad));
         hipLaunchKernelGGL(k_build_packs, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, gs, A, D.perm, D.perm_t, nf_slots, 1, cp, cph, rp, rph,
-                           rlf, rlt);
+                           rlf, rlt, bin_t, bin_f, RTpad, RFpad);
         LDW_HIP(hipGetLastError());
+        LDW_HIP(hipEventRecord(ev[0], gs));   // ev[0] .. ev[1]: the approximate GEMM alone (its launch time is the roofline's)
+        if (E.do_lr) {
+            ApxGemmArgs P;
+            memset(&P, 0, sizeof(P));
+            P.panel_f = c->panel[s][0].as<uint64_t>();
+            P.panel_t = lo_h->diag ? P.panel_f : c->panel[s][1].as<uint64_t>();
+            P.RTpad = RTpad;
+            P.RFpad = RFpad;
+            P.M2 = (int)(c->KW / 2);
+            P.dig_a = c->dig_a.as<uint8_t>();
+            P.dig_b = c->dig_b.as<uint8_t>();
+            P.shift = c->apx_shift.as<int32_t>();
+            P.G = c->Gapx[s].as<int32_t>();
+            P.lower_only = E.lower_only;
+            if (fuse) {
+                P.fuse = 1;
+                P.bin_t = bin_t;
+                P.bin_f = bin_f;
+                P.tab = A.tab11;
+                P.tab_nb = A.tab_nb;
+                P.clean = c->apx_clean[s].as<uint8_t>();
+            }
+            if (int rc = launch_gemm_apx(c, P, gs)) return rc;
+        }
+        LDW_HIP(hipEventRecord(ev[1], gs));
     }
     A.rloc_f = rlf;
     A.rloc_t = rlt;
@@ -1941,6 +1991,7 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     // both lists and the row lists keep the list order within a slot-count class, so the partners of a to-side SNP are a
     // contiguous row range per class
     std::vector<uint8_t> band((size_t)(hb.RTpad / TILE) * (hb.RFpad / 64), 0);
+    bool no_rowless = true;   // no SNP without an indicator row: a one-row SNP's row-list position is its slot (ApxGemmArgs::fuse)
     {
         const int ntx = hb.RFpad / 64;
         auto cls_of = [&](int32_t snp) { const int nr = c->h_row0[snp + 1] - c->h_row0[snp]; return nr <= 1 ? 0 : (nr == 2 ? 1 : 2); };
@@ -1954,10 +2005,12 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
             const int n = (int)(m & 7);
             if ((n == 1 || n == 2) && (((m >> 3) & ((2u << n) - 1u)) != ((2u << n) - 1u))) hb.lo.band_full = 1;
             if (n == 0) hb.lo.band_full = 1;   // SNPs without a row sit among the one-row SNPs in the row list but last in the tiles
+            if (n == 0) no_rowless = false;
         }
         for (int64_t b2 = 0; b2 < nt; ++b2) {
             const uint32_t m = c->h_slot_meta[(size_t)to_idx[b2]];
             const int n = (int)(m & 7);
+            if (n == 0) no_rowless = false;
             if ((n == 1 || n == 2) && (((m >> 3) & ((2u << n) - 1u)) != ((2u << n) - 1u))) hb.lo.band_full = 1;
         }
         {   // first row of each class region of the from-side row list (build_side: classes 1, 2, 4 in this order, 32-row aligned)
@@ -1996,6 +2049,7 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
                 }
             }
     }
+    hb.lo.fuse_ok = no_rowless ? 1 : 0;
     hb.o_cmax = o; o = al(o + cmax.size() * 4);
     hb.o_tbase = o; o = al(o + tbase.size() * 8);
     hb.o_tf = o; o = al(o + tf.size() * 4);

@@ -55,7 +55,8 @@ class Engine:
         """Launches and EXECUTED int8 operations of the block-wide GEMMs since the last reset (ldw_gemm_stats)."""
         v = np.zeros(6)
         L.check(L.lib().ldw_gemm_stats(self._ctx, L.ptr(v), int(reset)))
-        return dict(apx_launches=int(v[0]), apx_ops=float(v[1]), bits_launches=int(v[2]), bits_ops=float(v[3]), band_launches=int(v[4]))
+        return dict(apx_launches=int(v[0]), apx_ops=float(v[1]), bits_launches=int(v[2]), bits_ops=float(v[3]), band_launches=int(v[4]),
+                    apx_table_launches=int(v[5]))
 
     def counters(self):
         v = np.zeros(8, dtype=np.int64)

@@ -1124,6 +1124,47 @@ def test_apx_path_is_exact(engine):
         assert out["apx"][2]["apx_units_listed"] > 0 and out["apx"][2]["apx_pairs_listed"] > 0
 
 
+def test_table_test_in_the_gemm_epilogue_is_verified(engine):
+    """Long-range-only blocks of the approximate path: the GEMM's epilogue applies the threshold table to its own accumulators,
+    neither stores the 32 x 64 regions in which every pair passes nor lets the screen look at them.  Verify mode (every
+    dismissed pair is evaluated in fp64 and would count as a violation) must find nothing lost, the tables must equal the plain
+    path's, and the switch must really have been on for the far off-diagonal blocks."""
+    syn = synth_alignment(8400, 700, seed=23)
+    poly = np.array([len(np.unique(row)) >= 2 for row in syn["states"]])    # no monomorphic SNPs: a one-row SNP's row sits at its slot index
+    syn = dict(syn, states=np.ascontiguousarray(syn["states"][poly]), POS=syn["POS"][poly], paint=syn["paint"][poly])
+    st = syn["states"]
+    assert 7000 < len(st) <= 8400
+    uqe, r = orc.uqe_r(st)
+    engine.set_alignment(st)
+    hdw = engine.hamming_weights(len(st) // 10)
+    d = dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=syn["POS"], paint=syn["paint"], g=float(syn["g"]))
+    _setup(engine, d)
+    assert engine.apx_info()["usable"]
+    approx = MIH.lr_links_approx(syn["POS"], float(syn["g"]), 20000.0)
+    blocks = MIH.make_blocks(len(st), 2000)     # 4 x 4 (or 5 x 5) grid: (1,3) and (2,4) are far apart both ways round the circular genome
+    out = {}
+    for key, (mixed, scr, path) in dict(plain=(False, 0, 1), fast=(True, 1, 2), verify=(True, 2, 2)).items():
+        engine.set_mixed(mixed)
+        engine.set_screen(scr)
+        engine.set_path(path)
+        c0 = engine.counters()
+        engine.gemm_stats(reset=True)
+        for _ in range(2):
+            engine.mi_all_pairs(blocks, 20000.0, 40000.0, approx)
+        c1 = engine.counters()
+        out[key] = (engine.links(0), engine.links(1), {k: c1[k] - c0[k] for k in c1}, engine.gemm_stats())
+    engine.set_mixed(True)
+    engine.set_screen(1)
+    engine.set_path(0)
+    assert out["fast"][3]["apx_table_launches"] >= 2 and out["verify"][3]["apx_table_launches"] >= 2, out["fast"][3]
+    assert out["verify"][2]["screen_violations"] == 0
+    for which in (0, 1):
+        for key in ("fast", "verify"):
+            for x, y in zip(out["plain"][which], out[key][which]):
+                assert np.array_equal(x, y), (which, key)
+    assert len(out["plain"][1][2]) > 10000
+
+
 def test_apx_path_sr_only(engine):
     """SR-only passes need no block-wide GEMM at all in the approximate path (the screen lists the units that hold a
     short-range pair; their sums come from the popcounts): same table as the limb path, bit for bit."""
