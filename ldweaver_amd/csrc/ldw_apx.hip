@@ -277,16 +277,21 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
             bool ok = true;
 #pragma unroll
             for (int j = 0; j < NT; ++j) ok = ok && bf[j] != 255;
+            int bt[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int bt = (int)s_bt[32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh];
-                ok = ok && bt != 255;
+                bt[e] = (int)s_bt[32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh];
+                ok = ok && bt[e] != 255;
+            }
+            if (__ballot(!ok) == 0ull) {   // (a region with a row of another kind of SNP is stored without the 32 look-ups per lane)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int2 th = s_tab[(bt & 63) * P.tab_nb + (bf[j] & 63)];
-                    const int n = acc[i][j][e];
-                    ok = ok && n > th.x && n < th.y;
-                }
+                for (int e = 0; e < 16; ++e)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int2 th = s_tab[bt[e] * P.tab_nb + bf[j]];
+                        const int n = acc[i][j][e];
+                        ok = ok && n > th.x && n < th.y;
+                    }
             }
             const bool clean = __ballot(!ok) == 0ull;
             if (lane == 0) {
