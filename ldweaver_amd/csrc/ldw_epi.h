@@ -533,9 +533,14 @@ __device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSi
         }
     }
     if (APX) {
-        constexpr float lost = (float)((NA + 1) * (NB + 1)) * (float)(NA + NB + 1);
-        constexpr float lost_g = (float)((NA + 1) * (NB + 1) * NA * NB);
-        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + (lost + lost_g * A.E.apx_EG) * A.E.apx_s1;
+        // units (2^e_last) by which the cells of this table can be off, summed over the cells.  A GEMM entry n' is at most EG units
+        // below its sum (truncation at the exponent transitions), a marginal less than 1 unit below (floor), and the errors of a
+        // derived cell have OPPOSITE signs: row-derived (i, NB) = pa_i - sum_j n_ij is off by (-NB EG, 1), column-derived likewise,
+        // the corner pa_NA - sum_j pb_j + sum_ij n_ij by (-NB, 1 + NA NB EG).
+        const float EG = A.E.apx_EG;
+        const float lost_units = (float)(NA * NB) * EG + (float)NA * fmaxf(1.0f, (float)NB * EG) + (float)NB * fmaxf(1.0f, (float)NA * EG) +
+                                 fmaxf((float)NB, 1.0f + (float)(NA * NB) * EG);
+        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + lost_units * A.E.apx_s1;
         return fmaf(acc, 0.6931471805599453f, extra) * __builtin_amdgcn_rcpf(den);
     }
     return acc * (0.6931471805599453f * __builtin_amdgcn_rcpf(den));
@@ -603,8 +608,10 @@ __device__ __forceinline__ float pair_screen_generic(const EpiArgs &A, const Row
             }
         }
     }
-    if (APX) {   // see full_cells_screen: up to 25 cells, each may have lost 9 + 16 apx_EG units
-        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + 25.0f * (9.0f + 16.0f * A.E.apx_EG) * A.E.apx_s1;
+    if (APX) {   // see full_cells_screen: the units the cells can be off by, for na x nb indicator rows
+        const float EG = A.E.apx_EG, fa = (float)na, fb = (float)nb;
+        const float lost_units = fa * fb * EG + fa * fmaxf(1.0f, fb * EG) + fb * fmaxf(1.0f, fa * EG) + fmaxf(fb, 1.0f + fa * fb * EG);
+        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + lost_units * A.E.apx_s1;
         return fmaf(acc, 0.6931471805599453f, extra) * __builtin_amdgcn_rcpf(den);
     }
     return acc * (0.6931471805599453f * __builtin_amdgcn_rcpf(den));
