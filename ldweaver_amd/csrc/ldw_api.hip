@@ -792,6 +792,7 @@ int ensure_rows(ldw_ctx *c) {
     c->rows_ready = true;
     c->spec_B_next[0] = c->spec_B_next[1] = -1;   // bucket guesses of an earlier alignment / weighting say nothing about this one
     c->spec_seen[0] = c->spec_seen[1] = false;
+    c->spec_hist_n[0] = c->spec_hist_n[1] = 0;
     return LDW_OK;
 }
 

@@ -176,6 +176,8 @@ struct ldw_ctx {
                                          // GEMM -> k_mi_screen -> k_mi_units, which measures 7 % faster on C4
     bool spec_seen[2] = {false, false};  // a block of this kind (off-diagonal, diagonal) has set its own guess
     std::vector<hipEvent_t> ev_pool;     // 4 timing events per block
+    int spec_hist[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};   // the last true buckets per kind (adaptive margin of the guess)
+    int spec_hist_n[2] = {0, 0};
     int spec_B_next[2] = {-1, -1};       // bucket guess for the speculative long-range gather: [off-diagonal, diagonal]
     int64_t spec_misses = 0, fused_blocks = 0, unfused_blocks = 0, screen_violations = 0, mixed_blocks = 0;
     int screen = 1;                      // fp32 screen in front of the fp64 MI evaluation (0 off, 1 on, 2 verify)

@@ -2314,6 +2314,7 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
     LDW_HIP(hipEventSynchronize(c->ev_pick[s]));
     if (hb.fused) LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_gemm[s], 0));   // selection runs on the main stream
     ldw::PickOut *hp = static_cast<ldw::PickOut *>(c->pin_pick[s]);
+    bool missed = false;
     if (do_lr && hb.spec_B >= 0 && hp->n > 0 && !hp->spec_ok) {
         // the bucket guess was above the true bucket: redo the epilogue non-speculatively (the short-range rows are
         // already final): full histogram, dense store, then pick and gather with the true bucket.  The plain two-kernel
@@ -2336,16 +2337,37 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
         LDW_HIP(hipMemcpyAsync(c->pin_pick[s], sl.pick[s], sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
         LDW_HIP(hipStreamSynchronize(c->stream));
         ++c->spec_misses;
+        missed = true;
     }
     if (do_lr && hp->n > 0) {  // guesses for later blocks: a little below this block's bucket
         // buckets are 0.5 % wide: guess ~5 % below the threshold of the last block of the same kind.  Diagonal blocks
         // lose their closest pairs to the short-range table and sit ~8 % (16 buckets) lower than off-diagonal ones:
         // until a block of the other kind has been seen, its guess is derived from this one with a wider margin.
-        const int margin = 10, kind = hb.diag ? 1 : 0, other = kind ^ 1;
+        const int kind = hb.diag ? 1 : 0, other = kind ^ 1;
+        // the margin follows what the thresholds of this kind have actually done: the spread of the last six of them plus two
+        // buckets, between 4 and 10 (every bucket below the true one costs ~3000 more candidates on the C4 shape; a miss costs a
+        // full non-speculative pass of the block, after which the history starts over)
+        int &hn = c->spec_hist_n[kind];
+        if (missed) hn = 0;
+        c->spec_hist[kind][hn % 6] = hp->B_true;
+        ++hn;
+        int margin = 10;
+        if (hn >= 3) {
+            int lo = hp->B_true, hi = hp->B_true;
+            for (int k = 0; k < (hn < 6 ? hn : 6); ++k) {
+                lo = c->spec_hist[kind][k] < lo ? c->spec_hist[kind][k] : lo;
+                hi = c->spec_hist[kind][k] > hi ? c->spec_hist[kind][k] : hi;
+            }
+            // few kept rows per block (many blocks: C5 keeps ~800 per block) make the threshold itself noisier
+            const bool small = hp->n * (1.0 - hp->prob) < 5000.0;
+            margin = hi - lo + (small ? 4 : 2);
+            const int mmin = small ? 6 : 4;
+            margin = margin < mmin ? mmin : (margin > 10 ? 10 : margin);
+        }
         c->spec_B_next[kind] = hp->B_true - margin > 0 ? hp->B_true - margin : 0;
         c->spec_seen[kind] = true;
         if (!c->spec_seen[other]) {
-            const int g = hb.diag ? hp->B_true - margin : hp->B_true - 16 - 2 * margin;
+            const int g = hb.diag ? hp->B_true - 10 : hp->B_true - 16 - 2 * 10;
             c->spec_B_next[other] = g > 0 ? g : 0;
         }
     }
