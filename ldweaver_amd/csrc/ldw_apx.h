@@ -42,6 +42,7 @@ struct ApxGemmArgs {
     const int2 *tab;
     int tab_nb;
     uint8_t *clean;
+    const uint8_t *sr_mask;              // optional [RTpad / 128][RFpad / 64]: tiles that hold a short-range pair are never clean
 };
 
 int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st);

@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
             bool ok = true;
 #pragma unroll
             for (int j = 0; j < NT; ++j) ok = ok && bf[j] != 255;
+            if (P.sr_mask && P.sr_mask[(int64_t)ty * (P.RFpad / 64) + tx] != 0) ok = false;   // (TH = 128, TWd = 64: the band mask's own tiles)
             int bt[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {

@@ -1642,7 +1642,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     }
     // long-range-only blocks: the GEMM applies the table itself and neither stores nor lets the screen read the regions that pass
     static const bool fuse_on = getenv("LDW_NO_FUSE_TAB") == nullptr;
-    const bool fuse = fuse_on && lo_h->fuse_ok && A.tab11 && A.tab_nb == 64 && (use_pairs || c->screen == 2) && E.do_lr && !E.any_sr && !E.lower_only && RFpad % 64 == 0 &&   // (verify mode: the clean regions' units are listed as dismissed and checked in fp64)
+    const bool fuse = fuse_on && lo_h->fuse_ok && A.tab11 && A.tab_nb == 64 && (use_pairs || c->screen == 2) && E.do_lr && (!E.any_sr || (D.band_mask && !lo_h->band_full)) && !E.lower_only && RFpad % 64 == 0 &&   // (verify mode: the clean regions' units are listed as dismissed and checked in fp64)
                       2048 + (size_t)(c->KW / 2) * 256 + 64 * 64 * 8 + 1024 <= 65536;   // (the table shares the GEMM's LDS with the digit arrays)
     uint8_t *bin_t = c->apx_bins[s].as<uint8_t>(), *bin_f = bin_t + RTpad;
     if (fuse) {
@@ -1710,6 +1710,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
                 P.tab = A.tab11;
                 P.tab_nb = A.tab_nb;
                 P.clean = c->apx_clean[s].as<uint8_t>();
+                P.sr_mask = E.any_sr ? D.band_mask : nullptr;   // a block with a short-range corner: its band tiles stay with the screen
             }
             if (int rc = launch_gemm_apx(c, P, gs)) return rc;
         }
