@@ -161,7 +161,9 @@ def main():
         if len(sub):
             eng.mi_all_pairs(blocks[sub], sr_dist, lr_retain, approx)
             st = eng.block_stats()
-            local = {"sr": eng.links(0, device_tensors=True), "lr": eng.links(1, device_tensors=True)}
+            # the tables as they lie in HBM (no copy): on one rank they ARE the assembled result; on several ranks gather_begin packs
+            # them into its send buffer before the next blocks are computed
+            local = {"sr": eng.links_view(0), "lr": eng.links_view(1)}
             cnt = {"sr": st["n_sr"], "lr": st["n_lr_kept"]}
             if accumulate_timing:
                 for k, v in eng.last_timing().items():

@@ -210,6 +210,10 @@ int ldw_links_count(ldw_ctx *ctx, int which, int64_t *n_out);
  * gives each processed block's first row. */
 int ldw_links_fetch(ldw_ctx *ctx, int which, int32_t *a_out, int32_t *b_out, double *MI_out,
                     int64_t capacity, int on_device);
+/* The table itself, without a copy: DEVICE pointers to the context's own (a, b, MI) columns and the row count.  Valid until the
+ * next call that changes the table (ldw_mi_all_pairs, ldw_links_begin, ldw_links_import, ldw_ctx_destroy); read-only. */
+int ldw_links_device_ptrs(ldw_ctx *ctx, int which, const int32_t **a_out, const int32_t **b_out, const double **MI_out,
+                          int64_t *n_out);
 /* Replace the context's short-range (which = 0) or long-range (1) table by caller data (host or device memory): how the
  * rank that received the other ranks' tables in the multi-GPU gather hands the assembled table to the short-range model,
  * ARACNE and the post-processing entry points below, which work on the context's tables. */

@@ -70,6 +70,7 @@ _SIGS = {
     "ldw_set_screen": (C.c_int, [_p, C.c_int]),
     "ldw_set_path": (C.c_int, [_p, C.c_int]),
     "ldw_set_select": (C.c_int, [_p, C.c_int]),
+    "ldw_links_device_ptrs": (C.c_int, [_p, C.c_int, _p, _p, _p, _p]),
     "ldw_apx_info": (C.c_int, [_p, _p]),
     "ldw_links_count": (C.c_int, [_p, C.c_int, C.POINTER(_i64)]),
     "ldw_links_fetch": (C.c_int, [_p, C.c_int, _p, _p, _p, _i64, C.c_int]),

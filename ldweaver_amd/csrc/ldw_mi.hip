@@ -2757,6 +2757,18 @@ int ldw_links_count(ldw_ctx *c, int which, int64_t *n_out) {
     return LDW_OK;
 }
 
+int ldw_links_device_ptrs(ldw_ctx *c, int which, const int32_t **a_out, const int32_t **b_out, const double **MI_out, int64_t *n_out) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE((which == 0 || which == 1) && a_out && b_out && MI_out && n_out, LDW_ERR_ARG, "ldw_links_device_ptrs: bad argument");
+    LDW_REQUIRE(c->blk_capacity == 0, LDW_ERR_STATE, "ldw_links_device_ptrs: a link pass is still open (ldw_links_end)");
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    *a_out = (which == 0 ? c->sr_a : c->lr_a).as<int32_t>();
+    *b_out = (which == 0 ? c->sr_b : c->lr_b).as<int32_t>();
+    *MI_out = (which == 0 ? c->sr_mi : c->lr_mi).as<double>();
+    *n_out = which == 0 ? c->n_sr : c->n_lr;
+    return LDW_OK;
+}
+
 int ldw_links_fetch(ldw_ctx *c, int which, int32_t *a_out, int32_t *b_out, double *MI_out, int64_t capacity,
                     int on_device) {
     if (int rc = check_gpu(c)) return rc;

@@ -226,6 +226,23 @@ class Engine:
         L.check(L.lib().ldw_links_count(self._ctx, int(which), C.byref(n)))
         return int(n.value)
 
+    def links_view(self, which: int):
+        """(a, b, MI) as torch tensors that ALIAS the context's own table in HBM (no copy): valid until the next call that
+        changes the table; do not write to them."""
+        import torch
+        pa, pb, pm, n = C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_int64(0)
+        L.check(L.lib().ldw_links_device_ptrs(self._ctx, int(which), C.byref(pa), C.byref(pb), C.byref(pm), C.byref(n)))
+
+        class _View:
+            def __init__(self, ptr, n, typestr):
+                self.__cuda_array_interface__ = dict(shape=(n,), typestr=typestr, data=(ptr or 0, False), version=2)
+
+        dev = torch.device("cuda", self.device)
+        if n.value == 0:
+            return torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.float64, device=dev)
+        mk = lambda p, ts: torch.as_tensor(_View(p.value, n.value, ts), device=dev)
+        return mk(pa, "<i4"), mk(pb, "<i4"), mk(pm, "<f8")
+
     def links(self, which: int, device_tensors=False):
         """(a, b, MI): 0-based from-side / to-side SNP indices and MI of the short-range (0) or long-range (1) table."""
         n = self.links_count(which)

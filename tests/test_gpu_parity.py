@@ -195,6 +195,9 @@ def test_link_tables_match_golden(engine, sample):
         blocks = MIH.make_blocks(1268, mb)
         engine.mi_all_pairs(blocks, 20000.0, retain, float(sample[f"{tag}_lr_approx"]))
         _check_tables(engine, sample, tag, sample["POS"], sample["paint"])
+        for which in (0, 1):     # the zero-copy device view (ldw_links_device_ptrs) shows the same table
+            for x, y in zip(engine.links(which), engine.links_view(which)):
+                assert y.is_cuda and np.array_equal(x, y.cpu().numpy())
         st = engine.block_stats()
         assert st["n_lr_kept"].sum() == int(sample[f"{tag}_lr_n"])
 
