@@ -2449,6 +2449,9 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
 // whether the next block can be submitted before the current one is finished: the fused path needs a bucket guess
 bool can_submit_early(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p) {
     if (!c->overlap) return false;
+    // no bucket guess for this kind of block yet (the first blocks of a cold pass): the block in flight is about to provide one —
+    // submitted now, this block would take the non-speculative path (full 5-limb GEMM, fp64 for every pair: ~4 ms more)
+    if (c->engine == LDW_ENGINE_MFMA && !p->sr_only && c->screen && c->spec_B_next[hb.diag ? 1 : 0] < 0) return false;
     if (c->engine != LDW_ENGINE_MFMA || !c->fused || c->nlimbs > 5 || p->sr_only) return true;
     return c->spec_B_next[hb.diag ? 1 : 0] >= 0;
 }
