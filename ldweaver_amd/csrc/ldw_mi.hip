@@ -6,13 +6,22 @@
 //   (src/computeMI.cpp:19), writes the dense MI block, scatters the short-range links straight to their final rows and
 //   histograms the long-range MI values in LDS -> k_pick_bucket: ranks of the two order statistics of quantile type 7
 //   and the histogram bucket holding them -> k_lr_gather: every long-range pair at or above that bucket.
-// Every other block (speculative: the guess is the previous same-kind block's bucket minus a margin):
+// Every other block (speculative: the guess is an earlier same-kind block's bucket minus an adaptive margin), DEFAULT path when the
+// weights allow it (launch_block_apx, ldw_apx.hip): k_pack_panel -> k_zero4 -> k_build_packs -> gemm_apx_kernel (ONE dual-digit int8
+//   pass into the int32 block G'; on off-diagonal blocks its epilogue applies the threshold table and neither stores nor flags for
+//   screening the regions that pass) -> k_mi_screen<RM, true> / k_mi_screen_generic<true> (rigorous fp32 upper bound of MI from G';
+//   long-range candidates go to PAIR lists, units with a short-range pair to the unit list) -> k_pair_sums / k_pair_mi (exact int64
+//   sums of the listed pairs by class-wise popcounts, fp64 MI) + gemm_bits_kernel<5> on the band's tiles -> k_mi_units (short-range
+//   units) -> k_pick_bucket.
+// The limb paths (ldw_set_path(1), or weights the approximation cannot serve):
 //   GEMM, 3 high limbs -> k_build_packs (per-block SNP constants in epilogue order) -> k_mi_screen / k_mi_screen_generic
 //   (fp32 upper bound of MI per pair; lists the units = 64 from-side SNPs x 1 to-side SNP that hold a short-range pair
 //   or a pair that may reach the guessed bucket) -> gemm_lo_units_kernel (the 2 low limbs of the listed units' joint sums)
 //   -> k_mi_units<true|false> (fp64 MI of the listed units, short-range rows to their final rows, candidates >= the
 //   guessed bucket appended and counted) -> k_pick_bucket (verifies the guess).
-// Then, either way: two radix sorts (by MI, then by reference row order) with k_lr_thresh in between -> k_lr_append.
+// Then, either way: k_sel_thresh / k_sel_mark / k_sel_scatter / k_sel_clear (radix select of the threshold, bitmap ranks: no sort), or,
+// for blocks without a guess and very large candidate sets, two radix sorts (by MI, then by reference row order) with k_lr_thresh in
+// between -> k_lr_append.
 // The short-range test needs no arithmetic per pair: POS is ascending, so the partners of a to-side SNP within sr_dist
 // (circularly) are at most three index intervals of the from-side list, found on the host by binary search (ColInfo).
 // The fused alternative (GEMM + epilogue in one kernel, ldw_set_fused) lives in ldw_fused.hip.
