@@ -319,7 +319,7 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
                 P.RFpad, P.M2);
     const size_t lds = 2048 + (size_t)P.M2 * 256 + (P.fuse ? (size_t)P.tab_nb * P.tab_nb * 8 + 1024 : 0);
     LDW_REQUIRE(lds <= 65536, LDW_ERR_ARG, "launch_gemm_apx: %d positions do not fit the LDS digit arrays", P.M2 * 128);
-    LDW_REQUIRE(!P.fuse || (P.tab_nb == 64 && P.bin_t && P.bin_f && P.tab && P.clean && !P.lower_only), LDW_ERR_ARG, "launch_gemm_apx: bad table arguments");
+    LDW_REQUIRE(!P.fuse || (P.tab_nb == 64 && P.bin_t && P.bin_f && P.tab && P.clean), LDW_ERR_ARG, "launch_gemm_apx: bad table arguments");
     static const int tile = [] {
         const char *e = getenv("LDW_APX_TILE");   // tuning: wave tile in MFMA tiles, to side x from side (default 4 x 2)
         return e ? atoi(e) : 42;

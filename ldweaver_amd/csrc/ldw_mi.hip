@@ -640,13 +640,13 @@ __global__ __launch_bounds__(256) void k_mi_units(EpiArgs A, const int32_t *__re
 // one launch instead of four or five hipMemsetAsync per block (each a 4-5 us kernel of its own plus a dispatch gap): zeroes up to
 // four small buffers, sizes in 16-byte pieces
 struct ZeroArgs {
-    uint4 *p[4];
-    unsigned int n16[4];
+    uint4 *p[5];
+    unsigned int n16[5];
 };
 __global__ __launch_bounds__(256) void k_zero4(ZeroArgs Z) {
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 5; ++k)
         for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < Z.n16[k]; i += gridDim.x * 256u) Z.p[k][i] = z;
 }
 
@@ -1651,7 +1651,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     }
     // long-range-only blocks: the GEMM applies the table itself and neither stores nor lets the screen read the regions that pass
     static const bool fuse_on = getenv("LDW_NO_FUSE_TAB") == nullptr;
-    const bool fuse = fuse_on && lo_h->fuse_ok && A.tab11 && A.tab_nb == 64 && (use_pairs || c->screen == 2) && E.do_lr && (!E.any_sr || (D.band_mask && !lo_h->band_full)) && !E.lower_only && RFpad % 64 == 0 &&   // (verify mode: the clean regions' units are listed as dismissed and checked in fp64)
+    const bool fuse = fuse_on && lo_h->fuse_ok && A.tab11 && A.tab_nb == 64 && (use_pairs || c->screen == 2) && E.do_lr && (!E.any_sr || (D.band_mask && !lo_h->band_full)) && RFpad % 64 == 0 &&   // (verify mode: the clean regions' units are listed as dismissed and checked in fp64)
                       2048 + (size_t)(c->KW / 2) * 256 + 64 * 64 * 8 + 1024 <= 65536;   // (the table shares the GEMM's LDS with the digit arrays)
     uint8_t *bin_t = c->apx_bins[s].as<uint8_t>(), *bin_f = bin_t + RTpad;
     if (fuse) {
@@ -1684,6 +1684,10 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             if (use_pairs) {
                 Z.p[1] = reinterpret_cast<uint4 *>(c->pairs[s].p);
                 Z.n16[1] = (unsigned int)((o_pairs + 15) / 16);
+            }
+            if (fuse && E.lower_only) {   // diagonal block: the GEMM skips the tiles above the diagonal, whose regions must read "not clean"
+                Z.p[4] = reinterpret_cast<uint4 *>(c->apx_clean[s].p);
+                Z.n16[4] = (unsigned int)(((size_t)(RTpad / 32) * (size_t)(RFpad / 64) + 15) / 16);
             }
             if (zero_hist) {
                 Z.p[2] = reinterpret_cast<uint4 *>(zero_hist);
