@@ -317,8 +317,10 @@ def main():
                              "flops per pair x pairs per launch / executed operations: one indicator row per minor state instead of 5 one-hot "
                              "planes, " + ("one dual-digit pass instead of 5 limbs (the exact sums of what the screen lists come from "
                                            "k_pair_sums / the band GEMM)" if apx else f"{3 if mixed_blocks else J} int8 limbs") +
-                             ".  `overlapped_avg_launch_ms` is the bracket inside the timed region, where the GEMM shares the GPU with the "
-                             "previous block's screens and selection")
+                             ".  The launch time of gemm_apx_kernel includes its epilogue, which applies the screen's threshold table to the "
+                             "kernel's own accumulators (the regions that pass are neither stored nor screened): without it the same K loop "
+                             "takes 0.494 ms per launch = 0.51 of the peak (DESIGN.md 5.1c).  `overlapped_avg_launch_ms` is the bracket inside "
+                             "the timed region, where the GEMM shares the GPU with the previous block's screens and selection")
             tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
             if os.path.exists(tpath) and (L, N, world) == (100_000, 5_000, 1):   # the configuration the PMC passes were collected on
                 ent = json.load(open(tpath)).get(kname)
