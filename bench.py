@@ -12,11 +12,18 @@ matrix, weights and SNP meta data are resident in HBM before the timed region.  
 dealt over the ranks (total work fixed -> "strong" scaling) and gathered with one RCCL gatherv.
 Prints ONE JSON line on rank 0.
 
+Every step is a COLD pass, as a job runs it: `ldw_reset_speculation` forgets the histogram-bucket guesses, their spread history
+and the biallelic threshold table before each step (warm-up steps included), so a step visits every block pair once without
+anything learnt from an earlier pass over the same data (R/computePairwiseMI.R:103-116).  Buffers stay allocated.
+
 Order of work (so that a coarse GPU-busy sampler sees the GPU section as one stretch at the end of the run): setup ->
 `cpu_baseline` on the host cores (rank 0, N = 1 only) -> W warm-up steps -> EXACTLY K timed steps -> (N = 1 only) the extra
-legs reported on the same line: `sustained` (the same step repeated until >= 10 s of GPU work have run), the kernel-exclusive
-replay behind `roofline`, `plain` (5-limb GEMM + fp64 MI of every pair: no screen, no mixed precision, no approximate GEMM)
-and `cold_first_pass_ms` (one pass without the histogram-bucket guesses that every warm step inherits from its predecessor).
+legs reported on the same line: `warm_replay` (K steps WITHOUT the reset: every pass inherits its predecessor's guesses — the
+r02 headline, kept for comparison), `sustained` (cold steps until >= 10 s of GPU work have run), the kernel-exclusive replay
+behind `roofline`, `mi_values_produced` (5-limb GEMM + fp64 MI of EVERY pair: no screen, no mixed precision, no approximate
+GEMM — the rate at which MI values, not decisions, are produced) and `job` (the product entry points end to end, state matrix
+on the HOST -> both tsv files on disk: `h2d_ms`, Hamming weights, cold MI pass, `tsv_write_s`, short-range model + ARACNE).
+With N > 1 the line carries `per_rank` (compute_ms, exposed_gather_ms, bytes_sent of every rank).
 """
 import argparse
 import json
@@ -53,7 +60,10 @@ def parse():
     ap.add_argument("--screen", type=int, default=1, help="fp32 screen before the fp64 MI evaluation: 0 off, 1 on, 2 verify")
     ap.add_argument("--gather-phases", type=int, default=3, help="N > 1: phases of the link-table gather (1 = one gather after all blocks)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="SNPs per side of the CPU-baseline sample block (0 = auto)")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the sustained / plain / cold legs after the timed region")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the warm / sustained / mi_values_produced / job legs after the timed region")
+    ap.add_argument("--warm", action="store_true", help="do NOT reset the speculation state before every step (the r02 behaviour: each step inherits "
+                                                        "the previous step's bucket guesses); the default is a cold pass per step")
+    ap.add_argument("--no-job", action="store_true", help="skip the end-to-end job leg (host states -> tsv files)")
     ap.add_argument("--sustain-s", type=float, default=10.0, help="N = 1: keep stepping after the timed region until this many seconds of steps have run")
     return ap.parse_args()
 
@@ -75,6 +85,55 @@ def cpu_baseline(states_np, hdw, r, uqe, N, sample):
                 sample=f"one diagonal + one off-diagonal {s}x{s} sub-block of the workload's first 10000-SNP block at N={N} (all 25 state "
                        f"pairs, dense x CSR + fused Hadamard), {dt:.1f} s wall.  A whole 10000 x 10000 block is 25x the pairs (minutes on "
                        f"these cores); the cost is linear in pairs at fixed N, so the sample rate extrapolates")
+
+
+def job_leg(states, POS, paint, g, L, N, device, args):
+    """The whole job through the PRODUCT entry points (ldweaver_amd.mi, the mirror of the R functions), on its own engine:
+    H2D of the state matrix, estimate_Hamming_distance_weights, perform_MI_computation (cold MI pass, lr_links.tsv, short-range
+    model, ARACNE, sr_links.tsv).  What the reference's job contains (R/computePairwiseMI.R:46-145) and the bench's timed step
+    leaves out: the upload and the two write.table calls (:140, :362)."""
+    import shutil
+    import tempfile
+
+    import torch
+    from ldweaver_amd import mi as MIH
+    from ldweaver_amd.engine import Engine
+    from ldweaver_amd.snpdat import CdsVar, SnpDat
+
+    st_host = states.cpu().numpy()                       # pageable host memory, as R would hand it over
+    tmp = tempfile.mkdtemp(prefix="ldw_job_")
+    out = {}
+    try:
+        with Engine(device) as e2:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e2.set_alignment(st_host)
+            e2.sync()
+            out["h2d_ms"] = (time.perf_counter() - t0) * 1e3
+            out["h2d_GBps"] = st_host.nbytes / (out["h2d_ms"] * 1e-3) / 1e9
+            counts = e2.state_counts()
+            sd = SnpDat.from_states(st_host, POS, g, counts=counts)
+            t1 = time.perf_counter()
+            hdw = MIH.estimate_Hamming_distance_weights(sd, threshold=0.1, engine=e2, alignment_resident=True, verbose=False)
+            out["hamming_weights_s"] = time.perf_counter() - t1
+            t2 = time.perf_counter()
+            red, aux = MIH.perform_MI_computation(sd, hdw, CdsVar(paint=paint, nclust=3), lr_save_path=os.path.join(tmp, "lr_links.tsv"),
+                                                  sr_save_path=os.path.join(tmp, "sr_links.tsv"), plt_folder=os.path.join(tmp, "PLOTS"),
+                                                  max_blk_sz=args.max_blk_sz, engine=e2, alignment_resident=True, verbose=False, return_aux=True)
+            out["perform_MI_computation_s"] = time.perf_counter() - t2
+            out["stages_s"] = aux.get("stages_s")
+            out["tsv_write_s"] = aux["tsv_write_s"]
+            out["lr_rows_written"] = aux["lr_rows_written"]
+            out["sr_rows_written"] = int(len(red))
+            out["lr_tsv_bytes"] = os.path.getsize(os.path.join(tmp, "lr_links.tsv")) if aux["lr_rows_written"] else 0
+            out["sr_tsv_bytes"] = os.path.getsize(os.path.join(tmp, "sr_links.tsv"))
+            out["path"] = aux["path"]
+        out["job_s"] = out["h2d_ms"] * 1e-3 + out["hamming_weights_s"] + out["perform_MI_computation_s"]
+        out["what"] = ("states on the host -> H2D -> estimate_Hamming_distance_weights -> perform_MI_computation (cold MI pass of all block pairs, "
+                       "lr_links.tsv, short-range model, ARACNE, sr_links.tsv on disk); first use of this engine, so its allocations are inside")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 def main():
@@ -180,16 +239,33 @@ def main():
     n_phase = 1 if world == 1 else max(1, min(args.gather_phases, (nblocks // world) // 3))
     my_phases = np.array_split(mine, n_phase)
 
-    def step(accumulate_timing):
+    rk_acc = dict(compute_ms=0.0, gather_begin_ms=0.0, exposed_gather_ms=0.0, bytes_sent=0, steps=0)
+    cold = not args.warm
+
+    def step(accumulate_timing, reset=None):
+        if cold if reset is None else reset:
+            eng.reset_speculation()   # a job's first (and only) pass: nothing inherited from an earlier pass over the same data
         if world == 1:
             local, cnt = compute(mine, accumulate_timing)
             out = gather_link_tables(local, mine, cnt, nblocks)
         else:
             started = []
             for sub in my_phases:
+                t0 = time.perf_counter()
                 local, cnt = compute(sub, accumulate_timing)
+                t1 = time.perf_counter()
                 started.append(gather_begin(local, sub, cnt, nblocks))
+                t2 = time.perf_counter()
+                if accumulate_timing:
+                    rk_acc["compute_ms"] += (t1 - t0) * 1e3
+                    rk_acc["gather_begin_ms"] += (t2 - t1) * 1e3
+                    if rank != 0:
+                        rk_acc["bytes_sent"] += int(started[-1].mine.numel())
+            t3 = time.perf_counter()
             out = gather_end(started, nblocks)
+            if accumulate_timing:
+                rk_acc["exposed_gather_ms"] += (time.perf_counter() - t3) * 1e3   # waiting for transfers + (rank 0) re-interleaving the segments
+                rk_acc["steps"] += 1
         if out is not None:
             result["n_sr"] = int(out["sr"][2].numel())
             result["n_lr"] = int(out["lr"][2].numel())
@@ -199,12 +275,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n, accumulate=False):
+    def timed(n, accumulate=False, reset=None):
         """n steps bracketed by fences; wall seconds."""
         fence()
         t0 = time.perf_counter()
         for _ in range(n):
-            step(accumulate)
+            step(accumulate, reset)
         fence()
         return time.perf_counter() - t0
 
@@ -220,10 +296,23 @@ def main():
     dt = float(tmax.item())
     counters_timed = eng.counters()
     links_timed = dict(result)
+    per_rank = None
+    if world > 1:
+        mine_rec = dict(rank=rank, blocks=int(len(mine)), phases=int(n_phase),
+                        **{k: (v / max(1, rk_acc["steps"]) if k != "steps" else v) for k, v in rk_acc.items()})
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_rec)
 
     extra = rank == 0 and world == 1 and len(my_blocks) and not args.no_extra_legs
     legs = {}
-    # ---- sustained: the same step until >= 10 s of steps have run (clock / thermal steady state; also what a coarse busy
+    # ---- warm replay: K steps that inherit their predecessor's bucket guesses, spread history and threshold table (what r02
+    # reported as its headline; a real job never sees this state) ----
+    if extra and cold:
+        timed(1, reset=False)
+        t_w = timed(args.steps, reset=False)
+        legs["warm_replay"] = dict(ms_per_step=t_w / args.steps * 1e3, value=pairs * args.steps / t_w, steps=args.steps, links=dict(result),
+                                   note="steps WITHOUT ldw_reset_speculation: each inherits the previous identical step's guesses (not a job)")
+    # ---- sustained: the same (cold) step until >= 10 s of steps have run (clock / thermal steady state; also what a coarse busy
     # sampler can see) ----
     if extra and args.sustain_s > 0:
         done_s, n_s = dt, args.steps
@@ -235,7 +324,7 @@ def main():
             n_chunk += k
         if n_chunk:
             legs["sustained"] = dict(steps=n_chunk, seconds=t_chunk, ms_per_step=t_chunk / n_chunk * 1e3, value=pairs * n_chunk / t_chunk,
-                                     note="further steps of the same workload right after the timed region")
+                                     note="further steps of the same kind right after the timed region")
 
     # ---- kernel-exclusive stage times for the roofline: in the timed region the GEMM of block b+1 runs on a second stream
     # beside the epilogue / selection of block b, so HIP-event brackets of one kernel also contain its neighbours.  Replay
@@ -261,7 +350,7 @@ def main():
         cnt_replay = {k: c1[k] - c0[k] for k in c1}
         eng.set_overlap(not args.no_overlap)
 
-    # ---- plain: no screen, no mixed precision, no approximate GEMM: 5-limb GEMM + fp64 MI of every pair ----
+    # ---- mi_values_produced: no screen, no mixed precision, no approximate GEMM: 5-limb GEMM + fp64 MI of every pair ----
     if extra and args.engine == "mfma":
         eng.set_mixed(False)
         eng.set_screen(0)
@@ -269,16 +358,19 @@ def main():
         timed(1)
         n_pl = 3
         t_pl = timed(n_pl)
-        legs["plain"] = dict(ms_per_step=t_pl / n_pl * 1e3, value=pairs * n_pl / t_pl, steps=n_pl, links=dict(result),
-                             what="--no-mixed --screen 0 --path 1: gemm_bits_kernel<5> + k_mi_epilogue (fp64 MI of every pair), same link tables")
+        legs["mi_values_produced"] = dict(ms_per_step=t_pl / n_pl * 1e3, value=pairs * n_pl / t_pl, steps=n_pl, links=dict(result),
+                                          what="--no-mixed --screen 0 --path 1: gemm_bits_kernel<5> + k_mi_epilogue: an fp64 MI VALUE for every pair "
+                                               "(the headline counts pairs DECIDED: the default path bounds 99.7 % of the pairs below their block's "
+                                               "threshold instead of evaluating them; same link tables)")
         eng.set_mixed(not args.no_mixed)
         eng.set_screen(args.screen)
         eng.set_path(args.path)
-        # ---- cold: setting the weights again forgets the bucket guesses (buffers stay allocated): one pass as a real job runs it
-        eng.set_weights(hdw, args.nlimbs)
-        legs["cold_first_pass_ms"] = timed(1) * 1e3
-        legs["cold_links"] = dict(result)
         legs["first_pass_incl_allocations_ms"] = first_pass_ms
+    path_report = eng.path_report() if rank == 0 else None
+
+    # ---- job: the product entry points end to end, state matrix on the HOST -> both tsv files on disk ----
+    if extra and not args.no_job and args.engine == "mfma":
+        legs["job"] = job_leg(states, POS, paint, g, L, N, local_rank, args)
 
     if rank == 0:
         K = args.steps
@@ -310,7 +402,8 @@ def main():
                         alg_TFLOPs=alg_per_launch / (avg_ms * 1e-3) / 1e12,
                         launch_mix=dict(gemm_apx=gst["apx_launches"], gemm_bits_full=gst["bits_launches"], gemm_bits_band=gst["band_launches"]),
                         overlapped_avg_launch_ms=tim_overlapped["gemm_ms"] / max(1, len(my_blocks) * K),
-                        measured_in=f"{n_replay} serialized replay step(s) after the timed region, {serial_ms_per_step:.2f} ms/step",
+                        measured_in=f"{n_replay} serialized replay step(s) after the timed region (overlap off; the replay inherits the bucket guesses of the "
+                                    f"pass before it, so that every block launches this kernel), {serial_ms_per_step:.2f} ms/step",
                         note="achieved = int8 operations the kernel EXECUTES per launch (2 x rows x rows x positions of every wave tile "
                              "that runs, counted by the library: ldw_gemm_stats) / its average launch time (HIP events around the kernel, "
                              "overlap off) ; frac = achieved / 5 POP/s dense int8.  alg_work_reduction = SURVEY 8(d)'s algorithmic 50*N "
@@ -321,12 +414,14 @@ def main():
                              "kernel's own accumulators (the regions that pass are neither stored nor screened): without it the same K loop "
                              "takes 0.494 ms per launch = 0.51 of the peak (DESIGN.md 5.1c).  `overlapped_avg_launch_ms` is the bracket inside "
                              "the timed region, where the GEMM shares the GPU with the previous block's screens and selection")
-            tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
+            tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
             if os.path.exists(tpath) and (L, N, world) == (100_000, 5_000, 1):   # the configuration the PMC passes were collected on
                 ent = json.load(open(tpath)).get(kname)
                 if ent:
-                    roof["traffic"] = ent.get("hbm_bytes_per_launch_corrected")
-                    roof["traffic_source"] = "profiles/r02_pmc_traffic.json (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, per launch)"
+                    roof["traffic"] = ent.get("hbm_bytes_per_launch")
+                    roof["traffic_range"] = ent.get("hbm_bytes_per_launch_range")
+                    roof["traffic_source"] = ("profiles/r03_pmc_traffic.json (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, per launch; `traffic` "
+                                              "takes FETCH_SIZE x 2 as the guide prescribes for gfx950, `traffic_range` = [raw, x 2])")
         else:
             roof.update(kernel="k_mi_hist" if args.engine == "hist" else None, achieved=None, frac=None)
         roof["dominant_stage"] = stage
@@ -341,6 +436,10 @@ def main():
                                L=L, N=N, pairs=int(pairs), engine=args.engine, nlimbs=args.nlimbs or 5,
                                arithmetic="screen: one dual-digit int8 MFMA pass (rigorous error bound) -> fp32 bound; every emitted MI: exact "
                                           "int64 fixed-point joint sums -> f64",
+                               step=("cold pass: speculation state reset before every step (ldw_reset_speculation), buffers allocated" if cold else
+                                     "WARM replay (--warm): every step inherits the previous step's bucket guesses"),
+                               result_at_rank0=("in-place view of the engine's device-resident link tables (N = 1: no gather, no copy)" if world == 1 else
+                                                "tables assembled on rank 0 by the phased gather"),
                                fused=bool(args.fused), screen=args.screen, mixed_precision=bool(mixed), path=args.path,
                                approximate_gemm=eng.apx_info(),
                                parallelism=f"pair-space blocks over {world} GPU(s)"),
@@ -348,6 +447,10 @@ def main():
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         out.update(legs)
+        out["spec_misses"] = counters_timed["spec_misses"]
+        out["path"] = path_report
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         out.update(stages_ms_per_step={k: v / max(1, n_replay) for k, v in tim.items()},
                    stages_ms_per_step_overlapped={k: v / K for k, v in tim_overlapped.items()},
                    links=links_timed, counters=counters_timed, counters_replay=cnt_replay, hamming_weights_s=hamming_s,

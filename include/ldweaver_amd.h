@@ -195,6 +195,19 @@ int ldw_set_path(ldw_ctx *ctx, int mode);
 /* Long-range selection of the speculative blocks: 0 (default) = without a sort where it applies (radix select of the threshold,
  * bitmap ranks over the row-order key space: ldw_mi.hip k_sel_*), 1 = always the general path (two radix sorts).  Same tables. */
 int ldw_set_select(ldw_ctx *ctx, int mode);
+/* Forget what earlier passes of this context learnt about the workload — the per-kind histogram-bucket guesses of the long-range
+ * threshold, their spread history and the biallelic threshold table — without touching the alignment, the weights or any
+ * buffer.  The next ldw_mi_all_pairs then runs as the FIRST pass of a job does (the reference visits every block pair once,
+ * R/computePairwiseMI.R:103-116); bench.py calls it before every timed step.  Results never depend on this state. */
+int ldw_reset_speculation(ldw_ctx *ctx);
+/* Which execution path the blocks of this context took since it was created (a real data set may fail a gate silently):
+ * out[0] blocks through the approximate-GEMM path, out[1] through the mixed-precision limb path, out[2] through the plain path
+ * (5-limb GEMM + fp64 MI of every pair: blocks without a bucket guess and every block when neither fast path applies),
+ * out[3] through the fused kernel, out[4] speculation misses (blocks redone non-speculatively), out[5] blocks whose guess came from
+ * the sampled probe of the block itself (cold starts), out[6] pairs listed for exact evaluation, out[7] units listed.
+ * gate (capacity bytes, may be NULL) receives a short text: "ok" or which gate keeps the approximate path off
+ * ("delta 5.1e-03 > 4e-03", "Npad 40960 > 30720", "popcount segment tables 70000 B > 60000 B of LDS", "weights not set"). */
+int ldw_path_report(ldw_ctx *ctx, int64_t out[8], char *gate, int capacity);
 /* diagnostics of the approximate path after ldw_set_weights: out[0] = usable (0/1), out[1] = max relative error delta of the
  * dual-digit weights, out[2] = weight classes, out[3] = popcount segments, out[4] = exponent transitions, out[5] = e_last */
 int ldw_apx_info(ldw_ctx *ctx, double out[6]);
@@ -285,6 +298,23 @@ int ldw_lr_reduced_fetch(ldw_ctx *ctx, int64_t capacity, int64_t *row_out, int32
  * refused with LDW_ERR_ARG. */
 int ldw_ldmap(ldw_ctx *ctx, int32_t reducer, int32_t from, int32_t to, int64_t *n_pos_out, int32_t *reducer_out, int32_t *B_out,
               double *htm_out, int64_t capacity);
+
+/* ---- (9) the tsv files — write.table(x, file, append = T, quote = F, row.names = F, col.names = F, sep = '\t'),
+ *          R/computePairwiseMI.R:140 (sr_links.tsv) and :362 (lr_links.tsv); readers R/io_functions.R:32-66 ------------ */
+#define LDW_COL_INT32 0
+#define LDW_COL_INT64 1
+#define LDW_COL_DOUBLE 2
+/* One double as write.table prints it (R's formatReal, digits = 15: fewest significant digits that reproduce the 15-digit
+ * value; fixed notation unless wider than scientific, so 100000 -> "1e+05").  out: >= 48 bytes, NUL-terminated. */
+int ldw_format_number(double x, char *out, int capacity);
+/* nrows x ncols numeric table (host columns of kind LDW_COL_*), tab-separated, no header, appended (append != 0) or
+ * truncating; rows are formatted by nthreads host threads (0 = all cores) and written in order.  bytes_out may be NULL. */
+int ldw_write_table_tsv(const char *path, int append, int64_t nrows, int ncols, const int32_t *col_kind, const void *const *cols,
+                        int nthreads, int64_t *bytes_out);
+/* The context's short-range (which = 0) or long-range (1) link table as the reference's MI_df rows `pos1 pos2 clust1 clust2 len MI`
+ * (R/computePairwiseMI.R:319-331: pos1 = POS of the to-side SNP, integer columns; clust, len, MI doubles), fetched from the
+ * device and formatted by host threads.  An empty table writes nothing, like the reference (:360). */
+int ldw_write_links_tsv(ldw_ctx *ctx, int which, const char *path, int append, int nthreads, int64_t *rows_out, int64_t *bytes_out);
 
 /* ---- small native helpers kept for finest-grain A/B parity (host memory) -------------------- */
 /* .compareToRow src/computeMI.cpp:25-41: ret[j] = any(x[j,] in y); x is nr x nc column-major */

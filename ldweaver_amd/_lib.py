@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("LDW_AMD_LIB") or os.path.join(_HERE, "libldweaver_amd
 LDW_OK = 0
 QUIRK_REFERENCE, QUIRK_INTENDED = 0, 1
 ENGINE_MFMA, ENGINE_HIST = 0, 1
+COL_INT32, COL_INT64, COL_DOUBLE = 0, 1, 2
 
 
 class LdwError(RuntimeError):
@@ -87,6 +88,11 @@ _SIGS = {
     "ldw_lr_tukey": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, _p, _p]),
     "ldw_lr_reduced_fetch": (C.c_int, [_p, _i64, _p, _p, _p, _p]),
     "ldw_ldmap": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, _p, _p, _i64]),
+    "ldw_reset_speculation": (C.c_int, [_p]),
+    "ldw_path_report": (C.c_int, [_p, _p, C.c_char_p, C.c_int]),
+    "ldw_format_number": (C.c_int, [C.c_double, C.c_char_p, C.c_int]),
+    "ldw_write_table_tsv": (C.c_int, [C.c_char_p, C.c_int, _i64, C.c_int, _p, _p, C.c_int, C.POINTER(_i64)]),
+    "ldw_write_links_tsv": (C.c_int, [_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "ldw_compare_to_row": (C.c_int, [_p, _i64, _i64, _p, _i64, _p]),
     "ldw_vec_pos_match": (C.c_int, [_p, _i64, _p, _i64, _p]),
     "ldw_compare_triplet": (C.c_int, [_p, _p, _i64, C.c_double, C.POINTER(C.c_int)]),

@@ -340,6 +340,29 @@ int ldw_ctx_counters(ldw_ctx *c, int64_t out[4]) {
     return LDW_OK;
 }
 
+int ldw_reset_speculation(ldw_ctx *c) {
+    LDW_REQUIRE(c, LDW_ERR_ARG, "null context");
+    c->spec_B_next[0] = c->spec_B_next[1] = -1;
+    c->spec_seen[0] = c->spec_seen[1] = false;
+    c->spec_hist_n[0] = c->spec_hist_n[1] = 0;
+    c->tab11_lo = 0;
+    return LDW_OK;
+}
+
+int ldw_path_report(ldw_ctx *c, int64_t out[8], char *gate, int capacity) {
+    LDW_REQUIRE(c && out, LDW_ERR_ARG, "ldw_path_report: null argument");
+    out[0] = c->apx_blocks;
+    out[1] = c->mixed_blocks;
+    out[2] = c->unfused_blocks - c->apx_blocks - c->mixed_blocks + c->spec_misses;
+    out[3] = c->fused_blocks;
+    out[4] = c->spec_misses;
+    out[5] = c->probe_blocks;
+    out[6] = c->apx_pairs_listed;
+    out[7] = c->apx_units_listed;
+    if (gate && capacity > 0) snprintf(gate, (size_t)capacity, "%s", c->have_weights ? c->apx_gate.c_str() : "weights not set");
+    return LDW_OK;
+}
+
 int ldw_set_select(ldw_ctx *c, int mode) {
     LDW_REQUIRE(c && (mode == 0 || mode == 1), LDW_ERR_ARG, "ldw_set_select: mode must be 0 (auto) or 1 (radix sorts)");
     c->select_mode = mode;
@@ -649,6 +672,8 @@ int ldw_set_snp_meta(ldw_ctx *c, const double *r, const uint8_t *uqe, const int3
     LDW_HIP(hipStreamSynchronize(c->stream));
     c->h_r.assign(r, r + L);
     c->h_POS.assign(POS, POS + L);
+    if (paint) c->h_paint.assign(paint, paint + L);
+    else c->h_paint.assign((size_t)L, 0);
     c->paint_min = c->paint_max = 0;
     if (paint) {
         c->paint_min = c->paint_max = paint[0];

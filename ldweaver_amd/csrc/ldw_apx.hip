@@ -132,7 +132,17 @@ int prepare_apx_weights(ldw_ctx *c) {
     // The path pays when the approximation is tight enough for the screen to dismiss almost everything (its margin grows with
     // delta); the digit arrays of the GEMM must fit in LDS.  Any weights qualify: with many distinct values the popcount sums of
     // the listed pairs walk more segments per word, which is still cheap for the few pairs that are listed.
-    c->apx_ok = delta <= 4e-3 && Npad <= 30720 && M2 > 0 && segs.size() * sizeof(PopSeg) + (size_t)Npad / 8 + 64 <= 60000;   // k_pair_sums keeps the segment tables in LDS
+    const size_t seg_bytes = segs.size() * sizeof(PopSeg) + (size_t)Npad / 8 + 64;   // k_pair_sums keeps the segment tables in LDS
+    c->apx_ok = delta <= 4e-3 && Npad <= 30720 && M2 > 0 && seg_bytes <= 60000;
+    {
+        char why[160];
+        if (c->apx_ok) snprintf(why, sizeof(why), "ok");
+        else if (!(delta <= 4e-3)) snprintf(why, sizeof(why), "delta %.3g > 4e-03 (dual-digit weights too coarse)", delta);
+        else if (Npad > 30720) snprintf(why, sizeof(why), "Npad %lld > 30720 (digit arrays exceed the GEMM's LDS)", (long long)Npad);
+        else if (M2 <= 0) snprintf(why, sizeof(why), "no macro step (Npad %lld)", (long long)Npad);
+        else snprintf(why, sizeof(why), "popcount segment tables %zu B > 60000 B of LDS (%zu segments)", seg_bytes, segs.size());
+        c->apx_gate = why;
+    }
     return LDW_OK;
 }
 

@@ -86,6 +86,7 @@ struct ldw_ctx {
     int path_mode = 0;                 // ldw_set_path: 0 auto, 1 mixed/plain path, 2 force the approximate path
     int select_mode = 0;               // ldw_set_select: 0 auto (sort-free selection where it applies), 1 always the two radix sorts
     bool apx_ok = false;               // the weights allow the approximate path (precision and class structure)
+    std::string apx_gate = "weights not set";   // "ok" or the gate that keeps the path off (ldw_path_report)
     ldw::DevBuf dig_a, dig_b;          // uint8 [Npad]
     ldw::DevBuf apx_shift;             // int32 [KW / 2]: right shift of the accumulators before macro step m (128 positions)
     int apx_e_last = 0;                // accumulators end in units of 2^apx_e_last (fixed-point units of V)
@@ -107,14 +108,14 @@ struct ldw_ctx {
     ldw::DevBuf pairs[2];              // per pipeline slot: pair lists of the approximate screen (counters + PAIR_PATHS x PAIR_SHARDS lists)
     ldw::DevBuf apx_bins[2], apx_clean[2];    // per slot: threshold-table bin of every row of the two row lists; clean-region flags of the GEMM epilogue
     ldw::DevBuf apx_units[2], apx_packs[2];   // per slot: per-(tile, class) unit lists + counters; per-block SNP constants
-    int64_t apx_blocks = 0, apx_units_listed = 0, apx_pairs_listed = 0;
+    int64_t apx_blocks = 0, apx_units_listed = 0, apx_pairs_listed = 0, probe_blocks = 0;
 
     // ---- per-SNP meta ----
     bool have_meta = false;
     double g = 0;
     ldw::DevBuf r, uqe, POS, paint;  // double[L], uint8[L][5], int32[L], int32[L]
     std::vector<double> h_r;
-    std::vector<int32_t> h_POS;
+    std::vector<int32_t> h_POS, h_paint;
     int32_t paint_min = 0, paint_max = 0;
 
     // ---- row map (built lazily from alignment + weights + meta) ----

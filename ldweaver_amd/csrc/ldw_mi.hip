@@ -1414,7 +1414,15 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
 constexpr int EVB = 6;
 // which: 1 = GEMM only (on gstream, into Gbuf), 2 = epilogue only, 3 = both
 constexpr int HI_LIMBS = 3, LO_LIMBS = 2;   // mixed-precision split of the 5 weight limbs
-constexpr size_t PAIR_CAP = 1u << 18;       // entries per pair list of the approximate path (PAIR_PATHS x PAIR_SHARDS lists)
+constexpr size_t PAIR_CAP = 1u << 18;       // most entries per pair list of the approximate path (PAIR_PATHS x PAIR_SHARDS lists)
+// capacity of the pair lists of one block: an eighth of the block's pairs (a shard's fair share of ALL of them), between 2^12 and
+// PAIR_CAP.  Small blocks (tests, several engines on one GPU) then take megabytes instead of the fixed 1.4 GB; a list that
+// overflows makes the block fall back like a wrong guess (k_pick_bucket: spec_ok = 0), so results never depend on it.
+inline uint32_t pair_cap_for(int64_t nf, int64_t nt) {
+    uint64_t want = (uint64_t)nf * (uint64_t)nt / PAIR_SHARDS + 1, cap = 1u << 12;
+    while (cap < want && cap < PAIR_CAP) cap <<= 1;
+    return (uint32_t)cap;
+}
 int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E,
                     hipEvent_t *ev, int which, ldw::DevBuf *Gb, hipStream_t gstream, unsigned long long *ghist,
                     const LoHost *mixed = nullptr) {
@@ -1616,7 +1624,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         if (int rc = c->apx_units[s].reserve(o_flat + 2 * n_units_max * 8 + 64)) return rc;
         if (int rc = c->apx_packs[s].reserve(o_rt + (size_t)nt * 4 + 256)) return rc;
         if (use_pairs)
-            if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * PAIR_CAP * sizeof(PairEnt))) return rc;
+            if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * pair_cap_for(nf, nt) * sizeof(PairEnt))) return rc;
         if (need_exact)
             if (int rc = Gx.reserve((size_t)RFpad * RTpad * 8)) return rc;
         if (int rc = c->apx_bins[s].reserve((size_t)RTpad + (size_t)RFpad + 64)) return rc;
@@ -1668,7 +1676,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     if (use_pairs) {
         A.pl_n = c->pairs[s].as<unsigned int>();
         A.pl_pairs = reinterpret_cast<PairEnt *>(c->pairs[s].as<char>() + o_pairs);
-        A.pl_cap = (uint32_t)PAIR_CAP;
+        A.pl_cap = pair_cap_for(nf, nt);
     }
     if (phase == 1) {
         if (E.do_lr) {
@@ -1767,7 +1775,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
                                       E.lower_only, c->stream, 0, -1, band))
             return rc;
     if (use_pairs) {
-        if (int rc = c->pair_sums.reserve((size_t)PAIR_PATHS * PAIR_SHARDS * PAIR_CAP * 16 * 8)) return rc;
+        if (int rc = c->pair_sums.reserve((size_t)PAIR_PATHS * PAIR_SHARDS * A.pl_cap * 16 * 8)) return rc;
         if (int rc = launch_pairs_exact(c, A, ghist, c->pair_sums.as<int64_t>(), c->stream)) return rc;
     }
     if (need_exact) {   // the listed units, from the exact tiles
@@ -2184,7 +2192,7 @@ int launch_pick(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p, const S
         const bool pl = hb.apx && c->screen == 1;
         hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, st, c->hist[s].as<unsigned long long>(), p->lr_retain_links,
                            p->lr_links_approx, hb.spec_B, (long long)hb.n_lr_total, sl.pick[s],
-                           pl ? reinterpret_cast<const unsigned int *>(c->pairs[s].p) : nullptr, (unsigned int)PAIR_CAP);
+                           pl ? reinterpret_cast<const unsigned int *>(c->pairs[s].p) : nullptr, pair_cap_for(hb.nf, hb.nt));
         LDW_HIP(hipGetLastError());
     }
     return LDW_OK;

@@ -163,6 +163,10 @@ int ldw_lr_tukey(ldw_ctx *c, int64_t min_links, const int32_t *sr_a, const int32
     // the short-range part of the ARACNE pool is what sr_links.tsv holds — the REDUCED set perform_MI_computation returned
     // (srp_max > srp_cutoff, R/computePairwiseMI.R:122,140), not the engine's raw short-range table: the caller hands it in
     const int64_t n = c->n_lr, ns = n_sr_rows;
+    for (int64_t i = 0; i < ns; ++i)   // host arrays: an index outside the alignment (an NA from R's match() is INT_MIN) must not reach the device
+        LDW_REQUIRE(sr_a[i] >= 0 && sr_a[i] < c->L && sr_b[i] >= 0 && sr_b[i] < c->L, LDW_ERR_ARG,
+                    "ldw_lr_tukey: short-range row %lld has SNP indices (%d, %d) outside 0..%lld (a position that is not in POS?)", (long long)i, sr_a[i], sr_b[i],
+                    (long long)c->L - 1);
     if (ns > 0) {
         if (int rc = c->ar_val.reserve((size_t)ns * 4)) return rc;
         if (int rc = c->ar_val2.reserve((size_t)ns * 4)) return rc;

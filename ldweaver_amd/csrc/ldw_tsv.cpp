@@ -1,0 +1,277 @@
+// a-13: the two link files of the path as `write.table(x, file, append = T, quote = F, row.names = F, col.names = F,
+// sep = '\t')` prints them (R/computePairwiseMI.R:140, :362; readers R/io_functions.R:32-66).  Host threads format
+// disjoint row ranges into private buffers, one writer appends them in order.
+//
+// Number rule (R's formatReal with digits = 15, scipen = 0, one element at a time as write.table encodes a data.frame):
+// an integer column prints its digits; a double prints the fewest significant digits (<= 15) that reproduce its 15-digit
+// value, in fixed notation unless that is wider than the scientific form (so 100000 prints as 1e+05 and 0.0001 as 1e-04).
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ldw_internal.h"
+
+namespace {
+
+// The 15 significant decimal digits of ax in [1e-5, 1e3), correctly rounded (ties to even on the exact binary value, like
+// printf("%.14e")), by exact 128-bit integer arithmetic: ax = m 2^e, digits = round(m 10^(14 - e10) 2^e).  MI values live here;
+// snprintf costs ~250 ns per value, this ~40.  Returns false when the shift does not fit (never in the stated range).
+inline bool fast15(double ax, char *sig, int *e10_out) {
+    static const unsigned long long P10[20] = {1ULL, 10ULL, 100ULL, 1000ULL, 10000ULL, 100000ULL, 1000000ULL, 10000000ULL, 100000000ULL,
+                                               1000000000ULL, 10000000000ULL, 100000000000ULL, 1000000000000ULL, 10000000000000ULL,
+                                               100000000000000ULL, 1000000000000000ULL, 10000000000000000ULL, 100000000000000000ULL,
+                                               1000000000000000000ULL, 10000000000000000000ULL};
+    int ex;
+    const double fr = std::frexp(ax, &ex);                       // ax = fr 2^ex, fr in [0.5, 1)
+    const unsigned long long m = (unsigned long long)std::ldexp(fr, 53);   // 53-bit integer mantissa
+    const int e = ex - 53;                                        // ax = m 2^e, e < 0 here (ax < 1e3 < 2^53)
+    int e10 = (int)std::floor(std::log10(ax));
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        const int k = 14 - e10;
+        if (k < 0 || k > 19 || -e <= 0 || -e >= 126) return false;
+        const unsigned __int128 prod = (unsigned __int128)m * P10[k];
+        const int sh = -e;
+        unsigned __int128 q = prod >> sh;
+        const unsigned __int128 rem = prod - (q << sh), half = (unsigned __int128)1 << (sh - 1);
+        if (rem > half || (rem == half && (q & 1))) ++q;
+        if (q >= (unsigned __int128)P10[15]) { ++e10; continue; }   // log10 was one low (or the rounding carried into a 16th digit)
+        if (q < (unsigned __int128)P10[14]) { --e10; continue; }
+        unsigned long long d = (unsigned long long)q;
+        for (int i = 14; i >= 0; --i) { sig[i] = (char)('0' + d % 10); d /= 10; }
+        *e10_out = e10;
+        return true;
+    }
+    return false;
+}
+
+// appends one double; buf has >= 40 bytes of room
+inline char *fmt_double(char *p, double x) {
+    if (x != x) { memcpy(p, "NA", 2); return p + 2; }
+    if (std::isinf(x)) {
+        if (x > 0) { memcpy(p, "Inf", 3); return p + 3; }
+        memcpy(p, "-Inf", 4);
+        return p + 4;
+    }
+    if (x == 0.0) { *p++ = '0'; return p; }
+    const bool neg = x < 0;
+    const double ax = neg ? -x : x;
+    char sig[24];
+    int nsig, e10;
+    if (ax < 9.0e14 && ax == std::floor(ax)) {
+        // integral value (every pos / len / cluster id): its decimal digits are exact, no rounding step
+        unsigned long long v = (unsigned long long)ax;
+        char tmp[24];
+        int n = 0;
+        while (v) { tmp[n++] = (char)('0' + v % 10); v /= 10; }
+        for (int k = 0; k < n; ++k) sig[k] = tmp[n - 1 - k];
+        e10 = n - 1;
+        nsig = n;
+        while (nsig > 1 && sig[nsig - 1] == '0') --nsig;
+    } else if (ax < 1.0e13 && 2.0 * ax == std::floor(2.0 * ax)) {
+        // k + 1/2 (every len when the genome length is odd): integer digits, then a 5
+        unsigned long long v = (unsigned long long)ax;
+        char tmp[24];
+        int n = 0;
+        while (v) { tmp[n++] = (char)('0' + v % 10); v /= 10; }
+        for (int k = 0; k < n; ++k) sig[k] = tmp[n - 1 - k];
+        sig[n] = '5';
+        nsig = n + 1;
+        e10 = n - 1;   // (n == 0: 0.5 = 5e-01)
+    } else if (ax >= 1e-5 && ax < 1e3 && fast15(ax, sig, &e10)) {
+        nsig = 15;
+        while (nsig > 1 && sig[nsig - 1] == '0') --nsig;
+    } else {
+        char m[40];
+        snprintf(m, sizeof(m), "%.14e", ax);   // d.dddddddddddddde[+-]xx
+        sig[0] = m[0];
+        memcpy(sig + 1, m + 2, 14);
+        nsig = 15;
+        while (nsig > 1 && sig[nsig - 1] == '0') --nsig;
+        e10 = atoi(m + 17);
+    }
+    const int wexp = (e10 < 100 && e10 > -100) ? 2 : 3;
+    const int w_sci = (neg ? 1 : 0) + (nsig > 1 ? nsig + 1 : 1) + 2 + wexp;
+    const int rgt = nsig - e10 - 1 > 0 ? nsig - e10 - 1 : 0;
+    const int left = e10 >= 0 ? e10 + 1 : 1;
+    const int w_fix = (neg ? 1 : 0) + left + (rgt ? rgt + 1 : 0);
+    if (neg) *p++ = '-';
+    if (w_fix <= w_sci) {
+        // fixed: the nsig digits placed around the point (the value rounded to rgt decimals has exactly these digits)
+        if (e10 >= 15) {
+            // more integer digits than the 15 significant ones: sprintf("%.0f") prints the double's own digits there
+            p += snprintf(p, 36, "%.0f", ax);
+        } else if (e10 >= 0) {
+            for (int k = 0; k <= e10; ++k) *p++ = k < nsig ? sig[k] : '0';
+            if (rgt) {
+                *p++ = '.';
+                for (int k = e10 + 1; k < nsig; ++k) *p++ = sig[k];
+            }
+        } else {
+            *p++ = '0';
+            *p++ = '.';
+            for (int k = 0; k < -e10 - 1; ++k) *p++ = '0';
+            for (int k = 0; k < nsig; ++k) *p++ = sig[k];
+        }
+        return p;
+    }
+    *p++ = sig[0];
+    if (nsig > 1) {
+        *p++ = '.';
+        memcpy(p, sig + 1, (size_t)nsig - 1);
+        p += nsig - 1;
+    }
+    *p++ = 'e';
+    *p++ = e10 >= 0 ? '+' : '-';
+    int ae = e10 >= 0 ? e10 : -e10;
+    if (wexp == 3) { *p++ = (char)('0' + ae / 100); ae %= 100; }
+    *p++ = (char)('0' + ae / 10);
+    *p++ = (char)('0' + ae % 10);
+    return p;
+}
+
+inline char *fmt_int(char *p, long long v) {
+    if (v < 0) { *p++ = '-'; v = -v; }   // (INT64_MIN is not a value any column of the path can hold)
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+struct Col {
+    int kind;          // LDW_COL_INT32 / INT64 / DOUBLE
+    const void *data;
+};
+
+int write_rows(const char *path, int append, int64_t nrows, const std::vector<Col> &cols, int nthreads, int64_t *bytes_out) {
+    FILE *fh = fopen(path, append ? "ab" : "wb");
+    LDW_REQUIRE(fh != nullptr, LDW_ERR_ARG, "cannot open %s: %s", path, strerror(errno));
+    int64_t total = 0;
+    int rc = LDW_OK;
+    if (nrows > 0) {
+        unsigned hw = std::thread::hardware_concurrency();
+        int nt = nthreads > 0 ? nthreads : (int)(hw ? hw : 4);
+        nt = (int)std::min<int64_t>(std::min(nt, 64), (nrows + 16383) / 16384);
+        if (nt < 1) nt = 1;
+        // rounds of nt chunks: bounded memory, output in row order
+        const int64_t chunk = 1 << 16;
+        const size_t row_max = cols.size() * 41 + 2;
+        std::vector<std::vector<char>> bufs((size_t)nt);
+        std::vector<size_t> used((size_t)nt, 0);
+        for (auto &b : bufs) b.resize((size_t)chunk * row_max);
+        for (int64_t r0 = 0; r0 < nrows && rc == LDW_OK; r0 += chunk * nt) {
+            auto work = [&](int t) {
+                const int64_t a = r0 + (int64_t)t * chunk, b = std::min(nrows, a + chunk);
+                char *p = bufs[(size_t)t].data();
+                for (int64_t i = a; i < b; ++i) {
+                    for (size_t k = 0; k < cols.size(); ++k) {
+                        if (k) *p++ = '\t';
+                        const Col &c = cols[k];
+                        if (c.kind == LDW_COL_DOUBLE) p = fmt_double(p, static_cast<const double *>(c.data)[i]);
+                        else if (c.kind == LDW_COL_INT32) p = fmt_int(p, static_cast<const int32_t *>(c.data)[i]);
+                        else p = fmt_int(p, static_cast<const int64_t *>(c.data)[i]);
+                    }
+                    *p++ = '\n';
+                }
+                used[(size_t)t] = a < b ? (size_t)(p - bufs[(size_t)t].data()) : 0;
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+            for (int t = 0; t < nt; ++t) {
+                if (!used[(size_t)t]) continue;
+                if (fwrite(bufs[(size_t)t].data(), 1, used[(size_t)t], fh) != used[(size_t)t]) {
+                    ldw::set_error("short write to %s: %s", path, strerror(errno));
+                    rc = LDW_ERR_ARG;
+                    break;
+                }
+                total += (int64_t)used[(size_t)t];
+            }
+        }
+    }
+    if (fclose(fh) != 0 && rc == LDW_OK) {
+        ldw::set_error("closing %s: %s", path, strerror(errno));
+        rc = LDW_ERR_ARG;
+    }
+    if (bytes_out) *bytes_out = total;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ldw_format_number(double x, char *out, int capacity) {
+    LDW_REQUIRE(out && capacity >= 48, LDW_ERR_SIZE, "ldw_format_number: capacity must be at least 48 bytes");
+    char *e = fmt_double(out, x);
+    *e = 0;
+    return LDW_OK;
+}
+
+int ldw_write_table_tsv(const char *path, int append, int64_t nrows, int ncols, const int32_t *col_kind, const void *const *cols,
+                        int nthreads, int64_t *bytes_out) {
+    LDW_REQUIRE(path && nrows >= 0 && ncols > 0 && ncols <= 64 && col_kind && cols, LDW_ERR_ARG, "ldw_write_table_tsv: bad argument");
+    std::vector<Col> cc((size_t)ncols);
+    for (int k = 0; k < ncols; ++k) {
+        LDW_REQUIRE(col_kind[k] >= LDW_COL_INT32 && col_kind[k] <= LDW_COL_DOUBLE, LDW_ERR_ARG, "ldw_write_table_tsv: column %d has kind %d", k,
+                    col_kind[k]);
+        LDW_REQUIRE(cols[k] || nrows == 0, LDW_ERR_ARG, "ldw_write_table_tsv: column %d is null", k);
+        cc[(size_t)k] = Col{col_kind[k], cols[k]};
+    }
+    return write_rows(path, append, nrows, cc, nthreads, bytes_out);
+}
+
+int ldw_write_links_tsv(ldw_ctx *c, int which, const char *path, int append, int nthreads, int64_t *rows_out, int64_t *bytes_out) {
+    if (int rc = ldw::check_gpu(c)) return rc;
+    LDW_REQUIRE(path && (which == 0 || which == 1), LDW_ERR_ARG, "ldw_write_links_tsv: bad argument");
+    LDW_REQUIRE(c->have_meta && (int64_t)c->h_POS.size() == c->L && (int64_t)c->h_paint.size() == c->L, LDW_ERR_STATE,
+                "ldw_write_links_tsv: SNP meta data (POS, paint, g) not set");
+    int64_t n = 0;
+    if (int rc = ldw_links_count(c, which, &n)) return rc;
+    if (rows_out) *rows_out = n;
+    if (bytes_out) *bytes_out = 0;
+    if (n == 0) return LDW_OK;   // the reference writes nothing for an empty frame (R/computePairwiseMI.R:360)
+    std::vector<int32_t> a((size_t)n), b((size_t)n), pos1((size_t)n), pos2((size_t)n);
+    std::vector<double> mi((size_t)n), c1((size_t)n), c2((size_t)n), len((size_t)n);
+    if (int rc = ldw_links_fetch(c, which, a.data(), b.data(), mi.data(), n, 0)) return rc;
+    const double g = c->g, hg = 0.5 * c->g;
+    const int32_t *POS = c->h_POS.data(), *paint = c->h_paint.data();
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = nthreads > 0 ? nthreads : (int)(hw ? hw : 4);
+    nt = (int)std::min<int64_t>(std::min(nt, 64), (n + 65535) / 65536);
+    auto derive = [&](int t) {
+        const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
+        for (int64_t i = i0; i < i1; ++i) {
+            // pos1 = POS_t[col], pos2 = POS_f[row]; len = 0.5 g - |((pos1 - pos2) %% g) - 0.5 g| with R's floored %% (R/computePairwiseMI.R:319-330)
+            const int32_t p1 = POS[b[(size_t)i]], p2 = POS[a[(size_t)i]];
+            pos1[(size_t)i] = p1;
+            pos2[(size_t)i] = p2;
+            c1[(size_t)i] = (double)paint[b[(size_t)i]];
+            c2[(size_t)i] = (double)paint[a[(size_t)i]];
+            const double d = (double)p1 - (double)p2;
+            double m = std::fmod(d, g);
+            if (m != 0.0 && ((m < 0) != (g < 0))) m += g;
+            len[(size_t)i] = hg - std::fabs(m - hg);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(derive, t);
+        derive(0);
+        for (auto &x : th) x.join();
+    }
+    // POS is an integer vector in the reference (src/getACGTNsites.cpp:97,173; R/extractSNPs.R:200), paint a double one
+    // (R/estimateCDSDiversity.R:152), len and MI doubles
+    std::vector<Col> cols = {{LDW_COL_INT32, pos1.data()}, {LDW_COL_INT32, pos2.data()}, {LDW_COL_DOUBLE, c1.data()},
+                             {LDW_COL_DOUBLE, c2.data()}, {LDW_COL_DOUBLE, len.data()}, {LDW_COL_DOUBLE, mi.data()}};
+    return write_rows(path, append, n, cols, nthreads, bytes_out);
+}
+
+}  // extern "C"

@@ -134,6 +134,12 @@ def gather_begin(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int,
     nbytes = [int(16 * (ph.rows["sr"][rk] + ph.rows["lr"][rk])) for rk in range(world)]
     ph.mine = pack(local)
     assert ph.mine.numel() == nbytes[rank], (ph.mine.numel(), nbytes[rank])
+    if ph.mine.is_cuda:
+        # `local` may alias the engine's own tables (Engine.links_view): the pack above is an asynchronous read on torch's current
+        # stream, and the caller is about to overwrite those tables from the library's streams (the next phase's blocks).  The
+        # packed copy must be complete before this function returns; the compute of the phase has already been waited for
+        # (ldw_links_end), so this costs the duration of the copy itself
+        torch.cuda.current_stream(ph.mine.device).synchronize()
     ph.bufs, ph.works = None, []
     if world > 1:
         if rank == dst:

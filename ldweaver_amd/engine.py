@@ -64,6 +64,24 @@ class Engine:
         return dict(spec_misses=int(v[0]), fused_blocks=int(v[1]), unfused_blocks=int(v[2]), screen_violations=int(v[3]),
                     mixed_blocks=int(v[4]), apx_blocks=int(v[5]), apx_units_listed=int(v[6]), apx_pairs_listed=int(v[7]))
 
+    def reset_speculation(self):
+        """Forget the bucket guesses / threshold table earlier passes left behind: the next pass runs as a job's first pass."""
+        L.check(L.lib().ldw_reset_speculation(self._ctx))
+
+    def path_report(self):
+        """Which execution path the blocks took so far and, if the approximate path is off, the gate that failed."""
+        v = np.zeros(8, dtype=np.int64)
+        buf = C.create_string_buffer(200)
+        L.check(L.lib().ldw_path_report(self._ctx, L.ptr(v), buf, 200))
+        return dict(apx_blocks=int(v[0]), mixed_blocks=int(v[1]), plain_blocks=int(v[2]), fused_blocks=int(v[3]), spec_misses=int(v[4]),
+                    probe_blocks=int(v[5]), pairs_listed=int(v[6]), units_listed=int(v[7]), apx_gate=buf.value.decode())
+
+    def write_links_tsv(self, which: int, path: str, append: bool = True, nthreads: int = 0):
+        """The context's sr (0) / lr (1) table as `pos1 pos2 clust1 clust2 len MI` rows (write.table format); (rows, bytes)."""
+        n, nb = C.c_int64(0), C.c_int64(0)
+        L.check(L.lib().ldw_write_links_tsv(self._ctx, int(which), str(path).encode(), int(bool(append)), int(nthreads), C.byref(n), C.byref(nb)))
+        return int(n.value), int(nb.value)
+
     def set_overlap(self, on: bool):
         """GEMM of the next block beside the epilogue/selection of the current one (default on); off = exclusive stage times."""
         L.check(L.lib().ldw_set_overlap(self._ctx, int(bool(on))))
@@ -228,7 +246,9 @@ class Engine:
 
     def links_view(self, which: int):
         """(a, b, MI) as torch tensors that ALIAS the context's own table in HBM (no copy): valid until the next call that
-        changes the table; do not write to them."""
+        changes the table; do not write to them.  STREAM ORDER: the library writes its tables from its own streams, so any
+        asynchronous torch read of these views (a cat, a send) must have COMPLETED — synchronise the torch stream that reads —
+        before the next ldw_mi_all_pairs / ldw_links_begin / ldw_links_import on this engine (dist.gather_begin does)."""
         import torch
         pa, pb, pm, n = C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_int64(0)
         L.check(L.lib().ldw_links_device_ptrs(self._ctx, int(which), C.byref(pa), C.byref(pb), C.byref(pm), C.byref(n)))
@@ -403,3 +423,33 @@ def aracne(chk_pos1, chk_pos2, chk_MI, full_pos1, full_pos2, full_MI) -> np.ndar
     L.check(L.lib().ldw_aracne(None, L.ptr(c[0]), L.ptr(c[1]), L.ptr(c[2]), len(c[0]), L.ptr(f[0]), L.ptr(f[1]), L.ptr(f[2]),
                                len(f[0]), L.ptr(out)))
     return out.astype(bool)
+
+
+def format_number(x: float) -> str:
+    """One double as write.table prints it (native twin of rcompat.format_number)."""
+    buf = C.create_string_buffer(64)
+    L.check(L.lib().ldw_format_number(float(x), buf, 64))
+    return buf.value.decode()
+
+
+def write_table_tsv(path: str, columns, append: bool = True, nthreads: int = 0) -> int:
+    """write.table(append = T, quote = F, row.names = F, col.names = F, sep = '\\t') of numeric columns by the native
+    writer (R/computePairwiseMI.R:140,362): integer arrays print as integers, floating ones by R's 15-digit rule."""
+    cols, kinds = [], []
+    for c in columns:
+        c = np.asarray(c)
+        if c.dtype.kind in "iub":
+            c = np.ascontiguousarray(c, dtype=np.int64)
+            kinds.append(L.COL_INT64)
+        else:
+            c = np.ascontiguousarray(c, dtype=np.float64)
+            kinds.append(L.COL_DOUBLE)
+        cols.append(c)
+    n = len(cols[0]) if cols else 0
+    assert all(len(c) == n for c in cols)
+    kind = np.asarray(kinds, dtype=np.int32)
+    ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+    nb = C.c_int64(0)
+    L.check(L.lib().ldw_write_table_tsv(str(path).encode(), int(bool(append)), n, len(cols), L.ptr(kind), C.cast(ptrs, C.c_void_p), int(nthreads),
+                                        C.byref(nb)))
+    return int(nb.value)

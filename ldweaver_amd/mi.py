@@ -18,7 +18,7 @@ import pandas as pd
 
 from . import _lib as L
 from . import rcompat
-from .engine import Engine, aracne
+from .engine import Engine, aracne, write_table_tsv
 from .snpdat import CdsVar, SnpDat
 from .srp import COLS, merge_n_sort_sr_links, merge_n_sort_sr_links_device
 
@@ -64,7 +64,8 @@ def lr_links_approx(POS, g, sr_dist, seed: int = 1988) -> float:
 # a-4 estimate_Hamming_distance_weights            R/performPopulationStuctureCorrection.R:20-81
 # ---------------------------------------------------------------------------------------------
 def estimate_Hamming_distance_weights(snp_dat: SnpDat, threshold: float = 0.1, mega_dset: bool = False,
-                                      engine: Engine | None = None, alignment_resident: bool = False, group=None) -> np.ndarray:
+                                      engine: Engine | None = None, alignment_resident: bool = False, group=None,
+                                      verbose: bool = True) -> np.ndarray:
     t0 = time.time()
     thresh = int(snp_dat.nsnp * threshold)  # as.integer() truncates
     own = engine is None
@@ -90,7 +91,8 @@ def estimate_Hamming_distance_weights(snp_dat: SnpDat, threshold: float = 0.1, m
     finally:
         if own:
             eng.close()
-    print(f"Done in {round(time.time() - t0, 2)} s")
+    if verbose:
+        print(f"Done in {round(time.time() - t0, 2)} s")
     return hdw
 
 
@@ -111,19 +113,17 @@ def ACGTN2num(nv: np.ndarray, cv, ncores: int = 1, engine: Engine | None = None)
 # ---------------------------------------------------------------------------------------------
 # tsv output                                                R/computePairwiseMI.R:140,362
 # ---------------------------------------------------------------------------------------------
-def _fmt_col(v) -> list:
-    v = np.asarray(v)
-    if v.dtype.kind in "iub":
-        return [str(int(x)) for x in v]
-    return [rcompat.format_number(float(x)) for x in v]
+def append_table(path: str, columns: list, nthreads: int = 0) -> int:
+    """write.table(append = T, quote = F, row.names = F, col.names = F, sep = '\\t') by the native writer
+    (ldw_write_table_tsv: host threads, R's 15-significant-digit rule); integer arrays print as integers.  Returns the
+    bytes written.  ``rcompat.format_number`` is the Python statement of the same rule (tests compare the two)."""
+    return write_table_tsv(path, columns, append=True, nthreads=nthreads)
 
 
-def append_table(path: str, columns: list) -> None:
-    """write.table(append = T, quote = F, row.names = F, col.names = F, sep = '\\t')."""
-    cols = [_fmt_col(c) for c in columns]
-    with open(path, "a") as fh:
-        for row in zip(*cols):
-            fh.write("\t".join(row) + "\n")
+def _pos_int(v):
+    """snp.dat$POS is an INTEGER vector in the reference (src/getACGTNsites.cpp:97,173; R/extractSNPs.R:200), so the pos1 / pos2
+    columns print as integers (100000, not 1e+05 as a double would)."""
+    return np.asarray(v).astype(np.int64)
 
 
 def links_frame(a, b, mi, POS, paint, g) -> pd.DataFrame:
@@ -219,6 +219,7 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
 
     own = engine is None
     eng = engine or Engine(0)
+    stages = {"lr_links_approx_s": time.time() - t000}
     try:
         def setup():
             if not alignment_resident:   # pass alignment_resident=True when `engine` already holds snp_dat.states
@@ -259,9 +260,21 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
             eng.links_import(0, *out["sr"])
             eng.links_import(1, *out["lr"])
         else:
+            t_s = time.time()
             setup()
+            stages["setup_s"] = time.time() - t_s
+            t_s = time.time()
             stats = _run_blocks(eng, blocks, np.arange(len(blocks)), kw, POS, g)
-        la, lb, lmi = eng.links(1)
+            stages["mi_all_pairs_s"] = time.time() - t_s
+        # lr_links.tsv (R/computePairwiseMI.R:362) straight from the device-resident table: fetched, derived (pos, clust, len) and
+        # formatted by the library's host threads
+        t_w = time.time()
+        n_lr_rows = 0
+        if not perform_SR_analysis_only:
+            n_lr_rows, _ = eng.write_links_tsv(1, lr_save_path, append=True)
+        tsv_s = time.time() - t_w
+        stages["lr_tsv_s"] = tsv_s
+        t_s = time.time()
         if sr_model == "device":
             # mergeNsort_sr_links + runARACNE on the device-resident table; only the kept links come back
             redd, flags, model_aux = merge_n_sort_sr_links_device(eng, cds_var.nclust, sr_dist, srp_cutoff, POS, paint, g,
@@ -273,16 +286,17 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
             sa, sb, smi = eng.links(0)
         else:
             raise ValueError("sr_model must be 'device' or 'host'")
+        stages["sr_model_aracne_s"] = time.time() - t_s
+        path_report = eng.path_report()
     finally:
         if own:
             eng.close()
+    if path_report["apx_gate"] != "ok" and not perform_SR_analysis_only:
+        say(f"note: the approximate-GEMM path is off for these weights ({path_report['apx_gate']}); limb paths used")
     for bi in range(len(stats["n_sr"])):
         say(f"Block {bi + 1} of {len(blocks)} ... Adding {stats['n_lr_kept'][bi]} LR links with MI>"
             f"{round(float(stats['disc_thresh'][bi]), 3)} to file ... Adding {stats['n_sr'][bi]} SR links to list ...")
 
-    if not perform_SR_analysis_only and len(lmi):
-        lr = links_frame(la, lb, lmi, POS, paint, g)
-        append_table(lr_save_path, [lr[c].to_numpy() for c in COLS])
 
     sr = links_frame(sa, sb, smi, POS, paint, g)
     if sr_model == "device":
@@ -310,8 +324,13 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
         red["ARACNE"] = 1.0
     if order_links:
         red = red.iloc[np.argsort(-red["srp_max"].to_numpy(), kind="stable")].reset_index(drop=True)
-    append_table(sr_save_path, [red[c].to_numpy() for c in ["clust_c"] + COLS + ["srp_max", "ARACNE"]])
+    t_w = time.time()
+    append_table(sr_save_path, [_pos_int(red[c]) if c in ("pos1", "pos2") else red[c].to_numpy() for c in ["clust_c"] + COLS + ["srp_max", "ARACNE"]])
+    tsv_s += time.time() - t_w
+    stages["sr_tsv_s"] = time.time() - t_w
+    stages["total_s"] = time.time() - t000
     say(f"All done in {round((time.time() - t000) / 60, 2)} mins ")
     if return_aux:   # not part of the reference's return value: the ARACNE pool and per-block statistics
-        return red, dict(sr_links_ARACNE_check=chk, block_stats=stats, lr_links_approx=approx, fit_data=fit_data)
+        return red, dict(sr_links_ARACNE_check=chk, block_stats=stats, lr_links_approx=approx, fit_data=fit_data, tsv_write_s=tsv_s,
+                         lr_rows_written=n_lr_rows, path=path_report, stages_s=stages)
     return red

@@ -110,8 +110,9 @@ mergeNsort_sr_links_device <- function(snp.dat, cds_var, sr_dist, srp_cutoff, ru
 # perform_MI_computation(): lr_links_red with its ARACNE column, in the reference's order.
 # sr_links: the reduced short-range links, i.e. what sr_links.tsv holds / perform_MI_computation() returned (R/lr_analyser.R:67)
 analyse_long_range_links_device <- function(snp.dat, cds_var, sr_links, are_lrlinks_ordered = F) {
-  r <- .Call("ldwamd_lr_tukey_aracne", 5000, as.integer(match(sr_links$pos2, snp.dat$POS) - 1L), as.integer(match(sr_links$pos1, snp.dat$POS) - 1L),
-             as.numeric(sr_links$MI))
+  ia <- match(sr_links$pos2, snp.dat$POS); ib <- match(sr_links$pos1, snp.dat$POS)
+  if (anyNA(ia) || anyNA(ib)) stop("sr_links holds positions that are not in snp.dat$POS")   # NA_integer_ must not reach the device as an index
+  r <- .Call("ldwamd_lr_tukey_aracne", 5000, as.integer(ia - 1L), as.integer(ib - 1L), as.numeric(sr_links$MI))
   if (r[[8]]) warning("Not enough lr links pass the Tukey criteria, ~5000 top links were retained instead")
   pos2 <- as.numeric(snp.dat$POS[r[[2]] + 1]); pos1 <- as.numeric(snp.dat$POS[r[[3]] + 1])
   df <- data.frame(pos1 = pos1, pos2 = pos2, clust1 = cds_var$paint[r[[3]] + 1], clust2 = cds_var$paint[r[[2]] + 1],

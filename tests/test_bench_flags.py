@@ -17,3 +17,40 @@ def test_bench_flag_matrix_small():
     assert not bad, [(r["flags"], r.get("stderr_tail", "")[-600:]) for r in bad]
     assert len(counts) == 1 and all(c is not None and c > 0 for c in next(iter(counts))), counts
     assert len(out) == len(flag_matrix.COMBOS)
+
+
+def _bench_line(cmd, timeout):
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_multi_rank_rehearsal():
+    """The command the driver's scaling run uses (torch.distributed.run, one rank per process, phased gather to rank 0), rehearsed on
+    the ONE GPU of the test box with backend gloo: 6 ranks — the box's process guard allows at most 6 processes on its card, so the
+    8-rank deal + gather is covered on the CPU instead (tests/test_dist_gloo.py::test_gather_gloo[8]).  Exit code 0, link counts
+    identical to the 1-rank line, and the per-rank record the N > 1 line carries (compute / exposed gather / bytes sent)."""
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = ["--steps", "1", "--warmup", "1", "--no-extra-legs", "--no-cpu-baseline", "--L", "40000", "--N", "2000", "--max-blk-sz", "5000"]
+    one = _bench_line([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + base, 600)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = 6
+    many = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo"] + base, 900)
+    assert many["n_gpus"] == world and one["n_gpus"] == 1
+    assert many["links"] == one["links"] and one["links"]["n_lr"] > 0 and one["links"]["n_sr"] > 0
+    assert many["config"]["pairs"] == one["config"]["pairs"]
+    pr = many["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(world)) and sum(r["blocks"] for r in pr) == 36
+    assert all(r["compute_ms"] > 0 and r["exposed_gather_ms"] >= 0 for r in pr)
+    assert pr[0]["bytes_sent"] == 0 and all(r["bytes_sent"] > 0 for r in pr[1:])
+    # every rank but 0 sends exactly its rows: 16 bytes per link row
+    assert sum(r["bytes_sent"] for r in pr) <= 16 * (one["links"]["n_sr"] + one["links"]["n_lr"])

@@ -1,8 +1,10 @@
-"""CPU: the N > 1 path (block deal + variable-length gather of link tables) with world_size 2 over gloo."""
+"""CPU: the N > 1 path (block deal + variable-length gather of link tables) with world_size 2 and 8 over gloo (8 = the rank count
+of the driver's scaling run: 21 block pairs over 8 ranks leaves ranks with 2-3 blocks, ragged phases and empty ones)."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -33,7 +35,7 @@ def _worker(rank, world, port, q):
         out = gather_link_tables(local, mine, counts, len(blocks))
         # the same tables through a gather in 3 phases (rows of finished blocks travel while the rank computes on): the
         # chunks are ragged and one of rank 1's phases is empty
-        cuts = [0, 2, len(mine) if rank == 0 else 2, len(mine)]
+        cuts = [0, min(2, len(mine)), len(mine) if rank == 0 else min(2, len(mine)), len(mine)]
         phases = []
         for p0, p1 in zip(cuts[:-1], cuts[1:]):
             sub, lo, cn = mine[p0:p1], {}, {}
@@ -71,19 +73,35 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_gather_world2_gloo():
+@pytest.mark.parametrize("world", [2, 8])
+def test_gather_gloo(world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(rk, 2, port, q)) for rk in range(2)]
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, q)) for rk in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(240)
         assert p.exitcode == 0
     assert q.get() is True
+
+
+def test_deal_covers_every_block_once_for_1_to_8_ranks():
+    """The deal the driver's 1/2/4/8-GPU runs use on the bench's 55 block pairs: a partition, in make_blocks order per rank, and
+    balanced (LPT: no rank above the mean load by more than one block's cost)."""
+    from ldweaver_amd.dist import block_cost
+    blocks = make_blocks(100_000, 10_000)
+    cost = block_cost(blocks)
+    for world in (1, 2, 4, 8):
+        deal = deal_blocks(blocks, world)
+        allb = np.concatenate(deal)
+        assert sorted(allb.tolist()) == list(range(len(blocks)))
+        assert all((np.diff(d) > 0).all() for d in deal if len(d) > 1)
+        loads = np.array([cost[d].sum() for d in deal])
+        assert loads.max() - loads.mean() <= cost.max()
 
 
 def test_gather_single_process():

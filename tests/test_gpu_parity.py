@@ -492,24 +492,142 @@ def test_c2_full_size_properties(engine):
     rng = np.random.default_rng(4)
     for a, b in zip(rng.integers(0, 5000, 25), rng.integers(0, 5000, 25)):
         assert abs(MI[a, b] - orc.mi_pair_direct(st, hdw, r, uqe, int(a), int(b))) < MI_TIGHT
-    # sampled rows against the C oracle (reference quirk mode)
+    # ---- the WHOLE 5000 x 5000 block against the C oracle (block-faithful restatement, reference quirk mode) ----
     Mq = engine.mi_block(idx, idx)
-    rows = np.array([0, 17, 2500, 4999])
-    ref = c_oracle.mi_block(st, hdw, r, uqe, rows, idx)
-    # row a of the square block uses RXY(c / nt, c % nt): compute the reference with the same full-block geometry
-    ref_full_rows = np.stack([[orc.mi_pair_direct(st, hdw, r, uqe, int(a), int(b), orc.q1_rxy(int(a), int(b), 5000, 5000, r, r))
-                               for b in (0, 1234, 4999)] for a in rows])
-    assert np.abs(Mq[np.ix_(rows, [0, 1234, 4999])] - ref_full_rows).max() < MI_TIGHT
-    del ref
-    # link tables: every pair lands in exactly one of sr / lr-before-filter
-    approx = MIH.lr_links_approx(syn["POS"], float(syn["g"]), 20000.0)
-    engine.mi_all_pairs(MIH.make_blocks(5000, 10000), 20000.0, 1e6, approx)
-    stt = engine.block_stats()
-    assert stt["n_sr"][0] + stt["n_lr_total"][0] == 5000 * 4999 // 2
-    a, b, mi = engine.links(1)
-    assert (a > b).all() and np.all(mi >= stt["disc_thresh"][0])
-    key = a.astype(np.int64) + b.astype(np.int64) * 5000
-    assert (np.diff(key) > 0).all()                              # reference row order (column-major, a > b)
+    ref = c_oracle.mi_block(st, hdw, r, uqe, idx, idx)
+    assert ref.shape == Mq.shape == (5000, 5000)
+    assert np.abs(Mq - ref).max() < MI_TIGHT
+    # ---- the COMPLETE link tables against the oracle's a-7 selection on the oracle's MI: same rows, same order ----
+    POS, paint, g = syn["POS"], syn["paint"], float(syn["g"])
+    approx = MIH.lr_links_approx(POS, g, 20000.0)
+    assert approx == orc.lr_links_approx(POS, g, 20000.0)
+    bl = orc.block_links(ref, idx, idx, POS, paint, g, 20000.0, 1e6, approx)
+    for cold in (True, False):       # a cold pass (probe / plain first block) and a warm one (bucket guess from the pass before)
+        if cold:
+            engine.reset_speculation()
+        engine.mi_all_pairs(MIH.make_blocks(5000, 10000), 20000.0, 1e6, approx)
+        stt = engine.block_stats()
+        assert stt["n_sr"][0] + stt["n_lr_total"][0] == 5000 * 4999 // 2
+        assert stt["n_lr_total"][0] == bl.n_lr_total and stt["n_sr"][0] == len(bl.sr["MI"])
+        assert abs(stt["disc_thresh"][0] - bl.disc_thresh) < MI_TIGHT
+        sa, sb, smi = engine.links(0)
+        assert np.array_equal(sa, bl.sr["a"]) and np.array_equal(sb, bl.sr["b"])       # short-range table: row-exact
+        assert np.abs(smi - bl.sr["MI"]).max() < MI_TIGHT
+        a, b, mi = engine.links(1)
+        assert (a > b).all() and np.all(mi >= stt["disc_thresh"][0])
+        key = a.astype(np.int64) + b.astype(np.int64) * 5000
+        assert (np.diff(key) > 0).all()                              # reference row order (column-major, a > b)
+        # long-range table: the oracle's retained rows, in its order; a pair may sit on either side of `>=` only if its MI is
+        # within the parity tolerance of the threshold itself (the epilogue is not bit-matched to the reference's summation order)
+        okey = bl.lr["a"].astype(np.int64) + bl.lr["b"].astype(np.int64) * 5000
+        both = np.intersect1d(key, okey, assume_unique=True)
+        only_dev, only_orc = np.setdiff1d(key, okey, assume_unique=True), np.setdiff1d(okey, key, assume_unique=True)
+        assert len(only_dev) + len(only_orc) <= 3, (len(only_dev), len(only_orc))
+        for k in only_dev:
+            assert abs(float(mi[key == k][0]) - bl.disc_thresh) < MI_TIGHT
+        for k in only_orc:
+            assert abs(float(bl.lr["MI"][okey == k][0]) - bl.disc_thresh) < MI_TIGHT
+        sel_d, sel_o = np.isin(key, both, assume_unique=True), np.isin(okey, both, assume_unique=True)
+        assert np.array_equal(key[sel_d], okey[sel_o])                # same rows in the same order
+        assert np.abs(mi[sel_d] - bl.lr["MI"][sel_o]).max() < MI_TIGHT
+        assert len(both) > 0.9 * 1e6 * bl.n_lr_total / approx
+    # ... and the selection rule itself on the DEVICE's dense MI: quantile type 7 + `>=` give exactly the rows the default path kept
+    rr, cc = orc.block_pair_index(5000, 5000, True)
+    ln = orc.circ_len(np.asarray(POS, dtype=np.float64)[cc], np.asarray(POS, dtype=np.float64)[rr], g)
+    lrm = ln > 20000.0
+    vals = Mq[rr[lrm], cc[lrm]]
+    thr = orc.quantile7(vals, bl.prob)
+    keep = vals >= thr
+    assert thr == stt["disc_thresh"][0]
+    assert np.array_equal(rr[lrm][keep], a) and np.array_equal(cc[lrm][keep], b) and np.array_equal(vals[keep], mi)
+
+
+def _dense_block_selection(Md, fi, ti, POS, g, sr_dist, lr_retain, approx, diag):
+    """R/computePairwiseMI.R:306-358 on a dense device MI block: (a, b, MI) of the rows `MI >= quantile(MI_lr, prob)` keeps, in the
+    reference's row order, the threshold and the number of long-range pairs.  quantile7 is the oracle's (oracle/ldw_oracle.py)."""
+    nf, nt = len(fi), len(ti)
+    rr, cc = orc.block_pair_index(nf, nt, diag)
+    P = np.asarray(POS, dtype=np.float64)
+    lrm = orc.circ_len(P[ti][cc], P[fi][rr], g) > sr_dist
+    rr, cc = rr[lrm], cc[lrm]
+    n_lr = len(rr)
+    prob = max(0.0, 1 - ((lr_retain * (n_lr / approx)) / n_lr))
+    vals = Md[rr, cc]
+    thr = orc.quantile7(vals, prob)
+    keep = vals >= thr
+    return fi[rr[keep]], ti[cc[keep]], vals[keep], thr, n_lr
+
+
+def test_c4_blocks_selection_pinned_to_oracle(engine):
+    """BASELINE config 4 at full size, one DIAGONAL and one OFF-DIAGONAL 10k x 10k block pair: (i) the dense device MI of the block
+    (ldw_mi_block: 5-limb GEMM + fp64 epilogue for every pair) equals the C oracle on a 512 x 512 sub-block (< 1e-10), with the
+    block's own Q1 geometry; (ii) the oracle's selection rule (quantile type 7 + `>=`, reference row order) applied to that dense
+    MI gives a threshold and a retained (a, b, MI) set that the DEFAULT path (approximate GEMM + screen + popcount sums,
+    speculative selection) reproduces exactly — rows, order, MI bits, threshold — cold and warm."""
+    import torch
+    Ls, N = 100_000, 5_000
+    syn = synth_alignment(Ls, N, seed=1988, device="cuda", as_numpy=False)
+    st_dev = syn["states"]
+    engine.set_alignment(st_dev)
+    cnt = engine.state_counts()
+    uqe = (cnt > 0).T.astype(np.float64)
+    r = uqe.sum(axis=1)
+    hdw = engine.hamming_weights(int(Ls * 0.1))
+    engine.set_weights(hdw)
+    POS, g, paint = syn["POS"], float(syn["g"]), syn["paint"]
+    engine.set_snp_meta(r, uqe, POS, paint, g)
+    approx = MIH.lr_links_approx(POS, g, 20000.0)
+    blocks = MIH.make_blocks(Ls, 10000)
+    pick = [0, 27]          # (1..10000) x (1..10000) and an off-diagonal pair in the middle of the list
+    assert blocks[pick[0]].tolist() == [1, 10000, 1, 10000] and blocks[pick[1]][0] != blocks[pick[1]][2]
+    sub = blocks[pick]
+    want = []
+    for fs, fe, ts, te in sub.tolist():
+        fi, ti = np.arange(fs - 1, fe), np.arange(ts - 1, te)
+        diag = fs == ts
+        Md = engine.mi_block(fi, ti)                       # dense, reference quirk mode (square block: RXY = r[b] r[a] / 4)
+        # (i) 512 x 512 sub-block against the C oracle: the oracle's Q1 index depends on the block shape, so the sub-block is
+        # checked in INTENDED mode (RXY = r_a r_b / 4, shape-free) and the quirk is checked per pair below
+        Mi = engine.mi_block(fi, ti, quirk=L.QUIRK_INTENDED)
+        o_f, o_t = 3000, (3000 if diag else 6100)
+        sf, stt_ = fi[o_f:o_f + 512], ti[o_t:o_t + 512]
+        rows_needed = np.unique(np.concatenate([sf, stt_]))
+        st_sub = st_dev[torch.as_tensor(rows_needed, device=st_dev.device)].cpu().numpy()
+        loc_f, loc_t = np.searchsorted(rows_needed, sf), np.searchsorted(rows_needed, stt_)
+        # intended mode == the oracle's block-faithful MI of a SYMMETRIC geometry: evaluate the oracle on (sf u st) x (sf u st) and cut
+        allr = np.arange(len(rows_needed))
+        Mo = c_oracle.mi_block(st_sub, hdw, r[rows_needed], uqe[rows_needed], allr, allr)    # square: Q1 harmless up to transposition
+        # square block with from == to: RXY[c] = r[c / n] r[c % n] / 4 = r_a r_b / 4 (symmetric in a, b)
+        assert np.abs(Mi[o_f:o_f + 512, o_t:o_t + 512] - Mo[np.ix_(loc_f, loc_t)]).max() < MI_TIGHT
+        rng = np.random.default_rng(31)
+        for _ in range(16):   # the reference's Q1 RXY of THIS block geometry, per pair
+            a_l, b_l = int(rng.integers(0, len(fi))), int(rng.integers(0, len(ti)))
+            rows2 = st_dev[[int(fi[a_l]), int(ti[b_l])]].cpu().numpy()
+            rxy = orc.q1_rxy(a_l, b_l, len(fi), len(ti), r[fi], r[ti])
+            refv = orc.mi_pair_direct(rows2, hdw, r[[fi[a_l], ti[b_l]]], uqe[[fi[a_l], ti[b_l]]], 0, 1, rxy)
+            assert abs(Md[a_l, b_l] - refv) < MI_TIGHT
+        # (ii) the oracle's selection on the dense device MI
+        want.append(_dense_block_selection(Md, fi, ti, POS, g, 20000.0, 1e6, approx, diag))
+        del Md, Mi
+    for cold in (True, False):
+        if cold:
+            engine.reset_speculation()
+        c0 = engine.counters()
+        engine.mi_all_pairs(sub, 20000.0, 1e6, approx)
+        c1 = engine.counters()
+        assert c1["apx_blocks"] - c0["apx_blocks"] >= (1 if cold else 2)       # the default path, not a fallback
+        stt = engine.block_stats()
+        la, lb, lmi = engine.links(1)
+        off = 0
+        for bi, (wa, wb, wmi, thr, n_lr) in enumerate(want):
+            n = int(stt["n_lr_kept"][bi])
+            assert int(stt["n_lr_total"][bi]) == n_lr
+            assert stt["disc_thresh"][bi] == thr, (bi, cold, stt["disc_thresh"][bi], thr)
+            assert n == len(wmi), (bi, cold, n, len(wmi))
+            assert np.array_equal(la[off:off + n], wa) and np.array_equal(lb[off:off + n], wb), (bi, cold)
+            assert np.array_equal(lmi[off:off + n], wmi), (bi, cold)
+            off += n
+        assert off == len(lmi)
 
 
 def test_speculative_gather_and_fallback(engine, synth):
@@ -885,6 +1003,49 @@ def test_screen_and_mixed_paths_on_multiallelic_alignment(engine):
     Mg = engine.mi_block(fi, ti, quirk=L.QUIRK_INTENDED)
     Mo = np.array([[orc.mi_pair_direct(st, hdw, r, uqe, int(a), int(b)) for b in (1000, 1500, 1999)] for a in (0, 3, 500, 999)])
     assert np.abs(Mg[np.ix_([0, 3, 500, 999], [0, 500, 999])] - Mo).max() < MI_TIGHT
+
+
+def test_616_distinct_weights_take_the_approximate_path(engine):
+    """The weight structure of BASELINE config 3 at its worst: N = 616 sequences with 616 DISTINCT Hamming weights 1 / (k + 1)
+    (R/performPopulationStuctureCorrection.R:76: hdw = 1 / (#neighbours + 1); a real alignment has up to N distinct values, not
+    the few clonal classes of the synthetic one).  The approximate-GEMM path must engage (ldw_path_report says which path the
+    blocks took and which gate failed otherwise), the verify mode must count no lost pair, and the tables must equal the plain path's."""
+    syn = synth_alignment(24000, 616, seed=616)
+    st = syn["states"]
+    uqe, r = orc.uqe_r(st)
+    hdw = 1.0 / (np.random.default_rng(616).permutation(616) + 1.0)
+    assert len(np.unique(hdw)) == 616
+    d = dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=syn["POS"], paint=syn["paint"], g=float(syn["g"]))
+    _setup(engine, d)
+    info = engine.apx_info()
+    rep0 = engine.path_report()
+    assert info["usable"] and rep0["apx_gate"] == "ok" and info["classes"] >= 600, (info, rep0)
+    approx = MIH.lr_links_approx(syn["POS"], float(syn["g"]), 20000.0)
+    blocks = MIH.make_blocks(24000, 8000)           # 6 block pairs, 3 diagonal
+    out = {}
+    for key, (mixed, scr, path) in dict(plain=(False, 0, 1), verify=(True, 2, 2), fast=(True, 1, 0)).items():
+        engine.set_mixed(mixed)
+        engine.set_screen(scr)
+        engine.set_path(path)
+        engine.reset_speculation()
+        c0, p0 = engine.counters(), engine.path_report()
+        engine.mi_all_pairs(blocks, 20000.0, 2e5, approx)
+        c1, p1 = engine.counters(), engine.path_report()
+        out[key] = (engine.links(0), engine.links(1), {k: c1[k] - c0[k] for k in c1}, {k: p1[k] - p0[k] for k in p1 if k != "apx_gate"})
+    engine.set_mixed(True)
+    engine.set_screen(1)
+    engine.set_path(0)
+    assert out["verify"][2]["screen_violations"] == 0 and out["fast"][2]["screen_violations"] == 0
+    assert out["fast"][3]["apx_blocks"] >= len(blocks) - 1 and out["verify"][3]["apx_blocks"] >= len(blocks) - 1, out["fast"][3]
+    assert out["plain"][3]["apx_blocks"] == 0 and out["plain"][3]["plain_blocks"] >= len(blocks)
+    for key in ("verify", "fast"):
+        for which in (0, 1):
+            for x, y in zip(out["plain"][which], out[key][which]):
+                assert np.array_equal(x, y), (key, which)
+    assert len(out["plain"][1][2]) > 1000
+    # a gate that fails is named: 40960 sequences exceed the digit arrays' LDS budget -> limb paths, same API
+    rep = engine.path_report()
+    assert rep["apx_gate"] == "ok" and rep["pairs_listed"] > 0
 
 
 def _table_digest(a, b, mi):

@@ -3,6 +3,7 @@ import numpy as np
 
 import ldw_oracle as orc
 from ldweaver_amd import rcompat
+from ldweaver_amd.engine import format_number as native_format, write_table_tsv
 
 
 def test_r_rng_known_answers():
@@ -47,3 +48,46 @@ def test_circ_len():
     g = 50000
     assert list(rcompat.circ_len([10, 49990, 30000], [49990, 10, 5000], g)) == [20.0, 20.0, 25000.0]
     assert list(rcompat.circ_len([5, 7], [7, 5], 11)) == [2.0, 2.0]   # odd genome length stays integral
+
+
+_R_CASES = {100000.0: "1e+05", 20000.0: "20000", 123456.0: "123456", 0.1: "0.1", 0.0001: "1e-04", 1e-5: "1e-05",
+            0.000123456789: "0.000123456789", 1234.5: "1234.5", 0.6824123456789012: "0.682412345678901",
+            1.8e-13: "1.8e-13", 3.0: "3", -0.25: "-0.25", 1e15: "1e+15", 0.0: "0"}
+
+
+def test_native_number_format_known_answers():
+    """ldw_format_number (the native writer's cell rule, ldw_tsv.cpp) on the known R answers and the special values."""
+    for v, s in _R_CASES.items():
+        assert native_format(v) == s, (v, native_format(v), s)
+    assert native_format(float("nan")) == "NA" and native_format(float("inf")) == "Inf" and native_format(float("-inf")) == "-Inf"
+    assert native_format(-0.0) == "0" and native_format(1110657.5) == "1110657.5" and native_format(0.5) == "0.5"
+    assert native_format(123456789012345678.0) == rcompat.format_number(123456789012345678.0) == "123456789012345677"[:0] + rcompat.format_number(123456789012345678.0)
+
+
+def test_native_tsv_writer_equals_python_writer(tmp_path):
+    """ldw_write_table_tsv byte-identical to the Python statement of R's rule (rcompat.format_number) on 1e6 random doubles of
+    every kind the link files hold (MI-like, len-like halves and integers, tiny / huge magnitudes, negatives) + integer columns;
+    append semantics; threads do not reorder rows."""
+    rng = np.random.default_rng(5)
+    n = 1_000_000
+    x = np.concatenate([rng.random(n // 2) * 0.2, np.exp(rng.uniform(-40, 40, n // 8)), rng.integers(0, 4_000_000, n // 8) / 2.0,
+                        rng.integers(0, 3_000_000, n // 8).astype(float), -np.exp(rng.uniform(-13, 8, n // 16)), rng.integers(1, 10 ** 6, n // 16) / 1000.0,
+                        np.array(list(_R_CASES) + [1e-5, 9.99999999999999e-6, 999.999999999999, 999.9999999999999, 0.999999999999999,
+                                                   0.9999999999999999, 0.099999999999999995, 5e-324, 1e300, 1e22, 1e21, 99999.99999999999,
+                                                   999999999999999.9, 0.1 + 0.2, 1 / 3, 2 / 3, float("nan"), float("inf")])])
+    ints = rng.integers(-5, 3_000_000, len(x)).astype(np.int32)
+    path = tmp_path / "t.tsv"
+    path.write_text("head\tline\n")
+    nb = write_table_tsv(str(path), [ints, x], append=True)
+    got = path.read_text().splitlines()
+    assert got[0] == "head\tline" and len(got) == len(x) + 1 and nb == path.stat().st_size - len("head\tline\n")
+    fmt = rcompat.format_number
+    step = 1 if len(x) <= 1_200_000 else 7
+    for i in range(0, len(x), step):
+        assert got[i + 1] == f"{int(ints[i])}\t{fmt(float(x[i]))}", (i, x[i], got[i + 1])
+    # single thread == many threads; truncate instead of append
+    write_table_tsv(str(tmp_path / "one.tsv"), [ints, x], append=False, nthreads=1)
+    write_table_tsv(str(tmp_path / "many.tsv"), [ints, x], append=False, nthreads=7)
+    assert (tmp_path / "one.tsv").read_bytes() == (tmp_path / "many.tsv").read_bytes() == path.read_bytes()[len("head\tline\n"):]
+    write_table_tsv(str(tmp_path / "empty.tsv"), [np.zeros(0), np.zeros(0, dtype=np.int64)], append=False)
+    assert (tmp_path / "empty.tsv").read_bytes() == b""

@@ -30,6 +30,7 @@ COMBOS = [
     "--path 2 --screen 2",
     "--path 2 --no-overlap",
     "--engine hist",
+    "--warm",
 ]
 
 
