@@ -44,6 +44,11 @@ struct BlockStat {
     int64_t n_lr_total = 0, n_lr_kept = 0, n_sr = 0;
     double disc_thresh = 0;
 };
+// what the host knew / learnt about a block (LDW_BLOCK_TRACE=1 prints one line per block at ldw_links_end)
+struct BlockTrace {
+    int diag = 0, guess = -1, B_true = -1, margin = 0, path = 0 /* 0 plain, 1 mixed, 2 apx, 3 fused */, missed = 0, probed = 0;
+    long long n_cand = 0;
+};
 
 }  // namespace ldw
 
@@ -183,6 +188,7 @@ struct ldw_ctx {
     int64_t spec_misses = 0, fused_blocks = 0, unfused_blocks = 0, screen_violations = 0, mixed_blocks = 0;
     int screen = 1;                      // fp32 screen in front of the fp64 MI evaluation (0 off, 1 on, 2 verify)
     std::vector<ldw::BlockStat> stats;
+    std::vector<ldw::BlockTrace> trace;
 };
 
 namespace ldw {

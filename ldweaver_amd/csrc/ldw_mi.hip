@@ -2393,6 +2393,16 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
             c->spec_B_next[other] = g > 0 ? g : 0;
         }
     }
+    if ((int64_t)c->trace.size() <= hb.blk_no) c->trace.resize((size_t)hb.blk_no + 1);
+    {
+        ldw::BlockTrace &tr = c->trace[(size_t)hb.blk_no];
+        tr.diag = hb.diag ? 1 : 0;
+        tr.guess = hb.guess;
+        tr.B_true = do_lr ? hp->B_true : -1;
+        tr.path = hb.fused ? 3 : (hb.apx ? 2 : (hb.mixed ? 1 : 0));
+        tr.missed = missed ? 1 : 0;
+        tr.n_cand = do_lr ? (long long)hp->n_cand : 0;
+    }
     const int64_t m = do_lr ? (int64_t)hp->n_cand : 0;
     if (c->lrc_recorded) {   // exact number of long-range rows kept by all EARLIER blocks
         LDW_HIP(hipEventSynchronize(c->ev_lrc));
@@ -2596,6 +2606,7 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
     c->n_sr = 0;
     c->n_lr = 0;
     c->stats.clear();
+    c->trace.clear();
     c->blk_capacity = nblocks_capacity;
     c->blk_cursor = 0;
     for (int i = 0; i < 4; ++i) c->last_ms[i] = 0;
@@ -2668,6 +2679,14 @@ int ldw_links_end(ldw_ctx *c) {
         c->last_ms[1] += t12;
         c->last_ms[2] += t23;
         c->last_ms[3] += t01 + t12 + t23;
+        static const bool trace_on = getenv("LDW_BLOCK_TRACE") != nullptr;
+        if (trace_on && b < (int64_t)c->trace.size()) {
+            const ldw::BlockTrace &tr = c->trace[(size_t)b];
+            float span = 0;
+            if (b > 0) (void)hipEventElapsedTime(&span, c->ev_pool[(size_t)(b - 1) * EVB + 3], ev[3]);   // selection end of b-1 -> selection end of b
+            fprintf(stderr, "[ldw block %3lld] %s path %d guess %4d true %4d%s cand %8lld kept %7lld  gemm %.3f epi %.3f sel %.3f  span %.3f ms\n", (long long)b,
+                    tr.diag ? "diag" : "off ", tr.path, tr.guess, tr.B_true, tr.missed ? " MISS" : "", tr.n_cand, (long long)c->stats[b].n_lr_kept, t01, t12, t23, span);
+        }
     }
     c->blk_capacity = 0;
     return LDW_OK;

@@ -522,7 +522,10 @@ def test_c2_full_size_properties(engine):
         okey = bl.lr["a"].astype(np.int64) + bl.lr["b"].astype(np.int64) * 5000
         both = np.intersect1d(key, okey, assume_unique=True)
         only_dev, only_orc = np.setdiff1d(key, okey, assume_unique=True), np.setdiff1d(okey, key, assume_unique=True)
-        assert len(only_dev) + len(only_orc) <= 3, (len(only_dev), len(only_orc))
+        # (a tie group — pairs with equivalent joint tables — that holds the order statistic stays together on the device, where
+        # equal tables give equal bits, and is split in the last bit by the oracle's A,C,G,T,N summation order: seen here with 49
+        # partners of one SNP)
+        assert len(only_dev) + len(only_orc) <= max(3, len(okey) // 1000), (len(only_dev), len(only_orc))
         for k in only_dev:
             assert abs(float(mi[key == k][0]) - bl.disc_thresh) < MI_TIGHT
         for k in only_orc:
