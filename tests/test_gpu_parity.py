@@ -581,7 +581,7 @@ def test_c4_blocks_selection_pinned_to_oracle(engine):
     engine.set_snp_meta(r, uqe, POS, paint, g)
     approx = MIH.lr_links_approx(POS, g, 20000.0)
     blocks = MIH.make_blocks(Ls, 10000)
-    pick = [0, 27]          # (1..10000) x (1..10000) and an off-diagonal pair in the middle of the list
+    pick = [0, 30]          # (1..10000) x (1..10000) and an off-diagonal pair in the middle of the list: (30001..40000) x (60001..70000)
     assert blocks[pick[0]].tolist() == [1, 10000, 1, 10000] and blocks[pick[1]][0] != blocks[pick[1]][2]
     sub = blocks[pick]
     want = []
