@@ -46,7 +46,9 @@ def parse():
     ap.add_argument("--N", type=int, default=5_000)
     ap.add_argument("--max-blk-sz", type=int, default=10_000)
     ap.add_argument("--nlimbs", type=int, default=0)
-    ap.add_argument("--engine", choices=["mfma", "hist"], default="mfma")
+    ap.add_argument("--engine", choices=["mfma", "hist", "hist_states"], default="mfma",
+                    help="mfma: the default path; hist: joint histograms on bit planes (class-wise popcounts, k_cooc_popc) + the same fp64 epilogue; "
+                         "hist_states: the first histogram kernel (byte states in LDS, k_mi_hist)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
                                                       "smoke-testing the N > 1 path on a single GPU)")
@@ -173,7 +175,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)   # a real (non-null) stream shared by torch and the library
     torch.cuda.set_stream(stream)
     eng = Engine(local_rank, stream=stream.cuda_stream)
-    eng.set_engine(LL.ENGINE_HIST if args.engine == "hist" else LL.ENGINE_MFMA)
+    eng.set_engine({"mfma": LL.ENGINE_MFMA, "hist": LL.ENGINE_HIST, "hist_states": LL.ENGINE_HIST_STATES}[args.engine])
     eng.set_overlap(not args.no_overlap)
     eng.set_fused(args.fused)
     eng.set_screen(args.screen)
@@ -423,7 +425,7 @@ def main():
                     roof["traffic_source"] = ("profiles/r03_pmc_traffic.json (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, per launch; `traffic` "
                                               "takes FETCH_SIZE x 2 as the guide prescribes for gfx950, `traffic_range` = [raw, x 2])")
         else:
-            roof.update(kernel="k_mi_hist" if args.engine == "hist" else None, achieved=None, frac=None)
+            roof.update(kernel={"hist": "k_cooc_popc", "hist_states": "k_mi_hist"}.get(args.engine), achieved=None, frac=None)
         roof["dominant_stage"] = stage
         roof["hbm_alg_GBps_whole_step"] = (L * N + 8.0 * pairs) / (dt / K) / 1e9
         roof["hbm_frac_whole_step"] = roof["hbm_alg_GBps_whole_step"] / 8000.0

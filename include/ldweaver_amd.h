@@ -43,7 +43,8 @@ extern "C" {
 #define LDW_QUIRK_INTENDED 1  /* RXY = 0.25*r_a*r_b */
 
 #define LDW_ENGINE_MFMA 0 /* i8 MFMA fixed-point co-occurrence GEMM + fp64 epilogue (default) */
-#define LDW_ENGINE_HIST 1 /* LDS-tiled per-pair 5x5 histogram kernel (VALU), same results      */
+#define LDW_ENGINE_HIST 1 /* joint histograms on bit planes: LDS-tiled class-wise popcounts (VALU), exact int64 sums, same fp64 epilogue and results */
+#define LDW_ENGINE_HIST_STATES 2 /* the first histogram kernel: byte states in LDS, 25 sums per pair updated sequence by sequence (independent cross-check; ~200x slower) */
 
 typedef struct ldw_ctx ldw_ctx;
 

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("LDW_AMD_LIB") or os.path.join(_HERE, "libldweaver_amd
 
 LDW_OK = 0
 QUIRK_REFERENCE, QUIRK_INTENDED = 0, 1
-ENGINE_MFMA, ENGINE_HIST = 0, 1
+ENGINE_MFMA, ENGINE_HIST, ENGINE_HIST_STATES = 0, 1, 2
 COL_INT32, COL_INT64, COL_DOUBLE = 0, 1, 2
 
 

@@ -397,7 +397,7 @@ int ldw_gemm_stats(ldw_ctx *c, double out[6], int reset) {
 
 int ldw_set_engine(ldw_ctx *c, int engine) {
     LDW_REQUIRE(c, LDW_ERR_ARG, "null context");
-    LDW_REQUIRE(engine == LDW_ENGINE_MFMA || engine == LDW_ENGINE_HIST, LDW_ERR_ARG, "unknown engine %d", engine);
+    LDW_REQUIRE(engine == LDW_ENGINE_MFMA || engine == LDW_ENGINE_HIST || engine == LDW_ENGINE_HIST_STATES, LDW_ERR_ARG, "unknown engine %d", engine);
     c->engine = engine;
     return LDW_OK;
 }

@@ -181,6 +181,67 @@ int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *pa
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
+// Epilogue of a wave tile (MT x NT MFMA tiles at wave-tile coordinates ty, tx): the threshold-table test per region of 32 to-rows x
+// the wave's from-rows (P.fuse) and the store of the regions that are not clean.  s_bt: 256 wave-private LDS bytes.
+template <int MT, int NT>
+__device__ __forceinline__ void apx_gemm_epilogue(const ApxGemmArgs &P, v16i (&acc)[MT][NT], int ty, int tx, int lane, const int2 *s_tab, uint8_t *s_bt) {
+    constexpr int TH = 32 * MT, TWd = 32 * NT;
+    const int frow = lane & 31, fh = lane >> 5;
+    int bf[NT];
+    if (P.fuse) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[j] = (int)P.bin_f[tx * TWd + 32 * j + frow];
+        // one coalesced load of the wave tile's TH to-side bins, then LDS byte reads at static offsets (64 separate global byte
+        // loads per lane made the epilogue cost more than the screen saved)
+        for (int r = lane; r < TH; r += 64) s_bt[r] = P.bin_t[ty * TH + r];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0);   // (wave-private LDS: the writes of this wave are done before its reads)
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        bool store = true;
+        if (P.fuse) {   // region = to-rows [ty TH + 32 i, + 32) x the wave's from-rows (NT * 32 = 64 when NT = 2)
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ok = ok && bf[j] != 255;
+            if (P.sr_mask && P.sr_mask[(int64_t)ty * (P.RFpad / 64) + tx] != 0) ok = false;   // (TH = 128, TWd = 64: the band mask's own tiles)
+            int bt[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                bt[e] = (int)s_bt[32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh];
+                ok = ok && bt[e] != 255;
+            }
+            if (__ballot(!ok) == 0ull) {   // (a region with a row of another kind of SNP is stored without the 32 look-ups per lane)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int2 th = s_tab[bt[e] * P.tab_nb + bf[j]];
+                        const int n = acc[i][j][e];
+                        ok = ok && n > th.x && n < th.y;
+                    }
+            }
+            const bool clean = __ballot(!ok) == 0ull;
+            if (lane == 0) {
+#pragma unroll
+                for (int h = 0; h < (NT * 32) / 64; ++h) P.clean[(int64_t)((ty * TH + 32 * i) / 32) * (P.RFpad / 64) + (tx * TWd) / 64 + h] = clean ? 1 : 0;
+            }
+            store = !clean;
+        }
+        if (store) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int fcol = tx * TWd + 32 * j + frow;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int trow = ty * TH + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    P.G[(int64_t)trow * P.RFpad + fcol] = acc[i][j][e];
+                }
+            }
+        }
+    }
+}
+
 template <int MT, int NT>
 __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -269,61 +330,152 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     }
-    int bf[NT];
-    uint8_t *s_bt = reinterpret_cast<uint8_t *>(s_tab + 64 * 64) + wave * 256;   // the to-side bins of this wave's rows (P.fuse)
-    if (P.fuse) {
+    apx_gemm_epilogue<MT, NT>(P, acc, ty, tx, lane, s_tab, reinterpret_cast<uint8_t *>(s_tab + 64 * 64) + wave * 256);
+}
+// ------------------------------------------------------------------------------------------------
+// gemm_apx_lds_kernel: the same contraction with the operand expansion SHARED through LDS (r03).
+//
+// gemm_apx_kernel expands every fragment in the wave that consumes it: 6 expansions (48 VALU, 12 table reads) per 8 MFMAs, which
+// keeps the VALU issue port ~88 % busy at the full MFMA rate even on paper — it runs at 0.51 of the int8 peak.  Here a
+// workgroup of 8 waves (2 along the to side x 4 along the from side, 256 x 256 rows, wave tile 128 x 64 as before) expands
+// each operand row ONCE per 64 positions: thread t owns row t & 255 of side t >> 8, reads the row's 64-bit panel word, turns it
+// into four digit-masked 16-byte fragments (table look-ups as before) and writes them to an LDS byte tile; every wave then feeds
+// its MFMAs with ds_read_b128.  Per 64 positions a wave does 4 expansions (32 VALU, 8 table reads, 4 ds_write_b128) and
+// 12 ds_read_b128 for 16 MFMAs: 2 VALU per MFMA instead of 6.  Two LDS buffers, one workgroup barrier per 64 positions (512
+// MFMA cycles).  The byte tile is [row][64 B] with the 16-byte slot XOR-swizzled by (row >> 2) & 3: the 16 lanes that share
+// an LDS pass (rows r .. r + 15, same slot) then cover all 64 banks once, for the writes and for the fragment reads.
+// LDS: 2 x 32 KB tiles + 2 KB table + the digit arrays (+ 33 KB threshold table when the epilogue applies it): one workgroup
+// of 8 waves per CU, two waves per SIMD as before.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void gemm_apx_lds_kernel(ApxGemmArgs P) {
+    constexpr int MT = 4, NT = 2;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint64_t *lutFF = reinterpret_cast<uint64_t *>(smem);                       // [256]
+    uint8_t *sA = smem + 2048, *sB = sA + (size_t)P.M2 * 128;                   // digits by position
+    uint8_t *tile0 = sB + (size_t)P.M2 * 128;                                   // 2 buffers x (256 to-rows + 256 from-rows) x 64 B
+    int2 *s_tab = reinterpret_cast<int2 *>(tile0 + 2 * 32768);                  // threshold table (P.fuse)
+    const int tid = threadIdx.x;
+    if (P.fuse)
+        for (int i = tid; i < P.tab_nb * P.tab_nb; i += 512) s_tab[i] = P.tab[i];
+    if (tid < 256) {
+        uint64_t e = 0;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = (int)P.bin_f[tx * TWd + 32 * j + frow];
-        // one coalesced load of the wave tile's TH to-side bins, then LDS byte reads at static offsets (64 separate global byte
-        // loads per lane made the epilogue cost more than the screen saved)
-        for (int r = lane; r < TH; r += 64) s_bt[r] = P.bin_t[ty * TH + r];
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0);   // (wave-private LDS: the writes of this wave are done before its reads)
+        for (int k = 0; k < 8; ++k) e |= ((tid >> k) & 1) ? (0xFFull << (8 * k)) : 0ull;
+        lutFF[tid] = e;
     }
+    {
+        const int n16 = P.M2 * 8;
+        for (int i = tid; i < n16; i += 512) {
+            reinterpret_cast<uint4 *>(sA)[i] = reinterpret_cast<const uint4 *>(P.dig_a)[i];
+            reinterpret_cast<uint4 *>(sB)[i] = reinterpret_cast<const uint4 *>(P.dig_b)[i];
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wy = wave >> 2, wx = wave & 3;
+    const int ty = 2 * blockIdx.y + wy, tx = 4 * blockIdx.x + wx;      // wave-tile coordinates (128 to-rows, 64 from-rows)
+    constexpr int TH = 128, TWd = 64;
+    // the whole 256 x 256 tile above the diagonal: nothing to do (uniform over the workgroup: no barrier is skipped by a part of it)
+    if (P.lower_only && (int)(4 * blockIdx.x + 3) * TWd + TWd - 1 < (int)(2 * blockIdx.y) * TH) return;
+    const bool wave_live = ty * TH < P.RTpad && tx * TWd < P.RFpad && !(P.lower_only && tx * TWd + TWd - 1 < ty * TH);
+    // ---- expansion role: row er of side eside ----
+    const int eside = tid >> 8, er = tid & 255;
+    const int grow = eside == 0 ? (int)(2 * blockIdx.y) * TH + er : (int)(4 * blockIdx.x) * TWd + er;   // row in the side's row list
+    const int gmax = eside == 0 ? P.RTpad : P.RFpad;
+    const bool erow_ok = grow < gmax;
+    const uint64_t *prow = (eside == 0 ? P.panel_t : P.panel_f) + (int64_t)(erow_ok ? grow : 0) * 2;
+    const int64_t pst = (int64_t)gmax * 2;     // words per macro step in this side's panel
+    const uint8_t *dig = eside == 0 ? sA : sB;
+    const int wsw = (er >> 2) & 3;             // the row's slot swizzle
+    uint8_t *wdst = tile0 + eside * 16384 + er * 64;
+    typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
+    // all eight table reads of a chunk are issued before the first AND (one LDS round trip per chunk instead of four)
+    auto expand = [&](uint64_t w, int chunk, uint8_t *buf_base) {
+        const uint8_t *d = dig + chunk * 64;
+        u64x2v q[4];
+        v4i dg[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            q[g][0] = lutFF[(w >> (16 * g)) & 0xFFu];
+            q[g][1] = lutFF[(w >> (16 * g + 8)) & 0xFFu];
+            dg[g] = *reinterpret_cast<const v4i *>(d + 16 * g);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<v4i *>(buf_base + 16 * (g ^ wsw)) = __builtin_bit_cast(v4i, q[g]) & dg[g];
+    };
+    // ---- consumer role ----
+    const int frow = lane & 31, fh = lane >> 5;
+    int offA[MT], offB[NT];      // byte offset of this lane's row in the A / B half of a buffer, and its swizzle
+    int swA[MT], swB[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        bool store = true;
-        if (P.fuse) {   // region = to-rows [ty TH + 32 i, + 32) x the wave's from-rows (NT * 32 = 64 when NT = 2)
-            bool ok = true;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) ok = ok && bf[j] != 255;
-            if (P.sr_mask && P.sr_mask[(int64_t)ty * (P.RFpad / 64) + tx] != 0) ok = false;   // (TH = 128, TWd = 64: the band mask's own tiles)
-            int bt[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                bt[e] = (int)s_bt[32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh];
-                ok = ok && bt[e] != 255;
-            }
-            if (__ballot(!ok) == 0ull) {   // (a region with a row of another kind of SNP is stored without the 32 look-ups per lane)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const int2 th = s_tab[bt[e] * P.tab_nb + bf[j]];
-                        const int n = acc[i][j][e];
-                        ok = ok && n > th.x && n < th.y;
-                    }
-            }
-            const bool clean = __ballot(!ok) == 0ull;
-            if (lane == 0) {
-#pragma unroll
-                for (int h = 0; h < (NT * 32) / 64; ++h) P.clean[(int64_t)((ty * TH + 32 * i) / 32) * (P.RFpad / 64) + (tx * TWd) / 64 + h] = clean ? 1 : 0;
-            }
-            store = !clean;
-        }
-        if (store) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int fcol = tx * TWd + 32 * j + frow;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int trow = ty * TH + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    P.G[(int64_t)trow * P.RFpad + fcol] = acc[i][j][e];
-                }
-            }
-        }
+        const int r = wy * TH + 32 * i + frow;
+        offA[i] = r * 64;
+        swA[i] = (r >> 2) & 3;
     }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int r = wx * TWd + 32 * j + frow;
+        offB[j] = 16384 + r * 64;
+        swB[j] = (r >> 2) & 3;
+    }
+    v16i acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+    // one macro step (128 positions = two chunks) per iteration; the panel words of macro step m + 2 are requested at the top of
+    // iteration m and first touched at its bottom, two chunks of MFMAs later
+    u64x2v wcur = {0ull, 0ull}, wnext = {0ull, 0ull}, wfar = {0ull, 0ull};
+    if (erow_ok) wcur = *reinterpret_cast<const u64x2v *>(prow);
+    if (erow_ok && P.M2 > 1) wnext = *reinterpret_cast<const u64x2v *>(prow + pst);
+    __syncthreads();            // table, digits
+    expand(wcur[0], 0, wdst);
+    __syncthreads();
+    auto compute = [&](const uint8_t *cur) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v4i fa[MT], fb[NT];
+            const int slot = 2 * ks + fh;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const v4i *>(cur + offA[i] + 16 * (slot ^ swA[i]));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const v4i *>(cur + offB[j] + 16 * (slot ^ swB[j]));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    for (int m = 0; m < P.M2; ++m) {
+        if (erow_ok && m + 2 < P.M2) wfar = *reinterpret_cast<const u64x2v *>(prow + (int64_t)(m + 2) * pst);
+        // ---- chunk 2m (buffer 0); chunk 2m + 1 is expanded into buffer 1 meanwhile ----
+        expand(wcur[1], 2 * m + 1, wdst + 32768);
+        if (wave_live) {
+            const int sh = P.shift[m];
+            if (sh) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] = (int)((unsigned)acc[i][j][e] >> sh);
+            }
+            compute(tile0);
+        }
+        __syncthreads();
+        // ---- chunk 2m + 1 (buffer 1); the first chunk of the next macro step goes into buffer 0 ----
+        if (m + 1 < P.M2) expand(wnext[0], 2 * m + 2, wdst);
+        if (wave_live) compute(tile0 + 32768);
+        __syncthreads();
+        wcur = wnext;
+        wnext = wfar;
+    }
+    if (!wave_live) return;
+    apx_gemm_epilogue<MT, NT>(P, acc, ty, tx, lane, s_tab, reinterpret_cast<uint8_t *>(s_tab + 64 * 64) + wave * 256);
 }
+
 int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     LDW_REQUIRE(P.RTpad % APX_TW == 0 && P.RFpad % APX_TW == 0 && P.M2 > 0, LDW_ERR_ARG, "launch_gemm_apx: padding violated (RT %d RF %d M2 %d)", P.RTpad,
                 P.RFpad, P.M2);
@@ -334,6 +486,30 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
         const char *e = getenv("LDW_APX_TILE");   // tuning: wave tile in MFMA tiles, to side x from side (default 4 x 2)
         return e ? atoi(e) : 42;
     }();
+    static const int kern = [] {
+        const char *e = getenv("LDW_APX_KERNEL");   // "reg": operands expanded in registers per wave (r02); "lds": expansion shared through LDS (r03)
+        return (e && e[0] == 'r') ? 0 : 1;
+    }();
+    const size_t lds2 = 2048 + (size_t)P.M2 * 256 + 2 * 32768 + (P.fuse ? (size_t)P.tab_nb * P.tab_nb * 8 + 8 * 256 : 0);
+    if (kern == 1 && lds2 <= 160 * 1024 && tile == 42) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            LDW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_apx_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        const int ntx = P.RFpad / 64, nty = P.RTpad / 128;
+        hipLaunchKernelGGL(gemm_apx_lds_kernel, dim3((unsigned)((ntx + 3) / 4), (unsigned)((nty + 1) / 2)), dim3(512), lds2, st, P);
+        LDW_HIP(hipGetLastError());
+        int64_t waves = 0;
+        for (int ty = 0; ty < nty; ++ty) {
+            if (!P.lower_only) waves += ntx;
+            else for (int tx = 0; tx < ntx; ++tx) waves += (tx * 64 + 63 < ty * 128) ? 0 : 1;
+        }
+        c->gemm_stat[0] += 1;
+        if (P.fuse) c->gemm_stat[5] += 1;
+        c->gemm_stat[1] += 2.0 * (double)waves * 128 * 64 * ((double)P.M2 * 128.0);
+        return LDW_OK;
+    }
 #define LDW_APX_LAUNCH(MTv, NTv)                                                                                              \
     {                                                                                                                         \
         const int ntx = P.RFpad / (32 * NTv), nty = P.RTpad / (32 * MTv);                                                     \

@@ -1446,7 +1446,7 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
     E.nf = (int)nf;
     dim3 egrid((unsigned)(D.nf_tiles > 0 ? D.nf_tiles : (nf + 63) / 64), (unsigned)((nt + EPI_COLS - 1) / EPI_COLS));
     LDW_REQUIRE(egrid.y <= 65535u, LDW_ERR_ARG, "nt too large for the epilogue grid");
-    if (c->engine == LDW_ENGINE_HIST) {
+    if (c->engine == LDW_ENGINE_HIST_STATES) {
         LDW_HIP(hipEventRecord(ev[0], c->stream));
         LDW_HIP(hipEventRecord(ev[1], c->stream));
         if (int rc = launch_hist(c, D.idx_f, (int)nf, D.idx_t, (int)nt, c->pfix_state.as<int64_t>(), quirk, E.lower_only,
@@ -1462,8 +1462,10 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
     if (!epilogue_only) {
         if (int rc = Gbuf.reserve((size_t)RFpad * RTpad * 8)) return rc;
         LDW_HIP(hipEventRecord(ev[0], c->stream));
-        if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, Gbuf.as<int64_t>(), c->nlimbs,
-                                      c->digits.as<int8_t>(), E.lower_only, c->stream))
+        if (c->engine == LDW_ENGINE_HIST) {   // the histogram formulation on bit planes: class-wise popcounts instead of the MFMA GEMM
+            if (int rc = launch_cooc_popc(c, D.rl_t, RTpad, D.rl_f, RFpad, Gbuf.as<int64_t>(), E.lower_only, c->stream)) return rc;
+        } else if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, Gbuf.as<int64_t>(), c->nlimbs,
+                                             c->digits.as<int8_t>(), E.lower_only, c->stream))
             return rc;
         LDW_HIP(hipEventRecord(ev[1], c->stream));
     }
@@ -1576,7 +1578,7 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
         hipLaunchKernelGGL(k_mi_epilogue, egrid, dim3(256), 0, c->stream, A, D.perm, D.perm_t, ghist);
         LDW_HIP(hipGetLastError());
     }
-    if (which != 2 || c->engine != LDW_ENGINE_HIST) LDW_HIP(hipEventRecord(ev[2], c->stream));
+    LDW_HIP(hipEventRecord(ev[2], c->stream));
     return LDW_OK;
 }
 

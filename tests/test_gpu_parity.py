@@ -77,7 +77,7 @@ def test_joint_counts_bit_exact(engine, sample, synth):
     assert np.array_equal(cnt[:4], synth["joint_counts"])                       # golden
 
 
-@pytest.mark.parametrize("eng_kind", [L.ENGINE_MFMA, L.ENGINE_HIST])
+@pytest.mark.parametrize("eng_kind", [L.ENGINE_MFMA, L.ENGINE_HIST, L.ENGINE_HIST_STATES])
 def test_mi_blocks_match_oracle_and_golden(engine, sample, eng_kind):
     _setup(engine, sample)
     engine.set_engine(eng_kind)
@@ -149,7 +149,7 @@ def test_edge_cases_ragged_and_degenerate(engine):
     hdw = rng.choice([1.0, 0.5, 1 / 3, 1 / 7, 1 / 131], Ns)
     POS = np.sort(rng.choice(5000, Ls, replace=False) + 1).astype(np.int32)
     d = dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=POS, paint=np.ones(Ls, dtype=np.int32), g=5001.0)
-    for kind in (L.ENGINE_MFMA, L.ENGINE_HIST):
+    for kind in (L.ENGINE_MFMA, L.ENGINE_HIST, L.ENGINE_HIST_STATES):
         _setup(engine, d)
         engine.set_engine(kind)
         for fi, ti in ((np.arange(Ls), np.arange(Ls)), (np.arange(0, 40), np.arange(40, 77)), (np.array([5]), np.array([6])),
@@ -1049,6 +1049,46 @@ def test_616_distinct_weights_take_the_approximate_path(engine):
     # a gate that fails is named: 40960 sequences exceed the digit arrays' LDS budget -> limb paths, same API
     rep = engine.path_report()
     assert rep["apx_gate"] == "ok" and rep["pairs_listed"] > 0
+
+
+@pytest.mark.parametrize("Ns,weights", [(1000, "classes"), (616, "distinct"), (333, "unit")])
+def test_popcount_engine_equals_mfma_engine_bit_for_bit(engine, Ns, weights):
+    """LDW_ENGINE_HIST — the joint histograms on bit planes (k_cooc_popc: class-wise popcounts, three 16-bit limb sums) — produces
+    the SAME exact int64 joint sums as the 5-limb MFMA GEMM, so with the shared fp64 epilogue the dense MI blocks agree bit for bit
+    (diagonal, off-diagonal, ragged, N not a multiple of 32, few classes / N distinct weights / unit weights) and so do the link tables."""
+    Ls = 3000
+    syn = synth_alignment(Ls, Ns, seed=20 + Ns)
+    st = syn["states"]
+    uqe, r = orc.uqe_r(st)
+    rng = np.random.default_rng(Ns)
+    hdw = {"classes": lambda: 1.0 / rng.choice([1, 2, 3, 7, 31, 131, 400], Ns), "distinct": lambda: 1.0 / (rng.permutation(Ns) + 1.0),
+           "unit": lambda: np.ones(Ns)}[weights]()
+    d = dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=syn["POS"], paint=syn["paint"], g=float(syn["g"]))
+    approx = MIH.lr_links_approx(syn["POS"], float(syn["g"]), 20000.0)
+    blocks = MIH.make_blocks(Ls, 1000)[:5]
+    out = {}
+    for kind in (L.ENGINE_MFMA, L.ENGINE_HIST):
+        _setup(engine, d)
+        engine.set_engine(kind)
+        engine.set_mixed(False)
+        engine.set_screen(0)
+        engine.set_path(1)
+        dense = [engine.mi_block(fi, ti) for fi, ti in ((np.arange(0, 1000), np.arange(0, 1000)), (np.arange(0, 1000), np.arange(2000, 3000)),
+                                                        (np.arange(1000, 1777), np.arange(0, 1000)), (np.array([5, 9, 2999]), np.arange(40, 1077)))]
+        engine.mi_all_pairs(blocks, 20000.0, 5e4, approx)
+        out[kind] = (dense, engine.links(0), engine.links(1), engine.block_stats())
+    engine.set_engine(L.ENGINE_MFMA)
+    engine.set_mixed(True)
+    engine.set_screen(1)
+    engine.set_path(0)
+    for x, y in zip(out[L.ENGINE_MFMA][0], out[L.ENGINE_HIST][0]):
+        assert np.array_equal(x, y)
+    ref = c_oracle.mi_block(st, hdw, r, uqe, np.arange(1000, 1777), np.arange(0, 1000))
+    assert np.abs(out[L.ENGINE_HIST][0][2] - ref).max() < MI_TIGHT
+    for which in (1, 2):
+        for x, y in zip(out[L.ENGINE_MFMA][which], out[L.ENGINE_HIST][which]):
+            assert np.array_equal(x, y)
+    assert len(out[L.ENGINE_HIST][2][2]) > 100 and np.array_equal(out[L.ENGINE_MFMA][3]["disc_thresh"], out[L.ENGINE_HIST][3]["disc_thresh"])
 
 
 def _table_digest(a, b, mi):
