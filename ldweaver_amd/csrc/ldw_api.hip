@@ -265,7 +265,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
                            &c->srm_q, &c->srm_n, &c->srm_md, &c->srm_part, &c->srm_shape, &c->srm_cnt, &c->red_row, &c->red_meta,
                            &c->red_srp, &c->pool_a, &c->pool_b, &c->pool_mi, &c->ar_key, &c->ar_val, &c->ar_key2, &c->ar_val2,
                            &c->ar_off, &c->ar_flags, &c->seq_perm, &c->dig_a, &c->dig_b, &c->apx_shift, &c->slot_papx, &c->pop_segs, &c->pop_wbeg,
-                           &c->panel[0][0], &c->panel[0][1], &c->panel[1][0], &c->panel[1][1], &c->Gapx[0], &c->Gapx[1], &c->pair_sums, &c->tab11, &c->pairs[0], &c->pairs[1], &c->apx_units[0], &c->apx_units[1], &c->apx_packs[0], &c->apx_packs[1]};
+                           &c->panel[0][0], &c->panel[0][1], &c->panel[1][0], &c->panel[1][1], &c->Gapx[0], &c->Gapx[1], &c->pair_sums, &c->tab11[0], &c->tab11[1], &c->pairs[0], &c->pairs[1], &c->apx_units[0], &c->apx_units[1], &c->apx_packs[0], &c->apx_packs[1]};
     for (auto *b : bufs) b->release();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -345,7 +345,7 @@ int ldw_reset_speculation(ldw_ctx *c) {
     c->spec_B_next[0] = c->spec_B_next[1] = -1;
     c->spec_seen[0] = c->spec_seen[1] = false;
     c->spec_hist_n[0] = c->spec_hist_n[1] = 0;
-    c->tab11_lo = 0;
+    c->tab11_lo[0] = c->tab11_lo[1] = 0;
     return LDW_OK;
 }
 
@@ -648,7 +648,7 @@ int ldw_set_weights(ldw_ctx *c, const double *hdw, int64_t N, int nlimbs) {
     LDW_HIP(hipStreamSynchronize(c->stream));
     c->have_weights = true;
     c->rows_ready = false;
-    c->tab11_lo = 0;   // the threshold table belongs to the old weights
+    c->tab11_lo[0] = c->tab11_lo[1] = 0;   // the threshold tables belong to the old weights
     c->tab11_on = getenv("LDW_NO_TAB11") == nullptr;
     return LDW_OK;
 }

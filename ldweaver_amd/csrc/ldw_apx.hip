@@ -388,19 +388,24 @@ __global__ __launch_bounds__(512, 1) void gemm_apx_lds_kernel(ApxGemmArgs P) {
     const int wsw = (er >> 2) & 3;             // the row's slot swizzle
     uint8_t *wdst = tile0 + eside * 16384 + er * 64;
     typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
-    // all eight table reads of a chunk are issued before the first AND (one LDS round trip per chunk instead of four)
-    auto expand = [&](uint64_t w, int chunk, uint8_t *buf_base) {
+    // The expansion of a chunk is split around the MFMAs of the chunk being computed: the eight table reads and the digits are
+    // REQUESTED before the first k-step (exp_issue), masked and written behind it (exp_finish), so that the LDS round trip and
+    // the write pass run under MFMAs instead of in a phase of their own (all eight waves leave a barrier together: a phase
+    // without MFMAs is a phase in which the matrix pipe of every SIMD idles).
+    u64x2v xq[4];
+    v4i xdg[4];
+    auto exp_issue = [&](uint64_t w, int chunk) {
         const uint8_t *d = dig + chunk * 64;
-        u64x2v q[4];
-        v4i dg[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            q[g][0] = lutFF[(w >> (16 * g)) & 0xFFu];
-            q[g][1] = lutFF[(w >> (16 * g + 8)) & 0xFFu];
-            dg[g] = *reinterpret_cast<const v4i *>(d + 16 * g);
+            xq[g][0] = lutFF[(w >> (16 * g)) & 0xFFu];
+            xq[g][1] = lutFF[(w >> (16 * g + 8)) & 0xFFu];
+            xdg[g] = *reinterpret_cast<const v4i *>(d + 16 * g);
         }
+    };
+    auto exp_finish = [&](uint8_t *buf_base) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<v4i *>(buf_base + 16 * (g ^ wsw)) = __builtin_bit_cast(v4i, q[g]) & dg[g];
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<v4i *>(buf_base + 16 * (g ^ wsw)) = __builtin_bit_cast(v4i, xq[g]) & xdg[g];
     };
     // ---- consumer role ----
     const int frow = lane & 31, fh = lane >> 5;
@@ -431,30 +436,27 @@ __global__ __launch_bounds__(512, 1) void gemm_apx_lds_kernel(ApxGemmArgs P) {
     if (erow_ok) wcur = *reinterpret_cast<const u64x2v *>(prow);
     if (erow_ok && P.M2 > 1) wnext = *reinterpret_cast<const u64x2v *>(prow + pst);
     __syncthreads();            // table, digits
-    expand(wcur[0], 0, wdst);
+    exp_issue(wcur[0], 0);
+    exp_finish(wdst);
     __syncthreads();
-    auto compute = [&](const uint8_t *cur) {
+    auto kstep = [&](const uint8_t *cur, int ks) {
+        v4i fa[MT], fb[NT];
+        const int slot = 2 * ks + fh;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            v4i fa[MT], fb[NT];
-            const int slot = 2 * ks + fh;
+        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const v4i *>(cur + offA[i] + 16 * (slot ^ swA[i]));
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const v4i *>(cur + offA[i] + 16 * (slot ^ swA[i]));
+        for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const v4i *>(cur + offB[j] + 16 * (slot ^ swB[j]));
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const v4i *>(cur + offB[j] + 16 * (slot ^ swB[j]));
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
     };
     for (int m = 0; m < P.M2; ++m) {
         if (erow_ok && m + 2 < P.M2) wfar = *reinterpret_cast<const u64x2v *>(prow + (int64_t)(m + 2) * pst);
         // ---- chunk 2m (buffer 0); chunk 2m + 1 is expanded into buffer 1 meanwhile ----
-        expand(wcur[1], 2 * m + 1, wdst + 32768);
-        if (wave_live) {
+        {
             const int sh = P.shift[m];
-            if (sh) {
+            if (sh && wave_live) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -462,12 +464,17 @@ __global__ __launch_bounds__(512, 1) void gemm_apx_lds_kernel(ApxGemmArgs P) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) acc[i][j][e] = (int)((unsigned)acc[i][j][e] >> sh);
             }
-            compute(tile0);
         }
+        exp_issue(wcur[1], 2 * m + 1);
+        if (wave_live) kstep(tile0, 0);
+        exp_finish(wdst + 32768);
+        if (wave_live) kstep(tile0, 1);
         __syncthreads();
         // ---- chunk 2m + 1 (buffer 1); the first chunk of the next macro step goes into buffer 0 ----
-        if (m + 1 < P.M2) expand(wnext[0], 2 * m + 2, wdst);
-        if (wave_live) compute(tile0 + 32768);
+        if (m + 1 < P.M2) exp_issue(wnext[0], 2 * m + 2);
+        if (wave_live) kstep(tile0 + 32768, 0);
+        if (m + 1 < P.M2) exp_finish(wdst);
+        if (wave_live) kstep(tile0 + 32768, 1);
         __syncthreads();
         wcur = wnext;
         wnext = wfar;
@@ -487,8 +494,10 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
         return e ? atoi(e) : 42;
     }();
     static const int kern = [] {
-        const char *e = getenv("LDW_APX_KERNEL");   // "reg": operands expanded in registers per wave (r02); "lds": expansion shared through LDS (r03)
-        return (e && e[0] == 'r') ? 0 : 1;
+        // "reg" (default): operands expanded in registers per wave; "lds": expansion shared through LDS (r03 experiment: correct, and
+        // 28 % slower — 0.659 vs 0.515 ms per C4 launch — because the fragment reads + table reads + tile writes make it LDS-bound)
+        const char *e = getenv("LDW_APX_KERNEL");
+        return (e && e[0] == 'l') ? 1 : 0;
     }();
     const size_t lds2 = 2048 + (size_t)P.M2 * 256 + 2 * 32768 + (P.fuse ? (size_t)P.tab_nb * P.tab_nb * 8 + 8 * 256 : 0);
     if (kern == 1 && lds2 <= 160 * 1024 && tile == 42) {

@@ -104,8 +104,9 @@ struct ldw_ctx {
     int n_pop_segs = 0, n_classes = 0;
     ldw::DevBuf panel[2][2];           // [slot][from, to]: packed bit panels of a block's row lists, [KW/2][Rpad][2] u64
     ldw::DevBuf Gapx[2];               // int32 [RTpad][RFpad] approximate joint sums, one per pipeline slot
-    ldw::DevBuf tab11;                 // threshold table of the biallelic pairs (k_build_tab11), int2 [nb][nb]
-    double tab11_lo = 0;               // MI level it was built for (0: none)
+    ldw::DevBuf tab11[2];              // threshold tables of the biallelic pairs (k_build_tab11), int2 [nb][nb]: [off-diagonal, diagonal] blocks
+    double tab11_lo[2] = {0, 0};       // MI level each was built for (0: none)
+    int64_t tab11_builds = 0;
     float tab11_c = 0;
     int tab11_nb = 0;
     bool tab11_on = true;              // LDW_NO_TAB11 switches the table off (A/B measurements)

@@ -166,45 +166,58 @@ __device__ __forceinline__ double mi11_exact(double x, double pa, double pb, dou
     return (x * log(x * den / (A0 * B0)) + x01 * log(x01 * den / (A0 * B1)) + x10 * log(x10 * den / (A1 * B0)) + x11 * log(x11 * den / (A1 * B1))) / den;
 }
 
+// 32 lanes per bin pair: lanes 0..8 bisect H for one point of the 3 x 3 sample grid each, lanes 16..24 bisect L; xor-shuffles
+// combine them.  A bisection is a chain of dependent fp64 logarithms — latency, not throughput — so the table is built wide:
+// 512 workgroups, 20 steps per lane (always ending on the safe side: fewer steps only loosen a threshold by interval / 2^20),
+// cheap enough to rebuild whenever a block's level has drifted (launch_block_apx).
 __global__ __launch_bounds__(256) void k_build_tab11(double W, double lo, double delta, double eta, double sprime, int NB, float cbin, int2 *__restrict__ tab) {
-    const int id = blockIdx.x * 256 + threadIdx.x;
-    if (id >= NB * NB) return;
-    const int jb = id / NB, ia = id % NB;   // [bin of the to side][bin of the from side]
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int id = gid >> 5, role = gid & 31;
+    const int smp = role & 15;
+    const bool wantL = role >= 16;
+    const bool live = id < NB * NB && smp < 9;
+    const int idc = id < NB * NB ? id : NB * NB - 1;
+    const int jb = idc / NB, ia = idc % NB;   // [bin of the to side][bin of the from side]
     const double den = W + 2.0;
     double Lmax = -1e30, Hmin = 1e30;
-    for (int sa = 0; sa < 3; ++sa)
-        for (int sb = 0; sb < 3; ++sb) {
-            // bin k covers sqrt(p) * cbin in [k, k + 1); the last bin is open-ended: sample it up to the total weight
-            const double ua = (ia + 0.5 * sa) / cbin, ub = (jb + 0.5 * sb) / cbin;
-            double pa = ua * ua, pb = ub * ub;
-            if (ia == NB - 1 && sa > 0) pa = sa == 1 ? 0.5 * (pa + W) : W;
-            if (jb == NB - 1 && sb > 0) pb = sb == 1 ? 0.5 * (pb + W) : W;
-            pa = pa > W ? W : pa;
-            pb = pb > W ? W : pb;
-            const double E = (pa + 1.0) * (pb + 1.0) / den;
-            double xlo = 0.5, xhi = (pa < pb ? pa : pb) + 0.5;
-            const double xmin_feas = (pa + 1.0) + (pb + 1.0) - den + 0.5;
-            if (xmin_feas > xlo) xlo = xmin_feas;
-            double H = 1e30, L = -1e30;
+    if (live) {
+        const int sa = smp / 3, sb = smp % 3;
+        // bin k covers sqrt(p) * cbin in [k, k + 1); the last bin is open-ended: sample it up to the total weight
+        const double ua = (ia + 0.5 * sa) / cbin, ub = (jb + 0.5 * sb) / cbin;
+        double pa = ua * ua, pb = ub * ub;
+        if (ia == NB - 1 && sa > 0) pa = sa == 1 ? 0.5 * (pa + W) : W;
+        if (jb == NB - 1 && sb > 0) pb = sb == 1 ? 0.5 * (pb + W) : W;
+        pa = pa > W ? W : pa;
+        pb = pb > W ? W : pb;
+        const double E = (pa + 1.0) * (pb + 1.0) / den;
+        double xlo = 0.5, xhi = (pa < pb ? pa : pb) + 0.5;
+        const double xmin_feas = (pa + 1.0) + (pb + 1.0) - den + 0.5;
+        if (xmin_feas > xlo) xlo = xmin_feas;
+        if (!wantL) {
             if (E < xhi && mi11_exact(xhi, pa, pb, W, den) >= lo) {
                 double a = E > xlo ? E : xlo, b = xhi;
-                for (int it = 0; it < 40; ++it) {
+                for (int it = 0; it < 20; ++it) {
                     const double m = 0.5 * (a + b);
                     if (mi11_exact(m, pa, pb, W, den) < lo) a = m; else b = m;
                 }
-                H = a;   // MI(a) < lo: everything below a (and above E) is safe
+                Hmin = a;   // MI(a) < lo: everything below a (and above E) is safe
             }
-            if (E > xlo && mi11_exact(xlo, pa, pb, W, den) >= lo) {
-                double a = xlo, b = E < xhi ? E : xhi;
-                for (int it = 0; it < 40; ++it) {
-                    const double m = 0.5 * (a + b);
-                    if (mi11_exact(m, pa, pb, W, den) < lo) b = m; else a = m;
-                }
-                L = b;
+        } else if (E > xlo && mi11_exact(xlo, pa, pb, W, den) >= lo) {
+            double a = xlo, b = E < xhi ? E : xhi;
+            for (int it = 0; it < 20; ++it) {
+                const double m = 0.5 * (a + b);
+                if (mi11_exact(m, pa, pb, W, den) < lo) b = m; else a = m;
             }
-            Lmax = L > Lmax ? L : Lmax;
-            Hmin = H < Hmin ? H : Hmin;
+            Lmax = b;
         }
+    }
+#pragma unroll
+    for (int off = 1; off <= 16; off <<= 1) {
+        const double l2 = __shfl_xor(Lmax, off), h2 = __shfl_xor(Hmin, off);
+        Lmax = l2 > Lmax ? l2 : Lmax;
+        Hmin = h2 < Hmin ? h2 : Hmin;
+    }
+    if (role != 0 || id >= NB * NB) return;
     // n' is at most eta / sprime units below the sum of the approximate weights, which is within delta of the exact sum
     int2 e;
     const double hq = (Hmin * (1.0 - delta) - eta - 0.5) / sprime, lq = (Lmax * (1.0 + delta) + eta - 0.5) / sprime;
@@ -790,10 +803,12 @@ __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *_
         o.disc_thresh = nan("");
         if (run > 0) {
             const double dn = (double)run;
-            double prob = 1.0 - ((lr_retain * (dn / lr_approx)) / dn);
+            // every operation rounded on its own, in the reference's order (R does not contract a * b + c into an fma:
+            // R/computePairwiseMI.R:352, stats::quantile's index = 1 + (n - 1) * probs)
+            double prob = __dsub_rn(1.0, __ddiv_rn(__dmul_rn(lr_retain, __ddiv_rn(dn, lr_approx)), dn));
             if (!(prob > 0.0)) prob = 0.0;
             o.prob = prob;
-            o.index = 1.0 + (dn - 1.0) * prob;
+            o.index = __dadd_rn(1.0, __dmul_rn(dn - 1.0, prob));
             o.lo = (long long)floor(o.index);
             o.hi = (long long)ceil(o.index);
         }
@@ -886,7 +901,7 @@ __global__ void k_lr_thresh(const uint64_t *__restrict__ skey, PickOut *__restri
     double qs = xlo;
     if (o.index > (double)o.lo && xhi != qs) {
         const double h = o.index - (double)o.lo;
-        qs = (1.0 - h) * qs + h * xhi;
+        qs = __dadd_rn(__dmul_rn(1.0 - h, qs), __dmul_rn(h, xhi));   // two roundings + one, like R (stats::quantile is not fma-contracted)
     }
     const uint64_t kq = f64_key(qs);
     long long lo = 0, hi = m;
@@ -1095,7 +1110,7 @@ __global__ __launch_bounds__(1024) void k_sel_thresh(const uint64_t *__restrict_
         double qs = xlo;
         if (o.index > (double)o.lo && xhi != qs) {   // stats::quantile type 7 (the interpolation is skipped on a tie)
             const double h = o.index - (double)o.lo;
-            qs = (1.0 - h) * qs + h * xhi;
+            qs = __dadd_rn(__dmul_rn(1.0 - h, qs), __dmul_rn(h, xhi));   // two roundings + one, like R (stats::quantile is not fma-contracted)
         }
         pick->disc_thresh = qs;
         pick->n_kept = 0;                            // counted by k_sel_mark
@@ -1634,28 +1649,34 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     }
     if (phase == 1) {
         if (E.do_lr && c->tab11_on) {
-            // threshold table of the biallelic pairs: valid for every block whose level is at least the level it was built
-            // for (a higher level only widens the true interval), so it is rebuilt only when a block's level falls below it
+            // threshold table of the biallelic pairs, one per block kind (diagonal blocks sit ~8 % below the others): valid for every
+            // block whose level is at least the level it was built for — a higher level only widens the true interval, i.e. the
+            // table gets looser, and how tight it is decides how many regions the GEMM's epilogue finds clean — so it is rebuilt as
+            // soon as the block's level has left [tab_lo, 1.03 tab_lo] (one bucket = 0.5 %).  Phase 1 of every block runs in order
+            // on ONE stream, so the rebuild cannot overtake a reader.
+            const int kd = lo_h->diag ? 1 : 0;
             const double lo_blk = E.spec_lo - (double)E.scr_eps;
-            if (!(c->tab11_lo > 0) || lo_blk < c->tab11_lo || lo_blk > 1.5 * c->tab11_lo) {
+            if (!(c->tab11_lo[kd] > 0) || lo_blk < c->tab11_lo[kd] || lo_blk > 1.03 * c->tab11_lo[kd]) {
                 constexpr int NBINS_T = 64;
-                if (int rc = c->tab11.reserve((size_t)NBINS_T * NBINS_T * 8)) return rc;
+                if (int rc = c->tab11[kd].reserve((size_t)NBINS_T * NBINS_T * 8)) return rc;
                 const double W = std::ldexp((double)c->total_fixed, -c->frac_bits);
-                c->tab11_lo = 0.93 * lo_blk;   // buckets are 0.5 % wide and the guesses drift by a few per cent between blocks
+                c->tab11_lo[kd] = 0.99 * lo_blk;   // buckets are 0.5 % wide: the next blocks of the kind may guess two buckets lower without a rebuild
                 c->tab11_c = (float)(NBINS_T / std::sqrt(W + 1.0));
                 c->tab11_nb = NBINS_T;
                 const double sprime = std::ldexp(1.0, c->apx_e_last - c->frac_bits);
-                hipLaunchKernelGGL(k_build_tab11, dim3(NBINS_T * NBINS_T / 256), dim3(256), 0, gs, W, c->tab11_lo, c->apx_delta * 1.001,
-                                   (c->apx_lost_units + 1.0) * sprime, sprime, NBINS_T, c->tab11_c, c->tab11.as<int2>());
+                hipLaunchKernelGGL(k_build_tab11, dim3(NBINS_T * NBINS_T * 32 / 256), dim3(256), 0, gs, W, c->tab11_lo[kd], c->apx_delta * 1.001,
+                                   (c->apx_lost_units + 1.0) * sprime, sprime, NBINS_T, c->tab11_c, c->tab11[kd].as<int2>());
                 LDW_HIP(hipGetLastError());
+                ++c->tab11_builds;
             }
         }
     }
     EpiArgs A;
     fill_epi_args(c, D, nf, nt, RFpad, quirk, E, reinterpret_cast<const int64_t *>(c->Gapx[s].p), A);
     A.lo.slot_pfix_hi = c->slot_papx.as<int64_t>();   // the screen derives its cells from the marginals of the approximate weights
-    if (E.do_lr && c->tab11_on && c->tab11.p && c->tab11_lo > 0 && E.spec_lo - (double)E.scr_eps >= c->tab11_lo) {
-        A.tab11 = c->tab11.as<int2>();
+    const int kd_tab = lo_h->diag ? 1 : 0;
+    if (E.do_lr && c->tab11_on && c->tab11[kd_tab].p && c->tab11_lo[kd_tab] > 0 && E.spec_lo - (double)E.scr_eps >= c->tab11_lo[kd_tab]) {
+        A.tab11 = c->tab11[kd_tab].as<int2>();
         A.tab_nb = c->tab11_nb;
         A.tab_c = c->tab11_c;
     }
