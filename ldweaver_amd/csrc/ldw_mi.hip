@@ -803,12 +803,11 @@ __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *_
         o.disc_thresh = nan("");
         if (run > 0) {
             const double dn = (double)run;
-            // every operation rounded on its own, in the reference's order (R does not contract a * b + c into an fma:
-            // R/computePairwiseMI.R:352, stats::quantile's index = 1 + (n - 1) * probs)
-            double prob = __dsub_rn(1.0, __ddiv_rn(__dmul_rn(lr_retain, __ddiv_rn(dn, lr_approx)), dn));
+            // every operation rounded on its own, in the reference's order (ldw_dev.h: lr_prob, q7_index)
+            double prob = lr_prob(lr_retain, dn, lr_approx);
             if (!(prob > 0.0)) prob = 0.0;
             o.prob = prob;
-            o.index = __dadd_rn(1.0, __dmul_rn(dn - 1.0, prob));
+            o.index = q7_index(dn - 1.0, prob);
             o.lo = (long long)floor(o.index);
             o.hi = (long long)ceil(o.index);
         }
@@ -901,7 +900,7 @@ __global__ void k_lr_thresh(const uint64_t *__restrict__ skey, PickOut *__restri
     double qs = xlo;
     if (o.index > (double)o.lo && xhi != qs) {
         const double h = o.index - (double)o.lo;
-        qs = __dadd_rn(__dmul_rn(1.0 - h, qs), __dmul_rn(h, xhi));   // two roundings + one, like R (stats::quantile is not fma-contracted)
+        qs = q7_interp(h, qs, xhi);   // (no fma: ldw_dev.h)
     }
     const uint64_t kq = f64_key(qs);
     long long lo = 0, hi = m;
@@ -1110,7 +1109,7 @@ __global__ __launch_bounds__(1024) void k_sel_thresh(const uint64_t *__restrict_
         double qs = xlo;
         if (o.index > (double)o.lo && xhi != qs) {   // stats::quantile type 7 (the interpolation is skipped on a tie)
             const double h = o.index - (double)o.lo;
-            qs = __dadd_rn(__dmul_rn(1.0 - h, qs), __dmul_rn(h, xhi));   // two roundings + one, like R (stats::quantile is not fma-contracted)
+            qs = q7_interp(h, qs, xhi);   // (no fma: ldw_dev.h)
         }
         pick->disc_thresh = qs;
         pick->n_kept = 0;                            // counted by k_sel_mark

@@ -137,7 +137,7 @@ struct Q7 {
 };
 static Q7 q7_ranks(int64_t n, double p) {
     Q7 q;
-    q.index = 1.0 + (double)(n - 1 > 0 ? n - 1 : 0) * p;
+    q.index = ldw::q7_index((double)(n - 1 > 0 ? n - 1 : 0), p);
     q.lo = (int64_t)std::floor(q.index);
     q.hi = (int64_t)std::ceil(q.index);
     return q;
@@ -146,7 +146,7 @@ static double q7_value(const Q7 &q, double xlo, double xhi) {
     double qs = xlo;
     if (q.index > (double)q.lo && xhi != qs) {
         const double h = q.index - (double)q.lo;
-        qs = (1.0 - h) * qs + h * xhi;
+        qs = ldw::q7_interp(h, qs, xhi);
     }
     return qs;
 }

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_sr_quant(const SrPay *__restrict__ pay,
         const unsigned long long n = tot[c];
         cnt[(int64_t)(c - 1) * S + (l - 1)] = (int64_t)n;
         if (n) {
-            const double index = __dadd_rn(1.0, __dmul_rn((double)(n - 1), prob));   // R's 1-based index, rounded as R rounds it (no fma)
+            const double index = q7_index((double)(n - 1), prob);   // R's 1-based index, rounded as R rounds it (no fma: ldw_dev.h)
             tlo[c] = (unsigned long long)floor(index) - 1ull;
             thi[c] = (unsigned long long)ceil(index) - 1ull;
         } else {
