@@ -30,7 +30,7 @@ struct ApxGemmArgs {
     const uint64_t *panel_t, *panel_f;   // [M2][Rpad][2]: words 2m, 2m+1 of row list position r
     int RTpad, RFpad, M2;
     const uint8_t *dig_a, *dig_b;        // [128 * M2] by position
-    const int32_t *shift;                // [M2]
+    const int32_t *shift;                // [4 M2]: right shift before k-step k (32 positions)
     int32_t *G;                          // [RTpad][RFpad]
     int lower_only;
     // Threshold-table test in the epilogue (long-range-only blocks): bin_t / bin_f give every row of the two row lists its bin of

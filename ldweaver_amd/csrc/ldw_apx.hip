@@ -52,19 +52,22 @@ int prepare_apx_weights(ldw_ctx *c) {
     c->apx_ok = false;
     std::vector<int64_t> Vp((size_t)Npad, 0);
     for (int64_t p = 0; p < N; ++p) Vp[(size_t)p] = c->h_vfixed[(size_t)c->h_seq_perm[(size_t)p]];
-    // block exponents: smallest non-decreasing e(m) with ceil(Vmax(m) / 2^e) <= APX_PROD_CAP.  Products of two 7-bit digits
-    // are dense up to ~12000 (worst relative half-gap 1.0e-3 over [6000, 12000], 1.2e-3 over [3000, 12000]) and sparse
-    // above (15750 -> 15875: 4e-3), so the largest weight of a macro step is mapped below the sparse region
-    std::vector<int32_t> em((size_t)M2, 0), sh((size_t)M2, 0);
+    // block exponents, one per MFMA k-step of 32 consecutive positions (r03; r02 had one per macro step of 128, which put weights
+    // 1/128 .. 1 of an alignment with N distinct weights under ONE exponent: delta 6e-3, path off): smallest non-decreasing e(k)
+    // with ceil(Vmax(k) / 2^e) <= APX_PROD_CAP.  Products of two 7-bit digits are dense up to ~12000 (worst relative half-gap
+    // 1.0e-3 over [6000, 12000], 1.2e-3 over [3000, 12000]) and sparse above (15750 -> 15875: 4e-3), so the largest weight of a
+    // step is mapped below the sparse region
+    const int S4 = 4 * M2;
+    std::vector<int32_t> em((size_t)S4, 0), sh((size_t)S4, 0);
     int e_prev = 0, transitions = 0;
-    for (int m = 0; m < M2; ++m) {
+    for (int k = 0; k < S4; ++k) {
         int64_t vmax = 0;
-        for (int q = 0; q < 128; ++q) vmax = std::max(vmax, Vp[(size_t)m * 128 + q]);
+        for (int q = 0; q < 32; ++q) vmax = std::max(vmax, Vp[(size_t)k * 32 + q]);
         int e = e_prev;
         while (e < 62 && ((vmax + ((int64_t)1 << e) - 1) >> e) > APX_PROD_CAP) ++e;
-        em[(size_t)m] = e;
-        if (m > 0 && e > e_prev) {
-            sh[(size_t)m] = std::min(e - e_prev, 31);
+        em[(size_t)k] = e;
+        if (k > 0 && e > e_prev) {
+            sh[(size_t)k] = std::min(e - e_prev, 31);
             ++transitions;
         }
         e_prev = e;
@@ -75,7 +78,7 @@ int prepare_apx_weights(ldw_ctx *c) {
     for (int64_t p = 0; p < N; ++p) {
         const int64_t V = Vp[(size_t)p];
         if (V <= 0) continue;
-        const int e = em[(size_t)(p / 128)];
+        const int e = em[(size_t)(p / 32)];
         const size_t k = PT.nearest(std::ldexp((double)V, -e));
         da[(size_t)p] = PT.a[k];
         db[(size_t)p] = PT.b[k];
@@ -84,12 +87,12 @@ int prepare_apx_weights(ldw_ctx *c) {
         delta = std::max(delta, std::fabs((double)(Va - V)) / (double)V);
     }
     c->apx_delta = delta;
-    c->apx_e_last = M2 > 0 ? em[(size_t)M2 - 1] : 0;
+    c->apx_e_last = S4 > 0 ? em[(size_t)S4 - 1] : 0;
     c->apx_transitions = transitions;
     // units of 2^e_last a GEMM entry can have lost to the truncations: < 1 unit of 2^e(m) at every transition into macro step m
     c->apx_lost_units = 0;
-    for (int m = 1; m < M2; ++m)
-        if (sh[(size_t)m] > 0) c->apx_lost_units += std::ldexp(1.0, em[(size_t)m] - c->apx_e_last);
+    for (int k = 1; k < S4; ++k)
+        if (sh[(size_t)k] > 0) c->apx_lost_units += std::ldexp(1.0, em[(size_t)k] - c->apx_e_last);
     // weight classes = runs of equal V along the positions; segments = (32-bit word, class) intersections
     std::vector<PopSeg> segs;
     std::vector<int32_t> wbeg((size_t)(Npad / 32) + 1, 0);
@@ -120,12 +123,12 @@ int prepare_apx_weights(ldw_ctx *c) {
     if (segs.empty()) segs.push_back(PopSeg{0, 0, 0});
     if (int rc = c->dig_a.reserve((size_t)Npad)) return rc;
     if (int rc = c->dig_b.reserve((size_t)Npad)) return rc;
-    if (int rc = c->apx_shift.reserve((size_t)std::max(M2, 1) * 4)) return rc;
+    if (int rc = c->apx_shift.reserve((size_t)std::max(S4, 4) * 4)) return rc;
     if (int rc = c->pop_segs.reserve(segs.size() * sizeof(PopSeg))) return rc;
     if (int rc = c->pop_wbeg.reserve(wbeg.size() * 4)) return rc;
     LDW_HIP(hipMemcpyAsync(c->dig_a.p, da.data(), (size_t)Npad, hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipMemcpyAsync(c->dig_b.p, db.data(), (size_t)Npad, hipMemcpyHostToDevice, c->stream));
-    LDW_HIP(hipMemcpyAsync(c->apx_shift.p, sh.data(), (size_t)M2 * 4, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemcpyAsync(c->apx_shift.p, sh.data(), (size_t)S4 * 4, hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipMemcpyAsync(c->pop_segs.p, segs.data(), segs.size() * sizeof(PopSeg), hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipMemcpyAsync(c->pop_wbeg.p, wbeg.data(), wbeg.size() * 4, hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipStreamSynchronize(c->stream));
@@ -147,22 +150,46 @@ int prepare_apx_weights(ldw_ctx *c) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_pack_panel: panel[m][r][h] = Mbits[rowlist[r]][2 m + h].  Both consumers read one macro step (128 positions) of many
-// consecutive rows at a time; in this layout that is one contiguous run (16 B per row).
+// k_pack_panel: the 128 bits of macro step m of row-list position r as ONE 16-byte piece panel[m][r] (consecutive rows are
+// consecutive pieces: the GEMM's loads are contiguous runs).  interleave != 0 (gemm_apx_kernel): the eight 16-bit groups g of the
+// macro step are stored as word 0 = groups (0, 2, 4, 6), word 1 = groups (1, 3, 5, 7), so that the lane half fh of an MFMA
+// k-step kk finds ITS sixteen positions 32 kk + 16 fh .. + 15 — a k-step covers 32 CONSECUTIVE positions, one block exponent —
+// at bits 16 kk of word fh.  interleave == 0 (gemm_apx_lds_kernel): the words as they are.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_panel(const uint64_t *__restrict__ Mbits, int64_t KW, const int32_t *__restrict__ rowlist,
-                                                    int Rpad, int M2, uint64_t *__restrict__ panel) {
+                                                    int Rpad, int M2, uint64_t *__restrict__ panel, int interleave) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     const int r = blockIdx.x * 64 + (threadIdx.x & 63);
     if (r >= Rpad) return;
     const u64x2 *src = reinterpret_cast<const u64x2 *>(Mbits + (int64_t)rowlist[r] * KW);
     u64x2 *dst = reinterpret_cast<u64x2 *>(panel);
-    for (int m = threadIdx.x >> 6; m < M2; m += 4) dst[(int64_t)m * Rpad + r] = src[m];
+    for (int m = threadIdx.x >> 6; m < M2; m += 4) {
+        u64x2 v = src[m];
+        if (interleave) {
+            const unsigned long long x = v[0], y = v[1];
+            // groups of x: g0 g1 g2 g3 (16 bits each, g0 lowest), of y: g4 g5 g6 g7
+            const unsigned long long ex = (x & 0xFFFFull) | ((x >> 16) & 0xFFFF0000ull) | ((y & 0xFFFFull) << 32) | ((y << 16) & 0xFFFF000000000000ull);
+            const unsigned long long ox = ((x >> 16) & 0xFFFFull) | ((x >> 32) & 0xFFFF0000ull) | (((y >> 16) & 0xFFFFull) << 32) | (y & 0xFFFF000000000000ull);
+            v[0] = ex;   // g0 g2 g4 g6
+            v[1] = ox;   // g1 g3 g5 g7
+        }
+        dst[(int64_t)m * Rpad + r] = v;
+    }
+}
+
+static bool apx_kernel_is_lds() {
+    // "reg" (default): operands expanded in registers per wave; "lds": expansion shared through LDS (r03 experiment: correct, and
+    // 28 % slower — 0.659 vs 0.515 ms per C4 launch — because the fragment reads + table reads + tile writes make it LDS-bound)
+    static const bool lds = [] {
+        const char *e = getenv("LDW_APX_KERNEL");
+        return e && e[0] == 'l';
+    }();
+    return lds;
 }
 
 int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st) {
     hipLaunchKernelGGL(k_pack_panel, dim3((unsigned)((Rpad + 63) / 64)), dim3(256), 0, st, c->Mbits.as<uint64_t>(), c->KW, rowlist, Rpad,
-                       (int)(c->KW / 2), panel);
+                       (int)(c->KW / 2), panel, apx_kernel_is_lds() ? 0 : 1);
     LDW_HIP(hipGetLastError());
     return LDW_OK;
 }
@@ -298,20 +325,23 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
 #pragma unroll
             for (int i = 0; i < NT; ++i) nb[i] = pb[i][(int64_t)(m + 1) * stb];
         }
-        const int sh = P.shift[m];
-        if (sh) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = (int)((unsigned)acc[i][j][e] >> sh);
-        }
-        const uint8_t *dA = sA + m * 128 + fh * 64, *dB = sB + m * 128 + fh * 64;
+        const int4 sh4 = reinterpret_cast<const int4 *>(P.shift)[m];   // (wave-uniform: one scalar load per macro step)
+        const int shk[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+        // k-step kk = positions 128 m + 32 kk .. + 31 (k_pack_panel interleaves the panel words accordingly); lane half fh holds 16 of them
+        const uint8_t *dA = sA + m * 128 + fh * 16, *dB = sB + m * 128 + fh * 16;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const v4i da = *reinterpret_cast<const v4i *>(dA + 16 * kk);
-            const v4i db = *reinterpret_cast<const v4i *>(dB + 16 * kk);
+            const int sh = shk[kk];
+            if (sh) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] = (int)((unsigned)acc[i][j][e] >> sh);
+            }
+            const v4i da = *reinterpret_cast<const v4i *>(dA + 32 * kk);
+            const v4i db = *reinterpret_cast<const v4i *>(dB + 32 * kk);
             v4i fa[MT], fb[NT];
             typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -454,8 +484,8 @@ __global__ __launch_bounds__(512, 1) void gemm_apx_lds_kernel(ApxGemmArgs P) {
     for (int m = 0; m < P.M2; ++m) {
         if (erow_ok && m + 2 < P.M2) wfar = *reinterpret_cast<const u64x2v *>(prow + (int64_t)(m + 2) * pst);
         // ---- chunk 2m (buffer 0); chunk 2m + 1 is expanded into buffer 1 meanwhile ----
-        {
-            const int sh = P.shift[m];
+        const int4 sh4 = reinterpret_cast<const int4 *>(P.shift)[m];   // one exponent per k-step of 32 positions
+        auto rescale = [&](int sh) {
             if (sh && wave_live) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -464,16 +494,20 @@ __global__ __launch_bounds__(512, 1) void gemm_apx_lds_kernel(ApxGemmArgs P) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) acc[i][j][e] = (int)((unsigned)acc[i][j][e] >> sh);
             }
-        }
+        };
         exp_issue(wcur[1], 2 * m + 1);
+        rescale(sh4.x);
         if (wave_live) kstep(tile0, 0);
         exp_finish(wdst + 32768);
+        rescale(sh4.y);
         if (wave_live) kstep(tile0, 1);
         __syncthreads();
         // ---- chunk 2m + 1 (buffer 1); the first chunk of the next macro step goes into buffer 0 ----
         if (m + 1 < P.M2) exp_issue(wnext[0], 2 * m + 2);
+        rescale(sh4.z);
         if (wave_live) kstep(tile0 + 32768, 0);
         if (m + 1 < P.M2) exp_finish(wdst);
+        rescale(sh4.w);
         if (wave_live) kstep(tile0 + 32768, 1);
         __syncthreads();
         wcur = wnext;
@@ -493,12 +527,7 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
         const char *e = getenv("LDW_APX_TILE");   // tuning: wave tile in MFMA tiles, to side x from side (default 4 x 2)
         return e ? atoi(e) : 42;
     }();
-    static const int kern = [] {
-        // "reg" (default): operands expanded in registers per wave; "lds": expansion shared through LDS (r03 experiment: correct, and
-        // 28 % slower — 0.659 vs 0.515 ms per C4 launch — because the fragment reads + table reads + tile writes make it LDS-bound)
-        const char *e = getenv("LDW_APX_KERNEL");
-        return (e && e[0] == 'l') ? 1 : 0;
-    }();
+    const int kern = apx_kernel_is_lds() ? 1 : 0;
     const size_t lds2 = 2048 + (size_t)P.M2 * 256 + 2 * 32768 + (P.fuse ? (size_t)P.tab_nb * P.tab_nb * 8 + 8 * 256 : 0);
     if (kern == 1 && lds2 <= 160 * 1024 && tile == 42) {
         static bool attr_set = false;

@@ -93,9 +93,9 @@ struct ldw_ctx {
     bool apx_ok = false;               // the weights allow the approximate path (precision and class structure)
     std::string apx_gate = "weights not set";   // "ok" or the gate that keeps the path off (ldw_path_report)
     ldw::DevBuf dig_a, dig_b;          // uint8 [Npad]
-    ldw::DevBuf apx_shift;             // int32 [KW / 2]: right shift of the accumulators before macro step m (128 positions)
+    ldw::DevBuf apx_shift;             // int32 [2 KW]: right shift of the accumulators before MFMA k-step k (32 positions)
     int apx_e_last = 0;                // accumulators end in units of 2^apx_e_last (fixed-point units of V)
-    int apx_transitions = 0;           // macro steps with a shift: each loses < 1 unit (of ITS exponent) of a joint sum
+    int apx_transitions = 0;           // k-steps with a shift: each loses < 1 unit (of ITS exponent) of a joint sum
     double apx_lost_units = 0;         // what that adds up to in units of 2^apx_e_last (< 2: the exponents ascend)
     double apx_delta = 0;              // max_p |V'_p - V_p| / V_p
     std::vector<int64_t> h_vapx;       // [Npad] by SEQUENCE: V'_s = a b 2^e (exact integer)

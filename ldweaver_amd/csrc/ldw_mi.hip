@@ -2499,6 +2499,60 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
     return LDW_OK;
 }
 
+// Cold start: a bucket guess for a block kind from a LATTICE SAMPLE of one of its blocks.  Every PROBE_STRIDE-th SNP of both sides
+// (about 2000 per side, spanning the whole block, so the sample has the block's own mix of distances) is run through the plain
+// path — full-limb GEMM of the sample's rows, fp64 MI of every sampled pair, histogram of the long-range ones, bucket pick — and the
+// bucket that holds the type-7 rank of the SAMPLE becomes the guess, minus a margin for the sampling noise (~400-800 pairs in the
+// tail: +-0.3 bucket) and for the block-to-block drift.  ~0.2 ms, nothing is emitted, no table or counter of the pass is touched.
+// Without it the first block of a pass (and of every rank of a multi-GPU pass) takes the non-speculative path — 5-limb GEMM of the
+// whole block, fp64 MI of all 1e8 pairs, radix sorts: 3x the time of a speculative block — and the next one cannot overlap it.
+// A guess that turns out too high costs what it always costs: the block is redone non-speculatively (spec_misses).
+constexpr int64_t PROBE_SIDE = 2048;          // sampled SNPs per side
+constexpr int64_t PROBE_MIN_PAIRS = 16000000; // smaller blocks are cheap enough without a guess
+constexpr int PROBE_MARGIN = 6;
+
+int probe_kind_guess(ldw_ctx *c, const int32_t *fi, int64_t nf, const int32_t *ti, int64_t nt, const ldw_mi_params *p, const SmallLayout &sl,
+                     int kind) {
+    const int64_t stride = std::max<int64_t>(1, std::max(nf, nt) / PROBE_SIDE);
+    std::vector<int32_t> sf, st;
+    for (int64_t k = 0; k < nf; k += stride) sf.push_back(fi[k]);
+    for (int64_t k = 0; k < nt; k += stride) st.push_back(ti[k]);
+    ldw_mi_params q = *p;
+    q.keep_sr = 0;
+    HostBlock hb;
+    if (int rc = prep_block(c, sf.data(), (int64_t)sf.size(), st.data(), (int64_t)st.size(), &q, 0, 0, hb)) return rc;
+    if (hb.n_lr_total < 100000) return LDW_OK;   // too few long-range pairs in the sample to say anything
+    if (int rc = c->dstage[0].reserve(hb.total)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->dstage[0].p, c->pin[0], hb.total, hipMemcpyHostToDevice, c->stream));
+    const char *d = c->dstage[0].as<char>();
+    auto I = [&](size_t off) { return reinterpret_cast<const int32_t *>(d + off); };
+    auto B = [&](size_t off) { return reinterpret_cast<const uint8_t *>(d + off); };
+    hb.D = DevPtrs{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm), I(hb.o_perm_t),
+                   I(hb.o_pos_f), I(hb.o_pos_t), B(hb.o_cls_f), B(hb.o_cls_t), I(hb.o_cmax),
+                   reinterpret_cast<const int64_t *>(d + hb.o_tbase), I(hb.o_tf), B(hb.o_band), hb.nf_tiles, hb.gen_t0, hb.gen_q0};
+    if (int rc = c->hist[0].reserve((size_t)NBINS * 8)) return rc;
+    if (int rc = make_emit_args(c, hb, &q, sl, -1)) return rc;
+    hb.E.write_dense = 0;   // nothing reads the sample's MI values: only the histogram of the long-range ones
+    LDW_HIP(hipMemsetAsync(c->hist[0].p, 0, (size_t)NBINS * 8, c->stream));
+    LDW_HIP(hipMemsetAsync(sl.pick[0], 0, sizeof(ldw::PickOut), c->stream));
+    if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, LDW_QUIRK_INTENDED, hb.E, c->ev, 3, &c->G, nullptr, c->hist[0].as<unsigned long long>()))
+        return rc;
+    hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, c->stream, c->hist[0].as<unsigned long long>(), p->lr_retain_links, p->lr_links_approx, -1,
+                       (long long)hb.n_lr_total, sl.pick[0], (const unsigned int *)nullptr, 0u);
+    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipMemcpyAsync(c->pin_pick[0], sl.pick[0], sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    const ldw::PickOut *hp = static_cast<const ldw::PickOut *>(c->pin_pick[0]);
+    if (hp->n > 0 && hp->B_true < NBINS) {
+        const int g = hp->B_true - PROBE_MARGIN;
+        c->spec_B_next[kind] = g > 0 ? g : 0;
+        c->spec_hist_n[kind] = 0;
+        ++c->probe_blocks;
+    }
+    LDW_HIP(hipMemsetAsync(sl.pick[0], 0, sizeof(ldw::PickOut), c->stream));
+    return LDW_OK;
+}
+
 // whether the next block can be submitted before the current one is finished: the fused path needs a bucket guess
 bool can_submit_early(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p) {
     if (!c->overlap) return false;
@@ -2752,6 +2806,22 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     // a millisecond of list building for a 10k x 10k block — while the GPU works, and only then waits for block b's pick.
     // (Preparing b+1 between submit_b(b) and submit_a(b+1), as the first version did, delivered the GEMM of b+1 to the GPU when
     // the chain of b was already over: the two streams never ran side by side.)
+    // cold start: a sampled guess for each block kind that has none yet (probe_kind_guess), taken from the first block of the kind
+    static const bool probe_on = getenv("LDW_NO_PROBE") == nullptr;
+    if (probe_on && !p->sr_only && c->engine == LDW_ENGINE_MFMA && !c->fused) {
+        bool done_kind[2] = {false, false};
+        for (int64_t b = 0; b < nblocks && !(done_kind[0] && done_kind[1]); ++b) {
+            const bool diag = blocks[b * 4 + 0] == blocks[b * 4 + 2] && blocks[b * 4 + 1] == blocks[b * 4 + 3];
+            const int kind = diag ? 1 : 0;
+            if (done_kind[kind]) continue;
+            done_kind[kind] = true;
+            if (c->spec_B_next[kind] >= 0) continue;
+            if (int rc = fill(b)) return rc;
+            const int64_t npairs = diag ? (int64_t)fi.size() * ((int64_t)fi.size() - 1) / 2 : (int64_t)fi.size() * (int64_t)ti.size();
+            if (npairs < PROBE_MIN_PAIRS) continue;
+            if (int rc = probe_kind_guess(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, sl, kind)) return rc;
+        }
+    }
     HostBlock hb[3];
     static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
     double th[5] = {0, 0, 0, 0, 0};

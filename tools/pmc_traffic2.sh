@@ -21,11 +21,17 @@ WIDE = ("gemm_bits_kernel", "gemm_lo_units_kernel", "gemm_mi_fused_kernel")   # 
 res = {}
 for k, d in sorted(agg.items()):
     f = sum(d["FETCH_SIZE"]) / max(1, len(d["FETCH_SIZE"])); w = sum(d["WRITE_SIZE"]) / max(1, len(d["WRITE_SIZE"]))
+    raw, dbl = (f + w) * 1024, (2 * f + w) * 1024
+    wide = k.startswith(WIDE)
+    # `hbm_bytes_per_launch`: the guide's gfx950 correction applied (FETCH_SIZE x 2: it tallies 128-B requests at 64 B for wide coalesced
+    # reads).  For kernels whose reads are narrower than 16 B per lane the correction is uncalibrated: the doubled figure is then an UPPER
+    # bound and the range [raw, doubled] is what the counters support.
     e = dict(launches=len(d["FETCH_SIZE"]), FETCH_SIZE_KB_mean_per_launch=f, WRITE_SIZE_KB_mean_per_launch=w,
-             hbm_bytes_per_launch_uncorrected=(f + w) * 1024, hbm_bytes_per_launch_fetch_doubled=(2 * f + w) * 1024)
-    e["hbm_bytes_per_launch_corrected"] = e["hbm_bytes_per_launch_fetch_doubled"] if k.startswith(WIDE) else e["hbm_bytes_per_launch_uncorrected"]
-    e["correction"] = ("FETCH_SIZE x 2 (16-B-per-lane coalesced reads, gfx950 rule of the guide)" if k.startswith(WIDE) else
-                       "none: narrower / gathered reads are uncalibrated on gfx950 — the true read bytes lie between the uncorrected and the fetch-doubled figure")
+             hbm_bytes_per_launch=dbl, hbm_bytes_per_launch_range=[raw, dbl],
+             calibrated=bool(wide),
+             note=("16-B-per-lane coalesced reads: FETCH_SIZE x 2 is the guide's calibrated correction" if wide else
+                   "reads narrower than 16 B per lane / gathered: uncalibrated on gfx950 — true bytes lie in hbm_bytes_per_launch_range; "
+                   "hbm_bytes_per_launch is its upper end"))
     res[k] = e
 res["_how"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE (one pass) and --pmc WRITE_SIZE (another pass) -- python3 bench.py --no-cpu-baseline "
                "--no-extra-legs " + sys.argv[2] + "; means over all launches of each kernel (warm-up, timed and replay steps alike)")
