@@ -206,7 +206,8 @@ int ldw_reset_speculation(ldw_ctx *ctx);
  * (5-limb GEMM + fp64 MI of every pair: blocks without a bucket guess and every block when neither fast path applies),
  * out[3] through the fused kernel, out[4] speculation misses (blocks redone non-speculatively), out[5] blocks whose guess came from
  * the sampled probe of the block itself (cold starts), out[6] pairs listed for exact evaluation, out[7] units listed.
- * gate (capacity bytes, may be NULL) receives a short text: "ok" or which gate keeps the approximate path off
+ * gate (capacity bytes, may be NULL) receives a short text: "ok" ("ok (block exponents per 32 positions)" when the weights'
+ * dynamic range needs the finer exponents) or which gate keeps the approximate path off
  * ("delta 5.1e-03 > 4e-03", "Npad 40960 > 30720", "popcount segment tables 70000 B > 60000 B of LDS", "weights not set"). */
 int ldw_path_report(ldw_ctx *ctx, int64_t out[8], char *gate, int capacity);
 /* diagnostics of the approximate path after ldw_set_weights: out[0] = usable (0/1), out[1] = max relative error delta of the

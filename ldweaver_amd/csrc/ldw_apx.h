@@ -33,6 +33,7 @@ struct ApxGemmArgs {
     const int32_t *shift;                // [4 M2]: right shift before k-step k (32 positions)
     int32_t *G;                          // [RTpad][RFpad]
     int lower_only;
+    int fine;                            // exponents per k-step (panels interleaved by k_pack_panel) instead of per macro step
     // Threshold-table test in the epilogue (long-range-only blocks): bin_t / bin_f give every row of the two row lists its bin of
     // the 64 x 64 table `tab` (255: not a biallelic r = 2 SNP's row).  A region of 32 to-rows x 64 from-rows in which every
     // entry n' satisfies Lq < n' < Hq — what the screen would find for every one of its 2048 pairs — is flagged in

@@ -59,32 +59,49 @@ int prepare_apx_weights(ldw_ctx *c) {
     // step is mapped below the sparse region
     const int S4 = 4 * M2;
     std::vector<int32_t> em((size_t)S4, 0), sh((size_t)S4, 0);
-    int e_prev = 0, transitions = 0;
-    for (int k = 0; k < S4; ++k) {
-        int64_t vmax = 0;
-        for (int q = 0; q < 32; ++q) vmax = std::max(vmax, Vp[(size_t)k * 32 + q]);
-        int e = e_prev;
-        while (e < 62 && ((vmax + ((int64_t)1 << e) - 1) >> e) > APX_PROD_CAP) ++e;
-        em[(size_t)k] = e;
-        if (k > 0 && e > e_prev) {
-            sh[(size_t)k] = std::min(e - e_prev, 31);
-            ++transitions;
-        }
-        e_prev = e;
-    }
     std::vector<uint8_t> da((size_t)Npad, 0), db((size_t)Npad, 0);
-    c->h_vapx.assign((size_t)Npad, 0);
     double delta = 0;
-    for (int64_t p = 0; p < N; ++p) {
-        const int64_t V = Vp[(size_t)p];
-        if (V <= 0) continue;
-        const int e = em[(size_t)(p / 32)];
-        const size_t k = PT.nearest(std::ldexp((double)V, -e));
-        da[(size_t)p] = PT.a[k];
-        db[(size_t)p] = PT.b[k];
-        const int64_t Va = (int64_t)PT.val[k] << e;
-        c->h_vapx[(size_t)c->h_seq_perm[(size_t)p]] = Va;
-        delta = std::max(delta, std::fabs((double)(Va - V)) / (double)V);
+    int transitions = 0;
+    // gran = 4: one exponent per macro step of 128 positions (the faster kernel variant); gran = 1: one per k-step.  The coarse form
+    // is kept whenever it is tight enough (delta <= 1.5e-3: the screen's margin grows with delta)
+    auto assign = [&](int gran) {
+        std::fill(sh.begin(), sh.end(), 0);
+        std::fill(da.begin(), da.end(), 0);
+        std::fill(db.begin(), db.end(), 0);
+        c->h_vapx.assign((size_t)Npad, 0);
+        int e_prev = 0;
+        transitions = 0;
+        for (int k0 = 0; k0 < S4; k0 += gran) {
+            int64_t vmax = 0;
+            for (int q = 0; q < 32 * gran; ++q) vmax = std::max(vmax, Vp[(size_t)k0 * 32 + q]);
+            int e = e_prev;
+            while (e < 62 && ((vmax + ((int64_t)1 << e) - 1) >> e) > APX_PROD_CAP) ++e;
+            for (int k = k0; k < k0 + gran; ++k) em[(size_t)k] = e;
+            if (k0 > 0 && e > e_prev) {
+                sh[(size_t)k0] = std::min(e - e_prev, 31);
+                ++transitions;
+            }
+            e_prev = e;
+        }
+        delta = 0;
+        for (int64_t p = 0; p < N; ++p) {
+            const int64_t V = Vp[(size_t)p];
+            if (V <= 0) continue;
+            const int e = em[(size_t)(p / 32)];
+            const size_t k = PT.nearest(std::ldexp((double)V, -e));
+            da[(size_t)p] = PT.a[k];
+            db[(size_t)p] = PT.b[k];
+            const int64_t Va = (int64_t)PT.val[k] << e;
+            c->h_vapx[(size_t)c->h_seq_perm[(size_t)p]] = Va;
+            delta = std::max(delta, std::fabs((double)(Va - V)) / (double)V);
+        }
+    };
+    static const int force_gran = [] { const char *e = getenv("LDW_APX_GRAN"); return e ? atoi(e) : 0; }();   // 1 / 4: force fine / coarse (A/B)
+    assign(force_gran == 1 ? 1 : 4);
+    c->apx_fine = force_gran == 1;
+    if (force_gran == 0 && delta > 1.5e-3) {
+        assign(1);
+        c->apx_fine = true;
     }
     c->apx_delta = delta;
     c->apx_e_last = S4 > 0 ? em[(size_t)S4 - 1] : 0;
@@ -139,7 +156,7 @@ int prepare_apx_weights(ldw_ctx *c) {
     c->apx_ok = delta <= 4e-3 && Npad <= 30720 && M2 > 0 && seg_bytes <= 60000;
     {
         char why[160];
-        if (c->apx_ok) snprintf(why, sizeof(why), "ok");
+        if (c->apx_ok) snprintf(why, sizeof(why), c->apx_fine ? "ok (block exponents per 32 positions)" : "ok");
         else if (!(delta <= 4e-3)) snprintf(why, sizeof(why), "delta %.3g > 4e-03 (dual-digit weights too coarse)", delta);
         else if (Npad > 30720) snprintf(why, sizeof(why), "Npad %lld > 30720 (digit arrays exceed the GEMM's LDS)", (long long)Npad);
         else if (M2 <= 0) snprintf(why, sizeof(why), "no macro step (Npad %lld)", (long long)Npad);
@@ -189,7 +206,7 @@ static bool apx_kernel_is_lds() {
 
 int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st) {
     hipLaunchKernelGGL(k_pack_panel, dim3((unsigned)((Rpad + 63) / 64)), dim3(256), 0, st, c->Mbits.as<uint64_t>(), c->KW, rowlist, Rpad,
-                       (int)(c->KW / 2), panel, apx_kernel_is_lds() ? 0 : 1);
+                       (int)(c->KW / 2), panel, (c->apx_fine && !apx_kernel_is_lds()) ? 1 : 0);
     LDW_HIP(hipGetLastError());
     return LDW_OK;
 }
@@ -269,7 +286,7 @@ __device__ __forceinline__ void apx_gemm_epilogue(const ApxGemmArgs &P, v16i (&a
     }
 }
 
-template <int MT, int NT>
+template <int MT, int NT, bool FINE>
 __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint64_t *lutFF = reinterpret_cast<uint64_t *>(smem);           // [256]: byte of bits -> 8 bytes of 0xFF / 0x00
@@ -325,14 +342,16 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
 #pragma unroll
             for (int i = 0; i < NT; ++i) nb[i] = pb[i][(int64_t)(m + 1) * stb];
         }
+        // FINE: one block exponent per k-step; k-step kk = positions 128 m + 32 kk .. + 31 (k_pack_panel interleaves the panel words
+        // accordingly), lane half fh holds 16 of them.  Coarse (the weights' dynamic range within 128 positions is small: clonal
+        // data): one exponent per macro step, k-step kk = bits 16 kk of the plain words 0 and 1 — 4 % faster (0.517 vs 0.538 ms).
         const int4 sh4 = reinterpret_cast<const int4 *>(P.shift)[m];   // (wave-uniform: one scalar load per macro step)
         const int shk[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
-        // k-step kk = positions 128 m + 32 kk .. + 31 (k_pack_panel interleaves the panel words accordingly); lane half fh holds 16 of them
-        const uint8_t *dA = sA + m * 128 + fh * 16, *dB = sB + m * 128 + fh * 16;
+        const uint8_t *dA = sA + m * 128 + fh * (FINE ? 16 : 64), *dB = sB + m * 128 + fh * (FINE ? 16 : 64);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int sh = shk[kk];
-            if (sh) {
+            if ((FINE || kk == 0) && sh) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -340,8 +359,8 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) acc[i][j][e] = (int)((unsigned)acc[i][j][e] >> sh);
             }
-            const v4i da = *reinterpret_cast<const v4i *>(dA + 32 * kk);
-            const v4i db = *reinterpret_cast<const v4i *>(dB + 32 * kk);
+            const v4i da = *reinterpret_cast<const v4i *>(dA + (FINE ? 32 : 16) * kk);
+            const v4i db = *reinterpret_cast<const v4i *>(dB + (FINE ? 32 : 16) * kk);
             v4i fa[MT], fb[NT];
             typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -551,7 +570,8 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
 #define LDW_APX_LAUNCH(MTv, NTv)                                                                                              \
     {                                                                                                                         \
         const int ntx = P.RFpad / (32 * NTv), nty = P.RTpad / (32 * MTv);                                                     \
-        hipLaunchKernelGGL((gemm_apx_kernel<MTv, NTv>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P); \
+        if (P.fine) hipLaunchKernelGGL((gemm_apx_kernel<MTv, NTv, true>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P); \
+        else hipLaunchKernelGGL((gemm_apx_kernel<MTv, NTv, false>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P); \
     }
     if (tile == 22 && !P.fuse) LDW_APX_LAUNCH(2, 2)          // (the table epilogue assumes 64 from-rows per wave: NT = 2)
     else if (tile == 24 && !P.fuse) LDW_APX_LAUNCH(2, 4)

@@ -91,6 +91,7 @@ struct ldw_ctx {
     int path_mode = 0;                 // ldw_set_path: 0 auto, 1 mixed/plain path, 2 force the approximate path
     int select_mode = 0;               // ldw_set_select: 0 auto (sort-free selection where it applies), 1 always the two radix sorts
     bool apx_ok = false;               // the weights allow the approximate path (precision and class structure)
+    bool apx_fine = false;             // block exponents per MFMA k-step (32 positions) instead of per macro step (128): weights with a large dynamic range
     std::string apx_gate = "weights not set";   // "ok" or the gate that keeps the path off (ldw_path_report)
     ldw::DevBuf dig_a, dig_b;          // uint8 [Npad]
     ldw::DevBuf apx_shift;             // int32 [2 KW]: right shift of the accumulators before MFMA k-step k (32 positions)

@@ -1744,6 +1744,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             P.dig_a = c->dig_a.as<uint8_t>();
             P.dig_b = c->dig_b.as<uint8_t>();
             P.shift = c->apx_shift.as<int32_t>();
+            P.fine = c->apx_fine ? 1 : 0;
             P.G = c->Gapx[s].as<int32_t>();
             P.lower_only = E.lower_only;
             if (fuse) {

@@ -291,7 +291,7 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
     finally:
         if own:
             eng.close()
-    if path_report["apx_gate"] != "ok" and not perform_SR_analysis_only:
+    if not path_report["apx_gate"].startswith("ok") and not perform_SR_analysis_only:
         say(f"note: the approximate-GEMM path is off for these weights ({path_report['apx_gate']}); limb paths used")
     for bi in range(len(stats["n_sr"])):
         say(f"Block {bi + 1} of {len(blocks)} ... Adding {stats['n_lr_kept'][bi]} LR links with MI>"

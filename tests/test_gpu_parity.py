@@ -1022,7 +1022,7 @@ def test_616_distinct_weights_take_the_approximate_path(engine):
     _setup(engine, d)
     info = engine.apx_info()
     rep0 = engine.path_report()
-    assert info["usable"] and rep0["apx_gate"] == "ok" and info["classes"] >= 600, (info, rep0)
+    assert info["usable"] and rep0["apx_gate"] == "ok (block exponents per 32 positions)" and info["classes"] >= 600, (info, rep0)
     approx = MIH.lr_links_approx(syn["POS"], float(syn["g"]), 20000.0)
     blocks = MIH.make_blocks(24000, 8000)           # 6 block pairs, 3 diagonal
     out = {}
@@ -1048,7 +1048,7 @@ def test_616_distinct_weights_take_the_approximate_path(engine):
     assert len(out["plain"][1][2]) > 1000
     # a gate that fails is named: 40960 sequences exceed the digit arrays' LDS budget -> limb paths, same API
     rep = engine.path_report()
-    assert rep["apx_gate"] == "ok" and rep["pairs_listed"] > 0
+    assert rep["apx_gate"].startswith("ok") and rep["pairs_listed"] > 0 and info["delta"] <= 4e-3
 
 
 @pytest.mark.parametrize("Ns,weights", [(1000, "classes"), (616, "distinct"), (333, "unit")])

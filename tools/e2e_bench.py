@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Whole job on ONE GPU, stage by stage: synthetic alignment (resident) -> Hamming weights -> all-pairs MI with
-link selection -> short-range model (quantiles, excess statistics, p-values) -> ARACNE -> kept links on the host.
+link selection (a COLD pass: ldw_reset_speculation before every repetition, as a job runs it) -> lr_links.tsv by the native writer ->
+short-range model (quantiles, excess statistics, p-values) -> ARACNE -> kept links on the host.
 Prints one JSON line; `--out` also writes it to a file (profiles/).
 
     python tools/e2e_bench.py --L 100000 --N 5000           # BASELINE config 4 shape
@@ -62,8 +63,11 @@ def main():
         eng.set_snp_meta(uqe.sum(1), uqe, POS, paint, g)
         approx = lr_links_approx(POS, g, a.sr_dist)
         st.lap("setup_and_lr_approx_ms")
+        eng.reset_speculation()
         eng.mi_all_pairs(blocks, a.sr_dist, 1e6, approx)
         st.lap("mi_all_pairs_ms")
+        lr_rows, lr_bytes = eng.write_links_tsv(1, "/tmp/ldw_e2e_lr_links.tsv", append=False)
+        st.lap("lr_tsv_write_ms")
         n_sr, n_lr = eng.links_count(0), eng.links_count(1)
         qlo, qhi, cn = eng.sr_len_quantiles(3, a.sr_dist, 0.95)
         st.lap("sr_len_quantiles_ms")
@@ -102,7 +106,7 @@ def main():
                    total_ms=round(sum(st.out.values()), 3), mi_pairs_per_s=pairs / (st.out["mi_all_pairs_ms"] * 1e-3),
                    sr_model_rows_per_s=n_sr / max(1e-9, (st.out["sr_len_quantiles_ms"] + st.out["sr_excess_stats_ms"] + st.out["sr_pvalues_ms"]) * 1e-3),
                    beta_shapes=shape[:, :2].round(6).tolist(), hbm_peak_GB=round(torch.cuda.max_memory_allocated() / 1e9, 2),
-                   spec_misses=eng.counters()["spec_misses"])
+                   lr_tsv_rows=lr_rows, lr_tsv_bytes=lr_bytes, path=eng.path_report())
     line = json.dumps(res)
     print(line)
     if a.out:
