@@ -2333,7 +2333,7 @@ int submit_b(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr)) return rc;
     if (int rc = c->hist[s].reserve((size_t)NBINS * 8)) return rc;
     if (!hb.apx) LDW_HIP(hipMemsetAsync(c->hist[s].p, 0, (size_t)NBINS * 8, c->stream));   // (the approximate path zeroed both in its first phase: k_zero4)
-    if (int rc = make_emit_args(c, hb, p, sl, (hb.mixed || hb.apx) ? (do_lr ? hb.guess : -1) : ((do_lr && c->engine == LDW_ENGINE_MFMA) ? c->spec_B_next[hb.diag ? 1 : 0] : -1)))
+    if (int rc = make_emit_args(c, hb, p, sl, (hb.mixed || hb.apx) ? (do_lr ? hb.guess : -1) : ((do_lr && c->engine != LDW_ENGINE_HIST_STATES) ? c->spec_B_next[hb.diag ? 1 : 0] : -1)))   // (the bit-plane histogram engine shares the epilogue: it speculates like the MFMA engine)
         return rc;
     if (!hb.apx) LDW_HIP(hipMemsetAsync(sl.pick[s], 0, sizeof(ldw::PickOut), c->stream));
     hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
@@ -2809,7 +2809,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     // the chain of b was already over: the two streams never ran side by side.)
     // cold start: a sampled guess for each block kind that has none yet (probe_kind_guess), taken from the first block of the kind
     static const bool probe_on = getenv("LDW_NO_PROBE") == nullptr;
-    if (probe_on && !p->sr_only && c->engine == LDW_ENGINE_MFMA && !c->fused) {
+    if (probe_on && !p->sr_only && c->engine != LDW_ENGINE_HIST_STATES && !c->fused) {
         bool done_kind[2] = {false, false};
         for (int64_t b = 0; b < nblocks && !(done_kind[0] && done_kind[1]); ++b) {
             const bool diag = blocks[b * 4 + 0] == blocks[b * 4 + 2] && blocks[b * 4 + 1] == blocks[b * 4 + 3];
