@@ -47,12 +47,17 @@ perform_MI_computation <- function(snp.dat, hdw, cds_var, ncores, lr_save_path =
   res <- .Call("ldwamd_mi_all_pairs", as.integer(t(as.matrix(MI_cmp_blks))), sr_dist, lr_retain_links, lr_links_approx,
                perform_SR_analysis_only, 0L)
   to_df <- function(t) {
-    pos2 <- as.numeric(snp.dat$POS[t[[1]] + 1]); pos1 <- as.numeric(snp.dat$POS[t[[2]] + 1])
+    # POS keeps its type (an INTEGER vector in the reference, src/getACGTNsites.cpp:97,173: pos1 / pos2 print as integers)
+    pos2 <- snp.dat$POS[t[[1]] + 1]; pos1 <- snp.dat$POS[t[[2]] + 1]
     data.frame(pos1 = pos1, pos2 = pos2, clust1 = cds_var$paint[t[[2]] + 1], clust2 = cds_var$paint[t[[1]] + 1],
                len = 0.5 * snp.dat$g - abs((pos1 - pos2) %% snp.dat$g - 0.5 * snp.dat$g), MI = t[[3]])
   }
-  if (!perform_SR_analysis_only && length(res[[2]][[3]]) > 0)
-    write.table(to_df(res[[2]]), file = lr_save_path, append = T, quote = F, row.names = F, col.names = F, sep = "\t")
+  # lr_links.tsv (:362): options(ldwamd.native_tsv = TRUE) writes it from the device table with the library's threaded writer
+  # (same bytes as write.table, 1e6 rows in ~0.3 s instead of seconds); the default is R's own write.table
+  if (!perform_SR_analysis_only && length(res[[2]][[3]]) > 0) {
+    if (isTRUE(getOption("ldwamd.native_tsv", FALSE))) .Call("ldwamd_write_links_tsv", 1L, lr_save_path)
+    else write.table(to_df(res[[2]]), file = lr_save_path, append = T, quote = F, row.names = F, col.names = F, sep = "\t")
+  }
   sr <- to_df(res[[1]])
   sr_links <- lapply(1:cds_var$nclust, function(i) sr[sr$clust1 == i | sr$clust2 == i, ])
   sr_links_all <- mergeNsort_sr_links(cds_var = cds_var, sr_links = sr_links, sr_dist = sr_dist, plt_path = plt_folder,
@@ -99,7 +104,7 @@ mergeNsort_sr_links_device <- function(snp.dat, cds_var, sr_dist, srp_cutoff, ru
     c(p, lbeta(p[1], p[2]))
   }))
   r <- .Call("ldwamd_sr_pvalues_aracne", as.integer(nclust), as.numeric(t(md)), as.numeric(t(shape)), srp_cutoff, runARACNE)
-  pos2 <- as.numeric(snp.dat$POS[r[[2]] + 1]); pos1 <- as.numeric(snp.dat$POS[r[[3]] + 1])
+  pos2 <- snp.dat$POS[r[[2]] + 1]; pos1 <- snp.dat$POS[r[[3]] + 1]   # (integer like the reference's MI_df columns)
   df <- data.frame(clust_c = r[[5]], pos1 = pos1, pos2 = pos2, clust1 = cds_var$paint[r[[3]] + 1], clust2 = cds_var$paint[r[[2]] + 1],
                    len = 0.5 * snp.dat$g - abs((pos1 - pos2) %% snp.dat$g - 0.5 * snp.dat$g), MI = r[[4]], srp_max = r[[8]],
                    ARACNE = r[[9]])
@@ -114,7 +119,7 @@ analyse_long_range_links_device <- function(snp.dat, cds_var, sr_links, are_lrli
   if (anyNA(ia) || anyNA(ib)) stop("sr_links holds positions that are not in snp.dat$POS")   # NA_integer_ must not reach the device as an index
   r <- .Call("ldwamd_lr_tukey_aracne", 5000, as.integer(ia - 1L), as.integer(ib - 1L), as.numeric(sr_links$MI))
   if (r[[8]]) warning("Not enough lr links pass the Tukey criteria, ~5000 top links were retained instead")
-  pos2 <- as.numeric(snp.dat$POS[r[[2]] + 1]); pos1 <- as.numeric(snp.dat$POS[r[[3]] + 1])
+  pos2 <- snp.dat$POS[r[[2]] + 1]; pos1 <- snp.dat$POS[r[[3]] + 1]   # (integer like the reference's MI_df columns)
   df <- data.frame(pos1 = pos1, pos2 = pos2, clust1 = cds_var$paint[r[[3]] + 1], clust2 = cds_var$paint[r[[2]] + 1],
                    len = 0.5 * snp.dat$g - abs((pos1 - pos2) %% snp.dat$g - 0.5 * snp.dat$g), MI = r[[4]], ARACNE = r[[5]])
   if (!are_lrlinks_ordered) { df <- df[order(df$MI, decreasing = T), ]; rownames(df) <- NULL }

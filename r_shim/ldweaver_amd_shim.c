@@ -269,6 +269,34 @@ SEXP _LDWeaver_fast_intersect(SEXP A, SEXP B) {
     return out;
 }
 
+/* lr_links.tsv / raw sr rows straight from the device-resident table by the library's threaded writer: the bytes write.table(x, file,
+ * append = T, quote = F, row.names = F, col.names = F, sep = '\t') produces for the same rows (R/computePairwiseMI.R:362).  which: 0 sr, 1 lr.
+ * Returns the number of rows written. */
+SEXP ldwamd_write_links_tsv(SEXP which, SEXP path) {
+    int64_t rows = 0, bytes = 0;
+    CHK(ldw_write_links_tsv(ctx_or_stop(), asInteger(which), CHAR(STRING_ELT(path, 0)), 1, 0, &rows, &bytes));
+    return ScalarReal((double)rows);
+}
+
+/* any numeric data.frame's columns (INTSXP / REALSXP / LGLSXP-as-int) by the same writer; cols: a list of equally long vectors */
+SEXP ldwamd_write_table_tsv(SEXP cols, SEXP path) {
+    const int nc = (int)XLENGTH(cols);
+    if (nc <= 0 || nc > 64) error("ldweaver_amd: 1..64 columns expected");
+    const void *ptr[64];
+    int32_t kind[64];
+    const R_xlen_t n = XLENGTH(VECTOR_ELT(cols, 0));
+    for (int k = 0; k < nc; ++k) {
+        SEXP v = VECTOR_ELT(cols, k);
+        if (XLENGTH(v) != n) error("ldweaver_amd: columns of different lengths");
+        if (TYPEOF(v) == REALSXP) { kind[k] = LDW_COL_DOUBLE; ptr[k] = REAL(v); }
+        else if (TYPEOF(v) == INTSXP) { kind[k] = LDW_COL_INT32; ptr[k] = INTEGER(v); }   /* (NA_integer_ is not handled: the link frames hold none) */
+        else error("ldweaver_amd: column %d is neither integer nor double", k + 1);
+    }
+    int64_t bytes = 0;
+    CHK(ldw_write_table_tsv(CHAR(STRING_ELT(path, 0)), 1, (int64_t)n, nc, kind, ptr, 0, &bytes));
+    return ScalarReal((double)bytes);
+}
+
 static const R_CallMethodDef CallEntries[] = {
     {"_LDWeaver_ACGTN2num", (DL_FUNC)&_LDWeaver_ACGTN2num, 3},
     {"_LDWeaver_fastHadamard", (DL_FUNC)&_LDWeaver_fastHadamard, 9},
@@ -288,6 +316,8 @@ static const R_CallMethodDef CallEntries[] = {
     {"ldwamd_set_snp_meta", (DL_FUNC)&ldwamd_set_snp_meta, 5},
     {"ldwamd_mi_all_pairs", (DL_FUNC)&ldwamd_mi_all_pairs, 6},
     {"ldwamd_aracne", (DL_FUNC)&ldwamd_aracne, 6},
+    {"ldwamd_write_links_tsv", (DL_FUNC)&ldwamd_write_links_tsv, 2},
+    {"ldwamd_write_table_tsv", (DL_FUNC)&ldwamd_write_table_tsv, 2},
     {NULL, NULL, 0}};
 
 void R_init_ldweaver_amd_shim(DllInfo *dll) {
