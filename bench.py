@@ -392,8 +392,9 @@ def main():
             n_launch = gst["apx_launches"] + gst["bits_launches"]
             apx = gst["apx_launches"] >= gst["bits_launches"]
             mixed_blocks = cnt_replay.get("mixed_blocks", 0)
-            kname = "gemm_apx_kernel<4, 2>" if apx else (f"gemm_mi_fused_kernel<{J}>" if args.fused else
-                                                        f"gemm_bits_kernel<{3 if mixed_blocks else J}>")
+            fine = "per 32" in (path_report or {}).get("apx_gate", "")
+            apx_name = "gemm_apx_lds_kernel" if os.environ.get("LDW_APX_KERNEL", "r")[:1] == "l" else f"gemm_apx_kernel<4, 2, {'true' if fine else 'false'}>"
+            kname = apx_name if apx else (f"gemm_mi_fused_kernel<{J}>" if args.fused else f"gemm_bits_kernel<{3 if mixed_blocks else J}>")
             avg_ms = tim["gemm_ms"] / n_launch
             exec_per_launch = (gst["apx_ops"] + gst["bits_ops"]) / n_launch
             alg_per_launch = 50.0 * N * my_pairs * n_replay / n_launch      # 50 * N MAC-flops per pair

@@ -1651,15 +1651,15 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             // threshold table of the biallelic pairs, one per block kind (diagonal blocks sit ~8 % below the others): valid for every
             // block whose level is at least the level it was built for — a higher level only widens the true interval, i.e. the
             // table gets looser, and how tight it is decides how many regions the GEMM's epilogue finds clean — so it is rebuilt as
-            // soon as the block's level has left [tab_lo, 1.03 tab_lo] (one bucket = 0.5 %).  Phase 1 of every block runs in order
+            // soon as the block's level has left [tab_lo, 1.05 tab_lo] (one bucket = 0.5 %).  Phase 1 of every block runs in order
             // on ONE stream, so the rebuild cannot overtake a reader.
             const int kd = lo_h->diag ? 1 : 0;
             const double lo_blk = E.spec_lo - (double)E.scr_eps;
-            if (!(c->tab11_lo[kd] > 0) || lo_blk < c->tab11_lo[kd] || lo_blk > 1.03 * c->tab11_lo[kd]) {
+            if (!(c->tab11_lo[kd] > 0) || lo_blk < c->tab11_lo[kd] || lo_blk > 1.05 * c->tab11_lo[kd]) {
                 constexpr int NBINS_T = 64;
                 if (int rc = c->tab11[kd].reserve((size_t)NBINS_T * NBINS_T * 8)) return rc;
                 const double W = std::ldexp((double)c->total_fixed, -c->frac_bits);
-                c->tab11_lo[kd] = 0.99 * lo_blk;   // buckets are 0.5 % wide: the next blocks of the kind may guess two buckets lower without a rebuild
+                c->tab11_lo[kd] = 0.98 * lo_blk;   // buckets are 0.5 % wide: the next blocks of the kind may guess four buckets lower (six higher) without a rebuild (73 us)
                 c->tab11_c = (float)(NBINS_T / std::sqrt(W + 1.0));
                 c->tab11_nb = NBINS_T;
                 const double sprime = std::ldexp(1.0, c->apx_e_last - c->frac_bits);

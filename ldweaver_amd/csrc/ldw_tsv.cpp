@@ -7,10 +7,13 @@
 // value, in fixed notation unless that is wider than the scientific form (so 100000 prints as 1e+05 and 0.0001 as 1e-04).
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -149,52 +152,103 @@ struct Col {
     const void *data;
 };
 
+// default worker count: the machine's hardware threads, at most 16 (a container's CPU share is usually far below the host's count,
+// and the formatting saturates the file write well before that)
+int default_threads(int nthreads) {
+    if (nthreads > 0) return nthreads < 64 ? nthreads : 64;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int n = (int)(hw ? hw : 4);
+    return n < 16 ? n : 16;
+}
+
 int write_rows(const char *path, int append, int64_t nrows, const std::vector<Col> &cols, int nthreads, int64_t *bytes_out) {
     FILE *fh = fopen(path, append ? "ab" : "wb");
     LDW_REQUIRE(fh != nullptr, LDW_ERR_ARG, "cannot open %s: %s", path, strerror(errno));
     int64_t total = 0;
     int rc = LDW_OK;
     if (nrows > 0) {
-        unsigned hw = std::thread::hardware_concurrency();
-        int nt = nthreads > 0 ? nthreads : (int)(hw ? hw : 4);
-        nt = (int)std::min<int64_t>(std::min(nt, 64), (nrows + 16383) / 16384);
-        if (nt < 1) nt = 1;
-        // rounds of nt chunks: bounded memory, output in row order
-        const int64_t chunk = 1 << 16;
+        // nt workers are started ONCE (starting a thread in a process that has the HIP runtime loaded costs ~2 ms: one per chunk
+        // made the writer slower than a single thread) and walk the table in rounds of nt chunks of 8192 rows: worker t formats chunk
+        // r nt + t into buffer r & 1 of its own pair (allocated once, uninitialised), the calling thread appends the chunks of a
+        // round in row order while the workers are already formatting the next one.
+        const int64_t chunk = 1 << 13;
         const size_t row_max = cols.size() * 41 + 2;
-        std::vector<std::vector<char>> bufs((size_t)nt);
-        std::vector<size_t> used((size_t)nt, 0);
-        for (auto &b : bufs) b.resize((size_t)chunk * row_max);
-        for (int64_t r0 = 0; r0 < nrows && rc == LDW_OK; r0 += chunk * nt) {
-            auto work = [&](int t) {
-                const int64_t a = r0 + (int64_t)t * chunk, b = std::min(nrows, a + chunk);
-                char *p = bufs[(size_t)t].data();
-                for (int64_t i = a; i < b; ++i) {
-                    for (size_t k = 0; k < cols.size(); ++k) {
-                        if (k) *p++ = '\t';
-                        const Col &c = cols[k];
-                        if (c.kind == LDW_COL_DOUBLE) p = fmt_double(p, static_cast<const double *>(c.data)[i]);
-                        else if (c.kind == LDW_COL_INT32) p = fmt_int(p, static_cast<const int32_t *>(c.data)[i]);
-                        else p = fmt_int(p, static_cast<const int64_t *>(c.data)[i]);
-                    }
-                    *p++ = '\n';
+        const int64_t nchunks = (nrows + chunk - 1) / chunk;
+        int nt = default_threads(nthreads);
+        nt = (int)std::min<int64_t>(nt, nchunks);
+        if (nt < 1) nt = 1;
+        const int64_t rounds = (nchunks + nt - 1) / nt;
+        std::vector<std::unique_ptr<char[]>> bufs((size_t)nt * 2);
+        std::vector<size_t> used((size_t)nt * 2, 0);
+        for (auto &b : bufs) b.reset(new char[(size_t)chunk * row_max]);
+        std::mutex mu;
+        std::condition_variable cv;
+        int64_t flushed = 0;                              // rounds written to the file
+        std::vector<int64_t> done((size_t)nt, 0);         // rounds formatted by each worker
+        bool stop = false;
+        auto worker = [&](int t) {
+            for (int64_t r = 0; r < rounds; ++r) {
+                {   // buffer r & 1 was last used by round r - 2
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || flushed >= r - 1; });
+                    if (stop) return;
                 }
-                used[(size_t)t] = a < b ? (size_t)(p - bufs[(size_t)t].data()) : 0;
-            };
-            std::vector<std::thread> th;
-            for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-            work(0);
-            for (auto &x : th) x.join();
-            for (int t = 0; t < nt; ++t) {
-                if (!used[(size_t)t]) continue;
-                if (fwrite(bufs[(size_t)t].data(), 1, used[(size_t)t], fh) != used[(size_t)t]) {
+                const int64_t c = r * nt + t;
+                const size_t slot = (size_t)t * 2 + (size_t)(r & 1);
+                size_t u = 0;
+                if (c < nchunks) {
+                    const int64_t a = c * chunk, b = std::min(nrows, a + chunk);
+                    char *p = bufs[slot].get();
+                    for (int64_t i = a; i < b; ++i) {
+                        for (size_t k = 0; k < cols.size(); ++k) {
+                            if (k) *p++ = '\t';
+                            const Col &cl = cols[k];
+                            if (cl.kind == LDW_COL_DOUBLE) p = fmt_double(p, static_cast<const double *>(cl.data)[i]);
+                            else if (cl.kind == LDW_COL_INT32) p = fmt_int(p, static_cast<const int32_t *>(cl.data)[i]);
+                            else p = fmt_int(p, static_cast<const int64_t *>(cl.data)[i]);
+                        }
+                        *p++ = '\n';
+                    }
+                    u = (size_t)(p - bufs[slot].get());
+                }
+                std::lock_guard<std::mutex> lk(mu);
+                used[slot] = u;
+                done[(size_t)t] = r + 1;
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(worker, t);
+        for (int64_t r = 0; r < rounds; ++r) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] {
+                    for (int t = 0; t < nt; ++t)
+                        if (done[(size_t)t] < r + 1) return false;
+                    return true;
+                });
+            }
+            for (int t = 0; t < nt && rc == LDW_OK; ++t) {
+                const size_t slot = (size_t)t * 2 + (size_t)(r & 1), u = used[slot];
+                if (!u) continue;
+                if (fwrite(bufs[slot].get(), 1, u, fh) != u) {
                     ldw::set_error("short write to %s: %s", path, strerror(errno));
                     rc = LDW_ERR_ARG;
-                    break;
                 }
-                total += (int64_t)used[(size_t)t];
+                total += (int64_t)u;
             }
+            std::lock_guard<std::mutex> lk(mu);
+            flushed = r + 1;
+            if (rc != LDW_OK) stop = true;
+            cv.notify_all();
+            if (stop) break;
         }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc != LDW_OK) stop = true;
+            cv.notify_all();
+        }
+        for (auto &x : th) x.join();
     }
     if (fclose(fh) != 0 && rc == LDW_OK) {
         ldw::set_error("closing %s: %s", path, strerror(errno));
@@ -243,9 +297,8 @@ int ldw_write_links_tsv(ldw_ctx *c, int which, const char *path, int append, int
     if (int rc = ldw_links_fetch(c, which, a.data(), b.data(), mi.data(), n, 0)) return rc;
     const double g = c->g, hg = 0.5 * c->g;
     const int32_t *POS = c->h_POS.data(), *paint = c->h_paint.data();
-    unsigned hw = std::thread::hardware_concurrency();
-    int nt = nthreads > 0 ? nthreads : (int)(hw ? hw : 4);
-    nt = (int)std::min<int64_t>(std::min(nt, 64), (n + 65535) / 65536);
+    int nt = (int)std::min<int64_t>(default_threads(nthreads), (n + 65535) / 65536);
+    if (nt < 1) nt = 1;
     auto derive = [&](int t) {
         const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
         for (int64_t i = i0; i < i1; ++i) {

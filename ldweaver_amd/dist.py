@@ -59,11 +59,12 @@ def agree(ok: bool, group=None, what: str = "", force_collective=None) -> None:
         raise RuntimeError(f"{what or 'the computation'} failed on rank(s) {bad.tolist()} (this is rank {rank})")
 
 
-def block_cost(blocks: np.ndarray, diag_factor: float = 2.0) -> np.ndarray:
+def block_cost(blocks: np.ndarray, diag_factor: float = 3.3) -> np.ndarray:
     """Relative GPU time of the block pairs.  An off-diagonal pair costs its nf * nt pairs.  A diagonal pair has half the pairs
     (half the block-wide GEMM and screen) but holds the dense short-range band, whose units take the exact 5-limb GEMM of the
-    band's tiles (23 % of the tiles at C4) and the whole-unit fp64 kernel: measured on the C4 shape (rocprof, kernel-exclusive)
-    both kinds come to ~1.4 ms, i.e. ``diag_factor`` = 2 times a diagonal pair's own pair count."""
+    band's tiles and the whole-unit fp64 kernel: measured on the C4 shape (LDW_BLOCK_TRACE, r03: 1.40 ms per diagonal block against
+    0.85 ms per off-diagonal one, pass after pass) a diagonal pair costs 1.65 off-diagonal ones, i.e. ``diag_factor`` = 3.3 times
+    its own pair count (r02 assumed 2.0, which left the ranks holding two diagonal blocks ~1 ms late at N = 8)."""
     b = np.asarray(blocks, dtype=np.int64).reshape(-1, 4)
     nf, nt = b[:, 1] - b[:, 0] + 1, b[:, 3] - b[:, 2] + 1
     diag = (b[:, 0] == b[:, 2]) & (b[:, 1] == b[:, 3])

@@ -63,7 +63,7 @@ def test_make_blocks_and_deal():
     with pytest.raises(ValueError):
         MI.make_blocks(100, 0)
     cost = block_cost(b)
-    assert cost[0] == 10000 * 9999 and cost[1] == 10 ** 8      # a diagonal pair holds the dense short-range band
+    assert cost[0] == int(10000 * 9999 // 2 * 3.3) and cost[1] == 10 ** 8      # a diagonal pair holds the dense short-range band: 1.65 off-diagonal ones
     assert block_cost(b, diag_factor=1.0)[0] == 10000 * 9999 // 2
     for world in (1, 2, 4, 8):
         parts = deal_blocks(b, world)
