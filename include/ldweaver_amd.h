@@ -126,8 +126,9 @@ int ldw_hamming_counts(ldw_ctx *ctx, int32_t thresh, int32_t tile0, int32_t tile
  * like the reference's sqrt-scaled one-hots, quantised to nlimbs*8-bit fixed point (nlimbs in 1..6,
  * 0 = default 5; see DESIGN.md "fixed-point weights"). */
 int ldw_set_weights(ldw_ctx *ctx, const double *hdw, int64_t N, int nlimbs);
-/* r[L] (snp.dat$r), uqe[L][5] row-major 0/1 (snp.dat$uqe), POS[L] ascending, paint[L] (cds_var$paint),
- * g genome length (snp.dat$g). */
+/* r[L] (snp.dat$r), uqe[L][5] row-major 0/1 (snp.dat$uqe), POS[L] (snp.dat$POS: any order, like the reference — its own parser emits
+ * ascending positions, and blocks whose lists ascend take the fast paths; a block in another order runs the plain path and a
+ * predicate-based pair list), paint[L] (cds_var$paint), g genome length (snp.dat$g). */
 int ldw_set_snp_meta(ldw_ctx *ctx, const double *r, const uint8_t *uqe, const int32_t *POS,
                      const int32_t *paint, double g);
 int ldw_set_engine(ldw_ctx *ctx, int engine);

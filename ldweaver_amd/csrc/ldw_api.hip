@@ -353,7 +353,7 @@ int ldw_path_report(ldw_ctx *c, int64_t out[8], char *gate, int capacity) {
     LDW_REQUIRE(c && out, LDW_ERR_ARG, "ldw_path_report: null argument");
     out[0] = c->apx_blocks;
     out[1] = c->mixed_blocks;
-    out[2] = c->unfused_blocks - c->apx_blocks - c->mixed_blocks + c->spec_misses;
+    out[2] = c->unfused_blocks - c->apx_blocks - c->mixed_blocks + c->spec_misses + c->generic_blocks;   // (blocks in generic POS order always take the plain path)
     out[3] = c->fused_blocks;
     out[4] = c->spec_misses;
     out[5] = c->probe_blocks;
@@ -672,6 +672,8 @@ int ldw_set_snp_meta(ldw_ctx *c, const double *r, const uint8_t *uqe, const int3
     LDW_HIP(hipStreamSynchronize(c->stream));
     c->h_r.assign(r, r + L);
     c->h_POS.assign(POS, POS + L);
+    c->pos_sorted = true;
+    for (int64_t i = 1; i < L && c->pos_sorted; ++i) c->pos_sorted = POS[i] >= POS[i - 1];
     if (paint) c->h_paint.assign(paint, paint + L);
     else c->h_paint.assign((size_t)L, 0);
     c->paint_min = c->paint_max = 0;

@@ -115,7 +115,7 @@ struct ldw_ctx {
     ldw::DevBuf pairs[2];              // per pipeline slot: pair lists of the approximate screen (counters + PAIR_PATHS x PAIR_SHARDS lists)
     ldw::DevBuf apx_bins[2], apx_clean[2];    // per slot: threshold-table bin of every row of the two row lists; clean-region flags of the GEMM epilogue
     ldw::DevBuf apx_units[2], apx_packs[2];   // per slot: per-(tile, class) unit lists + counters; per-block SNP constants
-    int64_t apx_blocks = 0, apx_units_listed = 0, apx_pairs_listed = 0, probe_blocks = 0;
+    int64_t apx_blocks = 0, apx_units_listed = 0, apx_pairs_listed = 0, probe_blocks = 0, generic_blocks = 0;
 
     // ---- per-SNP meta ----
     bool have_meta = false;
@@ -124,6 +124,7 @@ struct ldw_ctx {
     std::vector<double> h_r;
     std::vector<int32_t> h_POS, h_paint;
     int32_t paint_min = 0, paint_max = 0;
+    bool pos_sorted = true;      // POS ascends over the whole alignment (the reference's parser emits it so; any order is accepted)
 
     // ---- row map (built lazily from alignment + weights + meta) ----
     bool rows_ready = false;

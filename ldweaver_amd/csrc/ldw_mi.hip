@@ -701,6 +701,90 @@ __global__ __launch_bounds__(256) void k_post_mi(EmitArgs E, const int32_t *__re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Blocks whose SNP lists are NOT ascending in POS (the reference imposes no order on snp.dat$POS: R/computePairwiseMI.R:176-177,
+// :306-333 work on whatever order the lists have).  The short-range partners of a column are then no index interval, so the
+// interval machinery (ColInfo, the band masks, the screens) does not apply: such a block runs the plain path — exact GEMM + fp64 MI
+// of every pair into the dense block — and these three kernels do the reference's pair list on it with the predicate itself
+// (len = circ_len(pos1, pos2) <= sr_dist per pair): counts per column, short-range rows to their final place (all upper rows
+// column-major, then all lower rows: R/computePairwiseMI.R:306-310), long-range histogram and candidate gather.  One wave per column.
+// ------------------------------------------------------------------------------------------------
+struct GenArgs {
+    const double *MI;            // dense block, column-major nf x nt
+    int nf, nt, lower_only, keep_sr, do_lr;
+    const int32_t *idx_f, *idx_t, *POS;
+    double g, sr_dist;
+};
+
+__device__ __forceinline__ bool gen_is_sr(const GenArgs &S, int a_loc, double pos1) {
+    return circ_len(pos1, (double)S.POS[S.idx_f[a_loc]], S.g) <= S.sr_dist;
+}
+
+__global__ __launch_bounds__(256) void k_gen_count(GenArgs S, int32_t *__restrict__ cnt_u, int32_t *__restrict__ cnt_l,
+                                                   unsigned long long *__restrict__ ghist) {
+    __shared__ unsigned int sh_hist[NBINS];
+    for (int i = threadIdx.x; i < NBINS; i += 256) sh_hist[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, b_loc = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b_loc < S.nt) {
+        const double pos1 = (double)S.POS[S.idx_t[b_loc]];
+        const double *col = S.MI + (int64_t)b_loc * S.nf;
+        int cu = 0, cl = 0;
+        for (int a_loc = lane; a_loc < S.nf; a_loc += 64) {
+            const int seg = pair_seg(a_loc, b_loc, S.lower_only);
+            if (seg < 0) continue;
+            if (gen_is_sr(S, a_loc, pos1)) {
+                cu += seg == 0;
+                cl += seg == 1;
+            } else if (S.do_lr) {
+                atomicAdd(&sh_hist[mi_bucket(col[a_loc])], 1u);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            cu += __shfl_xor(cu, off);
+            cl += __shfl_xor(cl, off);
+        }
+        if (lane == 0) {
+            cnt_u[b_loc] = cu;
+            cnt_l[b_loc] = cl;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NBINS; i += 256)
+        if (sh_hist[i]) atomicAdd(&ghist[i], (unsigned long long)sh_hist[i]);
+}
+
+// off_u / off_l: first row of the column's upper / lower short-range rows, relative to sr_base
+__global__ __launch_bounds__(256) void k_gen_emit_sr(GenArgs S, const int64_t *__restrict__ off_u, const int64_t *__restrict__ off_l, int64_t sr_base,
+                                                     int32_t *__restrict__ sr_a, int32_t *__restrict__ sr_b, double *__restrict__ sr_mi) {
+    const int lane = threadIdx.x & 63, b_loc = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b_loc >= S.nt) return;
+    const int sb = S.idx_t[b_loc];
+    const double pos1 = (double)S.POS[sb];
+    const double *col = S.MI + (int64_t)b_loc * S.nf;
+    int64_t ru = sr_base + off_u[b_loc], rl = sr_base + off_l[b_loc];
+    for (int a0 = 0; a0 < S.nf; a0 += 64) {
+        const int a_loc = a0 + lane;
+        int seg = -1;
+        bool sr = false;
+        if (a_loc < S.nf) {
+            seg = pair_seg(a_loc, b_loc, S.lower_only);
+            sr = seg >= 0 && gen_is_sr(S, a_loc, pos1);
+        }
+        const unsigned long long mu = __ballot(sr && seg == 0), ml = __ballot(sr && seg == 1);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (sr) {
+            const int64_t dst = seg == 0 ? ru + __popcll(mu & below) : rl + __popcll(ml & below);
+            sr_a[dst] = S.idx_f[a_loc];
+            sr_b[dst] = sb;
+            sr_mi[dst] = col[a_loc];
+        }
+        ru += __popcll(mu);
+        rl += __popcll(ml);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // joint tables for explicit pairs (test / inspection API): table[p][X][Y] from G entry (p, p)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_tables(const int64_t *__restrict__ G, int RFpad, const int32_t *idx_f, const int32_t *lrow_f,
@@ -883,6 +967,27 @@ __global__ __launch_bounds__(256) void k_lr_gather(GatherArgs S, PickOut *__rest
         }
     }
 }
+
+// the same gather for a block in generic order (k_gen_count / k_gen_emit_sr above): the predicate instead of the intervals
+__global__ __launch_bounds__(256) void k_gen_gather(GenArgs S, PickOut *__restrict__ pick, uint64_t *__restrict__ ckey, uint64_t *__restrict__ cval) {
+    const int B = pick->B;
+    if (B >= NBINS) return;
+    const int lane = threadIdx.x & 63, b_loc = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b_loc >= S.nt) return;
+    const double pos1 = (double)S.POS[S.idx_t[b_loc]];
+    const double *col = S.MI + (int64_t)b_loc * S.nf;
+    for (int a_loc = lane; a_loc < S.nf; a_loc += 64) {
+        const int seg = pair_seg(a_loc, b_loc, S.lower_only);
+        if (seg < 0) continue;
+        const double mi = col[a_loc];
+        if (mi_bucket(mi) < B) continue;
+        if (gen_is_sr(S, a_loc, pos1)) continue;
+        const unsigned long long p = atomicAdd(&pick->n_cand, 1ull);
+        ckey[p] = f64_key(mi);
+        cval[p] = ((uint64_t)seg << 62) | ((uint64_t)a_loc + (uint64_t)b_loc * (uint64_t)S.nf);
+    }
+}
+
 
 // candidates sorted ascending by MI: quantile type 7, then first kept index
 __global__ void k_lr_thresh(const uint64_t *__restrict__ skey, PickOut *__restrict__ pick) {
@@ -1924,6 +2029,7 @@ struct HostBlock {
     int gen_t0 = 0, gen_q0 = 0;
     bool mixed = false;        // high-limb GEMM + gathered low limbs (decided with the bucket guess at submit_a)
     bool apx = false;          // approximate GEMM + exact popcount sums of the listed units (ldw_apx.h); implies the lo geometry
+    bool generic = false;      // a SNP list of the block is not ascending in POS: plain path + the k_gen_* pair list
     int guess = -1;            // bucket guess the block was submitted with
     LoHost lo;
     size_t o_cmax = 0, o_tbase = 0, o_tf = 0, o_band = 0;
@@ -1955,7 +2061,18 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     hb.RFpad = SF.Rpad;
     hb.RTpad = ST.Rpad;
     std::vector<ColInfo> cols;
-    if (int rc = build_cols(c, from_idx, nf, to_idx, nt, hb.diag, p->sr_dist, cols, hb.n_sr_blk)) return rc;
+    auto ascending = [&](const int32_t *idx, int64_t n) {
+        for (int64_t k = 1; k < n; ++k)
+            if (c->h_POS[idx[k]] < c->h_POS[idx[k - 1]]) return false;
+        return true;
+    };
+    hb.generic = !ascending(from_idx, nf) || !ascending(to_idx, nt);
+    if (hb.generic) {   // no intervals: the pair list is made from the dense block with the predicate itself (submit_b)
+        ColInfo z;
+        memset(&z, 0, sizeof(z));
+        cols.assign((size_t)nt, z);
+        hb.n_sr_blk = 0;
+    } else if (int rc = build_cols(c, from_idx, nf, to_idx, nt, hb.diag, p->sr_dist, cols, hb.n_sr_blk)) return rc;
     hb.n_lr_total = (hb.diag ? nf * (nf - 1) / 2 : nf * nt - std::min(nf, nt)) - hb.n_sr_blk;
     auto al = [](size_t x) { return (x + 63) / 64 * 64; };
     size_t o = 0;
@@ -2242,7 +2359,7 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
                    reinterpret_cast<const int64_t *>(d + hb.o_tbase), I(hb.o_tf), B(hb.o_band), hb.nf_tiles, hb.gen_t0,
                    hb.gen_q0};
     hb.submitted = true;
-    if (c->engine != LDW_ENGINE_MFMA) return LDW_OK;
+    if (c->engine != LDW_ENGINE_MFMA || hb.generic) return LDW_OK;
     hipStream_t gs = c->overlap ? c->gemm_stream : c->stream;   // overlap off: the stages of all blocks run back to back
     LDW_HIP(hipStreamWaitEvent(gs, c->ev_up[s], 0));
     if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(gs, c->ev_done[s], 0));
@@ -2323,8 +2440,88 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
 }
 
 // Second phase (unfused path only): epilogue, histogram pick and the copy-back of the pick on the main stream.
+// A block in generic order (HostBlock::generic): dense MI of every pair by the plain path, then the reference's pair list from the
+// dense block with the len predicate (k_gen_count -> host scan of the 2 nt column counts -> k_gen_emit_sr, k_pick_bucket,
+// k_gen_gather).  Synchronous where it needs the counts; such blocks are the exception (the reference's own parser emits ascending
+// positions), correctness is what matters here.
+int submit_generic(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
+    const int s = hb.slot;
+    const bool do_lr = !p->sr_only;
+    LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_up[s], 0));
+    hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
+    EmitArgs E0;
+    memset(&E0, 0, sizeof(E0));
+    E0.write_dense = 1;
+    E0.spec_B = -1;
+    E0.lower_only = 0;   // every entry of the block (a diagonal block too: the pair list decides which ones are pairs)
+    if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E0, ev, 3, s ? &c->G2 : &c->G, nullptr, nullptr)) return rc;
+    LDW_HIP(hipEventRecord(ev[4], c->stream));
+    if (int rc = c->hist[s].reserve((size_t)NBINS * 8)) return rc;
+    if (int rc = c->colcnt.reserve((size_t)hb.nt * 8 + (size_t)hb.nt * 16 + 64)) return rc;
+    LDW_HIP(hipMemsetAsync(c->hist[s].p, 0, (size_t)NBINS * 8, c->stream));
+    LDW_HIP(hipMemsetAsync(sl.pick[s], 0, sizeof(ldw::PickOut), c->stream));
+    GenArgs S;
+    S.MI = c->MIblk.as<double>();
+    S.nf = (int)hb.nf;
+    S.nt = (int)hb.nt;
+    S.lower_only = hb.diag ? 1 : 0;
+    S.keep_sr = p->keep_sr ? 1 : 0;
+    S.do_lr = do_lr ? 1 : 0;
+    S.idx_f = hb.D.idx_f;
+    S.idx_t = hb.D.idx_t;
+    S.POS = c->POS.as<int32_t>();
+    S.g = c->g;
+    S.sr_dist = p->sr_dist;
+    int32_t *cnt_u = c->colcnt.as<int32_t>(), *cnt_l = cnt_u + hb.nt;
+    int64_t *off_u = reinterpret_cast<int64_t *>(c->colcnt.as<char>() + (((size_t)hb.nt * 8 + 15) / 16 * 16)), *off_l = off_u + hb.nt;
+    const unsigned gridc = (unsigned)((hb.nt + 3) / 4);
+    hipLaunchKernelGGL(k_gen_count, dim3(gridc), dim3(256), 0, c->stream, S, cnt_u, cnt_l, c->hist[s].as<unsigned long long>());
+    LDW_HIP(hipGetLastError());
+    std::vector<int32_t> hc((size_t)hb.nt * 2);
+    LDW_HIP(hipMemcpyAsync(hc.data(), cnt_u, (size_t)hb.nt * 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    std::vector<int64_t> ho((size_t)hb.nt * 2);
+    int64_t nu = 0, nl = 0;
+    for (int64_t b = 0; b < hb.nt; ++b) nu += hc[(size_t)b];
+    int64_t ru = 0, rl = nu;   // all upper rows first, then all lower rows
+    for (int64_t b = 0; b < hb.nt; ++b) {
+        ho[(size_t)b] = ru;
+        ho[(size_t)hb.nt + b] = rl;
+        ru += hc[(size_t)b];
+        rl += hc[(size_t)hb.nt + b];
+        nl += hc[(size_t)hb.nt + b];
+    }
+    hb.n_sr_blk = nu + nl;
+    hb.n_lr_total = (hb.diag ? hb.nf * (hb.nf - 1) / 2 : hb.nf * hb.nt - std::min(hb.nf, hb.nt)) - hb.n_sr_blk;
+    const int64_t sr_add = p->keep_sr ? hb.n_sr_blk : 0;
+    if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr)) return rc;
+    if (sr_add > 0) {
+        LDW_HIP(hipMemcpyAsync(off_u, ho.data(), (size_t)hb.nt * 16, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_gen_emit_sr, dim3(gridc), dim3(256), 0, c->stream, S, off_u, off_l, (int64_t)c->n_sr, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(),
+                           c->sr_mi.as<double>());
+        LDW_HIP(hipGetLastError());
+        LDW_HIP(hipStreamSynchronize(c->stream));   // (ho is a host vector: the copy must be done before it goes away)
+    }
+    c->n_sr += sr_add;
+    hb.spec_B = -1;
+    if (do_lr) {
+        const size_t cap = (size_t)hb.nf * hb.nt;
+        if (int rc = c->cand_key[s].reserve(cap * 8)) return rc;
+        if (int rc = c->cand_val[s].reserve(cap * 8)) return rc;
+        if (int rc = launch_pick(c, hb, p, sl, c->stream)) return rc;
+        hipLaunchKernelGGL(k_gen_gather, dim3(gridc), dim3(256), 0, c->stream, S, sl.pick[s], c->cand_key[s].as<uint64_t>(), c->cand_val[s].as<uint64_t>());
+        LDW_HIP(hipGetLastError());
+    }
+    LDW_HIP(hipEventRecord(ev[2], c->stream));
+    LDW_HIP(hipMemcpyAsync(c->pin_pick[s], sl.pick[s], sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipEventRecord(c->ev_pick[s], c->stream));
+    ++c->generic_blocks;
+    return LDW_OK;
+}
+
 int submit_b(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
     if (hb.fused) return LDW_OK;
+    if (hb.generic) return submit_generic(c, hb, p, sl);
     const int s = hb.slot;
     LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_up[s], 0));
     if (c->engine == LDW_ENGINE_MFMA) LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_gemm[s], 0));
@@ -2788,7 +2985,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         for (int32_t k = ts; k <= te; ++k) ti[k - ts] = k - 1;
         return LDW_OK;
     };
-    if (p->keep_sr && nblocks > 200) {  // big runs: size the short-range table once (its row count follows from POS alone)
+    if (p->keep_sr && nblocks > 200 && c->pos_sorted) {  // big runs: size the short-range table once (its row count follows from POS alone)
                                         // instead of growing it geometrically, which would double-buffer tens of GB
         int64_t total_sr = 0;
         std::vector<ColInfo> cols;
@@ -2809,7 +3006,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     // the chain of b was already over: the two streams never ran side by side.)
     // cold start: a sampled guess for each block kind that has none yet (probe_kind_guess), taken from the first block of the kind
     static const bool probe_on = getenv("LDW_NO_PROBE") == nullptr;
-    if (probe_on && !p->sr_only && c->engine != LDW_ENGINE_HIST_STATES && !c->fused) {
+    if (probe_on && !p->sr_only && c->engine != LDW_ENGINE_HIST_STATES && !c->fused && c->pos_sorted) {
         bool done_kind[2] = {false, false};
         for (int64_t b = 0; b < nblocks && !(done_kind[0] && done_kind[1]); ++b) {
             const bool diag = blocks[b * 4 + 0] == blocks[b * 4 + 2] && blocks[b * 4 + 1] == blocks[b * 4 + 3];

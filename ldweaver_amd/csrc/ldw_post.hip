@@ -278,6 +278,7 @@ int ldw_ldmap(ldw_ctx *c, int32_t reducer, int32_t from, int32_t to, int64_t *n_
     const int windowed = (from != 0 || to != 0) ? 1 : 0;
     LDW_REQUIRE(!windowed || (to > from && from >= 0), LDW_ERR_ARG, "ldw_ldmap: <to> must be greater than <from> and both positive");
     LDW_REQUIRE(reducer >= 0, LDW_ERR_ARG, "ldw_ldmap: reducer must be >= 0 (0 = default)");
+    LDW_REQUIRE(c->pos_sorted, LDW_ERR_STATE, "ldw_ldmap: the rank of a position is taken from the SNP order, which needs snp.dat$POS ascending");
     const int64_t L = c->L, nl = c->n_lr, ns = c->n_sr;
     LDW_REQUIRE(nl + ns > 0, LDW_ERR_STATE, "ldw_ldmap: no links");
     // ---- pos_vec: which SNPs occur in a link, and their rank ----

@@ -211,10 +211,7 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
     max_blk_sz = rcompat.round_thousands(max_blk_sz)
     blocks = make_blocks(snp_dat.nsnp, max_blk_sz)
     POS, g, paint = snp_dat.POS, float(snp_dat.g), np.asarray(cds_var.paint)
-    if np.any(np.diff(np.asarray(POS, dtype=np.float64)) < 0):
-        # the reference's parser emits SNPs in alignment order, so snp.dat$POS ascends; the device path relies on it (the
-        # short-range band of a block is a contiguous index range)
-        raise ValueError("snp.dat$POS must be in ascending order: sort the SNPs (states, POS, r, uqe, paint) by position first")
+    # (snp.dat$POS may be in any order, like in the reference: blocks whose lists do not ascend take the library's generic path)
     approx = None if perform_SR_analysis_only else lr_links_approx(POS, g, sr_dist)
 
     own = engine is None

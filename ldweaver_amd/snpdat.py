@@ -27,7 +27,7 @@ def encode_chars(chars: np.ndarray) -> np.ndarray:
 @dataclass
 class SnpDat:
     states: object                 # (L, N) uint8 numpy array or CUDA torch tensor
-    POS: np.ndarray                # int32 [L], ascending
+    POS: np.ndarray                # int32 [L] (any order; ascending is what the reference's parser emits and what the fast paths want)
     g: float | None                # genome length (None for SNP-only alignments until patched, R/BacGWES.R:338-345)
     uqe: np.ndarray                # (L, 5) 0/1: allele present  (R/extractSNPs.R:47)
     r: np.ndarray                  # rowSums(uqe)

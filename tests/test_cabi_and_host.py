@@ -193,11 +193,10 @@ def test_near_mask_equals_the_references_site_filter():
     assert 0 < kf.sum() < len(kf)
 
 
-def test_unsorted_positions_are_refused_with_a_clear_message(tmp_path):
-    from ldweaver_amd.snpdat import CdsVar, SnpDat
-    st = np.zeros((4, 8), dtype=np.uint8)
-    st[:, ::2] = 1
-    sd = SnpDat.from_states(st, np.array([10, 30, 20, 40]), 100.0)
-    with pytest.raises(ValueError, match="ascending"):
-        MI.perform_MI_computation(sd, np.ones(8), CdsVar(paint=np.ones(4, dtype=np.int32), nclust=1),
-                                   lr_save_path=str(tmp_path / "l"), sr_save_path=str(tmp_path / "s"), plt_folder=str(tmp_path / "p"))
+def test_lr_links_approx_on_unsorted_positions_matches_oracle():
+    """snp.dat$POS may be in any order (the reference imposes none, R/computePairwiseMI.R:94-97 works on whatever it gets): the host's
+    binary-search shortcut only applies to ascending positions, the general scan must give the oracle's number."""
+    rng = np.random.default_rng(5)
+    POS = rng.permutation(np.sort(rng.choice(500_000, 2600, replace=False) + 1)).astype(np.int32)
+    assert np.any(np.diff(POS) < 0)
+    assert MI.lr_links_approx(POS, 500_000.0, 20000.0) == orc.lr_links_approx(POS, 500_000.0, 20000.0)

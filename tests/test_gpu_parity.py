@@ -1091,6 +1091,89 @@ def test_popcount_engine_equals_mfma_engine_bit_for_bit(engine, Ns, weights):
     assert len(out[L.ENGINE_HIST][2][2]) > 100 and np.array_equal(out[L.ENGINE_MFMA][3]["disc_thresh"], out[L.ENGINE_HIST][3]["disc_thresh"])
 
 
+def test_unsorted_positions_match_oracle(engine, synth, tmp_path):
+    """snp.dat$POS in ANY order (the reference imposes none: blocks go by index, len by position, R/computePairwiseMI.R:176-177,
+    :306-333).  Blocks whose lists do not ascend in POS run the plain path and the predicate-based pair list (k_gen_*): short-range
+    table row-exact, long-range table row-exact up to threshold ties, thresholds and counts vs the oracle block by block — positions
+    fully shuffled, and a nearly sorted order with a few swaps (so that sorted and generic blocks mix in one pass, cold and warm);
+    then the drop-in entry point end to end against the oracle's a-5 loop."""
+    rng = np.random.default_rng(77)
+    Ls = 512
+    for case in ("shuffled", "few_swaps"):
+        POS = synth["POS"].copy()
+        if case == "shuffled":
+            POS = POS[rng.permutation(Ls)]
+        else:
+            for i in (40, 41, 300, 305, 470):
+                POS[[i, i + 3]] = POS[[i + 3, i]]
+        assert np.any(np.diff(POS.astype(np.int64)) < 0)
+        d = dict(synth)
+        d["POS"] = POS
+        _setup(engine, d)
+        g = synth["g"]
+        sr_dist = 60000.0 if case == "shuffled" else 20000.0
+        approx = orc.lr_links_approx(POS, g, sr_dist)
+        assert MIH.lr_links_approx(POS, g, sr_dist) == approx
+        blocks = np.array(orc.make_blocks(Ls, 150), dtype=np.int32)          # 4 x 4 grid, last one ragged: 10 block pairs
+        for rep in range(2):
+            if rep == 0:
+                engine.reset_speculation()
+            p0 = engine.path_report()
+            engine.mi_all_pairs(blocks, sr_dist, 4000.0, approx)
+            p1 = engine.path_report()
+            stt = engine.block_stats()
+            sr_t, lr_t = engine.links(0), engine.links(1)
+            so = lo = 0
+            n_generic = 0
+            for bi, (fs, fe, ts, te) in enumerate(blocks.tolist()):
+                fi, ti = np.arange(fs - 1, fe), np.arange(ts - 1, te)
+                n_generic += bool(np.any(np.diff(POS[fi].astype(np.int64)) < 0) or np.any(np.diff(POS[ti].astype(np.int64)) < 0))
+                Mb = c_oracle.mi_block(d["states"], d["hdw"], d["r"], d["uqe"], fi, ti)
+                bl = orc.block_links(Mb, fi, ti, POS, d["paint"], g, sr_dist, 4000.0, approx)
+                ns, nl = int(stt["n_sr"][bi]), int(stt["n_lr_kept"][bi])
+                assert ns == len(bl.sr["MI"]) and int(stt["n_lr_total"][bi]) == bl.n_lr_total, (case, bi)
+                assert np.array_equal(sr_t[0][so:so + ns], bl.sr["a"]) and np.array_equal(sr_t[1][so:so + ns], bl.sr["b"]), (case, bi)
+                assert ns == 0 or np.abs(sr_t[2][so:so + ns] - bl.sr["MI"]).max() < MI_TIGHT
+                if bl.n_lr_total:
+                    assert abs(stt["disc_thresh"][bi] - bl.disc_thresh) < MI_TIGHT
+                    dev = dict(zip(zip(lr_t[0][lo:lo + nl].tolist(), lr_t[1][lo:lo + nl].tolist()), lr_t[2][lo:lo + nl].tolist()))
+                    ref = dict(zip(zip(bl.lr["a"].tolist(), bl.lr["b"].tolist()), bl.lr["MI"].tolist()))
+                    _same_up_to_threshold_ties(ref, dev, bl.disc_thresh, MI_TIGHT)
+                    # order: the rows common to both appear in the oracle's order
+                    common = [k for k in zip(bl.lr["a"].tolist(), bl.lr["b"].tolist()) if k in dev]
+                    assert [k for k in zip(lr_t[0][lo:lo + nl].tolist(), lr_t[1][lo:lo + nl].tolist()) if k in ref] == common
+                so += ns
+                lo += nl
+            assert so == len(sr_t[2]) and lo == len(lr_t[2])
+            assert n_generic >= (len(blocks) if case == "shuffled" else 3)
+            assert p1["plain_blocks"] - p0["plain_blocks"] >= n_generic
+    # the drop-in entry point on shuffled positions against the oracle's a-5 loop
+    POS = synth["POS"][np.random.default_rng(3).permutation(Ls)]
+    sd = SnpDat.from_states(synth["states"], POS, synth["g"])
+    kw = dict(sr_dist=60000, lr_retain_links=3000, max_blk_sz=1000, srp_cutoff=0.5)
+    ref = None
+    for model in ("host", "device"):
+        red = MIH.perform_MI_computation(sd, synth["hdw"], CdsVar(paint=synth["paint"], nclust=3), lr_save_path=str(tmp_path / f"lr_{model}.tsv"),
+                                         sr_save_path=str(tmp_path / f"sr_{model}.tsv"), plt_folder=str(tmp_path / "P"), verbose=False, engine=engine,
+                                         sr_model=model, **kw)
+        if model == "host":
+            red_host = red
+    assert (tmp_path / "lr_host.tsv").read_bytes() == (tmp_path / "lr_device.tsv").read_bytes()
+    assert len(red) == len(red_host)
+    red = red_host
+    ref = orc.perform_mi_computation(synth["states"], POS, synth["g"], sd.r, sd.uqe, synth["hdw"], synth["paint"], 3, sr_dist=60000,
+                                     lr_retain_links=3000, max_blk_sz=1000, srp_cutoff=0.5)
+    rr = ref.sr_links_red
+    assert len(red) == len(rr["pos1"]) > 0
+    ko = np.lexsort((np.asarray(rr["clust_c"]), rr["pos2"], rr["pos1"]))
+    kg = np.lexsort((red["clust_c"].to_numpy(), red["pos2"].to_numpy(), red["pos1"].to_numpy()))
+    for k in ("clust_c", "pos1", "pos2", "len"):
+        assert np.array_equal(np.asarray(rr[k])[ko], red[k].to_numpy()[kg]), k
+    assert np.abs(np.asarray(rr["MI"])[ko] - red["MI"].to_numpy()[kg]).max() < MI_TIGHT
+    n_lines = sum(1 for _ in open(tmp_path / "lr_host.tsv"))
+    assert n_lines == len(ref.lr_rows["MI"])
+
+
 def _table_digest(a, b, mi):
     """Order-sensitive 64-bit digest of a device-resident link table (wrapping int64 arithmetic): equal tables, equal digest."""
     import torch
