@@ -2455,6 +2455,7 @@ int submit_generic(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
     E0.spec_B = -1;
     E0.lower_only = 0;   // every entry of the block (a diagonal block too: the pair list decides which ones are pairs)
     if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E0, ev, 3, s ? &c->G2 : &c->G, nullptr, nullptr)) return rc;
+    LDW_HIP(hipEventRecord(ev[5], c->stream));   // (ldw_links_end brackets ev[1] .. ev[5] and ev[4] .. ev[2]: every event of the block must be recorded)
     LDW_HIP(hipEventRecord(ev[4], c->stream));
     if (int rc = c->hist[s].reserve((size_t)NBINS * 8)) return rc;
     if (int rc = c->colcnt.reserve((size_t)hb.nt * 8 + (size_t)hb.nt * 16 + 64)) return rc;
@@ -2947,6 +2948,7 @@ int ldw_links_end(ldw_ctx *c) {
         if (c->engine == LDW_ENGINE_MFMA && !c->fused) {   // the screens of the approximate path run behind the GEMM on its stream
             float t15 = 0;
             if (hipEventElapsedTime(&t15, ev[1], ev[5]) == hipSuccess) t12 += t15;
+            else (void)hipGetLastError();   // (an event this block never recorded: the failed query must not surface at the next launch check)
         }
         LDW_HIP(hipEventElapsedTime(&t23, ev[2], ev[3]));
         c->last_ms[0] += t01;
