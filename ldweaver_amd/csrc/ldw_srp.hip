@@ -459,8 +459,8 @@ int ldw_sr_len_quantiles(ldw_ctx *c, int nclust, double sr_dist, double prob, in
     LDW_REQUIRE(c->paint_min >= 1 && c->paint_max <= nclust, LDW_ERR_ARG,
                 "ldw_sr_len_quantiles: cds_var$paint must lie in 1..nclust (found %d..%d, nclust %d)", (int)c->paint_min,
                 (int)c->paint_max, nclust);
-    for (size_t i = 1; i < c->h_POS.size(); ++i)
-        LDW_REQUIRE(c->h_POS[i] > c->h_POS[i - 1], LDW_ERR_ARG, "ldw_sr_len_quantiles: POS must be strictly increasing");
+    // (POS may be in any order and may repeat: every row's len is computed from its two positions, rows with len outside
+    // (0, sr_dist) are left out exactly as R/computePairwiseMI.R:414 does)
     const int64_t n = c->n_sr;
     c->srm_S = S;
     c->srm_nclust = nclust;
