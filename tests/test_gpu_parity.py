@@ -1170,8 +1170,14 @@ def test_unsorted_positions_match_oracle(engine, synth, tmp_path):
     for k in ("clust_c", "pos1", "pos2", "len"):
         assert np.array_equal(np.asarray(rr[k])[ko], red[k].to_numpy()[kg]), k
     assert np.abs(np.asarray(rr["MI"])[ko] - red["MI"].to_numpy()[kg]).max() < MI_TIGHT
-    n_lines = sum(1 for _ in open(tmp_path / "lr_host.tsv"))
-    assert n_lines == len(ref.lr_rows["MI"])
+    # the lr file: the oracle's rows; a tie group sitting on the block's threshold stays together on the device and is split in the last bit
+    # by the oracle's summation order (the clonal slice is full of equal joint tables): every row the two sides disagree on has the threshold's MI
+    lr_dev = pd.read_csv(tmp_path / "lr_host.tsv", sep="\t", header=None, names=["pos1", "pos2", "clust1", "clust2", "len", "MI"])
+    dkeys = dict(zip(zip(lr_dev["pos1"].tolist(), lr_dev["pos2"].tolist()), lr_dev["MI"].tolist()))
+    okeys = dict(zip(zip(ref.lr_rows["pos1"].astype(int).tolist(), ref.lr_rows["pos2"].astype(int).tolist()), ref.lr_rows["MI"].tolist()))
+    thr = min(okeys.values())
+    _same_up_to_threshold_ties(okeys, dkeys, thr, 1e-9)
+    assert abs(len(dkeys) - len(okeys)) <= 0.05 * len(okeys)
 
 
 def _table_digest(a, b, mi):
