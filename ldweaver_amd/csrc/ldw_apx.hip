@@ -382,6 +382,128 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
     apx_gemm_epilogue<MT, NT>(P, acc, ty, tx, lane, s_tab, reinterpret_cast<uint8_t *>(s_tab + 64 * 64) + wave * 256);
 }
 // ------------------------------------------------------------------------------------------------
+// gemm_apx_pipe_kernel (r03 experiment, LDW_APX_KERNEL=pipe; coarse exponents only): the register-expansion kernel with the expansion
+// of k-step s + 1 SOFTWARE-PIPELINED under the MFMAs of k-step s, at a dependency distance of three MFMA slots: slot k of a step
+// issues MFMA k, the index arithmetic and the two table reads of fragment k of the NEXT step (k < 6), and the four ANDs of the
+// fragment whose reads were issued three slots earlier.  Two fragment sets alternate (4 k-steps per macro step: no copies).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_apx_pipe_kernel(ApxGemmArgs P) {
+    constexpr int MT = 4, NT = 2;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint64_t *lutFF = reinterpret_cast<uint64_t *>(smem);
+    uint8_t *sA = smem + 2048, *sB = sA + (size_t)P.M2 * 128;
+    int2 *s_tab = reinterpret_cast<int2 *>(sB + (size_t)P.M2 * 128);
+    const int tid = threadIdx.x;
+    if (P.fuse)
+        for (int i = tid; i < P.tab_nb * P.tab_nb; i += 256) s_tab[i] = P.tab[i];
+    {
+        uint64_t e = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e |= ((tid >> k) & 1) ? (0xFFull << (8 * k)) : 0ull;
+        lutFF[tid] = e;
+        const int n16 = P.M2 * 8;
+        for (int i = tid; i < n16; i += 256) {
+            reinterpret_cast<uint4 *>(sA)[i] = reinterpret_cast<const uint4 *>(P.dig_a)[i];
+            reinterpret_cast<uint4 *>(sB)[i] = reinterpret_cast<const uint4 *>(P.dig_b)[i];
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ty = 2 * blockIdx.y + (wave >> 1), tx = 2 * blockIdx.x + (wave & 1);
+    constexpr int TH = 32 * MT, TWd = 32 * NT;
+    if (ty * TH >= P.RTpad || tx * TWd >= P.RFpad) return;
+    if (P.lower_only && tx * TWd + TWd - 1 < ty * TH) return;
+    const int frow = lane & 31, fh = lane >> 5;
+    const uint64_t *pw[6];   // rows of this lane: 0..3 to side, 4..5 from side
+#pragma unroll
+    for (int i = 0; i < MT; ++i) pw[i] = P.panel_t + ((int64_t)(ty * TH + 32 * i + frow) * 2 + fh);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) pw[MT + i] = P.panel_f + ((int64_t)(tx * TWd + 32 * i + frow) * 2 + fh);
+    const int64_t st6[6] = {(int64_t)P.RTpad * 2, (int64_t)P.RTpad * 2, (int64_t)P.RTpad * 2, (int64_t)P.RTpad * 2, (int64_t)P.RFpad * 2, (int64_t)P.RFpad * 2};
+    v16i acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+    typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
+    uint64_t wcur[6], wnxt[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        wcur[r] = pw[r][0];
+        wnxt[r] = P.M2 > 1 ? pw[r][st6[r]] : 0ull;
+    }
+    // fragment sets X (even k-steps) and Y (odd k-steps); index 0..3 to side, 4..5 from side
+    v4i fX[6], fY[6];
+    auto lut2 = [&](uint64_t w, int kk) -> v4i {
+        const u64x2v q = {lutFF[(w >> (16 * kk)) & 0xFFu], lutFF[(w >> (16 * kk + 8)) & 0xFFu]};
+        return __builtin_bit_cast(v4i, q);
+    };
+    const uint8_t *dAl = sA + fh * 64, *dBl = sB + fh * 64;
+    {   // prologue: fragments of k-step 0 into X
+        const v4i da = *reinterpret_cast<const v4i *>(dAl), db = *reinterpret_cast<const v4i *>(dBl);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) fX[r] = lut2(wcur[r], 0) & (r < MT ? da : db);
+    }
+    // fragment order of the expansion = the order in which the MFMAs of a step first need them
+    constexpr int ORD[6] = {4, 0, 1, 5, 2, 3};                    // B0 A0 A1 B1 A2 A3
+    constexpr int MI_[8] = {0, 1, 0, 1, 2, 2, 3, 3}, MJ_[8] = {0, 0, 1, 1, 0, 1, 0, 1};
+    for (int m = 0; m < P.M2; ++m) {
+        const int sh = P.shift[4 * m];
+        if (sh) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = (int)((unsigned)acc[i][j][e] >> sh);
+        }
+        const bool more = m + 1 < P.M2;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            v4i(&cur)[6] = (kk & 1) ? fY : fX;
+            v4i(&nxt)[6] = (kk & 1) ? fX : fY;
+            const int kn = (kk + 1) & 3;                            // k-step within its macro step of the NEXT step
+            const bool wrap = kk == 3;                              // the next step belongs to macro step m + 1
+            const int mo = wrap ? (m + 1) * 128 : m * 128;
+            const bool have_next = !wrap || more;
+            v4i dna = {0, 0, 0, 0}, dnb = {0, 0, 0, 0};
+            if (have_next) {
+                dna = *reinterpret_cast<const v4i *>(dAl + mo + 16 * kn);
+                dnb = *reinterpret_cast<const v4i *>(dBl + mo + 16 * kn);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                acc[MI_[k]][MJ_[k]] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur[MI_[k]], cur[MT + MJ_[k]], acc[MI_[k]][MJ_[k]], 0, 0, 0);
+                if (k < 6) {
+                    const int r = ORD[k];
+                    nxt[r] = lut2(wrap ? wnxt[r] : wcur[r], kn);
+                }
+                if (k >= 3 && k < 7) {
+                    const int r = ORD[k - 3];
+                    nxt[r] = nxt[r] & (r < MT ? dna : dnb);
+                }
+                if (k == 7) {
+                    nxt[ORD[4]] = nxt[ORD[4]] & dna;
+                    nxt[ORD[5]] = nxt[ORD[5]] & dna;
+                }
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+            }
+        }
+        // panel words: the next macro step's become current, the one after that is requested
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            wcur[r] = wnxt[r];
+            if (m + 2 < P.M2) wnxt[r] = pw[r][(int64_t)(m + 2) * st6[r]];
+        }
+    }
+    apx_gemm_epilogue<MT, NT>(P, acc, ty, tx, lane, s_tab, reinterpret_cast<uint8_t *>(s_tab + 64 * 64) + wave * 256);
+}
+
+// ------------------------------------------------------------------------------------------------
 // gemm_apx_lds_kernel: the same contraction with the operand expansion SHARED through LDS (r03).
 //
 // gemm_apx_kernel expands every fragment in the wave that consumes it: 6 expansions (48 VALU, 12 table reads) per 8 MFMAs, which
@@ -547,6 +669,21 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
         return e ? atoi(e) : 42;
     }();
     const int kern = apx_kernel_is_lds() ? 1 : 0;
+    static const bool pipe = [] { const char *e = getenv("LDW_APX_KERNEL"); return e && e[0] == 'p'; }();
+    if (pipe && !P.fine && tile == 42) {
+        const int ntx = P.RFpad / 64, nty = P.RTpad / 128;
+        hipLaunchKernelGGL(gemm_apx_pipe_kernel, dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P);
+        LDW_HIP(hipGetLastError());
+        int64_t waves = 0;
+        for (int ty = 0; ty < nty; ++ty) {
+            if (!P.lower_only) waves += ntx;
+            else for (int tx = 0; tx < ntx; ++tx) waves += (tx * 64 + 63 < ty * 128) ? 0 : 1;
+        }
+        c->gemm_stat[0] += 1;
+        if (P.fuse) c->gemm_stat[5] += 1;
+        c->gemm_stat[1] += 2.0 * (double)waves * 128 * 64 * ((double)P.M2 * 128.0);
+        return LDW_OK;
+    }
     const size_t lds2 = 2048 + (size_t)P.M2 * 256 + 2 * 32768 + (P.fuse ? (size_t)P.tab_nb * P.tab_nb * 8 + 8 * 256 : 0);
     if (kern == 1 && lds2 <= 160 * 1024 && tile == 42) {
         static bool attr_set = false;
