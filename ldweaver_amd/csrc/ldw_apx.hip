@@ -488,9 +488,11 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_pipe_kernel(ApxGemmArgs P) {
                     nxt[ORD[4]] = nxt[ORD[4]] & dna;
                     nxt[ORD[5]] = nxt[ORD[5]] & dna;
                 }
+#ifdef LDW_PIPE_SGB   // pinning the interleave (MFMA, 2 table reads, 8 VALU per slot): 0.572 ms; without it (the compiler's own order): see DESIGN 5.1c
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+#endif
             }
         }
         // panel words: the next macro step's become current, the one after that is requested
