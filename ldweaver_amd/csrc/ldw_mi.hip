@@ -33,6 +33,9 @@
 
 #include "ldw_internal.h"
 #include "ldw_dev.h"
+#ifndef LDW_SCREEN_V
+#define LDW_SCREEN_V 2   // columns in flight per wave in the multi-cell screen (tuning: make CXXFLAGS+=-DLDW_SCREEN_V=4)
+#endif
 #include "ldw_epi.h"
 #include "ldw_apx.h"
 
@@ -274,7 +277,7 @@ template <int NA, int U, int RM, bool APX>
 __device__ __forceinline__ unsigned int screen_cols_nb(int nb, const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc,
                                                        bool a_ok, float lo, int q0) {
     if (NA == 1 && nb == 1) return screen_cols<NA, 1, U, RM, APX>(A, R, cmu, a_loc, a_ok, lo, q0);   // (the table path is taken by the caller)
-    constexpr int V = U >= 2 ? 2 : 1;   // (two columns in flight also for two-row tiles: 387 -> 372 us per C4 block)
+    constexpr int V = LDW_SCREEN_V < U ? LDW_SCREEN_V : U;   // columns in flight for the multi-cell tables (2: 387 -> 372 us per C4 block in r02)
     unsigned int bits = 0;
     for (int u = 0; u < U; u += V) {
         const unsigned int b = nb == 1 ? screen_cols<NA, 1, V, RM, APX>(A, R, cmu + u, a_loc, a_ok, lo, q0 + u)
