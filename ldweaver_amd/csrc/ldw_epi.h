@@ -524,7 +524,11 @@ __device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSi
                 pxy = fmaf((float)(uint32_t)(C.n[i][j] >> A.E.scr_shift), A.E.scr_scale, 0.5f);
             }
             const float d = fmaf(pY, rY, fmaf(pX, pY, pXr));
+#ifdef LDW_ABLATE_SCREEN_LOGS   // timing ablation only (wrong results): what the two v_log_f32 per cell cost (tools/r03_ablate.sh)
+            const float lt = (pxy * den - d) * 1e-30f;   // (tiny: nothing passes, the arithmetic around the logarithms stays)
+#else
             const float lt = __builtin_amdgcn_logf(pxy * den) - __builtin_amdgcn_logf(d);
+#endif
             acc = fmaf(pxy, lt, acc);
             if (APX) {
                 acc_abs = fmaf(pxy, fabsf(lt), acc_abs);
