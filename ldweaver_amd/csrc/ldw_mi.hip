@@ -1874,17 +1874,26 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     A.colpack_hi = cph;
     A.rowpack = rp;
     A.rowpack_hi = rph;
+    // LDW_SCREEN_MAIN=1 (experiment): the block's screen at the head of phase 2 on the main stream — beside the NEXT block's GEMM on the GEMM
+    // stream — instead of behind its own GEMM
+    static const bool screen_main = getenv("LDW_SCREEN_MAIN") != nullptr;
+    const int rm_s = quirk == LDW_QUIRK_REFERENCE ? (nf == nt ? 1 : 2) : 0;
+#define LDW_SCREEN(RMv, ST) hipLaunchKernelGGL((k_mi_screen<RMv, true>), egrid, dim3(256), 0, ST, A, D.perm, D.perm_t, units, n_units, list_stride)
     if (phase == 1) {
-        const int rm = quirk == LDW_QUIRK_REFERENCE ? (nf == nt ? 1 : 2) : 0;
-#define LDW_SCREEN(RMv) hipLaunchKernelGGL((k_mi_screen<RMv, true>), egrid, dim3(256), 0, gs, A, D.perm, D.perm_t, units, n_units, list_stride)
-        if (rm == 0) LDW_SCREEN(0); else if (rm == 1) LDW_SCREEN(1); else LDW_SCREEN(2);
-#undef LDW_SCREEN
-        LDW_HIP(hipGetLastError());
+        if (!screen_main) {
+            if (rm_s == 0) LDW_SCREEN(0, gs); else if (rm_s == 1) LDW_SCREEN(1, gs); else LDW_SCREEN(2, gs);
+            LDW_HIP(hipGetLastError());
+        }
         LDW_HIP(hipEventRecord(ev[5], gs));
         return LDW_OK;
     }
     // ---- phase 2 ----
     LDW_HIP(hipEventRecord(ev[4], c->stream));
+    if (screen_main) {
+        if (rm_s == 0) LDW_SCREEN(0, c->stream); else if (rm_s == 1) LDW_SCREEN(1, c->stream); else LDW_SCREEN(2, c->stream);
+        LDW_HIP(hipGetLastError());
+    }
+#undef LDW_SCREEN
     // the units outside k_mi_screen's domain: generic from-tiles x all columns, the other tiles x the generic columns
     const int gt0 = std::min<int>(A.gen_t0, (int)egrid.x);
     const int q0 = std::min<int>(A.gen_q0, (int)nt) / GEN_COLS * GEN_COLS;
