@@ -267,8 +267,6 @@ int ldw_ctx_destroy(ldw_ctx *c) {
                            &c->ar_off, &c->ar_flags, &c->seq_perm, &c->dig_a, &c->dig_b, &c->apx_shift, &c->slot_papx, &c->pop_segs, &c->pop_wbeg,
                            &c->panel[0][0], &c->panel[0][1], &c->panel[1][0], &c->panel[1][1], &c->Gapx[0], &c->Gapx[1], &c->pair_sums, &c->tab11[0], &c->tab11[1], &c->pairs[0], &c->pairs[1], &c->apx_units[0], &c->apx_units[1], &c->apx_packs[0], &c->apx_packs[1]};
     for (auto *b : bufs) b->release();
-    for (auto &e : c->panel_cache) e.buf.release();
-    c->panel_cache.clear();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) {
@@ -348,7 +346,6 @@ int ldw_reset_speculation(ldw_ctx *c) {
     c->spec_seen[0] = c->spec_seen[1] = false;
     c->spec_hist_n[0] = c->spec_hist_n[1] = 0;
     c->tab11_lo[0] = c->tab11_lo[1] = 0;
-    for (auto &e : c->panel_cache) e.packed = false;   // a pass packs the panels of its sides itself (the buffers stay)
     return LDW_OK;
 }
 
@@ -820,7 +817,6 @@ int ensure_rows(ldw_ctx *c) {
     }
     LDW_HIP(hipStreamSynchronize(c->stream));
     c->rows_ready = true;
-    c->panel_cache_stale = true;
     c->spec_B_next[0] = c->spec_B_next[1] = -1;   // bucket guesses of an earlier alignment / weighting say nothing about this one
     c->spec_seen[0] = c->spec_seen[1] = false;
     c->spec_hist_n[0] = c->spec_hist_n[1] = 0;

@@ -104,13 +104,6 @@ struct ldw_ctx {
     ldw::DevBuf pop_segs, pop_wbeg;    // popcount segments (PopSeg) and first segment of every 32-bit word (+1)
     int n_pop_segs = 0, n_classes = 0;
     ldw::DevBuf panel[2][2];           // [slot][from, to]: packed bit panels of a block's row lists, [KW/2][Rpad][2] u64
-    // panels of CONTIGUOUS SNP ranges are kept for the rest of the pass: the 55 block pairs of C4 have 10 distinct sides, each packed
-    // once instead of ~10 times (the row list of a side is a function of its SNP list alone).  Read-only after the packing
-    // kernel; dropped when the alignment, the weights (sequence order) or the row map change.
-    struct PanelEnt { int32_t first = 0, n = 0, Rpad = 0; bool packed = false; ldw::DevBuf buf; };
-    std::vector<PanelEnt> panel_cache;
-    size_t panel_cache_bytes = 0;
-    bool panel_cache_stale = false;    // the row map was rebuilt: every entry must be dropped before its next use
     ldw::DevBuf Gapx[2];               // int32 [RTpad][RFpad] approximate joint sums, one per pipeline slot
     ldw::DevBuf tab11[2];              // threshold tables of the biallelic pairs (k_build_tab11), int2 [nb][nb]: [off-diagonal, diagonal] blocks
     double tab11_lo[2] = {0, 0};       // MI level each was built for (0: none)

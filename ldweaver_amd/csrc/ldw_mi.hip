@@ -1490,7 +1490,6 @@ struct LoHost {
     int32_t n_tiles_cf[3] = {0, 0, 0};   // from-tiles whose widest row-slot class is 1, 2, 4
     int band_full = 0;                   // the exact GEMM has to cover every tile (a SNP with unflagged slots: its units are not screened)
     int apx = 0, slot = 0, diag = 0;     // approximate-GEMM path (ldw_apx.h) instead of the high-limb GEMM + gathered low limbs
-    int32_t key_f[2] = {-1, 0}, key_t[2] = {-1, 0};   // (first SNP, count) of a side that is a contiguous ascending index range, else first = -1 (panel cache)
     int fuse_ok = 0;                     // rows of one-row SNPs sit at their slot index in both row lists (no SNP without a row): the
                                          // GEMM's epilogue may apply the threshold table by row (ApxGemmArgs::fuse)
 };
@@ -1718,61 +1717,10 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
 // Events: ev[0] / ev[1] around the packing + approximate GEMM, ev[5] after the screens and the band GEMM (gs); ev[4] / ev[2]
 // around phase 2.
 // ------------------------------------------------------------------------------------------------
-// The packed bit panel of one side of a block (k_pack_panel).  Sides that are contiguous SNP ranges (every block of ldw_mi_all_pairs) are
-// packed once per pass and kept (ldw_ctx::panel_cache, at most PANEL_CACHE_MAX bytes); anything else goes through the slot's own buffer.
-// All packing and all reads happen on the GEMM stream `gs`, in order.
-void drop_panel_cache(ldw_ctx *c) {
-    for (auto &e : c->panel_cache) e.buf.release();
-    c->panel_cache.clear();
-    c->panel_cache_bytes = 0;
-}
-
-constexpr size_t PANEL_CACHE_MAX = (size_t)8 << 30;
-int get_panel(ldw_ctx *c, const int32_t key[2], const int32_t *rowlist, int Rpad, int slot, int side, hipStream_t gs, const uint64_t **out) {
-    const size_t bytes = (size_t)Rpad * c->KW * 8;
-    static const bool cache_on = getenv("LDW_NO_PANEL_CACHE") == nullptr;
-    if (c->panel_cache_stale) {   // another alignment / weighting / row map: nothing of the old panels is valid (sizes may differ too)
-        drop_panel_cache(c);
-        c->panel_cache_stale = false;
-    }
-    if (cache_on && key[0] >= 0) {
-        for (auto &e : c->panel_cache)
-            if (e.first == key[0] && e.n == key[1] && e.Rpad == Rpad) {
-                if (!e.packed) {   // (ldw_reset_speculation: a new pass packs its sides again, into the buffers it already has)
-                    if (int rc = launch_pack_panel(c, rowlist, Rpad, e.buf.as<uint64_t>(), gs)) return rc;
-                    e.packed = true;
-                }
-                *out = e.buf.as<uint64_t>();
-                return LDW_OK;
-            }
-        if (c->panel_cache_bytes + bytes <= PANEL_CACHE_MAX) {
-            c->panel_cache.emplace_back();
-            ldw_ctx::PanelEnt &e = c->panel_cache.back();
-            if (int rc = e.buf.reserve(bytes)) {
-                c->panel_cache.pop_back();
-                return rc;
-            }
-            e.first = key[0];
-            e.n = key[1];
-            e.Rpad = Rpad;
-            e.packed = true;
-            c->panel_cache_bytes += bytes;
-            if (int rc = launch_pack_panel(c, rowlist, Rpad, e.buf.as<uint64_t>(), gs)) return rc;
-            *out = e.buf.as<uint64_t>();
-            return LDW_OK;
-        }
-    }
-    if (int rc = c->panel[slot][side].reserve(bytes)) return rc;
-    if (int rc = launch_pack_panel(c, rowlist, Rpad, c->panel[slot][side].as<uint64_t>(), gs)) return rc;
-    *out = c->panel[slot][side].as<uint64_t>();
-    return LDW_OK;
-}
-
 int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E, hipEvent_t *ev, int phase,
                      hipStream_t gs, unsigned long long *ghist, const LoHost *lo_h, void *zero_hist = nullptr, void *zero_pick = nullptr,
                      size_t zero_pick_bytes = 0) {
     const int s = lo_h->slot;
-    const uint64_t *panel_f_ptr = nullptr, *panel_t_ptr = nullptr;
     E.nf = (int)nf;
     E.MI = nullptr;
     dim3 egrid((unsigned)(D.nf_tiles > 0 ? D.nf_tiles : (nf + 63) / 64), (unsigned)((nt + EPI_COLS - 1) / EPI_COLS));
@@ -1792,7 +1740,9 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     const uint8_t *band = (use_pairs && !lo_h->band_full) ? D.band_mask : nullptr;
     ldw::DevBuf &Gx = s ? c->G2 : c->G;
     if (phase == 1) {
-
+        if (int rc = c->panel[s][0].reserve((size_t)RFpad * c->KW * 8)) return rc;
+        if (!lo_h->diag)
+            if (int rc = c->panel[s][1].reserve((size_t)RTpad * c->KW * 8)) return rc;
         if (E.do_lr)
             if (int rc = c->Gapx[s].reserve((size_t)RFpad * RTpad * 4)) return rc;
         if (int rc = c->apx_units[s].reserve(o_flat + 2 * n_units_max * 8 + 64)) return rc;
@@ -1860,10 +1810,9 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     }
     if (phase == 1) {
         if (E.do_lr) {
-            if (int rc = get_panel(c, lo_h->key_f, D.rl_f, RFpad, s, 0, gs, &panel_f_ptr)) return rc;
-            if (!lo_h->diag) {
-                if (int rc = get_panel(c, lo_h->key_t, D.rl_t, RTpad, s, 1, gs, &panel_t_ptr)) return rc;
-            } else panel_t_ptr = panel_f_ptr;
+            if (int rc = launch_pack_panel(c, D.rl_f, RFpad, c->panel[s][0].as<uint64_t>(), gs)) return rc;
+            if (!lo_h->diag)
+                if (int rc = launch_pack_panel(c, D.rl_t, RTpad, c->panel[s][1].as<uint64_t>(), gs)) return rc;
         }
         {   // the unit counters, the pair-list counters, this slot's histogram and pick record (submit_b skips its own memsets)
             ZeroArgs Z;
@@ -1895,8 +1844,8 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         if (E.do_lr) {
             ApxGemmArgs P;
             memset(&P, 0, sizeof(P));
-            P.panel_f = panel_f_ptr;
-            P.panel_t = panel_t_ptr;
+            P.panel_f = c->panel[s][0].as<uint64_t>();
+            P.panel_t = lo_h->diag ? P.panel_f : c->panel[s][1].as<uint64_t>();
             P.RTpad = RTpad;
             P.RFpad = RFpad;
             P.M2 = (int)(c->KW / 2);
@@ -2202,13 +2151,6 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
         lo.slot = slot;
         lo.diag = hb.diag ? 1 : 0;
         lo.glo_total = tb;
-        auto contiguous = [](const int32_t *idx, int64_t n) {
-            for (int64_t k = 1; k < n; ++k)
-                if (idx[k] != idx[k - 1] + 1) return false;
-            return true;
-        };
-        if (contiguous(from_idx, nf)) { lo.key_f[0] = from_idx[0]; lo.key_f[1] = (int32_t)nf; }
-        if (contiguous(to_idx, nt)) { lo.key_t[0] = to_idx[0]; lo.key_t[1] = (int32_t)nt; }
     }
     std::vector<int32_t> tf;
     // last tiles first: the tile of the SNPs with >= 3 minor states (generic code, every unit listed, cmax 4) is the
