@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
                                                       "smoke-testing the N > 1 path on a single GPU)")
+    ap.add_argument("--no-prune", action="store_true", help="A/B: no row ordering / tile pruning in the approximate GEMM")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the timed region with the GEMM/epilogue stream overlap off too (kernel-exclusive times everywhere; "
                          "the command profiles/*_serial_kernel_stats.csv was collected with)")
@@ -177,6 +178,7 @@ def main():
     eng = Engine(local_rank, stream=stream.cuda_stream)
     eng.set_engine({"mfma": LL.ENGINE_MFMA, "hist": LL.ENGINE_HIST, "hist_states": LL.ENGINE_HIST_STATES}[args.engine])
     eng.set_overlap(not args.no_overlap)
+    eng.set_prune(not args.no_prune)
     eng.set_fused(args.fused)
     eng.set_screen(args.screen)
     eng.set_mixed(not args.no_mixed)
@@ -452,6 +454,8 @@ def main():
         out.update(legs)
         out["spec_misses"] = counters_timed["spec_misses"]
         out["path"] = path_report
+        out["prune"] = dict(eng.prune_report(), what="wave tiles of the approximate GEMM whose pairs the threshold table dismisses whatever their joint "
+                                                     "count (rows ordered by minor-state weight): flagged clean without being computed; not in roofline.achieved")
         if per_rank is not None:
             out["per_rank"] = per_rank
         out.update(stages_ms_per_step={k: v / max(1, n_replay) for k, v in tim.items()},

@@ -211,6 +211,16 @@ int ldw_reset_speculation(ldw_ctx *ctx);
  * dynamic range needs the finer exponents) or which gate keeps the approximate path off
  * ("delta 5.1e-03 > 4e-03", "Npad 40960 > 30720", "popcount segment tables 70000 B > 60000 B of LDS", "weights not set"). */
 int ldw_path_report(ldw_ctx *ctx, int64_t out[8], char *gate, int capacity);
+/* Tile pruning of the approximate path (default on; LDW_NO_PRUNE in the environment = off).  In a block pair without a short-range
+ * pair the order of the rows within a slot class is free, so the biallelic SNPs are ordered by the weight of their minor state;
+ * a 128 x 64 wave tile of the approximate GEMM whose rectangle of threshold-table bins holds only unconditional entries — no joint
+ * count can lift a pair of such marginals to the block's level; real alignments are full of near-singleton sites — is then
+ * flagged clean without being computed or screened.  The link tables do not depend on it (the same table entries dismiss the
+ * same pairs either way; verify mode, ldw_set_screen 2, checks the pruned tiles' pairs in fp64 like every other dismissal).
+ * ldw_prune_report: out[0] blocks whose rows were ordered, out[1] wave tiles pruned, out[2] wave tiles of the GEMMs that could
+ * prune (both since the context was created; pruned tiles are not counted as executed work by ldw_gemm_stats), out[3] = on. */
+int ldw_set_prune(ldw_ctx *ctx, int on);
+int ldw_prune_report(ldw_ctx *ctx, int64_t out[4]);
 /* diagnostics of the approximate path after ldw_set_weights: out[0] = usable (0/1), out[1] = max relative error delta of the
  * dual-digit weights, out[2] = weight classes, out[3] = popcount segments, out[4] = exponent transitions, out[5] = e_last */
 int ldw_apx_info(ldw_ctx *ctx, double out[6]);

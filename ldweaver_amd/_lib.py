@@ -90,6 +90,8 @@ _SIGS = {
     "ldw_ldmap": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, _p, _p, _i64]),
     "ldw_reset_speculation": (C.c_int, [_p]),
     "ldw_path_report": (C.c_int, [_p, _p, C.c_char_p, C.c_int]),
+    "ldw_set_prune": (C.c_int, [_p, C.c_int]),
+    "ldw_prune_report": (C.c_int, [_p, _p]),
     "ldw_format_number": (C.c_int, [C.c_double, C.c_char_p, C.c_int]),
     "ldw_write_table_tsv": (C.c_int, [C.c_char_p, C.c_int, _i64, C.c_int, _p, _p, C.c_int, C.POINTER(_i64)]),
     "ldw_write_links_tsv": (C.c_int, [_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -246,6 +246,7 @@ int ldw_ctx_create(int device, ldw_ctx **out) {
     }
     ldw_ctx *c = new ldw_ctx();
     c->device = device;
+    c->prune = getenv("LDW_NO_PRUNE") == nullptr;
     LDW_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
     for (auto &e : c->ev) LDW_HIP(hipEventCreate(&e));
@@ -258,7 +259,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     ldw::DevBuf *bufs[] = {&c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
-                           &c->slot_meta, &c->slot_pfix, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
+                           &c->slot_meta, &c->slot_pfix, &c->apx_skip, &c->snp_sup, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
                            &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->perm_t, &c->scr_units, &c->slot_pfix_hi, &c->glo, &c->lo_rows, &c->packs, &c->hist[0], &c->hist[1], &c->colcnt, &c->cand_key[0], &c->cand_key[1],
                            &c->cand_val[0], &c->cand_val[1], &c->cand_key2, &c->cand_val2, &c->sel_bitmap, &c->sel_chunks, &c->sel_prefix, &c->apx_bins[0], &c->apx_bins[1], &c->apx_clean[0], &c->apx_clean[1], &c->scratch, &c->small, &c->sr_a, &c->sr_b,
                            &c->sr_mi, &c->lr_a, &c->lr_b, &c->lr_mi, &c->srm_pack, &c->srm_key, &c->srm_pack2, &c->srm_key2, &c->srm_pay, &c->srm_pay2, &c->srm_off,
@@ -360,6 +361,21 @@ int ldw_path_report(ldw_ctx *c, int64_t out[8], char *gate, int capacity) {
     out[6] = c->apx_pairs_listed;
     out[7] = c->apx_units_listed;
     if (gate && capacity > 0) snprintf(gate, (size_t)capacity, "%s", c->have_weights ? c->apx_gate.c_str() : "weights not set");
+    return LDW_OK;
+}
+
+int ldw_set_prune(ldw_ctx *c, int on) {
+    LDW_REQUIRE(c, LDW_ERR_ARG, "null context");
+    c->prune = on != 0;
+    return LDW_OK;
+}
+
+int ldw_prune_report(ldw_ctx *c, int64_t out[4]) {
+    LDW_REQUIRE(c && out, LDW_ERR_ARG, "ldw_prune_report: null argument");
+    out[0] = c->sorted_blocks;
+    out[1] = c->apx_waves_skipped;
+    out[2] = c->apx_waves_total;
+    out[3] = c->prune ? 1 : 0;
     return LDW_OK;
 }
 
@@ -671,6 +687,8 @@ int ldw_set_snp_meta(ldw_ctx *c, const double *r, const uint8_t *uqe, const int3
     else LDW_HIP(hipMemsetAsync(c->paint.p, 0, (size_t)L * 4, c->stream));
     LDW_HIP(hipStreamSynchronize(c->stream));
     c->h_r.assign(r, r + L);
+    c->r_min = r[0];
+    for (int64_t i = 1; i < L; ++i) c->r_min = r[i] < c->r_min ? r[i] : c->r_min;
     c->h_POS.assign(POS, POS + L);
     c->pos_sorted = true;
     for (int64_t i = 1; i < L && c->pos_sorted; ++i) c->pos_sorted = POS[i] >= POS[i - 1];
@@ -696,6 +714,73 @@ int ldw_set_snp_meta(ldw_ctx *c, const double *r, const uint8_t *uqe, const int3
 // row map: which (SNP, state) pairs get an indicator row
 // ------------------------------------------------------------------------------------------------
 namespace ldw {
+
+// ------------------------------------------------------------------------------------------------
+// k_snp_sup: how large can the MI of SNP a get, whatever its partner looks like?  With the marginals p_x of a fixed, the MI of
+// R/computePairwiseMI.R:390-398 is
+//     F(n) = 1/den sum_xy q_xy ln(q_xy den / D_xy),   q = n + 1/2,   D_xy = p_x pY_y + RXY + p_x r_a/2 + pY_y r_b/2,   pY_y = sum_x n_xy
+// over the joint tables n >= 0 with row sums p_x.  q and D are affine in n and q ln(q / D) is jointly convex (relative entropy),
+// so F is convex on that polytope — a product of simplices — and takes its maximum at a vertex: every state of a sends ALL
+// its weight to one state of the partner.  For a partner with k flagged states that is k^(states of a) tables: enumerate them.
+// F falls as RXY grows; the reference's scrambled RXY (quirk Q1) is r r' / 4 of two other SNPs of the block, at least
+// r_min^2 / 4: the m = 1 values use that floor.  Near-singleton sites (most of a real alignment) come out below any threshold
+// a long-range link has to reach: the screen and the approximate GEMM drop their pairs without looking at them
+// (apx_tile_prunable, k_mi_screen).  One thread per SNP, once per weighting.
+// ------------------------------------------------------------------------------------------------
+__device__ double mi_vertex_sup(const double *p, int ka, int kb, double neff, double rxy) {
+    const double den = neff + 0.5 * ka * kb, rX = 0.5 * ka, rY = 0.5 * kb;
+    int nv = 1;
+    for (int x = 0; x < ka; ++x) nv *= kb;
+    double best = -1e300;
+    for (int v = 0; v < nv; ++v) {
+        int phi[3];
+        double pY[3] = {0.0, 0.0, 0.0};
+        int t = v;
+        for (int x = 0; x < ka; ++x) {
+            phi[x] = t % kb;
+            t /= kb;
+            pY[phi[x]] += p[x];
+        }
+        double F = 0.0;
+        for (int x = 0; x < ka; ++x)
+            for (int y = 0; y < kb; ++y) {
+                const double q = (phi[x] == y ? p[x] : 0.0) + 0.5;
+                const double D = p[x] * pY[y] + rxy + p[x] * rX + pY[y] * rY;
+                if (!(D > 0.0)) return 1e300;   // (degenerate r: no statement)
+                F += q * log(q * den / D);
+            }
+        F /= den;
+        if (!(F == F)) return 1e300;
+        best = F > best ? F : best;
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(256) void k_snp_sup(int64_t L, const uint32_t *__restrict__ slot_meta, const int64_t *__restrict__ slot_pfix,
+                                                 const double *__restrict__ r, double scale, double neff, double r_min, double *__restrict__ sup) {
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= L) return;
+    const uint32_t m = slot_meta[a];
+    const int n = (int)(m & 7), ka = n + 1;
+    double out[4] = {1e300, 1e300, 1e300, 1e300};
+    const uint32_t full = (2u << n) - 1u;
+    if ((ka == 2 || ka == 3) && ((m >> 3) & full) == full && r[a] == (double)ka) {
+        double p[3] = {0.0, 0.0, 0.0};
+        double minor = 0.0;
+        for (int x = 0; x < ka; ++x) {
+            p[x] = (double)slot_pfix[a * 5 + x] * scale;
+            if (x < n) minor += p[x];
+        }
+        // a SNP with any sizeable minor state reaches every threshold of interest: not worth the enumeration (+inf is the safe answer)
+        if (minor < 0.05 * neff + 4.0)
+            for (int kb = 2; kb <= 3; ++kb) {
+                out[kb - 2] = mi_vertex_sup(p, ka, kb, neff, 0.25 * ka * kb) * (1.0 + 1e-12) + 1e-12;
+                const double rfloor = 0.25 * r_min * r_min;
+                out[2 + kb - 2] = mi_vertex_sup(p, ka, kb, neff, rfloor < 0.25 * ka * kb ? rfloor : 0.25 * ka * kb) * (1.0 + 1e-12) + 1e-12;
+            }
+    }
+    for (int k = 0; k < 4; ++k) sup[a * 4 + k] = out[k];
+}
 
 int ensure_rows(ldw_ctx *c) {
     if (c->rows_ready) return LDW_OK;
@@ -752,6 +837,10 @@ int ensure_rows(ldw_ctx *c) {
     }
     c->R = c->h_row0[L];
     c->h_slot_meta = meta;
+    c->h_minor_w.assign((size_t)L, INT64_MAX);   // order key of the tile pruning (prep_block): rows with a table bin first, by weight
+    for (int64_t a = 0; a < L; ++a)
+        if ((meta[a] & 7u) == 1u && ((meta[a] >> 3) & 3u) == 3u && c->h_r[(size_t)a] == 2.0) c->h_minor_w[(size_t)a] = spf[a * 5];
+    c->order_cache.clear();
     const int64_t R = c->R;
     if (int rc = c->row0.reserve((size_t)(L + 1) * 4)) return rc;
     if (int rc = c->slot_meta.reserve((size_t)L * 4)) return rc;
@@ -815,6 +904,10 @@ int ensure_rows(ldw_ctx *c) {
         LDW_REQUIRE(R < 2147483647LL, LDW_ERR_ARG, "too many indicator rows");
         if (int rc = fill_rows_bits(c, c->small.as<int32_t>(), R)) return rc;
     }
+    if (int rc = c->snp_sup.reserve((size_t)L * 32)) return rc;
+    hipLaunchKernelGGL(k_snp_sup, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, c->stream, L, c->slot_meta.as<uint32_t>(), c->slot_pfix.as<int64_t>(),
+                       c->r.as<double>(), std::ldexp(1.0, -c->frac_bits), c->neff, c->r_min, c->snp_sup.as<double>());
+    LDW_HIP(hipGetLastError());
     LDW_HIP(hipStreamSynchronize(c->stream));
     c->rows_ready = true;
     c->spec_B_next[0] = c->spec_B_next[1] = -1;   // bucket guesses of an earlier alignment / weighting say nothing about this one

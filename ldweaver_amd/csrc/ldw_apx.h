@@ -44,6 +44,13 @@ struct ApxGemmArgs {
     int tab_nb;
     uint8_t *clean;
     const uint8_t *sr_mask;              // optional [RTpad / 128][RFpad / 64]: tiles that hold a short-range pair are never clean
+    // Tile pruning (P.fuse only): a wave tile whose rows all carry table bins and whose bin rectangle [min, max] x [min, max] holds
+    // only unconditional entries (-1, INT_MAX) — no n' can make such a pair fail the test — flags its regions clean and leaves
+    // before the K loop; lane 0 counts it in *skip_ctr.  Null: every tile is computed.
+    unsigned long long *skip_ctr;
+    // the same for the wider tables: pruning flags (PF_*, ldw_epi.h) of every ROW of the two row lists, 0 for padding rows.  A tile
+    // whose to-rows are all of one kind and dead versus the (one) kind of its from-rows, or the other way round, is not computed.
+    const uint8_t *rflag_t, *rflag_f;
 };
 
 int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st);

@@ -286,6 +286,78 @@ __device__ __forceinline__ void apx_gemm_epilogue(const ApxGemmArgs &P, v16i (&a
     }
 }
 
+// Tile pruning (ApxGemmArgs::skip_ctr): is every pair of the wave tile (TH to-rows x TWd from-rows) one whose table entry is
+// unconditional?  Such an entry (-1, INT_MAX) says that NO joint count lifts a pair of these two marginal bins to the level —
+// the epilogue's test n' > L && n' < H would pass whatever the GEMM computed, so the tile is not computed.  The rows of a
+// block without short-range pairs are ordered by their marginal (prep_block), so a tile spans a few bins per side: the lanes
+// test the whole rectangle [tmin, tmax] x [fmin, fmax] of the table at once (rectangles of more than 64 entries are computed).
+template <int TH, int TWd>
+__device__ __forceinline__ bool apx_tile_prunable(const ApxGemmArgs &P, int ty, int tx, int lane, const int2 *__restrict__ s_tab, bool &all_binned) {
+    all_binned = false;
+    if (P.sr_mask && P.sr_mask[(int64_t)ty * (P.RFpad / 64) + tx] != 0) return false;
+    int tmin = 255, tmax = 0, fmin = 255, fmax = 0;   // 255: a row that is not a biallelic r = 2 SNP's (or padding): no table entry
+    unsigned tand = 0xFFu, tor = 0u, fand = 0xFFu, forr = 0u;   // pruning flags (PF_*) of the rows: AND and OR over the tile
+    for (int r = lane; r < TH; r += 64) {
+        const int b = (int)P.bin_t[ty * TH + r];
+        tmin = b < tmin ? b : tmin;
+        tmax = b > tmax ? b : tmax;
+        if (P.rflag_t) {
+            const unsigned f = P.rflag_t[ty * TH + r];
+            tand &= f;
+            tor |= f;
+        }
+    }
+    for (int r = lane; r < TWd; r += 64) {
+        const int b = (int)P.bin_f[tx * TWd + r];
+        fmin = b < fmin ? b : fmin;
+        fmax = b > fmax ? b : fmax;
+        if (P.rflag_f) {
+            const unsigned f = P.rflag_f[tx * TWd + r];
+            fand &= f;
+            forr |= f;
+        }
+    }
+    // one packed reduction: (tmin, 255 - tmax, fmin, 255 - fmax) by min, the flag bytes by AND / OR
+    unsigned mn = (unsigned)tmin | ((unsigned)(255 - tmax) << 8) | ((unsigned)fmin << 16) | ((unsigned)(255 - fmax) << 24);
+    unsigned fl = tand | ((tor ^ 0xFFu) << 8) | (fand << 16) | ((forr ^ 0xFFu) << 24);   // (OR as AND of the complement)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)mn, off);
+        unsigned r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned a = (mn >> (8 * k)) & 0xFFu, b = (o >> (8 * k)) & 0xFFu;
+            r |= (a < b ? a : b) << (8 * k);
+        }
+        mn = r;
+        fl &= (unsigned)__shfl_xor((int)fl, off);
+    }
+    tmin = (int)(mn & 0xFFu);
+    tmax = 255 - (int)((mn >> 8) & 0xFFu);
+    fmin = (int)((mn >> 16) & 0xFFu);
+    fmax = 255 - (int)(mn >> 24);
+    all_binned = tmax < P.tab_nb && fmax < P.tab_nb;
+    if (P.rflag_t) {   // the wider tables: rows of ONE kind per side, one side dead versus the other's kind (k_snp_sup)
+        tand = fl & 0xFFu;
+        tor = ((fl >> 8) & 0xFFu) ^ 0xFFu;
+        fand = (fl >> 16) & 0xFFu;
+        forr = (fl >> 24) ^ 0xFFu;
+        const unsigned kt = tand & PF_KIND, kf = fand & PF_KIND;
+        if (kt >= 2u && kt == (tor & PF_KIND) && kf >= 2u && kf == (forr & PF_KIND) &&
+            ((tand & (kf == 2u ? PF_DEAD2 : PF_DEAD3)) != 0u || (fand & (kt == 2u ? PF_DEAD2 : PF_DEAD3)) != 0u))
+            return true;
+    }
+    if (!all_binned) return false;
+    const int nbt = tmax - tmin + 1, nbf = fmax - fmin + 1;
+    if (nbt * nbf > 64) return false;
+    bool ok = true;
+    if (lane < nbt * nbf) {
+        const int2 th = s_tab[(tmin + lane / nbf) * P.tab_nb + fmin + lane % nbf];
+        ok = th.x < 0 && th.y == 2147483647;
+    }
+    return __ballot(!ok) == 0ull;
+}
+
 template <int MT, int NT, bool FINE>
 __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -293,6 +365,35 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
     uint8_t *sA = smem + 2048, *sB = sA + (size_t)P.M2 * 128;       // digits by position
     int2 *s_tab = reinterpret_cast<int2 *>(sB + (size_t)P.M2 * 128);  // threshold table (P.fuse)
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ty = 2 * blockIdx.y + (wave >> 1), tx = 2 * blockIdx.x + (wave & 1);
+    constexpr int TH = 32 * MT, TWd = 32 * NT;
+    const bool outside = ty * TH >= P.RTpad || tx * TWd >= P.RFpad || (P.lower_only && tx * TWd + TWd - 1 < ty * TH);
+    bool pruned = false;
+    if (P.fuse && P.skip_ctr) {
+        // tile pruning first, straight from the table in global memory: a workgroup whose wave tiles are all pruned (or outside)
+        // leaves before it has staged anything
+        int *s_live = reinterpret_cast<int *>(smem);
+        if (tid == 0) *s_live = 0;
+        __syncthreads();
+        bool all_binned = false;
+        pruned = !outside && apx_tile_prunable<TH, TWd>(P, ty, tx, lane, P.tab, all_binned);
+        if (pruned) {
+            // (clean flags speak of biallelic x biallelic regions only: k_mi_screen maps a region to a tile and 32 column slots by
+            // row position, which holds there; the other pruned tiles are found again by the screen from the SNPs' flags)
+            if (all_binned && lane < MT * ((NT * 32) / 64)) {
+                const int i = lane / ((NT * 32) / 64), h = lane % ((NT * 32) / 64);
+                P.clean[(int64_t)((ty * TH + 32 * i) / 32) * (P.RFpad / 64) + (tx * TWd) / 64 + h] = 1;
+            }
+            if (lane == 0) atomicAdd(P.skip_ctr, 1ull);
+        } else if (!outside && lane == 0) {
+            *s_live = 1;
+        }
+        __syncthreads();
+        const bool any_live = *s_live != 0;
+        __syncthreads();   // (smem is about to be overwritten)
+        if (!any_live) return;
+    }
     if (P.fuse)
         for (int i = tid; i < P.tab_nb * P.tab_nb; i += 256) s_tab[i] = P.tab[i];
     {
@@ -307,79 +408,77 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
         }
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    const int ty = 2 * blockIdx.y + (wave >> 1), tx = 2 * blockIdx.x + (wave & 1);
-    constexpr int TH = 32 * MT, TWd = 32 * NT;
-    if (ty * TH >= P.RTpad || tx * TWd >= P.RFpad) return;
-    if (P.lower_only && tx * TWd + TWd - 1 < ty * TH) return;
+    if (outside || pruned) return;
     const int frow = lane & 31, fh = lane >> 5;
-    const uint64_t *pa[MT], *pb[NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) pa[i] = P.panel_t + ((int64_t)(ty * TH + 32 * i + frow) * 2 + fh);
-#pragma unroll
-    for (int i = 0; i < NT; ++i) pb[i] = P.panel_f + ((int64_t)(tx * TWd + 32 * i + frow) * 2 + fh);
     const int64_t sta = (int64_t)P.RTpad * 2, stb = (int64_t)P.RFpad * 2;
-    v16i acc[MT][NT];
+    {
+        const uint64_t *pa[MT], *pb[NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) pa[i] = P.panel_t + ((int64_t)(ty * TH + 32 * i + frow) * 2 + fh);
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int i = 0; i < NT; ++i) pb[i] = P.panel_f + ((int64_t)(tx * TWd + 32 * i + frow) * 2 + fh);
+        v16i acc[MT][NT];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
-    uint64_t wa[MT], wb[NT], na[MT], nb[NT];
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int i = 0; i < MT; ++i) na[i] = pa[i][0];
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int i = 0; i < NT; ++i) nb[i] = pb[i][0];
-    for (int m = 0; m < P.M2; ++m) {
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+        uint64_t wa[MT], wb[NT], na[MT], nb[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) wa[i] = na[i];
+        for (int i = 0; i < MT; ++i) na[i] = pa[i][0];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) wb[i] = nb[i];
-        if (m + 1 < P.M2) {
+        for (int i = 0; i < NT; ++i) nb[i] = pb[i][0];
+        for (int m = 0; m < P.M2; ++m) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) na[i] = pa[i][(int64_t)(m + 1) * sta];
+            for (int i = 0; i < MT; ++i) wa[i] = na[i];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) nb[i] = pb[i][(int64_t)(m + 1) * stb];
-        }
-        // FINE: one block exponent per k-step; k-step kk = positions 128 m + 32 kk .. + 31 (k_pack_panel interleaves the panel words
-        // accordingly), lane half fh holds 16 of them.  Coarse (the weights' dynamic range within 128 positions is small: clonal
-        // data): one exponent per macro step, k-step kk = bits 16 kk of the plain words 0 and 1 — 4 % faster (0.517 vs 0.538 ms).
-        const int4 sh4 = reinterpret_cast<const int4 *>(P.shift)[m];   // (wave-uniform: one scalar load per macro step)
-        const int shk[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
-        const uint8_t *dA = sA + m * 128 + fh * (FINE ? 16 : 64), *dB = sB + m * 128 + fh * (FINE ? 16 : 64);
+            for (int i = 0; i < NT; ++i) wb[i] = nb[i];
+            if (m + 1 < P.M2) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int sh = shk[kk];
-            if ((FINE || kk == 0) && sh) {
+                for (int i = 0; i < MT; ++i) na[i] = pa[i][(int64_t)(m + 1) * sta];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) nb[i] = pb[i][(int64_t)(m + 1) * stb];
+            }
+            // FINE: one block exponent per k-step; k-step kk = positions 128 m + 32 kk .. + 31 (k_pack_panel interleaves the panel words
+            // accordingly), lane half fh holds 16 of them.  Coarse (the weights' dynamic range within 128 positions is small: clonal
+            // data): one exponent per macro step, k-step kk = bits 16 kk of the plain words 0 and 1 — 4 % faster (0.517 vs 0.538 ms).
+            const int4 sh4 = reinterpret_cast<const int4 *>(P.shift)[m];   // (wave-uniform: one scalar load per macro step)
+            const int shk[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+            const uint8_t *dA = sA + m * 128 + fh * (FINE ? 16 : 64), *dB = sB + m * 128 + fh * (FINE ? 16 : 64);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int sh = shk[kk];
+                if ((FINE || kk == 0) && sh) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[i][j][e] = (int)((unsigned)acc[i][j][e] >> sh);
+                }
+                const v4i da = *reinterpret_cast<const v4i *>(dA + (FINE ? 32 : 16) * kk);
+                const v4i db = *reinterpret_cast<const v4i *>(dB + (FINE ? 32 : 16) * kk);
+                v4i fa[MT], fb[NT];
+                typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const u64x2v qa = {lutFF[(wa[i] >> (16 * kk)) & 0xFFu], lutFF[(wa[i] >> (16 * kk + 8)) & 0xFFu]};
+                    fa[i] = __builtin_bit_cast(v4i, qa) & da;
+                }
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const u64x2v qb = {lutFF[(wb[i] >> (16 * kk)) & 0xFFu], lutFF[(wb[i] >> (16 * kk + 8)) & 0xFFu]};
+                    fb[i] = __builtin_bit_cast(v4i, qb) & db;
+                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[i][j][e] = (int)((unsigned)acc[i][j][e] >> sh);
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
-            const v4i da = *reinterpret_cast<const v4i *>(dA + (FINE ? 32 : 16) * kk);
-            const v4i db = *reinterpret_cast<const v4i *>(dB + (FINE ? 32 : 16) * kk);
-            v4i fa[MT], fb[NT];
-            typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const u64x2v qa = {lutFF[(wa[i] >> (16 * kk)) & 0xFFu], lutFF[(wa[i] >> (16 * kk + 8)) & 0xFFu]};
-                fa[i] = __builtin_bit_cast(v4i, qa) & da;
-            }
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const u64x2v qb = {lutFF[(wb[i] >> (16 * kk)) & 0xFFu], lutFF[(wb[i] >> (16 * kk + 8)) & 0xFFu]};
-                fb[i] = __builtin_bit_cast(v4i, qb) & db;
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
+        apx_gemm_epilogue<MT, NT>(P, acc, ty, tx, lane, s_tab, reinterpret_cast<uint8_t *>(s_tab + 64 * 64) + wave * 256);
     }
-    apx_gemm_epilogue<MT, NT>(P, acc, ty, tx, lane, s_tab, reinterpret_cast<uint8_t *>(s_tab + 64 * 64) + wave * 256);
 }
 // ------------------------------------------------------------------------------------------------
 // gemm_apx_pipe_kernel (r03 experiment, LDW_APX_KERNEL=pipe; coarse exponents only): the register-expansion kernel with the expansion
@@ -729,6 +828,10 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
         c->gemm_stat[0] += 1;
         if (P.fuse) c->gemm_stat[5] += 1;
         c->gemm_stat[1] += 2.0 * (double)waves * TH * TWd * ((double)P.M2 * 128.0);
+        if (P.fuse && P.skip_ctr) {   // the tiles the kernel prunes are taken off again when the counter is read (ldw_gemm_stats, ldw_links_end)
+            c->apx_ops_per_wave = 2.0 * TH * TWd * ((double)P.M2 * 128.0);
+            c->apx_waves_total += waves;
+        }
     }
     return LDW_OK;
 }

@@ -251,8 +251,20 @@ struct EpiArgs {
     // clean[(q / 32) * clean_stride + tile]; null: no such information
     const uint8_t *clean;
     int clean_stride;
+    // Pruning flags of the block's SNPs in epilogue order (k_build_packs; null: none): PF_KIND = 2 or 3 flagged states with r to match
+    // (0: anything else), PF_DEAD2 / PF_DEAD3 = the SNP cannot reach the block's level with ANY partner of kind 2 / 3 (k_snp_sup).
+    // sflag_f[64 * tile + lane], sflag_t[column slot]
+    const uint8_t *sflag_f, *sflag_t;
+    const double *snp_sup;    // [L][4] (k_snp_sup)
     EmitArgs E;
 };
+constexpr unsigned PF_KIND = 3u, PF_DEAD2 = 4u, PF_DEAD3 = 8u, PF_PAD = 0x80u;
+// may the pair of two SNPs with these flags be dropped unseen?  (either one is dead versus the other's kind)
+__host__ __device__ __forceinline__ bool pf_pair_dead(unsigned fa, unsigned fb) {
+    const unsigned ka = fa & PF_KIND, kb = fb & PF_KIND;
+    if (ka < 2u || kb < 2u) return false;
+    return (fa & (kb == 2u ? PF_DEAD2 : PF_DEAD3)) != 0u || (fb & (ka == 2u ? PF_DEAD2 : PF_DEAD3)) != 0u;
+}
 __host__ __device__ __forceinline__ int tab_bin(float p, float c, int nb) {
     const int b = (int)(sqrtf(p > 0.0f ? p : 0.0f) * c);
     return b < nb - 1 ? b : nb - 1;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/ldweaver_amd.h"
@@ -116,6 +117,20 @@ struct ldw_ctx {
     ldw::DevBuf apx_bins[2], apx_clean[2];    // per slot: threshold-table bin of every row of the two row lists; clean-region flags of the GEMM epilogue
     ldw::DevBuf apx_units[2], apx_packs[2];   // per slot: per-(tile, class) unit lists + counters; per-block SNP constants
     int64_t apx_blocks = 0, apx_units_listed = 0, apx_pairs_listed = 0, probe_blocks = 0, generic_blocks = 0;
+    // Tile pruning: in blocks without a short-range pair the one-row SNPs are ordered by the weight of their minor
+    // state, so that a wave tile of the approximate GEMM spans few bins of the threshold table; a tile whose whole bin rectangle is
+    // unconditionally below the level (no joint count can lift such a pair to it) is flagged clean without being computed.
+    bool prune = true;                 // LDW_NO_PRUNE switches ordering and skipping off (A/B measurements)
+    ldw::DevBuf apx_skip;              // uint64: wave tiles the GEMM skipped since the counter was last read
+    double apx_ops_per_wave = 0;       // executed-operation accounting of the skipped tiles (ldw_gemm_stats)
+    int64_t apx_waves_skipped = 0, apx_waves_total = 0, sorted_blocks = 0;
+    // Per-SNP bound behind the pruning of the wider tables (k_snp_sup): snp_sup[a * 4 + 2 * m + (k - 2)] = the largest MI SNP a (2 or
+    // 3 states, all flagged, r = its number of states) can reach with ANY partner of k = 2 or 3 flagged states and r = k, in the
+    // intended (m = 0) and the reference (m = 1: RXY at its floor r_min^2 / 4) reading of RXY; +inf for other SNPs.
+    ldw::DevBuf snp_sup;
+    double r_min = 0;                  // smallest r of the alignment (ldw_set_snp_meta)
+    struct OrderCache { std::vector<int32_t> idx, order; };
+    std::vector<std::unique_ptr<OrderCache>> order_cache;   // per SNP list: its one-row SNPs in ascending order of the minor state's weight
 
     // ---- per-SNP meta ----
     bool have_meta = false;
@@ -142,6 +157,7 @@ struct ldw_ctx {
     std::vector<int32_t> h_row0;
     std::vector<uint32_t> h_slot_meta;
     std::vector<int32_t> h_counts;
+    std::vector<int64_t> h_minor_w;   // [L]: fixed-point weight of slot 0 of a biallelic r = 2 SNP with one row (else INT64_MAX)
 
     // ---- per-block workspaces ----
     ldw::DevBuf G, G2;           // int64 [RTpad][RFpad] fixed-point joint sums, one per pipeline slot

@@ -49,9 +49,21 @@ __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *_
                                                      int nf_slots, int with_hi, ColMeta *__restrict__ cp, ColMeta *__restrict__ cp_hi,
                                                      RowPack *__restrict__ rp, RowPack *__restrict__ rp_hi, float *__restrict__ rloc_f,
                                                      float *__restrict__ rloc_t, uint8_t *__restrict__ bin_t = nullptr,
-                                                     uint8_t *__restrict__ bin_f = nullptr, int RTpad = 0, int RFpad = 0) {
+                                                     uint8_t *__restrict__ bin_f = nullptr, int RTpad = 0, int RFpad = 0,
+                                                     uint8_t *__restrict__ sflag_f = nullptr, uint8_t *__restrict__ sflag_t = nullptr,
+                                                     uint8_t *__restrict__ rflag_f = nullptr, uint8_t *__restrict__ rflag_t = nullptr) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool square = A.nf == A.nt;
+    // pruning flags (PF_*): kind of the SNP and whether its bound (k_snp_sup) stays below the block's level for partners of kind 2 / 3;
+    // by epilogue slot for the screen, by row of the row lists (zeroed beforehand: padding rows) for the approximate GEMM
+    const double lvl = A.E.spec_lo - (double)A.E.scr_eps;
+    auto prune_flags = [&](int snp, uint32_t meta, double r) -> unsigned {
+        const int n = (int)(meta & 7);
+        const uint32_t full = (2u << n) - 1u;
+        if (!(n == 1 || n == 2) || ((meta >> 3) & full) != full || r != (double)(n + 1)) return 0u;
+        const double *sp = A.snp_sup + (int64_t)snp * 4 + (A.quirk == LDW_QUIRK_REFERENCE ? 2 : 0);
+        return (unsigned)(n + 1) | (sp[0] < lvl ? PF_DEAD2 : 0u) | (sp[1] < lvl ? PF_DEAD3 : 0u);
+    };
     // bins of the threshold table by ROW of the two row lists for the GEMM's epilogue test (only used when the host has checked
     // that a one-row SNP's position in its row list equals its slot here: no SNP without a row in the block)
     int my_bt = 255, my_bf = 255;
@@ -62,6 +74,11 @@ __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *_
         load_col(A, perm_t, square, i, m, false);
         cp[i] = m;
         if ((m.mb & 7) == 1 && col_is_fast(m.mb) && m.rb == 2.0) my_bt = m.pad2 & 63;
+        if (sflag_t) {
+            const unsigned f = prune_flags(m.sb, m.mb, m.rb);
+            sflag_t[i] = (uint8_t)f;
+            for (int j = 0; j < (int)(m.mb & 7); ++j) rflag_t[m.rb0 + j] = (uint8_t)f;
+        }
         if (with_hi) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) m.pb[j] = A.lo.slot_pfix_hi[(int64_t)m.sb * 5 + j];
@@ -76,6 +93,12 @@ __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *_
         P.pad = A.tab11 ? tab_bin(P.R.pXf[0], A.tab_c, A.tab_nb) : 0;   // bin of the minor-state marginal (threshold table)
         rp[i] = P;
         if (ok && P.R.na == 1 && ((P.R.ma >> 3) & 3u) == 3u && P.R.ra == 2.0) my_bf = P.pad & 63;
+        if (sflag_f) {
+            const unsigned f = ok ? prune_flags(P.R.sa, P.R.ma, P.R.ra) : PF_PAD;
+            sflag_f[i] = (uint8_t)f;
+            if (ok)
+                for (int j = 0; j < P.R.na; ++j) rflag_f[P.R.ra0 + j] = (uint8_t)f;
+        }
         if (with_hi) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) P.R.pa[k] = A.lo.slot_pfix_hi[(int64_t)P.R.sa * 5 + k];
@@ -357,17 +380,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         }
         if (all_clean) return;
     }
+    const int wave = threadIdx.x >> 6;
+    const int c_first = wave * (EPI_COLS / 4);
+    const int q_base = blockIdx.y * EPI_COLS + c_first;
+    int n_it = A.nt - q_base;
+    n_it = n_it > EPI_COLS / 4 ? EPI_COLS / 4 : n_it;
+    // pruning by kind (k_snp_sup): columns whose pairs with EVERY SNP of the tile are dead — the tile's SNPs all dead versus the
+    // column's kind, or all of one kind the column's SNP is dead against — are dismissed unread (the approximate GEMM has not
+    // even computed most of their sums: apx_tile_prunable).  Not in verify mode, which has to see what is dismissed.  From the
+    // flags alone, so that a workgroup with nothing else to do leaves before it stages anything.
+    unsigned int dead_cols = 0, tri_cols = 0;
+    // Diagonal blocks (lower_only: a pair exists once, with a_loc > b_loc): both epilogue orders keep the list order within a class,
+    // so about half of the (tile, column) combinations hold no pair at all — columns whose SNP comes after every SNP of the tile.
+    // They used to run the whole bound and mask the result.
+    if (A.E.lower_only) {
+        int amax = perm_f[blockIdx.x * 64 + (threadIdx.x & 63)];   // (-1: padding slot)
+        const int pb = (int)(threadIdx.x & 63) < n_it ? perm_t[q_base + (threadIdx.x & 63)] : 0x7FFFFFFF;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_xor(amax, off);
+            amax = o > amax ? o : amax;
+        }
+        dead_cols = (unsigned int)__ballot((int)(threadIdx.x & 63) < n_it && pb >= amax);
+        tri_cols = dead_cols;
+        if (__syncthreads_and((n_it <= 0 || (n_it == EPI_COLS / 4 && dead_cols == 0xFFFFFFFFu)) ? 1 : 0)) return;
+    }
+    if (APX && A.sflag_f && A.E.scr_mode != 2 && A.E.do_lr && !A.E.any_sr) {
+        const unsigned fa = A.sflag_f[blockIdx.x * 64 + (threadIdx.x & 63)];
+        const bool real = (fa & PF_PAD) == 0u;   // (a padding slot of the tile: no SNP)
+        const unsigned ka = fa & PF_KIND;
+        const bool all_k2 = __ballot(real && ka != 2u) == 0ull, all_k3 = __ballot(real && ka != 3u) == 0ull;
+        if ((all_k2 || all_k3) && __ballot(real) != 0ull) {
+            const bool all_dead2 = __ballot(real && !(fa & PF_DEAD2)) == 0ull, all_dead3 = __ballot(real && !(fa & PF_DEAD3)) == 0ull;
+            const unsigned fb = (int)(threadIdx.x & 63) < n_it ? (unsigned)A.sflag_t[q_base + (threadIdx.x & 63)] : 0u;
+            const unsigned kb = fb & PF_KIND;
+            const bool dead = kb >= 2u && ((kb == 2u ? all_dead2 : all_dead3) || (fb & (all_k2 ? PF_DEAD2 : PF_DEAD3)) != 0u);
+            dead_cols |= (unsigned int)__ballot(dead);
+        }
+        const bool wave_done = n_it <= 0 || (n_it == EPI_COLS / 4 && dead_cols == 0xFFFFFFFFu);
+        if (__syncthreads_and(wave_done ? 1 : 0)) return;
+    }
     stage_cols(A, perm_t, square, cm, mixed);
     __syncthreads();
     RowSide R;
     int a_loc, na0;
     const bool a_ok = load_row_side(A, perm_f, square, blockIdx.x, R, a_loc, mixed);
     const bool wave_full = wave_is_full(R, a_ok, na0);
-    const int wave = threadIdx.x >> 6;
-    const int c_first = wave * (EPI_COLS / 4);
-    const int q_base = blockIdx.y * EPI_COLS + c_first;
-    int n_it = A.nt - q_base;
-    n_it = n_it > EPI_COLS / 4 ? EPI_COLS / 4 : n_it;
     if (n_it <= 0) return;
     const float lo = (float)A.E.spec_lo - A.E.scr_eps;
     // threshold-table path: every SNP of the tile biallelic with r = 2, long-range pass
@@ -391,6 +449,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         handled = 0xFFFFFFFFu;
     } else if (wave_full) {
         for (int it = 0; it < n_it; it += U) {
+            if (((dead_cols >> it) & ((1u << U) - 1u)) == ((1u << U) - 1u) && it + U <= n_it && A.E.scr_mode != 2) {
+                handled |= ((1u << U) - 1u) << it;
+                continue;
+            }
             const ColMeta *cmu = &cm[c_first + it];
             // the U columns of a group share one code path if they have the same slot count (the rule away from class borders)
             bool same = it + U <= n_it;
@@ -430,6 +492,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         }
     }
     const unsigned int all = n_it >= 32 ? 0xFFFFFFFFu : ((1u << n_it) - 1u);
+    if (A.E.scr_mode != 2) handled |= tri_cols;   // (columns without a pair need nobody's attention, whatever the tile looks like; verify mode lists
+                                                  // every unit and reads `handled` as "straight-line code applies": left alone there)
     wanted = (wanted | ~handled) & all;
     list_wave_units(A, cm, c_first, q_base, n_it, all, wanted, handled, units, n_units, list_stride);
 }
@@ -656,13 +720,13 @@ __global__ __launch_bounds__(256) void k_mi_units(EpiArgs A, const int32_t *__re
 // one launch instead of four or five hipMemsetAsync per block (each a 4-5 us kernel of its own plus a dispatch gap): zeroes up to
 // four small buffers, sizes in 16-byte pieces
 struct ZeroArgs {
-    uint4 *p[5];
-    unsigned int n16[5];
+    uint4 *p[6];
+    unsigned int n16[6];
 };
 __global__ __launch_bounds__(256) void k_zero4(ZeroArgs Z) {
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < 6; ++k)
         for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < Z.n16[k]; i += gridDim.x * 256u) Z.p[k][i] = z;
 }
 
@@ -1332,16 +1396,22 @@ struct SideLists {
     int Rpad = 0;
 };
 
-int build_side(ldw_ctx *c, const int32_t *idx, int64_t n, SideLists &S) {
+// order1 (optional): the list positions of the SNPs of class 1 in the order their rows are to take (prep_block: by the weight of
+// the minor state); the other classes, and class 1 without it, keep the list order.
+int build_side(ldw_ctx *c, const int32_t *idx, int64_t n, SideLists &S, const std::vector<int32_t> *order1 = nullptr) {
     S.lrow.assign((size_t)n, 0);
     S.rowlist.clear();
     S.pos.clear();
     S.cls.clear();
     const int32_t zero_row = (int32_t)c->R;   // rows R .. R+TILE-1 of Mbits are zero
+    for (int64_t k = 0; k < n; ++k)
+        LDW_REQUIRE(idx[k] >= 0 && idx[k] < c->L, LDW_ERR_ARG, "SNP index %d out of range 0..%lld", idx[k], (long long)c->L - 1);
     for (int cl : {1, 2, 4}) {
-        for (int64_t k = 0; k < n; ++k) {
+        const bool ordered = cl == 1 && order1 != nullptr;
+        const int64_t cnt = ordered ? (int64_t)order1->size() : n;
+        for (int64_t kk = 0; kk < cnt; ++kk) {
+            const int64_t k = ordered ? (int64_t)(*order1)[(size_t)kk] : kk;
             const int32_t a = idx[k];
-            if (cl == 1) LDW_REQUIRE(a >= 0 && a < c->L, LDW_ERR_ARG, "SNP index %d out of range 0..%lld", a, (long long)c->L - 1);
             const int nr = c->h_row0[a + 1] - c->h_row0[a];
             const int mine = nr <= 1 ? 1 : (nr == 2 ? 2 : 4);
             if (mine != cl) continue;
@@ -1490,6 +1560,7 @@ struct LoHost {
     int32_t n_tiles_cf[3] = {0, 0, 0};   // from-tiles whose widest row-slot class is 1, 2, 4
     int band_full = 0;                   // the exact GEMM has to cover every tile (a SNP with unflagged slots: its units are not screened)
     int apx = 0, slot = 0, diag = 0;     // approximate-GEMM path (ldw_apx.h) instead of the high-limb GEMM + gathered low limbs
+    int ordered = 0;                     // rows of the one-row SNPs in order of the minor state's weight (prep_block: tile pruning)
     int fuse_ok = 0;                     // rows of one-row SNPs sit at their slot index in both row lists (no SNP without a row): the
                                          // GEMM's epilogue may apply the threshold table by row (ApxGemmArgs::fuse)
 };
@@ -1523,6 +1594,8 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
     A.tab11 = nullptr;
     A.clean = nullptr;
     A.clean_stride = 0;
+    A.sflag_f = A.sflag_t = nullptr;
+    A.snp_sup = nullptr;
     A.tab_nb = 0;
     A.tab_c = 0;
     A.E = E;
@@ -1751,8 +1824,12 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * pair_cap_for(nf, nt) * sizeof(PairEnt))) return rc;
         if (need_exact)
             if (int rc = Gx.reserve((size_t)RFpad * RTpad * 8)) return rc;
-        if (int rc = c->apx_bins[s].reserve((size_t)RTpad + (size_t)RFpad + 64)) return rc;
+        if (int rc = c->apx_bins[s].reserve(2 * ((size_t)RTpad + (size_t)RFpad) + (size_t)nt + (size_t)nf_slots + 128)) return rc;
         if (int rc = c->apx_clean[s].reserve((size_t)(RTpad / 32) * (size_t)(RFpad / 64) + 64)) return rc;
+        if (!c->apx_skip.p) {
+            if (int rc = c->apx_skip.reserve(64)) return rc;
+            LDW_HIP(hipMemsetAsync(c->apx_skip.p, 0, 64, gs));
+        }
     }
     if (phase == 1) {
         if (E.do_lr && c->tab11_on) {
@@ -1782,7 +1859,9 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     fill_epi_args(c, D, nf, nt, RFpad, quirk, E, reinterpret_cast<const int64_t *>(c->Gapx[s].p), A);
     A.lo.slot_pfix_hi = c->slot_papx.as<int64_t>();   // the screen derives its cells from the marginals of the approximate weights
     const int kd_tab = lo_h->diag ? 1 : 0;
-    if (E.do_lr && c->tab11_on && c->tab11[kd_tab].p && c->tab11_lo[kd_tab] > 0 && E.spec_lo - (double)E.scr_eps >= c->tab11_lo[kd_tab]) {
+    // (the table is built for RXY = 1, the floor of the reference's scrambled RXY = r r' / 4 as long as no SNP has r < 2)
+    if (E.do_lr && c->tab11_on && c->tab11[kd_tab].p && c->tab11_lo[kd_tab] > 0 && E.spec_lo - (double)E.scr_eps >= c->tab11_lo[kd_tab] &&
+        (quirk != LDW_QUIRK_REFERENCE || c->r_min >= 2.0)) {
         A.tab11 = c->tab11[kd_tab].as<int2>();
         A.tab_nb = c->tab11_nb;
         A.tab_c = c->tab11_c;
@@ -1792,6 +1871,14 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     const bool fuse = fuse_on && lo_h->fuse_ok && A.tab11 && A.tab_nb == 64 && (use_pairs || c->screen == 2) && E.do_lr && (!E.any_sr || (D.band_mask && !lo_h->band_full)) && RFpad % 64 == 0 &&   // (verify mode: the clean regions' units are listed as dismissed and checked in fp64)
                       2048 + (size_t)(c->KW / 2) * 256 + 64 * 64 * 8 + 1024 <= 65536;   // (the table shares the GEMM's LDS with the digit arrays)
     uint8_t *bin_t = c->apx_bins[s].as<uint8_t>(), *bin_f = bin_t + RTpad;
+    // pruning flags by row (zeroed per block: padding rows) and by epilogue slot
+    uint8_t *rflag_t = bin_f + RFpad, *rflag_f = rflag_t + RTpad, *sflag_t = rflag_f + RFpad, *sflag_f = sflag_t + ((size_t)nt + 15) / 16 * 16;
+    const bool wide_prune = c->prune && c->snp_sup.p && E.do_lr && use_pairs;
+    if (wide_prune) {
+        A.snp_sup = c->snp_sup.as<double>();
+        A.sflag_f = sflag_f;
+        A.sflag_t = sflag_t;
+    }
     if (fuse) {
         A.clean = c->apx_clean[s].as<uint8_t>();
         A.clean_stride = RFpad / 64;
@@ -1827,6 +1914,10 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
                 Z.p[4] = reinterpret_cast<uint4 *>(c->apx_clean[s].p);
                 Z.n16[4] = (unsigned int)(((size_t)(RTpad / 32) * (size_t)(RFpad / 64) + 15) / 16);
             }
+            if (wide_prune) {
+                Z.p[5] = reinterpret_cast<uint4 *>(rflag_t);
+                Z.n16[5] = (unsigned int)(((size_t)RTpad + (size_t)RFpad) / 16);
+            }
             if (zero_hist) {
                 Z.p[2] = reinterpret_cast<uint4 *>(zero_hist);
                 Z.n16[2] = (unsigned int)(NBINS * 8 / 16);
@@ -1838,7 +1929,8 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         // the per-SNP constants in epilogue order — before the GEMM: its epilogue reads the table bins by row
         const int nthr = std::max<int>(std::max<int>((int)nt, nf_slots), std::max<int>(RTpad, RFpad));
         hipLaunchKernelGGL(k_build_packs, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, gs, A, D.perm, D.perm_t, nf_slots, 1, cp, cph, rp, rph,
-                           rlf, rlt, bin_t, bin_f, RTpad, RFpad);
+                           rlf, rlt, bin_t, bin_f, RTpad, RFpad, wide_prune ? sflag_f : nullptr, wide_prune ? sflag_t : nullptr, wide_prune ? rflag_f : nullptr,
+                           wide_prune ? rflag_t : nullptr);
         LDW_HIP(hipGetLastError());
         LDW_HIP(hipEventRecord(ev[0], gs));   // ev[0] .. ev[1]: the approximate GEMM alone (its launch time is the roofline's)
         if (E.do_lr) {
@@ -1857,6 +1949,11 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             P.lower_only = E.lower_only;
             if (fuse) {
                 P.fuse = 1;
+                P.skip_ctr = (c->prune && lo_h->ordered) ? c->apx_skip.as<unsigned long long>() : nullptr;   // (list order: a tile spans every bin)
+                if (P.skip_ctr && wide_prune) {
+                    P.rflag_t = rflag_t;
+                    P.rflag_f = rflag_f;
+                }
                 P.bin_t = bin_t;
                 P.bin_f = bin_f;
                 P.tab = A.tab11;
@@ -1944,22 +2041,47 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
 // The same for the from side of the epilogue kernels, which walk it in tiles of 64 (one wave): every class is padded
 // with -1 to a multiple of 64, so no tile mixes slot counts — a mixed tile cannot take the straight-line code and
 // would have all of its units listed for the fp64 kernel (and for the gathered low-limb GEMM).
-void build_perm_tiles(ldw_ctx *c, const int32_t *from_idx, int64_t nf, std::vector<int32_t> &perm) {
+void build_perm_tiles(ldw_ctx *c, const int32_t *from_idx, int64_t nf, std::vector<int32_t> &perm, const std::vector<int32_t> *order1 = nullptr) {
     perm.clear();
     for (int want : {1, 2, 3, 4, 0}) {
-        for (int64_t k = 0; k < nf; ++k)
-            if (c->h_row0[from_idx[k] + 1] - c->h_row0[from_idx[k]] == want) perm.push_back((int32_t)k);
+        if (want == 1 && order1) perm.insert(perm.end(), order1->begin(), order1->end());   // (every one-row SNP, in row order: build_side)
+        else
+            for (int64_t k = 0; k < nf; ++k)
+                if (c->h_row0[from_idx[k] + 1] - c->h_row0[from_idx[k]] == want) perm.push_back((int32_t)k);
         if (want != 3)   // 3 and 4 rows share the generic code anyway
             while (perm.size() % 64) perm.push_back(-1);
     }
     if (perm.empty()) perm.assign(64, -1);
 }
 
-void build_perm(ldw_ctx *c, const int32_t *from_idx, int64_t nf, int32_t *perm) {
+void build_perm(ldw_ctx *c, const int32_t *from_idx, int64_t nf, int32_t *perm, const std::vector<int32_t> *order1 = nullptr) {
     int64_t w = 0;
-    for (int want : {1, 2, 3, 4, 0})
+    for (int want : {1, 2, 3, 4, 0}) {
+        if (want == 1 && order1) {
+            for (int32_t k : *order1) perm[w++] = k;
+            continue;
+        }
         for (int64_t k = 0; k < nf; ++k)
             if (c->h_row0[from_idx[k] + 1] - c->h_row0[from_idx[k]] == want) perm[w++] = (int32_t)k;
+    }
+}
+
+// The one-row SNPs of a list in ascending order of h_minor_w (ties in list order), cached per list: the all-pairs loop presents
+// the same ten or fifty lists over and over, and a sort of 10^4 keys costs as much host time as the rest of prep_block.
+const std::vector<int32_t> *minor_weight_order(ldw_ctx *c, const int32_t *idx, int64_t n) {
+    for (auto &pe : c->order_cache)
+        if ((int64_t)pe->idx.size() == n && pe->idx[0] == idx[0] && memcmp(pe->idx.data(), idx, (size_t)n * 4) == 0) return &pe->order;
+    c->order_cache.emplace_back(new ldw_ctx::OrderCache());   // (entries are heap objects: the pointers handed out survive the vector's growth)
+    auto &e = *c->order_cache.back();
+    e.idx.assign(idx, idx + n);
+    std::vector<std::pair<int64_t, int32_t>> key;
+    key.reserve((size_t)n);
+    for (int64_t k = 0; k < n; ++k)
+        if (c->h_row0[idx[k] + 1] - c->h_row0[idx[k]] == 1) key.emplace_back(c->h_minor_w[(size_t)idx[k]], (int32_t)k);
+    std::sort(key.begin(), key.end());
+    e.order.resize(key.size());
+    for (size_t i = 0; i < key.size(); ++i) e.order[i] = key[i].second;
+    return &e.order;
 }
 
 // dense MI of one block, synchronous staging through ctx-owned buffers (ldw_mi_block, ldw_joint_tables style)
@@ -2068,10 +2190,6 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     hb.blk_no = blk_no;
     hb.diag = same_list(from_idx, nf, to_idx, nt);
     SideLists SF, ST;
-    if (int rc = build_side(c, from_idx, nf, SF)) return rc;
-    if (int rc = build_side(c, to_idx, nt, ST)) return rc;
-    hb.RFpad = SF.Rpad;
-    hb.RTpad = ST.Rpad;
     std::vector<ColInfo> cols;
     auto ascending = [&](const int32_t *idx, int64_t n) {
         for (int64_t k = 1; k < n; ++k)
@@ -2085,6 +2203,26 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
         cols.assign((size_t)nt, z);
         hb.n_sr_blk = 0;
     } else if (int rc = build_cols(c, from_idx, nf, to_idx, nt, hb.diag, p->sr_dist, cols, hb.n_sr_blk)) return rc;
+    // Blocks without a short-range pair (most off-diagonal ones): nothing depends on the order of the rows within a class, so the
+    // one-row SNPs are ordered by the weight of their minor state on both sides — rows and epilogue slots alike, which the table
+    // test of the GEMM's epilogue requires anyway.  The wave tiles of the approximate GEMM then span few bins of the threshold
+    // table and the tiles of the rare x rare corner are pruned whole (apx_tile_prunable).
+    const std::vector<int32_t> *ord_f = nullptr, *ord_t = nullptr;
+    if (c->prune && !hb.generic && hb.n_sr_blk == 0 && !hb.diag && c->engine == LDW_ENGINE_MFMA && c->apx_ok && !c->fused) {
+        bool rowless = false;
+        for (int64_t k = 0; k < nf && !rowless; ++k) rowless = c->h_row0[from_idx[k] + 1] == c->h_row0[from_idx[k]];
+        for (int64_t k = 0; k < nt && !rowless; ++k) rowless = c->h_row0[to_idx[k] + 1] == c->h_row0[to_idx[k]];
+        if (!rowless) {
+            if (c->order_cache.size() >= 256) c->order_cache.clear();   // (before the two look-ups of this block, never between them)
+            ord_f = minor_weight_order(c, from_idx, nf);
+            ord_t = minor_weight_order(c, to_idx, nt);
+            ++c->sorted_blocks;
+        }
+    }
+    if (int rc = build_side(c, from_idx, nf, SF, ord_f)) return rc;
+    if (int rc = build_side(c, to_idx, nt, ST, ord_t)) return rc;
+    hb.RFpad = SF.Rpad;
+    hb.RTpad = ST.Rpad;
     hb.n_lr_total = (hb.diag ? nf * (nf - 1) / 2 : nf * nt - std::min(nf, nt)) - hb.n_sr_blk;
     auto al = [](size_t x) { return (x + 63) / 64 * 64; };
     size_t o = 0;
@@ -2095,7 +2233,7 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     hb.o_lrow_f = o; o = al(o + (size_t)nf * 4);
     hb.o_lrow_t = o; o = al(o + (size_t)nt * 4);
     std::vector<int32_t> pf;
-    build_perm_tiles(c, from_idx, nf, pf);
+    build_perm_tiles(c, from_idx, nf, pf, ord_f);
     hb.nf_tiles = (int)(pf.size() / 64);
     {   // where the SNPs with 1 or 2 indicator rows end in either order
         int64_t n12f = 0, n1 = 0, n2 = 0;
@@ -2224,6 +2362,7 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
             }
     }
     hb.lo.fuse_ok = no_rowless ? 1 : 0;
+    hb.lo.ordered = ord_f != nullptr ? 1 : 0;
     hb.o_cmax = o; o = al(o + cmax.size() * 4);
     hb.o_tbase = o; o = al(o + tbase.size() * 8);
     hb.o_tf = o; o = al(o + tf.size() * 4);
@@ -2244,7 +2383,7 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     memcpy(b + hb.o_lrow_f, SF.lrow.data(), (size_t)nf * 4);
     memcpy(b + hb.o_lrow_t, ST.lrow.data(), (size_t)nt * 4);
     memcpy(b + hb.o_perm, pf.data(), pf.size() * 4);
-    build_perm(c, to_idx, nt, reinterpret_cast<int32_t *>(b + hb.o_perm_t));
+    build_perm(c, to_idx, nt, reinterpret_cast<int32_t *>(b + hb.o_perm_t), ord_t);
     memcpy(b + hb.o_cols, cols.data(), cols.size() * sizeof(ColInfo));
     memcpy(b + hb.o_pos_f, SF.pos.data(), SF.pos.size() * 4);
     memcpy(b + hb.o_pos_t, ST.pos.data(), ST.pos.size() * 4);
@@ -2938,6 +3077,11 @@ int ldw_links_end(ldw_ctx *c) {
     LDW_HIP(hipMemcpyAsync(&h_lr, sl.lr_count, 8, hipMemcpyDeviceToHost, c->stream));
     LDW_HIP(hipMemcpyAsync(&h_viol, sl.lr_count + 1, 8, hipMemcpyDeviceToHost, c->stream));
     LDW_HIP(hipMemcpyAsync(h_apx, sl.lr_count + 2, 16, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long h_skip = 0;
+    if (c->apx_skip.p) {   // wave tiles the approximate GEMMs pruned: not executed work (ldw_gemm_stats)
+        LDW_HIP(hipMemcpyAsync(&h_skip, c->apx_skip.p, 8, hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipMemsetAsync(c->apx_skip.p, 0, 8, c->stream));
+    }
     if (nb > 0) {
         LDW_HIP(hipMemcpyAsync(si.data(), sl.stats_i, (size_t)nb * 24, hipMemcpyDeviceToHost, c->stream));
         LDW_HIP(hipMemcpyAsync(sd.data(), sl.stats_d, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
@@ -2947,6 +3091,8 @@ int ldw_links_end(ldw_ctx *c) {
     c->screen_violations += h_viol;
     c->apx_units_listed += h_apx[0];
     c->apx_pairs_listed += h_apx[1];
+    c->apx_waves_skipped += (int64_t)h_skip;
+    c->gemm_stat[1] -= (double)h_skip * c->apx_ops_per_wave;
     c->stats.resize((size_t)nb);
     for (int64_t b = 0; b < nb; ++b) {
         c->stats[b].n_lr_total = si[b * 3 + 0];

@@ -76,6 +76,15 @@ class Engine:
         return dict(apx_blocks=int(v[0]), mixed_blocks=int(v[1]), plain_blocks=int(v[2]), fused_blocks=int(v[3]), spec_misses=int(v[4]),
                     probe_blocks=int(v[5]), pairs_listed=int(v[6]), units_listed=int(v[7]), apx_gate=buf.value.decode())
 
+    def set_prune(self, on: bool):
+        """Tile pruning of the approximate path (default on): rows ordered by minor-state weight, rare x rare tiles never computed."""
+        L.check(L.lib().ldw_set_prune(self._ctx, int(bool(on))))
+
+    def prune_report(self):
+        v = np.zeros(4, dtype=np.int64)
+        L.check(L.lib().ldw_prune_report(self._ctx, L.ptr(v)))
+        return dict(ordered_blocks=int(v[0]), tiles_pruned=int(v[1]), tiles_total=int(v[2]), on=bool(v[3]))
+
     def write_links_tsv(self, which: int, path: str, append: bool = True, nthreads: int = 0):
         """The context's sr (0) / lr (1) table as `pos1 pos2 clust1 clust2 len MI` rows (write.table format); (rows, bytes)."""
         n, nb = C.c_int64(0), C.c_int64(0)

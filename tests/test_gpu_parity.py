@@ -1439,23 +1439,34 @@ def test_table_test_in_the_gemm_epilogue_is_verified(engine):
     approx = MIH.lr_links_approx(syn["POS"], float(syn["g"]), 20000.0)
     blocks = MIH.make_blocks(len(st), 2000)     # 4 x 4 (or 5 x 5) grid: (1,3) and (2,4) are far apart both ways round the circular genome
     out = {}
-    for key, (mixed, scr, path) in dict(plain=(False, 0, 1), fast=(True, 1, 2), verify=(True, 2, 2)).items():
+    # ... and the tile pruning on top of it (rows ordered by minor-state weight, rare x rare wave tiles never computed): on in
+    # "fast" and "verify" — whose fp64 check covers the pruned tiles' pairs like every other dismissal — off in "noprune"
+    for key, (mixed, scr, path, prune) in dict(plain=(False, 0, 1, True), fast=(True, 1, 2, True), verify=(True, 2, 2, True),
+                                               noprune=(True, 1, 2, False)).items():
         engine.set_mixed(mixed)
         engine.set_screen(scr)
         engine.set_path(path)
+        engine.set_prune(prune)
         c0 = engine.counters()
+        p0 = engine.prune_report()
         engine.gemm_stats(reset=True)
         for _ in range(2):
             engine.mi_all_pairs(blocks, 20000.0, 40000.0, approx)
         c1 = engine.counters()
-        out[key] = (engine.links(0), engine.links(1), {k: c1[k] - c0[k] for k in c1}, engine.gemm_stats())
+        p1 = engine.prune_report()
+        out[key] = (engine.links(0), engine.links(1), {k: c1[k] - c0[k] for k in c1}, engine.gemm_stats(),
+                    {k: p1[k] - p0[k] for k in ("ordered_blocks", "tiles_pruned", "tiles_total")})
     engine.set_mixed(True)
     engine.set_screen(1)
     engine.set_path(0)
+    engine.set_prune(True)
     assert out["fast"][3]["apx_table_launches"] >= 2 and out["verify"][3]["apx_table_launches"] >= 2, out["fast"][3]
     assert out["verify"][2]["screen_violations"] == 0
+    assert out["fast"][4]["ordered_blocks"] >= 2 and out["fast"][4]["tiles_pruned"] > 0, out["fast"][4]
+    assert out["verify"][4]["tiles_pruned"] > 0 and out["noprune"][4]["ordered_blocks"] == 0 and out["noprune"][4]["tiles_pruned"] == 0
+    assert out["fast"][3]["apx_ops"] < out["noprune"][3]["apx_ops"]      # pruned tiles are not counted as executed work
     for which in (0, 1):
-        for key in ("fast", "verify"):
+        for key in ("fast", "verify", "noprune"):
             for x, y in zip(out["plain"][which], out[key][which]):
                 assert np.array_equal(x, y), (which, key)
     assert len(out["plain"][1][2]) > 10000

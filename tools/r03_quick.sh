@@ -14,7 +14,7 @@ python - "$T" <<'PY'
 import json,sys
 j=json.loads([l for l in open(f"gpurun_out/{sys.argv[1]}_bench.json") if l.startswith("{")][0])
 print({k: j.get(k) for k in ("value","ms_per_step","spec_misses","links")})
-for k in ("warm_replay","sustained","mi_values_produced","job","path","cpu_baseline","stages_ms_per_step","stages_ms_per_step_overlapped","counters"):
+for k in ("warm_replay","sustained","mi_values_produced","job","path","prune","cpu_baseline","stages_ms_per_step","stages_ms_per_step_overlapped","counters"):
     v=j.get(k)
     if isinstance(v,dict): v={a:b for a,b in v.items() if a not in ("what","note","sample")}
     print(k, v)
