@@ -48,6 +48,10 @@ struct ApxGemmArgs {
     // only unconditional entries (-1, INT_MAX) — no n' can make such a pair fail the test — flags its regions clean and leaves
     // before the K loop; lane 0 counts it in *skip_ctr.  Null: every tile is computed.
     unsigned long long *skip_ctr;
+    // with skip_ctr: k_apx_live_tiles writes the numbers of the wave tiles that have to be computed to tile_list (ty * ntx + tx, ntx =
+    // RFpad / 64) and their count to *n_live (zeroed by the caller); the GEMM then runs over that list, four tiles per workgroup
+    uint32_t *tile_list;
+    unsigned int *n_live;
     // the same for the wider tables: pruning flags (PF_*, ldw_epi.h) of every ROW of the two row lists, 0 for padding rows.  A tile
     // whose to-rows are all of one kind and dead versus the (one) kind of its from-rows, or the other way round, is not computed.
     const uint8_t *rflag_t, *rflag_f;

@@ -286,76 +286,96 @@ __device__ __forceinline__ void apx_gemm_epilogue(const ApxGemmArgs &P, v16i (&a
     }
 }
 
-// Tile pruning (ApxGemmArgs::skip_ctr): is every pair of the wave tile (TH to-rows x TWd from-rows) one whose table entry is
-// unconditional?  Such an entry (-1, INT_MAX) says that NO joint count lifts a pair of these two marginal bins to the level —
-// the epilogue's test n' > L && n' < H would pass whatever the GEMM computed, so the tile is not computed.  The rows of a
-// block without short-range pairs are ordered by their marginal (prep_block), so a tile spans a few bins per side: the lanes
-// test the whole rectangle [tmin, tmax] x [fmin, fmax] of the table at once (rectangles of more than 64 entries are computed).
-template <int TH, int TWd>
-__device__ __forceinline__ bool apx_tile_prunable(const ApxGemmArgs &P, int ty, int tx, int lane, const int2 *__restrict__ s_tab, bool &all_binned) {
-    all_binned = false;
-    if (P.sr_mask && P.sr_mask[(int64_t)ty * (P.RFpad / 64) + tx] != 0) return false;
-    int tmin = 255, tmax = 0, fmin = 255, fmax = 0;   // 255: a row that is not a biallelic r = 2 SNP's (or padding): no table entry
-    unsigned tand = 0xFFu, tor = 0u, fand = 0xFFu, forr = 0u;   // pruning flags (PF_*) of the rows: AND and OR over the tile
-    for (int r = lane; r < TH; r += 64) {
-        const int b = (int)P.bin_t[ty * TH + r];
-        tmin = b < tmin ? b : tmin;
-        tmax = b > tmax ? b : tmax;
-        if (P.rflag_t) {
-            const unsigned f = P.rflag_t[ty * TH + r];
-            tand &= f;
-            tor |= f;
-        }
-    }
-    for (int r = lane; r < TWd; r += 64) {
-        const int b = (int)P.bin_f[tx * TWd + r];
-        fmin = b < fmin ? b : fmin;
-        fmax = b > fmax ? b : fmax;
-        if (P.rflag_f) {
-            const unsigned f = P.rflag_f[tx * TWd + r];
-            fand &= f;
-            forr |= f;
-        }
-    }
-    // one packed reduction: (tmin, 255 - tmax, fmin, 255 - fmax) by min, the flag bytes by AND / OR
-    unsigned mn = (unsigned)tmin | ((unsigned)(255 - tmax) << 8) | ((unsigned)fmin << 16) | ((unsigned)(255 - fmax) << 24);
-    unsigned fl = tand | ((tor ^ 0xFFu) << 8) | (fand << 16) | ((forr ^ 0xFFu) << 24);   // (OR as AND of the complement)
+// Tile pruning (ApxGemmArgs::skip_ctr).  k_apx_live_tiles: which wave tiles (128 to-rows x 64 from-rows) does the approximate GEMM have
+// to compute?  A tile is pruned when EVERY pair in it is dismissed whatever its joint count:
+//   (a) all rows carry bins of the threshold table and the rectangle [min, max] x [min, max] of their bins holds only unconditional
+//       entries (-1, INT_MAX) — the epilogue's test n' > L && n' < H would pass whatever the GEMM computed.  The rows of a block are
+//       ordered by their marginal (prep_block), so a tile spans a few bins per side (rectangles of more than 64 entries: computed);
+//   (b) the rows of each side are all of ONE kind (2 or 3 flagged states) and one side is dead versus the other's kind (k_snp_sup).
+// One workgroup per 128-row group of the to side, one THREAD per tile: it folds the bins / flags of its 64 from-rows and of the
+// group's 128 to-rows (16-byte loads).  Pruned tiles are flagged clean where that applies and counted; the others are appended to
+// the list the GEMM runs over — in order within the group, ONE atomic per workgroup for the place of its run (a wave per tile with
+// an atomic each took 130 us for the 16.6k tiles of a C4 block; this takes a few).
+struct TileSummary {
+    int bmin, bmax;
+    unsigned fand, forr;
+};
+__device__ __forceinline__ TileSummary apx_fold_rows(const uint8_t *__restrict__ bins, const uint8_t *__restrict__ flags, int n) {
+    TileSummary S{255, 0, 0xFFu, 0u};
+    for (int i = 0; i < n; i += 16) {
+        const uint4 b = *reinterpret_cast<const uint4 *>(bins + i);
+        const unsigned w[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned o = (unsigned)__shfl_xor((int)mn, off);
-        unsigned r = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned a = (mn >> (8 * k)) & 0xFFu, b = (o >> (8 * k)) & 0xFFu;
-            r |= (a < b ? a : b) << (8 * k);
+        for (int k = 0; k < 16; ++k) {
+            const int v = (int)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+            S.bmin = v < S.bmin ? v : S.bmin;
+            S.bmax = v > S.bmax ? v : S.bmax;
         }
-        mn = r;
-        fl &= (unsigned)__shfl_xor((int)fl, off);
+        if (flags) {
+            const uint4 f = *reinterpret_cast<const uint4 *>(flags + i);
+            unsigned a = f.x & f.y & f.z & f.w, o = f.x | f.y | f.z | f.w;
+            a &= a >> 16; a &= a >> 8;
+            o |= o >> 16; o |= o >> 8;
+            S.fand &= a & 0xFFu;
+            S.forr |= o & 0xFFu;
+        }
     }
-    tmin = (int)(mn & 0xFFu);
-    tmax = 255 - (int)((mn >> 8) & 0xFFu);
-    fmin = (int)((mn >> 16) & 0xFFu);
-    fmax = 255 - (int)(mn >> 24);
-    all_binned = tmax < P.tab_nb && fmax < P.tab_nb;
-    if (P.rflag_t) {   // the wider tables: rows of ONE kind per side, one side dead versus the other's kind (k_snp_sup)
-        tand = fl & 0xFFu;
-        tor = ((fl >> 8) & 0xFFu) ^ 0xFFu;
-        fand = (fl >> 16) & 0xFFu;
-        forr = (fl >> 24) ^ 0xFFu;
-        const unsigned kt = tand & PF_KIND, kf = fand & PF_KIND;
-        if (kt >= 2u && kt == (tor & PF_KIND) && kf >= 2u && kf == (forr & PF_KIND) &&
-            ((tand & (kf == 2u ? PF_DEAD2 : PF_DEAD3)) != 0u || (fand & (kt == 2u ? PF_DEAD2 : PF_DEAD3)) != 0u))
-            return true;
+    return S;
+}
+
+__global__ __launch_bounds__(256) void k_apx_live_tiles(ApxGemmArgs P) {
+    constexpr int MT = 4, NT = 2, TH = 32 * MT, TWd = 32 * NT;
+    __shared__ unsigned int s_wave[4], s_base;
+    const int ty = (int)blockIdx.x, ntx = P.RFpad / TWd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const TileSummary T = apx_fold_rows(P.bin_t + (int64_t)ty * TH, P.rflag_t ? P.rflag_t + (int64_t)ty * TH : nullptr, TH);
+    unsigned int n_pruned = 0;
+    for (int tx0 = 0; tx0 < ntx; tx0 += 256) {
+        const int tx = tx0 + (int)threadIdx.x;
+        const bool valid = tx < ntx;
+        bool pruned = false, all_binned = false;
+        if (valid && !(P.sr_mask && P.sr_mask[(int64_t)ty * (P.RFpad / 64) + tx] != 0)) {
+            const TileSummary F = apx_fold_rows(P.bin_f + (int64_t)tx * TWd, P.rflag_f ? P.rflag_f + (int64_t)tx * TWd : nullptr, TWd);
+            all_binned = T.bmax < P.tab_nb && F.bmax < P.tab_nb;
+            if (P.rflag_t) {   // the wider tables: rows of ONE kind per side, one side dead versus the other's kind (k_snp_sup)
+                const unsigned kt = T.fand & PF_KIND, kf = F.fand & PF_KIND;
+                pruned = kt >= 2u && kt == (T.forr & PF_KIND) && kf >= 2u && kf == (F.forr & PF_KIND) &&
+                         ((T.fand & (kf == 2u ? PF_DEAD2 : PF_DEAD3)) != 0u || (F.fand & (kt == 2u ? PF_DEAD2 : PF_DEAD3)) != 0u);
+            }
+            if (!pruned && all_binned && (T.bmax - T.bmin + 1) * (F.bmax - F.bmin + 1) <= 64) {   // the table: only unconditional entries
+                bool ok = true;
+                for (int bt = T.bmin; bt <= T.bmax; ++bt)
+                    for (int bf = F.bmin; bf <= F.bmax; ++bf) {
+                        const int2 th = P.tab[bt * P.tab_nb + bf];
+                        ok = ok && th.x < 0 && th.y == 2147483647;
+                    }
+                pruned = ok;
+            }
+        }
+        if (pruned && all_binned) {
+            // (clean flags speak of biallelic x biallelic regions only: k_mi_screen maps a region to a tile and 32 column slots by row
+            // position, which holds there; the other pruned tiles are found again by the screen from the SNPs' flags)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int h = 0; h < (NT * 32) / 64; ++h) P.clean[(int64_t)((ty * TH + 32 * i) / 32) * (P.RFpad / 64) + (tx * TWd) / 64 + h] = 1;
+        }
+        const bool live = valid && !pruned;
+        const unsigned long long lm = __ballot(live);
+        n_pruned += (unsigned int)__popcll(__ballot(valid && pruned));
+        if (lane == 0) s_wave[wave] = (unsigned int)__popcll(lm);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            s_base = tot ? atomicAdd(P.n_live, tot) : 0u;
+        }
+        __syncthreads();
+        unsigned int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (live) P.tile_list[off + (unsigned int)__popcll(lm & ((1ull << lane) - 1ull))] = (uint32_t)(ty * ntx + tx);
+        __syncthreads();
     }
-    if (!all_binned) return false;
-    const int nbt = tmax - tmin + 1, nbf = fmax - fmin + 1;
-    if (nbt * nbf > 64) return false;
-    bool ok = true;
-    if (lane < nbt * nbf) {
-        const int2 th = s_tab[(tmin + lane / nbf) * P.tab_nb + fmin + lane % nbf];
-        ok = th.x < 0 && th.y == 2147483647;
-    }
-    return __ballot(!ok) == 0ull;
+    if (lane == 0 && n_pruned) atomicAdd(P.skip_ctr, (unsigned long long)n_pruned);
 }
 
 template <int MT, int NT, bool FINE>
@@ -366,33 +386,22 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
     int2 *s_tab = reinterpret_cast<int2 *>(sB + (size_t)P.M2 * 128);  // threshold table (P.fuse)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int ty = 2 * blockIdx.y + (wave >> 1), tx = 2 * blockIdx.x + (wave & 1);
     constexpr int TH = 32 * MT, TWd = 32 * NT;
-    const bool outside = ty * TH >= P.RTpad || tx * TWd >= P.RFpad || (P.lower_only && tx * TWd + TWd - 1 < ty * TH);
-    bool pruned = false;
-    if (P.fuse && P.skip_ctr) {
-        // tile pruning first, straight from the table in global memory: a workgroup whose wave tiles are all pruned (or outside)
-        // leaves before it has staged anything
-        int *s_live = reinterpret_cast<int *>(smem);
-        if (tid == 0) *s_live = 0;
-        __syncthreads();
-        bool all_binned = false;
-        pruned = !outside && apx_tile_prunable<TH, TWd>(P, ty, tx, lane, P.tab, all_binned);
-        if (pruned) {
-            // (clean flags speak of biallelic x biallelic regions only: k_mi_screen maps a region to a tile and 32 column slots by
-            // row position, which holds there; the other pruned tiles are found again by the screen from the SNPs' flags)
-            if (all_binned && lane < MT * ((NT * 32) / 64)) {
-                const int i = lane / ((NT * 32) / 64), h = lane % ((NT * 32) / 64);
-                P.clean[(int64_t)((ty * TH + 32 * i) / 32) * (P.RFpad / 64) + (tx * TWd) / 64 + h] = 1;
-            }
-            if (lane == 0) atomicAdd(P.skip_ctr, 1ull);
-        } else if (!outside && lane == 0) {
-            *s_live = 1;
-        }
-        __syncthreads();
-        const bool any_live = *s_live != 0;
-        __syncthreads();   // (smem is about to be overwritten)
-        if (!any_live) return;
+    int ty = 2 * blockIdx.y + (wave >> 1), tx = 2 * blockIdx.x + (wave & 1);
+    bool outside;
+    if (P.tile_list) {
+        // tile pruning (k_apx_live_tiles): the grid is 1-D over the list of the tiles that are left, four per workgroup; it is sized for
+        // the worst case, so the workgroups beyond the list leave at once, before anything is staged
+        const unsigned int n_live = *P.n_live;
+        if (blockIdx.x * 4u >= n_live) return;
+        const unsigned int k = blockIdx.x * 4u + (unsigned int)wave;
+        outside = k >= n_live;
+        const int t = outside ? 0 : (int)P.tile_list[k];
+        const int ntx = P.RFpad / TWd;
+        ty = t / ntx;
+        tx = t - ty * ntx;
+    } else {
+        outside = ty * TH >= P.RTpad || tx * TWd >= P.RFpad || (P.lower_only && tx * TWd + TWd - 1 < ty * TH);
     }
     if (P.fuse)
         for (int i = tid; i < P.tab_nb * P.tab_nb; i += 256) s_tab[i] = P.tab[i];
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
         }
     }
     __syncthreads();
-    if (outside || pruned) return;
+    if (outside) return;
     const int frow = lane & 31, fh = lane >> 5;
     const int64_t sta = (int64_t)P.RTpad * 2, stb = (int64_t)P.RFpad * 2;
     {
@@ -811,7 +820,13 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
         if (P.fine) hipLaunchKernelGGL((gemm_apx_kernel<MTv, NTv, true>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P); \
         else hipLaunchKernelGGL((gemm_apx_kernel<MTv, NTv, false>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P); \
     }
-    if (tile == 22 && !P.fuse) LDW_APX_LAUNCH(2, 2)          // (the table epilogue assumes 64 from-rows per wave: NT = 2)
+    if (P.skip_ctr) {
+        LDW_REQUIRE(P.fuse && P.tile_list && P.n_live && !P.lower_only && P.RFpad % 64 == 0, LDW_ERR_ARG, "launch_gemm_apx: bad pruning arguments");
+        const int tiles = (P.RTpad / 128) * (P.RFpad / 64), g = (tiles + 3) / 4;
+        hipLaunchKernelGGL(k_apx_live_tiles, dim3((unsigned)(P.RTpad / 128)), dim3(256), 0, st, P);
+        if (P.fine) hipLaunchKernelGGL((gemm_apx_kernel<4, 2, true>), dim3((unsigned)g), dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((gemm_apx_kernel<4, 2, false>), dim3((unsigned)g), dim3(256), lds, st, P);
+    } else if (tile == 22 && !P.fuse) LDW_APX_LAUNCH(2, 2)          // (the table epilogue assumes 64 from-rows per wave: NT = 2)
     else if (tile == 24 && !P.fuse) LDW_APX_LAUNCH(2, 4)
     else LDW_APX_LAUNCH(4, 2)
 #undef LDW_APX_LAUNCH

@@ -405,7 +405,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         tri_cols = dead_cols;
         if (__syncthreads_and((n_it <= 0 || (n_it == EPI_COLS / 4 && dead_cols == 0xFFFFFFFFu)) ? 1 : 0)) return;
     }
-    if (APX && A.sflag_f && A.E.scr_mode != 2 && A.E.do_lr && !A.E.any_sr) {
+    unsigned int prune_cols = 0;   // (in a block with short-range pairs these columns are dropped only where the unit holds none: below)
+    if (APX && A.sflag_f && A.E.scr_mode != 2 && A.E.do_lr) {
         const unsigned fa = A.sflag_f[blockIdx.x * 64 + (threadIdx.x & 63)];
         const bool real = (fa & PF_PAD) == 0u;   // (a padding slot of the tile: no SNP)
         const unsigned ka = fa & PF_KIND;
@@ -415,10 +416,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             const unsigned fb = (int)(threadIdx.x & 63) < n_it ? (unsigned)A.sflag_t[q_base + (threadIdx.x & 63)] : 0u;
             const unsigned kb = fb & PF_KIND;
             const bool dead = kb >= 2u && ((kb == 2u ? all_dead2 : all_dead3) || (fb & (all_k2 ? PF_DEAD2 : PF_DEAD3)) != 0u);
-            dead_cols |= (unsigned int)__ballot(dead);
+            prune_cols = (unsigned int)__ballot(dead);
         }
-        const bool wave_done = n_it <= 0 || (n_it == EPI_COLS / 4 && dead_cols == 0xFFFFFFFFu);
-        if (__syncthreads_and(wave_done ? 1 : 0)) return;
+        if (!A.E.any_sr) {
+            dead_cols |= prune_cols;
+            prune_cols = 0;
+            const bool wave_done = n_it <= 0 || (n_it == EPI_COLS / 4 && dead_cols == 0xFFFFFFFFu);
+            if (__syncthreads_and(wave_done ? 1 : 0)) return;
+        }
     }
     stage_cols(A, perm_t, square, cm, mixed);
     __syncthreads();
@@ -454,6 +459,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 continue;
             }
             const ColMeta *cmu = &cm[c_first + it];
+            if ((((dead_cols | prune_cols) >> it) & ((1u << U) - 1u)) == ((1u << U) - 1u) && it + U <= n_it && A.E.scr_mode != 2) {
+                // prunable columns of a block with short-range pairs: dropped unless the unit holds one (its tile is in the band then)
+                bool has_sr = false;
+#pragma unroll
+                for (int u = 0; u < U; ++u) has_sr = has_sr || col_is_sr(cmu[u].ci, a_loc);
+                if (__ballot(a_ok && has_sr) == 0ull) {
+                    handled |= ((1u << U) - 1u) << it;
+                    continue;
+                }
+            }
             // the U columns of a group share one code path if they have the same slot count (the rule away from class borders)
             bool same = it + U <= n_it;
             const uint32_t mb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmu[0].mb);
@@ -1824,7 +1839,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * pair_cap_for(nf, nt) * sizeof(PairEnt))) return rc;
         if (need_exact)
             if (int rc = Gx.reserve((size_t)RFpad * RTpad * 8)) return rc;
-        if (int rc = c->apx_bins[s].reserve(2 * ((size_t)RTpad + (size_t)RFpad) + (size_t)nt + (size_t)nf_slots + 128)) return rc;
+        if (int rc = c->apx_bins[s].reserve(2 * ((size_t)RTpad + (size_t)RFpad) + (size_t)nt + (size_t)nf_slots + 256 + (size_t)(RTpad / 128) * (size_t)(RFpad / 64) * 4)) return rc;
         if (int rc = c->apx_clean[s].reserve((size_t)(RTpad / 32) * (size_t)(RFpad / 64) + 64)) return rc;
         if (!c->apx_skip.p) {
             if (int rc = c->apx_skip.reserve(64)) return rc;
@@ -1872,7 +1887,11 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
                       2048 + (size_t)(c->KW / 2) * 256 + 64 * 64 * 8 + 1024 <= 65536;   // (the table shares the GEMM's LDS with the digit arrays)
     uint8_t *bin_t = c->apx_bins[s].as<uint8_t>(), *bin_f = bin_t + RTpad;
     // pruning flags by row (zeroed per block: padding rows) and by epilogue slot
-    uint8_t *rflag_t = bin_f + RFpad, *rflag_f = rflag_t + RTpad, *sflag_t = rflag_f + RFpad, *sflag_f = sflag_t + ((size_t)nt + 15) / 16 * 16;
+    // ... and, zeroed with the row flags, the count of the wave tiles the pruning leaves (k_apx_live_tiles), whose list ends the buffer
+    uint8_t *rflag_t = bin_f + RFpad, *rflag_f = rflag_t + RTpad;
+    unsigned int *n_live = reinterpret_cast<unsigned int *>(rflag_f + RFpad);
+    uint8_t *sflag_t = rflag_f + RFpad + 16, *sflag_f = sflag_t + ((size_t)nt + 15) / 16 * 16;
+    uint32_t *tile_list = reinterpret_cast<uint32_t *>(sflag_f + ((size_t)nf_slots + 15) / 16 * 16);
     const bool wide_prune = c->prune && c->snp_sup.p && E.do_lr && use_pairs;
     if (wide_prune) {
         A.snp_sup = c->snp_sup.as<double>();
@@ -1914,10 +1933,8 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
                 Z.p[4] = reinterpret_cast<uint4 *>(c->apx_clean[s].p);
                 Z.n16[4] = (unsigned int)(((size_t)(RTpad / 32) * (size_t)(RFpad / 64) + 15) / 16);
             }
-            if (wide_prune) {
-                Z.p[5] = reinterpret_cast<uint4 *>(rflag_t);
-                Z.n16[5] = (unsigned int)(((size_t)RTpad + (size_t)RFpad) / 16);
-            }
+            Z.p[5] = reinterpret_cast<uint4 *>(rflag_t);
+            Z.n16[5] = (unsigned int)(((size_t)RTpad + (size_t)RFpad) / 16 + 1);
             if (zero_hist) {
                 Z.p[2] = reinterpret_cast<uint4 *>(zero_hist);
                 Z.n16[2] = (unsigned int)(NBINS * 8 / 16);
@@ -1950,6 +1967,10 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             if (fuse) {
                 P.fuse = 1;
                 P.skip_ctr = (c->prune && lo_h->ordered) ? c->apx_skip.as<unsigned long long>() : nullptr;   // (list order: a tile spans every bin)
+                if (P.skip_ctr) {
+                    P.tile_list = tile_list;
+                    P.n_live = n_live;
+                }
                 if (P.skip_ctr && wide_prune) {
                     P.rflag_t = rflag_t;
                     P.rflag_f = rflag_f;
@@ -2207,8 +2228,13 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     // one-row SNPs are ordered by the weight of their minor state on both sides — rows and epilogue slots alike, which the table
     // test of the GEMM's epilogue requires anyway.  The wave tiles of the approximate GEMM then span few bins of the threshold
     // table and the tiles of the rare x rare corner are pruned whole (apx_tile_prunable).
+    // An off-diagonal block WITH a short-range corner (neighbouring blocks, and the pair that closes the circle): the SNPs that have a
+    // short-range partner in the block are a few hundred at the facing ends of the two lists.  They keep the list order — the band
+    // of tiles the exact GEMM covers needs their partners contiguous — behind the ordered rest.  Diagonal blocks stay as they are:
+    // every SNP has short-range partners there.
     const std::vector<int32_t> *ord_f = nullptr, *ord_t = nullptr;
-    if (c->prune && !hb.generic && hb.n_sr_blk == 0 && !hb.diag && c->engine == LDW_ENGINE_MFMA && c->apx_ok && !c->fused) {
+    std::vector<int32_t> ord_f_own, ord_t_own;
+    if (c->prune && !hb.generic && !hb.diag && c->engine == LDW_ENGINE_MFMA && c->apx_ok && !c->fused) {
         bool rowless = false;
         for (int64_t k = 0; k < nf && !rowless; ++k) rowless = c->h_row0[from_idx[k] + 1] == c->h_row0[from_idx[k]];
         for (int64_t k = 0; k < nt && !rowless; ++k) rowless = c->h_row0[to_idx[k] + 1] == c->h_row0[to_idx[k]];
@@ -2216,6 +2242,36 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
             if (c->order_cache.size() >= 256) c->order_cache.clear();   // (before the two look-ups of this block, never between them)
             ord_f = minor_weight_order(c, from_idx, nf);
             ord_t = minor_weight_order(c, to_idx, nt);
+            if (hb.n_sr_blk > 0) {
+                std::vector<int32_t> df((size_t)nf + 1, 0);
+                std::vector<uint8_t> in_f((size_t)nf, 0), in_t((size_t)nt, 0);
+                for (int64_t b = 0; b < nt; ++b)
+                    for (int iv = 0; iv < 3; ++iv) {
+                        const ColInfo &ci = cols[(size_t)b];
+                        if (ci.e[iv] <= ci.s[iv]) continue;
+                        in_t[(size_t)b] = 1;
+                        ++df[(size_t)ci.s[iv]];
+                        --df[(size_t)ci.e[iv]];
+                    }
+                int32_t run = 0;
+                for (int64_t a = 0; a < nf; ++a) {
+                    run += df[(size_t)a];
+                    in_f[(size_t)a] = run > 0 ? 1 : 0;
+                }
+                auto rest_then_corner = [&](const std::vector<int32_t> &sorted, const std::vector<uint8_t> &corner, const int32_t *idx, int64_t n,
+                                            std::vector<int32_t> &out) {
+                    out.clear();
+                    out.reserve(sorted.size());
+                    for (int32_t k : sorted)
+                        if (!corner[(size_t)k]) out.push_back(k);
+                    for (int64_t k = 0; k < n; ++k)
+                        if (corner[(size_t)k] && c->h_row0[idx[k] + 1] - c->h_row0[idx[k]] == 1) out.push_back((int32_t)k);
+                };
+                rest_then_corner(*ord_f, in_f, from_idx, nf, ord_f_own);
+                rest_then_corner(*ord_t, in_t, to_idx, nt, ord_t_own);
+                ord_f = &ord_f_own;
+                ord_t = &ord_t_own;
+            }
             ++c->sorted_blocks;
         }
     }
@@ -2337,6 +2393,13 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
             for (int64_t ty = t0 / TILE; ty <= (t1 - 1) / TILE; ++ty)
                 for (int64_t tx = f0 / 64; tx <= (f1 - 1) / 64; ++tx) band[(size_t)ty * ntx + tx] = 1;
         };
+        std::vector<int32_t> nxt1, prv1;   // first one-row SNP at or after / last one before a list position (ordered rows only)
+        if (hb.n_sr_blk > 0 && !hb.lo.band_full && ord_f) {
+            nxt1.assign((size_t)nf + 1, (int32_t)nf);
+            prv1.assign((size_t)nf + 1, -1);
+            for (int64_t a = nf - 1; a >= 0; --a) nxt1[(size_t)a] = cls_of(from_idx[a]) == 0 ? (int32_t)a : nxt1[(size_t)a + 1];
+            for (int64_t a = 0; a < nf; ++a) prv1[(size_t)a + 1] = cls_of(from_idx[a]) == 0 ? (int32_t)a : prv1[(size_t)a];
+        }
         if (hb.n_sr_blk > 0 && !hb.lo.band_full)
             for (int64_t b2 = 0; b2 < nt; ++b2) {
                 const ColInfo &ci = cols[(size_t)b2];
@@ -2350,6 +2413,13 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
                         // one class in list order = 64 << k consecutive rows), so the range grows to whole tiles; the tiles of the
                         // SNPs with 3 and 4 rows are ordered differently from their rows: their whole class region is kept
                         int64_t f0 = base[k] + (int64_t)(n0 / 64 * 64) * (1 << k), f1 = base[k] + (int64_t)((n1 + 63) / 64 * 64) * (1 << k);
+                        if (k == 0 && ord_f) {
+                            // ordered rows: the partners (corner SNPs, in list order among themselves) start at the row of the first
+                            // one-row SNP of the interval and end at that of the last
+                            const int64_t first = nxt1[(size_t)ci.s[iv]], last = prv1[(size_t)ci.e[iv]];
+                            f0 = (int64_t)SF.lrow[(size_t)first] / 64 * 64;
+                            f1 = ((int64_t)SF.lrow[(size_t)last] + 1 + 63) / 64 * 64;
+                        }
                         if (k == 2) {
                             f0 = base[2];
                             f1 = base[2] + (int64_t)pre[2][(size_t)nf] * 4;
