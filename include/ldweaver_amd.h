@@ -221,6 +221,13 @@ int ldw_path_report(ldw_ctx *ctx, int64_t out[8], char *gate, int capacity);
  * prune (both since the context was created; pruned tiles are not counted as executed work by ldw_gemm_stats), out[3] = on. */
 int ldw_set_prune(ldw_ctx *ctx, int on);
 int ldw_prune_report(ldw_ctx *ctx, int64_t out[4]);
+/* inspection only: the per-SNP bounds behind the pruning of the 2 x 3 / 3 x 3 tables.  out[a * 4 + 2 * m + (k - 2)] = the largest MI
+ * SNP a (2 or 3 states, all flagged in uqe, r = its number of states) can reach with ANY partner that has k = 2 or 3 flagged states
+ * and r = k — the maximum of the MI over the joint tables with a's marginals, which is convex there and sits at a vertex: every
+ * state of a sends all its weight to one state of the partner — under the intended (m = 0) and the reference (m = 1: RXY at its
+ * floor min(r)^2 / 4) reading of RXY; 1e300 for other SNPs and for SNPs with a sizeable minor state (not evaluated).  Needs the
+ * alignment, the weights and the SNP meta data; capacity in doubles (>= 4 L). */
+int ldw_snp_bounds(ldw_ctx *ctx, double *out, int64_t capacity);
 /* diagnostics of the approximate path after ldw_set_weights: out[0] = usable (0/1), out[1] = max relative error delta of the
  * dual-digit weights, out[2] = weight classes, out[3] = popcount segments, out[4] = exponent transitions, out[5] = e_last */
 int ldw_apx_info(ldw_ctx *ctx, double out[6]);

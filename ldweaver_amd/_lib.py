@@ -92,6 +92,7 @@ _SIGS = {
     "ldw_path_report": (C.c_int, [_p, _p, C.c_char_p, C.c_int]),
     "ldw_set_prune": (C.c_int, [_p, C.c_int]),
     "ldw_prune_report": (C.c_int, [_p, _p]),
+    "ldw_snp_bounds": (C.c_int, [_p, _p, C.c_int64]),
     "ldw_format_number": (C.c_int, [C.c_double, C.c_char_p, C.c_int]),
     "ldw_write_table_tsv": (C.c_int, [C.c_char_p, C.c_int, _i64, C.c_int, _p, _p, C.c_int, C.POINTER(_i64)]),
     "ldw_write_links_tsv": (C.c_int, [_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -379,6 +379,16 @@ int ldw_prune_report(ldw_ctx *c, int64_t out[4]) {
     return LDW_OK;
 }
 
+int ldw_snp_bounds(ldw_ctx *c, double *out, int64_t capacity) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(out, LDW_ERR_ARG, "ldw_snp_bounds: null argument");
+    if (int rc = ldw::ensure_rows(c)) return rc;
+    LDW_REQUIRE(capacity >= 4 * c->L, LDW_ERR_ARG, "ldw_snp_bounds: capacity %lld < 4 L = %lld", (long long)capacity, (long long)(4 * c->L));
+    LDW_HIP(hipMemcpyAsync(out, c->snp_sup.p, (size_t)c->L * 32, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
+
 int ldw_set_select(ldw_ctx *c, int mode) {
     LDW_REQUIRE(c && (mode == 0 || mode == 1), LDW_ERR_ARG, "ldw_set_select: mode must be 0 (auto) or 1 (radix sorts)");
     c->select_mode = mode;

@@ -58,6 +58,7 @@ struct ApxGemmArgs {
 };
 
 int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st);
+int launch_apx_live_tiles(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st);   // P.skip_ctr set: before launch_gemm_apx, same stream
 int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st);
 // the pair lists of A (filled by the approximate screen): exact sums, fp64 MI, emission
 int launch_pairs_exact(ldw_ctx *c, const EpiArgs &A, unsigned long long *ghist, int64_t *sums, hipStream_t st);

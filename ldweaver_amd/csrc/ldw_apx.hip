@@ -768,6 +768,14 @@ __global__ __launch_bounds__(512, 1) void gemm_apx_lds_kernel(ApxGemmArgs P) {
     apx_gemm_epilogue<MT, NT>(P, acc, ty, tx, lane, s_tab, reinterpret_cast<uint8_t *>(s_tab + 64 * 64) + wave * 256);
 }
 
+int launch_apx_live_tiles(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
+    LDW_REQUIRE(P.fuse && P.skip_ctr && P.tile_list && P.n_live && !P.lower_only && P.RTpad % 128 == 0 && P.RFpad % 64 == 0 && P.tab && P.tab_nb == 64,
+                LDW_ERR_ARG, "launch_apx_live_tiles: bad pruning arguments");
+    hipLaunchKernelGGL(k_apx_live_tiles, dim3((unsigned)(P.RTpad / 128)), dim3(256), 0, st, P);
+    LDW_HIP(hipGetLastError());
+    return LDW_OK;
+}
+
 int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     LDW_REQUIRE(P.RTpad % APX_TW == 0 && P.RFpad % APX_TW == 0 && P.M2 > 0, LDW_ERR_ARG, "launch_gemm_apx: padding violated (RT %d RF %d M2 %d)", P.RTpad,
                 P.RFpad, P.M2);
@@ -822,8 +830,7 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     }
     if (P.skip_ctr) {
         LDW_REQUIRE(P.fuse && P.tile_list && P.n_live && !P.lower_only && P.RFpad % 64 == 0, LDW_ERR_ARG, "launch_gemm_apx: bad pruning arguments");
-        const int tiles = (P.RTpad / 128) * (P.RFpad / 64), g = (tiles + 3) / 4;
-        hipLaunchKernelGGL(k_apx_live_tiles, dim3((unsigned)(P.RTpad / 128)), dim3(256), 0, st, P);
+        const int tiles = (P.RTpad / 128) * (P.RFpad / 64), g = (tiles + 3) / 4;   // (the list is made by launch_apx_live_tiles)
         if (P.fine) hipLaunchKernelGGL((gemm_apx_kernel<4, 2, true>), dim3((unsigned)g), dim3(256), lds, st, P);
         else hipLaunchKernelGGL((gemm_apx_kernel<4, 2, false>), dim3((unsigned)g), dim3(256), lds, st, P);
     } else if (tile == 22 && !P.fuse) LDW_APX_LAUNCH(2, 2)          // (the table epilogue assumes 64 from-rows per wave: NT = 2)

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         if (__syncthreads_and((n_it <= 0 || (n_it == EPI_COLS / 4 && dead_cols == 0xFFFFFFFFu)) ? 1 : 0)) return;
     }
     unsigned int prune_cols = 0;   // (in a block with short-range pairs these columns are dropped only where the unit holds none: below)
-    if (APX && A.sflag_f && A.E.scr_mode != 2 && A.E.do_lr) {
+    if (APX && A.sflag_f && A.E.do_lr) {
         const unsigned fa = A.sflag_f[blockIdx.x * 64 + (threadIdx.x & 63)];
         const bool real = (fa & PF_PAD) == 0u;   // (a padding slot of the tile: no SNP)
         const unsigned ka = fa & PF_KIND;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             const bool dead = kb >= 2u && ((kb == 2u ? all_dead2 : all_dead3) || (fb & (all_k2 ? PF_DEAD2 : PF_DEAD3)) != 0u);
             prune_cols = (unsigned int)__ballot(dead);
         }
-        if (!A.E.any_sr) {
+        if (!A.E.any_sr && A.E.scr_mode != 2) {   // (verify mode lists the pruned units as dismissed: their pairs are checked in fp64 like any other)
             dead_cols |= prune_cols;
             prune_cols = 0;
             const bool wave_done = n_it <= 0 || (n_it == EPI_COLS / 4 && dead_cols == 0xFFFFFFFFu);
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 continue;
             }
             const ColMeta *cmu = &cm[c_first + it];
-            if ((((dead_cols | prune_cols) >> it) & ((1u << U) - 1u)) == ((1u << U) - 1u) && it + U <= n_it && A.E.scr_mode != 2) {
+            if (((((A.E.scr_mode != 2 ? dead_cols : 0u) | prune_cols) >> it) & ((1u << U) - 1u)) == ((1u << U) - 1u) && it + U <= n_it) {
                 // prunable columns of a block with short-range pairs: dropped unless the unit holds one (its tile is in the band then)
                 bool has_sr = false;
 #pragma unroll
@@ -1892,7 +1892,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     unsigned int *n_live = reinterpret_cast<unsigned int *>(rflag_f + RFpad);
     uint8_t *sflag_t = rflag_f + RFpad + 16, *sflag_f = sflag_t + ((size_t)nt + 15) / 16 * 16;
     uint32_t *tile_list = reinterpret_cast<uint32_t *>(sflag_f + ((size_t)nf_slots + 15) / 16 * 16);
-    const bool wide_prune = c->prune && c->snp_sup.p && E.do_lr && use_pairs;
+    const bool wide_prune = c->prune && c->snp_sup.p && E.do_lr && (use_pairs || c->screen == 2);
     if (wide_prune) {
         A.snp_sup = c->snp_sup.as<double>();
         A.sflag_f = sflag_f;
@@ -1949,9 +1949,8 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
                            rlf, rlt, bin_t, bin_f, RTpad, RFpad, wide_prune ? sflag_f : nullptr, wide_prune ? sflag_t : nullptr, wide_prune ? rflag_f : nullptr,
                            wide_prune ? rflag_t : nullptr);
         LDW_HIP(hipGetLastError());
-        LDW_HIP(hipEventRecord(ev[0], gs));   // ev[0] .. ev[1]: the approximate GEMM alone (its launch time is the roofline's)
+        ApxGemmArgs P;
         if (E.do_lr) {
-            ApxGemmArgs P;
             memset(&P, 0, sizeof(P));
             P.panel_f = c->panel[s][0].as<uint64_t>();
             P.panel_t = lo_h->diag ? P.panel_f : c->panel[s][1].as<uint64_t>();
@@ -1982,8 +1981,12 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
                 P.clean = c->apx_clean[s].as<uint8_t>();
                 P.sr_mask = E.any_sr ? D.band_mask : nullptr;   // a block with a short-range corner: its band tiles stay with the screen
             }
-            if (int rc = launch_gemm_apx(c, P, gs)) return rc;
+            if (P.skip_ctr)
+                if (int rc = launch_apx_live_tiles(c, P, gs)) return rc;
         }
+        LDW_HIP(hipEventRecord(ev[0], gs));   // ev[0] .. ev[1]: the approximate GEMM alone (its launch time is the roofline's)
+        if (E.do_lr)
+            if (int rc = launch_gemm_apx(c, P, gs)) return rc;
         LDW_HIP(hipEventRecord(ev[1], gs));
     }
     A.rloc_f = rlf;

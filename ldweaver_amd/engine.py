@@ -85,6 +85,12 @@ class Engine:
         L.check(L.lib().ldw_prune_report(self._ctx, L.ptr(v)))
         return dict(ordered_blocks=int(v[0]), tiles_pruned=int(v[1]), tiles_total=int(v[2]), on=bool(v[3]))
 
+    def snp_bounds(self):
+        """(L, 2, 2) array [snp, RXY reading (intended, reference), partner kind (2, 3 states)]: the largest MI the SNP can reach."""
+        out = np.zeros(4 * self.L)
+        L.check(L.lib().ldw_snp_bounds(self._ctx, L.ptr(out), out.size))
+        return out.reshape(self.L, 2, 2)
+
     def write_links_tsv(self, which: int, path: str, append: bool = True, nthreads: int = 0):
         """The context's sr (0) / lr (1) table as `pos1 pos2 clust1 clust2 len MI` rows (write.table format); (rows, bytes)."""
         n, nb = C.c_int64(0), C.c_int64(0)

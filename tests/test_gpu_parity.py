@@ -1547,3 +1547,84 @@ def test_apx_path_on_irregular_weights(engine, synth):
     finally:
         engine.set_screen(1)
         engine.set_path(0)
+
+
+def test_snp_bounds_hold_for_every_partner(engine):
+    """The per-SNP MI bound behind the pruning of the 2 x 3 / 3 x 3 tables (k_snp_sup, ldw_snp_bounds): for an alignment full of rare
+    minor states and gaps, (1) the device values equal a numpy enumeration of the vertices of the joint-table polytope, (2) NO
+    pair of the alignment — every partner the oracle can offer, both readings of RXY (quirk Q1 on a square and on a ragged
+    block) — has an MI above the bound of either SNP for the other's kind, and (3) the bound is tight: a partner built to sit
+    on the best vertex reaches it to 1e-9."""
+    import itertools
+    rng = np.random.default_rng(5)
+    Ls, N = 700, 420
+    st = np.zeros((Ls, N), dtype=np.uint8)
+    for a in range(Ls):
+        maj, mnr = rng.choice(4, size=2, replace=False)
+        nm = int(rng.choice([1, 1, 2, 3, 5, 9, 30, 120]))
+        st[a] = maj
+        st[a, rng.choice(N, nm, replace=False)] = mnr
+        if a % 4 == 0:                                                   # a third state: gaps
+            st[a, rng.choice(N, int(rng.choice([1, 2, 6, 40])), replace=False)] = 4
+        if a % 7 == 3:                                                   # strong LD with the previous SNP
+            st[a] = np.where(st[a - 1] == st[a - 1][0], maj, mnr)
+    uqe, r = orc.uqe_r(st)
+    hdw = 1.0 / rng.integers(1, 6, size=N).astype(np.float64)
+    POS = np.sort(rng.choice(np.arange(1, 300000), size=Ls, replace=False)).astype(np.int32)
+    d = dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=POS, paint=np.ones(Ls, np.int32), g=300000.0)
+    _setup(engine, d)
+    sup = engine.snp_bounds()                                            # [snp, RXY reading, partner kind - 2]
+    kind = np.where((r == 2) | (r == 3), r, 0).astype(int)               # (uqe_r flags exactly the states that are present)
+    assert (kind == 2).sum() > 300 and (kind == 3).sum() > 100
+    v = np.sqrt(hdw) ** 2
+    neff = float(hdw.sum())
+    rmin = float(r.min())
+
+    def vertex_sup(p, kb, rxy):
+        ka = len(p)
+        den = neff + 0.5 * ka * kb
+        best = -1e300
+        for phi in itertools.product(range(kb), repeat=ka):
+            n = np.zeros((ka, kb))
+            for x, y in enumerate(phi):
+                n[x, y] = p[x]
+            pY = n.sum(0)
+            D = np.outer(p, pY) + rxy + (p * 0.5 * ka)[:, None] + (pY * 0.5 * kb)[None, :]
+            best = max(best, float(((n + 0.5) * np.log((n + 0.5) * den / D)).sum() / den))
+        return best
+
+    checked = 0
+    for a in rng.choice(np.where(kind > 0)[0], 60, replace=False):
+        p = np.array([v[st[a] == x].sum() for x in range(5) if (st[a] == x).any()])
+        if sup[a, 0, 0] > 1e299:
+            continue                                                     # sizeable minor state: not evaluated by design
+        for kb in (2, 3):
+            ka = int(kind[a])
+            assert abs(sup[a, 0, kb - 2] - vertex_sup(p, kb, 0.25 * ka * kb)) < 1e-9
+            assert abs(sup[a, 1, kb - 2] - vertex_sup(p, kb, min(0.25 * ka * kb, 0.25 * rmin * rmin))) < 1e-9
+        checked += 1
+    assert checked > 30
+    # (2) every pair of the alignment, three readings of RXY
+    blocks = [(np.arange(0, 350), np.arange(350, 700), L.QUIRK_INTENDED, 0), (np.arange(0, 350), np.arange(350, 700), L.QUIRK_REFERENCE, 1),
+              (np.arange(0, 400), np.arange(400, 700), L.QUIRK_REFERENCE, 1), (np.arange(0, 350), np.arange(0, 350), L.QUIRK_REFERENCE, 1)]
+    n_bound = 0
+    for fi, ti, quirk, m in blocks:
+        M = engine.mi_block(fi, ti, quirk=quirk)
+        ka, kb = kind[fi][:, None], kind[ti][None, :]
+        ok = (ka > 0) & (kb > 0) & (fi[:, None] != ti[None, :])
+        ba = np.where(kb == 3, sup[fi, m, 1][:, None], sup[fi, m, 0][:, None])      # a's bound against b's kind
+        bb = np.where(ka == 3, sup[ti, m, 1][None, :], sup[ti, m, 0][None, :])
+        assert np.all(M[ok] <= ba[ok] + 1e-12) and np.all(M[ok] <= bb[ok] + 1e-12), (quirk, float((M - ba)[ok].max()), float((M - bb)[ok].max()))
+        n_bound += int(((ba < 1e299) & ok).sum())
+    assert n_bound > 100000
+    # (3) tightness: copy a rare SNP into a partner with the same split (the vertex "minor -> minor, major -> major")
+    a = int(np.where((kind == 2) & (sup[:, 0, 0] < 1e299))[0][0])
+    st2 = st.copy()
+    b = a + 1 if a + 1 < Ls else a - 1
+    vals = [x for x in range(5) if (st[a] == x).any()]
+    st2[b] = np.where(st[a] == vals[0], 0, 1)
+    uqe2, r2 = orc.uqe_r(st2)
+    _setup(engine, dict(d, states=st2, uqe=uqe2, r=r2))
+    sup2 = engine.snp_bounds()
+    M = engine.mi_block(np.array([a]), np.array([b]), quirk=L.QUIRK_INTENDED)
+    assert abs(M[0, 0] - sup2[a, 0, 0]) < 1e-9 and M[0, 0] <= sup2[a, 0, 0] + 1e-12
