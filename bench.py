@@ -416,9 +416,12 @@ def main():
                              "planes, " + ("one dual-digit pass instead of 5 limbs (the exact sums of what the screen lists come from "
                                            "k_pair_sums / the band GEMM)" if apx else f"{3 if mixed_blocks else J} int8 limbs") +
                              ".  The launch time of gemm_apx_kernel includes its epilogue, which applies the screen's threshold table to the "
-                             "kernel's own accumulators (the regions that pass are neither stored nor screened): without it the same K loop "
-                             "takes 0.494 ms per launch = 0.51 of the peak (DESIGN.md 5.1c).  `overlapped_avg_launch_ms` is the bracket inside "
-                             "the timed region, where the GEMM shares the GPU with the previous block's screens and selection")
+                             "kernel's own accumulators (the regions that pass are neither stored nor screened).  Tile pruning (r03, `prune`): on 45 "
+                             "of the 55 block pairs the kernel runs over the list of the wave tiles whose pairs are NOT all dismissed by their "
+                             "marginals alone (k_apx_live_tiles; 40 % of the tiles on this data) — pruned tiles are not in `achieved`, and the "
+                             "shorter launches (3.2 rounds of wave tiles instead of 8.1) pay a larger share of ramp and tail: the same K loop on "
+                             "a full launch (diagonal blocks, --no-prune) runs at 0.49 of the peak (DESIGN.md 5.1c/d).  `overlapped_avg_launch_ms` "
+                             "is the bracket inside the timed region, where the GEMM shares the GPU with the previous block's screens and selection")
             tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
             if os.path.exists(tpath) and (L, N, world) == (100_000, 5_000, 1):   # the configuration the PMC passes were collected on
                 ent = json.load(open(tpath)).get(kname)

@@ -1965,7 +1965,8 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             P.lower_only = E.lower_only;
             if (fuse) {
                 P.fuse = 1;
-                P.skip_ctr = (c->prune && lo_h->ordered) ? c->apx_skip.as<unsigned long long>() : nullptr;   // (list order: a tile spans every bin)
+                static const bool std_kernel = getenv("LDW_APX_KERNEL") == nullptr && getenv("LDW_APX_TILE") == nullptr;   // (the experimental GEMM variants know no tile list)
+                P.skip_ctr = (c->prune && lo_h->ordered && std_kernel) ? c->apx_skip.as<unsigned long long>() : nullptr;   // (list order: a tile spans every bin)
                 if (P.skip_ctr) {
                     P.tile_list = tile_list;
                     P.n_live = n_live;
