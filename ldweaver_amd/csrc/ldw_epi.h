@@ -130,7 +130,14 @@ struct EmitArgs {
     int apx;                             // 1: G is int32 [RTpad][RFpad]
     float apx_EG;                        // units of 2^e_last a GEMM entry can have lost at the exponent transitions of the K loop
     float apx_dfac;                      // 1.01 delta / (1 - delta)
-    float apx_s1;                        // 2^(e_last - F) (2 ln(neff + 12.5) + 3.1) / (1 - delta): what one lost unit can add to den * MI
+    float apx_s1;                        // 2^(e_last - F) (2 ln(neff + 12.5) + 2.1) / (1 - delta): what one lost unit can add to den * MI
+    // r03: the first-order term of the bound splits into sum ln(x den / d) (x - x') and sum (x - x'); the second sum is not an error
+    // term at all but the difference of two totals — every sequence lies in exactly one cell, so sum x = W (the fixed-point total)
+    // and sum x' = (sum of the from-side SNP's approximate marginals) 2^(e_last - F), clamped cells only add to it — known per SNP
+    // (full_cells_screen).  apx_c1 = 0.02 (the c of the bound; 1.02 restores the r02 form, LDW_SCREEN_R02_BOUND), apx_W = W (0: r02 form),
+    // apx_unit = 2^(e_last - F)
+    float apx_c1;
+    double apx_W, apx_unit;
 };
 
 __device__ __forceinline__ void emit_pair(const EmitArgs &E, const ColInfo &c, int a_loc, int b_loc, int sa, int sb,
@@ -514,6 +521,14 @@ constexpr float SCREEN_EPS = 2e-4f;
 // floor of the marginals; every cell derived by subtraction inherits those of its terms), and f(x) = x ln(x den / d) has
 // f' = ln(x den / d) + 1, so  den MI <= sum f(x') + delta/(1-delta) sum x' (|ln(x' den / d)| + 1 + c) + eta/(1-delta) sum (|ln| + 1 + c)
 // with c = 2 (delta + 2 eta) / (1 - delta) < 0.02 and |ln| + 1 <= 2 ln(neff + 12.5) + 3 in the last sum (lo_bound, ldw_mi.hip).
+// r03 (fully flagged tables, i.e. this function): f is convex, so f(x) <= f(x') + f'(x) (x - x') with f'(x) = ln(x den / d) + 1, and
+//     sum_cells f'(x) (x - x') = sum ln(x den / d) (x - x')  +  sum (x - x').
+// The first sum is bounded as before WITHOUT the "+ 1" (|ln(x den / d)| <= |ln(x' den / d)| + c).  The second is exact: every sequence
+// lies in exactly one cell, so sum x = W + cells / 2, and the derived cells telescope — row i of the table sums to the approximate
+// marginal pa'_i whatever the GEMM entries lost — so sum x' = (sum_i pa'_i) 2^(e_last - F) + cells / 2 (more where a negative derived
+// cell was clamped): sum (x - x') <= W - (sum_i pa'_i) 2^(e_last - F), a per-SNP constant of a few 1e-2 (the weights are rounded to
+// the NEAREST dual-digit product: the errors of the 57 weight classes of C4 largely cancel) instead of delta sum x' = 0.27.  The
+// margin this removes, delta = 1.5e-3 nats, was three quarters of the bound's slack: 2.77e6 -> 1.98e6 listed pairs per C4 pass.
 template <int NA, int NB, bool APX = false>
 __device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSide &R, const ColMeta &M, double RXY,
                                                    const FullCells<NA, NB> &C) {
@@ -556,7 +571,14 @@ __device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSi
         const float EG = A.E.apx_EG;
         const float lost_units = (float)(NA * NB) * EG + (float)NA * fmaxf(1.0f, (float)NB * EG) + (float)NB * fmaxf(1.0f, (float)NA * EG) +
                                  fmaxf((float)NB, 1.0f + (float)(NA * NB) * EG);
-        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + lost_units * A.E.apx_s1;
+        float dW = 0.0f;
+        if (A.E.apx_W > 0.0) {   // sum (x - x') <= W - (sum of the from-side SNP's approximate marginals), in weight units (+ rounding room)
+            int64_t ta = 0;
+#pragma unroll
+            for (int i = 0; i <= NA; ++i) ta += R.pa[i];
+            dW = (float)(A.E.apx_W - (double)ta * A.E.apx_unit) + 4e-6f * (float)A.E.apx_W;
+        }
+        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, A.E.apx_c1 * xsum) + lost_units * A.E.apx_s1 + dW;
         return fmaf(acc, 0.6931471805599453f, extra) * __builtin_amdgcn_rcpf(den);
     }
     return acc * (0.6931471805599453f * __builtin_amdgcn_rcpf(den));
@@ -627,7 +649,8 @@ __device__ __forceinline__ float pair_screen_generic(const EpiArgs &A, const Row
     if (APX) {   // see full_cells_screen: the units the cells can be off by, for na x nb indicator rows
         const float EG = A.E.apx_EG, fa = (float)na, fb = (float)nb;
         const float lost_units = fa * fb * EG + fa * fmaxf(1.0f, fb * EG) + fb * fmaxf(1.0f, fa * EG) + fmaxf(fb, 1.0f + fa * fb * EG);
-        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + lost_units * A.E.apx_s1;
+        // (tables with unflagged cells: the totals argument of full_cells_screen does not apply; the r02 form, apx_s1 + one unit of |ln| + 1)
+        const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + lost_units * (A.E.apx_s1 + (float)A.E.apx_unit * 1.02f);
         return fmaf(acc, 0.6931471805599453f, extra) * __builtin_amdgcn_rcpf(den);
     }
     return acc * (0.6931471805599453f * __builtin_amdgcn_rcpf(den));

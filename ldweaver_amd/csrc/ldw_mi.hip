@@ -2540,7 +2540,11 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
         E.apx = 1;
         E.apx_EG = (float)(c->apx_lost_units * 1.001);
         E.apx_dfac = (float)(1.01 * c->apx_delta / (1.0 - c->apx_delta));
-        E.apx_s1 = (float)(std::ldexp(1.0, c->apx_e_last - c->frac_bits) * (2.0 * std::log(den + 12.5) + 3.1) / (1.0 - c->apx_delta) * 1.01);
+        static const bool r02_bound = getenv("LDW_SCREEN_R02_BOUND") != nullptr;   // A/B: the bound without the totals argument
+        E.apx_unit = std::ldexp(1.0, c->apx_e_last - c->frac_bits);
+        E.apx_s1 = (float)(E.apx_unit * (2.0 * std::log(den + 12.5) + (r02_bound ? 3.1 : 2.1)) / (1.0 - c->apx_delta) * 1.01);
+        E.apx_c1 = r02_bound ? 1.02f : 0.02f;
+        E.apx_W = r02_bound ? 0.0 : std::ldexp((double)c->total_fixed, -c->frac_bits);
         E.scr_shift = 0;
         E.scr_scale = (float)std::ldexp(1.0, c->apx_e_last - c->frac_bits);
         E.scr_eps = SCREEN_EPS;
