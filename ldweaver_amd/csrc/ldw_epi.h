@@ -528,7 +528,7 @@ constexpr float SCREEN_EPS = 2e-4f;
 // marginal pa'_i whatever the GEMM entries lost — so sum x' = (sum_i pa'_i) 2^(e_last - F) + cells / 2 (more where a negative derived
 // cell was clamped): sum (x - x') <= W - (sum_i pa'_i) 2^(e_last - F), a per-SNP constant of a few 1e-2 (the weights are rounded to
 // the NEAREST dual-digit product: the errors of the 57 weight classes of C4 largely cancel) instead of delta sum x' = 0.27.  The
-// margin this removes, delta = 1.5e-3 nats, was three quarters of the bound's slack: 2.77e6 -> 1.98e6 listed pairs per C4 pass.
+// margin this removes is delta = 1.5e-3 nats: 2.77e6 -> 2.17e6 listed pairs per C4 pass (LDW_SCREEN_R02_BOUND restores the old form).
 template <int NA, int NB, bool APX = false>
 __device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSide &R, const ColMeta &M, double RXY,
                                                    const FullCells<NA, NB> &C) {
