@@ -260,23 +260,27 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     ldw::DevBuf *bufs[] = {&c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->apx_skip, &c->snp_sup, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
-                           &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->perm_t, &c->scr_units, &c->slot_pfix_hi, &c->glo, &c->lo_rows, &c->packs, &c->hist[0], &c->hist[1], &c->colcnt, &c->cand_key[0], &c->cand_key[1],
-                           &c->cand_val[0], &c->cand_val[1], &c->cand_key2, &c->cand_val2, &c->sel_bitmap, &c->sel_chunks, &c->sel_prefix, &c->apx_bins[0], &c->apx_bins[1], &c->apx_clean[0], &c->apx_clean[1], &c->scratch, &c->small, &c->sr_a, &c->sr_b,
+                           &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->perm_t, &c->scr_units, &c->slot_pfix_hi, &c->glo, &c->lo_rows, &c->packs, &c->colcnt,
+                           &c->cand_key2, &c->cand_val2, &c->sel_bitmap, &c->sel_chunks, &c->sel_prefix, &c->scratch, &c->small, &c->sr_a, &c->sr_b,
                            &c->sr_mi, &c->lr_a, &c->lr_b, &c->lr_mi, &c->srm_pack, &c->srm_key, &c->srm_pack2, &c->srm_key2, &c->srm_pay, &c->srm_pay2, &c->srm_off,
                            &c->srm_q, &c->srm_n, &c->srm_md, &c->srm_part, &c->srm_shape, &c->srm_cnt, &c->red_row, &c->red_meta,
                            &c->red_srp, &c->pool_a, &c->pool_b, &c->pool_mi, &c->ar_key, &c->ar_val, &c->ar_key2, &c->ar_val2,
                            &c->ar_off, &c->ar_flags, &c->seq_perm, &c->dig_a, &c->dig_b, &c->apx_shift, &c->slot_papx, &c->pop_segs, &c->pop_wbeg,
-                           &c->panel[0][0], &c->panel[0][1], &c->panel[1][0], &c->panel[1][1], &c->Gapx[0], &c->Gapx[1], &c->pair_sums, &c->tab11[0], &c->tab11[1], &c->pairs[0], &c->pairs[1], &c->apx_units[0], &c->apx_units[1], &c->apx_packs[0], &c->apx_packs[1]};
+                           &c->pair_sums, &c->tab11[0], &c->tab11[1], &c->G2, &c->G3};
     for (auto *b : bufs) b->release();
+    for (int k = 0; k < LDW_NSLOT; ++k)
+        for (ldw::DevBuf *b : {&c->panel[k][0], &c->panel[k][1], &c->Gapx[k], &c->pairs[k], &c->apx_units[k], &c->apx_packs[k], &c->apx_bins[k], &c->apx_clean[k],
+                               &c->hist[k], &c->cand_key[k], &c->cand_val[k]})
+            b->release();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < LDW_NSLOT; ++k) {
         c->dstage[k].release();
         if (c->pin[k]) (void)hipHostFree(c->pin[k]);
         if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]);
         if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
     }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < LDW_NSLOT; ++k) {
         if (c->pin_pick[k]) (void)hipHostFree(c->pin_pick[k]);
         if (c->ev_pick[k]) (void)hipEventDestroy(c->ev_pick[k]);
     }
@@ -287,7 +291,6 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     if (c->gemm_stream) (void)hipStreamDestroy(c->gemm_stream);
     for (auto &e : c->ev_gemm)
         if (e) (void)hipEventDestroy(e);
-    c->G2.release();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LDW_OK;

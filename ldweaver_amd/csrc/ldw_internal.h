@@ -8,6 +8,10 @@
 
 #include "../../include/ldweaver_amd.h"
 
+// Pipeline slots of the all-pairs loop: the block-wide kernels (GEMM stream) may run LDW_NSLOT - 1 blocks ahead of the block whose
+// lists the main stream is evaluating; every per-block buffer exists once per slot (block b uses slot b % LDW_NSLOT).
+#define LDW_NSLOT 3
+
 namespace ldw {
 
 void set_error(const char *fmt, ...);
@@ -104,8 +108,8 @@ struct ldw_ctx {
     ldw::DevBuf slot_papx;             // int64 [L][5] by slot: floor(marginal of V' / 2^apx_e_last)
     ldw::DevBuf pop_segs, pop_wbeg;    // popcount segments (PopSeg) and first segment of every 32-bit word (+1)
     int n_pop_segs = 0, n_classes = 0;
-    ldw::DevBuf panel[2][2];           // [slot][from, to]: packed bit panels of a block's row lists, [KW/2][Rpad][2] u64
-    ldw::DevBuf Gapx[2];               // int32 [RTpad][RFpad] approximate joint sums, one per pipeline slot
+    ldw::DevBuf panel[LDW_NSLOT][2];           // [slot][from, to]: packed bit panels of a block's row lists, [KW/2][Rpad][2] u64
+    ldw::DevBuf Gapx[LDW_NSLOT];               // int32 [RTpad][RFpad] approximate joint sums, one per pipeline slot
     ldw::DevBuf tab11[2];              // threshold tables of the biallelic pairs (k_build_tab11), int2 [nb][nb]: [off-diagonal, diagonal] blocks
     double tab11_lo[2] = {0, 0};       // MI level each was built for (0: none)
     int64_t tab11_builds = 0;
@@ -113,9 +117,9 @@ struct ldw_ctx {
     int tab11_nb = 0;
     bool tab11_on = true;              // LDW_NO_TAB11 switches the table off (A/B measurements)
     ldw::DevBuf pair_sums;             // exact joint sums of the listed pairs (16 per pair)
-    ldw::DevBuf pairs[2];              // per pipeline slot: pair lists of the approximate screen (counters + PAIR_PATHS x PAIR_SHARDS lists)
-    ldw::DevBuf apx_bins[2], apx_clean[2];    // per slot: threshold-table bin of every row of the two row lists; clean-region flags of the GEMM epilogue
-    ldw::DevBuf apx_units[2], apx_packs[2];   // per slot: per-(tile, class) unit lists + counters; per-block SNP constants
+    ldw::DevBuf pairs[LDW_NSLOT];              // per pipeline slot: pair lists of the approximate screen (counters + PAIR_PATHS x PAIR_SHARDS lists)
+    ldw::DevBuf apx_bins[LDW_NSLOT], apx_clean[LDW_NSLOT];    // per slot: threshold-table bin of every row of the two row lists; clean-region flags of the GEMM epilogue
+    ldw::DevBuf apx_units[LDW_NSLOT], apx_packs[LDW_NSLOT];   // per slot: per-(tile, class) unit lists + counters; per-block SNP constants
     int64_t apx_blocks = 0, apx_units_listed = 0, apx_pairs_listed = 0, probe_blocks = 0, generic_blocks = 0;
     // Tile pruning: in blocks without a short-range pair the one-row SNPs are ordered by the weight of their minor
     // state, so that a wave tile of the approximate GEMM spans few bins of the threshold table; a tile whose whole bin rectangle is
@@ -160,11 +164,11 @@ struct ldw_ctx {
     std::vector<int64_t> h_minor_w;   // [L]: fixed-point weight of slot 0 of a biallelic r = 2 SNP with one row (else INT64_MAX)
 
     // ---- per-block workspaces ----
-    ldw::DevBuf G, G2;           // int64 [RTpad][RFpad] fixed-point joint sums, one per pipeline slot
+    ldw::DevBuf G, G2, G3;       // int64 [RTpad][RFpad] fixed-point joint sums, one per pipeline slot (gx())
     ldw::DevBuf MIblk;           // double [nf*nt]
     ldw::DevBuf rowlist_f, rowlist_t, idx_f, idx_t, lrow_f, lrow_t, perm_f, perm_t;
     ldw::DevBuf scr_units;       // uint32 count (64-B slot) + list of the block's units the fp32 screen wants evaluated exactly
-    ldw::DevBuf hist[2], cand_key[2], cand_val[2];   // per pipeline slot: histogram of the lr candidates, candidate list
+    ldw::DevBuf hist[LDW_NSLOT], cand_key[LDW_NSLOT], cand_val[LDW_NSLOT];   // per pipeline slot: histogram of the lr candidates, candidate list
     ldw::DevBuf colcnt, cand_key2, cand_val2, scratch, small;
     ldw::DevBuf sel_bitmap, sel_chunks, sel_prefix;   // fast selection (k_sel_thresh): bitmap, chunk and super-chunk (sel_prefix) counters, all-zero between blocks
 
@@ -184,16 +188,16 @@ struct ldw_ctx {
 
     // ---- pipelined block staging: host prep of block i+1 overlaps the GPU work of block i ----
     hipStream_t copy_stream = nullptr, gemm_stream = nullptr;
-    hipEvent_t ev_gemm[2] = {nullptr, nullptr};
+    hipEvent_t ev_gemm[LDW_NSLOT] = {};
     bool overlap = true;                 // GEMM of block b+1 on its own stream beside the epilogue/selection of block b
-    void *pin[2] = {nullptr, nullptr};   // pinned host staging, one packed buffer per slot
-    size_t pin_cap[2] = {0, 0};
-    ldw::DevBuf dstage[2];               // device image of the packed buffer
-    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-    bool done_recorded[2] = {false, false};
-    bool up_recorded[2] = {false, false};    // ev_up[slot] has been recorded at least once
-    void *pin_pick[2] = {nullptr, nullptr};   // pinned landing zone of the per-block PickOut, one per slot
-    hipEvent_t ev_pick[2] = {nullptr, nullptr};
+    void *pin[LDW_NSLOT] = {};   // pinned host staging, one packed buffer per slot
+    size_t pin_cap[LDW_NSLOT] = {};
+    ldw::DevBuf dstage[LDW_NSLOT];               // device image of the packed buffer
+    hipEvent_t ev_up[LDW_NSLOT] = {}, ev_done[LDW_NSLOT] = {};
+    bool done_recorded[LDW_NSLOT] = {};
+    bool up_recorded[LDW_NSLOT] = {};    // ev_up[slot] has been recorded at least once
+    void *pin_pick[LDW_NSLOT] = {};   // pinned landing zone of the per-block PickOut, one per slot
+    hipEvent_t ev_pick[LDW_NSLOT] = {};
     void *pin_lrc = nullptr;             // pinned copy of the running long-range row count
     hipEvent_t ev_lrc = nullptr;
     bool lrc_recorded = false;

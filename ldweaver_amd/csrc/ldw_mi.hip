@@ -37,11 +37,18 @@
 #define LDW_SCREEN_V 2   // columns in flight per wave in the multi-cell screen (tuning: make CXXFLAGS+=-DLDW_SCREEN_V=4)
 #endif
 #include "ldw_epi.h"
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include "ldw_apx.h"
 
 using namespace ldw;
 
 namespace ldw {
+
+// the exact-sum block of pipeline slot s
+static inline ldw::DevBuf &gx(ldw_ctx *c, int s) { return s == 0 ? c->G : (s == 1 ? c->G2 : c->G3); }
 
 // Per-block SNP constants in epilogue order, once per block instead of once per workgroup (k_mi_screen) or per unit
 // (k_mi_units): thread i builds column slot i (i < nt) and from-side slot i (i < 64 * tiles); A.colpack / A.rowpack are null here.
@@ -1826,7 +1833,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     // units are evaluated from EXACT sums: the 5-limb GEMM of the tiles they live in (all tiles when any unit can be listed)
     const bool need_exact = E.any_sr || !use_pairs || lo_h->band_full;
     const uint8_t *band = (use_pairs && !lo_h->band_full) ? D.band_mask : nullptr;
-    ldw::DevBuf &Gx = s ? c->G2 : c->G;
+    ldw::DevBuf &Gx = gx(c, s);
     if (phase == 1) {
         if (int rc = c->panel[s][0].reserve((size_t)RFpad * c->KW * 8)) return rc;
         if (!lo_h->diag)
@@ -2158,7 +2165,7 @@ int ensure_links_capacity(ldw_ctx *c, int64_t sr_rows, int64_t lr_rows) {
 // layout of ctx->small during link selection
 struct SmallLayout {
     int64_t *lr_count;   // running number of kept long-range rows (device side)
-    ldw::PickOut *pick[2];   // one per pipeline slot
+    ldw::PickOut *pick[LDW_NSLOT];   // one per pipeline slot
     int64_t *stats_i;    // [capacity][3]
     double *stats_d;     // [capacity]
 };
@@ -2168,9 +2175,8 @@ constexpr size_t PICK_STRIDE = ((sizeof(ldw::PickOut) + 63) / 64) * 64;
 void links_layout(ldw_ctx *c, SmallLayout &sl) {
     char *base = c->small.as<char>();
     sl.lr_count = reinterpret_cast<int64_t *>(base);
-    sl.pick[0] = reinterpret_cast<ldw::PickOut *>(base + 64);
-    sl.pick[1] = reinterpret_cast<ldw::PickOut *>(base + 64 + PICK_STRIDE);
-    sl.stats_i = reinterpret_cast<int64_t *>(base + 64 + 2 * PICK_STRIDE);
+    for (int k = 0; k < LDW_NSLOT; ++k) sl.pick[k] = reinterpret_cast<ldw::PickOut *>(base + 64 + (size_t)k * PICK_STRIDE);
+    sl.stats_i = reinterpret_cast<int64_t *>(base + 64 + LDW_NSLOT * PICK_STRIDE);
     sl.stats_d = reinterpret_cast<double *>(sl.stats_i + c->blk_capacity * 3);
 }
 
@@ -2630,7 +2636,7 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
         memset(&E, 0, sizeof(E));
         E.lower_only = hb.diag ? 1 : 0;
         E.do_lr = do_lr ? 1 : 0;
-        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, ev, 1, s ? &c->G2 : &c->G, gs, nullptr,
+        if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, ev, 1, &gx(c, s), gs, nullptr,
                                      hb.mixed ? &hb.lo : nullptr))
             return rc;
         LDW_HIP(hipEventRecord(c->ev_gemm[s], gs));
@@ -2683,7 +2689,7 @@ int submit_generic(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
     E0.write_dense = 1;
     E0.spec_B = -1;
     E0.lower_only = 0;   // every entry of the block (a diagonal block too: the pair list decides which ones are pairs)
-    if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E0, ev, 3, s ? &c->G2 : &c->G, nullptr, nullptr)) return rc;
+    if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E0, ev, 3, &gx(c, s), nullptr, nullptr)) return rc;
     LDW_HIP(hipEventRecord(ev[5], c->stream));   // (ldw_links_end brackets ev[1] .. ev[5] and ev[4] .. ev[2]: every event of the block must be recorded)
     LDW_HIP(hipEventRecord(ev[4], c->stream));
     if (int rc = c->hist[s].reserve((size_t)NBINS * 8)) return rc;
@@ -2768,7 +2774,7 @@ int submit_b(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
         if (int rc = launch_block_apx(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, 2, nullptr, c->hist[s].as<unsigned long long>(), &hb.lo))
             return rc;
     } else if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, c->engine == LDW_ENGINE_MFMA ? 2 : 3,
-                                        s ? &c->G2 : &c->G, nullptr, c->hist[s].as<unsigned long long>(), hb.mixed ? &hb.lo : nullptr))
+                                        &gx(c, s), nullptr, c->hist[s].as<unsigned long long>(), hb.mixed ? &hb.lo : nullptr))
         return rc;
     c->n_sr += sr_add;
     if (int rc = launch_pick(c, hb, p, sl, c->stream)) return rc;
@@ -2802,7 +2808,7 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
         hipEvent_t dummy[6] = {c->ev[3], c->ev[3], c->ev[4], c->ev[3], c->ev[5], c->ev[3]};   // keep the block's stage events as they are
         E.apx = 0;
         if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, E, dummy, (hb.fused || hb.mixed || hb.apx) ? 3 : 2,
-                                     s ? &c->G2 : &c->G, nullptr, c->hist[s].as<unsigned long long>()))
+                                     &gx(c, s), nullptr, c->hist[s].as<unsigned long long>()))
             return rc;
         if (int rc = launch_pick(c, hb, p, sl, c->stream)) return rc;
         if (int rc = launch_gather(c, hb, E, sl)) return rc;
@@ -3072,16 +3078,16 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(nblocks_capacity > 0, LDW_ERR_ARG, "ldw_links_begin: capacity must be positive");
     if (int rc = ensure_rows(c)) return rc;  // uses ctx->small for staging; link bookkeeping takes it over below
-    const size_t need = 64 + 2 * PICK_STRIDE + (size_t)nblocks_capacity * 32 + 64;
+    const size_t need = 64 + LDW_NSLOT * PICK_STRIDE + (size_t)nblocks_capacity * 32 + 64;
     if (int rc = c->small.reserve(need)) return rc;
     LDW_HIP(hipMemsetAsync(c->small.p, 0, need, c->stream));
     if (!c->copy_stream) {
         LDW_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < LDW_NSLOT; ++k) {
             LDW_HIP(hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming));
             LDW_HIP(hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
         }
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < LDW_NSLOT; ++k) {
             LDW_HIP(hipEventCreateWithFlags(&c->ev_pick[k], hipEventDisableTiming));
             LDW_HIP(hipHostMalloc(&c->pin_pick[k], sizeof(ldw::PickOut) + 64, hipHostMallocDefault));
         }
@@ -3092,10 +3098,21 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
             int lo_p = 0, hi_p = 0;
             LDW_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
             static const bool prio = getenv("LDW_NO_STREAM_PRIO") == nullptr;
-            if (prio) LDW_HIP(hipStreamCreateWithPriority(&c->gemm_stream, hipStreamNonBlocking, lo_p));
+            // LDW_CU_RESERVE=m (odd, experiment): the GEMM stream may not use every m-th CU, so that the main stream's chain of small
+            // kernels always finds free CUs while a block-wide kernel runs (an odd modulus spreads the reserved CUs over the XCDs
+            // whether the mask bits run XCD by XCD or interleave them)
+            static const int cu_mod = [] { const char *e = getenv("LDW_CU_RESERVE"); return e ? atoi(e) : 0; }();
+            if (cu_mod >= 3 && (cu_mod & 1)) {
+                int cus = 256;
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+                std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+                for (int i = 0; i < cus; ++i)
+                    if (i % cu_mod != cu_mod - 1) mask[(size_t)i / 32] |= 1u << (i % 32);
+                LDW_HIP(hipExtStreamCreateWithCUMask(&c->gemm_stream, (uint32_t)mask.size(), mask.data()));
+            } else if (prio) LDW_HIP(hipStreamCreateWithPriority(&c->gemm_stream, hipStreamNonBlocking, lo_p));
             else LDW_HIP(hipStreamCreateWithFlags(&c->gemm_stream, hipStreamNonBlocking));
         }
-        for (int k = 0; k < 2; ++k) LDW_HIP(hipEventCreateWithFlags(&c->ev_gemm[k], hipEventDisableTiming));
+        for (int k = 0; k < LDW_NSLOT; ++k) LDW_HIP(hipEventCreateWithFlags(&c->ev_gemm[k], hipEventDisableTiming));
     }
     // everything queued on the main stream so far (row map, weights) must be visible to the GEMM stream
     LDW_HIP(hipEventRecord(c->ev_up[0], c->stream));
@@ -3134,7 +3151,7 @@ int ldw_mi_block_links(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const in
     SmallLayout sl;
     links_layout(c, sl);
     HostBlock hb;
-    if (int rc = prep_block(c, from_idx, nf, to_idx, nt, p, (int)(c->blk_cursor & 1), c->blk_cursor, hb)) return rc;
+    if (int rc = prep_block(c, from_idx, nf, to_idx, nt, p, (int)(c->blk_cursor % LDW_NSLOT), c->blk_cursor, hb)) return rc;
     if (int rc = submit_a(c, hb, p, sl)) return rc;
     if (int rc = submit_b(c, hb, p, sl)) return rc;
     if (int rc = finish_block(c, hb, p, sl)) return rc;
@@ -3258,42 +3275,139 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
             if (int rc = probe_kind_guess(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, sl, kind)) return rc;
         }
     }
-    HostBlock hb[3];
+    // r03: the lists of a block are built by a HELPER THREAD that runs ahead of the submitting thread (prep_block is pure host work into the
+    // slot's pinned staging buffer: 0.45 ms per 10k x 10k block — once the GPU side of a block had come down to 0.5 ms it was the loop's
+    // critical path: LDW_HOST_TIMING showed submit 0.05 + prep 0.45 + wait 0.35 ms per block = the whole 47 ms of a pass, and the kernel timeline
+    // the GEMM stream idle for a third of it).  Hand-over through three counters under one mutex: block k may be prepared once block k - RING is
+    // finished (its ring entry is free) and block k - LDW_NSLOT has been submitted (the slot's staging buffer then belongs to an upload the
+    // helper waits for: ev_up); the GEMM stream runs up to LDW_NSLOT - 1 = 2 blocks ahead of the block the main stream evaluates.
+    constexpr int RING = 8;
+    HostBlock hb[RING];
     static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
     double th[5] = {0, 0, 0, 0, 0};
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    auto prep = [&](int64_t b) -> int {
-        if (int rc = fill(b)) return rc;
-        const int slot = (int)(b & 1);
-        if (c->up_recorded[slot]) LDW_HIP(hipEventSynchronize(c->ev_up[slot]));   // the staging buffer of this slot has been uploaded
-        return prep_block(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, slot, b, hb[b % 3]);
+    struct Shared {
+        std::mutex m;
+        std::condition_variable cv;
+        int64_t n_prepped = 0, n_sub = 0, n_done = 0;
+        int rc = LDW_OK;
+        bool stop = false;
+        std::string err;
+    } sh;
+    std::vector<int32_t> wfi, wti;   // the helper's own index lists
+    auto worker = [&]() {
+        (void)hipSetDevice(c->device);
+        for (int64_t k = 0; k < nblocks; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(sh.m);
+                sh.cv.wait(lk, [&] { return sh.stop || (k < sh.n_done + RING && k < sh.n_sub + LDW_NSLOT); });
+                if (sh.stop) return;
+            }
+            int rc = LDW_OK;
+            const int32_t fs = blocks[k * 4 + 0], fe = blocks[k * 4 + 1], ts = blocks[k * 4 + 2], te = blocks[k * 4 + 3];
+            if (!(fs >= 1 && fe >= fs && fe <= c->L && ts >= 1 && te >= ts && te <= c->L)) {
+                set_error("block %lld = (%d,%d,%d,%d) outside 1..%lld", (long long)k, fs, fe, ts, te, (long long)c->L);
+                rc = LDW_ERR_ARG;
+            } else {
+                wfi.resize((size_t)(fe - fs + 1));
+                wti.resize((size_t)(te - ts + 1));
+                for (int32_t q = fs; q <= fe; ++q) wfi[q - fs] = q - 1;
+                for (int32_t q = ts; q <= te; ++q) wti[q - ts] = q - 1;
+                const int slot = (int)(k % LDW_NSLOT);
+                if (c->up_recorded[slot] && hipEventSynchronize(c->ev_up[slot]) != hipSuccess) {   // the staging buffer of this slot has been uploaded
+                    set_error("prep: hipEventSynchronize failed");
+                    rc = LDW_ERR_HIP;
+                }
+                if (rc == LDW_OK) rc = prep_block(c, wfi.data(), (int64_t)wfi.size(), wti.data(), (int64_t)wti.size(), p, slot, k, hb[k % RING]);
+            }
+            std::lock_guard<std::mutex> lk(sh.m);
+            if (rc != LDW_OK) {
+                sh.rc = rc;
+                sh.err = ldw_last_error();
+                sh.stop = true;
+            } else {
+                sh.n_prepped = k + 1;
+            }
+            sh.cv.notify_all();
+            if (rc != LDW_OK) return;
+        }
     };
-    if (int rc = prep(0)) return rc;
-    if (int rc = submit_a(c, hb[0], p, sl)) return rc;
-    if (nblocks > 1)
-        if (int rc = prep(1)) return rc;
+    std::thread helper(worker);
+    struct Joiner {   // every way out of this function stops and joins the helper
+        Shared &sh;
+        std::thread &t;
+        ~Joiner() {
+            {
+                std::lock_guard<std::mutex> lk(sh.m);
+                sh.stop = true;
+            }
+            sh.cv.notify_all();
+            if (t.joinable()) t.join();
+        }
+    } joiner{sh, helper};
+    // blocks until block k is prepared (true) — or, with wait = false, says whether it is
+    auto prepped = [&](int64_t k, bool wait, int &rc) -> bool {
+        std::unique_lock<std::mutex> lk(sh.m);
+        if (wait) sh.cv.wait(lk, [&] { return sh.rc != LDW_OK || sh.n_prepped > k; });
+        rc = sh.rc;
+        if (rc != LDW_OK) set_error("%s", sh.err.c_str());
+        return sh.n_prepped > k;
+    };
+    int64_t n_sub = 0;   // blocks [0, n_sub) have been submitted to the GEMM stream
+    auto submit_next = [&]() -> int {
+        if (int rc = submit_a(c, hb[n_sub % RING], p, sl)) return rc;
+        ++n_sub;
+        {
+            std::lock_guard<std::mutex> lk(sh.m);
+            sh.n_sub = n_sub;
+        }
+        sh.cv.notify_all();
+        return LDW_OK;
+    };
+    const int64_t ahead = c->overlap ? LDW_NSLOT - 1 : 1;
+    {
+        int rc = LDW_OK;
+        prepped(0, true, rc);
+        if (rc) return rc;
+        if ((rc = submit_next())) return rc;
+    }
     for (int64_t b = 0; b < nblocks; ++b) {
-        HostBlock &cur = hb[b % 3], &nxt = hb[(b + 1) % 3];
+        HostBlock &cur = hb[b % RING];
         double t0 = now();
         if (int rc = submit_b(c, cur, p, sl)) return rc;                 // unfused: epilogue + pick of block b (main stream)
         th[0] += now() - t0;
         t0 = now();
-        if (b + 1 < nblocks && can_submit_early(c, nxt, p))
-            if (int rc = submit_a(c, nxt, p, sl)) return rc;              // block b+1 (GEMM stream) runs beside them
+        // blocks b+1 .. b+ahead (GEMM stream) run beside them: b+1 is waited for, the ones after it are taken if they are ready
+        while (n_sub < nblocks && n_sub <= b + ahead) {
+            int rc = LDW_OK;
+            const double tw = now();
+            const bool ready = prepped(n_sub, n_sub == b + 1, rc);
+            th[1] += now() - tw;
+            if (rc) return rc;
+            if (!ready || !can_submit_early(c, hb[n_sub % RING], p)) break;
+            if ((rc = submit_next())) return rc;
+        }
         th[2] += now() - t0;
         t0 = now();
-        if (b + 2 < nblocks)
-            if (int rc = prep(b + 2)) return rc;                          // host work, hidden behind the GPU
-        th[1] += now() - t0;
-        t0 = now();
+        // (tried: the second phase of block b+1 queued HERE, before the host waits for block b's pick, so that the main stream has work during the
+        // round trip — block b's selection then runs behind it, its slot is released later, and the pass got slower: 43.0 against 40.2 ms)
         if (int rc = finish_block(c, cur, p, sl)) return rc;             // round trip + selection of block b
         th[3] += now() - t0;
-        if (b + 1 < nblocks && !nxt.submitted)
-            if (int rc = submit_a(c, nxt, p, sl)) return rc;              // overlap off / no guess yet: one block after the other
+        {
+            std::lock_guard<std::mutex> lk(sh.m);
+            sh.n_done = b + 1;
+        }
+        sh.cv.notify_all();
+        if (n_sub <= b + 1 && b + 1 < nblocks) {                          // overlap off / no guess yet: one block after the other
+            int rc = LDW_OK;
+            prepped(b + 1, true, rc);
+            if (rc) return rc;
+            if ((rc = submit_next())) return rc;
+        }
         ++c->blk_cursor;
     }
     if (host_timing)
-        fprintf(stderr, "[ldw host us/block] submit_b %.1f  prep %.1f  submit_a %.1f  finish (incl. wait) %.1f  blocks %lld\n", th[0] / nblocks, th[1] / nblocks,
+        fprintf(stderr, "[ldw host us/block] submit_b %.1f  wait for the helper's prep %.1f  submit_a (incl. that wait) %.1f  finish (incl. wait) %.1f  blocks %lld\n", th[0] / nblocks, th[1] / nblocks,
                 th[2] / nblocks, th[3] / nblocks, (long long)nblocks);
     return ldw_links_end(c);
 }

@@ -13,12 +13,29 @@ def short(n):
     m = re.search(r"ldw::(\w+)", n)
     return m.group(1) if m else re.sub(r".*::", "", n)[:28]
 g = [i for i, r in enumerate(rows) if "gemm_apx_kernel" in r["Kernel_Name"]]
-g = g[-55:]                      # the last pass
+g = g[-165:-110]                 # the last TIMED (overlapped) pass: bench.py ends with two serialized replay passes
 i0, i1 = g[20], g[26]            # six blocks in the middle
+sys.stderr.write("columns: " + ",".join(rows[0].keys()) + "\n")
 t0 = int(rows[i0]["Start_Timestamp"])
+# busy / idle time of every queue over the whole pass
+lo_i, hi_i = g[0] - 6, min(len(rows), g[-1] + 30)
+span0, span1 = int(rows[lo_i]["Start_Timestamp"]), int(rows[hi_i - 1]["End_Timestamp"])
+busy = {}
+for r in rows[lo_i:hi_i]:
+    q = r.get("Queue_Id", "?")
+    busy.setdefault(q, []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+for q, iv in busy.items():
+    iv.sort()
+    tot, gaps, cur_e = 0, [], None
+    for s_, e_ in iv:
+        tot += e_ - s_
+        if cur_e is not None and s_ > cur_e: gaps.append((s_ - cur_e) / 1e3)
+        cur_e = e_ if cur_e is None else max(cur_e, e_)
+    big = sorted(gaps, reverse=True)[:12]
+    print(f"# queue {q}: pass span {(span1 - span0) / 1e6:.2f} ms, busy {tot / 1e6:.2f} ms, idle gaps > 30 us: {sum(1 for x in gaps if x > 30)} totalling {sum(x for x in gaps if x > 30) / 1e3:.2f} ms; largest {[round(x) for x in big]}")
 qs = {}
 for r in rows[i0 - 8:i1]:
-    q = r.get("Queue_Id", "?")
+    q = r.get("Queue_Id", r.get("Stream_Id", "?"))
     qs.setdefault(q, len(qs))
     s = (int(r["Start_Timestamp"]) - t0) / 1e3
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
