@@ -3122,7 +3122,7 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
         LDW_HIP(hipEventCreate(&e));
         c->ev_pool.push_back(e);
     }
-    c->done_recorded[0] = c->done_recorded[1] = false;
+    for (int k = 0; k < LDW_NSLOT; ++k) c->done_recorded[k] = false;
     c->lrc_recorded = false;
     c->n_sr = 0;
     c->n_lr = 0;
@@ -3275,6 +3275,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
             if (int rc = probe_kind_guess(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, sl, kind)) return rc;
         }
     }
+    // (The helper starts AFTER the cold-start probes above: they stage their sample through slot 0's buffers.)
     // r03: the lists of a block are built by a HELPER THREAD that runs ahead of the submitting thread (prep_block is pure host work into the
     // slot's pinned staging buffer: 0.45 ms per 10k x 10k block — once the GPU side of a block had come down to 0.5 ms it was the loop's
     // critical path: LDW_HOST_TIMING showed submit 0.05 + prep 0.45 + wait 0.35 ms per block = the whole 47 ms of a pass, and the kernel timeline
