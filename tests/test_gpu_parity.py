@@ -1628,3 +1628,27 @@ def test_snp_bounds_hold_for_every_partner(engine):
     sup2 = engine.snp_bounds()
     M = engine.mi_block(np.array([a]), np.array([b]), quirk=L.QUIRK_INTENDED)
     assert abs(M[0, 0] - sup2[a, 0, 0]) < 1e-9 and M[0, 0] <= sup2[a, 0, 0] + 1e-12
+
+
+def test_bad_block_in_the_middle_of_a_pass_is_reported_and_the_engine_survives(engine, synth):
+    """The block lists are prepared by a helper thread that runs ahead of the submitting thread: an invalid block in the middle of a pass
+    must come back as an ordinary error — no hang, no crash, the message of the helper's check — and the next pass on the same context
+    must give the usual tables."""
+    d = synth
+    _setup(engine, d)
+    Ls = len(d["states"])
+    approx = orc.lr_links_approx(d["POS"], d["g"], 20000.0)
+    blocks = np.array(orc.make_blocks(Ls, max(64, Ls // 6)), dtype=np.int32)
+    assert len(blocks) >= 10
+    engine.mi_all_pairs(blocks, 20000.0, 5000.0, approx)
+    ref = (engine.links(0), engine.links(1))
+    bad = blocks.copy()
+    bad[len(bad) // 2, 1] = Ls + 5                                      # from-range runs past the alignment
+    with pytest.raises(L.LdwError) as ei:
+        engine.mi_all_pairs(bad, 20000.0, 5000.0, approx)
+    assert "outside 1.." in str(ei.value)
+    for _ in range(2):
+        engine.mi_all_pairs(blocks, 20000.0, 5000.0, approx)
+        for which in (0, 1):
+            for x, y in zip(ref[which], engine.links(which)):
+                assert np.array_equal(x, y)
