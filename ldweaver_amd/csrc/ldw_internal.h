@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../include/ldweaver_amd.h"
@@ -127,7 +129,9 @@ struct ldw_ctx {
     bool prune = true;                 // LDW_NO_PRUNE switches ordering and skipping off (A/B measurements)
     ldw::DevBuf apx_skip;              // uint64: wave tiles the GEMM skipped since the counter was last read
     double apx_ops_per_wave = 0;       // executed-operation accounting of the skipped tiles (ldw_gemm_stats)
-    int64_t apx_waves_skipped = 0, apx_waves_total = 0, sorted_blocks = 0;
+    int64_t apx_waves_skipped = 0, apx_waves_total = 0;
+    std::atomic<int64_t> sorted_blocks{0};   // (prep_block runs on the helper thread and, for the cold-start probes, on the calling thread at once)
+    std::mutex order_mtx;                    // guards order_cache
     // Per-SNP bound behind the pruning of the wider tables (k_snp_sup): snp_sup[a * 4 + 2 * m + (k - 2)] = the largest MI SNP a (2 or
     // 3 states, all flagged, r = its number of states) can reach with ANY partner of k = 2 or 3 flagged states and r = k, in the
     // intended (m = 0) and the reference (m = 1: RXY at its floor r_min^2 / 4) reading of RXY; +inf for other SNPs.

@@ -2100,19 +2100,27 @@ void build_perm(ldw_ctx *c, const int32_t *from_idx, int64_t nf, int32_t *perm, 
 
 // The one-row SNPs of a list in ascending order of h_minor_w (ties in list order), cached per list: the all-pairs loop presents
 // the same ten or fifty lists over and over, and a sort of 10^4 keys costs as much host time as the rest of prep_block.
-const std::vector<int32_t> *minor_weight_order(ldw_ctx *c, const int32_t *idx, int64_t n) {
-    for (auto &pe : c->order_cache)
-        if ((int64_t)pe->idx.size() == n && pe->idx[0] == idx[0] && memcmp(pe->idx.data(), idx, (size_t)n * 4) == 0) return &pe->order;
-    c->order_cache.emplace_back(new ldw_ctx::OrderCache());   // (entries are heap objects: the pointers handed out survive the vector's growth)
-    auto &e = *c->order_cache.back();
-    e.idx.assign(idx, idx + n);
+// Entries are heap objects and are never removed while the row map lives (ensure_rows clears the cache): the pointers handed out stay
+// valid whatever another thread adds; a full cache (256 lists) computes into the caller's own vector instead.
+const std::vector<int32_t> *minor_weight_order(ldw_ctx *c, const int32_t *idx, int64_t n, std::vector<int32_t> &own) {
+    {
+        std::lock_guard<std::mutex> lk(c->order_mtx);
+        for (auto &pe : c->order_cache)
+            if ((int64_t)pe->idx.size() == n && pe->idx[0] == idx[0] && memcmp(pe->idx.data(), idx, (size_t)n * 4) == 0) return &pe->order;
+    }
     std::vector<std::pair<int64_t, int32_t>> key;
     key.reserve((size_t)n);
     for (int64_t k = 0; k < n; ++k)
         if (c->h_row0[idx[k] + 1] - c->h_row0[idx[k]] == 1) key.emplace_back(c->h_minor_w[(size_t)idx[k]], (int32_t)k);
     std::sort(key.begin(), key.end());
-    e.order.resize(key.size());
-    for (size_t i = 0; i < key.size(); ++i) e.order[i] = key[i].second;
+    own.resize(key.size());
+    for (size_t i = 0; i < key.size(); ++i) own[i] = key[i].second;
+    std::lock_guard<std::mutex> lk(c->order_mtx);
+    if (c->order_cache.size() >= 256) return &own;
+    c->order_cache.emplace_back(new ldw_ctx::OrderCache());
+    auto &e = *c->order_cache.back();
+    e.idx.assign(idx, idx + n);
+    e.order = own;
     return &e.order;
 }
 
@@ -2243,15 +2251,14 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     // of tiles the exact GEMM covers needs their partners contiguous — behind the ordered rest.  Diagonal blocks stay as they are:
     // every SNP has short-range partners there.
     const std::vector<int32_t> *ord_f = nullptr, *ord_t = nullptr;
-    std::vector<int32_t> ord_f_own, ord_t_own;
+    std::vector<int32_t> ord_f_own, ord_t_own, ord_f_full, ord_t_full;
     if (c->prune && !hb.generic && !hb.diag && c->engine == LDW_ENGINE_MFMA && c->apx_ok && !c->fused) {
         bool rowless = false;
         for (int64_t k = 0; k < nf && !rowless; ++k) rowless = c->h_row0[from_idx[k] + 1] == c->h_row0[from_idx[k]];
         for (int64_t k = 0; k < nt && !rowless; ++k) rowless = c->h_row0[to_idx[k] + 1] == c->h_row0[to_idx[k]];
         if (!rowless) {
-            if (c->order_cache.size() >= 256) c->order_cache.clear();   // (before the two look-ups of this block, never between them)
-            ord_f = minor_weight_order(c, from_idx, nf);
-            ord_t = minor_weight_order(c, to_idx, nt);
+            ord_f = minor_weight_order(c, from_idx, nf, ord_f_full);
+            ord_t = minor_weight_order(c, to_idx, nt, ord_t_full);
             if (hb.n_sr_blk > 0) {
                 std::vector<int32_t> df((size_t)nf + 1, 0);
                 std::vector<uint8_t> in_f((size_t)nf, 0), in_t((size_t)nt, 0);
@@ -2954,10 +2961,14 @@ int probe_kind_guess(ldw_ctx *c, const int32_t *fi, int64_t nf, const int32_t *t
     ldw_mi_params q = *p;
     q.keep_sr = 0;
     HostBlock hb;
-    if (int rc = prep_block(c, sf.data(), (int64_t)sf.size(), st.data(), (int64_t)st.size(), &q, 0, 0, hb)) return rc;
+    // (host staging of the LAST slot: the helper thread of ldw_mi_all_pairs is already building the first blocks' lists in the others)
+    constexpr int PS = LDW_NSLOT - 1;
+    if (int rc = prep_block(c, sf.data(), (int64_t)sf.size(), st.data(), (int64_t)st.size(), &q, PS, 0, hb)) return rc;
+    hb.slot = 0;      // the DEVICE side of the probe is slot 0's (its buffers are reserved below; block 0 is submitted after the probes)
+    hb.lo.slot = 0;
     if (hb.n_lr_total < 100000) return LDW_OK;   // too few long-range pairs in the sample to say anything
     if (int rc = c->dstage[0].reserve(hb.total)) return rc;
-    LDW_HIP(hipMemcpyAsync(c->dstage[0].p, c->pin[0], hb.total, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemcpyAsync(c->dstage[0].p, c->pin[PS], hb.total, hipMemcpyHostToDevice, c->stream));
     const char *d = c->dstage[0].as<char>();
     auto I = [&](size_t off) { return reinterpret_cast<const int32_t *>(d + off); };
     auto B = [&](size_t off) { return reinterpret_cast<const uint8_t *>(d + off); };
@@ -3259,23 +3270,6 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     // a millisecond of list building for a 10k x 10k block — while the GPU works, and only then waits for block b's pick.
     // (Preparing b+1 between submit_b(b) and submit_a(b+1), as the first version did, delivered the GEMM of b+1 to the GPU when
     // the chain of b was already over: the two streams never ran side by side.)
-    // cold start: a sampled guess for each block kind that has none yet (probe_kind_guess), taken from the first block of the kind
-    static const bool probe_on = getenv("LDW_NO_PROBE") == nullptr;
-    if (probe_on && !p->sr_only && c->engine != LDW_ENGINE_HIST_STATES && !c->fused && c->pos_sorted) {
-        bool done_kind[2] = {false, false};
-        for (int64_t b = 0; b < nblocks && !(done_kind[0] && done_kind[1]); ++b) {
-            const bool diag = blocks[b * 4 + 0] == blocks[b * 4 + 2] && blocks[b * 4 + 1] == blocks[b * 4 + 3];
-            const int kind = diag ? 1 : 0;
-            if (done_kind[kind]) continue;
-            done_kind[kind] = true;
-            if (c->spec_B_next[kind] >= 0) continue;
-            if (int rc = fill(b)) return rc;
-            const int64_t npairs = diag ? (int64_t)fi.size() * ((int64_t)fi.size() - 1) / 2 : (int64_t)fi.size() * (int64_t)ti.size();
-            if (npairs < PROBE_MIN_PAIRS) continue;
-            if (int rc = probe_kind_guess(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, sl, kind)) return rc;
-        }
-    }
-    // (The helper starts AFTER the cold-start probes above: they stage their sample through slot 0's buffers.)
     // r03: the lists of a block are built by a HELPER THREAD that runs ahead of the submitting thread (prep_block is pure host work into the
     // slot's pinned staging buffer: 0.45 ms per 10k x 10k block — once the GPU side of a block had come down to 0.5 ms it was the loop's
     // critical path: LDW_HOST_TIMING showed submit 0.05 + prep 0.45 + wait 0.35 ms per block = the whole 47 ms of a pass, and the kernel timeline
@@ -3292,7 +3286,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         std::condition_variable cv;
         int64_t n_prepped = 0, n_sub = 0, n_done = 0;
         int rc = LDW_OK;
-        bool stop = false;
+        bool stop = false, probing = true;   // probing: the cold-start probes (calling thread) still use the last slot's staging buffer
         std::string err;
     } sh;
     std::vector<int32_t> wfi, wti;   // the helper's own index lists
@@ -3301,7 +3295,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         for (int64_t k = 0; k < nblocks; ++k) {
             {
                 std::unique_lock<std::mutex> lk(sh.m);
-                sh.cv.wait(lk, [&] { return sh.stop || (k < sh.n_done + RING && k < sh.n_sub + LDW_NSLOT); });
+                sh.cv.wait(lk, [&] { return sh.stop || (k < sh.n_done + RING && k < sh.n_sub + LDW_NSLOT - (sh.probing ? 1 : 0)); });
                 if (sh.stop) return;
             }
             int rc = LDW_OK;
@@ -3346,6 +3340,28 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
             if (t.joinable()) t.join();
         }
     } joiner{sh, helper};
+    // (the helper is already building the first blocks' lists while the probes run; it stays out of the last slot until they are done)
+    // cold start: a sampled guess for each block kind that has none yet (probe_kind_guess), taken from the first block of the kind
+    static const bool probe_on = getenv("LDW_NO_PROBE") == nullptr;
+    if (probe_on && !p->sr_only && c->engine != LDW_ENGINE_HIST_STATES && !c->fused && c->pos_sorted) {
+        bool done_kind[2] = {false, false};
+        for (int64_t b = 0; b < nblocks && !(done_kind[0] && done_kind[1]); ++b) {
+            const bool diag = blocks[b * 4 + 0] == blocks[b * 4 + 2] && blocks[b * 4 + 1] == blocks[b * 4 + 3];
+            const int kind = diag ? 1 : 0;
+            if (done_kind[kind]) continue;
+            done_kind[kind] = true;
+            if (c->spec_B_next[kind] >= 0) continue;
+            if (int rc = fill(b)) return rc;
+            const int64_t npairs = diag ? (int64_t)fi.size() * ((int64_t)fi.size() - 1) / 2 : (int64_t)fi.size() * (int64_t)ti.size();
+            if (npairs < PROBE_MIN_PAIRS) continue;
+            if (int rc = probe_kind_guess(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, sl, kind)) return rc;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(sh.m);
+        sh.probing = false;
+    }
+    sh.cv.notify_all();
     // blocks until block k is prepared (true) — or, with wait = false, says whether it is
     auto prepped = [&](int64_t k, bool wait, int &rc) -> bool {
         std::unique_lock<std::mutex> lk(sh.m);

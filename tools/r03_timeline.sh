@@ -33,6 +33,14 @@ for q, iv in busy.items():
         cur_e = e_ if cur_e is None else max(cur_e, e_)
     big = sorted(gaps, reverse=True)[:12]
     print(f"# queue {q}: pass span {(span1 - span0) / 1e6:.2f} ms, busy {tot / 1e6:.2f} ms, idle gaps > 30 us: {sum(1 for x in gaps if x > 30)} totalling {sum(x for x in gaps if x > 30) / 1e3:.2f} ms; largest {[round(x) for x in big]}")
+agg = {}
+for r in rows[lo_i:hi_i]:
+    k = (r.get("Queue_Id", "?"), short(r["Kernel_Name"]))
+    a = agg.setdefault(k, [0, 0.0])
+    a[0] += 1
+    a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+for (q, k), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+    print(f"# queue {q} {k:28s} calls {n:4d} total {us / 1e3:7.2f} ms  avg {us / n:7.1f} us")
 qs = {}
 for r in rows[i0 - 8:i1]:
     q = r.get("Queue_Id", r.get("Stream_Id", "?"))
