@@ -348,6 +348,7 @@ int ldw_reset_speculation(ldw_ctx *c) {
     LDW_REQUIRE(c, LDW_ERR_ARG, "null context");
     c->spec_B_next[0] = c->spec_B_next[1] = -1;
     c->spec_seen[0] = c->spec_seen[1] = false;
+    c->spec_probed[0] = c->spec_probed[1] = false;
     c->spec_hist_n[0] = c->spec_hist_n[1] = 0;
     c->tab11_lo[0] = c->tab11_lo[1] = 0;
     return LDW_OK;
@@ -925,6 +926,7 @@ int ensure_rows(ldw_ctx *c) {
     c->rows_ready = true;
     c->spec_B_next[0] = c->spec_B_next[1] = -1;   // bucket guesses of an earlier alignment / weighting say nothing about this one
     c->spec_seen[0] = c->spec_seen[1] = false;
+    c->spec_probed[0] = c->spec_probed[1] = false;
     c->spec_hist_n[0] = c->spec_hist_n[1] = 0;
     return LDW_OK;
 }

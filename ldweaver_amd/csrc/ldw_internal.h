@@ -208,6 +208,7 @@ struct ldw_ctx {
     bool fused = false;                  // GEMM + epilogue in one kernel whenever a bucket guess exists (ldw_fused.hip); off:
                                          // GEMM -> k_mi_screen -> k_mi_units, which measures 7 % faster on C4
     bool spec_seen[2] = {false, false};  // a block of this kind (off-diagonal, diagonal) has set its own guess
+    bool spec_probed[2] = {false, false};   // the kind's current guess came from a cold-start probe of the kind itself
     std::vector<hipEvent_t> ev_pool;     // 4 timing events per block
     int spec_hist[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};   // the last true buckets per kind (adaptive margin of the guess)
     int spec_hist_n[2] = {0, 0};

@@ -2851,7 +2851,7 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
         }
         c->spec_B_next[kind] = hp->B_true - margin > 0 ? hp->B_true - margin : 0;
         c->spec_seen[kind] = true;
-        if (!c->spec_seen[other]) {
+        if (!c->spec_seen[other] && !c->spec_probed[other]) {   // (a probed guess of the other kind is better than one derived from this kind)
             const int g = hb.diag ? hp->B_true - 10 : hp->B_true - 16 - 2 * 10;
             c->spec_B_next[other] = g > 0 ? g : 0;
         }
@@ -2980,7 +2980,9 @@ int probe_kind_guess(ldw_ctx *c, const int32_t *fi, int64_t nf, const int32_t *t
     hb.E.write_dense = 0;   // nothing reads the sample's MI values: only the histogram of the long-range ones
     LDW_HIP(hipMemsetAsync(c->hist[0].p, 0, (size_t)NBINS * 8, c->stream));
     LDW_HIP(hipMemsetAsync(sl.pick[0], 0, sizeof(ldw::PickOut), c->stream));
-    if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, LDW_QUIRK_INTENDED, hb.E, c->ev, 3, &c->G, nullptr, c->hist[0].as<unsigned long long>()))
+    // (in the CALLER's reading of RXY: under quirk Q1 the scrambled RXY — r of two other SNPs — lifts 3-state x 3-state pairs into the tail of an
+    // off-diagonal block; a sample evaluated with the intended RXY sat 15 buckets = 7.5 % below the block's own threshold)
+    if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, c->ev, 3, &c->G, nullptr, c->hist[0].as<unsigned long long>()))
         return rc;
     hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, c->stream, c->hist[0].as<unsigned long long>(), p->lr_retain_links, p->lr_links_approx, -1,
                        (long long)hb.n_lr_total, sl.pick[0], (const unsigned int *)nullptr, 0u);
@@ -2992,7 +2994,11 @@ int probe_kind_guess(ldw_ctx *c, const int32_t *fi, int64_t nf, const int32_t *t
         const int g = hp->B_true - PROBE_MARGIN;
         c->spec_B_next[kind] = g > 0 ? g : 0;
         c->spec_hist_n[kind] = 0;
+        c->spec_probed[kind] = true;
         ++c->probe_blocks;
+        static const bool trace_on = getenv("LDW_BLOCK_TRACE") != nullptr;
+        if (trace_on) fprintf(stderr, "[ldw probe] kind %d: sample %lld x %lld, %lld long-range pairs, bucket %d -> guess %d\n", kind, (long long)hb.nf, (long long)hb.nt,
+                              (long long)hb.n_lr_total, hp->B_true, c->spec_B_next[kind]);
     }
     LDW_HIP(hipMemsetAsync(sl.pick[0], 0, sizeof(ldw::PickOut), c->stream));
     return LDW_OK;
