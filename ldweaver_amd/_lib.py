@@ -94,6 +94,7 @@ _SIGS = {
     "ldw_prune_report": (C.c_int, [_p, _p]),
     "ldw_snp_bounds": (C.c_int, [_p, _p, C.c_int64]),
     "ldw_format_number": (C.c_int, [C.c_double, C.c_char_p, C.c_int]),
+    "ldw_r_sample": (C.c_int, [C.c_uint32, C.c_int64, C.c_int64, _p]),
     "ldw_write_table_tsv": (C.c_int, [C.c_char_p, C.c_int, _i64, C.c_int, _p, _p, C.c_int, C.POINTER(_i64)]),
     "ldw_write_links_tsv": (C.c_int, [_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "ldw_compare_to_row": (C.c_int, [_p, _i64, _i64, _p, _i64, _p]),

@@ -40,7 +40,7 @@ def lr_links_approx(POS, g, sr_dist, seed: int = 1988) -> float:
     POS = np.asarray(POS, dtype=np.float64)
     nsnp = len(POS)
     snp_subset = min(nsnp, int(round(nsnp * 0.1)))
-    idx = rcompat.RRandom(seed).sample(nsnp, snp_subset) - 1
+    idx = rcompat.r_sample(seed, nsnp, snp_subset) - 1
     total = 0
     gi, si = float(g), float(sr_dist)
     if (nsnp > 2000 and np.all(np.diff(POS) >= 0) and gi == int(gi) and np.all(POS == np.rint(POS)) and 2 * si < gi

@@ -16,6 +16,15 @@ import math
 import numpy as np
 
 
+def r_sample(seed: int, n: int, size: int) -> np.ndarray:
+    """``set.seed(seed); sample(n, size)`` through the library's native statement of the stream (``ldw_r_sample``); ``RRandom`` below is
+    the Python statement the tests hold it against."""
+    from . import _lib as L
+    out = np.empty(int(size), dtype=np.int64)
+    L.check(L.lib().ldw_r_sample(int(seed) & 0xFFFFFFFF, int(n), int(size), L.ptr(out)))
+    return out
+
+
 class RRandom:
     """R's default RNG stream (Mersenne-Twister, inversion, sample.kind = "Rejection", R >= 3.6)."""
 

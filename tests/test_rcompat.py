@@ -24,6 +24,18 @@ def test_rng_product_equals_oracle_restatement():
     assert [r1.unif_rand() for _ in range(2000)] == [r2.unif_rand() for _ in range(2000)]
 
 
+def test_native_r_sample_is_r_s_stream():
+    """ldw_r_sample (what lr_links_approx draws its 10 % SNP subset with) against R's own known answers and the Python and oracle
+    statements of the stream, across refills of the 624-word state, bit widths 1..17 and the degenerate sizes."""
+    assert list(rcompat.r_sample(123, 10, 10)) == [3, 10, 2, 8, 6, 9, 1, 7, 5, 4]
+    assert list(rcompat.r_sample(42, 10, 10)) == [1, 5, 10, 8, 2, 4, 6, 9, 7, 3]
+    for seed, n, size in ((1988, 12680, 1268), (1988, 100000, 10000), (7, 1, 1), (5, 1000, 0), (99, 65536, 65536), (3, 65537, 4000), (2**32 - 1, 777, 777)):
+        a = rcompat.r_sample(seed, n, size)
+        assert np.array_equal(a, rcompat.RRandom(seed).sample(n, size)), (seed, n, size)
+        assert len(set(a.tolist())) == size and (size == 0 or (a.min() >= 1 and a.max() <= n))
+    assert np.array_equal(rcompat.r_sample(1988, 12680, 1268), orc.RMersenneTwister(1988).sample(12680, 1268))
+
+
 def test_quantile_type7():
     rng = np.random.default_rng(3)
     x = rng.gamma(0.3, size=1001)
