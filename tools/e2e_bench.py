@@ -87,11 +87,10 @@ def main():
         st.lap("host_decay_fit_ms")
         stats = eng.sr_excess_stats(md)
         st.lap("sr_excess_stats_ms")
-        from scipy import special
         shape = np.empty((3, 3))
         for ci in range(3):
             sa, sb = srp.beta_mle_stats(*stats[ci])
-            shape[ci] = sa, sb, special.betaln(sa, sb)
+            shape[ci] = sa, sb, srp._betaln(sa, sb)
         st.lap("host_beta_mle_ms")
         n_red, n_pool, min_mi = eng.sr_pvalues(md, shape, a.srp_cutoff)
         st.lap("sr_pvalues_ms")
