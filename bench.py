@@ -334,7 +334,7 @@ def main():
     # beside the epilogue / selection of block b, so HIP-event brackets of one kernel also contain its neighbours.  Replay
     # the same step with the overlap off (same kernels, same inputs, back to back on one stream) and bracket there. ----
     tim_overlapped = dict(tim)
-    n_replay, gst, serial_ms_per_step, cnt_replay = 0, None, None, None
+    n_replay, gst, serial_ms_per_step, cnt_replay, unpruned = 0, None, None, None, None
     if rank == 0 and len(my_blocks):
         eng.set_overlap(False)
         for k in tim:
@@ -352,6 +352,22 @@ def main():
         gst = eng.gemm_stats(reset=True)
         c1 = eng.counters()
         cnt_replay = {k: c1[k] - c0[k] for k in c1}
+        # the same kernel on FULL launches (tile pruning off): what its K loop delivers when every wave tile is computed
+        unpruned = None
+        if not args.no_prune and args.engine == "mfma":
+            eng.set_prune(False)
+            eng.mi_all_pairs(my_blocks, sr_dist, lr_retain, approx)
+            eng.gemm_stats(reset=True)
+            g_ms = 0.0
+            for _ in range(n_replay):
+                eng.mi_all_pairs(my_blocks, sr_dist, lr_retain, approx)
+                g_ms += eng.last_timing()["gemm_ms"]
+            torch.cuda.synchronize()
+            g2 = eng.gemm_stats(reset=True)
+            if g2["apx_launches"] > 0 and g_ms > 0:
+                unpruned = dict(avg_launch_ms=g_ms / g2["apx_launches"], achieved=g2["apx_ops"] / (g_ms * 1e-3) / 1e12)
+                unpruned["frac"] = unpruned["achieved"] / 5000.0
+            eng.set_prune(True)
         eng.set_overlap(not args.no_overlap)
 
     # ---- mi_values_produced: no screen, no mixed precision, no approximate GEMM: 5-limb GEMM + fp64 MI of every pair ----
@@ -406,6 +422,7 @@ def main():
                         alg_work_reduction=alg_per_launch / exec_per_launch,
                         alg_TFLOPs=alg_per_launch / (avg_ms * 1e-3) / 1e12,
                         launch_mix=dict(gemm_apx=gst["apx_launches"], gemm_bits_full=gst["bits_launches"], gemm_bits_band=gst["band_launches"]),
+                        full_launches_without_pruning=unpruned,
                         overlapped_avg_launch_ms=tim_overlapped["gemm_ms"] / max(1, len(my_blocks) * K),
                         measured_in=f"{n_replay} serialized replay step(s) after the timed region (overlap off; the replay inherits the bucket guesses of the "
                                     f"pass before it, so that every block launches this kernel), {serial_ms_per_step:.2f} ms/step",
@@ -420,7 +437,7 @@ def main():
                              "of the 55 block pairs the kernel runs over the list of the wave tiles whose pairs are NOT all dismissed by their "
                              "marginals alone (k_apx_live_tiles; 40 % of the tiles on this data) — pruned tiles are not in `achieved`, and the "
                              "shorter launches (3.2 rounds of wave tiles instead of 8.1) pay a larger share of ramp and tail: the same K loop on "
-                             "a full launch (diagonal blocks, --no-prune) runs at 0.49 of the peak (DESIGN.md 5.1c/d).  `overlapped_avg_launch_ms` "
+                             "full launches (`full_launches_without_pruning`: the same replay with ldw_set_prune(0), measured live) runs at 0.48 of the peak (DESIGN.md 5.1c/d).  `overlapped_avg_launch_ms` "
                              "is the bracket inside the timed region, where the GEMM shares the GPU with the previous block's screens and selection")
             tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
             if os.path.exists(tpath) and (L, N, world) == (100_000, 5_000, 1):   # the configuration the PMC passes were collected on
