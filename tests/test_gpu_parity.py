@@ -1652,3 +1652,54 @@ def test_bad_block_in_the_middle_of_a_pass_is_reported_and_the_engine_survives(e
         for which in (0, 1):
             for x, y in zip(ref[which], engine.links(which)):
                 assert np.array_equal(x, y)
+
+
+def test_pruning_under_the_reference_rxy_with_monomorphic_snps(engine):
+    """Quirk Q1 reads RXY from two OTHER SNPs of the block; with monomorphic SNPs in it (r = 1) the scrambled RXY can fall to 1/4, below
+    the RXY = 1 the biallelic threshold table is built for and below the proper RXY of the per-SNP bounds.  The table must then stay
+    off and the bounds must use the floor r_min^2 / 4: default path (pruning on) == plain path, verify mode finds nothing lost, on an
+    alignment with rare states, gaps and monomorphic sites, ragged last block column."""
+    rng = np.random.default_rng(91)
+    Ls, N = 2400, 512
+    st = np.zeros((Ls, N), dtype=np.uint8)
+    for a in range(Ls):
+        maj, mnr = rng.choice(4, size=2, replace=False)
+        st[a] = maj
+        if a % 9 != 4:                                                   # (a % 9 == 4: monomorphic, r = 1)
+            st[a, rng.choice(N, int(rng.choice([1, 1, 2, 3, 8, 40, 150])), replace=False)] = mnr
+        if a % 5 == 0:
+            st[a, rng.choice(N, int(rng.choice([1, 3, 20])), replace=False)] = 4
+        if a % 11 == 7 and a > 0:
+            st[a] = np.where(st[a - 1] == st[a - 1][0], maj, mnr)
+    uqe, r = orc.uqe_r(st)
+    assert r.min() == 1
+    POS = np.sort(rng.choice(np.arange(1, 400000), size=Ls, replace=False)).astype(np.int32)
+    hdw = 1.0 / rng.integers(1, 5, size=N).astype(np.float64)
+    d = dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=POS, paint=rng.integers(1, 4, Ls).astype(np.int32), g=400000.0)
+    _setup(engine, d)
+    assert engine.apx_info()["usable"]
+    approx = orc.lr_links_approx(POS, d["g"], 20000.0)
+    blocks = np.array(orc.make_blocks(Ls, 1000), dtype=np.int32)       # 1000, 1000, 400
+    out = {}
+    for key, (mixed, scr, path) in dict(plain=(False, 0, 1), apx=(True, 1, 2), verify=(True, 2, 2)).items():
+        engine.set_mixed(mixed)
+        engine.set_screen(scr)
+        engine.set_path(path)
+        c0, p0 = engine.counters(), engine.prune_report()
+        for _ in range(2):
+            engine.mi_all_pairs(blocks, 20000.0, 20000.0, approx, quirk=L.QUIRK_REFERENCE)
+        c1, p1 = engine.counters(), engine.prune_report()
+        out[key] = (engine.links(0), engine.links(1), {k: c1[k] - c0[k] for k in c1}, p1["tiles_pruned"] - p0["tiles_pruned"])
+    engine.set_mixed(True)
+    engine.set_screen(1)
+    engine.set_path(0)
+    assert out["verify"][2]["screen_violations"] == 0 and out["apx"][2]["apx_blocks"] >= len(blocks)
+    for which in (0, 1):
+        for key in ("apx", "verify"):
+            for x, y in zip(out["plain"][which], out[key][which]):
+                assert np.array_equal(x, y), (which, key)
+    assert len(out["plain"][1][2]) > 5000
+    # the bounds carry the floor: with r_min = 1 the reference-mode values sit above the intended-mode ones
+    sup = engine.snp_bounds()
+    fin = sup[:, 0, 0] < 1e299
+    assert fin.sum() > 500 and np.all(sup[fin, 1, :] >= sup[fin, 0, :] - 1e-15) and np.any(sup[fin, 1, 0] > sup[fin, 0, 0] + 1e-6)
