@@ -354,7 +354,7 @@ def main():
         cnt_replay = {k: c1[k] - c0[k] for k in c1}
         # the same kernel on FULL launches (tile pruning off): what its K loop delivers when every wave tile is computed
         unpruned = None
-        if not args.no_prune and args.engine == "mfma":
+        if not args.no_prune and args.engine == "mfma" and extra:   # (not under --no-extra-legs: the profiled commands, whose per-kernel averages must be those of `roofline`)
             eng.set_prune(False)
             eng.mi_all_pairs(my_blocks, sr_dist, lr_retain, approx)
             eng.gemm_stats(reset=True)

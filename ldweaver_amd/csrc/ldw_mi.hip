@@ -51,7 +51,8 @@ namespace ldw {
 static inline ldw::DevBuf &gx(ldw_ctx *c, int s) { return s == 0 ? c->G : (s == 1 ? c->G2 : c->G3); }
 
 // Per-block SNP constants in epilogue order, once per block instead of once per workgroup (k_mi_screen) or per unit
-// (k_mi_units): thread i builds column slot i (i < nt) and from-side slot i (i < 64 * tiles); A.colpack / A.rowpack are null here.
+// (k_mi_units): blockIdx.y = 0: thread i builds column slot i (i < nt); blockIdx.y = 1: from-side slot i (i < 64 * tiles) — two independent chains
+// of dependent loads, side by side instead of one after the other in the same thread (24 -> 13 us per C4 block); A.colpack / A.rowpack are null here.
 __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
                                                      int nf_slots, int with_hi, ColMeta *__restrict__ cp, ColMeta *__restrict__ cp_hi,
                                                      RowPack *__restrict__ rp, RowPack *__restrict__ rp_hi, float *__restrict__ rloc_f,
@@ -74,9 +75,10 @@ __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *_
     // bins of the threshold table by ROW of the two row lists for the GEMM's epilogue test (only used when the host has checked
     // that a one-row SNP's position in its row list equals its slot here: no SNP without a row in the block)
     int my_bt = 255, my_bf = 255;
-    if (i < A.nf) rloc_f[i] = (float)A.r[A.idx_f[i]];
-    if (i < A.nt) rloc_t[i] = (float)A.r[A.idx_t[i]];
-    if (i < A.nt) {
+    const bool to_side = blockIdx.y == 0;
+    if (!to_side && i < A.nf) rloc_f[i] = (float)A.r[A.idx_f[i]];
+    if (to_side && i < A.nt) rloc_t[i] = (float)A.r[A.idx_t[i]];
+    if (to_side && i < A.nt) {
         ColMeta m;
         load_col(A, perm_t, square, i, m, false);
         cp[i] = m;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *_
             cp_hi[i] = m;
         }
     }
-    if (i < nf_slots) {
+    if (!to_side && i < nf_slots) {
         RowPack P;
         int a_loc;
         const bool ok = load_row_side_at(A, perm_f, square, i, P.R, a_loc, false);
@@ -112,8 +114,8 @@ __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *_
             rp_hi[i] = P;
         }
     }
-    if (bin_t && i < RTpad) bin_t[i] = (uint8_t)my_bt;
-    if (bin_f && i < RFpad) bin_f[i] = (uint8_t)my_bf;
+    if (to_side && bin_t && i < RTpad) bin_t[i] = (uint8_t)my_bt;
+    if (!to_side && bin_f && i < RFpad) bin_f[i] = (uint8_t)my_bf;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1730,7 +1732,7 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
             RowPack *rp = reinterpret_cast<RowPack *>(pb + o_rp), *rph = reinterpret_cast<RowPack *>(pb + o_rph);
             float *rlf = reinterpret_cast<float *>(pb + o_rf), *rlt = reinterpret_cast<float *>(pb + o_rt);
             const int nthr = std::max<int>((int)nt, nf_slots);
-            hipLaunchKernelGGL(k_build_packs, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, A, D.perm, D.perm_t, nf_slots,
+            hipLaunchKernelGGL(k_build_packs, dim3((unsigned)((nthr + 255) / 256), 2), dim3(256), 0, c->stream, A, D.perm, D.perm_t, nf_slots,
                                mixed ? 1 : 0, cp, cph, rp, rph, rlf, rlt);
             A.rloc_f = rlf;
             A.rloc_t = rlt;
@@ -1952,7 +1954,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         }
         // the per-SNP constants in epilogue order — before the GEMM: its epilogue reads the table bins by row
         const int nthr = std::max<int>(std::max<int>((int)nt, nf_slots), std::max<int>(RTpad, RFpad));
-        hipLaunchKernelGGL(k_build_packs, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, gs, A, D.perm, D.perm_t, nf_slots, 1, cp, cph, rp, rph,
+        hipLaunchKernelGGL(k_build_packs, dim3((unsigned)((nthr + 255) / 256), 2), dim3(256), 0, gs, A, D.perm, D.perm_t, nf_slots, 1, cp, cph, rp, rph,
                            rlf, rlt, bin_t, bin_f, RTpad, RFpad, wide_prune ? sflag_f : nullptr, wide_prune ? sflag_t : nullptr, wide_prune ? rflag_f : nullptr,
                            wide_prune ? rflag_t : nullptr);
         LDW_HIP(hipGetLastError());
