@@ -57,7 +57,9 @@ struct ApxGemmArgs {
     const uint8_t *rflag_t, *rflag_f;
 };
 
-int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st);
+// (rowlist2 / Rpad2 / panel2: a second panel in the same launch)
+int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st, const int32_t *rowlist2 = nullptr, int Rpad2 = 0,
+                      uint64_t *panel2 = nullptr);
 int launch_apx_live_tiles(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st);   // P.skip_ctr set: before launch_gemm_apx, same stream
 int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st);
 // the pair lists of A (filled by the approximate screen): exact sums, fp64 MI, emission

@@ -173,9 +173,16 @@ int prepare_apx_weights(ldw_ctx *c) {
 // k-step kk finds ITS sixteen positions 32 kk + 16 fh .. + 15 — a k-step covers 32 CONSECUTIVE positions, one block exponent —
 // at bits 16 kk of word fh.  interleave == 0 (gemm_apx_lds_kernel): the words as they are.
 // ------------------------------------------------------------------------------------------------
+// blockIdx.y = 1: the second row list of the launch (rowlist2 / Rpad2 / panel2: the to side of an off-diagonal block — both panels in ONE launch).
 __global__ __launch_bounds__(256) void k_pack_panel(const uint64_t *__restrict__ Mbits, int64_t KW, const int32_t *__restrict__ rowlist,
-                                                    int Rpad, int M2, uint64_t *__restrict__ panel, int interleave) {
+                                                    int Rpad, int M2, uint64_t *__restrict__ panel, int interleave,
+                                                    const int32_t *__restrict__ rowlist2 = nullptr, int Rpad2 = 0, uint64_t *__restrict__ panel2 = nullptr) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    if (blockIdx.y == 1) {
+        rowlist = rowlist2;
+        Rpad = Rpad2;
+        panel = panel2;
+    }
     const int r = blockIdx.x * 64 + (threadIdx.x & 63);
     if (r >= Rpad) return;
     const u64x2 *src = reinterpret_cast<const u64x2 *>(Mbits + (int64_t)rowlist[r] * KW);
@@ -204,9 +211,10 @@ static bool apx_kernel_is_lds() {
     return lds;
 }
 
-int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st) {
-    hipLaunchKernelGGL(k_pack_panel, dim3((unsigned)((Rpad + 63) / 64)), dim3(256), 0, st, c->Mbits.as<uint64_t>(), c->KW, rowlist, Rpad,
-                       (int)(c->KW / 2), panel, (c->apx_fine && !apx_kernel_is_lds()) ? 1 : 0);
+int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st, const int32_t *rowlist2, int Rpad2, uint64_t *panel2) {
+    const int rmax = (rowlist2 && Rpad2 > Rpad) ? Rpad2 : Rpad;
+    hipLaunchKernelGGL(k_pack_panel, dim3((unsigned)((rmax + 63) / 64), rowlist2 ? 2u : 1u), dim3(256), 0, st, c->Mbits.as<uint64_t>(), c->KW, rowlist, Rpad,
+                       (int)(c->KW / 2), panel, (c->apx_fine && !apx_kernel_is_lds()) ? 1 : 0, rowlist2, Rpad2, panel2);
     LDW_HIP(hipGetLastError());
     return LDW_OK;
 }

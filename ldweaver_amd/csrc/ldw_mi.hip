@@ -1925,9 +1925,9 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     }
     if (phase == 1) {
         if (E.do_lr) {
-            if (int rc = launch_pack_panel(c, D.rl_f, RFpad, c->panel[s][0].as<uint64_t>(), gs)) return rc;
-            if (!lo_h->diag)
-                if (int rc = launch_pack_panel(c, D.rl_t, RTpad, c->panel[s][1].as<uint64_t>(), gs)) return rc;
+            if (int rc = launch_pack_panel(c, D.rl_f, RFpad, c->panel[s][0].as<uint64_t>(), gs, lo_h->diag ? nullptr : D.rl_t, RTpad,
+                                           lo_h->diag ? nullptr : c->panel[s][1].as<uint64_t>()))
+                return rc;
         }
         {   // the unit counters, the pair-list counters, this slot's histogram and pick record (submit_b skips its own memsets)
             ZeroArgs Z;
