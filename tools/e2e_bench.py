@@ -88,9 +88,13 @@ def main():
         stats = eng.sr_excess_stats(md)
         st.lap("sr_excess_stats_ms")
         shape = np.empty((3, 3))
+        import sys as _sys
         for ci in range(3):
+            _t = time.perf_counter()
             sa, sb = srp.beta_mle_stats(*stats[ci])
             shape[ci] = sa, sb, srp._betaln(sa, sb)
+            print(f"[e2e] beta MLE cluster {ci}: stats {[repr(float(x)) for x in stats[ci]]} -> ({sa!r}, {sb!r}) in {(time.perf_counter() - _t) * 1e3:.2f} ms, "
+                  f"simplex fallback loaded: {'scipy.optimize' in _sys.modules}", file=_sys.stderr)
         st.lap("host_beta_mle_ms")
         n_red, n_pool, min_mi = eng.sr_pvalues(md, shape, a.srp_cutoff)
         st.lap("sr_pvalues_ms")
