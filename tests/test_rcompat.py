@@ -103,3 +103,35 @@ def test_native_tsv_writer_equals_python_writer(tmp_path):
     assert (tmp_path / "one.tsv").read_bytes() == (tmp_path / "many.tsv").read_bytes() == path.read_bytes()[len("head\tline\n"):]
     write_table_tsv(str(tmp_path / "empty.tsv"), [np.zeros(0), np.zeros(0, dtype=np.int64)], append=False)
     assert (tmp_path / "empty.tsv").read_bytes() == b""
+
+
+def test_beta_mle_special_functions_and_noise_floor():
+    """The short-range model's scalar special functions (psi, psi', log B in plain Python: no scipy import on the product path) against
+    scipy / mpmath, and the beta MLE's Newton iteration on sufficient statistics with n ~ 1e8 (the C5 clusters: the score's rounding
+    noise keeps the step at ~1e-13 of the parameter; the iteration must stop there instead of falling through to the simplex)."""
+    import sys
+
+    from scipy import special
+
+    from ldweaver_amd import srp
+    rng = np.random.default_rng(0)
+    xs = list(rng.uniform(0.01, 300, 500)) + [1e-3, 0.5, 1.0, 2.0, 9.99, 10.0, 1e4]
+    for x in xs:
+        assert abs(srp._digamma(x) - special.digamma(x)) <= 2e-15 * max(1.0, abs(special.digamma(x)))
+        assert abs(srp._trigamma(x) - special.polygamma(1, x)) <= 2e-15 * special.polygamma(1, x)
+    try:
+        import mpmath
+        mpmath.mp.dps = 40
+        for a, b in [(0.359274, 97.758595), (0.396209, 132.942389), (1.7, 4000.0), (3.3, 10.0), (50.0, 60.0), (0.01, 1e5), (2.0, 3.0)]:
+            exact = float(mpmath.log(mpmath.beta(a, b)))
+            assert abs(srp._betaln(a, b) - exact) <= 2e-15 * max(1.0, abs(exact)), (a, b)
+            assert srp._betaln(a, b) == srp._betaln(b, a)
+    except ImportError:
+        for a, b in [(0.359274, 97.758595), (2.0, 3.0), (50.0, 60.0)]:
+            assert abs(srp._betaln(a, b) - special.betaln(a, b)) <= 1e-12
+    had = "scipy.optimize" in sys.modules
+    for st, want in (([28498592.0, 70777.64524797378, 17752.603752309653, -213122118.91724914, -85127.43904636076], (0.39620871781, 132.942388955)),
+                     ([128397431.0, 385079.5887454161, 109246.20739219322, -958929052.2912737, -473422.4968240424], (0.35927357102, 97.758594891))):
+        a, b = srp.beta_mle_stats(*st)
+        assert abs(a - want[0]) < 1e-10 and abs(b - want[1]) < 1e-8
+    assert ("scipy.optimize" in sys.modules) == had          # Newton converged: the simplex fallback was not needed
