@@ -2215,6 +2215,17 @@ struct HostBlock {
     int spec_B = -1;
 };
 
+// The speculative selection (bucket guess -> approximate GEMM / screen -> lists of the pairs that may pass) pays when the long-range filter
+// keeps a small fraction of the pairs.  When lr_retain_links is a sizeable part of lr_links_approx — a small alignment with the default
+// 1e6: 5000 SNPs keep 8 % — nearly every unit has to be listed and the lists cost more than evaluating everything: measured on 30k x 2k
+// (tools/keep_frac_probe.py, warm passes, default against plain): 6.5 / 11.2 ms at 0.02 %, 21.2 / 21.6 at 0.5 %, 24.1 / 22.8 at 1 %, 84.7 / 24.9 at
+// 5 %.  Above 0.7 % every block takes the plain path (5-limb GEMM, fp64 MI of every pair, full histogram), cold start included.
+// Only the automatic choice is gated: ldw_set_fused(1) and ldw_set_path(1 | 2) are honoured as given.
+static inline bool speculation_pays(const ldw_ctx *c, const ldw_mi_params *p) {
+    if (c->fused || c->path_mode != 0) return true;
+    return !(p->lr_links_approx > 0.0) || p->lr_retain_links < 0.007 * p->lr_links_approx;
+}
+
 int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt, const ldw_mi_params *p,
                int slot, int64_t blk_no, HostBlock &hb) {
     LDW_REQUIRE(nf > 0 && nt > 0, LDW_ERR_ARG, "empty block (nf=%lld nt=%lld)", (long long)nf, (long long)nt);
@@ -2539,7 +2550,7 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
     E.ckey = c->cand_key[s].as<uint64_t>();
     E.cval = c->cand_val[s].as<uint64_t>();
     // fp32 screen: only where a pair can be dismissed at all (speculative mode with a positive lower edge)
-    E.scr_mode = (hb.spec_B > 0 || !do_lr) && !E.write_dense ? c->screen : 0;
+    E.scr_mode = (hb.spec_B > 0 || !do_lr) && !E.write_dense && (!do_lr || speculation_pays(c, p)) ? c->screen : 0;   // (no screen where nearly every unit would be listed)
     // the screen reads the top 31 bits of a joint sum; in the mixed-precision path the sums are those of the high-limb
     // weights (units of 2^(16 - F)) and the margin also covers what the low limbs can add (lo_bound)
     const int64_t tot = hb.mixed ? c->total_fixed_hi : c->total_fixed;
@@ -2609,7 +2620,7 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(gs, c->ev_done[s], 0));
     hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
     const bool do_lr = !p->sr_only;
-    const int guess = do_lr ? c->spec_B_next[hb.diag ? 1 : 0] : 0;
+    const int guess = do_lr ? (speculation_pays(c, p) ? c->spec_B_next[hb.diag ? 1 : 0] : -1) : 0;
     hb.fused = c->fused && c->nlimbs <= 5 && (!do_lr || guess >= 0);
     ++(hb.fused ? c->fused_blocks : c->unfused_blocks);
     hb.guess = guess;
@@ -3009,6 +3020,7 @@ int probe_kind_guess(ldw_ctx *c, const int32_t *fi, int64_t nf, const int32_t *t
 // whether the next block can be submitted before the current one is finished: the fused path needs a bucket guess
 bool can_submit_early(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p) {
     if (!c->overlap) return false;
+    if (!p->sr_only && !speculation_pays(c, p)) return true;   // (plain blocks need no guess)
     // no bucket guess for this kind of block yet (the first blocks of a cold pass): the block in flight is about to provide one —
     // submitted now, this block would take the non-speculative path (full 5-limb GEMM, fp64 for every pair: ~4 ms more)
     if (c->engine == LDW_ENGINE_MFMA && !p->sr_only && c->screen && c->spec_B_next[hb.diag ? 1 : 0] < 0) return false;
@@ -3351,7 +3363,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     // (the helper is already building the first blocks' lists while the probes run; it stays out of the last slot until they are done)
     // cold start: a sampled guess for each block kind that has none yet (probe_kind_guess), taken from the first block of the kind
     static const bool probe_on = getenv("LDW_NO_PROBE") == nullptr;
-    if (probe_on && !p->sr_only && c->engine != LDW_ENGINE_HIST_STATES && !c->fused && c->pos_sorted) {
+    if (probe_on && !p->sr_only && c->engine != LDW_ENGINE_HIST_STATES && !c->fused && c->pos_sorted && speculation_pays(c, p)) {
         bool done_kind[2] = {false, false};
         for (int64_t b = 0; b < nblocks && !(done_kind[0] && done_kind[1]); ++b) {
             const bool diag = blocks[b * 4 + 0] == blocks[b * 4 + 2] && blocks[b * 4 + 1] == blocks[b * 4 + 3];
