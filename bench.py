@@ -139,8 +139,40 @@ def job_leg(states, POS, paint, g, L, N, device, args):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD process
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), relay rank 0's JSON line and the
+    child's exit code.  Runs before anything has touched torch or the GPU in this process (never re-exec a process that has: the
+    child is a plain subprocess, this process only waits for it)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), LDW_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"# bench.py --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    line = None
+    for l in p.stdout:
+        if l.startswith("{") and '"metric"' in l:
+            line = l.rstrip("\n")
+        else:
+            sys.stderr.write(l)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("# bench.py: the ranks exited 0 but rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
     from ldweaver_amd import _lib as LL
@@ -166,6 +198,8 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = dist.get_world_size() if world > 1 else 1          # the world as the communicator (RCCL for backend nccl) reports it
+    backend_seen = dist.get_backend() if world > 1 else None
 
     # ---- synthetic workload (same seed on every rank -> identical replicated alignment) ----
     L, N = args.L, args.N
@@ -417,6 +451,15 @@ def main():
             exec_per_launch = (gst["apx_ops"] + gst["bits_ops"]) / n_launch
             alg_per_launch = 50.0 * N * my_pairs * n_replay / n_launch      # 50 * N MAC-flops per pair
             achieved = exec_per_launch / (avg_ms * 1e-3) / 1e12
+            pr = eng.prune_report()
+            prune_note = ""
+            if pr.get("on") and pr.get("tiles_total", 0) > 0:   # every figure of the note is this run's own (no numbers of another shape)
+                prune_note = (f"Tile pruning (`prune`): since this engine was created the kernel ran on {pr['ordered_blocks']} weight-ordered launches over the "
+                              f"list of the wave tiles whose pairs are NOT all dismissed by their marginals alone (k_apx_live_tiles): "
+                              f"{pr['tiles_pruned']} of {pr['tiles_total']} wave tiles = {100.0 * pr['tiles_pruned'] / pr['tiles_total']:.1f} % pruned; pruned tiles are "
+                              f"not in `achieved`, and the shorter launches pay a larger share of ramp and tail" +
+                              (f": the same K loop on full launches (`full_launches_without_pruning`: the same replay with ldw_set_prune(0), measured "
+                               f"live) runs at {unpruned['frac']:.2f} of the peak (DESIGN.md 5.1c/d).  " if unpruned else ".  "))
             roof.update(kernel=kname, achieved=achieved, frac=achieved / i8_peak, avg_launch_ms=avg_ms, launches=n_launch,
                         executed_ops_per_launch=exec_per_launch,
                         alg_work_reduction=alg_per_launch / exec_per_launch,
@@ -433,11 +476,8 @@ def main():
                              "planes, " + ("one dual-digit pass instead of 5 limbs (the exact sums of what the screen lists come from "
                                            "k_pair_sums / the band GEMM)" if apx else f"{3 if mixed_blocks else J} int8 limbs") +
                              ".  The launch time of gemm_apx_kernel includes its epilogue, which applies the screen's threshold table to the "
-                             "kernel's own accumulators (the regions that pass are neither stored nor screened).  Tile pruning (r03, `prune`): on 45 "
-                             "of the 55 block pairs the kernel runs over the list of the wave tiles whose pairs are NOT all dismissed by their "
-                             "marginals alone (k_apx_live_tiles; 40 % of the tiles on this data) — pruned tiles are not in `achieved`, and the "
-                             "shorter launches (3.2 rounds of wave tiles instead of 8.1) pay a larger share of ramp and tail: the same K loop on "
-                             "full launches (`full_launches_without_pruning`: the same replay with ldw_set_prune(0), measured live) runs at 0.48 of the peak (DESIGN.md 5.1c/d).  `overlapped_avg_launch_ms` "
+                             "kernel's own accumulators (the regions that pass are neither stored nor screened).  " + prune_note +
+                             "`overlapped_avg_launch_ms` "
                              "is the bracket inside the timed region, where the GEMM shares the GPU with the previous block's screens and selection")
             tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
             if os.path.exists(tpath) and (L, N, world) == (100_000, 5_000, 1):   # the configuration the PMC passes were collected on
@@ -476,6 +516,9 @@ def main():
         out["path"] = path_report
         out["prune"] = dict(eng.prune_report(), what="wave tiles of the approximate GEMM whose pairs the threshold table dismisses whatever their joint "
                                                      "count (rows ordered by minor-state weight): flagged clean without being computed; not in roofline.achieved")
+        out["ranks_seen"] = ranks_seen
+        out["backend"] = backend_seen
+        out["self_launched"] = bool(os.environ.get("LDW_BENCH_SELF_LAUNCHED"))
         if per_rank is not None:
             out["per_rank"] = per_rank
         out.update(stages_ms_per_step={k: v / max(1, n_replay) for k, v in tim.items()},

@@ -22,7 +22,8 @@ def test_bench_flag_matrix_small():
 def _bench_line(cmd, timeout):
     import json
     import subprocess
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LDW_BENCH_SELF_LAUNCHED")}   # (no launcher around the child)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -31,21 +32,21 @@ def _bench_line(cmd, timeout):
 
 
 def test_bench_multi_rank_rehearsal():
-    """The command the driver's scaling run uses (torch.distributed.run, one rank per process, phased gather to rank 0), rehearsed on
+    """`python bench.py --gpus 4` (self-launching) = the command the driver's scaling run uses (torch.distributed.run, one rank per process, phased gather to rank 0), rehearsed on
     the ONE GPU of the test box with backend gloo: 4 ranks — the box's process guard allows at most 6 processes on its card, and the
     launcher and this pytest process may count among them (a 6-rank run was killed by it), so the 8-rank deal + gather is covered
     on the CPU instead (tests/test_dist_gloo.py::test_gather_gloo[8]).  Exit code 0, link counts
     identical to the 1-rank line, and the per-rank record the N > 1 line carries (compute / exposed gather / bytes sent)."""
-    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = ["--steps", "1", "--warmup", "1", "--no-extra-legs", "--no-cpu-baseline", "--L", "40000", "--N", "2000", "--max-blk-sz", "5000"]
     one = _bench_line([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + base, 600)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     world = 4
-    many = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo"] + base, 900)
+    # r04: no launcher around it — `python bench.py --gpus 4` starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node 4
+    # --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` itself (a child process, before this one touches the GPU),
+    # relays rank 0's line and the exit code
+    many = _bench_line([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo"] + base, 900)
+    assert many["ranks_seen"] == world and many["backend"] == "gloo" and many["self_launched"] is True
+    assert one["ranks_seen"] == 1 and one["self_launched"] is False
     assert many["n_gpus"] == world and one["n_gpus"] == 1
     assert many["links"] == one["links"] and one["links"]["n_lr"] > 0 and one["links"]["n_sr"] > 0
     assert many["config"]["pairs"] == one["config"]["pairs"]

@@ -200,3 +200,20 @@ def test_lr_links_approx_on_unsorted_positions_matches_oracle():
     POS = rng.permutation(np.sort(rng.choice(500_000, 2600, replace=False) + 1)).astype(np.int32)
     assert np.any(np.diff(POS) < 0)
     assert MI.lr_links_approx(POS, 500_000.0, 20000.0) == orc.lr_links_approx(POS, 500_000.0, 20000.0)
+
+
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` without a launcher around it must start 2 ranks (torch.distributed.run as a CHILD process) instead of
+    silently running one.  No GPU here: the ranks fail at their first device call, and that failure must come back
+    as a non-zero exit code of bench.py itself — with no JSON line — after the launcher command has been announced on stderr."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--L", "2000", "--N", "200", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline", "--no-extra-legs"], capture_output=True, text=True, timeout=600, env=env)
+    assert "starting 2 ranks" in p.stderr and "--nproc-per-node=2" in p.stderr and "--master-addr 127.0.0.1" in p.stderr, p.stderr[-2000:]
+    import torch
+    if not torch.cuda.is_available():
+        assert p.returncode != 0
+        assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
