@@ -328,7 +328,8 @@ int ldw_ldmap(ldw_ctx *ctx, int32_t reducer, int32_t from, int32_t to, int64_t *
  * value; fixed notation unless wider than scientific, so 100000 -> "1e+05").  out: >= 48 bytes, NUL-terminated. */
 int ldw_format_number(double x, char *out, int capacity);
 /* R's `set.seed(seed); sample(n, size)` (1-based, without replacement; Mersenne-Twister, rejection sampling: R >= 3.6 defaults) — the
- * draw behind the 10 % SNP subset of R/computePairwiseMI.R:94-97 (`lr_links_approx`).  Host only. */
+ * draw behind the 10 % SNP subset of R/computePairwiseMI.R:94-97 (`lr_links_approx`).  n > 1e7 with size <= n / 2 takes R's hashing
+ * variant (`sample.int(useHash = TRUE)`, do_sample2: elements re-drawn while they repeat an earlier one), as R itself does.  Host only. */
 int ldw_r_sample(uint32_t seed, int64_t n, int64_t size, int64_t *out);
 /* nrows x ncols numeric table (host columns of kind LDW_COL_*), tab-separated, no header, appended (append != 0) or
  * truncating; rows are formatted by nthreads host threads (0 = all cores) and written in order.  bytes_out may be NULL. */

@@ -196,6 +196,32 @@ int ldw_aracne(ldw_ctx * /*ctx*/, const double *chk_pos1, const double *chk_pos2
 int ldw_r_sample(uint32_t seed, int64_t n, int64_t size, int64_t *out) {
     LDW_REQUIRE(out && n >= 0 && size >= 0 && size <= n, LDW_ERR_ARG, "ldw_r_sample: bad argument (n %lld, size %lld)", (long long)n, (long long)size);
     RMersenne rng(seed);
+    if (n > 10000000 && size <= n / 2) {
+        // R >= 3.6: sample.int switches to do_sample2 (useHash = n > 1e7 && !replace && is.null(prob) && size <= n/2): every element is drawn
+        // with R_unif_index(n) + 1 and re-drawn while it repeats an earlier one (at most 100 draws per element, as in R).  Only WHICH values
+        // count as duplicates matters, not R's hash function: an open-addressing set of the values drawn so far.
+        size_t cap = 16;
+        while (cap < (size_t)size * 2 + 2) cap <<= 1;
+        std::vector<int64_t> set(cap, 0);   // 0 = empty (values are 1-based)
+        auto insert = [&](int64_t v) -> bool {   // false: already present
+            size_t h = (size_t)((uint64_t)v * 0x9E3779B97F4A7C15ull) & (cap - 1);
+            while (set[h] != 0) {
+                if (set[h] == v) return false;
+                h = (h + 1) & (cap - 1);
+            }
+            set[h] = v;
+            return true;
+        };
+        for (int64_t i = 0; i < size; ++i) {
+            int64_t v = 0;
+            for (int j = 0; j < 100; ++j) {
+                v = rng.unif_index((double)n) + 1;
+                if (insert(v)) break;
+            }
+            out[i] = v;
+        }
+        return LDW_OK;
+    }
     std::vector<int64_t> pool((size_t)n);
     for (int64_t i = 0; i < n; ++i) pool[(size_t)i] = i + 1;
     int64_t left = n;

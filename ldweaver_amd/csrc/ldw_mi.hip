@@ -3108,6 +3108,15 @@ int ldw_joint_tables(ldw_ctx *c, const int32_t *pair_a, const int32_t *pair_b, i
 int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(nblocks_capacity > 0, LDW_ERR_ARG, "ldw_links_begin: capacity must be positive");
+    if (c->blk_capacity != 0) {
+        // the previous pass never reached ldw_links_end (an error return in the middle of ldw_mi_all_pairs / ldw_mi_block_links): kernels of
+        // the aborted pass may still be queued on the three streams and read the index lists, staging images and per-slot buffers
+        // that this pass is about to overwrite
+        if (c->gemm_stream) LDW_HIP(hipStreamSynchronize(c->gemm_stream));
+        if (c->copy_stream) LDW_HIP(hipStreamSynchronize(c->copy_stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+        c->blk_capacity = 0;
+    }
     if (int rc = ensure_rows(c)) return rc;  // uses ctx->small for staging; link bookkeeping takes it over below
     const size_t need = 64 + LDW_NSLOT * PICK_STRIDE + (size_t)nblocks_capacity * 32 + 64;
     if (int rc = c->small.reserve(need)) return rc;
@@ -3320,20 +3329,28 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
             }
             int rc = LDW_OK;
             const int32_t fs = blocks[k * 4 + 0], fe = blocks[k * 4 + 1], ts = blocks[k * 4 + 2], te = blocks[k * 4 + 3];
-            if (!(fs >= 1 && fe >= fs && fe <= c->L && ts >= 1 && te >= ts && te <= c->L)) {
-                set_error("block %lld = (%d,%d,%d,%d) outside 1..%lld", (long long)k, fs, fe, ts, te, (long long)c->L);
-                rc = LDW_ERR_ARG;
-            } else {
-                wfi.resize((size_t)(fe - fs + 1));
-                wti.resize((size_t)(te - ts + 1));
-                for (int32_t q = fs; q <= fe; ++q) wfi[q - fs] = q - 1;
-                for (int32_t q = ts; q <= te; ++q) wti[q - ts] = q - 1;
-                const int slot = (int)(k % LDW_NSLOT);
-                if (c->up_recorded[slot] && hipEventSynchronize(c->ev_up[slot]) != hipSuccess) {   // the staging buffer of this slot has been uploaded
-                    set_error("prep: hipEventSynchronize failed");
-                    rc = LDW_ERR_HIP;
+            try {   // (prep_block allocates a dozen std::vectors: an exception on this thread must come back as an error code, not std::terminate)
+                if (!(fs >= 1 && fe >= fs && fe <= c->L && ts >= 1 && te >= ts && te <= c->L)) {
+                    set_error("block %lld = (%d,%d,%d,%d) outside 1..%lld", (long long)k, fs, fe, ts, te, (long long)c->L);
+                    rc = LDW_ERR_ARG;
+                } else {
+                    wfi.resize((size_t)(fe - fs + 1));
+                    wti.resize((size_t)(te - ts + 1));
+                    for (int32_t q = fs; q <= fe; ++q) wfi[q - fs] = q - 1;
+                    for (int32_t q = ts; q <= te; ++q) wti[q - ts] = q - 1;
+                    const int slot = (int)(k % LDW_NSLOT);
+                    if (c->up_recorded[slot] && hipEventSynchronize(c->ev_up[slot]) != hipSuccess) {   // the staging buffer of this slot has been uploaded
+                        set_error("prep: hipEventSynchronize failed");
+                        rc = LDW_ERR_HIP;
+                    }
+                    if (rc == LDW_OK) rc = prep_block(c, wfi.data(), (int64_t)wfi.size(), wti.data(), (int64_t)wti.size(), p, slot, k, hb[k % RING]);
                 }
-                if (rc == LDW_OK) rc = prep_block(c, wfi.data(), (int64_t)wfi.size(), wti.data(), (int64_t)wti.size(), p, slot, k, hb[k % RING]);
+            } catch (const std::exception &e) {
+                set_error("preparing block %lld: %s", (long long)k, e.what());
+                rc = LDW_ERR_HIP;
+            } catch (...) {
+                set_error("preparing block %lld: unknown exception", (long long)k);
+                rc = LDW_ERR_HIP;
             }
             std::lock_guard<std::mutex> lk(sh.m);
             if (rc != LDW_OK) {

@@ -41,10 +41,16 @@ inline bool fast15(double ax, char *sig, int *e10_out) {
         const unsigned __int128 prod = (unsigned __int128)m * P10[k];
         const int sh = -e;
         unsigned __int128 q = prod >> sh;
+        // the decimal exponent is decided on the quotient BEFORE rounding (with floor(log10) one too high, a value just below
+        // a power of ten rounded up to exactly 10^14 and passed for 1.00000000000000e(e10): 9.999999999999994e-05 printed as 1e-04)
+        if (q >= (unsigned __int128)P10[15]) { ++e10; continue; }   // log10 was one low
+        if (q < (unsigned __int128)P10[14]) { --e10; continue; }    // log10 was one high
         const unsigned __int128 rem = prod - (q << sh), half = (unsigned __int128)1 << (sh - 1);
         if (rem > half || (rem == half && (q & 1))) ++q;
-        if (q >= (unsigned __int128)P10[15]) { ++e10; continue; }   // log10 was one low (or the rounding carried into a 16th digit)
-        if (q < (unsigned __int128)P10[14]) { --e10; continue; }
+        if (q == (unsigned __int128)P10[15]) {                      // the rounding carried into a 16th digit: 9.99..95 -> 1.00..0 e(e10 + 1)
+            q = (unsigned __int128)P10[14];
+            ++e10;
+        }
         unsigned long long d = (unsigned long long)q;
         for (int i = 14; i >= 0; --i) { sig[i] = (char)('0' + d % 10); d /= 10; }
         *e10_out = e10;

@@ -96,7 +96,20 @@ class RRandom:
                 return v
 
     def sample(self, n: int, size: int) -> np.ndarray:
-        """``sample(n, size)`` without replacement; 1-based like R."""
+        """``sample(n, size)`` without replacement; 1-based like R.  ``n > 1e7 and size <= n/2``: R >= 3.6 takes ``do_sample2`` (hashing:
+        every element drawn with ``R_unif_index(n) + 1`` and re-drawn while it repeats an earlier one, at most 100 draws)."""
+        if n > 10_000_000 and size <= n // 2:
+            seen = set()
+            out = np.empty(size, dtype=np.int64)
+            for i in range(size):
+                v = 0
+                for _ in range(100):
+                    v = self._unif_index(n) + 1
+                    if v not in seen:
+                        seen.add(v)
+                        break
+                out[i] = v
+            return out
         pool = list(range(1, n + 1))
         out = np.empty(size, dtype=np.int64)
         left = n

@@ -34,6 +34,14 @@ def test_native_r_sample_is_r_s_stream():
         assert np.array_equal(a, rcompat.RRandom(seed).sample(n, size)), (seed, n, size)
         assert len(set(a.tolist())) == size and (size == 0 or (a.min() >= 1 and a.max() <= n))
     assert np.array_equal(rcompat.r_sample(1988, 12680, 1268), orc.RMersenneTwister(1988).sample(12680, 1268))
+    # n > 1e7 with size <= n / 2: R's sample.int(useHash = TRUE) draws with replacement-and-retry (do_sample2), not the partial shuffle
+    a = rcompat.r_sample(1988, 10_000_001, 20_000)
+    b = rcompat.RRandom(1988).sample(10_000_001, 20_000)
+    assert np.array_equal(a, b) and len(set(a.tolist())) == 20_000 and a.min() >= 1 and a.max() <= 10_000_001
+    draws = rcompat.RRandom(1988)
+    raw = [draws._unif_index(10_000_001) + 1 for _ in range(20_050)]
+    assert len(set(raw[:20_000])) < 20_000, "the case must contain a repeated draw, or the retry rule is not exercised"
+    assert list(a[:5]) == raw[:5]
 
 
 def test_quantile_type7():
@@ -74,6 +82,24 @@ def test_native_number_format_known_answers():
     assert native_format(float("nan")) == "NA" and native_format(float("inf")) == "Inf" and native_format(float("-inf")) == "-Inf"
     assert native_format(-0.0) == "0" and native_format(1110657.5) == "1110657.5" and native_format(0.5) == "0.5"
     assert native_format(123456789012345678.0) == rcompat.format_number(123456789012345678.0) == "123456789012345677"[:0] + rcompat.format_number(123456789012345678.0)
+
+
+def test_native_number_format_next_to_powers_of_ten():
+    """doubles just below a power of ten (floor(log10) comes out one too high; the rounded 15-digit quotient lands exactly on
+    10^14) must keep their own digits: 9.999999999999994e-05 is 9.99999999999999e-05, not 1e-04.  The nextafter neighbours (8 steps each
+    way) of 1e-5 ... 1e3, and values half a unit of the 15th digit around them, against the Python statement of R's rule."""
+    vals = [9.99999999999999e-05, 9.999999999999991e-05, 9.999999999999992e-05, 9.999999999999994e-05, 999.9999999999994]
+    for e in range(-5, 4):
+        p = 10.0 ** e
+        for d in (-1.0, 1.0):
+            v = p
+            for _ in range(8):
+                v = float(np.nextafter(v, d * np.inf))
+                vals.append(v)
+        vals += [p * (1 - 4e-16), p * (1 - 5e-16), p * (1 - 6e-16), p * (1 - 4.9e-15), p * (1 - 5.1e-15), p * (1 + 5e-15), p * (1 + 4.4e-16)]
+    for v in vals:
+        assert native_format(v) == rcompat.format_number(v), (repr(v), native_format(v), rcompat.format_number(v))
+    assert native_format(9.999999999999994e-05) == "9.99999999999999e-05" and native_format(999.9999999999994) == "999.999999999999"
 
 
 def test_native_tsv_writer_equals_python_writer(tmp_path):
