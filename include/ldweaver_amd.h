@@ -221,6 +221,17 @@ int ldw_path_report(ldw_ctx *ctx, int64_t out[8], char *gate, int capacity);
  * prune (both since the context was created; pruned tiles are not counted as executed work by ldw_gemm_stats), out[3] = on. */
 int ldw_set_prune(ldw_ctx *ctx, int on);
 int ldw_prune_report(ldw_ctx *ctx, int64_t out[4]);
+/* r04 — spans.  The reference's loop visits the block pairs of a block row one at a time (R/computePairwiseMI.R:103-116); consecutive
+ * LONG-RANGE-ONLY block pairs of one row (same from range, to ranges ascending, no pair within sr_dist) are run as ONE launch sequence
+ * over their concatenated to side, every reference block keeping its own histogram, threshold, candidate list and place in the append
+ * order (the lr filter is per block: :352-358).  Results never depend on it.  ldw_set_span: on != 0 (default), at most max_blocks
+ * (2..8; 0 keeps the current value) reference blocks per span.  ldw_span_report: out[0] spans run, out[1] reference blocks they covered,
+ * out[2] segments redone on their own after a wrong guess, out[3] on.
+ * ldw_set_pair_cap (tests only): a fixed capacity for the pair lists of the approximate path (0: automatic) — a list that overflows makes
+ * its block fall back like a wrong guess; process-wide. */
+int ldw_set_span(ldw_ctx *ctx, int on, int max_blocks);
+int ldw_span_report(ldw_ctx *ctx, int64_t out[4]);
+int ldw_set_pair_cap(uint32_t cap);
 /* inspection only: the per-SNP bounds behind the pruning of the 2 x 3 / 3 x 3 tables.  out[a * 4 + 2 * m + (k - 2)] = the largest MI
  * SNP a (2 or 3 states, all flagged in uqe, r = its number of states) can reach with ANY partner that has k = 2 or 3 flagged states
  * and r = k — the maximum of the MI over the joint tables with a's marginals, which is convex there and sits at a vertex: every

@@ -266,7 +266,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
                            &c->srm_q, &c->srm_n, &c->srm_md, &c->srm_part, &c->srm_shape, &c->srm_cnt, &c->red_row, &c->red_meta,
                            &c->red_srp, &c->pool_a, &c->pool_b, &c->pool_mi, &c->ar_key, &c->ar_val, &c->ar_key2, &c->ar_val2,
                            &c->ar_off, &c->ar_flags, &c->seq_perm, &c->dig_a, &c->dig_b, &c->apx_shift, &c->slot_papx, &c->pop_segs, &c->pop_wbeg,
-                           &c->pair_sums, &c->tab11[0], &c->tab11[1], &c->G2, &c->G3};
+                           &c->pair_sums, &c->tab11[0], &c->tab11[1], &c->G2, &c->G3, &c->miss_key, &c->miss_val};
     for (auto *b : bufs) b->release();
     for (int k = 0; k < LDW_NSLOT; ++k)
         for (ldw::DevBuf *b : {&c->panel[k][0], &c->panel[k][1], &c->Gapx[k], &c->pairs[k], &c->apx_units[k], &c->apx_packs[k], &c->apx_bins[k], &c->apx_clean[k],
@@ -280,6 +280,8 @@ int ldw_ctx_destroy(ldw_ctx *c) {
         if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]);
         if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
     }
+    c->dstage[LDW_NSLOT].release();   // (the staging of a span segment redone on its own)
+    if (c->pin[LDW_NSLOT]) (void)hipHostFree(c->pin[LDW_NSLOT]);
     for (int k = 0; k < LDW_NSLOT; ++k) {
         if (c->pin_pick[k]) (void)hipHostFree(c->pin_pick[k]);
         if (c->ev_pick[k]) (void)hipEventDestroy(c->ev_pick[k]);
@@ -855,6 +857,12 @@ int ensure_rows(ldw_ctx *c) {
     for (int64_t a = 0; a < L; ++a)
         if ((meta[a] & 7u) == 1u && ((meta[a] >> 3) & 3u) == 3u && c->h_r[(size_t)a] == 2.0) c->h_minor_w[(size_t)a] = spf[a * 5];
     c->order_cache.clear();
+    c->h_span_bad.assign((size_t)L + 1, 0);
+    for (int64_t a = 0; a < L; ++a) {
+        const int n = (int)(meta[a] & 7u);
+        const bool bad = n == 0 || ((n == 1 || n == 2) && (((meta[a] >> 3) & ((2u << n) - 1u)) != ((2u << n) - 1u)));
+        c->h_span_bad[(size_t)a + 1] = c->h_span_bad[(size_t)a] + (bad ? 1 : 0);
+    }
     const int64_t R = c->R;
     if (int rc = c->row0.reserve((size_t)(L + 1) * 4)) return rc;
     if (int rc = c->slot_meta.reserve((size_t)L * 4)) return rc;

@@ -1044,13 +1044,14 @@ __device__ __forceinline__ void pair_mi_body(const PairArgs &P, int path, unsign
         const RowPack &RP = A.rowpack[t];
         valid = valid && RP.a_loc >= 0;
         bool cand = false;
-        int bk = 0, seg = -1, a_loc = 0, b_loc = 0;
+        int bk = 0, seg = -1, a_loc = 0, b_loc = 0, sg = 0;
         double mi = 0.0;
         if (valid) {
             const RowSide R = RP.R;
             a_loc = RP.a_loc;
             const ColMeta M = A.colpack[q];
             b_loc = M.bl;
+            sg = A.span ? M.ci.pad[0] : 0;   // a span: the reference block (segment) of the column; b_loc is local to it
             const int64_t *sp = P.sums + ((int64_t)sub * A.pl_cap + idx) * 16;
             if constexpr (GEN) {
                 mi = pair_mi<4, 4>(A, R, M, a_loc, b_loc, square, gacc_plain(sp, 1, 4));
@@ -1064,6 +1065,28 @@ __device__ __forceinline__ void pair_mi_body(const PairArgs &P, int path, unsign
                 bk = mi_bucket(mi);
                 cand = bk >= E.spec_B;
             }
+        }
+        if (A.span) {
+            // every reference block of the span keeps its own candidate list and histogram (the long-range filter is per block:
+            // R/computePairwiseMI.R:352-358); the lanes of a wave hold columns of any segment (the to side is ordered by weight)
+            for (int k = 0; k < A.span; ++k) {
+                const bool mine = cand && sg == k;
+                const unsigned long long mk = __ballot(mine);
+                if (mk == 0ull) continue;
+                const int leader = __builtin_ctzll(mk);
+                unsigned long long pos = 0;
+                if (lane == leader) pos = atomicAdd(A.sseg[k].n_cand, (unsigned long long)__popcll(mk));
+                pos = __shfl(pos, leader);
+                if (mine) {
+                    pos += (unsigned long long)__popcll(mk & ((1ull << lane) - 1ull));
+                    A.sseg[k].ckey[pos] = f64_key(mi);
+                    A.sseg[k].cval[pos] = ((uint64_t)seg << 62) | ((uint64_t)a_loc + (uint64_t)b_loc * (uint64_t)E.nf);
+                    const int w = bk - (E.spec_B > 0 ? E.spec_B : 0);
+                    if (w < PAIR_HWIN) atomicAdd(&s_hist[k * PAIR_HWIN + w], 1u);
+                    else atomicAdd(&A.sseg[k].ghist[bk], 1ull);
+                }
+            }
+            continue;
         }
         const unsigned long long mk = __ballot(cand);
         if (mk == 0ull) continue;
@@ -1083,8 +1106,8 @@ __device__ __forceinline__ void pair_mi_body(const PairArgs &P, int path, unsign
 }
 
 __global__ __launch_bounds__(256) void k_pair_mi(PairArgs P) {
-    __shared__ unsigned int s_hist[PAIR_HWIN];
-    if (threadIdx.x < PAIR_HWIN) s_hist[threadIdx.x] = 0u;
+    __shared__ unsigned int s_hist[LDW_SPAN_MAX * PAIR_HWIN];   // one bucket window per segment of a span (segment 0: an ordinary block)
+    for (int i = threadIdx.x; i < LDW_SPAN_MAX * PAIR_HWIN; i += 256) s_hist[i] = 0u;
     __syncthreads();
     switch (blockIdx.z) {
         case 0: pair_mi_body<1, 1>(P, 0, s_hist); break;
@@ -1095,6 +1118,13 @@ __global__ __launch_bounds__(256) void k_pair_mi(PairArgs P) {
     }
     __syncthreads();
     const int hb0 = P.A.E.spec_B > 0 ? P.A.E.spec_B : 0;
+    if (P.A.span) {
+        for (int i = threadIdx.x; i < P.A.span * PAIR_HWIN; i += 256) {
+            const int k = i / PAIR_HWIN, w = i - k * PAIR_HWIN;
+            if (s_hist[i] != 0u && hb0 + w < NBINS) atomicAdd(&P.A.sseg[k].ghist[hb0 + w], (unsigned long long)s_hist[i]);
+        }
+        return;
+    }
     if (threadIdx.x < PAIR_HWIN && s_hist[threadIdx.x] != 0u && hb0 + (int)threadIdx.x < NBINS)
         atomicAdd(&P.ghist[hb0 + threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
 }

@@ -221,6 +221,19 @@ struct LoGeom {
 };
 __host__ __device__ __forceinline__ int lo_class(int nrows) { return nrows <= 1 ? 0 : (nrows == 2 ? 1 : 2); }
 
+// r04: a SPAN = several reference blocks that share their from side (one block row of make_blocks: R/computePairwiseMI.R:147-165), run as ONE
+// launch sequence over the concatenated to side.  Everything per-SNP and per-row is as for a single block; what belongs to the REFERENCE
+// block stays per segment: a column's local index (ColMeta::bl, counted from its segment's first SNP: pair identity a_loc != b_loc — quirk Q3 —,
+// the upper / lower triangle, the row-order key a + b nf of the selection), RXY as the reference's linear index reads it (Q1), the histogram,
+// candidate list and pick of the long-range filter (per block: R/computePairwiseMI.R:352-358).  A column carries its segment in
+// ColMeta::ci.pad[0] and its segment's first to-side index in ci.pad[1] (k_build_packs).
+constexpr int LDW_SPAN_MAX = 8;
+struct SpanSeg {
+    unsigned long long *n_cand;     // candidate counter of the segment (PickOut::n_cand)
+    uint64_t *ckey, *cval;          // its candidate list
+    unsigned long long *ghist;      // its NBINS histogram counters
+};
+
 struct PairEnt;
 struct EpiArgs {
     const int64_t *G;
@@ -263,6 +276,8 @@ struct EpiArgs {
     // sflag_f[64 * tile + lane], sflag_t[column slot]
     const uint8_t *sflag_f, *sflag_t;
     const double *snp_sup;    // [L][4] (k_snp_sup)
+    int span;                 // > 0: the to side is the concatenation of `span` reference blocks (segments), all long-range-only, nt of each = nf
+    SpanSeg sseg[LDW_SPAN_MAX];
     EmitArgs E;
 };
 constexpr unsigned PF_KIND = 3u, PF_DEAD2 = 4u, PF_DEAD3 = 8u, PF_PAD = 0x80u;
@@ -398,7 +413,9 @@ __device__ __forceinline__ double pair_mi(const EpiArgs &A, const RowSide &R, co
     if (A.quirk == LDW_QUIRK_REFERENCE) {
         // rft is nt x nf but read by the linear index c = a + b*nf of the nf x nt matrix (Q1):
         // 0.25 * rf[c / nt] * rt[c % nt]; on square blocks c / nt = b_loc and c % nt = a_loc
-        if (square) {
+        if (A.span) {   // (a span's segments are square blocks; b_loc is the column's index in ITS block, rt that block's to side)
+            RXY = (M.rq * (double)A.rloc_t[M.ci.pad[1] + a_loc]) * 0.25;
+        } else if (square) {
             RXY = (M.rq * R.rta) * 0.25;
         } else {
             const uint32_t c = (uint32_t)a_loc + (uint32_t)b_loc * (uint32_t)A.nf;
@@ -475,6 +492,7 @@ __device__ __forceinline__ void full_cells(const RowSide &R, const ColMeta &M, c
 // RXY of src/computeMI.cpp:19 as the reference reads it (quirk Q1) or as intended
 __device__ __forceinline__ double pair_rxy(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc, bool square) {
     if (A.quirk == LDW_QUIRK_REFERENCE) {
+        if (A.span) return (M.rq * (double)A.rloc_t[M.ci.pad[1] + a_loc]) * 0.25;
         if (square) return (M.rq * R.rta) * 0.25;
         const uint32_t c = (uint32_t)a_loc + (uint32_t)b_loc * (uint32_t)A.nf;
         const uint32_t q = c / (uint32_t)A.nt;
@@ -792,7 +810,7 @@ __device__ __forceinline__ GAcc g_entry(const EpiArgs &A, const RowSide &R, cons
 }
 
 // RXY as the screens need it.  mode 0: intended (r_a r_b); 1: reference quirk Q1 on a square block (r[from[b_loc]] r[to[a_loc]],
-// both staged per SNP); 2: Q1 on a ragged block — the linear index c = a_loc + b_loc nf of the nf x nt matrix read as
+// both staged per SNP); 3: the same on a span (r[to[a_loc]] of the column's segment: one look-up in rloc_t); 2: Q1 on a ragged block — the linear index c = a_loc + b_loc nf of the nf x nt matrix read as
 // nt x nf: r[from[c / nt]] r[to[c % nt]], looked up in the per-block local-order tables.
 __device__ __forceinline__ double screen_rxy(const EpiArgs &A, const RowSide &R, const ColMeta &M, int a_loc, int b_loc, int mode) {
     if (mode == 2) {
@@ -800,6 +818,7 @@ __device__ __forceinline__ double screen_rxy(const EpiArgs &A, const RowSide &R,
         const uint32_t q = c / (uint32_t)A.nt;
         return (double)(A.rloc_f[q] * A.rloc_t[c - q * (uint32_t)A.nt]) * 0.25;
     }
+    if (mode == 3) return (M.rq * (double)A.rloc_t[M.ci.pad[1] + a_loc]) * 0.25;   // a span: Q1 of the column's own (square) block
     return (mode == 1 ? M.rq * R.rta : R.ra * M.rb) * 0.25;
 }
 

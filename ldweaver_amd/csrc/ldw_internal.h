@@ -130,6 +130,10 @@ struct ldw_ctx {
     ldw::DevBuf apx_skip;              // uint64: wave tiles the GEMM skipped since the counter was last read
     double apx_ops_per_wave = 0;       // executed-operation accounting of the skipped tiles (ldw_gemm_stats)
     int64_t apx_waves_skipped = 0, apx_waves_total = 0;
+    // Spans (r04): consecutive long-range-only blocks of one block row run as ONE launch sequence over their concatenated to side
+    bool span_on = true;               // ldw_set_span / LDW_NO_SPAN
+    int span_max = 8;                  // most reference blocks per span (LDW_SPAN_MAX env, <= ldw::LDW_SPAN_MAX)
+    int64_t span_items = 0, span_blocks = 0, span_fallbacks = 0;   // spans run, reference blocks they covered, segments redone non-speculatively
     std::atomic<int64_t> sorted_blocks{0};   // (prep_block runs on the helper thread and, for the cold-start probes, on the calling thread at once)
     std::mutex order_mtx;                    // guards order_cache
     // Per-SNP bound behind the pruning of the wider tables (k_snp_sup): snp_sup[a * 4 + 2 * m + (k - 2)] = the largest MI SNP a (2 or
@@ -166,6 +170,7 @@ struct ldw_ctx {
     std::vector<uint32_t> h_slot_meta;
     std::vector<int32_t> h_counts;
     std::vector<int64_t> h_minor_w;   // [L]: fixed-point weight of slot 0 of a biallelic r = 2 SNP with one row (else INT64_MAX)
+    std::vector<int32_t> h_span_bad;  // [L + 1] prefix count of the SNPs a span cannot hold: no indicator row, or 1-2 rows with an unflagged slot (ensure_rows)
 
     // ---- per-block workspaces ----
     ldw::DevBuf G, G2, G3;       // int64 [RTpad][RFpad] fixed-point joint sums, one per pipeline slot (gx())
@@ -174,6 +179,8 @@ struct ldw_ctx {
     ldw::DevBuf scr_units;       // uint32 count (64-B slot) + list of the block's units the fp32 screen wants evaluated exactly
     ldw::DevBuf hist[LDW_NSLOT], cand_key[LDW_NSLOT], cand_val[LDW_NSLOT];   // per pipeline slot: histogram of the lr candidates, candidate list
     ldw::DevBuf colcnt, cand_key2, cand_val2, scratch, small;
+    ldw::DevBuf miss_key, miss_val;   // candidate list of a span's segment that is redone on its own (the slot's lists hold its neighbours')
+    std::vector<uint8_t> ev_valid;    // per block of the pass: its stage events were recorded (the segments of a span share the first one's)
     ldw::DevBuf sel_bitmap, sel_chunks, sel_prefix;   // fast selection (k_sel_thresh): bitmap, chunk and super-chunk (sel_prefix) counters, all-zero between blocks
 
     // ---- link tables (device resident) ----
@@ -194,9 +201,9 @@ struct ldw_ctx {
     hipStream_t copy_stream = nullptr, gemm_stream = nullptr;
     hipEvent_t ev_gemm[LDW_NSLOT] = {};
     bool overlap = true;                 // GEMM of block b+1 on its own stream beside the epilogue/selection of block b
-    void *pin[LDW_NSLOT] = {};   // pinned host staging, one packed buffer per slot
-    size_t pin_cap[LDW_NSLOT] = {};
-    ldw::DevBuf dstage[LDW_NSLOT];               // device image of the packed buffer
+    void *pin[LDW_NSLOT + 1] = {};   // pinned host staging, one packed buffer per slot (+ 1: a span segment that is redone on its own)
+    size_t pin_cap[LDW_NSLOT + 1] = {};
+    ldw::DevBuf dstage[LDW_NSLOT + 1];               // device image of the packed buffer
     hipEvent_t ev_up[LDW_NSLOT] = {}, ev_done[LDW_NSLOT] = {};
     bool done_recorded[LDW_NSLOT] = {};
     bool up_recorded[LDW_NSLOT] = {};    // ev_up[slot] has been recorded at least once

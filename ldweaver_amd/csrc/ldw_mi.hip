@@ -81,6 +81,10 @@ __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *_
     if (to_side && i < A.nt) {
         ColMeta m;
         load_col(A, perm_t, square, i, m, false);
+        if (A.span) {   // a column of a span: its index within ITS reference block, and the r of quirk Q1 on that (square) block
+            m.bl -= m.ci.pad[1];
+            m.rq = A.r[A.idx_f[m.bl]];
+        }
         cp[i] = m;
         if ((m.mb & 7) == 1 && col_is_fast(m.mb) && m.rb == 2.0) my_bt = m.pad2 & 63;
         if (sflag_t) {
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(256) void k_mi_screen_generic(EpiArgs A, const int3
     int n_it = A.nt - q_base;
     n_it = n_it > GEN_COLS / 4 ? GEN_COLS / 4 : n_it;
     if (n_it <= 0) return;
-    const int rxy_mode = A.quirk == LDW_QUIRK_REFERENCE ? (square ? 1 : 2) : 0;
+    const int rxy_mode = A.quirk == LDW_QUIRK_REFERENCE ? (A.span ? 3 : (square ? 1 : 2)) : 0;
     const float lo = (float)A.E.spec_lo - A.E.scr_eps;
     const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0, do_lr = A.E.do_lr != 0;
     unsigned int wanted = 0, mine = 0;   // mine: the units of this wave that belong to this kernel
@@ -944,9 +948,9 @@ struct PickOut {
 // holding rank lo.  One workgroup: chunked prefix sum over the NBINS counters.
 // In speculative mode (spec_B >= 0) the histogram only holds buckets >= spec_B; n_total is the block's long-range
 // pair count known to the host, and everything below spec_B is lumped into one virtual bucket.
-__global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *__restrict__ hist, double lr_retain,
-                                                     double lr_approx, int spec_B, long long n_total,
-                                                     PickOut *__restrict__ out, const unsigned int *__restrict__ pl_n, unsigned int pl_cap) {
+__device__ __forceinline__ void pick_bucket_body(const unsigned long long *__restrict__ hist, double lr_retain, double lr_approx, int spec_B,
+                                                 long long n_total, PickOut *__restrict__ out, const unsigned int *__restrict__ pl_n,
+                                                 unsigned int pl_cap) {
     __shared__ long long part[256];
     __shared__ long long s_lo;
     constexpr int PER = NBINS / 256;
@@ -1025,6 +1029,25 @@ __global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *_
     } else if (t == 0) {
         out->n_cand = 0;  // guess too high: the fallback gather starts from an empty list
     }
+}
+
+__global__ __launch_bounds__(256) void k_pick_bucket(const unsigned long long *__restrict__ hist, double lr_retain,
+                                                     double lr_approx, int spec_B, long long n_total,
+                                                     PickOut *__restrict__ out, const unsigned int *__restrict__ pl_n, unsigned int pl_cap) {
+    pick_bucket_body(hist, lr_retain, lr_approx, spec_B, n_total, out, pl_n, pl_cap);
+}
+
+// the same for every reference block of a span at once (blockIdx.x = segment): its own histogram, long-range pair count and pick
+// record; the pair lists (and their overflow test) are the span's
+struct PickSpanArgs {
+    long long n_total[LDW_SPAN_MAX];
+};
+__global__ __launch_bounds__(256) void k_pick_bucket_span(const unsigned long long *__restrict__ hist, double lr_retain, double lr_approx, int spec_B,
+                                                          PickSpanArgs S, char *__restrict__ picks, size_t pick_stride,
+                                                          const unsigned int *__restrict__ pl_n, unsigned int pl_cap) {
+    const int k = (int)blockIdx.x;
+    pick_bucket_body(hist + (size_t)k * NBINS, lr_retain, lr_approx, spec_B, S.n_total[k], reinterpret_cast<PickOut *>(picks + (size_t)k * pick_stride), pl_n,
+                     pl_cap);
 }
 
 struct GatherArgs {
@@ -1587,6 +1610,8 @@ struct LoHost {
     int ordered = 0;                     // rows of the one-row SNPs in order of the minor state's weight (prep_block: tile pruning)
     int fuse_ok = 0;                     // rows of one-row SNPs sit at their slot index in both row lists (no SNP without a row): the
                                          // GEMM's epilogue may apply the threshold table by row (ApxGemmArgs::fuse)
+    int span = 0;                        // reference blocks on the to side (0: an ordinary block); sseg: their candidate lists / histograms
+    const SpanSeg *sseg = nullptr;
 };
 
 void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int quirk, const EmitArgs &E, const int64_t *G,
@@ -1622,6 +1647,8 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
     A.snp_sup = nullptr;
     A.tab_nb = 0;
     A.tab_c = 0;
+    A.span = 0;
+    memset(A.sseg, 0, sizeof(A.sseg));
     A.E = E;
     memset(&A.lo, 0, sizeof(A.lo));
 }
@@ -1637,9 +1664,16 @@ constexpr size_t PAIR_CAP = 1u << 18;       // most entries per pair list of the
 // capacity of the pair lists of one block: an eighth of the block's pairs (a shard's fair share of ALL of them), between 2^12 and
 // PAIR_CAP.  Small blocks (tests, several engines on one GPU) then take megabytes instead of the fixed 1.4 GB; a list that
 // overflows makes the block fall back like a wrong guess (k_pick_bucket: spec_ok = 0), so results never depend on it.
-inline uint32_t pair_cap_for(int64_t nf, int64_t nt) {
+// nseg > 4: the lists of a span of that many reference blocks (about 4e4 listed pairs per 10k x 10k block, most of them in ONE of the five
+// paths: 3-state x 3-state SNP pairs) get twice the room.  g_pair_cap_override (ldw_set_pair_cap, tests only): a fixed small capacity, so
+// that the overflow fallback can be exercised.
+static std::atomic<uint32_t> g_pair_cap_override{0};
+inline uint32_t pair_cap_for(int64_t nf, int64_t nt, int nseg = 0) {
+    const uint32_t ovr = g_pair_cap_override.load();
+    if (ovr) return ovr;
+    const uint64_t top = nseg > 4 ? 2 * PAIR_CAP : PAIR_CAP;
     uint64_t want = (uint64_t)nf * (uint64_t)nt / PAIR_SHARDS + 1, cap = 1u << 12;
-    while (cap < want && cap < PAIR_CAP) cap <<= 1;
+    while (cap < want && cap < top) cap <<= 1;
     return (uint32_t)cap;
 }
 int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E,
@@ -1845,7 +1879,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         if (int rc = c->apx_units[s].reserve(o_flat + 2 * n_units_max * 8 + 64)) return rc;
         if (int rc = c->apx_packs[s].reserve(o_rt + (size_t)nt * 4 + 256)) return rc;
         if (use_pairs)
-            if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * pair_cap_for(nf, nt) * sizeof(PairEnt))) return rc;
+            if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * pair_cap_for(nf, nt, lo_h->span) * sizeof(PairEnt))) return rc;
         if (need_exact)
             if (int rc = Gx.reserve((size_t)RFpad * RTpad * 8)) return rc;
         if (int rc = c->apx_bins[s].reserve(2 * ((size_t)RTpad + (size_t)RFpad) + (size_t)nt + (size_t)nf_slots + 256 + (size_t)(RTpad / 128) * (size_t)(RFpad / 64) * 4)) return rc;
@@ -1882,6 +1916,11 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     EpiArgs A;
     fill_epi_args(c, D, nf, nt, RFpad, quirk, E, reinterpret_cast<const int64_t *>(c->Gapx[s].p), A);
     A.lo.slot_pfix_hi = c->slot_papx.as<int64_t>();   // the screen derives its cells from the marginals of the approximate weights
+    if (lo_h->span) {
+        LDW_REQUIRE(E.scr_mode == 1 && E.do_lr && !E.any_sr && !lo_h->band_full && lo_h->fuse_ok && lo_h->sseg, LDW_ERR_STATE, "a span needs long-range-only blocks and pair lists");
+        A.span = lo_h->span;
+        for (int k = 0; k < lo_h->span; ++k) A.sseg[k] = lo_h->sseg[k];
+    }
     const int kd_tab = lo_h->diag ? 1 : 0;
     // (the table is built for RXY = 1, the floor of the reference's scrambled RXY = r r' / 4 as long as no SNP has r < 2)
     if (E.do_lr && c->tab11_on && c->tab11[kd_tab].p && c->tab11_lo[kd_tab] > 0 && E.spec_lo - (double)E.scr_eps >= c->tab11_lo[kd_tab] &&
@@ -1921,7 +1960,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     if (use_pairs) {
         A.pl_n = c->pairs[s].as<unsigned int>();
         A.pl_pairs = reinterpret_cast<PairEnt *>(c->pairs[s].as<char>() + o_pairs);
-        A.pl_cap = pair_cap_for(nf, nt);
+        A.pl_cap = pair_cap_for(nf, nt, lo_h->span);
     }
     if (phase == 1) {
         if (E.do_lr) {
@@ -1946,7 +1985,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             Z.n16[5] = (unsigned int)(((size_t)RTpad + (size_t)RFpad) / 16 + 1);
             if (zero_hist) {
                 Z.p[2] = reinterpret_cast<uint4 *>(zero_hist);
-                Z.n16[2] = (unsigned int)(NBINS * 8 / 16);
+                Z.n16[2] = (unsigned int)((size_t)NBINS * 8 / 16 * (size_t)(lo_h->span ? lo_h->span : 1));   // (a span: one histogram per reference block)
                 Z.p[3] = reinterpret_cast<uint4 *>(zero_pick);
                 Z.n16[3] = (unsigned int)(zero_pick_bytes / 16);
             }
@@ -2008,11 +2047,11 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     // LDW_SCREEN_MAIN=1 (experiment): the block's screen at the head of phase 2 on the main stream — beside the NEXT block's GEMM on the GEMM
     // stream — instead of behind its own GEMM
     static const bool screen_main = getenv("LDW_SCREEN_MAIN") != nullptr;
-    const int rm_s = quirk == LDW_QUIRK_REFERENCE ? (nf == nt ? 1 : 2) : 0;
+    const int rm_s = quirk == LDW_QUIRK_REFERENCE ? (lo_h->span ? 3 : (nf == nt ? 1 : 2)) : 0;
 #define LDW_SCREEN(RMv, ST) hipLaunchKernelGGL((k_mi_screen<RMv, true>), egrid, dim3(256), 0, ST, A, D.perm, D.perm_t, units, n_units, list_stride)
     if (phase == 1) {
         if (!screen_main) {
-            if (rm_s == 0) LDW_SCREEN(0, gs); else if (rm_s == 1) LDW_SCREEN(1, gs); else LDW_SCREEN(2, gs);
+            if (rm_s == 0) LDW_SCREEN(0, gs); else if (rm_s == 1) LDW_SCREEN(1, gs); else if (rm_s == 3) LDW_SCREEN(3, gs); else LDW_SCREEN(2, gs);
             LDW_HIP(hipGetLastError());
         }
         LDW_HIP(hipEventRecord(ev[5], gs));
@@ -2021,7 +2060,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     // ---- phase 2 ----
     LDW_HIP(hipEventRecord(ev[4], c->stream));
     if (screen_main) {
-        if (rm_s == 0) LDW_SCREEN(0, c->stream); else if (rm_s == 1) LDW_SCREEN(1, c->stream); else LDW_SCREEN(2, c->stream);
+        if (rm_s == 0) LDW_SCREEN(0, c->stream); else if (rm_s == 1) LDW_SCREEN(1, c->stream); else if (rm_s == 3) LDW_SCREEN(3, c->stream); else LDW_SCREEN(2, c->stream);
         LDW_HIP(hipGetLastError());
     }
 #undef LDW_SCREEN
@@ -2185,8 +2224,9 @@ constexpr size_t PICK_STRIDE = ((sizeof(ldw::PickOut) + 63) / 64) * 64;
 void links_layout(ldw_ctx *c, SmallLayout &sl) {
     char *base = c->small.as<char>();
     sl.lr_count = reinterpret_cast<int64_t *>(base);
-    for (int k = 0; k < LDW_NSLOT; ++k) sl.pick[k] = reinterpret_cast<ldw::PickOut *>(base + 64 + (size_t)k * PICK_STRIDE);
-    sl.stats_i = reinterpret_cast<int64_t *>(base + 64 + LDW_NSLOT * PICK_STRIDE);
+    // (every slot has room for the pick records of a span's segments: segment k of slot s at sl.pick[s] + k * PICK_STRIDE bytes)
+    for (int k = 0; k < LDW_NSLOT; ++k) sl.pick[k] = reinterpret_cast<ldw::PickOut *>(base + 64 + (size_t)k * LDW_SPAN_MAX * PICK_STRIDE);
+    sl.stats_i = reinterpret_cast<int64_t *>(base + 64 + (size_t)LDW_NSLOT * LDW_SPAN_MAX * PICK_STRIDE);
     sl.stats_d = reinterpret_cast<double *>(sl.stats_i + c->blk_capacity * 3);
 }
 
@@ -2213,6 +2253,22 @@ struct HostBlock {
     DevPtrs D{};
     EmitArgs E{};
     int spec_B = -1;
+    // r04 span (ldw_epi.h): the to side is the concatenation of `span` reference blocks (0: an ordinary block)
+    int span = 0;
+    int32_t seg_start[LDW_SPAN_MAX] = {}, seg_nt[LDW_SPAN_MAX] = {};
+    int64_t seg_lr_total[LDW_SPAN_MAX] = {};
+    size_t cand_cap = 0;               // entries of every segment's candidate list
+    SpanSeg sseg[LDW_SPAN_MAX] = {};
+    int pin_slot = -1;                 // staging buffer the lists were built in (-1: the slot's own)
+    bool force_plain = false;          // never speculate: a span's segment that is redone after a wrong guess
+    bool span_alone = false;           // the span could not be submitted as one (no positive guess): its blocks run one by one in finish_span
+    std::vector<int32_t> span_from, span_to;   // the span's SNP lists (host): what a segment that runs on its own is prepared from
+};
+
+// the to side of a span: where each reference block starts in the concatenated list
+struct SpanPlan {
+    int nseg = 0;
+    int32_t start[LDW_SPAN_MAX] = {}, nt[LDW_SPAN_MAX] = {};
 };
 
 // The speculative selection (bucket guess -> approximate GEMM / screen -> lists of the pairs that may pass) pays when the long-range filter
@@ -2227,7 +2283,7 @@ static inline bool speculation_pays(const ldw_ctx *c, const ldw_mi_params *p) {
 }
 
 int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt, const ldw_mi_params *p,
-               int slot, int64_t blk_no, HostBlock &hb) {
+               int slot, int64_t blk_no, HostBlock &hb, const SpanPlan *sp = nullptr, int pin_slot = -1) {
     LDW_REQUIRE(nf > 0 && nt > 0, LDW_ERR_ARG, "empty block (nf=%lld nt=%lld)", (long long)nf, (long long)nt);
     LDW_REQUIRE(nf <= 1000000 && nt <= 1000000 && nf * nt < 2147483647LL, LDW_ERR_ARG, "block too large (%lld x %lld)",
                 (long long)nf, (long long)nt);
@@ -2240,6 +2296,7 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     hb.nt = nt;
     hb.slot = slot;
     hb.blk_no = blk_no;
+    hb.pin_slot = pin_slot;
     hb.diag = same_list(from_idx, nf, to_idx, nt);
     SideLists SF, ST;
     std::vector<ColInfo> cols;
@@ -2255,6 +2312,20 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
         cols.assign((size_t)nt, z);
         hb.n_sr_blk = 0;
     } else if (int rc = build_cols(c, from_idx, nf, to_idx, nt, hb.diag, p->sr_dist, cols, hb.n_sr_blk)) return rc;
+    if (sp) {   // a span: every column learns its reference block and where that block starts in the concatenated to side
+        LDW_REQUIRE(!hb.generic && !hb.diag && hb.n_sr_blk == 0 && sp->nseg >= 1 && sp->nseg <= LDW_SPAN_MAX, LDW_ERR_STATE,
+                    "span of %d blocks at block %lld is not long-range-only", sp->nseg, (long long)blk_no);
+        hb.span = sp->nseg;
+        for (int k = 0; k < sp->nseg; ++k) {
+            hb.seg_start[k] = sp->start[k];
+            hb.seg_nt[k] = sp->nt[k];
+            hb.seg_lr_total[k] = nf * (int64_t)sp->nt[k] - std::min<int64_t>(nf, sp->nt[k]);   // (off-diagonal blocks drop their own diagonal: Q3)
+            for (int32_t b = sp->start[k]; b < sp->start[k] + sp->nt[k]; ++b) {
+                cols[(size_t)b].pad[0] = k;
+                cols[(size_t)b].pad[1] = sp->start[k];
+            }
+        }
+    }
     // Blocks without a short-range pair (most off-diagonal ones): nothing depends on the order of the rows within a class, so the
     // one-row SNPs are ordered by the weight of their minor state on both sides — rows and epilogue slots alike, which the table
     // test of the GEMM's epilogue requires anyway.  The wave tiles of the approximate GEMM then span few bins of the threshold
@@ -2302,9 +2373,10 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
                 ord_f = &ord_f_own;
                 ord_t = &ord_t_own;
             }
-            ++c->sorted_blocks;
+            c->sorted_blocks += sp ? sp->nseg : 1;
         }
     }
+    LDW_REQUIRE(!sp || (ord_f && ord_t), LDW_ERR_STATE, "span at block %lld cannot be ordered", (long long)blk_no);
     if (int rc = build_side(c, from_idx, nf, SF, ord_f)) return rc;
     if (int rc = build_side(c, to_idx, nt, ST, ord_t)) return rc;
     hb.RFpad = SF.Rpad;
@@ -2468,14 +2540,15 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     hb.o_tf = o; o = al(o + tf.size() * 4);
     hb.o_band = o; o = al(o + band.size());
     hb.total = o;
-    if (c->pin_cap[slot] < o) {
-        if (c->pin[slot]) LDW_HIP(hipHostFree(c->pin[slot]));
-        c->pin[slot] = nullptr;
-        c->pin_cap[slot] = 0;
-        LDW_HIP(hipHostMalloc(&c->pin[slot], o * 2, hipHostMallocDefault));
-        c->pin_cap[slot] = o * 2;
+    const int ps = pin_slot >= 0 ? pin_slot : slot;
+    if (c->pin_cap[ps] < o) {
+        if (c->pin[ps]) LDW_HIP(hipHostFree(c->pin[ps]));
+        c->pin[ps] = nullptr;
+        c->pin_cap[ps] = 0;
+        LDW_HIP(hipHostMalloc(&c->pin[ps], o * 2, hipHostMallocDefault));
+        c->pin_cap[ps] = o * 2;
     }
-    char *b = static_cast<char *>(c->pin[slot]);
+    char *b = static_cast<char *>(c->pin[ps]);
     memcpy(b + hb.o_idx_f, from_idx, (size_t)nf * 4);
     memcpy(b + hb.o_idx_t, to_idx, (size_t)nt * 4);
     memcpy(b + hb.o_rl_f, SF.rowlist.data(), SF.rowlist.size() * 4);
@@ -2503,8 +2576,7 @@ int launch_gather(ldw_ctx *c, const HostBlock &hb, const EmitArgs &E, const Smal
     S.nf = (int)hb.nf;
     S.nt = (int)hb.nt;
     S.lower_only = E.lower_only;
-    hipLaunchKernelGGL(k_lr_gather, dim3((unsigned)((hb.nt + 15) / 16)), dim3(256), 0, c->stream, S, sl.pick[hb.slot],
-                       c->cand_key[hb.slot].as<uint64_t>(), c->cand_val[hb.slot].as<uint64_t>());
+    hipLaunchKernelGGL(k_lr_gather, dim3((unsigned)((hb.nt + 15) / 16)), dim3(256), 0, c->stream, S, sl.pick[hb.slot], E.ckey, E.cval);
     LDW_HIP(hipGetLastError());
     return LDW_OK;
 }
@@ -2521,7 +2593,7 @@ double lo_bound(const ldw_ctx *c) {
 int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl, int spec_B) {
     const int s = hb.slot;
     const bool do_lr = !p->sr_only;
-    const char *d = c->dstage[s].as<char>();
+    const char *d = c->dstage[hb.pin_slot >= 0 ? hb.pin_slot : s].as<char>();
     EmitArgs E;
     memset(&E, 0, sizeof(E));
     E.cols = reinterpret_cast<const ColInfo *>(d + hb.o_cols);
@@ -2537,10 +2609,28 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
     // dense MI block is neither written nor re-read; without one (first block, histogram engine) the dense block
     // is written and k_lr_gather collects them once the true bucket is known.
     hb.spec_B = spec_B;
-    const size_t cap = (size_t)hb.nf * hb.nt;  // worst case: every pair of the block
-    if (do_lr) {
+    size_t cap = (size_t)hb.nf * hb.nt;  // worst case: every pair of the block
+    if (hb.span) {
+        // a span only ever runs speculatively: a segment's candidates all come from the span's pair lists (a segment whose guess was
+        // wrong is redone on its own, with its own worst-case list)
+        size_t seg_max = 0;
+        for (int k = 0; k < hb.span; ++k) seg_max = std::max(seg_max, (size_t)hb.nf * (size_t)hb.seg_nt[k]);
+        hb.cand_cap = std::min<size_t>(seg_max, (size_t)PAIR_PATHS * PAIR_SHARDS * pair_cap_for(hb.nf, hb.nt, hb.span));
+        cap = hb.cand_cap * (size_t)hb.span;
+    }
+    if (do_lr && !hb.force_plain) {
         if (int rc = c->cand_key[s].reserve(cap * 8)) return rc;
         if (int rc = c->cand_val[s].reserve(cap * 8)) return rc;
+    }
+    if (hb.span) {
+        if (int rc = c->hist[s].reserve((size_t)hb.span * NBINS * 8)) return rc;
+        for (int k = 0; k < hb.span; ++k) {
+            ldw::PickOut *pk = reinterpret_cast<ldw::PickOut *>(reinterpret_cast<char *>(sl.pick[s]) + (size_t)k * PICK_STRIDE);
+            hb.sseg[k].n_cand = &pk->n_cand;
+            hb.sseg[k].ckey = c->cand_key[s].as<uint64_t>() + (size_t)k * hb.cand_cap;
+            hb.sseg[k].cval = c->cand_val[s].as<uint64_t>() + (size_t)k * hb.cand_cap;
+            hb.sseg[k].ghist = c->hist[s].as<unsigned long long>() + (size_t)k * NBINS;
+        }
     }
     E.write_dense = (do_lr && hb.spec_B < 0) ? 1 : 0;   // the dense block only feeds k_lr_gather; SR-only passes take the screen path
     E.spec_B = hb.spec_B;
@@ -2549,6 +2639,13 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
     E.n_cand = &sl.pick[s]->n_cand;
     E.ckey = c->cand_key[s].as<uint64_t>();
     E.cval = c->cand_val[s].as<uint64_t>();
+    if (hb.force_plain && do_lr) {
+        // a span's segment redone on its own: the slot's candidate buffers still hold the lists of the span's later segments
+        if (int rc = c->miss_key.reserve((size_t)hb.nf * hb.nt * 8)) return rc;
+        if (int rc = c->miss_val.reserve((size_t)hb.nf * hb.nt * 8)) return rc;
+        E.ckey = c->miss_key.as<uint64_t>();
+        E.cval = c->miss_val.as<uint64_t>();
+    }
     // fp32 screen: only where a pair can be dismissed at all (speculative mode with a positive lower edge)
     E.scr_mode = (hb.spec_B > 0 || !do_lr) && !E.write_dense && (!do_lr || speculation_pays(c, p)) ? c->screen : 0;   // (no screen where nearly every unit would be listed)
     // the screen reads the top 31 bits of a joint sum; in the mixed-precision path the sums are those of the high-limb
@@ -2583,6 +2680,16 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
 // bucket pick + copy-back of the pick of slot s on `st`
 int launch_pick(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl, hipStream_t st) {
     const int s = hb.slot;
+    if (hb.span) {
+        PickSpanArgs S;
+        memset(&S, 0, sizeof(S));
+        for (int k = 0; k < hb.span; ++k) S.n_total[k] = (long long)hb.seg_lr_total[k];
+        hipLaunchKernelGGL(k_pick_bucket_span, dim3((unsigned)hb.span), dim3(256), 0, st, c->hist[s].as<unsigned long long>(), p->lr_retain_links,
+                           p->lr_links_approx, hb.spec_B, S, reinterpret_cast<char *>(sl.pick[s]), PICK_STRIDE,
+                           reinterpret_cast<const unsigned int *>(c->pairs[s].p), pair_cap_for(hb.nf, hb.nt, hb.span));
+        LDW_HIP(hipGetLastError());
+        return LDW_OK;
+    }
     if (!p->sr_only) {
         const bool pl = hb.apx && c->screen == 1;
         hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, st, c->hist[s].as<unsigned long long>(), p->lr_retain_links,
@@ -2600,13 +2707,14 @@ int launch_pick(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p, const S
 //            the whole block overlaps the selection (sorts, host round trip) of the previous one.
 int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
     const int s = hb.slot;
-    if (int rc = c->dstage[s].reserve(hb.total)) return rc;
+    const int stg = hb.pin_slot >= 0 ? hb.pin_slot : s;   // (a span's segment that runs on its own is staged through the extra buffer)
+    if (int rc = c->dstage[stg].reserve(hb.total)) return rc;
     // the device image and the per-slot buffers (G, histogram, pick, candidates) were last used by the block two steps back
     if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_done[s], 0));
-    LDW_HIP(hipMemcpyAsync(c->dstage[s].p, c->pin[s], hb.total, hipMemcpyHostToDevice, c->copy_stream));
+    LDW_HIP(hipMemcpyAsync(c->dstage[stg].p, c->pin[stg], hb.total, hipMemcpyHostToDevice, c->copy_stream));
     LDW_HIP(hipEventRecord(c->ev_up[s], c->copy_stream));
     c->up_recorded[s] = true;
-    const char *d = c->dstage[s].as<char>();
+    const char *d = c->dstage[stg].as<char>();
     auto I = [&](size_t off) { return reinterpret_cast<const int32_t *>(d + off); };
     auto B = [&](size_t off) { return reinterpret_cast<const uint8_t *>(d + off); };
     hb.D = DevPtrs{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm), I(hb.o_perm_t),
@@ -2620,9 +2728,22 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(gs, c->ev_done[s], 0));
     hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
     const bool do_lr = !p->sr_only;
-    const int guess = do_lr ? (speculation_pays(c, p) ? c->spec_B_next[hb.diag ? 1 : 0] : -1) : 0;
+    const int guess = do_lr ? ((speculation_pays(c, p) && !hb.force_plain) ? c->spec_B_next[hb.diag ? 1 : 0] : -1) : 0;
+    if ((int64_t)c->ev_valid.size() < hb.blk_no + std::max(1, hb.span)) c->ev_valid.resize((size_t)(hb.blk_no + std::max(1, hb.span)), 1);
+    c->ev_valid[(size_t)hb.blk_no] = 1;
+    for (int k = 1; k < hb.span; ++k) c->ev_valid[(size_t)hb.blk_no + k] = 0;   // (the span's stage events are its first block's; a segment that runs alone records its own)
+    if (hb.span) {
+        // a span runs the approximate path or not at all: should the state it was planned on have gone (no positive guess any more),
+        // its reference blocks take the ordinary chain one after the other (finish_span)
+        const bool can = c->path_mode != 1 && c->apx_ok && c->screen == 1 && do_lr && guess > 0 && !c->fused && c->engine == LDW_ENGINE_MFMA;
+        if (!can) {
+            hb.span_alone = true;
+            return LDW_OK;
+        }
+    }
     hb.fused = c->fused && c->nlimbs <= 5 && (!do_lr || guess >= 0);
-    ++(hb.fused ? c->fused_blocks : c->unfused_blocks);
+    if (hb.span) c->unfused_blocks += hb.span;
+    else ++(hb.fused ? c->fused_blocks : c->unfused_blocks);
     hb.guess = guess;
     if (!hb.fused) {
         // mixed precision: with a bucket guess the block will run the screen, which only needs the high limbs; the low
@@ -2638,16 +2759,22 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
         if (hb.apx) {
             hb.mixed = false;
             hb.lo.apx = 1;
-            ++c->apx_blocks;
+            c->apx_blocks += hb.span ? hb.span : 1;
+        }
+        if (hb.span) {
+            ++c->span_items;
+            c->span_blocks += hb.span;
         }
         if (hb.mixed) ++c->mixed_blocks;
         if (hb.apx) {
             // phase 1 of the approximate path: panels, GEMM, SNP constants and the screens, all beside the previous block's tail.
             // The emission constants of phase 2 (table pointers, row base) are refreshed in submit_b.
             if (int rc = make_emit_args(c, hb, p, sl, do_lr ? guess : -1)) return rc;
-            if (int rc = c->hist[s].reserve((size_t)NBINS * 8)) return rc;
+            if (int rc = c->hist[s].reserve((size_t)NBINS * 8 * (size_t)(hb.span ? hb.span : 1))) return rc;
+            hb.lo.span = hb.span;
+            hb.lo.sseg = hb.sseg;
             if (int rc = launch_block_apx(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, 1, gs, nullptr, &hb.lo, c->hist[s].p, sl.pick[s],
-                                          PICK_STRIDE))
+                                          PICK_STRIDE * (size_t)(hb.span ? hb.span : 1)))
                 return rc;
             LDW_HIP(hipEventRecord(c->ev_gemm[s], gs));
             return LDW_OK;
@@ -2776,7 +2903,7 @@ int submit_generic(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
 }
 
 int submit_b(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
-    if (hb.fused) return LDW_OK;
+    if (hb.fused || hb.span_alone) return LDW_OK;
     if (hb.generic) return submit_generic(c, hb, p, sl);
     const int s = hb.slot;
     LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_up[s], 0));
@@ -2791,6 +2918,8 @@ int submit_b(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     if (!hb.apx) LDW_HIP(hipMemsetAsync(sl.pick[s], 0, sizeof(ldw::PickOut), c->stream));
     hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
     if (hb.apx) {
+        hb.lo.span = hb.span;
+        hb.lo.sseg = hb.sseg;
         if (int rc = launch_block_apx(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, 2, nullptr, c->hist[s].as<unsigned long long>(), &hb.lo))
             return rc;
     } else if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, c->engine == LDW_ENGINE_MFMA ? 2 : 3,
@@ -2800,12 +2929,119 @@ int submit_b(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     if (int rc = launch_pick(c, hb, p, sl, c->stream)) return rc;
     if (do_lr && hb.spec_B < 0)
         if (int rc = launch_gather(c, hb, hb.E, sl)) return rc;
-    LDW_HIP(hipMemcpyAsync(c->pin_pick[s], sl.pick[s], sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(c->pin_pick[s], sl.pick[s], hb.span ? PICK_STRIDE * (size_t)hb.span : sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
     LDW_HIP(hipEventRecord(c->ev_pick[s], c->stream));
     return LDW_OK;
 }
 
+// guesses for later blocks from the pick of a finished one: a little below this block's bucket
+void update_guess(ldw_ctx *c, bool diag, const ldw::PickOut *hp, bool missed) {
+    // buckets are 0.5 % wide: guess ~5 % below the threshold of the last block of the same kind.  Diagonal blocks
+    // lose their closest pairs to the short-range table and sit ~8 % (16 buckets) lower than off-diagonal ones:
+    // until a block of the other kind has been seen, its guess is derived from this one with a wider margin.
+    const int kind = diag ? 1 : 0, other = kind ^ 1;
+    // the margin follows what the thresholds of this kind have actually done: the spread of the last six of them plus two
+    // buckets, between 4 and 10 (every bucket below the true one costs ~3000 more candidates on the C4 shape; a miss costs a
+    // full non-speculative pass of the block, after which the history starts over)
+    int &hn = c->spec_hist_n[kind];
+    if (missed) hn = 0;
+    c->spec_hist[kind][hn % 6] = hp->B_true;
+    ++hn;
+    int margin = 10;
+    if (hn >= 3) {
+        int lo = hp->B_true, hi = hp->B_true;
+        for (int k = 0; k < (hn < 6 ? hn : 6); ++k) {
+            lo = c->spec_hist[kind][k] < lo ? c->spec_hist[kind][k] : lo;
+            hi = c->spec_hist[kind][k] > hi ? c->spec_hist[kind][k] : hi;
+        }
+        // few kept rows per block (many blocks: C5 keeps ~800 per block) make the threshold itself noisier
+        const bool small = hp->n * (1.0 - hp->prob) < 5000.0;
+        margin = hi - lo + (small ? 4 : 2);
+        const int mmin = small ? 6 : 4;
+        margin = margin < mmin ? mmin : (margin > 10 ? 10 : margin);
+    }
+    c->spec_B_next[kind] = hp->B_true - margin > 0 ? hp->B_true - margin : 0;
+    c->spec_seen[kind] = true;
+    if (!c->spec_seen[other] && !c->spec_probed[other]) {   // (a probed guess of the other kind is better than one derived from this kind)
+        const int g = diag ? hp->B_true - 10 : hp->B_true - 16 - 2 * 10;
+        c->spec_B_next[other] = g > 0 ? g : 0;
+    }
+}
+
+// The long-range selection of ONE reference block from its candidate list (m candidates; the pick record on the device knows the
+// ranks): threshold, kept rows in the reference's row order appended at *lr_count, then k_block_done (running count, block stats).
+struct SelIn {
+    int64_t m, nf, nt, blk_no, n_sr_blk;
+    uint64_t *ck, *cv;
+    ldw::PickOut *pick;                 // device
+    const int32_t *idx_f, *idx_t;       // device: the block's own index lists
+};
+int select_rows(ldw_ctx *c, const SelIn &S, bool do_lr, const SmallLayout &sl) {
+    const int64_t m = do_lr ? S.m : 0;
+    uint64_t *ck = S.ck, *cv = S.cv;
+    const uint64_t sel_space = (uint64_t)S.nf * (uint64_t)S.nt;
+    static const bool sel_fast_on = getenv("LDW_NO_FAST_SELECT") == nullptr;
+    const long long n_words = (long long)((2 * sel_space + 31) / 32) + 1, n_chunks = (long long)((2 * sel_space + SEL_CHUNK_BITS - 1) / SEL_CHUNK_BITS) + 1;
+    const long long n_super_ll = (n_chunks + SEL_SUPER - 1) / SEL_SUPER;
+    if (do_lr && m > 0 && sel_fast_on && c->select_mode == 0 && m <= SEL_MAX && n_super_ll <= SEL_MAX_SUPER) {
+        // the common case: radix select + bitmap ranks, four small launches, no sort (k_sel_thresh)
+        if (int rc = ensure_links_capacity(c, c->n_sr, c->n_lr + m)) return rc;
+        const int n_super = (int)n_super_ll;
+        if ((size_t)n_words * 4 > c->sel_bitmap.cap || (size_t)n_chunks * 4 > c->sel_chunks.cap || (size_t)n_super * 4 > c->sel_prefix.cap) {
+            // first use / a larger block: fresh zeroes
+            if (int rc = c->sel_bitmap.reserve((size_t)n_words * 4)) return rc;
+            if (int rc = c->sel_chunks.reserve((size_t)n_chunks * 4)) return rc;
+            if (int rc = c->sel_prefix.reserve((size_t)SEL_MAX_SUPER * 4)) return rc;
+            LDW_HIP(hipMemsetAsync(c->sel_bitmap.p, 0, c->sel_bitmap.cap, c->stream));
+            LDW_HIP(hipMemsetAsync(c->sel_chunks.p, 0, c->sel_chunks.cap, c->stream));
+            LDW_HIP(hipMemsetAsync(c->sel_prefix.p, 0, c->sel_prefix.cap, c->stream));
+        }
+        uint32_t *bm = c->sel_bitmap.as<uint32_t>(), *cc = c->sel_chunks.as<uint32_t>(), *sc = c->sel_prefix.as<uint32_t>();
+        const unsigned gridm = (unsigned)((m + 255) / 256);
+        hipLaunchKernelGGL(k_sel_thresh, dim3(1), dim3(1024), 0, c->stream, ck, S.pick);
+        hipLaunchKernelGGL(k_sel_mark, dim3(gridm), dim3(256), 0, c->stream, ck, cv, S.pick, sel_space, bm, cc, sc);
+        hipLaunchKernelGGL(k_sel_scatter, dim3(gridm), dim3(256), 0, c->stream, ck, cv, S.pick, sel_space, bm, cc, sc, n_super, S.idx_f, S.idx_t, (int)S.nf,
+                           sl.lr_count, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), c->lr_mi.as<double>());
+        hipLaunchKernelGGL(k_sel_clear, dim3(gridm), dim3(256), 0, c->stream, ck, cv, S.pick, sel_space, bm, cc, sc);
+        LDW_HIP(hipGetLastError());
+        c->n_lr += m;  // upper bound; the exact value is *lr_count
+    } else if (do_lr && m > 0) {
+        LDW_REQUIRE(m < 2147483647LL, LDW_ERR_SIZE, "too many quantile candidates (%lld)", (long long)m);
+        if (int rc = ensure_links_capacity(c, c->n_sr, c->n_lr + m)) return rc;
+        if (int rc = c->cand_key2.reserve((size_t)m * 8)) return rc;
+        if (int rc = c->cand_val2.reserve((size_t)m * 8)) return rc;
+        size_t tmp_bytes = 0;
+        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
+                                                   c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
+        if (int rc = c->scratch.reserve(tmp_bytes)) return rc;
+        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
+                                                   c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
+        hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, c->cand_key2.as<uint64_t>(), S.pick);
+        LDW_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_lr_mark, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), S.pick, ck, cv, (long long)m);
+        LDW_HIP(hipGetLastError());
+        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
+                                                   c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
+        hipLaunchKernelGGL(k_lr_append, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), S.pick, S.idx_f, S.idx_t, (int)S.nf,
+                           sl.lr_count, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), c->lr_mi.as<double>());
+        LDW_HIP(hipGetLastError());
+        c->n_lr += m;  // upper bound; the exact value is *lr_count
+    } else if (do_lr) {
+        hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, ck, S.pick);
+        LDW_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_block_done, dim3(1), dim3(64), 0, c->stream, S.pick, sl.lr_count, S.n_sr_blk,
+                       sl.stats_i + S.blk_no * 3, sl.stats_d + S.blk_no);
+    LDW_HIP(hipGetLastError());
+    return LDW_OK;
+}
+
+int finish_span(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl);
+
 int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
+    if (hb.span) return finish_span(c, hb, p, sl);
     const bool do_lr = !p->sr_only;
     const int s = hb.slot;
     // ---- the one host round trip of the block: the candidate count sizes the sorts ----
@@ -2837,38 +3073,7 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
         ++c->spec_misses;
         missed = true;
     }
-    if (do_lr && hp->n > 0) {  // guesses for later blocks: a little below this block's bucket
-        // buckets are 0.5 % wide: guess ~5 % below the threshold of the last block of the same kind.  Diagonal blocks
-        // lose their closest pairs to the short-range table and sit ~8 % (16 buckets) lower than off-diagonal ones:
-        // until a block of the other kind has been seen, its guess is derived from this one with a wider margin.
-        const int kind = hb.diag ? 1 : 0, other = kind ^ 1;
-        // the margin follows what the thresholds of this kind have actually done: the spread of the last six of them plus two
-        // buckets, between 4 and 10 (every bucket below the true one costs ~3000 more candidates on the C4 shape; a miss costs a
-        // full non-speculative pass of the block, after which the history starts over)
-        int &hn = c->spec_hist_n[kind];
-        if (missed) hn = 0;
-        c->spec_hist[kind][hn % 6] = hp->B_true;
-        ++hn;
-        int margin = 10;
-        if (hn >= 3) {
-            int lo = hp->B_true, hi = hp->B_true;
-            for (int k = 0; k < (hn < 6 ? hn : 6); ++k) {
-                lo = c->spec_hist[kind][k] < lo ? c->spec_hist[kind][k] : lo;
-                hi = c->spec_hist[kind][k] > hi ? c->spec_hist[kind][k] : hi;
-            }
-            // few kept rows per block (many blocks: C5 keeps ~800 per block) make the threshold itself noisier
-            const bool small = hp->n * (1.0 - hp->prob) < 5000.0;
-            margin = hi - lo + (small ? 4 : 2);
-            const int mmin = small ? 6 : 4;
-            margin = margin < mmin ? mmin : (margin > 10 ? 10 : margin);
-        }
-        c->spec_B_next[kind] = hp->B_true - margin > 0 ? hp->B_true - margin : 0;
-        c->spec_seen[kind] = true;
-        if (!c->spec_seen[other] && !c->spec_probed[other]) {   // (a probed guess of the other kind is better than one derived from this kind)
-            const int g = hb.diag ? hp->B_true - 10 : hp->B_true - 16 - 2 * 10;
-            c->spec_B_next[other] = g > 0 ? g : 0;
-        }
-    }
+    if (do_lr && hp->n > 0) update_guess(c, hb.diag, hp, missed || hb.force_plain);   // (force_plain: the redo of a span's segment whose guess was wrong)
     if ((int64_t)c->trace.size() <= hb.blk_no) c->trace.resize((size_t)hb.blk_no + 1);
     {
         ldw::BlockTrace &tr = c->trace[(size_t)hb.blk_no];
@@ -2876,74 +3081,110 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
         tr.guess = hb.guess;
         tr.B_true = do_lr ? hp->B_true : -1;
         tr.path = hb.fused ? 3 : (hb.apx ? 2 : (hb.mixed ? 1 : 0));
-        tr.missed = missed ? 1 : 0;
+        tr.missed = (missed || hb.force_plain) ? 1 : 0;
         tr.n_cand = do_lr ? (long long)hp->n_cand : 0;
     }
-    const int64_t m = do_lr ? (int64_t)hp->n_cand : 0;
     if (c->lrc_recorded) {   // exact number of long-range rows kept by all EARLIER blocks
         LDW_HIP(hipEventSynchronize(c->ev_lrc));
         memcpy(&c->n_lr, c->pin_lrc, 8);
     }
-    const int64_t nf = hb.nf;
-    const char *d = c->dstage[s].as<char>();
-    const int32_t *idx_f = reinterpret_cast<const int32_t *>(d + hb.o_idx_f), *idx_t = reinterpret_cast<const int32_t *>(d + hb.o_idx_t);
-    uint64_t *ck = c->cand_key[s].as<uint64_t>(), *cv = c->cand_val[s].as<uint64_t>();
-    const uint64_t sel_space = (uint64_t)hb.nf * (uint64_t)hb.nt;
-    static const bool sel_fast_on = getenv("LDW_NO_FAST_SELECT") == nullptr;
-    const long long n_words = (long long)((2 * sel_space + 31) / 32) + 1, n_chunks = (long long)((2 * sel_space + SEL_CHUNK_BITS - 1) / SEL_CHUNK_BITS) + 1;
-    const long long n_super_ll = (n_chunks + SEL_SUPER - 1) / SEL_SUPER;
-    if (do_lr && m > 0 && sel_fast_on && c->select_mode == 0 && m <= SEL_MAX && n_super_ll <= SEL_MAX_SUPER) {
-        // the common case: radix select + bitmap ranks, four small launches, no sort (k_sel_thresh)
-        if (int rc = ensure_links_capacity(c, c->n_sr, c->n_lr + m)) return rc;
-        const int n_super = (int)n_super_ll;
-        if ((size_t)n_words * 4 > c->sel_bitmap.cap || (size_t)n_chunks * 4 > c->sel_chunks.cap || (size_t)n_super * 4 > c->sel_prefix.cap) {
-            // first use / a larger block: fresh zeroes
-            if (int rc = c->sel_bitmap.reserve((size_t)n_words * 4)) return rc;
-            if (int rc = c->sel_chunks.reserve((size_t)n_chunks * 4)) return rc;
-            if (int rc = c->sel_prefix.reserve((size_t)SEL_MAX_SUPER * 4)) return rc;
-            LDW_HIP(hipMemsetAsync(c->sel_bitmap.p, 0, c->sel_bitmap.cap, c->stream));
-            LDW_HIP(hipMemsetAsync(c->sel_chunks.p, 0, c->sel_chunks.cap, c->stream));
-            LDW_HIP(hipMemsetAsync(c->sel_prefix.p, 0, c->sel_prefix.cap, c->stream));
-        }
-        uint32_t *bm = c->sel_bitmap.as<uint32_t>(), *cc = c->sel_chunks.as<uint32_t>(), *sc = c->sel_prefix.as<uint32_t>();
-        const unsigned gridm = (unsigned)((m + 255) / 256);
-        hipLaunchKernelGGL(k_sel_thresh, dim3(1), dim3(1024), 0, c->stream, ck, sl.pick[s]);
-        hipLaunchKernelGGL(k_sel_mark, dim3(gridm), dim3(256), 0, c->stream, ck, cv, sl.pick[s], sel_space, bm, cc, sc);
-        hipLaunchKernelGGL(k_sel_scatter, dim3(gridm), dim3(256), 0, c->stream, ck, cv, sl.pick[s], sel_space, bm, cc, sc, n_super, idx_f, idx_t, (int)nf,
-                           sl.lr_count, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), c->lr_mi.as<double>());
-        hipLaunchKernelGGL(k_sel_clear, dim3(gridm), dim3(256), 0, c->stream, ck, cv, sl.pick[s], sel_space, bm, cc, sc);
-        LDW_HIP(hipGetLastError());
-        c->n_lr += m;  // upper bound; the exact value is *lr_count
-    } else if (do_lr && m > 0) {
-        LDW_REQUIRE(m < 2147483647LL, LDW_ERR_SIZE, "too many quantile candidates (%lld)", (long long)m);
-        if (int rc = ensure_links_capacity(c, c->n_sr, c->n_lr + m)) return rc;
-        if (int rc = c->cand_key2.reserve((size_t)m * 8)) return rc;
-        if (int rc = c->cand_val2.reserve((size_t)m * 8)) return rc;
-        size_t tmp_bytes = 0;
-        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
-                                                   c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
-        if (int rc = c->scratch.reserve(tmp_bytes)) return rc;
-        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
-                                                   c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
-        hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, c->cand_key2.as<uint64_t>(), sl.pick[s]);
-        LDW_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_lr_mark, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), sl.pick[s], ck, cv, (long long)m);
-        LDW_HIP(hipGetLastError());
-        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
-                                                   c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
-        hipLaunchKernelGGL(k_lr_append, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                           c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), sl.pick[s], idx_f, idx_t, (int)nf,
-                           sl.lr_count, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), c->lr_mi.as<double>());
-        LDW_HIP(hipGetLastError());
-        c->n_lr += m;  // upper bound; the exact value is *lr_count
-    } else if (do_lr) {
-        hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, ck, sl.pick[s]);
-        LDW_HIP(hipGetLastError());
+    const char *d = c->dstage[hb.pin_slot >= 0 ? hb.pin_slot : s].as<char>();
+    SelIn S;
+    S.m = do_lr ? (int64_t)hp->n_cand : 0;
+    S.nf = hb.nf;
+    S.nt = hb.nt;
+    S.blk_no = hb.blk_no;
+    S.n_sr_blk = hb.n_sr_blk;
+    S.ck = hb.E.ckey ? hb.E.ckey : c->cand_key[s].as<uint64_t>();
+    S.cv = hb.E.cval ? hb.E.cval : c->cand_val[s].as<uint64_t>();
+    S.pick = sl.pick[s];
+    S.idx_f = reinterpret_cast<const int32_t *>(d + hb.o_idx_f);
+    S.idx_t = reinterpret_cast<const int32_t *>(d + hb.o_idx_t);
+    if (int rc = select_rows(c, S, do_lr, sl)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->pin_lrc, sl.lr_count, 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipEventRecord(c->ev_lrc, c->stream));
+    c->lrc_recorded = true;
+    LDW_HIP(hipEventRecord(c->ev_pool[(size_t)hb.blk_no * EVB + 3], c->stream));
+    LDW_HIP(hipEventRecord(c->ev_done[s], c->stream));
+    c->done_recorded[s] = true;
+    return LDW_OK;
+}
+
+// One reference block of a span through the ordinary per-block chain (prep -> submit_a -> submit_b -> finish_block), synchronously, on the
+// device buffers of the span's slot but staged through the extra staging buffer: the span's own lists are still read by the selection of
+// its other segments.  force_plain: non-speculatively (the segment's guess was wrong).
+int run_block_alone(ldw_ctx *c, const HostBlock &span, int k, const ldw_mi_params *p, const SmallLayout &sl, bool force_plain) {
+    HostBlock hb;
+    const int32_t *ti = span.span_to.data() + span.seg_start[k];
+    LDW_HIP(hipStreamSynchronize(c->stream));                        // the extra staging buffer: free (an earlier segment may have used it)
+    if (c->gemm_stream) LDW_HIP(hipStreamSynchronize(c->gemm_stream));
+    if (int rc = prep_block(c, span.span_from.data(), span.nf, ti, span.seg_nt[k], p, span.slot, span.blk_no + k, hb, nullptr, LDW_NSLOT)) return rc;
+    hb.force_plain = force_plain;
+    if (int rc = submit_a(c, hb, p, sl)) return rc;
+    if (int rc = submit_b(c, hb, p, sl)) return rc;
+    if (int rc = finish_block(c, hb, p, sl)) return rc;
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
+
+// The second half of a span: ONE host round trip for the pick records of all its reference blocks, then per block — in make_blocks
+// order, which is the order the reference appends in (R/computePairwiseMI.R:103-116, :362) — the guess update, the selection of its
+// candidates into the long-range table and its stats.  A block whose guess turned out too high (or all of them, when a pair list
+// overflowed) is redone on its own, non-speculatively, in its place in that order.
+int finish_span(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
+    const int s = hb.slot;
+    if (hb.span_alone) {
+        for (int k = 0; k < hb.span; ++k)
+            if (int rc = run_block_alone(c, hb, k, p, sl, false)) return rc;
+        LDW_HIP(hipEventRecord(c->ev_done[s], c->stream));
+        c->done_recorded[s] = true;
+        return LDW_OK;
     }
-    hipLaunchKernelGGL(k_block_done, dim3(1), dim3(64), 0, c->stream, sl.pick[s], sl.lr_count, hb.n_sr_blk,
-                       sl.stats_i + hb.blk_no * 3, sl.stats_d + hb.blk_no);
-    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipEventSynchronize(c->ev_pick[s]));
+    ldw::PickOut picks[LDW_SPAN_MAX];
+    for (int k = 0; k < hb.span; ++k) memcpy(&picks[k], static_cast<const char *>(c->pin_pick[s]) + (size_t)k * PICK_STRIDE, sizeof(ldw::PickOut));
+    if (c->lrc_recorded) {   // exact number of long-range rows kept by all EARLIER blocks (within the span: upper bounds add up)
+        LDW_HIP(hipEventSynchronize(c->ev_lrc));
+        memcpy(&c->n_lr, c->pin_lrc, 8);
+    }
+    const char *d = c->dstage[s].as<char>();
+    if ((int64_t)c->trace.size() < hb.blk_no + hb.span) c->trace.resize((size_t)(hb.blk_no + hb.span));
+    for (int k = 0; k < hb.span; ++k) {
+        const ldw::PickOut *hp = &picks[k];
+        const bool missed = hp->n > 0 && !hp->spec_ok;
+        if (missed) {
+            ++c->spec_misses;
+            ++c->span_fallbacks;
+            // (the redo reads the exact row count of everything before it: the selections of the span's earlier segments are queued, not counted yet)
+            LDW_HIP(hipMemcpyAsync(c->pin_lrc, sl.lr_count, 8, hipMemcpyDeviceToHost, c->stream));
+            LDW_HIP(hipEventRecord(c->ev_lrc, c->stream));
+            c->lrc_recorded = true;
+            if (int rc = run_block_alone(c, hb, k, p, sl, true)) return rc;
+            continue;
+        }
+        if (hp->n > 0) update_guess(c, false, hp, false);
+        {
+            ldw::BlockTrace &tr = c->trace[(size_t)hb.blk_no + k];
+            tr = ldw::BlockTrace();
+            tr.guess = hb.guess;
+            tr.B_true = hp->B_true;
+            tr.path = 4;   // span
+            tr.n_cand = (long long)hp->n_cand;
+        }
+        LDW_REQUIRE((size_t)hp->n_cand <= hb.cand_cap, LDW_ERR_STATE, "span segment %d lists %llu candidates, capacity %zu", k, (unsigned long long)hp->n_cand, hb.cand_cap);
+        SelIn S;
+        S.m = (int64_t)hp->n_cand;
+        S.nf = hb.nf;
+        S.nt = hb.seg_nt[k];
+        S.blk_no = hb.blk_no + k;
+        S.n_sr_blk = 0;
+        S.ck = hb.sseg[k].ckey;
+        S.cv = hb.sseg[k].cval;
+        S.pick = reinterpret_cast<ldw::PickOut *>(reinterpret_cast<char *>(sl.pick[s]) + (size_t)k * PICK_STRIDE);
+        S.idx_f = reinterpret_cast<const int32_t *>(d + hb.o_idx_f);
+        S.idx_t = reinterpret_cast<const int32_t *>(d + hb.o_idx_t) + hb.seg_start[k];
+        if (int rc = select_rows(c, S, true, sl)) return rc;
+    }
     LDW_HIP(hipMemcpyAsync(c->pin_lrc, sl.lr_count, 8, hipMemcpyDeviceToHost, c->stream));
     LDW_HIP(hipEventRecord(c->ev_lrc, c->stream));
     c->lrc_recorded = true;
@@ -3118,7 +3359,7 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
         c->blk_capacity = 0;
     }
     if (int rc = ensure_rows(c)) return rc;  // uses ctx->small for staging; link bookkeeping takes it over below
-    const size_t need = 64 + LDW_NSLOT * PICK_STRIDE + (size_t)nblocks_capacity * 32 + 64;
+    const size_t need = 64 + (size_t)LDW_NSLOT * LDW_SPAN_MAX * PICK_STRIDE + (size_t)nblocks_capacity * 32 + 64;
     if (int rc = c->small.reserve(need)) return rc;
     LDW_HIP(hipMemsetAsync(c->small.p, 0, need, c->stream));
     if (!c->copy_stream) {
@@ -3129,7 +3370,7 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
         }
         for (int k = 0; k < LDW_NSLOT; ++k) {
             LDW_HIP(hipEventCreateWithFlags(&c->ev_pick[k], hipEventDisableTiming));
-            LDW_HIP(hipHostMalloc(&c->pin_pick[k], sizeof(ldw::PickOut) + 64, hipHostMallocDefault));
+            LDW_HIP(hipHostMalloc(&c->pin_pick[k], (size_t)LDW_SPAN_MAX * PICK_STRIDE + 64, hipHostMallocDefault));
         }
         LDW_HIP(hipEventCreateWithFlags(&c->ev_lrc, hipEventDisableTiming));
         LDW_HIP(hipHostMalloc(&c->pin_lrc, 64, hipHostMallocDefault));
@@ -3163,6 +3404,7 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
         c->ev_pool.push_back(e);
     }
     for (int k = 0; k < LDW_NSLOT; ++k) c->done_recorded[k] = false;
+    c->ev_valid.assign((size_t)nblocks_capacity, 1);
     c->lrc_recorded = false;
     c->n_sr = 0;
     c->n_lr = 0;
@@ -3236,6 +3478,7 @@ int ldw_links_end(ldw_ctx *c) {
         c->stats[b].disc_thresh = sd[b];
         float t01 = 0, t12 = 0, t23 = 0;
         hipEvent_t *ev = &c->ev_pool[(size_t)b * EVB];
+        if (b < (int64_t)c->ev_valid.size() && !c->ev_valid[(size_t)b]) continue;   // a later segment of a span: its time is in the span's first block
         LDW_HIP(hipEventElapsedTime(&t01, ev[0], ev[1]));
         LDW_HIP(hipEventElapsedTime(&t12, ev[c->engine == LDW_ENGINE_MFMA ? 4 : 1], ev[2]));
         if (c->engine == LDW_ENGINE_MFMA && !c->fused) {   // the screens of the approximate path run behind the GEMM on its stream
@@ -3260,6 +3503,32 @@ int ldw_links_end(ldw_ctx *c) {
     c->blk_capacity = 0;
     return LDW_OK;
 }
+
+// ---- spans (r04): which blocks of the list may share a launch sequence ----
+// A block can be part of a span when its to side lies strictly AFTER its from side (make_blocks order: i < j), it is square, far enough
+// from its from side that no pair is short-range (POS ascends over the alignment: the test of build_cols on the four end positions), and
+// neither side holds a SNP the fused table test cannot place (no indicator row, or unflagged slots: h_span_bad).
+static bool span_candidate(const ldw_ctx *c, const int32_t *b, const ldw_mi_params *p) {
+    const int64_t fs = b[0], fe = b[1], ts = b[2], te = b[3];
+    if (!(fs >= 1 && fe >= fs && ts > fe && te >= ts && te <= c->L)) return false;
+    const int64_t nf = fe - fs + 1, nt = te - ts + 1;
+    if (nf != nt || nf < 2048) return false;
+    if ((int64_t)c->h_span_bad.size() != c->L + 1) return false;
+    if (c->h_span_bad[(size_t)fe] - c->h_span_bad[(size_t)fs - 1] != 0 || c->h_span_bad[(size_t)te] - c->h_span_bad[(size_t)ts - 1] != 0) return false;
+    const double pf_min = c->h_POS[(size_t)fs - 1], pf_max = c->h_POS[(size_t)fe - 1], pt_min = c->h_POS[(size_t)ts - 1], pt_max = c->h_POS[(size_t)te - 1];
+    return pt_min - pf_max > p->sr_dist && pf_min + c->g - pt_max > p->sr_dist && 2 * p->sr_dist < c->g;
+}
+// what the whole pass must offer (checked once, after the cold-start probes: a positive guess for off-diagonal blocks exists)
+static bool spans_possible(const ldw_ctx *c, const ldw_mi_params *p) {
+    static const bool env_off = getenv("LDW_NO_SPAN") != nullptr;
+    return c->span_on && !env_off && c->span_max >= 2 && c->prune && c->engine == LDW_ENGINE_MFMA && c->apx_ok && !c->fused && c->path_mode != 1 && c->screen == 1 &&
+           !p->sr_only && speculation_pays(c, p) && c->pos_sorted && c->spec_B_next[0] > 0 && c->tab11_on &&
+           (p->quirk_mode != LDW_QUIRK_REFERENCE || c->r_min >= 2.0);
+}
+struct WorkItem {
+    int64_t b0;
+    int nseg;   // 1: an ordinary block
+};
 
 int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const ldw_mi_params *p, int reset) {
     if (int rc = check_gpu(c)) return rc;
@@ -3294,62 +3563,91 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         }
         if (int rc = ensure_links_capacity(c, total_sr, 0)) return rc;
     }
-    // Software pipeline, three blocks deep on the host: block b's epilogue chain is submitted (main stream), then at once the
-    // block-wide pass of block b+1 (GEMM stream; prepared one iteration ago), THEN the host prepares block b+2 — about half
-    // a millisecond of list building for a 10k x 10k block — while the GPU works, and only then waits for block b's pick.
-    // (Preparing b+1 between submit_b(b) and submit_a(b+1), as the first version did, delivered the GEMM of b+1 to the GPU when
-    // the chain of b was already over: the two streams never ran side by side.)
-    // r03: the lists of a block are built by a HELPER THREAD that runs ahead of the submitting thread (prep_block is pure host work into the
+    // Software pipeline, three ITEMS deep on the host (an item = one block, or a span of consecutive long-range-only blocks of one block
+    // row: r04): item i's epilogue chain is submitted (main stream), then at once the block-wide pass of item i+1 (GEMM stream; prepared
+    // earlier), and only then the host waits for item i's pick(s).
+    // r03: the lists of an item are built by a HELPER THREAD that runs ahead of the submitting thread (prep_block is pure host work into the
     // slot's pinned staging buffer: 0.45 ms per 10k x 10k block — once the GPU side of a block had come down to 0.5 ms it was the loop's
-    // critical path: LDW_HOST_TIMING showed submit 0.05 + prep 0.45 + wait 0.35 ms per block = the whole 47 ms of a pass, and the kernel timeline
-    // the GEMM stream idle for a third of it).  Hand-over through three counters under one mutex: block k may be prepared once block k - RING is
-    // finished (its ring entry is free) and block k - LDW_NSLOT has been submitted (the slot's staging buffer then belongs to an upload the
-    // helper waits for: ev_up); the GEMM stream runs up to LDW_NSLOT - 1 = 2 blocks ahead of the block the main stream evaluates.
+    // critical path).  Hand-over through counters under one mutex: item k may be prepared once item k - RING is finished (its ring entry
+    // is free), item k - LDW_NSLOT has been submitted (the slot's staging buffer then belongs to an upload the helper waits for: ev_up) and
+    // the plan covers it (n_planned: the items behind the leading blocks are only known after the cold-start probes — whether spans may
+    // form depends on a guess existing); the GEMM stream runs up to LDW_NSLOT - 1 = 2 items ahead of the item the main stream evaluates.
     constexpr int RING = 8;
     HostBlock hb[RING];
     static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
     double th[5] = {0, 0, 0, 0, 0};
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    // the plan: items in block order.  Before the probes only the leading run of blocks that can never be part of a span is planned.
+    std::vector<WorkItem> items;
+    std::vector<uint8_t> cand((size_t)nblocks, 0);
+    for (int64_t b = 0; b < nblocks; ++b) cand[(size_t)b] = span_candidate(c, blocks + b * 4, p) ? 1 : 0;
+    int64_t lead = 0;
+    while (lead < nblocks && !cand[(size_t)lead]) ++lead;
+    for (int64_t b = 0; b < lead; ++b) items.push_back(WorkItem{b, 1});
     struct Shared {
         std::mutex m;
         std::condition_variable cv;
-        int64_t n_prepped = 0, n_sub = 0, n_done = 0;
+        int64_t n_prepped = 0, n_sub = 0, n_done = 0, n_planned = 0;
+        bool plan_final = false;
         int rc = LDW_OK;
         bool stop = false, probing = true;   // probing: the cold-start probes (calling thread) still use the last slot's staging buffer
         std::string err;
     } sh;
+    sh.n_planned = (int64_t)items.size();
+    sh.plan_final = lead == nblocks;
     std::vector<int32_t> wfi, wti;   // the helper's own index lists
     auto worker = [&]() {
         (void)hipSetDevice(c->device);
-        for (int64_t k = 0; k < nblocks; ++k) {
+        for (int64_t k = 0;; ++k) {
+            WorkItem it{0, 0};
             {
                 std::unique_lock<std::mutex> lk(sh.m);
-                sh.cv.wait(lk, [&] { return sh.stop || (k < sh.n_done + RING && k < sh.n_sub + LDW_NSLOT - (sh.probing ? 1 : 0)); });
-                if (sh.stop) return;
+                sh.cv.wait(lk, [&] {
+                    if (sh.stop) return true;
+                    if (k >= sh.n_planned) return sh.plan_final;   // (plan complete and nothing left: leave)
+                    return k < sh.n_done + RING && k < sh.n_sub + LDW_NSLOT - (sh.probing ? 1 : 0);
+                });
+                if (sh.stop || k >= sh.n_planned) return;
+                it = items[(size_t)k];
             }
             int rc = LDW_OK;
-            const int32_t fs = blocks[k * 4 + 0], fe = blocks[k * 4 + 1], ts = blocks[k * 4 + 2], te = blocks[k * 4 + 3];
             try {   // (prep_block allocates a dozen std::vectors: an exception on this thread must come back as an error code, not std::terminate)
-                if (!(fs >= 1 && fe >= fs && fe <= c->L && ts >= 1 && te >= ts && te <= c->L)) {
-                    set_error("block %lld = (%d,%d,%d,%d) outside 1..%lld", (long long)k, fs, fe, ts, te, (long long)c->L);
+                const int32_t fs = blocks[it.b0 * 4 + 0], fe = blocks[it.b0 * 4 + 1];
+                bool ok = fs >= 1 && fe >= fs && fe <= c->L;
+                SpanPlan spn;
+                wti.clear();
+                for (int q = 0; q < it.nseg && ok; ++q) {
+                    const int32_t ts = blocks[(it.b0 + q) * 4 + 2], te = blocks[(it.b0 + q) * 4 + 3];
+                    ok = ts >= 1 && te >= ts && te <= c->L;
+                    if (!ok) break;
+                    spn.start[q] = (int32_t)wti.size();
+                    spn.nt[q] = te - ts + 1;
+                    for (int32_t x = ts; x <= te; ++x) wti.push_back(x - 1);
+                }
+                spn.nseg = it.nseg;
+                if (!ok) {
+                    set_error("block %lld = (%d,%d,%d,%d) outside 1..%lld", (long long)it.b0, fs, fe, blocks[it.b0 * 4 + 2], blocks[it.b0 * 4 + 3], (long long)c->L);
                     rc = LDW_ERR_ARG;
                 } else {
                     wfi.resize((size_t)(fe - fs + 1));
-                    wti.resize((size_t)(te - ts + 1));
                     for (int32_t q = fs; q <= fe; ++q) wfi[q - fs] = q - 1;
-                    for (int32_t q = ts; q <= te; ++q) wti[q - ts] = q - 1;
                     const int slot = (int)(k % LDW_NSLOT);
                     if (c->up_recorded[slot] && hipEventSynchronize(c->ev_up[slot]) != hipSuccess) {   // the staging buffer of this slot has been uploaded
                         set_error("prep: hipEventSynchronize failed");
                         rc = LDW_ERR_HIP;
                     }
-                    if (rc == LDW_OK) rc = prep_block(c, wfi.data(), (int64_t)wfi.size(), wti.data(), (int64_t)wti.size(), p, slot, k, hb[k % RING]);
+                    HostBlock &h = hb[k % RING];
+                    if (rc == LDW_OK) rc = prep_block(c, wfi.data(), (int64_t)wfi.size(), wti.data(), (int64_t)wti.size(), p, slot, it.b0, h, it.nseg > 1 ? &spn : nullptr);
+                    if (rc == LDW_OK && it.nseg > 1) {
+                        h.span_from = wfi;
+                        h.span_to = wti;
+                    }
                 }
             } catch (const std::exception &e) {
-                set_error("preparing block %lld: %s", (long long)k, e.what());
+                set_error("preparing block %lld: %s", (long long)it.b0, e.what());
                 rc = LDW_ERR_HIP;
             } catch (...) {
-                set_error("preparing block %lld: unknown exception", (long long)k);
+                set_error("preparing block %lld: unknown exception", (long long)it.b0);
                 rc = LDW_ERR_HIP;
             }
             std::lock_guard<std::mutex> lk(sh.m);
@@ -3394,12 +3692,37 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
             if (int rc = probe_kind_guess(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, sl, kind)) return rc;
         }
     }
-    {
+    {   // the rest of the plan: consecutive candidates of one block row, to sides ascending, form a span (at most span_max blocks,
+        // nf x nt below the 32-bit index limit of the unit lists, the int32 block below ~6 GB)
+        const bool spans = spans_possible(c, p);
+        std::vector<WorkItem> rest;
+        for (int64_t b = lead; b < nblocks;) {
+            int n = 1;
+            if (spans && cand[(size_t)b]) {
+                const int64_t nf = blocks[b * 4 + 1] - blocks[b * 4 + 0] + 1;
+                int64_t nt_tot = blocks[b * 4 + 3] - blocks[b * 4 + 2] + 1;
+                static const int env_max = [] { const char *e = getenv("LDW_SPAN_MAX"); return e ? atoi(e) : 0; }();   // (A/B measurements)
+                const int nmax = std::min<int>(env_max >= 1 ? env_max : c->span_max, LDW_SPAN_MAX);
+                while (n < nmax && b + n < nblocks && cand[(size_t)(b + n)] && blocks[(b + n) * 4 + 0] == blocks[b * 4 + 0] && blocks[(b + n) * 4 + 1] == blocks[b * 4 + 1] &&
+                       blocks[(b + n) * 4 + 2] > blocks[(b + n - 1) * 4 + 3]) {
+                    const int64_t nt_k = blocks[(b + n) * 4 + 3] - blocks[(b + n) * 4 + 2] + 1;
+                    if (nf * (nt_tot + nt_k) >= 1500000000LL || (nt_tot + nt_k) > 900000) break;
+                    nt_tot += nt_k;
+                    ++n;
+                }
+            }
+            rest.push_back(WorkItem{b, n});
+            b += n;
+        }
         std::lock_guard<std::mutex> lk(sh.m);
+        items.insert(items.end(), rest.begin(), rest.end());
+        sh.n_planned = (int64_t)items.size();
+        sh.plan_final = true;
         sh.probing = false;
     }
     sh.cv.notify_all();
-    // blocks until block k is prepared (true) — or, with wait = false, says whether it is
+    const int64_t nitems = (int64_t)items.size();
+    // blocks until item k is prepared (true) — or, with wait = false, says whether it is
     auto prepped = [&](int64_t k, bool wait, int &rc) -> bool {
         std::unique_lock<std::mutex> lk(sh.m);
         if (wait) sh.cv.wait(lk, [&] { return sh.rc != LDW_OK || sh.n_prepped > k; });
@@ -3407,7 +3730,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         if (rc != LDW_OK) set_error("%s", sh.err.c_str());
         return sh.n_prepped > k;
     };
-    int64_t n_sub = 0;   // blocks [0, n_sub) have been submitted to the GEMM stream
+    int64_t n_sub = 0;   // items [0, n_sub) have been submitted to the GEMM stream
     auto submit_next = [&]() -> int {
         if (int rc = submit_a(c, hb[n_sub % RING], p, sl)) return rc;
         ++n_sub;
@@ -3425,14 +3748,14 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         if (rc) return rc;
         if ((rc = submit_next())) return rc;
     }
-    for (int64_t b = 0; b < nblocks; ++b) {
+    for (int64_t b = 0; b < nitems; ++b) {
         HostBlock &cur = hb[b % RING];
         double t0 = now();
-        if (int rc = submit_b(c, cur, p, sl)) return rc;                 // unfused: epilogue + pick of block b (main stream)
+        if (int rc = submit_b(c, cur, p, sl)) return rc;                 // unfused: epilogue + pick of item b (main stream)
         th[0] += now() - t0;
         t0 = now();
-        // blocks b+1 .. b+ahead (GEMM stream) run beside them: b+1 is waited for, the ones after it are taken if they are ready
-        while (n_sub < nblocks && n_sub <= b + ahead) {
+        // items b+1 .. b+ahead (GEMM stream) run beside them: b+1 is waited for, the ones after it are taken if they are ready
+        while (n_sub < nitems && n_sub <= b + ahead) {
             int rc = LDW_OK;
             const double tw = now();
             const bool ready = prepped(n_sub, n_sub == b + 1, rc);
@@ -3445,25 +3768,47 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         t0 = now();
         // (tried: the second phase of block b+1 queued HERE, before the host waits for block b's pick, so that the main stream has work during the
         // round trip — block b's selection then runs behind it, its slot is released later, and the pass got slower: 43.0 against 40.2 ms)
-        if (int rc = finish_block(c, cur, p, sl)) return rc;             // round trip + selection of block b
+        if (int rc = finish_block(c, cur, p, sl)) return rc;             // round trip + selection of item b
         th[3] += now() - t0;
         {
             std::lock_guard<std::mutex> lk(sh.m);
             sh.n_done = b + 1;
         }
         sh.cv.notify_all();
-        if (n_sub <= b + 1 && b + 1 < nblocks) {                          // overlap off / no guess yet: one block after the other
+        if (n_sub <= b + 1 && b + 1 < nitems) {                          // overlap off / no guess yet: one item after the other
             int rc = LDW_OK;
             prepped(b + 1, true, rc);
             if (rc) return rc;
             if ((rc = submit_next())) return rc;
         }
-        ++c->blk_cursor;
+        c->blk_cursor += items[(size_t)b].nseg;
     }
     if (host_timing)
-        fprintf(stderr, "[ldw host us/block] submit_b %.1f  wait for the helper's prep %.1f  submit_a (incl. that wait) %.1f  finish (incl. wait) %.1f  blocks %lld\n", th[0] / nblocks, th[1] / nblocks,
-                th[2] / nblocks, th[3] / nblocks, (long long)nblocks);
+        fprintf(stderr, "[ldw host us/item] submit_b %.1f  wait for the helper's prep %.1f  submit_a (incl. that wait) %.1f  finish (incl. wait) %.1f  items %lld (blocks %lld)\n", th[0] / nitems, th[1] / nitems,
+                th[2] / nitems, th[3] / nitems, (long long)nitems, (long long)nblocks);
     return ldw_links_end(c);
+}
+
+int ldw_set_span(ldw_ctx *c, int on, int max_blocks) {
+    LDW_REQUIRE(c && (max_blocks == 0 || (max_blocks >= 2 && max_blocks <= LDW_SPAN_MAX)), LDW_ERR_ARG, "ldw_set_span: max_blocks must be 0 or 2..%d", LDW_SPAN_MAX);
+    c->span_on = on != 0;
+    if (max_blocks) c->span_max = max_blocks;
+    return LDW_OK;
+}
+
+int ldw_span_report(ldw_ctx *c, int64_t out[4]) {
+    LDW_REQUIRE(c && out, LDW_ERR_ARG, "ldw_span_report: null argument");
+    out[0] = c->span_items;
+    out[1] = c->span_blocks;
+    out[2] = c->span_fallbacks;
+    out[3] = c->span_on ? 1 : 0;
+    return LDW_OK;
+}
+
+int ldw_set_pair_cap(uint32_t cap) {
+    LDW_REQUIRE(cap == 0 || (cap >= 16 && cap <= (1u << 22)), LDW_ERR_ARG, "ldw_set_pair_cap: 0 or 16..2^22");
+    g_pair_cap_override.store(cap);
+    return LDW_OK;
 }
 
 int ldw_set_overlap(ldw_ctx *c, int on) {

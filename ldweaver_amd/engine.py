@@ -85,6 +85,20 @@ class Engine:
         L.check(L.lib().ldw_prune_report(self._ctx, L.ptr(v)))
         return dict(ordered_blocks=int(v[0]), tiles_pruned=int(v[1]), tiles_total=int(v[2]), on=bool(v[3]))
 
+    def set_span(self, on: bool, max_blocks: int = 0):
+        """Spans (default on): consecutive long-range-only block pairs of one block row run as one launch sequence; results never depend on it."""
+        L.check(L.lib().ldw_set_span(self._ctx, int(bool(on)), int(max_blocks)))
+
+    def span_report(self):
+        v = np.zeros(4, dtype=np.int64)
+        L.check(L.lib().ldw_span_report(self._ctx, L.ptr(v)))
+        return dict(spans=int(v[0]), blocks=int(v[1]), redone=int(v[2]), on=bool(v[3]))
+
+    @staticmethod
+    def set_pair_cap(cap: int):
+        """Tests only: a fixed capacity of the approximate path's pair lists (0: automatic), process-wide."""
+        L.check(L.lib().ldw_set_pair_cap(int(cap)))
+
     def snp_bounds(self):
         """(L, 2, 2) array [snp, RXY reading (intended, reference), partner kind (2, 3 states)]: the largest MI the SNP can reach."""
         out = np.zeros(4 * self.L)

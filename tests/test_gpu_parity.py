@@ -1703,3 +1703,83 @@ def test_pruning_under_the_reference_rxy_with_monomorphic_snps(engine):
     sup = engine.snp_bounds()
     fin = sup[:, 0, 0] < 1e299
     assert fin.sum() > 500 and np.all(sup[fin, 1, :] >= sup[fin, 0, :] - 1e-15) and np.any(sup[fin, 1, 0] > sup[fin, 0, 0] + 1e-6)
+
+
+def test_spans_equal_block_by_block(engine):
+    """r04 spans: consecutive long-range-only block pairs of one block row run as ONE launch sequence over their concatenated to side
+    (VERDICT r03 item 1), every reference block keeping its own histogram, threshold, candidate list, row order and place in the append
+    order (R/computePairwiseMI.R:103-116, :352-362).  40k SNPs x 2k sequences, 8 x 8 blocks of 5000 (36 block pairs; rows of up to five
+    long-range-only pairs), cold and warm passes, both readings of RXY: link tables, per-block thresholds and row counts with spans ==
+    without == the plain path (5-limb GEMM, fp64 MI of every pair) bit for bit; then the overflow fallback: pair lists forced to 64
+    entries make every segment of every span (and every lone block) fall back like a wrong guess — redone on its own, non-speculatively,
+    in its place in the order — tables still identical."""
+    Ls, N, B = 40_000, 2_000, 5_000
+    syn = synth_alignment(Ls, N, seed=1988, device="cuda", as_numpy=False)
+    engine.set_engine(L.ENGINE_MFMA)
+    engine.set_alignment(syn["states"])
+    cnt = engine.state_counts()
+    uqe = (cnt > 0).T.astype(np.float64)
+    r = uqe.sum(axis=1)
+    hdw = engine.hamming_weights(int(Ls * 0.1))
+    engine.set_weights(hdw)
+    POS, g = syn["POS"], float(syn["g"])
+    engine.set_snp_meta(r, uqe, POS, syn["paint"], g)
+    approx = MIH.lr_links_approx(POS, g, 20000.0)
+    blocks = MIH.make_blocks(Ls, B)
+    assert len(blocks) == 36
+
+    def run(quirk, cold):
+        if cold:
+            engine.reset_speculation()
+        engine.mi_all_pairs(blocks, 20000.0, 1e6, approx, quirk=quirk)
+        return engine.links(0), engine.links(1), engine.block_stats()
+
+    def same(x, y, what):
+        for which in (0, 1):
+            for a, b in zip(x[which], y[which]):
+                assert np.array_equal(a, b), (what, which)
+        for k in ("n_lr_total", "n_lr_kept", "n_sr", "disc_thresh"):
+            assert np.array_equal(x[2][k], y[2][k]), (what, k)
+
+    try:
+        for quirk in (L.QUIRK_REFERENCE, L.QUIRK_INTENDED):
+            engine.set_mixed(False)
+            engine.set_screen(0)
+            engine.set_path(1)
+            plain = run(quirk, True)
+            engine.set_mixed(True)
+            engine.set_screen(1)
+            engine.set_path(0)
+            engine.set_span(False)
+            off_cold = run(quirk, True)
+            off_warm = run(quirk, False)
+            engine.set_span(True)
+            s0 = engine.span_report()
+            on_cold = run(quirk, True)
+            on_warm = run(quirk, False)
+            s1 = engine.span_report()
+            assert s1["spans"] - s0["spans"] >= 8 and s1["blocks"] - s0["blocks"] >= 24, (s0, s1)   # (rows 0..4 hold 5, 5, 4, 3, 2 long-range-only pairs; twice)
+            for tag, t in (("off cold", off_cold), ("off warm", off_warm), ("on cold", on_cold), ("on warm", on_warm)):
+                same(plain, t, (quirk, tag))
+            assert len(plain[1][2]) > 500_000 and len(plain[0][2]) > 1_000_000
+            # shorter spans give the same tables
+            engine.set_span(True, 2)
+            same(plain, run(quirk, True), (quirk, "spans of 2"))
+            engine.set_span(True, 8)
+        # overflow: every pair list holds 64 entries -> every speculative block / segment is redone non-speculatively
+        Engine.set_pair_cap(64)
+        c0, s0 = engine.counters(), engine.span_report()
+        over = run(L.QUIRK_REFERENCE, True)
+        c1, s1 = engine.counters(), engine.span_report()
+        Engine.set_pair_cap(0)
+        assert s1["redone"] - s0["redone"] >= 10 and c1["spec_misses"] - c0["spec_misses"] >= 20, (s0, s1, c0, c1)
+        engine.set_mixed(False)
+        engine.set_screen(0)
+        engine.set_path(1)
+        same(run(L.QUIRK_REFERENCE, True), over, "pair-list overflow")
+    finally:
+        Engine.set_pair_cap(0)
+        engine.set_span(True, 8)
+        engine.set_mixed(True)
+        engine.set_screen(1)
+        engine.set_path(0)
