@@ -1183,7 +1183,7 @@ __device__ __forceinline__ uint64_t sel_order_key(uint64_t cv, uint64_t space) {
 
 constexpr int SEL_LIST = 6144;   // keys of the threshold's bucket a k_sel_thresh workgroup keeps in LDS (more: it re-reads the global list)
 
-__global__ __launch_bounds__(1024) void k_sel_thresh(const uint64_t *__restrict__ ckey, PickOut *__restrict__ pick) {
+__device__ __forceinline__ void sel_thresh_body(const uint64_t *__restrict__ ckey, PickOut *__restrict__ pick) {
     __shared__ uint64_t list[SEL_LIST];
     __shared__ unsigned int hist[SEL_BINS];
     __shared__ unsigned int wsum[16];
@@ -1336,9 +1336,25 @@ __global__ __launch_bounds__(1024) void k_sel_thresh(const uint64_t *__restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_sel_mark(const uint64_t *__restrict__ ckey, const uint64_t *__restrict__ cval, PickOut *__restrict__ pick,
-                                                  uint64_t space, uint32_t *__restrict__ bitmap, uint32_t *__restrict__ chunk_cnt,
-                                                  uint32_t *__restrict__ super_cnt) {
+__global__ __launch_bounds__(1024) void k_sel_thresh(const uint64_t *__restrict__ ckey, PickOut *__restrict__ pick) { sel_thresh_body(ckey, pick); }
+
+// The selection of all reference blocks of a span in ONE launch per stage (blockIdx.y = segment): each segment has its own candidate
+// list, pick record, bitmap and counters; the rows of segment k go behind those of segments 0 .. k-1 (their n_kept are final when the
+// scatter starts), which is the order the reference appends in.
+struct SelSpan {
+    int n;
+    const uint64_t *ck[LDW_SPAN_MAX], *cv[LDW_SPAN_MAX];
+    PickOut *pick[LDW_SPAN_MAX];
+    const int32_t *idx_t[LDW_SPAN_MAX];
+    uint64_t space[LDW_SPAN_MAX];
+    uint32_t *bitmap[LDW_SPAN_MAX], *chunks[LDW_SPAN_MAX], *supers[LDW_SPAN_MAX];
+    int n_super[LDW_SPAN_MAX];
+};
+__global__ __launch_bounds__(1024) void k_sel_thresh_span(SelSpan S) { sel_thresh_body(S.ck[blockIdx.y], S.pick[blockIdx.y]); }
+
+__device__ __forceinline__ void sel_mark_body(const uint64_t *__restrict__ ckey, const uint64_t *__restrict__ cval, PickOut *__restrict__ pick,
+                                              uint64_t space, uint32_t *__restrict__ bitmap, uint32_t *__restrict__ chunk_cnt,
+                                              uint32_t *__restrict__ super_cnt) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const bool keep = i < (long long)pick->n_cand && ckey[i] >= (uint64_t)pick->kstart;
     if (keep) {
@@ -1351,11 +1367,21 @@ __global__ __launch_bounds__(256) void k_sel_mark(const uint64_t *__restrict__ c
     if (mk != 0ull && (threadIdx.x & 63) == __builtin_ctzll(mk)) atomicAdd((unsigned long long *)&pick->n_kept, (unsigned long long)__popcll(mk));
 }
 
-__global__ __launch_bounds__(256) void k_sel_scatter(const uint64_t *__restrict__ ckey, const uint64_t *__restrict__ cval, const PickOut *__restrict__ pick,
-                                                     uint64_t space, const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ chunk_cnt,
-                                                     const uint32_t *__restrict__ super_cnt, int n_super, const int32_t *__restrict__ idx_f,
-                                                     const int32_t *__restrict__ idx_t, int nf, const int64_t *__restrict__ lr_count,
-                                                     int32_t *__restrict__ out_a, int32_t *__restrict__ out_b, double *__restrict__ out_mi) {
+__global__ __launch_bounds__(256) void k_sel_mark(const uint64_t *__restrict__ ckey, const uint64_t *__restrict__ cval, PickOut *__restrict__ pick,
+                                                  uint64_t space, uint32_t *__restrict__ bitmap, uint32_t *__restrict__ chunk_cnt,
+                                                  uint32_t *__restrict__ super_cnt) {
+    sel_mark_body(ckey, cval, pick, space, bitmap, chunk_cnt, super_cnt);
+}
+__global__ __launch_bounds__(256) void k_sel_mark_span(SelSpan S) {
+    const int y = blockIdx.y;
+    sel_mark_body(S.ck[y], S.cv[y], S.pick[y], S.space[y], S.bitmap[y], S.chunks[y], S.supers[y]);
+}
+
+__device__ __forceinline__ void sel_scatter_body(const uint64_t *__restrict__ ckey, const uint64_t *__restrict__ cval, const PickOut *__restrict__ pick,
+                                                 uint64_t space, const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ chunk_cnt,
+                                                 const uint32_t *__restrict__ super_cnt, int n_super, const int32_t *__restrict__ idx_f,
+                                                 const int32_t *__restrict__ idx_t, int nf, int64_t row_base,
+                                                 int32_t *__restrict__ out_a, int32_t *__restrict__ out_b, double *__restrict__ out_mi) {
     __shared__ unsigned int spre[SEL_MAX_SUPER];
     __shared__ unsigned int wtot[4];
     // exclusive scan of the super-chunk counters, per workgroup: strips of consecutive counters per thread
@@ -1391,15 +1417,30 @@ __global__ __launch_bounds__(256) void k_sel_scatter(const uint64_t *__restrict_
     if ((long long)rank >= pick->n_kept) return;   // (cannot happen; never write past the rows reserved for this block)
     const uint64_t c = cv & 0x3FFFFFFFFFFFFFFFull;
     const int a_loc = (int)(c % (uint64_t)nf), b_loc = (int)(c / (uint64_t)nf);
-    const int64_t dst = *lr_count + rank;
+    const int64_t dst = row_base + rank;
     out_a[dst] = idx_f[a_loc];
     out_b[dst] = idx_t[b_loc];
     out_mi[dst] = key_f64(k);
 }
+__global__ __launch_bounds__(256) void k_sel_scatter(const uint64_t *__restrict__ ckey, const uint64_t *__restrict__ cval, const PickOut *__restrict__ pick,
+                                                     uint64_t space, const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ chunk_cnt,
+                                                     const uint32_t *__restrict__ super_cnt, int n_super, const int32_t *__restrict__ idx_f,
+                                                     const int32_t *__restrict__ idx_t, int nf, const int64_t *__restrict__ lr_count,
+                                                     int32_t *__restrict__ out_a, int32_t *__restrict__ out_b, double *__restrict__ out_mi) {
+    sel_scatter_body(ckey, cval, pick, space, bitmap, chunk_cnt, super_cnt, n_super, idx_f, idx_t, nf, *lr_count, out_a, out_b, out_mi);
+}
+__global__ __launch_bounds__(256) void k_sel_scatter_span(SelSpan S, const int32_t *__restrict__ idx_f, int nf, const int64_t *__restrict__ lr_count,
+                                                          int32_t *__restrict__ out_a, int32_t *__restrict__ out_b, double *__restrict__ out_mi) {
+    const int y = blockIdx.y;
+    int64_t base = *lr_count;
+    for (int j = 0; j < y; ++j) base += S.pick[j]->n_kept;   // (final: k_sel_mark_span of every segment has finished)
+    sel_scatter_body(S.ck[y], S.cv[y], S.pick[y], S.space[y], S.bitmap[y], S.chunks[y], S.supers[y], S.n_super[y], idx_f, S.idx_t[y], nf, base, out_a, out_b,
+                     out_mi);
+}
 
-__global__ __launch_bounds__(256) void k_sel_clear(const uint64_t *__restrict__ ckey, const uint64_t *__restrict__ cval, const PickOut *__restrict__ pick,
-                                                   uint64_t space, uint32_t *__restrict__ bitmap, uint32_t *__restrict__ chunk_cnt,
-                                                   uint32_t *__restrict__ super_cnt) {
+__device__ __forceinline__ void sel_clear_body(const uint64_t *__restrict__ ckey, const uint64_t *__restrict__ cval, const PickOut *__restrict__ pick,
+                                               uint64_t space, uint32_t *__restrict__ bitmap, uint32_t *__restrict__ chunk_cnt,
+                                               uint32_t *__restrict__ super_cnt) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= (long long)pick->n_cand) return;
     if (ckey[i] < (uint64_t)pick->kstart) return;
@@ -1407,6 +1448,31 @@ __global__ __launch_bounds__(256) void k_sel_clear(const uint64_t *__restrict__ 
     bitmap[ok >> 5] = 0u;
     chunk_cnt[ok / SEL_CHUNK_BITS] = 0u;
     super_cnt[ok / (SEL_CHUNK_BITS * SEL_SUPER)] = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_sel_clear(const uint64_t *__restrict__ ckey, const uint64_t *__restrict__ cval, const PickOut *__restrict__ pick,
+                                                   uint64_t space, uint32_t *__restrict__ bitmap, uint32_t *__restrict__ chunk_cnt,
+                                                   uint32_t *__restrict__ super_cnt) {
+    sel_clear_body(ckey, cval, pick, space, bitmap, chunk_cnt, super_cnt);
+}
+__global__ __launch_bounds__(256) void k_sel_clear_span(SelSpan S) {
+    const int y = blockIdx.y;
+    sel_clear_body(S.ck[y], S.cv[y], S.pick[y], S.space[y], S.bitmap[y], S.chunks[y], S.supers[y]);
+}
+// running count and stats of every reference block of a span (one thread)
+struct SpanDoneArgs {
+    long long n_sr[LDW_SPAN_MAX];
+};
+__global__ void k_span_done(SelSpan S, SpanDoneArgs D, int64_t *lr_count, int64_t *stats_i, double *stats_d) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int k = 0; k < S.n; ++k) {
+        const PickOut *pk = S.pick[k];
+        *lr_count += pk->n_kept;
+        stats_i[k * 3 + 0] = pk->n;
+        stats_i[k * 3 + 1] = pk->n_kept;
+        stats_i[k * 3 + 2] = D.n_sr[k];
+        stats_d[k] = pk->disc_thresh;
+    }
 }
 
 // running device-side counters and per-block stats
@@ -3149,7 +3215,75 @@ int finish_span(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLa
     }
     const char *d = c->dstage[s].as<char>();
     if ((int64_t)c->trace.size() < hb.blk_no + hb.span) c->trace.resize((size_t)(hb.blk_no + hb.span));
-    for (int k = 0; k < hb.span; ++k) {
+    // the common case — every guess held, every candidate set fits the sort-free selection — takes ONE launch per stage for all segments
+    static const bool sel_fast_on = getenv("LDW_NO_FAST_SELECT") == nullptr && getenv("LDW_NO_SPAN_SELECT") == nullptr;
+    bool batched = sel_fast_on && c->select_mode == 0;
+    long long m_max = 0, m_sum = 0;
+    for (int k = 0; k < hb.span && batched; ++k) {
+        const ldw::PickOut *hp = &picks[k];
+        const uint64_t space = (uint64_t)hb.nf * (uint64_t)hb.seg_nt[k];
+        const long long n_chunks = (long long)((2 * space + SEL_CHUNK_BITS - 1) / SEL_CHUNK_BITS) + 1, n_super = (n_chunks + SEL_SUPER - 1) / SEL_SUPER;
+        batched = !(hp->n > 0 && !hp->spec_ok) && (long long)hp->n_cand <= SEL_MAX && n_super <= SEL_MAX_SUPER && (size_t)hp->n_cand <= hb.cand_cap;
+        m_max = std::max<long long>(m_max, (long long)hp->n_cand);
+        m_sum += (long long)hp->n_cand;
+    }
+    if (batched) {
+        SelSpan S;
+        memset(&S, 0, sizeof(S));
+        SpanDoneArgs DA;
+        memset(&DA, 0, sizeof(DA));
+        S.n = hb.span;
+        size_t w_off = 0, c_off = 0;
+        size_t woff[LDW_SPAN_MAX], coff[LDW_SPAN_MAX];
+        for (int k = 0; k < hb.span; ++k) {
+            const uint64_t space = (uint64_t)hb.nf * (uint64_t)hb.seg_nt[k];
+            const size_t n_words = (size_t)((2 * space + 31) / 32) + 1, n_chunks = (size_t)((2 * space + SEL_CHUNK_BITS - 1) / SEL_CHUNK_BITS) + 1;
+            woff[k] = w_off;
+            coff[k] = c_off;
+            w_off += (n_words + 63) / 64 * 64;
+            c_off += (n_chunks + 63) / 64 * 64;
+            S.space[k] = space;
+            S.n_super[k] = (int)((n_chunks + SEL_SUPER - 1) / SEL_SUPER);
+        }
+        if (w_off * 4 > c->sel_bitmap.cap || c_off * 4 > c->sel_chunks.cap || (size_t)LDW_SPAN_MAX * SEL_MAX_SUPER * 4 > c->sel_prefix.cap) {
+            // first use / a larger span: fresh zeroes (all three arrays stay all-zero between uses: k_sel_clear)
+            if (int rc = c->sel_bitmap.reserve(w_off * 4)) return rc;
+            if (int rc = c->sel_chunks.reserve(c_off * 4)) return rc;
+            if (int rc = c->sel_prefix.reserve((size_t)LDW_SPAN_MAX * SEL_MAX_SUPER * 4)) return rc;
+            LDW_HIP(hipMemsetAsync(c->sel_bitmap.p, 0, c->sel_bitmap.cap, c->stream));
+            LDW_HIP(hipMemsetAsync(c->sel_chunks.p, 0, c->sel_chunks.cap, c->stream));
+            LDW_HIP(hipMemsetAsync(c->sel_prefix.p, 0, c->sel_prefix.cap, c->stream));
+        }
+        if (int rc = ensure_links_capacity(c, c->n_sr, c->n_lr + m_sum)) return rc;
+        for (int k = 0; k < hb.span; ++k) {
+            const ldw::PickOut *hp = &picks[k];
+            if (hp->n > 0) update_guess(c, false, hp, false);
+            ldw::BlockTrace &tr = c->trace[(size_t)hb.blk_no + k];
+            tr = ldw::BlockTrace();
+            tr.guess = hb.guess;
+            tr.B_true = hp->B_true;
+            tr.path = 4;   // span
+            tr.n_cand = (long long)hp->n_cand;
+            S.ck[k] = hb.sseg[k].ckey;
+            S.cv[k] = hb.sseg[k].cval;
+            S.pick[k] = reinterpret_cast<ldw::PickOut *>(reinterpret_cast<char *>(sl.pick[s]) + (size_t)k * PICK_STRIDE);
+            S.idx_t[k] = reinterpret_cast<const int32_t *>(d + hb.o_idx_t) + hb.seg_start[k];
+            S.bitmap[k] = c->sel_bitmap.as<uint32_t>() + woff[k];
+            S.chunks[k] = c->sel_chunks.as<uint32_t>() + coff[k];
+            S.supers[k] = c->sel_prefix.as<uint32_t>() + (size_t)k * SEL_MAX_SUPER;
+            DA.n_sr[k] = 0;
+        }
+        const unsigned gridm = (unsigned)std::max<long long>(1, (m_max + 255) / 256);
+        hipLaunchKernelGGL(k_sel_thresh_span, dim3(1, (unsigned)hb.span), dim3(1024), 0, c->stream, S);
+        hipLaunchKernelGGL(k_sel_mark_span, dim3(gridm, (unsigned)hb.span), dim3(256), 0, c->stream, S);
+        hipLaunchKernelGGL(k_sel_scatter_span, dim3(gridm, (unsigned)hb.span), dim3(256), 0, c->stream, S, reinterpret_cast<const int32_t *>(d + hb.o_idx_f), (int)hb.nf,
+                           sl.lr_count, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), c->lr_mi.as<double>());
+        hipLaunchKernelGGL(k_sel_clear_span, dim3(gridm, (unsigned)hb.span), dim3(256), 0, c->stream, S);
+        hipLaunchKernelGGL(k_span_done, dim3(1), dim3(64), 0, c->stream, S, DA, sl.lr_count, sl.stats_i + hb.blk_no * 3, sl.stats_d + hb.blk_no);
+        LDW_HIP(hipGetLastError());
+        c->n_lr += m_sum;   // upper bound; the exact value is *lr_count
+    }
+    for (int k = 0; k < hb.span && !batched; ++k) {
         const ldw::PickOut *hp = &picks[k];
         const bool missed = hp->n > 0 && !hp->spec_ok;
         if (missed) {
@@ -3495,7 +3629,9 @@ int ldw_links_end(ldw_ctx *c) {
         if (trace_on && b < (int64_t)c->trace.size()) {
             const ldw::BlockTrace &tr = c->trace[(size_t)b];
             float span = 0;
-            if (b > 0) (void)hipEventElapsedTime(&span, c->ev_pool[(size_t)(b - 1) * EVB + 3], ev[3]);   // selection end of b-1 -> selection end of b
+            int64_t pb = b - 1;
+            while (pb >= 0 && pb < (int64_t)c->ev_valid.size() && !c->ev_valid[(size_t)pb]) --pb;   // (the previous block that recorded events: a span's first)
+            if (pb >= 0 && hipEventElapsedTime(&span, c->ev_pool[(size_t)pb * EVB + 3], ev[3]) != hipSuccess) (void)hipGetLastError();   // selection end of the item before -> selection end of b
             fprintf(stderr, "[ldw block %3lld] %s path %d guess %4d true %4d%s cand %8lld kept %7lld  gemm %.3f epi %.3f sel %.3f  span %.3f ms\n", (long long)b,
                     tr.diag ? "diag" : "off ", tr.path, tr.guess, tr.B_true, tr.missed ? " MISS" : "", tr.n_cand, (long long)c->stats[b].n_lr_kept, t01, t12, t23, span);
         }
