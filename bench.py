@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--warm", action="store_true", help="do NOT reset the speculation state before every step (the r02 behaviour: each step inherits "
                                                         "the previous step's bucket guesses); the default is a cold pass per step")
     ap.add_argument("--no-job", action="store_true", help="skip the end-to-end job leg (host states -> tsv files)")
+    ap.add_argument("--no-adversarial", action="store_true", help="skip the adversarial-data leg (MAF uniform in [0.2, 0.5], no clonal groups)")
     ap.add_argument("--sustain-s", type=float, default=10.0, help="N = 1: keep stepping after the timed region until this many seconds of steps have run")
     return ap.parse_args()
 
@@ -136,6 +137,70 @@ def job_leg(states, POS, paint, g, L, N, device, args):
                        "lr_links.tsv, short-range model, ARACNE, sr_links.tsv on disk); first use of this engine, so its allocations are inside")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def adversarial_leg(L, N, device, args):
+    """what the default path costs on data that is NOT friendly to it.  Same L x N, MAF uniform in [0.2, 0.5] (no rare
+    minor states: the marginal-only tile pruning has nothing to dismiss), no clonal groups (synth kind 'adversarial'), on an engine of
+    its own, cold passes.  Two weightings: the one estimate_Hamming_distance_weights gives on that alignment (no sequence has a neighbour
+    within 10 %: all weights equal, N_eff = N / 2) and N DISTINCT weights in [1/50, 1] set directly (the dual-digit GEMM then needs its
+    per-32-position exponents).  Each with ms_per_step, path, prune, spec_misses, pairs listed, and the plain path beside it."""
+    import torch
+    from ldweaver_amd.engine import Engine
+    from ldweaver_amd.mi import lr_links_approx, make_blocks
+    from ldweaver_amd.synth import synth_alignment
+
+    syn = synth_alignment(L, N, seed=1988, device=torch.device("cuda", device), as_numpy=False, kind="adversarial")
+    POS, paint, g = syn["POS"], syn["paint"], float(syn["g"])
+    blocks = make_blocks(L, args.max_blk_sz)
+    pairs = 0
+    for fs, fe, ts, te in blocks.tolist():
+        nf, nt = fe - fs + 1, te - ts + 1
+        pairs += nf * (nf - 1) // 2 if (fs == ts and fe == te) else nf * nt - min(nf, nt)
+    approx = lr_links_approx(POS, g, 20000.0)
+    out = dict(what="synthetic kind 'adversarial': MAF uniform in [0.2, 0.5], no clonal groups; cold passes on an engine of its own", L=L, N=N, pairs=int(pairs))
+    with Engine(device) as e:
+        e.set_alignment(syn["states"])
+        counts = e.state_counts()
+        uqe = (counts > 0).T.astype(np.float64)
+        r = uqe.sum(axis=1)
+        hdw_h = e.hamming_weights(int(L * 0.1))
+        u = ((np.arange(N, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1 << 32)).astype(np.float64) / float(1 << 32)
+        hdw_d = 1.0 / (1.0 + 49.0 * u)
+        for tag, hdw in (("hamming_weights", hdw_h), ("distinct_weights", hdw_d)):
+            e.set_weights(hdw)
+            e.set_snp_meta(r, uqe, POS, paint, g)
+            rec = dict(weights=dict(distinct=int(len(np.unique(hdw))), neff=float(hdw.sum()), min=float(hdw.min()), max=float(hdw.max())),
+                       approximate_gemm=e.apx_info())
+
+            def run(n):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    e.reset_speculation()
+                    e.mi_all_pairs(blocks, 20000.0, 1e6, approx)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e3
+            for key, (mixed, scr, path) in (("default", (True, 1, 0)), ("plain", (False, 0, 1))):
+                e.set_mixed(mixed)
+                e.set_screen(scr)
+                e.set_path(path)
+                run(1)
+                p0, c0, pr0, sp0 = e.path_report(), e.counters(), e.prune_report(), e.span_report()
+                ms = run(2 if key == "plain" else 3)
+                p1, c1, pr1, sp1 = e.path_report(), e.counters(), e.prune_report(), e.span_report()
+                steps = 2 if key == "plain" else 3
+                rec[key] = dict(ms_per_step=ms, value=pairs / (ms * 1e-3), steps=steps, links=dict(n_sr=e.links_count(0), n_lr=e.links_count(1)),
+                                path={k: ((p1[k] - p0[k]) / steps if isinstance(p1[k], int) else p1[k]) for k in p1},
+                                spec_misses=c1["spec_misses"] - c0["spec_misses"], screen_violations=c1["screen_violations"] - c0["screen_violations"],
+                                prune=dict(tiles_pruned=pr1["tiles_pruned"] - pr0["tiles_pruned"], tiles_total=pr1["tiles_total"] - pr0["tiles_total"]),
+                                spans=(sp1["spans"] - sp0["spans"]) / steps, span_blocks_redone=sp1["redone"] - sp0["redone"])
+            e.set_mixed(True)
+            e.set_screen(1)
+            e.set_path(0)
+            rec["links_equal_plain"] = rec["default"]["links"] == rec["plain"]["links"]
+            out[tag] = rec
     return out
 
 
@@ -425,6 +490,9 @@ def main():
     # ---- job: the product entry points end to end, state matrix on the HOST -> both tsv files on disk ----
     if extra and not args.no_job and args.engine == "mfma":
         legs["job"] = job_leg(states, POS, paint, g, L, N, local_rank, args)
+
+    if extra and not args.no_adversarial and args.engine == "mfma":
+        legs["adversarial"] = adversarial_leg(L, N, local_rank, args)
 
     if rank == 0:
         K = args.steps

@@ -40,10 +40,13 @@ def zipf_group_sizes(N: int, G: int) -> np.ndarray:
 
 @torch.no_grad()
 def synth_alignment(L: int, N: int, seed: int = 1988, g: int = G_DEFAULT, device="cpu",
-                    chunk: int = 4096, as_numpy: bool | None = None) -> dict:
+                    chunk: int = 4096, as_numpy: bool | None = None, kind: str = "survey") -> dict:
     """Returns dict(states (L,N) uint8, POS int32[L], paint int32[L], g, nclust=3).
 
     ``device='cuda'`` keeps ``states`` on the GPU (torch tensor) unless ``as_numpy``.
+    ``kind='adversarial'``: the same recipe with the two properties the default path profits from taken away —
+    MAF uniform in [0.2, 0.5] (no rare minor states: nothing for the marginal-only tile pruning) and NO clonal groups (every
+    sequence draws its own block haplotypes: no down-weighted clones, N_eff near N instead of near N / 25).
     """
     dev = torch.device(device)
     if as_numpy is None:
@@ -56,6 +59,10 @@ def synth_alignment(L: int, N: int, seed: int = 1988, g: int = G_DEFAULT, device
     major = rs.integers(0, 4, L)
     minor = (major + rs.integers(1, 4, L)) % 4
     maf = np.clip(rs.beta(0.5, 2.0, L), 0.02, 0.5)
+    if kind == "adversarial":
+        maf = rs.uniform(0.2, 0.5, L)
+    elif kind != "survey":
+        raise ValueError(f"unknown synthetic alignment kind {kind!r}")
     has_gap = rs.random(L) < 0.15
     gap_rate = np.where(has_gap, rs.uniform(0.002, 0.10, L), 0.0)
     has_third = rs.random(L) < 0.005
@@ -66,8 +73,8 @@ def synth_alignment(L: int, N: int, seed: int = 1988, g: int = G_DEFAULT, device
     third = cand
 
     # --- population structure ---
-    G = max(1, math.ceil(N / 25))
-    sizes = zipf_group_sizes(N, G)
+    G = N if kind == "adversarial" else max(1, math.ceil(N / 25))
+    sizes = np.ones(N, dtype=np.int64) if kind == "adversarial" else zipf_group_sizes(N, G)
     group_of_seq = np.repeat(np.arange(G), sizes)
     rs.shuffle(group_of_seq)
     nb = math.ceil(L / 50)

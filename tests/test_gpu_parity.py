@@ -1783,3 +1783,232 @@ def test_spans_equal_block_by_block(engine):
         engine.set_mixed(True)
         engine.set_screen(1)
         engine.set_path(0)
+
+
+@pytest.mark.parametrize("weights", ["hamming", "distinct"])
+def test_adversarial_alignment_default_equals_plain(engine, weights):
+    """data that is NOT friendly to the default path — MAF uniform in [0.2, 0.5] (no rare minor states: the
+    marginal-only tile pruning has nothing to dismiss), no clonal groups (synth kind 'adversarial') — 20k SNPs x 2k sequences, 5000-SNP
+    blocks; with the weights estimate_Hamming_distance_weights gives there (all equal) and with N DISTINCT weights (per-k-step block
+    exponents).  The default path's tables == the plain path's bit for bit, cold and warm; verify mode (every pair evaluated both ways,
+    block by block and screen dismissals checked in fp64): 0 violations."""
+    Ls, N, B = 20_000, 2_000, 5_000
+    syn = synth_alignment(Ls, N, seed=1988, device="cuda", as_numpy=False, kind="adversarial")
+    engine.set_engine(L.ENGINE_MFMA)
+    engine.set_alignment(syn["states"])
+    cnt = engine.state_counts()
+    uqe = (cnt > 0).T.astype(np.float64)
+    r = uqe.sum(axis=1)
+    hdw = engine.hamming_weights(int(Ls * 0.1))
+    if weights == "hamming":
+        assert len(np.unique(hdw)) <= 3          # no sequence has a neighbour within 10 %: (nearly) all weights equal
+    else:
+        u = ((np.arange(N, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1 << 32)).astype(np.float64) / float(1 << 32)
+        hdw = 1.0 / (1.0 + 49.0 * u)
+        assert len(np.unique(hdw)) == N
+    engine.set_weights(hdw)
+    POS, g = syn["POS"], float(syn["g"])
+    engine.set_snp_meta(r, uqe, POS, syn["paint"], g)
+    approx = MIH.lr_links_approx(POS, g, 20000.0)
+    blocks = MIH.make_blocks(Ls, B)
+    lr_retain = 2e5     # keeps 0.1 % of the 2e8 pairs: the speculative path is the automatic choice
+    out = {}
+    try:
+        for key, (mixed, scr, path, cold) in dict(plain=(False, 0, 1, True), cold=(True, 1, 0, True), warm=(True, 1, 0, False), verify=(True, 2, 0, False)).items():
+            engine.set_mixed(mixed)
+            engine.set_screen(scr)
+            engine.set_path(path)
+            if cold:
+                engine.reset_speculation()
+            c0 = engine.counters()
+            engine.mi_all_pairs(blocks, 20000.0, lr_retain, approx)
+            c1 = engine.counters()
+            out[key] = (engine.links(0), engine.links(1), engine.block_stats(), {k: c1[k] - c0[k] for k in c1})
+    finally:
+        engine.set_mixed(True)
+        engine.set_screen(1)
+        engine.set_path(0)
+    info, rep = engine.apx_info(), engine.path_report()
+    assert info["usable"], (info, rep)
+    assert out["warm"][3]["apx_blocks"] == len(blocks) and out["verify"][3]["screen_violations"] == 0 and out["cold"][3]["screen_violations"] == 0
+    for key in ("cold", "warm", "verify"):
+        for which in (0, 1):
+            for x, y in zip(out["plain"][which], out[key][which]):
+                assert np.array_equal(x, y), (key, which)
+        for k in ("n_lr_total", "n_lr_kept", "n_sr", "disc_thresh"):
+            assert np.array_equal(out["plain"][2][k], out[key][2][k]), (key, k)
+    assert len(out["plain"][1][2]) > 100_000 and len(out["plain"][0][2]) > 100_000
+
+
+def _pin_selection_of_blocks(engine, st_dev, hdw, r, uqe, POS, g, approx, sub, whole_with_c_oracle=()):
+    """For each block of `sub`: dense device MI (ldw_mi_block, reference quirk mode) against the oracle — a 512 x 512 sub-block through
+    c_oracle in intended mode + 16 single pairs with the block's own Q1 geometry, or (block index in whole_with_c_oracle) the WHOLE block
+    against c_oracle.mi_block in reference quirk mode — then the oracle's selection rule on the dense MI against the default path's rows,
+    MI bits and threshold, cold and warm.  Returns per-block (n_lr, n_kept)."""
+    import torch
+    want = []
+    for bi, (fs, fe, ts, te) in enumerate(sub.tolist()):
+        fi, ti = np.arange(fs - 1, fe), np.arange(ts - 1, te)
+        diag = (fs, fe) == (ts, te)
+        Md = engine.mi_block(fi, ti)
+        if bi in whole_with_c_oracle:
+            rows_needed = np.unique(np.concatenate([fi, ti]))
+            st_sub = st_dev[torch.as_tensor(rows_needed, device=st_dev.device)].cpu().numpy()
+            Mo = c_oracle.mi_block(st_sub, hdw, r[rows_needed], uqe[rows_needed], np.searchsorted(rows_needed, fi), np.searchsorted(rows_needed, ti))
+            assert Mo.shape == Md.shape
+            err = float(np.abs(Md - Mo).max())
+            assert err < MI_TIGHT, (bi, err)
+            del Mo, st_sub
+        else:
+            Mi = engine.mi_block(fi, ti, quirk=L.QUIRK_INTENDED)
+            o_f, o_t = min(3000, len(fi) - 512), min(3000 if diag else 6100, len(ti) - 512)
+            sf, stt_ = fi[o_f:o_f + 512], ti[o_t:o_t + 512]
+            rows_needed = np.unique(np.concatenate([sf, stt_]))
+            st_sub = st_dev[torch.as_tensor(rows_needed, device=st_dev.device)].cpu().numpy()
+            loc_f, loc_t = np.searchsorted(rows_needed, sf), np.searchsorted(rows_needed, stt_)
+            allr = np.arange(len(rows_needed))
+            Mo = c_oracle.mi_block(st_sub, hdw, r[rows_needed], uqe[rows_needed], allr, allr)
+            assert np.abs(Mi[o_f:o_f + 512, o_t:o_t + 512] - Mo[np.ix_(loc_f, loc_t)]).max() < MI_TIGHT
+            rng = np.random.default_rng(31 + bi)
+            for _ in range(16):
+                a_l, b_l = int(rng.integers(0, len(fi))), int(rng.integers(0, len(ti)))
+                rows2 = st_dev[[int(fi[a_l]), int(ti[b_l])]].cpu().numpy()
+                rxy = orc.q1_rxy(a_l, b_l, len(fi), len(ti), r[fi], r[ti])
+                refv = orc.mi_pair_direct(rows2, hdw, r[[fi[a_l], ti[b_l]]], uqe[[fi[a_l], ti[b_l]]], 0, 1, rxy)
+                assert abs(Md[a_l, b_l] - refv) < MI_TIGHT
+            del Mi
+        want.append(_dense_block_selection(Md, fi, ti, POS, g, 20000.0, 1e6, approx, diag))
+        del Md
+    for cold in (True, False):
+        if cold:
+            engine.reset_speculation()
+        c0 = engine.counters()
+        engine.mi_all_pairs(sub, 20000.0, 1e6, approx)
+        c1 = engine.counters()
+        assert c1["apx_blocks"] - c0["apx_blocks"] >= (1 if cold else len(sub)), (cold, c0, c1)       # the default path, not a fallback
+        stt = engine.block_stats()
+        la, lb, lmi = engine.links(1)
+        off = 0
+        for bi, (wa, wb, wmi, thr, n_lr) in enumerate(want):
+            n = int(stt["n_lr_kept"][bi])
+            assert int(stt["n_lr_total"][bi]) == n_lr
+            assert stt["disc_thresh"][bi] == thr, (bi, cold, stt["disc_thresh"][bi], thr)
+            assert n == len(wmi), (bi, cold, n, len(wmi))
+            assert np.array_equal(la[off:off + n], wa) and np.array_equal(lb[off:off + n], wb), (bi, cold)
+            assert np.array_equal(lmi[off:off + n], wmi), (bi, cold)
+            off += n
+        assert off == len(lmi)
+    return [(w[4], len(w[2])) for w in want]
+
+
+def test_c5_blocks_selection_pinned_to_oracle(engine):
+    """VERDICT r03 item 3a, first half: the C4 treatment (test_c4_blocks_selection_pinned_to_oracle) at BASELINE config 5's size —
+    500k SNPs x 10k sequences (N = 10 000: twice the K of C4, 100 weight-class segments more), one DIAGONAL and one OFF-DIAGONAL
+    10k x 10k block pair from the middle of the 1275: dense device MI against the C oracle (512 x 512 sub-block + the block's own Q1
+    geometry per pair), then the oracle's selection rule on the dense MI == the default path's rows, MI bits and threshold, cold and warm."""
+    Ls, N = 500_000, 10_000
+    syn = synth_alignment(Ls, N, seed=1988, device="cuda", as_numpy=False)
+    st_dev = syn["states"]
+    engine.set_alignment(st_dev)
+    cnt = engine.state_counts()
+    uqe = (cnt > 0).T.astype(np.float64)
+    r = uqe.sum(axis=1)
+    hdw = engine.hamming_weights(int(Ls * 0.1))
+    engine.set_weights(hdw)
+    POS, g = syn["POS"], float(syn["g"])
+    engine.set_snp_meta(r, uqe, POS, syn["paint"], g)
+    approx = MIH.lr_links_approx(POS, g, 20000.0)
+    blocks = MIH.make_blocks(Ls, 10000)
+    assert len(blocks) == 1275
+    i_diag = next(i for i, b in enumerate(blocks.tolist()) if b[0] == b[2] and b[0] == 200_001)
+    i_off = next(i for i, b in enumerate(blocks.tolist()) if b[0] == 200_001 and b[2] == 350_001)
+    res = _pin_selection_of_blocks(engine, st_dev, hdw, r, uqe, POS, g, approx, blocks[[i_diag, i_off]])
+    assert all(n_lr > 3e7 and 100 < kept < 5000 for n_lr, kept in res), res
+
+
+def test_ragged_block_whole_against_c_oracle(engine):
+    """VERDICT r03 item 3a, second half: the shape of BASELINE config 3 (85 000 SNPs x 616 sequences: the last block column is 5000 wide,
+    N is no multiple of 64, 616 sequences in few clonal groups) — one RAGGED 10 000 x 5 000 block compared WHOLE (5e7 pairs) with
+    c_oracle.mi_block in the reference's quirk mode: the only geometry where Q1 scrambles RXY (rft = t(rf rt') read by the linear index
+    of the nf x nt matrix: R/computePairwiseMI.R:261 against src/computeMI.cpp:19) instead of merely transposing it — plus a square
+    off-diagonal neighbour of the same row through the sampled treatment; then the oracle's selection rule on the dense device MI ==
+    the default path's rows, MI bits and thresholds, cold and warm."""
+    Ls, N = 85_000, 616
+    syn = synth_alignment(Ls, N, seed=1988, device="cuda", as_numpy=False)
+    st_dev = syn["states"]
+    engine.set_alignment(st_dev)
+    cnt = engine.state_counts()
+    uqe = (cnt > 0).T.astype(np.float64)
+    r = uqe.sum(axis=1)
+    hdw = engine.hamming_weights(int(Ls * 0.1))
+    engine.set_weights(hdw)
+    POS, g = syn["POS"], float(syn["g"])
+    engine.set_snp_meta(r, uqe, POS, syn["paint"], g)
+    approx = MIH.lr_links_approx(POS, g, 20000.0)
+    blocks = MIH.make_blocks(Ls, 10000)
+    bl = blocks.tolist()
+    i_rag = next(i for i, b in enumerate(bl) if b[0] == 30_001 and b[2] == 80_001)
+    i_sq = next(i for i, b in enumerate(bl) if b[0] == 30_001 and b[2] == 60_001)
+    assert bl[i_rag] == [30_001, 40_000, 80_001, 85_000]
+    res = _pin_selection_of_blocks(engine, st_dev, hdw, r, uqe, POS, g, approx, blocks[[i_sq, i_rag]], whole_with_c_oracle=(1,))
+    assert res[1][0] == 10_000 * 5_000 - 5_000 and all(kept > 1000 for _, kept in res), res
+
+
+@pytest.mark.parametrize("case", ["npad_gate", "segment_gate"])
+def test_gates_of_the_approximate_path_fall_back_to_the_limb_paths(engine, case):
+    """the two gates of the approximate path that no test reached (prepare_apx_weights, ldw_apx.hip).  (i) more
+    than 30 720 padded sequences — the two digit arrays no longer fit the GEMM's LDS beside its tables: N = 30 848; (ii) so many
+    weight classes that the popcount segment tables of k_pair_sums exceed 60 000 bytes of LDS: 4000 DISTINCT weights.  Either way
+    ldw_path_report names the gate, the blocks run the limb paths (mixed precision: 3 high limbs + gathered low limbs) with the screen,
+    and the link tables equal the plain path's bit for bit.  (The third fallback — a pair list that overflows — is forced in
+    test_spans_equal_block_by_block with ldw_set_pair_cap.)"""
+    if case == "npad_gate":
+        Ls, N = 2_400, 30_848
+    else:
+        Ls, N = 2_400, 4_000
+    syn = synth_alignment(Ls, N, seed=5, device="cuda", as_numpy=False)
+    engine.set_engine(L.ENGINE_MFMA)
+    engine.set_alignment(syn["states"])
+    cnt = engine.state_counts()
+    uqe = (cnt > 0).T.astype(np.float64)
+    r = uqe.sum(axis=1)
+    hdw = engine.hamming_weights(int(Ls * 0.1))
+    if case == "segment_gate":
+        u = ((np.arange(N, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1 << 32)).astype(np.float64) / float(1 << 32)
+        hdw = 1.0 / (1.0 + 49.0 * u)
+    engine.set_weights(hdw)
+    POS, g = syn["POS"], float(syn["g"])
+    engine.set_snp_meta(r, uqe, POS, syn["paint"], g)
+    info, rep = engine.apx_info(), engine.path_report()
+    assert not info["usable"], info
+    if case == "npad_gate":
+        assert "Npad" in rep["apx_gate"] and "30720" in rep["apx_gate"], rep
+    else:
+        assert "segment" in rep["apx_gate"] and info["delta"] <= 4e-3, (rep, info)
+    approx = MIH.lr_links_approx(POS, g, 20000.0)
+    blocks = MIH.make_blocks(Ls, 1200)
+    lr_retain = 4000.0    # 0.14 % of the 2.9e6 pairs: speculation is the automatic choice
+    out = {}
+    try:
+        for key, (mixed, scr, path) in dict(plain=(False, 0, 1), default=(True, 1, 0)).items():
+            engine.set_mixed(mixed)
+            engine.set_screen(scr)
+            engine.set_path(path)
+            engine.reset_speculation()
+            c0 = engine.counters()
+            for _ in range(2):
+                engine.mi_all_pairs(blocks, 20000.0, lr_retain, approx)
+            c1 = engine.counters()
+            out[key] = (engine.links(0), engine.links(1), engine.block_stats(), {k: c1[k] - c0[k] for k in c1})
+    finally:
+        engine.set_mixed(True)
+        engine.set_screen(1)
+        engine.set_path(0)
+    d = out["default"][3]
+    assert d["apx_blocks"] == 0 and d["mixed_blocks"] >= len(blocks), d     # the gate sent every speculative block to the limb paths
+    for which in (0, 1):
+        for x, y in zip(out["plain"][which], out["default"][which]):
+            assert np.array_equal(x, y), (case, which)
+    for k in ("n_lr_total", "n_lr_kept", "n_sr", "disc_thresh"):
+        assert np.array_equal(out["plain"][2][k], out["default"][2][k]), (case, k)
+    assert len(out["plain"][1][2]) > 1000
