@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void k_build_tab11(double W, double lo, double
     const int jb = idc / NB, ia = idc % NB;   // [bin of the to side][bin of the from side]
     const double den = W + 2.0;
     double Lmax = -1e30, Hmin = 1e30;
+    bool reach = false;   // this lane's sample point can reach the level at all on the H side (x above independence)
     if (live) {
         const int sa = smp / 3, sb = smp % 3;
         // bin k covers sqrt(p) * cbin in [k, k + 1); the last bin is open-ended: sample it up to the total weight
@@ -240,6 +241,16 @@ __global__ __launch_bounds__(256) void k_build_tab11(double W, double lo, double
                     if (mi11_exact(m, pa, pb, W, den) < lo) a = m; else b = m;
                 }
                 Hmin = a;   // MI(a) < lo: everything below a (and above E) is safe
+                reach = true;
+            } else {
+                // r04 (found by the adversarial alignment: a rare state that co-occurs PERFECTLY with a common one — x = xhi, the largest
+                // feasible value — was dismissed).  This sample point cannot reach the level even at its largest feasible x = xhi, but a
+                // point with larger marginals in the same bin may: H ascends with both marginals, so over the bin it is smallest where the
+                // level just becomes reachable, and there H = that point's own xhi >= this sample's xhi.  An unreachable sample therefore
+                // bounds H from below by ITS xhi (r03 let it contribute "no bound", and the minimum over the samples then skipped the
+                // stretch between the last unreachable and the first reachable sample).  A bin none of whose samples reaches the level is
+                // unreachable as a whole (the perfect-association MI is largest in a corner of the bin): unconditional, below.
+                Hmin = xhi;
             }
         } else if (E > xlo && mi11_exact(xlo, pa, pb, W, den) >= lo) {
             double a = xlo, b = E < xhi ? E : xhi;
@@ -250,12 +261,15 @@ __global__ __launch_bounds__(256) void k_build_tab11(double W, double lo, double
             Lmax = b;
         }
     }
+    int any_reach = reach ? 1 : 0;
 #pragma unroll
     for (int off = 1; off <= 16; off <<= 1) {
         const double l2 = __shfl_xor(Lmax, off), h2 = __shfl_xor(Hmin, off);
         Lmax = l2 > Lmax ? l2 : Lmax;
         Hmin = h2 < Hmin ? h2 : Hmin;
+        any_reach |= __shfl_xor(any_reach, off);
     }
+    if (!any_reach) Hmin = 1e30;
     if (role != 0 || id >= NB * NB) return;
     // n' is at most eta / sprime units below the sum of the approximate weights, which is within delta of the exact sum
     int2 e;

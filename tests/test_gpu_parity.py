@@ -1923,7 +1923,7 @@ def test_c5_blocks_selection_pinned_to_oracle(engine):
     i_diag = next(i for i, b in enumerate(blocks.tolist()) if b[0] == b[2] and b[0] == 200_001)
     i_off = next(i for i, b in enumerate(blocks.tolist()) if b[0] == 200_001 and b[2] == 350_001)
     res = _pin_selection_of_blocks(engine, st_dev, hdw, r, uqe, POS, g, approx, blocks[[i_diag, i_off]])
-    assert all(n_lr > 3e7 and 100 < kept < 5000 for n_lr, kept in res), res
+    assert res[0][0] < res[1][0] == 10_000 * 10_000 - 10_000 and all(n_lr > 1e7 and 50 < kept < 5000 for n_lr, kept in res), res   # (4.4 bp per SNP: most of a diagonal block's pairs are short-range)
 
 
 def test_ragged_block_whole_against_c_oracle(engine):
