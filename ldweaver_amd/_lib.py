@@ -92,6 +92,7 @@ _SIGS = {
     "ldw_path_report": (C.c_int, [_p, _p, C.c_char_p, C.c_int]),
     "ldw_set_prune": (C.c_int, [_p, C.c_int]),
     "ldw_prune_report": (C.c_int, [_p, _p]),
+    "ldw_ctx_reserve": (C.c_int, [_p, C.c_int64, C.c_int64, C.c_int64]),
     "ldw_set_span": (C.c_int, [_p, C.c_int, C.c_int]),
     "ldw_span_report": (C.c_int, [_p, _p]),
     "ldw_set_pair_cap": (C.c_int, [C.c_uint32]),

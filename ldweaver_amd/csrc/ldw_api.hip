@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <thread>
 #include "ldw_internal.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -250,13 +251,82 @@ int ldw_ctx_create(int device, ldw_ctx **out) {
     LDW_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
     for (auto &e : c->ev) LDW_HIP(hipEventCreate(&e));
+    // r04: the two extra streams of the all-pairs loop (hipStreamCreate: 12 ms each on this box), its events and pinned pick records are made
+    // WITH the context, and the code objects of the pass's kernels (loaded at the first launch of a kernel of each translation unit
+    // otherwise) by a side thread that starts with it — not inside the first pass of the job.  Joined by the entry points (join_prepare).
+    static const bool no_prep = getenv("LDW_NO_PREPARE") != nullptr;
+    if (!no_prep) {
+        // (the streams here, synchronously: a side thread inside hipStreamCreate slowed the caller's upload of the alignment from 9.5 to 17 ms)
+        if (int rc = ldw::ensure_streams(c)) {
+            *out = c;
+            return rc;
+        }
+        c->prep_thread = new std::thread([c] {
+            int rc = LDW_OK;
+            if (hipSetDevice(c->device) != hipSuccess) rc = LDW_ERR_HIP;
+            if (rc == LDW_OK) {
+                ldw::warm_mi();
+                ldw::warm_apx();
+                ldw::warm_gemm_bits();
+                ldw::warm_srp();
+                ldw::warm_post();
+            }
+            if (rc != LDW_OK) c->prep_err = ldw_last_error();
+            c->prep_rc = rc;
+        });
+    }
     *out = c;
+    return LDW_OK;
+}
+
+// r04: the pinned staging buffers of the all-pairs loop (hipHostMalloc: 0.2 ms per MB on this box; three of ~12 MB) and their device
+// images, sized from the block geometry, by a second side thread — while the caller uploads the alignment and runs the Hamming GEMM.
+// (tools/scratch/malloc_probe.cpp: hipMalloc itself is 0.02-0.25 ms whatever the size; what a first pass paid for was hipStreamCreate —
+// now made with the context —, hipHostMalloc, the code-object loads and ensure_rows.)  Optional: everything is also made lazily.
+int ldw_ctx_reserve(ldw_ctx *c, int64_t L, int64_t N, int64_t max_blk_sz) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(L > 0 && N > 0 && max_blk_sz > 0, LDW_ERR_ARG, "ldw_ctx_reserve: L, N and max_blk_sz must be positive");
+    if (c->prep_thread2) {   // an earlier reservation: finish it first
+        if (c->prep_thread2->joinable()) c->prep_thread2->join();
+        delete c->prep_thread2;
+        c->prep_thread2 = nullptr;
+    }
+    static const bool no_prep = getenv("LDW_NO_PREPARE") != nullptr;
+    if (no_prep) return LDW_OK;
+    const int64_t blk = std::min<int64_t>(L, max_blk_sz);
+    const int64_t nblk = (L + blk - 1) / blk;
+    const int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(c->span_on ? c->span_max : 1, nblk - 2));
+    // the packed staging image of a span (prep_block): index, row and permutation lists of both sides, 48 bytes of intervals per to-side SNP
+    const int64_t nt = blk * nseg, rows_f = blk * 5 / 4 + 512, rows_t = nt * 5 / 4 + 512;
+    const size_t stage = (size_t)((blk + nt) * 12 + (rows_f + rows_t) * 9 + nt * 52 + (blk + 64) * 16 + (rows_t / 128 + 1) * (rows_f / 64 + 1) + 65536);
+    const int64_t Npad = (N + ldw::KSTEP - 1) / ldw::KSTEP * ldw::KSTEP;
+    c->prep_thread2 = new std::thread([c, stage, Npad, blk, nseg] {
+        int rc = LDW_OK;
+        if (hipSetDevice(c->device) != hipSuccess) rc = LDW_ERR_HIP;
+        if (rc == LDW_OK) rc = ldw::reserve_slot_buffers(c, Npad, blk, nseg);
+        for (int k = 0; k < LDW_NSLOT && rc == LDW_OK; ++k) {
+            if (c->pin_cap[k] >= stage) continue;
+            if (c->pin[k]) (void)hipHostFree(c->pin[k]);
+            c->pin[k] = nullptr;
+            c->pin_cap[k] = 0;
+            if (hipHostMalloc(&c->pin[k], stage * 2, hipHostMallocDefault) != hipSuccess) {
+                ldw::set_error("ldw_ctx_reserve: hipHostMalloc of %zu bytes failed", stage * 2);
+                rc = LDW_ERR_HIP;
+                break;
+            }
+            c->pin_cap[k] = stage * 2;
+            if (c->dstage[k].reserve(stage * 2) != LDW_OK) rc = LDW_ERR_HIP;
+        }
+        if (rc != LDW_OK) c->prep_err2 = ldw_last_error();
+        c->prep_rc2 = rc;
+    });
     return LDW_OK;
 }
 
 int ldw_ctx_destroy(ldw_ctx *c) {
     if (!c) return LDW_OK;
     (void)hipSetDevice(c->device);
+    (void)ldw::join_prepare(c);
     (void)hipStreamSynchronize(c->stream);
     ldw::DevBuf *bufs[] = {&c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->apx_skip, &c->snp_sup, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
@@ -721,6 +791,10 @@ int ldw_set_snp_meta(ldw_ctx *c, const double *r, const uint8_t *uqe, const int3
     c->g = g;
     c->have_meta = true;
     c->rows_ready = false;
+    // r04: with the alignment and the weights in place the row map (indicator rows, marginals, per-SNP bounds: ensure_rows, ~9 ms at C4) is
+    // built HERE — it belongs to handing over the data — instead of lazily inside the first block loop; a later ldw_set_weights
+    // invalidates it again and the next pass rebuilds it
+    if (c->L > 0 && c->have_weights) return ldw::ensure_rows(c);
     return LDW_OK;
 }
 

@@ -152,15 +152,15 @@ int prepare_apx_weights(ldw_ctx *c) {
     // The path pays when the approximation is tight enough for the screen to dismiss almost everything (its margin grows with
     // delta); the digit arrays of the GEMM must fit in LDS.  Any weights qualify: with many distinct values the popcount sums of
     // the listed pairs walk more segments per word, which is still cheap for the few pairs that are listed.
-    const size_t seg_bytes = segs.size() * sizeof(PopSeg) + (size_t)Npad / 8 + 64;   // k_pair_sums keeps the segment tables in LDS
-    c->apx_ok = delta <= 4e-3 && Npad <= 30720 && M2 > 0 && seg_bytes <= 60000;
+    // (r03 also required the popcount segment tables of k_pair_sums to fit 60 000 B of LDS, which switched the path off for ~3700 and more
+    // distinct weights; the kernel now reads larger tables from global memory)
+    c->apx_ok = delta <= 4e-3 && Npad <= 30720 && M2 > 0;
     {
         char why[160];
         if (c->apx_ok) snprintf(why, sizeof(why), c->apx_fine ? "ok (block exponents per 32 positions)" : "ok");
         else if (!(delta <= 4e-3)) snprintf(why, sizeof(why), "delta %.3g > 4e-03 (dual-digit weights too coarse)", delta);
         else if (Npad > 30720) snprintf(why, sizeof(why), "Npad %lld > 30720 (digit arrays exceed the GEMM's LDS)", (long long)Npad);
-        else if (M2 <= 0) snprintf(why, sizeof(why), "no macro step (Npad %lld)", (long long)Npad);
-        else snprintf(why, sizeof(why), "popcount segment tables %zu B > 60000 B of LDS (%zu segments)", seg_bytes, segs.size());
+        else snprintf(why, sizeof(why), "no macro step (Npad %lld)", (long long)Npad);
         c->apx_gate = why;
     }
     return LDW_OK;
@@ -880,6 +880,7 @@ struct PairArgs {
     const uint64_t *Mbits;
     int64_t KW;
     int nwords, path, nseg;      // 32-bit words per row; segment records
+    int seg_in_lds;              // the segment tables fit the workgroup's LDS (else they are read from global memory)
     const PopSeg *segs;
     const int32_t *wbeg, *row0;
     int32_t zero_row;
@@ -1000,9 +1001,14 @@ __global__ __launch_bounds__(256) void k_pair_sums(PairArgs P) {
     PopSeg *s_segs = reinterpret_cast<PopSeg *>(pop_smem + (((size_t)P.nwords + 4) * 4 + 15) / 16 * 16);
     const int path = GEN ? 4 : (int)blockIdx.z;
     if (blockIdx.x * 4u >= P.A.pl_n[path * PAIR_SHARDS + (int)blockIdx.y]) return;   // nothing for this workgroup
-    for (int i = threadIdx.x; i < P.nwords + 1; i += 256) s_wbeg[i] = P.wbeg[i];
-    for (int i = threadIdx.x; i < P.nseg; i += 256) s_segs[i] = P.segs[i];
-    __syncthreads();
+    if (P.seg_in_lds) {
+        for (int i = threadIdx.x; i < P.nwords + 1; i += 256) s_wbeg[i] = P.wbeg[i];
+        for (int i = threadIdx.x; i < P.nseg; i += 256) s_segs[i] = P.segs[i];
+        __syncthreads();
+    } else {   // r04: thousands of weight classes (N distinct weights): the tables stay in global memory (L2-resident: every wave reads the same records)
+        s_wbeg = const_cast<int32_t *>(P.wbeg);
+        s_segs = const_cast<PopSeg *>(P.segs);
+    }
     if constexpr (GEN) {
         pair_sums_body<4, 4>(P, 4, s_wbeg, s_segs);
     } else {
@@ -1144,8 +1150,9 @@ int launch_pairs_exact(ldw_ctx *c, const EpiArgs &A, unsigned long long *ghist, 
     P.A = A;
     P.ghist = ghist;
     // 1024 waves per list stride over its pairs (one wave per pair), then one lane per pair for the fp64 value
-    const size_t lds = (((size_t)P.nwords + 4) * 4 + 15) / 16 * 16 + (size_t)P.nseg * sizeof(PopSeg);
-    LDW_REQUIRE(lds <= 65536, LDW_ERR_ARG, "launch_pairs_exact: %d weight segments do not fit in LDS", P.nseg);
+    size_t lds = (((size_t)P.nwords + 4) * 4 + 15) / 16 * 16 + (size_t)P.nseg * sizeof(PopSeg);
+    P.seg_in_lds = lds <= 60000 ? 1 : 0;
+    if (!P.seg_in_lds) lds = 0;
     hipLaunchKernelGGL(k_pair_sums<false>, dim3(256, PAIR_SHARDS, 4), dim3(256), lds, st, P);
     hipLaunchKernelGGL(k_pair_sums<true>, dim3(256, PAIR_SHARDS, 1), dim3(256), lds, st, P);
     hipLaunchKernelGGL(k_pair_mi, dim3(64, PAIR_SHARDS, PAIR_PATHS), dim3(256), 0, st, P);
@@ -1153,4 +1160,12 @@ int launch_pairs_exact(ldw_ctx *c, const EpiArgs &A, unsigned long long *ghist, 
     return LDW_OK;
 }
 
+}  // namespace ldw
+
+namespace ldw {
+void warm_apx() {   // ldw_ctx_reserve: load this translation unit's code object ahead of its first launch
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_pack_panel));
+    (void)hipGetLastError();
+}
 }  // namespace ldw

@@ -235,3 +235,11 @@ int fill_rows_bits(ldw_ctx *c, const int32_t *d_rowinfo, int64_t R) {
 }
 
 }  // namespace ldw
+
+namespace ldw {
+void warm_gemm_bits() {   // ldw_ctx_reserve: load this translation unit's code object ahead of its first launch
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&gemm_bits_kernel<5>));
+    (void)hipGetLastError();
+}
+}  // namespace ldw

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/ldweaver_amd.h"
@@ -224,6 +225,12 @@ struct ldw_ctx {
     int screen = 1;                      // fp32 screen in front of the fp64 MI evaluation (0 off, 1 on, 2 verify)
     std::vector<ldw::BlockStat> stats;
     std::vector<ldw::BlockTrace> trace;
+    // ldw_ctx_reserve (r04): what a job's FIRST pass otherwise pays inside its timed loop — two hipStreamCreate (12 ms each on this box), the
+    // pinned staging buffers (hipHostMalloc: 0.2 ms per MB), the lazy load of the code objects of the pass's kernels — done by a side thread
+    // while the caller uploads the alignment and runs the Hamming GEMM.  Joined by every entry point that uses what it prepares.
+    std::thread *prep_thread = nullptr, *prep_thread2 = nullptr;   // started by ldw_ctx_create (streams, code objects) / ldw_ctx_reserve (staging buffers)
+    int prep_rc = 0, prep_rc2 = 0;
+    std::string prep_err, prep_err2;
 };
 
 namespace ldw {
@@ -242,4 +249,12 @@ int launch_cooc_popc(ldw_ctx *ctx, const int32_t *rowlist_t, int RTpad, const in
 int fill_rows_bits(ldw_ctx *ctx, const int32_t *d_rowinfo, int64_t R);
 int prepare_apx_weights(ldw_ctx *ctx);   // ldw_apx.hip: dual digits, exponents, popcount segments from h_vfixed / h_seq_perm
 int check_gpu(ldw_ctx *ctx);
+int join_prepare(ldw_ctx *ctx);      // waits for the side thread of ldw_ctx_reserve (no-op without one); its error, if any, becomes the caller's
+int reserve_slot_buffers(ldw_ctx *ctx, int64_t Npad, int64_t blk, int64_t nseg);   // ldw_mi.hip: per-slot device buffers from the block geometry
+int ensure_streams(ldw_ctx *ctx);    // the copy / GEMM streams, per-slot events and pinned pick records of the all-pairs loop (once per context)
+void warm_mi();                      // lazy code-object loads of the translation units whose kernels a pass launches (hipFuncGetAttributes)
+void warm_apx();
+void warm_gemm_bits();
+void warm_srp();
+void warm_post();
 }  // namespace ldw

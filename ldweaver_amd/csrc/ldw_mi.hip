@@ -2248,6 +2248,7 @@ const std::vector<int32_t> *minor_weight_order(ldw_ctx *c, const int32_t *idx, i
 // dense MI of one block, synchronous staging through ctx-owned buffers (ldw_mi_block, ldw_joint_tables style)
 int run_block_mi(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt, int quirk,
                  EmitArgs E) {
+    if (int rc = join_prepare(c)) return rc;
     if (int rc = ensure_rows(c)) return rc;
     LDW_REQUIRE(nf > 0 && nt > 0, LDW_ERR_ARG, "empty block (nf=%lld nt=%lld)", (long long)nf, (long long)nt);
     LDW_REQUIRE(nf <= 1000000 && nt <= 1000000, LDW_ERR_ARG, "block side too long");
@@ -3419,6 +3420,101 @@ bool can_submit_early(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p) {
 
 }  // namespace
 
+namespace ldw {
+int ensure_streams(ldw_ctx *c) {
+    if (!c->copy_stream) {
+        LDW_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < LDW_NSLOT; ++k) {
+            LDW_HIP(hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming));
+            LDW_HIP(hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
+        }
+        for (int k = 0; k < LDW_NSLOT; ++k) {
+            LDW_HIP(hipEventCreateWithFlags(&c->ev_pick[k], hipEventDisableTiming));
+            LDW_HIP(hipHostMalloc(&c->pin_pick[k], (size_t)LDW_SPAN_MAX * PICK_STRIDE + 64, hipHostMallocDefault));
+        }
+        LDW_HIP(hipEventCreateWithFlags(&c->ev_lrc, hipEventDisableTiming));
+        LDW_HIP(hipHostMalloc(&c->pin_lrc, 64, hipHostMallocDefault));
+        {   // the block-wide kernels (GEMM, screens) fill the chip; the tail of the previous block on the main stream is a chain of
+            // small latency-bound kernels that should be dispatched as soon as they are ready: lowest priority for this stream
+            int lo_p = 0, hi_p = 0;
+            LDW_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+            static const bool prio = getenv("LDW_NO_STREAM_PRIO") == nullptr;
+            // LDW_CU_RESERVE=m (odd, experiment): the GEMM stream may not use every m-th CU, so that the main stream's chain of small
+            // kernels always finds free CUs while a block-wide kernel runs (an odd modulus spreads the reserved CUs over the XCDs
+            // whether the mask bits run XCD by XCD or interleave them)
+            static const int cu_mod = [] { const char *e = getenv("LDW_CU_RESERVE"); return e ? atoi(e) : 0; }();
+            if (cu_mod >= 3 && (cu_mod & 1)) {
+                int cus = 256;
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+                std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+                for (int i = 0; i < cus; ++i)
+                    if (i % cu_mod != cu_mod - 1) mask[(size_t)i / 32] |= 1u << (i % 32);
+                LDW_HIP(hipExtStreamCreateWithCUMask(&c->gemm_stream, (uint32_t)mask.size(), mask.data()));
+            } else if (prio) LDW_HIP(hipStreamCreateWithPriority(&c->gemm_stream, hipStreamNonBlocking, lo_p));
+            else LDW_HIP(hipStreamCreateWithFlags(&c->gemm_stream, hipStreamNonBlocking));
+        }
+        for (int k = 0; k < LDW_NSLOT; ++k) LDW_HIP(hipEventCreateWithFlags(&c->ev_gemm[k], hipEventDisableTiming));
+    }
+    return LDW_OK;
+}
+
+int join_prepare(ldw_ctx *c) {
+    if (!c) return LDW_OK;
+    int rc = LDW_OK;
+    for (int which = 0; which < 2; ++which) {
+        std::thread *&t = which == 0 ? c->prep_thread : c->prep_thread2;
+        if (!t) continue;
+        if (t->joinable()) t->join();
+        delete t;
+        t = nullptr;
+        int &trc = which == 0 ? c->prep_rc : c->prep_rc2;
+        if (trc != LDW_OK && rc == LDW_OK) {
+            rc = trc;
+            set_error("side thread of %s: %s", which == 0 ? "ldw_ctx_create" : "ldw_ctx_reserve", (which == 0 ? c->prep_err : c->prep_err2).c_str());
+        }
+        trc = LDW_OK;
+    }
+    return rc;
+}
+
+// ldw_ctx_reserve's side thread: the per-slot device buffers of a pass of blocks of `blk` SNPs (spans of up to nseg of them), from estimates
+// of the row counts (1.25 rows per SNP + padding; a C4 block has 1.16) — whatever turns out too small grows where it is used, as before.
+int reserve_slot_buffers(ldw_ctx *c, int64_t Npad, int64_t blk, int64_t nseg) {
+    const int64_t KW = Npad / 64;
+    const int64_t nt = blk * nseg;
+    const size_t RF = (size_t)((blk * 5 / 4 + 512 + 127) / 128 * 128), RT = (size_t)((nt * 5 / 4 + 512 + 127) / 128 * 128);
+    const size_t nf_tiles = (size_t)(blk / 64 + 6), nf_slots = nf_tiles * 64;
+    const size_t n_units = nf_tiles * (size_t)nt;
+    const size_t cap = pair_cap_for(blk, nt, (int)nseg);
+    const size_t o_cph = ((size_t)nt * sizeof(ColMeta) + 255) / 256 * 256, o_rph = ((size_t)nf_slots * sizeof(RowPack) + 255) / 256 * 256;
+    const size_t one = (size_t)blk * (size_t)blk;
+    for (int s = 0; s < LDW_NSLOT; ++s) {
+        if (int rc = c->panel[s][0].reserve(RF * (size_t)KW * 8)) return rc;
+        if (int rc = c->panel[s][1].reserve(RT * (size_t)KW * 8)) return rc;
+        if (int rc = c->Gapx[s].reserve(RF * RT * 4)) return rc;
+        if (int rc = c->apx_units[s].reserve(64 + 2 * n_units * 8 + 64)) return rc;
+        if (int rc = c->apx_packs[s].reserve(2 * o_cph + 2 * o_rph + ((size_t)blk + (size_t)nt) * 4 + 1024)) return rc;
+        if (int rc = c->pairs[s].reserve(256 + (size_t)PAIR_PATHS * PAIR_SHARDS * cap * sizeof(PairEnt))) return rc;
+        if (int rc = c->apx_bins[s].reserve(2 * (RT + RF) + (size_t)nt + nf_slots + 256 + (RT / 128) * (RF / 64) * 4)) return rc;
+        if (int rc = c->apx_clean[s].reserve((RT / 32) * (RF / 64) + 64)) return rc;
+        if (int rc = c->hist[s].reserve((size_t)nseg * NBINS * 8)) return rc;
+        const size_t cand = std::max<size_t>(one, (size_t)nseg * std::min<size_t>(one, (size_t)PAIR_PATHS * PAIR_SHARDS * cap));
+        if (int rc = c->cand_key[s].reserve(cand * 8)) return rc;
+        if (int rc = c->cand_val[s].reserve(cand * 8)) return rc;
+        if (int rc = gx(c, s).reserve(RF * RF * 8)) return rc;   // the exact 5-limb sums of a single block's band tiles
+    }
+    if (int rc = c->pair_sums.reserve((size_t)PAIR_PATHS * PAIR_SHARDS * cap * 16 * 8)) return rc;
+    return LDW_OK;
+}
+
+void warm_mi() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_zero4));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_mi_screen<1, true>));
+    (void)hipGetLastError();
+}
+}  // namespace ldw
+
 extern "C" {
 
 int ldw_mi_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt, int quirk_mode,
@@ -3496,6 +3592,7 @@ int ldw_joint_tables(ldw_ctx *c, const int32_t *pair_a, const int32_t *pair_b, i
 
 int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
     if (int rc = check_gpu(c)) return rc;
+    if (int rc = join_prepare(c)) return rc;
     LDW_REQUIRE(nblocks_capacity > 0, LDW_ERR_ARG, "ldw_links_begin: capacity must be positive");
     if (c->blk_capacity != 0) {
         // the previous pass never reached ldw_links_end (an error return in the middle of ldw_mi_all_pairs / ldw_mi_block_links): kernels of
@@ -3510,39 +3607,7 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
     const size_t need = 64 + (size_t)LDW_NSLOT * LDW_SPAN_MAX * PICK_STRIDE + (size_t)nblocks_capacity * 32 + 64;
     if (int rc = c->small.reserve(need)) return rc;
     LDW_HIP(hipMemsetAsync(c->small.p, 0, need, c->stream));
-    if (!c->copy_stream) {
-        LDW_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (int k = 0; k < LDW_NSLOT; ++k) {
-            LDW_HIP(hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming));
-            LDW_HIP(hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
-        }
-        for (int k = 0; k < LDW_NSLOT; ++k) {
-            LDW_HIP(hipEventCreateWithFlags(&c->ev_pick[k], hipEventDisableTiming));
-            LDW_HIP(hipHostMalloc(&c->pin_pick[k], (size_t)LDW_SPAN_MAX * PICK_STRIDE + 64, hipHostMallocDefault));
-        }
-        LDW_HIP(hipEventCreateWithFlags(&c->ev_lrc, hipEventDisableTiming));
-        LDW_HIP(hipHostMalloc(&c->pin_lrc, 64, hipHostMallocDefault));
-        {   // the block-wide kernels (GEMM, screens) fill the chip; the tail of the previous block on the main stream is a chain of
-            // small latency-bound kernels that should be dispatched as soon as they are ready: lowest priority for this stream
-            int lo_p = 0, hi_p = 0;
-            LDW_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-            static const bool prio = getenv("LDW_NO_STREAM_PRIO") == nullptr;
-            // LDW_CU_RESERVE=m (odd, experiment): the GEMM stream may not use every m-th CU, so that the main stream's chain of small
-            // kernels always finds free CUs while a block-wide kernel runs (an odd modulus spreads the reserved CUs over the XCDs
-            // whether the mask bits run XCD by XCD or interleave them)
-            static const int cu_mod = [] { const char *e = getenv("LDW_CU_RESERVE"); return e ? atoi(e) : 0; }();
-            if (cu_mod >= 3 && (cu_mod & 1)) {
-                int cus = 256;
-                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-                std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
-                for (int i = 0; i < cus; ++i)
-                    if (i % cu_mod != cu_mod - 1) mask[(size_t)i / 32] |= 1u << (i % 32);
-                LDW_HIP(hipExtStreamCreateWithCUMask(&c->gemm_stream, (uint32_t)mask.size(), mask.data()));
-            } else if (prio) LDW_HIP(hipStreamCreateWithPriority(&c->gemm_stream, hipStreamNonBlocking, lo_p));
-            else LDW_HIP(hipStreamCreateWithFlags(&c->gemm_stream, hipStreamNonBlocking));
-        }
-        for (int k = 0; k < LDW_NSLOT; ++k) LDW_HIP(hipEventCreateWithFlags(&c->ev_gemm[k], hipEventDisableTiming));
-    }
+    if (int rc = ensure_streams(c)) return rc;
     // everything queued on the main stream so far (row map, weights) must be visible to the GEMM stream
     LDW_HIP(hipEventRecord(c->ev_up[0], c->stream));
     LDW_HIP(hipStreamWaitEvent(c->gemm_stream, c->ev_up[0], 0));
@@ -3684,8 +3749,14 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(blocks && p && nblocks > 0, LDW_ERR_ARG, "ldw_mi_all_pairs: bad argument");
     LDW_REQUIRE(reset, LDW_ERR_ARG, "ldw_mi_all_pairs: appending to earlier calls is not supported (reset must be 1)");
+    static const bool host_timing0 = getenv("LDW_HOST_TIMING") != nullptr;
+    auto now0 = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_enter = now0();
+    if (int rc = join_prepare(c)) return rc;
+    const double t_joined = now0();
     if (int rc = ldw_links_begin(c, nblocks)) return rc;
     if (int rc = links_check(c, p)) return rc;
+    const double t_begun = now0();
     SmallLayout sl;
     links_layout(c, sl);
     std::vector<int32_t> fi, ti;
@@ -3699,19 +3770,26 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         for (int32_t k = ts; k <= te; ++k) ti[k - ts] = k - 1;
         return LDW_OK;
     };
-    if (p->keep_sr && nblocks > 200 && c->pos_sorted) {  // big runs: size the short-range table once (its row count follows from POS alone)
-                                        // instead of growing it geometrically, which would double-buffer tens of GB
-        int64_t total_sr = 0;
-        std::vector<ColInfo> cols;
-        for (int64_t b = 0; b < nblocks; ++b) {
-            if (int rc = fill(b)) return rc;
-            int64_t n_sr_blk = 0;
-            const bool diag = same_list(fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size());
-            if (int rc = build_cols(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), diag, p->sr_dist, cols, n_sr_blk))
-                return rc;
-            total_sr += n_sr_blk;
+    if (p->keep_sr && c->pos_sorted && 2 * p->sr_dist < c->g) {
+        // Size the short-range table ONCE: geometric growth re-copies up to a gigabyte and synchronises both streams every time (ten times in
+        // the first pass of C4), and would double-buffer tens of GB at C5.  The blocks of a pass hold every unordered SNP pair at most once,
+        // so the number of pairs within sr_dist on the circle bounds the rows: POS ascends — a two-pointer walk, O(L) (r03 ran build_cols
+        // over every block for this, 0.2 ms each, and only for passes of more than 200 blocks).
+        const int64_t Ls = c->L;
+        const std::vector<int32_t> &P = c->h_POS;
+        int64_t total_sr = 0, hi = 0, wlo = 0;
+        for (int64_t a = 0; a < Ls; ++a) {
+            if (hi < a + 1) hi = a + 1;
+            while (hi < Ls && (double)P[(size_t)hi] - (double)P[(size_t)a] <= p->sr_dist) ++hi;
+            total_sr += hi - a - 1;                                   // partners ahead of a, directly
         }
-        if (int rc = ensure_links_capacity(c, total_sr, 0)) return rc;
+        for (int64_t a = 0; a < Ls; ++a) {   // partners across the origin: b before a with P[b] + g - P[a] <= sr_dist (the limit ascends with a)
+            const double lim = p->sr_dist - c->g + (double)P[(size_t)a];
+            if (lim < (double)P[0]) continue;
+            while (wlo < Ls && (double)P[(size_t)wlo] <= lim) ++wlo;
+            total_sr += std::min<int64_t>(wlo, a);
+        }
+        if (int rc = ensure_links_capacity(c, total_sr + 1024, 0)) return rc;
     }
     // Software pipeline, three ITEMS deep on the host (an item = one block, or a span of consecutive long-range-only blocks of one block
     // row: r04): item i's epilogue chain is submitted (main stream), then at once the block-wide pass of item i+1 (GEMM stream; prepared
@@ -3872,6 +3950,10 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     }
     sh.cv.notify_all();
     const int64_t nitems = (int64_t)items.size();
+    const double t_planned = now0();
+    if (host_timing0)
+        fprintf(stderr, "[ldw host us] waiting for the side threads %.0f  links_begin (row map if stale, bookkeeping) %.0f  table sizing + cold-start probes + plan %.0f\n",
+                t_joined - t_enter, t_begun - t_joined, t_planned - t_begun);
     // blocks until item k is prepared (true) — or, with wait = false, says whether it is
     auto prepped = [&](int64_t k, bool wait, int &rc) -> bool {
         std::unique_lock<std::mutex> lk(sh.m);
@@ -3933,10 +4015,14 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         }
         c->blk_cursor += items[(size_t)b].nseg;
     }
+    const double t_loop = now0();
+    const int rc_end = ldw_links_end(c);
+    if (host_timing)
+        fprintf(stderr, "[ldw host us] item loop %.0f  links_end %.0f  whole call %.0f\n", t_loop - t_planned, now0() - t_loop, now0() - t_enter);
     if (host_timing)
         fprintf(stderr, "[ldw host us/item] submit_b %.1f  wait for the helper's prep %.1f  submit_a (incl. that wait) %.1f  finish (incl. wait) %.1f  items %lld (blocks %lld)\n", th[0] / nitems, th[1] / nitems,
                 th[2] / nitems, th[3] / nitems, (long long)nitems, (long long)nblocks);
-    return ldw_links_end(c);
+    return rc_end;
 }
 
 int ldw_set_span(ldw_ctx *c, int on, int max_blocks) {
@@ -3993,6 +4079,7 @@ int ldw_links_count(ldw_ctx *c, int which, int64_t *n_out) {
 
 int ldw_links_device_ptrs(ldw_ctx *c, int which, const int32_t **a_out, const int32_t **b_out, const double **MI_out, int64_t *n_out) {
     if (int rc = check_gpu(c)) return rc;
+    if (int rc = join_prepare(c)) return rc;
     LDW_REQUIRE((which == 0 || which == 1) && a_out && b_out && MI_out && n_out, LDW_ERR_ARG, "ldw_links_device_ptrs: bad argument");
     LDW_REQUIRE(c->blk_capacity == 0, LDW_ERR_STATE, "ldw_links_device_ptrs: a link pass is still open (ldw_links_end)");
     LDW_HIP(hipStreamSynchronize(c->stream));
@@ -4022,6 +4109,7 @@ int ldw_links_fetch(ldw_ctx *c, int which, int32_t *a_out, int32_t *b_out, doubl
 
 int ldw_links_import(ldw_ctx *c, int which, const int32_t *a, const int32_t *b, const double *MI, int64_t n, int on_device) {
     if (int rc = check_gpu(c)) return rc;
+    if (int rc = join_prepare(c)) return rc;
     LDW_REQUIRE(which == 0 || which == 1, LDW_ERR_ARG, "ldw_links_import: which must be 0 (sr) or 1 (lr)");
     LDW_REQUIRE(n >= 0 && (n == 0 || (a && b && MI)), LDW_ERR_ARG, "ldw_links_import: bad argument");
     LDW_REQUIRE(c->blk_capacity == 0, LDW_ERR_STATE, "ldw_links_import: a link pass is still open (ldw_links_end)");

@@ -335,3 +335,11 @@ int ldw_ldmap(ldw_ctx *c, int32_t reducer, int32_t from, int32_t to, int64_t *n_
 }
 
 }  // extern "C"
+
+namespace ldw {
+void warm_post() {   // ldw_ctx_reserve: load this translation unit's code object ahead of its first launch
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_mi_keys));
+    (void)hipGetLastError();
+}
+}  // namespace ldw

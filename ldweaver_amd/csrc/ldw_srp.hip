@@ -721,3 +721,11 @@ int ldw_aracne_device(ldw_ctx *c, int64_t capacity, uint8_t *flags_out) {
 }
 
 }  // extern "C"
+
+namespace ldw {
+void warm_srp() {   // ldw_ctx_reserve: load this translation unit's code object ahead of its first launch
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_sr_tag));
+    (void)hipGetLastError();
+}
+}  // namespace ldw

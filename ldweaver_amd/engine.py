@@ -146,7 +146,12 @@ class Engine:
         L.check(L.lib().ldw_set_engine(self._ctx, int(engine)))
 
     # -- alignment -----------------------------------------------------------
-    def set_alignment(self, states):
+    def reserve(self, L_snps: int, N_seqs: int, max_blk_sz: int = 10000):
+        """Start the side thread that creates the pass's streams, pinned staging buffers and code objects (ldw_ctx_reserve) — behind the
+        upload of the alignment and the Hamming GEMM instead of inside the first pass.  Optional; set_alignment calls it."""
+        L.check(L.lib().ldw_ctx_reserve(self._ctx, int(L_snps), int(N_seqs), int(max_blk_sz)))
+
+    def set_alignment(self, states, max_blk_sz: int = 10000):
         """states: (L, N) uint8 numpy array or CUDA torch tensor (values 0..4)."""
         if _is_torch(states):
             assert states.dtype.__str__() == "torch.uint8" and states.dim() == 2 and states.is_contiguous()
@@ -162,6 +167,9 @@ class Engine:
             Ls, Ns = st.shape
             L.check(L.lib().ldw_set_alignment(self._ctx, L.ptr(st), Ls, Ns, 0))
         self.L, self.N = int(Ls), int(Ns)
+        if not getattr(self, "_reserved", False):
+            self._reserved = True
+            self.reserve(self.L, self.N, max_blk_sz)   # (a side thread: the pinned staging buffers, while the caller goes on to the Hamming weights)
 
     def alignment_scan(self, chars: np.ndarray) -> np.ndarray:
         """Upload the raw (N, L_total) alignment and return the 5 x L_total allele counts of every column."""

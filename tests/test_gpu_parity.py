@@ -1954,14 +1954,15 @@ def test_ragged_block_whole_against_c_oracle(engine):
     assert res[1][0] == 10_000 * 5_000 - 5_000 and all(kept > 1000 for _, kept in res), res
 
 
-@pytest.mark.parametrize("case", ["npad_gate", "segment_gate"])
+@pytest.mark.parametrize("case", ["npad_gate", "many_classes"])
 def test_gates_of_the_approximate_path_fall_back_to_the_limb_paths(engine, case):
-    """the two gates of the approximate path that no test reached (prepare_apx_weights, ldw_apx.hip).  (i) more
-    than 30 720 padded sequences — the two digit arrays no longer fit the GEMM's LDS beside its tables: N = 30 848; (ii) so many
-    weight classes that the popcount segment tables of k_pair_sums exceed 60 000 bytes of LDS: 4000 DISTINCT weights.  Either way
-    ldw_path_report names the gate, the blocks run the limb paths (mixed precision: 3 high limbs + gathered low limbs) with the screen,
-    and the link tables equal the plain path's bit for bit.  (The third fallback — a pair list that overflows — is forced in
-    test_spans_equal_block_by_block with ldw_set_pair_cap.)"""
+    """the gates of the approximate path that no test reached (prepare_apx_weights, ldw_apx.hip).  (i) more than
+    30 720 padded sequences — the two digit arrays no longer fit the GEMM's LDS beside its tables: N = 30 848: ldw_path_report names the
+    gate, the blocks run the limb paths (mixed precision: 3 high limbs + gathered low limbs) with the screen.  (ii) r03's third gate —
+    so many weight classes that the popcount segment tables of k_pair_sums exceed 60 000 bytes of LDS: 4000 DISTINCT weights — is GONE
+    (r04: the kernel reads such tables from global memory): the approximate path runs.  Either way the link tables equal the plain
+    path's bit for bit.  (The remaining fallback — a pair list that overflows — is forced in test_spans_equal_block_by_block with
+    ldw_set_pair_cap.)"""
     if case == "npad_gate":
         Ls, N = 2_400, 30_848
     else:
@@ -1973,28 +1974,28 @@ def test_gates_of_the_approximate_path_fall_back_to_the_limb_paths(engine, case)
     uqe = (cnt > 0).T.astype(np.float64)
     r = uqe.sum(axis=1)
     hdw = engine.hamming_weights(int(Ls * 0.1))
-    if case == "segment_gate":
+    if case == "many_classes":
         u = ((np.arange(N, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1 << 32)).astype(np.float64) / float(1 << 32)
         hdw = 1.0 / (1.0 + 49.0 * u)
     engine.set_weights(hdw)
     POS, g = syn["POS"], float(syn["g"])
     engine.set_snp_meta(r, uqe, POS, syn["paint"], g)
     info, rep = engine.apx_info(), engine.path_report()
-    assert not info["usable"], info
     if case == "npad_gate":
-        assert "Npad" in rep["apx_gate"] and "30720" in rep["apx_gate"], rep
+        assert not info["usable"] and "Npad" in rep["apx_gate"] and "30720" in rep["apx_gate"], (info, rep)
     else:
-        assert "segment" in rep["apx_gate"] and info["delta"] <= 4e-3, (rep, info)
+        assert info["usable"] and info["classes"] == N and info["segments"] * 16 > 60000 and info["delta"] <= 4e-3, (rep, info)
     approx = MIH.lr_links_approx(POS, g, 20000.0)
     blocks = MIH.make_blocks(Ls, 1200)
     lr_retain = 4000.0    # 0.14 % of the 2.9e6 pairs: speculation is the automatic choice
     out = {}
     try:
-        for key, (mixed, scr, path) in dict(plain=(False, 0, 1), default=(True, 1, 0)).items():
+        for key, (mixed, scr, path) in dict(plain=(False, 0, 1), default=(True, 1, 0), verify=(True, 2, 0)).items():
             engine.set_mixed(mixed)
             engine.set_screen(scr)
             engine.set_path(path)
-            engine.reset_speculation()
+            if key != "verify":
+                engine.reset_speculation()
             c0 = engine.counters()
             for _ in range(2):
                 engine.mi_all_pairs(blocks, 20000.0, lr_retain, approx)
@@ -2005,10 +2006,15 @@ def test_gates_of_the_approximate_path_fall_back_to_the_limb_paths(engine, case)
         engine.set_screen(1)
         engine.set_path(0)
     d = out["default"][3]
-    assert d["apx_blocks"] == 0 and d["mixed_blocks"] >= len(blocks), d     # the gate sent every speculative block to the limb paths
-    for which in (0, 1):
-        for x, y in zip(out["plain"][which], out["default"][which]):
-            assert np.array_equal(x, y), (case, which)
-    for k in ("n_lr_total", "n_lr_kept", "n_sr", "disc_thresh"):
-        assert np.array_equal(out["plain"][2][k], out["default"][2][k]), (case, k)
+    if case == "npad_gate":
+        assert d["apx_blocks"] == 0 and d["mixed_blocks"] >= len(blocks), d     # the gate sent every speculative block to the limb paths
+    else:
+        assert d["apx_blocks"] >= len(blocks) and d["apx_pairs_listed"] > 0, d   # ... and here the approximate path ran, its pair sums from global tables
+    assert out["verify"][3]["screen_violations"] == 0
+    for key in ("default", "verify"):
+        for which in (0, 1):
+            for x, y in zip(out["plain"][which], out[key][which]):
+                assert np.array_equal(x, y), (case, key, which)
+        for k in ("n_lr_total", "n_lr_kept", "n_sr", "disc_thresh"):
+            assert np.array_equal(out["plain"][2][k], out[key][2][k]), (case, key, k)
     assert len(out["plain"][1][2]) > 1000
