@@ -29,7 +29,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
-#include <hipcub/hipcub.hpp>
+#include "ldw_prim.h"
 
 #include "ldw_internal.h"
 #include "ldw_dev.h"
@@ -3092,17 +3092,17 @@ int select_rows(ldw_ctx *c, const SelIn &S, bool do_lr, const SmallLayout &sl) {
         if (int rc = c->cand_key2.reserve((size_t)m * 8)) return rc;
         if (int rc = c->cand_val2.reserve((size_t)m * 8)) return rc;
         size_t tmp_bytes = 0;
-        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
+        LDW_HIP(prim_sort_pairs(nullptr, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
                                                    c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
         if (int rc = c->scratch.reserve(tmp_bytes)) return rc;
-        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
+        LDW_HIP(prim_sort_pairs(c->scratch.p, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
                                                    c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
         hipLaunchKernelGGL(k_lr_thresh, dim3(1), dim3(64), 0, c->stream, c->cand_key2.as<uint64_t>(), S.pick);
         LDW_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_lr_mark, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
                            c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), S.pick, ck, cv, (long long)m);
         LDW_HIP(hipGetLastError());
-        LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
+        LDW_HIP(prim_sort_pairs(c->scratch.p, tmp_bytes, ck, c->cand_key2.as<uint64_t>(), cv,
                                                    c->cand_val2.as<uint64_t>(), (int)m, 0, 64, c->stream));
         hipLaunchKernelGGL(k_lr_append, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
                            c->cand_key2.as<uint64_t>(), c->cand_val2.as<uint64_t>(), S.pick, S.idx_f, S.idx_t, (int)S.nf,

@@ -13,7 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <hipcub/hipcub.hpp>
+#include "ldw_prim.h"
 #include <vector>
 
 #include "ldw_internal.h"
@@ -186,10 +186,10 @@ int ldw_lr_tukey(ldw_ctx *c, int64_t min_links, const int32_t *sr_a, const int32
     const int grid = (int)std::min<int64_t>((n + 255) / 256, 16384);
     hipLaunchKernelGGL(k_mi_keys, dim3(grid), dim3(256), 0, c->stream, c->lr_mi.as<double>(), n, c->ar_key.as<uint64_t>());
     size_t tb = 0;
-    LDW_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, c->ar_key.as<uint64_t>(), c->ar_key2.as<uint64_t>(), (int)n, 0, 64, c->stream));
+    LDW_HIP(prim_sort_keys(nullptr, tb, c->ar_key.as<uint64_t>(), c->ar_key2.as<uint64_t>(), (int)n, 0, 64, c->stream));
     if (int rc = c->scratch.reserve(tb)) return rc;
     tb = c->scratch.cap;
-    LDW_HIP(hipcub::DeviceRadixSort::SortKeys(c->scratch.p, tb, c->ar_key.as<uint64_t>(), c->ar_key2.as<uint64_t>(), (int)n, 0, 64, c->stream));
+    LDW_HIP(prim_sort_keys(c->scratch.p, tb, c->ar_key.as<uint64_t>(), c->ar_key2.as<uint64_t>(), (int)n, 0, 64, c->stream));
     auto order_stats = [&](double p, double &q) -> int {
         const Q7 r = q7_ranks(n, p);
         uint64_t k[2];
@@ -215,11 +215,11 @@ int ldw_lr_tukey(ldw_ctx *c, int64_t min_links, const int32_t *sr_a, const int32
         if (ns > 0) hipLaunchKernelGGL(k_count_gt, dim3((unsigned)nseg_s), dim3(256), 0, c->stream, d_smi, ns, t, cnt_s);
         LDW_HIP(hipGetLastError());
         size_t sb = 0;
-        LDW_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, cnt_l, off_l, (int)nseg_l, c->stream));
+        LDW_HIP(prim_exclusive_sum(nullptr, sb, cnt_l, off_l, (int)nseg_l, c->stream));
         if (int rc = c->scratch.reserve(sb)) return rc;
         sb = c->scratch.cap;
-        LDW_HIP(hipcub::DeviceScan::ExclusiveSum(c->scratch.p, sb, cnt_l, off_l, (int)nseg_l, c->stream));
-        if (ns > 0) LDW_HIP(hipcub::DeviceScan::ExclusiveSum(c->scratch.p, sb, cnt_s, off_s, (int)nseg_s, c->stream));
+        LDW_HIP(prim_exclusive_sum(c->scratch.p, sb, cnt_l, off_l, (int)nseg_l, c->stream));
+        if (ns > 0) LDW_HIP(prim_exclusive_sum(c->scratch.p, sb, cnt_s, off_s, (int)nseg_s, c->stream));
         int64_t last[4] = {0, 0, 0, 0};
         LDW_HIP(hipMemcpyAsync(&last[0], off_l + nseg_l - 1, 8, hipMemcpyDeviceToHost, c->stream));
         LDW_HIP(hipMemcpyAsync(&last[1], cnt_l + nseg_l - 1, 8, hipMemcpyDeviceToHost, c->stream));
@@ -291,10 +291,10 @@ int ldw_ldmap(ldw_ctx *c, int32_t reducer, int32_t from, int32_t to, int64_t *n_
     if (ns > 0) hipLaunchKernelGGL(k_mark_used, grid_of(ns), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), ns, POS, from, to, windowed, used);
     LDW_HIP(hipGetLastError());
     size_t sb = 0;
-    LDW_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, used, rank, (int)(L + 1), c->stream));
+    LDW_HIP(prim_exclusive_sum(nullptr, sb, used, rank, (int)(L + 1), c->stream));
     if (int rc = c->scratch.reserve(sb)) return rc;
     sb = c->scratch.cap;
-    LDW_HIP(hipcub::DeviceScan::ExclusiveSum(c->scratch.p, sb, used, rank, (int)(L + 1), c->stream));
+    LDW_HIP(prim_exclusive_sum(c->scratch.p, sb, used, rank, (int)(L + 1), c->stream));
     int32_t n_pos = 0;
     LDW_HIP(hipMemcpyAsync(&n_pos, rank + L, 4, hipMemcpyDeviceToHost, c->stream));
     LDW_HIP(hipStreamSynchronize(c->stream));

@@ -22,7 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <hipcub/hipcub.hpp>
+#include "ldw_prim.h"
 #include <vector>
 
 #include "ldw_internal.h"
@@ -488,20 +488,20 @@ int ldw_sr_len_quantiles(ldw_ctx *c, int nclust, double sr_dist, double prob, in
                        c->sr_mi.as<double>(), n, c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, sr_dist, pack, key);
     // Two stable LSD sorts, both over the FULL width of their key type: by MI (u64 keys, tags as values), then by len
     // (u16 keys, {MI key, tag} as values) -> ordered by (len, MI).  rocPRIM 7.2's merge-sort path mis-sorts u32 keys on a
-    // partial bit range at mid sizes (reproduced standalone with hipcub::DeviceRadixSort::SortKeys), so no begin_bit/end_bit tricks here.
+    // partial bit range at mid sizes (reproduced standalone through the hipCUB interface), so no begin_bit/end_bit tricks here.
     if (int rc = c->srm_pay.reserve((size_t)n * sizeof(SrPay))) return rc;
     if (int rc = c->srm_pay2.reserve((size_t)n * sizeof(SrPay))) return rc;
     uint16_t *len16 = reinterpret_cast<uint16_t *>(pack), *len16b = len16 + n;   // pack is free after the first sort
     SrPay *pay = c->srm_pay.as<SrPay>(), *pay2 = c->srm_pay2.as<SrPay>();
     size_t t1 = 0, t2 = 0;
-    LDW_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t1, key, key2, pack, pack2, n, 0, 64, c->stream));
-    LDW_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t2, len16, len16b, pay, pay2, n, 0, 16, c->stream));
+    LDW_HIP(prim_sort_pairs(nullptr, t1, key, key2, pack, pack2, n, 0, 64, c->stream));
+    LDW_HIP(prim_sort_pairs(nullptr, t2, len16, len16b, pay, pay2, n, 0, 16, c->stream));
     if (int rc = c->scratch.reserve(std::max(t1, t2))) return rc;
     size_t tb = c->scratch.cap;
-    LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tb, key, key2, pack, pack2, n, 0, 64, c->stream));
+    LDW_HIP(prim_sort_pairs(c->scratch.p, tb, key, key2, pack, pack2, n, 0, 64, c->stream));
     hipLaunchKernelGGL(k_sr_split, dim3(grid), dim3(256), 0, c->stream, pack2, key2, n, len16, pay);
     tb = c->scratch.cap;
-    LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tb, len16, len16b, pay, pay2, n, 0, 16, c->stream));
+    LDW_HIP(prim_sort_pairs(c->scratch.p, tb, len16, len16b, pay, pay2, n, 0, 16, c->stream));
     hipLaunchKernelGGL(k_sr_seg_offsets, dim3((S + 2 + 255) / 256), dim3(256), 0, c->stream, len16b, n, S, c->srm_off.as<int64_t>());
     LDW_HIP(hipMemcpyAsync(c->srm_q.p, q.data(), cells * 16, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_sr_quant, dim3(S), dim3(256), 0, c->stream, pay2, c->srm_off.as<int64_t>(), S, nclust, prob,
@@ -700,11 +700,11 @@ int ldw_aracne_device(ldw_ctx *c, int64_t capacity, uint8_t *flags_out) {
     hipLaunchKernelGGL(k_ar_edges, dim3(grid), dim3(256), 0, c->stream, c->pool_a.as<int32_t>(), c->pool_b.as<int32_t>(),
                        c->pool_mi.as<double>(), np, c->ar_key.as<uint64_t>(), c->ar_val.as<double>());
     size_t tb = 0;
-    LDW_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, c->ar_key.as<uint64_t>(), c->ar_key2.as<uint64_t>(), c->ar_val.as<double>(),
+    LDW_HIP(prim_sort_pairs(nullptr, tb, c->ar_key.as<uint64_t>(), c->ar_key2.as<uint64_t>(), c->ar_val.as<double>(),
                                                c->ar_val2.as<double>(), n2, 0, 64, c->stream));
     if (int rc = c->scratch.reserve(tb)) return rc;
     tb = c->scratch.cap;
-    LDW_HIP(hipcub::DeviceRadixSort::SortPairs(c->scratch.p, tb, c->ar_key.as<uint64_t>(), c->ar_key2.as<uint64_t>(),
+    LDW_HIP(prim_sort_pairs(c->scratch.p, tb, c->ar_key.as<uint64_t>(), c->ar_key2.as<uint64_t>(),
                                                c->ar_val.as<double>(), c->ar_val2.as<double>(), n2, 0, 64, c->stream));
     hipLaunchKernelGGL(k_ar_offsets, dim3((unsigned)((L + 1 + 255) / 256)), dim3(256), 0, c->stream, c->ar_key2.as<uint64_t>(), n2, L,
                        c->ar_off.as<int64_t>());
