@@ -224,7 +224,9 @@ int ldw_prune_report(ldw_ctx *ctx, int64_t out[4]);
 /* r04 — spans.  The reference's loop visits the block pairs of a block row one at a time (R/computePairwiseMI.R:103-116); consecutive
  * LONG-RANGE-ONLY block pairs of one row (same from range, to ranges ascending, no pair within sr_dist) are run as ONE launch sequence
  * over their concatenated to side, every reference block keeping its own histogram, threshold, candidate list and place in the append
- * order (the lr filter is per block: :352-358).  Results never depend on it.  ldw_set_span: on != 0 (default), at most max_blocks
+ * order (the lr filter is per block: :352-358).  Results never depend on it.  ldw_set_span: on != 0 (default; on = 3 also lets CORNER
+ * block pairs — the neighbouring pair of the row, the pair that closes the circle: a few short-range pairs — join the spans, their
+ * short-range pairs evaluated by an SR sub-pass: correct, measured slower on MI355X, so not the default), at most max_blocks
  * (2..8; 0 keeps the current value) reference blocks per span.  ldw_span_report: out[0] spans run, out[1] reference blocks they covered,
  * out[2] segments redone on their own after a wrong guess, out[3] on.
  * ldw_set_pair_cap (tests only): a fixed capacity for the pair lists of the approximate path (0: automatic) — a list that overflows makes

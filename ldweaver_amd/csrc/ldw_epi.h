@@ -276,7 +276,9 @@ struct EpiArgs {
     // sflag_f[64 * tile + lane], sflag_t[column slot]
     const uint8_t *sflag_f, *sflag_t;
     const double *snp_sup;    // [L][4] (k_snp_sup)
-    int span;                 // > 0: the to side is the concatenation of `span` reference blocks (segments), all long-range-only, nt of each = nf
+    int sr_excl;              // 1: the block's short-range pairs are evaluated elsewhere (an SR sub-pass over the same block in list order): the
+                              // screens only keep them out of the long-range candidates and never list a unit for them (E.any_sr is 0 then)
+    int span;                 // > 0: the to side is the concatenation of `span` reference blocks (segments), nt of each = nf
     SpanSeg sseg[LDW_SPAN_MAX];
     EmitArgs E;
 };

@@ -133,8 +133,11 @@ struct ldw_ctx {
     int64_t apx_waves_skipped = 0, apx_waves_total = 0;
     // Spans (r04): consecutive long-range-only blocks of one block row run as ONE launch sequence over their concatenated to side
     bool span_on = true;               // ldw_set_span / LDW_NO_SPAN
+    bool span_corners = false;         // ldw_set_span(on | 2) / LDW_SPAN_CORNERS: corner blocks join the spans (SR sub-passes); measured slower, off by default
     int span_max = 8;                  // most reference blocks per span (LDW_SPAN_MAX env, <= ldw::LDW_SPAN_MAX)
     int64_t span_items = 0, span_blocks = 0, span_fallbacks = 0;   // spans run, reference blocks they covered, segments redone non-speculatively
+    int64_t span_sr_subs = 0;          // SR sub-passes run for corner segments of spans
+    bool early_sr = false;             // this pass assigns an item's short-range rows when the item is SUBMITTED (submit order = block order), not in its second phase
     std::atomic<int64_t> sorted_blocks{0};   // (prep_block runs on the helper thread and, for the cold-start probes, on the calling thread at once)
     std::mutex order_mtx;                    // guards order_cache
     // Per-SNP bound behind the pruning of the wider tables (k_snp_sup): snp_sup[a * 4 + 2 * m + (k - 2)] = the largest MI SNP a (2 or

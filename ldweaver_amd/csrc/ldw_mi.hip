@@ -155,7 +155,7 @@ __device__ __forceinline__ void append_pairs(const EpiArgs &A, int path, unsigne
 
 template <int NA, int NB, int U, int RM, bool APX>
 __device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc, bool a_ok, float lo, int q0) {
-    const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0, do_lr = A.E.do_lr != 0;
+    const bool test_sr = A.E.any_sr != 0 || A.sr_excl != 0, keep_sr = A.E.keep_sr != 0 && !A.sr_excl, do_lr = A.E.do_lr != 0;
     FullCells<NA, NB> C[U];
     if (do_lr) {   // an SR-only pass needs no MI here at all: a unit is wanted iff it holds a short-range pair
 #pragma unroll
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_build_tab11(double W, double lo, double
 template <int U, int RM>
 __device__ __forceinline__ unsigned int screen_cols_tab(const EpiArgs &A, const RowSide &R, int binA, const ColMeta *cmu, int a_loc, bool a_ok, float lo,
                                                         int q0) {
-    const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0;
+    const bool test_sr = A.E.any_sr != 0 || A.sr_excl != 0, keep_sr = A.E.keep_sr != 0 && !A.sr_excl;
     int n[U];
     int2 th[U];
 #pragma unroll
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void k_mi_screen_generic(EpiArgs A, const int3
     if (n_it <= 0) return;
     const int rxy_mode = A.quirk == LDW_QUIRK_REFERENCE ? (A.span ? 3 : (square ? 1 : 2)) : 0;
     const float lo = (float)A.E.spec_lo - A.E.scr_eps;
-    const bool test_sr = A.E.any_sr != 0, keep_sr = A.E.keep_sr != 0, do_lr = A.E.do_lr != 0;
+    const bool test_sr = A.E.any_sr != 0 || A.sr_excl != 0, keep_sr = A.E.keep_sr != 0 && !A.sr_excl, do_lr = A.E.do_lr != 0;
     unsigned int wanted = 0, mine = 0;   // mine: the units of this wave that belong to this kernel
     for (int it = 0; it < n_it; ++it) {
         // the same split as k_mi_screen's: its domain is tile < gen_t0 and q < gen_q0, where it takes the fast units and
@@ -1690,6 +1690,8 @@ struct LoHost {
     int ordered = 0;                     // rows of the one-row SNPs in order of the minor state's weight (prep_block: tile pruning)
     int fuse_ok = 0;                     // rows of one-row SNPs sit at their slot index in both row lists (no SNP without a row): the
                                          // GEMM's epilogue may apply the threshold table by row (ApxGemmArgs::fuse)
+    int sr_sub = 0;                      // an SR sub-pass (short-range pairs of a span's corner segment): see HostBlock::sr_sub
+    int sr_excl = 0;                     // the block's short-range pairs are evaluated by an SR sub-pass: keep them out of the candidates, list no unit for them
     int span = 0;                        // reference blocks on the to side (0: an ordinary block); sseg: their candidate lists / histograms
     const SpanSeg *sseg = nullptr;
 };
@@ -1728,6 +1730,7 @@ void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFp
     A.tab_nb = 0;
     A.tab_c = 0;
     A.span = 0;
+    A.sr_excl = 0;
     memset(A.sseg, 0, sizeof(A.sseg));
     A.E = E;
     memset(&A.lo, 0, sizeof(A.lo));
@@ -1930,8 +1933,9 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
 // ------------------------------------------------------------------------------------------------
 int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E, hipEvent_t *ev, int phase,
                      hipStream_t gs, unsigned long long *ghist, const LoHost *lo_h, void *zero_hist = nullptr, void *zero_pick = nullptr,
-                     size_t zero_pick_bytes = 0) {
+                     size_t zero_pick_bytes = 0, hipStream_t s2 = nullptr) {
     const int s = lo_h->slot;
+    if (!s2) s2 = c->stream;   // stream of phase 2 (an SR sub-pass runs both phases on the GEMM stream)
     E.nf = (int)nf;
     E.MI = nullptr;
     dim3 egrid((unsigned)(D.nf_tiles > 0 ? D.nf_tiles : (nf + 63) / 64), (unsigned)((nt + EPI_COLS - 1) / EPI_COLS));
@@ -1948,7 +1952,8 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     const bool use_pairs = E.scr_mode == 1 && E.do_lr;   // verify mode keeps whole units: it must see the dismissed ones
     // units are evaluated from EXACT sums: the 5-limb GEMM of the tiles they live in (all tiles when any unit can be listed)
     const bool need_exact = E.any_sr || !use_pairs || lo_h->band_full;
-    const uint8_t *band = (use_pairs && !lo_h->band_full) ? D.band_mask : nullptr;
+    // (an SR sub-pass only ever lists units that hold a short-range pair: the band's tiles are all the exact GEMM has to cover)
+    const uint8_t *band = ((use_pairs || lo_h->sr_sub) && !lo_h->band_full) ? D.band_mask : nullptr;
     ldw::DevBuf &Gx = gx(c, s);
     if (phase == 1) {
         if (int rc = c->panel[s][0].reserve((size_t)RFpad * c->KW * 8)) return rc;
@@ -1996,6 +2001,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     EpiArgs A;
     fill_epi_args(c, D, nf, nt, RFpad, quirk, E, reinterpret_cast<const int64_t *>(c->Gapx[s].p), A);
     A.lo.slot_pfix_hi = c->slot_papx.as<int64_t>();   // the screen derives its cells from the marginals of the approximate weights
+    A.sr_excl = lo_h->sr_excl;
     if (lo_h->span) {
         LDW_REQUIRE(E.scr_mode == 1 && E.do_lr && !E.any_sr && !lo_h->band_full && lo_h->fuse_ok && lo_h->sseg, LDW_ERR_STATE, "a span needs long-range-only blocks and pair lists");
         A.span = lo_h->span;
@@ -2126,7 +2132,10 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     A.rowpack_hi = rph;
     // LDW_SCREEN_MAIN=1 (experiment): the block's screen at the head of phase 2 on the main stream — beside the NEXT block's GEMM on the GEMM
     // stream — instead of behind its own GEMM
-    static const bool screen_main = getenv("LDW_SCREEN_MAIN") != nullptr;
+    // r04: a SPAN's screen does run at the head of phase 2 (main stream): with the corner blocks inside the spans the GEMM stream carried 32 ms of a
+    // 39 ms pass (approximate GEMMs, every screen, the SR sub-passes) and the main stream 18 (profiles/r04_timeline_*); LDW_SPAN_SCREEN_GS=1 keeps it behind the GEMM
+    static const bool screen_main_env = getenv("LDW_SCREEN_MAIN") != nullptr, span_screen_gs = getenv("LDW_SPAN_SCREEN_GS") != nullptr;
+    const bool screen_main = screen_main_env || (lo_h->span > 0 && !span_screen_gs);
     const int rm_s = quirk == LDW_QUIRK_REFERENCE ? (lo_h->span ? 3 : (nf == nt ? 1 : 2)) : 0;
 #define LDW_SCREEN(RMv, ST) hipLaunchKernelGGL((k_mi_screen<RMv, true>), egrid, dim3(256), 0, ST, A, D.perm, D.perm_t, units, n_units, list_stride)
     if (phase == 1) {
@@ -2138,9 +2147,9 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         return LDW_OK;
     }
     // ---- phase 2 ----
-    LDW_HIP(hipEventRecord(ev[4], c->stream));
+    LDW_HIP(hipEventRecord(ev[4], s2));
     if (screen_main) {
-        if (rm_s == 0) LDW_SCREEN(0, c->stream); else if (rm_s == 1) LDW_SCREEN(1, c->stream); else if (rm_s == 3) LDW_SCREEN(3, c->stream); else LDW_SCREEN(2, c->stream);
+        if (rm_s == 0) LDW_SCREEN(0, s2); else if (rm_s == 1) LDW_SCREEN(1, s2); else if (rm_s == 3) LDW_SCREEN(3, s2); else LDW_SCREEN(2, s2);
         LDW_HIP(hipGetLastError());
     }
 #undef LDW_SCREEN
@@ -2157,16 +2166,16 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         Rg.ncg_b = Rg.nt_b > 0 ? (int)((nt - q0 + GEN_COLS - 1) / GEN_COLS) : 0;
         const long long nblk = (long long)Rg.nt_a * Rg.ncg_a + (long long)Rg.nt_b * Rg.ncg_b;
         if (nblk > 0)
-            hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3((unsigned)nblk), dim3(256), 0, c->stream, A, D.perm, D.perm_t, units, n_units, list_stride, Rg);
+            hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3((unsigned)nblk), dim3(256), 0, s2, A, D.perm, D.perm_t, units, n_units, list_stride, Rg);
     }
     LDW_HIP(hipGetLastError());
     if (need_exact)
         if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, Gx.as<int64_t>(), c->nlimbs, c->digits.as<int8_t>(),
-                                      E.lower_only, c->stream, 0, -1, band))
+                                      E.lower_only, s2, 0, -1, band))
             return rc;
     if (use_pairs) {
         if (int rc = c->pair_sums.reserve((size_t)PAIR_PATHS * PAIR_SHARDS * A.pl_cap * 16 * 8)) return rc;
-        if (int rc = launch_pairs_exact(c, A, ghist, c->pair_sums.as<int64_t>(), c->stream)) return rc;
+        if (int rc = launch_pairs_exact(c, A, ghist, c->pair_sums.as<int64_t>(), s2)) return rc;
     }
     if (need_exact) {   // the listed units, from the exact tiles
         EpiArgs Ax = A;
@@ -2177,16 +2186,16 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         memset(&UL, 0, sizeof(UL));
         UL.units[0] = units;
         UL.n[0] = n_units;
-        hipLaunchKernelGGL(k_mi_units<true>, dim3(2048, 1), dim3(256), 0, c->stream, Ax, D.perm, D.perm_t, UL, ghist);
+        hipLaunchKernelGGL(k_mi_units<true>, dim3(2048, 1), dim3(256), 0, s2, Ax, D.perm, D.perm_t, UL, ghist);
         UnitLists UG;
         memset(&UG, 0, sizeof(UG));
         UG.units[0] = units + list_stride;
         UG.n[0] = n_units + 1;
-        hipLaunchKernelGGL(k_mi_units<false>, dim3(512, 1), dim3(256), 0, c->stream, Ax, D.perm, D.perm_t, UG, ghist);
+        hipLaunchKernelGGL(k_mi_units<false>, dim3(512, 1), dim3(256), 0, s2, Ax, D.perm, D.perm_t, UG, ghist);
     }
-    hipLaunchKernelGGL(k_apx_stats, dim3(1), dim3(64), 0, c->stream, n_units, A.pl_n, A.pl_cap, A.E.scr_viol + 1);
+    hipLaunchKernelGGL(k_apx_stats, dim3(1), dim3(64), 0, s2, n_units, A.pl_n, A.pl_cap, A.E.scr_viol + 1);
     LDW_HIP(hipGetLastError());
-    LDW_HIP(hipEventRecord(ev[2], c->stream));
+    LDW_HIP(hipEventRecord(ev[2], s2));
     return LDW_OK;
 }
 
@@ -2343,6 +2352,17 @@ struct HostBlock {
     int pin_slot = -1;                 // staging buffer the lists were built in (-1: the slot's own)
     bool force_plain = false;          // never speculate: a span's segment that is redone after a wrong guess
     bool span_alone = false;           // the span could not be submitted as one (no positive guess): its blocks run one by one in finish_span
+    // r04b: short-range pairs of a span's CORNER segments (the neighbouring block pair of the row, the pair that closes the circle) are evaluated by an SR
+    // sub-pass over that block alone, in list order (band GEMM + whole units: the r03 machinery in its SR-only form), queued in front of the span's
+    // own kernels; the span treats the segment as long-range-only and keeps the short-range pairs out of its candidates (EpiArgs::sr_excl)
+    bool sr_sub = false;               // this HostBlock IS such a sub-pass (list order, no ordering of its rows)
+    size_t stage_base = 0;             // offset of its image in the item's staging buffer
+    int64_t sr_base = 0;               // first row of the item's short-range rows (set when the item is submitted: submit order = block order)
+    int64_t seg_n_sr[LDW_SPAN_MAX] = {};
+    std::vector<HostBlock> subs;       // the SR sub-passes of a span (at most one per segment), subs_seg[i] = its segment
+    std::vector<int> subs_seg;
+    size_t stage_total = 0;            // bytes of the item's whole staging image (its own lists + those of its sub-passes); 0: total
+    bool sr_base_fixed = false;        // sr_base was assigned by the caller (a span's segment that runs alone): do not touch the running row count
     std::vector<int32_t> span_from, span_to;   // the span's SNP lists (host): what a segment that runs on its own is prepared from
 };
 
@@ -2364,7 +2384,7 @@ static inline bool speculation_pays(const ldw_ctx *c, const ldw_mi_params *p) {
 }
 
 int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt, const ldw_mi_params *p,
-               int slot, int64_t blk_no, HostBlock &hb, const SpanPlan *sp = nullptr, int pin_slot = -1) {
+               int slot, int64_t blk_no, HostBlock &hb, const SpanPlan *sp = nullptr, int pin_slot = -1, bool sr_sub = false, size_t stage_base = 0) {
     LDW_REQUIRE(nf > 0 && nt > 0, LDW_ERR_ARG, "empty block (nf=%lld nt=%lld)", (long long)nf, (long long)nt);
     LDW_REQUIRE(nf <= 1000000 && nt <= 1000000 && nf * nt < 2147483647LL, LDW_ERR_ARG, "block too large (%lld x %lld)",
                 (long long)nf, (long long)nt);
@@ -2378,6 +2398,8 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     hb.slot = slot;
     hb.blk_no = blk_no;
     hb.pin_slot = pin_slot;
+    hb.sr_sub = sr_sub;
+    hb.stage_base = stage_base;
     hb.diag = same_list(from_idx, nf, to_idx, nt);
     SideLists SF, ST;
     std::vector<ColInfo> cols;
@@ -2392,10 +2414,22 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
         memset(&z, 0, sizeof(z));
         cols.assign((size_t)nt, z);
         hb.n_sr_blk = 0;
+    } else if (sp) {
+        // a span: the intervals segment by segment (the long-range-only ones leave build_cols at its range test; one pass over the
+        // concatenated list would take the slow path for all of them as soon as ONE segment is a corner block)
+        cols.resize((size_t)nt);
+        std::vector<ColInfo> ck;
+        for (int k = 0; k < sp->nseg; ++k) {
+            int64_t n_k = 0;
+            if (int rc = build_cols(c, from_idx, nf, to_idx + sp->start[k], sp->nt[k], false, p->sr_dist, ck, n_k)) return rc;
+            std::copy(ck.begin(), ck.end(), cols.begin() + sp->start[k]);
+        }
+        hb.n_sr_blk = 0;
     } else if (int rc = build_cols(c, from_idx, nf, to_idx, nt, hb.diag, p->sr_dist, cols, hb.n_sr_blk)) return rc;
     if (sp) {   // a span: every column learns its reference block and where that block starts in the concatenated to side
-        LDW_REQUIRE(!hb.generic && !hb.diag && hb.n_sr_blk == 0 && sp->nseg >= 1 && sp->nseg <= LDW_SPAN_MAX, LDW_ERR_STATE,
-                    "span of %d blocks at block %lld is not long-range-only", sp->nseg, (long long)blk_no);
+        LDW_REQUIRE(!hb.generic && !hb.diag && sp->nseg >= 1 && sp->nseg <= LDW_SPAN_MAX, LDW_ERR_STATE,
+                    "span of %d blocks at block %lld cannot be formed", sp->nseg, (long long)blk_no);
+        hb.n_sr_blk = 0;   // (the span itself emits no short-range row: its corner segments' pairs belong to their SR sub-passes; the intervals stay: sr_excl)
         hb.span = sp->nseg;
         for (int k = 0; k < sp->nseg; ++k) {
             hb.seg_start[k] = sp->start[k];
@@ -2417,7 +2451,7 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     // every SNP has short-range partners there.
     const std::vector<int32_t> *ord_f = nullptr, *ord_t = nullptr;
     std::vector<int32_t> ord_f_own, ord_t_own, ord_f_full, ord_t_full;
-    if (c->prune && !hb.generic && !hb.diag && c->engine == LDW_ENGINE_MFMA && c->apx_ok && !c->fused) {
+    if (c->prune && !hb.generic && !hb.diag && !sr_sub && c->engine == LDW_ENGINE_MFMA && c->apx_ok && !c->fused) {
         bool rowless = false;
         for (int64_t k = 0; k < nf && !rowless; ++k) rowless = c->h_row0[from_idx[k] + 1] == c->h_row0[from_idx[k]];
         for (int64_t k = 0; k < nt && !rowless; ++k) rowless = c->h_row0[to_idx[k] + 1] == c->h_row0[to_idx[k]];
@@ -2622,14 +2656,15 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     hb.o_band = o; o = al(o + band.size());
     hb.total = o;
     const int ps = pin_slot >= 0 ? pin_slot : slot;
-    if (c->pin_cap[ps] < o) {
+    if (c->pin_cap[ps] < stage_base + o) {
+        void *np = nullptr;
+        LDW_HIP(hipHostMalloc(&np, (stage_base + o) * 2, hipHostMallocDefault));
+        if (c->pin[ps] && stage_base) memcpy(np, c->pin[ps], stage_base);   // (the images of the item's earlier parts)
         if (c->pin[ps]) LDW_HIP(hipHostFree(c->pin[ps]));
-        c->pin[ps] = nullptr;
-        c->pin_cap[ps] = 0;
-        LDW_HIP(hipHostMalloc(&c->pin[ps], o * 2, hipHostMallocDefault));
-        c->pin_cap[ps] = o * 2;
+        c->pin[ps] = np;
+        c->pin_cap[ps] = (stage_base + o) * 2;
     }
-    char *b = static_cast<char *>(c->pin[ps]);
+    char *b = static_cast<char *>(c->pin[ps]) + stage_base;
     memcpy(b + hb.o_idx_f, from_idx, (size_t)nf * 4);
     memcpy(b + hb.o_idx_t, to_idx, (size_t)nt * 4);
     memcpy(b + hb.o_rl_f, SF.rowlist.data(), SF.rowlist.size() * 4);
@@ -2670,11 +2705,16 @@ double lo_bound(const ldw_ctx *c) {
     return c->lo_abs_sum * (2.0 * std::log(den + 12.5) + 3.0) / den;
 }
 
+// device image of a block's index structures (its part of the item's staging buffer)
+static inline const char *stage_ptr(ldw_ctx *c, const HostBlock &hb) {
+    return c->dstage[hb.pin_slot >= 0 ? hb.pin_slot : hb.slot].as<char>() + hb.stage_base;
+}
+
 // what the emission of a block's pairs needs (short-range table, candidate list of this slot)
 int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl, int spec_B) {
     const int s = hb.slot;
     const bool do_lr = !p->sr_only;
-    const char *d = c->dstage[hb.pin_slot >= 0 ? hb.pin_slot : s].as<char>();
+    const char *d = stage_ptr(c, hb);
     EmitArgs E;
     memset(&E, 0, sizeof(E));
     E.cols = reinterpret_cast<const ColInfo *>(d + hb.o_cols);
@@ -2682,7 +2722,7 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
     E.lower_only = hb.diag ? 1 : 0;
     E.keep_sr = p->keep_sr ? 1 : 0;
     E.do_lr = do_lr ? 1 : 0;
-    E.sr_base = c->n_sr;
+    E.sr_base = (c->early_sr || hb.sr_base_fixed) ? hb.sr_base : c->n_sr;   // (early_sr: the rows were assigned when the item was submitted)
     E.sr_a = c->sr_a.as<int32_t>();
     E.sr_b = c->sr_b.as<int32_t>();
     E.sr_mi = c->sr_mi.as<double>();
@@ -2716,7 +2756,7 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
     E.write_dense = (do_lr && hb.spec_B < 0) ? 1 : 0;   // the dense block only feeds k_lr_gather; SR-only passes take the screen path
     E.spec_B = hb.spec_B;
     E.spec_lo = hb.spec_B > 0 ? bucket_lo(hb.spec_B) : -1e300;
-    E.any_sr = hb.n_sr_blk > 0 ? 1 : 0;
+    E.any_sr = (hb.n_sr_blk > 0 && !hb.span) ? 1 : 0;   // (a span never emits a short-range row itself: sr_excl)
     E.n_cand = &sl.pick[s]->n_cand;
     E.ckey = c->cand_key[s].as<uint64_t>();
     E.cval = c->cand_val[s].as<uint64_t>();
@@ -2786,22 +2826,49 @@ int launch_pick(ldw_ctx *c, const HostBlock &hb, const ldw_mi_params *p, const S
 //            previous block's epilogue / selection still uses, so it overlaps the tail of block b;
 //   fused:   GEMM + epilogue in one kernel, the bucket pick and the copy-back of the pick, all on the GEMM stream:
 //            the whole block overlaps the selection (sorts, host round trip) of the previous one.
-int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
-    const int s = hb.slot;
-    const int stg = hb.pin_slot >= 0 ? hb.pin_slot : s;   // (a span's segment that runs on its own is staged through the extra buffer)
-    if (int rc = c->dstage[stg].reserve(hb.total)) return rc;
-    // the device image and the per-slot buffers (G, histogram, pick, candidates) were last used by the block two steps back
-    if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_done[s], 0));
-    LDW_HIP(hipMemcpyAsync(c->dstage[stg].p, c->pin[stg], hb.total, hipMemcpyHostToDevice, c->copy_stream));
-    LDW_HIP(hipEventRecord(c->ev_up[s], c->copy_stream));
-    c->up_recorded[s] = true;
-    const char *d = c->dstage[stg].as<char>();
+static void fill_dev_ptrs(ldw_ctx *c, HostBlock &hb) {
+    const char *d = stage_ptr(c, hb);
     auto I = [&](size_t off) { return reinterpret_cast<const int32_t *>(d + off); };
     auto B = [&](size_t off) { return reinterpret_cast<const uint8_t *>(d + off); };
     hb.D = DevPtrs{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm), I(hb.o_perm_t),
                    I(hb.o_pos_f), I(hb.o_pos_t), B(hb.o_cls_f), B(hb.o_cls_t), I(hb.o_cmax),
                    reinterpret_cast<const int64_t *>(d + hb.o_tbase), I(hb.o_tf), B(hb.o_band), hb.nf_tiles, hb.gen_t0,
                    hb.gen_q0};
+}
+
+// The short-range pairs of one corner segment of a span: the block alone, in list order, through the SR-only form of the approximate path —
+// per-SNP constants, k_mi_screen (lists the units that hold a short-range pair: no MI needed for that), the exact 5-limb GEMM of the band's
+// tiles, k_mi_units (fp64 MI of the listed units; only the short-range pairs are emitted, to their final rows) — both phases on the GEMM
+// stream, in front of the span's own kernels, which then reuse the slot's buffers.
+int launch_sr_sub(ldw_ctx *c, HostBlock &sub, const ldw_mi_params *p, const SmallLayout &sl, hipStream_t gs, int64_t sr_base) {
+    fill_dev_ptrs(c, sub);
+    ldw_mi_params q = *p;
+    q.sr_only = 1;
+    sub.sr_base = sr_base;
+    sub.sr_base_fixed = true;
+    sub.apx = true;
+    sub.lo.apx = 1;
+    sub.lo.sr_sub = 1;
+    LDW_REQUIRE(!sub.lo.band_full && !sub.generic && sub.n_sr_blk > 0, LDW_ERR_STATE, "SR sub-pass of block %lld: unexpected block structure", (long long)sub.blk_no);
+    if (int rc = make_emit_args(c, sub, &q, sl, -1)) return rc;
+    hipEvent_t dummy[6] = {c->ev[3], c->ev[3], c->ev[3], c->ev[3], c->ev[3], c->ev[3]};
+    if (int rc = launch_block_apx(c, sub.D, sub.nf, sub.nt, sub.RFpad, sub.RTpad, p->quirk_mode, sub.E, dummy, 1, gs, nullptr, &sub.lo)) return rc;
+    if (int rc = launch_block_apx(c, sub.D, sub.nf, sub.nt, sub.RFpad, sub.RTpad, p->quirk_mode, sub.E, dummy, 2, gs, nullptr, &sub.lo, nullptr, nullptr, 0, gs)) return rc;
+    ++c->span_sr_subs;
+    return LDW_OK;
+}
+
+int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayout &sl) {
+    const int s = hb.slot;
+    const int stg = hb.pin_slot >= 0 ? hb.pin_slot : s;   // (a span's segment that runs on its own is staged through the extra buffer)
+    const size_t img = hb.stage_total ? hb.stage_total : hb.total;   // (a span's image includes the lists of its SR sub-passes)
+    if (int rc = c->dstage[stg].reserve(img)) return rc;
+    // the device image and the per-slot buffers (G, histogram, pick, candidates) were last used by the block two steps back
+    if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_done[s], 0));
+    LDW_HIP(hipMemcpyAsync(c->dstage[stg].p, c->pin[stg], img, hipMemcpyHostToDevice, c->copy_stream));
+    LDW_HIP(hipEventRecord(c->ev_up[s], c->copy_stream));
+    c->up_recorded[s] = true;
+    fill_dev_ptrs(c, hb);
     hb.submitted = true;
     if (c->engine != LDW_ENGINE_MFMA || hb.generic) return LDW_OK;
     hipStream_t gs = c->overlap ? c->gemm_stream : c->stream;   // overlap off: the stages of all blocks run back to back
@@ -2813,6 +2880,18 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     if ((int64_t)c->ev_valid.size() < hb.blk_no + std::max(1, hb.span)) c->ev_valid.resize((size_t)(hb.blk_no + std::max(1, hb.span)), 1);
     c->ev_valid[(size_t)hb.blk_no] = 1;
     for (int k = 1; k < hb.span; ++k) c->ev_valid[(size_t)hb.blk_no + k] = 0;   // (the span's stage events are its first block's; a segment that runs alone records its own)
+    if (c->early_sr && !hb.sr_base_fixed) {
+        // this pass assigns short-range rows in SUBMIT order (= block order): the SR sub-passes of a span write theirs from the GEMM stream, ahead
+        // of the second phase of the items before it
+        int64_t sr_add = 0;
+        if (p->keep_sr) {
+            if (hb.span) for (int k = 0; k < hb.span; ++k) sr_add += hb.seg_n_sr[k];
+            else sr_add = hb.n_sr_blk;
+        }
+        if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr)) return rc;
+        hb.sr_base = c->n_sr;
+        c->n_sr += sr_add;
+    }
     if (hb.span) {
         // a span runs the approximate path or not at all: should the state it was planned on have gone (no positive guess any more),
         // its reference blocks take the ordinary chain one after the other (finish_span)
@@ -2820,6 +2899,17 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
         if (!can) {
             hb.span_alone = true;
             return LDW_OK;
+        }
+    }
+    if (hb.span && !hb.subs.empty() && p->keep_sr) {
+        int64_t base = hb.sr_base;
+        size_t si = 0;
+        for (int k = 0; k < hb.span; ++k) {
+            if (si < hb.subs.size() && hb.subs_seg[si] == k) {
+                if (int rc = launch_sr_sub(c, hb.subs[si], p, sl, gs, base)) return rc;
+                ++si;
+            }
+            base += hb.seg_n_sr[k];
         }
     }
     hb.fused = c->fused && c->nlimbs <= 5 && (!do_lr || guess >= 0);
@@ -2854,6 +2944,7 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
             if (int rc = c->hist[s].reserve((size_t)NBINS * 8 * (size_t)(hb.span ? hb.span : 1))) return rc;
             hb.lo.span = hb.span;
             hb.lo.sseg = hb.sseg;
+            hb.lo.sr_excl = (hb.span && !hb.subs.empty()) ? 1 : 0;
             if (int rc = launch_block_apx(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, 1, gs, nullptr, &hb.lo, c->hist[s].p, sl.pick[s],
                                           PICK_STRIDE * (size_t)(hb.span ? hb.span : 1)))
                 return rc;
@@ -2990,7 +3081,7 @@ int submit_b(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_up[s], 0));
     if (c->engine == LDW_ENGINE_MFMA) LDW_HIP(hipStreamWaitEvent(c->stream, c->ev_gemm[s], 0));
     const bool do_lr = !p->sr_only;
-    const int64_t sr_add = p->keep_sr ? hb.n_sr_blk : 0;
+    const int64_t sr_add = (p->keep_sr && !c->early_sr && !hb.sr_base_fixed) ? hb.n_sr_blk : 0;   // (early_sr: assigned in submit_a)
     if (int rc = ensure_links_capacity(c, c->n_sr + sr_add, c->n_lr)) return rc;
     if (int rc = c->hist[s].reserve((size_t)NBINS * 8)) return rc;
     if (!hb.apx) LDW_HIP(hipMemsetAsync(c->hist[s].p, 0, (size_t)NBINS * 8, c->stream));   // (the approximate path zeroed both in its first phase: k_zero4)
@@ -3001,6 +3092,7 @@ int submit_b(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     if (hb.apx) {
         hb.lo.span = hb.span;
         hb.lo.sseg = hb.sseg;
+        hb.lo.sr_excl = (hb.span && !hb.subs.empty()) ? 1 : 0;
         if (int rc = launch_block_apx(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, 2, nullptr, c->hist[s].as<unsigned long long>(), &hb.lo))
             return rc;
     } else if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, c->engine == LDW_ENGINE_MFMA ? 2 : 3,
@@ -3169,7 +3261,7 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
         LDW_HIP(hipEventSynchronize(c->ev_lrc));
         memcpy(&c->n_lr, c->pin_lrc, 8);
     }
-    const char *d = c->dstage[hb.pin_slot >= 0 ? hb.pin_slot : s].as<char>();
+    const char *d = stage_ptr(c, hb);
     SelIn S;
     S.m = do_lr ? (int64_t)hp->n_cand : 0;
     S.nf = hb.nf;
@@ -3201,6 +3293,14 @@ int run_block_alone(ldw_ctx *c, const HostBlock &span, int k, const ldw_mi_param
     if (c->gemm_stream) LDW_HIP(hipStreamSynchronize(c->gemm_stream));
     if (int rc = prep_block(c, span.span_from.data(), span.nf, ti, span.seg_nt[k], p, span.slot, span.blk_no + k, hb, nullptr, LDW_NSLOT)) return rc;
     hb.force_plain = force_plain;
+    // the segment's short-range rows: their place was assigned with the span; after a wrong guess (force_plain) the span's SR sub-pass has
+    // already written them
+    ldw_mi_params q = *p;
+    if (force_plain) q.keep_sr = 0;
+    hb.sr_base = span.sr_base;
+    for (int j = 0; j < k; ++j) hb.sr_base += span.seg_n_sr[j];
+    hb.sr_base_fixed = true;
+    p = &q;
     if (int rc = submit_a(c, hb, p, sl)) return rc;
     if (int rc = submit_b(c, hb, p, sl)) return rc;
     if (int rc = finish_block(c, hb, p, sl)) return rc;
@@ -3228,7 +3328,7 @@ int finish_span(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLa
         LDW_HIP(hipEventSynchronize(c->ev_lrc));
         memcpy(&c->n_lr, c->pin_lrc, 8);
     }
-    const char *d = c->dstage[s].as<char>();
+    const char *d = stage_ptr(c, hb);
     if ((int64_t)c->trace.size() < hb.blk_no + hb.span) c->trace.resize((size_t)(hb.blk_no + hb.span));
     // the common case — every guess held, every candidate set fits the sort-free selection — takes ONE launch per stage for all segments
     static const bool sel_fast_on = getenv("LDW_NO_FAST_SELECT") == nullptr && getenv("LDW_NO_SPAN_SELECT") == nullptr;
@@ -3286,7 +3386,7 @@ int finish_span(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLa
             S.bitmap[k] = c->sel_bitmap.as<uint32_t>() + woff[k];
             S.chunks[k] = c->sel_chunks.as<uint32_t>() + coff[k];
             S.supers[k] = c->sel_prefix.as<uint32_t>() + (size_t)k * SEL_MAX_SUPER;
-            DA.n_sr[k] = 0;
+            DA.n_sr[k] = hb.seg_n_sr[k];
         }
         const unsigned gridm = (unsigned)std::max<long long>(1, (m_max + 255) / 256);
         hipLaunchKernelGGL(k_sel_thresh_span, dim3(1, (unsigned)hb.span), dim3(1024), 0, c->stream, S);
@@ -3326,7 +3426,7 @@ int finish_span(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLa
         S.nf = hb.nf;
         S.nt = hb.seg_nt[k];
         S.blk_no = hb.blk_no + k;
-        S.n_sr_blk = 0;
+        S.n_sr_blk = hb.seg_n_sr[k];
         S.ck = hb.sseg[k].ckey;
         S.cv = hb.sseg[k].cval;
         S.pick = reinterpret_cast<ldw::PickOut *>(reinterpret_cast<char *>(sl.pick[s]) + (size_t)k * PICK_STRIDE);
@@ -3617,6 +3717,7 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
         c->ev_pool.push_back(e);
     }
     for (int k = 0; k < LDW_NSLOT; ++k) c->done_recorded[k] = false;
+    c->early_sr = false;
     c->ev_valid.assign((size_t)nblocks_capacity, 1);
     c->lrc_recorded = false;
     c->n_sr = 0;
@@ -3723,15 +3824,31 @@ int ldw_links_end(ldw_ctx *c) {
 // A block can be part of a span when its to side lies strictly AFTER its from side (make_blocks order: i < j), it is square, far enough
 // from its from side that no pair is short-range (POS ascends over the alignment: the test of build_cols on the four end positions), and
 // neither side holds a SNP the fused table test cannot place (no indicator row, or unflagged slots: h_span_bad).
-static bool span_candidate(const ldw_ctx *c, const int32_t *b, const ldw_mi_params *p) {
+// Returns 0 (no), 1 (long-range-only) or 2 (a CORNER block: its few short-range pairs — the facing ends of two neighbouring blocks, or the two
+// ends of the circle — go to an SR sub-pass, the rest joins the span).
+static int span_candidate(const ldw_ctx *c, const int32_t *b, const ldw_mi_params *p) {
     const int64_t fs = b[0], fe = b[1], ts = b[2], te = b[3];
-    if (!(fs >= 1 && fe >= fs && ts > fe && te >= ts && te <= c->L)) return false;
+    if (!(fs >= 1 && fe >= fs && ts > fe && te >= ts && te <= c->L)) return 0;
     const int64_t nf = fe - fs + 1, nt = te - ts + 1;
-    if (nf != nt || nf < 2048) return false;
-    if ((int64_t)c->h_span_bad.size() != c->L + 1) return false;
-    if (c->h_span_bad[(size_t)fe] - c->h_span_bad[(size_t)fs - 1] != 0 || c->h_span_bad[(size_t)te] - c->h_span_bad[(size_t)ts - 1] != 0) return false;
-    const double pf_min = c->h_POS[(size_t)fs - 1], pf_max = c->h_POS[(size_t)fe - 1], pt_min = c->h_POS[(size_t)ts - 1], pt_max = c->h_POS[(size_t)te - 1];
-    return pt_min - pf_max > p->sr_dist && pf_min + c->g - pt_max > p->sr_dist && 2 * p->sr_dist < c->g;
+    if (nf != nt || nf < 2048) return 0;
+    if ((int64_t)c->h_span_bad.size() != c->L + 1) return 0;
+    if (c->h_span_bad[(size_t)fe] - c->h_span_bad[(size_t)fs - 1] != 0 || c->h_span_bad[(size_t)te] - c->h_span_bad[(size_t)ts - 1] != 0) return 0;
+    if (!(2 * p->sr_dist < c->g)) return 0;
+    const std::vector<int32_t> &P = c->h_POS;
+    const double pf_min = P[(size_t)fs - 1], pf_max = P[(size_t)fe - 1], pt_min = P[(size_t)ts - 1], pt_max = P[(size_t)te - 1];
+    if (pt_min - pf_max > p->sr_dist && pf_min + c->g - pt_max > p->sr_dist) return 1;
+    // Measured (C4, same box, 20 cold steps): spans of long-range-only blocks 36.0 ms per pass; with the corner blocks inside them 39.8 ms although the
+    // serialized kernel time fell from 36.6 to 35.2 ms — 20 large items instead of 28 alternate "diagonal block, span of eight" and the two queues no
+    // longer fill each other's gaps (profiles/r04_timeline_corner_spans.txt) — so corner blocks stay items of their own unless LDW_SPAN_CORNERS=1 /
+    // ldw_set_span(.., corners) asks for them (kept, tested: test_spans_equal_block_by_block runs both)
+    static const bool corners_env = getenv("LDW_SPAN_CORNERS") != nullptr;
+    if (!corners_env && !c->span_corners) return 0;
+    // short-range pairs of the block: POS ascends, so they sit where the two ranges face each other (directly, or across the origin)
+    auto count_le = [&](int64_t lo, int64_t hi, double v) { return (int64_t)(std::upper_bound(P.begin() + (lo - 1), P.begin() + hi, (int32_t)std::floor(v)) - (P.begin() + (lo - 1))); };
+    const int64_t f_tail = nf - count_le(fs, fe, pt_min - p->sr_dist - 1.0), t_head = count_le(ts, te, pf_max + p->sr_dist);      // from SNPs within sr_dist of the to side's first / to SNPs of the from side's last
+    const int64_t f_head = count_le(fs, fe, pt_max + p->sr_dist - c->g), t_tail = nt - count_le(ts, te, pf_min - p->sr_dist + c->g - 1.0);
+    const int64_t est = f_tail * t_head + f_head * t_tail;   // (an upper bound of the pair count; a quarter of a block's side at most per corner)
+    return (est > 0 && est <= 4000000 && f_tail <= nf / 4 && t_head <= nt / 4 && f_head <= nf / 4 && t_tail <= nt / 4) ? 2 : 0;
 }
 // what the whole pass must offer (checked once, after the cold-start probes: a positive guess for off-diagonal blocks exists)
 static bool spans_possible(const ldw_ctx *c, const ldw_mi_params *p) {
@@ -3742,7 +3859,8 @@ static bool spans_possible(const ldw_ctx *c, const ldw_mi_params *p) {
 }
 struct WorkItem {
     int64_t b0;
-    int nseg;   // 1: an ordinary block
+    int nseg;           // 1: an ordinary block
+    uint32_t sr_mask;   // segments of a span that are corner blocks (SR sub-pass)
 };
 
 int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const ldw_mi_params *p, int reset) {
@@ -3808,14 +3926,15 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     // the plan: items in block order.  Before the probes only the leading run of blocks that can never be part of a span is planned.
     std::vector<WorkItem> items;
     std::vector<uint8_t> cand((size_t)nblocks, 0);
-    for (int64_t b = 0; b < nblocks; ++b) cand[(size_t)b] = span_candidate(c, blocks + b * 4, p) ? 1 : 0;
+    for (int64_t b = 0; b < nblocks; ++b) cand[(size_t)b] = (uint8_t)span_candidate(c, blocks + b * 4, p);
     int64_t lead = 0;
     while (lead < nblocks && !cand[(size_t)lead]) ++lead;
-    for (int64_t b = 0; b < lead; ++b) items.push_back(WorkItem{b, 1});
+    for (int64_t b = 0; b < lead; ++b) items.push_back(WorkItem{b, 1, 0u});
     struct Shared {
         std::mutex m;
         std::condition_variable cv;
-        int64_t n_prepped = 0, n_sub = 0, n_done = 0, n_planned = 0;
+        int64_t n_sub = 0, n_done = 0, n_planned = 0, next = 0;   // next: the item the next free helper takes
+        std::vector<uint8_t> prepped;                              // per item (helpers finish out of order)
         bool plan_final = false;
         int rc = LDW_OK;
         bool stop = false, probing = true;   // probing: the cold-start probes (calling thread) still use the last slot's staging buffer
@@ -3823,19 +3942,24 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     } sh;
     sh.n_planned = (int64_t)items.size();
     sh.plan_final = lead == nblocks;
-    std::vector<int32_t> wfi, wti;   // the helper's own index lists
+    sh.prepped.assign((size_t)nblocks + 1, 0);
+    // r04: TWO helpers (a span of eight blocks with a corner segment takes ~3 ms of list building, a diagonal block in front of it gives the
+    // GPU 1.3 ms of work: one helper left the GEMM stream waiting).  Each takes the next item; items k, k+1, k+2 use different slots.
     auto worker = [&]() {
         (void)hipSetDevice(c->device);
-        for (int64_t k = 0;; ++k) {
-            WorkItem it{0, 0};
+        std::vector<int32_t> wfi, wti;   // this helper's own index lists
+        for (;;) {
+            WorkItem it{0, 0, 0u};
+            int64_t k = 0;
             {
                 std::unique_lock<std::mutex> lk(sh.m);
                 sh.cv.wait(lk, [&] {
                     if (sh.stop) return true;
-                    if (k >= sh.n_planned) return sh.plan_final;   // (plan complete and nothing left: leave)
-                    return k < sh.n_done + RING && k < sh.n_sub + LDW_NSLOT - (sh.probing ? 1 : 0);
+                    if (sh.next >= sh.n_planned) return sh.plan_final;   // (plan complete and nothing left: leave)
+                    return sh.next < sh.n_done + RING && sh.next < sh.n_sub + LDW_NSLOT - (sh.probing ? 1 : 0);
                 });
-                if (sh.stop || k >= sh.n_planned) return;
+                if (sh.stop || sh.next >= sh.n_planned) return;
+                k = sh.next++;
                 it = items[(size_t)k];
             }
             int rc = LDW_OK;
@@ -3869,6 +3993,26 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
                     if (rc == LDW_OK && it.nseg > 1) {
                         h.span_from = wfi;
                         h.span_to = wti;
+                        // the SR sub-passes of its corner segments: the block alone, in list order, behind the span's own image
+                        size_t base = (h.total + 255) / 256 * 256;
+                        for (int q = 0; q < it.nseg && rc == LDW_OK; ++q) {
+                            if (!((it.sr_mask >> q) & 1u)) continue;
+                            HostBlock sub;
+                            rc = prep_block(c, wfi.data(), (int64_t)wfi.size(), wti.data() + spn.start[q], spn.nt[q], p, slot, it.b0 + q, sub, nullptr, -1, true, base);
+                            if (rc != LDW_OK) break;
+                            if (sub.n_sr_blk <= 0) continue;   // (no pair within sr_dist after all)
+                            if (sub.lo.band_full || sub.generic) {
+                                set_error("corner block %lld cannot take an SR sub-pass", (long long)(it.b0 + q));
+                                rc = LDW_ERR_STATE;
+                                break;
+                            }
+                            h.seg_n_sr[q] = sub.n_sr_blk;
+                            h.seg_lr_total[q] -= sub.n_sr_blk;
+                            base = (base + sub.total + 255) / 256 * 256;
+                            h.subs.push_back(std::move(sub));
+                            h.subs_seg.push_back(q);
+                        }
+                        h.stage_total = base;
                     }
                 }
             } catch (const std::exception &e) {
@@ -3880,29 +4024,35 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
             }
             std::lock_guard<std::mutex> lk(sh.m);
             if (rc != LDW_OK) {
-                sh.rc = rc;
-                sh.err = ldw_last_error();
+                if (sh.rc == LDW_OK) {
+                    sh.rc = rc;
+                    sh.err = ldw_last_error();
+                }
                 sh.stop = true;
             } else {
-                sh.n_prepped = k + 1;
+                sh.prepped[(size_t)k] = 1;
             }
             sh.cv.notify_all();
             if (rc != LDW_OK) return;
         }
     };
-    std::thread helper(worker);
-    struct Joiner {   // every way out of this function stops and joins the helper
+    static const int n_helpers = [] { const char *e = getenv("LDW_HELPERS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 3 ? 3 : v); }();
+    std::thread helpers[3];
+    for (int i = 0; i < n_helpers; ++i) helpers[i] = std::thread(worker);
+    struct Joiner {   // every way out of this function stops and joins the helpers
         Shared &sh;
-        std::thread &t;
+        std::thread *t;
+        int n;
         ~Joiner() {
             {
                 std::lock_guard<std::mutex> lk(sh.m);
                 sh.stop = true;
             }
             sh.cv.notify_all();
-            if (t.joinable()) t.join();
+            for (int i = 0; i < n; ++i)
+                if (t[i].joinable()) t[i].join();
         }
-    } joiner{sh, helper};
+    } joiner{sh, helpers, n_helpers};
     // (the helper is already building the first blocks' lists while the probes run; it stays out of the last slot until they are done)
     // cold start: a sampled guess for each block kind that has none yet (probe_kind_guess), taken from the first block of the kind
     static const bool probe_on = getenv("LDW_NO_PROBE") == nullptr;
@@ -3939,9 +4089,13 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
                     ++n;
                 }
             }
-            rest.push_back(WorkItem{b, n});
+            uint32_t srm = 0;
+            for (int k = 0; k < n; ++k)
+                if (n > 1 && cand[(size_t)(b + k)] == 2) srm |= 1u << k;
+            rest.push_back(WorkItem{b, n, srm});
             b += n;
         }
+        c->early_sr = spans;
         std::lock_guard<std::mutex> lk(sh.m);
         items.insert(items.end(), rest.begin(), rest.end());
         sh.n_planned = (int64_t)items.size();
@@ -3957,10 +4111,10 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     // blocks until item k is prepared (true) — or, with wait = false, says whether it is
     auto prepped = [&](int64_t k, bool wait, int &rc) -> bool {
         std::unique_lock<std::mutex> lk(sh.m);
-        if (wait) sh.cv.wait(lk, [&] { return sh.rc != LDW_OK || sh.n_prepped > k; });
+        if (wait) sh.cv.wait(lk, [&] { return sh.rc != LDW_OK || sh.prepped[(size_t)k] != 0; });
         rc = sh.rc;
         if (rc != LDW_OK) set_error("%s", sh.err.c_str());
-        return sh.n_prepped > k;
+        return sh.prepped[(size_t)k] != 0;
     };
     int64_t n_sub = 0;   // items [0, n_sub) have been submitted to the GEMM stream
     auto submit_next = [&]() -> int {
@@ -4027,6 +4181,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
 
 int ldw_set_span(ldw_ctx *c, int on, int max_blocks) {
     LDW_REQUIRE(c && (max_blocks == 0 || (max_blocks >= 2 && max_blocks <= LDW_SPAN_MAX)), LDW_ERR_ARG, "ldw_set_span: max_blocks must be 0 or 2..%d", LDW_SPAN_MAX);
+    c->span_corners = (on & 2) != 0;   // bit 1: corner blocks (few short-range pairs) join the spans, their short-range pairs go to SR sub-passes (off by default: slower)
     c->span_on = on != 0;
     if (max_blocks) c->span_max = max_blocks;
     return LDW_OK;

@@ -1765,6 +1765,13 @@ def test_spans_equal_block_by_block(engine):
             # shorter spans give the same tables
             engine.set_span(True, 2)
             same(plain, run(quirk, True), (quirk, "spans of 2"))
+            # corner block pairs inside the spans (their short-range pairs through SR sub-passes): the same tables, short-range rows included
+            engine.set_span(True, 8, corners=True)
+            s2 = engine.span_report()
+            same(plain, run(quirk, True), (quirk, "spans with corner blocks, cold"))
+            same(plain, run(quirk, False), (quirk, "spans with corner blocks, warm"))
+            s3 = engine.span_report()
+            assert s3["blocks"] - s2["blocks"] >= 50, (s2, s3)    # (rows 0..5: every off-diagonal pair of the row in one span: 7 + 6 + 5 + 4 + 3 + 2, twice)
             engine.set_span(True, 8)
         # overflow: every pair list holds 64 entries -> every speculative block / segment is redone non-speculatively
         Engine.set_pair_cap(64)
