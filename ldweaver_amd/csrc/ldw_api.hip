@@ -339,7 +339,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
                            &c->pair_sums, &c->tab11[0], &c->tab11[1], &c->G2, &c->G3, &c->miss_key, &c->miss_val};
     for (auto *b : bufs) b->release();
     for (int k = 0; k < LDW_NSLOT; ++k)
-        for (ldw::DevBuf *b : {&c->panel[k][0], &c->panel[k][1], &c->Gapx[k], &c->pairs[k], &c->apx_units[k], &c->apx_packs[k], &c->apx_bins[k], &c->apx_clean[k],
+        for (ldw::DevBuf *b : {&c->panel[k][0], &c->panel[k][1], &c->Gapx[k], &c->pairs[k], &c->apx_units[k], &c->apx_packs[k], &c->apx_bins[k], &c->apx_clean[k], &c->scr_live[k],
                                &c->hist[k], &c->cand_key[k], &c->cand_val[k]})
             b->release();
     for (auto &e : c->ev)
@@ -791,6 +791,8 @@ int ldw_set_snp_meta(ldw_ctx *c, const double *r, const uint8_t *uqe, const int3
     c->g = g;
     c->have_meta = true;
     c->rows_ready = false;
+    c->sr_total = -1;
+    c->sr_total_dist = -1;
     // r04: with the alignment and the weights in place the row map (indicator rows, marginals, per-SNP bounds: ensure_rows, ~9 ms at C4) is
     // built HERE — it belongs to handing over the data — instead of lazily inside the first block loop; a later ldw_set_weights
     // invalidates it again and the next pass rebuilds it

@@ -692,9 +692,9 @@ __device__ __forceinline__ double pair_mi_full(const EpiArgs &A, const RowSide &
 // hi_cells (mixed-precision screen): the integer marginals pb / pa that the joint-table cells are derived from are those of
 // the high-limb weights, consistent with the high-limb G; the floating-point marginals stay the exact ones.
 __device__ __forceinline__ void stage_cols(const EpiArgs &A, const int32_t *__restrict__ perm_t, bool square, ColMeta *cm,
-                                           bool hi_cells = false) {
+                                           bool hi_cells = false, int cgy = -1) {   // cgy: column group (default: blockIdx.y)
     if (threadIdx.x < EPI_COLS) {
-        const int q = blockIdx.y * EPI_COLS + threadIdx.x;
+        const int q = (cgy >= 0 ? cgy : (int)blockIdx.y) * EPI_COLS + threadIdx.x;
         if (q < A.nt && A.colpack) {
             cm[threadIdx.x] = (hi_cells ? A.colpack_hi : A.colpack)[q];
         } else if (q < A.nt) {

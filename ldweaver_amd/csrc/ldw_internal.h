@@ -121,6 +121,7 @@ struct ldw_ctx {
     bool tab11_on = true;              // LDW_NO_TAB11 switches the table off (A/B measurements)
     ldw::DevBuf pair_sums;             // exact joint sums of the listed pairs (16 per pair)
     ldw::DevBuf pairs[LDW_NSLOT];              // per pipeline slot: pair lists of the approximate screen (counters + PAIR_PATHS x PAIR_SHARDS lists)
+    ldw::DevBuf scr_live[LDW_NSLOT];           // per slot: counter, per-tile summaries and the list of the (tile, column group) combinations the screen has work for
     ldw::DevBuf apx_bins[LDW_NSLOT], apx_clean[LDW_NSLOT];    // per slot: threshold-table bin of every row of the two row lists; clean-region flags of the GEMM epilogue
     ldw::DevBuf apx_units[LDW_NSLOT], apx_packs[LDW_NSLOT];   // per slot: per-(tile, class) unit lists + counters; per-block SNP constants
     int64_t apx_blocks = 0, apx_units_listed = 0, apx_pairs_listed = 0, probe_blocks = 0, generic_blocks = 0;
@@ -156,6 +157,8 @@ struct ldw_ctx {
     std::vector<int32_t> h_POS, h_paint;
     int32_t paint_min = 0, paint_max = 0;
     bool pos_sorted = true;      // POS ascends over the whole alignment (the reference's parser emits it so; any order is accepted)
+    double sr_total_dist = -1;   // number of SNP pairs within sr_total_dist on the circle (sizes the short-range table once; reset with the meta data)
+    int64_t sr_total = -1;
 
     // ---- row map (built lazily from alignment + weights + meta) ----
     bool rows_ready = false;

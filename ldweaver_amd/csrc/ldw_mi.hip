@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_build_packs(EpiArgs A, const int32_t *_
 // long-range candidates of one column of one wave -> pair list `path` (approximate-GEMM path)
 __device__ __forceinline__ void append_pairs(const EpiArgs &A, int path, unsigned long long m, bool mine, uint32_t t, uint32_t q, int sa, int sb) {
     const int lane = threadIdx.x & 63;
-    const int sub = path * PAIR_SHARDS + (int)(blockIdx.x & (PAIR_SHARDS - 1));
+    const int sub = path * PAIR_SHARDS + (int)((t >> 6) & (PAIR_SHARDS - 1));   // (t = 64 * from-tile + lane: sharded by tile)
     unsigned int base = 0;
     if (lane == 0) base = atomicAdd(A.pl_n + sub, (unsigned int)__popcll(m));
     base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
@@ -154,7 +154,7 @@ __device__ __forceinline__ void append_pairs(const EpiArgs &A, int path, unsigne
 }
 
 template <int NA, int NB, int U, int RM, bool APX>
-__device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc, bool a_ok, float lo, int q0) {
+__device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc, bool a_ok, float lo, int q0, int tile) {
     const bool test_sr = A.E.any_sr != 0 || A.sr_excl != 0, keep_sr = A.E.keep_sr != 0 && !A.sr_excl, do_lr = A.E.do_lr != 0;
     FullCells<NA, NB> C[U];
     if (do_lr) {   // an SR-only pass needs no MI here at all: a unit is wanted iff it holds a short-range pair
@@ -177,7 +177,7 @@ __device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowS
                 bits |= 1u << u;
             } else {
                 const unsigned long long m = __ballot(need_lr);
-                if (m != 0ull) append_pairs(A, (NA - 1) + 2 * (NB - 1), m, need_lr, (uint32_t)(blockIdx.x * 64 + (threadIdx.x & 63)), (uint32_t)(q0 + u), R.sa, M.sb);
+                if (m != 0ull) append_pairs(A, (NA - 1) + 2 * (NB - 1), m, need_lr, (uint32_t)(tile * 64 + (threadIdx.x & 63)), (uint32_t)(q0 + u), R.sa, M.sb);
             }
         } else {
             const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_build_tab11(double W, double lo, double
 // biallelic x biallelic columns of the approximate screen through the threshold table
 template <int U, int RM>
 __device__ __forceinline__ unsigned int screen_cols_tab(const EpiArgs &A, const RowSide &R, int binA, const ColMeta *cmu, int a_loc, bool a_ok, float lo,
-                                                        int q0) {
+                                                        int q0, int tile) {
     const bool test_sr = A.E.any_sr != 0 || A.sr_excl != 0, keep_sr = A.E.keep_sr != 0 && !A.sr_excl;
     int n[U];
     int2 th[U];
@@ -315,7 +315,7 @@ __device__ __forceinline__ unsigned int screen_cols_tab(const EpiArgs &A, const 
         const bool need_lr = maybe && ms >= lo;
         const unsigned long long m = __ballot(need_lr);
         if (m == 0ull) continue;
-        if (A.pl_pairs) append_pairs(A, 0, m, need_lr, (uint32_t)(blockIdx.x * 64 + (threadIdx.x & 63)), (uint32_t)(q0 + u), R.sa, M.sb);
+        if (A.pl_pairs) append_pairs(A, 0, m, need_lr, (uint32_t)(tile * 64 + (threadIdx.x & 63)), (uint32_t)(q0 + u), R.sa, M.sb);
         else bits |= 1u << u;   // verify mode: whole units (the dismissed ones are evaluated too and must not produce anything)
     }
     return bits;
@@ -325,13 +325,13 @@ __device__ __forceinline__ unsigned int screen_cols_tab(const EpiArgs &A, const 
 // at a time, which keeps the kernel near 64 VGPRs
 template <int NA, int U, int RM, bool APX>
 __device__ __forceinline__ unsigned int screen_cols_nb(int nb, const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc,
-                                                       bool a_ok, float lo, int q0) {
-    if (NA == 1 && nb == 1) return screen_cols<NA, 1, U, RM, APX>(A, R, cmu, a_loc, a_ok, lo, q0);   // (the table path is taken by the caller)
+                                                       bool a_ok, float lo, int q0, int tile) {
+    if (NA == 1 && nb == 1) return screen_cols<NA, 1, U, RM, APX>(A, R, cmu, a_loc, a_ok, lo, q0, tile);   // (the table path is taken by the caller)
     constexpr int V = LDW_SCREEN_V < U ? LDW_SCREEN_V : U;   // columns in flight for the multi-cell tables (2: 387 -> 372 us per C4 block in r02)
     unsigned int bits = 0;
     for (int u = 0; u < U; u += V) {
-        const unsigned int b = nb == 1 ? screen_cols<NA, 1, V, RM, APX>(A, R, cmu + u, a_loc, a_ok, lo, q0 + u)
-                                       : screen_cols<NA, 2, V, RM, APX>(A, R, cmu + u, a_loc, a_ok, lo, q0 + u);
+        const unsigned int b = nb == 1 ? screen_cols<NA, 1, V, RM, APX>(A, R, cmu + u, a_loc, a_ok, lo, q0 + u, tile)
+                                       : screen_cols<NA, 2, V, RM, APX>(A, R, cmu + u, a_loc, a_ok, lo, q0 + u, tile);
         bits |= b << u;
     }
     return bits;
@@ -387,29 +387,27 @@ __device__ __forceinline__ void list_wave_units(const EpiArgs &A, const ColMeta 
 
 // RM: how RXY is read (screen_rxy) — a template parameter so that the common square-block code carries neither the
 // division nor the table look-ups of the ragged case
+// One workgroup's share of the screen: from-tile `tile` (64 SNPs, perm_f order) x column group `cgy` (EPI_COLS column slots, perm_t order).
 template <int RM, bool APX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_mi_screen(EpiArgs A, const int32_t *__restrict__ perm_f,
-                                                                                            const int32_t *__restrict__ perm_t,
-                                                                                            uint64_t *__restrict__ units,
-                                                                                            unsigned int *__restrict__ n_units,
-                                                                                            int64_t list_stride) {
-    __shared__ ColMeta cm[EPI_COLS];
+__device__ __forceinline__ void screen_wg(const EpiArgs &A, const int32_t *__restrict__ perm_f, const int32_t *__restrict__ perm_t,
+                                          uint64_t *__restrict__ units, unsigned int *__restrict__ n_units, int64_t list_stride, ColMeta *cm, int tile,
+                                          int cgy) {
     const bool square = A.nf == A.nt;
     const bool mixed = A.lo.on != 0 || APX;   // cells derived from the marginals of the weights the block-wide sums were taken with
-    if (APX && A.clean && A.E.scr_mode != 2 && (int)blockIdx.x < A.clean_stride && (int)blockIdx.x < A.gen_t0) {
+    if (APX && A.clean && A.E.scr_mode != 2 && tile < A.clean_stride && tile < A.gen_t0) {
         // all four 32-column regions of this workgroup found clean by the GEMM's epilogue: nothing to stage, nothing to list
         bool all_clean = true;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const int qb = (int)blockIdx.y * EPI_COLS + w * (EPI_COLS / 4);
+            const int qb = cgy * EPI_COLS + w * (EPI_COLS / 4);
             const bool whole = qb + EPI_COLS / 4 <= A.nt && qb + EPI_COLS / 4 <= A.gen_q0;
-            all_clean = all_clean && whole && A.clean[(int64_t)(qb / 32) * A.clean_stride + blockIdx.x] != 0;
+            all_clean = all_clean && whole && A.clean[(int64_t)(qb / 32) * A.clean_stride + tile] != 0;
         }
         if (all_clean) return;
     }
     const int wave = threadIdx.x >> 6;
     const int c_first = wave * (EPI_COLS / 4);
-    const int q_base = blockIdx.y * EPI_COLS + c_first;
+    const int q_base = cgy * EPI_COLS + c_first;
     int n_it = A.nt - q_base;
     n_it = n_it > EPI_COLS / 4 ? EPI_COLS / 4 : n_it;
     // pruning by kind (k_snp_sup): columns whose pairs with EVERY SNP of the tile are dead — the tile's SNPs all dead versus the
@@ -421,7 +419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // so about half of the (tile, column) combinations hold no pair at all — columns whose SNP comes after every SNP of the tile.
     // They used to run the whole bound and mask the result.
     if (A.E.lower_only) {
-        int amax = perm_f[blockIdx.x * 64 + (threadIdx.x & 63)];   // (-1: padding slot)
+        int amax = perm_f[tile * 64 + (threadIdx.x & 63)];   // (-1: padding slot)
         const int pb = (int)(threadIdx.x & 63) < n_it ? perm_t[q_base + (threadIdx.x & 63)] : 0x7FFFFFFF;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -434,7 +432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
     unsigned int prune_cols = 0;   // (in a block with short-range pairs these columns are dropped only where the unit holds none: below)
     if (APX && A.sflag_f && A.E.do_lr) {
-        const unsigned fa = A.sflag_f[blockIdx.x * 64 + (threadIdx.x & 63)];
+        const unsigned fa = A.sflag_f[tile * 64 + (threadIdx.x & 63)];
         const bool real = (fa & PF_PAD) == 0u;   // (a padding slot of the tile: no SNP)
         const unsigned ka = fa & PF_KIND;
         const bool all_k2 = __ballot(real && ka != 2u) == 0ull, all_k3 = __ballot(real && ka != 3u) == 0ull;
@@ -452,11 +450,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             if (__syncthreads_and(wave_done ? 1 : 0)) return;
         }
     }
-    stage_cols(A, perm_t, square, cm, mixed);
+    stage_cols(A, perm_t, square, cm, mixed, cgy);
     __syncthreads();
     RowSide R;
     int a_loc, na0;
-    const bool a_ok = load_row_side(A, perm_f, square, blockIdx.x, R, a_loc, mixed);
+    const bool a_ok = load_row_side(A, perm_f, square, tile, R, a_loc, mixed);
     const bool wave_full = wave_is_full(R, a_ok, na0);
     if (n_it <= 0) return;
     const float lo = (float)A.E.spec_lo - A.E.scr_eps;
@@ -464,19 +462,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     int binA = 0;
     bool use_tab = false;
     if (APX && A.tab11 && A.rowpack && A.E.do_lr && wave_full && na0 == 1) {
-        binA = A.rowpack[blockIdx.x * 64 + (threadIdx.x & 63)].pad;
+        binA = A.rowpack[tile * 64 + (threadIdx.x & 63)].pad;
         use_tab = __ballot(a_ok && R.ra != 2.0) == 0ull;
     }
     // wanted: units that need the fp64 kernel; handled: units this kernel could judge (the others are wanted by default)
     unsigned int wanted = 0, handled = 0;
     constexpr int U = 4;
     // from-tiles >= gen_t0 and column slots >= gen_q0 (SNPs with >= 3 minor states, or none) belong to k_mi_screen_generic
-    if ((int)blockIdx.x >= A.gen_t0 || q_base >= A.gen_q0) return;
+    if (tile >= A.gen_t0 || q_base >= A.gen_q0) return;
     if (q_base + n_it > A.gen_q0) n_it = A.gen_q0 - q_base;
     // a region the GEMM's epilogue found clean (every one of its 64 x 32 pairs inside the table thresholds — the very test the
     // table path below would make) is dismissed without a single load
-    const bool region_clean = APX && A.clean && n_it == EPI_COLS / 4 && (int)blockIdx.x < A.clean_stride &&
-                              A.clean[(int64_t)(q_base / 32) * A.clean_stride + blockIdx.x] != 0;
+    const bool region_clean = APX && A.clean && n_it == EPI_COLS / 4 && tile < A.clean_stride &&
+                              A.clean[(int64_t)(q_base / 32) * A.clean_stride + tile] != 0;
     if (region_clean) {
         handled = 0xFFFFFFFFu;
     } else if (wave_full) {
@@ -515,18 +513,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #pragma unroll
                     for (int u = 0; u < U; ++u) tab_ok = tab_ok && cmu[u].rb == 2.0;
                 }
-                if (tab_ok) b = screen_cols_tab<U, RM>(A, R, binA, cmu, a_loc, a_ok, lo, q_base + it);
+                if (tab_ok) b = screen_cols_tab<U, RM>(A, R, binA, cmu, a_loc, a_ok, lo, q_base + it, tile);
                 else
-                    b = na0 == 1 ? screen_cols_nb<1, U, RM, APX>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo, q_base + it)
-                                 : screen_cols_nb<2, U, RM, APX>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo, q_base + it);
+                    b = na0 == 1 ? screen_cols_nb<1, U, RM, APX>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo, q_base + it, tile)
+                                 : screen_cols_nb<2, U, RM, APX>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo, q_base + it, tile);
                 wanted |= b << it;
                 handled |= ((1u << U) - 1u) << it;
             } else {
                 for (int u = 0; u < U && it + u < n_it; ++u) {
                     const uint32_t mbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmu[u].mb);
                     if (!col_is_fast(mbu)) continue;
-                    const unsigned int b = na0 == 1 ? screen_cols_nb<1, 1, RM, APX>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, lo, q_base + it + u)
-                                                    : screen_cols_nb<2, 1, RM, APX>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, lo, q_base + it + u);
+                    const unsigned int b = na0 == 1 ? screen_cols_nb<1, 1, RM, APX>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, lo, q_base + it + u, tile)
+                                                    : screen_cols_nb<2, 1, RM, APX>((int)(mbu & 7), A, R, cmu + u, a_loc, a_ok, lo, q_base + it + u, tile);
                     wanted |= b << (it + u);
                     handled |= 1u << (it + u);
                 }
@@ -537,7 +535,122 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     if (A.E.scr_mode != 2) handled |= tri_cols;   // (columns without a pair need nobody's attention, whatever the tile looks like; verify mode lists
                                                   // every unit and reads `handled` as "straight-line code applies": left alone there)
     wanted = (wanted | ~handled) & all;
-    list_wave_units(A, cm, c_first, q_base, n_it, all, wanted, handled, units, n_units, list_stride);
+    list_wave_units(A, cm, c_first, q_base, n_it, all, wanted, handled, units, n_units, list_stride, tile);
+}
+
+
+// the whole grid: one workgroup per (from-tile, column group)
+template <int RM, bool APX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_mi_screen(EpiArgs A, const int32_t *__restrict__ perm_f,
+                                                                                            const int32_t *__restrict__ perm_t,
+                                                                                            uint64_t *__restrict__ units,
+                                                                                            unsigned int *__restrict__ n_units,
+                                                                                            int64_t list_stride) {
+    __shared__ ColMeta cm[EPI_COLS];
+    screen_wg<RM, APX>(A, perm_f, perm_t, units, n_units, list_stride, cm, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// r04: LIST-DRIVEN.  Three quarters of the (tile, column group) combinations of a long-range block have nothing to screen — all four of their
+// regions flagged clean by the GEMM's epilogue or pruned with their tile, or every column dead against the tile's kind — and each of them still
+// cost a workgroup dispatch (~4 ns: the floor of the full-grid kernel was 47 us per 10k x 10k block, 0.33 ms per span of seven, with every
+// column dropped).  k_screen_live lists the combinations that are left; a fixed grid of workgroups strides over the list.
+template <int RM, bool APX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_mi_screen_list(EpiArgs A, const int32_t *__restrict__ perm_f,
+                                                                                                 const int32_t *__restrict__ perm_t,
+                                                                                                 uint64_t *__restrict__ units,
+                                                                                                 unsigned int *__restrict__ n_units, int64_t list_stride,
+                                                                                                 const uint32_t *__restrict__ live,
+                                                                                                 const unsigned int *__restrict__ n_live) {
+    __shared__ ColMeta cm[EPI_COLS];
+    const unsigned int n = *n_live;
+    for (unsigned int i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t e = live[i];
+        screen_wg<RM, APX>(A, perm_f, perm_t, units, n_units, list_stride, cm, (int)(e & 0xFFFFu), (int)(e >> 16));
+        __syncthreads();   // (cm is staged again for the next entry)
+    }
+}
+
+// Which (from-tile, column group) combinations does k_mi_screen have something to do for?  Its own workgroup-wide exits, from flags alone:
+// outside its domain (tiles / columns of the generic screen); all four 32-column regions clean; every column dead against the tile's kind
+// (long-range-only blocks); on a diagonal block every column's SNP behind every SNP of the tile.  One workgroup per column group, its
+// threads stride over the tiles; entries = tile | column group << 16, appended per wave.
+struct TileState {
+    int amax;            // largest list index among the tile's SNPs (-1: none)
+    unsigned kind;       // bit 0: all real SNPs of kind 2, bit 1: all of kind 3, bit 2: all dead versus kind 2, bit 3: all dead versus kind 3, bit 4: some real SNP
+};
+__global__ __launch_bounds__(64) void k_screen_tiles(EpiArgs A, const int32_t *__restrict__ perm_f, int ntiles, TileState *__restrict__ ts,
+                                                     unsigned int *__restrict__ n_live) {
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    int a = perm_f[tile * 64 + lane];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_xor(a, off);
+        a = o > a ? o : a;
+    }
+    unsigned kind = 0;
+    if (A.sflag_f) {
+        const unsigned fa = A.sflag_f[tile * 64 + lane];
+        const bool real = (fa & PF_PAD) == 0u;
+        const unsigned ka = fa & PF_KIND;
+        kind = (__ballot(real && ka != 2u) == 0ull ? 1u : 0u) | (__ballot(real && ka != 3u) == 0ull ? 2u : 0u) | (__ballot(real && !(fa & PF_DEAD2)) == 0ull ? 4u : 0u) |
+               (__ballot(real && !(fa & PF_DEAD3)) == 0ull ? 8u : 0u) | (__ballot(real) != 0ull ? 16u : 0u);
+    }
+    if (lane == 0) ts[tile] = TileState{a, kind};
+    if (n_live && tile == 0 && lane == 0) *n_live = 0u;   // (k_screen_live, next on the stream, counts from zero)
+}
+template <bool APX>
+__global__ __launch_bounds__(256) void k_screen_live(EpiArgs A, const int32_t *__restrict__ perm_t, const TileState *__restrict__ ts, int ntiles,
+                                                     uint32_t *__restrict__ live, unsigned int *__restrict__ n_live) {
+    __shared__ unsigned int s_dead[8];   // [tile state: (k2 | k3) x all_dead2 x all_dead3]: every column of the group dead for such a tile
+    __shared__ int s_minb;
+    const int cgy = blockIdx.x, t = threadIdx.x;
+    const int q0 = cgy * EPI_COLS;
+    if (t < 8) s_dead[t] = 1u;
+    if (t == 0) s_minb = 0x7FFFFFFF;
+    __syncthreads();
+    const bool prune_on = APX && A.sflag_f && A.E.do_lr && !A.E.any_sr && A.E.scr_mode != 2;
+    if (t < EPI_COLS) {
+        const int q = q0 + t;
+        if (q < A.nt) {
+            if (A.E.lower_only) atomicMin(&s_minb, perm_t[q]);
+            if (prune_on) {
+                const unsigned fb = A.sflag_t[q], kb = fb & PF_KIND;
+                for (int s = 0; s < 8; ++s) {
+                    const bool all_k2 = (s & 4) == 0, ad2 = (s & 1) != 0, ad3 = (s & 2) != 0;   // s: bit 2 = tile of kind 3 (else kind 2)
+                    const bool dead = kb >= 2u && ((kb == 2u ? ad2 : ad3) || (fb & (all_k2 ? PF_DEAD2 : PF_DEAD3)) != 0u);
+                    if (!dead) s_dead[s] = 0u;   // (benign race: every writer stores 0)
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const bool whole = q0 + EPI_COLS <= A.nt;
+    for (int tile0 = 0; tile0 < ntiles; tile0 += 256) {
+        const int tile = tile0 + t;
+        bool keep = tile < ntiles && tile < A.gen_t0 && q0 < A.gen_q0;
+        if (keep && APX && A.clean && A.E.scr_mode != 2 && tile < A.clean_stride && whole && q0 + EPI_COLS <= A.gen_q0) {
+            bool all_clean = true;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) all_clean = all_clean && A.clean[(int64_t)((q0 + w * (EPI_COLS / 4)) / 32) * A.clean_stride + tile] != 0;
+            keep = !all_clean;
+        }
+        if (keep) {
+            const TileState T = ts[tile];
+            if (A.E.lower_only && whole && A.E.scr_mode != 2 && s_minb >= T.amax) keep = false;   // no pair: every column's SNP behind every SNP of the tile
+            if (keep && prune_on && whole && (T.kind & 16u) && (T.kind & 3u)) {
+                const int s = ((T.kind & 1u) ? 0 : 4) | ((T.kind >> 2) & 3u);
+                if (s_dead[s]) keep = false;
+            }
+        }
+        const unsigned long long mk = __ballot(keep);
+        if (mk != 0ull) {
+            unsigned int base = 0;
+            const int lane = t & 63;
+            if (lane == __builtin_ctzll(mk)) base = atomicAdd(n_live, (unsigned int)__popcll(mk));
+            base = (unsigned int)__shfl((int)base, __builtin_ctzll(mk));
+            if (keep) live[base + (unsigned int)__popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)tile | ((uint32_t)cgy << 16);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2137,10 +2250,36 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     static const bool screen_main_env = getenv("LDW_SCREEN_MAIN") != nullptr, span_screen_gs = getenv("LDW_SPAN_SCREEN_GS") != nullptr;
     const bool screen_main = screen_main_env || (lo_h->span > 0 && !span_screen_gs);
     const int rm_s = quirk == LDW_QUIRK_REFERENCE ? (lo_h->span ? 3 : (nf == nt ? 1 : 2)) : 0;
-#define LDW_SCREEN(RMv, ST) hipLaunchKernelGGL((k_mi_screen<RMv, true>), egrid, dim3(256), 0, ST, A, D.perm, D.perm_t, units, n_units, list_stride)
+    // r04 experiment: list-driven screen (k_screen_tiles -> k_screen_live -> k_mi_screen_list) instead of one workgroup per (tile, column group)
+    // (measured r04, C4, 10 cold steps per setting on one box: full grid 36.9 ms per pass, list-driven with 1536 / 4096 / 12288 / 32768 striding
+    // workgroups 38.2 / 37.0 / 36.0 / 37.0: no gain — the dispatcher balances 86k short workgroups better than a strided list does, and the
+    // two list kernels cost what the empty workgroups did; kept behind LDW_SCREEN_LIST=1)
+    static const bool screen_list = getenv("LDW_SCREEN_LIST") != nullptr;
+    const size_t o_ts = 64, o_live = o_ts + ((size_t)egrid.x * sizeof(TileState) + 63) / 64 * 64;
+    if (screen_list)
+        if (int rc = c->scr_live[s].reserve(o_live + (size_t)egrid.x * egrid.y * 4 + 64)) return rc;
+    unsigned int *n_live_scr = screen_list ? c->scr_live[s].as<unsigned int>() : nullptr;
+    TileState *ts_scr = screen_list ? reinterpret_cast<TileState *>(c->scr_live[s].as<char>() + o_ts) : nullptr;
+    uint32_t *live_scr = screen_list ? reinterpret_cast<uint32_t *>(c->scr_live[s].as<char>() + o_live) : nullptr;
+    static const size_t lgrid_max = [] { const char *e = getenv("LDW_SCREEN_GRID"); return e ? (size_t)atol(e) : (size_t)1536; }();
+    const unsigned lgrid = (unsigned)std::min<size_t>((size_t)egrid.x * egrid.y, lgrid_max);
+#define LDW_SCREEN(RMv, ST)                                                                                                                       \
+    do {                                                                                                                                          \
+        if (screen_list) {                                                                                                                        \
+            hipLaunchKernelGGL(k_screen_tiles, dim3(egrid.x), dim3(64), 0, ST, A, D.perm, (int)egrid.x, ts_scr, n_live_scr);                        \
+            hipLaunchKernelGGL(k_screen_live<true>, dim3(egrid.y), dim3(256), 0, ST, A, D.perm_t, ts_scr, (int)egrid.x, live_scr, n_live_scr);    \
+            hipLaunchKernelGGL((k_mi_screen_list<RMv, true>), dim3(lgrid), dim3(256), 0, ST, A, D.perm, D.perm_t, units, n_units, list_stride,    \
+                               live_scr, n_live_scr);                                                                                             \
+        } else {                                                                                                                                  \
+            hipLaunchKernelGGL((k_mi_screen<RMv, true>), egrid, dim3(256), 0, ST, A, D.perm, D.perm_t, units, n_units, list_stride);                \
+        }                                                                                                                                         \
+    } while (0)
     if (phase == 1) {
         if (!screen_main) {
-            if (rm_s == 0) LDW_SCREEN(0, gs); else if (rm_s == 1) LDW_SCREEN(1, gs); else if (rm_s == 3) LDW_SCREEN(3, gs); else LDW_SCREEN(2, gs);
+            if (rm_s == 0) LDW_SCREEN(0, gs);
+            else if (rm_s == 1) LDW_SCREEN(1, gs);
+            else if (rm_s == 3) LDW_SCREEN(3, gs);
+            else LDW_SCREEN(2, gs);
             LDW_HIP(hipGetLastError());
         }
         LDW_HIP(hipEventRecord(ev[5], gs));
@@ -2149,7 +2288,10 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     // ---- phase 2 ----
     LDW_HIP(hipEventRecord(ev[4], s2));
     if (screen_main) {
-        if (rm_s == 0) LDW_SCREEN(0, s2); else if (rm_s == 1) LDW_SCREEN(1, s2); else if (rm_s == 3) LDW_SCREEN(3, s2); else LDW_SCREEN(2, s2);
+        if (rm_s == 0) LDW_SCREEN(0, s2);
+        else if (rm_s == 1) LDW_SCREEN(1, s2);
+        else if (rm_s == 3) LDW_SCREEN(3, s2);
+        else LDW_SCREEN(2, s2);
         LDW_HIP(hipGetLastError());
     }
 #undef LDW_SCREEN
@@ -3455,56 +3597,67 @@ constexpr int64_t PROBE_SIDE = 2048;          // sampled SNPs per side
 constexpr int64_t PROBE_MIN_PAIRS = 16000000; // smaller blocks are cheap enough without a guess
 constexpr int PROBE_MARGIN = 6;
 
-int probe_kind_guess(ldw_ctx *c, const int32_t *fi, int64_t nf, const int32_t *ti, int64_t nt, const ldw_mi_params *p, const SmallLayout &sl,
-                     int kind) {
+// r04: in two halves, so that the probes of both kinds are queued back to back and waited for ONCE (1.25 ms of a cold pass went into two
+// prep / upload / run / wait round trips): probe `which` (0, 1) uses the device buffers of pipeline slot `which` and its own part of
+// the last slot's pinned staging buffer.
+struct Probe {
+    HostBlock hb;
+    int kind = 0, which = 0;
+    bool queued = false;
+};
+int probe_enqueue(ldw_ctx *c, const int32_t *fi, int64_t nf, const int32_t *ti, int64_t nt, const ldw_mi_params *p, const SmallLayout &sl, int kind, int which,
+                  size_t pin_base, Probe &P) {
     const int64_t stride = std::max<int64_t>(1, std::max(nf, nt) / PROBE_SIDE);
     std::vector<int32_t> sf, st;
     for (int64_t k = 0; k < nf; k += stride) sf.push_back(fi[k]);
     for (int64_t k = 0; k < nt; k += stride) st.push_back(ti[k]);
     ldw_mi_params q = *p;
     q.keep_sr = 0;
-    HostBlock hb;
-    // (host staging of the LAST slot: the helper thread of ldw_mi_all_pairs is already building the first blocks' lists in the others)
+    HostBlock &hb = P.hb;
+    P.kind = kind;
+    P.which = which;
+    P.queued = false;
+    // (host staging of the LAST slot: the helper threads of ldw_mi_all_pairs are already building the first blocks' lists in the others)
     constexpr int PS = LDW_NSLOT - 1;
-    if (int rc = prep_block(c, sf.data(), (int64_t)sf.size(), st.data(), (int64_t)st.size(), &q, PS, 0, hb)) return rc;
-    hb.slot = 0;      // the DEVICE side of the probe is slot 0's (its buffers are reserved below; block 0 is submitted after the probes)
-    hb.lo.slot = 0;
+    if (int rc = prep_block(c, sf.data(), (int64_t)sf.size(), st.data(), (int64_t)st.size(), &q, PS, 0, hb, nullptr, -1, false, pin_base)) return rc;
+    hb.slot = which;      // the DEVICE side of the probe is slot `which`'s (the blocks are submitted after the probes)
+    hb.lo.slot = which;
+    hb.stage_base = 0;    // (its device image starts its slot's staging buffer)
     if (hb.n_lr_total < 100000) return LDW_OK;   // too few long-range pairs in the sample to say anything
-    if (int rc = c->dstage[0].reserve(hb.total)) return rc;
-    LDW_HIP(hipMemcpyAsync(c->dstage[0].p, c->pin[PS], hb.total, hipMemcpyHostToDevice, c->stream));
-    const char *d = c->dstage[0].as<char>();
-    auto I = [&](size_t off) { return reinterpret_cast<const int32_t *>(d + off); };
-    auto B = [&](size_t off) { return reinterpret_cast<const uint8_t *>(d + off); };
-    hb.D = DevPtrs{I(hb.o_idx_f), I(hb.o_idx_t), I(hb.o_rl_f), I(hb.o_rl_t), I(hb.o_lrow_f), I(hb.o_lrow_t), I(hb.o_perm), I(hb.o_perm_t),
-                   I(hb.o_pos_f), I(hb.o_pos_t), B(hb.o_cls_f), B(hb.o_cls_t), I(hb.o_cmax),
-                   reinterpret_cast<const int64_t *>(d + hb.o_tbase), I(hb.o_tf), B(hb.o_band), hb.nf_tiles, hb.gen_t0, hb.gen_q0};
-    if (int rc = c->hist[0].reserve((size_t)NBINS * 8)) return rc;
+    if (int rc = c->dstage[which].reserve(hb.total)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->dstage[which].p, static_cast<const char *>(c->pin[PS]) + pin_base, hb.total, hipMemcpyHostToDevice, c->stream));
+    fill_dev_ptrs(c, hb);
+    if (int rc = c->hist[which].reserve((size_t)NBINS * 8)) return rc;
     if (int rc = make_emit_args(c, hb, &q, sl, -1)) return rc;
     hb.E.write_dense = 0;   // nothing reads the sample's MI values: only the histogram of the long-range ones
-    LDW_HIP(hipMemsetAsync(c->hist[0].p, 0, (size_t)NBINS * 8, c->stream));
-    LDW_HIP(hipMemsetAsync(sl.pick[0], 0, sizeof(ldw::PickOut), c->stream));
+    LDW_HIP(hipMemsetAsync(c->hist[which].p, 0, (size_t)NBINS * 8, c->stream));
+    LDW_HIP(hipMemsetAsync(sl.pick[which], 0, sizeof(ldw::PickOut), c->stream));
     // (in the CALLER's reading of RXY: under quirk Q1 the scrambled RXY — r of two other SNPs — lifts 3-state x 3-state pairs into the tail of an
     // off-diagonal block; a sample evaluated with the intended RXY sat 15 buckets = 7.5 % below the block's own threshold)
-    if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, c->ev, 3, &c->G, nullptr, c->hist[0].as<unsigned long long>()))
+    if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, c->ev, 3, &gx(c, which), nullptr, c->hist[which].as<unsigned long long>()))
         return rc;
-    hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, c->stream, c->hist[0].as<unsigned long long>(), p->lr_retain_links, p->lr_links_approx, -1,
-                       (long long)hb.n_lr_total, sl.pick[0], (const unsigned int *)nullptr, 0u);
+    hipLaunchKernelGGL(k_pick_bucket, dim3(1), dim3(256), 0, c->stream, c->hist[which].as<unsigned long long>(), p->lr_retain_links, p->lr_links_approx, -1,
+                       (long long)hb.n_lr_total, sl.pick[which], (const unsigned int *)nullptr, 0u);
     LDW_HIP(hipGetLastError());
-    LDW_HIP(hipMemcpyAsync(c->pin_pick[0], sl.pick[0], sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
-    LDW_HIP(hipStreamSynchronize(c->stream));
-    const ldw::PickOut *hp = static_cast<const ldw::PickOut *>(c->pin_pick[0]);
+    LDW_HIP(hipMemcpyAsync(c->pin_pick[which], sl.pick[which], sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemsetAsync(sl.pick[which], 0, sizeof(ldw::PickOut), c->stream));
+    P.queued = true;
+    return LDW_OK;
+}
+// after hipStreamSynchronize(c->stream)
+void probe_collect(ldw_ctx *c, const Probe &P) {
+    if (!P.queued) return;
+    const ldw::PickOut *hp = static_cast<const ldw::PickOut *>(c->pin_pick[P.which]);
     if (hp->n > 0 && hp->B_true < NBINS) {
         const int g = hp->B_true - PROBE_MARGIN;
-        c->spec_B_next[kind] = g > 0 ? g : 0;
-        c->spec_hist_n[kind] = 0;
-        c->spec_probed[kind] = true;
+        c->spec_B_next[P.kind] = g > 0 ? g : 0;
+        c->spec_hist_n[P.kind] = 0;
+        c->spec_probed[P.kind] = true;
         ++c->probe_blocks;
         static const bool trace_on = getenv("LDW_BLOCK_TRACE") != nullptr;
-        if (trace_on) fprintf(stderr, "[ldw probe] kind %d: sample %lld x %lld, %lld long-range pairs, bucket %d -> guess %d\n", kind, (long long)hb.nf, (long long)hb.nt,
-                              (long long)hb.n_lr_total, hp->B_true, c->spec_B_next[kind]);
+        if (trace_on) fprintf(stderr, "[ldw probe] kind %d: sample %lld x %lld, %lld long-range pairs, bucket %d -> guess %d\n", P.kind, (long long)P.hb.nf, (long long)P.hb.nt,
+                              (long long)P.hb.n_lr_total, hp->B_true, c->spec_B_next[P.kind]);
     }
-    LDW_HIP(hipMemsetAsync(sl.pick[0], 0, sizeof(ldw::PickOut), c->stream));
-    return LDW_OK;
 }
 
 // whether the next block can be submitted before the current one is finished: the fused path needs a bucket guess
@@ -3896,6 +4049,8 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         const int64_t Ls = c->L;
         const std::vector<int32_t> &P = c->h_POS;
         int64_t total_sr = 0, hi = 0, wlo = 0;
+        if (c->sr_total_dist == p->sr_dist && c->sr_total >= 0) total_sr = c->sr_total;   // (the walk is 1 ms at L = 100k: once per positions and sr_dist)
+        else {
         for (int64_t a = 0; a < Ls; ++a) {
             if (hi < a + 1) hi = a + 1;
             while (hi < Ls && (double)P[(size_t)hi] - (double)P[(size_t)a] <= p->sr_dist) ++hi;
@@ -3906,6 +4061,9 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
             if (lim < (double)P[0]) continue;
             while (wlo < Ls && (double)P[(size_t)wlo] <= lim) ++wlo;
             total_sr += std::min<int64_t>(wlo, a);
+        }
+        c->sr_total = total_sr;
+        c->sr_total_dist = p->sr_dist;
         }
         if (int rc = ensure_links_capacity(c, total_sr + 1024, 0)) return rc;
     }
@@ -4053,11 +4211,15 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
                 if (t[i].joinable()) t[i].join();
         }
     } joiner{sh, helpers, n_helpers};
+    const double t_sized = now0();
     // (the helper is already building the first blocks' lists while the probes run; it stays out of the last slot until they are done)
     // cold start: a sampled guess for each block kind that has none yet (probe_kind_guess), taken from the first block of the kind
     static const bool probe_on = getenv("LDW_NO_PROBE") == nullptr;
     if (probe_on && !p->sr_only && c->engine != LDW_ENGINE_HIST_STATES && !c->fused && c->pos_sorted && speculation_pays(c, p)) {
         bool done_kind[2] = {false, false};
+        Probe probes[2];
+        int n_probe = 0;
+        size_t pin_base = 0;
         for (int64_t b = 0; b < nblocks && !(done_kind[0] && done_kind[1]); ++b) {
             const bool diag = blocks[b * 4 + 0] == blocks[b * 4 + 2] && blocks[b * 4 + 1] == blocks[b * 4 + 3];
             const int kind = diag ? 1 : 0;
@@ -4067,9 +4229,18 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
             if (int rc = fill(b)) return rc;
             const int64_t npairs = diag ? (int64_t)fi.size() * ((int64_t)fi.size() - 1) / 2 : (int64_t)fi.size() * (int64_t)ti.size();
             if (npairs < PROBE_MIN_PAIRS) continue;
-            if (int rc = probe_kind_guess(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, sl, kind)) return rc;
+            // (a staging buffer that has to grow for the second sample is reallocated: the first sample's upload must have left it)
+            if (n_probe > 0 && c->pin_cap[LDW_NSLOT - 1] < pin_base + 2 * probes[0].hb.total + 65536) LDW_HIP(hipStreamSynchronize(c->stream));
+            if (int rc = probe_enqueue(c, fi.data(), (int64_t)fi.size(), ti.data(), (int64_t)ti.size(), p, sl, kind, n_probe, pin_base, probes[n_probe])) return rc;
+            pin_base = (pin_base + probes[n_probe].hb.total + 255) / 256 * 256;
+            ++n_probe;
+        }
+        if (n_probe > 0) {
+            LDW_HIP(hipStreamSynchronize(c->stream));
+            for (int k = 0; k < n_probe; ++k) probe_collect(c, probes[k]);
         }
     }
+    const double t_probed = now0();
     {   // the rest of the plan: consecutive candidates of one block row, to sides ascending, form a span (at most span_max blocks,
         // nf x nt below the 32-bit index limit of the unit lists, the int32 block below ~6 GB)
         const bool spans = spans_possible(c, p);
@@ -4106,8 +4277,8 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     const int64_t nitems = (int64_t)items.size();
     const double t_planned = now0();
     if (host_timing0)
-        fprintf(stderr, "[ldw host us] waiting for the side threads %.0f  links_begin (row map if stale, bookkeeping) %.0f  table sizing + cold-start probes + plan %.0f\n",
-                t_joined - t_enter, t_begun - t_joined, t_planned - t_begun);
+        fprintf(stderr, "[ldw host us] waiting for the side threads %.0f  links_begin (row map if stale, bookkeeping) %.0f  table sizing + helper start %.0f  cold-start probes %.0f  plan %.0f\n",
+                t_joined - t_enter, t_begun - t_joined, t_sized - t_begun, t_probed - t_sized, t_planned - t_probed);
     // blocks until item k is prepared (true) — or, with wait = false, says whether it is
     auto prepped = [&](int64_t k, bool wait, int &rc) -> bool {
         std::unique_lock<std::mutex> lk(sh.m);
