@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256) void k_apx_live_tiles(ApxGemmArgs P) {
     unsigned int n_pruned = 0;
     for (int tx0 = 0; tx0 < ntx; tx0 += 256) {
         const int tx = tx0 + (int)threadIdx.x;
-        const bool valid = tx < ntx;
+        // (a diagonal block: the tiles above the diagonal of row positions are not part of the GEMM at all — their regions keep the zero the host set)
+        const bool valid = tx < ntx && !(P.lower_only && tx * TWd + TWd - 1 < ty * TH);
         bool pruned = false, all_binned = false;
         if (valid && !(P.sr_mask && P.sr_mask[(int64_t)ty * (P.RFpad / 64) + tx] != 0)) {
             const TileSummary F = apx_fold_rows(P.bin_f + (int64_t)tx * TWd, P.rflag_f ? P.rflag_f + (int64_t)tx * TWd : nullptr, TWd);
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(512, 1) void gemm_apx_lds_kernel(ApxGemmArgs P) {
 }
 
 int launch_apx_live_tiles(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
-    LDW_REQUIRE(P.fuse && P.skip_ctr && P.tile_list && P.n_live && !P.lower_only && P.RTpad % 128 == 0 && P.RFpad % 64 == 0 && P.tab && P.tab_nb == 64,
+    LDW_REQUIRE(P.fuse && P.skip_ctr && P.tile_list && P.n_live && P.RTpad % 128 == 0 && P.RFpad % 64 == 0 && P.tab && P.tab_nb == 64,
                 LDW_ERR_ARG, "launch_apx_live_tiles: bad pruning arguments");
     hipLaunchKernelGGL(k_apx_live_tiles, dim3((unsigned)(P.RTpad / 128)), dim3(256), 0, st, P);
     LDW_HIP(hipGetLastError());
@@ -837,7 +838,7 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
         else hipLaunchKernelGGL((gemm_apx_kernel<MTv, NTv, false>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P); \
     }
     if (P.skip_ctr) {
-        LDW_REQUIRE(P.fuse && P.tile_list && P.n_live && !P.lower_only && P.RFpad % 64 == 0, LDW_ERR_ARG, "launch_gemm_apx: bad pruning arguments");
+        LDW_REQUIRE(P.fuse && P.tile_list && P.n_live && P.RFpad % 64 == 0, LDW_ERR_ARG, "launch_gemm_apx: bad pruning arguments");
         const int tiles = (P.RTpad / 128) * (P.RFpad / 64), g = (tiles + 3) / 4;   // (the list is made by launch_apx_live_tiles)
         if (P.fine) hipLaunchKernelGGL((gemm_apx_kernel<4, 2, true>), dim3((unsigned)g), dim3(256), lds, st, P);
         else hipLaunchKernelGGL((gemm_apx_kernel<4, 2, false>), dim3((unsigned)g), dim3(256), lds, st, P);
@@ -889,8 +890,11 @@ struct PairArgs {
     unsigned long long *ghist;
 };
 
+// CA x CB = 4 x 4 is the list of the pairs with a SNP of three or four indicator rows: nearly all of them 3 x 1 or 3 x 2, so the products with the
+// absent rows (na, nb are wave-uniform: scalar branches) are skipped — r03 ran all sixteen against rows of zeros (k_pair_sums<true>: 1.0 ms per C4 pass)
 template <int CA, int CB>
 __device__ __forceinline__ void pair_sums_body(const PairArgs &P, int path, const int32_t *s_wbeg, const PopSeg *s_segs) {
+    constexpr bool GENB = CA == 4 && CB == 4;
     const EpiArgs &A = P.A;
     const int sub = path * PAIR_SHARDS + (int)blockIdx.y;
     unsigned int n = A.pl_n[sub];
@@ -940,9 +944,9 @@ __device__ __forceinline__ void pair_sums_body(const PairArgs &P, int path, cons
             const int w = lane + 64 * k;
             const bool in = w < P.nwords;
 #pragma unroll
-            for (int i = 0; i < CA; ++i) f[k][i] = in ? fr[i][w] : 0u;
+            for (int i = 0; i < CA; ++i) f[k][i] = (in && (!GENB || i < na)) ? fr[i][w] : 0u;
 #pragma unroll
-            for (int j = 0; j < CB; ++j) tt[k][j] = in ? tr[j][w] : 0u;
+            for (int j = 0; j < CB; ++j) tt[k][j] = (in && (!GENB || j < nb)) ? tr[j][w] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < KW; ++k) {
@@ -954,7 +958,8 @@ __device__ __forceinline__ void pair_sums_body(const PairArgs &P, int path, cons
 #pragma unroll
                     for (int j = 0; j < CB; ++j)
 #pragma unroll
-                        for (int i = 0; i < CA; ++i) s[j][i] += (int64_t)((uint64_t)__popc(f[k][i] & tt[k][j] & seg.mask) * (uint64_t)seg.V);
+                        for (int i = 0; i < CA; ++i)
+                            if (!GENB || (i < na && j < nb)) s[j][i] += (int64_t)((uint64_t)__popc(f[k][i] & tt[k][j] & seg.mask) * (uint64_t)seg.V);
                 }
             } else {
 #pragma unroll
@@ -962,22 +967,24 @@ __device__ __forceinline__ void pair_sums_body(const PairArgs &P, int path, cons
 #pragma unroll
                     for (int j = 0; j < CB; ++j)
 #pragma unroll
-                        for (int i = 0; i < CA; ++i) s[j][i] += (int64_t)((uint64_t)__popc(f[k][i] & tt[k][j] & smask[k][q2]) * (uint64_t)sV[k][q2]);
+                        for (int i = 0; i < CA; ++i)
+                            if (!GENB || (i < na && j < nb)) s[j][i] += (int64_t)((uint64_t)__popc(f[k][i] & tt[k][j] & smask[k][q2]) * (uint64_t)sV[k][q2]);
             }
         }
         for (int w = lane + 64 * KW; w < P.nwords; w += 64) {   // longer rows (more than 6144 sequences): the rest through the table
             uint32_t f2[CA], t2[CB];
 #pragma unroll
-            for (int i = 0; i < CA; ++i) f2[i] = fr[i][w];
+            for (int i = 0; i < CA; ++i) f2[i] = (!GENB || i < na) ? fr[i][w] : 0u;
 #pragma unroll
-            for (int j = 0; j < CB; ++j) t2[j] = tr[j][w];
+            for (int j = 0; j < CB; ++j) t2[j] = (!GENB || j < nb) ? tr[j][w] : 0u;
             const int s0 = s_wbeg[w] & 0x7FFFFFFF, s1 = s_wbeg[w + 1] & 0x7FFFFFFF;
             for (int sg = s0; sg < s1; ++sg) {
                 const PopSeg seg = s_segs[sg];
 #pragma unroll
                 for (int j = 0; j < CB; ++j)
 #pragma unroll
-                    for (int i = 0; i < CA; ++i) s[j][i] += (int64_t)((uint64_t)__popc(f2[i] & t2[j] & seg.mask) * (uint64_t)seg.V);
+                    for (int i = 0; i < CA; ++i)
+                        if (!GENB || (i < na && j < nb)) s[j][i] += (int64_t)((uint64_t)__popc(f2[i] & t2[j] & seg.mask) * (uint64_t)seg.V);
             }
         }
 #pragma unroll
@@ -985,8 +992,10 @@ __device__ __forceinline__ void pair_sums_body(const PairArgs &P, int path, cons
 #pragma unroll
             for (int i = 0; i < CA; ++i) {
                 int64_t v = s[j][i];
+                if (!GENB || (i < na && j < nb)) {
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                }
                 if (lane == 0) P.sums[((int64_t)sub * A.pl_cap + idx) * 16 + j * 4 + i] = v;
             }
     }

@@ -121,6 +121,7 @@ struct ldw_ctx {
     bool tab11_on = true;              // LDW_NO_TAB11 switches the table off (A/B measurements)
     ldw::DevBuf pair_sums;             // exact joint sums of the listed pairs (16 per pair)
     ldw::DevBuf pairs[LDW_NSLOT];              // per pipeline slot: pair lists of the approximate screen (counters + PAIR_PATHS x PAIR_SHARDS lists)
+    ldw::DevBuf sub_units[LDW_NSLOT], sub_packs[LDW_NSLOT], sub_bins[LDW_NSLOT], sub_live[LDW_NSLOT];   // the same four for an item's SR sub-pass
     ldw::DevBuf scr_live[LDW_NSLOT];           // per slot: counter, per-tile summaries and the list of the (tile, column group) combinations the screen has work for
     ldw::DevBuf apx_bins[LDW_NSLOT], apx_clean[LDW_NSLOT];    // per slot: threshold-table bin of every row of the two row lists; clean-region flags of the GEMM epilogue
     ldw::DevBuf apx_units[LDW_NSLOT], apx_packs[LDW_NSLOT];   // per slot: per-(tile, class) unit lists + counters; per-block SNP constants
@@ -134,6 +135,7 @@ struct ldw_ctx {
     int64_t apx_waves_skipped = 0, apx_waves_total = 0;
     // Spans (r04): consecutive long-range-only blocks of one block row run as ONE launch sequence over their concatenated to side
     bool span_on = true;               // ldw_set_span / LDW_NO_SPAN
+    bool diag_split = false;           // ldw_set_span(on | 4) / LDW_DIAG_SPLIT: diagonal blocks as SR sub-pass + weight-ordered long-range pass
     bool span_corners = false;         // ldw_set_span(on | 2) / LDW_SPAN_CORNERS: corner blocks join the spans (SR sub-passes); measured slower, off by default
     int span_max = 8;                  // most reference blocks per span (LDW_SPAN_MAX env, <= ldw::LDW_SPAN_MAX)
     int64_t span_items = 0, span_blocks = 0, span_fallbacks = 0;   // spans run, reference blocks they covered, segments redone non-speculatively

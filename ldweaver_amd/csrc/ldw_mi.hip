@@ -2048,7 +2048,11 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
                      hipStream_t gs, unsigned long long *ghist, const LoHost *lo_h, void *zero_hist = nullptr, void *zero_pick = nullptr,
                      size_t zero_pick_bytes = 0, hipStream_t s2 = nullptr) {
     const int s = lo_h->slot;
-    if (!s2) s2 = c->stream;   // stream of phase 2 (an SR sub-pass runs both phases on the GEMM stream)
+    if (!s2) s2 = c->stream;   // stream of phase 2 (an SR sub-pass runs both of its phases on one stream)
+    // an SR sub-pass has the slot's second set of list / constant buffers: it runs on the main stream while the item's long-range pass, whose
+    // first phase filled the first set on the GEMM stream, still needs them for its second phase
+    ldw::DevBuf &B_units = lo_h->sr_sub ? c->sub_units[s] : c->apx_units[s], &B_packs = lo_h->sr_sub ? c->sub_packs[s] : c->apx_packs[s],
+                &B_bins = lo_h->sr_sub ? c->sub_bins[s] : c->apx_bins[s], &B_live = lo_h->sr_sub ? c->sub_live[s] : c->scr_live[s];
     E.nf = (int)nf;
     E.MI = nullptr;
     dim3 egrid((unsigned)(D.nf_tiles > 0 ? D.nf_tiles : (nf + 63) / 64), (unsigned)((nt + EPI_COLS - 1) / EPI_COLS));
@@ -2074,13 +2078,13 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             if (int rc = c->panel[s][1].reserve((size_t)RTpad * c->KW * 8)) return rc;
         if (E.do_lr)
             if (int rc = c->Gapx[s].reserve((size_t)RFpad * RTpad * 4)) return rc;
-        if (int rc = c->apx_units[s].reserve(o_flat + 2 * n_units_max * 8 + 64)) return rc;
-        if (int rc = c->apx_packs[s].reserve(o_rt + (size_t)nt * 4 + 256)) return rc;
+        if (int rc = B_units.reserve(o_flat + 2 * n_units_max * 8 + 64)) return rc;
+        if (int rc = B_packs.reserve(o_rt + (size_t)nt * 4 + 256)) return rc;
         if (use_pairs)
             if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * pair_cap_for(nf, nt, lo_h->span) * sizeof(PairEnt))) return rc;
         if (need_exact)
             if (int rc = Gx.reserve((size_t)RFpad * RTpad * 8)) return rc;
-        if (int rc = c->apx_bins[s].reserve(2 * ((size_t)RTpad + (size_t)RFpad) + (size_t)nt + (size_t)nf_slots + 256 + (size_t)(RTpad / 128) * (size_t)(RFpad / 64) * 4)) return rc;
+        if (int rc = B_bins.reserve(2 * ((size_t)RTpad + (size_t)RFpad) + (size_t)nt + (size_t)nf_slots + 256 + (size_t)(RTpad / 128) * (size_t)(RFpad / 64) * 4)) return rc;
         if (int rc = c->apx_clean[s].reserve((size_t)(RTpad / 32) * (size_t)(RFpad / 64) + 64)) return rc;
         if (!c->apx_skip.p) {
             if (int rc = c->apx_skip.reserve(64)) return rc;
@@ -2132,7 +2136,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     static const bool fuse_on = getenv("LDW_NO_FUSE_TAB") == nullptr;
     const bool fuse = fuse_on && lo_h->fuse_ok && A.tab11 && A.tab_nb == 64 && (use_pairs || c->screen == 2) && E.do_lr && (!E.any_sr || (D.band_mask && !lo_h->band_full)) && RFpad % 64 == 0 &&   // (verify mode: the clean regions' units are listed as dismissed and checked in fp64)
                       2048 + (size_t)(c->KW / 2) * 256 + 64 * 64 * 8 + 1024 <= 65536;   // (the table shares the GEMM's LDS with the digit arrays)
-    uint8_t *bin_t = c->apx_bins[s].as<uint8_t>(), *bin_f = bin_t + RTpad;
+    uint8_t *bin_t = B_bins.as<uint8_t>(), *bin_f = bin_t + RTpad;
     // pruning flags by row (zeroed per block: padding rows) and by epilogue slot
     // ... and, zeroed with the row flags, the count of the wave tiles the pruning leaves (k_apx_live_tiles), whose list ends the buffer
     uint8_t *rflag_t = bin_f + RFpad, *rflag_f = rflag_t + RTpad;
@@ -2149,10 +2153,10 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         A.clean = c->apx_clean[s].as<uint8_t>();
         A.clean_stride = RFpad / 64;
     }
-    char *ub = c->apx_units[s].as<char>();
+    char *ub = B_units.as<char>();
     unsigned int *n_units = reinterpret_cast<unsigned int *>(ub);
     uint64_t *units = reinterpret_cast<uint64_t *>(ub + o_flat);
-    char *pb = c->apx_packs[s].as<char>();
+    char *pb = B_packs.as<char>();
     ColMeta *cp = reinterpret_cast<ColMeta *>(pb), *cph = reinterpret_cast<ColMeta *>(pb + o_cph);
     RowPack *rp = reinterpret_cast<RowPack *>(pb + o_rp), *rph = reinterpret_cast<RowPack *>(pb + o_rph);
     float *rlf = reinterpret_cast<float *>(pb + o_rf), *rlt = reinterpret_cast<float *>(pb + o_rt);
@@ -2257,10 +2261,10 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     static const bool screen_list = getenv("LDW_SCREEN_LIST") != nullptr;
     const size_t o_ts = 64, o_live = o_ts + ((size_t)egrid.x * sizeof(TileState) + 63) / 64 * 64;
     if (screen_list)
-        if (int rc = c->scr_live[s].reserve(o_live + (size_t)egrid.x * egrid.y * 4 + 64)) return rc;
-    unsigned int *n_live_scr = screen_list ? c->scr_live[s].as<unsigned int>() : nullptr;
-    TileState *ts_scr = screen_list ? reinterpret_cast<TileState *>(c->scr_live[s].as<char>() + o_ts) : nullptr;
-    uint32_t *live_scr = screen_list ? reinterpret_cast<uint32_t *>(c->scr_live[s].as<char>() + o_live) : nullptr;
+        if (int rc = B_live.reserve(o_live + (size_t)egrid.x * egrid.y * 4 + 64)) return rc;
+    unsigned int *n_live_scr = screen_list ? B_live.as<unsigned int>() : nullptr;
+    TileState *ts_scr = screen_list ? reinterpret_cast<TileState *>(B_live.as<char>() + o_ts) : nullptr;
+    uint32_t *live_scr = screen_list ? reinterpret_cast<uint32_t *>(B_live.as<char>() + o_live) : nullptr;
     static const size_t lgrid_max = [] { const char *e = getenv("LDW_SCREEN_GRID"); return e ? (size_t)atol(e) : (size_t)1536; }();
     const unsigned lgrid = (unsigned)std::min<size_t>((size_t)egrid.x * egrid.y, lgrid_max);
 #define LDW_SCREEN(RMv, ST)                                                                                                                       \
@@ -2498,6 +2502,8 @@ struct HostBlock {
     // sub-pass over that block alone, in list order (band GEMM + whole units: the r03 machinery in its SR-only form), queued in front of the span's
     // own kernels; the span treats the segment as long-range-only and keeps the short-range pairs out of its candidates (EpiArgs::sr_excl)
     bool sr_sub = false;               // this HostBlock IS such a sub-pass (list order, no ordering of its rows)
+    bool lr_split = false;             // a single block (diagonal) whose short-range pairs go to an SR sub-pass: its own rows are ordered by weight like a
+                                       // long-range-only block's, its screens keep the short-range pairs out (sr_excl), no band, no units
     size_t stage_base = 0;             // offset of its image in the item's staging buffer
     int64_t sr_base = 0;               // first row of the item's short-range rows (set when the item is submitted: submit order = block order)
     int64_t seg_n_sr[LDW_SPAN_MAX] = {};
@@ -2526,7 +2532,8 @@ static inline bool speculation_pays(const ldw_ctx *c, const ldw_mi_params *p) {
 }
 
 int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *to_idx, int64_t nt, const ldw_mi_params *p,
-               int slot, int64_t blk_no, HostBlock &hb, const SpanPlan *sp = nullptr, int pin_slot = -1, bool sr_sub = false, size_t stage_base = 0) {
+               int slot, int64_t blk_no, HostBlock &hb, const SpanPlan *sp = nullptr, int pin_slot = -1, bool sr_sub = false, size_t stage_base = 0,
+               bool lr_split = false) {
     LDW_REQUIRE(nf > 0 && nt > 0, LDW_ERR_ARG, "empty block (nf=%lld nt=%lld)", (long long)nf, (long long)nt);
     LDW_REQUIRE(nf <= 1000000 && nt <= 1000000 && nf * nt < 2147483647LL, LDW_ERR_ARG, "block too large (%lld x %lld)",
                 (long long)nf, (long long)nt);
@@ -2541,6 +2548,7 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     hb.blk_no = blk_no;
     hb.pin_slot = pin_slot;
     hb.sr_sub = sr_sub;
+    hb.lr_split = lr_split;
     hb.stage_base = stage_base;
     hb.diag = same_list(from_idx, nf, to_idx, nt);
     SideLists SF, ST;
@@ -2593,14 +2601,14 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
     // every SNP has short-range partners there.
     const std::vector<int32_t> *ord_f = nullptr, *ord_t = nullptr;
     std::vector<int32_t> ord_f_own, ord_t_own, ord_f_full, ord_t_full;
-    if (c->prune && !hb.generic && !hb.diag && !sr_sub && c->engine == LDW_ENGINE_MFMA && c->apx_ok && !c->fused) {
+    if (c->prune && !hb.generic && (!hb.diag || lr_split) && !sr_sub && c->engine == LDW_ENGINE_MFMA && c->apx_ok && !c->fused) {
         bool rowless = false;
         for (int64_t k = 0; k < nf && !rowless; ++k) rowless = c->h_row0[from_idx[k] + 1] == c->h_row0[from_idx[k]];
         for (int64_t k = 0; k < nt && !rowless; ++k) rowless = c->h_row0[to_idx[k] + 1] == c->h_row0[to_idx[k]];
         if (!rowless) {
             ord_f = minor_weight_order(c, from_idx, nf, ord_f_full);
             ord_t = minor_weight_order(c, to_idx, nt, ord_t_full);
-            if (hb.n_sr_blk > 0) {
+            if (hb.n_sr_blk > 0 && !lr_split) {
                 std::vector<int32_t> df((size_t)nf + 1, 0);
                 std::vector<uint8_t> in_f((size_t)nf, 0), in_t((size_t)nt, 0);
                 for (int64_t b = 0; b < nt; ++b)
@@ -2753,13 +2761,13 @@ int prep_block(ldw_ctx *c, const int32_t *from_idx, int64_t nf, const int32_t *t
                 for (int64_t tx = f0 / 64; tx <= (f1 - 1) / 64; ++tx) band[(size_t)ty * ntx + tx] = 1;
         };
         std::vector<int32_t> nxt1, prv1;   // first one-row SNP at or after / last one before a list position (ordered rows only)
-        if (hb.n_sr_blk > 0 && !hb.lo.band_full && ord_f) {
+        if (hb.n_sr_blk > 0 && !hb.lo.band_full && ord_f && !lr_split) {
             nxt1.assign((size_t)nf + 1, (int32_t)nf);
             prv1.assign((size_t)nf + 1, -1);
             for (int64_t a = nf - 1; a >= 0; --a) nxt1[(size_t)a] = cls_of(from_idx[a]) == 0 ? (int32_t)a : nxt1[(size_t)a + 1];
             for (int64_t a = 0; a < nf; ++a) prv1[(size_t)a + 1] = cls_of(from_idx[a]) == 0 ? (int32_t)a : prv1[(size_t)a];
         }
-        if (hb.n_sr_blk > 0 && !hb.lo.band_full)
+        if (hb.n_sr_blk > 0 && !hb.lo.band_full && !lr_split)
             for (int64_t b2 = 0; b2 < nt; ++b2) {
                 const ColInfo &ci = cols[(size_t)b2];
                 const int64_t rb0 = ST.lrow[(size_t)b2], rb1 = rb0 + (1 << cls_of(to_idx[b2]));
@@ -2898,7 +2906,7 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
     E.write_dense = (do_lr && hb.spec_B < 0) ? 1 : 0;   // the dense block only feeds k_lr_gather; SR-only passes take the screen path
     E.spec_B = hb.spec_B;
     E.spec_lo = hb.spec_B > 0 ? bucket_lo(hb.spec_B) : -1e300;
-    E.any_sr = (hb.n_sr_blk > 0 && !hb.span) ? 1 : 0;   // (a span never emits a short-range row itself: sr_excl)
+    E.any_sr = (hb.n_sr_blk > 0 && !hb.span && !hb.lr_split) ? 1 : 0;   // (a span / a split block never emits a short-range row itself: sr_excl)
     E.n_cand = &sl.pick[s]->n_cand;
     E.ckey = c->cand_key[s].as<uint64_t>();
     E.cval = c->cand_val[s].as<uint64_t>();
@@ -2981,7 +2989,7 @@ static void fill_dev_ptrs(ldw_ctx *c, HostBlock &hb) {
 // The short-range pairs of one corner segment of a span: the block alone, in list order, through the SR-only form of the approximate path —
 // per-SNP constants, k_mi_screen (lists the units that hold a short-range pair: no MI needed for that), the exact 5-limb GEMM of the band's
 // tiles, k_mi_units (fp64 MI of the listed units; only the short-range pairs are emitted, to their final rows) — both phases on the GEMM
-// stream, in front of the span's own kernels, which then reuse the slot's buffers.
+// given stream (the main one, in front of the item's second phase), with the slot's second set of list / constant buffers.
 int launch_sr_sub(ldw_ctx *c, HostBlock &sub, const ldw_mi_params *p, const SmallLayout &sl, hipStream_t gs, int64_t sr_base) {
     fill_dev_ptrs(c, sub);
     ldw_mi_params q = *p;
@@ -3018,7 +3026,15 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     if (c->done_recorded[s]) LDW_HIP(hipStreamWaitEvent(gs, c->ev_done[s], 0));
     hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
     const bool do_lr = !p->sr_only;
-    const int guess = do_lr ? ((speculation_pays(c, p) && !hb.force_plain) ? c->spec_B_next[hb.diag ? 1 : 0] : -1) : 0;
+    int guess = do_lr ? ((speculation_pays(c, p) && !hb.force_plain) ? c->spec_B_next[hb.diag ? 1 : 0] : -1) : 0;
+    if (hb.lr_split && !(guess > 0 && c->path_mode != 1 && c->apx_ok && c->screen == 1 && do_lr && !c->fused)) {
+        // prepared for the split, but no positive guess for its kind (no probe for blocks this small, say): the plain path does the whole
+        // block — short-range rows included — on the ordered rows (it reads every position through the row maps)
+        hb.lr_split = false;
+        hb.subs.clear();
+        hb.subs_seg.clear();
+        guess = do_lr ? -1 : 0;
+    }
     if ((int64_t)c->ev_valid.size() < hb.blk_no + std::max(1, hb.span)) c->ev_valid.resize((size_t)(hb.blk_no + std::max(1, hb.span)), 1);
     c->ev_valid[(size_t)hb.blk_no] = 1;
     for (int k = 1; k < hb.span; ++k) c->ev_valid[(size_t)hb.blk_no + k] = 0;   // (the span's stage events are its first block's; a segment that runs alone records its own)
@@ -3043,17 +3059,6 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
             return LDW_OK;
         }
     }
-    if (hb.span && !hb.subs.empty() && p->keep_sr) {
-        int64_t base = hb.sr_base;
-        size_t si = 0;
-        for (int k = 0; k < hb.span; ++k) {
-            if (si < hb.subs.size() && hb.subs_seg[si] == k) {
-                if (int rc = launch_sr_sub(c, hb.subs[si], p, sl, gs, base)) return rc;
-                ++si;
-            }
-            base += hb.seg_n_sr[k];
-        }
-    }
     hb.fused = c->fused && c->nlimbs <= 5 && (!do_lr || guess >= 0);
     if (hb.span) c->unfused_blocks += hb.span;
     else ++(hb.fused ? c->fused_blocks : c->unfused_blocks);
@@ -3069,6 +3074,8 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
         LDW_REQUIRE(c->path_mode != 2 || hb.apx || (do_lr && guess <= 0), LDW_ERR_STATE,
                     "ldw_set_path(2): the approximate path is not available (delta %.3g, %d weight classes, %lld sequences, screen %d)", c->apx_delta,
                     c->n_classes, (long long)c->N, c->screen);
+        LDW_REQUIRE(!hb.lr_split || hb.apx, LDW_ERR_STATE, "block %lld was prepared for the split (SR sub-pass + ordered long-range pass) but cannot take the approximate path",
+                    (long long)hb.blk_no);
         if (hb.apx) {
             hb.mixed = false;
             hb.lo.apx = 1;
@@ -3086,7 +3093,7 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
             if (int rc = c->hist[s].reserve((size_t)NBINS * 8 * (size_t)(hb.span ? hb.span : 1))) return rc;
             hb.lo.span = hb.span;
             hb.lo.sseg = hb.sseg;
-            hb.lo.sr_excl = (hb.span && !hb.subs.empty()) ? 1 : 0;
+            hb.lo.sr_excl = ((hb.span && !hb.subs.empty()) || hb.lr_split) ? 1 : 0;
             if (int rc = launch_block_apx(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, 1, gs, nullptr, &hb.lo, c->hist[s].p, sl.pick[s],
                                           PICK_STRIDE * (size_t)(hb.span ? hb.span : 1)))
                 return rc;
@@ -3231,10 +3238,27 @@ int submit_b(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
         return rc;
     if (!hb.apx) LDW_HIP(hipMemsetAsync(sl.pick[s], 0, sizeof(ldw::PickOut), c->stream));
     hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
+    // the SR sub-passes of the item (a split diagonal block; the corner segments of a span) — on the MAIN stream, in front of the item's own second
+    // phase: on the GEMM stream (r04b) they lengthened the longer of the two queues (39.8 against 36.0 ms per C4 pass with the corner blocks)
+    if (hb.apx && !hb.subs.empty() && p->keep_sr) {
+        if (!hb.span) {
+            if (int rc = launch_sr_sub(c, hb.subs[0], p, sl, c->stream, hb.sr_base)) return rc;
+        } else {
+            int64_t base = hb.sr_base;
+            size_t si = 0;
+            for (int k = 0; k < hb.span; ++k) {
+                if (si < hb.subs.size() && hb.subs_seg[si] == k) {
+                    if (int rc = launch_sr_sub(c, hb.subs[si], p, sl, c->stream, base)) return rc;
+                    ++si;
+                }
+                base += hb.seg_n_sr[k];
+            }
+        }
+    }
     if (hb.apx) {
         hb.lo.span = hb.span;
         hb.lo.sseg = hb.sseg;
-        hb.lo.sr_excl = (hb.span && !hb.subs.empty()) ? 1 : 0;
+        hb.lo.sr_excl = ((hb.span && !hb.subs.empty()) || hb.lr_split) ? 1 : 0;
         if (int rc = launch_block_apx(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, 2, nullptr, c->hist[s].as<unsigned long long>(), &hb.lo))
             return rc;
     } else if (int rc = launch_block_mi(c, hb.D, hb.nf, hb.nt, hb.RFpad, hb.RTpad, p->quirk_mode, hb.E, ev, c->engine == LDW_ENGINE_MFMA ? 2 : 3,
@@ -3372,6 +3396,7 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
         E.write_dense = 1;
         E.spec_B = -1;
         E.keep_sr = 0;
+        E.any_sr = hb.n_sr_blk > 0 ? 1 : 0;   // (a split block's speculative pass had it off — sr_excl —: the plain epilogue must keep its short-range pairs out of the histogram itself)
         E.scr_mode = 0;   // every pair goes into the histogram
         hb.spec_B = -1;
         LDW_HIP(hipMemsetAsync(c->hist[s].p, 0, (size_t)NBINS * 8, c->stream));
@@ -4010,6 +4035,16 @@ static bool spans_possible(const ldw_ctx *c, const ldw_mi_params *p) {
            !p->sr_only && speculation_pays(c, p) && c->pos_sorted && c->spec_B_next[0] > 0 && c->tab11_on &&
            (p->quirk_mode != LDW_QUIRK_REFERENCE || c->r_min >= 2.0);
 }
+// r04c: a DIAGONAL block can run as SR sub-pass (list order: band GEMM + whole units) + long-range pass with its rows ordered by weight like any
+// long-range-only block (tile pruning, clean regions), the short-range pairs kept out of its candidates: LDW_DIAG_SPLIT=1 / ldw_set_span(on | 4)
+static bool diag_split_ok(const ldw_ctx *c, const int32_t *b) {
+    static const bool env_on = getenv("LDW_DIAG_SPLIT") != nullptr;
+    if (!env_on && !c->diag_split) return false;
+    const int64_t fs = b[0], fe = b[1];
+    if (!(b[2] == fs && b[3] == fe) || fe - fs + 1 < 2048) return false;
+    if ((int64_t)c->h_span_bad.size() != c->L + 1) return false;
+    return c->h_span_bad[(size_t)fe] - c->h_span_bad[(size_t)fs - 1] == 0;
+}
 struct WorkItem {
     int64_t b0;
     int nseg;           // 1: an ordinary block
@@ -4086,7 +4121,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     std::vector<uint8_t> cand((size_t)nblocks, 0);
     for (int64_t b = 0; b < nblocks; ++b) cand[(size_t)b] = (uint8_t)span_candidate(c, blocks + b * 4, p);
     int64_t lead = 0;
-    while (lead < nblocks && !cand[(size_t)lead]) ++lead;
+    while (lead < nblocks && !cand[(size_t)lead] && !diag_split_ok(c, blocks + lead * 4)) ++lead;   // (a block that may be split is planned after the probes)
     for (int64_t b = 0; b < lead; ++b) items.push_back(WorkItem{b, 1, 0u});
     struct Shared {
         std::mutex m;
@@ -4147,7 +4182,22 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
                         rc = LDW_ERR_HIP;
                     }
                     HostBlock &h = hb[k % RING];
-                    if (rc == LDW_OK) rc = prep_block(c, wfi.data(), (int64_t)wfi.size(), wti.data(), (int64_t)wti.size(), p, slot, it.b0, h, it.nseg > 1 ? &spn : nullptr);
+                    const bool split1 = it.nseg == 1 && (it.sr_mask & 1u);   // a diagonal block: SR sub-pass + weight-ordered long-range pass
+                    if (rc == LDW_OK) rc = prep_block(c, wfi.data(), (int64_t)wfi.size(), wti.data(), (int64_t)wti.size(), p, slot, it.b0, h, it.nseg > 1 ? &spn : nullptr, -1, false, 0, split1);
+                    if (rc == LDW_OK && split1) {
+                        if (h.n_sr_blk > 0 && !h.lo.band_full && !h.generic && h.lo.ordered) {
+                            const size_t base = (h.total + 255) / 256 * 256;
+                            HostBlock sub;
+                            rc = prep_block(c, wfi.data(), (int64_t)wfi.size(), wti.data(), (int64_t)wti.size(), p, slot, it.b0, sub, nullptr, -1, true, base);
+                            if (rc == LDW_OK) {
+                                h.stage_total = (base + sub.total + 255) / 256 * 256;
+                                h.subs.push_back(std::move(sub));
+                                h.subs_seg.push_back(0);
+                            }
+                        } else {   // nothing to split after all: the ordinary form of the block
+                            rc = prep_block(c, wfi.data(), (int64_t)wfi.size(), wti.data(), (int64_t)wti.size(), p, slot, it.b0, h);
+                        }
+                    }
                     if (rc == LDW_OK && it.nseg > 1) {
                         h.span_from = wfi;
                         h.span_to = wti;
@@ -4263,6 +4313,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
             uint32_t srm = 0;
             for (int k = 0; k < n; ++k)
                 if (n > 1 && cand[(size_t)(b + k)] == 2) srm |= 1u << k;
+            if (n == 1 && spans && diag_split_ok(c, blocks + b * 4)) srm = 1u;
             rest.push_back(WorkItem{b, n, srm});
             b += n;
         }
@@ -4352,6 +4403,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
 
 int ldw_set_span(ldw_ctx *c, int on, int max_blocks) {
     LDW_REQUIRE(c && (max_blocks == 0 || (max_blocks >= 2 && max_blocks <= LDW_SPAN_MAX)), LDW_ERR_ARG, "ldw_set_span: max_blocks must be 0 or 2..%d", LDW_SPAN_MAX);
+    c->diag_split = (on & 4) != 0;     // bit 2: diagonal blocks as SR sub-pass + weight-ordered long-range pass
     c->span_corners = (on & 2) != 0;   // bit 1: corner blocks (few short-range pairs) join the spans, their short-range pairs go to SR sub-passes (off by default: slower)
     c->span_on = on != 0;
     if (max_blocks) c->span_max = max_blocks;

@@ -85,10 +85,11 @@ class Engine:
         L.check(L.lib().ldw_prune_report(self._ctx, L.ptr(v)))
         return dict(ordered_blocks=int(v[0]), tiles_pruned=int(v[1]), tiles_total=int(v[2]), on=bool(v[3]))
 
-    def set_span(self, on: bool, max_blocks: int = 0, corners: bool = False):
+    def set_span(self, on: bool, max_blocks: int = 0, corners: bool = False, diag_split: bool = False):
         """Spans (default on): consecutive long-range-only block pairs of one block row run as one launch sequence; results never depend on it.
-        corners: corner block pairs join them too (their short-range pairs through SR sub-passes; slower, off by default)."""
-        L.check(L.lib().ldw_set_span(self._ctx, (1 if on else 0) | (2 if (on and corners) else 0), int(max_blocks)))
+        corners: corner block pairs join them too (their short-range pairs through SR sub-passes; slower, off by default).
+        diag_split: diagonal blocks run as SR sub-pass + weight-ordered long-range pass (off by default)."""
+        L.check(L.lib().ldw_set_span(self._ctx, (1 if on else 0) | (2 if (on and corners) else 0) | (4 if (on and diag_split) else 0), int(max_blocks)))
 
     def span_report(self):
         v = np.zeros(4, dtype=np.int64)

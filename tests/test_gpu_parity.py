@@ -1771,6 +1771,12 @@ def test_spans_equal_block_by_block(engine):
             same(plain, run(quirk, True), (quirk, "spans with corner blocks, cold"))
             same(plain, run(quirk, False), (quirk, "spans with corner blocks, warm"))
             s3 = engine.span_report()
+            # diagonal blocks as SR sub-pass (list order) + long-range pass with rows ordered by weight (tile pruning on the lower triangle)
+            engine.set_span(True, 8, corners=False, diag_split=True)
+            same(plain, run(quirk, True), (quirk, "diagonal blocks split, cold"))
+            same(plain, run(quirk, False), (quirk, "diagonal blocks split, warm"))
+            engine.set_span(True, 8, corners=True, diag_split=True)
+            same(plain, run(quirk, True), (quirk, "corners + diagonal split"))
             assert s3["blocks"] - s2["blocks"] >= 50, (s2, s3)    # (rows 0..5: every off-diagonal pair of the row in one span: 7 + 6 + 5 + 4 + 3 + 2, twice)
             engine.set_span(True, 8)
         # overflow: every pair list holds 64 entries -> every speculative block / segment is redone non-speculatively
