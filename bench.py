@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--path", type=int, default=0, help="block-wide pass of the speculative blocks: 0 auto, 1 limb GEMM paths, 2 approximate GEMM + popcount sums")
     ap.add_argument("--screen", type=int, default=1, help="fp32 screen before the fp64 MI evaluation: 0 off, 1 on, 2 verify")
     ap.add_argument("--gather-phases", type=int, default=3, help="N > 1: phases of the link-table gather (1 = one gather after all blocks)")
+    ap.add_argument("--full-sr-rows", dest="sr_mi_only", action="store_false", help="N > 1: send all three columns of the short-range rows (r03) instead of "
+                                                                                   "their MI column alone (rank 0 rebuilds the index columns: 8 instead of 16 bytes per row)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="SNPs per side of the CPU-baseline sample block (0 = auto)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the warm / sustained / mi_values_produced / job legs after the timed region")
     ap.add_argument("--warm", action="store_true", help="do NOT reset the speculation state before every step (the r02 behaviour: each step inherits "
@@ -350,14 +352,14 @@ def main():
             eng.reset_speculation()   # a job's first (and only) pass: nothing inherited from an earlier pass over the same data
         if world == 1:
             local, cnt = compute(mine, accumulate_timing)
-            out = gather_link_tables(local, mine, cnt, nblocks)
+            out = gather_link_tables(local, mine, cnt, nblocks)   # (one rank: an in-place view, nothing moves)
         else:
             started = []
             for sub in my_phases:
                 t0 = time.perf_counter()
                 local, cnt = compute(sub, accumulate_timing)
                 t1 = time.perf_counter()
-                started.append(gather_begin(local, sub, cnt, nblocks))
+                started.append(gather_begin(local, sub, cnt, nblocks, sr_index=not args.sr_mi_only))
                 t2 = time.perf_counter()
                 if accumulate_timing:
                     rk_acc["compute_ms"] += (t1 - t0) * 1e3
@@ -365,7 +367,8 @@ def main():
                     if rank != 0:
                         rk_acc["bytes_sent"] += int(started[-1].mine.numel())
             t3 = time.perf_counter()
-            out = gather_end(started, nblocks)
+            # (--sr-mi-only, default: the short-range rows travel as their MI column alone; rank 0 rebuilds their index columns from the positions)
+            out = gather_end(started, nblocks, sr_pairs=(lambda n: eng.sr_pairs(blocks, sr_dist, n)) if args.sr_mi_only else None)
             if accumulate_timing:
                 rk_acc["exposed_gather_ms"] += (time.perf_counter() - t3) * 1e3   # waiting for transfers + (rank 0) re-interleaving the segments
                 rk_acc["steps"] += 1
@@ -572,7 +575,8 @@ def main():
                                step=("cold pass: speculation state reset before every step (ldw_reset_speculation), buffers allocated" if cold else
                                      "WARM replay (--warm): every step inherits the previous step's bucket guesses"),
                                result_at_rank0=("in-place view of the engine's device-resident link tables (N = 1: no gather, no copy)" if world == 1 else
-                                                "tables assembled on rank 0 by the phased gather"),
+                                                ("tables assembled on rank 0 by the phased gather" +
+                                                 (": short-range rows travel as their MI column (8 B), rank 0 rebuilds their index columns from the positions" if args.sr_mi_only else ""))),
                                fused=bool(args.fused), screen=args.screen, mixed_precision=bool(mixed), path=args.path,
                                approximate_gemm=eng.apx_info(),
                                parallelism=f"pair-space blocks over {world} GPU(s)"),

@@ -236,6 +236,12 @@ int ldw_prune_report(ldw_ctx *ctx, int64_t out[4]);
  * from L, N and max_blk_sz: call it before uploading the alignment and it hides behind the upload and the Hamming GEMM).  Both are
  * optional (everything is also made lazily: LDW_NO_PREPARE=1 switches them off); the entry points that use what they prepare wait for them. */
 int ldw_ctx_reserve(ldw_ctx *ctx, int64_t L, int64_t N, int64_t max_blk_sz);
+/* r04 — the index columns of the short-range table from positions alone.  The short-range rows a pass emits for a block pair of contiguous SNP
+ * ranges are a pure function of POS, g, sr_dist and the block geometry (R/computePairwiseMI.R:306-333: upper-triangle rows column by
+ * column, then the lower ones; pos1 = POS_t[col], pos2 = POS_f[row]) — so a multi-GPU gather sends only their MI column and rank 0 rebuilds
+ * (a, b) here.  blocks: nblocks x 4 (from_s, from_e, to_s, to_e), 1-based inclusive, in the order of the table; a_out / b_out: DEVICE int32 arrays
+ * of `capacity` rows (both null: count only); *n_out = rows.  Needs POS ascending (ldw_set_snp_meta). */
+int ldw_sr_pairs_fill(ldw_ctx *ctx, const int32_t *blocks, int64_t nblocks, double sr_dist, int32_t *a_out, int32_t *b_out, int64_t capacity, int64_t *n_out);
 int ldw_set_span(ldw_ctx *ctx, int on, int max_blocks);
 int ldw_span_report(ldw_ctx *ctx, int64_t out[4]);
 int ldw_set_pair_cap(uint32_t cap);

@@ -93,6 +93,7 @@ _SIGS = {
     "ldw_set_prune": (C.c_int, [_p, C.c_int]),
     "ldw_prune_report": (C.c_int, [_p, _p]),
     "ldw_ctx_reserve": (C.c_int, [_p, C.c_int64, C.c_int64, C.c_int64]),
+    "ldw_sr_pairs_fill": (C.c_int, [_p, _p, C.c_int64, C.c_double, _p, _p, C.c_int64, _p]),
     "ldw_set_span": (C.c_int, [_p, C.c_int, C.c_int]),
     "ldw_span_report": (C.c_int, [_p, _p]),
     "ldw_set_pair_cap": (C.c_int, [C.c_uint32]),

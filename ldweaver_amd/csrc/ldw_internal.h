@@ -228,6 +228,7 @@ struct ldw_ctx {
     std::vector<hipEvent_t> ev_pool;     // 4 timing events per block
     int spec_hist[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};   // the last true buckets per kind (adaptive margin of the guess)
     int spec_hist_n[2] = {0, 0};
+    bool spec_small[2] = {false, false};   // the kind's blocks keep few rows (< 5000): noisier thresholds, wider margins
     int spec_B_next[2] = {-1, -1};       // bucket guess for the speculative long-range gather: [off-diagonal, diagonal]
     int64_t spec_misses = 0, fused_blocks = 0, unfused_blocks = 0, screen_violations = 0, mixed_blocks = 0;
     int screen = 1;                      // fp32 screen in front of the fp64 MI evaluation (0 off, 1 on, 2 verify)

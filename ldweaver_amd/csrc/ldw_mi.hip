@@ -1602,6 +1602,25 @@ __global__ void k_span_done(SelSpan S, SpanDoneArgs D, int64_t *lr_count, int64_
     }
 }
 
+// (a, b) of the short-range rows of ONE block of contiguous SNP ranges, from positions alone: the rows a pass emits there are a pure
+// function of POS, g, sr_dist and the block geometry (R/computePairwiseMI.R:306-333) — what lets a multi-GPU gather send only the MI column of
+// the short-range table (8 of 16 bytes per row) and rank 0 rebuild the index columns itself.  One wave per to-side SNP.
+__global__ __launch_bounds__(256) void k_sr_fill(const ColInfo *__restrict__ cols, int nf, int nt, int fs0, int ts0, int lower_only, int64_t base,
+                                                 int32_t *__restrict__ a_out, int32_t *__restrict__ b_out) {
+    const int lane = threadIdx.x & 63, b_loc = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b_loc >= nt) return;
+    const ColInfo c = cols[b_loc];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int a_loc = c.s[k] + lane; a_loc < c.e[k]; a_loc += 64) {
+            const int seg = pair_seg(a_loc, b_loc, lower_only);
+            if (seg < 0) continue;
+            const int64_t dst = base + (seg == 0 ? c.off_u + col_count(c, 0, a_loc) : c.off_l + col_count(c, b_loc + 1, a_loc));
+            a_out[dst] = fs0 + a_loc;
+            b_out[dst] = ts0 + b_loc;
+        }
+}
+
 // running device-side counters and per-block stats
 __global__ void k_block_done(PickOut *pick, int64_t *lr_count, int64_t n_sr_blk, int64_t *stats_i, double *stats_d) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -2249,10 +2268,11 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     A.rowpack_hi = rph;
     // LDW_SCREEN_MAIN=1 (experiment): the block's screen at the head of phase 2 on the main stream — beside the NEXT block's GEMM on the GEMM
     // stream — instead of behind its own GEMM
-    // r04: a SPAN's screen does run at the head of phase 2 (main stream): with the corner blocks inside the spans the GEMM stream carried 32 ms of a
-    // 39 ms pass (approximate GEMMs, every screen, the SR sub-passes) and the main stream 18 (profiles/r04_timeline_*); LDW_SPAN_SCREEN_GS=1 keeps it behind the GEMM
-    static const bool screen_main_env = getenv("LDW_SCREEN_MAIN") != nullptr, span_screen_gs = getenv("LDW_SPAN_SCREEN_GS") != nullptr;
-    const bool screen_main = screen_main_env || (lo_h->span > 0 && !span_screen_gs);
+    // (r04: a span's screen at the head of phase 2 was tried for balance — no gain at C4 — and is WRONG in general: phase 2 is queued after the
+    // first phase of LATER items, which may rebuild the threshold table for their level; the screen then either finds no table it may use and,
+    // with it, no clean flags — it reads the regions the GEMM's epilogue did not store: 20-60 million pairs listed per span at C5, overflowing
+    // lists, 43 segments redone per pass — or races the rebuild.  The screen belongs behind its own GEMM, on the GEMM stream.)
+    static const bool screen_main = getenv("LDW_SCREEN_MAIN") != nullptr;
     const int rm_s = quirk == LDW_QUIRK_REFERENCE ? (lo_h->span ? 3 : (nf == nt ? 1 : 2)) : 0;
     // r04 experiment: list-driven screen (k_screen_tiles -> k_screen_live -> k_mi_screen_list) instead of one workgroup per (tile, column group)
     // (measured r04, C4, 10 cold steps per setting on one box: full grid 36.9 ms per pass, list-driven with 1536 / 4096 / 12288 / 32768 striding
@@ -3027,6 +3047,14 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     hipEvent_t *ev = &c->ev_pool[(size_t)hb.blk_no * EVB];
     const bool do_lr = !p->sr_only;
     int guess = do_lr ? ((speculation_pays(c, p) && !hb.force_plain) ? c->spec_B_next[hb.diag ? 1 : 0] : -1) : 0;
+    if (hb.span > 1 && guess > 0) {
+        // one guess serves every reference block of the span, and the next guess only arrives after all of them: LDW_SPAN_MARGIN=k lowers it by k
+        // more buckets.  Not needed: at C5 (800 kept rows per block, the noisiest thresholds) 3 of 1275 blocks miss per pass with k = 0, as many
+        // as block by block, and k = 4 lists 40 % more pairs (858 against 846 ms per pass)
+        static const int extra_env = [] { const char *e = getenv("LDW_SPAN_MARGIN"); return e ? atoi(e) : -1; }();
+        const int extra = extra_env >= 0 ? extra_env : 0;
+        guess = guess > extra ? guess - extra : 1;
+    }
     if (hb.lr_split && !(guess > 0 && c->path_mode != 1 && c->apx_ok && c->screen == 1 && do_lr && !c->fused)) {
         // prepared for the split, but no positive guess for its kind (no probe for blocks this small, say): the plain path does the whole
         // block — short-range rows included — on the ordered rows (it reads every position through the row maps)
@@ -3295,6 +3323,7 @@ void update_guess(ldw_ctx *c, bool diag, const ldw::PickOut *hp, bool missed) {
         }
         // few kept rows per block (many blocks: C5 keeps ~800 per block) make the threshold itself noisier
         const bool small = hp->n * (1.0 - hp->prob) < 5000.0;
+        c->spec_small[kind] = small;
         margin = hi - lo + (small ? 4 : 2);
         const int mmin = small ? 6 : 4;
         margin = margin < mmin ? mmin : (margin > 10 ? 10 : margin);
@@ -3497,6 +3526,23 @@ int finish_span(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLa
     }
     const char *d = stage_ptr(c, hb);
     if ((int64_t)c->trace.size() < hb.blk_no + hb.span) c->trace.resize((size_t)(hb.blk_no + hb.span));
+    {
+        static const bool trace_on = getenv("LDW_BLOCK_TRACE") != nullptr;
+        if (trace_on && picks[0].n > 0 && !picks[0].spec_ok) {   // a span that missed: its pair-list counters (an overflowing list fails every segment)
+            unsigned int pl[PAIR_PATHS * PAIR_SHARDS];
+            LDW_HIP(hipMemcpy(pl, c->pairs[s].p, sizeof(pl), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[ldw span at block %lld] guess %d, %d segments, pair-list capacity %u, counters by path:", (long long)hb.blk_no, hb.guess, hb.span, pair_cap_for(hb.nf, hb.nt, hb.span));
+            for (int pth = 0; pth < PAIR_PATHS; ++pth) {
+                unsigned long long tot = 0, mx = 0;
+                for (int sh2 = 0; sh2 < PAIR_SHARDS; ++sh2) {
+                    tot += pl[pth * PAIR_SHARDS + sh2];
+                    mx = std::max<unsigned long long>(mx, pl[pth * PAIR_SHARDS + sh2]);
+                }
+                fprintf(stderr, "  [%d] total %llu max %llu", pth, tot, mx);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
     // the common case — every guess held, every candidate set fits the sort-free selection — takes ONE launch per stage for all segments
     static const bool sel_fast_on = getenv("LDW_NO_FAST_SELECT") == nullptr && getenv("LDW_NO_SPAN_SELECT") == nullptr;
     bool batched = sel_fast_on && c->select_mode == 0;
@@ -4399,6 +4445,46 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         fprintf(stderr, "[ldw host us/item] submit_b %.1f  wait for the helper's prep %.1f  submit_a (incl. that wait) %.1f  finish (incl. wait) %.1f  items %lld (blocks %lld)\n", th[0] / nitems, th[1] / nitems,
                 th[2] / nitems, th[3] / nitems, (long long)nitems, (long long)nblocks);
     return rc_end;
+}
+
+int ldw_sr_pairs_fill(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, double sr_dist, int32_t *a_out, int32_t *b_out, int64_t capacity, int64_t *n_out) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(blocks && nblocks > 0 && n_out && sr_dist >= 0, LDW_ERR_ARG, "ldw_sr_pairs_fill: bad argument");
+    LDW_REQUIRE(c->have_meta && c->pos_sorted, LDW_ERR_STATE, "ldw_sr_pairs_fill: needs SNP positions in ascending order (ldw_set_snp_meta)");
+    std::vector<int32_t> fi, ti;
+    std::vector<ColInfo> cols;
+    int64_t base = 0;
+    ldw::DevBuf dcols;
+    struct Rel {
+        ldw::DevBuf &b;
+        ~Rel() { b.release(); }
+    } rel{dcols};
+    for (int64_t b = 0; b < nblocks; ++b) {
+        const int32_t fs = blocks[b * 4 + 0], fe = blocks[b * 4 + 1], ts = blocks[b * 4 + 2], te = blocks[b * 4 + 3];
+        LDW_REQUIRE(fs >= 1 && fe >= fs && fe <= c->L && ts >= 1 && te >= ts && te <= c->L, LDW_ERR_ARG, "block %lld = (%d,%d,%d,%d) outside 1..%lld", (long long)b, fs, fe,
+                    ts, te, (long long)c->L);
+        const int64_t nf = fe - fs + 1, nt = te - ts + 1;
+        fi.resize((size_t)nf);
+        ti.resize((size_t)nt);
+        for (int64_t k = 0; k < nf; ++k) fi[(size_t)k] = fs - 1 + (int32_t)k;
+        for (int64_t k = 0; k < nt; ++k) ti[(size_t)k] = ts - 1 + (int32_t)k;
+        const bool diag = fs == ts && fe == te;
+        int64_t n_blk = 0;
+        if (int rc = build_cols(c, fi.data(), nf, ti.data(), nt, diag, sr_dist, cols, n_blk)) return rc;
+        if (n_blk > 0 && a_out && b_out) {
+            LDW_REQUIRE(base + n_blk <= capacity, LDW_ERR_SIZE, "ldw_sr_pairs_fill: capacity %lld < %lld rows", (long long)capacity, (long long)(base + n_blk));
+            LDW_HIP(hipStreamSynchronize(c->stream));   // (cols of the block before is still being read)
+            if (int rc = dcols.reserve(cols.size() * sizeof(ColInfo))) return rc;
+            LDW_HIP(hipMemcpyAsync(dcols.p, cols.data(), cols.size() * sizeof(ColInfo), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_sr_fill, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, c->stream, dcols.as<ColInfo>(), (int)nf, (int)nt, fs - 1, ts - 1, diag ? 1 : 0, base,
+                               a_out, b_out);
+            LDW_HIP(hipGetLastError());
+        }
+        base += n_blk;
+    }
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    *n_out = base;
+    return LDW_OK;
 }
 
 int ldw_set_span(ldw_ctx *c, int on, int max_blocks) {

@@ -87,11 +87,11 @@ def deal_blocks(blocks: np.ndarray, world: int, cost: np.ndarray | None = None) 
 
 class _Phase:
     """One started gather: the count table of its blocks, the packed buffers and the outstanding transfers."""
-    __slots__ = ("tab", "owner", "rows", "bufs", "works", "mine", "out_dev", "rank", "world", "dst")
+    __slots__ = ("tab", "owner", "rows", "bufs", "works", "mine", "out_dev", "rank", "world", "dst", "sr_index")
 
 
 def gather_begin(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int, group=None, dst: int = 0,
-                 force_collective=None) -> _Phase:
+                 force_collective=None, sr_index: bool = True) -> _Phase:
     """Start the gather of the link tables of a SUBSET of blocks (this rank's ``my_blocks``, any rank's may be empty) and
     return without waiting for the transfers: the caller goes on computing its next blocks while the rows travel, and
     hands all its phases to ``gather_end``.  Every rank must call it the same number of times (it contains a collective).
@@ -99,8 +99,12 @@ def gather_begin(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int,
     local:   {"sr": (a, b, mi), "lr": (a, b, mi)} tensors of this rank (int32, int32, float64), rows grouped by
              block in the order of ``my_blocks``.
     counts:  {"sr": int64[len(my_blocks)], "lr": ...} rows per owned block.
+    sr_index=False (r04): the index columns (a, b) of the SHORT-RANGE rows stay at home — they are a pure function of the positions and
+             the block geometry (R/computePairwiseMI.R:306-333), the destination rebuilds them (``gather_end(..., sr_pairs=...)``,
+             ``Engine.sr_pairs``) — and only their MI column travels: 8 instead of 16 bytes per row of the table that is 99 % of the gather.
     """
     ph = _Phase()
+    ph.sr_index = bool(sr_index)
     world, rank = _world_rank(group)
     loopback = world == 1 and _forced(force_collective) and dist.is_initialized()
     ph.world, ph.rank, ph.dst = world, rank, dst
@@ -128,11 +132,13 @@ def gather_begin(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int,
     def pack(tabs):
         parts = []
         for k in kinds:
-            parts += [t.contiguous().view(torch.uint8) for t in tabs[k] if t.numel()]   # (an empty tensor may have stride 0)
+            cols = tabs[k] if (k != "sr" or ph.sr_index) else tabs[k][2:]   # [sr_mi] alone when the index columns stay at home
+            parts += [t.contiguous().view(torch.uint8) for t in cols if t.numel()]   # (an empty tensor may have stride 0)
         return torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8, device=dev)
 
     ph.rows = {k: np.array([tab[ph.owner == rk, i].sum() for rk in range(world)]) for i, k in enumerate(kinds)}
-    nbytes = [int(16 * (ph.rows["sr"][rk] + ph.rows["lr"][rk])) for rk in range(world)]
+    sr_b = 16 if ph.sr_index else 8
+    nbytes = [int(sr_b * ph.rows["sr"][rk] + 16 * ph.rows["lr"][rk]) for rk in range(world)]
     ph.mine = pack(local)
     assert ph.mine.numel() == nbytes[rank], (ph.mine.numel(), nbytes[rank])
     if ph.mine.is_cuda:
@@ -159,9 +165,10 @@ def gather_begin(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int,
     return ph
 
 
-def gather_end(phases: list, nblocks: int):
+def gather_end(phases: list, nblocks: int, sr_pairs=None):
     """Wait for the transfers of all phases and assemble the global link tables on the destination rank in make_blocks
-    order (None elsewhere)."""
+    order (None elsewhere).  Phases begun with ``sr_index=False`` need ``sr_pairs``: a callable ``n_rows -> (a, b)`` giving the index
+    columns of the assembled short-range table (``Engine.sr_pairs`` over the whole block list)."""
     for ph in phases:
         for w in ph.works:
             w.wait()
@@ -180,8 +187,11 @@ def gather_end(phases: list, nblocks: int):
             o, d = 0, {}
             for k in kinds:
                 n = int(ph.rows[k][rk])
-                a = ph.bufs[rk][o:o + 4 * n].view(torch.int32); o += 4 * n
-                b = ph.bufs[rk][o:o + 4 * n].view(torch.int32); o += 4 * n
+                if k == "sr" and not ph.sr_index:
+                    a = b = None
+                else:
+                    a = ph.bufs[rk][o:o + 4 * n].view(torch.int32); o += 4 * n
+                    b = ph.bufs[rk][o:o + 4 * n].view(torch.int32); o += 4 * n
                 mi = ph.bufs[rk][o:o + 8 * n].view(torch.float64); o += 8 * n
                 d[k] = (a, b, mi)
             per_rank.append(d)
@@ -195,22 +205,36 @@ def gather_end(phases: list, nblocks: int):
                 n = int(ph.tab[bi, ki])
                 c0 = cursor[rk]
                 for j in range(3):
-                    segs[k][bi][j] = per_rank[rk][k][j][c0:c0 + n]
+                    col = per_rank[rk][k][j]
+                    segs[k][bi][j] = col[c0:c0 + n] if col is not None else None
                 cursor[rk] = c0 + n
     if not owned.all():
         raise RuntimeError("some blocks were processed by no rank")
     out = {}
+    rebuild_sr = any(not ph.sr_index for ph in phases)
+    if rebuild_sr and not all(not ph.sr_index for ph in phases):
+        raise RuntimeError("gather_end: every phase must be begun with the same sr_index")
     for k in kinds:
         cols = []
         for j, dt in enumerate((torch.int32, torch.int32, torch.float64)):
+            if k == "sr" and rebuild_sr and j < 2:
+                cols.append(None)
+                continue
             parts = [segs[k][bi][j] for bi in range(nblocks) if segs[k][bi][j] is not None and len(segs[k][bi][j])]
             cols.append((torch.cat(parts) if parts else torch.empty(0, dtype=dt)).to(ph0.out_dev))
+        if k == "sr" and rebuild_sr:
+            if sr_pairs is None:
+                raise RuntimeError("gather_end: phases begun with sr_index=False need sr_pairs")
+            a, b = sr_pairs(int(cols[2].numel()))
+            if a.numel() != cols[2].numel() or b.numel() != cols[2].numel():
+                raise RuntimeError(f"gather_end: sr_pairs gave {a.numel()} rows, the gathered table has {cols[2].numel()}")
+            cols[0], cols[1] = a.to(ph0.out_dev), b.to(ph0.out_dev)
         out[k] = tuple(cols)
     return out
 
 
 def gather_link_tables(local: dict, my_blocks: np.ndarray, counts: dict, nblocks: int, group=None, dst: int = 0,
-                       force_collective=None):
+                       force_collective=None, sr_pairs=None):
     """Assemble the global link tables on rank ``dst`` in make_blocks order (one phase: see gather_begin / gather_end).
     Returns the same dict of global tensors on rank dst, None elsewhere."""
     world, _ = _world_rank(group)
@@ -219,7 +243,8 @@ def gather_link_tables(local: dict, my_blocks: np.ndarray, counts: dict, nblocks
         if len(my_blocks) != nblocks:
             raise RuntimeError("some blocks were processed by no rank")
         return {k: tuple(local[k]) for k in ("sr", "lr")}
-    return gather_end([gather_begin(local, my_blocks, counts, nblocks, group=group, dst=dst, force_collective=force_collective)], nblocks)
+    return gather_end([gather_begin(local, my_blocks, counts, nblocks, group=group, dst=dst, force_collective=force_collective,
+                                    sr_index=sr_pairs is None)], nblocks, sr_pairs=sr_pairs)
 
 
 def gather_block_stats(my_stats: dict, my_blocks: np.ndarray, nblocks: int, group=None, force_collective=None) -> dict:

@@ -85,6 +85,23 @@ class Engine:
         L.check(L.lib().ldw_prune_report(self._ctx, L.ptr(v)))
         return dict(ordered_blocks=int(v[0]), tiles_pruned=int(v[1]), tiles_total=int(v[2]), on=bool(v[3]))
 
+    def sr_pairs(self, blocks, sr_dist: float, n_rows: int | None = None):
+        """(a, b) int32 CUDA tensors: the index columns of the short-range table of a pass over `blocks` (in their order), rebuilt from the
+        positions alone (ldw_sr_pairs_fill).  What rank 0 of a multi-GPU run does instead of receiving them."""
+        import torch
+        bl = L.as_c(blocks, np.int32).reshape(-1, 4)
+        n = C.c_int64(0)
+        if n_rows is None:
+            L.check(L.lib().ldw_sr_pairs_fill(self._ctx, L.ptr(bl), len(bl), float(sr_dist), None, None, 0, C.byref(n)))
+            n_rows = int(n.value)
+        dev = torch.device("cuda", self.device)
+        a = torch.empty(max(1, n_rows), dtype=torch.int32, device=dev)
+        b = torch.empty(max(1, n_rows), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        L.check(L.lib().ldw_sr_pairs_fill(self._ctx, L.ptr(bl), len(bl), float(sr_dist), C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), n_rows, C.byref(n)))
+        assert int(n.value) == n_rows, (int(n.value), n_rows)
+        return a[:n_rows], b[:n_rows]
+
     def set_span(self, on: bool, max_blocks: int = 0, corners: bool = False, diag_split: bool = False):
         """Spans (default on): consecutive long-range-only block pairs of one block row run as one launch sequence; results never depend on it.
         corners: corner block pairs join them too (their short-range pairs through SR sub-passes; slower, off by default).

@@ -250,7 +250,12 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
                 agree(err is None, group, "perform_MI_computation")
             except RuntimeError as e:
                 raise e from err
-            out = gather_link_tables(local, mine, {"sr": my_stats["n_sr"], "lr": my_stats["n_lr_kept"]}, len(blocks), group=group)
+            # r04: the index columns of the short-range rows are a function of the positions alone (R/computePairwiseMI.R:306-333): with ascending
+            # POS and whole blocks only their MI column travels and rank 0 rebuilds (a, b) (Engine.sr_pairs); SR-only passes (filtered site
+            # lists) and unsorted positions send all three columns
+            mi_only = (not perform_SR_analysis_only) and bool(np.all(np.diff(np.asarray(POS, dtype=np.int64)) >= 0))
+            out = gather_link_tables(local, mine, {"sr": my_stats["n_sr"], "lr": my_stats["n_lr_kept"]}, len(blocks), group=group,
+                                     sr_pairs=(lambda n: eng.sr_pairs(blocks, sr_dist, n)) if mi_only else None)
             stats = gather_block_stats(my_stats, mine, len(blocks), group=group)
             if rank != 0:
                 return None

@@ -52,6 +52,35 @@ def _worker(rank, world, port, q):
                     assert torch.equal(out3[kind][j], out[kind][j])
         else:
             assert out3 is None
+        # r04: the same phases with the short-range index columns left at home (sr_index=False): only sr_mi travels — 8 instead of 16 bytes
+        # per short-range row — and the destination rebuilds (a, b) itself (here: from the fake generator; in the product: Engine.sr_pairs)
+        phases_mi, sent16, sent8 = [], 0, 0
+        for p0, p1 in zip(cuts[:-1], cuts[1:]):
+            sub, lo, cn = mine[p0:p1], {}, {}
+            for kind in ("sr", "lr"):
+                segs = [_fake_block_links(int(bi), kind) for bi in sub]
+                cn[kind] = np.array([len(s[2]) for s in segs], dtype=np.int64)
+                cat = lambda j, dt: torch.as_tensor(np.concatenate([s[j] for s in segs]) if segs else np.zeros(0), dtype=dt)
+                lo[kind] = (cat(0, torch.int32), cat(1, torch.int32), cat(2, torch.float64))
+            ph = gather_begin(lo, sub, cn, len(blocks), sr_index=False)
+            phases_mi.append(ph)
+            sent8 += int(ph.mine.numel())
+            sent16 += 16 * int(cn["sr"].sum() + cn["lr"].sum())
+            assert int(ph.mine.numel()) == 8 * int(cn["sr"].sum()) + 16 * int(cn["lr"].sum())
+
+        def fake_pairs(n_rows):
+            exp = [_fake_block_links(bi, "sr") for bi in range(len(blocks))]
+            a = torch.as_tensor(np.concatenate([e[0] for e in exp]), dtype=torch.int32)
+            b = torch.as_tensor(np.concatenate([e[1] for e in exp]), dtype=torch.int32)
+            assert len(a) == n_rows
+            return a, b
+        out_mi = gather_end(phases_mi, len(blocks), sr_pairs=fake_pairs if rank == 0 else None)
+        if rank == 0:
+            for kind in ("sr", "lr"):
+                for j in range(3):
+                    assert torch.equal(out_mi[kind][j], out[kind][j]), (kind, j)
+        else:
+            assert out_mi is None and (sent16 == 0 or sent8 < sent16)
         # per-block diagnostics travel the same way: every rank ends up with all blocks' rows
         fake = lambda bi: (1000 + bi, 10 + bi, 5 * bi, float("nan") if bi % 4 == 0 else 0.25 + bi)
         st = {k: np.array([fake(int(bi))[j] for bi in mine], dtype=np.float64 if k == "disc_thresh" else np.int64)

@@ -1762,6 +1762,10 @@ def test_spans_equal_block_by_block(engine):
             for tag, t in (("off cold", off_cold), ("off warm", off_warm), ("on cold", on_cold), ("on warm", on_warm)):
                 same(plain, t, (quirk, tag))
             assert len(plain[1][2]) > 500_000 and len(plain[0][2]) > 1_000_000
+            # the index columns of the short-range table from the positions alone (ldw_sr_pairs_fill: what rank 0 of a multi-GPU run rebuilds
+            # instead of receiving) == the pass's own
+            pa, pb = engine.sr_pairs(blocks, 20000.0)
+            assert np.array_equal(pa.cpu().numpy(), plain[0][0]) and np.array_equal(pb.cpu().numpy(), plain[0][1])
             # shorter spans give the same tables
             engine.set_span(True, 2)
             same(plain, run(quirk, True), (quirk, "spans of 2"))
