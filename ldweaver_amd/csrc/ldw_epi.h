@@ -464,6 +464,39 @@ struct FullCells {
     int64_t n[NA + 1][NB + 1];
 };
 
+// the int32 table of the approximate path from entries already in registers (g[j][i]: slot i of the from-side SNP, slot j of the to-side SNP):
+// the same cells as full_cells computes (the approximate marginals and their differences fit 31 bits: they are sums of the int32 block)
+template <int NA, int NB>
+struct FullCells32 {
+    int n[NA + 1][NB + 1];
+};
+template <int NA, int NB>
+__device__ __forceinline__ void full_cells32(const RowSide &R, const ColMeta &M, const int (&g)[NB][NA], FullCells32<NA, NB> &C) {
+    int rs[NA], cs[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) rs[i] = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) cs[j] = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = g[j][i];
+            C.n[i][j] = v;
+            rs[i] += v;
+            cs[j] += v;
+        }
+    int dd = (int)R.pa[NA];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        C.n[NA][j] = (int)M.pb[j] - cs[j];
+        dd -= C.n[NA][j];
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) C.n[i][NB] = (int)R.pa[i] - rs[i];
+    C.n[NA][NB] = dd;
+}
+
 template <int NA, int NB>
 __device__ __forceinline__ void full_cells(const RowSide &R, const ColMeta &M, const GAcc &Ga, FullCells<NA, NB> &C) {
     int64_t rs[NA > 0 ? NA : 1], cs[NB > 0 ? NB : 1];
@@ -549,9 +582,9 @@ constexpr float SCREEN_EPS = 2e-4f;
 // cell was clamped): sum (x - x') <= W - (sum_i pa'_i) 2^(e_last - F), a per-SNP constant of a few 1e-2 (the weights are rounded to
 // the NEAREST dual-digit product: the errors of the 57 weight classes of C4 largely cancel) instead of delta sum x' = 0.27.  The
 // margin this removes is delta = 1.5e-3 nats: 2.77e6 -> 2.17e6 listed pairs per C4 pass (LDW_SCREEN_R02_BOUND restores the old form).
-template <int NA, int NB, bool APX = false>
+template <int NA, int NB, bool APX = false, typename FC = FullCells<NA, NB>>
 __device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSide &R, const ColMeta &M, double RXY,
-                                                   const FullCells<NA, NB> &C) {
+                                                   const FC &C) {
     const float ra = (float)R.ra, rb = (float)M.rb;
     const float den = (float)A.neff + (ra * rb) * 0.5f;
     const float rX = 0.5f * ra, rY = 0.5f * rb, rxy = (float)RXY;

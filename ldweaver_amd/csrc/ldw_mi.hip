@@ -36,6 +36,9 @@
 #ifndef LDW_SCREEN_V
 #define LDW_SCREEN_V 2   // columns in flight per wave in the multi-cell screen (tuning: make CXXFLAGS+=-DLDW_SCREEN_V=4)
 #endif
+#ifndef LDW_SCREEN_WAVES
+#define LDW_SCREEN_WAVES 6   // waves per SIMD the screen is compiled for (80 VGPRs; 5: 96)
+#endif
 #include "ldw_epi.h"
 #include <condition_variable>
 #include <mutex>
@@ -187,6 +190,86 @@ __device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowS
     return bits;
 }
 
+// r04: the same columns on the approximate path with pair lists, for blocks whose entries are never read transposed (all but the diagonal
+// ones).  Measured (LDW_SCREEN_EXP, profiles/r04_screen_breakdown.txt): 73 % of a span's screen is this multi-cell evaluation, and its waves
+// spend 73 % of their cycles waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES) with the VALU at 45 %: two columns' entries in flight per wave were too
+// few.  Here the entries of all U columns (and the r look-ups of quirk Q1 on a span) are requested up front — to-side row base in SGPRs, the
+// lane's from-side row as a 32-bit offset — and the tables are built in int32 from registers, one column at a time.
+template <int NA, int NB, int U, int RM>
+__device__ __forceinline__ unsigned int screen_cols_apx(const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc, bool a_ok, float lo, int q0,
+                                                        int tile) {
+    const bool test_sr = A.E.any_sr != 0 || A.sr_excl != 0, keep_sr = A.E.keep_sr != 0 && !A.sr_excl, do_lr = A.E.do_lr != 0;
+    const int32_t *G32 = reinterpret_cast<const int32_t *>(A.G);
+    int raw[U][NB][NA];
+    float rl[U];
+    if (do_lr) {   // (an SR-only pass needs no MI here at all: a unit is wanted iff it holds a short-range pair)
+        if (!A.E.lower_only) {
+            const uint32_t ra0 = (uint32_t)R.ra0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rb0 = __builtin_amdgcn_readfirstlane(cmu[u].rb0);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int32_t *row = G32 + (int64_t)(rb0 + j) * A.RFpad;
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) raw[u][j][i] = row[ra0 + (uint32_t)i];
+                }
+            }
+        } else {
+            // a diagonal block: the GEMM skips the tiles above the diagonal of ROW positions, so the entry of a pair may only exist transposed
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t rb0 = cmu[u].rb0;
+                const bool tr = R.ra0 < rb0;
+                const int32_t *g = G32 + (tr ? R.ra0 * A.RFpad + rb0 : rb0 * A.RFpad + R.ra0);
+                const int64_t si = tr ? (int64_t)A.RFpad : 1, sj = tr ? 1 : (int64_t)A.RFpad;
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) raw[u][j][i] = g[i * si + j * sj];
+            }
+        }
+        if (RM == 3) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) rl[u] = A.rloc_t[__builtin_amdgcn_readfirstlane(cmu[u].ci.pad[1]) + (a_loc < 0 ? 0 : a_loc)];
+        }
+    }
+    unsigned int bits = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const ColMeta &M = cmu[u];
+        const int b_loc = M.bl;
+        float ms = 0.0f;
+        if (do_lr) {
+            FullCells32<NA, NB> C;
+            full_cells32<NA, NB>(R, M, raw[u], C);
+            // (r is a small integer: the products are exact in fp32, the value is the one screen_rxy returns)
+            const float rxy = RM == 3 ? ((float)M.rq * rl[u]) * 0.25f : (float)screen_rxy(A, R, M, a_loc, b_loc, RM);
+#ifdef LDW_ABLATE_SCREEN_MATH   // timing ablation only (wrong results): the loads and the control flow without the bound's arithmetic
+            ms = (float)(C.n[NA][NB] ^ C.n[0][0]) * 1e-30f + rxy * 1e-30f;
+#else
+            ms = full_cells_screen<NA, NB, true>(A, R, M, (double)rxy, C);
+#endif
+        }
+        const bool act = a_ok && (A.E.lower_only ? a_loc > b_loc : a_loc != b_loc);
+        const bool is_sr = test_sr && col_is_sr(M.ci, a_loc);
+        if (A.pl_pairs) {
+            // a unit with a short-range pair is evaluated whole (its band is dense); otherwise only the candidates themselves
+            const bool need_lr = act && !is_sr && do_lr && ms >= lo;
+            if (test_sr && __ballot(act && is_sr && keep_sr) != 0ull) {
+                bits |= 1u << u;
+            } else {
+                const unsigned long long m = __ballot(need_lr);
+                if (m != 0ull) append_pairs(A, (NA - 1) + 2 * (NB - 1), m, need_lr, (uint32_t)(tile * 64 + (threadIdx.x & 63)), (uint32_t)(q0 + u), R.sa, M.sb);
+            }
+        } else {   // (verify mode: whole units)
+            const bool need = act && (is_sr ? keep_sr : (do_lr && ms >= lo));
+            if (__ballot(need) != 0ull) bits |= 1u << u;
+        }
+    }
+    return bits;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Threshold table of the biallelic x biallelic pairs (both SNPs: one indicator row, r = 2).  With the marginals fixed the
 // joint table has ONE free number, x = pxy of (minor, minor), and MI is convex in it with its minimum at independence: MI
@@ -326,6 +409,8 @@ __device__ __forceinline__ unsigned int screen_cols_tab(const EpiArgs &A, const 
 template <int NA, int U, int RM, bool APX>
 __device__ __forceinline__ unsigned int screen_cols_nb(int nb, const EpiArgs &A, const RowSide &R, const ColMeta *cmu, int a_loc,
                                                        bool a_ok, float lo, int q0, int tile) {
+    static_assert(U <= 4, "screen_cols_apx keeps U columns' entries in registers");
+    if (APX) return nb == 1 ? screen_cols_apx<NA, 1, U, RM>(A, R, cmu, a_loc, a_ok, lo, q0, tile) : screen_cols_apx<NA, 2, U, RM>(A, R, cmu, a_loc, a_ok, lo, q0, tile);
     if (NA == 1 && nb == 1) return screen_cols<NA, 1, U, RM, APX>(A, R, cmu, a_loc, a_ok, lo, q0, tile);   // (the table path is taken by the caller)
     constexpr int V = LDW_SCREEN_V < U ? LDW_SCREEN_V : U;   // columns in flight for the multi-cell tables (2: 387 -> 372 us per C4 block in r02)
     unsigned int bits = 0;
@@ -541,7 +626,7 @@ __device__ __forceinline__ void screen_wg(const EpiArgs &A, const int32_t *__res
 
 // the whole grid: one workgroup per (from-tile, column group)
 template <int RM, bool APX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_mi_screen(EpiArgs A, const int32_t *__restrict__ perm_f,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LDW_SCREEN_WAVES, 8))) void k_mi_screen(EpiArgs A, const int32_t *__restrict__ perm_f,
                                                                                             const int32_t *__restrict__ perm_t,
                                                                                             uint64_t *__restrict__ units,
                                                                                             unsigned int *__restrict__ n_units,

@@ -167,6 +167,238 @@ __global__ __launch_bounds__(256) void k_sr_quant(const SrPay *__restrict__ pay,
 }
 
 // ------------------------------------------------------------------------------------------------
+// r04: the same order statistics WITHOUT sorting the table by MI.  The quantiles are 2 order statistics per (cluster, len) — 3 x 19 999
+// pairs of numbers out of up to 2.25e9 rows — and the 64-bit radix sort by MI alone moved 192 B per row (8 passes x 24 B: 140 of the 227 ms
+// of a C5 job's quantile step).  What is left: ONE sort, by len (16-bit keys, 2 radix passes), reading its keys and its 12-byte payload
+// {MI key, cluster tags} straight from the table through transform iterators (no tagging pass), and a radix SELECT per len:
+//   sweep A   members and the AND / OR of the members' keys per cluster (wave-aggregated: no atomics in the loop) -> ranks wanted, common prefix
+//   sweep B.. histogram of the next 11 key bits below the common prefix, per cluster, in LDS -> the bucket holding the rank; repeated on
+//             the bucket until it holds at most SEL_CAP keys (typically once: the prefix skips the bits all MI values share)
+//   sweep C   the bucket's keys into LDS + the smallest key ABOVE the bucket (the second order statistic when the first is the bucket's last)
+//   then the rank within the bucket by counting (O(m^2 / 64) LDS reads per cluster, m <= 512).
+// Values are == the sorted path's (they are order statistics; equal keys are equal values).  Used for nclust <= SEL_MAXCL; more clusters
+// (or >= 2^32 rows) take the two-sort path above.
+// ------------------------------------------------------------------------------------------------
+constexpr int SEL_MAXCL = 4, SEL_BITS = 11, SEL_BINS = 1 << SEL_BITS, SEL_CAP = 512;
+
+struct SrRowsView {
+    const int32_t *sa, *sb;
+    const double *smi;
+    const int32_t *POS, *paint;
+    double g, sr_dist;
+};
+struct SrLenOf {
+    SrRowsView v;
+    __host__ __device__ uint16_t operator()(int64_t i) const { return (uint16_t)row_tag(v.sa[i], v.sb[i], v.POS, v.paint, v.g, v.sr_dist).len; }
+};
+struct SrPayOf {
+    SrRowsView v;
+    __host__ __device__ SrPay operator()(int64_t i) const {
+        const RowTag t = row_tag(v.sa[i], v.sb[i], v.POS, v.paint, v.g, v.sr_dist);
+        const uint64_t k = f64_key(v.smi[i]);
+        return SrPay{(uint32_t)k, (uint32_t)(k >> 32), ((uint32_t)t.len << 16) | ((uint32_t)t.c1 << 8) | (uint32_t)t.c2};
+    }
+};
+
+__global__ __launch_bounds__(256) void k_sr_select(const SrPay *__restrict__ pay, const int64_t *__restrict__ off, int S, int nclust, double prob,
+                                                   double *__restrict__ q, int64_t *__restrict__ cnt) {
+    __shared__ unsigned int hist[SEL_MAXCL][SEL_BINS];
+    __shared__ unsigned long long cand[SEL_MAXCL][SEL_CAP];
+    __shared__ unsigned long long tot[SEL_MAXCL], kand[SEL_MAXCL], kor[SEL_MAXCL], above[SEL_MAXCL], pfx[SEL_MAXCL], msk[SEL_MAXCL], rnk[SEL_MAXCL];
+    __shared__ unsigned int ncand[SEL_MAXCL], cbk[SEL_MAXCL];
+    __shared__ int shf[SEL_MAXCL], state[SEL_MAXCL], two[SEL_MAXCL];   // state 0: refining, 1: bucket fits (gather), 2: bucket of equal keys, 3: done / empty
+    __shared__ int n_refining;
+    const int l = blockIdx.x + 1;
+    const int64_t beg = off[l], end = off[l + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < SEL_MAXCL) {
+        tot[tid] = 0;
+        kand[tid] = ~0ull;
+        kor[tid] = 0;
+        above[tid] = ~0ull;
+        ncand[tid] = 0;
+    }
+    __syncthreads();
+    // ---- sweep A
+    {
+        unsigned long long n_c[SEL_MAXCL], a_c[SEL_MAXCL], o_c[SEL_MAXCL];
+#pragma unroll
+        for (int c = 0; c < SEL_MAXCL; ++c) {
+            n_c[c] = 0;
+            a_c[c] = ~0ull;
+            o_c[c] = 0;
+        }
+        for (int64_t base = beg; base < end; base += 256) {
+            const int64_t i = base + tid;
+            int c1 = 0, c2 = 0;
+            unsigned long long k = 0;
+            if (i < end) {
+                const SrPay py = pay[i];
+                c1 = (py.tag >> 8) & 0xFF;
+                c2 = py.tag & 0xFF;
+                k = ((unsigned long long)py.khi << 32) | py.klo;
+            }
+#pragma unroll
+            for (int c = 0; c < SEL_MAXCL; ++c) {
+                const bool m = c1 == c + 1 || c2 == c + 1;
+                n_c[c] += (unsigned long long)__popcll(__ballot(m));   // (wave-uniform count)
+                if (m) {
+                    a_c[c] &= k;
+                    o_c[c] |= k;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < SEL_MAXCL; ++c) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                a_c[c] &= __shfl_xor(a_c[c], o);
+                o_c[c] |= __shfl_xor(o_c[c], o);
+            }
+            if (lane == 0 && c < nclust) {
+                atomicAdd(&tot[c], n_c[c]);
+                atomicAnd(&kand[c], a_c[c]);
+                atomicOr(&kor[c], o_c[c]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < nclust) {
+        const int c = tid;
+        const unsigned long long n = tot[c];
+        cnt[(int64_t)c * S + (l - 1)] = (int64_t)n;
+        if (n == 0) {
+            state[c] = 3;   // (the host pre-filled q with NaN)
+        } else {
+            const double index = q7_index((double)(n - 1), prob);   // R's 1-based index, rounded as R rounds it (no fma: ldw_dev.h)
+            const unsigned long long tlo = (unsigned long long)floor(index) - 1ull, thi = (unsigned long long)ceil(index) - 1ull;
+            rnk[c] = tlo;
+            two[c] = thi != tlo;
+            const unsigned long long diff = kand[c] ^ kor[c];
+            if (diff == 0) {   // every member has the same MI
+                const int64_t o = ((int64_t)c * S + (l - 1)) * 2;
+                q[o] = q[o + 1] = key_f64(kand[c]);
+                state[c] = 3;
+            } else {
+                const int top = 63 - __clzll((long long)diff);          // highest bit in which two members differ
+                const int sh = top + 1 > SEL_BITS ? top + 1 - SEL_BITS : 0;
+                shf[c] = sh;
+                msk[c] = sh + SEL_BITS >= 64 ? 0ull : ~((1ull << (sh + SEL_BITS)) - 1ull);
+                pfx[c] = kand[c] & msk[c];
+                state[c] = 0;
+            }
+        }
+    } else if (tid < SEL_MAXCL) {
+        state[tid] = 3;
+    }
+    __syncthreads();
+    // ---- histogram sweeps until every cluster's bucket fits
+    for (;;) {
+        if (tid == 0) {
+            int r = 0;
+            for (int c = 0; c < SEL_MAXCL; ++c) r += state[c] == 0;
+            n_refining = r;
+        }
+        for (int b = tid; b < SEL_MAXCL * SEL_BINS; b += 256) (&hist[0][0])[b] = 0;
+        __syncthreads();
+        if (n_refining == 0) break;
+        for (int64_t i = beg + tid; i < end; i += 256) {
+            const SrPay py = pay[i];
+            const int c1 = (py.tag >> 8) & 0xFF, c2 = py.tag & 0xFF;
+            const unsigned long long k = ((unsigned long long)py.khi << 32) | py.klo;
+#pragma unroll
+            for (int c = 0; c < SEL_MAXCL; ++c)
+                if ((c1 == c + 1 || c2 == c + 1) && state[c] == 0 && (k & msk[c]) == pfx[c]) atomicAdd(&hist[c][(k >> shf[c]) & (SEL_BINS - 1)], 1u);
+        }
+        __syncthreads();
+        // wave c: the bucket of cluster c that holds the rank (32 bins per lane, wave scan)
+        if (wv < SEL_MAXCL && state[wv] == 0) {
+            const int c = wv;
+            unsigned int mine = 0;
+            for (int b = 0; b < SEL_BINS / 64; ++b) mine += hist[c][lane * (SEL_BINS / 64) + b];
+            unsigned int incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            const unsigned long long r = rnk[c];
+            const bool here = (unsigned long long)(incl - mine) <= r && r < (unsigned long long)incl;
+            if (here) {   // exactly one lane
+                unsigned int before = incl - mine;
+                int b = lane * (SEL_BINS / 64);
+                while ((unsigned long long)before + hist[c][b] <= r) before += hist[c][b++];
+                const unsigned int cb = hist[c][b];
+                const int sh = shf[c];
+                rnk[c] = r - before;
+                pfx[c] |= (unsigned long long)b << sh;
+                msk[c] |= (unsigned long long)(SEL_BINS - 1) << sh;
+                cbk[c] = cb;
+                if (cb <= (unsigned int)SEL_CAP) state[c] = 1;
+                else if (sh == 0) state[c] = 2;   // all 64 bits fixed: the bucket's keys are equal
+                else {
+                    const int ns = sh > SEL_BITS ? sh - SEL_BITS : 0;   // (the next digit may overlap bits already fixed: harmless, they match)
+                    shf[c] = ns;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- sweep C: the buckets' keys and the smallest key above each bucket
+    {
+        bool any = false;
+        for (int c = 0; c < SEL_MAXCL; ++c) any = any || state[c] == 1 || state[c] == 2;
+        if (any) {
+            for (int64_t i = beg + tid; i < end; i += 256) {
+                const SrPay py = pay[i];
+                const int c1 = (py.tag >> 8) & 0xFF, c2 = py.tag & 0xFF;
+                const unsigned long long k = ((unsigned long long)py.khi << 32) | py.klo;
+#pragma unroll
+                for (int c = 0; c < SEL_MAXCL; ++c) {
+                    if (!(c1 == c + 1 || c2 == c + 1) || state[c] == 3) continue;
+                    if ((k & msk[c]) == pfx[c]) {
+                        if (state[c] == 1) cand[c][atomicAdd(&ncand[c], 1u)] = k;
+                    } else if (k > pfx[c] && k < above[c]) {   // (k > pfx and outside the bucket: above it; the read of `above` is only a filter)
+                        atomicMin(&above[c], k);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the rank within the bucket
+    if (wv < SEL_MAXCL && (state[wv] == 1 || state[wv] == 2)) {
+        const int c = wv;
+        const int64_t o = ((int64_t)c * S + (l - 1)) * 2;
+        const unsigned long long r = rnk[c];
+        if (state[c] == 2) {
+            if (lane == 0) {
+                q[o] = key_f64(pfx[c]);
+                q[o + 1] = key_f64((!two[c] || r + 1 < (unsigned long long)cbk[c]) ? pfx[c] : above[c]);
+            }
+        } else {
+            const unsigned int m = ncand[c];
+            if (lane == 0 && two[c] && r + 1 >= (unsigned long long)m) q[o + 1] = key_f64(above[c]);
+            for (unsigned int i = lane; i < m; i += 64) {
+                const unsigned long long k = cand[c][i];
+                unsigned int less = 0, eq = 0;
+                for (unsigned int j = 0; j < m; ++j) {
+                    const unsigned long long kj = cand[c][j];
+                    less += kj < k;
+                    eq += kj == k;
+                }
+                if ((unsigned long long)less <= r && r < (unsigned long long)less + eq) q[o] = key_f64(k);
+                if (!two[c]) {
+                    if ((unsigned long long)less <= r && r < (unsigned long long)less + eq) q[o + 1] = key_f64(k);
+                } else if ((unsigned long long)less <= r + 1 && r + 1 < (unsigned long long)less + eq) {
+                    q[o + 1] = key_f64(k);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // positive excesses over the fitted decay: sufficient statistics of the beta likelihood
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
@@ -471,6 +703,39 @@ int ldw_sr_len_quantiles(ldw_ctx *c, int nclust, double sr_dist, double prob, in
         for (size_t k = 0; k < cells; ++k) {
             q_lo_out[k] = q_hi_out[k] = std::nan("");
             n_out[k] = 0;
+        }
+        return LDW_OK;
+    }
+    static const bool force_sort = getenv("LDW_SR_QUANT_SORT") != nullptr;   // (A/B and tests: the two-sort path for any nclust)
+    if (nclust <= SEL_MAXCL && n < (int64_t)0xFFFFFFFFll && !force_sort) {
+        // r04: one sort (by len) fed from the table itself, then a radix select per len (k_sr_select)
+        if (int rc = c->srm_pack.reserve((size_t)n * 2 + 64)) return rc;
+        if (int rc = c->srm_pack2.reserve((size_t)n * 2 + 64)) return rc;
+        if (int rc = c->srm_pay.reserve((size_t)n * sizeof(SrPay))) return rc;
+        if (int rc = c->srm_off.reserve((size_t)(S + 2) * 8)) return rc;
+        if (int rc = c->srm_q.reserve(cells * 16)) return rc;
+        if (int rc = c->srm_n.reserve(cells * 8)) return rc;
+        const SrRowsView V{c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), c->sr_mi.as<double>(), c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, sr_dist};
+        auto kin = rocprim::make_transform_iterator(rocprim::counting_iterator<int64_t>(0), SrLenOf{V});
+        auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<int64_t>(0), SrPayOf{V});
+        uint16_t *len_sorted = c->srm_pack2.as<uint16_t>();
+        SrPay *pay_sorted = c->srm_pay.as<SrPay>();
+        size_t tb = 0;
+        LDW_HIP(rocprim::radix_sort_pairs(nullptr, tb, kin, len_sorted, vin, pay_sorted, (size_t)n, 0u, 16u, c->stream));
+        if (int rc = c->scratch.reserve(tb)) return rc;
+        tb = c->scratch.cap;
+        LDW_HIP(rocprim::radix_sort_pairs(c->scratch.p, tb, kin, len_sorted, vin, pay_sorted, (size_t)n, 0u, 16u, c->stream));
+        hipLaunchKernelGGL(k_sr_seg_offsets, dim3((S + 2 + 255) / 256), dim3(256), 0, c->stream, len_sorted, n, S, c->srm_off.as<int64_t>());
+        LDW_HIP(hipMemcpyAsync(c->srm_q.p, q.data(), cells * 16, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_sr_select, dim3(S), dim3(256), 0, c->stream, pay_sorted, c->srm_off.as<int64_t>(), S, nclust, prob, c->srm_q.as<double>(),
+                           c->srm_n.as<int64_t>());
+        LDW_HIP(hipGetLastError());
+        LDW_HIP(hipMemcpyAsync(q.data(), c->srm_q.p, cells * 16, hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipMemcpyAsync(n_out, c->srm_n.p, cells * 8, hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+        for (size_t k = 0; k < cells; ++k) {
+            q_lo_out[k] = q[2 * k];
+            q_hi_out[k] = q[2 * k + 1];
         }
         return LDW_OK;
     }
