@@ -187,20 +187,28 @@ struct SrRowsView {
     const int32_t *POS, *paint;
     double g, sr_dist;
 };
+// (the sort evaluates both functors once per row and pass: the key needs the two positions only — in integers: POS and g are integers, so
+// circ_len's 0.5 g - |d - 0.5 g| is min(d, g - d) exactly — the payload the two cluster ids only)
 struct SrLenOf {
     SrRowsView v;
-    __host__ __device__ uint16_t operator()(int64_t i) const { return (uint16_t)row_tag(v.sa[i], v.sb[i], v.POS, v.paint, v.g, v.sr_dist).len; }
+    __host__ __device__ uint16_t operator()(int64_t i) const {
+        const int64_t gi = (int64_t)v.g;
+        int64_t d = ((int64_t)v.POS[v.sb[i]] - (int64_t)v.POS[v.sa[i]]) % gi;
+        if (d < 0) d += gi;
+        const int64_t len = d < gi - d ? d : gi - d;
+        return (len > 0 && (double)len < v.sr_dist) ? (uint16_t)len : (uint16_t)0;
+    }
 };
 struct SrPayOf {
     SrRowsView v;
     __host__ __device__ SrPay operator()(int64_t i) const {
-        const RowTag t = row_tag(v.sa[i], v.sb[i], v.POS, v.paint, v.g, v.sr_dist);
         const uint64_t k = f64_key(v.smi[i]);
-        return SrPay{(uint32_t)k, (uint32_t)(k >> 32), ((uint32_t)t.len << 16) | ((uint32_t)t.c1 << 8) | (uint32_t)t.c2};
+        return SrPay{(uint32_t)k, (uint32_t)(k >> 32), ((uint32_t)v.paint[v.sb[i]] << 8) | (uint32_t)v.paint[v.sa[i]]};
     }
 };
 
-__global__ __launch_bounds__(256) void k_sr_select(const SrPay *__restrict__ pay, const int64_t *__restrict__ off, int S, int nclust, double prob,
+constexpr int SEL_NT = 512;   // threads per workgroup: 3 workgroups per CU (LDS) = 6 waves per SIMD streaming the segment
+__global__ __launch_bounds__(SEL_NT) void k_sr_select(const SrPay *__restrict__ pay, const int64_t *__restrict__ off, int S, int nclust, double prob,
                                                    double *__restrict__ q, int64_t *__restrict__ cnt) {
     __shared__ unsigned int hist[SEL_MAXCL][SEL_BINS];
     __shared__ unsigned long long cand[SEL_MAXCL][SEL_CAP];
@@ -228,23 +236,22 @@ __global__ __launch_bounds__(256) void k_sr_select(const SrPay *__restrict__ pay
             a_c[c] = ~0ull;
             o_c[c] = 0;
         }
-        for (int64_t base = beg; base < end; base += 256) {
-            const int64_t i = base + tid;
-            int c1 = 0, c2 = 0;
-            unsigned long long k = 0;
-            if (i < end) {
-                const SrPay py = pay[i];
-                c1 = (py.tag >> 8) & 0xFF;
-                c2 = py.tag & 0xFF;
-                k = ((unsigned long long)py.khi << 32) | py.klo;
-            }
+        for (int64_t base = beg; base < end; base += 2 * SEL_NT) {   // two rows per thread in flight
+            const int64_t i0 = base + tid, i1 = i0 + SEL_NT;
+            const SrPay pa = i0 < end ? pay[i0] : SrPay{0u, 0u, 0u}, pb = i1 < end ? pay[i1] : SrPay{0u, 0u, 0u};   // (tag 0: no cluster)
 #pragma unroll
-            for (int c = 0; c < SEL_MAXCL; ++c) {
-                const bool m = c1 == c + 1 || c2 == c + 1;
-                n_c[c] += (unsigned long long)__popcll(__ballot(m));   // (wave-uniform count)
-                if (m) {
-                    a_c[c] &= k;
-                    o_c[c] |= k;
+            for (int h = 0; h < 2; ++h) {
+                const SrPay py = h ? pb : pa;
+                const int c1 = (py.tag >> 8) & 0xFF, c2 = py.tag & 0xFF;
+                const unsigned long long k = ((unsigned long long)py.khi << 32) | py.klo;
+#pragma unroll
+                for (int c = 0; c < SEL_MAXCL; ++c) {
+                    const bool m = c1 == c + 1 || c2 == c + 1;
+                    n_c[c] += (unsigned long long)__popcll(__ballot(m));   // (wave-uniform count)
+                    if (m) {
+                        a_c[c] &= k;
+                        o_c[c] |= k;
+                    }
                 }
             }
         }
@@ -299,16 +306,21 @@ __global__ __launch_bounds__(256) void k_sr_select(const SrPay *__restrict__ pay
             for (int c = 0; c < SEL_MAXCL; ++c) r += state[c] == 0;
             n_refining = r;
         }
-        for (int b = tid; b < SEL_MAXCL * SEL_BINS; b += 256) (&hist[0][0])[b] = 0;
+        for (int b = tid; b < SEL_MAXCL * SEL_BINS; b += SEL_NT) (&hist[0][0])[b] = 0;
         __syncthreads();
         if (n_refining == 0) break;
-        for (int64_t i = beg + tid; i < end; i += 256) {
-            const SrPay py = pay[i];
-            const int c1 = (py.tag >> 8) & 0xFF, c2 = py.tag & 0xFF;
-            const unsigned long long k = ((unsigned long long)py.khi << 32) | py.klo;
+        for (int64_t i0 = beg + tid; i0 < end; i0 += 2 * SEL_NT) {   // two rows per thread in flight
+            const int64_t i1 = i0 + SEL_NT;
+            const SrPay pa = pay[i0], pb = i1 < end ? pay[i1] : SrPay{0u, 0u, 0u};   // (tag 0: no cluster)
 #pragma unroll
-            for (int c = 0; c < SEL_MAXCL; ++c)
-                if ((c1 == c + 1 || c2 == c + 1) && state[c] == 0 && (k & msk[c]) == pfx[c]) atomicAdd(&hist[c][(k >> shf[c]) & (SEL_BINS - 1)], 1u);
+            for (int h = 0; h < 2; ++h) {
+                const SrPay py = h ? pb : pa;
+                const int c1 = (py.tag >> 8) & 0xFF, c2 = py.tag & 0xFF;
+                const unsigned long long k = ((unsigned long long)py.khi << 32) | py.klo;
+#pragma unroll
+                for (int c = 0; c < SEL_MAXCL; ++c)
+                    if ((c1 == c + 1 || c2 == c + 1) && state[c] == 0 && (k & msk[c]) == pfx[c]) atomicAdd(&hist[c][(k >> shf[c]) & (SEL_BINS - 1)], 1u);
+            }
         }
         __syncthreads();
         // wave c: the bucket of cluster c that holds the rank (32 bins per lane, wave scan)
@@ -349,17 +361,22 @@ __global__ __launch_bounds__(256) void k_sr_select(const SrPay *__restrict__ pay
         bool any = false;
         for (int c = 0; c < SEL_MAXCL; ++c) any = any || state[c] == 1 || state[c] == 2;
         if (any) {
-            for (int64_t i = beg + tid; i < end; i += 256) {
-                const SrPay py = pay[i];
-                const int c1 = (py.tag >> 8) & 0xFF, c2 = py.tag & 0xFF;
-                const unsigned long long k = ((unsigned long long)py.khi << 32) | py.klo;
+            for (int64_t i0 = beg + tid; i0 < end; i0 += 2 * SEL_NT) {
+                const int64_t i1 = i0 + SEL_NT;
+                const SrPay pa = pay[i0], pb = i1 < end ? pay[i1] : SrPay{0u, 0u, 0u};
 #pragma unroll
-                for (int c = 0; c < SEL_MAXCL; ++c) {
-                    if (!(c1 == c + 1 || c2 == c + 1) || state[c] == 3) continue;
-                    if ((k & msk[c]) == pfx[c]) {
-                        if (state[c] == 1) cand[c][atomicAdd(&ncand[c], 1u)] = k;
-                    } else if (k > pfx[c] && k < above[c]) {   // (k > pfx and outside the bucket: above it; the read of `above` is only a filter)
-                        atomicMin(&above[c], k);
+                for (int h = 0; h < 2; ++h) {
+                    const SrPay py = h ? pb : pa;
+                    const int c1 = (py.tag >> 8) & 0xFF, c2 = py.tag & 0xFF;
+                    const unsigned long long k = ((unsigned long long)py.khi << 32) | py.klo;
+#pragma unroll
+                    for (int c = 0; c < SEL_MAXCL; ++c) {
+                        if (!(c1 == c + 1 || c2 == c + 1) || state[c] == 3) continue;
+                        if ((k & msk[c]) == pfx[c]) {
+                            if (state[c] == 1) cand[c][atomicAdd(&ncand[c], 1u)] = k;
+                        } else if (k > pfx[c] && k < above[c]) {   // (k > pfx and outside the bucket: above it; the read of `above` is only a filter)
+                            atomicMin(&above[c], k);
+                        }
                     }
                 }
             }
@@ -706,7 +723,7 @@ int ldw_sr_len_quantiles(ldw_ctx *c, int nclust, double sr_dist, double prob, in
         }
         return LDW_OK;
     }
-    static const bool force_sort = getenv("LDW_SR_QUANT_SORT") != nullptr;   // (A/B and tests: the two-sort path for any nclust)
+    const bool force_sort = getenv("LDW_SR_QUANT_SORT") != nullptr;   // (A/B and tests: the two-sort path for any nclust; read per call)
     if (nclust <= SEL_MAXCL && n < (int64_t)0xFFFFFFFFll && !force_sort) {
         // r04: one sort (by len) fed from the table itself, then a radix select per len (k_sr_select)
         if (int rc = c->srm_pack.reserve((size_t)n * 2 + 64)) return rc;
@@ -727,7 +744,7 @@ int ldw_sr_len_quantiles(ldw_ctx *c, int nclust, double sr_dist, double prob, in
         LDW_HIP(rocprim::radix_sort_pairs(c->scratch.p, tb, kin, len_sorted, vin, pay_sorted, (size_t)n, 0u, 16u, c->stream));
         hipLaunchKernelGGL(k_sr_seg_offsets, dim3((S + 2 + 255) / 256), dim3(256), 0, c->stream, len_sorted, n, S, c->srm_off.as<int64_t>());
         LDW_HIP(hipMemcpyAsync(c->srm_q.p, q.data(), cells * 16, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_sr_select, dim3(S), dim3(256), 0, c->stream, pay_sorted, c->srm_off.as<int64_t>(), S, nclust, prob, c->srm_q.as<double>(),
+        hipLaunchKernelGGL(k_sr_select, dim3(S), dim3(SEL_NT), 0, c->stream, pay_sorted, c->srm_off.as<int64_t>(), S, nclust, prob, c->srm_q.as<double>(),
                            c->srm_n.as<int64_t>());
         LDW_HIP(hipGetLastError());
         LDW_HIP(hipMemcpyAsync(q.data(), c->srm_q.p, cells * 16, hipMemcpyDeviceToHost, c->stream));
@@ -835,7 +852,17 @@ int ldw_sr_pvalues(ldw_ctx *c, int nclust, int32_t S, const double *mean_dist, c
     const int32_t *sa = c->sr_a.as<int32_t>(), *sb = c->sr_b.as<int32_t>();
     const double *smi = c->sr_mi.as<double>();
     const int32_t *POS = c->POS.as<int32_t>(), *paint = c->paint.as<int32_t>();
-    // pass 1 writes into whatever capacity is there; a second pass runs only if it was too small
+    // pass 1 writes into whatever capacity is there; a second pass runs only if it was too small.  r04: a floor of 4 M rows (144 MB in all)
+    // under both outputs, so that the FIRST job of a context does not pay the two kernels twice (C5: 1.5 M rows kept of 2.25e9, 50 ms per pass)
+    {
+        const size_t floor_rows = (size_t)std::min<int64_t>(n, (int64_t)1 << 22);
+        if (int rc = c->red_row.reserve(floor_rows * 8)) return rc;
+        if (int rc = c->red_meta.reserve(floor_rows * 4)) return rc;
+        if (int rc = c->red_srp.reserve(floor_rows * 8)) return rc;
+        if (int rc = c->pool_a.reserve(floor_rows * 4)) return rc;
+        if (int rc = c->pool_b.reserve(floor_rows * 4)) return rc;
+        if (int rc = c->pool_mi.reserve(floor_rows * 8)) return rc;
+    }
     for (int pass = 0; pass < 2; ++pass) {
         const int64_t cap = (int64_t)(c->red_row.cap / 8);
         LDW_HIP(hipMemcpyAsync(d, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));

@@ -409,6 +409,86 @@ def test_device_sr_model_matches_host_model(engine, sample, tmp_path, max_blk_sz
     assert np.array_equal(stats, engine.sr_excess_stats(md))     # fixed reduction order: bit-identical on a re-run
 
 
+def _np_len_quantiles(a, b, mi, POS, paint, g, sr_dist, nclust, prob):
+    """numpy twin of R/computePairwiseMI.R:417-424 (quantile type 7's two order statistics per cluster and integer len)."""
+    S = int(np.ceil(sr_dist)) - 1
+    ln = orc.circ_len(POS[b].astype(float), POS[a].astype(float), float(g))
+    ok = (ln > 0) & (ln < sr_dist)
+    qlo, qhi, cnt = np.full((nclust, S), np.nan), np.full((nclust, S), np.nan), np.zeros((nclust, S), np.int64)
+    for ci in range(1, nclust + 1):
+        sel = ok & ((paint[b] == ci) | (paint[a] == ci))
+        li, x = ln[sel].astype(np.int64), mi[sel]
+        o = np.lexsort((x, li))
+        li, x = li[o], x[o]
+        n = np.bincount(li, minlength=S + 1)[1:S + 1]
+        cnt[ci - 1] = n
+        start = np.concatenate(([0], np.cumsum(np.bincount(li, minlength=S + 1))))[1:S + 1]
+        has = n > 0
+        idx = 1 + (n[has] - 1).astype(float) * prob
+        qlo[ci - 1, has] = x[start[has] + np.floor(idx).astype(np.int64) - 1]
+        qhi[ci - 1, has] = x[start[has] + np.ceil(idx).astype(np.int64) - 1]
+    return qlo, qhi, cnt
+
+
+@pytest.mark.parametrize("nclust", [3, 4, 6])
+def test_sr_len_quantiles_select_equals_sort_equals_numpy(engine, synth, nclust):
+    """the per-(cluster, len) order statistics by ONE sort (by len) + a radix select per len (k_sr_select, nclust <= 4)
+    against the two-sort path (LDW_SR_QUANT_SORT=1; also what nclust = 6 takes) and numpy, over EVERY len, on the engine's own table and on
+    tables built to hit the select's corners: all MI of a len equal, ties across the bucket border, a zero and a denormal among ordinary
+    values (keys that differ in their top bits), one-row segments, prob 0 / 0.5 / 1 (the two order statistics coincide)."""
+    import os
+    d = dict(synth)
+    rng = np.random.default_rng(7)
+    d["paint"] = rng.integers(1, nclust + 1, len(d["POS"])).astype(np.int32)
+    _setup(engine, d)
+    blocks = orc.make_blocks(512, 1000)
+    engine.mi_all_pairs(blocks, sr_dist=3000.0, lr_retain_links=1e6, lr_links_approx=1e5)
+    a, b, mi = engine.links(0)
+    POS, paint, g = d["POS"], d["paint"], d["g"]
+
+    def check(a, b, mi, probs):
+        for prob in probs:
+            want = _np_len_quantiles(a, b, mi, POS, paint, g, 3000.0, nclust, prob)
+            os.environ.pop("LDW_SR_QUANT_SORT", None)
+            got = engine.sr_len_quantiles(nclust, 3000.0, prob)
+            os.environ["LDW_SR_QUANT_SORT"] = "1"
+            try:
+                srt = engine.sr_len_quantiles(nclust, 3000.0, prob)
+            finally:
+                os.environ.pop("LDW_SR_QUANT_SORT", None)
+            for w, x, y, nm in zip(want, got, srt, ("q_lo", "q_hi", "n")):
+                assert np.array_equal(w, x, equal_nan=True), (nm, prob, "select")
+                assert np.array_equal(w, y, equal_nan=True), (nm, prob, "sort")
+
+    check(a, b, mi, (0.95, 0.5, 0.0, 1.0, 0.999))
+    # corners, on the same pairs: (i) few distinct values (long runs of equal keys: buckets of equal keys larger than the LDS candidate
+    # array when the table is large enough, ties at the ranks), (ii) values spanning the whole exponent range incl. 0 and a denormal
+    mi2 = rng.choice(np.array([0.125, 0.25, 0.25 + 2.0 ** -50, 0.5]), len(mi))
+    engine.links_import(0, a, b, mi2)
+    check(a, b, mi2, (0.95, 0.5))
+    mi3 = np.abs(rng.standard_normal(len(mi))) * 10.0 ** rng.integers(-12, 1, len(mi))
+    mi3[rng.integers(0, len(mi), 50)] = 0.0
+    mi3[rng.integers(0, len(mi), 50)] = 5e-324
+    mi3[rng.integers(0, len(mi), 50)] = -1e-17       # (a rounding-negative MI: the key order must still be the value order)
+    engine.links_import(0, a, b, mi3)
+    check(a, b, mi3, (0.95, 0.02))
+    # (iv) a few lens with 60 000 rows each (rows may repeat a pair: the table is what is imported): buckets beyond the LDS candidate array ->
+    # further histogram sweeps; with 4 distinct values the bucket is a run of EQUAL keys larger than the array
+    pick = rng.choice(len(mi), 6, replace=False)
+    ab, bb = np.repeat(a[pick], 60000), np.repeat(b[pick], 60000)
+    big = np.abs(rng.standard_normal(len(ab))) * 0.05
+    engine.links_import(0, ab, bb, big)
+    check(ab, bb, big, (0.95, 0.5, 1.0))
+    big2 = rng.choice(np.array([0.125, 0.25, 0.25 + 2.0 ** -50, 0.5]), len(ab), p=(0.05, 0.6, 0.3, 0.05))
+    engine.links_import(0, ab, bb, big2)
+    check(ab, bb, big2, (0.95, 0.65, 0.05))
+    # (iii) a handful of rows: one-row and two-row segments
+    keep = rng.choice(len(mi), 40, replace=False)
+    keep.sort()
+    engine.links_import(0, a[keep], b[keep], mi[keep])
+    check(a[keep], b[keep], mi[keep], (0.95, 0.5))
+
+
 def test_device_beta_tail_against_scipy(engine, synth):
     """-log P_beta(X > x): the device continued fraction against scipy (mpmath where the tail underflows a double) over
     both branches and deep tails, through ldw_sr_pvalues on a table whose MI values are the probes themselves."""
