@@ -328,7 +328,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)ldw::join_prepare(c);
     (void)hipStreamSynchronize(c->stream);
-    ldw::DevBuf *bufs[] = {&c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
+    ldw::DevBuf *bufs[] = {&c->srm_tmp, &c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->apx_skip, &c->snp_sup, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
                            &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->perm_t, &c->scr_units, &c->slot_pfix_hi, &c->glo, &c->lo_rows, &c->packs, &c->colcnt,
                            &c->cand_key2, &c->cand_val2, &c->sel_bitmap, &c->sel_chunks, &c->sel_prefix, &c->scratch, &c->small, &c->sr_a, &c->sr_b,

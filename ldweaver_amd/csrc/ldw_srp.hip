@@ -20,9 +20,11 @@
 //
 // HBM-bound integer/byte work apart from the log/continued-fraction arithmetic of the p-values.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include "ldw_prim.h"
+#include <thread>
 #include <vector>
 
 #include "ldw_internal.h"
@@ -685,6 +687,22 @@ __global__ void k_red_gather(const int64_t *__restrict__ row, int64_t n, const i
     mi[i] = smi[r];
 }
 
+// Buffers of the select path.  (r04, tried and dropped: reserving them on a side thread while the MI pass runs, with and without touching the
+// new memory there.  The first quantile step of a context costs ~20 ms more than a later one (2.4 GB of fresh device memory at C4), but the
+// wait only moved — from hipMalloc to the first sort — and the memset took 5 ms from the MI pass: tools/quant_cold_probe.py, tools/job_profile.py --cold.)
+static size_t srm_sort_temp_bytes(int64_t n) {
+    const SrRowsView V{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 1.0};
+    auto kin = rocprim::make_transform_iterator(rocprim::counting_iterator<int64_t>(0), SrLenOf{V});
+    auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<int64_t>(0), SrPayOf{V});
+    size_t tb = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tb, kin, (uint16_t *)nullptr, vin, (SrPay *)nullptr, (size_t)n, 0u, 16u, (hipStream_t)0) != hipSuccess) return 0;
+    return tb;
+}
+static int srm_reserve_select(ldw_ctx *c, int64_t n) {
+    if (int rc = c->srm_pack2.reserve((size_t)n * 2 + 64)) return rc;
+    if (int rc = c->srm_pay.reserve((size_t)n * sizeof(SrPay))) return rc;
+    return c->srm_tmp.reserve(srm_sort_temp_bytes(n) + 256);
+}
 static int sr_ready(ldw_ctx *c, const char *who) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(c->have_meta, LDW_ERR_STATE, "%s: ldw_set_snp_meta has not been called", who);
@@ -723,12 +741,14 @@ int ldw_sr_len_quantiles(ldw_ctx *c, int nclust, double sr_dist, double prob, in
         }
         return LDW_OK;
     }
+    static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_0 = now();
     const bool force_sort = getenv("LDW_SR_QUANT_SORT") != nullptr;   // (A/B and tests: the two-sort path for any nclust; read per call)
     if (nclust <= SEL_MAXCL && n < (int64_t)0xFFFFFFFFll && !force_sort) {
         // r04: one sort (by len) fed from the table itself, then a radix select per len (k_sr_select)
-        if (int rc = c->srm_pack.reserve((size_t)n * 2 + 64)) return rc;
-        if (int rc = c->srm_pack2.reserve((size_t)n * 2 + 64)) return rc;
-        if (int rc = c->srm_pay.reserve((size_t)n * sizeof(SrPay))) return rc;
+        if (int rc = srm_reserve_select(c, n)) return rc;
         if (int rc = c->srm_off.reserve((size_t)(S + 2) * 8)) return rc;
         if (int rc = c->srm_q.reserve(cells * 16)) return rc;
         if (int rc = c->srm_n.reserve(cells * 8)) return rc;
@@ -737,11 +757,17 @@ int ldw_sr_len_quantiles(ldw_ctx *c, int nclust, double sr_dist, double prob, in
         auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<int64_t>(0), SrPayOf{V});
         uint16_t *len_sorted = c->srm_pack2.as<uint16_t>();
         SrPay *pay_sorted = c->srm_pay.as<SrPay>();
-        size_t tb = 0;
-        LDW_HIP(rocprim::radix_sort_pairs(nullptr, tb, kin, len_sorted, vin, pay_sorted, (size_t)n, 0u, 16u, c->stream));
-        if (int rc = c->scratch.reserve(tb)) return rc;
-        tb = c->scratch.cap;
-        LDW_HIP(rocprim::radix_sort_pairs(c->scratch.p, tb, kin, len_sorted, vin, pay_sorted, (size_t)n, 0u, 16u, c->stream));
+        size_t tb = c->srm_tmp.cap;
+        const auto t_1 = now();
+        if (host_timing) LDW_HIP(hipStreamSynchronize(c->stream));
+        const auto t_1b = now();
+        LDW_HIP(rocprim::radix_sort_pairs(c->srm_tmp.p, tb, kin, len_sorted, vin, pay_sorted, (size_t)n, 0u, 16u, c->stream));
+        if (host_timing) {
+            const auto t_2 = now();
+            LDW_HIP(hipStreamSynchronize(c->stream));
+            fprintf(stderr, "[ldw] sr quantiles: reserve %.2f ms (scratch %.1f MB), stream drain %.2f, sort enqueue %.2f + wait %.2f\n", ms(t_0, t_1), (double)tb / 1e6,
+                    ms(t_1, t_1b), ms(t_1b, t_2), ms(t_2, now()));
+        }
         hipLaunchKernelGGL(k_sr_seg_offsets, dim3((S + 2 + 255) / 256), dim3(256), 0, c->stream, len_sorted, n, S, c->srm_off.as<int64_t>());
         LDW_HIP(hipMemcpyAsync(c->srm_q.p, q.data(), cells * 16, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_sr_select, dim3(S), dim3(SEL_NT), 0, c->stream, pay_sorted, c->srm_off.as<int64_t>(), S, nclust, prob, c->srm_q.as<double>(),

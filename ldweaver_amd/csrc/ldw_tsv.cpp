@@ -10,12 +10,15 @@
 #include <condition_variable>
 #include <mutex>
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
 #include <thread>
+#include <fcntl.h>
+#include <unistd.h>
 #include <vector>
 
 #include "ldw_internal.h"
@@ -168,43 +171,54 @@ int default_threads(int nthreads) {
 }
 
 int write_rows(const char *path, int append, int64_t nrows, const std::vector<Col> &cols, int nthreads, int64_t *bytes_out) {
-    FILE *fh = fopen(path, append ? "ab" : "wb");
-    LDW_REQUIRE(fh != nullptr, LDW_ERR_ARG, "cannot open %s: %s", path, strerror(errno));
+    // r04: the file is written by the workers themselves with pwrite at offsets that follow from the chunk sizes (the one calling thread's
+    // fwrite of 45 MB — a copy into the page cache at 2-3 GB/s — was most of the 19 ms an lr_links.tsv of 1e6 rows took: the formatting had long
+    // been parallel).  Rounds of nt chunks: every worker formats its chunk into its own buffer, the last one to finish turns the
+    // sizes of the round into offsets, every worker writes its own chunk and goes on to the next round.
+    const int fd = open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0666);
+    LDW_REQUIRE(fd >= 0, LDW_ERR_ARG, "cannot open %s: %s", path, strerror(errno));
+    int64_t base = 0;
+    if (append) {
+        base = (int64_t)lseek(fd, 0, SEEK_END);
+        if (base < 0) {
+            ldw::set_error("cannot seek in %s: %s", path, strerror(errno));
+            close(fd);
+            return LDW_ERR_ARG;
+        }
+    }
     int64_t total = 0;
     int rc = LDW_OK;
     if (nrows > 0) {
-        // nt workers are started ONCE (starting a thread in a process that has the HIP runtime loaded costs ~2 ms: one per chunk
-        // made the writer slower than a single thread) and walk the table in rounds of nt chunks of 8192 rows: worker t formats chunk
-        // r nt + t into buffer r & 1 of its own pair (allocated once, uninitialised), the calling thread appends the chunks of a
-        // round in row order while the workers are already formatting the next one.
-        const int64_t chunk = 1 << 13;
+        // one chunk per worker and round: the whole share of a worker when its buffer stays below 64 MB (one barrier for a table of a
+        // million rows instead of eight: the barrier waits were 3 of the 13 ms), at least 8192 rows
         const size_t row_max = cols.size() * 41 + 2;
-        const int64_t nchunks = (nrows + chunk - 1) / chunk;
         int nt = default_threads(nthreads);
-        nt = (int)std::min<int64_t>(nt, nchunks);
+        nt = (int)std::min<int64_t>(nt, (nrows + 8191) / 8192);
         if (nt < 1) nt = 1;
+        const int64_t cap_rows = std::max<int64_t>(8192, (int64_t)(((size_t)64 << 20) / row_max));
+        const int64_t chunk = std::min<int64_t>((nrows + nt - 1) / nt, cap_rows);
+        const int64_t nchunks = (nrows + chunk - 1) / chunk;
         const int64_t rounds = (nchunks + nt - 1) / nt;
-        std::vector<std::unique_ptr<char[]>> bufs((size_t)nt * 2);
-        std::vector<size_t> used((size_t)nt * 2, 0);
-        for (auto &b : bufs) b.reset(new char[(size_t)chunk * row_max]);
+        std::vector<std::unique_ptr<char[]>> bufs((size_t)nt);
+        std::vector<size_t> used((size_t)nt, 0);
+        std::vector<int64_t> at((size_t)nt, 0);
         std::mutex mu;
         std::condition_variable cv;
-        int64_t flushed = 0;                              // rounds written to the file
-        std::vector<int64_t> done((size_t)nt, 0);         // rounds formatted by each worker
-        bool stop = false;
+        int arrived = 0;           // workers that have formatted their chunk of the current round
+        int64_t round_open = -1;   // the last round whose offsets are known
+        int64_t next_off = base;
+        bool failed = false;
+        static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
+        std::vector<double> t_fmt((size_t)nt, 0.0), t_wait((size_t)nt, 0.0), t_wr((size_t)nt, 0.0);
         auto worker = [&](int t) {
+            bufs[(size_t)t].reset(new char[(size_t)chunk * row_max]);   // (uninitialised; first touched by the thread that fills it)
             for (int64_t r = 0; r < rounds; ++r) {
-                {   // buffer r & 1 was last used by round r - 2
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return stop || flushed >= r - 1; });
-                    if (stop) return;
-                }
+                const auto w0 = std::chrono::steady_clock::now();
                 const int64_t c = r * nt + t;
-                const size_t slot = (size_t)t * 2 + (size_t)(r & 1);
                 size_t u = 0;
                 if (c < nchunks) {
                     const int64_t a = c * chunk, b = std::min(nrows, a + chunk);
-                    char *p = bufs[slot].get();
+                    char *p = bufs[(size_t)t].get();
                     for (int64_t i = a; i < b; ++i) {
                         for (size_t k = 0; k < cols.size(); ++k) {
                             if (k) *p++ = '\t';
@@ -215,48 +229,59 @@ int write_rows(const char *path, int append, int64_t nrows, const std::vector<Co
                         }
                         *p++ = '\n';
                     }
-                    u = (size_t)(p - bufs[slot].get());
+                    u = (size_t)(p - bufs[(size_t)t].get());
                 }
-                std::lock_guard<std::mutex> lk(mu);
-                used[slot] = u;
-                done[(size_t)t] = r + 1;
-                cv.notify_all();
+                const auto w1 = std::chrono::steady_clock::now();
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    used[(size_t)t] = u;
+                    if (++arrived == nt) {   // the round is complete: offsets in chunk (= row) order
+                        for (int k = 0; k < nt; ++k) {
+                            at[(size_t)k] = next_off;
+                            next_off += (int64_t)used[(size_t)k];
+                        }
+                        arrived = 0;
+                        round_open = r;
+                        cv.notify_all();
+                    } else {
+                        cv.wait(lk, [&] { return round_open >= r; });
+                    }
+                }
+                const int64_t my_at = at[(size_t)t];
+                const auto w2 = std::chrono::steady_clock::now();
+                size_t w = 0;
+                while (w < u) {
+                    const ssize_t k = pwrite(fd, bufs[(size_t)t].get() + w, u - w, (off_t)(my_at + (int64_t)w));
+                    if (k < 0) {
+                        if (errno == EINTR) continue;
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (!failed) ldw::set_error("short write to %s: %s", path, strerror(errno));
+                        failed = true;
+                        break;
+                    }
+                    w += (size_t)k;
+                }
+                // (at[] of round r + 1 is written only after every worker has arrived there, i.e. after it has read its offset of round r)
+                if (host_timing) {
+                    const auto w3 = std::chrono::steady_clock::now();
+                    t_fmt[(size_t)t] += std::chrono::duration<double, std::milli>(w1 - w0).count();
+                    t_wait[(size_t)t] += std::chrono::duration<double, std::milli>(w2 - w1).count();
+                    t_wr[(size_t)t] += std::chrono::duration<double, std::milli>(w3 - w2).count();
+                }
             }
         };
         std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(worker, t);
-        for (int64_t r = 0; r < rounds; ++r) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] {
-                    for (int t = 0; t < nt; ++t)
-                        if (done[(size_t)t] < r + 1) return false;
-                    return true;
-                });
-            }
-            for (int t = 0; t < nt && rc == LDW_OK; ++t) {
-                const size_t slot = (size_t)t * 2 + (size_t)(r & 1), u = used[slot];
-                if (!u) continue;
-                if (fwrite(bufs[slot].get(), 1, u, fh) != u) {
-                    ldw::set_error("short write to %s: %s", path, strerror(errno));
-                    rc = LDW_ERR_ARG;
-                }
-                total += (int64_t)u;
-            }
-            std::lock_guard<std::mutex> lk(mu);
-            flushed = r + 1;
-            if (rc != LDW_OK) stop = true;
-            cv.notify_all();
-            if (stop) break;
-        }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            if (rc != LDW_OK) stop = true;
-            cv.notify_all();
-        }
+        for (int t = 1; t < nt; ++t) th.emplace_back(worker, t);
+        worker(0);
         for (auto &x : th) x.join();
+        total = next_off - base;
+        if (failed) rc = LDW_ERR_ARG;
+        if (host_timing)
+            fprintf(stderr, "[ldw] tsv writer: %d threads, %lld rounds; thread 0: format %.2f ms, barrier %.2f, pwrite %.2f; max over threads: %.2f / %.2f / %.2f\n", nt,
+                    (long long)rounds, t_fmt[0], t_wait[0], t_wr[0], *std::max_element(t_fmt.begin(), t_fmt.end()), *std::max_element(t_wait.begin(), t_wait.end()),
+                    *std::max_element(t_wr.begin(), t_wr.end()));
     }
-    if (fclose(fh) != 0 && rc == LDW_OK) {
+    if (close(fd) != 0 && rc == LDW_OK) {
         ldw::set_error("closing %s: %s", path, strerror(errno));
         rc = LDW_ERR_ARG;
     }
@@ -298,9 +323,15 @@ int ldw_write_links_tsv(ldw_ctx *c, int which, const char *path, int append, int
     if (rows_out) *rows_out = n;
     if (bytes_out) *bytes_out = 0;
     if (n == 0) return LDW_OK;   // the reference writes nothing for an empty frame (R/computePairwiseMI.R:360)
-    std::vector<int32_t> a((size_t)n), b((size_t)n), pos1((size_t)n), pos2((size_t)n);
-    std::vector<double> mi((size_t)n), c1((size_t)n), c2((size_t)n), len((size_t)n);
-    if (int rc = ldw_links_fetch(c, which, a.data(), b.data(), mi.data(), n, 0)) return rc;
+    // (uninitialised arrays: a std::vector would clear 48 bytes per row on the calling thread before anything is written)
+    std::unique_ptr<int32_t[]> a_(new int32_t[(size_t)n]), b_(new int32_t[(size_t)n]), pos1_(new int32_t[(size_t)n]), pos2_(new int32_t[(size_t)n]);
+    std::unique_ptr<double[]> mi_(new double[(size_t)n]), c1_(new double[(size_t)n]), c2_(new double[(size_t)n]), len_(new double[(size_t)n]);
+    int32_t *a = a_.get(), *b = b_.get(), *pos1 = pos1_.get(), *pos2 = pos2_.get();
+    double *mi = mi_.get(), *c1 = c1_.get(), *c2 = c2_.get(), *len = len_.get();
+    static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
+    if (int rc = ldw_links_fetch(c, which, a, b, mi, n, 0)) return rc;
+    const auto t_1 = std::chrono::steady_clock::now();
     const double g = c->g, hg = 0.5 * c->g;
     const int32_t *POS = c->h_POS.data(), *paint = c->h_paint.data();
     int nt = (int)std::min<int64_t>(default_threads(nthreads), (n + 65535) / 65536);
@@ -328,9 +359,15 @@ int ldw_write_links_tsv(ldw_ctx *c, int which, const char *path, int append, int
     }
     // POS is an integer vector in the reference (src/getACGTNsites.cpp:97,173; R/extractSNPs.R:200), paint a double one
     // (R/estimateCDSDiversity.R:152), len and MI doubles
-    std::vector<Col> cols = {{LDW_COL_INT32, pos1.data()}, {LDW_COL_INT32, pos2.data()}, {LDW_COL_DOUBLE, c1.data()},
-                             {LDW_COL_DOUBLE, c2.data()}, {LDW_COL_DOUBLE, len.data()}, {LDW_COL_DOUBLE, mi.data()}};
-    return write_rows(path, append, n, cols, nthreads, bytes_out);
+    std::vector<Col> cols = {{LDW_COL_INT32, pos1}, {LDW_COL_INT32, pos2}, {LDW_COL_DOUBLE, c1}, {LDW_COL_DOUBLE, c2}, {LDW_COL_DOUBLE, len}, {LDW_COL_DOUBLE, mi}};
+    const auto t_2 = std::chrono::steady_clock::now();
+    const int rc = write_rows(path, append, n, cols, nthreads, bytes_out);
+    if (host_timing) {
+        auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+        fprintf(stderr, "[ldw] links tsv (%lld rows): fetch %.2f ms, derive %.2f, format + write %.2f\n", (long long)n, ms(t_0, t_1), ms(t_1, t_2),
+                ms(t_2, std::chrono::steady_clock::now()));
+    }
+    return rc;
 }
 
 }  // extern "C"

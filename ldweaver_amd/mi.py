@@ -280,7 +280,7 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
         if sr_model == "device":
             # mergeNsort_sr_links + runARACNE on the device-resident table; only the kept links come back
             redd, flags, model_aux = merge_n_sort_sr_links_device(eng, cds_var.nclust, sr_dist, srp_cutoff, POS, paint, g,
-                                                                  run_aracne=runARACNE)
+                                                                  run_aracne=runARACNE, order_links=order_links)
             pool = eng.sr_pool() if return_aux else None
             fit_data = model_aux["fit_data"]
             sa, sb, smi = redd["a"], redd["b"], redd["MI"]
@@ -324,7 +324,7 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
     if not runARACNE:
         warnings.warn("ARACNE not run, all values will be set to 1")
         red["ARACNE"] = 1.0
-    if order_links:
+    if order_links and sr_model != "device":   # (the device path has ordered the columns before the frame was built)
         red = red.iloc[np.argsort(-red["srp_max"].to_numpy(), kind="stable")].reset_index(drop=True)
     t_w = time.time()
     append_table(sr_save_path, [_pos_int(red[c]) if c in ("pos1", "pos2") else red[c].to_numpy() for c in ["clust_c"] + COLS + ["srp_max", "ARACNE"]])

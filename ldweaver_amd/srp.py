@@ -164,7 +164,18 @@ def fit_decay(ulen: np.ndarray, maxvls: np.ndarray) -> np.ndarray:
     return np.exp(X @ coef)
 
 
-def merge_n_sort_sr_links_device(eng, nclust: int, sr_dist: float, srp_cutoff: float, POS, paint, g, run_aracne=True):
+def stable_argsort_desc(v: np.ndarray) -> np.ndarray:
+    """order(-v) of R (stable): numpy's default argsort (vectorised quicksort: 5x faster than its stable kinds at 250 000 doubles) is
+    stable wherever no two values are equal, which is the rule for p-values; the stable sort runs only when a tie exists."""
+    neg = -np.asarray(v)
+    idx = np.argsort(neg)
+    s = neg[idx]
+    if len(s) > 1 and bool(np.any(s[1:] == s[:-1])) or bool(np.isnan(s).any()):
+        return np.argsort(neg, kind="stable")
+    return idx
+
+
+def merge_n_sort_sr_links_device(eng, nclust: int, sr_dist: float, srp_cutoff: float, POS, paint, g, run_aracne=True, order_links=False):
     """mergeNsort_sr_links + runARACNE with the link table left on the device by ``eng.mi_all_pairs``: the O(#links)
     work (per-length quantiles, excess statistics, p-values, de-duplication, ARACNE) runs in HBM, the host keeps the
     least-squares fit and the beta MLE.  Returns sr_links_red (same rows, order and columns as the host path) with the
@@ -197,7 +208,16 @@ def merge_n_sort_sr_links_device(eng, nclust: int, sr_dist: float, srp_cutoff: f
     # reference row order: per cluster the links inside one cluster, then the cross-cluster links in order of first
     # appearance (R/computePairwiseMI.R:470-486)
     key_cl = np.where(red["dup"], red["first_clust"], red["clust_c"])
-    order = np.lexsort((red["row"], key_cl, red["dup"]))
+    row = np.asarray(red["row"], dtype=np.int64)
+    if n_red and int(row.max()) < (1 << 48) and int(key_cl.max()) < (1 << 14):
+        # one 64-bit key (dup | cluster | row) instead of a three-key lexsort: a third of the time at 250 000 rows
+        order = np.argsort((np.asarray(red["dup"], dtype=np.int64) << 62) | (key_cl.astype(np.int64) << 48) | row)   # (keys are unique: rows are)
+    else:
+        order = np.lexsort((row, key_cl, red["dup"]))
+    if order_links:
+        # sr_links_red[order(-srp_max)] (R/computePairwiseMI.R:126; order() is stable) folded into the same gather: the columns are
+        # permuted once, as arrays, instead of once here and once more as a DataFrame
+        order = order[stable_argsort_desc(red["srp_max"][order])]
     return {k: v[order] for k, v in red.items()}, flags[order], dict(mean_dist=md, shape=shape, stats=stats, n_pool=n_pool,
                                                                      min_mi=min_mi, counts=cnt, fit_data=fit_data)
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""cProfile of the product entry point perform_MI_computation on the bench workload (second call on a warm engine): where the host time goes."""
+"""cProfile of the product entry point perform_MI_computation on the bench workload: where the host time goes.
+Default: the second call on a warm engine; --cold: the FIRST call of a fresh engine (what bench.py's job leg times)."""
 import cProfile
 import os
 import pstats
@@ -24,10 +25,11 @@ with Engine(0) as e:
     hdw = MIH.estimate_Hamming_distance_weights(sd, threshold=0.1, engine=e, alignment_resident=True, verbose=False)
     kw = dict(lr_save_path=os.path.join(tmp, "lr.tsv"), sr_save_path=os.path.join(tmp, "sr.tsv"), plt_folder=os.path.join(tmp, "P"), engine=e,
               alignment_resident=True, verbose=False, return_aux=True)
-    MIH.perform_MI_computation(sd, hdw, CdsVar(paint=syn["paint"], nclust=3), **kw)
+    if "--cold" not in sys.argv:
+        MIH.perform_MI_computation(sd, hdw, CdsVar(paint=syn["paint"], nclust=3), **kw)
     pr = cProfile.Profile()
     pr.enable()
     red, aux = MIH.perform_MI_computation(sd, hdw, CdsVar(paint=syn["paint"], nclust=3), **kw)
     pr.disable()
     print(aux["stages_s"])
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
