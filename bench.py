@@ -550,13 +550,13 @@ def main():
                              "kernel's own accumulators (the regions that pass are neither stored nor screened).  " + prune_note +
                              "`overlapped_avg_launch_ms` "
                              "is the bracket inside the timed region, where the GEMM shares the GPU with the previous block's screens and selection")
-            tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
+            tpath = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
             if os.path.exists(tpath) and (L, N, world) == (100_000, 5_000, 1):   # the configuration the PMC passes were collected on
                 ent = json.load(open(tpath)).get(kname)
                 if ent:
                     roof["traffic"] = ent.get("hbm_bytes_per_launch")
                     roof["traffic_range"] = ent.get("hbm_bytes_per_launch_range")
-                    roof["traffic_source"] = ("profiles/r03_pmc_traffic.json (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, per launch; `traffic` "
+                    roof["traffic_source"] = ("profiles/r04_pmc_traffic.json (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, per launch; `traffic` "
                                               "takes FETCH_SIZE x 2 as the guide prescribes for gfx950, `traffic_range` = [raw, x 2])")
         else:
             roof.update(kernel={"hist": "k_cooc_popc", "hist_states": "k_mi_hist"}.get(args.engine), achieved=None, frac=None)
