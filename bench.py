@@ -16,13 +16,15 @@ Every step is a COLD pass, as a job runs it: `ldw_reset_speculation` forgets the
 and the biallelic threshold table before each step (warm-up steps included), so a step visits every block pair once without
 anything learnt from an earlier pass over the same data (R/computePairwiseMI.R:103-116).  Buffers stay allocated.
 
-Order of work (so that a coarse GPU-busy sampler sees the GPU section as one stretch at the end of the run): setup ->
-`cpu_baseline` on the host cores (rank 0, N = 1 only) -> W warm-up steps -> EXACTLY K timed steps -> (N = 1 only) the extra
+Order of work (the GPU section is one stretch, the CPU baseline follows it: r04 — a GPU left idle for the baseline's 20-30 s made the first pass
+after it 30 ms slower than the first pass of a job, which follows the set-up at once): setup ->
+W warm-up steps -> EXACTLY K timed steps -> (N = 1 only) the extra
 legs reported on the same line: `warm_replay` (K steps WITHOUT the reset: every pass inherits its predecessor's guesses — the
 r02 headline, kept for comparison), `sustained` (cold steps until >= 10 s of GPU work have run), the kernel-exclusive replay
 behind `roofline`, `mi_values_produced` (5-limb GEMM + fp64 MI of EVERY pair: no screen, no mixed precision, no approximate
 GEMM — the rate at which MI values, not decisions, are produced) and `job` (the product entry points end to end, state matrix
-on the HOST -> both tsv files on disk: `h2d_ms`, Hamming weights, cold MI pass, `tsv_write_s`, short-range model + ARACNE).
+on the HOST -> both tsv files on disk: `h2d_ms`, Hamming weights, cold MI pass, `tsv_write_s`, short-range model + ARACNE), the
+`adversarial` workload; last, `cpu_baseline` on the host cores (rank 0, N = 1 only).
 With N > 1 the line carries `per_rank` (compute_ms, exposed_gather_ms, bytes_sent of every rank).
 """
 import argparse
@@ -30,6 +32,11 @@ import json
 import os
 import sys
 import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from ldweaver_amd.cpushare import cpu_share, limit_thread_pools  # noqa: E402  (before numpy: see the module)
+
+limit_thread_pools()
 
 import numpy as np
 
@@ -79,7 +86,7 @@ def cpu_baseline(states_np, hdw, r, uqe, N, sample):
     off-diagonal sample block of the same workload, all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
-    cores = c_oracle.max_threads()
+    cores = min(c_oracle.max_threads(), cpu_share())   # (the cgroup's share, not the host's 256 CPUs: more threads than that only get the process throttled)
     s = sample
     fi, ti = np.arange(0, s), np.arange(s, 2 * s)
     t0 = time.time()
@@ -304,13 +311,9 @@ def main():
     my_blocks = blocks[mine]
     setup_s = time.time() - t_setup
 
-    # ---- CPU baseline first: the GPU section below then runs as one stretch until the end of the process ----
+    # (the CPU baseline runs LAST, r04: between the set-up and the first pass its 20-30 s left the GPU idle, and the first pass after such a
+    # pause took 74 ms against the 42 ms it takes when it follows the set-up at once, as it does in a job)
     cpu_base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sample = args.cpu_sample or max(200, min(2000, L // 2))   # ~10-30 s of host work at N = 5000
-        st_np = states[: 2 * sample].cpu().numpy()
-        cpu_base = cpu_baseline(st_np, hdw, r[: 2 * sample], uqe[: 2 * sample], N, sample)
-        del st_np
 
     pairs = 0
     for fs, fe, ts, te in blocks.tolist():
@@ -581,6 +584,11 @@ def main():
                                approximate_gemm=eng.apx_info(),
                                parallelism=f"pair-space blocks over {world} GPU(s)"),
                    roofline=roof)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            sample = args.cpu_sample or max(200, min(2000, L // 2))   # ~10-30 s of host work at N = 5000
+            st_np = states[: 2 * sample].cpu().numpy()
+            cpu_base = cpu_baseline(st_np, hdw, r[: 2 * sample], uqe[: 2 * sample], N, sample)
+            del st_np
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         out.update(legs)

@@ -356,6 +356,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
         if (c->pin_pick[k]) (void)hipHostFree(c->pin_pick[k]);
         if (c->ev_pick[k]) (void)hipEventDestroy(c->ev_pick[k]);
     }
+    if (c->pin_fetch) (void)hipHostFree(c->pin_fetch);
     if (c->pin_lrc) (void)hipHostFree(c->pin_lrc);
     if (c->ev_lrc) (void)hipEventDestroy(c->ev_lrc);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);

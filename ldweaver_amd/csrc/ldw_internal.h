@@ -198,6 +198,8 @@ struct ldw_ctx {
     int64_t blk_capacity = 0, blk_cursor = 0;  // ldw_links_begin / ldw_mi_block_links / ldw_links_end
 
     // ---- short-range model and ARACNE on the device-resident sr table (ldw_srp.hip) ----
+    void *pin_fetch = nullptr;   // r04: pinned host arena the tsv writer fetches a link table into (see ldw_write_links_tsv)
+    size_t pin_fetch_cap = 0;
     ldw::DevBuf srm_pack, srm_key, srm_pack2, srm_key2, srm_pay, srm_pay2, srm_off, srm_q, srm_n, srm_md, srm_part, srm_shape, srm_cnt, srm_tmp;
     double gemm_stat[6] = {0, 0, 0, 0, 0, 0};   // ldw_gemm_stats: launches and executed int8 ops of the block-wide GEMMs
     ldw::DevBuf red_row, red_meta, red_srp, pool_a, pool_b, pool_mi, ar_key, ar_val, ar_key2, ar_val2, ar_off, ar_flags;

@@ -748,24 +748,45 @@ int ldw_sr_len_quantiles(ldw_ctx *c, int nclust, double sr_dist, double prob, in
     const bool force_sort = getenv("LDW_SR_QUANT_SORT") != nullptr;   // (A/B and tests: the two-sort path for any nclust; read per call)
     if (nclust <= SEL_MAXCL && n < (int64_t)0xFFFFFFFFll && !force_sort) {
         // r04: one sort (by len) fed from the table itself, then a radix select per len (k_sr_select)
-        if (int rc = srm_reserve_select(c, n)) return rc;
+        // Working memory: the three G' blocks of the MI pass's pipeline slots (4.3 GB each for 10k-SNP blocks) lie idle once the pass is over,
+        // and the quantile step of a job follows that pass: it borrows them when its arrays fit (C4: 0.2 + 1.1 + 1.3 GB) instead of allocating
+        // 2.4 GB of fresh device memory, whose first use cost the first job of a context ~20 ms (job leg: 24-28 ms against 4-5 ms for the
+        // same call on memory that had been used before).  Stream order makes it safe: ldw_mi_all_pairs returns with its streams drained.
+        const size_t need[3] = {(size_t)n * 2 + 64, (size_t)n * sizeof(SrPay), srm_sort_temp_bytes(n) + 256};
+        void *mem[3];
+        size_t tmp_cap;
+        const bool borrow = LDW_NSLOT >= 3 && c->Gapx[0].cap >= need[0] && c->Gapx[1].cap >= need[1] && c->Gapx[2].cap >= need[2] && getenv("LDW_SR_QUANT_OWN") == nullptr;
+        const auto t_a = now();
+        if (borrow) {
+            if (c->gemm_stream) LDW_HIP(hipStreamSynchronize(c->gemm_stream));   // (idle already; the G' blocks belong to that stream's kernels)
+            for (int k = 0; k < 3; ++k) mem[k] = c->Gapx[k].p;
+            tmp_cap = c->Gapx[2].cap;
+        } else {
+            if (int rc = srm_reserve_select(c, n)) return rc;
+            mem[0] = c->srm_pack2.p;
+            mem[1] = c->srm_pay.p;
+            mem[2] = c->srm_tmp.p;
+            tmp_cap = c->srm_tmp.cap;
+        }
+        const auto t_b = now();
         if (int rc = c->srm_off.reserve((size_t)(S + 2) * 8)) return rc;
         if (int rc = c->srm_q.reserve(cells * 16)) return rc;
         if (int rc = c->srm_n.reserve(cells * 8)) return rc;
+        if (host_timing) fprintf(stderr, "[ldw] sr quantiles: temp query %.2f ms, gemm stream sync / reserve %.2f, small reserves %.2f\n", ms(t_0, t_a), ms(t_a, t_b), ms(t_b, now()));
         const SrRowsView V{c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), c->sr_mi.as<double>(), c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, sr_dist};
         auto kin = rocprim::make_transform_iterator(rocprim::counting_iterator<int64_t>(0), SrLenOf{V});
         auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<int64_t>(0), SrPayOf{V});
-        uint16_t *len_sorted = c->srm_pack2.as<uint16_t>();
-        SrPay *pay_sorted = c->srm_pay.as<SrPay>();
-        size_t tb = c->srm_tmp.cap;
+        uint16_t *len_sorted = static_cast<uint16_t *>(mem[0]);
+        SrPay *pay_sorted = static_cast<SrPay *>(mem[1]);
+        size_t tb = tmp_cap;
         const auto t_1 = now();
         if (host_timing) LDW_HIP(hipStreamSynchronize(c->stream));
         const auto t_1b = now();
-        LDW_HIP(rocprim::radix_sort_pairs(c->srm_tmp.p, tb, kin, len_sorted, vin, pay_sorted, (size_t)n, 0u, 16u, c->stream));
+        LDW_HIP(rocprim::radix_sort_pairs(mem[2], tb, kin, len_sorted, vin, pay_sorted, (size_t)n, 0u, 16u, c->stream));
         if (host_timing) {
             const auto t_2 = now();
             LDW_HIP(hipStreamSynchronize(c->stream));
-            fprintf(stderr, "[ldw] sr quantiles: reserve %.2f ms (scratch %.1f MB), stream drain %.2f, sort enqueue %.2f + wait %.2f\n", ms(t_0, t_1), (double)tb / 1e6,
+            fprintf(stderr, "[ldw] sr quantiles%s: reserve %.2f ms (scratch %.1f MB), stream drain %.2f, sort enqueue %.2f + wait %.2f\n", borrow ? " (memory borrowed from the pass)" : "", ms(t_0, t_1), (double)tb / 1e6,
                     ms(t_1, t_1b), ms(t_1b, t_2), ms(t_2, now()));
         }
         hipLaunchKernelGGL(k_sr_seg_offsets, dim3((S + 2 + 255) / 256), dim3(256), 0, c->stream, len_sorted, n, S, c->srm_off.as<int64_t>());

@@ -11,7 +11,11 @@
 #include <mutex>
 #include <cerrno>
 #include <chrono>
+#include <climits>
 #include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <utility>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -163,10 +167,72 @@ struct Col {
 
 // default worker count: the machine's hardware threads, at most 16 (a container's CPU share is usually far below the host's count,
 // and the formatting saturates the file write well before that)
+// Big host buffers of the writer (thread buffers, derived columns) come from a small process-wide pool and go back to it instead of to the
+// OS: see ldw_write_links_tsv on what an munmap next to GPU work can cost.  Blocks are kept for the life of the process (a C4 job: ~100 MB).
+class HostPool {
+public:
+    void *get(size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu_);
+        size_t best = SIZE_MAX;
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].second >= bytes && (best == SIZE_MAX || free_[i].second < free_[best].second)) best = i;
+        if (best != SIZE_MAX) {
+            void *p = free_[best].first;
+            used_.push_back(free_[best]);
+            free_.erase(free_.begin() + (long)best);
+            return p;
+        }
+        void *p = malloc(bytes);
+        if (p) used_.push_back({p, bytes});
+        return p;
+    }
+    void put(void *p) {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(mu_);
+        for (size_t i = 0; i < used_.size(); ++i)
+            if (used_[i].first == p) {
+                free_.push_back(used_[i]);
+                used_.erase(used_.begin() + (long)i);
+                return;
+            }
+    }
+private:
+    std::mutex mu_;
+    std::vector<std::pair<void *, size_t>> free_, used_;
+};
+HostPool &host_pool() {
+    static HostPool *p = new HostPool;   // (never destroyed: threads may still hold blocks at exit)
+    return *p;
+}
+struct PoolBlock {
+    void *p = nullptr;
+    explicit PoolBlock(size_t bytes) : p(host_pool().get(bytes)) {}
+    ~PoolBlock() { host_pool().put(p); }
+    PoolBlock(const PoolBlock &) = delete;
+    PoolBlock &operator=(const PoolBlock &) = delete;
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
 int default_threads(int nthreads) {
     if (nthreads > 0) return nthreads < 64 ? nthreads : 64;
+    if (const char *e = getenv("LDW_TSV_THREADS")) {   // (experiments)
+        const int k = atoi(e);
+        if (k > 0) return k < 64 ? k : 64;
+    }
     const unsigned hw = std::thread::hardware_concurrency();
-    const int n = (int)(hw ? hw : 4);
+    int n = (int)(hw ? hw : 4);
+    // r04: the cgroup's CPU quota, when there is one (a container sees the host's CPU count; workers beyond the quota get the whole process
+    // throttled for the rest of the scheduling period — seen as a 15-25 ms stall in the NEXT call of a job)
+    if (FILE *fh = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32];
+        long long period = 0;
+        if (fscanf(fh, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long long share = atoll(q) / period;
+            if (share >= 1 && share < n) n = (int)share;
+        }
+        fclose(fh);
+    }
+    if (n > 4) n -= 2;   // (room for the calling thread's other duties and the HIP runtime's own threads)
     return n < 16 ? n : 16;
 }
 
@@ -199,7 +265,7 @@ int write_rows(const char *path, int append, int64_t nrows, const std::vector<Co
         const int64_t chunk = std::min<int64_t>((nrows + nt - 1) / nt, cap_rows);
         const int64_t nchunks = (nrows + chunk - 1) / chunk;
         const int64_t rounds = (nchunks + nt - 1) / nt;
-        std::vector<std::unique_ptr<char[]>> bufs((size_t)nt);
+        std::vector<std::unique_ptr<PoolBlock>> bufs((size_t)nt);
         std::vector<size_t> used((size_t)nt, 0);
         std::vector<int64_t> at((size_t)nt, 0);
         std::mutex mu;
@@ -211,14 +277,19 @@ int write_rows(const char *path, int append, int64_t nrows, const std::vector<Co
         static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
         std::vector<double> t_fmt((size_t)nt, 0.0), t_wait((size_t)nt, 0.0), t_wr((size_t)nt, 0.0);
         auto worker = [&](int t) {
-            bufs[(size_t)t].reset(new char[(size_t)chunk * row_max]);   // (uninitialised; first touched by the thread that fills it)
+            bufs[(size_t)t].reset(new PoolBlock((size_t)chunk * row_max));   // (uninitialised; first touched by the thread that fills it)
+            if (!bufs[(size_t)t]->p) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!failed) ldw::set_error("out of host memory for the tsv writer's buffers");
+                failed = true;
+            }
             for (int64_t r = 0; r < rounds; ++r) {
                 const auto w0 = std::chrono::steady_clock::now();
                 const int64_t c = r * nt + t;
                 size_t u = 0;
-                if (c < nchunks) {
+                if (c < nchunks && bufs[(size_t)t]->p) {
                     const int64_t a = c * chunk, b = std::min(nrows, a + chunk);
-                    char *p = bufs[(size_t)t].get();
+                    char *p = bufs[(size_t)t]->as<char>();
                     for (int64_t i = a; i < b; ++i) {
                         for (size_t k = 0; k < cols.size(); ++k) {
                             if (k) *p++ = '\t';
@@ -229,7 +300,7 @@ int write_rows(const char *path, int append, int64_t nrows, const std::vector<Co
                         }
                         *p++ = '\n';
                     }
-                    u = (size_t)(p - bufs[(size_t)t].get());
+                    u = (size_t)(p - bufs[(size_t)t]->as<char>());
                 }
                 const auto w1 = std::chrono::steady_clock::now();
                 {
@@ -251,7 +322,7 @@ int write_rows(const char *path, int append, int64_t nrows, const std::vector<Co
                 const auto w2 = std::chrono::steady_clock::now();
                 size_t w = 0;
                 while (w < u) {
-                    const ssize_t k = pwrite(fd, bufs[(size_t)t].get() + w, u - w, (off_t)(my_at + (int64_t)w));
+                    const ssize_t k = pwrite(fd, bufs[(size_t)t]->as<char>() + w, u - w, (off_t)(my_at + (int64_t)w));
                     if (k < 0) {
                         if (errno == EINTR) continue;
                         std::lock_guard<std::mutex> lk(mu);
@@ -324,10 +395,46 @@ int ldw_write_links_tsv(ldw_ctx *c, int which, const char *path, int append, int
     if (bytes_out) *bytes_out = 0;
     if (n == 0) return LDW_OK;   // the reference writes nothing for an empty frame (R/computePairwiseMI.R:360)
     // (uninitialised arrays: a std::vector would clear 48 bytes per row on the calling thread before anything is written)
-    std::unique_ptr<int32_t[]> a_(new int32_t[(size_t)n]), b_(new int32_t[(size_t)n]), pos1_(new int32_t[(size_t)n]), pos2_(new int32_t[(size_t)n]);
-    std::unique_ptr<double[]> mi_(new double[(size_t)n]), c1_(new double[(size_t)n]), c2_(new double[(size_t)n]), len_(new double[(size_t)n]);
-    int32_t *a = a_.get(), *b = b_.get(), *pos1 = pos1_.get(), *pos2 = pos2_.get();
-    double *mi = mi_.get(), *c1 = c1_.get(), *c2 = c2_.get(), *len = len_.get();
+    // The table itself (a, b, MI: 16 bytes per row) is fetched into a PINNED arena that stays with the context.  r04, measured
+    // (tools/job_profile.py --cold with LDW_TSV_LEAK / LDW_EXP_SLEEP_MS): a D2H copy into pageable memory makes the runtime register those pages
+    // with the GPU for the DMA, and giving such memory back to the OS afterwards (arrays of this size are mmap'ed, so delete[] is munmap) stalls
+    // the process's NEXT GPU call by ~20 ms — the driver quiesces the queues to drop the registration and restores them a moment later; the
+    // short-range model's first stream synchronisation after lr_links.tsv paid it in every job.
+    const size_t fetch_bytes = (size_t)n * 16;
+    std::unique_ptr<int32_t[]> a_, b_;
+    std::unique_ptr<double[]> mi_;
+    PoolBlock derived((size_t)n * 32);   // pos1, pos2 (int32), clust1, clust2, len (double)
+    LDW_REQUIRE(derived.p != nullptr, LDW_ERR_ARG, "ldw_write_links_tsv: out of host memory");
+    int32_t *a, *b;
+    double *mi;
+    if (fetch_bytes <= ((size_t)2 << 30)) {
+        if (c->pin_fetch_cap < fetch_bytes) {
+            if (c->pin_fetch) (void)hipHostFree(c->pin_fetch);
+            c->pin_fetch = nullptr;
+            c->pin_fetch_cap = 0;
+            const size_t want = fetch_bytes + fetch_bytes / 8 + 4096;
+            if (hipHostMalloc(&c->pin_fetch, want, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                c->pin_fetch = nullptr;
+            } else {
+                c->pin_fetch_cap = want;
+            }
+        }
+    }
+    if (c->pin_fetch && c->pin_fetch_cap >= fetch_bytes) {
+        mi = static_cast<double *>(c->pin_fetch);
+        a = reinterpret_cast<int32_t *>(mi + n);
+        b = a + n;
+    } else {   // (tables beyond 2 GB, or no pinned memory to be had: pageable arrays)
+        a_.reset(new int32_t[(size_t)n]);
+        b_.reset(new int32_t[(size_t)n]);
+        mi_.reset(new double[(size_t)n]);
+        a = a_.get();
+        b = b_.get();
+        mi = mi_.get();
+    }
+    double *c1 = derived.as<double>(), *c2 = c1 + n, *len = c2 + n;
+    int32_t *pos1 = reinterpret_cast<int32_t *>(len + n), *pos2 = pos1 + n;
     static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
     const auto t_0 = std::chrono::steady_clock::now();
     if (int rc = ldw_links_fetch(c, which, a, b, mi, n, 0)) return rc;
@@ -362,6 +469,7 @@ int ldw_write_links_tsv(ldw_ctx *c, int which, const char *path, int append, int
     std::vector<Col> cols = {{LDW_COL_INT32, pos1}, {LDW_COL_INT32, pos2}, {LDW_COL_DOUBLE, c1}, {LDW_COL_DOUBLE, c2}, {LDW_COL_DOUBLE, len}, {LDW_COL_DOUBLE, mi}};
     const auto t_2 = std::chrono::steady_clock::now();
     const int rc = write_rows(path, append, n, cols, nthreads, bytes_out);
+
     if (host_timing) {
         auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
         fprintf(stderr, "[ldw] links tsv (%lld rows): fetch %.2f ms, derive %.2f, format + write %.2f\n", (long long)n, ms(t_0, t_1), ms(t_1, t_2),

@@ -16,6 +16,9 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ldweaver_amd.cpushare import limit_thread_pools  # noqa: E402
+
+limit_thread_pools()   # (before numpy / torch: keep their pools inside the cgroup's CPU share)
 import torch  # noqa: E402
 
 from ldweaver_amd import srp  # noqa: E402

@@ -8,6 +8,9 @@ import sys
 import tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ldweaver_amd.cpushare import limit_thread_pools  # noqa: E402
+
+limit_thread_pools()   # (before numpy / torch: keep their pools inside the cgroup's CPU share)
 import numpy as np
 
 from ldweaver_amd import mi as MIH
