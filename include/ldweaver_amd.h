@@ -231,9 +231,10 @@ int ldw_prune_report(ldw_ctx *ctx, int64_t out[4]);
  * out[2] segments redone on their own after a wrong guess, out[3] on.
  * ldw_set_pair_cap (tests only): a fixed capacity for the pair lists of the approximate path (0: automatic) — a list that overflows makes
  * its block fall back like a wrong guess; process-wide. */
-/* r04 — off the critical path.  ldw_ctx_create starts a side thread that creates the two extra streams of the all-pairs loop (12 ms each
- * on MI355X) and loads the code objects of the pass's kernels; ldw_ctx_reserve starts a second one for the pinned staging buffers (sized
- * from L, N and max_blk_sz: call it before uploading the alignment and it hides behind the upload and the Hamming GEMM).  Both are
+/* r04 — off the critical path.  ldw_ctx_create makes the two extra streams of the all-pairs loop itself (12 ms each on MI355X: part of
+ * creating a context, not of a job's pass) and starts a side thread that loads the code objects of the pass's kernels; ldw_ctx_reserve starts a second one for the pinned staging buffers and the
+ * per-slot device buffers (sized from L, N and max_blk_sz: call it right AFTER uploading the alignment — beside the upload it slowed the H2D
+ * copy from 9.5 to 17 ms — and it hides behind the Hamming GEMM and the set-up calls).  Both are
  * optional (everything is also made lazily: LDW_NO_PREPARE=1 switches them off); the entry points that use what they prepare wait for them. */
 int ldw_ctx_reserve(ldw_ctx *ctx, int64_t L, int64_t N, int64_t max_blk_sz);
 /* r04 — the index columns of the short-range table from positions alone.  The short-range rows a pass emits for a block pair of contiguous SNP

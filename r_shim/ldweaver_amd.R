@@ -41,6 +41,7 @@ perform_MI_computation <- function(snp.dat, hdw, cds_var, ncores, lr_save_path =
     lr_links_approx <- sum(cnt) / snp_subset * snp.dat$nsnp / 2
   }
   .Call("ldwamd_set_alignment", .ldwamd_states_from_snpdat(snp.dat), snp.dat$nsnp, snp.dat$nseq)
+  .Call("ldwamd_ctx_reserve", snp.dat$nsnp, snp.dat$nseq, max_blk_sz)        # r04: the pass's buffers, on a side thread, while the weights are set
   .Call("ldwamd_set_weights", as.numeric(hdw))
   .Call("ldwamd_set_snp_meta", as.numeric(snp.dat$r), as.raw(t(snp.dat$uqe)), as.integer(snp.dat$POS),
         as.integer(cds_var$paint), as.numeric(snp.dat$g))

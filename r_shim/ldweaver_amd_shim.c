@@ -37,6 +37,18 @@ SEXP ldwamd_set_alignment(SEXP states, SEXP L, SEXP N) {
     return R_NilValue;
 }
 
+/* r04: per-block buffers of the all-pairs loop sized and pinned on a side thread (call after ldwamd_set_alignment; optional) */
+SEXP ldwamd_ctx_reserve(SEXP L, SEXP N, SEXP max_blk_sz) {
+    CHK(ldw_ctx_reserve(ctx_or_stop(), (int64_t)asReal(L), (int64_t)asReal(N), (int64_t)asReal(max_blk_sz)));
+    return R_NilValue;
+}
+
+/* r04: spans on / off and their length (execution option: results do not depend on it) */
+SEXP ldwamd_set_span(SEXP on, SEXP max_blocks) {
+    CHK(ldw_set_span(ctx_or_stop(), asInteger(on), asInteger(max_blocks)));
+    return R_NilValue;
+}
+
 /* estimate_Hamming_distance_weights core: thresh = as.integer(nsnp*threshold) computed in R */
 SEXP ldwamd_hamming_weights(SEXP thresh, SEXP N) {
     SEXP out = PROTECT(allocVector(REALSXP, (R_xlen_t)asReal(N)));
@@ -311,6 +323,8 @@ static const R_CallMethodDef CallEntries[] = {
     {"ldwamd_sr_pvalues_aracne", (DL_FUNC)&ldwamd_sr_pvalues_aracne, 5},
     {"ldwamd_ACGTN2num", (DL_FUNC)&ldwamd_ACGTN2num, 3},
     {"ldwamd_set_alignment", (DL_FUNC)&ldwamd_set_alignment, 3},
+    {"ldwamd_ctx_reserve", (DL_FUNC)&ldwamd_ctx_reserve, 3},
+    {"ldwamd_set_span", (DL_FUNC)&ldwamd_set_span, 2},
     {"ldwamd_hamming_weights", (DL_FUNC)&ldwamd_hamming_weights, 2},
     {"ldwamd_set_weights", (DL_FUNC)&ldwamd_set_weights, 1},
     {"ldwamd_set_snp_meta", (DL_FUNC)&ldwamd_set_snp_meta, 5},
