@@ -364,6 +364,14 @@ int ldw_write_table_tsv(const char *path, int append, int64_t nrows, int ncols, 
  * (R/computePairwiseMI.R:319-331: pos1 = POS of the to-side SNP, integer columns; clust, len, MI doubles), fetched from the
  * device and formatted by host threads.  An empty table writes nothing, like the reference (:360). */
 int ldw_write_links_tsv(ldw_ctx *ctx, int which, const char *path, int append, int nthreads, int64_t *rows_out, int64_t *bytes_out);
+/* r04 — the same table written BESIDE the caller's next calls: _begin fetches the table from the device (synchronously: the table may be
+ * replaced afterwards) and returns while host threads derive, format and write it; _end waits for them and reports rows, bytes and the
+ * writer's status.  lr_links.tsv (R/computePairwiseMI.R:362) does not depend on the short-range model that follows it (:119-126), so a job
+ * hides the 15 ms of its million rows behind that model.  One asynchronous table per context at a time (_begin, the synchronous call,
+ * ldw_set_snp_meta and ldw_ctx_destroy finish a pending one first); _end without _begin returns 0 rows. */
+int ldw_write_links_tsv_begin(ldw_ctx *ctx, int which, const char *path, int append, int nthreads);
+int ldw_write_links_tsv_end(ldw_ctx *ctx, int64_t *rows_out, int64_t *bytes_out);
+int ldw_tsv_join(ldw_ctx *ctx);   /* waits for a pending asynchronous table, discarding its counts (status returned) */
 
 /* ---- small native helpers kept for finest-grain A/B parity (host memory) -------------------- */
 /* .compareToRow src/computeMI.cpp:25-41: ret[j] = any(x[j,] in y); x is nr x nc column-major */

@@ -102,6 +102,9 @@ _SIGS = {
     "ldw_r_sample": (C.c_int, [C.c_uint32, C.c_int64, C.c_int64, _p]),
     "ldw_write_table_tsv": (C.c_int, [C.c_char_p, C.c_int, _i64, C.c_int, _p, _p, C.c_int, C.POINTER(_i64)]),
     "ldw_write_links_tsv": (C.c_int, [_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
+    "ldw_write_links_tsv_begin": (C.c_int, [_p, C.c_int, C.c_char_p, C.c_int, C.c_int]),
+    "ldw_write_links_tsv_end": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64)]),
+    "ldw_tsv_join": (C.c_int, [_p]),
     "ldw_compare_to_row": (C.c_int, [_p, _i64, _i64, _p, _i64, _p]),
     "ldw_vec_pos_match": (C.c_int, [_p, _i64, _p, _i64, _p]),
     "ldw_compare_triplet": (C.c_int, [_p, _p, _i64, C.c_double, C.POINTER(C.c_int)]),

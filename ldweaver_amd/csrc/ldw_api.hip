@@ -327,6 +327,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     if (!c) return LDW_OK;
     (void)hipSetDevice(c->device);
     (void)ldw::join_prepare(c);
+    (void)ldw_tsv_join(c);
     (void)hipStreamSynchronize(c->stream);
     ldw::DevBuf *bufs[] = {&c->srm_tmp, &c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->apx_skip, &c->snp_sup, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
@@ -759,6 +760,7 @@ int ldw_set_weights(ldw_ctx *c, const double *hdw, int64_t N, int nlimbs) {
 int ldw_set_snp_meta(ldw_ctx *c, const double *r, const uint8_t *uqe, const int32_t *POS, const int32_t *paint, double g) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(c->L > 0, LDW_ERR_STATE, "ldw_set_snp_meta: set the alignment first");
+    if (int rc = ldw_tsv_join(c)) return rc;   // (a pending asynchronous table reads the positions this call replaces)
     LDW_REQUIRE(r && uqe && POS, LDW_ERR_ARG, "ldw_set_snp_meta: null argument");
     LDW_REQUIRE(g > 0, LDW_ERR_ARG, "ldw_set_snp_meta: genome length g must be positive (snp.dat$g)");
     const int64_t L = c->L;

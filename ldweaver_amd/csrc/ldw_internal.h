@@ -198,6 +198,7 @@ struct ldw_ctx {
     int64_t blk_capacity = 0, blk_cursor = 0;  // ldw_links_begin / ldw_mi_block_links / ldw_links_end
 
     // ---- short-range model and ARACNE on the device-resident sr table (ldw_srp.hip) ----
+    void *tsv_async = nullptr;   // r04: the asynchronous link-table writer, if one is running (ldw_tsv.cpp: TsvAsync)
     void *pin_fetch = nullptr;   // r04: pinned host arena the tsv writer fetches a link table into (see ldw_write_links_tsv)
     size_t pin_fetch_cap = 0;
     ldw::DevBuf srm_pack, srm_key, srm_pack2, srm_key2, srm_pay, srm_pay2, srm_off, srm_q, srm_n, srm_md, srm_part, srm_shape, srm_cnt, srm_tmp;

@@ -384,29 +384,46 @@ int ldw_write_table_tsv(const char *path, int append, int64_t nrows, int ncols, 
     return write_rows(path, append, nrows, cc, nthreads, bytes_out);
 }
 
-int ldw_write_links_tsv(ldw_ctx *c, int which, const char *path, int append, int nthreads, int64_t *rows_out, int64_t *bytes_out) {
+// One lr_links.tsv / sr_links.tsv job: the synchronous half (count, fetch into the pinned arena) and the host half (derive the reference's
+// columns, format, write), which ldw_write_links_tsv_begin runs on a thread of its own beside the caller's next GPU work.
+struct LinksTsvJob {
+    int64_t n = 0;
+    int32_t *a = nullptr, *b = nullptr;
+    double *mi = nullptr;
+    std::unique_ptr<int32_t[]> a_own, b_own;
+    std::unique_ptr<double[]> mi_own;
+    std::unique_ptr<PoolBlock> derived;
+    std::string path;
+    int append = 0, nthreads = 0;
+    double g = 0;
+    const int32_t *POS = nullptr, *paint = nullptr;
+    double fetch_ms = 0;
+};
+
+static int links_tsv_prepare(ldw_ctx *c, int which, const char *path, int append, int nthreads, LinksTsvJob &J) {
     if (int rc = ldw::check_gpu(c)) return rc;
     LDW_REQUIRE(path && (which == 0 || which == 1), LDW_ERR_ARG, "ldw_write_links_tsv: bad argument");
     LDW_REQUIRE(c->have_meta && (int64_t)c->h_POS.size() == c->L && (int64_t)c->h_paint.size() == c->L, LDW_ERR_STATE,
                 "ldw_write_links_tsv: SNP meta data (POS, paint, g) not set");
     int64_t n = 0;
     if (int rc = ldw_links_count(c, which, &n)) return rc;
-    if (rows_out) *rows_out = n;
-    if (bytes_out) *bytes_out = 0;
+    J.n = n;
+    J.path = path;
+    J.append = append;
+    J.nthreads = nthreads;
+    J.g = c->g;
+    J.POS = c->h_POS.data();
+    J.paint = c->h_paint.data();
     if (n == 0) return LDW_OK;   // the reference writes nothing for an empty frame (R/computePairwiseMI.R:360)
     // (uninitialised arrays: a std::vector would clear 48 bytes per row on the calling thread before anything is written)
     // The table itself (a, b, MI: 16 bytes per row) is fetched into a PINNED arena that stays with the context.  r04, measured
-    // (tools/job_profile.py --cold with LDW_TSV_LEAK / LDW_EXP_SLEEP_MS): a D2H copy into pageable memory makes the runtime register those pages
-    // with the GPU for the DMA, and giving such memory back to the OS afterwards (arrays of this size are mmap'ed, so delete[] is munmap) stalls
-    // the process's NEXT GPU call by ~20 ms — the driver quiesces the queues to drop the registration and restores them a moment later; the
-    // short-range model's first stream synchronisation after lr_links.tsv paid it in every job.
+    // (tools/job_profile.py --cold with two switches that leaked the arrays / slept before the next call): a D2H copy into pageable memory makes
+    // the runtime register those pages with the GPU for the DMA, and giving such memory back to the OS afterwards (arrays of this size are
+    // mmap'ed, so delete[] is munmap) stalls the process's NEXT GPU call by ~20 ms — the driver quiesces the queues to drop the registration
+    // and restores them a moment later; the short-range model's first stream synchronisation after lr_links.tsv paid it in every job.
     const size_t fetch_bytes = (size_t)n * 16;
-    std::unique_ptr<int32_t[]> a_, b_;
-    std::unique_ptr<double[]> mi_;
-    PoolBlock derived((size_t)n * 32);   // pos1, pos2 (int32), clust1, clust2, len (double)
-    LDW_REQUIRE(derived.p != nullptr, LDW_ERR_ARG, "ldw_write_links_tsv: out of host memory");
-    int32_t *a, *b;
-    double *mi;
+    J.derived.reset(new PoolBlock((size_t)n * 32));   // pos1, pos2 (int32), clust1, clust2, len (double)
+    LDW_REQUIRE(J.derived->p != nullptr, LDW_ERR_ARG, "ldw_write_links_tsv: out of host memory");
     if (fetch_bytes <= ((size_t)2 << 30)) {
         if (c->pin_fetch_cap < fetch_bytes) {
             if (c->pin_fetch) (void)hipHostFree(c->pin_fetch);
@@ -422,26 +439,36 @@ int ldw_write_links_tsv(ldw_ctx *c, int which, const char *path, int append, int
         }
     }
     if (c->pin_fetch && c->pin_fetch_cap >= fetch_bytes) {
-        mi = static_cast<double *>(c->pin_fetch);
-        a = reinterpret_cast<int32_t *>(mi + n);
-        b = a + n;
+        J.mi = static_cast<double *>(c->pin_fetch);
+        J.a = reinterpret_cast<int32_t *>(J.mi + n);
+        J.b = J.a + n;
     } else {   // (tables beyond 2 GB, or no pinned memory to be had: pageable arrays)
-        a_.reset(new int32_t[(size_t)n]);
-        b_.reset(new int32_t[(size_t)n]);
-        mi_.reset(new double[(size_t)n]);
-        a = a_.get();
-        b = b_.get();
-        mi = mi_.get();
+        J.a_own.reset(new int32_t[(size_t)n]);
+        J.b_own.reset(new int32_t[(size_t)n]);
+        J.mi_own.reset(new double[(size_t)n]);
+        J.a = J.a_own.get();
+        J.b = J.b_own.get();
+        J.mi = J.mi_own.get();
     }
-    double *c1 = derived.as<double>(), *c2 = c1 + n, *len = c2 + n;
-    int32_t *pos1 = reinterpret_cast<int32_t *>(len + n), *pos2 = pos1 + n;
-    static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
     const auto t_0 = std::chrono::steady_clock::now();
-    if (int rc = ldw_links_fetch(c, which, a, b, mi, n, 0)) return rc;
+    if (int rc = ldw_links_fetch(c, which, J.a, J.b, J.mi, n, 0)) return rc;
+    J.fetch_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count();
+    return LDW_OK;
+}
+
+static int links_tsv_finish(LinksTsvJob &J, int64_t *bytes_out) {
+    if (bytes_out) *bytes_out = 0;
+    const int64_t n = J.n;
+    if (n == 0) return LDW_OK;
+    static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
     const auto t_1 = std::chrono::steady_clock::now();
-    const double g = c->g, hg = 0.5 * c->g;
-    const int32_t *POS = c->h_POS.data(), *paint = c->h_paint.data();
-    int nt = (int)std::min<int64_t>(default_threads(nthreads), (n + 65535) / 65536);
+    const int32_t *a = J.a, *b = J.b;
+    double *mi = J.mi;
+    double *c1 = J.derived->as<double>(), *c2 = c1 + n, *len = c2 + n;
+    int32_t *pos1 = reinterpret_cast<int32_t *>(len + n), *pos2 = pos1 + n;
+    const double g = J.g, hg = 0.5 * J.g;
+    const int32_t *POS = J.POS, *paint = J.paint;
+    int nt = (int)std::min<int64_t>(default_threads(J.nthreads), (n + 65535) / 65536);
     if (nt < 1) nt = 1;
     auto derive = [&](int t) {
         const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
@@ -468,14 +495,79 @@ int ldw_write_links_tsv(ldw_ctx *c, int which, const char *path, int append, int
     // (R/estimateCDSDiversity.R:152), len and MI doubles
     std::vector<Col> cols = {{LDW_COL_INT32, pos1}, {LDW_COL_INT32, pos2}, {LDW_COL_DOUBLE, c1}, {LDW_COL_DOUBLE, c2}, {LDW_COL_DOUBLE, len}, {LDW_COL_DOUBLE, mi}};
     const auto t_2 = std::chrono::steady_clock::now();
-    const int rc = write_rows(path, append, n, cols, nthreads, bytes_out);
-
+    const int rc = write_rows(J.path.c_str(), J.append, n, cols, J.nthreads, bytes_out);
     if (host_timing) {
         auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
-        fprintf(stderr, "[ldw] links tsv (%lld rows): fetch %.2f ms, derive %.2f, format + write %.2f\n", (long long)n, ms(t_0, t_1), ms(t_1, t_2),
+        fprintf(stderr, "[ldw] links tsv (%lld rows): fetch %.2f ms, derive %.2f, format + write %.2f\n", (long long)n, J.fetch_ms, ms(t_1, t_2),
                 ms(t_2, std::chrono::steady_clock::now()));
     }
+    J.derived.reset();
     return rc;
+}
+
+// the asynchronous writer of a context, if one is running: joined by every call that needs what it holds (the pinned arena, h_POS / h_paint)
+struct TsvAsync {
+    std::thread th;
+    LinksTsvJob job;
+    int rc = LDW_OK;
+    int64_t bytes = 0;
+    std::string err;
+};
+static int tsv_async_join(ldw_ctx *c, int64_t *rows_out, int64_t *bytes_out) {
+    TsvAsync *A = static_cast<TsvAsync *>(c->tsv_async);
+    if (!A) return LDW_OK;
+    if (A->th.joinable()) A->th.join();
+    const int rc = A->rc;
+    if (rows_out) *rows_out = A->job.n;
+    if (bytes_out) *bytes_out = A->bytes;
+    if (rc != LDW_OK) ldw::set_error("%s", A->err.c_str());
+    delete A;
+    c->tsv_async = nullptr;
+    return rc;
+}
+
+int ldw_tsv_join(ldw_ctx *c) { return tsv_async_join(c, nullptr, nullptr); }   // (ldw_ctx_destroy, ldw_set_snp_meta)
+
+int ldw_write_links_tsv(ldw_ctx *c, int which, const char *path, int append, int nthreads, int64_t *rows_out, int64_t *bytes_out) {
+    if (c && c->tsv_async) {
+        if (int rc = tsv_async_join(c, nullptr, nullptr)) return rc;   // (an unfinished asynchronous table: its error, if any, first)
+    }
+    LinksTsvJob J;
+    if (int rc = links_tsv_prepare(c, which, path, append, nthreads, J)) return rc;
+    if (rows_out) *rows_out = J.n;
+    return links_tsv_finish(J, bytes_out);
+}
+
+int ldw_write_links_tsv_begin(ldw_ctx *c, int which, const char *path, int append, int nthreads) {
+    if (c && c->tsv_async) {
+        if (int rc = tsv_async_join(c, nullptr, nullptr)) return rc;
+    }
+    TsvAsync *A = new TsvAsync;
+    if (int rc = links_tsv_prepare(c, which, path, append, nthreads, A->job)) {
+        delete A;
+        return rc;
+    }
+    c->tsv_async = A;
+    A->th = std::thread([A] {
+        try {
+            A->rc = links_tsv_finish(A->job, &A->bytes);
+            if (A->rc != LDW_OK) A->err = ldw_last_error();   // (the error text is per thread: carried over to the joining one)
+        } catch (const std::exception &e) {
+            A->rc = LDW_ERR_ARG;
+            A->err = std::string("ldw_write_links_tsv_begin: ") + e.what();
+        } catch (...) {
+            A->rc = LDW_ERR_ARG;
+            A->err = "ldw_write_links_tsv_begin: unknown exception in the writer thread";
+        }
+    });
+    return LDW_OK;
+}
+
+int ldw_write_links_tsv_end(ldw_ctx *c, int64_t *rows_out, int64_t *bytes_out) {
+    LDW_REQUIRE(c != nullptr, LDW_ERR_ARG, "ldw_write_links_tsv_end: null context");
+    if (rows_out) *rows_out = 0;
+    if (bytes_out) *bytes_out = 0;
+    return tsv_async_join(c, rows_out, bytes_out);
 }
 
 }  // extern "C"

@@ -130,6 +130,16 @@ class Engine:
         L.check(L.lib().ldw_write_links_tsv(self._ctx, int(which), str(path).encode(), int(bool(append)), int(nthreads), C.byref(n), C.byref(nb)))
         return int(n.value), int(nb.value)
 
+    def write_links_tsv_begin(self, which: int, path: str, append: bool = True, nthreads: int = 0):
+        """Fetch the table now, derive / format / write it on host threads while the caller goes on (``write_links_tsv_end`` waits)."""
+        L.check(L.lib().ldw_write_links_tsv_begin(self._ctx, int(which), str(path).encode(), int(bool(append)), int(nthreads)))
+
+    def write_links_tsv_end(self):
+        """(rows, bytes) of the table started by ``write_links_tsv_begin``; raises what its writer reported."""
+        n, nb = C.c_int64(0), C.c_int64(0)
+        L.check(L.lib().ldw_write_links_tsv_end(self._ctx, C.byref(n), C.byref(nb)))
+        return int(n.value), int(nb.value)
+
     def set_overlap(self, on: bool):
         """GEMM of the next block beside the epilogue/selection of the current one (default on); off = exclusive stage times."""
         L.check(L.lib().ldw_set_overlap(self._ctx, int(bool(on))))

@@ -14,6 +14,19 @@ from .rcompat import circ_len
 SR_TSV_COLS = ["clust_c", "pos1", "pos2", "clust1", "clust2", "len", "MI", "srp_max", "ARACNE"]   # R/computePairwiseMI.R:140
 
 
+def positions_to_snp_index(POS, p) -> np.ndarray:
+    """0-based SNP index of every position in ``p`` — ``snp.dat$POS`` in ANY order (the reference imposes none: R/computePairwiseMI.R:176-177;
+    r03 assumed ascending positions here); a position held by several SNPs maps to the first of them.  Raises on a position that is no SNP's."""
+    POS = np.asarray(POS)
+    p = np.asarray(p)
+    order = np.argsort(POS, kind="stable")
+    srt = POS[order]
+    k = np.searchsorted(srt, p, side="left")
+    if len(p) and not np.array_equal(srt[np.minimum(k, len(srt) - 1)], p):
+        raise ValueError("sr_links holds positions that are not SNP positions of snp_dat")
+    return order[np.minimum(k, len(srt) - 1)] if len(p) else np.zeros(0, dtype=np.int64)
+
+
 def analyse_long_range_links(eng, snp_dat, sr_links, cds_var=None, are_lrlinks_ordered: bool = False, min_links: int = 5000) -> dict:
     """Tukey outlier analysis + ARACNE of the long-range links the engine holds after ``perform_MI_computation`` /
     ``mi_all_pairs`` (the reference reads them back from lr_links.tsv).  ``sr_links`` is the short-range part of the ARACNE
@@ -25,9 +38,7 @@ def analyse_long_range_links(eng, snp_dat, sr_links, cds_var=None, are_lrlinks_o
         sr_links = pd.read_csv(sr_links, sep="\t", header=None, names=SR_TSV_COLS)
     POS_ = np.asarray(snp_dat.POS)
     p1, p2 = np.asarray(sr_links["pos1"]), np.asarray(sr_links["pos2"])
-    sb_, sa_ = np.searchsorted(POS_, p1), np.searchsorted(POS_, p2)      # pos1 = to side (b), pos2 = from side (a)
-    if len(p1) and not (np.array_equal(POS_[np.minimum(sb_, len(POS_) - 1)], p1) and np.array_equal(POS_[np.minimum(sa_, len(POS_) - 1)], p2)):
-        raise ValueError("sr_links holds positions that are not SNP positions of snp_dat")
+    sb_, sa_ = positions_to_snp_index(POS_, p1), positions_to_snp_index(POS_, p2)      # pos1 = to side (b), pos2 = from side (a)
     info = eng.lr_tukey(min_links, sr=(sa_, sb_, np.asarray(sr_links["MI"], dtype=np.float64)))
     if info["fallback"]:   # R/lr_analyser.R:96
         warnings.warn("Not enough lr links pass the Tukey criteria, ~5000 top links were retained instead")

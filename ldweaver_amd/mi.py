@@ -270,12 +270,13 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
             stages["mi_all_pairs_s"] = time.time() - t_s
         # lr_links.tsv (R/computePairwiseMI.R:362) straight from the device-resident table: fetched, derived (pos, clust, len) and
         # formatted by the library's host threads
+        # r04: the table is fetched here and formatted / written by host threads WHILE the short-range model below runs on the GPU (the model
+        # does not touch the long-range table: R/computePairwiseMI.R:119-126); `lr_tsv_s` = what the job waits for it (fetch + the final join)
         t_w = time.time()
         n_lr_rows = 0
         if not perform_SR_analysis_only:
-            n_lr_rows, _ = eng.write_links_tsv(1, lr_save_path, append=True)
+            eng.write_links_tsv_begin(1, lr_save_path, append=True)
         tsv_s = time.time() - t_w
-        stages["lr_tsv_s"] = tsv_s
         t_s = time.time()
         if sr_model == "device":
             # mergeNsort_sr_links + runARACNE on the device-resident table; only the kept links come back
@@ -289,6 +290,11 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
         else:
             raise ValueError("sr_model must be 'device' or 'host'")
         stages["sr_model_aracne_s"] = time.time() - t_s
+        t_w = time.time()
+        if not perform_SR_analysis_only:
+            n_lr_rows, _ = eng.write_links_tsv_end()
+        tsv_s += time.time() - t_w
+        stages["lr_tsv_s"] = tsv_s
         path_report = eng.path_report()
     finally:
         if own:

@@ -217,3 +217,18 @@ def test_bench_gpus_n_launches_n_ranks_itself():
     if not torch.cuda.is_available():
         assert p.returncode != 0
         assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_positions_to_snp_index_any_order():
+    """lr.analyse_long_range_links maps the positions of sr_links.tsv back to SNP indices with POS in any order."""
+    from ldweaver_amd.lr import positions_to_snp_index
+    rng = np.random.default_rng(3)
+    POS = rng.permutation(np.arange(10, 5000, 7))
+    pick = rng.integers(0, len(POS), 300)
+    assert np.array_equal(positions_to_snp_index(POS, POS[pick]), pick)
+    assert np.array_equal(positions_to_snp_index(np.sort(POS), np.sort(POS)[pick]), pick)
+    assert len(positions_to_snp_index(POS, np.zeros(0, dtype=POS.dtype))) == 0
+    dup = np.array([5, 9, 5, 7])
+    assert positions_to_snp_index(dup, np.array([5, 7])).tolist() == [0, 3]          # first holder of a repeated position
+    with pytest.raises(ValueError):
+        positions_to_snp_index(POS, np.array([11]))

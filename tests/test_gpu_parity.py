@@ -338,6 +338,39 @@ def test_perform_mi_computation_end_to_end(engine, sample, tmp_path):
         assert list(tsv.columns) == ["len", "max", "fit"] and len(tsv) == len(fd)
 
 
+def test_links_tsv_written_beside_other_calls(engine, synth, tmp_path):
+    """ldw_write_links_tsv_begin / _end: the table is fetched at _begin, so the file holds THAT table byte for byte whatever the context does
+    before _end (here: the short-range reductions, and a replacement of the table itself); a second _begin finishes the first; _end without
+    _begin reports nothing; an unwritable path is reported by _end."""
+    d = synth
+    _setup(engine, d)
+    engine.mi_all_pairs(orc.make_blocks(512, 1000), sr_dist=3000.0, lr_retain_links=1e6, lr_links_approx=1e5)
+    for which in (1, 0):
+        sync_p, async_p = tmp_path / f"sync{which}.tsv", tmp_path / f"async{which}.tsv"
+        rows, nbytes = engine.write_links_tsv(which, str(sync_p), append=False)
+        a, b, mi = engine.links(which)
+        engine.write_links_tsv_begin(which, str(async_p), append=False)
+        engine.sr_len_quantiles(3, 3000.0, 0.95)                      # GPU work of the same context meanwhile
+        engine.links_import(which, a[::-1].copy(), b[::-1].copy(), mi[::-1].copy())   # ... and the table itself replaced
+        assert engine.write_links_tsv_end() == (rows, nbytes)
+        assert async_p.read_bytes() == sync_p.read_bytes() and rows == len(mi) > 0
+        engine.links_import(which, a, b, mi)
+    assert engine.write_links_tsv_end() == (0, 0)
+    engine.write_links_tsv_begin(1, str(tmp_path / "first.tsv"), append=False)
+    engine.write_links_tsv_begin(1, str(tmp_path / "second.tsv"), append=False)     # finishes "first"
+    assert (tmp_path / "first.tsv").read_bytes() == (tmp_path / "sync1.tsv").read_bytes()
+    engine.write_links_tsv_end()
+    assert (tmp_path / "second.tsv").read_bytes() == (tmp_path / "sync1.tsv").read_bytes()
+    # append mode continues an existing file
+    (tmp_path / "app.tsv").write_text("header\n")
+    engine.write_links_tsv_begin(1, str(tmp_path / "app.tsv"), append=True)
+    engine.write_links_tsv_end()
+    assert (tmp_path / "app.tsv").read_bytes() == b"header\n" + (tmp_path / "sync1.tsv").read_bytes()
+    with pytest.raises(RuntimeError):
+        engine.write_links_tsv_begin(1, str(tmp_path / "no_such_dir" / "x.tsv"), append=False)
+        engine.write_links_tsv_end()
+
+
 @pytest.mark.parametrize("max_blk_sz", [10000, 1000])
 def test_device_sr_model_matches_host_model(engine, sample, tmp_path, max_blk_sz):
     """mergeNsort_sr_links + runARACNE on the device-resident link table (csrc/ldw_srp.hip) against the host mirror
