@@ -36,7 +36,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from ldweaver_amd.cpushare import cpu_share, limit_thread_pools  # noqa: E402  (before numpy: see the module)
 
-limit_thread_pools()
+# (one process per GPU: every rank of a node takes its part of the cgroup's CPU share)
+limit_thread_pools(max(1, cpu_share() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))))
 
 import numpy as np
 
