@@ -55,7 +55,19 @@ struct ApxGemmArgs {
     // the same for the wider tables: pruning flags (PF_*, ldw_epi.h) of every ROW of the two row lists, 0 for padding rows.  A tile
     // whose to-rows are all of one kind and dead versus the (one) kind of its from-rows, or the other way round, is not computed.
     const uint8_t *rflag_t, *rflag_f;
+    // r04 — failing pairs straight from the accumulators (long-range blocks with pair lists, not the diagonal ones): a table-eligible region
+    // with at most APX_MAYBE_MAX entries outside their thresholds appends those entries {to row, from row, n'} to `maybe` (capacity maybe_cap;
+    // *maybe_n counts, and may exceed the capacity: the consumer, k_screen_maybe, then forces the block's overflow path) and is flagged CLEAN:
+    // it is neither stored nor screened.  Null: such a region is stored and screened whole, as before.
+    struct ApxMaybe *maybe;
+    unsigned int *maybe_n;
+    unsigned int maybe_cap;
 };
+struct ApxMaybe {
+    uint32_t trow, fcol;   // row-list positions = column slot / from slot of the epilogue orders (biallelic rows: position == slot)
+    int32_t n;             // the approximate joint sum n'
+};
+constexpr int APX_MAYBE_MAX = 96;   // more failing entries than this in a region of 2048: storing the region is the cheaper path
 
 // (rowlist2 / Rpad2 / panel2: a second panel in the same launch)
 int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st, const int32_t *rowlist2 = nullptr, int Rpad2 = 0,

@@ -263,17 +263,63 @@ __device__ __forceinline__ void apx_gemm_epilogue(const ApxGemmArgs &P, v16i (&a
                 bt[e] = (int)s_bt[32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh];
                 ok = ok && bt[e] != 255;
             }
-            if (__ballot(!ok) == 0ull) {   // (a region with a row of another kind of SNP is stored without the 32 look-ups per lane)
+            unsigned int fails = 0;   // bit e * NT + j: entry outside its thresholds
+            const bool eligible = __ballot(!ok) == 0ull;
+            if (eligible) {   // (a region with a row of another kind of SNP is stored without the 32 look-ups per lane)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         const int2 th = s_tab[bt[e] * P.tab_nb + bf[j]];
                         const int n = acc[i][j][e];
-                        ok = ok && n > th.x && n < th.y;
+                        const bool in = n > th.x && n < th.y;
+                        ok = ok && in;
+                        if (!in) fails |= 1u << (e * NT + j);
                     }
             }
+            if (NT == 2 && P.maybe && eligible && __ballot(!ok) != 0ull) {
+                // r04: the few entries outside their thresholds go to the maybe list, the region counts as clean
+                const unsigned int mine = (unsigned int)__popc(fails);
+                unsigned int incl = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned int t = __shfl_up(incl, o);
+                    if (lane >= o) incl += t;
+                }
+                const unsigned int tot = (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
+                if (tot <= (unsigned int)APX_MAYBE_MAX) {
+                    unsigned int base = 0;
+                    if (lane == 0) base = atomicAdd(P.maybe_n, tot);
+                    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                    unsigned int pos = base + incl - mine;
+                    unsigned int f = fails;
+                    while (f) {
+                        const int b = __builtin_ctz(f);
+                        f &= f - 1;
+                        const int e = b / NT, j = b % NT;
+                        if (pos < P.maybe_cap) {
+                            ApxMaybe m;
+                            m.trow = (uint32_t)(ty * TH + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh);
+                            m.fcol = (uint32_t)(tx * TWd + 32 * j + frow);
+                            // (dynamic index into the accumulator tile: a select chain over the 32 candidates, only on this rare path)
+                            int v = 0;
+#pragma unroll
+                            for (int ee = 0; ee < 16; ++ee)
+#pragma unroll
+                                for (int jj = 0; jj < NT; ++jj) v = (ee == e && jj == j) ? acc[i][jj][ee] : v;
+                            m.n = v;
+                            P.maybe[pos] = m;
+                        }
+                        ++pos;
+                    }
+                    ok = true;   // handled: clean
+                }
+            }
+#ifdef LDW_ABLATE_GEMM_STORE   // timing ablation only (wrong results): what the G' stores of the table-eligible regions that are not clean cost
+            const bool clean = __ballot(bf[0] == 255 || bt[0] == 255) == 0ull || __ballot(!ok) == 0ull;
+#else
             const bool clean = __ballot(!ok) == 0ull;
+#endif
             if (lane == 0) {
 #pragma unroll
                 for (int h = 0; h < (NT * 32) / 64; ++h) P.clean[(int64_t)((ty * TH + 32 * i) / 32) * (P.RFpad / 64) + (tx * TWd) / 64 + h] = clean ? 1 : 0;

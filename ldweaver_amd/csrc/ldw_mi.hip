@@ -624,6 +624,51 @@ __device__ __forceinline__ void screen_wg(const EpiArgs &A, const int32_t *__res
 }
 
 
+// r04: the entries the GEMM's epilogue found outside their table thresholds (ApxGemmArgs::maybe): one lane per entry evaluates the full
+// bound of that ONE pair — what screen_cols_tab does for the columns of a region in which some lane fails the table test — and lists the
+// pair if it may reach the block's level.  Both SNPs are biallelic with r = 2 and fully flagged (their rows carry table bins), so a row-list
+// position is the epilogue slot: trow = column slot, fcol = 64 * from-tile + lane.  Not used for diagonal blocks or in verify mode.
+template <int RM>
+__global__ __launch_bounds__(256) void k_screen_maybe(EpiArgs A, const ApxMaybe *__restrict__ maybe, const unsigned int *__restrict__ maybe_n,
+                                                      unsigned int maybe_cap) {
+    const unsigned int n_all = *maybe_n;
+    if (n_all > maybe_cap) {   // the list overflowed: make the block take the pair lists' overflow path (k_pick_bucket sees the counter)
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(A.pl_n, A.pl_cap + 1u);
+        return;
+    }
+    const float lo = (float)A.E.spec_lo - A.E.scr_eps;
+    const bool test_sr = A.E.any_sr != 0 || A.sr_excl != 0;
+    for (unsigned int k = blockIdx.x * 256u + threadIdx.x; k < n_all; k += gridDim.x * 256u) {
+        const ApxMaybe e = maybe[k];
+        // (the _hi packs: integer marginals of the APPROXIMATE weights, the ones n' was summed with — what the screen's cells are derived from)
+        const ColMeta &M = A.colpack_hi[e.trow];
+        const RowPack &P = A.rowpack_hi[e.fcol];
+        const RowSide &R = P.R;
+        const int a_loc = P.a_loc, b_loc = M.bl;
+        if (a_loc < 0 || a_loc == b_loc) continue;                       // (padding slot; quirk Q3: an off-diagonal block drops its own diagonal)
+        if (test_sr && col_is_sr(M.ci, a_loc)) continue;                 // (cannot happen: tiles with a short-range pair are never table-tested)
+        FullCells32<1, 1> C;
+        const int v = e.n;
+        C.n[0][0] = v;
+        C.n[1][0] = (int)M.pb[0] - v;
+        C.n[0][1] = (int)R.pa[0] - v;
+        C.n[1][1] = (int)R.pa[1] - C.n[1][0];
+        const float ms = full_cells_screen<1, 1, true>(A, R, M, screen_rxy(A, R, M, a_loc, b_loc, RM), C);
+        if (!(ms >= lo)) continue;
+        const int sub = (int)((e.fcol >> 6) & (PAIR_SHARDS - 1));        // path 0 (1 x 1 indicator rows), sharded by from-tile like append_pairs
+        const unsigned int pos = atomicAdd(A.pl_n + sub, 1u);
+        if (pos < A.pl_cap) {
+            const int32_t r0a = A.row0[R.sa], r0b = A.row0[M.sb];
+            PairEnt pe;
+            pe.t = e.fcol;
+            pe.q = e.trow;
+            pe.ra = (uint32_t)r0a | ((uint32_t)(A.row0[R.sa + 1] - r0a) << 29);
+            pe.rb = (uint32_t)r0b | ((uint32_t)(A.row0[M.sb + 1] - r0b) << 29);
+            A.pl_pairs[(int64_t)sub * A.pl_cap + pos] = pe;
+        }
+    }
+}
+
 // the whole grid: one workgroup per (from-tile, column group)
 template <int RM, bool APX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LDW_SCREEN_WAVES, 8))) void k_mi_screen(EpiArgs A, const int32_t *__restrict__ perm_f,
@@ -1976,6 +2021,8 @@ inline uint32_t pair_cap_for(int64_t nf, int64_t nt, int nseg = 0) {
     while (cap < want && cap < top) cap <<= 1;
     return (uint32_t)cap;
 }
+// entries of the maybe list of a block (ApxGemmArgs::maybe): one pair in a few thousand fails its table thresholds
+inline uint32_t maybe_cap_for(int64_t nf, int64_t nt) { return (uint32_t)std::min<int64_t>(nf * nt / 256 + 65536, (int64_t)1 << 26); }
 int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E,
                     hipEvent_t *ev, int which, ldw::DevBuf *Gb, hipStream_t gstream, unsigned long long *ghist,
                     const LoHost *mixed = nullptr) {
@@ -2185,7 +2232,9 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         if (int rc = B_units.reserve(o_flat + 2 * n_units_max * 8 + 64)) return rc;
         if (int rc = B_packs.reserve(o_rt + (size_t)nt * 4 + 256)) return rc;
         if (use_pairs)
-            if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * pair_cap_for(nf, nt, lo_h->span) * sizeof(PairEnt))) return rc;
+            if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * pair_cap_for(nf, nt, lo_h->span) * sizeof(PairEnt) +
+                                             (size_t)maybe_cap_for(nf, nt) * sizeof(ApxMaybe) + 64))
+                return rc;
         if (need_exact)
             if (int rc = Gx.reserve((size_t)RFpad * RTpad * 8)) return rc;
         if (int rc = B_bins.reserve(2 * ((size_t)RTpad + (size_t)RFpad) + (size_t)nt + (size_t)nf_slots + 256 + (size_t)(RTpad / 128) * (size_t)(RFpad / 64) * 4)) return rc;
@@ -2269,6 +2318,13 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         A.pl_pairs = reinterpret_cast<PairEnt *>(c->pairs[s].as<char>() + o_pairs);
         A.pl_cap = pair_cap_for(nf, nt, lo_h->span);
     }
+    // r04: table-eligible regions with a few failing entries hand those entries over instead of being stored and screened (k_screen_maybe);
+    // the counter lives in the zeroed header of the pair lists, the entries behind the lists
+    static const bool maybe_on = getenv("LDW_NO_MAYBE") == nullptr;
+    const bool use_maybe = maybe_on && fuse && use_pairs && c->screen == 1 && !E.lower_only;
+    unsigned int *maybe_n = use_maybe ? c->pairs[s].as<unsigned int>() + 48 : nullptr;
+    const unsigned int maybe_cap = maybe_cap_for(nf, nt);
+    ApxMaybe *maybe_list = use_maybe ? reinterpret_cast<ApxMaybe *>(c->pairs[s].as<char>() + o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * A.pl_cap * sizeof(PairEnt)) : nullptr;
     if (phase == 1) {
         if (E.do_lr) {
             if (int rc = launch_pack_panel(c, D.rl_f, RFpad, c->panel[s][0].as<uint64_t>(), gs, lo_h->diag ? nullptr : D.rl_t, RTpad,
@@ -2336,6 +2392,11 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
                 P.tab_nb = A.tab_nb;
                 P.clean = c->apx_clean[s].as<uint8_t>();
                 P.sr_mask = E.any_sr ? D.band_mask : nullptr;   // a block with a short-range corner: its band tiles stay with the screen
+                if (use_maybe) {
+                    P.maybe = maybe_list;
+                    P.maybe_n = maybe_n;
+                    P.maybe_cap = maybe_cap;
+                }
             }
             if (P.skip_ctr)
                 if (int rc = launch_apx_live_tiles(c, P, gs)) return rc;
@@ -2389,6 +2450,13 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             else if (rm_s == 1) LDW_SCREEN(1, gs);
             else if (rm_s == 3) LDW_SCREEN(3, gs);
             else LDW_SCREEN(2, gs);
+            LDW_HIP(hipGetLastError());
+        }
+        if (use_maybe && E.do_lr) {
+            if (rm_s == 0) hipLaunchKernelGGL((k_screen_maybe<0>), dim3(512), dim3(256), 0, gs, A, maybe_list, maybe_n, maybe_cap);
+            else if (rm_s == 1) hipLaunchKernelGGL((k_screen_maybe<1>), dim3(512), dim3(256), 0, gs, A, maybe_list, maybe_n, maybe_cap);
+            else if (rm_s == 3) hipLaunchKernelGGL((k_screen_maybe<3>), dim3(512), dim3(256), 0, gs, A, maybe_list, maybe_n, maybe_cap);
+            else hipLaunchKernelGGL((k_screen_maybe<2>), dim3(512), dim3(256), 0, gs, A, maybe_list, maybe_n, maybe_cap);
             LDW_HIP(hipGetLastError());
         }
         LDW_HIP(hipEventRecord(ev[5], gs));
@@ -3903,7 +3971,7 @@ int reserve_slot_buffers(ldw_ctx *c, int64_t Npad, int64_t blk, int64_t nseg) {
         if (int rc = c->Gapx[s].reserve(RF * RT * 4)) return rc;
         if (int rc = c->apx_units[s].reserve(64 + 2 * n_units * 8 + 64)) return rc;
         if (int rc = c->apx_packs[s].reserve(2 * o_cph + 2 * o_rph + ((size_t)blk + (size_t)nt) * 4 + 1024)) return rc;
-        if (int rc = c->pairs[s].reserve(256 + (size_t)PAIR_PATHS * PAIR_SHARDS * cap * sizeof(PairEnt))) return rc;
+        if (int rc = c->pairs[s].reserve(256 + (size_t)PAIR_PATHS * PAIR_SHARDS * cap * sizeof(PairEnt) + (size_t)maybe_cap_for(blk, nt) * sizeof(ApxMaybe) + 64)) return rc;
         if (int rc = c->apx_bins[s].reserve(2 * (RT + RF) + (size_t)nt + nf_slots + 256 + (RT / 128) * (RF / 64) * 4)) return rc;
         if (int rc = c->apx_clean[s].reserve((RT / 32) * (RF / 64) + 64)) return rc;
         if (int rc = c->hist[s].reserve((size_t)nseg * NBINS * 8)) return rc;

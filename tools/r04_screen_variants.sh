@@ -12,7 +12,7 @@ for spec in "$@"; do
     unset LDW_AMD_LIB
   fi
   bash tools/prof_run.sh var_$name --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --no-overlap > /dev/null 2>&1
-  echo "== $name ($flags)"; grep -E "k_mi_screen<" gpurun_out/var_${name}_kernel_stats.csv
+  echo "== $name ($flags)"; grep -E "k_mi_screen<|gemm_apx" gpurun_out/var_${name}_kernel_stats.csv
   timeout -k 10 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-legs 2>/dev/null | python -c "import sys,json; j=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print('ms_per_step', round(j['ms_per_step'],2), 'misses', j['spec_misses'], j['links'], 'pairs', j['counters']['apx_pairs_listed'])"
   [ -n "$flags" ] && rm -rf $dir
 done
