@@ -190,6 +190,9 @@ __device__ __forceinline__ unsigned int screen_cols(const EpiArgs &A, const RowS
     return bits;
 }
 
+#ifdef LDW_SCREEN_STATS
+__device__ unsigned long long g_scr_stats[16];
+#endif
 // r04: the same columns on the approximate path with pair lists, for blocks whose entries are never read transposed (all but the diagonal
 // ones).  Measured (LDW_SCREEN_EXP, profiles/r04_screen_breakdown.txt): 73 % of a span's screen is this multi-cell evaluation, and its waves
 // spend 73 % of their cycles waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES) with the VALU at 45 %: two columns' entries in flight per wave were too
@@ -249,6 +252,49 @@ __device__ __forceinline__ unsigned int screen_cols_apx(const EpiArgs &A, const 
             ms = (float)(C.n[NA][NB] ^ C.n[0][0]) * 1e-30f + rxy * 1e-30f;
 #else
             ms = full_cells_screen<NA, NB, true>(A, R, M, (double)rxy, C);
+#endif
+#ifdef LDW_SCREEN_STATS   // measurement build only: how often would a cheaper first-level bound let a pair / a (wave, column) through?
+            {
+                const float ra = (float)R.ra, rb = (float)M.rb, den = (float)A.neff + (ra * rb) * 0.5f, Lden = __builtin_amdgcn_logf(den);
+                float S = 0.0f, SA = 0.0f, xs = 0.0f, SC = 0.0f;
+#pragma unroll
+                for (int i = 0; i <= NA; ++i)
+#pragma unroll
+                    for (int j = 0; j <= NB; ++j) {
+                        const int nn = C.n[i][j];
+                        const float x = fmaf((float)(nn < 0 ? 0 : nn), A.E.scr_scale, 0.5f);
+                        const float dl = (R.pXf[i] + 1.0f) * (M.pYf[j] + 1.0f);
+                        const float l = __builtin_amdgcn_logf(x) + Lden - __builtin_amdgcn_logf(dl);
+                        S = fmaf(x, l, S);
+                        SA = fmaf(x, fabsf(l), SA);
+                        xs += x;
+                        SC += x * x * den * __builtin_amdgcn_rcpf(dl) - x;
+                    }
+                const float EG = A.E.apx_EG;
+                const float lost_units = (float)(NA * NB) * EG + (float)NA * fmaxf(1.0f, (float)NB * EG) + (float)NB * fmaxf(1.0f, (float)NA * EG) +
+                                         fmaxf((float)NB, 1.0f + (float)(NA * NB) * EG);
+                int64_t ta = 0;
+#pragma unroll
+                for (int i = 0; i <= NA; ++i) ta += R.pa[i];
+                const float dW = (float)(A.E.apx_W - (double)ta * A.E.apx_unit) + 4e-6f * (float)A.E.apx_W;
+                const float ex = A.E.apx_dfac * fmaf(SA + 2.65f * xs, 0.6931471805599453f, A.E.apx_c1 * xs) + lost_units * A.E.apx_s1 + dW;
+                const float U1 = fmaf(S, 0.6931471805599453f, ex) * __builtin_amdgcn_rcpf(den), U2 = (SC + ex) * __builtin_amdgcn_rcpf(den);
+                const bool actl = a_ok && a_loc != M.bl;
+                const unsigned long long b0 = __ballot(actl), b1 = __ballot(actl && ms >= lo), b2 = __ballot(actl && U1 >= lo), b3 = __ballot(actl && U2 >= lo),
+                                         v1 = __ballot(actl && U1 < ms), v2 = __ballot(actl && U2 < ms);
+                if ((threadIdx.x & 63) == 0) {
+                    atomicAdd(&g_scr_stats[0], (unsigned long long)__popcll(b0));
+                    atomicAdd(&g_scr_stats[1], (unsigned long long)__popcll(b1));
+                    atomicAdd(&g_scr_stats[2], (unsigned long long)__popcll(b2));
+                    atomicAdd(&g_scr_stats[3], (unsigned long long)__popcll(b3));
+                    atomicAdd(&g_scr_stats[4], 1ull);
+                    atomicAdd(&g_scr_stats[5], b1 ? 1ull : 0ull);
+                    atomicAdd(&g_scr_stats[6], b2 ? 1ull : 0ull);
+                    atomicAdd(&g_scr_stats[7], b3 ? 1ull : 0ull);
+                    atomicAdd(&g_scr_stats[8], (unsigned long long)__popcll(v1));
+                    atomicAdd(&g_scr_stats[9], (unsigned long long)__popcll(v2));
+                }
+            }
 #endif
         }
         const bool act = a_ok && (A.E.lower_only ? a_loc > b_loc : a_loc != b_loc);
@@ -4707,6 +4753,12 @@ int ldw_links_device_ptrs(ldw_ctx *c, int which, const int32_t **a_out, const in
     return LDW_OK;
 }
 
+#ifdef LDW_SCREEN_STATS
+int ldw_debug_screen_stats(unsigned long long *out16) {   // (measurement build only; not in the header)
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ldw::g_scr_stats), 16 * 8) != hipSuccess) return LDW_ERR_HIP;
+    return LDW_OK;
+}
+#endif
 int ldw_links_fetch(ldw_ctx *c, int which, int32_t *a_out, int32_t *b_out, double *MI_out, int64_t capacity,
                     int on_device) {
     if (int rc = check_gpu(c)) return rc;
