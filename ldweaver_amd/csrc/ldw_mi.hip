@@ -678,8 +678,9 @@ template <int RM>
 __global__ __launch_bounds__(256) void k_screen_maybe(EpiArgs A, const ApxMaybe *__restrict__ maybe, const unsigned int *__restrict__ maybe_n,
                                                       unsigned int maybe_cap) {
     const unsigned int n_all = *maybe_n;
-    if (n_all > maybe_cap) {   // the list overflowed: make the block take the pair lists' overflow path (k_pick_bucket sees the counter)
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(A.pl_n, A.pl_cap + 1u);
+    if (n_all > maybe_cap) {   // the list overflowed: the block takes the pair lists' overflow path — through a word of its own behind the 40 list
+        // counters, which k_pick_bucket reads with them (bumping a real counter would make its consumers read entries that were never written)
+        if (blockIdx.x == 0 && threadIdx.x == 0) A.pl_n[PAIR_PATHS * PAIR_SHARDS] = 0xFFFFFFFFu;
         return;
     }
     const float lo = (float)A.E.spec_lo - A.E.scr_eps;
@@ -1324,7 +1325,7 @@ __device__ __forceinline__ void pick_bucket_body(const unsigned long long *__res
                 // a pair list of the approximate path that overflowed lost candidates: treat like a guess that was too high
                 bool over = false;
                 if (pl_n)
-                    for (int i = 0; i < PAIR_PATHS * PAIR_SHARDS; ++i) over = over || pl_n[i] > pl_cap;
+                    for (int i = 0; i <= PAIR_PATHS * PAIR_SHARDS; ++i) over = over || pl_n[i] > pl_cap;   // (word 40: the maybe list's overflow, k_screen_maybe)
                 out->spec_ok = over ? 0 : 1;
             }
             cum += loc[k];
@@ -2068,7 +2069,13 @@ inline uint32_t pair_cap_for(int64_t nf, int64_t nt, int nseg = 0) {
     return (uint32_t)cap;
 }
 // entries of the maybe list of a block (ApxGemmArgs::maybe): one pair in a few thousand fails its table thresholds
-inline uint32_t maybe_cap_for(int64_t nf, int64_t nt) { return (uint32_t)std::min<int64_t>(nf * nt / 256 + 65536, (int64_t)1 << 26); }
+inline uint32_t maybe_cap_for(int64_t nf, int64_t nt) {
+    if (const char *e = getenv("LDW_MAYBE_CAP")) {   // (tests: a list that overflows makes its block take the pair lists' overflow path)
+        const long k = atol(e);
+        if (k > 0) return (uint32_t)k;
+    }
+    return (uint32_t)std::min<int64_t>(nf * nt / 256 + 65536, (int64_t)1 << 26);
+}
 int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E,
                     hipEvent_t *ev, int which, ldw::DevBuf *Gb, hipStream_t gstream, unsigned long long *ghist,
                     const LoHost *mixed = nullptr) {
@@ -2366,7 +2373,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     }
     // r04: table-eligible regions with a few failing entries hand those entries over instead of being stored and screened (k_screen_maybe);
     // the counter lives in the zeroed header of the pair lists, the entries behind the lists
-    static const bool maybe_on = getenv("LDW_NO_MAYBE") == nullptr;
+    const bool maybe_on = getenv("LDW_NO_MAYBE") == nullptr;   // (read per call: the tests switch it)
     const bool use_maybe = maybe_on && fuse && use_pairs && c->screen == 1 && !E.lower_only;
     unsigned int *maybe_n = use_maybe ? c->pairs[s].as<unsigned int>() + 48 : nullptr;
     const unsigned int maybe_cap = maybe_cap_for(nf, nt);

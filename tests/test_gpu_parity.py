@@ -1903,10 +1903,29 @@ def test_spans_equal_block_by_block(engine):
         c1, s1 = engine.counters(), engine.span_report()
         Engine.set_pair_cap(0)
         assert s1["redone"] - s0["redone"] >= 10 and c1["spec_misses"] - c0["spec_misses"] >= 20, (s0, s1, c0, c1)
+        # r04, the maybe list (entries outside their table thresholds, handed over by the GEMM's epilogue): the same tables without it, and a
+        # list of 16 entries overflows -> its block takes the pair lists' overflow path
+        import os
+        os.environ["LDW_NO_MAYBE"] = "1"
+        try:
+            no_maybe = run(L.QUIRK_REFERENCE, True)
+        finally:
+            os.environ.pop("LDW_NO_MAYBE")
+        os.environ["LDW_MAYBE_CAP"] = "16"
+        try:
+            c0 = engine.counters()
+            tiny = run(L.QUIRK_REFERENCE, True)
+            c1 = engine.counters()
+        finally:
+            os.environ.pop("LDW_MAYBE_CAP")
+        assert c1["spec_misses"] - c0["spec_misses"] >= 10, (c0, c1)
         engine.set_mixed(False)
         engine.set_screen(0)
         engine.set_path(1)
-        same(run(L.QUIRK_REFERENCE, True), over, "pair-list overflow")
+        plain_ref = run(L.QUIRK_REFERENCE, True)
+        same(plain_ref, over, "pair-list overflow")
+        same(plain_ref, no_maybe, "without the maybe list")
+        same(plain_ref, tiny, "maybe-list overflow")
     finally:
         Engine.set_pair_cap(0)
         engine.set_span(True, 8)
