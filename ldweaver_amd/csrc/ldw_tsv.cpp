@@ -206,8 +206,14 @@ HostPool &host_pool() {
 }
 struct PoolBlock {
     void *p = nullptr;
-    explicit PoolBlock(size_t bytes) : p(host_pool().get(bytes)) {}
-    ~PoolBlock() { host_pool().put(p); }
+    bool pooled = true;
+    // (blocks beyond 256 MB — the full short-range table of a 500k-SNP alignment would need 72 GB — are ordinary allocations: kept they would
+    // pin that memory for the life of the process; the stall they may cost the next GPU call is the lesser evil there)
+    explicit PoolBlock(size_t bytes) : pooled(bytes <= ((size_t)256 << 20)) { p = pooled ? host_pool().get(bytes) : malloc(bytes); }
+    ~PoolBlock() {
+        if (pooled) host_pool().put(p);
+        else free(p);
+    }
     PoolBlock(const PoolBlock &) = delete;
     PoolBlock &operator=(const PoolBlock &) = delete;
     template <class T> T *as() const { return static_cast<T *>(p); }
