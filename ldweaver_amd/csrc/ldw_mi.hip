@@ -644,6 +644,10 @@ __device__ __forceinline__ void screen_wg(const EpiArgs &A, const int32_t *__res
 #pragma unroll
                     for (int u = 0; u < U; ++u) tab_ok = tab_ok && cmu[u].rb == 2.0;
                 }
+#ifdef LDW_SCREEN_EXP   // timing ablation only (wrong results; profiles/r04_screen_breakdown.txt): bit 0 skips the table path, bit 1 the multi-cell path
+                if ((tab_ok && ((LDW_SCREEN_EXP) & 1)) || (!tab_ok && ((LDW_SCREEN_EXP) & 2))) b = 0;
+                else
+#endif
                 if (tab_ok) b = screen_cols_tab<U, RM>(A, R, binA, cmu, a_loc, a_ok, lo, q_base + it, tile);
                 else
                     b = na0 == 1 ? screen_cols_nb<1, U, RM, APX>((int)(mb0 & 7), A, R, cmu, a_loc, a_ok, lo, q_base + it, tile)
