@@ -232,3 +232,16 @@ def test_positions_to_snp_index_any_order():
     assert positions_to_snp_index(dup, np.array([5, 7])).tolist() == [0, 3]          # first holder of a repeated position
     with pytest.raises(ValueError):
         positions_to_snp_index(POS, np.array([11]))
+
+
+def test_cpu_share_and_thread_pool_limits(monkeypatch):
+    """cpushare: the CPUs the cgroup / affinity mask grants (never more than the visible count), and environment defaults that leave the
+    user's own settings alone."""
+    import os
+    from ldweaver_amd.cpushare import cpu_share, limit_thread_pools
+    n = cpu_share()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+    monkeypatch.setenv("OPENBLAS_NUM_THREADS", "3")
+    assert limit_thread_pools(5) == 5
+    assert os.environ["OMP_NUM_THREADS"] == "5" and os.environ["OPENBLAS_NUM_THREADS"] == "3"
