@@ -2378,7 +2378,10 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     // r04: table-eligible regions with a few failing entries hand those entries over instead of being stored and screened (k_screen_maybe);
     // the counter lives in the zeroed header of the pair lists, the entries behind the lists
     const bool maybe_on = getenv("LDW_NO_MAYBE") == nullptr;   // (read per call: the tests switch it)
-    const bool use_maybe = maybe_on && fuse && use_pairs && c->screen == 1 && !E.lower_only;
+    // (only where the K loop is long enough to carry the epilogue's extra work — the mask of the failing entries is built for every eligible
+    // region: at N = 616 the GEMM's launch went from 0.091 to 0.107 ms and the pass from 19.4 to 20.1 ms with it, at N = 5000 the launch does
+    // not move and the pass gains 0.3-0.4 ms; building the mask only in failing regions was slower at both sizes)
+    const bool use_maybe = maybe_on && fuse && use_pairs && c->screen == 1 && !E.lower_only && c->KW >= 32;
     unsigned int *maybe_n = use_maybe ? c->pairs[s].as<unsigned int>() + 48 : nullptr;
     const unsigned int maybe_cap = maybe_cap_for(nf, nt);
     ApxMaybe *maybe_list = use_maybe ? reinterpret_cast<ApxMaybe *>(c->pairs[s].as<char>() + o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * A.pl_cap * sizeof(PairEnt)) : nullptr;
