@@ -337,6 +337,9 @@ struct ColMeta {
     int64_t pb[5];
     float pYf[5];
     int32_t pad2;
+#ifdef LDW_COLMETA_PAD   // measurement only: how sensitive are the screens to the size of the staged column?
+    char padx[LDW_COLMETA_PAD];
+#endif
     ColInfo ci;
 };
 
