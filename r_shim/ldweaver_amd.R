@@ -55,9 +55,13 @@ perform_MI_computation <- function(snp.dat, hdw, cds_var, ncores, lr_save_path =
   }
   # lr_links.tsv (:362): options(ldwamd.native_tsv = TRUE) writes it from the device table with the library's threaded writer
   # (same bytes as write.table, 1e6 rows in ~0.3 s instead of seconds); the default is R's own write.table
+  native_lr <- FALSE
   if (!perform_SR_analysis_only && length(res[[2]][[3]]) > 0) {
-    if (isTRUE(getOption("ldwamd.native_tsv", FALSE))) .Call("ldwamd_write_links_tsv", 1L, lr_save_path)
-    else write.table(to_df(res[[2]]), file = lr_save_path, append = T, quote = F, row.names = F, col.names = F, sep = "\t")
+    if (isTRUE(getOption("ldwamd.native_tsv", FALSE))) {
+      .Call("ldwamd_write_links_tsv_begin", 1L, lr_save_path)   # r04: written by host threads while mergeNsort_sr_links runs below
+      native_lr <- TRUE
+      on.exit(if (native_lr) try(.Call("ldwamd_write_links_tsv_end"), silent = TRUE), add = TRUE)   # (an error below must not leave the writer unjoined)
+    } else write.table(to_df(res[[2]]), file = lr_save_path, append = T, quote = F, row.names = F, col.names = F, sep = "\t")
   }
   sr <- to_df(res[[1]])
   sr_links <- lapply(1:cds_var$nclust, function(i) sr[sr$clust1 == i | sr$clust2 == i, ])
@@ -65,6 +69,7 @@ perform_MI_computation <- function(snp.dat, hdw, cds_var, ncores, lr_save_path =
                                       srp_cutoff = srp_cutoff)                # reference's own function, unchanged
   sr_links_red <- sr_links_all$sr_links_red
   chk <- sr_links_all$sr_links_ARACNE_check
+  if (native_lr) { .Call("ldwamd_write_links_tsv_end"); native_lr <- FALSE }                # lr_links.tsv is complete from here on
   if (runARACNE) {
     sr_links_red$ARACNE <- as.numeric(.Call("ldwamd_aracne", sr_links_red$pos1, sr_links_red$pos2, sr_links_red$MI,
                                             chk$pos1, chk$pos2, chk$MI))

@@ -290,6 +290,18 @@ SEXP ldwamd_write_links_tsv(SEXP which, SEXP path) {
     return ScalarReal((double)rows);
 }
 
+/* r04: the same table written BESIDE the next calls — _begin fetches it from the device and returns, host threads format and write it while
+ * R runs mergeNsort_sr_links (which does not touch the long-range table: R/computePairwiseMI.R:119-126); _end waits, returns the rows written */
+SEXP ldwamd_write_links_tsv_begin(SEXP which, SEXP path) {
+    CHK(ldw_write_links_tsv_begin(ctx_or_stop(), asInteger(which), CHAR(STRING_ELT(path, 0)), 1, 0));
+    return R_NilValue;
+}
+SEXP ldwamd_write_links_tsv_end(void) {
+    int64_t rows = 0, bytes = 0;
+    CHK(ldw_write_links_tsv_end(ctx_or_stop(), &rows, &bytes));
+    return ScalarReal((double)rows);
+}
+
 /* any numeric data.frame's columns (INTSXP / REALSXP / LGLSXP-as-int) by the same writer; cols: a list of equally long vectors */
 SEXP ldwamd_write_table_tsv(SEXP cols, SEXP path) {
     const int nc = (int)XLENGTH(cols);
@@ -331,6 +343,8 @@ static const R_CallMethodDef CallEntries[] = {
     {"ldwamd_mi_all_pairs", (DL_FUNC)&ldwamd_mi_all_pairs, 6},
     {"ldwamd_aracne", (DL_FUNC)&ldwamd_aracne, 6},
     {"ldwamd_write_links_tsv", (DL_FUNC)&ldwamd_write_links_tsv, 2},
+    {"ldwamd_write_links_tsv_begin", (DL_FUNC)&ldwamd_write_links_tsv_begin, 2},
+    {"ldwamd_write_links_tsv_end", (DL_FUNC)&ldwamd_write_links_tsv_end, 0},
     {"ldwamd_write_table_tsv", (DL_FUNC)&ldwamd_write_table_tsv, 2},
     {NULL, NULL, 0}};
 
