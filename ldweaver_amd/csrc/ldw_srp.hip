@@ -45,8 +45,18 @@ struct RowTag {
 __device__ __forceinline__ RowTag row_tag(int32_t a, int32_t b, const int32_t *__restrict__ POS,
                                           const int32_t *__restrict__ paint, double g, double sr_dist) {
     RowTag t;
-    const double len = circ_len((double)POS[b], (double)POS[a], g);
-    t.len = (len > 0.0 && len < sr_dist) ? (int)len : 0;
+    const int64_t gi = (int64_t)g;
+    if ((double)gi == g && gi > 0) {
+        // integral genome length (the rule: ldw_sr_len_quantiles requires it): POS are integers, so circ_len's 0.5 g - |d - 0.5 g| is min(d, g - d)
+        // exactly — no fp64 division per row (r04: k_sr_stats / k_sr_pval stream 2.25e9 rows at C5)
+        int64_t d = ((int64_t)POS[b] - (int64_t)POS[a]) % gi;
+        if (d < 0) d += gi;
+        const int64_t len = d < gi - d ? d : gi - d;
+        t.len = (len > 0 && (double)len < sr_dist) ? (int)len : 0;
+    } else {
+        const double len = circ_len((double)POS[b], (double)POS[a], g);
+        t.len = (len > 0.0 && len < sr_dist) ? (int)len : 0;
+    }
     t.c1 = paint[b];
     t.c2 = paint[a];
     return t;
