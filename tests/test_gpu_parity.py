@@ -440,6 +440,14 @@ def test_device_sr_model_matches_host_model(engine, sample, tmp_path, max_blk_sz
         want = [len(x), x.sum(), (x * x).sum(), np.log(x).sum(), np.log1p(-x).sum()]
         np.testing.assert_allclose(stats[ci - 1], want, rtol=1e-12)
     assert np.array_equal(stats, engine.sr_excess_stats(md))     # fixed reduction order: bit-identical on a re-run
+    import os
+    os.environ["LDW_SR_STATS_PEEL"] = "1"                        # the kernel for any cluster count (per-wave peeling): the same sums in another order
+    try:
+        peel = engine.sr_excess_stats(md)
+        assert np.array_equal(peel, engine.sr_excess_stats(md))
+    finally:
+        os.environ.pop("LDW_SR_STATS_PEEL")
+    np.testing.assert_allclose(peel, stats, rtol=1e-12)
 
 
 def _np_len_quantiles(a, b, mi, POS, paint, g, sr_dist, nclust, prob):
