@@ -448,6 +448,26 @@ def test_device_sr_model_matches_host_model(engine, sample, tmp_path, max_blk_sz
     finally:
         os.environ.pop("LDW_SR_STATS_PEEL")
     np.testing.assert_allclose(peel, stats, rtol=1e-12)
+    # p-values: rows below their cluster's crossing of the cut-off are dropped without the continued fraction (r04) — the same reduced set as
+    # with every positive excess evaluated (LDW_SR_PVAL_ALL=1), for cut-offs on both sides of the tail's range
+    shape = np.array([[0.35, 40.0, 0.0], [0.4, 60.0, 0.0], [0.3, 25.0, 0.0]])
+    for k in range(3):
+        shape[k, 2] = srp_host._betaln(shape[k, 0], shape[k, 1])
+    for cut in (3.0, 0.5, 40.0, -1.0):
+        got = engine.sr_pvalues(md, shape, cut)
+        red = engine.sr_reduced()
+        os.environ["LDW_SR_PVAL_ALL"] = "1"
+        try:
+            want = engine.sr_pvalues(md, shape, cut)
+            red0 = engine.sr_reduced()
+        finally:
+            os.environ.pop("LDW_SR_PVAL_ALL")
+        assert got[:2] == want[:2] and (got[2] == want[2] or (np.isnan(got[2]) and np.isnan(want[2]))), (cut, got, want)
+        o, o0 = np.argsort(red["row"]), np.argsort(red0["row"])
+        for kk in red:
+            assert np.array_equal(np.asarray(red[kk])[o], np.asarray(red0[kk])[o0]), (cut, kk)
+        if cut == 3.0:
+            assert 0 < got[0] < len(mi)
 
 
 def _np_len_quantiles(a, b, mi, POS, paint, g, sr_dist, nclust, prob):
