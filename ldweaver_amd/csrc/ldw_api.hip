@@ -1,5 +1,6 @@
 // Context, residency, set-up kernels and the small element-wise twins of libldweaver_amd.so.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -877,8 +878,50 @@ __global__ __launch_bounds__(256) void k_snp_sup(int64_t L, const uint32_t *__re
     for (int k = 0; k < 4; ++k) sup[a * 4 + k] = out[k];
 }
 
+// Marginals of the high-limb weights, by slot, for the screen of the MIXED-precision path — made when a block first takes that path (r04: the
+// default path never does, and building them eagerly cost 2.5 ms of every job's ldw_set_snp_meta).
+int ensure_hi_marginals(ldw_ctx *c) {
+    if (c->hi_ready || c->nlimbs != 5) return LDW_OK;
+    const int64_t L = c->L, Npad = c->Npad;
+    const std::vector<uint32_t> &meta = c->h_slot_meta;
+    LDW_REQUIRE((int64_t)meta.size() == L, LDW_ERR_STATE, "ensure_hi_marginals: the row map has not been built");
+    {
+        ldw::DevBuf d_vhi, d_phi, d_cnt2;
+        int rc = LDW_OK;
+        if ((rc = d_vhi.reserve((size_t)Npad * 8)) || (rc = d_phi.reserve((size_t)L * 40)) || (rc = d_cnt2.reserve((size_t)L * 20)) ||
+            (rc = c->slot_pfix_hi.reserve((size_t)L * 40))) {
+            d_vhi.release(); d_phi.release(); d_cnt2.release();
+            return rc;
+        }
+        hipError_t he = hipMemcpyAsync(d_vhi.p, c->h_vfixed_hi.data(), (size_t)Npad * 8, hipMemcpyHostToDevice, c->stream);
+        hipLaunchKernelGGL(k_counts_marginals, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, c->stream, c->states.as<uint8_t>(), L, Npad,
+                           d_vhi.as<int64_t>(), d_cnt2.as<int32_t>(), d_phi.as<int64_t>());
+        std::vector<int64_t> phs((size_t)L * 5), sph((size_t)L * 5, 0);
+        if (he == hipSuccess) he = hipMemcpyAsync(phs.data(), d_phi.p, (size_t)L * 40, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        d_vhi.release(); d_phi.release(); d_cnt2.release();
+        if (he != hipSuccess) return ldw::hip_fail(he, "high-limb marginals", __FILE__, __LINE__);
+        for (int64_t a = 0; a < L; ++a) {
+            const uint32_t m = meta[a];
+            const int n = (int)(m & 7);
+            for (int i = 0; i <= n; ++i) sph[a * 5 + i] = phs[a * 5 + ((m >> (8 + 3 * i)) & 7)];
+        }
+        LDW_HIP(hipMemcpyAsync(c->slot_pfix_hi.p, sph.data(), (size_t)L * 40, hipMemcpyHostToDevice, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+    }
+    c->hi_ready = true;
+    return LDW_OK;
+}
+
 int ensure_rows(ldw_ctx *c) {
     if (c->rows_ready) return LDW_OK;
+    static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
+    const auto t_rows0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!host_timing) return;
+        (void)hipStreamSynchronize(c->stream);
+        fprintf(stderr, "[ldw] ensure_rows: %.2f ms at %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rows0).count(), what);
+    };
     LDW_REQUIRE(c->L > 0 && c->have_weights && c->have_meta, LDW_ERR_STATE,
                 "MI needs the alignment, the weights and the SNP meta data to be set first");
     const int64_t L = c->L, Npad = c->Npad;
@@ -896,6 +939,7 @@ int ensure_rows(ldw_ctx *c) {
     LDW_HIP(hipMemcpyAsync(pfs.data(), d_pfix_state, (size_t)L * 40, hipMemcpyDeviceToHost, c->stream));
     LDW_HIP(hipMemcpyAsync(uqe.data(), c->uqe.p, (size_t)L * 5, hipMemcpyDeviceToHost, c->stream));
     LDW_HIP(hipStreamSynchronize(c->stream));
+    lap("counts + exact marginals fetched");
 
     // Slots of SNP a: one per state that is present (count > 0) or flagged in uqe.  The most frequent
     // present state is the "drop" slot: it gets no indicator row, its joint cells follow from the
@@ -943,6 +987,7 @@ int ensure_rows(ldw_ctx *c) {
         c->h_span_bad[(size_t)a + 1] = c->h_span_bad[(size_t)a] + (bad ? 1 : 0);
     }
     const int64_t R = c->R;
+    lap("slot maps built on the host");
     if (int rc = c->row0.reserve((size_t)(L + 1) * 4)) return rc;
     if (int rc = c->slot_meta.reserve((size_t)L * 4)) return rc;
     if (int rc = c->Mbits.reserve((size_t)(R + TILE) * c->KW * 8)) return rc;
@@ -950,30 +995,7 @@ int ensure_rows(ldw_ctx *c) {
     LDW_HIP(hipMemcpyAsync(c->row0.p, c->h_row0.data(), (size_t)(L + 1) * 4, hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipMemcpyAsync(c->slot_meta.p, meta.data(), (size_t)L * 4, hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipMemcpyAsync(c->slot_pfix.p, spf.data(), (size_t)L * 40, hipMemcpyHostToDevice, c->stream));
-    if (c->nlimbs == 5) {   // marginals of the high-limb weights, by slot, for the screen of the mixed-precision path
-        ldw::DevBuf d_vhi, d_phi, d_cnt2;
-        int rc = LDW_OK;
-        if ((rc = d_vhi.reserve((size_t)Npad * 8)) || (rc = d_phi.reserve((size_t)L * 40)) || (rc = d_cnt2.reserve((size_t)L * 20)) ||
-            (rc = c->slot_pfix_hi.reserve((size_t)L * 40))) {
-            d_vhi.release(); d_phi.release(); d_cnt2.release();
-            return rc;
-        }
-        hipError_t he = hipMemcpyAsync(d_vhi.p, c->h_vfixed_hi.data(), (size_t)Npad * 8, hipMemcpyHostToDevice, c->stream);
-        hipLaunchKernelGGL(k_counts_marginals, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, c->stream, c->states.as<uint8_t>(), L, Npad,
-                           d_vhi.as<int64_t>(), d_cnt2.as<int32_t>(), d_phi.as<int64_t>());
-        std::vector<int64_t> phs((size_t)L * 5), sph((size_t)L * 5, 0);
-        if (he == hipSuccess) he = hipMemcpyAsync(phs.data(), d_phi.p, (size_t)L * 40, hipMemcpyDeviceToHost, c->stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-        d_vhi.release(); d_phi.release(); d_cnt2.release();
-        if (he != hipSuccess) return ldw::hip_fail(he, "high-limb marginals", __FILE__, __LINE__);
-        for (int64_t a = 0; a < L; ++a) {
-            const uint32_t m = meta[a];
-            const int n = (int)(m & 7);
-            for (int i = 0; i <= n; ++i) sph[a * 5 + i] = phs[a * 5 + ((m >> (8 + 3 * i)) & 7)];
-        }
-        LDW_HIP(hipMemcpyAsync(c->slot_pfix_hi.p, sph.data(), (size_t)L * 40, hipMemcpyHostToDevice, c->stream));
-        LDW_HIP(hipStreamSynchronize(c->stream));
-    }
+    c->hi_ready = false;   // (the high-limb marginals of the mixed-precision path are made when a block first takes that path: ensure_hi_marginals)
     if (c->apx_ok) {   // marginals of the approximate weights V' = a b 2^e by slot, in the accumulators' final unit 2^e_last (floor)
         ldw::DevBuf d_v, d_p, d_cnt2;
         int rc = LDW_OK;
@@ -1000,6 +1022,7 @@ int ensure_rows(ldw_ctx *c) {
     }
     // rows R .. R+TILE-1 stay zero: tile padding of the row lists points at row R
     LDW_HIP(hipMemsetAsync(c->Mbits.as<uint64_t>() + (size_t)R * c->KW, 0, (size_t)TILE * c->KW * 8, c->stream));
+    lap("approximate marginals");
     if (R > 0) {
         LDW_HIP(hipMemcpyAsync(c->small.p, rowinfo.data(), (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
         LDW_REQUIRE(R < 2147483647LL, LDW_ERR_ARG, "too many indicator rows");
@@ -1010,6 +1033,7 @@ int ensure_rows(ldw_ctx *c) {
                        c->r.as<double>(), std::ldexp(1.0, -c->frac_bits), c->neff, c->r_min, c->snp_sup.as<double>());
     LDW_HIP(hipGetLastError());
     LDW_HIP(hipStreamSynchronize(c->stream));
+    lap("bit rows + per-SNP bounds");
     c->rows_ready = true;
     c->spec_B_next[0] = c->spec_B_next[1] = -1;   // bucket guesses of an earlier alignment / weighting say nothing about this one
     c->spec_seen[0] = c->spec_seen[1] = false;

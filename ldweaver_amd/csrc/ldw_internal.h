@@ -169,7 +169,8 @@ struct ldw_ctx {
     ldw::DevBuf row0;            // int32 [L+1]: first row of each SNP
     ldw::DevBuf slot_meta;       // uint32 [L]: nrows (3 bits) | uq-by-slot (5 bits <<3) | slot states (5 x 3 bits << 8)
     ldw::DevBuf slot_pfix;       // int64 [L][5]: fixed-point marginal of the state in each slot
-    ldw::DevBuf slot_pfix_hi;    // the same for the high-limb weights V_hi (nlimbs == 5)
+    ldw::DevBuf slot_pfix_hi;    // the same for the high-limb weights V_hi (nlimbs == 5), built on demand
+    bool hi_ready = false;
     ldw::DevBuf glo;             // int32: low-limb joint sums of the listed units (gathered GEMM)
     ldw::DevBuf lo_rows;         // int32 row lists of the gathered GEMM's workgroups
     ldw::DevBuf packs;           // per-block SNP constants in epilogue order (ColMeta / RowPack arrays, k_build_packs)
@@ -261,6 +262,7 @@ int launch_cooc_popc(ldw_ctx *ctx, const int32_t *rowlist_t, int RTpad, const in
 int fill_rows_bits(ldw_ctx *ctx, const int32_t *d_rowinfo, int64_t R);
 int prepare_apx_weights(ldw_ctx *ctx);   // ldw_apx.hip: dual digits, exponents, popcount segments from h_vfixed / h_seq_perm
 int check_gpu(ldw_ctx *ctx);
+int ensure_hi_marginals(ldw_ctx *ctx);   // slot_pfix_hi on demand (mixed-precision path)
 int join_prepare(ldw_ctx *ctx);      // waits for the side thread of ldw_ctx_reserve (no-op without one); its error, if any, becomes the caller's
 int reserve_slot_buffers(ldw_ctx *ctx, int64_t Npad, int64_t blk, int64_t nseg);   // ldw_mi.hip: per-slot device buffers from the block geometry
 int ensure_streams(ldw_ctx *ctx);    // the copy / GEMM streams, per-slot events and pinned pick records of the all-pairs loop (once per context)

@@ -2141,6 +2141,7 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
         LDW_HIP(hipMemsetAsync(ub, 0, o_flat, c->stream));   // the unit counter and the per-(tile, class) counters
         if (mixed) {
             LDW_REQUIRE(mixed->ntiles == (int)egrid.x, LDW_ERR_STATE, "mixed-precision geometry does not match the epilogue grid");
+            if (int rc = ensure_hi_marginals(c)) return rc;
             if (int rc = c->glo.reserve((size_t)mixed->glo_total * 4 + 64)) return rc;
             LoGeom &lo = A.lo;
             for (int k = 0; k < 3; ++k) {
