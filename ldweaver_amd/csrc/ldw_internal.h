@@ -115,6 +115,7 @@ struct ldw_ctx {
     ldw::DevBuf Gapx[LDW_NSLOT];               // int32 [RTpad][RFpad] approximate joint sums, one per pipeline slot
     ldw::DevBuf tab11[2];              // threshold tables of the biallelic pairs (k_build_tab11), int2 [nb][nb]: [off-diagonal, diagonal] blocks
     double tab11_lo[2] = {0, 0};       // MI level each was built for (0: none)
+    int tab11_cur[2] = {0, 0};         // r04: each kind's buffer holds a RING of 4 tables; this one is current (a rebuild takes the next: items in flight keep theirs)
     int64_t tab11_builds = 0;
     float tab11_c = 0;
     int tab11_nb = 0;

@@ -2007,6 +2007,10 @@ struct LoHost {
     int sr_excl = 0;                     // the block's short-range pairs are evaluated by an SR sub-pass: keep them out of the candidates, list no unit for them
     int span = 0;                        // reference blocks on the to side (0: an ordinary block); sseg: their candidate lists / histograms
     const SpanSeg *sseg = nullptr;
+    // r04: the threshold table this item's FIRST phase chose (null: none applies) — its second phase, queued after the first phases of later
+    // items (which may rebuild the table for their level), takes exactly this one
+    mutable const int2 *tab_p = nullptr;
+    mutable bool tab_set = false;
 };
 
 void fill_epi_args(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int quirk, const EmitArgs &E, const int64_t *G,
@@ -2280,6 +2284,11 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     const bool need_exact = E.any_sr || !use_pairs || lo_h->band_full;
     // (an SR sub-pass only ever lists units that hold a short-range pair: the band's tiles are all the exact GEMM has to cover)
     const uint8_t *band = ((use_pairs || lo_h->sr_sub) && !lo_h->band_full) ? D.band_mask : nullptr;
+    static const bool band_early_env = getenv("LDW_BAND_LATE") == nullptr;
+    // r04: the exact band GEMM in phase 1, on the GEMM stream (an SR sub-pass runs both phases on one stream anyway) — for alignments of at
+    // least 4096 sequences, where the GEMMs are long: see screen_main below
+    const int64_t swap_kw = [] { const char *e = getenv("LDW_QUEUE_SWAP_KW"); return e ? (int64_t)atol(e) : (int64_t)64; }();   // (per call: the tests lower it)
+    const bool band_early = band_early_env && !lo_h->sr_sub && c->KW >= swap_kw;
     ldw::DevBuf &Gx = gx(c, s);
     if (phase == 1) {
         if (int rc = c->panel[s][0].reserve((size_t)RFpad * c->KW * 8)) return rc;
@@ -2313,14 +2322,15 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             const double lo_blk = E.spec_lo - (double)E.scr_eps;
             if (!(c->tab11_lo[kd] > 0) || lo_blk < c->tab11_lo[kd] || lo_blk > 1.05 * c->tab11_lo[kd]) {
                 constexpr int NBINS_T = 64;
-                if (int rc = c->tab11[kd].reserve((size_t)NBINS_T * NBINS_T * 8)) return rc;
+                if (int rc = c->tab11[kd].reserve((size_t)4 * NBINS_T * NBINS_T * 8)) return rc;   // a ring of four tables
+                c->tab11_cur[kd] = (c->tab11_cur[kd] + 1) & 3;   // (items in flight — at most the two before this one — keep the tables they were screened for)
                 const double W = std::ldexp((double)c->total_fixed, -c->frac_bits);
                 c->tab11_lo[kd] = 0.98 * lo_blk;   // buckets are 0.5 % wide: the next blocks of the kind may guess four buckets lower (six higher) without a rebuild (73 us)
                 c->tab11_c = (float)(NBINS_T / std::sqrt(W + 1.0));
                 c->tab11_nb = NBINS_T;
                 const double sprime = std::ldexp(1.0, c->apx_e_last - c->frac_bits);
                 hipLaunchKernelGGL(k_build_tab11, dim3(NBINS_T * NBINS_T * 32 / 256), dim3(256), 0, gs, W, c->tab11_lo[kd], c->apx_delta * 1.001,
-                                   (c->apx_lost_units + 1.0) * sprime, sprime, NBINS_T, c->tab11_c, c->tab11[kd].as<int2>());
+                                   (c->apx_lost_units + 1.0) * sprime, sprime, NBINS_T, c->tab11_c, c->tab11[kd].as<int2>() + (size_t)c->tab11_cur[kd] * NBINS_T * NBINS_T);
                 LDW_HIP(hipGetLastError());
                 ++c->tab11_builds;
             }
@@ -2337,9 +2347,15 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     }
     const int kd_tab = lo_h->diag ? 1 : 0;
     // (the table is built for RXY = 1, the floor of the reference's scrambled RXY = r r' / 4 as long as no SNP has r < 2)
-    if (E.do_lr && c->tab11_on && c->tab11[kd_tab].p && c->tab11_lo[kd_tab] > 0 && E.spec_lo - (double)E.scr_eps >= c->tab11_lo[kd_tab] &&
-        (quirk != LDW_QUIRK_REFERENCE || c->r_min >= 2.0)) {
-        A.tab11 = c->tab11[kd_tab].as<int2>();
+    if (phase == 1 || !lo_h->tab_set) {
+        lo_h->tab_p = nullptr;
+        if (E.do_lr && c->tab11_on && c->tab11[kd_tab].p && c->tab11_lo[kd_tab] > 0 && E.spec_lo - (double)E.scr_eps >= c->tab11_lo[kd_tab] &&
+            (quirk != LDW_QUIRK_REFERENCE || c->r_min >= 2.0))
+            lo_h->tab_p = c->tab11[kd_tab].as<int2>() + (size_t)c->tab11_cur[kd_tab] * 64 * 64;
+        lo_h->tab_set = true;
+    }
+    if (lo_h->tab_p) {   // (phase 2: the table of phase 1, whatever later items have built since)
+        A.tab11 = lo_h->tab_p;
         A.tab_nb = c->tab11_nb;
         A.tab_c = c->tab11_c;
     }
@@ -2475,11 +2491,19 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     A.rowpack_hi = rph;
     // LDW_SCREEN_MAIN=1 (experiment): the block's screen at the head of phase 2 on the main stream — beside the NEXT block's GEMM on the GEMM
     // stream — instead of behind its own GEMM
-    // (r04: a span's screen at the head of phase 2 was tried for balance — no gain at C4 — and is WRONG in general: phase 2 is queued after the
-    // first phase of LATER items, which may rebuild the threshold table for their level; the screen then either finds no table it may use and,
-    // with it, no clean flags — it reads the regions the GEMM's epilogue did not store: 20-60 million pairs listed per span at C5, overflowing
-    // lists, 43 segments redone per pass — or races the rebuild.  The screen belongs behind its own GEMM, on the GEMM stream.)
-    static const bool screen_main = getenv("LDW_SCREEN_MAIN") != nullptr;
+    // (r04, first attempt: a span's screen at the head of phase 2 went WRONG — phase 2 is queued after the first phase of LATER items, which may
+    // rebuild the threshold table for their level; the screen then either found no table it might use and, with it, no clean flags — it read the
+    // regions the GEMM's epilogue had not stored: 20-60 million pairs listed per span at C5, overflowing lists, 43 segments redone per pass — or
+    // raced the rebuild.  Cured by LoHost::tab_p: every item keeps the table its first phase chose, out of a ring of four per kind.)
+    // r04 (end of the round): with the table a per-item snapshot out of a ring (above) the screen may run at the head of phase 2 on the main
+    // stream for every item, and the exact band GEMM moves the other way, into phase 1 on the GEMM stream: one queue holds the MFMA kernels, the
+    // other the VALU- and latency-bound ones, which share the CUs better than two GEMMs do (C4, alternating runs: 33.6 / 33.2 against 34.2 / 34.2
+    // ms; the band GEMM alone on the GEMM stream: 35.3 / 34.9; three more alternating pairs at the end: 33.6 / 33.2 / 33.4 against 34.0 / 33.8 /
+    // 34.0; C5 819 against 824 ms, 3 misses per pass either way).  Only where the GEMMs are long (N >= 4096): at 85k x 616 the approximate GEMM
+    // is 2.7 ms of a 19-ms pass, the GEMM queue would idle and the main queue carry everything — 20.9 / 21.1 against 19.3 / 19.1 ms — so short
+    // alignments keep the old places.  LDW_SCREEN_GEMMQ=1 / LDW_BAND_LATE=1 restore them for any size.
+    static const bool screen_main_env = getenv("LDW_SCREEN_GEMMQ") == nullptr;
+    const bool screen_main = screen_main_env && !lo_h->sr_sub && c->KW >= swap_kw;
     const int rm_s = quirk == LDW_QUIRK_REFERENCE ? (lo_h->span ? 3 : (nf == nt ? 1 : 2)) : 0;
     // r04 experiment: list-driven screen (k_screen_tiles -> k_screen_live -> k_mi_screen_list) instead of one workgroup per (tile, column group)
     // (measured r04, C4, 10 cold steps per setting on one box: full grid 36.9 ms per pass, list-driven with 1536 / 4096 / 12288 / 32768 striding
@@ -2513,6 +2537,10 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             else LDW_SCREEN(2, gs);
             LDW_HIP(hipGetLastError());
         }
+        if (band_early && need_exact)
+            if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, Gx.as<int64_t>(), c->nlimbs, c->digits.as<int8_t>(),
+                                          E.lower_only, gs, 0, -1, band))
+                return rc;
         if (use_maybe && E.do_lr) {
             if (rm_s == 0) hipLaunchKernelGGL((k_screen_maybe<0>), dim3(512), dim3(256), 0, gs, A, maybe_list, maybe_n, maybe_cap);
             else if (rm_s == 1) hipLaunchKernelGGL((k_screen_maybe<1>), dim3(512), dim3(256), 0, gs, A, maybe_list, maybe_n, maybe_cap);
@@ -2549,7 +2577,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             hipLaunchKernelGGL(k_mi_screen_generic<true>, dim3((unsigned)nblk), dim3(256), 0, s2, A, D.perm, D.perm_t, units, n_units, list_stride, Rg);
     }
     LDW_HIP(hipGetLastError());
-    if (need_exact)
+    if (need_exact && !band_early)
         if (int rc = launch_gemm_bits(c, c->Mbits.as<uint64_t>(), c->KW, D.rl_t, RTpad, D.rl_f, RFpad, Gx.as<int64_t>(), c->nlimbs, c->digits.as<int8_t>(),
                                       E.lower_only, s2, 0, -1, band))
             return rc;

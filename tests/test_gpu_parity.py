@@ -1924,6 +1924,27 @@ def test_spans_equal_block_by_block(engine):
             same(plain, run(quirk, True), (quirk, "corners + diagonal split"))
             assert s3["blocks"] - s2["blocks"] >= 50, (s2, s3)    # (rows 0..5: every off-diagonal pair of the row in one span: 7 + 6 + 5 + 4 + 3 + 2, twice)
             engine.set_span(True, 8)
+        # r04 (end): the queue assignment of long alignments — screens at the head of phase 2 on the main stream, exact band GEMM on the GEMM
+        # stream, every item keeping the threshold table of its first phase — forced on this short one, through the same variants
+        import os
+        os.environ["LDW_QUEUE_SWAP_KW"] = "1"
+        try:
+            for quirk in (L.QUIRK_REFERENCE, L.QUIRK_INTENDED):
+                engine.set_mixed(False); engine.set_screen(0); engine.set_path(1)
+                plain_q = run(quirk, True)
+                engine.set_mixed(True); engine.set_screen(1); engine.set_path(0)
+                engine.set_span(True, 8)
+                same(plain_q, run(quirk, True), (quirk, "queues swapped, spans, cold"))
+                same(plain_q, run(quirk, False), (quirk, "queues swapped, spans, warm"))
+                engine.set_span(False, 8)
+                same(plain_q, run(quirk, True), (quirk, "queues swapped, no spans"))
+                engine.set_span(True, 8, corners=True)
+                same(plain_q, run(quirk, True), (quirk, "queues swapped, corner spans"))
+                engine.set_span(True, 8, corners=False, diag_split=True)
+                same(plain_q, run(quirk, True), (quirk, "queues swapped, diagonal split"))
+                engine.set_span(True, 8)
+        finally:
+            os.environ.pop("LDW_QUEUE_SWAP_KW")
         # overflow: every pair list holds 64 entries -> every speculative block / segment is redone non-speculatively
         Engine.set_pair_cap(64)
         c0, s0 = engine.counters(), engine.span_report()
