@@ -197,20 +197,34 @@ def adversarial_leg(L, N, device, args):
                 e.set_screen(scr)
                 e.set_path(path)
                 run(1)
-                p0, c0, pr0, sp0 = e.path_report(), e.counters(), e.prune_report(), e.span_report()
+                p0, c0, pr0, sp0, ov0 = e.path_report(), e.counters(), e.prune_report(), e.span_report(), e.overflow_report()
                 ms = run(2 if key == "plain" else 3)
-                p1, c1, pr1, sp1 = e.path_report(), e.counters(), e.prune_report(), e.span_report()
+                p1, c1, pr1, sp1, ov1 = e.path_report(), e.counters(), e.prune_report(), e.span_report(), e.overflow_report()
                 steps = 2 if key == "plain" else 3
                 rec[key] = dict(ms_per_step=ms, value=pairs / (ms * 1e-3), steps=steps, links=dict(n_sr=e.links_count(0), n_lr=e.links_count(1)),
                                 path={k: ((p1[k] - p0[k]) / steps if isinstance(p1[k], int) else p1[k]) for k in p1},
                                 spec_misses=c1["spec_misses"] - c0["spec_misses"], screen_violations=c1["screen_violations"] - c0["screen_violations"],
                                 prune=dict(tiles_pruned=pr1["tiles_pruned"] - pr0["tiles_pruned"], tiles_total=pr1["tiles_total"] - pr0["tiles_total"]),
-                                spans=(sp1["spans"] - sp0["spans"]) / steps, span_blocks_redone=sp1["redone"] - sp0["redone"])
+                                spans=(sp1["spans"] - sp0["spans"]) / steps, span_blocks_redone=sp1["redone"] - sp0["redone"],
+                                list_overflows=dict(pair_list=ov1["pair_list"] - ov0["pair_list"], maybe_list=ov1["maybe_list"] - ov0["maybe_list"]))
             e.set_mixed(True)
             e.set_screen(1)
             e.set_path(0)
             rec["links_equal_plain"] = rec["default"]["links"] == rec["plain"]["links"]
+            # r05: the guard that was missing — the default path has to beat the plain path here too, without a
+            # single block redone; anything else is said on the line in words
+            d = rec["default"]
+            rec["default_over_plain"] = d["ms_per_step"] / rec["plain"]["ms_per_step"]
+            bad = []
+            if rec["default_over_plain"] > 1.0:
+                bad.append(f"REGRESSION: default path {d['ms_per_step']:.1f} ms is SLOWER than the plain path {rec['plain']['ms_per_step']:.1f} ms")
+            if d["spec_misses"] or d["span_blocks_redone"] or d["list_overflows"]["pair_list"] or d["list_overflows"]["maybe_list"]:
+                bad.append(f"REGRESSION: {d['spec_misses']} blocks redone ({d['span_blocks_redone']} span segments; list overflows {d['list_overflows']}) in {d['steps']} cold passes")
+            if not rec["links_equal_plain"]:
+                bad.append("WRONG: link counts differ from the plain path")
+            rec["note"] = "; ".join(bad) if bad else "ok: default faster than plain, 0 blocks redone, 0 list overflows, links equal"
             out[tag] = rec
+    out["ok"] = all(out[t]["note"].startswith("ok") for t in ("hamming_weights", "distinct_weights"))
     return out
 
 

@@ -245,6 +245,12 @@ int ldw_ctx_reserve(ldw_ctx *ctx, int64_t L, int64_t N, int64_t max_blk_sz);
 int ldw_sr_pairs_fill(ldw_ctx *ctx, const int32_t *blocks, int64_t nblocks, double sr_dist, int32_t *a_out, int32_t *b_out, int64_t capacity, int64_t *n_out);
 int ldw_set_span(ldw_ctx *ctx, int on, int max_blocks);
 int ldw_span_report(ldw_ctx *ctx, int64_t out[4]);
+/* r05 — list overflows.  The default path lists its candidates in fixed-capacity device lists; a list that overflows makes its block (or
+ * its segment of a span) be redone on the plain path (counted in spec_misses like a wrong bucket guess), so results never depend on a
+ * capacity.  out[0] blocks / segments redone because a PAIR list overflowed, out[1] because the MAYBE list of the approximate GEMM's
+ * epilogue did (sized for the worst case since r05: non-zero only under the test override LDW_MAYBE_CAP), out[2] = 1 while the maybe list
+ * is switched off for the rest of the pass after such an overflow (ldw_reset_speculation switches it on again), out[3] reserved (0). */
+int ldw_overflow_report(ldw_ctx *ctx, int64_t out[4]);
 int ldw_set_pair_cap(uint32_t cap);
 /* inspection only: the per-SNP bounds behind the pruning of the 2 x 3 / 3 x 3 tables.  out[a * 4 + 2 * m + (k - 2)] = the largest MI
  * SNP a (2 or 3 states, all flagged in uqe, r = its number of states) can reach with ANY partner that has k = 2 or 3 flagged states

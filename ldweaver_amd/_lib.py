@@ -96,6 +96,7 @@ _SIGS = {
     "ldw_sr_pairs_fill": (C.c_int, [_p, _p, C.c_int64, C.c_double, _p, _p, C.c_int64, _p]),
     "ldw_set_span": (C.c_int, [_p, C.c_int, C.c_int]),
     "ldw_span_report": (C.c_int, [_p, _p]),
+    "ldw_overflow_report": (C.c_int, [_p, _p]),
     "ldw_set_pair_cap": (C.c_int, [C.c_uint32]),
     "ldw_snp_bounds": (C.c_int, [_p, _p, C.c_int64]),
     "ldw_format_number": (C.c_int, [C.c_double, C.c_char_p, C.c_int]),

@@ -258,8 +258,11 @@ int ldw_ctx_create(int device, ldw_ctx **out) {
     static const bool no_prep = getenv("LDW_NO_PREPARE") != nullptr;
     if (!no_prep) {
         // (the streams here, synchronously: a side thread inside hipStreamCreate slowed the caller's upload of the alignment from 9.5 to 17 ms)
-        if (int rc = ldw::ensure_streams(c)) {
-            *out = c;
+        if (int rc = ldw::ensure_streams(c)) {   // (a half-built context is not handed out — destroyed here, *out stays null)
+            const std::string msg = ldw_last_error();
+            ldw_ctx_destroy(c);
+            *out = nullptr;
+            ldw::set_error("%s", msg.c_str());
             return rc;
         }
         c->prep_thread = new std::thread([c] {
@@ -426,6 +429,7 @@ int ldw_reset_speculation(ldw_ctx *c) {
     c->spec_probed[0] = c->spec_probed[1] = false;
     c->spec_hist_n[0] = c->spec_hist_n[1] = 0;
     c->tab11_lo[0] = c->tab11_lo[1] = 0;
+    c->maybe_off = false;
     return LDW_OK;
 }
 

@@ -139,6 +139,8 @@ struct ldw_ctx {
     bool diag_split = false;           // ldw_set_span(on | 4) / LDW_DIAG_SPLIT: diagonal blocks as SR sub-pass + weight-ordered long-range pass
     bool span_corners = false;         // ldw_set_span(on | 2) / LDW_SPAN_CORNERS: corner blocks join the spans (SR sub-passes); measured slower, off by default
     int span_max = 8;                  // most reference blocks per span (LDW_SPAN_MAX env, <= ldw::LDW_SPAN_MAX)
+    int64_t pair_list_overflows = 0, maybe_overflows = 0;   // blocks / segments redone because a pair list / the maybe list overflowed (ldw_overflow_report)
+    bool maybe_off = false;              // the maybe list overflowed in this pass: off until ldw_reset_speculation / new weights
     int64_t span_items = 0, span_blocks = 0, span_fallbacks = 0;   // spans run, reference blocks they covered, segments redone non-speculatively
     int64_t span_sr_subs = 0;          // SR sub-passes run for corner segments of spans
     bool early_sr = false;             // this pass assigns an item's short-range rows when the item is SUBMITTED (submit order = block order), not in its second phase

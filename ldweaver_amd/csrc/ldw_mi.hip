@@ -1244,7 +1244,7 @@ struct PickOut {
     double index, prob;
     int B;              // first bucket gathered
     int spec_ok;        // the speculative candidate list of the epilogue covers bucket B
-    int B_true, pad2;   // bucket that holds rank lo (before the speculative override)
+    int B_true, over;   // bucket that holds rank lo (before the speculative override); over: bit 0 a pair list overflowed, bit 1 the maybe list did
     unsigned long long n_cand;  // filled by k_lr_gather
     long long n_kept;           // filled by k_lr_thresh
     double disc_thresh;
@@ -1327,9 +1327,12 @@ __device__ __forceinline__ void pick_bucket_body(const unsigned long long *__res
                 out->B = spec_B;
                 out->n_below = cum;
                 // a pair list of the approximate path that overflowed lost candidates: treat like a guess that was too high
-                bool over = false;
-                if (pl_n)
-                    for (int i = 0; i <= PAIR_PATHS * PAIR_SHARDS; ++i) over = over || pl_n[i] > pl_cap;   // (word 40: the maybe list's overflow, k_screen_maybe)
+                int over = 0;
+                if (pl_n) {
+                    for (int i = 0; i < PAIR_PATHS * PAIR_SHARDS; ++i) over |= pl_n[i] > pl_cap ? 1 : 0;
+                    over |= pl_n[PAIR_PATHS * PAIR_SHARDS] > pl_cap ? 2 : 0;   // (word 40: the maybe list's overflow, k_screen_maybe)
+                }
+                out->over = over;
                 out->spec_ok = over ? 0 : 1;
             }
             cum += loc[k];
@@ -2076,13 +2079,26 @@ inline uint32_t pair_cap_for(int64_t nf, int64_t nt, int nseg = 0) {
     while (cap < want && cap < top) cap <<= 1;
     return (uint32_t)cap;
 }
-// entries of the maybe list of a block (ApxGemmArgs::maybe): one pair in a few thousand fails its table thresholds
-inline uint32_t maybe_cap_for(int64_t nf, int64_t nt) {
+// entries of the maybe list of an item (ApxGemmArgs::maybe).  r05: the WORST case — every region of 32 to-rows x 64 from-rows of the row
+// rectangle hands over APX_MAYBE_MAX entries (0.56 B per entry of G', a seventh of G' itself) — so the list cannot overflow whatever the data
+// look like.  r04 sized it for "one pair in a few thousand fails its table thresholds" (nf nt / 256 + 65 536), which holds on alignments full
+// of rare states; on an alignment without them (MAF 0.2-0.5: the bench's adversarial leg) most regions hand over tens of entries, the list
+// overflowed on nearly every block and each of them was redone on the plain path — 216 ms per pass against 155 ms for the plain path itself.
+inline uint32_t maybe_cap_for(int64_t RTpad, int64_t RFpad) {
     if (const char *e = getenv("LDW_MAYBE_CAP")) {   // (tests: a list that overflows makes its block take the pair lists' overflow path)
         const long k = atol(e);
         if (k > 0) return (uint32_t)k;
     }
-    return (uint32_t)std::min<int64_t>(nf * nt / 256 + 65536, (int64_t)1 << 26);
+    return (uint32_t)std::min<int64_t>(((RTpad + 31) / 32) * ((RFpad + 63) / 64) * (int64_t)APX_MAYBE_MAX + 64, (int64_t)1 << 30);
+}
+// a block (or a span's segment) redone because a list overflowed (PickOut::over): counted, and a maybe list that overflowed — impossible at its
+// worst-case capacity, so only under LDW_MAYBE_CAP — is switched off for the rest of the pass instead of overflowing item after item
+inline void note_overflow(ldw_ctx *c, int over) {
+    if (over & 1) ++c->pair_list_overflows;
+    if (over & 2) {
+        ++c->maybe_overflows;
+        c->maybe_off = true;
+    }
 }
 int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RFpad, int RTpad, int quirk, EmitArgs E,
                     hipEvent_t *ev, int which, ldw::DevBuf *Gb, hipStream_t gstream, unsigned long long *ghist,
@@ -2300,7 +2316,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         if (int rc = B_packs.reserve(o_rt + (size_t)nt * 4 + 256)) return rc;
         if (use_pairs)
             if (int rc = c->pairs[s].reserve(o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * pair_cap_for(nf, nt, lo_h->span) * sizeof(PairEnt) +
-                                             (size_t)maybe_cap_for(nf, nt) * sizeof(ApxMaybe) + 64))
+                                             (size_t)maybe_cap_for(RTpad, RFpad) * sizeof(ApxMaybe) + 64))
                 return rc;
         if (need_exact)
             if (int rc = Gx.reserve((size_t)RFpad * RTpad * 8)) return rc;
@@ -2398,9 +2414,9 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     // (only where the K loop is long enough to carry the epilogue's extra work — the mask of the failing entries is built for every eligible
     // region: at N = 616 the GEMM's launch went from 0.091 to 0.107 ms and the pass from 19.4 to 20.1 ms with it, at N = 5000 the launch does
     // not move and the pass gains 0.3-0.4 ms; building the mask only in failing regions was slower at both sizes)
-    const bool use_maybe = maybe_on && fuse && use_pairs && c->screen == 1 && !E.lower_only && c->KW >= 32;
+    const bool use_maybe = maybe_on && !c->maybe_off && fuse && use_pairs && c->screen == 1 && !E.lower_only && c->KW >= 32;
     unsigned int *maybe_n = use_maybe ? c->pairs[s].as<unsigned int>() + 48 : nullptr;
-    const unsigned int maybe_cap = maybe_cap_for(nf, nt);
+    const unsigned int maybe_cap = maybe_cap_for(RTpad, RFpad);
     ApxMaybe *maybe_list = use_maybe ? reinterpret_cast<ApxMaybe *>(c->pairs[s].as<char>() + o_pairs + (size_t)PAIR_PATHS * PAIR_SHARDS * A.pl_cap * sizeof(PairEnt)) : nullptr;
     if (phase == 1) {
         if (E.do_lr) {
@@ -3682,6 +3698,7 @@ int finish_block(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallL
         LDW_HIP(hipMemcpyAsync(c->pin_pick[s], sl.pick[s], sizeof(ldw::PickOut), hipMemcpyDeviceToHost, c->stream));
         LDW_HIP(hipStreamSynchronize(c->stream));
         ++c->spec_misses;
+        note_overflow(c, hp->over);
         missed = true;
     }
     if (do_lr && hp->n > 0) update_guess(c, hb.diag, hp, missed || hb.force_plain);   // (force_plain: the redo of a span's segment whose guess was wrong)
@@ -3859,6 +3876,7 @@ int finish_span(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLa
         if (missed) {
             ++c->spec_misses;
             ++c->span_fallbacks;
+            note_overflow(c, hp->over);
             // (the redo reads the exact row count of everything before it: the selections of the span's earlier segments are queued, not counted yet)
             LDW_HIP(hipMemcpyAsync(c->pin_lrc, sl.lr_count, 8, hipMemcpyDeviceToHost, c->stream));
             LDW_HIP(hipEventRecord(c->ev_lrc, c->stream));
@@ -4060,7 +4078,7 @@ int reserve_slot_buffers(ldw_ctx *c, int64_t Npad, int64_t blk, int64_t nseg) {
         if (int rc = c->Gapx[s].reserve(RF * RT * 4)) return rc;
         if (int rc = c->apx_units[s].reserve(64 + 2 * n_units * 8 + 64)) return rc;
         if (int rc = c->apx_packs[s].reserve(2 * o_cph + 2 * o_rph + ((size_t)blk + (size_t)nt) * 4 + 1024)) return rc;
-        if (int rc = c->pairs[s].reserve(256 + (size_t)PAIR_PATHS * PAIR_SHARDS * cap * sizeof(PairEnt) + (size_t)maybe_cap_for(blk, nt) * sizeof(ApxMaybe) + 64)) return rc;
+        if (int rc = c->pairs[s].reserve(256 + (size_t)PAIR_PATHS * PAIR_SHARDS * cap * sizeof(PairEnt) + (size_t)maybe_cap_for((int64_t)RT, (int64_t)RF) * sizeof(ApxMaybe) + 64)) return rc;
         if (int rc = c->apx_bins[s].reserve(2 * (RT + RF) + (size_t)nt + nf_slots + 256 + (RT / 128) * (RF / 64) * 4)) return rc;
         if (int rc = c->apx_clean[s].reserve((RT / 32) * (RF / 64) + 64)) return rc;
         if (int rc = c->hist[s].reserve((size_t)nseg * NBINS * 8)) return rc;
@@ -4108,6 +4126,7 @@ int ldw_joint_tables(ldw_ctx *c, const int32_t *pair_a, const int32_t *pair_b, i
                      int64_t *fixed_out, int *frac_bits_out) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(pair_a && pair_b && np > 0, LDW_ERR_ARG, "ldw_joint_tables: bad argument");
+    if (int rc = join_prepare(c)) return rc;   // (ldw_ctx_reserve's side thread sizes c->G's neighbours gx(c, s) — no entry point touches them beside it)
     if (int rc = ensure_rows(c)) return rc;
     if (frac_bits_out) *frac_bits_out = c->frac_bits;
     const int64_t CH = 1024;
@@ -4735,6 +4754,15 @@ int ldw_set_span(ldw_ctx *c, int on, int max_blocks) {
     c->span_corners = (on & 2) != 0;   // bit 1: corner blocks (few short-range pairs) join the spans, their short-range pairs go to SR sub-passes (off by default: slower)
     c->span_on = on != 0;
     if (max_blocks) c->span_max = max_blocks;
+    return LDW_OK;
+}
+
+int ldw_overflow_report(ldw_ctx *c, int64_t out[4]) {
+    LDW_REQUIRE(c && out, LDW_ERR_ARG, "ldw_overflow_report: null argument");
+    out[0] = c->pair_list_overflows;
+    out[1] = c->maybe_overflows;
+    out[2] = c->maybe_off ? 1 : 0;
+    out[3] = 0;
     return LDW_OK;
 }
 

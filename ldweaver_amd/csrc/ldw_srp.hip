@@ -809,6 +809,7 @@ extern "C" {
 int ldw_sr_len_quantiles(ldw_ctx *c, int nclust, double sr_dist, double prob, int32_t S, double *q_lo_out, double *q_hi_out,
                          int64_t *n_out) {
     if (int rc = sr_ready(c, "ldw_sr_len_quantiles")) return rc;
+    if (int rc = ldw::join_prepare(c)) return rc;   // (reads and may borrow Gapx[k], which ldw_ctx_reserve's side thread sizes)
     LDW_REQUIRE(nclust >= 1 && nclust <= SRM_MAXCL, LDW_ERR_ARG, "ldw_sr_len_quantiles: nclust must be in 1..%d", SRM_MAXCL);
     LDW_REQUIRE(sr_dist > 1 && sr_dist <= 65535, LDW_ERR_ARG, "ldw_sr_len_quantiles: sr_dist must be in (1, 65535]");
     LDW_REQUIRE(prob >= 0 && prob <= 1, LDW_ERR_ARG, "ldw_sr_len_quantiles: prob outside [0,1]");

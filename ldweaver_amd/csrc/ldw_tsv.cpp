@@ -532,7 +532,10 @@ static int tsv_async_join(ldw_ctx *c, int64_t *rows_out, int64_t *bytes_out) {
     return rc;
 }
 
-int ldw_tsv_join(ldw_ctx *c) { return tsv_async_join(c, nullptr, nullptr); }   // (ldw_ctx_destroy, ldw_set_snp_meta)
+int ldw_tsv_join(ldw_ctx *c) {
+    LDW_REQUIRE(c != nullptr, LDW_ERR_ARG, "ldw_tsv_join: null context");
+    return tsv_async_join(c, nullptr, nullptr);
+}   // (ldw_ctx_destroy, ldw_set_snp_meta)
 
 int ldw_write_links_tsv(ldw_ctx *c, int which, const char *path, int append, int nthreads, int64_t *rows_out, int64_t *bytes_out) {
     if (c && c->tsv_async) {

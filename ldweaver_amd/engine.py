@@ -113,6 +113,13 @@ class Engine:
         L.check(L.lib().ldw_span_report(self._ctx, L.ptr(v)))
         return dict(spans=int(v[0]), blocks=int(v[1]), redone=int(v[2]), on=bool(v[3]))
 
+    def overflow_report(self):
+        """Blocks / span segments redone because a device list overflowed: pair lists, the maybe list (worst-case sized: 0 unless
+        LDW_MAYBE_CAP is set), and whether the maybe list is switched off for the rest of the pass."""
+        v = np.zeros(4, dtype=np.int64)
+        L.check(L.lib().ldw_overflow_report(self._ctx, L.ptr(v)))
+        return dict(pair_list=int(v[0]), maybe_list=int(v[1]), maybe_off=bool(v[2]))
+
     @staticmethod
     def set_pair_cap(cap: int):
         """Tests only: a fixed capacity of the approximate path's pair lists (0: automatic), process-wide."""
