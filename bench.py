@@ -78,6 +78,9 @@ def parse():
                                                         "the previous step's bucket guesses); the default is a cold pass per step")
     ap.add_argument("--no-job", action="store_true", help="skip the end-to-end job leg (host states -> tsv files)")
     ap.add_argument("--no-adversarial", action="store_true", help="skip the adversarial-data leg (MAF uniform in [0.2, 0.5], no clonal groups)")
+    ap.add_argument("--inproc", action="store_true", help="N > 1 WITHOUT one process per GPU: this one process creates one context per device and runs "
+                                                          "ldw_mi_all_pairs_multi (worker threads + peer-to-peer gather inside the library) — the route the R shim takes")
+    ap.add_argument("--inproc-devices", default="", help="comma-separated device ids for --inproc (default 0..gpus-1; '0,0' = two contexts on one GPU)")
     ap.add_argument("--sustain-s", type=float, default=10.0, help="N = 1: keep stepping after the timed region until this many seconds of steps have run")
     return ap.parse_args()
 
@@ -258,8 +261,84 @@ def self_launch(args):
     return rc
 
 
+def inproc_main(args):
+    """`--inproc`: the block loop over several contexts of THIS process (ldw_mi_all_pairs_multi) — one context per device,
+    worker threads and the peer-to-peer gather inside the library, no torch.distributed.  Same workload, same cold steps, same line;
+    `inproc` carries the slowest pass, the gather and every context's own pass time."""
+    import torch
+    from ldweaver_amd.engine import Engine
+    from ldweaver_amd.mi import lr_links_approx, make_blocks
+    from ldweaver_amd.synth import synth_alignment
+    devs = [int(x) for x in args.inproc_devices.split(",")] if args.inproc_devices else list(range(args.gpus))
+    L, N = args.L, args.N
+    torch.cuda.set_device(devs[0])
+    syn = synth_alignment(L, N, seed=1988, device=torch.device("cuda", devs[0]), as_numpy=False)
+    POS, paint, g = syn["POS"], syn["paint"], float(syn["g"])
+    blocks = make_blocks(L, args.max_blk_sz)
+    pairs = 0
+    for fs, fe, ts, te in blocks.tolist():
+        nf, nt = fe - fs + 1, te - ts + 1
+        pairs += nf * (nf - 1) // 2 if (fs == ts and fe == te) else nf * nt - min(nf, nt)
+    approx = lr_links_approx(POS, g, 20000.0)
+    engs = [Engine(d) for d in devs]
+    try:
+        st_host = syn["states"].cpu().numpy()
+        for e in engs:
+            e.set_alignment(syn["states"] if e.device == devs[0] else st_host)
+        counts = engs[0].state_counts()
+        uqe = (counts > 0).T.astype(np.float64)
+        r = uqe.sum(axis=1)
+        t0 = time.perf_counter()
+        hdw = Engine.hamming_weights_multi(engs, int(L * 0.1))
+        hamming_s = time.perf_counter() - t0
+        for e in engs:
+            e.set_weights(hdw, args.nlimbs)
+            e.set_snp_meta(r, uqe, POS, paint, g)
+        info = {}
+
+        def step():
+            for e in engs:
+                e.reset_speculation()
+            info.update(Engine.mi_all_pairs_multi(engs, blocks, 20000.0, 1e6, approx))
+
+        def sync():
+            for d in set(devs):
+                torch.cuda.synchronize(d)
+        for _ in range(args.warmup):
+            step()
+        sync()
+        acc = dict(pass_ms=0.0, gather_ms=0.0, per_engine_ms=np.zeros(min(len(engs), 8)))
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            acc["pass_ms"] += info["pass_ms"]
+            acc["gather_ms"] += info["gather_ms"]
+            acc["per_engine_ms"] += np.asarray(info["per_engine_ms"])
+        sync()
+        dt = time.perf_counter() - t0
+        K = args.steps
+        out = dict(metric="MI SNP-pairs/sec", value=pairs * K / dt, unit="pairs/s", n_gpus=len(set(devs)), steps=K, warmup=args.warmup, ms_per_step=dt / K * 1e3,
+                   higher_is_better=True, scaling="strong", vs_baseline=None, dtype="i8", data="synthetic",
+                   config=dict(workload=f"synthetic {L} SNPs x {N} seqs, all {len(blocks)} block pairs of make_blocks(max_blk_sz={args.max_blk_sz}), sr_dist=20000, "
+                                        f"lr_retain_links=1e6, sr+lr link tables assembled in context 0", L=L, N=N, pairs=int(pairs),
+                               step="cold pass per step (ldw_reset_speculation on every context)",
+                               parallelism=f"ONE process, {len(engs)} contexts on devices {devs}: ldw_mi_all_pairs_multi (worker threads, peer-to-peer gather)"),
+                   inproc=dict(contexts=len(engs), devices=devs, blocks_per_context=np.bincount(info["owner"], minlength=len(engs)).tolist(),
+                               slowest_pass_ms=acc["pass_ms"] / K, gather_ms=acc["gather_ms"] / K, per_context_pass_ms=(acc["per_engine_ms"] / K).tolist(),
+                               hamming_weights_s=hamming_s),
+                   links=dict(n_sr=engs[0].links_count(0), n_lr=engs[0].links_count(1)),
+                   spec_misses=sum(e.counters()["spec_misses"] for e in engs))
+        print(json.dumps(out), flush=True)
+    finally:
+        for e in engs:
+            e.close()
+    return 0
+
+
 def main():
     args = parse()
+    if args.inproc:
+        sys.exit(inproc_main(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     import torch

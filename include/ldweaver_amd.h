@@ -161,6 +161,27 @@ typedef struct ldw_mi_params {
  * a block, in the reference's row order (R/computePairwiseMI.R:306-310).  reset != 0 clears the tables. */
 int ldw_mi_all_pairs(ldw_ctx *ctx, const int32_t *blocks, int64_t nblocks, const ldw_mi_params *p,
                      int reset);
+/* r05 — the same loop over SEVERAL contexts of this process, one per GPU ("block list, lr prob, device list -> sr table,
+ * lr table"; the loop it shards is R/computePairwiseMI.R:103-116).  Every context must hold the same alignment, weights and SNP meta data
+ * (ldw_set_alignment / ldw_set_weights / ldw_set_snp_meta on each; ldw_hamming_weights_multi shares the weights' own computation).  The
+ * block pairs are dealt over the contexts by cost (ldw_deal_blocks: a diagonal pair counts 3.3 times its pairs — its dense short-range
+ * band —, longest first to the least loaded, every context keeps make_blocks order; the same deal as ldweaver_amd/dist.py), each context
+ * runs ldw_mi_all_pairs on its share on a worker thread of its own, and the link tables are assembled in ctx[0] in the caller's block order —
+ * the order the reference appends in — by peer-to-peer copies (each source's rows over its own xGMI link; the short-range rows travel as
+ * their MI column alone when POS ascends, ctx[0] rebuilds their index columns: ldw_sr_pairs_fill).  Afterwards ctx[0] is exactly in the
+ * state ldw_mi_all_pairs(ctx[0], all blocks) would have left it in — tables, ldw_block_stats over all nblocks — so the short-range model,
+ * ARACNE, the post-processing and the tsv writers run on it unchanged; the other contexts keep their own shares.  The long-range filter is
+ * per block (:352-358), so the retained set does not depend on n_ctx.  One failing context fails the call (its message is reported).
+ * owner_out (nblocks, may be NULL) receives the deal; ms_out (10 doubles, may be NULL): [0] deal + slowest pass, [1] gather, [2..9] the
+ * pass of contexts 0..7.  n_ctx = 1 is ldw_mi_all_pairs(ctx[0], ..., reset = 1). */
+int ldw_mi_all_pairs_multi(ldw_ctx **ctx, int n_ctx, const int32_t *blocks, int64_t nblocks, const ldw_mi_params *p,
+                           int32_t *owner_out, double *ms_out);
+/* the deal alone (host only, no context): owner_out[b] = rank of block b */
+int ldw_deal_blocks(const int32_t *blocks, int64_t nblocks, int n_ranks, int32_t *owner_out);
+/* estimate_Hamming_distance_weights over several contexts holding the same alignment: the symmetric sequence x sequence comparison is
+ * cut into strips of 128-sequence row tiles of equal area, one per context (ldw_hamming_counts), the integer neighbour counts are added
+ * on the host: hdw_out[N] is bit-identical to ldw_hamming_weights on one context. */
+int ldw_hamming_weights_multi(ldw_ctx **ctx, int n_ctx, int32_t thresh, double *hdw_out);
 /* The same loop opened up for blocks that are not contiguous index ranges (SR-only mode drops SNPs
  * without a short-range partner before each block, R/computePairwiseMI.R:179-189):
  * ldw_links_begin(capacity in blocks) ; ldw_mi_block_links(...) per block ; ldw_links_end(). */

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDW_AMD_LIB") or os.path.join(_HERE, "libldweaver_amd.so")  # override for kernel A/B experiments
 
 LDW_OK = 0
+LDW_ERR_ARG, LDW_ERR_HIP, LDW_ERR_STATE, LDW_ERR_NOGPU, LDW_ERR_SIZE = 1, 2, 3, 4, 5
 QUIRK_REFERENCE, QUIRK_INTENDED = 0, 1
 ENGINE_MFMA, ENGINE_HIST, ENGINE_HIST_STATES = 0, 1, 2
 COL_INT32, COL_INT64, COL_DOUBLE = 0, 1, 2
@@ -61,6 +62,9 @@ _SIGS = {
     "ldw_mi_block": (C.c_int, [_p, _p, _i64, _p, _i64, C.c_int, _p, C.c_int]),
     "ldw_joint_tables": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
     "ldw_mi_all_pairs": (C.c_int, [_p, _p, _i64, C.POINTER(MIParams), C.c_int]),
+    "ldw_mi_all_pairs_multi": (C.c_int, [_p, C.c_int, _p, _i64, C.POINTER(MIParams), _p, _p]),
+    "ldw_deal_blocks": (C.c_int, [_p, _i64, C.c_int, _p]),
+    "ldw_hamming_weights_multi": (C.c_int, [_p, C.c_int, C.c_int32, _p]),
     "ldw_links_begin": (C.c_int, [_p, _i64]),
     "ldw_mi_block_links": (C.c_int, [_p, _p, _i64, _p, _i64, C.POINTER(MIParams)]),
     "ldw_links_end": (C.c_int, [_p]),

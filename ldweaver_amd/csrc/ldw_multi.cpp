@@ -6,6 +6,7 @@
 // exchange is this one variable-length gather, as in ldweaver_amd/dist.py, which does the same across processes with RCCL).
 // A host that cannot start one process per GPU — R through .Call is the case this is for — reaches all GPUs of a node this way.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -235,8 +236,6 @@ int ldw_mi_all_pairs_multi(ldw_ctx **ctx, int n_ctx, const int32_t *blocks, int6
     std::swap(c0->lr_b, nB[1]);
     std::swap(c0->lr_mi, nM[1]);
     fail(LDW_OK);
-    c0->links_cap[0] = tot[0] > 0 ? tot[0] : 1;
-    c0->links_cap[1] = tot[1] > 0 ? tot[1] : 1;
     c0->n_sr = tot[0];
     c0->n_lr = tot[1];
     c0->n_red = c0->n_pool = 0;

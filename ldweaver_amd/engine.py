@@ -296,6 +296,33 @@ class Engine:
         L.check(L.lib().ldw_mi_all_pairs(self._ctx, L.ptr(bl), len(bl), C.byref(p), 1))
         self._nblocks = len(bl)
 
+    @staticmethod
+    def mi_all_pairs_multi(engines, blocks, sr_dist=20000.0, lr_retain_links=1e6, lr_links_approx=1.0, sr_only=False,
+                           quirk=L.QUIRK_REFERENCE, keep_sr=True):
+        """The block loop over several engines of THIS process, one per GPU (ldw_mi_all_pairs_multi): every engine must hold the same
+        alignment, weights and SNP meta data; the blocks are dealt by cost, each engine runs its share on a worker thread inside the
+        library, and engines[0] ends up with the assembled tables in make_blocks order (and the block statistics of all blocks) — exactly
+        as if it had run every block itself.  Returns dict(owner=int32[nblocks], pass_ms, gather_ms, per_engine_ms)."""
+        bl = L.as_c(blocks, np.int32).reshape(-1, 4)
+        p = L.MIParams(float(sr_dist), float(lr_retain_links), float(lr_links_approx), int(bool(sr_only)), int(quirk),
+                       int(bool(keep_sr)), 0)
+        arr = (C.c_void_p * len(engines))(*[e._ctx.value for e in engines])
+        owner = np.zeros(len(bl), dtype=np.int32)
+        ms = np.zeros(10, dtype=np.float64)
+        L.check(L.lib().ldw_mi_all_pairs_multi(arr, len(engines), L.ptr(bl), len(bl), C.byref(p), L.ptr(owner), L.ptr(ms)))
+        engines[0]._nblocks = len(bl)
+        for k, e in enumerate(engines[1:], start=1):
+            e._nblocks = int((owner == k).sum())
+        return dict(owner=owner, pass_ms=float(ms[0]), gather_ms=float(ms[1]), per_engine_ms=ms[2:2 + min(len(engines), 8)].tolist())
+
+    @staticmethod
+    def hamming_weights_multi(engines, thresh: int) -> np.ndarray:
+        """estimate_Hamming_distance_weights with the sequence x sequence comparison cut into one strip per engine (same alignment on all)."""
+        arr = (C.c_void_p * len(engines))(*[e._ctx.value for e in engines])
+        hdw = np.empty(engines[0].N, dtype=np.float64)
+        L.check(L.lib().ldw_hamming_weights_multi(arr, len(engines), int(thresh), L.ptr(hdw)))
+        return hdw
+
     def links_begin(self, nblocks: int):
         L.check(L.lib().ldw_links_begin(self._ctx, int(nblocks)))
         self._nblocks = 0

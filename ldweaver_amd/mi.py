@@ -65,14 +65,22 @@ def lr_links_approx(POS, g, sr_dist, seed: int = 1988) -> float:
 # ---------------------------------------------------------------------------------------------
 def estimate_Hamming_distance_weights(snp_dat: SnpDat, threshold: float = 0.1, mega_dset: bool = False,
                                       engine: Engine | None = None, alignment_resident: bool = False, group=None,
-                                      verbose: bool = True) -> np.ndarray:
+                                      verbose: bool = True, engines=None) -> np.ndarray:
+    """``engines`` (r05): several engines of this process, one per GPU — the sequence x sequence comparison is cut into one strip per
+    engine inside the library (``ldw_hamming_weights_multi``); bit-identical weights."""
     t0 = time.time()
     thresh = int(snp_dat.nsnp * threshold)  # as.integer() truncates
+    if engines is not None:
+        if engine is not None or len(engines) < 1:
+            raise ValueError("pass either `engine` or a non-empty `engines` list")
+        engine = engines[0]
     own = engine is None
     eng = engine or Engine(0)
+    inproc = engines is not None and len(engines) > 1
     try:
         if not alignment_resident:
-            eng.set_alignment(snp_dat.states)
+            for e in (engines if inproc else [eng]):
+                e.set_alignment(snp_dat.states)
         world = 1
         forced = os.environ.get("LDW_FORCE_COLLECTIVE", "0") not in ("", "0")
         try:
@@ -86,6 +94,8 @@ def estimate_Hamming_distance_weights(snp_dat: SnpDat, threshold: float = 0.1, m
         if world > 1 or forced:   # one process per GPU: every rank counts a strip of the sequence x sequence comparison
             from .dist import hamming_weights_sharded
             hdw = hamming_weights_sharded(eng, thresh, group=group)
+        elif inproc:
+            hdw = Engine.hamming_weights_multi(engines, thresh)
         else:
             hdw = eng.hamming_weights(thresh)
     finally:
@@ -187,7 +197,7 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
                            runARACNE=True, perform_SR_analysis_only=False, order_links=True, mega_dset=False, *,
                            engine: Engine | None = None, alignment_resident: bool = False,
                            quirk_mode: int = L.QUIRK_REFERENCE, nlimbs: int = 0, verbose: bool = True,
-                           return_aux: bool = False, sr_model: str = "device", group=None):
+                           return_aux: bool = False, sr_model: str = "device", group=None, engines=None):
     """Returns the short-range link data.frame (clust_c,pos1,pos2,clust1,clust2,len,MI,srp_max,ARACNE);
     long-range links are appended to ``lr_save_path`` and the returned frame to ``sr_save_path``.
 
@@ -195,7 +205,13 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
     this function with the same arguments and its own ``engine``), the block pairs of ``make_blocks`` are dealt over the
     ranks, every rank computes its share on its GPU, ONE variable-length gather assembles the link tables on rank 0
     (``dist.gather_link_tables``), rank 0 adopts them (``ldw_links_import``) and runs the short-range model / ARACNE on
-    them and writes the files; the other ranks return None."""
+    them and writes the files; the other ranks return None.
+
+    ``engines`` (r05): several engines of THIS process, one per GPU (``[Engine(d) for d in devices]``) — the route a host that cannot
+    start one process per GPU takes (R through .Call: ``options(ldwamd.devices = 0:7)`` in r_shim/).  Every engine receives the alignment,
+    weights and meta data, ``ldw_mi_all_pairs_multi`` deals the block pairs over them inside the library (worker threads, peer-to-peer
+    gather into ``engines[0]``), and the short-range model, ARACNE and the files run on ``engines[0]``.  SR-only passes (per-block site
+    filters, :179-189) run on ``engines[0]`` alone."""
     t000 = time.time()
     say = print if verbose else (lambda *a, **k: None)
     if lr_save_path is None:
@@ -214,15 +230,21 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
     # (snp.dat$POS may be in any order, like in the reference: blocks whose lists do not ascend take the library's generic path)
     approx = None if perform_SR_analysis_only else lr_links_approx(POS, g, sr_dist)
 
+    if engines is not None:
+        if engine is not None or len(engines) < 1:
+            raise ValueError("pass either `engine` or a non-empty `engines` list")
+        engine = engines[0]
     own = engine is None
     eng = engine or Engine(0)
+    inproc = engines is not None and len(engines) > 1 and not perform_SR_analysis_only
     stages = {"lr_links_approx_s": time.time() - t000}
     try:
         def setup():
-            if not alignment_resident:   # pass alignment_resident=True when `engine` already holds snp_dat.states
-                eng.set_alignment(snp_dat.states)
-            eng.set_weights(hdw, nlimbs)
-            eng.set_snp_meta(snp_dat.r, snp_dat.uqe, POS, paint, g)
+            for e in (engines if inproc else [eng]):
+                if not alignment_resident:   # pass alignment_resident=True when `engine` (every one of `engines`) already holds snp_dat.states
+                    e.set_alignment(snp_dat.states)
+                e.set_weights(hdw, nlimbs)
+                e.set_snp_meta(snp_dat.r, snp_dat.uqe, POS, paint, g)
 
         kw = dict(sr_dist=sr_dist, lr_retain_links=lr_retain_links, lr_links_approx=approx or 1.0,
                   sr_only=perform_SR_analysis_only, quirk=quirk_mode)
@@ -266,7 +288,12 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
             setup()
             stages["setup_s"] = time.time() - t_s
             t_s = time.time()
-            stats = _run_blocks(eng, blocks, np.arange(len(blocks)), kw, POS, g)
+            if inproc:
+                stages["inproc"] = Engine.mi_all_pairs_multi(engines, blocks, **kw)
+                stages["inproc"]["owner"] = stages["inproc"]["owner"].tolist()
+                stats = eng.block_stats()
+            else:
+                stats = _run_blocks(eng, blocks, np.arange(len(blocks)), kw, POS, g)
             stages["mi_all_pairs_s"] = time.time() - t_s
         # lr_links.tsv (R/computePairwiseMI.R:362) straight from the device-resident table: fetched, derived (pos, clust, len) and
         # formatted by the library's host threads

@@ -12,10 +12,24 @@
   st
 }
 
+# r05: options(ldwamd.devices = 0:7) -> one context per GPU of the node; the block loop (R/computePairwiseMI.R:103-116) and the
+# sequence x sequence comparison of the Hamming weights are then shared over them INSIDE the library (ldw_mi_all_pairs_multi,
+# ldw_hamming_weights_multi: worker threads, peer-to-peer gather into device ldwamd.devices[1]); results do not depend on it.
+.ldwamd_devices_set <- NULL
+.ldwamd_use_devices <- function() {
+  devs <- as.integer(getOption("ldwamd.devices", 0L))
+  if (!identical(devs, .ldwamd_devices_set)) {
+    .Call("ldwamd_set_devices", devs)
+    .ldwamd_devices_set <<- devs
+  }
+  invisible(devs)
+}
+
 .ACGTN2num <- function(nv, cv, ncores) invisible(.Call("ldwamd_ACGTN2num", nv, cv, as.integer(ncores)))
 
 estimate_Hamming_distance_weights <- function(snp.dat, threshold = 0.1, mega_dset = F) {
   t0 <- Sys.time()
+  .ldwamd_use_devices()
   .Call("ldwamd_set_alignment", .ldwamd_states_from_snpdat(snp.dat), snp.dat$nsnp, snp.dat$nseq)
   hdw <- .Call("ldwamd_hamming_weights", as.integer(snp.dat$nsnp * threshold), snp.dat$nseq)
   names(hdw) <- snp.dat$seq.names
@@ -40,6 +54,7 @@ perform_MI_computation <- function(snp.dat, hdw, cds_var, ncores, lr_save_path =
                   function(x) sum((0.5 * snp.dat$g - abs((x - snp.dat$POS) %% snp.dat$g - 0.5 * snp.dat$g)) > sr_dist))
     lr_links_approx <- sum(cnt) / snp_subset * snp.dat$nsnp / 2
   }
+  .ldwamd_use_devices()
   .Call("ldwamd_set_alignment", .ldwamd_states_from_snpdat(snp.dat), snp.dat$nsnp, snp.dat$nseq)
   .Call("ldwamd_ctx_reserve", snp.dat$nsnp, snp.dat$nseq, max_blk_sz)        # r04: the pass's buffers, on a side thread, while the weights are set
   .Call("ldwamd_set_weights", as.numeric(hdw))

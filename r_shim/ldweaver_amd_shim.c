@@ -14,13 +14,34 @@
 
 #include "ldweaver_amd.h"
 
-static ldw_ctx *g_ctx = NULL;
+/* r05: one context per device of options(ldwamd.devices = 0:7) (ldwamd_set_devices); g_ctxs[0] is the context the tables end up in and
+ * every single-context entry point works on.  Without the option: one context on device 0, as before. */
+#define LDWAMD_MAX_DEV 64
+static ldw_ctx *g_ctxs[LDWAMD_MAX_DEV];
+static int g_nctx = 0;
+#define g_ctx (g_ctxs[0])
 
 static ldw_ctx *ctx_or_stop(void) {
-    if (!g_ctx && ldw_ctx_create(0, &g_ctx) != LDW_OK) error("ldweaver_amd: %s", ldw_last_error());
+    if (g_nctx == 0) {
+        if (ldw_ctx_create(0, &g_ctxs[0]) != LDW_OK) error("ldweaver_amd: %s", ldw_last_error());
+        g_nctx = 1;
+    }
     return g_ctx;
 }
 #define CHK(call) do { if ((call) != LDW_OK) error("ldweaver_amd: %s", ldw_last_error()); } while (0)
+
+/* devices: INTSXP of HIP device ids, one context each (existing contexts are destroyed first: call it before the alignment is set) */
+SEXP ldwamd_set_devices(SEXP devices) {
+    const R_xlen_t n = XLENGTH(devices);
+    if (n < 1 || n > LDWAMD_MAX_DEV) error("ldweaver_amd: 1..%d devices", LDWAMD_MAX_DEV);
+    for (int k = 0; k < g_nctx; ++k) { ldw_ctx_destroy(g_ctxs[k]); g_ctxs[k] = NULL; }
+    g_nctx = 0;
+    for (R_xlen_t k = 0; k < n; ++k) {
+        if (ldw_ctx_create(INTEGER(devices)[k], &g_ctxs[k]) != LDW_OK) error("ldweaver_amd: device %d: %s", INTEGER(devices)[k], ldw_last_error());
+        g_nctx = (int)k + 1;
+    }
+    return ScalarInteger(g_nctx);
+}
 
 /* .ACGTN2num(nv, cv, ncores): nv REALSXP 5 x L mutated in place, returns R_NilValue (src/RcppExports.cpp:16-25) */
 SEXP ldwamd_ACGTN2num(SEXP nv, SEXP cv, SEXP ncores) {
@@ -33,13 +54,15 @@ SEXP ldwamd_ACGTN2num(SEXP nv, SEXP cv, SEXP ncores) {
 
 /* states: RAWSXP L x N in ROW-major order (built by ldwamd_states_from_snpdat in the .R file) */
 SEXP ldwamd_set_alignment(SEXP states, SEXP L, SEXP N) {
-    CHK(ldw_set_alignment(ctx_or_stop(), RAW(states), (int64_t)asReal(L), (int64_t)asReal(N), 0));
+    ctx_or_stop();
+    for (int k = 0; k < g_nctx; ++k) CHK(ldw_set_alignment(g_ctxs[k], RAW(states), (int64_t)asReal(L), (int64_t)asReal(N), 0));   /* replicated: <= 5 GB of 288 per GPU */
     return R_NilValue;
 }
 
 /* r04: per-block buffers of the all-pairs loop sized and pinned on a side thread (call after ldwamd_set_alignment; optional) */
 SEXP ldwamd_ctx_reserve(SEXP L, SEXP N, SEXP max_blk_sz) {
-    CHK(ldw_ctx_reserve(ctx_or_stop(), (int64_t)asReal(L), (int64_t)asReal(N), (int64_t)asReal(max_blk_sz)));
+    ctx_or_stop();
+    for (int k = 0; k < g_nctx; ++k) CHK(ldw_ctx_reserve(g_ctxs[k], (int64_t)asReal(L), (int64_t)asReal(N), (int64_t)asReal(max_blk_sz)));
     return R_NilValue;
 }
 
@@ -52,19 +75,23 @@ SEXP ldwamd_set_span(SEXP on, SEXP max_blocks) {
 /* estimate_Hamming_distance_weights core: thresh = as.integer(nsnp*threshold) computed in R */
 SEXP ldwamd_hamming_weights(SEXP thresh, SEXP N) {
     SEXP out = PROTECT(allocVector(REALSXP, (R_xlen_t)asReal(N)));
-    CHK(ldw_hamming_weights(ctx_or_stop(), asInteger(thresh), REAL(out), NULL));
+    ctx_or_stop();
+    if (g_nctx > 1) CHK(ldw_hamming_weights_multi(g_ctxs, g_nctx, asInteger(thresh), REAL(out)));   /* one strip of the comparison per device, same integers */
+    else CHK(ldw_hamming_weights(g_ctx, asInteger(thresh), REAL(out), NULL));
     UNPROTECT(1);
     return out;
 }
 
 SEXP ldwamd_set_weights(SEXP hdw) {
-    CHK(ldw_set_weights(ctx_or_stop(), REAL(hdw), (int64_t)XLENGTH(hdw), 0));
+    ctx_or_stop();
+    for (int k = 0; k < g_nctx; ++k) CHK(ldw_set_weights(g_ctxs[k], REAL(hdw), (int64_t)XLENGTH(hdw), 0));
     return R_NilValue;
 }
 
 /* r: REALSXP[L]; uqe: RAWSXP L x 5 row-major; POS, paint: INTSXP[L]; g: scalar */
 SEXP ldwamd_set_snp_meta(SEXP r, SEXP uqe, SEXP POS, SEXP paint, SEXP g) {
-    CHK(ldw_set_snp_meta(ctx_or_stop(), REAL(r), RAW(uqe), INTEGER(POS), INTEGER(paint), asReal(g)));
+    ctx_or_stop();
+    for (int k = 0; k < g_nctx; ++k) CHK(ldw_set_snp_meta(g_ctxs[k], REAL(r), RAW(uqe), INTEGER(POS), INTEGER(paint), asReal(g)));
     return R_NilValue;
 }
 
@@ -80,7 +107,10 @@ SEXP ldwamd_mi_all_pairs(SEXP blocks, SEXP sr_dist, SEXP lr_retain, SEXP lr_appr
     p.sr_only = asLogical(sr_only);
     p.quirk_mode = asInteger(quirk);
     p.keep_sr = 1;
-    CHK(ldw_mi_all_pairs(c, INTEGER(blocks), nb, &p, 1));
+    /* r05: the block loop of R/computePairwiseMI.R:103-116 over every device of options(ldwamd.devices): dealt, run and gathered into
+     * context 0 inside the library; what follows reads context 0 exactly as after a single-device pass */
+    if (g_nctx > 1) CHK(ldw_mi_all_pairs_multi(g_ctxs, g_nctx, INTEGER(blocks), nb, &p, NULL, NULL));
+    else CHK(ldw_mi_all_pairs(c, INTEGER(blocks), nb, &p, 1));
     SEXP res = PROTECT(allocVector(VECSXP, 3));
     for (int which = 0; which < 2; ++which) {
         int64_t n = 0;
@@ -337,6 +367,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"ldwamd_set_alignment", (DL_FUNC)&ldwamd_set_alignment, 3},
     {"ldwamd_ctx_reserve", (DL_FUNC)&ldwamd_ctx_reserve, 3},
     {"ldwamd_set_span", (DL_FUNC)&ldwamd_set_span, 2},
+    {"ldwamd_set_devices", (DL_FUNC)&ldwamd_set_devices, 1},
     {"ldwamd_hamming_weights", (DL_FUNC)&ldwamd_hamming_weights, 2},
     {"ldwamd_set_weights", (DL_FUNC)&ldwamd_set_weights, 1},
     {"ldwamd_set_snp_meta", (DL_FUNC)&ldwamd_set_snp_meta, 5},

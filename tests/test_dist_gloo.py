@@ -133,6 +133,23 @@ def test_deal_covers_every_block_once_for_1_to_8_ranks():
         assert loads.max() - loads.mean() <= cost.max()
 
 
+def test_native_deal_equals_python_deal():
+    """ldw_deal_blocks (the deal of ldw_mi_all_pairs_multi, host only: no GPU needed) == dist.deal_blocks block for block — one deal,
+    whichever way the GPUs of a node are driven — on the bench's blocks, a ragged last block column and a single block."""
+    from ldweaver_amd import _lib as LL
+    for Ls, B in ((100_000, 10_000), (85_000, 10_000), (500_000, 10_000), (1268, 1000), (300, 1000)):
+        blocks = np.ascontiguousarray(make_blocks(Ls, B), dtype=np.int32)
+        for world in (1, 2, 3, 4, 8):
+            owner = np.full(len(blocks), -1, dtype=np.int32)
+            LL.check(LL.lib().ldw_deal_blocks(LL.ptr(blocks), len(blocks), world, LL.ptr(owner)))
+            want = np.empty(len(blocks), dtype=np.int32)
+            for rk, ids in enumerate(deal_blocks(blocks, world)):
+                want[ids] = rk
+            assert np.array_equal(owner, want), (Ls, B, world)
+    bad = np.array([[5, 4, 1, 3]], dtype=np.int32)
+    assert LL.lib().ldw_deal_blocks(LL.ptr(bad), 1, 2, LL.ptr(np.zeros(1, dtype=np.int32))) == LL.LDW_ERR_ARG
+
+
 def test_gather_single_process():
     blocks = make_blocks(9000, 4000)
     mine = np.arange(len(blocks))

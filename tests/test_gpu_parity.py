@@ -2233,3 +2233,109 @@ def test_gates_of_the_approximate_path_fall_back_to_the_limb_paths(engine, case)
         for k in ("n_lr_total", "n_lr_kept", "n_sr", "disc_thresh"):
             assert np.array_equal(out["plain"][2][k], out[key][2][k]), (case, key, k)
     assert len(out["plain"][1][2]) > 1000
+
+
+def test_in_process_multi_context_equals_one_context(sample, tmp_path):
+    """VERDICT r04 item 3 / SURVEY 8(b)(5): ldw_mi_all_pairs_multi — the block loop of R/computePairwiseMI.R:103-116 dealt over several
+    contexts of ONE process (worker threads inside the library, peer-to-peer gather into ctx[0]) — with TWO and THREE contexts on this
+    box's one GPU: link tables, block statistics and lr_links.tsv bytes identical to one context; the short-range rows travel as their MI
+    column alone (index columns rebuilt by ldw_sr_pairs_fill) and, forced, as all three columns; unsorted positions and an SR-only
+    parameter set take the three-column route by themselves; the Hamming weights shared over the contexts are bit-identical; a context
+    with other weights is refused; perform_MI_computation(engines=[...]) returns the single-engine frame and files."""
+    Ls, N, B = 12_000, 1_000, 3_000
+    syn = synth_alignment(Ls, N, seed=1988, device="cuda", as_numpy=False)
+    POS, g, paint = syn["POS"], float(syn["g"]), syn["paint"]
+    blocks = MIH.make_blocks(Ls, B)
+    approx = MIH.lr_links_approx(POS, g, 20000.0)
+    engs = [Engine(0) for _ in range(3)]
+    try:
+        for e in engs:
+            e.set_alignment(syn["states"])
+        cnt = engs[0].state_counts()
+        uqe = (cnt > 0).T.astype(np.float64)
+        r = uqe.sum(axis=1)
+        thresh = int(Ls * 0.1)
+        hdw = engs[0].hamming_weights(thresh)
+        for n in (1, 2, 3):
+            assert np.array_equal(Engine.hamming_weights_multi(engs[:n], thresh), hdw), n
+        for e in engs:
+            e.set_weights(hdw)
+            e.set_snp_meta(r, uqe, POS, paint, g)
+
+        def tables(e):
+            return e.links(0), e.links(1), e.block_stats()
+
+        def same(x, y, what):
+            for w in (0, 1):
+                for u, v in zip(x[w], y[w]):
+                    assert np.array_equal(u, v), (what, w)
+            for k in ("n_lr_total", "n_lr_kept", "n_sr"):
+                assert np.array_equal(x[2][k], y[2][k]), (what, k)
+            assert np.array_equal(x[2]["disc_thresh"], y[2]["disc_thresh"], equal_nan=True), what
+
+        kw = dict(sr_dist=20000.0, lr_retain_links=2e5, lr_links_approx=approx)
+        engs[0].reset_speculation()
+        engs[0].mi_all_pairs(blocks, **kw)
+        one = tables(engs[0])
+        engs[0].write_links_tsv(1, str(tmp_path / "one.tsv"))
+        assert len(one[0][2]) > 100_000 and len(one[1][2]) > 10_000
+        for n in (2, 3):
+            for e in engs:
+                e.reset_speculation()
+            info = Engine.mi_all_pairs_multi(engs[:n], blocks, **kw)
+            assert sorted(set(info["owner"].tolist())) == list(range(n)) and len(info["per_engine_ms"]) == n
+            same(one, tables(engs[0]), f"{n} contexts")
+            engs[0].write_links_tsv(1, str(tmp_path / f"multi{n}.tsv"))
+            assert (tmp_path / "one.tsv").read_bytes() == (tmp_path / f"multi{n}.tsv").read_bytes()
+            # the other contexts keep their own share
+            assert engs[1].links_count(0) == int(one[2]["n_sr"][info["owner"] == 1].sum())
+        os.environ["LDW_MULTI_FULL_SR"] = "1"
+        try:
+            Engine.mi_all_pairs_multi(engs[:2], blocks, **kw)
+            same(one, tables(engs[0]), "2 contexts, all three short-range columns sent")
+        finally:
+            os.environ.pop("LDW_MULTI_FULL_SR")
+        # the consumers of the tables run on ctx[0] unchanged: short-range quantiles on the assembled table == on the single-context one
+        q_multi = engs[0].sr_len_quantiles(3, 20000.0)
+        engs[0].mi_all_pairs(blocks, **kw)
+        q_one = engs[0].sr_len_quantiles(3, 20000.0)
+        for u, v in zip(q_one, q_multi):
+            assert np.array_equal(u, v, equal_nan=True)
+        # SR-only parameter set (no long-range part): three-column route
+        kw_sr = dict(kw, sr_only=True)
+        engs[0].mi_all_pairs(blocks, **kw_sr)
+        one_sr = tables(engs[0])
+        Engine.mi_all_pairs_multi(engs[:2], blocks, **kw_sr)
+        same(one_sr, tables(engs[0]), "2 contexts, sr_only")
+        # a context that holds other weights is refused before anything runs
+        engs[2].set_weights(np.full(N, 0.25))
+        with pytest.raises(L.LdwError) as ei:
+            Engine.mi_all_pairs_multi(engs, blocks, **kw)
+        assert ei.value.code == L.LDW_ERR_STATE and "context 2" in str(ei.value)
+        engs[2].set_weights(hdw)
+        # unsorted positions: generic pair lists, all three columns travel
+        perm = np.random.default_rng(5).permutation(Ls)
+        for e in engs[:2]:
+            e.set_snp_meta(r, uqe, POS[perm], paint, g)
+        engs[0].mi_all_pairs(blocks, **kw)
+        one_u = tables(engs[0])
+        Engine.mi_all_pairs_multi(engs[:2], blocks, **kw)
+        same(one_u, tables(engs[0]), "2 contexts, unsorted POS")
+    finally:
+        for e in engs:
+            e.close()
+    # the host mirror end to end on the reference's bundled sample: perform_MI_computation(engines=[...]) == (engine=...)
+    sd = SnpDat.from_states(sample["states"], sample["POS"], sample["g"])
+    d1, d2 = tmp_path / "e1", tmp_path / "e2"
+    d1.mkdir()
+    d2.mkdir()
+    args = dict(ncores=1, max_blk_sz=1000, lr_retain_links=1e5, verbose=False, quirk_mode=L.QUIRK_INTENDED)
+    with Engine(0) as e1:
+        red1 = MIH.perform_MI_computation(sd, sample["hdw"], CdsVar(paint=sample["paint"], nclust=3), lr_save_path=str(d1 / "lr_links.tsv"),
+                                          sr_save_path=str(d1 / "sr_links.tsv"), plt_folder=str(d1 / "PLOTS"), engine=e1, **args)
+    with Engine(0) as ea, Engine(0) as eb:
+        red2 = MIH.perform_MI_computation(sd, sample["hdw"], CdsVar(paint=sample["paint"], nclust=3), lr_save_path=str(d2 / "lr_links.tsv"),
+                                          sr_save_path=str(d2 / "sr_links.tsv"), plt_folder=str(d2 / "PLOTS"), engines=[ea, eb], **args)
+    _frames_equal(red1, red2)
+    assert (d1 / "lr_links.tsv").read_bytes() == (d2 / "lr_links.tsv").read_bytes()
+    assert (d1 / "sr_links.tsv").read_bytes() == (d2 / "sr_links.tsv").read_bytes()
