@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--gather-phases", type=int, default=3, help="N > 1: phases of the link-table gather (1 = one gather after all blocks)")
     ap.add_argument("--full-sr-rows", dest="sr_mi_only", action="store_false", help="N > 1: send all three columns of the short-range rows (r03) instead of "
                                                                                    "their MI column alone (rank 0 rebuilds the index columns: 8 instead of 16 bytes per row)")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="CPU baseline on the sample BASELINE.md 3 states: one diagonal + one off-diagonal 10 000 x 10 000 "
+                                                                     "block at the config's N (minutes on 16 cores; the default times a 2 000 x 2 000 sub-block pair)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="SNPs per side of the CPU-baseline sample block (0 = auto)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the warm / sustained / mi_values_produced / job legs after the timed region")
     ap.add_argument("--warm", action="store_true", help="do NOT reset the speculation state before every step (the r02 behaviour: each step inherits "
@@ -98,10 +100,13 @@ def cpu_baseline(states_np, hdw, r, uqe, N, sample):
     c_oracle.mi_block(states_np, hdw, r, uqe, fi, ti, cores)
     dt = time.time() - t0
     pairs = s * (s - 1) // 2 + s * s
-    return dict(value=pairs / dt, unit="MI SNP-pairs/s", cores=cores, kind="port",
-                sample=f"one diagonal + one off-diagonal {s}x{s} sub-block of the workload's first 10000-SNP block at N={N} (all 25 state "
-                       f"pairs, dense x CSR + fused Hadamard), {dt:.1f} s wall.  A whole 10000 x 10000 block is 25x the pairs (minutes on "
-                       f"these cores); the cost is linear in pairs at fixed N, so the sample rate extrapolates")
+    stated = s >= 10_000   # BASELINE.md 3 / SURVEY 8(d): one diagonal + one off-diagonal block of max_blk_sz = 10 000 SNPs at the config's N
+    return dict(value=pairs / dt, unit="MI SNP-pairs/s", cores=cores, kind="port", sample_is_stated_block=bool(stated), sample_pairs=int(pairs), sample_s=dt,
+                sample=(f"one diagonal + one off-diagonal {s}x{s} block of the workload (its first two 10000-SNP blocks) at N={N}: the sample BASELINE.md 3 states "
+                        f"(all 25 state pairs, dense x CSR + fused Hadamard), {dt:.1f} s wall" if stated else
+                        f"one diagonal + one off-diagonal {s}x{s} sub-block of the workload's first 10000-SNP block at N={N} (all 25 state "
+                        f"pairs, dense x CSR + fused Hadamard), {dt:.1f} s wall.  NOT the stated sample (a whole 10000 x 10000 block pair is 25x the pairs: "
+                        f"minutes on these cores — `--cpu-baseline-full` runs it); the cost is linear in pairs at fixed N, so the sample rate extrapolates"))
 
 
 def job_leg(states, POS, paint, g, L, N, device, args):
@@ -575,12 +580,41 @@ def main():
         eng.set_screen(0)
         eng.set_path(1)
         timed(1)
-        n_pl = 3
+        n_pl = max(10, min(args.steps, 20))   # (at least 10 steps, like the headline)
         t_pl = timed(n_pl)
         legs["mi_values_produced"] = dict(ms_per_step=t_pl / n_pl * 1e3, value=pairs * n_pl / t_pl, steps=n_pl, links=dict(result),
                                           what="--no-mixed --screen 0 --path 1: gemm_bits_kernel<5> + k_mi_epilogue: an fp64 MI VALUE for every pair "
                                                "(the headline counts pairs DECIDED: the default path bounds 99.7 % of the pairs below their block's "
                                                "threshold instead of evaluating them; same link tables)")
+        # its own roofline: the 5-limb exact GEMM, timed kernel-exclusively (overlap off) with HIP events, executed int8 operations counted by the library
+        eng.set_overlap(False)
+        eng.gemm_stats(reset=True)
+        n_rp = 2
+        g_ms = e_ms = s_ms = 0.0
+        for _ in range(n_rp):
+            eng.mi_all_pairs(my_blocks, sr_dist, lr_retain, approx)
+            lt = eng.last_timing()
+            g_ms, e_ms, s_ms = g_ms + lt["gemm_ms"], e_ms + lt["epilogue_ms"], s_ms + lt["select_ms"]
+        torch.cuda.synchronize()
+        g5 = eng.gemm_stats(reset=True)
+        eng.set_overlap(not args.no_overlap)
+        if g5["bits_launches"] > 0 and g_ms > 0:
+            avg = g_ms / g5["bits_launches"]
+            ach = g5["bits_ops"] / g5["bits_launches"] / (avg * 1e-3) / 1e12
+            legs["roofline_mi_produced"] = dict(
+                bound="mfma", kernel=f"gemm_bits_kernel<{args.nlimbs or 5}>", peak=5000.0, unit="TFLOP/s", achieved=ach, frac=ach / 5000.0,
+                avg_launch_ms=avg, launches=g5["bits_launches"], executed_ops_per_launch=g5["bits_ops"] / g5["bits_launches"],
+                alg_ops_per_launch=50.0 * N * pairs * n_rp / g5["bits_launches"],
+                alg_frac=50.0 * N * pairs * n_rp / g5["bits_launches"] / (avg * 1e-3) / 1e12 / 5000.0,
+                stages_ms_per_step=dict(gemm_ms=g_ms / n_rp, epilogue_ms=e_ms / n_rp, select_ms=s_ms / n_rp),
+                epilogue=dict(kernel="k_mi_epilogue", bound="valu (fp64)", ps_per_pair=e_ms / n_rp * 1e-3 / pairs * 1e12,
+                              note="one fp64 MI per pair: ~4.6 cells x (1 v_rcp_f64 + ~40 fp64 / integer operations) — no roof in the guide prices it; reported as time per pair"),
+                hbm_alg_GBps=(L * N + 8.0 * pairs) / (t_pl / n_pl) / 1e9, hbm_frac=(L * N + 8.0 * pairs) / (t_pl / n_pl) / 1e9 / 8000.0,
+                measured_in=f"{n_rp} serialized replay steps of the plain path (overlap off), HIP events around the kernels",
+                note="achieved = executed int8 operations (2 x rows x rows x positions x 5 limbs of every workgroup tile that runs; one indicator row per minor "
+                     "state: 1.16 rows per SNP) / launch time; alg_frac prices SURVEY 8(d)'s 50 N flops per pair against the same peak — above `frac` "
+                     "because the row reduction removes 18x of the one-hot formulation's work and the 5 limbs put 5x back.  profiles/r05_c4_plain_serial_kernel_stats.csv "
+                     "holds rocprofv3's average for the same kernel")
         eng.set_mixed(not args.no_mixed)
         eng.set_screen(args.screen)
         eng.set_path(args.path)
@@ -669,6 +703,9 @@ def main():
                                L=L, N=N, pairs=int(pairs), engine=args.engine, nlimbs=args.nlimbs or 5,
                                arithmetic="screen: one dual-digit int8 MFMA pass (rigorous error bound) -> fp32 bound; every emitted MI: exact "
                                           "int64 fixed-point joint sums -> f64",
+                               value_counts="pairs DECIDED: every pair's MI is either produced (short-range pairs, long-range candidates: exact fp64) or "
+                                            "rigorously bounded below its block's long-range threshold; link tables identical to producing every MI "
+                                            "(`value_mi_produced`: the rate at which an fp64 MI of EVERY pair is produced, SURVEY 8(d)'s P)",
                                step=("cold pass: speculation state reset before every step (ldw_reset_speculation), buffers allocated" if cold else
                                      "WARM replay (--warm): every step inherits the previous step's bucket guesses"),
                                result_at_rank0=("in-place view of the engine's device-resident link tables (N = 1: no gather, no copy)" if world == 1 else
@@ -679,13 +716,16 @@ def main():
                                parallelism=f"pair-space blocks over {world} GPU(s)"),
                    roofline=roof)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample or max(200, min(2000, L // 2))   # ~10-30 s of host work at N = 5000
+            sample = args.cpu_sample or (min(10_000, L // 2) if args.cpu_baseline_full else max(200, min(2000, L // 2)))   # default: ~10-30 s of host work at N = 5000
             st_np = states[: 2 * sample].cpu().numpy()
             cpu_base = cpu_baseline(st_np, hdw, r[: 2 * sample], uqe[: 2 * sample], N, sample)
             del st_np
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         out.update(legs)
+        if "mi_values_produced" in legs:   # SURVEY 8(d)'s metric — pairs whose MI is PRODUCED — as a first-class number beside the job rate
+            out["value_mi_produced"] = legs["mi_values_produced"]["value"]
+            out["ms_per_step_mi_produced"] = legs["mi_values_produced"]["ms_per_step"]
         out["spec_misses"] = counters_timed["spec_misses"]
         out["path"] = path_report
         out["prune"] = dict(eng.prune_report(), what="wave tiles of the approximate GEMM whose pairs the threshold table dismisses whatever their joint "

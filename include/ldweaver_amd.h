@@ -50,6 +50,10 @@ typedef struct ldw_ctx ldw_ctx;
 
 /* ---- library / device ------------------------------------------------------------------ */
 int ldw_version(void);
+/* bit 0: built with -DLDW_EXPERIMENTS (make EXPERIMENTS=1): the measured-slower kernel variants and their environment switches are in the
+ * library (the fused GEMM + epilogue kernel, LDW_ENGINE_HIST_STATES, corner spans / split diagonal blocks of ldw_set_span, the alternative
+ * approximate GEMMs, the list-driven screen).  The default library returns 0, holds none of them and answers LDW_ERR_STATE where one is asked for. */
+int ldw_build_info(void);
 const char *ldw_last_error(void);
 /* number of visible HIP devices (0 when none); never initialises a context */
 int ldw_device_count(void);
@@ -398,7 +402,17 @@ int ldw_write_links_tsv(ldw_ctx *ctx, int which, const char *path, int append, i
  * ldw_set_snp_meta and ldw_ctx_destroy finish a pending one first); _end without _begin returns 0 rows. */
 int ldw_write_links_tsv_begin(ldw_ctx *ctx, int which, const char *path, int append, int nthreads);
 int ldw_write_links_tsv_end(ldw_ctx *ctx, int64_t *rows_out, int64_t *bytes_out);
-int ldw_tsv_join(ldw_ctx *ctx);   /* waits for a pending asynchronous table, discarding its counts (status returned) */
+int ldw_tsv_join(ldw_ctx *ctx);
+/* r05 — lr_links.tsv appended WHILE the pass runs, as the reference appends it block by block (R/computePairwiseMI.R:362).  _begin (before
+ * ldw_mi_all_pairs; append = 0 truncates the file first) opens a writer thread on the context; after every finished item of the pass (a
+ * block, or a span of blocks) the rows it added to the long-range table — final: the filter is per block (:352-358) — are fetched on a
+ * stream of their own, formatted like ldw_write_links_tsv and appended.  The file is at all times a prefix of the complete file in whole
+ * blocks; a pass that fails at block k leaves the rows of blocks 0..k-1 (the items already submitted are run to their end first), a killed
+ * process those of the items written so far.  _end waits for the writer and reports rows, bytes and the number of blocks whose rows are in
+ * the file (any output may be NULL); without _begin it returns zeros.  Single context, single pass: the multi-context gather reorders rows
+ * and keeps the table-at-once writer. */
+int ldw_lr_stream_begin(ldw_ctx *ctx, const char *path, int append, int nthreads);
+int ldw_lr_stream_end(ldw_ctx *ctx, int64_t *rows_out, int64_t *bytes_out, int64_t *blocks_out);   /* waits for a pending asynchronous table, discarding its counts (status returned) */
 
 /* ---- small native helpers kept for finest-grain A/B parity (host memory) -------------------- */
 /* .compareToRow src/computeMI.cpp:25-41: ret[j] = any(x[j,] in y); x is nr x nc column-major */

@@ -62,6 +62,7 @@ _SIGS = {
     "ldw_mi_block": (C.c_int, [_p, _p, _i64, _p, _i64, C.c_int, _p, C.c_int]),
     "ldw_joint_tables": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
     "ldw_mi_all_pairs": (C.c_int, [_p, _p, _i64, C.POINTER(MIParams), C.c_int]),
+    "ldw_build_info": (C.c_int, []),
     "ldw_mi_all_pairs_multi": (C.c_int, [_p, C.c_int, _p, _i64, C.POINTER(MIParams), _p, _p]),
     "ldw_deal_blocks": (C.c_int, [_p, _i64, C.c_int, _p]),
     "ldw_hamming_weights_multi": (C.c_int, [_p, C.c_int, C.c_int32, _p]),
@@ -110,6 +111,8 @@ _SIGS = {
     "ldw_write_links_tsv_begin": (C.c_int, [_p, C.c_int, C.c_char_p, C.c_int, C.c_int]),
     "ldw_write_links_tsv_end": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64)]),
     "ldw_tsv_join": (C.c_int, [_p]),
+    "ldw_lr_stream_begin": (C.c_int, [_p, C.c_char_p, C.c_int, C.c_int]),
+    "ldw_lr_stream_end": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "ldw_compare_to_row": (C.c_int, [_p, _i64, _i64, _p, _i64, _p]),
     "ldw_vec_pos_match": (C.c_int, [_p, _i64, _p, _i64, _p]),
     "ldw_compare_triplet": (C.c_int, [_p, _p, _i64, C.c_double, C.POINTER(C.c_int)]),
@@ -129,6 +132,13 @@ def lib():
             raise FileNotFoundError(
                 f"{LIB_PATH} not found: build it with `make -C ldweaver_amd/csrc` or "
                 "`python -c 'import __graft_entry__ as g; g.build()'` — there is no CPU fallback")
+        # Load order (r05, found by tests/test_bench_flags.py running first): torch bundles its own HIP runtime; if THIS library — and with it
+        # the system's libamdhip64 — is the first of the two in the process, torch's later lazy initialisation finds "No HIP GPUs".  The Python
+        # side uses torch for device memory anyway (engine.py), so torch's runtime goes in first.  (A host without torch, R, has one runtime.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
@@ -136,6 +146,11 @@ def lib():
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+def has_experiments() -> bool:
+    """The loaded library was built with -DLDW_EXPERIMENTS (make EXPERIMENTS=1; LDW_AMD_LIB selects it)."""
+    return bool(lib().ldw_build_info() & 1)
 
 
 def check(code: int):

@@ -225,6 +225,8 @@ int ldw_version(void) { return 100; }
 
 const char *ldw_last_error(void) { return ldw::g_err; }
 
+int ldw_build_info(void) { return LDW_HAS_EXPERIMENTS ? 1 : 0; }
+
 int ldw_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -332,6 +334,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)ldw::join_prepare(c);
     (void)ldw_tsv_join(c);
+    (void)ldw_lr_stream_end(c, nullptr, nullptr, nullptr);
     (void)hipStreamSynchronize(c->stream);
     ldw::DevBuf *bufs[] = {&c->srm_tmp, &c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->apx_skip, &c->snp_sup, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
@@ -507,6 +510,8 @@ int ldw_gemm_stats(ldw_ctx *c, double out[6], int reset) {
 int ldw_set_engine(ldw_ctx *c, int engine) {
     LDW_REQUIRE(c, LDW_ERR_ARG, "null context");
     LDW_REQUIRE(engine == LDW_ENGINE_MFMA || engine == LDW_ENGINE_HIST || engine == LDW_ENGINE_HIST_STATES, LDW_ERR_ARG, "unknown engine %d", engine);
+    LDW_REQUIRE(engine != LDW_ENGINE_HIST_STATES || LDW_HAS_EXPERIMENTS, LDW_ERR_STATE,
+                "LDW_ENGINE_HIST_STATES (the first, byte-state histogram kernel: ~200x slower, kept as a cross-check) is only in the LDW_EXPERIMENTS build");
     c->engine = engine;
     return LDW_OK;
 }
@@ -758,7 +763,7 @@ int ldw_set_weights(ldw_ctx *c, const double *hdw, int64_t N, int nlimbs) {
     c->have_weights = true;
     c->rows_ready = false;
     c->tab11_lo[0] = c->tab11_lo[1] = 0;   // the threshold tables belong to the old weights
-    c->tab11_on = getenv("LDW_NO_TAB11") == nullptr;
+    c->tab11_on = ldw::exp_env("LDW_NO_TAB11") == nullptr;
     return LDW_OK;
 }
 

@@ -96,7 +96,7 @@ int prepare_apx_weights(ldw_ctx *c) {
             delta = std::max(delta, std::fabs((double)(Va - V)) / (double)V);
         }
     };
-    static const int force_gran = [] { const char *e = getenv("LDW_APX_GRAN"); return e ? atoi(e) : 0; }();   // 1 / 4: force fine / coarse (A/B)
+    static const int force_gran = [] { const char *e = exp_env("LDW_APX_GRAN"); return e ? atoi(e) : 0; }();   // 1 / 4: force fine / coarse (A/B)
     assign(force_gran == 1 ? 1 : 4);
     c->apx_fine = force_gran == 1;
     if (force_gran == 0 && delta > 1.5e-3) {
@@ -205,7 +205,7 @@ static bool apx_kernel_is_lds() {
     // "reg" (default): operands expanded in registers per wave; "lds": expansion shared through LDS (r03 experiment: correct, and
     // 28 % slower — 0.659 vs 0.515 ms per C4 launch — because the fragment reads + table reads + tile writes make it LDS-bound)
     static const bool lds = [] {
-        const char *e = getenv("LDW_APX_KERNEL");
+        const char *e = exp_env("LDW_APX_KERNEL");
         return e && e[0] == 'l';
     }();
     return lds;
@@ -544,6 +544,7 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
         apx_gemm_epilogue<MT, NT>(P, acc, ty, tx, lane, s_tab, reinterpret_cast<uint8_t *>(s_tab + 64 * 64) + wave * 256);
     }
 }
+#ifdef LDW_EXPERIMENTS
 // ------------------------------------------------------------------------------------------------
 // gemm_apx_pipe_kernel (r03 experiment, LDW_APX_KERNEL=pipe; coarse exponents only): the register-expansion kernel with the expansion
 // of k-step s + 1 SOFTWARE-PIPELINED under the MFMAs of k-step s, at a dependency distance of three MFMA slots: slot k of a step
@@ -823,6 +824,8 @@ __global__ __launch_bounds__(512, 1) void gemm_apx_lds_kernel(ApxGemmArgs P) {
     apx_gemm_epilogue<MT, NT>(P, acc, ty, tx, lane, s_tab, reinterpret_cast<uint8_t *>(s_tab + 64 * 64) + wave * 256);
 }
 
+#endif   // LDW_EXPERIMENTS
+
 int launch_apx_live_tiles(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     LDW_REQUIRE(P.fuse && P.skip_ctr && P.tile_list && P.n_live && P.RTpad % 128 == 0 && P.RFpad % 64 == 0 && P.tab && P.tab_nb == 64,
                 LDW_ERR_ARG, "launch_apx_live_tiles: bad pruning arguments");
@@ -838,11 +841,12 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     LDW_REQUIRE(lds <= 65536, LDW_ERR_ARG, "launch_gemm_apx: %d positions do not fit the LDS digit arrays", P.M2 * 128);
     LDW_REQUIRE(!P.fuse || (P.tab_nb == 64 && P.bin_t && P.bin_f && P.tab && P.clean), LDW_ERR_ARG, "launch_gemm_apx: bad table arguments");
     static const int tile = [] {
-        const char *e = getenv("LDW_APX_TILE");   // tuning: wave tile in MFMA tiles, to side x from side (default 4 x 2)
+        const char *e = exp_env("LDW_APX_TILE");   // tuning: wave tile in MFMA tiles, to side x from side (default 4 x 2)
         return e ? atoi(e) : 42;
     }();
+#ifdef LDW_EXPERIMENTS
     const int kern = apx_kernel_is_lds() ? 1 : 0;
-    static const bool pipe = [] { const char *e = getenv("LDW_APX_KERNEL"); return e && e[0] == 'p'; }();
+    static const bool pipe = [] { const char *e = exp_env("LDW_APX_KERNEL"); return e && e[0] == 'p'; }();
     if (pipe && !P.fine && tile == 42) {
         const int ntx = P.RFpad / 64, nty = P.RTpad / 128;
         hipLaunchKernelGGL(gemm_apx_pipe_kernel, dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P);
@@ -877,6 +881,7 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
         c->gemm_stat[1] += 2.0 * (double)waves * 128 * 64 * ((double)P.M2 * 128.0);
         return LDW_OK;
     }
+#endif   // LDW_EXPERIMENTS
 #define LDW_APX_LAUNCH(MTv, NTv)                                                                                              \
     {                                                                                                                         \
         const int ntx = P.RFpad / (32 * NTv), nty = P.RTpad / (32 * MTv);                                                     \
@@ -888,8 +893,11 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
         const int tiles = (P.RTpad / 128) * (P.RFpad / 64), g = (tiles + 3) / 4;   // (the list is made by launch_apx_live_tiles)
         if (P.fine) hipLaunchKernelGGL((gemm_apx_kernel<4, 2, true>), dim3((unsigned)g), dim3(256), lds, st, P);
         else hipLaunchKernelGGL((gemm_apx_kernel<4, 2, false>), dim3((unsigned)g), dim3(256), lds, st, P);
-    } else if (tile == 22 && !P.fuse) LDW_APX_LAUNCH(2, 2)          // (the table epilogue assumes 64 from-rows per wave: NT = 2)
+    }
+#ifdef LDW_EXPERIMENTS
+    else if (tile == 22 && !P.fuse) LDW_APX_LAUNCH(2, 2)          // (the table epilogue assumes 64 from-rows per wave: NT = 2)
     else if (tile == 24 && !P.fuse) LDW_APX_LAUNCH(2, 4)
+#endif
     else LDW_APX_LAUNCH(4, 2)
 #undef LDW_APX_LAUNCH
     LDW_HIP(hipGetLastError());

@@ -26,6 +26,7 @@ using namespace ldw;
 
 namespace ldw {
 
+#ifdef LDW_EXPERIMENTS   // (k_mi_hist, LDW_ENGINE_HIST_STATES: the r01 byte-state kernel, kept as the record and an independent cross-check)
 constexpr int HS = 256;  // sequences per LDS chunk
 constexpr int HB = 4;    // to-side SNPs handled one after the other by each thread
 
@@ -144,6 +145,8 @@ int launch_hist(ldw_ctx *c, const int32_t *idx_f, int nf, const int32_t *idx_t, 
     LDW_HIP(hipGetLastError());
     return LDW_OK;
 }
+
+#endif   // LDW_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // k_cooc_popc: G[t][f] = sum_s V_s [row t has s][row f has s], exact, by popcounts over the weight classes.

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <atomic>
 #include <memory>
@@ -15,7 +16,27 @@
 // lists the main stream is evaluating; every per-block buffer exists once per slot (block b uses slot b % LDW_NSLOT).
 #define LDW_NSLOT 3
 
+// LDW_EXPERIMENTS (make EXPERIMENTS=1 -> libldweaver_amd_exp.so): the measured-slower variants kept as the record of what was tried — the
+// pipelined and LDS-shared approximate GEMMs, the fused GEMM + epilogue kernel, the byte-state histogram kernel, corner spans, the split
+// diagonal blocks, the list-driven screen — and the environment switches that select them.  The DEFAULT library holds none of it: the
+// entry points that would select a variant return LDW_ERR_STATE, the switches are not read (ldw::exp_env).
+#ifdef LDW_EXPERIMENTS
+#define LDW_HAS_EXPERIMENTS 1
+#else
+#define LDW_HAS_EXPERIMENTS 0
+#endif
+
 namespace ldw {
+
+// an environment switch of the experiments build (null in the default library, whatever the environment says)
+inline const char *exp_env(const char *name) {
+#ifdef LDW_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what, const char *file, int line);
@@ -202,6 +223,7 @@ struct ldw_ctx {
     int64_t blk_capacity = 0, blk_cursor = 0;  // ldw_links_begin / ldw_mi_block_links / ldw_links_end
 
     // ---- short-range model and ARACNE on the device-resident sr table (ldw_srp.hip) ----
+    void *lr_stream = nullptr;   // r05: lr_links.tsv appended while the pass runs (ldw_tsv.cpp: LrStream), if ldw_lr_stream_begin opened one
     void *tsv_async = nullptr;   // r04: the asynchronous link-table writer, if one is running (ldw_tsv.cpp: TsvAsync)
     void *pin_fetch = nullptr;   // r04: pinned host arena the tsv writer fetches a link table into (see ldw_write_links_tsv)
     size_t pin_fetch_cap = 0;
@@ -266,6 +288,8 @@ int fill_rows_bits(ldw_ctx *ctx, const int32_t *d_rowinfo, int64_t R);
 int prepare_apx_weights(ldw_ctx *ctx);   // ldw_apx.hip: dual digits, exponents, popcount segments from h_vfixed / h_seq_perm
 int check_gpu(ldw_ctx *ctx);
 int ensure_hi_marginals(ldw_ctx *ctx);   // slot_pfix_hi on demand (mixed-precision path)
+void lr_stream_push(ldw_ctx *ctx, hipStream_t s, const int64_t *d_lr_count, int64_t blocks_done);   // ldw_tsv.cpp: no-ops without an open stream
+void lr_stream_drain(ldw_ctx *ctx);
 int join_prepare(ldw_ctx *ctx);      // waits for the side thread of ldw_ctx_reserve (no-op without one); its error, if any, becomes the caller's
 int reserve_slot_buffers(ldw_ctx *ctx, int64_t Npad, int64_t blk, int64_t nseg);   // ldw_mi.hip: per-slot device buffers from the block geometry
 int ensure_streams(ldw_ctx *ctx);    // the copy / GEMM streams, per-slot events and pinned pick records of the all-pairs loop (once per context)

@@ -731,6 +731,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LDW_SCREEN_
     screen_wg<RM, APX>(A, perm_f, perm_t, units, n_units, list_stride, cm, (int)blockIdx.x, (int)blockIdx.y);
 }
 
+#ifdef LDW_EXPERIMENTS
 // r04: LIST-DRIVEN.  Three quarters of the (tile, column group) combinations of a long-range block have nothing to screen — all four of their
 // regions flagged clean by the GEMM's epilogue or pruned with their tile, or every column dead against the tile's kind — and each of them still
 // cost a workgroup dispatch (~4 ns: the floor of the full-grid kernel was 47 us per 10k x 10k block, 0.33 ms per span of seven, with every
@@ -833,6 +834,8 @@ __global__ __launch_bounds__(256) void k_screen_live(EpiArgs A, const int32_t *_
         }
     }
 }
+
+#endif   // LDW_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // k_mi_screen_generic: the fp32 screen for the units k_mi_screen leaves out — a from-tile or a column whose SNPs have >= 3
@@ -2126,9 +2129,13 @@ int launch_block_mi(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int RF
     if (c->engine == LDW_ENGINE_HIST_STATES) {
         LDW_HIP(hipEventRecord(ev[0], c->stream));
         LDW_HIP(hipEventRecord(ev[1], c->stream));
+#ifdef LDW_EXPERIMENTS
         if (int rc = launch_hist(c, D.idx_f, (int)nf, D.idx_t, (int)nt, c->pfix_state.as<int64_t>(), quirk, E.lower_only,
                                  c->MIblk.as<double>()))
             return rc;
+#else
+        LDW_REQUIRE(false, LDW_ERR_STATE, "LDW_ENGINE_HIST_STATES is not part of this build (LDW_EXPERIMENTS)");   // (unreachable: ldw_set_engine refuses)
+#endif
         if (E.cols) {
             hipLaunchKernelGGL(k_post_mi, egrid, dim3(256), 0, c->stream, E, D.idx_f, D.idx_t, (int)nt, ghist);
             LDW_HIP(hipGetLastError());
@@ -2300,7 +2307,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     const bool need_exact = E.any_sr || !use_pairs || lo_h->band_full;
     // (an SR sub-pass only ever lists units that hold a short-range pair: the band's tiles are all the exact GEMM has to cover)
     const uint8_t *band = ((use_pairs || lo_h->sr_sub) && !lo_h->band_full) ? D.band_mask : nullptr;
-    static const bool band_early_env = getenv("LDW_BAND_LATE") == nullptr;
+    static const bool band_early_env = exp_env("LDW_BAND_LATE") == nullptr;
     // r04: the exact band GEMM in phase 1, on the GEMM stream (an SR sub-pass runs both phases on one stream anyway) — for alignments of at
     // least 4096 sequences, where the GEMMs are long: see screen_main below
     const int64_t swap_kw = [] { const char *e = getenv("LDW_QUEUE_SWAP_KW"); return e ? (int64_t)atol(e) : (int64_t)64; }();   // (per call: the tests lower it)
@@ -2376,7 +2383,7 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
         A.tab_c = c->tab11_c;
     }
     // long-range-only blocks: the GEMM applies the table itself and neither stores nor lets the screen read the regions that pass
-    static const bool fuse_on = getenv("LDW_NO_FUSE_TAB") == nullptr;
+    static const bool fuse_on = exp_env("LDW_NO_FUSE_TAB") == nullptr;
     const bool fuse = fuse_on && lo_h->fuse_ok && A.tab11 && A.tab_nb == 64 && (use_pairs || c->screen == 2) && E.do_lr && (!E.any_sr || (D.band_mask && !lo_h->band_full)) && RFpad % 64 == 0 &&   // (verify mode: the clean regions' units are listed as dismissed and checked in fp64)
                       2048 + (size_t)(c->KW / 2) * 256 + 64 * 64 * 8 + 1024 <= 65536;   // (the table shares the GEMM's LDS with the digit arrays)
     uint8_t *bin_t = B_bins.as<uint8_t>(), *bin_f = bin_t + RTpad;
@@ -2518,21 +2525,22 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
     // 34.0; C5 819 against 824 ms, 3 misses per pass either way).  Only where the GEMMs are long (N >= 4096): at 85k x 616 the approximate GEMM
     // is 2.7 ms of a 19-ms pass, the GEMM queue would idle and the main queue carry everything — 20.9 / 21.1 against 19.3 / 19.1 ms — so short
     // alignments keep the old places.  LDW_SCREEN_GEMMQ=1 / LDW_BAND_LATE=1 restore them for any size.
-    static const bool screen_main_env = getenv("LDW_SCREEN_GEMMQ") == nullptr;
+    static const bool screen_main_env = exp_env("LDW_SCREEN_GEMMQ") == nullptr;
     const bool screen_main = screen_main_env && !lo_h->sr_sub && c->KW >= swap_kw;
     const int rm_s = quirk == LDW_QUIRK_REFERENCE ? (lo_h->span ? 3 : (nf == nt ? 1 : 2)) : 0;
+#ifdef LDW_EXPERIMENTS
     // r04 experiment: list-driven screen (k_screen_tiles -> k_screen_live -> k_mi_screen_list) instead of one workgroup per (tile, column group)
     // (measured r04, C4, 10 cold steps per setting on one box: full grid 36.9 ms per pass, list-driven with 1536 / 4096 / 12288 / 32768 striding
     // workgroups 38.2 / 37.0 / 36.0 / 37.0: no gain — the dispatcher balances 86k short workgroups better than a strided list does, and the
-    // two list kernels cost what the empty workgroups did; kept behind LDW_SCREEN_LIST=1)
-    static const bool screen_list = getenv("LDW_SCREEN_LIST") != nullptr;
+    // two list kernels cost what the empty workgroups did; kept behind LDW_SCREEN_LIST=1 in the experiments build)
+    static const bool screen_list = exp_env("LDW_SCREEN_LIST") != nullptr;
     const size_t o_ts = 64, o_live = o_ts + ((size_t)egrid.x * sizeof(TileState) + 63) / 64 * 64;
     if (screen_list)
         if (int rc = B_live.reserve(o_live + (size_t)egrid.x * egrid.y * 4 + 64)) return rc;
     unsigned int *n_live_scr = screen_list ? B_live.as<unsigned int>() : nullptr;
     TileState *ts_scr = screen_list ? reinterpret_cast<TileState *>(B_live.as<char>() + o_ts) : nullptr;
     uint32_t *live_scr = screen_list ? reinterpret_cast<uint32_t *>(B_live.as<char>() + o_live) : nullptr;
-    static const size_t lgrid_max = [] { const char *e = getenv("LDW_SCREEN_GRID"); return e ? (size_t)atol(e) : (size_t)1536; }();
+    static const size_t lgrid_max = [] { const char *e = exp_env("LDW_SCREEN_GRID"); return e ? (size_t)atol(e) : (size_t)1536; }();
     const unsigned lgrid = (unsigned)std::min<size_t>((size_t)egrid.x * egrid.y, lgrid_max);
 #define LDW_SCREEN(RMv, ST)                                                                                                                       \
     do {                                                                                                                                          \
@@ -2545,6 +2553,10 @@ int launch_block_apx(ldw_ctx *c, const DevPtrs &D, int64_t nf, int64_t nt, int R
             hipLaunchKernelGGL((k_mi_screen<RMv, true>), egrid, dim3(256), 0, ST, A, D.perm, D.perm_t, units, n_units, list_stride);                \
         }                                                                                                                                         \
     } while (0)
+#else
+    (void)B_live;
+#define LDW_SCREEN(RMv, ST) hipLaunchKernelGGL((k_mi_screen<RMv, true>), egrid, dim3(256), 0, ST, A, D.perm, D.perm_t, units, n_units, list_stride)
+#endif
     if (phase == 1) {
         if (!screen_main) {
             if (rm_s == 0) LDW_SCREEN(0, gs);
@@ -2719,6 +2731,8 @@ int ensure_links_capacity(ldw_ctx *c, int64_t sr_rows, int64_t lr_rows) {
     if (int rc = c->sr_b.reserve_keep((size_t)sr_rows * 4, (size_t)c->n_sr * 4, c->stream)) return rc;
     if (int rc = c->sr_mi.reserve_keep((size_t)sr_rows * 8, (size_t)c->n_sr * 8, c->stream)) return rc;
     if (grow_sr) LDW_HIP(hipStreamSynchronize(c->stream));
+    if (c->lr_stream && ((size_t)lr_rows * 8 > c->lr_mi.cap || (size_t)lr_rows * 4 > c->lr_a.cap || (size_t)lr_rows * 4 > c->lr_b.cap))
+        lr_stream_drain(c);   // (the writer thread reads these buffers on its own stream: everything handed over is on disk before they move)
     if (int rc = c->lr_a.reserve_keep((size_t)lr_rows * 4, (size_t)c->n_lr * 4, c->stream)) return rc;
     if (int rc = c->lr_b.reserve_keep((size_t)lr_rows * 4, (size_t)c->n_lr * 4, c->stream)) return rc;
     if (int rc = c->lr_mi.reserve_keep((size_t)lr_rows * 8, (size_t)c->n_lr * 8, c->stream)) return rc;
@@ -3212,7 +3226,7 @@ int make_emit_args(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const Smal
         E.apx = 1;
         E.apx_EG = (float)(c->apx_lost_units * 1.001);
         E.apx_dfac = (float)(1.01 * c->apx_delta / (1.0 - c->apx_delta));
-        static const bool r02_bound = getenv("LDW_SCREEN_R02_BOUND") != nullptr;   // A/B: the bound without the totals argument
+        static const bool r02_bound = exp_env("LDW_SCREEN_R02_BOUND") != nullptr;   // A/B: the bound without the totals argument
         E.apx_unit = std::ldexp(1.0, c->apx_e_last - c->frac_bits);
         E.apx_s1 = (float)(E.apx_unit * (2.0 * std::log(den + 12.5) + (r02_bound ? 3.1 : 2.1)) / (1.0 - c->apx_delta) * 1.01);
         E.apx_c1 = r02_bound ? 1.02f : 0.02f;
@@ -3309,7 +3323,7 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
         // one guess serves every reference block of the span, and the next guess only arrives after all of them: LDW_SPAN_MARGIN=k lowers it by k
         // more buckets.  Not needed: at C5 (800 kept rows per block, the noisiest thresholds) 3 of 1275 blocks miss per pass with k = 0, as many
         // as block by block, and k = 4 lists 40 % more pairs (858 against 846 ms per pass)
-        static const int extra_env = [] { const char *e = getenv("LDW_SPAN_MARGIN"); return e ? atoi(e) : -1; }();
+        static const int extra_env = [] { const char *e = exp_env("LDW_SPAN_MARGIN"); return e ? atoi(e) : -1; }();
         const int extra = extra_env >= 0 ? extra_env : 0;
         guess = guess > extra ? guess - extra : 1;
     }
@@ -3417,7 +3431,11 @@ int submit_a(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLayou
     F.ghist = c->hist[s].as<unsigned long long>();
     fill_epi_args(c, hb.D, hb.nf, hb.nt, hb.RFpad, p->quirk_mode, hb.E, nullptr, F.A);
     LDW_HIP(hipEventRecord(ev[0], gs));
+#ifdef LDW_EXPERIMENTS
     if (int rc = launch_fused(c, F, hb.RFpad, hb.RTpad, c->nlimbs, gs)) return rc;
+#else
+    LDW_REQUIRE(false, LDW_ERR_STATE, "the fused kernel is not part of this build (LDW_EXPERIMENTS)");   // (unreachable: ldw_set_fused refuses)
+#endif
     LDW_HIP(hipEventRecord(ev[1], gs));
     LDW_HIP(hipEventRecord(ev[4], gs));
     LDW_HIP(hipEventRecord(ev[2], gs));
@@ -3803,7 +3821,7 @@ int finish_span(ldw_ctx *c, HostBlock &hb, const ldw_mi_params *p, const SmallLa
         }
     }
     // the common case — every guess held, every candidate set fits the sort-free selection — takes ONE launch per stage for all segments
-    static const bool sel_fast_on = getenv("LDW_NO_FAST_SELECT") == nullptr && getenv("LDW_NO_SPAN_SELECT") == nullptr;
+    static const bool sel_fast_on = getenv("LDW_NO_FAST_SELECT") == nullptr && exp_env("LDW_NO_SPAN_SELECT") == nullptr;
     bool batched = sel_fast_on && c->select_mode == 0;
     long long m_max = 0, m_sum = 0;
     for (int k = 0; k < hb.span && batched; ++k) {
@@ -4022,11 +4040,11 @@ int ensure_streams(ldw_ctx *c) {
             // small latency-bound kernels that should be dispatched as soon as they are ready: lowest priority for this stream
             int lo_p = 0, hi_p = 0;
             LDW_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-            static const bool prio = getenv("LDW_NO_STREAM_PRIO") == nullptr;
+            static const bool prio = exp_env("LDW_NO_STREAM_PRIO") == nullptr;
             // LDW_CU_RESERVE=m (odd, experiment): the GEMM stream may not use every m-th CU, so that the main stream's chain of small
             // kernels always finds free CUs while a block-wide kernel runs (an odd modulus spreads the reserved CUs over the XCDs
             // whether the mask bits run XCD by XCD or interleave them)
-            static const int cu_mod = [] { const char *e = getenv("LDW_CU_RESERVE"); return e ? atoi(e) : 0; }();
+            static const int cu_mod = [] { const char *e = exp_env("LDW_CU_RESERVE"); return e ? atoi(e) : 0; }();
             if (cu_mod >= 3 && (cu_mod & 1)) {
                 int cus = 256;
                 (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
@@ -4326,7 +4344,7 @@ static int span_candidate(const ldw_ctx *c, const int32_t *b, const ldw_mi_param
     // serialized kernel time fell from 36.6 to 35.2 ms — 20 large items instead of 28 alternate "diagonal block, span of eight" and the two queues no
     // longer fill each other's gaps (profiles/r04_timeline_corner_spans.txt) — so corner blocks stay items of their own unless LDW_SPAN_CORNERS=1 /
     // ldw_set_span(.., corners) asks for them (kept, tested: test_spans_equal_block_by_block runs both)
-    static const bool corners_env = getenv("LDW_SPAN_CORNERS") != nullptr;
+    static const bool corners_env = exp_env("LDW_SPAN_CORNERS") != nullptr;
     if (!corners_env && !c->span_corners) return 0;
     // short-range pairs of the block: POS ascends, so they sit where the two ranges face each other (directly, or across the origin)
     auto count_le = [&](int64_t lo, int64_t hi, double v) { return (int64_t)(std::upper_bound(P.begin() + (lo - 1), P.begin() + hi, (int32_t)std::floor(v)) - (P.begin() + (lo - 1))); };
@@ -4345,7 +4363,7 @@ static bool spans_possible(const ldw_ctx *c, const ldw_mi_params *p) {
 // r04c: a DIAGONAL block can run as SR sub-pass (list order: band GEMM + whole units) + long-range pass with its rows ordered by weight like any
 // long-range-only block (tile pruning, clean regions), the short-range pairs kept out of its candidates: LDW_DIAG_SPLIT=1 / ldw_set_span(on | 4)
 static bool diag_split_ok(const ldw_ctx *c, const int32_t *b) {
-    static const bool env_on = getenv("LDW_DIAG_SPLIT") != nullptr;
+    static const bool env_on = exp_env("LDW_DIAG_SPLIT") != nullptr;
     if (!env_on && !c->diag_split) return false;
     const int64_t fs = b[0], fe = b[1];
     if (!(b[2] == fs && b[3] == fe) || fe - fs + 1 < 2048) return false;
@@ -4437,6 +4455,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         std::vector<uint8_t> prepped;                              // per item (helpers finish out of order)
         bool plan_final = false;
         int rc = LDW_OK;
+        int64_t bad = INT64_MAX;             // the first item whose preparation failed (items before it are still good: r05)
         bool stop = false, probing = true;   // probing: the cold-start probes (calling thread) still use the last slot's staging buffer
         std::string err;
     } sh;
@@ -4539,10 +4558,11 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
             }
             std::lock_guard<std::mutex> lk(sh.m);
             if (rc != LDW_OK) {
-                if (sh.rc == LDW_OK) {
+                if (sh.rc == LDW_OK || k < sh.bad) {
                     sh.rc = rc;
                     sh.err = ldw_last_error();
                 }
+                sh.bad = std::min(sh.bad, k);
                 sh.stop = true;
             } else {
                 sh.prepped[(size_t)k] = 1;
@@ -4551,7 +4571,7 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
             if (rc != LDW_OK) return;
         }
     };
-    static const int n_helpers = [] { const char *e = getenv("LDW_HELPERS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 3 ? 3 : v); }();
+    static const int n_helpers = [] { const char *e = exp_env("LDW_HELPERS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 3 ? 3 : v); }();
     std::thread helpers[3];
     for (int i = 0; i < n_helpers; ++i) helpers[i] = std::thread(worker);
     struct Joiner {   // every way out of this function stops and joins the helpers
@@ -4640,8 +4660,10 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
     // blocks until item k is prepared (true) — or, with wait = false, says whether it is
     auto prepped = [&](int64_t k, bool wait, int &rc) -> bool {
         std::unique_lock<std::mutex> lk(sh.m);
-        if (wait) sh.cv.wait(lk, [&] { return sh.rc != LDW_OK || sh.prepped[(size_t)k] != 0; });
-        rc = sh.rc;
+        // (a failure of a LATER item does not concern this one: the helpers take the items in order, so every item before the failed one is
+        // prepared or being prepared — the pass runs on to the failed item itself, like the reference's loop: R/computePairwiseMI.R:103-116)
+        if (wait) sh.cv.wait(lk, [&] { return (sh.rc != LDW_OK && k >= sh.bad) || sh.prepped[(size_t)k] != 0; });
+        rc = (sh.rc != LDW_OK && k >= sh.bad) ? sh.rc : LDW_OK;
         if (rc != LDW_OK) set_error("%s", sh.err.c_str());
         return sh.prepped[(size_t)k] != 0;
     };
@@ -4663,10 +4685,21 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         if (rc) return rc;
         if ((rc = submit_next())) return rc;
     }
-    for (int64_t b = 0; b < nitems; ++b) {
+    int fail_rc = LDW_OK;
+    std::string fail_msg;
+    int64_t b_fail = -1;          // the item the loop was at when it failed
+    bool b_fail_submitted = false, b_fail_finished = false;
+    auto failed = [&](int rc, int64_t b, bool sub_b, bool fin) {
+        fail_rc = rc;
+        fail_msg = ldw_last_error();
+        b_fail = b;
+        b_fail_submitted = sub_b;
+        b_fail_finished = fin;
+    };
+    for (int64_t b = 0; b < nitems && fail_rc == LDW_OK; ++b) {
         HostBlock &cur = hb[b % RING];
         double t0 = now();
-        if (int rc = submit_b(c, cur, p, sl)) return rc;                 // unfused: epilogue + pick of item b (main stream)
+        if (int rc = submit_b(c, cur, p, sl)) { failed(rc, b, false, false); break; }   // unfused: epilogue + pick of item b (main stream)
         th[0] += now() - t0;
         t0 = now();
         // items b+1 .. b+ahead (GEMM stream) run beside them: b+1 is waited for, the ones after it are taken if they are ready
@@ -4675,28 +4708,48 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
             const double tw = now();
             const bool ready = prepped(n_sub, n_sub == b + 1, rc);
             th[1] += now() - tw;
-            if (rc) return rc;
+            if (rc) { failed(rc, b, true, false); break; }
             if (!ready || !can_submit_early(c, hb[n_sub % RING], p)) break;
-            if ((rc = submit_next())) return rc;
+            if ((rc = submit_next())) { failed(rc, b, true, false); break; }
         }
+        if (fail_rc != LDW_OK) break;
         th[2] += now() - t0;
         t0 = now();
         // (tried: the second phase of block b+1 queued HERE, before the host waits for block b's pick, so that the main stream has work during the
         // round trip — block b's selection then runs behind it, its slot is released later, and the pass got slower: 43.0 against 40.2 ms)
-        if (int rc = finish_block(c, cur, p, sl)) return rc;             // round trip + selection of item b
+        if (int rc = finish_block(c, cur, p, sl)) { failed(rc, b, true, false); break; }   // round trip + selection of item b
         th[3] += now() - t0;
         {
             std::lock_guard<std::mutex> lk(sh.m);
             sh.n_done = b + 1;
         }
         sh.cv.notify_all();
+        c->blk_cursor += items[(size_t)b].nseg;
+        lr_stream_push(c, c->stream, sl.lr_count, c->blk_cursor);   // (no-op without ldw_lr_stream_begin: the rows of this item may go to lr_links.tsv now)
         if (n_sub <= b + 1 && b + 1 < nitems) {                          // overlap off / no guess yet: one item after the other
             int rc = LDW_OK;
             prepped(b + 1, true, rc);
-            if (rc) return rc;
-            if ((rc = submit_next())) return rc;
+            if (rc) { failed(rc, b, true, true); break; }
+            if ((rc = submit_next())) { failed(rc, b, true, true); break; }
         }
-        c->blk_cursor += items[(size_t)b].nseg;
+    }
+    if (fail_rc != LDW_OK) {
+        // r05: with lr_links.tsv streaming, the items that were submitted before the failure are run to their end, so that the file holds
+        // the rows of EVERY block in front of the failed one — what the reference's loop has appended when it stops at a block (:362).
+        // Best effort: a second failure in here is ignored, the first one is reported.
+        if (c->lr_stream && b_fail >= 0) {
+            for (int64_t bb = b_fail; bb < n_sub; ++bb) {
+                HostBlock &h = hb[bb % RING];
+                if (bb == b_fail && b_fail_finished) continue;
+                if (!(bb == b_fail && b_fail_submitted))
+                    if (submit_b(c, h, p, sl) != LDW_OK) break;
+                if (finish_block(c, h, p, sl) != LDW_OK) break;
+                c->blk_cursor += items[(size_t)bb].nseg;
+                lr_stream_push(c, c->stream, sl.lr_count, c->blk_cursor);
+            }
+        }
+        set_error("%s", fail_msg.c_str());
+        return fail_rc;
     }
     const double t_loop = now0();
     const int rc_end = ldw_links_end(c);
@@ -4750,6 +4803,7 @@ int ldw_sr_pairs_fill(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, double
 
 int ldw_set_span(ldw_ctx *c, int on, int max_blocks) {
     LDW_REQUIRE(c && (max_blocks == 0 || (max_blocks >= 2 && max_blocks <= LDW_SPAN_MAX)), LDW_ERR_ARG, "ldw_set_span: max_blocks must be 0 or 2..%d", LDW_SPAN_MAX);
+    LDW_REQUIRE(!(on & 6) || LDW_HAS_EXPERIMENTS, LDW_ERR_STATE, "ldw_set_span: corner spans / split diagonal blocks (measured slower, r04) are only in the LDW_EXPERIMENTS build");
     c->diag_split = (on & 4) != 0;     // bit 2: diagonal blocks as SR sub-pass + weight-ordered long-range pass
     c->span_corners = (on & 2) != 0;   // bit 1: corner blocks (few short-range pairs) join the spans, their short-range pairs go to SR sub-passes (off by default: slower)
     c->span_on = on != 0;
@@ -4800,6 +4854,7 @@ int ldw_set_mixed(ldw_ctx *c, int on) {
 }
 
 int ldw_set_fused(ldw_ctx *c, int on) {
+    LDW_REQUIRE(!on || LDW_HAS_EXPERIMENTS, LDW_ERR_STATE, "ldw_set_fused(1): the fused GEMM + epilogue kernel (measured slower since r01) is only in the LDW_EXPERIMENTS build");
     LDW_REQUIRE(c, LDW_ERR_ARG, "null context");
     c->fused = on != 0;
     return LDW_OK;

@@ -849,7 +849,7 @@ int ldw_sr_len_quantiles(ldw_ctx *c, int nclust, double sr_dist, double prob, in
         const size_t need[3] = {(size_t)n * 2 + 64, (size_t)n * sizeof(SrPay), srm_sort_temp_bytes(n) + 256};
         void *mem[3];
         size_t tmp_cap;
-        const bool borrow = LDW_NSLOT >= 3 && c->blk_capacity == 0 /* (no link pass open: its slots are really idle) */ && c->Gapx[0].cap >= need[0] && c->Gapx[1].cap >= need[1] && c->Gapx[2].cap >= need[2] && getenv("LDW_SR_QUANT_OWN") == nullptr;
+        const bool borrow = LDW_NSLOT >= 3 && c->blk_capacity == 0 /* (no link pass open: its slots are really idle) */ && c->Gapx[0].cap >= need[0] && c->Gapx[1].cap >= need[1] && c->Gapx[2].cap >= need[2] && ldw::exp_env("LDW_SR_QUANT_OWN") == nullptr;
         const auto t_a = now();
         if (borrow) {
             if (c->gemm_stream) LDW_HIP(hipStreamSynchronize(c->gemm_stream));   // (idle already; the G' blocks belong to that stream's kernels)

@@ -428,8 +428,6 @@ static int links_tsv_prepare(ldw_ctx *c, int which, const char *path, int append
     // mmap'ed, so delete[] is munmap) stalls the process's NEXT GPU call by ~20 ms — the driver quiesces the queues to drop the registration
     // and restores them a moment later; the short-range model's first stream synchronisation after lr_links.tsv paid it in every job.
     const size_t fetch_bytes = (size_t)n * 16;
-    J.derived.reset(new PoolBlock((size_t)n * 32));   // pos1, pos2 (int32), clust1, clust2, len (double)
-    LDW_REQUIRE(J.derived->p != nullptr, LDW_ERR_ARG, "ldw_write_links_tsv: out of host memory");
     if (fetch_bytes <= ((size_t)2 << 30)) {
         if (c->pin_fetch_cap < fetch_bytes) {
             if (c->pin_fetch) (void)hipHostFree(c->pin_fetch);
@@ -462,19 +460,160 @@ static int links_tsv_prepare(ldw_ctx *c, int which, const char *path, int append
     return LDW_OK;
 }
 
-static int links_tsv_finish(LinksTsvJob &J, int64_t *bytes_out) {
+// ---- r05: lr_links.tsv appended WHILE the pass runs (the reference appends per block: R/computePairwiseMI.R:362) ------------------------------
+// The long-range table grows in block order on the device (k_sel_scatter appends at the running count).  After every finished item the
+// submitting thread queues a copy of that count and an event (lr_stream_push); a writer thread of the context waits for the event, fetches
+// the rows that are new since its last batch on a stream of its own, derives pos1 pos2 clust1 clust2 len, formats and appends them.  Rows of
+// finished blocks are final (the filter is per block: :352-358), so what is on disk at any time is a prefix of the reference's file in
+// whole blocks — a pass that fails at block k leaves the rows of blocks 0..k-1, like the reference's loop.
+struct LrStream {
+    static constexpr int RING = 64;
+    ldw_ctx *c = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[RING] = {};
+    int64_t *counts = nullptr;          // pinned [RING]
+    int64_t pushed = 0, consumed = 0;   // ring entries handed over / fully written
+    bool busy = false, closing = false;
+    int64_t rows = 0, bytes = 0;        // written so far
+    int64_t blocks_seen = 0;
+    std::string path, err;
+    int append = 1, nthreads = 0, rc = LDW_OK;
+    bool first_batch = true;
+    void *pin = nullptr;                // pinned staging of a batch (a, b, MI)
+    size_t pin_cap = 0;
+};
+
+static int write_link_rows(const char *path, int append, int nthreads, int64_t n, const int32_t *a, const int32_t *b, double *mi, const int32_t *POS,
+                           const int32_t *paint, double g, int64_t *bytes_out);
+
+static void lr_stream_batch(LrStream *S, int64_t hi) {
+    ldw_ctx *c = S->c;
+    const int64_t lo = S->rows, n = hi - lo;
+    if (n <= 0 || S->rc != LDW_OK) return;
+    const size_t need = (size_t)n * 16;
+    if (S->pin_cap < need) {
+        if (S->pin) (void)hipHostFree(S->pin);
+        S->pin = nullptr;
+        S->pin_cap = 0;
+        const size_t want = std::max<size_t>(need + need / 2, (size_t)4 << 20);
+        if (hipHostMalloc(&S->pin, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            S->rc = LDW_ERR_HIP;
+            S->err = "lr stream: no pinned staging memory";
+            return;
+        }
+        S->pin_cap = want;
+    }
+    double *mi = static_cast<double *>(S->pin);
+    int32_t *a = reinterpret_cast<int32_t *>(mi + n), *b = a + n;
+    // (the table's buffers cannot move under this copy: a growth of the long-range table drains the stream first — ensure_links_capacity)
+    hipError_t e = hipMemcpyAsync(a, c->lr_a.as<int32_t>() + lo, (size_t)n * 4, hipMemcpyDeviceToHost, S->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(b, c->lr_b.as<int32_t>() + lo, (size_t)n * 4, hipMemcpyDeviceToHost, S->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(mi, c->lr_mi.as<double>() + lo, (size_t)n * 8, hipMemcpyDeviceToHost, S->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(S->st);
+    if (e != hipSuccess) {
+        S->rc = LDW_ERR_HIP;
+        S->err = std::string("lr stream: fetching rows failed: ") + hipGetErrorString(e);
+        return;
+    }
+    int64_t wrote = 0;
+    const int rc = write_link_rows(S->path.c_str(), S->first_batch ? S->append : 1, S->nthreads, n, a, b, mi, c->h_POS.data(), c->h_paint.data(), c->g, &wrote);
+    S->first_batch = false;
+    if (rc != LDW_OK) {
+        S->rc = rc;
+        S->err = ldw_last_error();
+        return;
+    }
+    S->rows = hi;
+    S->bytes += wrote;
+}
+
+static void lr_stream_main(LrStream *S) {
+    (void)hipSetDevice(S->c->device);
+    for (;;) {
+        int64_t take_to;
+        {
+            std::unique_lock<std::mutex> lk(S->mu);
+            S->cv.wait(lk, [&] { return S->closing || S->pushed > S->consumed; });
+            if (S->pushed == S->consumed) return;   // closing and nothing left
+            take_to = S->pushed;                    // everything handed over so far: one batch (the newest entry's count covers the older ones)
+            S->busy = true;
+        }
+        const int idx = (int)((take_to - 1) % LrStream::RING);
+        int64_t hi = -1;
+        if (hipEventSynchronize(S->ev[idx]) == hipSuccess) hi = S->counts[idx];
+        else {
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> lk(S->mu);
+            if (S->rc == LDW_OK) {
+                S->rc = LDW_ERR_HIP;
+                S->err = "lr stream: waiting for a finished item failed";
+            }
+        }
+        try {
+            if (hi >= 0) lr_stream_batch(S, hi);
+        } catch (const std::exception &e) {
+            S->rc = LDW_ERR_ARG;
+            S->err = std::string("lr stream: ") + e.what();
+        }
+        {
+            std::lock_guard<std::mutex> lk(S->mu);
+            S->consumed = take_to;
+            S->busy = false;
+        }
+        S->cv.notify_all();
+    }
+}
+
+extern "C++" {
+namespace ldw {
+// called by the item loop after the selection of an item has been QUEUED on `s`: the running long-range row count as it will be once that
+// selection has run, and an event behind it
+void lr_stream_push(ldw_ctx *c, hipStream_t s, const int64_t *d_lr_count, int64_t blocks_done) {
+    LrStream *S = static_cast<LrStream *>(c->lr_stream);
+    if (!S) return;
+    {
+        std::unique_lock<std::mutex> lk(S->mu);
+        S->cv.wait(lk, [&] { return S->pushed - S->consumed < LrStream::RING; });   // (the writer is a whole ring behind: wait for a slot)
+    }
+    const int idx = (int)(S->pushed % LrStream::RING);
+    if (hipMemcpyAsync(&S->counts[idx], d_lr_count, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(S->ev[idx], s) != hipSuccess) {
+        (void)hipGetLastError();
+        return;   // (this item's rows go out with the next one's, or with the final push of ldw_lr_stream_end)
+    }
+    {
+        std::lock_guard<std::mutex> lk(S->mu);
+        ++S->pushed;
+        S->blocks_seen = blocks_done;
+    }
+    S->cv.notify_all();
+}
+// everything handed over so far is on disk when this returns (before the long-range table's buffers are reallocated, and at the end)
+void lr_stream_drain(ldw_ctx *c) {
+    LrStream *S = static_cast<LrStream *>(c->lr_stream);
+    if (!S) return;
+    std::unique_lock<std::mutex> lk(S->mu);
+    S->cv.wait(lk, [&] { return S->pushed == S->consumed && !S->busy; });
+}
+}  // namespace ldw
+}  // extern "C++"
+
+// the rows (a, b, MI) of a link table as the reference's MI_df rows `pos1 pos2 clust1 clust2 len MI` (R/computePairwiseMI.R:319-331), appended to `path`
+static int write_link_rows(const char *path, int append, int nthreads, int64_t n, const int32_t *a, const int32_t *b, double *mi, const int32_t *POS,
+                           const int32_t *paint, double g, int64_t *bytes_out) {
     if (bytes_out) *bytes_out = 0;
-    const int64_t n = J.n;
     if (n == 0) return LDW_OK;
     static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
     const auto t_1 = std::chrono::steady_clock::now();
-    const int32_t *a = J.a, *b = J.b;
-    double *mi = J.mi;
-    double *c1 = J.derived->as<double>(), *c2 = c1 + n, *len = c2 + n;
+    PoolBlock derived((size_t)n * 32);   // pos1, pos2 (int32), clust1, clust2, len (double)
+    LDW_REQUIRE(derived.p != nullptr, LDW_ERR_ARG, "ldw_write_links_tsv: out of host memory");
+    double *c1 = derived.as<double>(), *c2 = c1 + n, *len = c2 + n;
     int32_t *pos1 = reinterpret_cast<int32_t *>(len + n), *pos2 = pos1 + n;
-    const double g = J.g, hg = 0.5 * J.g;
-    const int32_t *POS = J.POS, *paint = J.paint;
-    int nt = (int)std::min<int64_t>(default_threads(J.nthreads), (n + 65535) / 65536);
+    const double hg = 0.5 * g;
+    int nt = (int)std::min<int64_t>(default_threads(nthreads), (n + 65535) / 65536);
     if (nt < 1) nt = 1;
     auto derive = [&](int t) {
         const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
@@ -501,12 +640,20 @@ static int links_tsv_finish(LinksTsvJob &J, int64_t *bytes_out) {
     // (R/estimateCDSDiversity.R:152), len and MI doubles
     std::vector<Col> cols = {{LDW_COL_INT32, pos1}, {LDW_COL_INT32, pos2}, {LDW_COL_DOUBLE, c1}, {LDW_COL_DOUBLE, c2}, {LDW_COL_DOUBLE, len}, {LDW_COL_DOUBLE, mi}};
     const auto t_2 = std::chrono::steady_clock::now();
-    const int rc = write_rows(J.path.c_str(), J.append, n, cols, J.nthreads, bytes_out);
+    const int rc = write_rows(path, append, n, cols, nthreads, bytes_out);
     if (host_timing) {
         auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
-        fprintf(stderr, "[ldw] links tsv (%lld rows): fetch %.2f ms, derive %.2f, format + write %.2f\n", (long long)n, J.fetch_ms, ms(t_1, t_2),
-                ms(t_2, std::chrono::steady_clock::now()));
+        fprintf(stderr, "[ldw] links tsv (%lld rows): derive %.2f ms, format + write %.2f\n", (long long)n, ms(t_1, t_2), ms(t_2, std::chrono::steady_clock::now()));
     }
+    return rc;
+}
+
+static int links_tsv_finish(LinksTsvJob &J, int64_t *bytes_out) {
+    if (bytes_out) *bytes_out = 0;
+    if (J.n == 0) return LDW_OK;
+    static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
+    if (host_timing) fprintf(stderr, "[ldw] links tsv: fetch %.2f ms\n", J.fetch_ms);
+    const int rc = write_link_rows(J.path.c_str(), J.append, J.nthreads, J.n, J.a, J.b, J.mi, J.POS, J.paint, J.g, bytes_out);
     J.derived.reset();
     return rc;
 }
@@ -570,6 +717,69 @@ int ldw_write_links_tsv_begin(ldw_ctx *c, int which, const char *path, int appen
         }
     });
     return LDW_OK;
+}
+
+int ldw_lr_stream_begin(ldw_ctx *c, const char *path, int append, int nthreads) {
+    if (int rc = ldw::check_gpu(c)) return rc;
+    LDW_REQUIRE(path != nullptr, LDW_ERR_ARG, "ldw_lr_stream_begin: null path");
+    LDW_REQUIRE(c->lr_stream == nullptr, LDW_ERR_STATE, "ldw_lr_stream_begin: a stream is already open (ldw_lr_stream_end)");
+    LDW_REQUIRE(c->have_meta && (int64_t)c->h_POS.size() == c->L && (int64_t)c->h_paint.size() == c->L, LDW_ERR_STATE,
+                "ldw_lr_stream_begin: SNP meta data (POS, paint, g) not set");
+    if (!append) {   // (truncate now: a pass that keeps no long-range row writes nothing, like the reference — :360 — but must not leave an old file behind)
+        const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        LDW_REQUIRE(fd >= 0, LDW_ERR_ARG, "cannot open %s: %s", path, strerror(errno));
+        close(fd);
+    }
+    std::unique_ptr<LrStream> S(new LrStream);
+    S->c = c;
+    S->path = path;
+    S->append = 1;
+    S->nthreads = nthreads;
+    LDW_HIP(hipStreamCreateWithFlags(&S->st, hipStreamNonBlocking));
+    bool ok = hipHostMalloc(reinterpret_cast<void **>(&S->counts), sizeof(int64_t) * LrStream::RING, hipHostMallocDefault) == hipSuccess;
+    for (int k = 0; k < LrStream::RING && ok; ++k) ok = hipEventCreateWithFlags(&S->ev[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (auto &e : S->ev)
+            if (e) (void)hipEventDestroy(e);
+        if (S->counts) (void)hipHostFree(S->counts);
+        (void)hipStreamDestroy(S->st);
+        ldw::set_error("ldw_lr_stream_begin: could not create the stream's events / pinned counters");
+        return LDW_ERR_HIP;
+    }
+    LrStream *raw = S.release();
+    raw->th = std::thread(lr_stream_main, raw);
+    c->lr_stream = raw;
+    return LDW_OK;
+}
+
+int ldw_lr_stream_end(ldw_ctx *c, int64_t *rows_out, int64_t *bytes_out, int64_t *blocks_out) {
+    LDW_REQUIRE(c != nullptr, LDW_ERR_ARG, "ldw_lr_stream_end: null context");
+    if (rows_out) *rows_out = 0;
+    if (bytes_out) *bytes_out = 0;
+    if (blocks_out) *blocks_out = 0;
+    LrStream *S = static_cast<LrStream *>(c->lr_stream);
+    if (!S) return LDW_OK;
+    (void)hipSetDevice(c->device);
+    {
+        std::lock_guard<std::mutex> lk(S->mu);
+        S->closing = true;
+    }
+    S->cv.notify_all();
+    if (S->th.joinable()) S->th.join();
+    const int rc = S->rc;
+    if (rows_out) *rows_out = S->rows;
+    if (bytes_out) *bytes_out = S->bytes;
+    if (blocks_out) *blocks_out = S->blocks_seen;
+    if (rc != LDW_OK) ldw::set_error("%s", S->err.c_str());
+    for (auto &e : S->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (S->counts) (void)hipHostFree(S->counts);
+    if (S->pin) (void)hipHostFree(S->pin);
+    if (S->st) (void)hipStreamDestroy(S->st);
+    delete S;
+    c->lr_stream = nullptr;
+    return rc;
 }
 
 int ldw_write_links_tsv_end(ldw_ctx *c, int64_t *rows_out, int64_t *bytes_out) {

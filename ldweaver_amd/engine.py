@@ -137,6 +137,16 @@ class Engine:
         L.check(L.lib().ldw_write_links_tsv(self._ctx, int(which), str(path).encode(), int(bool(append)), int(nthreads), C.byref(n), C.byref(nb)))
         return int(n.value), int(nb.value)
 
+    def lr_stream_begin(self, path: str, append: bool = True, nthreads: int = 0):
+        """lr_links.tsv appended while the next ``mi_all_pairs`` runs, item by item (the reference appends per block: R/computePairwiseMI.R:362)."""
+        L.check(L.lib().ldw_lr_stream_begin(self._ctx, str(path).encode(), int(bool(append)), int(nthreads)))
+
+    def lr_stream_end(self):
+        """Wait for the streaming writer; (rows, bytes, blocks whose rows are in the file)."""
+        n, nb, blk = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        L.check(L.lib().ldw_lr_stream_end(self._ctx, C.byref(n), C.byref(nb), C.byref(blk)))
+        return int(n.value), int(nb.value), int(blk.value)
+
     def write_links_tsv_begin(self, which: int, path: str, append: bool = True, nthreads: int = 0):
         """Fetch the table now, derive / format / write it on host threads while the caller goes on (``write_links_tsv_end`` waits)."""
         L.check(L.lib().ldw_write_links_tsv_begin(self._ctx, int(which), str(path).encode(), int(bool(append)), int(nthreads)))

@@ -197,7 +197,7 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
                            runARACNE=True, perform_SR_analysis_only=False, order_links=True, mega_dset=False, *,
                            engine: Engine | None = None, alignment_resident: bool = False,
                            quirk_mode: int = L.QUIRK_REFERENCE, nlimbs: int = 0, verbose: bool = True,
-                           return_aux: bool = False, sr_model: str = "device", group=None, engines=None):
+                           return_aux: bool = False, sr_model: str = "device", group=None, engines=None, stream_lr: bool = True):
     """Returns the short-range link data.frame (clust_c,pos1,pos2,clust1,clust2,len,MI,srp_max,ARACNE);
     long-range links are appended to ``lr_save_path`` and the returned frame to ``sr_save_path``.
 
@@ -211,7 +211,10 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
     start one process per GPU takes (R through .Call: ``options(ldwamd.devices = 0:7)`` in r_shim/).  Every engine receives the alignment,
     weights and meta data, ``ldw_mi_all_pairs_multi`` deals the block pairs over them inside the library (worker threads, peer-to-peer
     gather into ``engines[0]``), and the short-range model, ARACNE and the files run on ``engines[0]``.  SR-only passes (per-block site
-    filters, :179-189) run on ``engines[0]`` alone."""
+    filters, :179-189) run on ``engines[0]`` alone.
+
+    ``stream_lr`` (r05, default): on one engine ``lr_links.tsv`` is appended while the block loop runs (``ldw_lr_stream_begin`` / ``_end``) like the
+    reference's per-block ``write.table(append = T)`` (:362); ``False`` writes the table after the pass, beside the short-range model (r04)."""
     t000 = time.time()
     say = print if verbose else (lambda *a, **k: None)
     if lr_save_path is None:
@@ -238,6 +241,7 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
     eng = engine or Engine(0)
     inproc = engines is not None and len(engines) > 1 and not perform_SR_analysis_only
     stages = {"lr_links_approx_s": time.time() - t000}
+    lr_stream, streamed = False, None
     try:
         def setup():
             for e in (engines if inproc else [eng]):
@@ -287,13 +291,24 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
             t_s = time.time()
             setup()
             stages["setup_s"] = time.time() - t_s
+            lr_stream = stream_lr and not inproc and not perform_SR_analysis_only
             t_s = time.time()
             if inproc:
                 stages["inproc"] = Engine.mi_all_pairs_multi(engines, blocks, **kw)
                 stages["inproc"]["owner"] = stages["inproc"]["owner"].tolist()
                 stats = eng.block_stats()
             else:
-                stats = _run_blocks(eng, blocks, np.arange(len(blocks)), kw, POS, g)
+                # r05: lr_links.tsv is appended WHILE the pass runs, item by item, as the reference appends it block by block
+                # (R/computePairwiseMI.R:362): a pass that dies leaves the finished blocks' rows, and the file is complete when the pass is
+                if lr_stream:
+                    eng.lr_stream_begin(lr_save_path, append=True)
+                try:
+                    stats = _run_blocks(eng, blocks, np.arange(len(blocks)), kw, POS, g)
+                finally:
+                    if lr_stream:
+                        t_w0 = time.time()
+                        streamed = eng.lr_stream_end()   # (also on failure: what was finished is on disk)
+                        stages["lr_stream_wait_s"] = time.time() - t_w0
             stages["mi_all_pairs_s"] = time.time() - t_s
         # lr_links.tsv (R/computePairwiseMI.R:362) straight from the device-resident table: fetched, derived (pos, clust, len) and
         # formatted by the library's host threads
@@ -301,7 +316,7 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
         # does not touch the long-range table: R/computePairwiseMI.R:119-126); `lr_tsv_s` = what the job waits for it (fetch + the final join)
         t_w = time.time()
         n_lr_rows = 0
-        if not perform_SR_analysis_only:
+        if not perform_SR_analysis_only and not lr_stream:
             eng.write_links_tsv_begin(1, lr_save_path, append=True)
         tsv_s = time.time() - t_w
         t_s = time.time()
@@ -318,9 +333,11 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
             raise ValueError("sr_model must be 'device' or 'host'")
         stages["sr_model_aracne_s"] = time.time() - t_s
         t_w = time.time()
-        if not perform_SR_analysis_only:
+        if not perform_SR_analysis_only and not lr_stream:
             n_lr_rows, _ = eng.write_links_tsv_end()
-        tsv_s += time.time() - t_w
+        elif lr_stream and streamed is not None:
+            n_lr_rows = streamed[0]
+        tsv_s += time.time() - t_w + stages.get("lr_stream_wait_s", 0.0)
         stages["lr_tsv_s"] = tsv_s
         path_report = eng.path_report()
     finally:

@@ -32,6 +32,18 @@ def test_library_exports_every_declared_symbol():
     assert lib.ldw_version() >= 100
 
 
+def test_default_library_is_lean():
+    """the library the package loads by default is the production build — no LDW_EXPERIMENTS kernels or switches
+    (ldw_build_info bit 0 clear), under 8 MB; the experiments build is a separate file (make EXPERIMENTS=1, LDW_AMD_LIB)."""
+    if os.environ.get("LDW_AMD_LIB"):
+        pytest.skip("LDW_AMD_LIB points at another build")
+    assert L.lib().ldw_build_info() == 0 and not L.has_experiments()
+    assert os.path.getsize(L.LIB_PATH) < 8 * 1024 * 1024, os.path.getsize(L.LIB_PATH)
+    syms = os.popen(f"nm -D --defined-only {L.LIB_PATH}").read()
+    for name in ("launch_fused", "launch_hist"):   # (host launchers of experiment kernels; device kernels live in the fat binary)
+        assert name not in syms, name
+
+
 def test_no_cpu_fallback():
     """Without a GPU the context cannot be created and says so; with one the test is vacuous."""
     lib = L.lib()

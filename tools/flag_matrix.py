@@ -16,13 +16,19 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+def _experiments() -> bool:
+    sys.path.insert(0, ROOT)
+    from ldweaver_amd import _lib
+    return _lib.has_experiments()
+
+
 COMBOS = [
     "",
     "--no-mixed",
     "--screen 0",
     "--screen 2",
     "--no-mixed --screen 0",
-    "--fused",
+] + (["--fused"] if _experiments() else []) + [   # (the fused kernel is not in the default library: r05)
     "--no-overlap",
     "--no-mixed --no-overlap",
     "--path 1",
