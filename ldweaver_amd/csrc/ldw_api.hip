@@ -368,6 +368,11 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     if (c->pin_lrc) (void)hipHostFree(c->pin_lrc);
     if (c->ev_lrc) (void)hipEventDestroy(c->ev_lrc);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
+    for (auto &e : c->lr_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->lr_counts) (void)hipHostFree(c->lr_counts);
+    if (c->lr_pin) (void)hipHostFree(c->lr_pin);
+    if (c->lr_st) (void)hipStreamDestroy(c->lr_st);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->gemm_stream) (void)hipStreamDestroy(c->gemm_stream);
     for (auto &e : c->ev_gemm)

@@ -224,6 +224,12 @@ struct ldw_ctx {
 
     // ---- short-range model and ARACNE on the device-resident sr table (ldw_srp.hip) ----
     void *lr_stream = nullptr;   // r05: lr_links.tsv appended while the pass runs (ldw_tsv.cpp: LrStream), if ldw_lr_stream_begin opened one
+    // its device-side resources, made once with the context's other streams (hipStreamCreate is a 12-ms call: not inside a job's pass)
+    hipStream_t lr_st = nullptr;
+    hipEvent_t lr_ev[64] = {};
+    int64_t *lr_counts = nullptr;   // pinned [64]
+    void *lr_pin = nullptr;         // pinned staging of a batch of rows (a, b, MI); grows on demand
+    size_t lr_pin_cap = 0;
     void *tsv_async = nullptr;   // r04: the asynchronous link-table writer, if one is running (ldw_tsv.cpp: TsvAsync)
     void *pin_fetch = nullptr;   // r04: pinned host arena the tsv writer fetches a link table into (see ldw_write_links_tsv)
     size_t pin_fetch_cap = 0;

@@ -4056,6 +4056,12 @@ int ensure_streams(ldw_ctx *c) {
             else LDW_HIP(hipStreamCreateWithFlags(&c->gemm_stream, hipStreamNonBlocking));
         }
         for (int k = 0; k < LDW_NSLOT; ++k) LDW_HIP(hipEventCreateWithFlags(&c->ev_gemm[k], hipEventDisableTiming));
+        // r05: what the streaming lr_links.tsv writer needs on the device side (ldw_lr_stream_begin): made here, not inside a job
+        LDW_HIP(hipStreamCreateWithFlags(&c->lr_st, hipStreamNonBlocking));
+        for (auto &e : c->lr_ev) LDW_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        LDW_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->lr_counts), sizeof(int64_t) * 64, hipHostMallocDefault));
+        c->lr_pin_cap = (size_t)32 << 20;   // (2 M rows: a batch of eight items of a C4 pass is 0.2-0.6 M)
+        LDW_HIP(hipHostMalloc(&c->lr_pin, c->lr_pin_cap, hipHostMallocDefault));
     }
     return LDW_OK;
 }
@@ -4426,6 +4432,18 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         c->sr_total_dist = p->sr_dist;
         }
         if (int rc = ensure_links_capacity(c, total_sr + 1024, 0)) return rc;
+    }
+    if (!p->sr_only) {
+        // r05: the long-range table sized ONCE as well.  The per-block filter keeps about lr_retain_links rows in all (R/computePairwiseMI.R:347-358:
+        // prob = 1 - lr_retain_links / lr_links_approx), and what a selection needs beyond the rows kept so far is its own candidate count (<= 2^20 on
+        // the sort-free path): 1.25 lr_retain_links + 4 M rows, at most the pass's pairs.  A fresh context grew the table nine times in its first
+        // pass — each time a stream synchronisation, and with lr_links.tsv streaming (ldw_lr_stream_begin) a wait for the writer thread on top
+        // (tools/lr_stream_probe.py: first pass 72-88 ms against 41).  Whatever this under-estimates still grows where it is used.
+        double tot_pairs = 0;
+        for (int64_t b = 0; b < nblocks; ++b) tot_pairs += (double)(blocks[b * 4 + 1] - blocks[b * 4 + 0] + 1) * (double)(blocks[b * 4 + 3] - blocks[b * 4 + 2] + 1);
+        const double want = std::min(tot_pairs, std::max(0.0, p->lr_retain_links) * 1.25 + (double)(4 << 20));
+        if (want < 4e9)
+            if (int rc = ensure_links_capacity(c, c->n_sr, (int64_t)want)) return rc;
     }
     // Software pipeline, three ITEMS deep on the host (an item = one block, or a span of consecutive long-range-only blocks of one block
     // row: r04): item i's epilogue chain is submitted (main stream), then at once the block-wide pass of item i+1 (GEMM stream; prepared

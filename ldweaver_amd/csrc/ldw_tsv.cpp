@@ -472,18 +472,20 @@ struct LrStream {
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
-    hipStream_t st = nullptr;
-    hipEvent_t ev[RING] = {};
+    hipStream_t st = nullptr;           // the context's lr_st / lr_ev / lr_counts (ensure_streams)
+    hipEvent_t *ev = nullptr;
     int64_t *counts = nullptr;          // pinned [RING]
     int64_t pushed = 0, consumed = 0;   // ring entries handed over / fully written
     bool busy = false, closing = false;
+    int drain_req = 0;                  // > 0: someone waits in lr_stream_drain: write what there is, whatever the batch size
+    static constexpr int BATCH_ITEMS = 8;   // items per batch while the pass runs (every HIP call of this thread contends with the submitting thread's
+                                            // ~600 launches per pass for the runtime's locks: a batch per item cost the C4 pass 5-12 ms, r05)
     int64_t rows = 0, bytes = 0;        // written so far
     int64_t blocks_seen = 0;
     std::string path, err;
     int append = 1, nthreads = 0, rc = LDW_OK;
     bool first_batch = true;
-    void *pin = nullptr;                // pinned staging of a batch (a, b, MI)
-    size_t pin_cap = 0;
+    bool closing_seen = false;          // (the writer's own copy of `closing`, read outside the lock)
 };
 
 static int write_link_rows(const char *path, int append, int nthreads, int64_t n, const int32_t *a, const int32_t *b, double *mi, const int32_t *POS,
@@ -494,20 +496,20 @@ static void lr_stream_batch(LrStream *S, int64_t hi) {
     const int64_t lo = S->rows, n = hi - lo;
     if (n <= 0 || S->rc != LDW_OK) return;
     const size_t need = (size_t)n * 16;
-    if (S->pin_cap < need) {
-        if (S->pin) (void)hipHostFree(S->pin);
-        S->pin = nullptr;
-        S->pin_cap = 0;
-        const size_t want = std::max<size_t>(need + need / 2, (size_t)4 << 20);
-        if (hipHostMalloc(&S->pin, want, hipHostMallocDefault) != hipSuccess) {
+    if (c->lr_pin_cap < need) {
+        if (c->lr_pin) (void)hipHostFree(c->lr_pin);
+        c->lr_pin = nullptr;
+        c->lr_pin_cap = 0;
+        const size_t want = std::max<size_t>(need + need / 2, (size_t)8 << 20);
+        if (hipHostMalloc(&c->lr_pin, want, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             S->rc = LDW_ERR_HIP;
             S->err = "lr stream: no pinned staging memory";
             return;
         }
-        S->pin_cap = want;
+        c->lr_pin_cap = want;
     }
-    double *mi = static_cast<double *>(S->pin);
+    double *mi = static_cast<double *>(c->lr_pin);
     int32_t *a = reinterpret_cast<int32_t *>(mi + n), *b = a + n;
     // (the table's buffers cannot move under this copy: a growth of the long-range table drains the stream first — ensure_links_capacity)
     hipError_t e = hipMemcpyAsync(a, c->lr_a.as<int32_t>() + lo, (size_t)n * 4, hipMemcpyDeviceToHost, S->st);
@@ -520,7 +522,8 @@ static void lr_stream_batch(LrStream *S, int64_t hi) {
         return;
     }
     int64_t wrote = 0;
-    const int rc = write_link_rows(S->path.c_str(), S->first_batch ? S->append : 1, S->nthreads, n, a, b, mi, c->h_POS.data(), c->h_paint.data(), c->g, &wrote);
+    // (while the pass runs: few threads — the submitting thread and its helpers need the host more; once the stream is closing the pass is over)
+    const int rc = write_link_rows(S->path.c_str(), S->first_batch ? S->append : 1, S->closing_seen ? 0 : S->nthreads, n, a, b, mi, c->h_POS.data(), c->h_paint.data(), c->g, &wrote);
     S->first_batch = false;
     if (rc != LDW_OK) {
         S->rc = rc;
@@ -537,10 +540,14 @@ static void lr_stream_main(LrStream *S) {
         int64_t take_to;
         {
             std::unique_lock<std::mutex> lk(S->mu);
-            S->cv.wait(lk, [&] { return S->closing || S->pushed > S->consumed; });
-            if (S->pushed == S->consumed) return;   // closing and nothing left
+            S->cv.wait(lk, [&] { return S->closing || S->drain_req > 0 ? (S->closing || S->pushed > S->consumed) : S->pushed - S->consumed >= LrStream::BATCH_ITEMS; });
+            if (S->pushed == S->consumed) {
+                if (S->closing) return;   // closing and nothing left
+                continue;
+            }
             take_to = S->pushed;                    // everything handed over so far: one batch (the newest entry's count covers the older ones)
             S->busy = true;
+            S->closing_seen = S->closing;
         }
         const int idx = (int)((take_to - 1) % LrStream::RING);
         int64_t hi = -1;
@@ -596,7 +603,10 @@ void lr_stream_drain(ldw_ctx *c) {
     LrStream *S = static_cast<LrStream *>(c->lr_stream);
     if (!S) return;
     std::unique_lock<std::mutex> lk(S->mu);
+    ++S->drain_req;
+    S->cv.notify_all();
     S->cv.wait(lk, [&] { return S->pushed == S->consumed && !S->busy; });
+    --S->drain_req;
 }
 }  // namespace ldw
 }  // extern "C++"
@@ -734,19 +744,11 @@ int ldw_lr_stream_begin(ldw_ctx *c, const char *path, int append, int nthreads) 
     S->c = c;
     S->path = path;
     S->append = 1;
-    S->nthreads = nthreads;
-    LDW_HIP(hipStreamCreateWithFlags(&S->st, hipStreamNonBlocking));
-    bool ok = hipHostMalloc(reinterpret_cast<void **>(&S->counts), sizeof(int64_t) * LrStream::RING, hipHostMallocDefault) == hipSuccess;
-    for (int k = 0; k < LrStream::RING && ok; ++k) ok = hipEventCreateWithFlags(&S->ev[k], hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-        (void)hipGetLastError();
-        for (auto &e : S->ev)
-            if (e) (void)hipEventDestroy(e);
-        if (S->counts) (void)hipHostFree(S->counts);
-        (void)hipStreamDestroy(S->st);
-        ldw::set_error("ldw_lr_stream_begin: could not create the stream's events / pinned counters");
-        return LDW_ERR_HIP;
-    }
+    S->nthreads = nthreads > 0 ? nthreads : 4;   // (beside a running pass: its two helper threads and the submitting thread need the host's share more)
+    if (int rc = ldw::ensure_streams(c)) return rc;   // (made with the context unless LDW_NO_PREPARE: the writer's stream, event ring, pinned counters)
+    S->st = c->lr_st;
+    S->ev = c->lr_ev;
+    S->counts = c->lr_counts;
     LrStream *raw = S.release();
     raw->th = std::thread(lr_stream_main, raw);
     c->lr_stream = raw;
@@ -772,11 +774,6 @@ int ldw_lr_stream_end(ldw_ctx *c, int64_t *rows_out, int64_t *bytes_out, int64_t
     if (bytes_out) *bytes_out = S->bytes;
     if (blocks_out) *blocks_out = S->blocks_seen;
     if (rc != LDW_OK) ldw::set_error("%s", S->err.c_str());
-    for (auto &e : S->ev)
-        if (e) (void)hipEventDestroy(e);
-    if (S->counts) (void)hipHostFree(S->counts);
-    if (S->pin) (void)hipHostFree(S->pin);
-    if (S->st) (void)hipStreamDestroy(S->st);
     delete S;
     c->lr_stream = nullptr;
     return rc;

@@ -304,11 +304,11 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
                     eng.lr_stream_begin(lr_save_path, append=True)
                 try:
                     stats = _run_blocks(eng, blocks, np.arange(len(blocks)), kw, POS, g)
-                finally:
+                except BaseException:
                     if lr_stream:
-                        t_w0 = time.time()
-                        streamed = eng.lr_stream_end()   # (also on failure: what was finished is on disk)
-                        stages["lr_stream_wait_s"] = time.time() - t_w0
+                        eng.lr_stream_end()   # (on failure: what was finished is on disk before the error travels on)
+                    raise
+                # (the writer's last batch is formatted beside the short-range model below, like the r04 table-at-once writer: lr_stream_end follows it)
             stages["mi_all_pairs_s"] = time.time() - t_s
         # lr_links.tsv (R/computePairwiseMI.R:362) straight from the device-resident table: fetched, derived (pos, clust, len) and
         # formatted by the library's host threads
@@ -335,12 +335,18 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
         t_w = time.time()
         if not perform_SR_analysis_only and not lr_stream:
             n_lr_rows, _ = eng.write_links_tsv_end()
-        elif lr_stream and streamed is not None:
+        elif lr_stream:
+            streamed = eng.lr_stream_end()
             n_lr_rows = streamed[0]
-        tsv_s += time.time() - t_w + stages.get("lr_stream_wait_s", 0.0)
+        tsv_s += time.time() - t_w
         stages["lr_tsv_s"] = tsv_s
         path_report = eng.path_report()
     finally:
+        if lr_stream:
+            try:
+                eng.lr_stream_end()   # (no-op after the regular end above; an error on the way here must not leave the writer open on the caller's engine)
+            except Exception:
+                pass
         if own:
             eng.close()
     if not path_report["apx_gate"].startswith("ok") and not perform_SR_analysis_only:
