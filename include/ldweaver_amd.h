@@ -403,6 +403,14 @@ int ldw_write_links_tsv(ldw_ctx *ctx, int which, const char *path, int append, i
 int ldw_write_links_tsv_begin(ldw_ctx *ctx, int which, const char *path, int append, int nthreads);
 int ldw_write_links_tsv_end(ldw_ctx *ctx, int64_t *rows_out, int64_t *bytes_out);
 int ldw_tsv_join(ldw_ctx *ctx);
+/* Host memory the library keeps between calls — the tsv writers' pooled buffers (process-wide, ~100 MB after a C4 job) and the context's pinned
+ * fetch arena (16 B per row of the largest table written, <= 2.25 GB) — is released here (ctx may be NULL: the pool only).  Call it BETWEEN jobs:
+ * on this driver stack giving large host regions back next to GPU work stalls the process's next GPU call.  bytes_out: released. */
+int ldw_host_trim(ldw_ctx *ctx, int64_t *bytes_out);
+/* SINGLE WRITER PER PATH: the tsv writers position their workers' writes by offsets computed from the file's size at the start of the call
+ * (pwrite), so two writers appending to one path at the same time — two contexts or ranks, or a synchronous call beside a pending
+ * ldw_write_links_tsv_begin / ldw_lr_stream_begin on the same file — overwrite each other.  One process appends to lr_links.tsv, as in the
+ * reference's serial loop (R/computePairwiseMI.R:103-116). */
 /* r05 — lr_links.tsv appended WHILE the pass runs, as the reference appends it block by block (R/computePairwiseMI.R:362).  _begin (before
  * ldw_mi_all_pairs; append = 0 truncates the file first) opens a writer thread on the context; after every finished item of the pass (a
  * block, or a span of blocks) the rows it added to the long-range table — final: the filter is per block (:352-358) — are fetched on a

@@ -111,6 +111,7 @@ _SIGS = {
     "ldw_write_links_tsv_begin": (C.c_int, [_p, C.c_int, C.c_char_p, C.c_int, C.c_int]),
     "ldw_write_links_tsv_end": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64)]),
     "ldw_tsv_join": (C.c_int, [_p]),
+    "ldw_host_trim": (C.c_int, [_p, C.POINTER(_i64)]),
     "ldw_lr_stream_begin": (C.c_int, [_p, C.c_char_p, C.c_int, C.c_int]),
     "ldw_lr_stream_end": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "ldw_compare_to_row": (C.c_int, [_p, _i64, _i64, _p, _i64, _p]),

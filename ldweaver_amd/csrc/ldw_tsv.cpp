@@ -174,8 +174,9 @@ public:
     void *get(size_t bytes) {
         std::lock_guard<std::mutex> lk(mu_);
         size_t best = SIZE_MAX;
+        // (best fit, but never a block more than twice the request: a 256-MB block handed to a small request forced a second large allocation later — ADVICE r04)
         for (size_t i = 0; i < free_.size(); ++i)
-            if (free_[i].second >= bytes && (best == SIZE_MAX || free_[i].second < free_[best].second)) best = i;
+            if (free_[i].second >= bytes && free_[i].second <= 2 * bytes + 4096 && (best == SIZE_MAX || free_[i].second < free_[best].second)) best = i;
         if (best != SIZE_MAX) {
             void *p = free_[best].first;
             used_.push_back(free_[best]);
@@ -195,6 +196,17 @@ public:
                 used_.erase(used_.begin() + (long)i);
                 return;
             }
+    }
+    // gives the idle blocks back to the OS (ldw_host_trim); returns the bytes released
+    size_t trim() {
+        std::lock_guard<std::mutex> lk(mu_);
+        size_t n = 0;
+        for (auto &b : free_) {
+            n += b.second;
+            free(b.first);
+        }
+        free_.clear();
+        return n;
     }
 private:
     std::mutex mu_;
@@ -726,6 +738,25 @@ int ldw_write_links_tsv_begin(ldw_ctx *c, int which, const char *path, int appen
             A->err = "ldw_write_links_tsv_begin: unknown exception in the writer thread";
         }
     });
+    return LDW_OK;
+}
+
+int ldw_host_trim(ldw_ctx *c, int64_t *bytes_out) {
+    // a long-lived R / Python session keeps, after one big job, the writer's pooled thread buffers (process-wide) and the context's
+    // pinned fetch arena (up to 2 GB x 1.125) until the context dies.  They are kept on purpose WHILE jobs run (an munmap next to GPU work
+    // stalls the process's next GPU call by ~20 ms: DESIGN.md 8); this gives them back between jobs, when the caller says so.
+    int64_t n = (int64_t)host_pool().trim();
+    if (c) {
+        if (int rc = tsv_async_join(c, nullptr, nullptr)) return rc;
+        if (c->lr_stream == nullptr && c->pin_fetch) {
+            (void)hipSetDevice(c->device);
+            (void)hipHostFree(c->pin_fetch);
+            n += (int64_t)c->pin_fetch_cap;
+            c->pin_fetch = nullptr;
+            c->pin_fetch_cap = 0;
+        }
+    }
+    if (bytes_out) *bytes_out = n;
     return LDW_OK;
 }
 

@@ -137,6 +137,12 @@ class Engine:
         L.check(L.lib().ldw_write_links_tsv(self._ctx, int(which), str(path).encode(), int(bool(append)), int(nthreads), C.byref(n), C.byref(nb)))
         return int(n.value), int(nb.value)
 
+    def host_trim(self) -> int:
+        """Release the host memory the library keeps between calls (writer pool, pinned fetch arena); call between jobs.  Bytes released."""
+        n = C.c_int64(0)
+        L.check(L.lib().ldw_host_trim(self._ctx, C.byref(n)))
+        return int(n.value)
+
     def lr_stream_begin(self, path: str, append: bool = True, nthreads: int = 0):
         """lr_links.tsv appended while the next ``mi_all_pairs`` runs, item by item (the reference appends per block: R/computePairwiseMI.R:362)."""
         L.check(L.lib().ldw_lr_stream_begin(self._ctx, str(path).encode(), int(bool(append)), int(nthreads)))

@@ -44,6 +44,17 @@ def test_default_library_is_lean():
         assert name not in syms, name
 
 
+def test_host_trim_without_a_context(tmp_path):
+    """ldw_host_trim(NULL): the tsv writers' process-wide buffer pool goes back to the OS; the writer works again afterwards."""
+    cols = [np.arange(50_000, dtype=np.int32), np.linspace(0, 1, 50_000)]
+    MI.append_table(str(tmp_path / "a.tsv"), cols)
+    n = C.c_int64(-1)
+    assert L.lib().ldw_host_trim(None, C.byref(n)) == L.LDW_OK and n.value > 0
+    assert L.lib().ldw_host_trim(None, C.byref(n)) == L.LDW_OK and n.value == 0
+    MI.append_table(str(tmp_path / "b.tsv"), cols)
+    assert (tmp_path / "a.tsv").read_bytes() == (tmp_path / "b.tsv").read_bytes()
+
+
 def test_no_cpu_fallback():
     """Without a GPU the context cannot be created and says so; with one the test is vacuous."""
     lib = L.lib()
