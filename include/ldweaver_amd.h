@@ -171,8 +171,7 @@ int ldw_mi_all_pairs(ldw_ctx *ctx, const int32_t *blocks, int64_t nblocks, const
  * block pairs are dealt over the contexts by cost (ldw_deal_blocks: a diagonal pair counts 3.3 times its pairs — its dense short-range
  * band —, longest first to the least loaded, every context keeps make_blocks order; the same deal as ldweaver_amd/dist.py), each context
  * runs ldw_mi_all_pairs on its share on a worker thread of its own, and the link tables are assembled in ctx[0] in the caller's block order —
- * the order the reference appends in — by peer-to-peer copies (each source's rows over its own xGMI link; the short-range rows travel as
- * their MI column alone when POS ascends, ctx[0] rebuilds their index columns: ldw_sr_pairs_fill).  Afterwards ctx[0] is exactly in the
+ * the order the reference appends in — by peer-to-peer copies (each source's rows over its own xGMI link).  Afterwards ctx[0] is exactly in the
  * state ldw_mi_all_pairs(ctx[0], all blocks) would have left it in — tables, ldw_block_stats over all nblocks — so the short-range model,
  * ARACNE, the post-processing and the tsv writers run on it unchanged; the other contexts keep their own shares.  The long-range filter is
  * per block (:352-358), so the retained set does not depend on n_ctx.  One failing context fails the call (its message is reported).

@@ -161,10 +161,12 @@ int ldw_mi_all_pairs_multi(ldw_ctx **ctx, int n_ctx, const int32_t *blocks, int6
         }
     }
     LDW_HIP(hipSetDevice(c0->device));
-    // The short-range rows are a pure function of the positions and the block geometry (R/computePairwiseMI.R:306-333): when POS ascends and the
-    // pass is not SR-only only their MI column travels (8 instead of 16 bytes per row of the table that is 99 % of the bytes) and ctx[0]
-    // rebuilds (a, b) itself with the band enumerator beside the copies (ldw_sr_pairs_fill) — as the RCCL gather of dist.py does.
-    const bool sr_mi_only = c0->pos_sorted && !p->sr_only && p->keep_sr && getenv("LDW_MULTI_FULL_SR") == nullptr;
+    // The short-range rows are a pure function of the positions and the block geometry (R/computePairwiseMI.R:306-333), so their index columns
+    // need not travel: ctx[0] can rebuild (a, b) with the band enumerator (ldw_sr_pairs_fill) and only the MI column (8 of 16 bytes per row)
+    // crosses xGMI — what the RCCL gather of dist.py does.  In process it is the OPTION (LDW_MULTI_SR_MI_ONLY=1), not the default: the
+    // enumerator walks every block on the host (0.2 ms each: 12 ms for C4's 55 blocks, measured with two contexts on one GPU) while the bytes
+    // it saves are 90 MB per peer, each over its own link (~2 ms at N = 8) — every source already holds the index columns of its own rows.
+    const bool sr_mi_only = c0->pos_sorted && !p->sr_only && p->keep_sr && getenv("LDW_MULTI_SR_MI_ONLY") != nullptr;
     ldw::DevBuf nA[2], nB[2], nM[2];
     auto fail = [&](int rc) {
         for (int w = 0; w < 2; ++w) {
