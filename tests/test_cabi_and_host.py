@@ -268,3 +268,81 @@ def test_cpu_share_and_thread_pool_limits(monkeypatch):
     monkeypatch.setenv("OPENBLAS_NUM_THREADS", "3")
     assert limit_thread_pools(5) == 5
     assert os.environ["OMP_NUM_THREADS"] == "5" and os.environ["OPENBLAS_NUM_THREADS"] == "3"
+
+
+def test_r_shim_is_consistent_with_itself_and_the_header():
+    """The R shim cannot be compiled here (no R headers in the image), so it is checked statically: every `.Call("ldwamd_*", ...)` of
+    r_shim/ldweaver_amd.R names a routine registered in the shim's R_CallMethodDef table with the number of arguments the call passes; every
+    registered routine is defined with that many SEXP parameters; every `ldw_*` function the shim calls is declared in include/ldweaver_amd.h
+    and called with the declared number of arguments; the reference's own six `.Call` symbols are registered with the reference's arities
+    (src/RcppExports.cpp:154-160)."""
+    c_src = open(os.path.join(ROOT, "r_shim", "ldweaver_amd_shim.c")).read()
+    r_src = open(os.path.join(ROOT, "r_shim", "ldweaver_amd.R")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ldweaver_amd.h")).read(), flags=re.S)
+    c_code = re.sub(r"/\*.*?\*/", "", c_src, flags=re.S)
+
+    def split_args(s):
+        out, depth, cur, in_str = [], 0, "", None
+        for ch in s:
+            if in_str:
+                cur += ch
+                if ch == in_str:
+                    in_str = None
+                continue
+            if ch in "\"'":
+                in_str = ch
+                cur += ch
+            elif ch in "([{":
+                depth += 1
+                cur += ch
+            elif ch in ")]}":
+                depth -= 1
+                cur += ch
+            elif ch == "," and depth == 0:
+                out.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            out.append(cur)
+        return out
+
+    def call_args(src, start):
+        """argument list of the call whose '(' is at src[start]"""
+        depth, i = 0, start
+        while True:
+            depth += src[i] == "("
+            depth -= src[i] == ")"
+            if depth == 0:
+                return split_args(src[start + 1:i])
+            i += 1
+
+    table = {m.group(1): int(m.group(3)) for m in re.finditer(r'\{"(\w+)",\s*\(DL_FUNC\)\s*&(\w+),\s*(\d+)\}', c_code)}
+    assert len(table) >= 20
+    for name, arity in table.items():
+        m = re.search(r"\bSEXP\s+" + re.escape(name if not name.startswith("_LDWeaver_") else name) + r"\s*\(", c_code)
+        if m is None:      # (the reference-named entries point at differently named adapters)
+            target = re.search(r'\{"' + re.escape(name) + r'",\s*\(DL_FUNC\)\s*&(\w+)', c_code).group(1)
+            m = re.search(r"\bSEXP\s+" + re.escape(target) + r"\s*\(", c_code)
+        assert m, name
+        params = call_args(c_code, m.end() - 1)
+        n = 0 if [p.strip() for p in params] in ([], ["void"]) else len(params)
+        assert n == arity, (name, n, arity)
+    for m in re.finditer(r'\.Call\("(\w+)"', r_src):
+        name = m.group(1)
+        assert name in table, f".Call of an unregistered routine {name}"
+        nargs = len(call_args(r_src, r_src.index("(", m.start()))) - 1
+        assert nargs == table[name], (name, nargs, table[name])
+    want = dict(_LDWeaver_ACGTN2num=3, _LDWeaver_fastHadamard=9, _LDWeaver_compareToRow=2, _LDWeaver_vecPosMatch=2, _LDWeaver_compareTriplet=3,
+                _LDWeaver_fast_intersect=2)
+    for k, v in want.items():
+        assert table.get(k) == v, (k, table.get(k))
+    declared = {}
+    for m in re.finditer(r"\b(ldw_[a-z0-9_]+)\s*\(", hdr):
+        args = call_args(hdr, m.end() - 1)
+        declared[m.group(1)] = 0 if [a.strip() for a in args] == ["void"] else len(args)
+    for m in re.finditer(r"\b(ldw_[a-z0-9_]+)\s*\(", c_code):
+        name = m.group(1)
+        assert name in declared, f"the shim calls {name}, which the header does not declare"
+        n = len(call_args(c_code, m.end() - 1))
+        assert n == declared[name], (name, n, declared[name])
