@@ -60,8 +60,14 @@ perform_MI_computation <- function(snp.dat, hdw, cds_var, ncores, lr_save_path =
   .Call("ldwamd_set_weights", as.numeric(hdw))
   .Call("ldwamd_set_snp_meta", as.numeric(snp.dat$r), as.raw(t(snp.dat$uqe)), as.integer(snp.dat$POS),
         as.integer(cds_var$paint), as.numeric(snp.dat$g))
-  res <- .Call("ldwamd_mi_all_pairs", as.integer(t(as.matrix(MI_cmp_blks))), sr_dist, lr_retain_links, lr_links_approx,
-               perform_SR_analysis_only, 0L)
+  # r05: with options(ldwamd.native_tsv = TRUE) on ONE device lr_links.tsv is appended while the block loop runs, item by item — the reference's
+  # per-block write.table(append = T) (:362): a job that dies leaves the finished blocks' rows
+  stream_lr <- isTRUE(getOption("ldwamd.native_tsv", FALSE)) && !perform_SR_analysis_only && length(getOption("ldwamd.devices", 0L)) == 1
+  if (stream_lr) .Call("ldwamd_lr_stream_begin", lr_save_path)
+  res <- tryCatch(.Call("ldwamd_mi_all_pairs", as.integer(t(as.matrix(MI_cmp_blks))), sr_dist, lr_retain_links, lr_links_approx,
+                        perform_SR_analysis_only, 0L),
+                  error = function(e) { if (stream_lr) try(.Call("ldwamd_lr_stream_end"), silent = TRUE); stop(e) })
+  if (stream_lr) .Call("ldwamd_lr_stream_end")
   to_df <- function(t) {
     # POS keeps its type (an INTEGER vector in the reference, src/getACGTNsites.cpp:97,173: pos1 / pos2 print as integers)
     pos2 <- snp.dat$POS[t[[1]] + 1]; pos1 <- snp.dat$POS[t[[2]] + 1]
@@ -71,7 +77,7 @@ perform_MI_computation <- function(snp.dat, hdw, cds_var, ncores, lr_save_path =
   # lr_links.tsv (:362): options(ldwamd.native_tsv = TRUE) writes it from the device table with the library's threaded writer
   # (same bytes as write.table, 1e6 rows in ~0.3 s instead of seconds); the default is R's own write.table
   native_lr <- FALSE
-  if (!perform_SR_analysis_only && length(res[[2]][[3]]) > 0) {
+  if (!perform_SR_analysis_only && !stream_lr && length(res[[2]][[3]]) > 0) {
     if (isTRUE(getOption("ldwamd.native_tsv", FALSE))) {
       .Call("ldwamd_write_links_tsv_begin", 1L, lr_save_path)   # r04: written by host threads while mergeNsort_sr_links runs below
       native_lr <- TRUE

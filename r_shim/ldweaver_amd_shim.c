@@ -332,6 +332,25 @@ SEXP ldwamd_write_links_tsv_end(void) {
     return ScalarReal((double)rows);
 }
 
+/* r05: lr_links.tsv appended WHILE ldwamd_mi_all_pairs runs, item by item, like the reference's per-block write.table(append = T)
+ * (R/computePairwiseMI.R:362): _begin before the pass (single device only: the multi-device gather reorders rows), _end after it — also on
+ * error: what the pass finished is on disk.  _end returns c(rows, blocks whose rows are in the file). */
+SEXP ldwamd_lr_stream_begin(SEXP path) {
+    ctx_or_stop();
+    if (g_nctx > 1) error("ldweaver_amd: lr_links.tsv streaming needs a single device (options(ldwamd.devices) has %d)", g_nctx);
+    CHK(ldw_lr_stream_begin(g_ctx, CHAR(STRING_ELT(path, 0)), 1, 0));
+    return R_NilValue;
+}
+SEXP ldwamd_lr_stream_end(void) {
+    int64_t rows = 0, bytes = 0, blocks = 0;
+    CHK(ldw_lr_stream_end(ctx_or_stop(), &rows, &bytes, &blocks));
+    SEXP out = PROTECT(allocVector(REALSXP, 2));
+    REAL(out)[0] = (double)rows;
+    REAL(out)[1] = (double)blocks;
+    UNPROTECT(1);
+    return out;
+}
+
 /* any numeric data.frame's columns (INTSXP / REALSXP / LGLSXP-as-int) by the same writer; cols: a list of equally long vectors */
 SEXP ldwamd_write_table_tsv(SEXP cols, SEXP path) {
     const int nc = (int)XLENGTH(cols);
@@ -376,6 +395,8 @@ static const R_CallMethodDef CallEntries[] = {
     {"ldwamd_write_links_tsv", (DL_FUNC)&ldwamd_write_links_tsv, 2},
     {"ldwamd_write_links_tsv_begin", (DL_FUNC)&ldwamd_write_links_tsv_begin, 2},
     {"ldwamd_write_links_tsv_end", (DL_FUNC)&ldwamd_write_links_tsv_end, 0},
+    {"ldwamd_lr_stream_begin", (DL_FUNC)&ldwamd_lr_stream_begin, 1},
+    {"ldwamd_lr_stream_end", (DL_FUNC)&ldwamd_lr_stream_end, 0},
     {"ldwamd_write_table_tsv", (DL_FUNC)&ldwamd_write_table_tsv, 2},
     {NULL, NULL, 0}};
 
