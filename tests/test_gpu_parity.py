@@ -2333,6 +2333,23 @@ def test_in_process_multi_context_equals_one_context(sample, tmp_path):
         one_sr = tables(engs[0])
         Engine.mi_all_pairs_multi(engs[:2], blocks, **kw_sr)
         same(one_sr, tables(engs[0]), "2 contexts, sr_only")
+        # more contexts than blocks: the idle context is dealt nothing and the result does not change; one context == ldw_mi_all_pairs
+        two_blocks = blocks[:2]
+        engs[0].mi_all_pairs(two_blocks, **kw)
+        one2 = tables(engs[0])
+        info = Engine.mi_all_pairs_multi(engs, two_blocks, **kw)
+        assert sorted(info["owner"].tolist()) == [0, 1]
+        same(one2, tables(engs[0]), "3 contexts, 2 blocks")
+        Engine.mi_all_pairs_multi(engs[:1], two_blocks, **kw)
+        same(one2, tables(engs[0]), "1 context through the multi entry point")
+        # a bad block on one context's share fails the call with that context's message; the engines survive
+        bad = blocks.copy()
+        bad[len(bad) - 1, 3] = Ls + 9
+        with pytest.raises(L.LdwError) as ei:
+            Engine.mi_all_pairs_multi(engs[:2], bad, **kw)
+        assert "context" in str(ei.value) and "outside 1.." in str(ei.value)
+        Engine.mi_all_pairs_multi(engs[:2], blocks, **kw)
+        same(one, tables(engs[0]), "2 contexts after a failed call")
         # a context that holds other weights is refused before anything runs
         engs[2].set_weights(np.full(N, 0.25))
         with pytest.raises(L.LdwError) as ei:
