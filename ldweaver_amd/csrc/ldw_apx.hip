@@ -333,7 +333,7 @@ __device__ __forceinline__ void apx_gemm_epilogue(const ApxGemmArgs &P, v16i (&a
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int trow = ty * TH + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    P.G[(int64_t)trow * P.RFpad + fcol] = acc[i][j][e];
+                    if (128 % TH == 0 || trow < P.RTpad) P.G[(int64_t)trow * P.RFpad + fcol] = acc[i][j][e];
                 }
             }
         }
@@ -433,8 +433,8 @@ __global__ __launch_bounds__(256) void k_apx_live_tiles(ApxGemmArgs P) {
     if (lane == 0 && n_pruned) atomicAdd(P.skip_ctr, (unsigned long long)n_pruned);
 }
 
-template <int MT, int NT, bool FINE>
-__global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
+template <int MT, int NT, bool FINE, int WPS = 2>
+__global__ __launch_bounds__(256, WPS) void gemm_apx_kernel(ApxGemmArgs P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint64_t *lutFF = reinterpret_cast<uint64_t *>(smem);           // [256]: byte of bits -> 8 bytes of 0xFF / 0x00
     uint8_t *sA = smem + 2048, *sB = sA + (size_t)P.M2 * 128;       // digits by position
@@ -478,7 +478,11 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_kernel(ApxGemmArgs P) {
     {
         const uint64_t *pa[MT], *pb[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) pa[i] = P.panel_t + ((int64_t)(ty * TH + 32 * i + frow) * 2 + fh);
+        for (int i = 0; i < MT; ++i) {
+            int rt = ty * TH + 32 * i + frow;
+            if (128 % TH != 0 && rt >= P.RTpad) rt = P.RTpad - 1;   // (only the 96-row tiles of the r05 experiment can run past RTpad, a multiple of 128)
+            pa[i] = P.panel_t + ((int64_t)rt * 2 + fh);
+        }
 #pragma unroll
         for (int i = 0; i < NT; ++i) pb[i] = P.panel_f + ((int64_t)(tx * TWd + 32 * i + frow) * 2 + fh);
         v16i acc[MT][NT];
@@ -897,13 +901,18 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
 #ifdef LDW_EXPERIMENTS
     else if (tile == 22 && !P.fuse) LDW_APX_LAUNCH(2, 2)          // (the table epilogue assumes 64 from-rows per wave: NT = 2)
     else if (tile == 24 && !P.fuse) LDW_APX_LAUNCH(2, 4)
+    else if (tile == 32 && !P.fuse) {   // r05: 3 x 2 MFMA tiles per wave = 96 accumulators, built for THREE waves per SIMD (<= 170 VGPRs)
+        const int ntx = P.RFpad / 64, nty = (P.RTpad + 95) / 96;
+        if (P.fine) hipLaunchKernelGGL((gemm_apx_kernel<3, 2, true, 3>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((gemm_apx_kernel<3, 2, false, 3>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P);
+    }
 #endif
     else LDW_APX_LAUNCH(4, 2)
 #undef LDW_APX_LAUNCH
     LDW_HIP(hipGetLastError());
     {   // executed work (ldw_gemm_stats): waves that do not leave at once, each 2 * rows_t * rows_f * K int8 operations
         const int tl = P.fuse ? 42 : tile;
-        const int MTv = tl == 22 || tl == 24 ? 2 : 4, NTv = tl == 24 ? 4 : 2, TH = 32 * MTv, TWd = 32 * NTv;
+        const int MTv = tl == 22 || tl == 24 ? 2 : (tl == 32 ? 3 : 4), NTv = tl == 24 ? 4 : 2, TH = 32 * MTv, TWd = 32 * NTv;
         int64_t waves = 0;
         for (int ty = 0; ty * TH < P.RTpad; ++ty) {
             const int ntx = P.RFpad / TWd;
