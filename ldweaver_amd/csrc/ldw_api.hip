@@ -336,6 +336,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     (void)ldw_tsv_join(c);
     (void)ldw_lr_stream_end(c, nullptr, nullptr, nullptr);
     (void)hipStreamSynchronize(c->stream);
+    c->logtab.release();
     ldw::DevBuf *bufs[] = {&c->srm_tmp, &c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->apx_skip, &c->snp_sup, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
                            &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->perm_t, &c->scr_units, &c->slot_pfix_hi, &c->glo, &c->lo_rows, &c->packs, &c->colcnt,
@@ -939,6 +940,19 @@ int ensure_rows(ldw_ctx *c) {
     LDW_REQUIRE(c->L > 0 && c->have_weights && c->have_meta, LDW_ERR_STATE,
                 "MI needs the alignment, the weights and the SNP meta data to be set first");
     const int64_t L = c->L, Npad = c->Npad;
+#ifdef LDW_LOG_TABLE   // (measurement build only: tools/r05_logtab.sh)
+    if (!c->logtab.p) {   // the table of the table-based fp64 logarithm (ldw_epi.h, -DLDW_LOG_TABLE): 128 x {1 / c_i, log c_i}, c_i = 1 + (i + 1/2) / 128
+        double h[256];
+        for (int i = 0; i < 128; ++i) {
+            const double ci = 1.0 + ((double)i + 0.5) / 128.0;
+            h[2 * i] = 1.0 / ci;
+            h[2 * i + 1] = std::log(ci);
+        }
+        if (int rc = c->logtab.reserve(sizeof(h))) return rc;
+        LDW_HIP(hipMemcpyAsync(c->logtab.p, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));   // (h is on this frame)
+    }
+#endif
     if (int rc = c->counts.reserve((size_t)L * 20)) return rc;
     if (int rc = c->slot_pfix.reserve((size_t)L * 40)) return rc;
     if (int rc = c->pfix_state.reserve((size_t)L * 40)) return rc;

@@ -103,6 +103,34 @@ __device__ __forceinline__ double fast_log_ratio(double N, double D) {
     return fma((double)k, 0.693147180559945309417, lm);
 }
 
+// r05 experiment (-DLDW_LOG_TABLE, a measurement build: tools/r05_logtab.sh; NOT shipped — measured SLOWER: k_mi_epilogue 60.5 -> 68.8 ms per C4 pass of
+// the plain path, the two 16-byte table gathers per cell cost more than the reciprocal + three series terms they replace; same tables, parity tests green):
+// the same logarithm WITHOUT the reciprocal — log N - log D from a 128-entry table.  x = 2^e m, m in [1, 2);
+// i = the top 7 bits of the mantissa, c_i = 1 + (i + 1/2) / 128; r = m / c_i - 1 as ONE fma with the tabulated 1 / c_i (|r| <= 2^-8);
+// log m = log c_i + log1p(r), log1p by its series to r^6 (r^7 / 7 < 2e-18).  tab[i] = {1 / c_i, log c_i} (ldw_ctx::logtab, 2 KB).
+struct LogEnt {
+    double inv_c, log_c;
+};
+__device__ __forceinline__ double log1p_small(double r) {
+    double p = -1.0 / 6.0;
+    p = fma(p, r, 1.0 / 5.0);
+    p = fma(p, r, -1.0 / 4.0);
+    p = fma(p, r, 1.0 / 3.0);
+    p = fma(p, r, -1.0 / 2.0);
+    p = p * r;
+    return fma(p, r, r);
+}
+__device__ __forceinline__ double fast_log_ratio_tab(double N, double D, const LogEnt *__restrict__ tab) {
+    const int hn = __double2hiint(N), hd = __double2hiint(D);
+    const int k = ((hn >> 20) & 0x7FF) - ((hd >> 20) & 0x7FF);
+    const LogEnt tn = tab[(hn >> 13) & 0x7F], td = tab[(hd >> 13) & 0x7F];
+    const double mn = __hiloint2double((hn & 0x000FFFFF) | 0x3FF00000, __double2loint(N));
+    const double md = __hiloint2double((hd & 0x000FFFFF) | 0x3FF00000, __double2loint(D));
+    const double rn = fma(mn, tn.inv_c, -1.0), rd = fma(md, td.inv_c, -1.0);
+    const double lm = (tn.log_c - td.log_c) + (log1p_small(rn) - log1p_small(rd));
+    return fma((double)k, 0.693147180559945309417, lm);
+}
+
 // ------------------------------------------------------------------------------------------------
 // what happens to one finished pair: dense store, short-range scatter, long-range histogram
 // ------------------------------------------------------------------------------------------------
@@ -278,6 +306,7 @@ struct EpiArgs {
     const double *snp_sup;    // [L][4] (k_snp_sup)
     int sr_excl;              // 1: the block's short-range pairs are evaluated elsewhere (an SR sub-pass over the same block in list order): the
                               // screens only keep them out of the long-range candidates and never list a unit for them (E.any_sr is 0 then)
+    const struct LogEnt *logtab;   // (-DLDW_LOG_TABLE) 128 x {1 / c_i, log c_i}: ldw_ctx::logtab
     int span;                 // > 0: the to side is the concatenation of `span` reference blocks (segments), nt of each = nf
     SpanSeg sseg[LDW_SPAN_MAX];
     EmitArgs E;
@@ -450,7 +479,11 @@ __device__ __forceinline__ double pair_mi(const EpiArgs &A, const RowSide &R, co
                     const double pY = M.pYd[j];
                     const double pxy = fma(u52_to_double(nfix), A.scale, 0.5);
                     const double d = fma(pY, rY, fma(pX, pY, pXr));
+#ifdef LDW_LOG_TABLE
+                    acc = fma(pxy, fast_log_ratio_tab(pxy * den, d, A.logtab), acc);
+#else
                     acc = fma(pxy, fast_log_ratio(pxy * den, d), acc);
+#endif
                 }
             }
         }
@@ -555,7 +588,11 @@ __device__ __forceinline__ double full_cells_mi(const EpiArgs &A, const RowSide 
             const double pY = M.pYd[j];
             const double pxy = fma(u52_to_double(C.n[i][j]), A.scale, 0.5);
             const double d = fma(pY, rY, fma(pX, pY, pXr));
+#ifdef LDW_LOG_TABLE
+            acc = fma(pxy, fast_log_ratio_tab(pxy * den, d, A.logtab), acc);
+#else
             acc = fma(pxy, fast_log_ratio(pxy * den, d), acc);
+#endif
         }
     }
     return acc * fast_rcp(den);

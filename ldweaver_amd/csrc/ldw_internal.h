@@ -223,6 +223,7 @@ struct ldw_ctx {
     int64_t blk_capacity = 0, blk_cursor = 0;  // ldw_links_begin / ldw_mi_block_links / ldw_links_end
 
     // ---- short-range model and ARACNE on the device-resident sr table (ldw_srp.hip) ----
+    ldw::DevBuf logtab;          // (-DLDW_LOG_TABLE) 128 x {1 / c_i, log c_i} of the table-based fp64 logarithm (ldw_epi.h)
     void *lr_stream = nullptr;   // r05: lr_links.tsv appended while the pass runs (ldw_tsv.cpp: LrStream), if ldw_lr_stream_begin opened one
     // its device-side resources, made once with the context's other streams (hipStreamCreate is a 12-ms call: not inside a job's pass)
     hipStream_t lr_st = nullptr;
