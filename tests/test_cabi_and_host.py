@@ -346,3 +346,25 @@ def test_r_shim_is_consistent_with_itself_and_the_header():
         assert name in declared, f"the shim calls {name}, which the header does not declare"
         n = len(call_args(c_code, m.end() - 1))
         assert n == declared[name], (name, n, declared[name])
+
+
+def test_new_entry_points_refuse_bad_arguments_without_a_gpu():
+    """Argument checks of the r05 entry points that need no device: null / out-of-range arguments come back as LDW_ERR_ARG with a message,
+    never as a crash."""
+    lib = L.lib()
+    blocks = np.ascontiguousarray(MI.make_blocks(3000, 1000), dtype=np.int32)
+    owner = np.zeros(len(blocks), dtype=np.int32)
+    assert lib.ldw_deal_blocks(None, len(blocks), 2, L.ptr(owner)) == L.LDW_ERR_ARG
+    assert lib.ldw_deal_blocks(L.ptr(blocks), len(blocks), 0, L.ptr(owner)) == L.LDW_ERR_ARG
+    assert lib.ldw_deal_blocks(L.ptr(blocks), 0, 2, L.ptr(owner)) == L.LDW_ERR_ARG
+    p = L.MIParams(20000.0, 1e6, 1.0, 0, 0, 1, 0)
+    assert lib.ldw_mi_all_pairs_multi(None, 2, L.ptr(blocks), len(blocks), C.byref(p), None, None) == L.LDW_ERR_ARG
+    arr = (C.c_void_p * 2)(None, None)
+    assert lib.ldw_mi_all_pairs_multi(arr, 2, L.ptr(blocks), len(blocks), C.byref(p), None, None) == L.LDW_ERR_ARG
+    assert b"context 0 is null" in lib.ldw_last_error()
+    assert lib.ldw_mi_all_pairs_multi(arr, 65, L.ptr(blocks), len(blocks), C.byref(p), None, None) == L.LDW_ERR_ARG
+    assert lib.ldw_hamming_weights_multi(None, 1, 10, L.ptr(np.zeros(4))) == L.LDW_ERR_ARG
+    assert lib.ldw_lr_stream_end(None, None, None, None) == L.LDW_ERR_ARG
+    assert lib.ldw_tsv_join(None) == L.LDW_ERR_ARG
+    assert lib.ldw_overflow_report(None, L.ptr(np.zeros(4, dtype=np.int64))) == L.LDW_ERR_ARG
+    assert lib.ldw_build_info() in (0, 1)
