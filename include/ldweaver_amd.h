@@ -273,7 +273,8 @@ int ldw_span_report(ldw_ctx *ctx, int64_t out[4]);
  * its segment of a span) be redone on the plain path (counted in spec_misses like a wrong bucket guess), so results never depend on a
  * capacity.  out[0] blocks / segments redone because a PAIR list overflowed, out[1] because the MAYBE list of the approximate GEMM's
  * epilogue did (sized for the worst case since r05: non-zero only under the test override LDW_MAYBE_CAP), out[2] = 1 while the maybe list
- * is switched off for the rest of the pass after such an overflow (ldw_reset_speculation switches it on again), out[3] reserved (0). */
+ * is switched off for the rest of the pass after such an overflow (ldw_reset_speculation switches it on again), out[3] entries handed to the
+ * maybe list since the context was created. */
 int ldw_overflow_report(ldw_ctx *ctx, int64_t out[4]);
 int ldw_set_pair_cap(uint32_t cap);
 /* inspection only: the per-SNP bounds behind the pruning of the 2 x 3 / 3 x 3 tables.  out[a * 4 + 2 * m + (k - 2)] = the largest MI

@@ -348,7 +348,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
                            &c->pair_sums, &c->tab11[0], &c->tab11[1], &c->G2, &c->G3, &c->miss_key, &c->miss_val};
     for (auto *b : bufs) b->release();
     for (int k = 0; k < LDW_NSLOT; ++k)
-        for (ldw::DevBuf *b : {&c->panel[k][0], &c->panel[k][1], &c->Gapx[k], &c->pairs[k], &c->apx_units[k], &c->apx_packs[k], &c->apx_bins[k], &c->apx_clean[k], &c->scr_live[k], &c->sub_units[k], &c->sub_packs[k], &c->sub_bins[k], &c->sub_live[k],
+        for (ldw::DevBuf *b : {&c->panel[k][0], &c->panel[k][1], &c->Gapx[k], &c->pairs[k], &c->apx_mini[k], &c->apx_units[k], &c->apx_packs[k], &c->apx_bins[k], &c->apx_clean[k], &c->scr_live[k], &c->sub_units[k], &c->sub_packs[k], &c->sub_bins[k], &c->sub_live[k],
                                &c->hist[k], &c->cand_key[k], &c->cand_val[k]})
             b->release();
     for (auto &e : c->ev)

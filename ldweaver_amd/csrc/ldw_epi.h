@@ -262,6 +262,23 @@ struct SpanSeg {
     unsigned long long *ghist;      // its NBINS histogram counters
 };
 
+// r05: what k_screen_maybe needs of a biallelic SNP, in 32 bytes instead of the ~200-byte ColMeta / RowPack (its entries arrive from the GEMM's
+// epilogue in region order, ~17 M per span on data without rare states, and the kernel was bound by the gathers of the two full records:
+// 1.32 ms per span).  Built by k_build_packs from the _hi packs (marginals of the APPROXIMATE weights: < 2^31 units); 0 / -1 for other SNPs.
+struct MiniCol {
+    int32_t pb0;        // approximate minor marginal (units of 2^e_last)
+    float pY0, pY1;     // weighted marginals of the two states (ColMeta::pYf)
+    float rb, rq;       // r of the SNP; Q1 on square blocks / spans: r[idx_f[b_loc]]
+    int32_t bl, seg0;   // local index in its reference block; first to-side index of its segment (a span's ColInfo::pad[1])
+    int32_t sb;
+};
+struct MiniRow {
+    int32_t pa0, pa1;
+    float pX0, pX1;
+    float ra, rta;
+    int32_t a_loc, sa;
+};
+
 struct PairEnt;
 struct EpiArgs {
     const int64_t *G;
@@ -306,6 +323,8 @@ struct EpiArgs {
     const double *snp_sup;    // [L][4] (k_snp_sup)
     int sr_excl;              // 1: the block's short-range pairs are evaluated elsewhere (an SR sub-pass over the same block in list order): the
                               // screens only keep them out of the long-range candidates and never list a unit for them (E.any_sr is 0 then)
+    const MiniCol *mini_c;    // [nt] / [64 * from-tiles] (k_screen_maybe); null: not built
+    const MiniRow *mini_r;
     const struct LogEnt *logtab;   // (-DLDW_LOG_TABLE) 128 x {1 / c_i, log c_i}: ldw_ctx::logtab
     int span;                 // > 0: the to side is the concatenation of `span` reference blocks (segments), nt of each = nf
     SpanSeg sseg[LDW_SPAN_MAX];

@@ -146,6 +146,7 @@ struct ldw_ctx {
     ldw::DevBuf sub_units[LDW_NSLOT], sub_packs[LDW_NSLOT], sub_bins[LDW_NSLOT], sub_live[LDW_NSLOT];   // the same four for an item's SR sub-pass
     ldw::DevBuf scr_live[LDW_NSLOT];           // per slot: counter, per-tile summaries and the list of the (tile, column group) combinations the screen has work for
     ldw::DevBuf apx_bins[LDW_NSLOT], apx_clean[LDW_NSLOT];    // per slot: threshold-table bin of every row of the two row lists; clean-region flags of the GEMM epilogue
+    ldw::DevBuf apx_mini[LDW_NSLOT];           // per slot: the 32-byte per-SNP extracts k_screen_maybe reads (MiniCol [nt], MiniRow [64 * from-tiles])
     ldw::DevBuf apx_units[LDW_NSLOT], apx_packs[LDW_NSLOT];   // per slot: per-(tile, class) unit lists + counters; per-block SNP constants
     int64_t apx_blocks = 0, apx_units_listed = 0, apx_pairs_listed = 0, probe_blocks = 0, generic_blocks = 0;
     // Tile pruning: in blocks without a short-range pair the one-row SNPs are ordered by the weight of their minor
@@ -160,6 +161,7 @@ struct ldw_ctx {
     bool diag_split = false;           // ldw_set_span(on | 4) / LDW_DIAG_SPLIT: diagonal blocks as SR sub-pass + weight-ordered long-range pass
     bool span_corners = false;         // ldw_set_span(on | 2) / LDW_SPAN_CORNERS: corner blocks join the spans (SR sub-passes); measured slower, off by default
     int span_max = 8;                  // most reference blocks per span (LDW_SPAN_MAX env, <= ldw::LDW_SPAN_MAX)
+    int64_t maybe_entries = 0;           // entries handed to the maybe list since the context was created (ldw_overflow_report out[3])
     int64_t pair_list_overflows = 0, maybe_overflows = 0;   // blocks / segments redone because a pair list / the maybe list overflowed (ldw_overflow_report)
     bool maybe_off = false;              // the maybe list overflowed in this pass: off until ldw_reset_speculation / new weights
     int64_t span_items = 0, span_blocks = 0, span_fallbacks = 0;   // spans run, reference blocks they covered, segments redone non-speculatively

@@ -142,6 +142,7 @@ int reserve_slot_buffers(ldw_ctx *c, int64_t Npad, int64_t blk, int64_t nseg) {
         if (int rc = c->Gapx[s].reserve(RF * RT * 4)) return rc;
         if (int rc = c->apx_units[s].reserve(64 + 2 * n_units * 8 + 64)) return rc;
         if (int rc = c->apx_packs[s].reserve(2 * o_cph + 2 * o_rph + ((size_t)blk + (size_t)nt) * 4 + 1024)) return rc;
+        if (int rc = c->apx_mini[s].reserve(((size_t)nt + nf_slots) * 32 + 512)) return rc;
         if (int rc = c->pairs[s].reserve(256 + (size_t)PAIR_PATHS * PAIR_SHARDS * cap * sizeof(PairEnt) + (size_t)maybe_cap_for((int64_t)RT, (int64_t)RF) * sizeof(ApxMaybe) + 64)) return rc;
         if (int rc = c->apx_bins[s].reserve(2 * (RT + RF) + (size_t)nt + nf_slots + 256 + (RT / 128) * (RF / 64) * 4)) return rc;
         if (int rc = c->apx_clean[s].reserve((RT / 32) * (RF / 64) + 64)) return rc;
@@ -313,10 +314,10 @@ int ldw_links_end(ldw_ctx *c) {
     int64_t h_lr = 0;
     std::vector<int64_t> si((size_t)nb * 3 + 1);
     std::vector<double> sd((size_t)nb + 1);
-    int64_t h_viol = 0, h_apx[2] = {0, 0};
+    int64_t h_viol = 0, h_apx[3] = {0, 0, 0};
     LDW_HIP(hipMemcpyAsync(&h_lr, sl.lr_count, 8, hipMemcpyDeviceToHost, c->stream));
     LDW_HIP(hipMemcpyAsync(&h_viol, sl.lr_count + 1, 8, hipMemcpyDeviceToHost, c->stream));
-    LDW_HIP(hipMemcpyAsync(h_apx, sl.lr_count + 2, 16, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipMemcpyAsync(h_apx, sl.lr_count + 2, 24, hipMemcpyDeviceToHost, c->stream));
     unsigned long long h_skip = 0;
     if (c->apx_skip.p) {   // wave tiles the approximate GEMMs pruned: not executed work (ldw_gemm_stats)
         LDW_HIP(hipMemcpyAsync(&h_skip, c->apx_skip.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -331,6 +332,7 @@ int ldw_links_end(ldw_ctx *c) {
     c->screen_violations += h_viol;
     c->apx_units_listed += h_apx[0];
     c->apx_pairs_listed += h_apx[1];
+    c->maybe_entries += h_apx[2];
     c->apx_waves_skipped += (int64_t)h_skip;
     c->gemm_stat[1] -= (double)h_skip * c->apx_ops_per_wave;
     c->stats.resize((size_t)nb);
@@ -874,7 +876,7 @@ int ldw_overflow_report(ldw_ctx *c, int64_t out[4]) {
     out[0] = c->pair_list_overflows;
     out[1] = c->maybe_overflows;
     out[2] = c->maybe_off ? 1 : 0;
-    out[3] = 0;
+    out[3] = c->maybe_entries;
     return LDW_OK;
 }
 

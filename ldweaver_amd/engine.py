@@ -118,7 +118,7 @@ class Engine:
         LDW_MAYBE_CAP is set), and whether the maybe list is switched off for the rest of the pass."""
         v = np.zeros(4, dtype=np.int64)
         L.check(L.lib().ldw_overflow_report(self._ctx, L.ptr(v)))
-        return dict(pair_list=int(v[0]), maybe_list=int(v[1]), maybe_off=bool(v[2]))
+        return dict(pair_list=int(v[0]), maybe_list=int(v[1]), maybe_off=bool(v[2]), maybe_entries=int(v[3]))
 
     @staticmethod
     def set_pair_cap(cap: int):
