@@ -344,7 +344,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
                            &c->sr_mi, &c->lr_a, &c->lr_b, &c->lr_mi, &c->srm_pack, &c->srm_key, &c->srm_pack2, &c->srm_key2, &c->srm_pay, &c->srm_pay2, &c->srm_off,
                            &c->srm_q, &c->srm_n, &c->srm_md, &c->srm_part, &c->srm_shape, &c->srm_cnt, &c->red_row, &c->red_meta,
                            &c->red_srp, &c->pool_a, &c->pool_b, &c->pool_mi, &c->ar_key, &c->ar_val, &c->ar_key2, &c->ar_val2,
-                           &c->ar_off, &c->ar_flags, &c->seq_perm, &c->dig_a, &c->dig_b, &c->apx_shift, &c->slot_papx, &c->pop_segs, &c->pop_wbeg,
+                           &c->ar_off, &c->ar_flags, &c->seq_perm, &c->dig_a, &c->dig_b, &c->apx_shift, &c->slot_papx, &c->pop_segs, &c->pop_wbeg, &c->pop_vpos,
                            &c->pair_sums, &c->tab11[0], &c->tab11[1], &c->G2, &c->G3, &c->miss_key, &c->miss_val};
     for (auto *b : bufs) b->release();
     for (int k = 0; k < LDW_NSLOT; ++k)

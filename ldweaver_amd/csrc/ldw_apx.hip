@@ -143,6 +143,13 @@ int prepare_apx_weights(ldw_ctx *c) {
     if (int rc = c->apx_shift.reserve((size_t)std::max(S4, 4) * 4)) return rc;
     if (int rc = c->pop_segs.reserve(segs.size() * sizeof(PopSeg))) return rc;
     if (int rc = c->pop_wbeg.reserve(wbeg.size() * 4)) return rc;
+    {   // r05: the fixed-point weight of every POSITION (0 in the padding) for the bit-walking pair sums of weightings with many classes (k_pair_sums_bits)
+        std::vector<int64_t> vpos((size_t)Npad, 0);
+        for (int64_t q = 0; q < N; ++q) vpos[(size_t)q] = Vp[(size_t)q];
+        if (int rc = c->pop_vpos.reserve((size_t)Npad * 8)) return rc;
+        LDW_HIP(hipMemcpyAsync(c->pop_vpos.p, vpos.data(), (size_t)Npad * 8, hipMemcpyHostToDevice, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));   // (vpos is on this frame)
+    }
     LDW_HIP(hipMemcpyAsync(c->dig_a.p, da.data(), (size_t)Npad, hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipMemcpyAsync(c->dig_b.p, db.data(), (size_t)Npad, hipMemcpyHostToDevice, c->stream));
     LDW_HIP(hipMemcpyAsync(c->apx_shift.p, sh.data(), (size_t)S4 * 4, hipMemcpyHostToDevice, c->stream));
@@ -1093,6 +1100,96 @@ __global__ __launch_bounds__(256) void k_pair_sums(PairArgs P) {
     }
 }
 
+// r05: the same exact sums for weightings with MANY classes (every sequence its own weight: hdw = 1 / (k + 1) with all k distinct, the bench's
+// adversarial "distinct weights" case).  The class-wise form above then walks one segment per POSITION — 32 records per word, read from global
+// memory because 5 000 records do not fit LDS: 1.37 ms per launch, 38 ms of an 85 ms pass, bound by the L2.  Here a lane walks the SET BITS of
+// its words instead (two SNPs' minor states co-occur in a few sequences per word) and adds the weight of each position from a table in LDS,
+// laid out [bit][word] so that the lanes of a wave — different words, any bit — never share a bank (stride a multiple of 32 words).
+// Same integers (a sum of the same int64 terms in another order), so the tables downstream are bit-identical.
+template <int CA, int CB>
+__device__ __forceinline__ void pair_sums_bits_body(const PairArgs &P, int path, const int64_t *sVT, int stride) {
+    constexpr bool GENB = CA == 4 && CB == 4;
+    const EpiArgs &A = P.A;
+    const int sub = path * PAIR_SHARDS + (int)blockIdx.y;
+    unsigned int n = A.pl_n[sub];
+    n = n > A.pl_cap ? A.pl_cap : n;
+    const int lane = threadIdx.x & 63;
+    const PairEnt *list = A.pl_pairs + (int64_t)sub * A.pl_cap;
+    for (unsigned int idx = blockIdx.x * 4u + (threadIdx.x >> 6); idx < n; idx += gridDim.x * 4u) {
+        const PairEnt e = list[idx];
+        const uint32_t era = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.ra), erb = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.rb);
+        const int r0a = (int)(era & 0x1FFFFFFFu), na = (int)(era >> 29), r0b = (int)(erb & 0x1FFFFFFFu), nb = (int)(erb >> 29);
+        const uint32_t *fr[CA], *tr[CB];
+#pragma unroll
+        for (int i = 0; i < CA; ++i) fr[i] = reinterpret_cast<const uint32_t *>(P.Mbits + (int64_t)(i < na ? r0a + i : P.zero_row) * P.KW);
+#pragma unroll
+        for (int j = 0; j < CB; ++j) tr[j] = reinterpret_cast<const uint32_t *>(P.Mbits + (int64_t)(j < nb ? r0b + j : P.zero_row) * P.KW);
+        int64_t s[CB][CA];
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int i = 0; i < CA; ++i) s[j][i] = 0;
+        for (int w = lane; w < P.nwords; w += 64) {
+            uint32_t f[CA], t[CB], uf = 0u, ut = 0u;
+#pragma unroll
+            for (int i = 0; i < CA; ++i) {
+                f[i] = (!GENB || i < na) ? fr[i][w] : 0u;
+                uf |= f[i];
+            }
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                t[j] = (!GENB || j < nb) ? tr[j][w] : 0u;
+                ut |= t[j];
+            }
+            uint32_t u = uf & ut;   // positions where SOME row of a and some row of b are set
+            while (u) {
+                const int b = __builtin_ctz(u);
+                u &= u - 1u;
+                const int64_t v = sVT[b * stride + w];
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int i = 0; i < CA; ++i)
+                        if (CA * CB == 1 || (((f[i] & t[j]) >> b) & 1u)) s[j][i] += v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int i = 0; i < CA; ++i) {
+                int64_t v = s[j][i];
+                if (!GENB || (i < na && j < nb)) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                }
+                if (lane == 0) P.sums[((int64_t)sub * A.pl_cap + idx) * 16 + j * 4 + i] = v;
+            }
+    }
+}
+
+template <bool GEN>
+__global__ __launch_bounds__(256) void k_pair_sums_bits(PairArgs P, const int64_t *__restrict__ vpos, int stride) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t pop_smem[];
+    int64_t *sVT = reinterpret_cast<int64_t *>(pop_smem);
+    const int path = GEN ? 4 : (int)blockIdx.z;
+    if (blockIdx.x * 4u >= P.A.pl_n[path * PAIR_SHARDS + (int)blockIdx.y]) return;   // nothing for this workgroup
+    for (int i = threadIdx.x; i < 32 * stride; i += 256) {
+        const int b = i / stride, w = i - b * stride;
+        sVT[i] = w < P.nwords ? vpos[32 * w + b] : 0;
+    }
+    __syncthreads();
+    if constexpr (GEN) {
+        pair_sums_bits_body<4, 4>(P, 4, sVT, stride);
+    } else {
+        switch (path) {
+            case 0: pair_sums_bits_body<1, 1>(P, 0, sVT, stride); break;
+            case 1: pair_sums_bits_body<2, 1>(P, 1, sVT, stride); break;
+            case 2: pair_sums_bits_body<1, 2>(P, 2, sVT, stride); break;
+            default: pair_sums_bits_body<2, 2>(P, 3, sVT, stride); break;
+        }
+    }
+}
+
 // Emission of the listed pairs.  Nearly all of them ARE candidates (they sit in the few buckets just above the guess), so one
 // returning atomic on the candidate counter plus one histogram atomic per pair made the kernel a queue at two or three
 // addresses of the L2 (100 us for 7e4 pairs; 14 us with the atomics compiled out): a wave bumps the counter ONCE for all its
@@ -1225,8 +1322,26 @@ int launch_pairs_exact(ldw_ctx *c, const EpiArgs &A, unsigned long long *ghist, 
     size_t lds = (((size_t)P.nwords + 4) * 4 + 15) / 16 * 16 + (size_t)P.nseg * sizeof(PopSeg);
     P.seg_in_lds = lds <= 60000 ? 1 : 0;
     if (!P.seg_in_lds) lds = 0;
-    hipLaunchKernelGGL(k_pair_sums<false>, dim3(256, PAIR_SHARDS, 4), dim3(256), lds, st, P);
-    hipLaunchKernelGGL(k_pair_sums<true>, dim3(256, PAIR_SHARDS, 1), dim3(256), lds, st, P);
+    // r05: many weight classes (the segment tables do not fit LDS) -> walk the set bits against a per-position weight table in LDS instead, as long as
+    // THAT fits (256 B per word of a row: 40 KB at N = 5120, 80 KB at 10 240; beyond 160 KB — N > 20 480 — the class-wise kernel reads its tables from global memory)
+    const int stride = (P.nwords + 31) / 32 * 32;
+    const size_t lds_bits = (size_t)32 * stride * 8;
+    const bool bits_off = getenv("LDW_NO_PAIR_BITS") != nullptr;   // (read per call: A/B, and the test runs both forms)
+    // (which form: the class-wise one costs a popcount per SEGMENT — 1.3 segments per word with C4's 57 clonal classes —, the bit walk an LDS read per
+    // co-occurring position; from ~8 segments per word on, i.e. weightings whose classes are a few sequences each, the bits are fewer than the segments)
+    const bool many_classes = !P.seg_in_lds || P.nseg >= 8 * P.nwords;
+    if (many_classes && !bits_off && lds_bits <= 160 * 1024 && c->pop_vpos.p) {
+        if (lds_bits > 64 * 1024 && !c->pair_bits_attr) {
+            LDW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_sums_bits<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            LDW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_sums_bits<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            c->pair_bits_attr = true;
+        }
+        hipLaunchKernelGGL(k_pair_sums_bits<false>, dim3(256, PAIR_SHARDS, 4), dim3(256), lds_bits, st, P, c->pop_vpos.as<int64_t>(), stride);
+        hipLaunchKernelGGL(k_pair_sums_bits<true>, dim3(256, PAIR_SHARDS, 1), dim3(256), lds_bits, st, P, c->pop_vpos.as<int64_t>(), stride);
+    } else {
+        hipLaunchKernelGGL(k_pair_sums<false>, dim3(256, PAIR_SHARDS, 4), dim3(256), lds, st, P);
+        hipLaunchKernelGGL(k_pair_sums<true>, dim3(256, PAIR_SHARDS, 1), dim3(256), lds, st, P);
+    }
     hipLaunchKernelGGL(k_pair_mi, dim3(64, PAIR_SHARDS, PAIR_PATHS), dim3(256), 0, st, P);
     LDW_HIP(hipGetLastError());
     return LDW_OK;

@@ -131,6 +131,8 @@ struct ldw_ctx {
     std::vector<int64_t> h_vapx;       // [Npad] by SEQUENCE: V'_s = a b 2^e (exact integer)
     ldw::DevBuf slot_papx;             // int64 [L][5] by slot: floor(marginal of V' / 2^apx_e_last)
     ldw::DevBuf pop_segs, pop_wbeg;    // popcount segments (PopSeg) and first segment of every 32-bit word (+1)
+    ldw::DevBuf pop_vpos;              // r05: int64 [Npad] fixed-point weight by POSITION (k_pair_sums_bits: weightings with many classes)
+    bool pair_bits_attr = false;       // the > 64 KB dynamic-LDS attribute of k_pair_sums_bits has been set (this context's device)
     int n_pop_segs = 0, n_classes = 0;
     ldw::DevBuf panel[LDW_NSLOT][2];           // [slot][from, to]: packed bit panels of a block's row lists, [KW/2][Rpad][2] u64
     ldw::DevBuf Gapx[LDW_NSLOT];               // int32 [RTpad][RFpad] approximate joint sums, one per pipeline slot

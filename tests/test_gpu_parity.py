@@ -2045,10 +2045,17 @@ def test_adversarial_alignment_default_equals_plain(engine, weights):
     lr_retain = 2e5     # keeps 0.1 % of the 2e8 pairs: the speculative path is the automatic choice
     out = {}
     try:
-        for key, (mixed, scr, path, cold) in dict(plain=(False, 0, 1, True), cold=(True, 1, 0, True), warm=(True, 1, 0, False), verify=(True, 2, 0, False)).items():
+        # (classwise: r05 — the exact sums of the listed pairs by the class-wise popcount kernel where the default walks the set bits against a
+        # per-position weight table, k_pair_sums_bits: the form weightings with many classes take; same integers, so the same tables)
+        for key, (mixed, scr, path, cold) in dict(plain=(False, 0, 1, True), cold=(True, 1, 0, True), warm=(True, 1, 0, False), verify=(True, 2, 0, False),
+                                                  classwise=(True, 1, 0, False)).items():
             engine.set_mixed(mixed)
             engine.set_screen(scr)
             engine.set_path(path)
+            if key == "classwise":
+                os.environ["LDW_NO_PAIR_BITS"] = "1"
+            else:
+                os.environ.pop("LDW_NO_PAIR_BITS", None)
             if cold:
                 engine.reset_speculation()
             c0, o0, s0 = engine.counters(), engine.overflow_report(), engine.span_report()
@@ -2059,6 +2066,7 @@ def test_adversarial_alignment_default_equals_plain(engine, weights):
                      span_blocks_redone=s1["redone"] - s0["redone"], maybe_off=o1["maybe_off"])
             out[key] = (engine.links(0), engine.links(1), engine.block_stats(), d)
     finally:
+        os.environ.pop("LDW_NO_PAIR_BITS", None)
         engine.set_mixed(True)
         engine.set_screen(1)
         engine.set_path(0)
@@ -2072,7 +2080,7 @@ def test_adversarial_alignment_default_equals_plain(engine, weights):
         assert d["spec_misses"] == 0 and d["span_blocks_redone"] == 0, (key, d)
         assert d["pair_list_overflows"] == 0 and d["maybe_list_overflows"] == 0 and not d["maybe_off"], (key, d)
         assert d["apx_blocks"] >= len(blocks) - 1, (key, d)   # (cold: the pass's very first block may run before its kind has a guess)
-    for key in ("cold", "warm", "verify"):
+    for key in ("cold", "warm", "verify", "classwise"):
         for which in (0, 1):
             for x, y in zip(out["plain"][which], out[key][which]):
                 assert np.array_equal(x, y), (key, which)
