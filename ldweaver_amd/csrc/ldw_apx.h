@@ -67,7 +67,10 @@ struct ApxMaybe {
     uint32_t trow, fcol;   // row-list positions = column slot / from slot of the epilogue orders (biallelic rows: position == slot)
     int32_t n;             // the approximate joint sum n'
 };
-constexpr int APX_MAYBE_MAX = 96;   // more failing entries than this in a region of 2048: storing the region is the cheaper path
+#ifndef LDW_MAYBE_MAX
+#define LDW_MAYBE_MAX 96
+#endif
+constexpr int APX_MAYBE_MAX = LDW_MAYBE_MAX;   // more failing entries than this in a region of 2048: storing the region is the cheaper path
 
 // (rowlist2 / Rpad2 / panel2: a second panel in the same launch)
 int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st, const int32_t *rowlist2 = nullptr, int Rpad2 = 0,
