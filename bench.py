@@ -83,6 +83,8 @@ def parse():
     ap.add_argument("--inproc", action="store_true", help="N > 1 WITHOUT one process per GPU: this one process creates one context per device and runs "
                                                           "ldw_mi_all_pairs_multi (worker threads + peer-to-peer gather inside the library) — the route the R shim takes")
     ap.add_argument("--inproc-devices", default="", help="comma-separated device ids for --inproc (default 0..gpus-1; '0,0' = two contexts on one GPU)")
+    ap.add_argument("--no-sr-tail-leg", action="store_true", help="N > 1: skip the leg that runs the short-range model + ARACNE behind the pass both ways "
+                    "(table gathered to rank 0 / rows left on their ranks: ldweaver_amd/dist_srp.py)")
     ap.add_argument("--sustain-s", type=float, default=10.0, help="N = 1: keep stepping after the timed region until this many seconds of steps have run")
     return ap.parse_args()
 
@@ -234,6 +236,88 @@ def adversarial_leg(L, N, device, args):
             out[tag] = rec
     out["ok"] = all(out[t]["note"].startswith("ok") for t in ("hamming_weights", "distinct_weights"))
     return out
+
+
+def sr_tail_leg(eng, blocks, mine, sr_dist, lr_retain, approx, POS, paint, g, dev, rank, world, fence):
+    """N > 1, after the timed region: pass + short-range model + ARACNE, (a) the r04 route — link tables gathered to rank 0
+    (short-range rows as their MI column), rank 0 runs the model alone on the assembled 1.44 GB table — against (b) the rows LEFT on their ranks
+    (dist_srp.merge_n_sort_sr_links_dist: bounds, ~7 % of the MI column, block sums, kept links and pool travel; only the long-range table is gathered).
+    Same kept links, srp and flags; per-rank bytes on the line.  Both wall clocks include the pass itself."""
+    import torch
+    import torch.distributed as dist
+    from ldweaver_amd.dist import gather_block_stats, gather_link_tables
+    from ldweaver_amd.dist_srp import merge_n_sort_sr_links_dist
+    from ldweaver_amd.srp import merge_n_sort_sr_links_device
+    nblocks, nclust, cut = len(blocks), int(np.max(paint)), 3.0
+
+    def run_pass():
+        eng.reset_speculation()
+        if len(mine):
+            eng.mi_all_pairs(blocks[mine], sr_dist, lr_retain, approx)
+            return eng.block_stats()
+        eng.links_begin(1)
+        eng.links_end()
+        z = np.zeros(0, dtype=np.int64)
+        return dict(n_sr=z, n_lr_kept=z, n_lr_total=z, disc_thresh=np.zeros(0))
+
+    def digest(red, flags):
+        return dict(rows=int(len(red["MI"])), aracne_true=int(np.sum(flags)), mi_sum=float(np.sum(red["MI"])), srp_sum=float(np.sum(red["srp_max"])),
+                    first=[int(red["a"][0]), int(red["b"][0])] if len(red["MI"]) else None)
+
+    res = {}
+    # (a) gather, then the model on rank 0
+    fence()
+    t0 = time.perf_counter()
+    st = run_pass()
+    out = gather_link_tables({"sr": eng.links_view(0), "lr": eng.links_view(1)}, mine, {"sr": st["n_sr"], "lr": st["n_lr_kept"]}, nblocks,
+                             sr_pairs=lambda n: eng.sr_pairs(blocks, sr_dist, n))
+    sent_a = int(8 * np.sum(st["n_sr"]) + 16 * np.sum(st["n_lr_kept"])) if rank != 0 else 0
+    fence()
+    t1 = time.perf_counter()
+    dig_a = None
+    stats_all = gather_block_stats(st, mine, nblocks)
+    if rank == 0:
+        eng.links_import(0, *out["sr"])
+        eng.links_import(1, *out["lr"])
+        red, flags, _ = merge_n_sort_sr_links_device(eng, nclust, sr_dist, cut, POS, paint, g, run_aracne=True, order_links=True, block_rows=stats_all["n_sr"])
+        dig_a = digest(red, flags)
+    del out
+    fence()
+    t2 = time.perf_counter()
+    res["gather"] = dict(pass_and_gather_ms=(t1 - t0) * 1e3, model_aracne_on_rank0_ms=(t2 - t1) * 1e3, total_ms=(t2 - t0) * 1e3)
+    # (b) the rows stay
+    fence()
+    t0 = time.perf_counter()
+    st = run_pass()
+    stats_all = gather_block_stats(st, mine, nblocks)
+    e = lambda dt: torch.empty(0, dtype=dt, device=dev)
+    out = gather_link_tables({"sr": (e(torch.int32), e(torch.int32), e(torch.float64)), "lr": eng.links_view(1)}, mine,
+                             {"sr": np.zeros(len(mine), dtype=np.int64), "lr": st["n_lr_kept"]}, nblocks)
+    fence()
+    t1 = time.perf_counter()
+    red, flags, aux = merge_n_sort_sr_links_dist(eng, nclust, sr_dist, cut, POS, paint, g, mine, stats_all["n_sr"], run_aracne=True, order_links=True)
+    fence()
+    t2 = time.perf_counter()
+    sent_b = dict(aux["bytes_sent"], lr_table=int(16 * np.sum(st["n_lr_kept"])) if rank != 0 else 0)
+    res["dist"] = dict(pass_and_lr_gather_ms=(t1 - t0) * 1e3, model_aracne_over_ranks_ms=(t2 - t1) * 1e3, total_ms=(t2 - t0) * 1e3)
+    mine_rec = dict(rank=rank, sr_rows=int(np.sum(st["n_sr"])), candidates=int(aux["candidates"]), bytes_sent_gather=sent_a,
+                    bytes_sent_dist=int(sum(sent_b.values())), bytes_sent_dist_by_exchange=sent_b)
+    recs = [None] * world
+    dist.all_gather_object(recs, mine_rec)
+    if rank != 0:
+        return None
+    dig_b = digest(red, flags)
+    res["per_rank"] = recs
+    res["kept_links"] = dict(gather=dig_a, dist=dig_b)
+    same = dig_a == dig_b   # (bit for bit: both routes sum the excess statistics per reference block in make_blocks order)
+    res["kept_links_equal"] = bool(same)
+    peers = [r for r in recs if r["rank"] != 0]
+    res["max_bytes_sent_per_peer"] = dict(gather=max(r["bytes_sent_gather"] for r in peers), dist=max(r["bytes_sent_dist"] for r in peers))
+    res["what"] = ("pass + mergeNsort_sr_links + runARACNE behind it, wall clock incl. the pass: `gather` = link tables assembled on rank 0 (short-range rows as their MI "
+                   "column), model on rank 0 alone; `dist` = short-range rows left on their ranks (only bounds, the rows from the smallest local 95 % order statistic up, "
+                   "block sums, kept links and the ARACNE pool travel; the long-range table is gathered as before).  All ranks share ONE GPU when the backend is gloo: "
+                   "times there say nothing about xGMI (unmeasured on hardware); the bytes do")
+    return res
 
 
 def self_launch(args):
@@ -511,6 +595,10 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine_rec)
 
+    sr_tail = None
+    if world > 1 and not args.no_extra_legs and not args.no_sr_tail_leg and args.engine == "mfma":
+        sr_tail = sr_tail_leg(eng, blocks, mine, sr_dist, lr_retain, approx, POS, paint, g, dev, rank, world, fence)
+
     extra = rank == 0 and world == 1 and len(my_blocks) and not args.no_extra_legs
     legs = {}
     # ---- warm replay: K steps that inherit their predecessor's bucket guesses, spread history and threshold table (what r02
@@ -744,6 +832,8 @@ def main():
         out["self_launched"] = bool(os.environ.get("LDW_BENCH_SELF_LAUNCHED"))
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if sr_tail is not None:
+            out["sr_tail"] = sr_tail
         out.update(stages_ms_per_step={k: v / max(1, n_replay) for k, v in tim.items()},
                    stages_ms_per_step_overlapped={k: v / K for k, v in tim_overlapped.items()},
                    links=links_timed, counters=counters_timed, counters_replay=cnt_replay, hamming_weights_s=hamming_s,

@@ -337,7 +337,7 @@ int ldw_sr_excess_stats(ldw_ctx *ctx, int nclust, int32_t S, const double *mean_
 /* (:453, :475-490) shape[c*3 + {0,1,2}] = beta shape1, shape2, log B(shape1, shape2).  srp = -log P(X > diff)
  * per link and cluster, maximum over the link's clusters (ties: smaller cluster id), links with
  * srp > srp_cutoff are kept on the device (n_red), and the ARACNE pool = links with a positive excess in
- * some cluster and MI >= min MI kept (n_pool). */
+ * some cluster and MI >= min MI kept (n_pool; n_pool_out = NULL: no pool is built, see ldw_sr_pool_build). */
 int ldw_sr_pvalues(ldw_ctx *ctx, int nclust, int32_t S, const double *mean_dist, const double *shape,
                    double srp_cutoff, int64_t *n_red_out, int64_t *n_pool_out, double *min_mi_out);
 /* kept links in no particular order: row in the sr table (ldw_links_fetch order) and that row's (a, b, MI),
@@ -351,6 +351,37 @@ int ldw_sr_pool_fetch(ldw_ctx *ctx, int64_t capacity, int32_t *a_out, int32_t *b
  * flags_out[i] belongs to row_out[i] of ldw_sr_reduced_fetch (after ldw_sr_pvalues) or ldw_lr_reduced_fetch (after
  * ldw_lr_tukey). */
 int ldw_aracne_device(ldw_ctx *ctx, int64_t capacity, uint8_t *flags_out);
+
+/* ---- (7b) r05 — the same model with the short-range table LEFT on the GPUs that computed it (multi-GPU jobs: SURVEY.md 8(e); the
+ *          reference's mergeNsort_sr_links, R/computePairwiseMI.R:400-495, sees one table).  Every rank calls (7) on its own rows; what
+ *          travels between ranks is per-group bounds and counts, ~7 % of the MI column, five sums per block and cluster, the kept links and
+ *          the ARACNE pool — not the table (host side: ldweaver_amd/dist_srp.py; protocol and proof of the bound: DESIGN.md 7b). ---- */
+/* Rows of the context's table at or above a per-(cluster, len) bound.  lower[c*S + l-1] (host; NaN: send nothing, -inf: every member).  A group's
+ * rows are the table rows with that len whose pos1 or pos2 lies in cluster c+1 (a row of two clusters is a member of both, :411-414).
+ * cnt_out[(l-1)*nclust + c] (host, len-major) = rows passing, *n_out their sum; mi_out (host or device, `capacity` doubles; NULL: count
+ * only) = their MI values grouped in that order, in no particular order within a group.  After ldw_sr_len_quantiles (same nclust, S). */
+int ldw_sr_tail_extract(ldw_ctx *ctx, int nclust, int32_t S, const double *lower, int64_t *cnt_out, double *mi_out, int64_t capacity,
+                        int on_device, int64_t *n_out);
+/* The order statistics of quantile(type 7, prob) per (cluster, len) from the candidates of n_src ranks: mi_src[r] / cnt_src[r] = what
+ * ldw_sr_tail_extract gave on rank r (values: host or device by on_device; counts: host), n_total[c*S + l-1] = the group's size over all
+ * ranks.  Every row that is NOT among the candidates must lie below every candidate of its group (bounds from ldw_sr_len_quantiles of the
+ * ranks: the smallest local lower order statistic is one).  q_lo_out / q_hi_out as ldw_sr_len_quantiles.  *violations_out = groups whose
+ * order statistic does not lie among the candidates (NaN there; NULL: such a group is an error).  Needs no table, alignment or meta data. */
+int ldw_sr_quantiles_merge(ldw_ctx *ctx, int nclust, int32_t S, double prob, int n_src, const double *const *mi_src,
+                           const int64_t *const *cnt_src, const int64_t *n_total, int on_device, double *q_lo_out, double *q_hi_out,
+                           int64_t *violations_out);
+/* ldw_sr_excess_stats per reference block: the table's rows are those of `nblocks` blocks in order, rows_per_block[b] each (sum = the
+ * table's rows); stats_out[(b*nclust + c)*5 + k].  A block's sums depend on its own rows only (64 strips, fixed order), so the sum over
+ * all blocks in make_blocks order is bit-identical however the blocks were dealt over ranks. */
+int ldw_sr_excess_stats_blocks(ldw_ctx *ctx, int nclust, int32_t S, const double *mean_dist, int64_t nblocks, const int64_t *rows_per_block,
+                               double *stats_out);
+/* The ARACNE pool of this context's rows for a minimum taken over all ranks (ldw_sr_pvalues with n_pool_out = NULL builds none): rows with a
+ * positive excess in some cluster and MI >= min_mi (:489-490); NaN: empty.  Then ldw_sr_pool_fetch. */
+int ldw_sr_pool_build(ldw_ctx *ctx, double min_mi, int64_t *n_pool_out);
+/* Rank 0: adopt the kept links and the pool of all ranks (host arrays, 0-based from-side / to-side SNP index and MI).  The kept links REPLACE
+ * the context's short-range table (rows 0..n_red-1); ldw_aracne_device then answers for them in that order. */
+int ldw_sr_reduced_import(ldw_ctx *ctx, int64_t n_red, const int32_t *a, const int32_t *b, const double *MI, int64_t n_pool,
+                          const int32_t *pool_a, const int32_t *pool_b, const double *pool_MI);
 
 /* ---- (8) consumers of the link tables, on the device-resident tables ------------------ */
 /* Numeric core of analyse_long_range_links (R/lr_analyser.R:72-111): q13_out = quantile(MI, c(.25,.75)) (type 7) of the

@@ -89,6 +89,11 @@ _SIGS = {
     "ldw_sr_reduced_fetch": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "ldw_sr_pool_fetch": (C.c_int, [_p, _i64, _p, _p, _p]),
     "ldw_aracne_device": (C.c_int, [_p, _i64, _p]),
+    "ldw_sr_tail_extract": (C.c_int, [_p, C.c_int, C.c_int32, _p, _p, _p, _i64, C.c_int, _p]),
+    "ldw_sr_quantiles_merge": (C.c_int, [_p, C.c_int, C.c_int32, C.c_double, C.c_int, _p, _p, _p, C.c_int, _p, _p, _p]),
+    "ldw_sr_excess_stats_blocks": (C.c_int, [_p, C.c_int, C.c_int32, _p, _i64, _p, _p]),
+    "ldw_sr_pool_build": (C.c_int, [_p, C.c_double, _p]),
+    "ldw_sr_reduced_import": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _p]),
     "ldw_gemm_stats": (C.c_int, [_p, _p, C.c_int]),
     "ldw_lr_tukey": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, _p, _p]),
     "ldw_lr_reduced_fetch": (C.c_int, [_p, _i64, _p, _p, _p, _p]),

@@ -345,7 +345,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
                            &c->srm_q, &c->srm_n, &c->srm_md, &c->srm_part, &c->srm_shape, &c->srm_cnt, &c->red_row, &c->red_meta,
                            &c->red_srp, &c->pool_a, &c->pool_b, &c->pool_mi, &c->ar_key, &c->ar_val, &c->ar_key2, &c->ar_val2,
                            &c->ar_off, &c->ar_flags, &c->seq_perm, &c->dig_a, &c->dig_b, &c->apx_shift, &c->slot_papx, &c->pop_segs, &c->pop_wbeg, &c->pop_vpos,
-                           &c->pair_sums, &c->tab11[0], &c->tab11[1], &c->G2, &c->G3, &c->miss_key, &c->miss_val};
+                           &c->pair_sums, &c->tab11[0], &c->tab11[1], &c->G2, &c->G3, &c->miss_key, &c->miss_val, &c->srd_lower, &c->srd_cur, &c->srd_out, &c->srd_seg};
     for (auto *b : bufs) b->release();
     for (int k = 0; k < LDW_NSLOT; ++k)
         for (ldw::DevBuf *b : {&c->panel[k][0], &c->panel[k][1], &c->Gapx[k], &c->pairs[k], &c->apx_mini[k], &c->apx_units[k], &c->apx_packs[k], &c->apx_bins[k], &c->apx_clean[k], &c->scr_live[k], &c->sub_units[k], &c->sub_packs[k], &c->sub_bins[k], &c->sub_live[k],

@@ -106,8 +106,12 @@ __global__ void k_sr_seg_offsets(const uint16_t *__restrict__ pack, int64_t n, i
 
 // One workgroup per len.  q[(c*S + l-1)*2 + {0,1}] = the order statistics of rank floor(h), ceil(h), h = (n-1)*prob,
 // among the MI values of the links of that len that touch cluster c+1; cnt[c*S + l-1] = n.
+// r05: `gtot` (may be null) — the rows in `pay` are only the TOP of every group (the candidates rank 0 received from all ranks: ldw_sr_quantiles_merge);
+// gtot[c*S + l-1] = the group's size over ALL ranks, the rows that are not here all lie below every row that is, so a wanted rank moves down by
+// (gtot - members here); a rank that falls outside what is here (the senders' bound was wrong) is counted in *viol and leaves NaN.
 __global__ __launch_bounds__(256) void k_sr_quant(const SrPay *__restrict__ pay, const int64_t *__restrict__ off, int S, int nclust, double prob,
-                                                  double *__restrict__ q, int64_t *__restrict__ cnt) {
+                                                  double *__restrict__ q, int64_t *__restrict__ cnt, const int64_t *__restrict__ gtot,
+                                                  unsigned int *__restrict__ viol) {
     __shared__ unsigned long long tot[SRM_MAXCL + 1], run[SRM_MAXCL + 1], tlo[SRM_MAXCL + 1], thi[SRM_MAXCL + 1];
     __shared__ unsigned int ccnt[SRM_MAXCL + 1];
     __shared__ unsigned int wcnt[4];
@@ -128,14 +132,22 @@ __global__ __launch_bounds__(256) void k_sr_quant(const SrPay *__restrict__ pay,
     }
     __syncthreads();
     for (int c = tid + 1; c <= nclust; c += 256) {
-        const unsigned long long n = tot[c];
+        const unsigned long long here = tot[c];
+        const unsigned long long n = gtot ? (unsigned long long)gtot[(int64_t)(c - 1) * S + (l - 1)] : here;
         cnt[(int64_t)(c - 1) * S + (l - 1)] = (int64_t)n;
         if (n) {
             const double index = q7_index((double)(n - 1), prob);   // R's 1-based index, rounded as R rounds it (no fma: ldw_dev.h)
-            tlo[c] = (unsigned long long)floor(index) - 1ull;
-            thi[c] = (unsigned long long)ceil(index) - 1ull;
+            const unsigned long long below = n - (here < n ? here : n), lo = (unsigned long long)floor(index) - 1ull, hi = (unsigned long long)ceil(index) - 1ull;
+            if (here > n || lo < below) {   // (only with gtot: more members here than the group has, or the rank lies among the rows that stayed at home)
+                tlo[c] = thi[c] = ~0ull;
+                if (viol) atomicAdd(viol, 1u);
+            } else {
+                tlo[c] = lo - below;
+                thi[c] = hi - below;
+            }
         } else {
             tlo[c] = thi[c] = ~0ull;
+            if (here && viol) atomicAdd(viol, 1u);
         }
     }
     __syncthreads();
@@ -442,6 +454,23 @@ __device__ __forceinline__ double excess(double mi, int len, int c, const double
     return mi - md[(int64_t)(c - 1) * S + (len - 1)];
 }
 
+// The rows of one workgroup.  seg == null: the table cut into gridDim.x contiguous strips.  r05, seg != null: segment blockIdx.x / strips of the table
+// (seg[2 k], seg[2 k + 1]) = [first row, end) — the rows of ONE reference block — cut into `strips` strips: a segment's partial sums are then a function
+// of that block's rows alone, whichever rank holds them and whatever else its table holds (ldw_sr_excess_stats_blocks).
+__device__ __forceinline__ void strip_of(int64_t n, const int64_t *__restrict__ seg, int strips, int64_t &beg, int64_t &end) {
+    if (seg) {
+        const int k = blockIdx.x / strips, j = blockIdx.x % strips;
+        const int64_t b0 = seg[2 * k], b1 = seg[2 * k + 1];
+        const int64_t per = (b1 - b0 + strips - 1) / strips;
+        beg = b0 + (int64_t)j * per < b1 ? b0 + (int64_t)j * per : b1;
+        end = beg + per < b1 ? beg + per : b1;
+    } else {
+        const int64_t per = (n + gridDim.x - 1) / gridDim.x;   // contiguous strip per workgroup
+        beg = (int64_t)blockIdx.x * per;
+        end = beg + per < n ? beg + per : n;
+    }
+}
+
 // r04: the same statistics for nclust <= 4 with the sums kept PER LANE over the workgroup's whole strip (5 running sums per cluster in
 // registers, predicated adds) and reduced once at the end — lanes in index order, then the four waves, as before the workgroups on the host:
 // still a fixed order, bit-identical from run to run.  k_sr_stats peels the clusters of every wave of 64 rows and reduces five doubles across
@@ -450,11 +479,12 @@ template <int NC>
 __global__ __launch_bounds__(256) void k_sr_stats_small(const int32_t *__restrict__ sa, const int32_t *__restrict__ sb,
                                                         const double *__restrict__ smi, int64_t n, const int32_t *__restrict__ POS,
                                                         const int32_t *__restrict__ paint, double g, double sr_dist,
-                                                        const double *__restrict__ md, int S, int nclust, double *__restrict__ part) {
+                                                        const double *__restrict__ md, int S, int nclust, double *__restrict__ part,
+                                                        const int64_t *__restrict__ seg, int strips) {
     __shared__ double red[4][NC][5];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t per = (n + gridDim.x - 1) / gridDim.x;   // contiguous strip per workgroup
-    const int64_t beg = (int64_t)blockIdx.x * per, end = beg + per < n ? beg + per : n;
+    int64_t beg, end;
+    strip_of(n, seg, strips, beg, end);
     double a[NC][5];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -500,14 +530,14 @@ __global__ __launch_bounds__(256) void k_sr_stats(const int32_t *__restrict__ sa
                                                   const double *__restrict__ smi, int64_t n, const int32_t *__restrict__ POS,
                                                   const int32_t *__restrict__ paint, double g, double sr_dist,
                                                   const double *__restrict__ md, int S, int nclust,
-                                                  double *__restrict__ part) {
+                                                  double *__restrict__ part, const int64_t *__restrict__ seg, int strips) {
     extern __shared__ double acc[];   // [4 waves][nclust][5]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int k = tid; k < 4 * nclust * 5; k += 256) acc[k] = 0.0;
     __syncthreads();
     double *mine = acc + (int64_t)wv * nclust * 5;
-    const int64_t per = (n + gridDim.x - 1) / gridDim.x;   // contiguous strip per workgroup
-    const int64_t beg = (int64_t)blockIdx.x * per, end = beg + per < n ? beg + per : n;
+    int64_t beg, end;
+    strip_of(n, seg, strips, beg, end);
     for (int64_t base = beg; base < end; base += 256) {
         const int64_t i = base + tid;
         int cs[2] = {0, 0};
@@ -796,6 +826,102 @@ static int srm_reserve_select(ldw_ctx *c, int64_t n) {
     if (int rc = c->srm_pay.reserve((size_t)n * sizeof(SrPay))) return rc;
     return c->srm_tmp.reserve(srm_sort_temp_bytes(n) + 256);
 }
+// ------------------------------------------------------------------------------------------------
+// r05: the short-range model with the rows LEFT on the rank that computed them.  What travels instead of the table:
+// per (cluster, len) group the rows at or above a bound that is known to lie below the group's order statistics (k_sr_tail: ~7 % of the MI
+// column), five sums per reference block and cluster, the kept links and the ARACNE pool.
+// ------------------------------------------------------------------------------------------------
+// Rows at or above their group's bound, group id = (len - 1) * nclust + (cluster - 1) (len-major: what the merging side sorts by).  A row
+// whose two SNPs lie in different clusters is a member of both groups (R/computePairwiseMI.R:411-414) and is listed in each.
+// MODE 0: cur[g] += members passing; MODE 1: out[cur[g]++] = MI (cur preset to the groups' first output positions).  NaN bound: nothing passes.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sr_tail(const int32_t *__restrict__ sa, const int32_t *__restrict__ sb, const double *__restrict__ smi,
+                                                 int64_t n, const int32_t *__restrict__ POS, const int32_t *__restrict__ paint, double g,
+                                                 double sr_dist, const double *__restrict__ lower, int S, int nclust,
+                                                 unsigned long long *__restrict__ cur, double *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const RowTag t = row_tag(sa[i], sb[i], POS, paint, g, sr_dist);
+        if (t.len <= 0 || t.len > S) continue;
+        const double mi = smi[i];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c = s == 0 ? t.c1 : (t.c2 != t.c1 ? t.c2 : 0);
+            if (c < 1 || c > nclust) continue;
+            if (!(mi >= lower[(int64_t)(c - 1) * S + (t.len - 1)])) continue;
+            const unsigned long long pos = atomicAdd(&cur[(int64_t)(t.len - 1) * nclust + (c - 1)], 1ull);
+            if (MODE == 1) out[pos] = mi;
+        }
+    }
+}
+
+// One source's candidates (values grouped len-major, goff = exclusive scan of its group counts, G + 1 entries) as tagged rows of the
+// two-sort path: pack = len << 16 | c << 8 | c (a member of ONE cluster: a row of two clusters was listed once per group), key = key of MI.
+__global__ __launch_bounds__(256) void k_tail_unpack(const double *__restrict__ mi, int64_t m, const int64_t *__restrict__ goff, int G, int nclust,
+                                                     int64_t base, uint32_t *__restrict__ pack, uint64_t *__restrict__ key) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+        int lo = 0, hi = G;   // the group whose range [goff[g], goff[g + 1]) holds i: last g with goff[g] <= i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (goff[mid] <= i) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t l = (uint32_t)(lo / nclust) + 1u, c = (uint32_t)(lo % nclust) + 1u;
+        pack[base + i] = (l << 16) | (c << 8) | c;
+        key[base + i] = f64_key(mi[i]);
+    }
+}
+
+__global__ void k_iota64(int64_t *__restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+// The two-sort path from tagged rows on: c->srm_pack[i] = len << 16 | clust1 << 8 | clust2, c->srm_key[i] = key of MI, n rows (k_sr_tag, or the
+// candidates of all ranks: k_tail_unpack).  Two stable LSD sorts, both over the FULL width of their key type: by MI (u64 keys, tags as values), then
+// by len (u16 keys, {MI key, tag} as values) -> ordered by (len, MI).  rocPRIM 7.2's merge-sort path mis-sorts u32 keys on a partial bit range at
+// mid sizes (reproduced standalone through the hipCUB interface), so no begin_bit/end_bit tricks here.  q: host, 2 * nclust * S (NaN-filled by
+// the caller: uploaded first); gtot / viol_out: see k_sr_quant.
+static int quant_reserve_sorts(ldw_ctx *c, int64_t n, int32_t S, size_t cells) {
+    if (int rc = c->srm_pack.reserve((size_t)n * 4)) return rc;
+    if (int rc = c->srm_pack2.reserve((size_t)n * 4)) return rc;
+    if (int rc = c->srm_key.reserve((size_t)n * 8)) return rc;
+    if (int rc = c->srm_key2.reserve((size_t)n * 8)) return rc;
+    if (int rc = c->srm_off.reserve((size_t)(S + 2) * 8)) return rc;
+    if (int rc = c->srm_q.reserve(cells * 16)) return rc;
+    if (int rc = c->srm_n.reserve(cells * 8 + 64)) return rc;
+    if (int rc = c->srm_pay.reserve((size_t)n * sizeof(SrPay))) return rc;
+    return c->srm_pay2.reserve((size_t)n * sizeof(SrPay));
+}
+static int quant_two_sorts(ldw_ctx *c, int64_t n, int32_t S, int nclust, double prob, const int64_t *d_gtot, std::vector<double> &q, int64_t *n_out,
+                           unsigned int *viol_out) {
+    const size_t cells = (size_t)nclust * S;
+    uint32_t *pack = c->srm_pack.as<uint32_t>(), *pack2 = c->srm_pack2.as<uint32_t>();
+    uint64_t *key = c->srm_key.as<uint64_t>(), *key2 = c->srm_key2.as<uint64_t>();
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 65536);
+    uint16_t *len16 = reinterpret_cast<uint16_t *>(pack), *len16b = len16 + n;   // pack is free after the first sort
+    SrPay *pay = c->srm_pay.as<SrPay>(), *pay2 = c->srm_pay2.as<SrPay>();
+    size_t t1 = 0, t2 = 0;
+    LDW_HIP(prim_sort_pairs(nullptr, t1, key, key2, pack, pack2, n, 0, 64, c->stream));
+    LDW_HIP(prim_sort_pairs(nullptr, t2, len16, len16b, pay, pay2, n, 0, 16, c->stream));
+    if (int rc = c->scratch.reserve(std::max(t1, t2))) return rc;
+    size_t tb = c->scratch.cap;
+    LDW_HIP(prim_sort_pairs(c->scratch.p, tb, key, key2, pack, pack2, n, 0, 64, c->stream));
+    hipLaunchKernelGGL(k_sr_split, dim3(grid), dim3(256), 0, c->stream, pack2, key2, n, len16, pay);
+    tb = c->scratch.cap;
+    LDW_HIP(prim_sort_pairs(c->scratch.p, tb, len16, len16b, pay, pay2, n, 0, 16, c->stream));
+    hipLaunchKernelGGL(k_sr_seg_offsets, dim3((S + 2 + 255) / 256), dim3(256), 0, c->stream, len16b, n, S, c->srm_off.as<int64_t>());
+    LDW_HIP(hipMemcpyAsync(c->srm_q.p, q.data(), cells * 16, hipMemcpyHostToDevice, c->stream));
+    unsigned int *d_viol = reinterpret_cast<unsigned int *>(c->srm_n.as<char>() + cells * 8);   // (the 64 spare bytes behind the counts)
+    if (viol_out) LDW_HIP(hipMemsetAsync(d_viol, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_sr_quant, dim3(S), dim3(256), 0, c->stream, pay2, c->srm_off.as<int64_t>(), S, nclust, prob,
+                       c->srm_q.as<double>(), c->srm_n.as<int64_t>(), d_gtot, viol_out ? d_viol : (unsigned int *)nullptr);
+    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipMemcpyAsync(q.data(), c->srm_q.p, cells * 16, hipMemcpyDeviceToHost, c->stream));
+    if (n_out) LDW_HIP(hipMemcpyAsync(n_out, c->srm_n.p, cells * 8, hipMemcpyDeviceToHost, c->stream));
+    if (viol_out) LDW_HIP(hipMemcpyAsync(viol_out, d_viol, 4, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
 static int sr_ready(ldw_ctx *c, const char *who) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(c->have_meta, LDW_ERR_STATE, "%s: ldw_set_snp_meta has not been called", who);
@@ -897,45 +1023,50 @@ int ldw_sr_len_quantiles(ldw_ctx *c, int nclust, double sr_dist, double prob, in
         }
         return LDW_OK;
     }
-    if (int rc = c->srm_pack.reserve((size_t)n * 4)) return rc;
-    if (int rc = c->srm_pack2.reserve((size_t)n * 4)) return rc;
-    if (int rc = c->srm_key.reserve((size_t)n * 8)) return rc;
-    if (int rc = c->srm_key2.reserve((size_t)n * 8)) return rc;
-    if (int rc = c->srm_off.reserve((size_t)(S + 2) * 8)) return rc;
-    if (int rc = c->srm_q.reserve(cells * 16)) return rc;
-    if (int rc = c->srm_n.reserve(cells * 8)) return rc;
-    uint32_t *pack = c->srm_pack.as<uint32_t>(), *pack2 = c->srm_pack2.as<uint32_t>();
-    uint64_t *key = c->srm_key.as<uint64_t>(), *key2 = c->srm_key2.as<uint64_t>();
+    if (int rc = quant_reserve_sorts(c, n, S, cells)) return rc;
     const int grid = (int)std::min<int64_t>((n + 255) / 256, 65536);
     hipLaunchKernelGGL(k_sr_tag, dim3(grid), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(),
-                       c->sr_mi.as<double>(), n, c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, sr_dist, pack, key);
-    // Two stable LSD sorts, both over the FULL width of their key type: by MI (u64 keys, tags as values), then by len
-    // (u16 keys, {MI key, tag} as values) -> ordered by (len, MI).  rocPRIM 7.2's merge-sort path mis-sorts u32 keys on a
-    // partial bit range at mid sizes (reproduced standalone through the hipCUB interface), so no begin_bit/end_bit tricks here.
-    if (int rc = c->srm_pay.reserve((size_t)n * sizeof(SrPay))) return rc;
-    if (int rc = c->srm_pay2.reserve((size_t)n * sizeof(SrPay))) return rc;
-    uint16_t *len16 = reinterpret_cast<uint16_t *>(pack), *len16b = len16 + n;   // pack is free after the first sort
-    SrPay *pay = c->srm_pay.as<SrPay>(), *pay2 = c->srm_pay2.as<SrPay>();
-    size_t t1 = 0, t2 = 0;
-    LDW_HIP(prim_sort_pairs(nullptr, t1, key, key2, pack, pack2, n, 0, 64, c->stream));
-    LDW_HIP(prim_sort_pairs(nullptr, t2, len16, len16b, pay, pay2, n, 0, 16, c->stream));
-    if (int rc = c->scratch.reserve(std::max(t1, t2))) return rc;
-    size_t tb = c->scratch.cap;
-    LDW_HIP(prim_sort_pairs(c->scratch.p, tb, key, key2, pack, pack2, n, 0, 64, c->stream));
-    hipLaunchKernelGGL(k_sr_split, dim3(grid), dim3(256), 0, c->stream, pack2, key2, n, len16, pay);
-    tb = c->scratch.cap;
-    LDW_HIP(prim_sort_pairs(c->scratch.p, tb, len16, len16b, pay, pay2, n, 0, 16, c->stream));
-    hipLaunchKernelGGL(k_sr_seg_offsets, dim3((S + 2 + 255) / 256), dim3(256), 0, c->stream, len16b, n, S, c->srm_off.as<int64_t>());
-    LDW_HIP(hipMemcpyAsync(c->srm_q.p, q.data(), cells * 16, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_sr_quant, dim3(S), dim3(256), 0, c->stream, pay2, c->srm_off.as<int64_t>(), S, nclust, prob,
-                       c->srm_q.as<double>(), c->srm_n.as<int64_t>());
-    LDW_HIP(hipGetLastError());
-    LDW_HIP(hipMemcpyAsync(q.data(), c->srm_q.p, cells * 16, hipMemcpyDeviceToHost, c->stream));
-    LDW_HIP(hipMemcpyAsync(n_out, c->srm_n.p, cells * 8, hipMemcpyDeviceToHost, c->stream));
-    LDW_HIP(hipStreamSynchronize(c->stream));
+                       c->sr_mi.as<double>(), n, c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, sr_dist, c->srm_pack.as<uint32_t>(), c->srm_key.as<uint64_t>());
+    if (int rc = quant_two_sorts(c, n, S, nclust, prob, nullptr, q, n_out, nullptr)) return rc;
     for (size_t k = 0; k < cells; ++k) {
         q_lo_out[k] = q[2 * k];
         q_hi_out[k] = q[2 * k + 1];
+    }
+    return LDW_OK;
+}
+
+// ARACNE pool of the context's short-range table: rows with a positive excess in some cluster and MI key >= min_key (R/computePairwiseMI.R:489-490);
+// needs the fitted decay on the device (upload_md) and the geometry of the last ldw_sr_len_quantiles call.  Sets c->n_pool.
+static int build_pool(ldw_ctx *c, unsigned long long min_key) {
+    const int64_t n = c->n_sr;
+    c->n_pool = 0;
+    if (n == 0) return LDW_OK;
+    if (int rc = c->srm_cnt.reserve(sizeof(SrCounters))) return rc;
+    SrCounters *d = c->srm_cnt.as<SrCounters>();
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 16384);
+    {
+        const size_t floor_rows = (size_t)std::min<int64_t>(n, (int64_t)1 << 22);
+        if (int rc = c->pool_a.reserve(floor_rows * 4)) return rc;
+        if (int rc = c->pool_b.reserve(floor_rows * 4)) return rc;
+        if (int rc = c->pool_mi.reserve(floor_rows * 8)) return rc;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        const int64_t cap = std::min<int64_t>((int64_t)(c->pool_a.cap / 4), std::min<int64_t>((int64_t)(c->pool_b.cap / 4), (int64_t)(c->pool_mi.cap / 8)));
+        SrCounters h2 = {0, 0, min_key};
+        LDW_HIP(hipMemcpyAsync(d, &h2, sizeof(h2), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_sr_pool<1>, dim3(grid), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), c->sr_mi.as<double>(), n,
+                           c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, c->srm_sr_dist, c->srm_md.as<double>(), c->srm_S, d, c->pool_a.as<int32_t>(),
+                           c->pool_b.as<int32_t>(), c->pool_mi.as<double>(), cap);
+        LDW_HIP(hipGetLastError());
+        SrCounters got;
+        LDW_HIP(hipMemcpyAsync(&got, d, sizeof(got), hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+        c->n_pool = (int64_t)got.n_pool;
+        if (c->n_pool <= cap) break;
+        LDW_REQUIRE(pass == 0, LDW_ERR_STATE, "short-range pool changed size between passes");
+        if (int rc = c->pool_a.reserve((size_t)c->n_pool * 4)) return rc;
+        if (int rc = c->pool_b.reserve((size_t)c->n_pool * 4)) return rc;
+        if (int rc = c->pool_mi.reserve((size_t)c->n_pool * 8)) return rc;
     }
     return LDW_OK;
 }
@@ -960,11 +1091,12 @@ int ldw_sr_excess_stats(ldw_ctx *c, int nclust, int32_t S, const double *mean_di
     if (int rc = c->srm_part.reserve(pbytes)) return rc;
     if (nclust <= 4 && getenv("LDW_SR_STATS_PEEL") == nullptr)
         hipLaunchKernelGGL(k_sr_stats_small<4>, dim3(grid), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), c->sr_mi.as<double>(), n,
-                           c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, c->srm_sr_dist, c->srm_md.as<double>(), S, nclust, c->srm_part.as<double>());
+                           c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, c->srm_sr_dist, c->srm_md.as<double>(), S, nclust, c->srm_part.as<double>(),
+                           (const int64_t *)nullptr, 0);
     else
     hipLaunchKernelGGL(k_sr_stats, dim3(grid), dim3(256), (size_t)4 * nclust * 5 * 8, c->stream, c->sr_a.as<int32_t>(),
                        c->sr_b.as<int32_t>(), c->sr_mi.as<double>(), n, c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g,
-                       c->srm_sr_dist, c->srm_md.as<double>(), S, nclust, c->srm_part.as<double>());
+                       c->srm_sr_dist, c->srm_md.as<double>(), S, nclust, c->srm_part.as<double>(), (const int64_t *)nullptr, 0);
     LDW_HIP(hipGetLastError());
     std::vector<double> part((size_t)grid * nclust * 5);
     LDW_HIP(hipMemcpyAsync(part.data(), c->srm_part.p, pbytes, hipMemcpyDeviceToHost, c->stream));
@@ -978,14 +1110,15 @@ int ldw_sr_pvalues(ldw_ctx *c, int nclust, int32_t S, const double *mean_dist, c
                    int64_t *n_red_out, int64_t *n_pool_out, double *min_mi_out) {
     if (int rc = sr_ready(c, "ldw_sr_pvalues")) return rc;
     if (int rc = upload_md(c, nclust, S, mean_dist, "ldw_sr_pvalues")) return rc;
-    LDW_REQUIRE(shape && n_red_out && n_pool_out, LDW_ERR_ARG, "ldw_sr_pvalues: null argument");
+    LDW_REQUIRE(shape && n_red_out, LDW_ERR_ARG, "ldw_sr_pvalues: null argument");   // (n_pool_out null: no pool — the caller builds it from a minimum over all ranks, ldw_sr_pool_build)
     for (int k = 0; k < nclust; ++k)
         LDW_REQUIRE(shape[3 * k] > 0 && shape[3 * k + 1] > 0 && std::isfinite(shape[3 * k + 2]), LDW_ERR_ARG,
                     "ldw_sr_pvalues: cluster %d has an invalid beta shape", k + 1);
     const int64_t n = c->n_sr;
     c->n_red = c->n_pool = 0;
     c->red_from_lr = false;
-    *n_red_out = *n_pool_out = 0;
+    *n_red_out = 0;
+    if (n_pool_out) *n_pool_out = 0;
     if (min_mi_out) *min_mi_out = std::nan("");
     if (n == 0) return LDW_OK;
     if (int rc = c->srm_shape.reserve((size_t)nclust * 32)) return rc;
@@ -1039,23 +1172,8 @@ int ldw_sr_pvalues(ldw_ctx *c, int nclust, int32_t S, const double *mean_dist, c
     *n_red_out = c->n_red;
     if (c->n_red == 0) return LDW_OK;
     if (min_mi_out) *min_mi_out = key_f64(h.min_key);
-    for (int pass = 0; pass < 2; ++pass) {
-        const int64_t cap = std::min<int64_t>((int64_t)(c->pool_a.cap / 4), std::min<int64_t>((int64_t)(c->pool_b.cap / 4), (int64_t)(c->pool_mi.cap / 8)));
-        SrCounters h2 = {0, 0, h.min_key};
-        LDW_HIP(hipMemcpyAsync(d, &h2, sizeof(h2), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_sr_pool<1>, dim3(grid), dim3(256), 0, c->stream, sa, sb, smi, n, POS, paint, c->g, c->srm_sr_dist,
-                           c->srm_md.as<double>(), S, d, c->pool_a.as<int32_t>(), c->pool_b.as<int32_t>(), c->pool_mi.as<double>(), cap);
-        LDW_HIP(hipGetLastError());
-        SrCounters got;
-        LDW_HIP(hipMemcpyAsync(&got, d, sizeof(got), hipMemcpyDeviceToHost, c->stream));
-        LDW_HIP(hipStreamSynchronize(c->stream));
-        c->n_pool = (int64_t)got.n_pool;
-        if (c->n_pool <= cap) break;
-        LDW_REQUIRE(pass == 0, LDW_ERR_STATE, "ldw_sr_pvalues: pool changed size between passes");
-        if (int rc = c->pool_a.reserve((size_t)c->n_pool * 4)) return rc;
-        if (int rc = c->pool_b.reserve((size_t)c->n_pool * 4)) return rc;
-        if (int rc = c->pool_mi.reserve((size_t)c->n_pool * 8)) return rc;
-    }
+    if (!n_pool_out) return LDW_OK;
+    if (int rc = build_pool(c, h.min_key)) return rc;
     *n_pool_out = c->n_pool;
     return LDW_OK;
 }
@@ -1161,6 +1279,216 @@ int ldw_aracne_device(ldw_ctx *c, int64_t capacity, uint8_t *flags_out) {
     LDW_HIP(hipGetLastError());
     LDW_HIP(hipMemcpyAsync(flags_out, c->ar_flags.p, (size_t)nr, hipMemcpyDeviceToHost, c->stream));
     LDW_HIP(hipStreamSynchronize(c->stream));
+    return LDW_OK;
+}
+
+// ---- r05: the short-range model over ranks: the table stays where it was computed ----------------------------------------
+
+int ldw_sr_tail_extract(ldw_ctx *c, int nclust, int32_t S, const double *lower, int64_t *cnt_out, double *mi_out, int64_t capacity, int on_device,
+                        int64_t *n_out) {
+    if (int rc = sr_ready(c, "ldw_sr_tail_extract")) return rc;
+    LDW_REQUIRE(nclust == c->srm_nclust && S == c->srm_S && nclust >= 1 && S >= 1, LDW_ERR_STATE,
+                "ldw_sr_tail_extract: nclust/S differ from the last ldw_sr_len_quantiles call");
+    LDW_REQUIRE(lower && cnt_out && n_out, LDW_ERR_ARG, "ldw_sr_tail_extract: null argument");
+    const int64_t n = c->n_sr, G = (int64_t)nclust * S;
+    *n_out = 0;
+    for (int64_t k = 0; k < G; ++k) cnt_out[k] = 0;
+    if (n == 0) return LDW_OK;
+    if (int rc = c->srd_lower.reserve((size_t)G * 8)) return rc;
+    if (int rc = c->srd_cur.reserve((size_t)G * 8)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->srd_lower.p, lower, (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
+    LDW_HIP(hipMemsetAsync(c->srd_cur.p, 0, (size_t)G * 8, c->stream));
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 16384);
+    const int32_t *sa = c->sr_a.as<int32_t>(), *sb = c->sr_b.as<int32_t>();
+    const double *smi = c->sr_mi.as<double>();
+    hipLaunchKernelGGL(k_sr_tail<0>, dim3(grid), dim3(256), 0, c->stream, sa, sb, smi, n, c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, c->srm_sr_dist,
+                       c->srd_lower.as<double>(), S, nclust, c->srd_cur.as<unsigned long long>(), (double *)nullptr);
+    LDW_HIP(hipGetLastError());
+    LDW_HIP(hipMemcpyAsync(cnt_out, c->srd_cur.p, (size_t)G * 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    int64_t total = 0;
+    for (int64_t k = 0; k < G; ++k) total += cnt_out[k];
+    *n_out = total;
+    if (!mi_out || total == 0) return LDW_OK;   // (count only: the caller sizes its buffer and calls again)
+    LDW_REQUIRE(capacity >= total, LDW_ERR_SIZE, "ldw_sr_tail_extract: capacity %lld < %lld rows", (long long)capacity, (long long)total);
+    std::vector<int64_t> first((size_t)G);
+    int64_t run = 0;
+    for (int64_t k = 0; k < G; ++k) {
+        first[(size_t)k] = run;
+        run += cnt_out[k];
+    }
+    LDW_HIP(hipMemcpyAsync(c->srd_cur.p, first.data(), (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
+    double *d_out = mi_out;
+    if (!on_device) {
+        if (int rc = c->srd_out.reserve((size_t)total * 8)) return rc;
+        d_out = c->srd_out.as<double>();
+    }
+    hipLaunchKernelGGL(k_sr_tail<1>, dim3(grid), dim3(256), 0, c->stream, sa, sb, smi, n, c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, c->srm_sr_dist,
+                       c->srd_lower.as<double>(), S, nclust, c->srd_cur.as<unsigned long long>(), d_out);
+    LDW_HIP(hipGetLastError());
+    if (!on_device) LDW_HIP(hipMemcpyAsync(mi_out, d_out, (size_t)total * 8, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));   // (`first` is read by the copy above)
+    return LDW_OK;
+}
+
+int ldw_sr_quantiles_merge(ldw_ctx *c, int nclust, int32_t S, double prob, int n_src, const double *const *mi_src, const int64_t *const *cnt_src,
+                           const int64_t *n_total, int on_device, double *q_lo_out, double *q_hi_out, int64_t *violations_out) {
+    if (int rc = check_gpu(c)) return rc;
+    if (int rc = ldw::join_prepare(c)) return rc;
+    LDW_REQUIRE(nclust >= 1 && nclust <= SRM_MAXCL && S >= 1 && S <= 65534, LDW_ERR_ARG, "ldw_sr_quantiles_merge: nclust must be in 1..%d, S in 1..65534", SRM_MAXCL);
+    LDW_REQUIRE(prob >= 0 && prob <= 1, LDW_ERR_ARG, "ldw_sr_quantiles_merge: prob outside [0,1]");
+    LDW_REQUIRE(n_src >= 1 && mi_src && cnt_src && n_total && q_lo_out && q_hi_out, LDW_ERR_ARG, "ldw_sr_quantiles_merge: null argument");
+    const int64_t G = (int64_t)nclust * S;
+    const size_t cells = (size_t)G;
+    int64_t m = 0;
+    std::vector<int64_t> m_src((size_t)n_src, 0);
+    for (int r = 0; r < n_src; ++r) {
+        LDW_REQUIRE(cnt_src[r], LDW_ERR_ARG, "ldw_sr_quantiles_merge: source %d has no counts", r);
+        for (int64_t k = 0; k < G; ++k) {
+            LDW_REQUIRE(cnt_src[r][k] >= 0, LDW_ERR_ARG, "ldw_sr_quantiles_merge: negative count");
+            m_src[(size_t)r] += cnt_src[r][k];
+        }
+        LDW_REQUIRE(m_src[(size_t)r] == 0 || mi_src[r], LDW_ERR_ARG, "ldw_sr_quantiles_merge: source %d has no values", r);
+        m += m_src[(size_t)r];
+    }
+    std::vector<double> q(cells * 2, std::nan(""));
+    unsigned int viol = 0;
+    if (m == 0) {
+        for (size_t k = 0; k < cells; ++k) viol += n_total[k] != 0;
+    } else {
+        LDW_REQUIRE(m < (int64_t)0x7FFFFFFFll * 4, LDW_ERR_SIZE, "ldw_sr_quantiles_merge: too many candidates");
+        if (int rc = quant_reserve_sorts(c, m, S, cells)) return rc;
+        if (int rc = c->srd_lower.reserve((size_t)G * 8)) return rc;
+        if (int rc = c->srd_seg.reserve((size_t)n_src * (size_t)(G + 1) * 8)) return rc;
+        if (!on_device)
+            if (int rc = c->srd_out.reserve((size_t)m * 8)) return rc;
+        LDW_HIP(hipMemcpyAsync(c->srd_lower.p, n_total, (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
+        std::vector<int64_t> goff((size_t)n_src * (size_t)(G + 1));
+        int64_t base = 0;
+        for (int r = 0; r < n_src; ++r) {
+            int64_t *go = goff.data() + (size_t)r * (size_t)(G + 1);
+            go[0] = 0;
+            for (int64_t k = 0; k < G; ++k) go[k + 1] = go[k] + cnt_src[r][k];
+            const int64_t mr = m_src[(size_t)r];
+            if (mr == 0) continue;
+            int64_t *d_go = c->srd_seg.as<int64_t>() + (size_t)r * (size_t)(G + 1);
+            LDW_HIP(hipMemcpyAsync(d_go, go, (size_t)(G + 1) * 8, hipMemcpyHostToDevice, c->stream));
+            const double *d_mi = mi_src[r];
+            if (!on_device) {
+                LDW_HIP(hipMemcpyAsync(c->srd_out.as<double>() + base, mi_src[r], (size_t)mr * 8, hipMemcpyHostToDevice, c->stream));
+                d_mi = c->srd_out.as<double>() + base;
+            }
+            hipLaunchKernelGGL(k_tail_unpack, dim3((unsigned)std::min<int64_t>((mr + 255) / 256, 16384)), dim3(256), 0, c->stream, d_mi, mr, d_go, (int)G, nclust,
+                               base, c->srm_pack.as<uint32_t>(), c->srm_key.as<uint64_t>());
+            LDW_HIP(hipGetLastError());
+            base += mr;
+        }
+        if (int rc = quant_two_sorts(c, m, S, nclust, prob, c->srd_lower.as<int64_t>(), q, nullptr, &viol)) return rc;   // (synchronises: goff may go)
+    }
+    for (size_t k = 0; k < cells; ++k) {
+        q_lo_out[k] = q[2 * k];
+        q_hi_out[k] = q[2 * k + 1];
+    }
+    if (violations_out) *violations_out = (int64_t)viol;
+    LDW_REQUIRE(viol == 0 || violations_out, LDW_ERR_STATE, "ldw_sr_quantiles_merge: %u groups whose order statistic lies below the candidates sent", viol);
+    return LDW_OK;
+}
+
+int ldw_sr_excess_stats_blocks(ldw_ctx *c, int nclust, int32_t S, const double *mean_dist, int64_t nblocks, const int64_t *rows_per_block,
+                               double *stats_out) {
+    if (int rc = sr_ready(c, "ldw_sr_excess_stats_blocks")) return rc;
+    if (int rc = upload_md(c, nclust, S, mean_dist, "ldw_sr_excess_stats_blocks")) return rc;
+    LDW_REQUIRE(nblocks >= 0 && (nblocks == 0 || (rows_per_block && stats_out)), LDW_ERR_ARG, "ldw_sr_excess_stats_blocks: null argument");
+    constexpr int STRIPS = 64;   // strips per block: fixed, so that a block's sums do not depend on which rank holds it
+    std::vector<int64_t> seg;
+    std::vector<int64_t> which;
+    int64_t run = 0;
+    for (int64_t b = 0; b < nblocks; ++b) {
+        LDW_REQUIRE(rows_per_block[b] >= 0, LDW_ERR_ARG, "ldw_sr_excess_stats_blocks: negative row count");
+        if (rows_per_block[b] > 0) {
+            seg.push_back(run);
+            seg.push_back(run + rows_per_block[b]);
+            which.push_back(b);
+        }
+        run += rows_per_block[b];
+    }
+    LDW_REQUIRE(run == c->n_sr, LDW_ERR_ARG, "ldw_sr_excess_stats_blocks: the blocks hold %lld rows, the short-range table %lld", (long long)run, (long long)c->n_sr);
+    const size_t per = (size_t)nclust * 5;
+    for (size_t k = 0; k < (size_t)nblocks * per; ++k) stats_out[k] = 0.0;
+    const int64_t nb = (int64_t)which.size();
+    if (nb == 0) return LDW_OK;
+    LDW_REQUIRE(nb * STRIPS < (int64_t)1 << 30, LDW_ERR_SIZE, "ldw_sr_excess_stats_blocks: too many blocks");
+    const int grid = (int)(nb * STRIPS);
+    const size_t pbytes = (size_t)grid * per * 8;
+    if (int rc = c->srm_part.reserve(pbytes)) return rc;
+    if (int rc = c->srd_seg.reserve(seg.size() * 8)) return rc;
+    LDW_HIP(hipMemcpyAsync(c->srd_seg.p, seg.data(), seg.size() * 8, hipMemcpyHostToDevice, c->stream));
+    const int64_t n = c->n_sr;
+    if (nclust <= 4 && getenv("LDW_SR_STATS_PEEL") == nullptr)
+        hipLaunchKernelGGL(k_sr_stats_small<4>, dim3(grid), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), c->sr_mi.as<double>(), n,
+                           c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, c->srm_sr_dist, c->srm_md.as<double>(), S, nclust, c->srm_part.as<double>(),
+                           c->srd_seg.as<int64_t>(), STRIPS);
+    else
+        hipLaunchKernelGGL(k_sr_stats, dim3(grid), dim3(256), (size_t)4 * nclust * 5 * 8, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(),
+                           c->sr_mi.as<double>(), n, c->POS.as<int32_t>(), c->paint.as<int32_t>(), c->g, c->srm_sr_dist, c->srm_md.as<double>(), S, nclust,
+                           c->srm_part.as<double>(), c->srd_seg.as<int64_t>(), STRIPS);
+    LDW_HIP(hipGetLastError());
+    std::vector<double> part((size_t)grid * per);
+    LDW_HIP(hipMemcpyAsync(part.data(), c->srm_part.p, pbytes, hipMemcpyDeviceToHost, c->stream));
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    for (int64_t k = 0; k < nb; ++k) {   // strips in order: fixed
+        double *o = stats_out + (size_t)which[(size_t)k] * per;
+        for (int j = 0; j < STRIPS; ++j)
+            for (size_t t = 0; t < per; ++t) o[t] += part[((size_t)k * STRIPS + (size_t)j) * per + t];
+    }
+    return LDW_OK;
+}
+
+int ldw_sr_pool_build(ldw_ctx *c, double min_mi, int64_t *n_pool_out) {
+    if (int rc = sr_ready(c, "ldw_sr_pool_build")) return rc;
+    LDW_REQUIRE(n_pool_out, LDW_ERR_ARG, "ldw_sr_pool_build: null output");
+    LDW_REQUIRE(c->srm_S > 0 && c->srm_md.p, LDW_ERR_STATE, "ldw_sr_pool_build: call ldw_sr_pvalues first (the fitted decay is not on the device)");
+    *n_pool_out = 0;
+    c->n_pool = 0;
+    if (std::isnan(min_mi)) return LDW_OK;   // nothing was kept anywhere: no pool
+    if (int rc = build_pool(c, (unsigned long long)f64_key(min_mi))) return rc;
+    *n_pool_out = c->n_pool;
+    return LDW_OK;
+}
+
+int ldw_sr_reduced_import(ldw_ctx *c, int64_t n_red, const int32_t *a, const int32_t *b, const double *MI, int64_t n_pool, const int32_t *pool_a,
+                          const int32_t *pool_b, const double *pool_MI) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(n_red >= 0 && n_pool >= 0 && (n_red == 0 || (a && b && MI)) && (n_pool == 0 || (pool_a && pool_b && pool_MI)), LDW_ERR_ARG,
+                "ldw_sr_reduced_import: bad argument");
+    for (int64_t i = 0; i < n_red; ++i)
+        LDW_REQUIRE(a[i] >= 0 && a[i] < c->L && b[i] >= 0 && b[i] < c->L, LDW_ERR_ARG, "ldw_sr_reduced_import: link %lld has a SNP index outside 0..L-1", (long long)i);
+    for (int64_t i = 0; i < n_pool; ++i)
+        LDW_REQUIRE(pool_a[i] >= 0 && pool_a[i] < c->L && pool_b[i] >= 0 && pool_b[i] < c->L, LDW_ERR_ARG,
+                    "ldw_sr_reduced_import: pool link %lld has a SNP index outside 0..L-1", (long long)i);
+    if (int rc = ldw_links_import(c, 0, a, b, MI, n_red, 0)) return rc;   // the kept links ARE the short-range table now (rows 0..n_red-1)
+    c->red_from_lr = false;
+    const size_t nr = (size_t)std::max<int64_t>(n_red, 1), np = (size_t)std::max<int64_t>(n_pool, 1);
+    if (int rc = c->red_row.reserve(nr * 8)) return rc;
+    if (int rc = c->red_meta.reserve(nr * 4)) return rc;
+    if (int rc = c->red_srp.reserve(nr * 8)) return rc;
+    if (int rc = c->pool_a.reserve(np * 4)) return rc;
+    if (int rc = c->pool_b.reserve(np * 4)) return rc;
+    if (int rc = c->pool_mi.reserve(np * 8)) return rc;
+    LDW_HIP(hipMemsetAsync(c->red_meta.p, 0, nr * 4, c->stream));
+    LDW_HIP(hipMemsetAsync(c->red_srp.p, 0, nr * 8, c->stream));
+    if (n_red > 0) {
+        hipLaunchKernelGGL(k_iota64, dim3((unsigned)((n_red + 255) / 256)), dim3(256), 0, c->stream, c->red_row.as<int64_t>(), n_red);
+        LDW_HIP(hipGetLastError());
+    }
+    if (n_pool > 0) {
+        LDW_HIP(hipMemcpyAsync(c->pool_a.p, pool_a, (size_t)n_pool * 4, hipMemcpyHostToDevice, c->stream));
+        LDW_HIP(hipMemcpyAsync(c->pool_b.p, pool_b, (size_t)n_pool * 4, hipMemcpyHostToDevice, c->stream));
+        LDW_HIP(hipMemcpyAsync(c->pool_mi.p, pool_MI, (size_t)n_pool * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    LDW_HIP(hipStreamSynchronize(c->stream));
+    c->n_red = n_red;
+    c->n_pool = n_pool;
     return LDW_OK;
 }
 

@@ -468,6 +468,68 @@ class Engine:
         L.check(L.lib().ldw_sr_pool_fetch(self._ctx, n, L.ptr(a), L.ptr(b), L.ptr(mi)))
         return a, b, mi
 
+    # -- r05: the same model with the table left on the ranks that computed it (dist_srp.py) ---------
+    def sr_excess_stats_blocks(self, mean_dist: np.ndarray, rows_per_block) -> np.ndarray:
+        """(nblocks, nclust, 5): ldw_sr_excess_stats per reference block of this engine's table (rows of the blocks in order)."""
+        md = np.ascontiguousarray(mean_dist, dtype=np.float64)
+        rows = np.ascontiguousarray(rows_per_block, dtype=np.int64)
+        out = np.zeros((len(rows), md.shape[0], 5), dtype=np.float64)
+        L.check(L.lib().ldw_sr_excess_stats_blocks(self._ctx, md.shape[0], md.shape[1], L.ptr(md), len(rows), L.ptr(rows), L.ptr(out)))
+        return out
+
+    def sr_tail_extract(self, lower: np.ndarray):
+        """Rows at or above ``lower`` (nclust, S) per (cluster, len): (cnt, mi) with cnt (S, nclust) — len-major — and mi their MI values
+        grouped in that order (host arrays)."""
+        lo = np.ascontiguousarray(lower, dtype=np.float64)
+        nclust, S = lo.shape
+        cnt = np.zeros((S, nclust), dtype=np.int64)
+        n = C.c_int64(0)
+        L.check(L.lib().ldw_sr_tail_extract(self._ctx, nclust, S, L.ptr(lo), L.ptr(cnt), None, 0, 0, C.byref(n)))
+        mi = np.empty(n.value, dtype=np.float64)
+        if n.value:
+            L.check(L.lib().ldw_sr_tail_extract(self._ctx, nclust, S, L.ptr(lo), L.ptr(cnt), L.ptr(mi), n.value, 0, C.byref(n)))
+        return cnt, mi
+
+    def sr_quantiles_merge(self, prob: float, cnts: list, mis: list, n_total: np.ndarray):
+        """(q_lo, q_hi, violations) of the groups over all ranks from the candidates ``sr_tail_extract`` gave on each (``cnts[r]`` (S, nclust),
+        ``mis[r]``) and the groups' global sizes ``n_total`` (nclust, S)."""
+        nt = np.ascontiguousarray(n_total, dtype=np.int64)
+        nclust, S = nt.shape
+        cs = [np.ascontiguousarray(c, dtype=np.int64) for c in cnts]
+        ms = [np.ascontiguousarray(m, dtype=np.float64) for m in mis]
+        assert len(cs) == len(ms) >= 1 and all(c.shape == (S, nclust) for c in cs)
+        pm = (C.c_void_p * len(ms))(*[m.ctypes.data if m.size else None for m in ms])
+        pc = (C.c_void_p * len(cs))(*[c.ctypes.data for c in cs])
+        qlo = np.empty((nclust, S), dtype=np.float64)
+        qhi = np.empty((nclust, S), dtype=np.float64)
+        viol = C.c_int64(0)
+        L.check(L.lib().ldw_sr_quantiles_merge(self._ctx, nclust, S, float(prob), len(ms), pm, pc, L.ptr(nt), 0, L.ptr(qlo), L.ptr(qhi), C.byref(viol)))
+        return qlo, qhi, int(viol.value)
+
+    def sr_pvalues_local(self, mean_dist: np.ndarray, shape: np.ndarray, srp_cutoff: float):
+        """ldw_sr_pvalues without the pool: (n_red, min MI kept on this engine — NaN when nothing was kept)."""
+        md = np.ascontiguousarray(mean_dist, dtype=np.float64)
+        sh = np.ascontiguousarray(shape, dtype=np.float64)
+        assert sh.shape == (md.shape[0], 3)
+        nr, mn = C.c_int64(0), C.c_double(0)
+        L.check(L.lib().ldw_sr_pvalues(self._ctx, md.shape[0], md.shape[1], L.ptr(md), L.ptr(sh), float(srp_cutoff), C.byref(nr), None, C.byref(mn)))
+        self._n_red, self._n_pool = nr.value, 0
+        return nr.value, mn.value
+
+    def sr_pool_build(self, min_mi: float) -> int:
+        n = C.c_int64(0)
+        L.check(L.lib().ldw_sr_pool_build(self._ctx, float(min_mi), C.byref(n)))
+        self._n_pool = n.value
+        return n.value
+
+    def sr_reduced_import(self, a, b, mi, pool_a, pool_b, pool_mi):
+        """Adopt the kept links and the pool of all ranks; ``aracne_device`` then answers for the kept links in the order given."""
+        a, b, mi = L.as_c(a, np.int32), L.as_c(b, np.int32), L.as_c(mi, np.float64)
+        pa, pb, pm = L.as_c(pool_a, np.int32), L.as_c(pool_b, np.int32), L.as_c(pool_mi, np.float64)
+        assert len(a) == len(b) == len(mi) and len(pa) == len(pb) == len(pm)
+        L.check(L.lib().ldw_sr_reduced_import(self._ctx, len(mi), L.ptr(a), L.ptr(b), L.ptr(mi), len(pm), L.ptr(pa), L.ptr(pb), L.ptr(pm)))
+        self._n_red, self._n_pool = len(mi), len(pm)
+
     def aracne_device(self) -> np.ndarray:
         """ARACNE flags of the kept links (order of sr_reduced()) against the device-resident pool."""
         out = np.ones(self._n_red, dtype=np.uint8)

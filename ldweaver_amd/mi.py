@@ -197,7 +197,8 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
                            runARACNE=True, perform_SR_analysis_only=False, order_links=True, mega_dset=False, *,
                            engine: Engine | None = None, alignment_resident: bool = False,
                            quirk_mode: int = L.QUIRK_REFERENCE, nlimbs: int = 0, verbose: bool = True,
-                           return_aux: bool = False, sr_model: str = "device", group=None, engines=None, stream_lr: bool = True):
+                           return_aux: bool = False, sr_model: str = "device", group=None, engines=None, stream_lr: bool = True,
+                           sr_tail: str = "gather"):
     """Returns the short-range link data.frame (clust_c,pos1,pos2,clust1,clust2,len,MI,srp_max,ARACNE);
     long-range links are appended to ``lr_save_path`` and the returned frame to ``sr_save_path``.
 
@@ -206,6 +207,11 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
     ranks, every rank computes its share on its GPU, ONE variable-length gather assembles the link tables on rank 0
     (``dist.gather_link_tables``), rank 0 adopts them (``ldw_links_import``) and runs the short-range model / ARACNE on
     them and writes the files; the other ranks return None.
+
+    ``sr_tail`` (r05, several ranks): "gather" assembles both link tables on rank 0 as above; "dist" leaves the short-range rows — 99 % of the
+    links — on the ranks that computed them: only the long-range table is gathered and the short-range model + ARACNE run over the ranks
+    (``dist_srp.merge_n_sort_sr_links_dist``: per-group bounds, ~7 % of the MI column, block sums, the kept links and the pool travel).  Same
+    frame and files; needs ``sr_model="device"``.
 
     ``engines`` (r05): several engines of THIS process, one per GPU (``[Engine(d) for d in devices]``) — the route a host that cannot
     start one process per GPU takes (R through .Call: ``options(ldwamd.devices = 0:7)`` in r_shim/).  Every engine receives the alignment,
@@ -242,6 +248,7 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
     inproc = engines is not None and len(engines) > 1 and not perform_SR_analysis_only
     stages = {"lr_links_approx_s": time.time() - t000}
     lr_stream, streamed = False, None
+    dist_tail = None
     try:
         def setup():
             for e in (engines if inproc else [eng]):
@@ -280,13 +287,31 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
             # POS and whole blocks only their MI column travels and rank 0 rebuilds (a, b) (Engine.sr_pairs); SR-only passes (filtered site
             # lists) and unsorted positions send all three columns
             mi_only = (not perform_SR_analysis_only) and bool(np.all(np.diff(np.asarray(POS, dtype=np.int64)) >= 0))
-            out = gather_link_tables(local, mine, {"sr": my_stats["n_sr"], "lr": my_stats["n_lr_kept"]}, len(blocks), group=group,
-                                     sr_pairs=(lambda n: eng.sr_pairs(blocks, sr_dist, n)) if mi_only else None)
-            stats = gather_block_stats(my_stats, mine, len(blocks), group=group)
-            if rank != 0:
-                return None
-            eng.links_import(0, *out["sr"])
-            eng.links_import(1, *out["lr"])
+            if sr_tail == "dist":
+                if sr_model != "device":
+                    raise ValueError("sr_tail='dist' needs sr_model='device'")
+                import torch
+                e_ = lambda dt: torch.empty(0, dtype=dt, device=local["lr"][2].device)
+                out = gather_link_tables({"sr": (e_(torch.int32), e_(torch.int32), e_(torch.float64)), "lr": local["lr"]}, mine,
+                                         {"sr": np.zeros(len(mine), dtype=np.int64), "lr": my_stats["n_lr_kept"]}, len(blocks), group=group)
+                stats = gather_block_stats(my_stats, mine, len(blocks), group=group)
+                dist_tail = (mine, stats["n_sr"])
+                if rank != 0:   # this rank's rows take part in the model below; nothing comes back to it
+                    from .dist_srp import merge_n_sort_sr_links_dist
+                    merge_n_sort_sr_links_dist(eng, cds_var.nclust, sr_dist, srp_cutoff, POS, paint, g, mine, stats["n_sr"], run_aracne=runARACNE,
+                                               order_links=order_links, group=group)
+                    return None
+                eng.links_import(1, *out["lr"])
+            elif sr_tail != "gather":
+                raise ValueError("sr_tail must be 'gather' or 'dist'")
+            else:
+                out = gather_link_tables(local, mine, {"sr": my_stats["n_sr"], "lr": my_stats["n_lr_kept"]}, len(blocks), group=group,
+                                         sr_pairs=(lambda n: eng.sr_pairs(blocks, sr_dist, n)) if mi_only else None)
+                stats = gather_block_stats(my_stats, mine, len(blocks), group=group)
+                if rank != 0:
+                    return None
+                eng.links_import(0, *out["sr"])
+                eng.links_import(1, *out["lr"])
         else:
             t_s = time.time()
             setup()
@@ -320,10 +345,18 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
             eng.write_links_tsv_begin(1, lr_save_path, append=True)
         tsv_s = time.time() - t_w
         t_s = time.time()
-        if sr_model == "device":
+        if sr_model == "device" and dist_tail is not None:
+            from .dist_srp import merge_n_sort_sr_links_dist
+            redd, flags, model_aux = merge_n_sort_sr_links_dist(eng, cds_var.nclust, sr_dist, srp_cutoff, POS, paint, g, dist_tail[0], dist_tail[1],
+                                                                run_aracne=runARACNE, order_links=order_links, group=group)
+            pool = eng.sr_pool() if (return_aux and runARACNE and len(redd["MI"])) else None   # (the pool of all ranks, as rank 0 adopted it)
+            fit_data = model_aux["fit_data"]
+            sa, sb, smi = redd["a"], redd["b"], redd["MI"]
+            stages["sr_tail_bytes_sent"] = model_aux["bytes_sent"]
+        elif sr_model == "device":
             # mergeNsort_sr_links + runARACNE on the device-resident table; only the kept links come back
             redd, flags, model_aux = merge_n_sort_sr_links_device(eng, cds_var.nclust, sr_dist, srp_cutoff, POS, paint, g,
-                                                                  run_aracne=runARACNE, order_links=order_links)
+                                                                  run_aracne=runARACNE, order_links=order_links, block_rows=stats["n_sr"])
             pool = eng.sr_pool() if return_aux else None
             fit_data = model_aux["fit_data"]
             sa, sb, smi = redd["a"], redd["b"], redd["MI"]

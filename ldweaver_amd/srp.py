@@ -175,11 +175,17 @@ def stable_argsort_desc(v: np.ndarray) -> np.ndarray:
     return idx
 
 
-def merge_n_sort_sr_links_device(eng, nclust: int, sr_dist: float, srp_cutoff: float, POS, paint, g, run_aracne=True, order_links=False):
+def merge_n_sort_sr_links_device(eng, nclust: int, sr_dist: float, srp_cutoff: float, POS, paint, g, run_aracne=True, order_links=False,
+                                 block_rows=None):
     """mergeNsort_sr_links + runARACNE with the link table left on the device by ``eng.mi_all_pairs``: the O(#links)
     work (per-length quantiles, excess statistics, p-values, de-duplication, ARACNE) runs in HBM, the host keeps the
     least-squares fit and the beta MLE.  Returns sr_links_red (same rows, order and columns as the host path) with the
-    ARACNE column filled, and a dict of side results."""
+    ARACNE column filled, and a dict of side results.
+
+    ``block_rows`` (r05): short-range rows of every block of the pass that left the table, in table order.  The excess statistics are then
+    summed per reference block and over the blocks in that order (``ldw_sr_excess_stats_blocks``) — the order the model over ranks uses
+    (``dist_srp.merge_n_sort_sr_links_dist``), so that a job's sr_links.tsv is the same file, byte for byte, on one GPU, with the table gathered
+    from several, and with the rows left on their ranks.  Without it: strips of the whole table (a table of unknown block structure)."""
     if int(np.max(paint)) > nclust or int(np.min(paint)) < 1:
         raise ValueError("Cluster mismatch detected, stopping!")
     qlo, qhi, cnt = eng.sr_len_quantiles(nclust, sr_dist, 0.95)
@@ -197,7 +203,12 @@ def merge_n_sort_sr_links_device(eng, nclust: int, sr_dist: float, srp_cutoff: f
         mean_dist = fit_decay(lens[has], maxvls)
         md[ci, :len(mean_dist)] = mean_dist             # looked up by the VALUE of len (Q5)
         fit_data.append(pd.DataFrame({"len": lens[has], "max": maxvls, "fit": mean_dist}))
-    stats = eng.sr_excess_stats(md)
+    if block_rows is not None and int(np.sum(block_rows)) == eng.links_count(0):
+        stats = np.zeros((nclust, 5))
+        for part in eng.sr_excess_stats_blocks(md, block_rows):   # in block order
+            stats += part
+    else:
+        stats = eng.sr_excess_stats(md)
     shape = np.empty((nclust, 3))
     for ci in range(nclust):
         a_, b_ = beta_mle_stats(*stats[ci])
