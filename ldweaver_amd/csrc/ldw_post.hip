@@ -62,24 +62,28 @@ __global__ __launch_bounds__(256) void k_select_gt(const int32_t *__restrict__ a
 
 // ---- LD map ----
 __global__ __launch_bounds__(256) void k_mark_used(const int32_t *__restrict__ a, const int32_t *__restrict__ b, int64_t n,
-                                                   const int32_t *__restrict__ POS, int from, int to, int windowed, int32_t *__restrict__ used) {
+                                                   const int32_t *__restrict__ POS, int from, int to, int windowed, int32_t *__restrict__ used,
+                                                   const int32_t *__restrict__ slot) {
+    // slot (r05; null: the SNP index itself): index of a SNP's position among the sorted DISTINCT positions — POS in any order, positions held by
+    // several SNPs counted once, like the reference's sort(unique(c(pos1, pos2))) (R/LDSummaryPlot.R:57)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int32_t x = a[i], y = b[i];
         // positions of ALL links define pos_vec; the window then keeps from < pos < to (R/LDSummaryPlot.R:57-62)
-        if (!windowed || (POS[x] > from && POS[x] < to)) used[x] = 1;
-        if (!windowed || (POS[y] > from && POS[y] < to)) used[y] = 1;
+        if (!windowed || (POS[x] > from && POS[x] < to)) used[slot ? slot[x] : x] = 1;
+        if (!windowed || (POS[y] > from && POS[y] < to)) used[slot ? slot[y] : y] = 1;
     }
 }
 
 __global__ __launch_bounds__(256) void k_ldmap_add(const int32_t *__restrict__ a, const int32_t *__restrict__ b, const double *__restrict__ mi,
                                                    int64_t n, const int32_t *__restrict__ POS, int from, int to, int windowed,
                                                    const int32_t *__restrict__ used, const int32_t *__restrict__ rank, int r, int B,
-                                                   double *__restrict__ red) {
+                                                   double *__restrict__ red, const int32_t *__restrict__ slot) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int32_t x = a[i], y = b[i];
         if (windowed && !(POS[x] >= from && POS[x] <= to && POS[y] >= from && POS[y] <= to)) continue;   // :66-67
-        if (!used[x] || !used[y]) continue;   // a window edge position: no level in pos_vec
-        const int bi = rank[x] / r, bj = rank[y] / r;
+        const int32_t sx = slot ? slot[x] : x, sy = slot ? slot[y] : y;
+        if (!used[sx] || !used[sy]) continue;   // a window edge position: no level in pos_vec
+        const int bi = rank[sx] / r, bj = rank[sy] / r;
         if (bi >= B || bj >= B) continue;     // ranks beyond floor(n / r) * r fall outside every column of .mat()
         // i, j and j, i (:78-80): a pair inside one block counts twice.  Only the upper triangle is accumulated (the
         // mirror cell gets the same value afterwards), so the map is exactly symmetric whatever order the atomics land in.
@@ -278,17 +282,37 @@ int ldw_ldmap(ldw_ctx *c, int32_t reducer, int32_t from, int32_t to, int64_t *n_
     const int windowed = (from != 0 || to != 0) ? 1 : 0;
     LDW_REQUIRE(!windowed || (to > from && from >= 0), LDW_ERR_ARG, "ldw_ldmap: <to> must be greater than <from> and both positive");
     LDW_REQUIRE(reducer >= 0, LDW_ERR_ARG, "ldw_ldmap: reducer must be >= 0 (0 = default)");
-    LDW_REQUIRE(c->pos_sorted, LDW_ERR_STATE, "ldw_ldmap: the rank of a position is taken from the SNP order, which needs snp.dat$POS ascending");
     const int64_t L = c->L, nl = c->n_lr, ns = c->n_sr;
     LDW_REQUIRE(nl + ns > 0, LDW_ERR_STATE, "ldw_ldmap: no links");
+    // r05: the rank of a position in pos_vec is its rank among the sorted distinct positions.  With POS strictly ascending (what the reference's parser
+    // emits) that is the SNP order; otherwise (any order, repeated positions) through a slot per SNP, built once per call on the host.
+    const int32_t *d_slot = nullptr;
+    {
+        bool strict = c->pos_sorted;
+        for (int64_t i = 1; i < L && strict; ++i) strict = c->h_POS[(size_t)i] > c->h_POS[(size_t)i - 1];
+        if (!strict) {
+            std::vector<int32_t> ord((size_t)L), slot((size_t)L);
+            for (int64_t i = 0; i < L; ++i) ord[(size_t)i] = (int32_t)i;
+            std::stable_sort(ord.begin(), ord.end(), [&](int32_t u, int32_t v) { return c->h_POS[(size_t)u] < c->h_POS[(size_t)v]; });
+            int32_t k = -1;
+            for (int64_t i = 0; i < L; ++i) {
+                if (i == 0 || c->h_POS[(size_t)ord[(size_t)i]] != c->h_POS[(size_t)ord[(size_t)i - 1]]) ++k;
+                slot[(size_t)ord[(size_t)i]] = k;
+            }
+            if (int rc = c->srd_lower.reserve((size_t)L * 4)) return rc;
+            LDW_HIP(hipMemcpyAsync(c->srd_lower.p, slot.data(), (size_t)L * 4, hipMemcpyHostToDevice, c->stream));
+            LDW_HIP(hipStreamSynchronize(c->stream));   // (`slot` goes out of scope)
+            d_slot = c->srd_lower.as<int32_t>();
+        }
+    }
     // ---- pos_vec: which SNPs occur in a link, and their rank ----
     if (int rc = c->srm_cnt.reserve((size_t)(L + 1) * 4 * 2)) return rc;
     int32_t *used = c->srm_cnt.as<int32_t>(), *rank = used + L + 1;
     LDW_HIP(hipMemsetAsync(used, 0, (size_t)(L + 1) * 4, c->stream));
     const int32_t *POS = c->POS.as<int32_t>();
     auto grid_of = [](int64_t n) { return dim3((unsigned)std::min<int64_t>((n + 255) / 256, 16384)); };
-    if (nl > 0) hipLaunchKernelGGL(k_mark_used, grid_of(nl), dim3(256), 0, c->stream, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), nl, POS, from, to, windowed, used);
-    if (ns > 0) hipLaunchKernelGGL(k_mark_used, grid_of(ns), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), ns, POS, from, to, windowed, used);
+    if (nl > 0) hipLaunchKernelGGL(k_mark_used, grid_of(nl), dim3(256), 0, c->stream, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), nl, POS, from, to, windowed, used, d_slot);
+    if (ns > 0) hipLaunchKernelGGL(k_mark_used, grid_of(ns), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), ns, POS, from, to, windowed, used, d_slot);
     LDW_HIP(hipGetLastError());
     size_t sb = 0;
     LDW_HIP(prim_exclusive_sum(nullptr, sb, used, rank, (int)(L + 1), c->stream));
@@ -314,8 +338,8 @@ int ldw_ldmap(ldw_ctx *c, int32_t reducer, int32_t from, int32_t to, int64_t *n_
     if (int rc = c->srm_q.reserve((size_t)nb * 16 + (size_t)rgrid * 16)) return rc;
     double *red = c->srm_q.as<double>(), *htm = red + nb, *mm = htm + nb;
     LDW_HIP(hipMemsetAsync(red, 0, (size_t)nb * 8, c->stream));
-    if (nl > 0) hipLaunchKernelGGL(k_ldmap_add, grid_of(nl), dim3(256), 0, c->stream, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), c->lr_mi.as<double>(), nl, POS, from, to, windowed, used, rank, r, B, red);
-    if (ns > 0) hipLaunchKernelGGL(k_ldmap_add, grid_of(ns), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), c->sr_mi.as<double>(), ns, POS, from, to, windowed, used, rank, r, B, red);
+    if (nl > 0) hipLaunchKernelGGL(k_ldmap_add, grid_of(nl), dim3(256), 0, c->stream, c->lr_a.as<int32_t>(), c->lr_b.as<int32_t>(), c->lr_mi.as<double>(), nl, POS, from, to, windowed, used, rank, r, B, red, d_slot);
+    if (ns > 0) hipLaunchKernelGGL(k_ldmap_add, grid_of(ns), dim3(256), 0, c->stream, c->sr_a.as<int32_t>(), c->sr_b.as<int32_t>(), c->sr_mi.as<double>(), ns, POS, from, to, windowed, used, rank, r, B, red, d_slot);
     hipLaunchKernelGGL(k_ldmap_log, dim3(rgrid), dim3(256), 0, c->stream, red, (int)B, 1.0 / ((double)r * (double)r), htm, mm);
     LDW_HIP(hipGetLastError());
     std::vector<double> hmm((size_t)rgrid * 2);

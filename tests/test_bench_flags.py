@@ -44,7 +44,8 @@ def test_bench_multi_rank_rehearsal():
     # r04: no launcher around it — `python bench.py --gpus 4` starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node 4
     # --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` itself (a child process, before this one touches the GPU),
     # relays rank 0's line and the exit code
-    many = _bench_line([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo"] + base, 900)
+    # (the 4-rank line runs its extra leg: `sr_tail`, the short-range model + ARACNE behind the pass with the table gathered / the rows left on their ranks)
+    many = _bench_line([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo"] + [a for a in base if a != "--no-extra-legs"], 900)
     assert many["ranks_seen"] == world and many["backend"] == "gloo" and many["self_launched"] is True
     assert one["ranks_seen"] == 1 and one["self_launched"] is False
     assert many["n_gpus"] == world and one["n_gpus"] == 1
@@ -56,6 +57,11 @@ def test_bench_multi_rank_rehearsal():
     assert pr[0]["bytes_sent"] == 0 and all(r["bytes_sent"] > 0 for r in pr[1:])
     # every rank but 0 sends exactly its rows: r04: 8 bytes per short-range row (the MI column; rank 0 rebuilds the index columns from the
     # positions), 16 per long-range row — about half of r03's 16 bytes per row
+    # r05: the same job with the short-range rows left on their ranks — same kept links bit for bit, a fraction of the bytes
+    tail = many["sr_tail"]
+    assert tail["kept_links_equal"] is True and tail["kept_links"]["dist"]["rows"] > 100, tail["kept_links"]
+    assert tail["max_bytes_sent_per_peer"]["dist"] < 0.4 * tail["max_bytes_sent_per_peer"]["gather"], tail["max_bytes_sent_per_peer"]
+    assert all(r["candidates"] < 0.25 * r["sr_rows"] for r in tail["per_rank"] if r["sr_rows"] > 0)
     sent = sum(r["bytes_sent"] for r in pr)
     assert sent <= 8 * one["links"]["n_sr"] + 16 * one["links"]["n_lr"]
     assert sent < 0.6 * 16 * (one["links"]["n_sr"] + one["links"]["n_lr"]) * 3 / 4 + 16 * one["links"]["n_lr"]

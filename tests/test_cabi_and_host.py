@@ -368,3 +368,12 @@ def test_new_entry_points_refuse_bad_arguments_without_a_gpu():
     assert lib.ldw_tsv_join(None) == L.LDW_ERR_ARG
     assert lib.ldw_overflow_report(None, L.ptr(np.zeros(4, dtype=np.int64))) == L.LDW_ERR_ARG
     assert lib.ldw_build_info() in (0, 1)
+    # r05, the short-range model over ranks: no context -> LDW_ERR_ARG, never a crash
+    z8, zi = np.zeros(8), np.zeros(8, dtype=np.int64)
+    n = C.c_int64(0)
+    assert lib.ldw_sr_tail_extract(None, 1, 4, L.ptr(z8), L.ptr(zi), None, 0, 0, C.byref(n)) == L.LDW_ERR_ARG
+    assert lib.ldw_sr_quantiles_merge(None, 1, 4, 0.95, 1, None, None, L.ptr(zi), 0, L.ptr(z8), L.ptr(z8), None) == L.LDW_ERR_ARG
+    assert lib.ldw_sr_excess_stats_blocks(None, 1, 4, L.ptr(z8), 1, L.ptr(zi), L.ptr(z8)) == L.LDW_ERR_ARG
+    assert lib.ldw_sr_pool_build(None, 0.1, C.byref(n)) == L.LDW_ERR_ARG
+    assert lib.ldw_sr_reduced_import(None, 0, None, None, None, 0, None, None, None) == L.LDW_ERR_ARG
+    assert b"null context" in lib.ldw_last_error()

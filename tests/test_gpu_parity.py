@@ -984,6 +984,27 @@ def test_ldmap_matches_oracle(engine, synth):
         assert htm.min() == 0.0 and htm.max() == 1.0 and np.array_equal(htm, htm.T)
     with pytest.raises(RuntimeError):
         engine.ldmap(0)          # default reducer round(512 / 1000) = 1 <= 1: the unreduced branch is refused
+    # r05: snp.dat$POS in ANY order and positions held by two SNPs — the rank of a position is its rank among the sorted
+    # DISTINCT positions (R/LDSummaryPlot.R:57: sort(unique(c(pos1, pos2)))), not the SNP index.  The same links under a permutation of the SNPs,
+    # then with repeated positions, against the oracle on the positions themselves
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(512)
+    inv = np.empty(512, dtype=np.int32)
+    inv[perm] = np.arange(512, dtype=np.int32)
+    tabs = [engine.links(w) for w in (0, 1)]
+    for label, POS2 in (("permuted", POS[perm]), ("repeated", np.repeat(POS[::2], 2)[perm])):
+        engine.set_snp_meta(synth["r"][perm], synth["uqe"][perm], POS2, synth["paint"][perm], g)
+        for w in (0, 1):
+            a, b, mi = tabs[w]
+            engine.links_import(w, inv[a], inv[b], mi)
+        lr2, sr2 = _tables_as_dicts(engine, POS2)
+        for reducer, win in ((7, None), (5, (int(POS[40]), int(POS[400])))):
+            ref = orc.ld_map(lr2, sr2, reducer=reducer, from_=win[0] if win else None, to=win[1] if win else None)
+            htm, n_pos, r = engine.ldmap(reducer, *(win or (0, 0)))
+            assert n_pos == len(ref["pos_vec"]) and r == ref["reducer"] and htm.shape == ref["htm"].shape, label
+            assert np.abs(htm - ref["htm"]).max() < 1e-12 and np.array_equal(htm, htm.T), label
+        if label == "repeated":
+            assert n_pos <= 256
 
 
 def test_mixed_precision_gemm_is_exact(engine, synth):
