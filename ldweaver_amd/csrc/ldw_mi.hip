@@ -825,6 +825,60 @@ int ldw_sr_pairs_fill(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, double
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(blocks && nblocks > 0 && n_out && sr_dist >= 0, LDW_ERR_ARG, "ldw_sr_pairs_fill: bad argument");
     LDW_REQUIRE(c->have_meta && c->pos_sorted, LDW_ERR_STATE, "ldw_sr_pairs_fill: needs SNP positions in ascending order (ldw_set_snp_meta)");
+    *n_out = 0;
+    // r05: everything on the device (k_cols_dev ... k_sr_fill_all) — the host loop below built the intervals of C4's 20 band blocks in 17 ms, which a
+    // multi-GPU job's rank 0 paid after every gather.  Integral genome length (every len is then an exact integer on host and device alike); a column
+    // whose interval check fails (none on ascending positions) sends the call down the host path, as does LDW_SR_PAIRS_HOST=1 (A/B, tests).
+    if (c->g == std::floor(c->g) && getenv("LDW_SR_PAIRS_HOST") == nullptr) {
+        std::vector<SrBlkDev> hb;
+        int64_t ncols = 0;
+        const std::vector<int32_t> &Ph = c->h_POS;
+        for (int64_t b = 0; b < nblocks; ++b) {
+            const int32_t fs = blocks[b * 4 + 0], fe = blocks[b * 4 + 1], ts = blocks[b * 4 + 2], te = blocks[b * 4 + 3];
+            LDW_REQUIRE(fs >= 1 && fe >= fs && fe <= c->L && ts >= 1 && te >= ts && te <= c->L, LDW_ERR_ARG, "block %lld = (%d,%d,%d,%d) outside 1..%lld", (long long)b, fs, fe,
+                        ts, te, (long long)c->L);
+            if (ts > fe && 2 * sr_dist < c->g) {   // (as below: ranges further apart than sr_dist directly and across the origin)
+                const double pf_min = Ph[(size_t)fs - 1], pf_max = Ph[(size_t)fe - 1], pt_min = Ph[(size_t)ts - 1], pt_max = Ph[(size_t)te - 1];
+                if (pt_min - pf_max > sr_dist && pf_min + c->g - pt_max > sr_dist) continue;
+            }
+            hb.push_back(SrBlkDev{fs - 1, fe - fs + 1, ts - 1, te - ts + 1, (fs == ts && fe == te) ? 1 : 0, 0, ncols});
+            ncols += te - ts + 1;
+        }
+        if (hb.empty()) return LDW_OK;
+        const size_t nb = hb.size();
+        const size_t o_cu = nb * sizeof(SrBlkDev), o_cl = o_cu + (size_t)ncols * 4, o_rows = (o_cl + (size_t)ncols * 4 + 7) / 8 * 8, o_base = o_rows + nb * 8,
+                     o_bad = o_base + (nb + 1) * 8;
+        if (int rc = c->srd_seg.reserve(o_bad + 8)) return rc;
+        if (int rc = c->srd_out.reserve((size_t)ncols * sizeof(ColInfo))) return rc;
+        char *aux = c->srd_seg.as<char>();
+        SrBlkDev *d_blk = reinterpret_cast<SrBlkDev *>(aux);
+        int32_t *d_cu = reinterpret_cast<int32_t *>(aux + o_cu), *d_cl = reinterpret_cast<int32_t *>(aux + o_cl);
+        int64_t *d_rows = reinterpret_cast<int64_t *>(aux + o_rows), *d_base = reinterpret_cast<int64_t *>(aux + o_base);
+        int *d_bad = reinterpret_cast<int *>(aux + o_bad);
+        ColInfo *d_cols = c->srd_out.as<ColInfo>();
+        LDW_HIP(hipMemcpyAsync(d_blk, hb.data(), nb * sizeof(SrBlkDev), hipMemcpyHostToDevice, c->stream));
+        LDW_HIP(hipMemsetAsync(d_bad, 0, 8, c->stream));
+        hipLaunchKernelGGL(k_cols_dev, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, c->stream, c->POS.as<int32_t>(), c->g, sr_dist, d_blk, (int)nb, ncols, d_cols, d_cu,
+                           d_cl, d_bad);
+        hipLaunchKernelGGL(k_cols_scan, dim3((unsigned)nb), dim3(256), 0, c->stream, d_blk, d_cols, d_cu, d_cl, d_rows);
+        hipLaunchKernelGGL(k_blk_bases, dim3(1), dim3(64), 0, c->stream, d_rows, (int)nb, d_base);
+        LDW_HIP(hipGetLastError());
+        int64_t total = 0;
+        int bad = 0;
+        LDW_HIP(hipMemcpyAsync(&total, d_base + nb, 8, hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+        if (!bad) {
+            *n_out = total;
+            if (total > 0 && a_out && b_out) {
+                LDW_REQUIRE(total <= capacity, LDW_ERR_SIZE, "ldw_sr_pairs_fill: capacity %lld < %lld rows", (long long)capacity, (long long)total);
+                hipLaunchKernelGGL(k_sr_fill_all, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, c->stream, d_cols, d_blk, (int)nb, ncols, d_base, a_out, b_out);
+                LDW_HIP(hipGetLastError());
+                LDW_HIP(hipStreamSynchronize(c->stream));
+            }
+            return LDW_OK;
+        }
+    }
     std::vector<int32_t> fi, ti;
     std::vector<ColInfo> cols2[2];
     int64_t base = 0;

@@ -162,11 +162,11 @@ int ldw_mi_all_pairs_multi(ldw_ctx **ctx, int n_ctx, const int32_t *blocks, int6
     }
     LDW_HIP(hipSetDevice(c0->device));
     // The short-range rows are a pure function of the positions and the block geometry (R/computePairwiseMI.R:306-333), so their index columns
-    // need not travel: ctx[0] can rebuild (a, b) with the band enumerator (ldw_sr_pairs_fill) and only the MI column (8 of 16 bytes per row)
-    // crosses xGMI — what the RCCL gather of dist.py does.  In process it is the OPTION (LDW_MULTI_SR_MI_ONLY=1), not the default: the
-    // enumerator walks every block on the host (0.2 ms each: 12 ms for C4's 55 blocks, measured with two contexts on one GPU) while the bytes
-    // it saves are 90 MB per peer, each over its own link (~2 ms at N = 8) — every source already holds the index columns of its own rows.
-    const bool sr_mi_only = c0->pos_sorted && !p->sr_only && p->keep_sr && getenv("LDW_MULTI_SR_MI_ONLY") != nullptr;
+    // need not travel: ctx[0] rebuilds (a, b) with the band enumerator (ldw_sr_pairs_fill) and only the MI column (8 of 16 bytes per row) crosses
+    // xGMI — what the RCCL gather of dist.py does.  The DEFAULT since the enumerator builds its intervals on the device (r05: 0.8 ms for C4's
+    // 9e7 rows; its host loop took 12-19 ms, which made this the option, LDW_MULTI_SR_MI_ONLY, earlier in the round); LDW_MULTI_SR_FULL_ROWS=1 sends all
+    // three columns (also what unsorted positions, a fractional genome length and SR-only passes do).
+    const bool sr_mi_only = c0->pos_sorted && c0->g == std::floor(c0->g) && !p->sr_only && p->keep_sr && getenv("LDW_MULTI_SR_FULL_ROWS") == nullptr;
     ldw::DevBuf nA[2], nB[2], nM[2];
     auto fail = [&](int rc) {
         for (int w = 0; w < 2; ++w) {

@@ -2317,7 +2317,7 @@ def test_in_process_multi_context_equals_one_context(sample, tmp_path):
     """VERDICT r04 item 3 / SURVEY 8(b)(5): ldw_mi_all_pairs_multi — the block loop of R/computePairwiseMI.R:103-116 dealt over several
     contexts of ONE process (worker threads inside the library, peer-to-peer gather into ctx[0]) — with TWO and THREE contexts on this
     box's one GPU: link tables, block statistics and lr_links.tsv bytes identical to one context; the short-range rows travel with their
-    index columns (default) or as their MI column alone (index columns rebuilt by ldw_sr_pairs_fill: LDW_MULTI_SR_MI_ONLY); unsorted positions and
+    MI column alone (default: index columns rebuilt by ldw_sr_pairs_fill on the device) or with their index columns (LDW_MULTI_SR_FULL_ROWS); unsorted positions and
     an SR-only parameter set; the Hamming weights shared over the contexts are bit-identical; a context
     with other weights is refused; perform_MI_computation(engines=[...]) returns the single-engine frame and files."""
     Ls, N, B = 12_000, 1_000, 3_000
@@ -2367,12 +2367,15 @@ def test_in_process_multi_context_equals_one_context(sample, tmp_path):
             assert (tmp_path / "one.tsv").read_bytes() == (tmp_path / f"multi{n}.tsv").read_bytes()
             # the other contexts keep their own share
             assert engs[1].links_count(0) == int(one[2]["n_sr"][info["owner"] == 1].sum())
-        os.environ["LDW_MULTI_SR_MI_ONLY"] = "1"
-        try:
-            Engine.mi_all_pairs_multi(engs[:2], blocks, **kw)
-            same(one, tables(engs[0]), "2 contexts, short-range rows sent as their MI column, index columns rebuilt (ldw_sr_pairs_fill)")
-        finally:
-            os.environ.pop("LDW_MULTI_SR_MI_ONLY")
+        # (default since the band enumerator builds its intervals on the device: short-range rows travel as their MI column, ctx[0] rebuilds the
+        # index columns — ldw_sr_pairs_fill; the other form, and the enumerator's host loop)
+        for var in ("LDW_MULTI_SR_FULL_ROWS", "LDW_SR_PAIRS_HOST"):
+            os.environ[var] = "1"
+            try:
+                Engine.mi_all_pairs_multi(engs[:2], blocks, **kw)
+                same(one, tables(engs[0]), f"2 contexts, {var}")
+            finally:
+                os.environ.pop(var)
         # the consumers of the tables run on ctx[0] unchanged: short-range quantiles on the assembled table == on the single-context one
         q_multi = engs[0].sr_len_quantiles(3, 20000.0)
         engs[0].mi_all_pairs(blocks, **kw)
