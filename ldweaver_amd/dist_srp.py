@@ -35,7 +35,9 @@ class Comm:
     def __init__(self, group=None, device=None):
         self.group, self.world, self.rank, self.dev = group, 1, 0, None
         self.bytes_sent = 0
+        self.alone = True    # no exchange at all (one rank, collectives not forced)
         try:
+            import os
             import torch
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
@@ -44,6 +46,9 @@ class Comm:
                     self.dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
                 else:
                     self.dev = torch.device("cpu")
+                # LDW_FORCE_COLLECTIVE=1 (dist.py): a group of ONE rank runs every collective anyway — the all-reduces and broadcasts on the backend's
+                # tensors, the gathers as a loop-back isend / irecv — so the RCCL branch of this file executes on a box with one GPU (tests/rccl_worker.py)
+                self.alone = self.world == 1 and os.environ.get("LDW_FORCE_COLLECTIVE", "0") in ("", "0")
         except ImportError:
             pass
 
@@ -53,7 +58,7 @@ class Comm:
 
     def all_reduce(self, arr: np.ndarray, op: str) -> np.ndarray:
         """op: 'sum' | 'min'; same shape and dtype on every rank."""
-        if self.world == 1:
+        if self.alone:
             return np.array(arr, copy=True)
         import torch.distributed as dist
         t = self._t(arr)
@@ -62,7 +67,7 @@ class Comm:
         return t.cpu().numpy()
 
     def bcast(self, arr, shape, dtype, src: int = 0) -> np.ndarray:
-        if self.world == 1:
+        if self.alone:
             return np.asarray(arr, dtype=dtype).reshape(shape)
         import torch
         import torch.distributed as dist
@@ -74,20 +79,20 @@ class Comm:
 
     def agree(self, err, what: str) -> None:
         """Every rank learns whether a step failed on ANY rank before it enters the next exchange (``err``: this rank's exception or None)."""
-        if self.world == 1:
+        if self.alone:
             if err is not None:
                 raise err
             return
         from .dist import agree
         try:
-            agree(err is None, self.group, what)
+            agree(err is None, self.group, what, force_collective=True if self.world == 1 else None)
         except RuntimeError as e:
             raise e from err
 
     def gatherv(self, arr: np.ndarray, dst: int = 0):
         """1-D arrays of one dtype and any length -> list of every rank's array on ``dst`` (None elsewhere)."""
         arr = np.ascontiguousarray(arr)
-        if self.world == 1:
+        if self.alone:
             return [arr]
         import torch
         import torch.distributed as dist
@@ -95,6 +100,15 @@ class Comm:
         nb[self.rank] = arr.nbytes
         nb = self.all_reduce(nb, "sum")
         mine = self._t(arr.view(np.uint8).reshape(-1))
+        if self.world == 1:   # collectives forced on one rank: the buffer travels rank 0 -> rank 0 through the same grouped isend / irecv
+            buf = torch.empty(int(nb[0]), dtype=torch.uint8, device=self.dev)
+            if nb[0] > 0:
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, 0, self.group), dist.P2POp(dist.isend, mine, 0, self.group)]):
+                    w.wait()
+                if self.dev.type == "cuda":
+                    torch.cuda.current_stream(self.dev).synchronize()
+            self.bytes_sent += int(nb[0])
+            return [buf.cpu().numpy().view(arr.dtype)]
         if self.rank == dst:
             bufs = [mine if r == dst else torch.empty(int(nb[r]), dtype=torch.uint8, device=self.dev) for r in range(self.world)]
             ops = [dist.P2POp(dist.irecv, bufs[r], r, self.group) for r in range(self.world) if r != dst and nb[r] > 0]
@@ -127,7 +141,7 @@ class ThreadGroup:
 
 class ThreadComm(Comm):
     def __init__(self, tg: ThreadGroup, rank: int):
-        self.group, self.world, self.rank, self.dev, self.bytes_sent, self.tg = None, tg.world, int(rank), None, 0, tg
+        self.group, self.world, self.rank, self.dev, self.bytes_sent, self.tg, self.alone = None, tg.world, int(rank), None, 0, tg, False
 
     def _exchange(self, obj):
         self.tg.slots[self.rank] = obj

@@ -93,6 +93,14 @@ def main():
                                                  perform_SR_analysis_only=sr_only, sr_dist=(3000 if sr_only else 20000), verbose=False, quirk_mode=1)
                 red.to_pickle(os.path.join(outdir, f"red_{tag}.pkl"))
                 report[f"n_red_{tag}"] = int(len(red))
+            # r05: the short-range model over ranks (dist_srp.py) through the same backend — all-reduces, broadcast and the three variable-length
+            # gathers on GPU tensors; only the long-range table is gathered
+            red, aux = MIH.perform_MI_computation(sd, o["hdw"], CdsVar(paint=o["paint"], nclust=3), ncores=1,
+                                                  lr_save_path=os.path.join(outdir, "lr_rows_stay.tsv"), sr_save_path=os.path.join(outdir, "sr_rows_stay.tsv"),
+                                                  plt_folder=os.path.join(outdir, "PLOTS_rows_stay"), max_blk_sz=1000, lr_retain_links=1e5, engine=eng,
+                                                  verbose=False, quirk_mode=1, sr_tail="dist", return_aux=True)
+            red.to_pickle(os.path.join(outdir, "red_rows_stay.pkl"))
+            report["sr_tail_bytes_sent"] = aux["stages_s"]["sr_tail_bytes_sent"]
         report["backend"] = dist.get_backend()
         json.dump(report, open(os.path.join(outdir, "report.json"), "w"))
     finally:

@@ -1155,6 +1155,11 @@ def test_rccl_single_rank_walk(engine, sample, tmp_path):
         assert (one / "sr.tsv").read_bytes() == (tmp_path / f"sr_{tag}.tsv").read_bytes()
         if not sr_only:
             assert (one / "lr.tsv").read_bytes() == (tmp_path / "lr_full.tsv").read_bytes()
+            # r05: ... and with the short-range rows left on their rank (sr_tail="dist": dist_srp's exchanges on RCCL tensors)
+            assert (one / "sr.tsv").read_bytes() == (tmp_path / "sr_rows_stay.tsv").read_bytes()
+            assert (one / "lr.tsv").read_bytes() == (tmp_path / "lr_rows_stay.tsv").read_bytes()
+            _frames_equal(red1, pd.read_pickle(tmp_path / "red_rows_stay.pkl"))
+            assert rep["sr_tail_bytes_sent"]["candidates"] > 0 and rep["sr_tail_bytes_sent"]["kept_links_and_pool"] > 0
 
 
 def test_screen_and_mixed_paths_on_multiallelic_alignment(engine):
