@@ -417,6 +417,29 @@ def inproc_main(args):
                                hamming_weights_s=hamming_s),
                    links=dict(n_sr=engs[0].links_count(0), n_lr=engs[0].links_count(1)),
                    spec_misses=sum(e.counters()["spec_misses"] for e in engs))
+        # r05, after the timed region: pass + short-range model + ARACNE both ways — tables gathered into context 0 and the model there, or the short-range
+        # rows left on their contexts (LDW_MI_SR_ROWS_STAY) and the model's reductions over the contexts (ldw_sr_*_multi)
+        if len(engs) > 1 and not args.no_sr_tail_leg:
+            from ldweaver_amd.engine import EngineGroup
+            from ldweaver_amd.srp import merge_n_sort_sr_links_device
+            nclust, leg = int(np.max(paint)), {}
+            dig = {}
+            for tag, stay in (("gather", False), ("rows_stay", True)):
+                for e in engs:
+                    e.reset_speculation()
+                sync()
+                t0 = time.perf_counter()
+                inf = Engine.mi_all_pairs_multi(engs, blocks, 20000.0, 1e6, approx, sr_rows_stay=stay)
+                t1 = time.perf_counter()
+                view = EngineGroup(engs) if stay else engs[0]
+                red, flags, _ = merge_n_sort_sr_links_device(view, nclust, 20000.0, 3.0, POS, paint, g, run_aracne=True, order_links=True,
+                                                             block_rows=None if stay else engs[0].block_stats()["n_sr"])
+                t2 = time.perf_counter()
+                leg[tag] = dict(pass_and_gather_ms=(t1 - t0) * 1e3, gather_ms=inf["gather_ms"], model_aracne_ms=(t2 - t1) * 1e3, total_ms=(t2 - t0) * 1e3)
+                dig[tag] = dict(rows=int(len(red["MI"])), aracne_true=int(np.sum(flags)), mi_sum=float(np.sum(red["MI"])), srp_sum=float(np.sum(red["srp_max"])))
+            leg["kept_links"] = dig
+            leg["kept_links_equal"] = dig["gather"] == dig["rows_stay"]
+            out["sr_tail"] = leg
         print(json.dumps(out), flush=True)
     finally:
         for e in engs:

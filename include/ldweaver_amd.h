@@ -157,8 +157,11 @@ typedef struct ldw_mi_params {
     int32_t sr_only;         /* perform_SR_analysis_only: lr part skipped */
     int32_t quirk_mode;      /* LDW_QUIRK_* */
     int32_t keep_sr;         /* 0: do not materialise sr links (throughput measurement of lr only) */
-    int32_t reserved;
+    int32_t flags;           /* LDW_MI_* bits (0: none) */
 } ldw_mi_params;
+/* r05, ldw_mi_all_pairs_multi only: the short-range rows STAY on the contexts that computed them — only the long-range table is assembled in
+ * ctx[0] — and the short-range model runs over the contexts (ldw_sr_len_quantiles_multi, ldw_sr_excess_stats_multi, ldw_sr_pvalues_multi below) */
+#define LDW_MI_SR_ROWS_STAY 1
 
 /* blocks[nblocks][4] = (from_s, from_e, to_s, to_e), 1-based inclusive, e.g. this rank's share of
  * make_blocks().  Links are appended to the context's device-resident tables in block order and, within
@@ -176,7 +179,7 @@ int ldw_mi_all_pairs(ldw_ctx *ctx, const int32_t *blocks, int64_t nblocks, const
  * ARACNE, the post-processing and the tsv writers run on it unchanged; the other contexts keep their own shares.  The long-range filter is
  * per block (:352-358), so the retained set does not depend on n_ctx.  One failing context fails the call (its message is reported).
  * owner_out (nblocks, may be NULL) receives the deal; ms_out (10 doubles, may be NULL): [0] deal + slowest pass, [1] gather, [2..9] the
- * pass of contexts 0..7.  n_ctx = 1 is ldw_mi_all_pairs(ctx[0], ..., reset = 1). */
+ * pass of contexts 0..7.  n_ctx = 1 is ldw_mi_all_pairs(ctx[0], ..., reset = 1).  p->flags & LDW_MI_SR_ROWS_STAY: see (7c). */
 int ldw_mi_all_pairs_multi(ldw_ctx **ctx, int n_ctx, const int32_t *blocks, int64_t nblocks, const ldw_mi_params *p,
                            int32_t *owner_out, double *ms_out);
 /* the deal alone (host only, no context): owner_out[b] = rank of block b */
@@ -382,6 +385,19 @@ int ldw_sr_pool_build(ldw_ctx *ctx, double min_mi, int64_t *n_pool_out);
  * the context's short-range table (rows 0..n_red-1); ldw_aracne_device then answers for them in that order. */
 int ldw_sr_reduced_import(ldw_ctx *ctx, int64_t n_red, const int32_t *a, const int32_t *b, const double *MI, int64_t n_pool,
                           const int32_t *pool_a, const int32_t *pool_b, const double *pool_MI);
+
+/* ---- (7c) r05 — (7) over the contexts of ONE process after ldw_mi_all_pairs_multi(.., flags = LDW_MI_SR_ROWS_STAY): the protocol of (7b) run by the
+ *          library itself (a worker thread per context, exchanges staged through host memory), behind the signatures of (7) — so a single-process
+ *          host (R: r_shim/) keeps its three calls and its own fit / optimiser between them.  ctx[0] of that call must be ctx[0] here.  With one
+ *          context, or tables that were gathered (no flag), they are (7) on ctx[0] — with the excess sums taken per block when the table's block
+ *          structure is known, so that one context and several give the same bits. ---- */
+int ldw_sr_len_quantiles_multi(ldw_ctx **ctx, int n_ctx, int nclust, double sr_dist, double prob, int32_t S, double *q_lo_out, double *q_hi_out,
+                               int64_t *n_out);
+int ldw_sr_excess_stats_multi(ldw_ctx **ctx, int n_ctx, int nclust, int32_t S, const double *mean_dist, double *stats_out);
+/* ... and the kept links of ALL contexts end up in ctx[0] (they replace its short-range table, ordered as in the job's table: make_blocks order), with the
+ * pool of all contexts: ldw_sr_reduced_fetch / ldw_sr_pool_fetch / ldw_aracne_device on ctx[0] follow as after ldw_sr_pvalues. */
+int ldw_sr_pvalues_multi(ldw_ctx **ctx, int n_ctx, int nclust, int32_t S, const double *mean_dist, const double *shape, double srp_cutoff,
+                         int64_t *n_red_out, int64_t *n_pool_out, double *min_mi_out);
 
 /* ---- (8) consumers of the link tables, on the device-resident tables ------------------ */
 /* Numeric core of analyse_long_range_links (R/lr_analyser.R:72-111): q13_out = quantile(MI, c(.25,.75)) (type 7) of the

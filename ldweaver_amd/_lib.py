@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("LDW_AMD_LIB") or os.path.join(_HERE, "libldweaver_amd
 LDW_OK = 0
 LDW_ERR_ARG, LDW_ERR_HIP, LDW_ERR_STATE, LDW_ERR_NOGPU, LDW_ERR_SIZE = 1, 2, 3, 4, 5
 QUIRK_REFERENCE, QUIRK_INTENDED = 0, 1
+MI_SR_ROWS_STAY = 1
 ENGINE_MFMA, ENGINE_HIST, ENGINE_HIST_STATES = 0, 1, 2
 COL_INT32, COL_INT64, COL_DOUBLE = 0, 1, 2
 
@@ -29,7 +30,7 @@ class LdwError(RuntimeError):
 
 class MIParams(C.Structure):
     _fields_ = [("sr_dist", C.c_double), ("lr_retain_links", C.c_double), ("lr_links_approx", C.c_double),
-                ("sr_only", C.c_int32), ("quirk_mode", C.c_int32), ("keep_sr", C.c_int32), ("reserved", C.c_int32)]
+                ("sr_only", C.c_int32), ("quirk_mode", C.c_int32), ("keep_sr", C.c_int32), ("flags", C.c_int32)]
 
 
 _lib = None
@@ -94,6 +95,9 @@ _SIGS = {
     "ldw_sr_excess_stats_blocks": (C.c_int, [_p, C.c_int, C.c_int32, _p, _i64, _p, _p]),
     "ldw_sr_pool_build": (C.c_int, [_p, C.c_double, _p]),
     "ldw_sr_reduced_import": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _p]),
+    "ldw_sr_len_quantiles_multi": (C.c_int, [_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int32, _p, _p, _p]),
+    "ldw_sr_excess_stats_multi": (C.c_int, [_p, C.c_int, C.c_int, C.c_int32, _p, _p]),
+    "ldw_sr_pvalues_multi": (C.c_int, [_p, C.c_int, C.c_int, C.c_int32, _p, _p, C.c_double, _p, _p, _p]),
     "ldw_gemm_stats": (C.c_int, [_p, _p, C.c_int]),
     "ldw_lr_tukey": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, _p, _p]),
     "ldw_lr_reduced_fetch": (C.c_int, [_p, _i64, _p, _p, _p, _p]),

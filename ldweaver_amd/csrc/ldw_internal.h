@@ -274,6 +274,7 @@ struct ldw_ctx {
     int64_t spec_misses = 0, fused_blocks = 0, unfused_blocks = 0, screen_violations = 0, mixed_blocks = 0;
     int screen = 1;                      // fp32 screen in front of the fp64 MI evaluation (0 off, 1 on, 2 verify)
     std::vector<ldw::BlockStat> stats;
+    std::vector<int32_t> multi_owner;    // r05: ctx[0] of ldw_mi_all_pairs_multi(.., LDW_MI_SR_ROWS_STAY): the deal (owner of every block); empty otherwise
     std::vector<ldw::BlockTrace> trace;
     // ldw_ctx_reserve (r04): what a job's FIRST pass otherwise pays inside its timed loop — two hipStreamCreate (12 ms each on this box), the
     // pinned staging buffers (hipHostMalloc: 0.2 ms per MB), the lazy load of the code objects of the pass's kernels — done by a side thread
@@ -309,5 +310,8 @@ void warm_mi();                      // lazy code-object loads of the translatio
 void warm_apx();
 void warm_gemm_bits();
 void warm_srp();
+// ldw_srp.hip: ldw_sr_reduced_import with the kept links' meta words (clust_c | first << 8 | dup << 16) and srp values (both may be null)
+int reduced_import_full(ldw_ctx *ctx, int64_t n_red, const int32_t *a, const int32_t *b, const double *MI, const uint32_t *meta, const double *srp, int64_t n_pool,
+                        const int32_t *pool_a, const int32_t *pool_b, const double *pool_MI);
 void warm_post();
 }  // namespace ldw

@@ -125,7 +125,9 @@ int ldw_mi_all_pairs_multi(ldw_ctx **ctx, int n_ctx, const int32_t *blocks, int6
         ms_out[1] = 0;           // the gather (below)
         for (int k = 0; k < n_ctx && k < 8; ++k) ms_out[2 + k] = W[(size_t)k].ms;
     }
+    c0->multi_owner.clear();
     if (n_ctx == 1) return LDW_OK;
+    const bool rows_stay = (p->flags & LDW_MI_SR_ROWS_STAY) != 0 && p->keep_sr;   // r05: only the long-range table is assembled; (7c) runs the model over the contexts
     // ---- 4) the gather: rows of block b lie at the running offset of its owner's table; their place in ctx[0]'s assembled table is the
     //         running offset over ALL blocks in the caller's (make_blocks) order
     std::vector<ldw::BlockStat> stats((size_t)nblocks);
@@ -166,7 +168,7 @@ int ldw_mi_all_pairs_multi(ldw_ctx **ctx, int n_ctx, const int32_t *blocks, int6
     // xGMI — what the RCCL gather of dist.py does.  The DEFAULT since the enumerator builds its intervals on the device (r05: 0.8 ms for C4's
     // 9e7 rows; its host loop took 12-19 ms, which made this the option, LDW_MULTI_SR_MI_ONLY, earlier in the round); LDW_MULTI_SR_FULL_ROWS=1 sends all
     // three columns (also what unsorted positions, a fractional genome length and SR-only passes do).
-    const bool sr_mi_only = c0->pos_sorted && c0->g == std::floor(c0->g) && !p->sr_only && p->keep_sr && getenv("LDW_MULTI_SR_FULL_ROWS") == nullptr;
+    const bool sr_mi_only = !rows_stay && c0->pos_sorted && c0->g == std::floor(c0->g) && !p->sr_only && p->keep_sr && getenv("LDW_MULTI_SR_FULL_ROWS") == nullptr;
     ldw::DevBuf nA[2], nB[2], nM[2];
     auto fail = [&](int rc) {
         for (int w = 0; w < 2; ++w) {
@@ -176,7 +178,7 @@ int ldw_mi_all_pairs_multi(ldw_ctx **ctx, int n_ctx, const int32_t *blocks, int6
         }
         return rc;
     };
-    for (int w = 0; w < 2; ++w) {
+    for (int w = rows_stay ? 1 : 0; w < 2; ++w) {
         const size_t n = (size_t)std::max<int64_t>(tot[w], 1);
         if (int rc = nA[w].reserve(n * 4)) return fail(rc);
         if (int rc = nB[w].reserve(n * 4)) return fail(rc);
@@ -200,7 +202,7 @@ int ldw_mi_all_pairs_multi(ldw_ctx **ctx, int n_ctx, const int32_t *blocks, int6
             he = hipErrorInvalidDevice;
             break;
         }
-        for (int w = 0; w < 2 && he == hipSuccess; ++w) {
+        for (int w = rows_stay ? 1 : 0; w < 2 && he == hipSuccess; ++w) {
             const int64_t so = src_off[(size_t)k * 2 + w], d = dst_off[w], n = rows[w];
             const ldw::DevBuf &sa = w == 0 ? ck->sr_a : ck->lr_a, &sb = w == 0 ? ck->sr_b : ck->lr_b, &sm = w == 0 ? ck->sr_mi : ck->lr_mi;
             if (!(w == 0 && sr_mi_only)) {
@@ -231,17 +233,20 @@ int ldw_mi_all_pairs_multi(ldw_ctx **ctx, int n_ctx, const int32_t *blocks, int6
     (void)hipSetDevice(c0->device);
     if (rc != LDW_OK) return fail(rc);
     // ---- 5) ctx[0] adopts the assembled tables (its own share's buffers are released) and the per-block records of ALL blocks
-    std::swap(c0->sr_a, nA[0]);
-    std::swap(c0->sr_b, nB[0]);
-    std::swap(c0->sr_mi, nM[0]);
+    if (!rows_stay) {
+        std::swap(c0->sr_a, nA[0]);
+        std::swap(c0->sr_b, nB[0]);
+        std::swap(c0->sr_mi, nM[0]);
+    }
     std::swap(c0->lr_a, nA[1]);
     std::swap(c0->lr_b, nB[1]);
     std::swap(c0->lr_mi, nM[1]);
     fail(LDW_OK);
-    c0->n_sr = tot[0];
+    if (!rows_stay) c0->n_sr = tot[0];   // (rows_stay: ctx[0] keeps the short-range rows of its own share, like every other context)
     c0->n_lr = tot[1];
     c0->n_red = c0->n_pool = 0;
-    c0->stats = stats;
+    c0->stats = stats;                    // the records of ALL blocks, in the caller's order (ldw_block_stats)
+    if (rows_stay) c0->multi_owner = owner;
     if (ms_out) ms_out[1] = now_ms() - t_1;
     return LDW_OK;
 }
@@ -290,6 +295,255 @@ int ldw_hamming_weights_multi(ldw_ctx **ctx, int n_ctx, int32_t thresh, double *
         for (int k = 0; k < n_ctx; ++k) n += cnt[(size_t)k][(size_t)j];
         hdw_out[j] = 1.0 / ((double)n + 1.0);
     }
+    return LDW_OK;
+}
+
+}  // extern "C"
+
+// ---- (7c) the short-range model over the contexts of this process (r05) ---------------------------------------------------------------------
+namespace {
+
+// run f(k) for every context on a thread of its own (context 0 on the caller's); the first failure (lowest k) becomes the caller's error
+template <class F>
+int for_each_ctx(ldw_ctx **ctx, int n_ctx, const char *who, F f) {
+    std::vector<int> rcs((size_t)n_ctx, LDW_OK);
+    std::vector<std::string> errs((size_t)n_ctx);
+    auto run = [&](int k) {
+        if (hipSetDevice(ctx[k]->device) != hipSuccess) {
+            rcs[(size_t)k] = LDW_ERR_HIP;
+            errs[(size_t)k] = "hipSetDevice failed";
+            return;
+        }
+        try {
+            rcs[(size_t)k] = f(k);
+            if (rcs[(size_t)k] != LDW_OK) errs[(size_t)k] = ldw_last_error();
+        } catch (const std::exception &e) {
+            rcs[(size_t)k] = LDW_ERR_STATE;
+            errs[(size_t)k] = e.what();
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int k = 1; k < n_ctx; ++k) th.emplace_back(run, k);
+        run(0);
+        for (auto &t : th) t.join();
+    }
+    (void)hipSetDevice(ctx[0]->device);
+    for (int k = 0; k < n_ctx; ++k)
+        if (rcs[(size_t)k] != LDW_OK) {
+            ldw::set_error("%s: context %d (device %d): %s", who, k, ctx[k]->device, errs[(size_t)k].c_str());
+            return rcs[(size_t)k];
+        }
+    return LDW_OK;
+}
+
+// the contexts hold the shares ldw_mi_all_pairs_multi(.., LDW_MI_SR_ROWS_STAY) left?  mine[k] = the blocks of context k in its table's order, rows[k] their row counts
+int shares_of(ldw_ctx **ctx, int n_ctx, const char *who, bool &spread, std::vector<std::vector<int64_t>> &mine, std::vector<std::vector<int64_t>> &rows) {
+    LDW_REQUIRE(ctx && n_ctx >= 1 && n_ctx <= 64 && ctx[0], LDW_ERR_ARG, "%s: bad argument", who);
+    for (int k = 0; k < n_ctx; ++k) LDW_REQUIRE(ctx[k], LDW_ERR_ARG, "%s: context %d is null", who, k);
+    const ldw_ctx *c0 = ctx[0];
+    spread = n_ctx > 1 && !c0->multi_owner.empty();
+    mine.assign((size_t)n_ctx, {});
+    rows.assign((size_t)n_ctx, {});
+    if (!spread) return LDW_OK;
+    LDW_REQUIRE(c0->multi_owner.size() == c0->stats.size(), LDW_ERR_STATE, "%s: context 0 is not the context 0 of the last ldw_mi_all_pairs_multi call", who);
+    for (size_t b = 0; b < c0->multi_owner.size(); ++b) {
+        const int k = c0->multi_owner[b];
+        LDW_REQUIRE(k >= 0 && k < n_ctx, LDW_ERR_STATE, "%s: block %lld belongs to context %d, %d contexts given", who, (long long)b, k, n_ctx);
+        mine[(size_t)k].push_back((int64_t)b);
+        rows[(size_t)k].push_back(c0->stats[b].n_sr);
+    }
+    for (int k = 0; k < n_ctx; ++k) {
+        int64_t s = 0;
+        for (int64_t r : rows[(size_t)k]) s += r;
+        LDW_REQUIRE(s == ctx[k]->n_sr, LDW_ERR_STATE, "%s: context %d holds %lld short-range rows, its blocks of the last ldw_mi_all_pairs_multi call %lld", who, k,
+                    (long long)ctx[k]->n_sr, (long long)s);
+    }
+    return LDW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ldw_sr_len_quantiles_multi(ldw_ctx **ctx, int n_ctx, int nclust, double sr_dist, double prob, int32_t S, double *q_lo_out, double *q_hi_out, int64_t *n_out) {
+    bool spread = false;
+    std::vector<std::vector<int64_t>> mine, rows;
+    if (int rc = shares_of(ctx, n_ctx, "ldw_sr_len_quantiles_multi", spread, mine, rows)) return rc;
+    if (!spread) return ldw_sr_len_quantiles(ctx[0], nclust, sr_dist, prob, S, q_lo_out, q_hi_out, n_out);
+    LDW_REQUIRE(q_lo_out && q_hi_out && n_out && nclust >= 1 && S >= 1, LDW_ERR_ARG, "ldw_sr_len_quantiles_multi: bad argument");
+    const size_t G = (size_t)nclust * (size_t)S;
+    // 1) every context's own counts and order statistics
+    std::vector<std::vector<double>> qlo((size_t)n_ctx, std::vector<double>(G)), qhi((size_t)n_ctx, std::vector<double>(G));
+    std::vector<std::vector<int64_t>> cnt((size_t)n_ctx, std::vector<int64_t>(G));
+    if (int rc = for_each_ctx(ctx, n_ctx, "ldw_sr_len_quantiles_multi", [&](int k) {
+            return ldw_sr_len_quantiles(ctx[k], nclust, sr_dist, prob, S, qlo[(size_t)k].data(), qhi[(size_t)k].data(), cnt[(size_t)k].data());
+        }))
+        return rc;
+    // 2) the bound: the smallest local lower statistic of a group lies at or below the group's own
+    std::vector<double> lower(G, std::nan(""));
+    std::vector<int64_t> total(G, 0);
+    for (size_t i = 0; i < G; ++i)
+        for (int k = 0; k < n_ctx; ++k) {
+            total[i] += cnt[(size_t)k][i];
+            if (cnt[(size_t)k][i] > 0 && !(lower[i] <= qlo[(size_t)k][i])) lower[i] = qlo[(size_t)k][i];   // (NaN-safe minimum)
+        }
+    // 3) every context's rows at or above it (values only, grouped len-major), through host memory
+    std::vector<std::vector<int64_t>> tcnt((size_t)n_ctx, std::vector<int64_t>(G));
+    std::vector<std::vector<double>> tmi((size_t)n_ctx);
+    if (int rc = for_each_ctx(ctx, n_ctx, "ldw_sr_len_quantiles_multi", [&](int k) {
+            int64_t n = 0;
+            if (int r = ldw_sr_tail_extract(ctx[k], nclust, S, lower.data(), tcnt[(size_t)k].data(), nullptr, 0, 0, &n)) return r;
+            tmi[(size_t)k].resize((size_t)std::max<int64_t>(n, 1));
+            if (n == 0) return (int)LDW_OK;
+            return ldw_sr_tail_extract(ctx[k], nclust, S, lower.data(), tcnt[(size_t)k].data(), tmi[(size_t)k].data(), n, 0, &n);
+        }))
+        return rc;
+    // 4) context 0 selects by rank from the top
+    std::vector<const double *> pm((size_t)n_ctx);
+    std::vector<const int64_t *> pc((size_t)n_ctx);
+    for (int k = 0; k < n_ctx; ++k) {
+        pm[(size_t)k] = tmi[(size_t)k].data();
+        pc[(size_t)k] = tcnt[(size_t)k].data();
+    }
+    LDW_HIP(hipSetDevice(ctx[0]->device));
+    if (int rc = ldw_sr_quantiles_merge(ctx[0], nclust, S, prob, n_ctx, pm.data(), pc.data(), total.data(), 0, q_lo_out, q_hi_out, nullptr)) return rc;
+    memcpy(n_out, total.data(), G * 8);
+    return LDW_OK;
+}
+
+int ldw_sr_excess_stats_multi(ldw_ctx **ctx, int n_ctx, int nclust, int32_t S, const double *mean_dist, double *stats_out) {
+    bool spread = false;
+    std::vector<std::vector<int64_t>> mine, rows;
+    if (int rc = shares_of(ctx, n_ctx, "ldw_sr_excess_stats_multi", spread, mine, rows)) return rc;
+    LDW_REQUIRE(stats_out && nclust >= 1, LDW_ERR_ARG, "ldw_sr_excess_stats_multi: bad argument");
+    const size_t per = (size_t)nclust * 5;
+    if (!spread) {
+        // one table: per block when its block structure is known (the rows of the last pass / gather), else strips of the whole table
+        ldw_ctx *c = ctx[0];
+        int64_t s = 0;
+        std::vector<int64_t> r;
+        for (const auto &st : c->stats) {
+            r.push_back(st.n_sr);
+            s += st.n_sr;
+        }
+        if (r.empty() || s != c->n_sr) return ldw_sr_excess_stats(c, nclust, S, mean_dist, stats_out);
+        std::vector<double> part(r.size() * per);
+        if (int rc = ldw_sr_excess_stats_blocks(c, nclust, S, mean_dist, (int64_t)r.size(), r.data(), part.data())) return rc;
+        for (size_t t = 0; t < per; ++t) stats_out[t] = 0.0;
+        for (size_t b = 0; b < r.size(); ++b)
+            for (size_t t = 0; t < per; ++t) stats_out[t] += part[b * per + t];
+        return LDW_OK;
+    }
+    const size_t nb = ctx[0]->stats.size();
+    std::vector<std::vector<double>> part((size_t)n_ctx);
+    if (int rc = for_each_ctx(ctx, n_ctx, "ldw_sr_excess_stats_multi", [&](int k) {
+            part[(size_t)k].assign(std::max<size_t>(rows[(size_t)k].size(), 1) * per, 0.0);
+            return ldw_sr_excess_stats_blocks(ctx[k], nclust, S, mean_dist, (int64_t)rows[(size_t)k].size(), rows[(size_t)k].data(), part[(size_t)k].data());
+        }))
+        return rc;
+    std::vector<const double *> of(nb, nullptr);
+    for (int k = 0; k < n_ctx; ++k)
+        for (size_t i = 0; i < mine[(size_t)k].size(); ++i) of[(size_t)mine[(size_t)k][i]] = part[(size_t)k].data() + i * per;
+    for (size_t t = 0; t < per; ++t) stats_out[t] = 0.0;
+    for (size_t b = 0; b < nb; ++b)   // make_blocks order: the same sum for any deal
+        for (size_t t = 0; t < per; ++t) stats_out[t] += of[b][t];
+    return LDW_OK;
+}
+
+int ldw_sr_pvalues_multi(ldw_ctx **ctx, int n_ctx, int nclust, int32_t S, const double *mean_dist, const double *shape, double srp_cutoff, int64_t *n_red_out,
+                         int64_t *n_pool_out, double *min_mi_out) {
+    bool spread = false;
+    std::vector<std::vector<int64_t>> mine, rows;
+    if (int rc = shares_of(ctx, n_ctx, "ldw_sr_pvalues_multi", spread, mine, rows)) return rc;
+    if (!spread) return ldw_sr_pvalues(ctx[0], nclust, S, mean_dist, shape, srp_cutoff, n_red_out, n_pool_out, min_mi_out);
+    LDW_REQUIRE(n_red_out && n_pool_out, LDW_ERR_ARG, "ldw_sr_pvalues_multi: null output");
+    // 1) p-values where the rows lie; the smallest kept MI over all contexts
+    std::vector<int64_t> nr((size_t)n_ctx, 0), np((size_t)n_ctx, 0);
+    std::vector<double> mn((size_t)n_ctx, std::nan(""));
+    if (int rc = for_each_ctx(ctx, n_ctx, "ldw_sr_pvalues_multi",
+                              [&](int k) { return ldw_sr_pvalues(ctx[k], nclust, S, mean_dist, shape, srp_cutoff, &nr[(size_t)k], nullptr, &mn[(size_t)k]); }))
+        return rc;
+    double gmin = std::nan("");
+    for (int k = 0; k < n_ctx; ++k)
+        if (nr[(size_t)k] > 0 && !(gmin <= mn[(size_t)k])) gmin = mn[(size_t)k];
+    // 2) every context's pool for THAT minimum, its kept links and pool to the host
+    struct Kept {
+        std::vector<int64_t> row;
+        std::vector<int32_t> a, b, cc, first;
+        std::vector<uint8_t> dup;
+        std::vector<double> mi, srp;
+        std::vector<int32_t> pa, pb;
+        std::vector<double> pmi;
+    };
+    std::vector<Kept> K((size_t)n_ctx);
+    if (int rc = for_each_ctx(ctx, n_ctx, "ldw_sr_pvalues_multi", [&](int k) {
+            Kept &q = K[(size_t)k];
+            if (int r = ldw_sr_pool_build(ctx[k], gmin, &np[(size_t)k])) return r;
+            const size_t n = (size_t)nr[(size_t)k], m = (size_t)np[(size_t)k];
+            q.row.resize(n); q.a.resize(n); q.b.resize(n); q.cc.resize(n); q.first.resize(n); q.dup.resize(n); q.mi.resize(n); q.srp.resize(n);
+            q.pa.resize(m); q.pb.resize(m); q.pmi.resize(m);
+            if (n)
+                if (int r = ldw_sr_reduced_fetch(ctx[k], (int64_t)n, q.row.data(), q.a.data(), q.b.data(), q.mi.data(), q.cc.data(), q.first.data(), q.dup.data(), q.srp.data())) return r;
+            if (m)
+                if (int r = ldw_sr_pool_fetch(ctx[k], (int64_t)m, q.pa.data(), q.pb.data(), q.pmi.data())) return r;
+            return (int)LDW_OK;
+        }))
+        return rc;
+    // 3) rows of a context's table -> rows of the job's table (make_blocks order); all kept links in that order
+    const size_t nb = ctx[0]->stats.size();
+    std::vector<int64_t> goff(nb + 1, 0);
+    for (size_t b = 0; b < nb; ++b) goff[b + 1] = goff[b] + ctx[0]->stats[b].n_sr;
+    int64_t n_red = 0, n_pool = 0;
+    for (int k = 0; k < n_ctx; ++k) {
+        n_red += nr[(size_t)k];
+        n_pool += np[(size_t)k];
+    }
+    struct Ref {
+        int64_t grow;
+        int32_t k;
+        int64_t i;
+    };
+    std::vector<Ref> order;
+    order.reserve((size_t)n_red);
+    for (int k = 0; k < n_ctx; ++k) {
+        std::vector<int64_t> loff(rows[(size_t)k].size() + 1, 0);
+        for (size_t i = 0; i < rows[(size_t)k].size(); ++i) loff[i + 1] = loff[i] + rows[(size_t)k][i];
+        for (int64_t i = 0; i < nr[(size_t)k]; ++i) {
+            const int64_t r = K[(size_t)k].row[(size_t)i];
+            const size_t bi = (size_t)(std::upper_bound(loff.begin(), loff.end(), r) - loff.begin()) - 1;
+            LDW_REQUIRE(bi < rows[(size_t)k].size(), LDW_ERR_STATE, "ldw_sr_pvalues_multi: context %d reports row %lld of %lld", k, (long long)r, (long long)loff.back());
+            order.push_back(Ref{goff[(size_t)mine[(size_t)k][bi]] + (r - loff[bi]), k, i});
+        }
+    }
+    std::sort(order.begin(), order.end(), [](const Ref &x, const Ref &y) { return x.grow < y.grow; });   // (rows are distinct)
+    std::vector<int32_t> A((size_t)n_red), B((size_t)n_red), PA((size_t)n_pool), PB((size_t)n_pool);
+    std::vector<double> M((size_t)n_red), SRP((size_t)n_red), PM((size_t)n_pool);
+    std::vector<uint32_t> META((size_t)n_red);
+    for (size_t j = 0; j < order.size(); ++j) {
+        const Kept &q = K[(size_t)order[j].k];
+        const size_t i = (size_t)order[j].i;
+        A[j] = q.a[i];
+        B[j] = q.b[i];
+        M[j] = q.mi[i];
+        SRP[j] = q.srp[i];
+        META[j] = (uint32_t)q.cc[i] | ((uint32_t)q.first[i] << 8) | ((uint32_t)(q.dup[i] ? 1 : 0) << 16);
+    }
+    size_t o = 0;
+    for (int k = 0; k < n_ctx; ++k) {
+        const Kept &q = K[(size_t)k];
+        std::copy(q.pa.begin(), q.pa.end(), PA.begin() + (std::ptrdiff_t)o);
+        std::copy(q.pb.begin(), q.pb.end(), PB.begin() + (std::ptrdiff_t)o);
+        std::copy(q.pmi.begin(), q.pmi.end(), PM.begin() + (std::ptrdiff_t)o);
+        o += q.pmi.size();
+    }
+    // 4) context 0 adopts them: ldw_sr_reduced_fetch / ldw_sr_pool_fetch / ldw_aracne_device follow as after ldw_sr_pvalues
+    LDW_HIP(hipSetDevice(ctx[0]->device));
+    if (int rc = ldw::reduced_import_full(ctx[0], n_red, A.data(), B.data(), M.data(), META.data(), SRP.data(), n_pool, PA.data(), PB.data(), PM.data())) return rc;
+    ctx[0]->multi_owner.clear();   // (its short-range table is the kept set now: the shares are gone)
+    *n_red_out = n_red;
+    *n_pool_out = n_pool;
+    if (min_mi_out) *min_mi_out = gmin;
     return LDW_OK;
 }
 

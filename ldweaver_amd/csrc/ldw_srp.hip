@@ -1458,6 +1458,14 @@ int ldw_sr_pool_build(ldw_ctx *c, double min_mi, int64_t *n_pool_out) {
 
 int ldw_sr_reduced_import(ldw_ctx *c, int64_t n_red, const int32_t *a, const int32_t *b, const double *MI, int64_t n_pool, const int32_t *pool_a,
                           const int32_t *pool_b, const double *pool_MI) {
+    return ldw::reduced_import_full(c, n_red, a, b, MI, nullptr, nullptr, n_pool, pool_a, pool_b, pool_MI);
+}
+
+}  // extern "C"
+
+namespace ldw {
+int reduced_import_full(ldw_ctx *c, int64_t n_red, const int32_t *a, const int32_t *b, const double *MI, const uint32_t *meta, const double *srp, int64_t n_pool,
+                        const int32_t *pool_a, const int32_t *pool_b, const double *pool_MI) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(n_red >= 0 && n_pool >= 0 && (n_red == 0 || (a && b && MI)) && (n_pool == 0 || (pool_a && pool_b && pool_MI)), LDW_ERR_ARG,
                 "ldw_sr_reduced_import: bad argument");
@@ -1475,8 +1483,10 @@ int ldw_sr_reduced_import(ldw_ctx *c, int64_t n_red, const int32_t *a, const int
     if (int rc = c->pool_a.reserve(np * 4)) return rc;
     if (int rc = c->pool_b.reserve(np * 4)) return rc;
     if (int rc = c->pool_mi.reserve(np * 8)) return rc;
-    LDW_HIP(hipMemsetAsync(c->red_meta.p, 0, nr * 4, c->stream));
-    LDW_HIP(hipMemsetAsync(c->red_srp.p, 0, nr * 8, c->stream));
+    if (meta && n_red > 0) LDW_HIP(hipMemcpyAsync(c->red_meta.p, meta, (size_t)n_red * 4, hipMemcpyHostToDevice, c->stream));
+    else LDW_HIP(hipMemsetAsync(c->red_meta.p, 0, nr * 4, c->stream));
+    if (srp && n_red > 0) LDW_HIP(hipMemcpyAsync(c->red_srp.p, srp, (size_t)n_red * 8, hipMemcpyHostToDevice, c->stream));
+    else LDW_HIP(hipMemsetAsync(c->red_srp.p, 0, nr * 8, c->stream));
     if (n_red > 0) {
         hipLaunchKernelGGL(k_iota64, dim3((unsigned)((n_red + 255) / 256)), dim3(256), 0, c->stream, c->red_row.as<int64_t>(), n_red);
         LDW_HIP(hipGetLastError());
@@ -1492,9 +1502,6 @@ int ldw_sr_reduced_import(ldw_ctx *c, int64_t n_red, const int32_t *a, const int
     return LDW_OK;
 }
 
-}  // extern "C"
-
-namespace ldw {
 void warm_srp() {   // ldw_ctx_reserve: load this translation unit's code object ahead of its first launch
     hipFuncAttributes a;
     (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_sr_tag));

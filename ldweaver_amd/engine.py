@@ -314,14 +314,16 @@ class Engine:
 
     @staticmethod
     def mi_all_pairs_multi(engines, blocks, sr_dist=20000.0, lr_retain_links=1e6, lr_links_approx=1.0, sr_only=False,
-                           quirk=L.QUIRK_REFERENCE, keep_sr=True):
+                           quirk=L.QUIRK_REFERENCE, keep_sr=True, sr_rows_stay=False):
         """The block loop over several engines of THIS process, one per GPU (ldw_mi_all_pairs_multi): every engine must hold the same
         alignment, weights and SNP meta data; the blocks are dealt by cost, each engine runs its share on a worker thread inside the
         library, and engines[0] ends up with the assembled tables in make_blocks order (and the block statistics of all blocks) — exactly
-        as if it had run every block itself.  Returns dict(owner=int32[nblocks], pass_ms, gather_ms, per_engine_ms)."""
+        as if it had run every block itself.  Returns dict(owner=int32[nblocks], pass_ms, gather_ms, per_engine_ms).
+        ``sr_rows_stay`` (LDW_MI_SR_ROWS_STAY): only the long-range table is assembled; every engine keeps the short-range rows of its own
+        share and ``EngineGroup(engines)`` runs the short-range model over them."""
         bl = L.as_c(blocks, np.int32).reshape(-1, 4)
         p = L.MIParams(float(sr_dist), float(lr_retain_links), float(lr_links_approx), int(bool(sr_only)), int(quirk),
-                       int(bool(keep_sr)), 0)
+                       int(bool(keep_sr)), L.MI_SR_ROWS_STAY if sr_rows_stay else 0)
         arr = (C.c_void_p * len(engines))(*[e._ctx.value for e in engines])
         owner = np.zeros(len(bl), dtype=np.int32)
         ms = np.zeros(10, dtype=np.float64)
@@ -631,3 +633,51 @@ def write_table_tsv(path: str, columns, append: bool = True, nthreads: int = 0) 
     L.check(L.lib().ldw_write_table_tsv(str(path).encode(), int(bool(append)), n, len(cols), L.ptr(kind), C.cast(ptrs, C.c_void_p), int(nthreads),
                                         C.byref(nb)))
     return int(nb.value)
+
+
+
+class EngineGroup:
+    """The short-range model's view of SEVERAL engines of this process after ``Engine.mi_all_pairs_multi(.., sr_rows_stay=True)``: the reductions
+    of ``srp.merge_n_sort_sr_links_device`` run over the engines' own rows inside the library (ldw_sr_len_quantiles_multi / _excess_stats_multi /
+    _pvalues_multi: a worker thread per context), everything after them on engines[0]."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        self._arr = (C.c_void_p * len(self.engines))(*[e._ctx.value for e in self.engines])
+        self.device = self.engines[0].device
+
+    def links_count(self, which: int) -> int:
+        return self.engines[0].links_count(which) if which else sum(e.links_count(0) for e in self.engines)
+
+    def sr_len_quantiles(self, nclust: int, sr_dist: float, prob: float = 0.95):
+        S = int(np.ceil(sr_dist)) - 1
+        qlo = np.empty((nclust, S), dtype=np.float64)
+        qhi = np.empty((nclust, S), dtype=np.float64)
+        n = np.empty((nclust, S), dtype=np.int64)
+        L.check(L.lib().ldw_sr_len_quantiles_multi(self._arr, len(self.engines), int(nclust), float(sr_dist), float(prob), S, L.ptr(qlo), L.ptr(qhi), L.ptr(n)))
+        return qlo, qhi, n
+
+    def sr_excess_stats(self, mean_dist: np.ndarray) -> np.ndarray:
+        md = np.ascontiguousarray(mean_dist, dtype=np.float64)
+        out = np.empty((md.shape[0], 5), dtype=np.float64)
+        L.check(L.lib().ldw_sr_excess_stats_multi(self._arr, len(self.engines), md.shape[0], md.shape[1], L.ptr(md), L.ptr(out)))
+        return out
+
+    def sr_pvalues(self, mean_dist: np.ndarray, shape: np.ndarray, srp_cutoff: float):
+        md = np.ascontiguousarray(mean_dist, dtype=np.float64)
+        sh = np.ascontiguousarray(shape, dtype=np.float64)
+        assert sh.shape == (md.shape[0], 3)
+        nr, npool, mn = C.c_int64(0), C.c_int64(0), C.c_double(0)
+        L.check(L.lib().ldw_sr_pvalues_multi(self._arr, len(self.engines), md.shape[0], md.shape[1], L.ptr(md), L.ptr(sh), float(srp_cutoff),
+                                             C.byref(nr), C.byref(npool), C.byref(mn)))
+        self.engines[0]._n_red, self.engines[0]._n_pool = nr.value, npool.value
+        return nr.value, npool.value, mn.value
+
+    def sr_reduced(self):
+        return self.engines[0].sr_reduced()
+
+    def sr_pool(self):
+        return self.engines[0].sr_pool()
+
+    def aracne_device(self):
+        return self.engines[0].aracne_device()

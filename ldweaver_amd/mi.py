@@ -248,7 +248,7 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
     inproc = engines is not None and len(engines) > 1 and not perform_SR_analysis_only
     stages = {"lr_links_approx_s": time.time() - t000}
     lr_stream, streamed = False, None
-    dist_tail = None
+    dist_tail, inproc_rows_stay = None, False
     try:
         def setup():
             for e in (engines if inproc else [eng]):
@@ -319,7 +319,10 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
             lr_stream = stream_lr and not inproc and not perform_SR_analysis_only
             t_s = time.time()
             if inproc:
-                stages["inproc"] = Engine.mi_all_pairs_multi(engines, blocks, **kw)
+                if sr_tail not in ("gather", "dist"):
+                    raise ValueError("sr_tail must be 'gather' or 'dist'")
+                inproc_rows_stay = sr_tail == "dist" and sr_model == "device"
+                stages["inproc"] = Engine.mi_all_pairs_multi(engines, blocks, sr_rows_stay=inproc_rows_stay, **kw)
                 stages["inproc"]["owner"] = stages["inproc"]["owner"].tolist()
                 stats = eng.block_stats()
             else:
@@ -353,6 +356,15 @@ def perform_MI_computation(snp_dat: SnpDat, hdw, cds_var: CdsVar, ncores: int = 
             fit_data = model_aux["fit_data"]
             sa, sb, smi = redd["a"], redd["b"], redd["MI"]
             stages["sr_tail_bytes_sent"] = model_aux["bytes_sent"]
+        elif sr_model == "device" and inproc_rows_stay:
+            # r05: the short-range rows stayed on the engines that computed them; the model's reductions run over them inside the library
+            from .engine import EngineGroup
+            grp = EngineGroup(engines)
+            redd, flags, model_aux = merge_n_sort_sr_links_device(grp, cds_var.nclust, sr_dist, srp_cutoff, POS, paint, g,
+                                                                  run_aracne=runARACNE, order_links=order_links)
+            pool = grp.sr_pool() if return_aux else None
+            fit_data = model_aux["fit_data"]
+            sa, sb, smi = redd["a"], redd["b"], redd["MI"]
         elif sr_model == "device":
             # mergeNsort_sr_links + runARACNE on the device-resident table; only the kept links come back
             redd, flags, model_aux = merge_n_sort_sr_links_device(eng, cds_var.nclust, sr_dist, srp_cutoff, POS, paint, g,

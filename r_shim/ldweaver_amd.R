@@ -15,6 +15,9 @@
 # r05: options(ldwamd.devices = 0:7) -> one context per GPU of the node; the block loop (R/computePairwiseMI.R:103-116) and the
 # sequence x sequence comparison of the Hamming weights are then shared over them INSIDE the library (ldw_mi_all_pairs_multi,
 # ldw_hamming_weights_multi: worker threads, peer-to-peer gather into device ldwamd.devices[1]); results do not depend on it.
+# options(ldwamd.sr_rows_stay = TRUE) (with several devices): the short-range rows — 99 % of the links — are NOT gathered; every device keeps
+# the rows it computed, perform_MI_computation takes mergeNsort_sr_links_device below and the library runs the model's reductions over the
+# devices (ldw_sr_len_quantiles_multi / _excess_stats_multi / _pvalues_multi); same sr_links.tsv.
 .ldwamd_devices_set <- NULL
 .ldwamd_use_devices <- function() {
   devs <- as.integer(getOption("ldwamd.devices", 0L))
@@ -22,6 +25,7 @@
     .Call("ldwamd_set_devices", devs)
     .ldwamd_devices_set <<- devs
   }
+  .Call("ldwamd_set_sr_rows_stay", isTRUE(getOption("ldwamd.sr_rows_stay", FALSE)) && length(devs) > 1)
   invisible(devs)
 }
 
@@ -83,6 +87,15 @@ perform_MI_computation <- function(snp.dat, hdw, cds_var, ncores, lr_save_path =
       native_lr <- TRUE
       on.exit(if (native_lr) try(.Call("ldwamd_write_links_tsv_end"), silent = TRUE), add = TRUE)   # (an error below must not leave the writer unjoined)
     } else write.table(to_df(res[[2]]), file = lr_save_path, append = T, quote = F, row.names = F, col.names = F, sep = "\t")
+  }
+  rows_stay <- isTRUE(getOption("ldwamd.sr_rows_stay", FALSE)) && length(getOption("ldwamd.devices", 0L)) > 1 && !perform_SR_analysis_only
+  if (rows_stay) {   # r05: the table is spread over the devices and never comes into R: the model and ARACNE run where the rows lie
+    sr_links_red <- mergeNsort_sr_links_device(snp.dat, cds_var, sr_dist, srp_cutoff, runARACNE, plt_folder)
+    if (native_lr) { .Call("ldwamd_write_links_tsv_end"); native_lr <- FALSE }
+    if (!runARACNE) warning("ARACNE not run, all values will be set to 1")
+    if (order_links) { sr_links_red <- sr_links_red[order(sr_links_red$srp_max, decreasing = T), ]; rownames(sr_links_red) <- NULL }
+    write.table(x = sr_links_red, file = sr_save_path, append = T, quote = F, row.names = F, col.names = F, sep = "\t")
+    return(sr_links_red)
   }
   sr <- to_df(res[[1]])
   sr_links <- lapply(1:cds_var$nclust, function(i) sr[sr$clust1 == i | sr$clust2 == i, ])

@@ -19,6 +19,7 @@
 #define LDWAMD_MAX_DEV 64
 static ldw_ctx *g_ctxs[LDWAMD_MAX_DEV];
 static int g_nctx = 0;
+static int g_rows_stay = 0;   /* options(ldwamd.sr_rows_stay): see ldwamd_mi_all_pairs */
 #define g_ctx (g_ctxs[0])
 
 static ldw_ctx *ctx_or_stop(void) {
@@ -95,6 +96,11 @@ SEXP ldwamd_set_snp_meta(SEXP r, SEXP uqe, SEXP POS, SEXP paint, SEXP g) {
     return R_NilValue;
 }
 
+SEXP ldwamd_set_sr_rows_stay(SEXP on) {
+    g_rows_stay = asLogical(on) == TRUE;
+    return ScalarLogical(g_rows_stay);
+}
+
 /* blocks: INTSXP 4 x nb (column-major == [nb][4] row-major); returns list(sr = list(a, b, MI), lr = ..., stats) */
 SEXP ldwamd_mi_all_pairs(SEXP blocks, SEXP sr_dist, SEXP lr_retain, SEXP lr_approx, SEXP sr_only, SEXP quirk) {
     ldw_ctx *c = ctx_or_stop();
@@ -108,16 +114,21 @@ SEXP ldwamd_mi_all_pairs(SEXP blocks, SEXP sr_dist, SEXP lr_retain, SEXP lr_appr
     p.quirk_mode = asInteger(quirk);
     p.keep_sr = 1;
     /* r05: the block loop of R/computePairwiseMI.R:103-116 over every device of options(ldwamd.devices): dealt, run and gathered into
-     * context 0 inside the library; what follows reads context 0 exactly as after a single-device pass */
+     * context 0 inside the library; what follows reads context 0 exactly as after a single-device pass.  options(ldwamd.sr_rows_stay = TRUE):
+     * only the long-range table is gathered, every device keeps the short-range rows it computed (the returned sr list is EMPTY) and
+     * mergeNsort_sr_links_device runs the model over the devices (ldw_sr_*_multi) */
+    const int rows_stay = g_rows_stay && g_nctx > 1 && !p.sr_only;
+    if (rows_stay) p.flags |= LDW_MI_SR_ROWS_STAY;
     if (g_nctx > 1) CHK(ldw_mi_all_pairs_multi(g_ctxs, g_nctx, INTEGER(blocks), nb, &p, NULL, NULL));
     else CHK(ldw_mi_all_pairs(c, INTEGER(blocks), nb, &p, 1));
     SEXP res = PROTECT(allocVector(VECSXP, 3));
     for (int which = 0; which < 2; ++which) {
         int64_t n = 0;
         CHK(ldw_links_count(c, which, &n));
+        if (which == 0 && rows_stay) n = 0;   /* (context 0 holds its own share only: nothing of it goes to R) */
         SEXP a = PROTECT(allocVector(INTSXP, (R_xlen_t)n)), b = PROTECT(allocVector(INTSXP, (R_xlen_t)n));
         SEXP mi = PROTECT(allocVector(REALSXP, (R_xlen_t)n));
-        CHK(ldw_links_fetch(c, which, INTEGER(a), INTEGER(b), REAL(mi), n, 0));
+        if (n > 0) CHK(ldw_links_fetch(c, which, INTEGER(a), INTEGER(b), REAL(mi), n, 0));
         SEXP t = PROTECT(allocVector(VECSXP, 3));
         SET_VECTOR_ELT(t, 0, a); SET_VECTOR_ELT(t, 1, b); SET_VECTOR_ELT(t, 2, mi);
         SET_VECTOR_ELT(res, which, t);
@@ -150,7 +161,8 @@ SEXP ldwamd_sr_len_quantiles(SEXP nclust, SEXP sr_dist, SEXP prob) {
     SEXP res = PROTECT(allocVector(VECSXP, 3));
     SEXP lo = PROTECT(allocVector(REALSXP, (R_xlen_t)nc * S)), hi = PROTECT(allocVector(REALSXP, (R_xlen_t)nc * S));
     int64_t *n = (int64_t *)R_alloc((size_t)nc * S, sizeof(int64_t));
-    CHK(ldw_sr_len_quantiles(c, nc, asReal(sr_dist), asReal(prob), S, REAL(lo), REAL(hi), n));
+    (void)c;   /* (the _multi forms are the one-table calls on context 0 unless the last pass left the rows on their devices) */
+    CHK(ldw_sr_len_quantiles_multi(g_ctxs, g_nctx, nc, asReal(sr_dist), asReal(prob), S, REAL(lo), REAL(hi), n));
     SEXP nn = PROTECT(allocVector(REALSXP, (R_xlen_t)nc * S));
     for (R_xlen_t i = 0; i < (R_xlen_t)nc * S; ++i) REAL(nn)[i] = (double)n[i];
     SET_VECTOR_ELT(res, 0, lo); SET_VECTOR_ELT(res, 1, hi); SET_VECTOR_ELT(res, 2, nn);
@@ -163,7 +175,8 @@ SEXP ldwamd_sr_excess_stats(SEXP nclust, SEXP mean_dist) {
     ldw_ctx *c = ctx_or_stop();
     const int nc = asInteger(nclust);
     SEXP out = PROTECT(allocVector(REALSXP, (R_xlen_t)nc * 5));
-    CHK(ldw_sr_excess_stats(c, nc, (int32_t)(XLENGTH(mean_dist) / nc), REAL(mean_dist), REAL(out)));
+    (void)c;
+    CHK(ldw_sr_excess_stats_multi(g_ctxs, g_nctx, nc, (int32_t)(XLENGTH(mean_dist) / nc), REAL(mean_dist), REAL(out)));
     UNPROTECT(1);
     return out;
 }
@@ -175,7 +188,7 @@ SEXP ldwamd_sr_pvalues_aracne(SEXP nclust, SEXP mean_dist, SEXP shape, SEXP srp_
     const int nc = asInteger(nclust);
     int64_t n_red = 0, n_pool = 0;
     double min_mi = 0;
-    CHK(ldw_sr_pvalues(c, nc, (int32_t)(XLENGTH(mean_dist) / nc), REAL(mean_dist), REAL(shape), asReal(srp_cutoff), &n_red, &n_pool, &min_mi));
+    CHK(ldw_sr_pvalues_multi(g_ctxs, g_nctx, nc, (int32_t)(XLENGTH(mean_dist) / nc), REAL(mean_dist), REAL(shape), asReal(srp_cutoff), &n_red, &n_pool, &min_mi));
     const R_xlen_t n = (R_xlen_t)n_red;
     SEXP res = PROTECT(allocVector(VECSXP, 9));
     SEXP row = PROTECT(allocVector(REALSXP, n)), a = PROTECT(allocVector(INTSXP, n)), b = PROTECT(allocVector(INTSXP, n));
@@ -379,6 +392,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_LDWeaver_fast_intersect", (DL_FUNC)&_LDWeaver_fast_intersect, 2},
     {"ldwamd_lr_tukey_aracne", (DL_FUNC)&ldwamd_lr_tukey_aracne, 4},
     {"ldwamd_ldmap", (DL_FUNC)&ldwamd_ldmap, 3},
+    {"ldwamd_set_sr_rows_stay", (DL_FUNC)&ldwamd_set_sr_rows_stay, 1},
     {"ldwamd_sr_len_quantiles", (DL_FUNC)&ldwamd_sr_len_quantiles, 3},
     {"ldwamd_sr_excess_stats", (DL_FUNC)&ldwamd_sr_excess_stats, 2},
     {"ldwamd_sr_pvalues_aracne", (DL_FUNC)&ldwamd_sr_pvalues_aracne, 5},

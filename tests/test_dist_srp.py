@@ -414,6 +414,45 @@ def test_sr_model_over_ranks_equals_one_table(tmp_path):
         for k in ("a", "b", "MI", "clust_c", "row", "srp_max", "first_clust", "dup"):
             assert np.array_equal(redd[k], one[0][k]), k
         assert np.array_equal(flags, one[1]) and np.array_equal(aux["shape"], one[2]["shape"]) and np.array_equal(aux["stats"], one[2]["stats"])
+
+        # (v) the same inside the library: ldw_mi_all_pairs_multi(.., LDW_MI_SR_ROWS_STAY) leaves every context its own short-range rows and
+        # ldw_sr_len_quantiles_multi / _excess_stats_multi / _pvalues_multi run the protocol over the contexts (worker threads, host-staged
+        # exchanges) behind the one-table signatures — what a single-process host (R) calls
+        from ldweaver_amd.engine import EngineGroup
+        lr_one = engs[0].links(1)
+        for n in (1, 2, 3):
+            for e in engs:
+                e.reset_speculation()
+            info = Engine.mi_all_pairs_multi(engs[:n], blocks, sr_rows_stay=True, **kw)
+            for u, v in zip(lr_one, engs[0].links(1)):
+                assert np.array_equal(u, v), n
+            assert np.array_equal(engs[0].block_stats()["n_sr"], n_sr_blocks)
+            if n > 1:
+                assert engs[0].links_count(0) == int(n_sr_blocks[info["owner"] == 0].sum()) < int(n_sr_blocks.sum())   # its own share only
+            grp = EngineGroup(engs[:n])
+            redd, flags, aux = srp_host.merge_n_sort_sr_links_device(grp, nclust, 20000.0, cut, POS, paint, g, run_aracne=True, order_links=True)
+            for k in ("a", "b", "MI", "clust_c", "srp_max", "first_clust", "dup"):
+                assert np.array_equal(redd[k], one[0][k]), (n, k)
+            assert np.array_equal(flags, one[1]) and np.array_equal(aux["shape"], one[2]["shape"]) and np.array_equal(aux["stats"], one[2]["stats"]), n
+            assert np.array_equal(aux["mean_dist"], one[2]["mean_dist"], equal_nan=True)
+            pa, pb, pm = grp.sr_pool()
+            assert len(pm) == one[2]["n_pool"]
+        # a group that does not belong to the last multi call is refused
+        Engine.mi_all_pairs_multi(engs[:2], blocks, sr_rows_stay=True, **kw)
+        with pytest.raises(Exception, match="short-range rows|contexts given"):
+            EngineGroup([engs[0], engs[2]]).sr_len_quantiles(nclust, 20000.0)
+        # perform_MI_computation(engines=[...], sr_tail="dist") == the single-engine job, both files byte for byte
+        from ldweaver_amd.snpdat import CdsVar, SnpDat
+        sd = SnpDat(states=syn["states"], POS=POS, g=g, uqe=uqe, r=r)
+        cv = CdsVar(paint=paint, nclust=nclust)
+        outs = {}
+        for tag, kws in (("one", dict(engine=engs[0])), ("three", dict(engines=engs, sr_tail="dist"))):
+            d = tmp_path / tag
+            d.mkdir()
+            outs[tag] = MIH.perform_MI_computation(sd, hdw, cv, lr_save_path=str(d / "lr.tsv"), sr_save_path=str(d / "sr.tsv"), plt_folder=str(d / "P"),
+                                                   max_blk_sz=B, lr_retain_links=2e5, verbose=False, alignment_resident=True, srp_cutoff=cut, **kws)
+        assert (tmp_path / "one" / "lr.tsv").read_bytes() == (tmp_path / "three" / "lr.tsv").read_bytes()
+        assert (tmp_path / "one" / "sr.tsv").read_bytes() == (tmp_path / "three" / "sr.tsv").read_bytes() and len(outs["one"]) == len(outs["three"]) > 500
     finally:
         for e in engs:
             e.close()
