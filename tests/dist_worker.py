@@ -2,7 +2,7 @@
 rank of a torch.distributed (gloo) run of perform_MI_computation, every rank with its own engine (on the one GPU of the test
 box).  Rank 0 writes the files.
 
-    dist_worker.py OUTDIR [full | sr_only | fail | rows_stay]      (rows_stay: sr_tail="dist", the short-range rows are not gathered)
+    dist_worker.py OUTDIR [full | sr_only | fail | rows_stay | sr_only_rows_stay]      (rows_stay: sr_tail="dist", the short-range rows are not gathered)
 """
 import os
 import sys
@@ -44,9 +44,9 @@ def main():
         red = MIH.perform_MI_computation(sd, o["hdw"], CdsVar(paint=o["paint"], nclust=3), ncores=1,
                                          lr_save_path=os.path.join(outdir, "lr_links.tsv"), sr_save_path=os.path.join(outdir, "sr_links.tsv"),
                                          plt_folder=os.path.join(outdir, "PLOTS"), max_blk_sz=1000, lr_retain_links=1e5, engine=eng,
-                                         perform_SR_analysis_only=(mode == "sr_only"), sr_dist=(3000 if mode == "sr_only" else 20000),
+                                         perform_SR_analysis_only=("sr_only" in mode), sr_dist=(3000 if "sr_only" in mode else 20000),
                                          verbose=False, quirk_mode=1,   # LDW_QUIRK_INTENDED, like the single-process run of the test
-                                         sr_tail=("dist" if mode == "rows_stay" else "gather"))
+                                         sr_tail=("dist" if "rows_stay" in mode else "gather"))
     if dist.get_rank() == 0:
         assert red is not None
         red.to_pickle(os.path.join(outdir, "red.pkl"))

@@ -1121,6 +1121,14 @@ def test_sr_only_two_ranks(engine, sample, tmp_path):
     assert not (one / "lr_links.tsv").exists() and not (two / "lr_links.tsv").exists()
     assert (one / "sr_links.tsv").read_bytes() == (two / "sr_links.tsv").read_bytes()
     _frames_equal(red1, pd.read_pickle(two / "red.pkl"))
+    # r05: ... and with the rows left on their ranks (filtered site lists per block: the model over ranks only needs every block's row count)
+    three = tmp_path / "three"
+    three.mkdir()
+    r = _torchrun(2, 29539, "dist_worker.py", three, "sr_only_rows_stay")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert not (three / "lr_links.tsv").exists()
+    assert (one / "sr_links.tsv").read_bytes() == (three / "sr_links.tsv").read_bytes()
+    _frames_equal(red1, pd.read_pickle(three / "red.pkl"))
 
 
 def test_failing_rank_is_agreed_on(tmp_path):
