@@ -85,6 +85,8 @@ def parse():
     ap.add_argument("--inproc-devices", default="", help="comma-separated device ids for --inproc (default 0..gpus-1; '0,0' = two contexts on one GPU)")
     ap.add_argument("--no-sr-tail-leg", action="store_true", help="N > 1: skip the leg that runs the short-range model + ARACNE behind the pass both ways "
                     "(table gathered to rank 0 / rows left on their ranks: ldweaver_amd/dist_srp.py)")
+    ap.add_argument("--sr-tail-leg", action="store_true", help="N > 1 with backend nccl: run that leg too.  It runs by default under gloo (the rehearsal) and with --inproc; under "
+                    "RCCL it is opt-in: its exchanges have only ever run on ONE GPU (tests/rccl_worker.py), and a hang there would take the line of the timed region with it")
     ap.add_argument("--sustain-s", type=float, default=10.0, help="N = 1: keep stepping after the timed region until this many seconds of steps have run")
     return ap.parse_args()
 
@@ -619,7 +621,7 @@ def main():
         dist.all_gather_object(per_rank, mine_rec)
 
     sr_tail = None
-    if world > 1 and not args.no_extra_legs and not args.no_sr_tail_leg and args.engine == "mfma":
+    if world > 1 and not args.no_extra_legs and not args.no_sr_tail_leg and args.engine == "mfma" and (args.backend == "gloo" or args.sr_tail_leg):
         sr_tail = sr_tail_leg(eng, blocks, mine, sr_dist, lr_retain, approx, POS, paint, g, dev, rank, world, fence)
 
     extra = rank == 0 and world == 1 and len(my_blocks) and not args.no_extra_legs
@@ -857,6 +859,9 @@ def main():
             out["per_rank"] = per_rank
         if sr_tail is not None:
             out["sr_tail"] = sr_tail
+        elif world > 1:
+            out["sr_tail"] = dict(note="not run on this line (backend nccl: opt-in with --sr-tail-leg).  The short-range model over ranks (ldweaver_amd/dist_srp.py) is UNMEASURED ON "
+                                       "HARDWARE; profiles/r05_bench_4rank_gloo.json holds the 4-rank rehearsal on one GPU (215 -> 28 MB sent per peer, same kept links)")
         out.update(stages_ms_per_step={k: v / max(1, n_replay) for k, v in tim.items()},
                    stages_ms_per_step_overlapped={k: v / K for k, v in tim_overlapped.items()},
                    links=links_timed, counters=counters_timed, counters_replay=cnt_replay, hamming_weights_s=hamming_s,
