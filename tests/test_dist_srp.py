@@ -349,6 +349,26 @@ def test_sr_model_over_ranks_equals_one_table(tmp_path):
         np.testing.assert_allclose(per_block.sum(axis=0), engs[0].sr_excess_stats(md), rtol=1e-12)
         with pytest.raises(Exception, match="rows"):
             engs[0].sr_excess_stats_blocks(md, n_sr_blocks[:-1])
+        # six clusters: the kernels for any cluster count (k_sr_stats per block, k_sr_tail, the merge) on the same table under another paint
+        paint6 = ((paint - 1) * 2 + (np.arange(Ls) // 7) % 2 + 1).astype(paint.dtype)
+        engs[0].set_snp_meta(r, uqe, POS, paint6, g)
+        ref6 = NumpyRank(a, b, mi, POS, paint6, g)
+        q6 = engs[0].sr_len_quantiles(6, 20000.0, 0.95)
+        r6 = ref6.sr_len_quantiles(6, 20000.0, 0.95)
+        for u, v in zip(q6, r6):
+            assert np.array_equal(u, v, equal_nan=True)
+        md6 = np.full((6, 19999), np.nan)
+        md6[:, :3000] = 0.05 * np.arange(1, 3001, dtype=float) ** -0.4
+        pb6, want6 = engs[0].sr_excess_stats_blocks(md6, n_sr_blocks), ref6.sr_excess_stats_blocks(md6, n_sr_blocks)
+        np.testing.assert_allclose(pb6, want6, rtol=1e-11, atol=1e-300)
+        assert np.array_equal(pb6[:, :, 0], want6[:, :, 0]) and pb6[:, 3:, 0].sum() > 0
+        lo6 = np.where(q6[2] > 0, q6[0], np.nan)
+        c6, m6 = engs[0].sr_tail_extract(lo6)
+        rc6, rm6 = ref6.sr_tail_extract(lo6)
+        assert np.array_equal(c6, rc6) and np.array_equal(np.sort(m6), np.sort(rm6))
+        g6 = engs[1].sr_quantiles_merge(0.95, [c6], [m6], q6[2])
+        assert g6[2] == 0 and np.array_equal(g6[0], q6[0], equal_nan=True) and np.array_equal(g6[1], q6[1], equal_nan=True)
+        engs[0].set_snp_meta(r, uqe, POS, paint, g)
 
         # (ii) the model over ranks
         def run(world):
