@@ -388,26 +388,58 @@ int ldw_sr_len_quantiles_multi(ldw_ctx **ctx, int n_ctx, int nclust, double sr_d
             total[i] += cnt[(size_t)k][i];
             if (cnt[(size_t)k][i] > 0 && !(lower[i] <= qlo[(size_t)k][i])) lower[i] = qlo[(size_t)k][i];   // (NaN-safe minimum)
         }
-    // 3) every context's rows at or above it (values only, grouped len-major), through host memory
+    // 3) every context's rows at or above it (values only, grouped len-major): extracted into a buffer on ITS device, then device to device into one buffer on
+    //    context 0's (peer copies queued on the source's stream, as the link-table gather does) — at config 5 the candidates are 1.4 GB: through pageable host
+    //    vectors (the first version) that was most of the call
     std::vector<std::vector<int64_t>> tcnt((size_t)n_ctx, std::vector<int64_t>(G));
-    std::vector<std::vector<double>> tmi((size_t)n_ctx);
+    std::vector<int64_t> tn((size_t)n_ctx, 0);
     if (int rc = for_each_ctx(ctx, n_ctx, "ldw_sr_len_quantiles_multi", [&](int k) {
             int64_t n = 0;
             if (int r = ldw_sr_tail_extract(ctx[k], nclust, S, lower.data(), tcnt[(size_t)k].data(), nullptr, 0, 0, &n)) return r;
-            tmi[(size_t)k].resize((size_t)std::max<int64_t>(n, 1));
+            tn[(size_t)k] = n;
             if (n == 0) return (int)LDW_OK;
-            return ldw_sr_tail_extract(ctx[k], nclust, S, lower.data(), tcnt[(size_t)k].data(), tmi[(size_t)k].data(), n, 0, &n);
+            if (int r = ctx[k]->srd_out.reserve((size_t)n * 8)) return r;
+            return ldw_sr_tail_extract(ctx[k], nclust, S, lower.data(), tcnt[(size_t)k].data(), ctx[k]->srd_out.as<double>(), n, 1, &n);
         }))
         return rc;
-    // 4) context 0 selects by rank from the top
+    ldw_ctx *c0 = ctx[0];
+    int64_t others = 0;
+    for (int k = 1; k < n_ctx; ++k) others += tn[(size_t)k];
+    ldw::DevBuf stage;   // the other contexts' candidates on context 0's device
+    struct Rel {
+        ldw::DevBuf &b;
+        ~Rel() { b.release(); }
+    } rel{stage};
+    LDW_HIP(hipSetDevice(c0->device));
+    if (int rc = stage.reserve((size_t)std::max<int64_t>(others, 1) * 8)) return rc;
+    LDW_HIP(hipStreamSynchronize(c0->stream));   // (the fresh buffer is visible to every queue before a peer writes into it)
     std::vector<const double *> pm((size_t)n_ctx);
     std::vector<const int64_t *> pc((size_t)n_ctx);
-    for (int k = 0; k < n_ctx; ++k) {
-        pm[(size_t)k] = tmi[(size_t)k].data();
-        pc[(size_t)k] = tcnt[(size_t)k].data();
+    {
+        int64_t off = 0;
+        hipError_t he = hipSuccess;
+        pm[0] = c0->srd_out.as<double>();
+        pc[0] = tcnt[0].data();
+        for (int k = 1; k < n_ctx && he == hipSuccess; ++k) {
+            pm[(size_t)k] = stage.as<double>() + off;
+            pc[(size_t)k] = tcnt[(size_t)k].data();
+            if (tn[(size_t)k] == 0) continue;
+            if (hipSetDevice(ctx[k]->device) != hipSuccess) {
+                he = hipErrorInvalidDevice;
+                break;
+            }
+            he = copy_rows(stage.as<double>() + off, c0, ctx[k]->srd_out.p, ctx[k], (size_t)tn[(size_t)k] * 8);
+            off += tn[(size_t)k];
+        }
+        for (int k = 1; k < n_ctx; ++k)   // every source's copy has landed
+            if (hipSetDevice(ctx[k]->device) != hipSuccess || hipStreamSynchronize(ctx[k]->stream) != hipSuccess) {
+                if (he == hipSuccess) he = hipGetLastError();
+            }
+        (void)hipSetDevice(c0->device);
+        if (he != hipSuccess) return ldw::hip_fail(he, "peer copy of the quantile candidates", __FILE__, __LINE__);
     }
-    LDW_HIP(hipSetDevice(ctx[0]->device));
-    if (int rc = ldw_sr_quantiles_merge(ctx[0], nclust, S, prob, n_ctx, pm.data(), pc.data(), total.data(), 0, q_lo_out, q_hi_out, nullptr)) return rc;
+    // 4) context 0 selects by rank from the top
+    if (int rc = ldw_sr_quantiles_merge(c0, nclust, S, prob, n_ctx, pm.data(), pc.data(), total.data(), 1, q_lo_out, q_hi_out, nullptr)) return rc;
     memcpy(n_out, total.data(), G * 8);
     return LDW_OK;
 }

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""The short-range model with the rows left on their contexts at the CONFIG-5 shape (500k SNPs x 10k sequences, 2.25e9 short-range rows),
+two contexts on one GPU (ldw_mi_all_pairs_multi with LDW_MI_SR_ROWS_STAY, then ldw_sr_*_multi), against the same job on one context
+with the whole table: kept links, srp and ARACNE flags must be equal bit for bit.  Prints free device memory at every stage.
+
+    python tools/c5_rows_stay_probe.py [--L 500000 --N 10000]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ldweaver_amd.cpushare import limit_thread_pools  # noqa: E402
+
+limit_thread_pools()
+import torch  # noqa: E402
+
+from ldweaver_amd.engine import Engine, EngineGroup  # noqa: E402
+from ldweaver_amd.mi import lr_links_approx, make_blocks  # noqa: E402
+from ldweaver_amd.srp import merge_n_sort_sr_links_device  # noqa: E402
+from ldweaver_amd.synth import synth_alignment  # noqa: E402
+
+
+def free_gb():
+    f, t = torch.cuda.mem_get_info(0)
+    return round(f / 1e9, 1)
+
+
+def digest(red, flags):
+    return dict(rows=int(len(red["MI"])), aracne_true=int(np.sum(flags)), mi_sum=float(np.sum(red["MI"])), srp_sum=float(np.sum(red["srp_max"])),
+                a_sum=int(np.sum(red["a"].astype(np.int64))), first=[int(red["a"][0]), int(red["b"][0])] if len(red["MI"]) else None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--L", type=int, default=500000)
+    ap.add_argument("--N", type=int, default=10000)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    L, N = a.L, a.N
+    say = lambda *x: print(*x, flush=True)
+    syn = synth_alignment(L, N, seed=1988, device="cuda", as_numpy=False)
+    engs = [Engine(0), Engine(0)]
+    for e in engs:
+        e.set_alignment(syn["states"])
+    del syn["states"]
+    torch.cuda.empty_cache()
+    cnt = engs[0].state_counts()
+    uqe = (cnt > 0).T.astype(np.float64)
+    POS, paint, g = syn["POS"], syn["paint"], float(syn["g"])
+    blocks = make_blocks(L, 10000)
+    hdw = Engine.hamming_weights_multi(engs, int(L * 0.1))
+    for e in engs:
+        e.set_weights(hdw)
+        e.set_snp_meta(uqe.sum(1), uqe, POS, paint, g)
+    approx = lr_links_approx(POS, g, 20000.0)
+    nclust = int(np.max(paint))
+    say(f"[probe] {L} x {N}, {len(blocks)} blocks; free device memory {free_gb()} GB")
+    out = dict(workload=f"synthetic {L} SNPs x {N} seqs, seed 1988, two contexts on ONE GPU")
+    # ---- the rows stay ----
+    t0 = time.perf_counter()
+    info = Engine.mi_all_pairs_multi(engs, blocks, 20000.0, 1e6, approx, sr_rows_stay=True)
+    t1 = time.perf_counter()
+    rows = [e.links_count(0) for e in engs]
+    say(f"[probe] pass {1e3 * (t1 - t0):.0f} ms (gather of the long-range table {info['gather_ms']:.1f} ms); short-range rows per context {rows}; free {free_gb()} GB")
+    grp = EngineGroup(engs)
+    red, flags, aux = merge_n_sort_sr_links_device(grp, nclust, 20000.0, 3.0, POS, paint, g, run_aracne=True, order_links=True)
+    t2 = time.perf_counter()
+    d_stay = digest(red, flags)
+    say(f"[probe] model + ARACNE over the contexts {1e3 * (t2 - t1):.0f} ms; free {free_gb()} GB; {d_stay}")
+    out["rows_stay"] = dict(pass_ms=1e3 * (t1 - t0), lr_gather_ms=info["gather_ms"], model_aracne_ms=1e3 * (t2 - t1), sr_rows_per_context=rows, kept=d_stay)
+    del red, flags
+    # ---- one context, the whole table ----
+    engs[1].close()
+    torch.cuda.empty_cache()
+    e = engs[0]
+    e.reset_speculation()
+    t0 = time.perf_counter()
+    e.mi_all_pairs(blocks, 20000.0, 1e6, approx)
+    t1 = time.perf_counter()
+    say(f"[probe] one context: pass {1e3 * (t1 - t0):.0f} ms, {e.links_count(0)} short-range rows; free {free_gb()} GB")
+    red, flags, aux1 = merge_n_sort_sr_links_device(e, nclust, 20000.0, 3.0, POS, paint, g, run_aracne=True, order_links=True, block_rows=e.block_stats()["n_sr"])
+    t2 = time.perf_counter()
+    d_one = digest(red, flags)
+    say(f"[probe] one context: model + ARACNE {1e3 * (t2 - t1):.0f} ms; {d_one}")
+    out["one_table"] = dict(pass_ms=1e3 * (t1 - t0), model_aracne_ms=1e3 * (t2 - t1), sr_rows=e.links_count(0), kept=d_one)
+    out["kept_links_equal"] = d_stay == d_one
+    out["shapes_equal"] = bool(np.array_equal(aux["shape"], aux1["shape"]) and np.array_equal(aux["mean_dist"], aux1["mean_dist"], equal_nan=True))
+    say(json.dumps(out))
+    if a.out:
+        with open(a.out, "w") as fh:
+            fh.write(json.dumps(out) + "\n")
+    e.close()
+    return 0 if out["kept_links_equal"] and out["shapes_equal"] else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
