@@ -125,6 +125,35 @@ class Comm:
         return [b.cpu().numpy().view(arr.dtype) for b in bufs]
 
 
+def _gatherv_device(cm: "Comm", t, dst: int = 0):
+    """Comm.gatherv for ONE-dimensional float64 tensors that already lie on the backend's device (RCCL): no pass through host memory."""
+    import torch
+    import torch.distributed as dist
+    nb = np.zeros(cm.world, dtype=np.int64)
+    nb[cm.rank] = t.numel()
+    nb = cm.all_reduce(nb, "sum")
+    torch.cuda.current_stream(t.device).synchronize()
+    if cm.world == 1:    # collectives forced on one rank: loop-back
+        buf = torch.empty(int(nb[0]), dtype=t.dtype, device=t.device)
+        if nb[0] > 0:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, 0, cm.group), dist.P2POp(dist.isend, t, 0, cm.group)]):
+                w.wait()
+            torch.cuda.current_stream(t.device).synchronize()
+        cm.bytes_sent += int(nb[0]) * 8
+        return [buf]
+    if cm.rank == dst:
+        bufs = [t if r == dst else torch.empty(int(nb[r]), dtype=t.dtype, device=t.device) for r in range(cm.world)]
+        ops = [dist.P2POp(dist.irecv, bufs[r], r, cm.group) for r in range(cm.world) if r != dst and nb[r] > 0]
+    else:
+        bufs = None
+        ops = [dist.P2POp(dist.isend, t, dst, cm.group)] if nb[cm.rank] > 0 else []
+        cm.bytes_sent += int(nb[cm.rank]) * 8
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    torch.cuda.current_stream(t.device).synchronize()
+    return bufs
+
+
 class ThreadGroup:
     """Ranks that are THREADS of one process, one engine (one GPU) each: the exchanges of ``Comm`` through shared memory.  The library's calls
     release the interpreter lock, so the ranks' kernels run side by side."""
@@ -207,9 +236,17 @@ def merge_n_sort_sr_links_dist(eng, nclust: int, sr_dist: float, srp_cutoff: flo
     n_total = cm.all_reduce(cnt, "sum")
     lower = cm.all_reduce(np.where(cnt > 0, qlo, np.inf), "min")
     lower = np.where(np.isfinite(lower), lower, np.nan)            # groups without a member anywhere: nothing to send
-    tcnt, tmi = eng.sr_tail_extract(lower)
-    took("bounds")
-    cnts, mis = cm.gatherv(tcnt.reshape(-1)), cm.gatherv(tmi)
+    # under RCCL the candidates stay on the device from the extraction to the merge (at config 5 they are 180 MB per rank of eight: through host
+    # memory twice on every rank and once more on rank 0 would be most of the step); gloo and the in-process ranks use host arrays
+    on_dev = (not cm.alone) and cm.dev is not None and cm.dev.type == "cuda" and hasattr(eng, "_ctx")
+    if on_dev:
+        tcnt, tmi = eng.sr_tail_extract(lower, on_device=True)
+        took("bounds")
+        cnts, mis = cm.gatherv(tcnt.reshape(-1)), _gatherv_device(cm, tmi)
+    else:
+        tcnt, tmi = eng.sr_tail_extract(lower)
+        took("bounds")
+        cnts, mis = cm.gatherv(tcnt.reshape(-1)), cm.gatherv(tmi)
     took("candidates")
     md = None
     fit_data = []
@@ -271,7 +308,7 @@ def merge_n_sort_sr_links_dist(eng, nclust: int, sr_dist: float, srp_cutoff: flo
     reds, pools = cm.gatherv(rec), cm.gatherv(prec)
     took("kept_links_and_pool")
     aux = dict(mean_dist=md, shape=shape, stats=stats, min_mi=min_mi if np.isfinite(min_mi) else np.nan, counts=n_total, fit_data=fit_data, bytes_sent=sent,
-               candidates=int(len(tmi)), local_rows=int(rows_mine.sum()))
+               candidates=int(tmi.numel() if hasattr(tmi, "numel") else len(tmi)), local_rows=int(rows_mine.sum()))
     if cm.rank != 0:
         return None, None, aux
     allr, allp = np.concatenate(reds), np.concatenate(pools)

@@ -479,14 +479,22 @@ class Engine:
         L.check(L.lib().ldw_sr_excess_stats_blocks(self._ctx, md.shape[0], md.shape[1], L.ptr(md), len(rows), L.ptr(rows), L.ptr(out)))
         return out
 
-    def sr_tail_extract(self, lower: np.ndarray):
+    def sr_tail_extract(self, lower: np.ndarray, on_device: bool = False):
         """Rows at or above ``lower`` (nclust, S) per (cluster, len): (cnt, mi) with cnt (S, nclust) — len-major — and mi their MI values
-        grouped in that order (host arrays)."""
+        grouped in that order: a host array, or (``on_device``) a torch tensor on this engine's GPU — what an RCCL exchange sends as it is."""
         lo = np.ascontiguousarray(lower, dtype=np.float64)
         nclust, S = lo.shape
         cnt = np.zeros((S, nclust), dtype=np.int64)
         n = C.c_int64(0)
         L.check(L.lib().ldw_sr_tail_extract(self._ctx, nclust, S, L.ptr(lo), L.ptr(cnt), None, 0, 0, C.byref(n)))
+        if on_device:
+            import torch
+            dev = torch.device("cuda", self.device)
+            mi = torch.empty(n.value, dtype=torch.float64, device=dev)
+            if n.value:
+                torch.cuda.synchronize(dev)
+                L.check(L.lib().ldw_sr_tail_extract(self._ctx, nclust, S, L.ptr(lo), L.ptr(cnt), L.ptr(mi), n.value, 1, C.byref(n)))
+            return cnt, mi
         mi = np.empty(n.value, dtype=np.float64)
         if n.value:
             L.check(L.lib().ldw_sr_tail_extract(self._ctx, nclust, S, L.ptr(lo), L.ptr(cnt), L.ptr(mi), n.value, 0, C.byref(n)))
@@ -498,14 +506,22 @@ class Engine:
         nt = np.ascontiguousarray(n_total, dtype=np.int64)
         nclust, S = nt.shape
         cs = [np.ascontiguousarray(c, dtype=np.int64) for c in cnts]
-        ms = [np.ascontiguousarray(m, dtype=np.float64) for m in mis]
-        assert len(cs) == len(ms) >= 1 and all(c.shape == (S, nclust) for c in cs)
-        pm = (C.c_void_p * len(ms))(*[m.ctypes.data if m.size else None for m in ms])
+        assert len(cs) == len(mis) >= 1 and all(c.shape == (S, nclust) for c in cs)
+        on_dev = all(_is_torch(m) and m.is_cuda for m in mis)    # (what sr_tail_extract(.., on_device=True) gave and an RCCL gather delivered)
+        if on_dev:
+            import torch
+            ms = [m.contiguous() for m in mis]
+            assert all(str(m.dtype) == "torch.float64" and m.device.index == self.device for m in ms)
+            torch.cuda.synchronize(ms[0].device)                 # the library reads them on its own stream
+            pm = (C.c_void_p * len(ms))(*[m.data_ptr() if m.numel() else None for m in ms])
+        else:
+            ms = [np.ascontiguousarray(m.cpu().numpy() if _is_torch(m) else m, dtype=np.float64) for m in mis]
+            pm = (C.c_void_p * len(ms))(*[m.ctypes.data if m.size else None for m in ms])
         pc = (C.c_void_p * len(cs))(*[c.ctypes.data for c in cs])
         qlo = np.empty((nclust, S), dtype=np.float64)
         qhi = np.empty((nclust, S), dtype=np.float64)
         viol = C.c_int64(0)
-        L.check(L.lib().ldw_sr_quantiles_merge(self._ctx, nclust, S, float(prob), len(ms), pm, pc, L.ptr(nt), 0, L.ptr(qlo), L.ptr(qhi), C.byref(viol)))
+        L.check(L.lib().ldw_sr_quantiles_merge(self._ctx, nclust, S, float(prob), len(ms), pm, pc, L.ptr(nt), int(on_dev), L.ptr(qlo), L.ptr(qhi), C.byref(viol)))
         return qlo, qhi, int(viol.value)
 
     def sr_pvalues_local(self, mean_dist: np.ndarray, shape: np.ndarray, srp_cutoff: float):
