@@ -302,7 +302,7 @@ def sr_tail_leg(eng, blocks, mine, sr_dist, lr_retain, approx, POS, paint, g, de
     t2 = time.perf_counter()
     sent_b = dict(aux["bytes_sent"], lr_table=int(16 * np.sum(st["n_lr_kept"])) if rank != 0 else 0)
     res["dist"] = dict(pass_and_lr_gather_ms=(t1 - t0) * 1e3, model_aracne_over_ranks_ms=(t2 - t1) * 1e3, total_ms=(t2 - t0) * 1e3)
-    mine_rec = dict(rank=rank, sr_rows=int(np.sum(st["n_sr"])), candidates=int(aux["candidates"]), bytes_sent_gather=sent_a,
+    mine_rec = dict(rank=rank, sr_rows=int(np.sum(st["n_sr"])), candidates=int(aux["candidates"]), bytes_sent_gather=sent_a, dist_ms_by_step={k: round(v, 2) for k, v in aux["ms"].items()},
                     bytes_sent_dist=int(sum(sent_b.values())), bytes_sent_dist_by_exchange=sent_b)
     recs = [None] * world
     dist.all_gather_object(recs, mine_rec)

@@ -223,12 +223,15 @@ def merge_n_sort_sr_links_dist(eng, nclust: int, sr_dist: float, srp_cutoff: flo
     my_blocks = np.asarray(my_blocks, dtype=np.int64)
     n_sr_blocks = np.asarray(n_sr_blocks, dtype=np.int64)
     rows_mine = n_sr_blocks[my_blocks]
-    sent = {}
-    mark = [cm.bytes_sent]
+    import time
+    sent, ms = {}, {}
+    mark = [cm.bytes_sent, time.perf_counter()]
 
-    def took(what):
+    def took(what):   # bytes this rank sent and wall clock since the last mark (local work + the exchange + waiting for the slowest rank)
+        now = time.perf_counter()
         sent[what] = cm.bytes_sent - mark[0]
-        mark[0] = cm.bytes_sent
+        ms[what] = (now - mark[1]) * 1e3
+        mark[0], mark[1] = cm.bytes_sent, now
 
     # 1. order statistics per (cluster, len)
     qlo, qhi, cnt = eng.sr_len_quantiles(nclust, sr_dist, 0.95)
@@ -307,7 +310,7 @@ def merge_n_sort_sr_links_dist(eng, nclust: int, sr_dist: float, srp_cutoff: flo
     took("minimum")
     reds, pools = cm.gatherv(rec), cm.gatherv(prec)
     took("kept_links_and_pool")
-    aux = dict(mean_dist=md, shape=shape, stats=stats, min_mi=min_mi if np.isfinite(min_mi) else np.nan, counts=n_total, fit_data=fit_data, bytes_sent=sent,
+    aux = dict(mean_dist=md, shape=shape, stats=stats, min_mi=min_mi if np.isfinite(min_mi) else np.nan, counts=n_total, fit_data=fit_data, bytes_sent=sent, ms=ms,
                candidates=int(tmi.numel() if hasattr(tmi, "numel") else len(tmi)), local_rows=int(rows_mine.sum()))
     if cm.rank != 0:
         return None, None, aux
@@ -319,6 +322,7 @@ def merge_n_sort_sr_links_dist(eng, nclust: int, sr_dist: float, srp_cutoff: flo
         flags = eng.aracne_device()
     else:
         flags = np.ones(n_red, dtype=bool)
+    took("aracne_on_rank0")
     # reference row order: per cluster the links inside one cluster, then the cross-cluster links in order of first appearance (:470-486)
     dup = allr["dup"].astype(bool)
     key_cl = np.where(dup, allr["first_clust"], allr["clust_c"])
