@@ -110,6 +110,12 @@ int prepare_apx_weights(ldw_ctx *c) {
     c->apx_lost_units = 0;
     for (int k = 1; k < S4; ++k)
         if (sh[(size_t)k] > 0) c->apx_lost_units += std::ldexp(1.0, em[(size_t)k] - c->apx_e_last);
+    // (experiments build, a PRICING switch: LDW_APX_EXTRA_UNITS=x treats every GEMM entry as up to x WEIGHT units low on top of that — what an absolute
+    // slack per entry, e.g. of a contraction over compressed clone groups, would cost the screen in listed pairs; results stay exact)
+    if (const char *xs = exp_env("LDW_APX_EXTRA_UNITS")) {
+        const double x = atof(xs);
+        if (x > 0) c->apx_lost_units += x / std::ldexp(1.0, c->apx_e_last - c->frac_bits);
+    }
     // weight classes = runs of equal V along the positions; segments = (32-bit word, class) intersections
     std::vector<PopSeg> segs;
     std::vector<int32_t> wbeg((size_t)(Npad / 32) + 1, 0);
