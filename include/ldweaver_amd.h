@@ -452,7 +452,9 @@ int ldw_write_links_tsv_end(ldw_ctx *ctx, int64_t *rows_out, int64_t *bytes_out)
 int ldw_tsv_join(ldw_ctx *ctx);
 /* Host memory the library keeps between calls — the tsv writers' pooled buffers (process-wide, ~100 MB after a C4 job) and the context's pinned
  * fetch arena (16 B per row of the largest table written, <= 2.25 GB) — is released here (ctx may be NULL: the pool only).  Call it BETWEEN jobs:
- * on this driver stack giving large host regions back next to GPU work stalls the process's next GPU call.  bytes_out: released. */
+ * on this driver stack giving large host regions back next to GPU work stalls the process's next GPU call.  bytes_out: released.
+ * r05: also the DEVICE blocks (>= 64 MB each, <= LDW_DEVPOOL_GB = 48 GB in all) that released buffers and destroyed contexts leave for the next taker — fetching
+ * device memory from the driver costs up to 40 ms per GB on this stack, a second for every context created after another one was destroyed. */
 int ldw_host_trim(ldw_ctx *ctx, int64_t *bytes_out);
 /* SINGLE WRITER PER PATH: the tsv writers position their workers' writes by offsets computed from the file's size at the start of the call
  * (pwrite), so two writers appending to one path at the same time — two contexts or ranks, or a synchronous call beside a pending

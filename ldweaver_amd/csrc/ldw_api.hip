@@ -28,16 +28,114 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     return LDW_ERR_HIP;
 }
 
+// ---- r05: released device blocks are kept for the next taker (process-wide, per device).  tools/scratch/realloc_probe.cpp: device memory the runtime has to fetch from the driver
+// costs up to 40 ms per GB on this stack (4 x 12 GB: 1.9 s, fresh or right after freeing the same amount; under ~16 GB the runtime re-uses what it just freed), so an engine created after
+// another one was destroyed — every test, every job of a long session — waited about a second for the 13-19 GB its context reserves.  Blocks of >= 64 MB go to a free list on release and are
+// handed out again best-fit (at most a quarter larger than asked for); LDW_DEVPOOL_GB (default 48, 0: off) caps what is kept; a failing hipMalloc flushes the list and tries again;
+// ldw_host_trim gives everything back.  A block is given up only after the device has drained (what hipFree does implicitly), so its next owner cannot meet the last one's kernels.
+namespace {
+struct PoolBlock {
+    void *p;
+    size_t cap;
+    int dev;
+};
+std::mutex g_pool_mtx;
+std::vector<PoolBlock> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t POOL_MIN = (size_t)64 << 20;
+size_t pool_limit() {
+    static const size_t v = [] {
+        const char *e = getenv("LDW_DEVPOOL_GB");
+        const double gb = e ? atof(e) : 48.0;
+        return gb > 0 ? (size_t)(gb * 1073741824.0) : (size_t)0;
+    }();
+    return v;
+}
+void *pool_take(size_t want, size_t &cap_out) {
+    if (want < POOL_MIN || pool_limit() == 0) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pool_mtx);
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < g_pool.size(); ++i)
+        if (g_pool[i].dev == dev && g_pool[i].cap >= want && g_pool[i].cap <= want + want / 4 && (best == (size_t)-1 || g_pool[i].cap < g_pool[best].cap)) best = i;
+    if (best == (size_t)-1) return nullptr;
+    void *p = g_pool[best].p;
+    cap_out = g_pool[best].cap;
+    g_pool_bytes -= cap_out;
+    g_pool[best] = g_pool.back();
+    g_pool.pop_back();
+    return p;
+}
+void pool_give(void *p, size_t cap) {
+    if (!p) return;
+    if (cap >= POOL_MIN && pool_limit() > 0) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess) {
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            if (cur != at.device) (void)hipSetDevice(at.device);
+            const bool drained = hipDeviceSynchronize() == hipSuccess;   // (the releasing context's kernels are done with it: what hipFree waits for as well)
+            if (cur != at.device) (void)hipSetDevice(cur);
+            if (drained) {
+                std::lock_guard<std::mutex> lk(g_pool_mtx);
+                if (g_pool_bytes + cap <= pool_limit()) {
+                    g_pool.push_back(PoolBlock{p, cap, at.device});
+                    g_pool_bytes += cap;
+                    return;
+                }
+            }
+        }
+        (void)hipGetLastError();
+    }
+    (void)hipFree(p);
+}
+size_t pool_flush() {
+    std::vector<PoolBlock> all;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mtx);
+        all.swap(g_pool);
+        g_pool_bytes = 0;
+    }
+    size_t n = 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const PoolBlock &b : all) {
+        (void)hipSetDevice(b.dev);
+        (void)hipFree(b.p);
+        n += b.cap;
+    }
+    if (!all.empty()) (void)hipSetDevice(cur);
+    return n;
+}
+// a block of at least `want` bytes: from the free list, else from the runtime (a second try after giving the free list back)
+hipError_t dev_alloc(void **out, size_t want, size_t &cap_out) {
+    if (void *p = pool_take(want, cap_out)) {
+        *out = p;
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (pool_flush() > 0) e = hipMalloc(out, want);
+    }
+    cap_out = want;
+    return e;
+}
+}  // namespace
+
+size_t device_pool_trim() { return pool_flush(); }
+
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap && p) return LDW_OK;
     if (p) {
-        LDW_HIP(hipFree(p));
+        pool_give(p, cap);
         p = nullptr;
         cap = 0;
     }
-    size_t want = bytes < 256 ? 256 : bytes;
-    LDW_HIP(hipMalloc(&p, want));
-    cap = want;
+    size_t want = bytes < 256 ? 256 : bytes, got = 0;
+    LDW_HIP(dev_alloc(&p, want, got));
+    cap = got;
     return LDW_OK;
 }
 
@@ -46,8 +144,9 @@ int DevBuf::reserve_keep(size_t bytes, size_t used, hipStream_t s) {
     size_t want = bytes < 256 ? 256 : bytes;
     if (want < cap + cap / 2) want = cap + cap / 2;  // geometric growth for the link tables
     void *np = nullptr;
+    size_t got = 0;
     {
-        hipError_t e = hipMalloc(&np, want);
+        hipError_t e = dev_alloc(&np, want, got);
         if (e != hipSuccess) {
             size_t fr = 0, tot = 0;
             (void)hipMemGetInfo(&fr, &tot);
@@ -59,14 +158,14 @@ int DevBuf::reserve_keep(size_t bytes, size_t used, hipStream_t s) {
         LDW_HIP(hipMemcpyAsync(np, p, used, hipMemcpyDeviceToDevice, s));
         LDW_HIP(hipStreamSynchronize(s));
     }
-    if (p) LDW_HIP(hipFree(p));
+    if (p) pool_give(p, cap);
     p = np;
-    cap = want;
+    cap = got;
     return LDW_OK;
 }
 
 void DevBuf::release() {
-    if (p) (void)hipFree(p);
+    if (p) pool_give(p, cap);
     p = nullptr;
     cap = 0;
 }
@@ -812,6 +911,7 @@ int ldw_set_snp_meta(ldw_ctx *c, const double *r, const uint8_t *uqe, const int3
     c->rows_ready = false;
     c->sr_total = -1;
     c->sr_total_dist = -1;
+    c->sr_share_rows = -1;
     // r04: with the alignment and the weights in place the row map (indicator rows, marginals, per-SNP bounds: ensure_rows, ~9 ms at C4) is
     // built HERE — it belongs to handing over the data — instead of lazily inside the first block loop; a later ldw_set_weights
     // invalidates it again and the next pass rebuilds it

@@ -189,6 +189,8 @@ struct ldw_ctx {
     bool pos_sorted = true;      // POS ascends over the whole alignment (the reference's parser emits it so; any order is accepted)
     double sr_total_dist = -1;   // number of SNP pairs within sr_total_dist on the circle (sizes the short-range table once; reset with the meta data)
     int64_t sr_total = -1;
+    uint64_t sr_share_key = 0;   // r05: the last SHARE of the block list a pass was sized for (hash of blocks + sr_dist) and its exact short-range row count
+    int64_t sr_share_rows = -1;
 
     // ---- row map (built lazily from alignment + weights + meta) ----
     bool rows_ready = false;
@@ -309,6 +311,7 @@ int ensure_streams(ldw_ctx *ctx);    // the copy / GEMM streams, per-slot events
 void warm_mi();                      // lazy code-object loads of the translation units whose kernels a pass launches (hipFuncGetAttributes)
 void warm_apx();
 void warm_gemm_bits();
+size_t device_pool_trim();          // ldw_api.hip: give the released device blocks kept for re-use back to the runtime (ldw_host_trim); bytes
 void warm_srp();
 // ldw_srp.hip: ldw_sr_reduced_import with the kept links' meta words (clust_c | first << 8 | dup << 16) and srp values (both may be null)
 int reduced_import_full(ldw_ctx *ctx, int64_t n_red, const int32_t *a, const int32_t *b, const double *MI, const uint32_t *meta, const double *srp, int64_t n_pool,

@@ -473,7 +473,30 @@ int ldw_mi_all_pairs(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, const l
         c->sr_total = total_sr;
         c->sr_total_dist = p->sr_dist;
         }
-        if (int rc = ensure_links_capacity(c, total_sr + 1024, 0)) return rc;
+        // r05: a SHARE of the block list (a rank or context of a multi-GPU job: under three quarters of the pair space) is sized for the rows of ITS blocks — the band
+        // enumerator counts them on the device in well under a millisecond (ldw_sr_pairs_fill without outputs; cached per block list) — instead of the whole alignment's:
+        // at config 5 that is 4.5 instead of 36 GB per rank of eight.  Whatever this under-estimates still grows where it is used (ensure_links_capacity per item).
+        int64_t want_sr = total_sr;
+        {
+            double share_pairs = 0;
+            uint64_t key = 1469598103934665603ull ^ (uint64_t)(int64_t)(p->sr_dist * 16.0);
+            for (int64_t b = 0; b < nblocks; ++b) {
+                share_pairs += (double)(blocks[b * 4 + 1] - blocks[b * 4 + 0] + 1) * (double)(blocks[b * 4 + 3] - blocks[b * 4 + 2] + 1);
+                for (int q = 0; q < 4; ++q) key = (key ^ (uint64_t)(uint32_t)blocks[b * 4 + q]) * 1099511628211ull;
+            }
+            if (share_pairs < 0.375 * (double)Ls * (double)Ls && c->g == std::floor(c->g)) {
+                if (c->sr_share_rows >= 0 && c->sr_share_key == key) want_sr = std::min(total_sr, c->sr_share_rows);
+                else {
+                    int64_t n_share = 0;
+                    if (ldw_sr_pairs_fill(c, blocks, nblocks, p->sr_dist, nullptr, nullptr, 0, &n_share) == LDW_OK && n_share <= total_sr) {
+                        c->sr_share_key = key;
+                        c->sr_share_rows = n_share;
+                        want_sr = n_share;
+                    }
+                }
+            }
+        }
+        if (int rc = ensure_links_capacity(c, want_sr + 1024, 0)) return rc;
     }
     if (!p->sr_only) {
         // r05: the long-range table sized ONCE as well.  The per-block filter keeps about lr_retain_links rows in all (R/computePairwiseMI.R:347-358:

@@ -746,6 +746,7 @@ int ldw_host_trim(ldw_ctx *c, int64_t *bytes_out) {
     // pinned fetch arena (up to 2 GB x 1.125) until the context dies.  They are kept on purpose WHILE jobs run (an munmap next to GPU work
     // stalls the process's next GPU call by ~20 ms: DESIGN.md 8); this gives them back between jobs, when the caller says so.
     int64_t n = (int64_t)host_pool().trim();
+    n += (int64_t)ldw::device_pool_trim();   // r05: + the released DEVICE blocks kept for the next context (ldw_api.hip)
     if (c) {
         if (int rc = tsv_async_join(c, nullptr, nullptr)) return rc;
         if (c->lr_stream == nullptr && c->pin_fetch) {
