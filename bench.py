@@ -85,8 +85,7 @@ def parse():
     ap.add_argument("--inproc-devices", default="", help="comma-separated device ids for --inproc (default 0..gpus-1; '0,0' = two contexts on one GPU)")
     ap.add_argument("--no-sr-tail-leg", action="store_true", help="N > 1: skip the leg that runs the short-range model + ARACNE behind the pass both ways "
                     "(table gathered to rank 0 / rows left on their ranks: ldweaver_amd/dist_srp.py)")
-    ap.add_argument("--sr-tail-leg", action="store_true", help="N > 1 with backend nccl: run that leg too.  It runs by default under gloo (the rehearsal) and with --inproc; under "
-                    "RCCL it is opt-in: its exchanges have only ever run on ONE GPU (tests/rccl_worker.py), and a hang there would take the line of the timed region with it")
+    ap.add_argument("--sr-tail-timeout", type=float, default=240.0, help="N > 1: seconds the sr_tail leg may take before every rank abandons it and rank 0 prints the line without it")
     ap.add_argument("--sustain-s", type=float, default=10.0, help="N = 1: keep stepping after the timed region until this many seconds of steps have run")
     return ap.parse_args()
 
@@ -620,9 +619,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine_rec)
 
-    sr_tail = None
-    if world > 1 and not args.no_extra_legs and not args.no_sr_tail_leg and args.engine == "mfma" and (args.backend == "gloo" or args.sr_tail_leg):
-        sr_tail = sr_tail_leg(eng, blocks, mine, sr_dist, lr_retain, approx, POS, paint, g, dev, rank, world, fence)
+    run_sr_tail = world > 1 and not args.no_extra_legs and not args.no_sr_tail_leg and args.engine == "mfma"   # (after the line is assembled: see the end of main)
 
     extra = rank == 0 and world == 1 and len(my_blocks) and not args.no_extra_legs
     legs = {}
@@ -857,16 +854,41 @@ def main():
         out["self_launched"] = bool(os.environ.get("LDW_BENCH_SELF_LAUNCHED"))
         if per_rank is not None:
             out["per_rank"] = per_rank
-        if sr_tail is not None:
-            out["sr_tail"] = sr_tail
-        elif world > 1:
-            out["sr_tail"] = dict(note="not run on this line (backend nccl: opt-in with --sr-tail-leg).  The short-range model over ranks (ldweaver_amd/dist_srp.py) is UNMEASURED ON "
-                                       "HARDWARE; profiles/r05_bench_4rank_gloo.json holds the 4-rank rehearsal on one GPU (215 -> 28 MB sent per peer, same kept links)")
         out.update(stages_ms_per_step={k: v / max(1, n_replay) for k, v in tim.items()},
                    stages_ms_per_step_overlapped={k: v / K for k, v in tim_overlapped.items()},
                    links=links_timed, counters=counters_timed, counters_replay=cnt_replay, hamming_weights_s=hamming_s,
                    hamming_gemm_ms=hamming_kernel_ms, setup_s=setup_s)
-        print(json.dumps(out))
+    # ---- N > 1, LAST: the short-range model behind the pass, table gathered / rows left on their ranks (sr_tail_leg).  Everything the line holds is
+    # assembled by now, and a watchdog on every rank bounds the leg: its exchanges have only run under gloo and on ONE GPU under RCCL (tests/rccl_worker.py), and
+    # a rank stuck in a collective must not cost the line of the timed region — after --sr-tail-timeout seconds rank 0 prints the line without the leg and
+    # every rank leaves (os._exit: a thread blocked inside a collective cannot be interrupted).
+    if run_sr_tail:
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["sr_tail"] = dict(note=f"the leg did not finish within {args.sr_tail_timeout} s on this line and was abandoned (unmeasured on hardware)")
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.sr_tail_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            res = sr_tail_leg(eng, blocks, mine, sr_dist, lr_retain, approx, POS, paint, g, dev, rank, world, fence)
+            dog.cancel()
+            if rank == 0:
+                out["sr_tail"] = res
+        except BaseException as e:   # noqa: BLE001 — the line matters more than the leg; the other ranks leave through their own watchdogs
+            dog.cancel()
+            if rank == 0:
+                out["sr_tail"] = dict(note=f"the leg failed on rank 0 ({type(e).__name__}: {e}); unmeasured on hardware")
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+    elif world > 1 and rank == 0:
+        out["sr_tail"] = dict(note="not run on this line (--no-extra-legs / --no-sr-tail-leg)")
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
         dist.barrier()

@@ -62,6 +62,9 @@ def test_bench_multi_rank_rehearsal():
     assert tail["kept_links_equal"] is True and tail["kept_links"]["dist"]["rows"] > 100, tail["kept_links"]
     assert tail["max_bytes_sent_per_peer"]["dist"] < 0.4 * tail["max_bytes_sent_per_peer"]["gather"], tail["max_bytes_sent_per_peer"]
     assert all(r["candidates"] < 0.25 * r["sr_rows"] for r in tail["per_rank"] if r["sr_rows"] > 0)
+    # ... and the leg can never cost the line: with a watchdog of 50 ms every rank abandons it, rank 0 prints the line without it, exit code 0
+    cut = _bench_line([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--sr-tail-timeout", "0.05"] + [a for a in base if a != "--no-extra-legs"], 600)
+    assert cut["n_gpus"] == 2 and cut["links"] == one["links"] and "abandoned" in cut["sr_tail"]["note"]
     sent = sum(r["bytes_sent"] for r in pr)
     assert sent <= 8 * one["links"]["n_sr"] + 16 * one["links"]["n_lr"]
     assert sent < 0.6 * 16 * (one["links"]["n_sr"] + one["links"]["n_lr"]) * 3 / 4 + 16 * one["links"]["n_lr"]
