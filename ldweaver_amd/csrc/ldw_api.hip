@@ -109,10 +109,26 @@ size_t pool_flush() {
     return n;
 }
 // a block of at least `want` bytes: from the free list, else from the runtime (a second try after giving the free list back)
+// LDW_POISON_ALLOC=1 (debugging aid, any build): every block handed out is filled with 0xA5 first — fresh device memory happens to be zero on this stack, a block from
+// the free list (or from the runtime's own cache) is not, and code that reads what it never wrote must not depend on the difference (tools/fuzz_paths.py found one such read)
+bool poison_on() {
+    static const bool on = getenv("LDW_POISON_ALLOC") != nullptr;
+    return on;
+}
 hipError_t dev_alloc(void **out, size_t want, size_t &cap_out) {
     if (void *p = pool_take(want, cap_out)) {
-        *out = p;
-        return hipSuccess;
+        // a block from the free list holds its last owner's data; memory that comes from the driver is zero, and the engine has always been handed zeroed
+        // blocks (nothing else was ever observed on this stack): keep it so — LDW_POISON_ALLOC (below) found kernels that read index arrays before writing
+        // them, which zeroes make harmless and another buffer's contents would not.  The pages are mapped already: the fill runs at HBM speed (7 ms for 20 GB).
+        hipError_t e = hipMemsetAsync(p, poison_on() ? 0xA5 : 0, cap_out, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();   // (the library's streams do not synchronise with the null stream)
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(p);
+        } else {
+            *out = p;
+            return hipSuccess;
+        }
     }
     hipError_t e = hipMalloc(out, want);
     if (e != hipSuccess) {
@@ -120,6 +136,7 @@ hipError_t dev_alloc(void **out, size_t want, size_t &cap_out) {
         if (pool_flush() > 0) e = hipMalloc(out, want);
     }
     cap_out = want;
+    if (e == hipSuccess && poison_on()) (void)hipMemset(*out, 0xA5, want);
     return e;
 }
 }  // namespace
@@ -789,6 +806,36 @@ int ldw_set_weights(ldw_ctx *c, const double *hdw, int64_t N, int nlimbs) {
                 (long long)N, (long long)c->N);
     if (nlimbs == 0) nlimbs = 5;
     LDW_REQUIRE(nlimbs >= 1 && nlimbs <= 6, LDW_ERR_ARG, "ldw_set_weights: nlimbs must be 1..6");
+    if (const char *dz = getenv("LDW_DEBUG_ZERO")) {   // debugging aid: zero whole buffer groups when the weights change (which stale tail does a later, smaller problem read?)
+        const int mask = atoi(dz);
+        if (int rc = join_prepare(c)) return rc;
+        LDW_HIP(hipDeviceSynchronize());
+        std::vector<ldw::DevBuf *> g;
+        if (mask & 1) g.insert(g.end(), {&c->dig_a, &c->dig_b, &c->apx_shift, &c->seq_perm, &c->digits, &c->vfixed});
+        if (mask & 2) g.insert(g.end(), {&c->pop_segs, &c->pop_wbeg, &c->pop_vpos, &c->slot_papx});
+        if (mask & 4)
+            for (int k = 0; k < LDW_NSLOT; ++k) g.insert(g.end(), {&c->panel[k][0], &c->panel[k][1], &c->Gapx[k]});
+        if (mask & 8)
+            for (int k = 0; k < LDW_NSLOT; ++k)
+                g.insert(g.end(), {&c->apx_bins[k], &c->apx_clean[k], &c->apx_mini[k], &c->apx_units[k], &c->apx_packs[k], &c->scr_live[k], &c->pairs[k], &c->sub_units[k], &c->sub_packs[k],
+                                   &c->sub_bins[k], &c->sub_live[k]});
+        for (int k = 0; k < LDW_NSLOT; ++k) {
+            ldw::DevBuf *one[8] = {&c->apx_bins[k], &c->apx_clean[k], &c->apx_mini[k], &c->apx_units[k], &c->apx_packs[k], &c->scr_live[k], &c->pairs[k], &c->sub_units[k]};
+            for (int q = 0; q < 8; ++q)
+                if (mask & (64 << q)) g.push_back(one[q]);
+        }
+        if (mask & 16)
+            g.insert(g.end(), {&c->Mbits, &c->row0, &c->slot_meta, &c->slot_pfix, &c->slot_pfix_hi, &c->counts, &c->pfix_state, &c->snp_sup, &c->packs, &c->glo, &c->lo_rows});
+        if (mask & 32) {
+            g.insert(g.end(), {&c->G, &c->G2, &c->G3, &c->MIblk, &c->rowlist_f, &c->rowlist_t, &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->perm_t, &c->scr_units, &c->colcnt,
+                               &c->cand_key2, &c->cand_val2, &c->sel_bitmap, &c->sel_chunks, &c->sel_prefix, &c->scratch, &c->small, &c->pair_sums, &c->tab11[0], &c->tab11[1], &c->miss_key,
+                               &c->miss_val});
+            for (int k = 0; k < LDW_NSLOT; ++k) g.insert(g.end(), {&c->hist[k], &c->cand_key[k], &c->cand_val[k], &c->dstage[k]});
+        }
+        for (ldw::DevBuf *b : g)
+            if (b->p) LDW_HIP(hipMemsetAsync(b->p, 0, b->cap, c->stream));
+        LDW_HIP(hipStreamSynchronize(c->stream));
+    }
     std::vector<double> v((size_t)N);
     long double neff = 0.0L, vsum = 0.0L;
     double vmax = 0;

@@ -2452,6 +2452,19 @@ def test_in_process_multi_context_equals_one_context(sample, tmp_path):
     assert (d1 / "sr_links.tsv").read_bytes() == (d2 / "sr_links.tsv").read_bytes()
 
 
+def test_paths_agree_on_one_context_across_changing_problems():
+    """tools/fuzz_paths.py, three short sequences of random problems (shape, weighting, block size, sr_dist, retention, quirk mode, position layout) run one
+    after the other on ONE context: default / verify / no-span paths == the plain path bit for bit, cold and warm, zero screen violations.  Seed 23 from its
+    third case on is the sequence that found the stale clean-region flags of r01-r05 (a problem with N = 40 after one with N = 257 read the larger one's flags:
+    334 violations); the others are fresh draws."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_paths.py")
+    for args in (["--cases", "5", "--seed", "23", "--start", "2"], ["--cases", "12", "--seed", "11"], ["--cases", "12", "--seed", "4242"]):
+        r = subprocess.run([sys.executable, tool] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "DIFFERENT" not in r.stdout, r.stdout[-3000:] + r.stderr[-1500:]
+        assert r.stdout.count(": ok") >= 3
+
+
 def test_default_library_refuses_experiment_variants(engine):
     """The default library holds none of the measured-slower variants: asking for one is an error (LDW_ERR_STATE), not a silent fallback."""
     if L.has_experiments():
