@@ -115,13 +115,22 @@ bool poison_on() {
     static const bool on = getenv("LDW_POISON_ALLOC") != nullptr;
     return on;
 }
+// LDW_POISON_ALLOC=1: bytes 0xA5 (an index read from it is wild: the kernel faults).  LDW_POISON_ALLOC=2: int32 words of 1 — indices stay in range, flags
+// read "set", floats are denormals: a read-before-write shows as a wrong RESULT instead of a fault (the gentler first probe)
+void poison_fill(void *p, size_t bytes) {
+    static const int mode = getenv("LDW_POISON_ALLOC") ? atoi(getenv("LDW_POISON_ALLOC")) : 0;
+    if (mode == 2) (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), 1, bytes / 4);
+    else (void)hipMemset(p, 0xA5, bytes);
+    (void)hipDeviceSynchronize();
+}
 hipError_t dev_alloc(void **out, size_t want, size_t &cap_out) {
     if (void *p = pool_take(want, cap_out)) {
         // a block from the free list holds its last owner's data; memory that comes from the driver is zero, and the engine has always been handed zeroed
         // blocks (nothing else was ever observed on this stack): keep it so — LDW_POISON_ALLOC (below) found kernels that read index arrays before writing
         // them, which zeroes make harmless and another buffer's contents would not.  The pages are mapped already: the fill runs at HBM speed (7 ms for 20 GB).
-        hipError_t e = hipMemsetAsync(p, poison_on() ? 0xA5 : 0, cap_out, nullptr);
+        hipError_t e = hipMemsetAsync(p, 0, cap_out, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();   // (the library's streams do not synchronise with the null stream)
+        if (e == hipSuccess && poison_on()) poison_fill(p, cap_out);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(p);
@@ -136,7 +145,7 @@ hipError_t dev_alloc(void **out, size_t want, size_t &cap_out) {
         if (pool_flush() > 0) e = hipMalloc(out, want);
     }
     cap_out = want;
-    if (e == hipSuccess && poison_on()) (void)hipMemset(*out, 0xA5, want);
+    if (e == hipSuccess && poison_on()) poison_fill(*out, want);
     return e;
 }
 }  // namespace
