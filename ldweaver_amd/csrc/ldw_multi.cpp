@@ -103,6 +103,12 @@ int ldw_mi_all_pairs_multi(ldw_ctx **ctx, int n_ctx, const int32_t *blocks, int6
         if (!w.ids.empty()) {
             w.rc = ldw_mi_all_pairs(ctx[k], w.blocks.data(), (int64_t)w.ids.size(), p, 1);
             if (w.rc != LDW_OK) w.err = ldw_last_error();   // (the message is thread-local: taken here, reported by the caller's thread)
+        } else {
+            // a context the deal left without a block holds EMPTY tables afterwards, not those of an earlier call (tools/fuzz_sr_model.py: one block pair, two contexts —
+            // the idle one still held its rows of the problem before, and the model over the contexts refused its "share")
+            w.rc = ldw_links_begin(ctx[k], 1);
+            if (w.rc == LDW_OK) w.rc = ldw_links_end(ctx[k]);
+            if (w.rc != LDW_OK) w.err = ldw_last_error();
         }
         w.ms = now_ms() - t0;
     };

@@ -2465,6 +2465,16 @@ def test_paths_agree_on_one_context_across_changing_problems():
         assert r.stdout.count(": ok") >= 3
 
 
+def test_consumers_of_a_reused_context_equal_a_fresh_one():
+    """tools/fuzz_sr_model.py: a sequence of random problems on contexts that are RE-USED from case to case — the short-range model + ARACNE, the Tukey analysis of
+    the long-range links and the LD map must equal a fresh context's bit for bit, and the model over two re-used contexts (LDW_MI_SR_ROWS_STAY) the one-table model.
+    (It found that a context the in-process deal leaves without a block kept the rows of the problem before.)"""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_sr_model.py")
+    r = subprocess.run([sys.executable, tool, "--cases", "16", "--seed", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIFFERENT" not in r.stdout and r.stdout.count(": ok") == 16, r.stdout[-3000:] + r.stderr[-1500:]
+
+
 def test_default_library_refuses_experiment_variants(engine):
     """The default library holds none of the measured-slower variants: asking for one is an error (LDW_ERR_STATE), not a silent fallback."""
     if L.has_experiments():
