@@ -287,6 +287,14 @@ int ldw_set_pair_cap(uint32_t cap);
  * floor min(r)^2 / 4) reading of RXY; 1e300 for other SNPs and for SNPs with a sizeable minor state (not evaluated).  Needs the
  * alignment, the weights and the SNP meta data; capacity in doubles (>= 4 L). */
 int ldw_snp_bounds(ldw_ctx *ctx, double *out, int64_t capacity);
+/* inspection only (r05): out[0] = pairs that verify mode (ldw_set_screen 2) counted as "the screen would have lost this one" since the last call, out[1 + 4 k ..] = (from SNP,
+ * to SNP, exact MI, level) of the first 16 of them.  65 doubles. */
+int ldw_debug_violations(ldw_ctx *ctx, double *out);
+/* (test hook) the threshold table of the biallelic pairs (k_build_tab11) for a total weight W, an MI level lo, the approximate sums' relative
+ * error delta, their absolute slack eta and the unit sprime of the int32 sums: out[64 * 64 * 2] = (Lq, Hq) of entry [bin of the to side][bin of the
+ * from side], bin = min(63, floor(sqrtf(p) * cbin)); a sum n' with Lq < n' < Hq is dismissed.  tests/test_gpu_parity.py checks the table against
+ * the MI formula on a grid of joint tables. */
+int ldw_debug_tab11(ldw_ctx *ctx, double W, double lo, double delta, double eta, double sprime, int32_t *out, double *cbin_out);
 /* diagnostics of the approximate path after ldw_set_weights: out[0] = usable (0/1), out[1] = max relative error delta of the
  * dual-digit weights, out[2] = weight classes, out[3] = popcount segments, out[4] = exponent transitions, out[5] = e_last */
 int ldw_apx_info(ldw_ctx *ctx, double out[6]);

@@ -959,6 +959,37 @@ int ldw_sr_pairs_fill(ldw_ctx *c, const int32_t *blocks, int64_t nblocks, double
     return LDW_OK;
 }
 
+// inspection only: the first 16 pairs verify mode counted as violations since the library was loaded — (from SNP, to SNP, exact MI, the level they were judged against) —
+// and how many there were; resets the record.  out: 1 + 64 doubles.
+int ldw_debug_violations(ldw_ctx *c, double *out) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(out, LDW_ERR_ARG, "ldw_debug_violations: null output");
+    LDW_HIP(hipDeviceSynchronize());
+    unsigned long long n = 0, zero = 0;
+    LDW_HIP(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_viol_n), 8));
+    LDW_HIP(hipMemcpyFromSymbol(out + 1, HIP_SYMBOL(g_viol_rec), 64 * 8));
+    LDW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_viol_n), &zero, 8));
+    out[0] = (double)n;
+    return LDW_OK;
+}
+
+int ldw_debug_tab11(ldw_ctx *c, double W, double lo, double delta, double eta, double sprime, int32_t *out, double *cbin_out) {
+    if (int rc = check_gpu(c)) return rc;
+    LDW_REQUIRE(out && cbin_out && W > 0 && lo > 0 && delta >= 0 && eta >= 0 && sprime > 0, LDW_ERR_ARG, "ldw_debug_tab11: bad argument");
+    constexpr int NB = 64;
+    ldw::DevBuf t;
+    if (int rc = t.reserve((size_t)NB * NB * 8)) return rc;
+    const float cbin = (float)(NB / std::sqrt(W + 1.0));
+    hipLaunchKernelGGL(ldw::k_build_tab11, dim3(NB * NB * 32 / 256), dim3(256), 0, c->stream, W, lo, delta, eta, sprime, NB, cbin, t.as<int2>());
+    hipError_t he = hipGetLastError();
+    if (he == hipSuccess) he = hipMemcpyAsync(out, t.p, (size_t)NB * NB * 8, hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    t.release();
+    if (he != hipSuccess) return ldw::hip_fail(he, "ldw_debug_tab11", __FILE__, __LINE__);
+    *cbin_out = (double)cbin;
+    return LDW_OK;
+}
+
 int ldw_set_span(ldw_ctx *c, int on, int max_blocks) {
     LDW_REQUIRE(c && (max_blocks == 0 || (max_blocks >= 2 && max_blocks <= LDW_SPAN_MAX)), LDW_ERR_ARG, "ldw_set_span: max_blocks must be 0 or 2..%d", LDW_SPAN_MAX);
     LDW_REQUIRE(!(on & 6) || LDW_HAS_EXPERIMENTS, LDW_ERR_STATE, "ldw_set_span: corner spans / split diagonal blocks (measured slower, r04) are only in the LDW_EXPERIMENTS build");

@@ -2465,6 +2465,68 @@ def test_paths_agree_on_one_context_across_changing_problems():
         assert r.stdout.count(": ok") >= 3
 
 
+def _mi11(n, pa, pb, W):
+    """MI of a biallelic x biallelic pair (r = 2 both, RXY = 1) from the joint weight n of the two flagged states and their marginals (R/computePairwiseMI.R:390-398)."""
+    den = W + 2.0
+    A0, A1, B0, B1 = pa + 1.0, W - pa + 1.0, pb + 1.0, W - pb + 1.0
+    x = n + 0.5
+    x01, x10, x11 = A0 - x, B0 - x, den - A0 - B0 + x
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return (x * np.log(x * den / (A0 * B0)) + x01 * np.log(x01 * den / (A0 * B1)) + x10 * np.log(x10 * den / (A1 * B0)) + x11 * np.log(x11 * den / (A1 * B1))) / den
+
+
+@pytest.mark.parametrize("W,lo", [(6.614192337876547, 0.98 * 0.314453125), (6.614192337876547, 0.33), (3.0, 0.2), (41.5, 0.5), (41.5, 0.05), (100.0, 0.1), (1000.0, 0.05), (1000.0, 0.62),
+                                  (4321.0, 0.2), (4321.0, 0.66)])
+def test_threshold_table_never_dismisses_a_pair_that_reaches_the_level(engine, W, lo):
+    """The threshold table of the biallelic pairs (k_build_tab11) against the MI formula on a grid of joint tables: whenever MI >= lo the sum must lie
+    outside (Lq, Hq) of its marginals' bin.  The grid holds what the 3 x 3 corner sampling cannot see by itself: tables on the line pa + pb = W with an EMPTY joint cell
+    (perfect anti-association — r05: tools/fuzz_paths.py --seed 203 --only 96 found two such pairs dismissed at W = 6.6, the first parameter set here) and on the
+    diagonal pa = pb with a full one, next to a dense sweep.  The table must also still DO something: most tables far below the level are dismissed."""
+    import ctypes as C
+    s = 2.0 ** -12
+    tab = np.zeros(64 * 64 * 2, dtype=np.int32)
+    cb = C.c_double(0.0)
+    L.check(L.lib().ldw_debug_tab11(engine._ctx, W, lo, 0.0, s, s, L.ptr(tab), C.byref(cb)))
+    tab = tab.reshape(64, 64, 2)
+    cbin = np.float32(cb.value)
+    binof = lambda p: np.minimum(63, (np.sqrt(p.astype(np.float32)) * cbin).astype(np.int64))
+    g = np.unique(np.concatenate([np.linspace(0.0, W, 241), (np.arange(65) / float(cbin)) ** 2, W - (np.arange(65) / float(cbin)) ** 2, [W / 2, W / 2 * (1 - 1e-9), W / 2 * (1 + 1e-9)]]))
+    g = g[(g >= 0) & (g <= W)]
+    pa, pb = np.meshgrid(g, g, indexing="ij")
+    pa, pb = pa.ravel(), pb.ravel()
+    extra = np.random.default_rng(5).uniform(0.0, W, 4000)     # the two lines, densely
+    pa = np.concatenate([pa, extra, extra])
+    pb = np.concatenate([pb, W - extra, extra])
+    nlo, nhi = np.maximum(0.0, pa + pb - W), np.minimum(pa, pb)
+    lost = dismissed_low = low = 0
+    for f in np.concatenate([[0.0, 1.0], np.linspace(0.0, 1.0, 41)[1:-1], [1e-6, 1 - 1e-6]]):
+        n = nlo + f * (nhi - nlo)
+        mi = _mi11(n, pa, pb, W)
+        nq = np.rint(n / s).astype(np.int64)    # (the int32 sum of a pair: its error is the eta the table was built with)
+        t = tab[binof(pb), binof(pa)]
+        dismissed = (nq > t[:, 0]) & (nq < t[:, 1])
+        bad = dismissed & (mi >= lo)
+        if bad.any():
+            k = int(np.argmax(bad))
+            raise AssertionError(f"dismissed although MI {mi[k]!r} >= {lo}: pa {pa[k]!r} pb {pb[k]!r} n {n[k]!r} bins {int(binof(pa[k:k+1])[0])} {int(binof(pb[k:k+1])[0])} thresholds {t[k] * s}")
+        lost += int(bad.sum())
+        sel = mi < 0.5 * lo
+        low += int(sel.sum())
+        dismissed_low += int((dismissed & sel).sum())
+    assert lost == 0
+    print(f"W {W} lo {lo}: {dismissed_low} of {low} tables below half the level dismissed")
+    assert dismissed_low > 0.6 * low, (dismissed_low, low)
+
+
+def test_anti_associated_pairs_at_a_small_total_weight_are_not_dismissed(engine):
+    """The problem that found the hole above (24 000 SNPs x 130 sequences, Hamming weights summing to 6.6, survey alignment, sr_dist 500.5): verify mode counts no lost
+    pair and the default path's tables equal the plain path's."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_paths.py")
+    r = subprocess.run([sys.executable, tool, "--cases", "100", "--seed", "203", "--only", "96"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIFFERENT" not in r.stdout and r.stdout.count(": ok") == 1 and "violations 0" in r.stdout, r.stdout[-3000:] + r.stderr[-1500:]
+
+
 def test_consumers_of_a_reused_context_equal_a_fresh_one():
     """tools/fuzz_sr_model.py: a sequence of random problems on contexts that are RE-USED from case to case — the short-range model + ARACNE, the Tukey analysis of
     the long-range links and the LD map must equal a fresh context's bit for bit, and the model over two re-used contexts (LDW_MI_SR_ROWS_STAY) the one-table model.
