@@ -4,7 +4,8 @@ on the same engine also covers state that survives between problems (tools/fuzz_
 Hamming weights (bit-exact), unweighted joint counts of random pairs (bit-exact), the dense MI of a random index-list pair in the reference's quirk mode against
 the block-faithful oracle and in the intended mode against the per-pair direct oracle (1e-10), and the link tables of every block pair against the oracle's
 selection rule (R/computePairwiseMI.R:306-364) applied to the device's own dense MI: short-range rows in the reference's order with the dense block's bits,
-long-range rows equal as a set with the same threshold."""
+long-range rows equal as a set with the same threshold.  Part of the cases rewrite a share of the alignment first (tools/fuzz_paths.py mutate():
+copies and relabelled copies of SNPs, 30-70 % gaps, three to five states at comparable frequencies, two states of exactly N / 2 sequences)."""
 import os
 import sys
 
@@ -14,10 +15,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import ldw_oracle as orc  # noqa: E402
 from ldweaver_amd import _lib as L  # noqa: E402
 from ldweaver_amd.synth import synth_alignment  # noqa: E402
+from fuzz_paths import mutate  # noqa: E402  (tools/: rewrites part of an alignment — copies and complements of SNPs, heavy gaps, 3-5 states, exact halves)
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +29,7 @@ def _case(rs):
     return dict(L=int(rs.choice([230, 517, 900, 1400])), N=int(rs.choice([17, 64, 129, 300])), B=int(rs.choice([1000, 2000])),
                 kind=str(rs.choice(["survey", "survey", "adversarial"])), weights=str(rs.choice(["hamming", "hamming", "few", "unit", "distinct"])),
                 thr=float(rs.choice([0.1, 0.3])), sr_dist=float(rs.choice([20000.0, 3000.0, 100000.0])), retain=float(rs.choice([2e3, 2e4, 1e6])),
-                quirk=int(rs.integers(0, 2)), seed=int(rs.integers(1, 10 ** 6)))
+                quirk=int(rs.integers(0, 2)), seed=int(rs.integers(1, 10 ** 6)), mutate=str(rs.choice(["none", "none", "copies", "gaps", "states", "half", "all"])))
 
 
 _SEEDS = [int(x) for x in os.environ.get("LDW_FUZZ_SEEDS", "3,14").split(",")]   # (more seeds for a longer hunt: LDW_FUZZ_SEEDS=1,2,3,...)
@@ -42,6 +45,8 @@ def test_random_problems_on_one_context_against_the_oracle(engine, seed):
         syn = synth_alignment(p["L"], p["N"], seed=p["seed"], kind=p["kind"])
         st, POS, paint, g = syn["states"], syn["POS"], syn["paint"], float(syn["g"])
         r2 = np.random.default_rng(p["seed"])
+        if p["mutate"] != "none":
+            st = mutate(st, p["mutate"], np.random.default_rng(p["seed"] + 1))
         uqe, r = orc.uqe_r(st)
         engine.set_engine(L.ENGINE_MFMA)
         engine.set_alignment(st)

@@ -2459,7 +2459,8 @@ def test_paths_agree_on_one_context_across_changing_problems():
     334 violations); the others are fresh draws."""
     import subprocess
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_paths.py")
-    for args in (["--cases", "5", "--seed", "23", "--start", "2"], ["--cases", "12", "--seed", "11"], ["--cases", "12", "--seed", "4242"]):
+    for args in (["--cases", "5", "--seed", "23", "--start", "2"], ["--cases", "12", "--seed", "11"], ["--cases", "12", "--seed", "4242"],
+                 ["--cases", "10", "--seed", "401", "--mutate", "mix"]):   # (the last: alignments partly rewritten — copies and complements of SNPs, heavy gaps, 3-5 states, exact halves)
         r = subprocess.run([sys.executable, tool] + args, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "DIFFERENT" not in r.stdout, r.stdout[-3000:] + r.stderr[-1500:]
         assert r.stdout.count(": ok") >= 3

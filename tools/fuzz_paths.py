@@ -29,6 +29,35 @@ def case_params(rs):
                 pos=str(rs.choice(["recipe", "recipe", "dense", "shuffled_some"])), seed=int(rs.integers(1, 10 ** 6)))
 
 
+def mutate(st, kind, r2):
+    """Edge structure the recipe does not draw by itself (--mutate): every SNP row of `st` (L x N, states 0..4) may be rewritten.
+    copies: 5 % of the SNPs become exact copies of another SNP under a random relabelling of its states (perfect association and,
+    for two states, perfect anti-association, long-range as well as short-range); gaps: 10 % of the SNPs get 30-70 % gaps; states: 10 % of
+    the SNPs get three to five states at comparable frequencies; half: 10 % of the SNPs are rewritten to two states of exactly N / 2
+    sequences each (flagged-by-count ties)."""
+    Ls, N = st.shape
+    st = st.copy()
+    pick = lambda frac: r2.choice(Ls, size=max(1, int(frac * Ls)), replace=False)
+    if kind in ("copies", "all"):
+        dst = pick(0.05)
+        src = r2.integers(0, Ls, len(dst))
+        for d, s_ in zip(dst.tolist(), src.tolist()):
+            st[d] = r2.permutation(5).astype(st.dtype)[st[s_]]
+    if kind in ("gaps", "all"):
+        for d in pick(0.10).tolist():
+            st[d, r2.random(N) < r2.uniform(0.3, 0.7)] = 4
+    if kind in ("states", "all"):
+        for d in pick(0.10).tolist():
+            k = int(r2.integers(3, 6))
+            st[d] = r2.permutation(5)[:k].astype(st.dtype)[r2.integers(0, k, N)]
+    if kind in ("half", "all"):
+        for d in pick(0.10).tolist():
+            row = np.zeros(N, dtype=st.dtype)
+            row[r2.permutation(N)[: N // 2]] = 1
+            st[d] = r2.permutation(4)[:2].astype(st.dtype)[row]
+    return st
+
+
 def tables(eng):
     return eng.links(0), eng.links(1), eng.block_stats()
 
@@ -50,18 +79,24 @@ def main():
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--start", type=int, default=0, help="skip the cases before this one (their parameters are still drawn)")
+    ap.add_argument("--mutate", default="none", choices=["none", "copies", "gaps", "states", "half", "all", "mix"], help="rewrite part of every alignment (see mutate()); mix: a random kind per case")
+    ap.add_argument("--max-l", type=int, default=0, help="skip the cases with more SNPs than this (0: none; the host-side rewriting of --mutate is slow on the largest)")
     a = ap.parse_args()
     rs = np.random.default_rng(a.seed)
     bad = 0
     eng = Engine(0)
     for k in range(a.cases):
         p = case_params(rs)
-        if (a.only >= 0 and k != a.only) or k < a.start:
+        mkind = a.mutate if a.mutate != "mix" else str(np.random.default_rng(a.seed * 1000 + k).choice(["copies", "gaps", "states", "half", "all"]))
+        if (a.only >= 0 and k != a.only) or k < a.start or (a.max_l and p["L"] > a.max_l):
             continue
         t0 = time.time()
         syn = synth_alignment(p["L"], p["N"], seed=p["seed"], kind=p["kind"])
         st, POS, paint, g = syn["states"], syn["POS"].copy(), syn["paint"], float(syn["g"])
         r2 = np.random.default_rng(p["seed"])
+        if mkind != "none":
+            st = mutate(np.asarray(st), mkind, np.random.default_rng(p["seed"] + 1))
+            p = dict(p, mutate=mkind)
         if p["pos"] == "dense":          # a genome barely longer than the SNPs are many: nearly every pair is short-range at the larger distances
             POS = np.sort(r2.choice(np.arange(1, 3 * p["L"]), size=p["L"], replace=False)).astype(POS.dtype)
             g = float(3 * p["L"] + 7)
