@@ -27,7 +27,7 @@ pytestmark = pytest.mark.gpu
 
 def _case(rs):
     return dict(L=int(rs.choice([230, 517, 900, 1400])), N=int(rs.choice([17, 64, 129, 300])), B=int(rs.choice([1000, 2000])),
-                kind=str(rs.choice(["survey", "survey", "adversarial"])), weights=str(rs.choice(["hamming", "hamming", "few", "unit", "distinct"])),
+                kind=str(rs.choice(["survey", "survey", "adversarial"])), weights=str(rs.choice(["hamming", "hamming", "few", "unit", "distinct", "wide", "zeros"])),
                 thr=float(rs.choice([0.1, 0.3])), sr_dist=float(rs.choice([20000.0, 3000.0, 100000.0])), retain=float(rs.choice([2e3, 2e4, 1e6])),
                 quirk=int(rs.integers(0, 2)), seed=int(rs.integers(1, 10 ** 6)), mutate=str(rs.choice(["none", "none", "copies", "gaps", "states", "half", "all"])))
 
@@ -54,7 +54,9 @@ def test_random_problems_on_one_context_against_the_oracle(engine, seed):
         hd = engine.hamming_weights(int(p["L"] * p["thr"]))
         assert np.array_equal(hd, orc.hamming_weights(st, p["thr"])), tag
         hdw = {"hamming": hd, "unit": np.ones(p["N"]), "few": r2.choice([0.5, 0.25, 1.0 / 3, 0.02], size=p["N"]),
-               "distinct": 1.0 / (1.0 + r2.permutation(p["N"]))}[p["weights"]].astype(np.float64)
+               "distinct": 1.0 / (1.0 + r2.permutation(p["N"])), "wide": 10.0 ** r2.uniform(-5.0, 0.0, p["N"]),
+               "zeros": np.where(r2.random(p["N"]) < 0.2, 0.0, r2.choice([1.0, 0.5, 0.25, 1.0 / 3], size=p["N"]))}[p["weights"]].astype(np.float64)
+        hdw[0] = max(hdw[0], 0.25)   # (never all zero)
         engine.set_weights(hdw)
         engine.set_snp_meta(r, uqe, POS, paint, g)
         # joint counts of random pairs: bit-exact

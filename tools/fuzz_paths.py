@@ -20,11 +20,15 @@ from ldweaver_amd.mi import lr_links_approx, make_blocks  # noqa: E402
 from ldweaver_amd.synth import synth_alignment  # noqa: E402
 
 
+EXTRA_WEIGHTS = False   # --extra-weights: also weights over five orders of magnitude and weightings with a fifth of the sequences at weight 0 (not in the
+                        # default draw: the committed seeds keep their cases)
+
+
 def case_params(rs):
     Ls = int(rs.choice([700, 1500, 2600, 4100, 6000, 9000, 15000, 24000]))
     N = int(rs.choice([40, 130, 257, 616, 1000, 2100, 5000]))
     B = int(rs.choice([1000, 2000, 3000, 5000, 10000]))
-    return dict(L=Ls, N=N, B=B, kind=str(rs.choice(["survey", "survey", "adversarial"])), weights=str(rs.choice(["hamming", "hamming", "distinct", "unit", "few"])),
+    return dict(L=Ls, N=N, B=B, kind=str(rs.choice(["survey", "survey", "adversarial"])), weights=str(rs.choice(["hamming", "hamming", "distinct", "unit", "few"] + (["wide", "zeros"] if EXTRA_WEIGHTS else []))),
                 sr_dist=float(rs.choice([20000.0, 3000.0, 60000.0, 500.5])), retain=float(rs.choice([2e4, 2e5, 1e6, 3e3])), quirk=int(rs.integers(0, 2)),
                 pos=str(rs.choice(["recipe", "recipe", "dense", "shuffled_some"])), seed=int(rs.integers(1, 10 ** 6)))
 
@@ -81,7 +85,10 @@ def main():
     ap.add_argument("--start", type=int, default=0, help="skip the cases before this one (their parameters are still drawn)")
     ap.add_argument("--mutate", default="none", choices=["none", "copies", "gaps", "states", "half", "all", "mix"], help="rewrite part of every alignment (see mutate()); mix: a random kind per case")
     ap.add_argument("--max-l", type=int, default=0, help="skip the cases with more SNPs than this (0: none; the host-side rewriting of --mutate is slow on the largest)")
+    ap.add_argument("--extra-weights", action="store_true", help="also draw weights over five orders of magnitude and weightings with zeros")
     a = ap.parse_args()
+    global EXTRA_WEIGHTS
+    EXTRA_WEIGHTS = a.extra_weights
     rs = np.random.default_rng(a.seed)
     bad = 0
     eng = Engine(0)
@@ -115,6 +122,11 @@ def main():
             hdw = 1.0 / (1.0 + r2.permutation(p["N"]).astype(np.float64))
         elif p["weights"] == "unit":
             hdw = np.ones(p["N"])
+        elif p["weights"] == "wide":
+            hdw = 10.0 ** r2.uniform(-5.0, 0.0, p["N"])
+        elif p["weights"] == "zeros":
+            hdw = np.where(r2.random(p["N"]) < 0.2, 0.0, r2.choice([1.0, 0.5, 0.25, 1.0 / 3], size=p["N"]))
+            hdw[0] = 1.0
         else:
             hdw = r2.choice([0.5, 0.25, 1.0 / 3, 1.0 / 7, 0.02], size=p["N"])
         eng.set_weights(hdw)
