@@ -1015,6 +1015,11 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     }
 #ifdef LDW_EXPERIMENTS
     else if (tile == 22 && !P.fuse) LDW_APX_LAUNCH(2, 2)          // (the table epilogue assumes 64 from-rows per wave: NT = 2)
+    else if (tile == 224 && !P.fuse) {   // r05: 2 x 2 tiles built for FOUR waves per SIMD (<= 128 VGPRs)
+        const int ntx = P.RFpad / 64, nty = P.RTpad / 64;
+        if (P.fine) hipLaunchKernelGGL((gemm_apx_kernel<2, 2, true, 4>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((gemm_apx_kernel<2, 2, false, 4>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P);
+    }
     else if (tile == 24 && !P.fuse) LDW_APX_LAUNCH(2, 4)
     else if (tile == 32 && !P.fuse) {   // r05: 3 x 2 MFMA tiles per wave = 96 accumulators, built for THREE waves per SIMD (<= 170 VGPRs)
         const int ntx = P.RFpad / 64, nty = (P.RTpad + 95) / 96;
@@ -1027,7 +1032,7 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     LDW_HIP(hipGetLastError());
     {   // executed work (ldw_gemm_stats): waves that do not leave at once, each 2 * rows_t * rows_f * K int8 operations
         const int tl = P.fuse ? 42 : tile;
-        const int MTv = tl == 22 || tl == 24 ? 2 : (tl == 32 ? 3 : 4), NTv = tl == 24 ? 4 : 2, TH = 32 * MTv, TWd = 32 * NTv;
+        const int MTv = tl == 22 || tl == 24 || tl == 224 ? 2 : (tl == 32 ? 3 : 4), NTv = tl == 24 ? 4 : 2, TH = 32 * MTv, TWd = 32 * NTv;
         int64_t waves = 0;
         for (int ty = 0; ty * TH < P.RTpad; ++ty) {
             const int ntx = P.RFpad / TWd;
