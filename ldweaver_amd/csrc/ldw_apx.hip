@@ -245,6 +245,14 @@ int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *pa
 // ------------------------------------------------------------------------------------------------
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+// Wave tile of the pruned, table-fused launches (the default path's): APX_MT x 2 MFMA tiles of 32 x 32.  4 (128 to-rows x 64 from-rows, two
+// waves per SIMD) since r02; -DLDW_APX_MT=2: 64 x 64 at FOUR waves per SIMD (<= 128 VGPRs) with the tile list, the band mask test and the
+// epilogue's regions at 64-row granularity (r05).
+#ifndef LDW_APX_MT
+#define LDW_APX_MT 4
+#endif
+constexpr int APX_MT = LDW_APX_MT, APX_WPS = APX_MT == 2 ? 4 : 2;
+static_assert(APX_MT == 2 || APX_MT == 4, "LDW_APX_MT must be 2 or 4");
 
 #ifdef LDW_APX_SDWA
 // r05 experiment, measured SLOWER (DESIGN 5.1c "r05: SDWA"; tools/r05_sdwa_ab.sh): byte B of a dword, times 8 (the byte offset of its entry in the
@@ -320,7 +328,7 @@ __device__ __forceinline__ void apx_gemm_epilogue(const ApxGemmArgs &P, v16i (&a
             bool ok = true;
 #pragma unroll
             for (int j = 0; j < NT; ++j) ok = ok && bf[j] != 255;
-            if (P.sr_mask && P.sr_mask[(int64_t)ty * (P.RFpad / 64) + tx] != 0) ok = false;   // (TH = 128, TWd = 64: the band mask's own tiles)
+            if (P.sr_mask && P.sr_mask[(int64_t)((ty * TH) / 128) * (P.RFpad / 64) + tx] != 0) ok = false;   // (the band mask's tiles are 128 x 64; TWd = 64)
             int bt[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -442,7 +450,7 @@ __device__ __forceinline__ TileSummary apx_fold_rows(const uint8_t *__restrict__
 }
 
 __global__ __launch_bounds__(256) void k_apx_live_tiles(ApxGemmArgs P) {
-    constexpr int MT = 4, NT = 2, TH = 32 * MT, TWd = 32 * NT;
+    constexpr int MT = APX_MT, NT = 2, TH = 32 * MT, TWd = 32 * NT;
     __shared__ unsigned int s_wave[4], s_base;
     const int ty = (int)blockIdx.x, ntx = P.RFpad / TWd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(256) void k_apx_live_tiles(ApxGemmArgs P) {
         // (a diagonal block: the tiles above the diagonal of row positions are not part of the GEMM at all — their regions keep the zero the host set)
         const bool valid = tx < ntx && !(P.lower_only && tx * TWd + TWd - 1 < ty * TH);
         bool pruned = false, all_binned = false;
-        if (valid && !(P.sr_mask && P.sr_mask[(int64_t)ty * (P.RFpad / 64) + tx] != 0)) {
+        if (valid && !(P.sr_mask && P.sr_mask[(int64_t)((ty * TH) / 128) * (P.RFpad / 64) + tx] != 0)) {
             const TileSummary F = apx_fold_rows(P.bin_f + (int64_t)tx * TWd, P.rflag_f ? P.rflag_f + (int64_t)tx * TWd : nullptr, TWd);
             all_binned = T.bmax < P.tab_nb && F.bmax < P.tab_nb;
             if (P.rflag_t) {   // the wider tables: rows of ONE kind per side, one side dead versus the other's kind (k_snp_sup)
@@ -938,7 +946,7 @@ __global__ __launch_bounds__(512, 1) void gemm_apx_lds_kernel(ApxGemmArgs P) {
 int launch_apx_live_tiles(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     LDW_REQUIRE(P.fuse && P.skip_ctr && P.tile_list && P.n_live && P.RTpad % 128 == 0 && P.RFpad % 64 == 0 && P.tab && P.tab_nb == 64,
                 LDW_ERR_ARG, "launch_apx_live_tiles: bad pruning arguments");
-    hipLaunchKernelGGL(k_apx_live_tiles, dim3((unsigned)(P.RTpad / 128)), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_apx_live_tiles, dim3((unsigned)(P.RTpad / (32 * APX_MT))), dim3(256), 0, st, P);
     LDW_HIP(hipGetLastError());
     return LDW_OK;
 }
@@ -1009,9 +1017,9 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     }
     if (P.skip_ctr) {
         LDW_REQUIRE(P.fuse && P.tile_list && P.n_live && P.RFpad % 64 == 0, LDW_ERR_ARG, "launch_gemm_apx: bad pruning arguments");
-        const int tiles = (P.RTpad / 128) * (P.RFpad / 64), g = (tiles + 3) / 4;   // (the list is made by launch_apx_live_tiles)
-        if (P.fine) hipLaunchKernelGGL((gemm_apx_kernel<4, 2, true>), dim3((unsigned)g), dim3(256), lds, st, P);
-        else hipLaunchKernelGGL((gemm_apx_kernel<4, 2, false>), dim3((unsigned)g), dim3(256), lds, st, P);
+        const int tiles = (P.RTpad / (32 * APX_MT)) * (P.RFpad / 64), g = (tiles + 3) / 4;   // (the list is made by launch_apx_live_tiles)
+        if (P.fine) hipLaunchKernelGGL((gemm_apx_kernel<APX_MT, 2, true, APX_WPS>), dim3((unsigned)g), dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((gemm_apx_kernel<APX_MT, 2, false, APX_WPS>), dim3((unsigned)g), dim3(256), lds, st, P);
     }
 #ifdef LDW_EXPERIMENTS
     else if (tile == 22 && !P.fuse) LDW_APX_LAUNCH(2, 2)          // (the table epilogue assumes 64 from-rows per wave: NT = 2)
@@ -1032,7 +1040,7 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     LDW_HIP(hipGetLastError());
     {   // executed work (ldw_gemm_stats): waves that do not leave at once, each 2 * rows_t * rows_f * K int8 operations
         const int tl = P.fuse ? 42 : tile;
-        const int MTv = tl == 22 || tl == 24 || tl == 224 ? 2 : (tl == 32 ? 3 : 4), NTv = tl == 24 ? 4 : 2, TH = 32 * MTv, TWd = 32 * NTv;
+        const int MTv = (P.fuse && P.skip_ctr) ? APX_MT : (tl == 22 || tl == 24 || tl == 224 ? 2 : (tl == 32 ? 3 : 4)), NTv = tl == 24 ? 4 : 2, TH = 32 * MTv, TWd = 32 * NTv;
         int64_t waves = 0;
         for (int ty = 0; ty * TH < P.RTpad; ++ty) {
             const int ntx = P.RFpad / TWd;
