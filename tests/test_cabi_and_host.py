@@ -270,6 +270,33 @@ def test_cpu_share_and_thread_pool_limits(monkeypatch):
     assert os.environ["OMP_NUM_THREADS"] == "5" and os.environ["OPENBLAS_NUM_THREADS"] == "3"
 
 
+def test_r_shim_type_checks_and_links_against_the_library(tmp_path):
+    """The image has no R, so the shim (r_shim/ldweaver_amd_shim.c) had never met a compiler: gcc type-checks it here against include/ldweaver_amd.h and a
+    DECLARATION-ONLY stand-in for the part of R's C API it uses (tests/r_api_mock/: test infrastructure, not R) — wrong arities or pointer types in a
+    call into the library are errors — and every ldw_* symbol the object needs must be exported by the built library."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or shutil.which("nm") is None:
+        pytest.skip("no gcc / nm")
+    src = os.path.join(ROOT, "r_shim", "ldweaver_amd_shim.c")
+    inc = ["-I", os.path.join(ROOT, "tests", "r_api_mock"), "-I", os.path.join(ROOT, "include")]
+    r = subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-cast-function-type", "-Werror"] + inc + [src],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    obj = str(tmp_path / "shim.o")
+    r = subprocess.run(["gcc", "-std=c11", "-c", "-fPIC"] + inc + [src, "-o", obj], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    needs = {ln.split()[-1] for ln in subprocess.run(["nm", "-u", obj], capture_output=True, text=True).stdout.splitlines() if ln.split()[-1].startswith("ldw_")}
+    assert len(needs) >= 30, sorted(needs)
+    lib = L.lib()
+    missing = [n for n in sorted(needs) if not hasattr(lib, n)]
+    assert not missing, missing
+    # the six routines of the reference's registration table (src/RcppExports.cpp:154-160) are defined by the object
+    defined = {ln.split()[-1] for ln in subprocess.run(["nm", "--defined-only", obj], capture_output=True, text=True).stdout.splitlines() if ln.strip()}
+    for name in ("_LDWeaver_ACGTN2num", "_LDWeaver_fastHadamard", "_LDWeaver_compareToRow", "R_init_ldweaver_amd_shim"):
+        assert name in defined, name
+
+
 def test_r_shim_is_consistent_with_itself_and_the_header():
     """The R shim cannot be compiled here (no R headers in the image), so it is checked statically: every `.Call("ldwamd_*", ...)` of
     r_shim/ldweaver_amd.R names a routine registered in the shim's R_CallMethodDef table with the number of arguments the call passes; every
