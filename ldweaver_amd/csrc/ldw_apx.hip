@@ -252,7 +252,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #define LDW_APX_MT 4
 #endif
 constexpr int APX_MT = LDW_APX_MT, APX_WPS = APX_MT == 2 ? 4 : 2;
-static_assert(APX_MT == 2 || APX_MT == 4, "LDW_APX_MT must be 2 or 4");
+static_assert(APX_MT == 2 || APX_MT == 4 || APX_MT == 5, "LDW_APX_MT must be 2, 4 or 5");
 
 #ifdef LDW_APX_SDWA
 // r05 experiment, measured SLOWER (DESIGN 5.1c "r05: SDWA"; tools/r05_sdwa_ab.sh): byte B of a dword, times 8 (the byte offset of its entry in the
@@ -405,7 +405,7 @@ __device__ __forceinline__ void apx_gemm_epilogue(const ApxGemmArgs &P, v16i (&a
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int trow = ty * TH + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    if (128 % TH == 0 || trow < P.RTpad) P.G[(int64_t)trow * P.RFpad + fcol] = acc[i][j][e];
+                    if ((128 % TH == 0 || trow < P.RTpad) && (64 % TWd == 0 || fcol < P.RFpad)) P.G[(int64_t)trow * P.RFpad + fcol] = acc[i][j][e];
                 }
             }
         }
@@ -572,7 +572,11 @@ __global__ __launch_bounds__(256, WPS) void gemm_apx_kernel(ApxGemmArgs P) {
             pa[i] = P.panel_t + ((int64_t)rt * 2 + fh);
         }
 #pragma unroll
-        for (int i = 0; i < NT; ++i) pb[i] = P.panel_f + ((int64_t)(tx * TWd + 32 * i + frow) * 2 + fh);
+        for (int i = 0; i < NT; ++i) {
+            int rf = tx * TWd + 32 * i + frow;
+            if (64 % TWd != 0 && rf >= P.RFpad) rf = P.RFpad - 1;   // (only the 96-column tiles of the r05 experiments can run past RFpad, a multiple of 64)
+            pb[i] = P.panel_f + ((int64_t)rf * 2 + fh);
+        }
         v16i acc[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -1023,6 +1027,11 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     }
 #ifdef LDW_EXPERIMENTS
     else if (tile == 22 && !P.fuse) LDW_APX_LAUNCH(2, 2)          // (the table epilogue assumes 64 from-rows per wave: NT = 2)
+    else if (tile == 33 && !P.fuse) {   // r05: 3 x 3 MFMA tiles per wave (96 x 96: 6 fragments per 9 MFMAs instead of 6 per 8), two waves per SIMD
+        const int ntx = (P.RFpad + 95) / 96, nty = (P.RTpad + 95) / 96;
+        if (P.fine) hipLaunchKernelGGL((gemm_apx_kernel<3, 3, true, 2>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((gemm_apx_kernel<3, 3, false, 2>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P);
+    }
     else if (tile == 224 && !P.fuse) {   // r05: 2 x 2 tiles built for FOUR waves per SIMD (<= 128 VGPRs)
         const int ntx = P.RFpad / 64, nty = P.RTpad / 64;
         if (P.fine) hipLaunchKernelGGL((gemm_apx_kernel<2, 2, true, 4>), dim3((unsigned)((ntx + 1) / 2), (unsigned)((nty + 1) / 2)), dim3(256), lds, st, P);
@@ -1040,7 +1049,7 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     LDW_HIP(hipGetLastError());
     {   // executed work (ldw_gemm_stats): waves that do not leave at once, each 2 * rows_t * rows_f * K int8 operations
         const int tl = P.fuse ? 42 : tile;
-        const int MTv = (P.fuse && P.skip_ctr) ? APX_MT : (tl == 22 || tl == 24 || tl == 224 ? 2 : (tl == 32 ? 3 : 4)), NTv = tl == 24 ? 4 : 2, TH = 32 * MTv, TWd = 32 * NTv;
+        const int MTv = (P.fuse && P.skip_ctr) ? APX_MT : (tl == 22 || tl == 24 || tl == 224 ? 2 : (tl == 32 || tl == 33 ? 3 : 4)), NTv = tl == 24 ? 4 : (tl == 33 ? 3 : 2), TH = 32 * MTv, TWd = 32 * NTv;
         int64_t waves = 0;
         for (int ty = 0; ty * TH < P.RTpad; ++ty) {
             const int ntx = P.RFpad / TWd;
