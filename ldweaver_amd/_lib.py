@@ -115,6 +115,10 @@ _SIGS = {
     "ldw_snp_bounds": (C.c_int, [_p, _p, C.c_int64]),
     "ldw_debug_violations": (C.c_int, [_p, _p]),
     "ldw_debug_tab11": (C.c_int, [_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _p, _p]),
+    "ldw_debug_apx_params": (C.c_int, [_p, _p, _p, _p, _i64]),
+    "ldw_debug_rows": (C.c_int, [_p, _p, _p, _i64]),
+    "ldw_debug_apx_gemm": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, _p]),
+    "ldw_debug_screen_bound": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "ldw_format_number": (C.c_int, [C.c_double, C.c_char_p, C.c_int]),
     "ldw_r_sample": (C.c_int, [C.c_uint32, C.c_int64, C.c_int64, _p]),
     "ldw_write_table_tsv": (C.c_int, [C.c_char_p, C.c_int, _i64, C.c_int, _p, _p, C.c_int, C.POINTER(_i64)]),

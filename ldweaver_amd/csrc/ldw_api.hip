@@ -1,5 +1,6 @@
 // Context, residency, set-up kernels and the small element-wise twins of libldweaver_amd.so.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -67,6 +68,18 @@ void *pool_take(size_t want, size_t &cap_out) {
     g_pool.pop_back();
     return p;
 }
+// r06: a caller that has drained every stream that could touch its blocks (ldw_ctx_destroy: the context's own streams) says so for the
+// duration of its releases, and the device-wide synchronisation — which stalls OTHER contexts of the device in the middle of their passes — is skipped
+thread_local bool g_owner_drained = false;
+std::atomic<int> g_live_ctx{0};
+size_t pool_idle_limit() {   // what the free list may keep once the process holds no context at all (LDW_DEVPOOL_IDLE_GB, default 24; the live cap is LDW_DEVPOOL_GB)
+    static const size_t v = [] {
+        const char *e = getenv("LDW_DEVPOOL_IDLE_GB");
+        const double gb = e ? atof(e) : 24.0;
+        return gb > 0 ? (size_t)(gb * 1073741824.0) : (size_t)0;
+    }();
+    return v;
+}
 void pool_give(void *p, size_t cap) {
     if (!p) return;
     if (cap >= POOL_MIN && pool_limit() > 0) {
@@ -75,7 +88,7 @@ void pool_give(void *p, size_t cap) {
             int cur = 0;
             (void)hipGetDevice(&cur);
             if (cur != at.device) (void)hipSetDevice(at.device);
-            const bool drained = hipDeviceSynchronize() == hipSuccess;   // (the releasing context's kernels are done with it: what hipFree waits for as well)
+            const bool drained = g_owner_drained || hipDeviceSynchronize() == hipSuccess;   // (the releasing context's kernels are done with it: what hipFree waits for as well)
             if (cur != at.device) (void)hipSetDevice(cur);
             if (drained) {
                 std::lock_guard<std::mutex> lk(g_pool_mtx);
@@ -90,12 +103,22 @@ void pool_give(void *p, size_t cap) {
     }
     (void)hipFree(p);
 }
-size_t pool_flush() {
+// keep: bytes the list may hold afterwards (0: give everything back); the largest blocks go first
+size_t pool_flush(size_t keep = 0) {
     std::vector<PoolBlock> all;
     {
         std::lock_guard<std::mutex> lk(g_pool_mtx);
-        all.swap(g_pool);
-        g_pool_bytes = 0;
+        if (keep == 0) {
+            all.swap(g_pool);
+            g_pool_bytes = 0;
+        } else {
+            std::sort(g_pool.begin(), g_pool.end(), [](const PoolBlock &x, const PoolBlock &y) { return x.cap < y.cap; });
+            while (g_pool_bytes > keep && !g_pool.empty()) {
+                all.push_back(g_pool.back());
+                g_pool_bytes -= g_pool.back().cap;
+                g_pool.pop_back();
+            }
+        }
     }
     size_t n = 0;
     int cur = 0;
@@ -120,6 +143,7 @@ bool poison_on() {
 void poison_fill(void *p, size_t bytes) {
     static const int mode = getenv("LDW_POISON_ALLOC") ? atoi(getenv("LDW_POISON_ALLOC")) : 0;
     if (mode == 2) (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), 1, bytes / 4);
+    else if (mode == 3) (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), 0x00000A5A, bytes / 4);   // a second in-range pattern: index 2650, flags set, float denormal
     else (void)hipMemset(p, 0xA5, bytes);
     (void)hipDeviceSynchronize();
 }
@@ -145,12 +169,29 @@ hipError_t dev_alloc(void **out, size_t want, size_t &cap_out) {
         if (pool_flush() > 0) e = hipMalloc(out, want);
     }
     cap_out = want;
+    // r06: a block from the runtime is zero-filled as well.  HIP does not promise zeroed memory (the runtime re-uses what it freed below ~16 GB), and
+    // "a fresh DevBuf reads as zero" is an invariant the engine may rely on — stated here, instead of an accident of the stack.  It is NOT what makes stale data
+    // harmless: a DevBuf kept across problems holds the last problem's bytes, which tools/fuzz_paths.py / tests exercise by running problem after problem on one context.
+    if (e == hipSuccess) {
+        e = hipMemsetAsync(*out, 0, want, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(*out);
+            *out = nullptr;
+        }
+    }
     if (e == hipSuccess && poison_on()) poison_fill(*out, want);
     return e;
 }
 }  // namespace
 
 size_t device_pool_trim() { return pool_flush(); }
+void ctx_count(int d) {
+    if (g_live_ctx.fetch_add(d) + d <= 0 && d < 0) (void)pool_flush(pool_idle_limit() ? pool_idle_limit() : 0);   // the last context of the process has gone
+}
+DrainedScope::DrainedScope() { g_owner_drained = true; }
+DrainedScope::~DrainedScope() { g_owner_drained = false; }
 
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap && p) return LDW_OK;
@@ -374,6 +415,7 @@ int ldw_ctx_create(int device, ldw_ctx **out) {
         return LDW_ERR_NOGPU;
     }
     ldw_ctx *c = new ldw_ctx();
+    ldw::ctx_count(+1);
     c->device = device;
     c->prune = getenv("LDW_NO_PRUNE") == nullptr;
     LDW_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -461,6 +503,11 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     (void)ldw_tsv_join(c);
     (void)ldw_lr_stream_end(c, nullptr, nullptr, nullptr);
     (void)hipStreamSynchronize(c->stream);
+    if (c->gemm_stream) (void)hipStreamSynchronize(c->gemm_stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->lr_st) (void)hipStreamSynchronize(c->lr_st);
+    {
+    ldw::DrainedScope drained;   // every stream that could touch this context's blocks is idle: no device-wide synchronisation per released block
     c->logtab.release();
     ldw::DevBuf *bufs[] = {&c->srm_tmp, &c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->apx_skip, &c->snp_sup, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
@@ -485,6 +532,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
         if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
     }
     c->dstage[LDW_NSLOT].release();   // (the staging of a span segment redone on its own)
+    }
     if (c->pin[LDW_NSLOT]) (void)hipHostFree(c->pin[LDW_NSLOT]);
     for (int k = 0; k < LDW_NSLOT; ++k) {
         if (c->pin_pick[k]) (void)hipHostFree(c->pin_pick[k]);
@@ -505,6 +553,7 @@ int ldw_ctx_destroy(ldw_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    ldw::ctx_count(-1);
     return LDW_OK;
 }
 

@@ -2,6 +2,7 @@
 // (ldw_fused.hip): histogram buckets, short-range interval tests, the fp64 log helpers, the per-pair MI
 // (src/computeMI.cpp:19 cell by cell) and the emission of one finished pair.
 #pragma once
+#include <cmath>
 #include "ldw_internal.h"
 #include "ldw_dev.h"
 
@@ -166,7 +167,29 @@ struct EmitArgs {
     // apx_unit = 2^(e_last - F)
     float apx_c1;
     double apx_W, apx_unit;
+    // r06: units a MARGINAL of the approximate weights is below its sum: slot_papx = floor(sum V' / 2^e_last) loses less than one — and nothing when e_last = 0
+    // (unit weights: V' = V = 1, a unit is a whole sequence and one lost unit per derived cell made the bound useless there: tests/test_bounds.py)
+    float apx_MU;
 };
+
+// The constants of the approximate path's screen bound (full_cells_screen<.., APX>, pair_screen_generic<APX>) from the context's weights: the
+// screen reads int32 sums of the approximate weights V' in units of 2^e_last; its bound of the exact MI carries the relative error delta of the
+// weights and the units lost to truncation.  One place for the engine (make_emit_args, ldw_mi_items.inc) and the test hook (ldw_debug_apx_params):
+// BOUNDS.md 3 states what each constant has to cover.
+inline void apx_screen_params(const ldw_ctx *c, EmitArgs &E, bool r02_bound = false) {
+    const double den = c->neff > 1.0 ? c->neff : 1.0;
+    E.apx = 1;
+    E.apx_EG = (float)(c->apx_lost_units * 1.001);
+    E.apx_dfac = (float)(1.01 * c->apx_delta / (1.0 - c->apx_delta));
+    E.apx_unit = std::ldexp(1.0, c->apx_e_last - c->frac_bits);
+    E.apx_s1 = (float)(E.apx_unit * (2.0 * std::log(den + 12.5) + (r02_bound ? 3.1 : 2.1)) / (1.0 - c->apx_delta) * 1.01);
+    E.apx_c1 = r02_bound ? 1.02f : 0.02f;
+    E.apx_W = r02_bound ? 0.0 : std::ldexp((double)c->total_fixed, -c->frac_bits);
+    E.scr_shift = 0;
+    E.scr_scale = (float)std::ldexp(1.0, c->apx_e_last - c->frac_bits);
+    E.scr_eps = 2e-4f;   // SCREEN_EPS (below)
+    E.apx_MU = c->apx_e_last == 0 ? 0.0f : 1.0f;
+}
 
 __device__ __forceinline__ void emit_pair(const EmitArgs &E, const ColInfo &c, int a_loc, int b_loc, int sa, int sb,
                                           double mi, unsigned int *sh_hist) {
@@ -678,11 +701,11 @@ __device__ __forceinline__ float full_cells_screen(const EpiArgs &A, const RowSi
     if (APX) {
         // units (2^e_last) by which the cells of this table can be off, summed over the cells.  A GEMM entry n' is at most EG units
         // below its sum (truncation at the exponent transitions), a marginal less than 1 unit below (floor), and the errors of a
-        // derived cell have OPPOSITE signs: row-derived (i, NB) = pa_i - sum_j n_ij is off by (-NB EG, 1), column-derived likewise,
-        // the corner pa_NA - sum_j pb_j + sum_ij n_ij by (-NB, 1 + NA NB EG).
-        const float EG = A.E.apx_EG;
-        const float lost_units = (float)(NA * NB) * EG + (float)NA * fmaxf(1.0f, (float)NB * EG) + (float)NB * fmaxf(1.0f, (float)NA * EG) +
-                                 fmaxf((float)NB, 1.0f + (float)(NA * NB) * EG);
+        // derived cell have OPPOSITE signs: row-derived (i, NB) = pa_i - sum_j n_ij is off by (-NB EG, MU), column-derived likewise,
+        // the corner pa_NA - sum_j pb_j + sum_ij n_ij by (-NB MU, MU + NA NB EG); MU = 1, or 0 where the marginals are exact (EmitArgs::apx_MU).
+        const float EG = A.E.apx_EG, MU = A.E.apx_MU;
+        const float lost_units = (float)(NA * NB) * EG + (float)NA * fmaxf(MU, (float)NB * EG) + (float)NB * fmaxf(MU, (float)NA * EG) +
+                                 fmaxf((float)NB * MU, MU + (float)(NA * NB) * EG);
         float dW = 0.0f;
         if (A.E.apx_W > 0.0) {   // sum (x - x') <= W - (sum of the from-side SNP's approximate marginals), in weight units (+ rounding room)
             int64_t ta = 0;
@@ -759,8 +782,8 @@ __device__ __forceinline__ float pair_screen_generic(const EpiArgs &A, const Row
         }
     }
     if (APX) {   // see full_cells_screen: the units the cells can be off by, for na x nb indicator rows
-        const float EG = A.E.apx_EG, fa = (float)na, fb = (float)nb;
-        const float lost_units = fa * fb * EG + fa * fmaxf(1.0f, fb * EG) + fb * fmaxf(1.0f, fa * EG) + fmaxf(fb, 1.0f + fa * fb * EG);
+        const float EG = A.E.apx_EG, MU = A.E.apx_MU, fa = (float)na, fb = (float)nb;
+        const float lost_units = fa * fb * EG + fa * fmaxf(MU, fb * EG) + fb * fmaxf(MU, fa * EG) + fmaxf(fb * MU, MU + fa * fb * EG);
         // (tables with unflagged cells: the totals argument of full_cells_screen does not apply; the r02 form, apx_s1 + one unit of |ln| + 1)
         const float extra = A.E.apx_dfac * fmaf(acc_abs, 0.6931471805599453f, 1.02f * xsum) + lost_units * (A.E.apx_s1 + (float)A.E.apx_unit * 1.02f);
         return fmaf(acc, 0.6931471805599453f, extra) * __builtin_amdgcn_rcpf(den);

@@ -273,6 +273,7 @@ int ldw_links_begin(ldw_ctx *c, int64_t nblocks_capacity) {
     c->n_sr = 0;
     c->n_lr = 0;
     c->stats.clear();
+    c->multi_owner.clear();   // (a deal of ldw_mi_all_pairs_multi(.., LDW_MI_SR_ROWS_STAY) describes the tables of THAT pass only: ADVICE r05)
     c->trace.clear();
     c->blk_capacity = nblocks_capacity;
     c->blk_cursor = 0;
@@ -1110,7 +1111,9 @@ int ldw_links_import(ldw_ctx *c, int which, const int32_t *a, const int32_t *b, 
         LDW_HIP(hipStreamSynchronize(c->stream));
     }
     (which == 0 ? c->n_sr : c->n_lr) = n;
-    c->n_red = c->n_pool = 0;   // whatever was derived from the old table is stale
+    c->n_red = c->n_pool = 0;   // whatever was derived from the old table is stale:
+    c->stats.clear();           // the per-block records of the pass that made it (ldw_block_stats answers LDW_ERR_ARG until the next pass) ...
+    c->multi_owner.clear();     // ... and the deal of an in-process pass whose shares these rows replace
     return LDW_OK;
 }
 

@@ -68,6 +68,7 @@ int ldw_deal_blocks(const int32_t *blocks, int64_t nblocks, int n_ranks, int32_t
 }
 
 int ldw_mi_all_pairs_multi(ldw_ctx **ctx, int n_ctx, const int32_t *blocks, int64_t nblocks, const ldw_mi_params *p, int32_t *owner_out, double *ms_out) {
+    if (ctx && n_ctx >= 1 && ctx[0]) ctx[0]->multi_owner.clear();   // whatever this call returns, the deal of an EARLIER call no longer describes ctx[0]
     LDW_REQUIRE(ctx && n_ctx >= 1 && n_ctx <= 64 && blocks && p && nblocks > 0, LDW_ERR_ARG, "ldw_mi_all_pairs_multi: bad argument");
     for (int k = 0; k < n_ctx; ++k) {
         LDW_REQUIRE(ctx[k], LDW_ERR_ARG, "ldw_mi_all_pairs_multi: context %d is null", k);

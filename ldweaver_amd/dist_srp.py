@@ -233,8 +233,20 @@ def merge_n_sort_sr_links_dist(eng, nclust: int, sr_dist: float, srp_cutoff: flo
         ms[what] = (now - mark[1]) * 1e3
         mark[0], mark[1] = cm.bytes_sent, now
 
+    def local(what, fn):
+        """A rank-local stage between two exchanges: run it, then let every rank learn whether it failed ANYWHERE before anybody enters the
+        next exchange (a rank that raises — out of memory at config 5, a refused argument — would otherwise leave the others blocked in an
+        all-reduce / gather until the backend's timeout).  One int32 all-reduce per stage (``dist.agree``); nothing when there is one rank."""
+        out, err = None, None
+        try:
+            out = fn()
+        except Exception as e:
+            err = e
+        cm.agree(err, f"the short-range model's '{what}' stage")
+        return out
+
     # 1. order statistics per (cluster, len)
-    qlo, qhi, cnt = eng.sr_len_quantiles(nclust, sr_dist, 0.95)
+    qlo, qhi, cnt = local("len quantiles", lambda: eng.sr_len_quantiles(nclust, sr_dist, 0.95))
     S = qlo.shape[1]
     n_total = cm.all_reduce(cnt, "sum")
     lower = cm.all_reduce(np.where(cnt > 0, qlo, np.inf), "min")
@@ -243,11 +255,11 @@ def merge_n_sort_sr_links_dist(eng, nclust: int, sr_dist: float, srp_cutoff: flo
     # memory twice on every rank and once more on rank 0 would be most of the step); gloo and the in-process ranks use host arrays
     on_dev = (not cm.alone) and cm.dev is not None and cm.dev.type == "cuda" and hasattr(eng, "_ctx")
     if on_dev:
-        tcnt, tmi = eng.sr_tail_extract(lower, on_device=True)
+        tcnt, tmi = local("tail extract", lambda: eng.sr_tail_extract(lower, on_device=True))
         took("bounds")
         cnts, mis = cm.gatherv(tcnt.reshape(-1)), _gatherv_device(cm, tmi)
     else:
-        tcnt, tmi = eng.sr_tail_extract(lower)
+        tcnt, tmi = local("tail extract", lambda: eng.sr_tail_extract(lower))
         took("bounds")
         cnts, mis = cm.gatherv(tcnt.reshape(-1)), cm.gatherv(tmi)
     took("candidates")
@@ -278,35 +290,43 @@ def merge_n_sort_sr_links_dist(eng, nclust: int, sr_dist: float, srp_cutoff: flo
     md = cm.bcast(md, (nclust, S), np.float64)
     took("fitted_decay")
     # 2. excess statistics: per block, summed in make_blocks order (adding the zeros of the other ranks' blocks is exact)
-    part = np.zeros((len(n_sr_blocks), nclust, 5))
-    if len(my_blocks):
-        part[my_blocks] = eng.sr_excess_stats_blocks(md, rows_mine)
-    part = cm.all_reduce(part, "sum")
+    def block_sums():
+        part = np.zeros((len(n_sr_blocks), nclust, 5))
+        if len(my_blocks):
+            part[my_blocks] = eng.sr_excess_stats_blocks(md, rows_mine)
+        return part
+    part = cm.all_reduce(local("block sums", block_sums), "sum")
     took("block_sums")
     stats = np.zeros((nclust, 5))
     for b in range(len(n_sr_blocks)):
         stats += part[b]
-    shape = np.empty((nclust, 3))
-    for ci in range(nclust):
-        a_, b_ = beta_mle_stats(*stats[ci])
-        shape[ci] = a_, b_, _betaln(a_, b_)
     # 3. p-values where the rows lie; 4. the pool for the minimum over ranks
-    n_red_local, min_local = eng.sr_pvalues_local(md, shape, srp_cutoff)
+    def pvalues():
+        shape = np.empty((nclust, 3))
+        for ci in range(nclust):
+            a_, b_ = beta_mle_stats(*stats[ci])
+            shape[ci] = a_, b_, _betaln(a_, b_)
+        return (shape,) + tuple(eng.sr_pvalues_local(md, shape, srp_cutoff))
+    shape, n_red_local, min_local = local("p-values", pvalues)
     min_mi = float(cm.all_reduce(np.array([min_local if n_red_local else np.inf]), "min")[0])
-    n_pool_local = eng.sr_pool_build(min_mi) if np.isfinite(min_mi) else 0
-    red = eng.sr_reduced()
-    pa, pb, pmi = eng.sr_pool() if n_pool_local else (np.empty(0, np.int32), np.empty(0, np.int32), np.empty(0))
-    # rows of this rank's table -> rows of the job's table in make_blocks order
-    loc_off = np.concatenate([[0], np.cumsum(rows_mine)])
-    glo_off = np.concatenate([[0], np.cumsum(n_sr_blocks)])
-    bi = np.searchsorted(loc_off, red["row"], side="right") - 1
-    rec = np.zeros(n_red_local, dtype=RED_DT)
-    rec["row"] = glo_off[my_blocks[bi]] + (red["row"] - loc_off[bi])
-    for k in ("MI", "srp_max", "a", "b", "clust_c", "first_clust"):
-        rec[k] = red[k]
-    rec["dup"] = red["dup"]
-    prec = np.zeros(n_pool_local, dtype=POOL_DT)
-    prec["MI"], prec["a"], prec["b"] = pmi, pa, pb
+
+    def kept_and_pool():
+        n_pool_local = eng.sr_pool_build(min_mi) if np.isfinite(min_mi) else 0
+        red = eng.sr_reduced()
+        pa, pb, pmi = eng.sr_pool() if n_pool_local else (np.empty(0, np.int32), np.empty(0, np.int32), np.empty(0))
+        # rows of this rank's table -> rows of the job's table in make_blocks order
+        loc_off = np.concatenate([[0], np.cumsum(rows_mine)])
+        glo_off = np.concatenate([[0], np.cumsum(n_sr_blocks)])
+        bi = np.searchsorted(loc_off, red["row"], side="right") - 1
+        rec = np.zeros(n_red_local, dtype=RED_DT)
+        rec["row"] = glo_off[my_blocks[bi]] + (red["row"] - loc_off[bi])
+        for k in ("MI", "srp_max", "a", "b", "clust_c", "first_clust"):
+            rec[k] = red[k]
+        rec["dup"] = red["dup"]
+        prec = np.zeros(n_pool_local, dtype=POOL_DT)
+        prec["MI"], prec["a"], prec["b"] = pmi, pa, pb
+        return rec, prec
+    rec, prec = local("kept links and pool", kept_and_pool)
     took("minimum")
     reds, pools = cm.gatherv(rec), cm.gatherv(prec)
     took("kept_links_and_pool")

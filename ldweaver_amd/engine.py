@@ -131,6 +131,52 @@ class Engine:
         L.check(L.lib().ldw_snp_bounds(self._ctx, L.ptr(out), out.size))
         return out.reshape(self.L, 2, 2)
 
+    # -- test hooks: the bounds of the default path as functions (BOUNDS.md; csrc/ldw_debug.hip) --------------------
+    APX_PARAM_NAMES = ("F", "e_last", "delta", "lost_units", "total_fixed", "neff", "apx_EG", "apx_dfac", "apx_s1", "apx_c1", "apx_W", "apx_unit", "scr_scale",
+                       "scr_shift_exact", "scr_scale_exact", "flags")
+
+    def debug_apx_params(self, want_weights: bool = True):
+        """(params[16], V[N], V'[N]): the constants of the approximate screen's bound for the current weights (names: APX_PARAM_NAMES) and, per sequence, the
+        exact fixed-point weight and its dual-digit approximation."""
+        out = np.zeros(16)
+        V = np.zeros(self.N if want_weights else 0, dtype=np.int64)
+        Va = np.zeros(self.N if want_weights else 0, dtype=np.int64)
+        L.check(L.lib().ldw_debug_apx_params(self._ctx, L.ptr(out), L.ptr(V) if want_weights else None, L.ptr(Va) if want_weights else None, self.N))
+        return out, V, Va
+
+    def debug_rows(self):
+        """(row0[L + 1], slot_meta[L]): first indicator row of every SNP; rows | uqe flags << 3 | slot states << 8."""
+        row0 = np.zeros(self.L + 1, dtype=np.int32)
+        meta = np.zeros(self.L, dtype=np.uint32)
+        L.check(L.lib().ldw_debug_rows(self._ctx, L.ptr(row0), L.ptr(meta), self.L + 1))
+        return row0, meta
+
+    def debug_apx_gemm(self, rows_t, rows_f):
+        """gemm_apx_kernel over the given indicator rows: int32 [len(rows_t), len(rows_f)] sums of the dual-digit weights in units of 2^e_last."""
+        rt = np.ascontiguousarray(rows_t, dtype=np.int32)
+        rf = np.ascontiguousarray(rows_f, dtype=np.int32)
+        out = np.zeros((len(rt), len(rf)), dtype=np.int32)
+        L.check(L.lib().ldw_debug_apx_gemm(self._ctx, L.ptr(rt), len(rt), L.ptr(rf), len(rf), L.ptr(out)))
+        return out
+
+    def debug_screen_bound(self, kind: int, na: int, nb: int, g, pa, pb, pX, pY, rr, params, masks=None):
+        """The engine's screen / evaluation device functions on caller-made joint tables (ldw_debug_screen_bound): kind 0 / 1 the approximate path's upper
+        bounds (straight-line / predicated), 2 / 3 the fp32 MI of the exact-limb screens, 4 the fp64 value the engine emits."""
+        g = np.ascontiguousarray(g, dtype=np.int64).reshape(-1, 16)
+        n = len(g)
+        pa = np.ascontiguousarray(pa, dtype=np.int64).reshape(n, 5)
+        pb = np.ascontiguousarray(pb, dtype=np.int64).reshape(n, 5)
+        pX = np.ascontiguousarray(pX, dtype=np.float32).reshape(n, 5)
+        pY = np.ascontiguousarray(pY, dtype=np.float32).reshape(n, 5)
+        rr = np.ascontiguousarray(rr, dtype=np.float64).reshape(n, 3)
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(16)
+        mk = None if masks is None else np.ascontiguousarray(masks, dtype=np.uint32).reshape(n, 2)
+        out = np.zeros(n, dtype=np.float32)
+        out64 = np.zeros(n, dtype=np.float64)
+        L.check(L.lib().ldw_debug_screen_bound(self._ctx, int(kind), int(na), int(nb), n, L.ptr(g), L.ptr(pa), L.ptr(pb), L.ptr(pX), L.ptr(pY), L.ptr(rr),
+                                               L.ptr(mk), L.ptr(params), L.ptr(out), L.ptr(out64)))
+        return out64 if kind == 4 else out
+
     def write_links_tsv(self, which: int, path: str, append: bool = True, nthreads: int = 0):
         """The context's sr (0) / lr (1) table as `pos1 pos2 clust1 clust2 len MI` rows (write.table format); (rows, bytes)."""
         n, nb = C.c_int64(0), C.c_int64(0)
