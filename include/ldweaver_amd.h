@@ -299,20 +299,21 @@ int ldw_debug_tab11(ldw_ctx *ctx, double W, double lo, double delta, double eta,
  * ldw_debug_apx_params: the constants the approximate screen's bound is built from for the CURRENT weights, as the engine derives them:
  *   out[0] F (fraction bits of the fixed-point weights), [1] e_last, [2] delta = max |V'/V - 1|, [3] lost units of a GEMM entry, [4] sum of the fixed-point weights,
  *   [5] neff, [6] apx_EG, [7] apx_dfac, [8] apx_s1, [9] apx_c1, [10] apx_W, [11] apx_unit = 2^(e_last - F), [12] scr_scale of the approximate screen,
- *   [13] scr_shift and [14] scr_scale of the exact-limb screen, [15] bit 0: the path is usable, bit 1: block exponents per 32 positions;
+ *   [13] scr_shift and [14] scr_scale of the exact-limb screen, [15] bit 0: the path is usable, bit 1: block exponents per 32 positions,
+ *   [16] lo_abs_sum = sum |V_lo| 2^-F and [17] lo_bound, the margin the mixed-precision screen adds for the two low limbs, [18] apx_MU (units a floor marginal can be low: 1, or 0 at e_last = 0), [19] limbs;
  *   vfixed_out / vapx_out (may be NULL; capacity >= N): the exact fixed-point weight V_s and its dual-digit approximation V'_s = a b 2^e of every SEQUENCE.
  * ldw_debug_rows: row0_out[L + 1] = first indicator row of every SNP, slot_meta_out[L] = rows (3 bits) | uqe flag of slot i << (3 + i) | state of slot i << (8 + 3 i).
  * ldw_debug_apx_gemm: gemm_apx_kernel over the given indicator rows (indices 0..R; R = the all-zero padding row): out[nrt][nrf] = the int32 sums G' in units of 2^e_last.
  * ldw_debug_screen_bound: the engine's own device functions on n caller-made joint tables (arrays by case: g[16] = sums of the indicator rows, g[j * 4 + i] = slot i of the
  *   from-side SNP x slot j of the to-side SNP; pa / pb[5] integer marginals by slot; pX / pY[5] weighted marginals; rr[3] = r_a, r_b, RXY; masks[2] = slot meta of both SNPs,
- *   kinds 1 / 3 only; params = the 16 numbers of ldw_debug_apx_params, which the caller may alter).  kind 0: full_cells_screen<na, nb, APX> — the approximate path's upper
+ *   kinds 1 / 3 only; params = the 20 numbers of ldw_debug_apx_params, which the caller may alter).  kind 0: full_cells_screen<na, nb, APX> — the approximate path's upper
  *   bound of MI; 1: pair_screen_generic<APX>; 2: full_cells_screen<na, nb> on exact sums (an fp32 MI); 3: pair_screen_generic on exact sums; 4: full_cells_mi<na, nb>, the
  *   fp64 value the engine emits (out64).  na, nb in {1, 2} for kinds 0 / 2 / 4. */
-int ldw_debug_apx_params(ldw_ctx *ctx, double out[16], int64_t *vfixed_out, int64_t *vapx_out, int64_t capacity);
+int ldw_debug_apx_params(ldw_ctx *ctx, double out[20], int64_t *vfixed_out, int64_t *vapx_out, int64_t capacity);
 int ldw_debug_rows(ldw_ctx *ctx, int32_t *row0_out, uint32_t *slot_meta_out, int64_t capacity);
 int ldw_debug_apx_gemm(ldw_ctx *ctx, const int32_t *rows_t, int nrt, const int32_t *rows_f, int nrf, int32_t *out);
 int ldw_debug_screen_bound(ldw_ctx *ctx, int kind, int na, int nb, int64_t n, const int64_t *g, const int64_t *pa, const int64_t *pb, const float *pX, const float *pY,
-                           const double *rr, const uint32_t *masks, const double params[16], float *out, double *out64);
+                           const double *rr, const uint32_t *masks, const double params[20], float *out, double *out64);
 /* diagnostics of the approximate path after ldw_set_weights: out[0] = usable (0/1), out[1] = max relative error delta of the
  * dual-digit weights, out[2] = weight classes, out[3] = popcount segments, out[4] = exponent transitions, out[5] = e_last */
 int ldw_apx_info(ldw_ctx *ctx, double out[6]);

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_dbg_generic(EpiArgs A, DbgArrays D) {
 
 extern "C" {
 
-int ldw_debug_apx_params(ldw_ctx *c, double out[16], int64_t *vfixed_out, int64_t *vapx_out, int64_t capacity) {
+int ldw_debug_apx_params(ldw_ctx *c, double out[20], int64_t *vfixed_out, int64_t *vapx_out, int64_t capacity) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(out, LDW_ERR_ARG, "ldw_debug_apx_params: null output");
     LDW_REQUIRE(c->have_weights, LDW_ERR_STATE, "ldw_debug_apx_params: no weights (ldw_set_weights)");
@@ -134,6 +134,13 @@ int ldw_debug_apx_params(ldw_ctx *c, double out[16], int64_t *vfixed_out, int64_
         out[14] = std::ldexp(1.0, shift - c->frac_bits);
     }
     out[15] = (c->apx_ok ? 1 : 0) | (c->apx_fine ? 2 : 0);
+    out[16] = c->lo_abs_sum;   // mixed-precision path: sum_s |V_lo,s| 2^-F and the margin it adds to the screen (lo_bound, ldw_mi_items.inc)
+    {
+        const double den = c->neff > 1.0 ? c->neff : 1.0;
+        out[17] = c->lo_abs_sum * (2.0 * std::log(den + 12.5) + 3.0) / den;
+    }
+    out[18] = E.apx_MU;
+    out[19] = c->nlimbs;
     if (vfixed_out || vapx_out) {
         LDW_REQUIRE(capacity >= c->N, LDW_ERR_SIZE, "ldw_debug_apx_params: capacity %lld < N %lld", (long long)capacity, (long long)c->N);
         for (int64_t s = 0; s < c->N; ++s) {
@@ -202,7 +209,7 @@ int ldw_debug_apx_gemm(ldw_ctx *c, const int32_t *rows_t, int nrt, const int32_t
 }
 
 int ldw_debug_screen_bound(ldw_ctx *c, int kind, int na, int nb, int64_t n, const int64_t *g, const int64_t *pa, const int64_t *pb, const float *pX, const float *pY,
-                           const double *rr, const uint32_t *masks, const double params[16], float *out, double *out64) {
+                           const double *rr, const uint32_t *masks, const double params[20], float *out, double *out64) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(n > 0 && n < ((int64_t)1 << 28) && g && pa && pb && pX && pY && rr && params, LDW_ERR_ARG, "ldw_debug_screen_bound: bad argument");
     LDW_REQUIRE(kind >= 0 && kind <= 4 && ((kind == 4) ? out64 != nullptr : out != nullptr), LDW_ERR_ARG, "ldw_debug_screen_bound: kind %d / missing output", kind);
@@ -246,7 +253,7 @@ int ldw_debug_screen_bound(ldw_ctx *c, int kind, int na, int nb, int64_t n, cons
         A.E.apx_c1 = (float)params[9];
         A.E.apx_W = params[10];
         A.E.apx_unit = params[11];
-        A.E.apx_MU = params[1] == 0.0 ? 0.0f : 1.0f;   // (apx_screen_params: the marginals' floor loses nothing at e_last = 0)
+        A.E.apx_MU = (float)params[18];
         A.E.scr_shift = apx ? 0 : (int)params[13];
         A.E.scr_scale = (float)(apx ? params[12] : params[14]);
         DbgArrays D;

@@ -133,12 +133,12 @@ class Engine:
 
     # -- test hooks: the bounds of the default path as functions (BOUNDS.md; csrc/ldw_debug.hip) --------------------
     APX_PARAM_NAMES = ("F", "e_last", "delta", "lost_units", "total_fixed", "neff", "apx_EG", "apx_dfac", "apx_s1", "apx_c1", "apx_W", "apx_unit", "scr_scale",
-                       "scr_shift_exact", "scr_scale_exact", "flags")
+                       "scr_shift_exact", "scr_scale_exact", "flags", "lo_abs_sum", "lo_bound", "apx_MU", "nlimbs")
 
     def debug_apx_params(self, want_weights: bool = True):
-        """(params[16], V[N], V'[N]): the constants of the approximate screen's bound for the current weights (names: APX_PARAM_NAMES) and, per sequence, the
+        """(params[20], V[N], V'[N]): the constants of the approximate screen's bound for the current weights (names: APX_PARAM_NAMES) and, per sequence, the
         exact fixed-point weight and its dual-digit approximation."""
-        out = np.zeros(16)
+        out = np.zeros(20)
         V = np.zeros(self.N if want_weights else 0, dtype=np.int64)
         Va = np.zeros(self.N if want_weights else 0, dtype=np.int64)
         L.check(L.lib().ldw_debug_apx_params(self._ctx, L.ptr(out), L.ptr(V) if want_weights else None, L.ptr(Va) if want_weights else None, self.N))
@@ -169,7 +169,7 @@ class Engine:
         pX = np.ascontiguousarray(pX, dtype=np.float32).reshape(n, 5)
         pY = np.ascontiguousarray(pY, dtype=np.float32).reshape(n, 5)
         rr = np.ascontiguousarray(rr, dtype=np.float64).reshape(n, 3)
-        params = np.ascontiguousarray(params, dtype=np.float64).reshape(16)
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(20)
         mk = None if masks is None else np.ascontiguousarray(masks, dtype=np.uint32).reshape(n, 2)
         out = np.zeros(n, dtype=np.float32)
         out64 = np.zeros(n, dtype=np.float64)

@@ -284,6 +284,38 @@ def test_exact_limb_screens_and_the_fp64_evaluation_match_the_formula(engine):
     print(f"fp32 screens: max |value - MI| {e32:.2e} (SCREEN_EPS {SCREEN_EPS:.0e}); fp64 evaluation: {e64:.2e}")
 
 
+@pytest.mark.parametrize("kind,N,seed", [("hamming", 2000, 31), ("distinct", 616, 32), ("wide", 400, 33)])
+def test_mixed_precision_screen_margin_covers_the_low_limbs(engine, kind, N, seed):
+    """The mixed-precision limb path screens on the sums of V_hi = (V - V_lo) / 2^16 (three high limbs) and widens its margin by lo_bound =
+    lo_abs_sum (2 ln(neff + 12.5) + 3) / neff: the fp32 screen value of the HIGH-limb table is never more than lo_bound + SCREEN_EPS / 2 below the MI of the
+    exact sums (lo_bound, ldw_mi_items.inc; the path switches itself off above lo_bound = 1e-3)."""
+    _engine_with(engine, N, kind, seed)
+    par, V, _ = engine.debug_apx_params()
+    P = dict(zip(Engine.APX_PARAM_NAMES, par))
+    if int(P["nlimbs"]) != 5:
+        pytest.skip("the weighting does not take 5 limbs: no mixed-precision path")
+    lo = ((V + 32896) % 65536) - 32896                 # two balanced base-256 digits: -32896 .. 32639
+    Vhi = (V - lo) // 65536
+    assert np.all(Vhi * 65536 + lo == V) and abs(float(np.abs(lo).sum()) * 2.0 ** -int(P["F"]) - P["lo_abs_sum"]) <= 1e-12 * max(1.0, P["lo_abs_sum"])
+    tot_hi = int(Vhi.sum())
+    shift = max(tot_hi.bit_length() - 31, 0)
+    par_hi = par.copy()
+    par_hi[13], par_hi[14] = shift, 2.0 ** (shift - int(P["F"]) + 16)
+    rng = np.random.default_rng(seed)
+    scale = 2.0 ** -int(P["F"])
+    n, worst = 4000, 0.0
+    for ka, kb in [(2, 2), (2, 3), (3, 2), (3, 3)]:
+        a, b = _random_state_pairs(rng, n, N, ka, kb)
+        Sx, Sh = _sums(a, b, V, ka, kb), _sums(a, b, Vhi, ka, kb).astype(np.int64)
+        g, pa, pb, pX, pY = _pack(n, ka, kb, Sh, Sh.sum(axis=2), Sh.sum(axis=1), (Sx.sum(axis=2) * scale).astype(np.float32), (Sx.sum(axis=1) * scale).astype(np.float32))
+        ra, rb, rxy = _r_and_rxy(rng, n, ka, kb)
+        mi = _mi_formula(Sx, scale, ra, rb, rxy, P["neff"])
+        v = engine.debug_screen_bound(2, ka - 1, kb - 1, g, pa, pb, pX, pY, np.stack([ra, rb, rxy], axis=1), par_hi).astype(np.float64)
+        worst = min(worst, float((v - mi).min()))
+        assert (v - mi).min() > -(P["lo_bound"] + 0.5 * SCREEN_EPS), (kind, ka, kb, float((v - mi).min()), P["lo_bound"])
+    print(f"{kind}: lo_bound {P['lo_bound']:.2e}, worst high-limb screen - MI {worst:.2e}")
+
+
 # ------------------------------------------------------------------------------------------------
 # BOUNDS.md 4: the per-SNP bound behind the tile pruning, against arbitrary partners
 # ------------------------------------------------------------------------------------------------
