@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--no-sr-tail-leg", action="store_true", help="N > 1: skip the leg that runs the short-range model + ARACNE behind the pass both ways "
                     "(table gathered to rank 0 / rows left on their ranks: ldweaver_amd/dist_srp.py)")
     ap.add_argument("--sr-tail-timeout", type=float, default=240.0, help="N > 1: seconds the sr_tail leg may take before every rank abandons it and rank 0 prints the line without it")
+    ap.add_argument("--strict-exit", action="store_true", help="N > 1: exit code 3 when the sr_tail leg is abandoned or fails AFTER rank 0 has printed the line (default 0: the line of "
+                                                                "the timed region is complete and says in `sr_tail.note` what happened to the leg; a launcher that drops the line of a non-zero exit would lose the measurement)")
     ap.add_argument("--sustain-s", type=float, default=10.0, help="N = 1: keep stepping after the timed region until this many seconds of steps have run")
     return ap.parse_args()
 
@@ -110,6 +112,95 @@ def cpu_baseline(states_np, hdw, r, uqe, N, sample):
                         f"one diagonal + one off-diagonal {s}x{s} sub-block of the workload's first 10000-SNP block at N={N} (all 25 state "
                         f"pairs, dense x CSR + fused Hadamard), {dt:.1f} s wall.  NOT the stated sample (a whole 10000 x 10000 block pair is 25x the pairs: "
                         f"minutes on these cores — `--cpu-baseline-full` runs it); the cost is linear in pairs at fixed N, so the sample rate extrapolates"))
+
+
+def scaling_model_leg(eng, blocks, sr_dist, lr_retain, approx, pairs, gather_phases, measured_n, measured_ms):
+    """a PREDICTED strong-scaling curve on every line, so that the first multi-GPU record has a stated expectation to be held against.
+    No number here was measured on more than one GPU.  What is measured, on THIS GPU: for N = 1, 2, 4, 8 the cost-weighted deal of the block pairs
+    (dist.deal_blocks, the deal the N-rank run makes) and every rank's share run ALONE as the N-rank run runs it — a cold start (probes), its phases as
+    separate ldw_mi_all_pairs calls — so call overheads, per-rank probes and the shorter spans of a small share are in `compute_ms`.  What is modelled:
+    the gather.  Rows of a finished phase travel while the next is computed (dist.gather_begin), so only the LAST phase's transfer is exposed: its
+    bytes (8 B per short-range row: the MI column; 16 B per long-range row) over the peer's own xGMI link to rank 0 at 153 GB/s (MI355X_MICROARCH.md: 7
+    links per GPU, point to point), then rank 0 re-interleaves the segments into make_blocks order (read + write of the assembled table at 3 TB/s),
+    rebuilds the short-range index columns (ldw_sr_pairs_fill: 0.76 ms at this shape, profiles/r05_sr_pairs_probe.txt) and pays ~0.15 ms per phase
+    for the count all-reduce + grouped send / receive launches.  predicted_ms = slowest share + exposed gather."""
+    import torch
+    from ldweaver_amd.dist import deal_blocks
+    link_GBps, hbm_copy_GBps, fill_ms, coll_ms = 153.0, 3000.0, 0.76, 0.15
+    nblocks = len(blocks)
+    pred = {}
+    for n in (1, 2, 4, 8):
+        shares = deal_blocks(blocks, n)
+        n_phase = 1 if n == 1 else max(1, min(gather_phases, (nblocks // n) // 3))
+        ranks = []
+        for rk, mine in enumerate(shares):
+            phases = np.array_split(mine, n_phase)
+            best, rows = None, None
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                eng.reset_speculation()
+                rows = []
+                for sub in phases:
+                    if len(sub):
+                        eng.mi_all_pairs(blocks[sub], sr_dist, lr_retain, approx)
+                        st = eng.block_stats()
+                        rows.append(8 * int(np.sum(st["n_sr"])) + 16 * int(np.sum(st["n_lr_kept"])))
+                    else:
+                        rows.append(0)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) * 1e3
+                best = ms if best is None else min(best, ms)
+            ranks.append(dict(rank=rk, blocks=int(len(mine)), compute_ms=best, table_bytes=int(sum(rows)), last_phase_bytes=int(rows[-1])))
+        compute = max(r["compute_ms"] for r in ranks)
+        total_bytes = sum(r["table_bytes"] for r in ranks)
+        if n == 1:
+            gather = 0.0
+        else:
+            gather = (max(r["last_phase_bytes"] for r in ranks[1:]) / (link_GBps * 1e9) * 1e3 + 2.0 * total_bytes / (hbm_copy_GBps * 1e9) * 1e3 + fill_ms + coll_ms * n_phase)
+        pred[str(n)] = dict(predicted_ms_per_step=compute + gather, predicted_value=pairs / ((compute + gather) * 1e-3), slowest_share_compute_ms=compute,
+                            exposed_gather_model_ms=gather, phases=n_phase, per_rank=ranks)
+    return dict(status="MODEL, UNMEASURED: no run of this repository has seen more than one GPU (SCALE_r01..r05 were skipped by the driver)",
+                predicted=pred, measured_here=dict(n_gpus=measured_n, ms_per_step=measured_ms),
+                assumptions=dict(xgmi_link_GBps=link_GBps, rank0_reinterleave_GBps=hbm_copy_GBps, sr_pairs_fill_ms=fill_ms, collective_launch_ms_per_phase=coll_ms,
+                                 exposed="last phase's bytes of the slowest peer; earlier phases overlap the next phase's compute",
+                                 not_modelled="RCCL start-up (outside the timed region), contention of 7 inbound links at rank 0's HBM (1.07 TB/s of 8), clock differences between GPUs"),
+                how="every share of dist.deal_blocks(blocks, N) run alone on this GPU, cold, in its phases (best of 2); transfer from bytes / link rate")
+
+
+def epilogue_roofline(ms_per_step, pairs, shape):
+    """k_mi_epilogue (one fp64 MI per pair) against the VALU issue port: SQ counters of the same command, collected in their own rocprofv3 --pmc passes
+    (tools/pmc_run.sh -> profiles/r06_pmc_epilogue.json; the bench cannot run under the counters itself).  A wave64 VALU instruction holds its SIMD's issue
+    port for 4 cycles and a CU has 4 SIMDs: one VALU instruction per CU-cycle is the roof; valu_issue_frac = SQ_INSTS_VALU / SQ_BUSY_CU_CYCLES."""
+    out = dict(kernel="k_mi_epilogue", bound="valu issue (fp64)", ms_per_step=ms_per_step, ps_per_pair=ms_per_step * 1e-3 / pairs * 1e12, valu_issue_frac=None)
+    path = os.path.join(ROOT, "profiles", "r06_pmc_epilogue.json")
+    if os.path.exists(path) and shape == (100_000, 5_000, 1):
+        ent = json.load(open(path)).get("ldw::k_mi_epilogue")
+        if ent:
+            d = ent["derived"]
+            out.update(valu_issue_frac=d["valu_issue_frac"], valu_busy_frac=d["valu_busy_frac"], valu_insts_per_pair=ent["SQ_INSTS_VALU"] * 64.0 * 55 / pairs,
+                       salu_per_valu=d["salu_per_valu"], lanes_active_per_valu=d["lanes_active_per_valu"], wait_inst_any_frac=d["wait_inst_any_frac"],
+                       counters_source="profiles/r06_pmc_epilogue.json (per-launch averages over 169 launches of the plain path; separate --pmc passes)",
+                       note="~4.6 cells per pair x (1 v_rcp_f64 + ~45 fp64 / integer operations): the kernel issues VALU instructions on 0.66 of the cycles its CUs are busy "
+                            "(0.70 counting the quarter-rate reciprocal's extra cycles), 58 of 64 lanes active")
+    return out
+
+
+def hamming_roofline(hs, gs, wall_s, L, N):
+    """the Hamming stage priced like the MI pass.  Its GEMM (`gemm_bits_kernel<1>` over ~1.3 L bit columns, tiles on or below the
+    diagonal) against the dense int8 peak on the operations it EXECUTES (ldw_gemm_stats); the kernels around it (column bits, bit transpose, per-sequence
+    counts in front; the N x N neighbour count behind) against HBM on their algorithmic bytes; what is left of the call's wall clock is host work
+    (state counts to the host, the column list, allocations, uploads).  SURVEY 8(d): ops_alg = N^2 / 2 x L state compares."""
+    out = dict(columns=hs["columns"], wall_ms=wall_s * 1e3, kernels_ms=hs["pre_ms"] + hs["gemm_ms"] + hs["post_ms"],
+               host_ms=wall_s * 1e3 - (hs["pre_ms"] + hs["gemm_ms"] + hs["post_ms"]))
+    if hs["gemm_ms"] > 0 and gs["bits_ops"] > 0:
+        ach = gs["bits_ops"] / (hs["gemm_ms"] * 1e-3) / 1e12
+        out["gemm"] = dict(kernel="gemm_bits_kernel<1>", bound="mfma", ms=hs["gemm_ms"], executed_ops=gs["bits_ops"], achieved=ach, peak=5000.0, unit="TFLOP/s", frac=ach / 5000.0,
+                           alg_ops=0.5 * N * N * L, alg_frac=0.5 * N * N * L / (hs["gemm_ms"] * 1e-3) / 1e12 / 5000.0)
+    for key, ms, nbytes, what in (("pre", hs["pre_ms"], hs["pre_bytes"], "k_hamming_cols + k_bits_transpose + k_seq_minor_count"), ("post", hs["post_ms"], hs["post_bytes"], "k_hdw")):
+        if ms > 0:
+            out[key] = dict(kernels=what, bound="hbm", ms=ms, alg_bytes=nbytes, achieved=nbytes / (ms * 1e-3) / 1e9, peak=8000.0, unit="GB/s", frac=nbytes / (ms * 1e-3) / 1e9 / 8000.0)
+    return out
 
 
 def job_leg(states, POS, paint, g, L, N, device, args):
@@ -503,11 +594,13 @@ def main():
     uqe = (counts > 0).T.astype(np.float64)
     r = uqe.sum(axis=1)
     torch.cuda.synchronize()
+    eng.gemm_stats(reset=True)
     t0 = time.time()
     hdw = eng.hamming_weights(int(L * 0.1))
     torch.cuda.synchronize()
     hamming_s = time.time() - t0
     hamming_kernel_ms = eng.last_timing()["gemm_ms"]
+    roof_hamming = hamming_roofline(eng.hamming_stats(), eng.gemm_stats(reset=True), hamming_s, L, N)
     eng.set_weights(hdw, args.nlimbs)
     eng.set_snp_meta(r, uqe, POS, paint, g)
     sr_dist, lr_retain = 20000.0, 1e6
@@ -717,8 +810,7 @@ def main():
                 alg_ops_per_launch=50.0 * N * pairs * n_rp / g5["bits_launches"],
                 alg_frac=50.0 * N * pairs * n_rp / g5["bits_launches"] / (avg * 1e-3) / 1e12 / 5000.0,
                 stages_ms_per_step=dict(gemm_ms=g_ms / n_rp, epilogue_ms=e_ms / n_rp, select_ms=s_ms / n_rp),
-                epilogue=dict(kernel="k_mi_epilogue", bound="valu (fp64)", ps_per_pair=e_ms / n_rp * 1e-3 / pairs * 1e12,
-                              note="one fp64 MI per pair: ~4.6 cells x (1 v_rcp_f64 + ~40 fp64 / integer operations) — no roof in the guide prices it; reported as time per pair"),
+                epilogue=epilogue_roofline(e_ms / n_rp, pairs, (L, N, world)),
                 hbm_alg_GBps=(L * N + 8.0 * pairs) / (t_pl / n_pl) / 1e9, hbm_frac=(L * N + 8.0 * pairs) / (t_pl / n_pl) / 1e9 / 8000.0,
                 traffic=None,
                 measured_in=f"{n_rp} serialized replay steps of the plain path (overlap off), HIP events around the kernels",
@@ -744,6 +836,10 @@ def main():
 
     if extra and not args.no_adversarial and args.engine == "mfma":
         legs["adversarial"] = adversarial_leg(L, N, local_rank, args)
+
+    # ---- a predicted strong-scaling curve on every line (rank 0 runs every share of the N = 1, 2, 4, 8 deals alone; the other ranks wait at the next fence) ----
+    if rank == 0 and not args.no_extra_legs and args.engine == "mfma" and nblocks >= 8:
+        legs["scaling_model"] = scaling_model_leg(eng, blocks, sr_dist, lr_retain, approx, pairs, args.gather_phases, world, dt / args.steps * 1e3)
 
     if rank == 0:
         K = args.steps
@@ -857,7 +953,7 @@ def main():
         out.update(stages_ms_per_step={k: v / max(1, n_replay) for k, v in tim.items()},
                    stages_ms_per_step_overlapped={k: v / K for k, v in tim_overlapped.items()},
                    links=links_timed, counters=counters_timed, counters_replay=cnt_replay, hamming_weights_s=hamming_s,
-                   hamming_gemm_ms=hamming_kernel_ms, setup_s=setup_s)
+                   hamming_gemm_ms=hamming_kernel_ms, roofline_hamming=roof_hamming, setup_s=setup_s)
     # ---- N > 1, LAST: the short-range model behind the pass, table gathered / rows left on their ranks (sr_tail_leg).  Everything the line holds is
     # assembled by now, and a watchdog on every rank bounds the leg: its exchanges have only run under gloo and on ONE GPU under RCCL (tests/rccl_worker.py), and
     # a rank stuck in a collective must not cost the line of the timed region — after --sr-tail-timeout seconds rank 0 prints the line without the leg and
@@ -865,11 +961,24 @@ def main():
     if run_sr_tail:
         import threading
 
+        line_lock = threading.Lock()
+        line_state = dict(printed=False)
+
+        def print_line_once():
+            # (the timer can fire between the leg returning and dog.cancel(): one line, whoever gets here first)
+            with line_lock:
+                if not line_state["printed"] and rank == 0:
+                    print(json.dumps(out), flush=True)
+                line_state["printed"] = True
+
         def bail():
+            with line_lock:
+                if line_state["printed"]:
+                    return
             if rank == 0:
                 out["sr_tail"] = dict(note=f"the leg did not finish within {args.sr_tail_timeout} s on this line and was abandoned (unmeasured on hardware)")
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+            print_line_once()
+            os._exit(3 if args.strict_exit else 0)   # the line of the timed region is out and says the leg was abandoned; --strict-exit: the launcher sees a failure too
 
         dog = threading.Timer(args.sr_tail_timeout, bail)
         dog.daemon = True
@@ -882,12 +991,14 @@ def main():
         except BaseException as e:   # noqa: BLE001 — the line matters more than the leg; the other ranks leave through their own watchdogs
             dog.cancel()
             if rank == 0:
-                out["sr_tail"] = dict(note=f"the leg failed on rank 0 ({type(e).__name__}: {e}); unmeasured on hardware")
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+                # (a peer whose watchdog fires first closes its connections: rank 0 then sees an error of the transport before its own timer)
+                out["sr_tail"] = dict(note=f"the leg was abandoned by a peer's watchdog ({args.sr_tail_timeout} s) or failed on rank 0 ({type(e).__name__}: {e}); unmeasured on hardware")
+            print_line_once()
+            os._exit(3 if args.strict_exit else 0)
+        print_line_once()
     elif world > 1 and rank == 0:
         out["sr_tail"] = dict(note="not run on this line (--no-extra-legs / --no-sr-tail-leg)")
-    if rank == 0:
+    if rank == 0 and not run_sr_tail:
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

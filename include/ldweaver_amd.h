@@ -124,6 +124,12 @@ int ldw_hamming_weights(ldw_ctx *ctx, int32_t thresh, double *hdw_out, int32_t *
  * of all ranks add up to the full count n_j (self included), hdw[j] = 1 / (n_j + 1): exact integers, so every rank
  * derives bit-identical weights after one all-reduce of N counts. */
 int ldw_hamming_counts(ldw_ctx *ctx, int32_t thresh, int32_t tile0, int32_t tile1, int64_t *counts_out);
+/* r06 — what the last ldw_hamming_weights of this context did, for its roofline (bench.py `roofline_hamming`): out[0] = bit columns K (one per minor state + one
+ * "not the major state" column per multi-allelic SNP: ~1.3 L), [1] = K padded to the GEMM's word pairs, [2] = ms of the kernels in front of the GEMM (column bits, bit
+ * transpose, per-sequence counts; HIP events), [3] = ms of the lower-triangular int8 GEMM, [4] = ms of the N x N neighbour count, [5] / [6] = algorithmic bytes
+ * of the kernels in front of / behind the GEMM, [7] = wall ms of the whole call on the host (allocations, state counts, column list, uploads included).
+ * The GEMM's executed int8 operations are in ldw_gemm_stats (bits_ops). */
+int ldw_hamming_stats(ldw_ctx *ctx, double out[8]);
 
 /* ---- MI set-up ------------------------------------------------------------------------------ */
 /* Per-sequence weights hdw[N] (R/computePairwiseMI.R:77,89).  The engine uses v_s = fl(sqrt(hdw_s))^2

@@ -57,6 +57,7 @@ _SIGS = {
     "ldw_get_alignment": (C.c_int, [_p, _p]),
     "ldw_hamming_weights": (C.c_int, [_p, C.c_int32, _p, _p]),
     "ldw_hamming_counts": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p]),
+    "ldw_hamming_stats": (C.c_int, [_p, _p]),
     "ldw_set_weights": (C.c_int, [_p, _p, _i64, C.c_int]),
     "ldw_set_snp_meta": (C.c_int, [_p, _p, _p, _p, _p, C.c_double]),
     "ldw_set_engine": (C.c_int, [_p, C.c_int]),

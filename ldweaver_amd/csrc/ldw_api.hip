@@ -80,6 +80,12 @@ size_t pool_idle_limit() {   // what the free list may keep once the process hol
     }();
     return v;
 }
+// a block goes back to the runtime: large ones zero-filled first (the runtime may hand the same memory to the next hipMalloc without clearing it;
+// the pages are mapped, so this runs at HBM speed), so that whatever dev_alloc gets from the runtime reads as zero
+void pool_free_zeroed(void *p, size_t cap) {
+    if (cap >= POOL_MIN && hipMemsetAsync(p, 0, cap, nullptr) != hipSuccess) (void)hipGetLastError();
+    (void)hipFree(p);   // (waits for the fill)
+}
 void pool_give(void *p, size_t cap) {
     if (!p) return;
     if (cap >= POOL_MIN && pool_limit() > 0) {
@@ -101,7 +107,7 @@ void pool_give(void *p, size_t cap) {
         }
         (void)hipGetLastError();
     }
-    (void)hipFree(p);
+    pool_free_zeroed(p, cap);
 }
 // keep: bytes the list may hold afterwards (0: give everything back); the largest blocks go first
 size_t pool_flush(size_t keep = 0) {
@@ -125,7 +131,7 @@ size_t pool_flush(size_t keep = 0) {
     (void)hipGetDevice(&cur);
     for (const PoolBlock &b : all) {
         (void)hipSetDevice(b.dev);
-        (void)hipFree(b.p);
+        pool_free_zeroed(b.p, b.cap);
         n += b.cap;
     }
     if (!all.empty()) (void)hipSetDevice(cur);
@@ -153,7 +159,7 @@ hipError_t dev_alloc(void **out, size_t want, size_t &cap_out) {
         // blocks (nothing else was ever observed on this stack): keep it so — LDW_POISON_ALLOC (below) found kernels that read index arrays before writing
         // them, which zeroes make harmless and another buffer's contents would not.  The pages are mapped already: the fill runs at HBM speed (7 ms for 20 GB).
         hipError_t e = hipMemsetAsync(p, 0, cap_out, nullptr);
-        if (e == hipSuccess) e = hipDeviceSynchronize();   // (the library's streams do not synchronise with the null stream)
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);   // (the library's streams do not synchronise with the null stream; only the fill has to be done — no device-wide wait)
         if (e == hipSuccess && poison_on()) poison_fill(p, cap_out);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -169,12 +175,17 @@ hipError_t dev_alloc(void **out, size_t want, size_t &cap_out) {
         if (pool_flush() > 0) e = hipMalloc(out, want);
     }
     cap_out = want;
-    // r06: a block from the runtime is zero-filled as well.  HIP does not promise zeroed memory (the runtime re-uses what it freed below ~16 GB), and
-    // "a fresh DevBuf reads as zero" is an invariant the engine may rely on — stated here, instead of an accident of the stack.  It is NOT what makes stale data
-    // harmless: a DevBuf kept across problems holds the last problem's bytes, which tools/fuzz_paths.py / tests exercise by running problem after problem on one context.
-    if (e == hipSuccess) {
+    // r06 — "a fresh DevBuf reads as zero" as an invariant with a reason per source, instead of an accident of the stack:
+    //   * from the free list: zero-filled above (mapped pages: HBM speed);
+    //   * small blocks (< 64 MB, never pooled: the runtime caches and re-uses them DIRTY): zero-filled here, microseconds;
+    //   * large blocks from the runtime: either fresh from the driver — the kernel driver clears VRAM it hands to a process — or a block this library
+    //     gave back with hipFree, and those are zero-filled BEFORE they are freed (pool_free_zeroed).  Filling them here as well was measured: it maps
+    //     every page of the 13-19 GB a context reserves (0.37 s on a job's first Hamming call against 6 ms: profiles/r06_alloc_zero_fill.txt).
+    // It is NOT what makes stale data harmless: a DevBuf kept across problems holds the last problem's bytes; tools/fuzz_paths.py and tests/test_bounds.py
+    // run ~500 problems one after the other on one context for that, LDW_POISON_ALLOC=2 / 3 fill every block with in-range garbage instead of zeroes.
+    if (e == hipSuccess && want < POOL_MIN) {
         e = hipMemsetAsync(*out, 0, want, nullptr);
-        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(*out);

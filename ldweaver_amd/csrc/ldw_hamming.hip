@@ -14,6 +14,7 @@
 // none).  The GEMM is gemm_bits_kernel<1> (ldw_gemm_bits.hip) on a sequence-major bit matrix with the weights as
 // its per-k digit; only tiles on or below the diagonal are computed.  Everything is integer arithmetic: bit-exact.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <vector>
 
@@ -25,28 +26,34 @@ namespace ldw {
 
 // Column bits, SNP-major like Mbits: Hb[k][w] bit i = predicate(states[snp(k)][64 w + i]); info = snp*16 + mode*8 + state,
 // mode 0: x == state, mode 1: x != state (and x is a real state, not padding)
+// r06: one thread per (column, 64-sequence word) over the FLAT index space — the r01 form gave every column a workgroup of 256 threads for its KW words
+// (80 at N = 5 000: 29 of 64 lanes active, 522 k waves, SALU-bound; profiles/r06_pmc_epilogue.json).
 __global__ __launch_bounds__(256) void k_hamming_cols(const uint8_t *__restrict__ states, int64_t Npad, const int32_t *__restrict__ info,
-                                                      int64_t KW, uint64_t *__restrict__ Hb) {
-    const int64_t k = blockIdx.x;
+                                                      int64_t KW, int64_t KR, uint64_t *__restrict__ Hb) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= KR * KW) return;
+    const int64_t k = t / KW, w = t - k * KW;
     const int32_t inf = info[k];
     const int64_t snp = inf >> 4;
     const uint32_t st = (uint32_t)(inf & 7);
     const bool neq = (inf >> 3) & 1;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(states + snp * Npad);
-    for (int64_t w = threadIdx.x; w < KW; w += blockDim.x) {
-        uint64_t bits = 0;
+    const uint4 *src = reinterpret_cast<const uint4 *>(states + snp * Npad + w * 64);
+    uint64_t bits = 0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const uint32_t x = src[w * 16 + q];
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const uint4 v4 = src[q4];
+        const uint32_t xs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const uint32_t v = (x >> (8 * b)) & 0xFFu;
+                const uint32_t v = (xs[q] >> (8 * b)) & 0xFFu;
                 const bool on = neq ? (v != st && v < 5u) : (v == st);
-                bits |= (uint64_t)on << (4 * q + b);
+                bits |= (uint64_t)on << (16 * q4 + 4 * q + b);
             }
         }
-        Hb[k * KW + w] = bits;
     }
+    Hb[t] = bits;
 }
 
 // 64 x 64 bit-tile transpose: Hb[KR][KW] (columns x sequence words) -> T[KW*64][KWr] (sequences x column words).
@@ -129,6 +136,7 @@ __global__ void k_shared_i32(const int64_t *__restrict__ G, int ld, const int32_
 // tile0 < 0: the whole matrix -> hdw_out (and shared_out); else the strip of 128-sequence row tiles [tile0, tile1) -> counts_out
 static int hamming_impl(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *shared_out, int tile0, int tile1, int64_t *counts_out) {
     if (int rc = check_gpu(c)) return rc;
+    const auto wall0 = std::chrono::steady_clock::now();
     LDW_REQUIRE(c->L > 0, LDW_ERR_STATE, "ldw_hamming_weights: set the alignment first");
     const bool strip = tile0 >= 0;
     LDW_REQUIRE(strip ? counts_out != nullptr : hdw_out != nullptr, LDW_ERR_ARG, "ldw_hamming_weights: output is null");
@@ -139,7 +147,14 @@ static int hamming_impl(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *sh
     ldw::DevBuf info, Hb, T, dig, um, Gh, rl, scnt, dhdw;
     int rc = LDW_OK;
     auto done = [&](int code) {
-        for (ldw::DevBuf *b : {&info, &Hb, &T, &dig, &um, &Gh, &rl, &scnt, &dhdw}) b->release();
+        // (the stream has been drained on every path that reaches this with work queued; a failed launch has queued nothing behind it)
+        const bool drained = hipStreamSynchronize(c->stream) == hipSuccess;
+        if (drained) {
+            ldw::DrainedScope quiet;   // no device-wide synchronisation per released block (other contexts of the device may be in the middle of a pass)
+            for (ldw::DevBuf *b : {&info, &Hb, &T, &dig, &um, &Gh, &rl, &scnt, &dhdw}) b->release();
+        } else {
+            for (ldw::DevBuf *b : {&info, &Hb, &T, &dig, &um, &Gh, &rl, &scnt, &dhdw}) b->release();
+        }
         return code;
     };
     hipError_t he;
@@ -196,9 +211,14 @@ static int hamming_impl(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *sh
     HC(hipMemcpyAsync(dig.p, digits.data(), (size_t)Kpad, hipMemcpyHostToDevice, c->stream));
     HC(hipMemcpyAsync(um.p, umask.data(), (size_t)KWr * 8, hipMemcpyHostToDevice, c->stream));
     HC(hipMemcpyAsync(rl.p, rowlist.data(), (size_t)Rp * 4, hipMemcpyHostToDevice, c->stream));
+    HC(hipEventRecord(c->ev[4], c->stream));   // (r06: the kernels in front of the GEMM bracketed on their own — ev[0] also sees the host work above)
     if (KR > 0) {
-        hipLaunchKernelGGL(k_hamming_cols, dim3((unsigned)KR), dim3(256), 0, c->stream, c->states.as<uint8_t>(), Npad, info.as<int32_t>(),
-                           KW, Hb.as<uint64_t>());
+        if (KR * KW >= ((int64_t)1 << 39)) {
+            ldw::set_error("ldw_hamming_weights: %lld columns x %lld words exceed the launch grid", (long long)KR, (long long)KW);
+            return done(LDW_ERR_SIZE);
+        }
+        hipLaunchKernelGGL(k_hamming_cols, dim3((unsigned)((KR * KW + 255) / 256)), dim3(256), 0, c->stream, c->states.as<uint8_t>(), Npad, info.as<int32_t>(),
+                           KW, KR, Hb.as<uint64_t>());
         HC(hipGetLastError());
     }
     hipLaunchKernelGGL(k_bits_transpose, dim3((unsigned)((KWr + 3) / 4), (unsigned)KW), dim3(256), 0, c->stream, Hb.as<uint64_t>(), KR, KW,
@@ -233,6 +253,7 @@ static int hamming_impl(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *sh
     hipLaunchKernelGGL(k_hdw, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream, Gh.as<int64_t>(), Rp, scnt.as<int32_t>(), N, L,
                        (int)thresh, dhdw.as<double>());
     HC(hipGetLastError());
+    HC(hipEventRecord(c->ev[3], c->stream));
     HC(hipMemcpyAsync(hdw_out, dhdw.p, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
     if (shared_out) {
         ldw::DevBuf s32;
@@ -248,15 +269,36 @@ static int hamming_impl(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *sh
     float t = 0, tg = 0;
     HC(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
     HC(hipEventElapsedTime(&tg, c->ev[2], c->ev[1]));
+    float tp = 0, tpre = 0;
+    HC(hipEventElapsedTime(&tp, c->ev[1], c->ev[3]));
+    HC(hipEventElapsedTime(&tpre, c->ev[4], c->ev[2]));
     c->last_ms[0] = tg;          // the GEMM alone
-    c->last_ms[1] = c->last_ms[2] = 0;
+    c->last_ms[1] = tp;          // r06: the N x N neighbour count (k_hdw)
+    c->last_ms[2] = 0;
     c->last_ms[3] = t;           // counts + column bits + transpose + GEMM
+    // r06: what the stage moved, for its roofline on the bench line (ldw_hamming_stats).  Algorithmic bytes of the kernels around the
+    // GEMM: k_hamming_cols reads its SNP's state row once per COLUMN and writes the column's bits, k_bits_transpose reads and writes the bit matrix,
+    // k_seq_minor_count reads it once more; k_hdw reads the lower triangle of G twice (every (i, j) from row min(i, j)) and writes N doubles.
+    c->ham_stat[0] = (double)KR;
+    c->ham_stat[1] = (double)Kpad;
+    c->ham_stat[2] = (double)tpre;
+    c->ham_stat[3] = (double)tg;
+    c->ham_stat[4] = (double)tp;
+    c->ham_stat[5] = (double)KR * (double)Npad + 2.0 * (double)KR * (double)KW * 8.0 + 2.0 * (double)Rp * (double)KWr * 8.0;
+    c->ham_stat[6] = (double)N * (double)N * 8.0 + (double)N * 8.0;
+    c->ham_stat[7] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 #undef HC
     return done(LDW_OK);
 }
 
 extern "C" int ldw_hamming_weights(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *shared_out) {
     return hamming_impl(c, thresh, hdw_out, shared_out, -1, -1, nullptr);
+}
+
+extern "C" int ldw_hamming_stats(ldw_ctx *c, double out[8]) {
+    LDW_REQUIRE(c && out, LDW_ERR_ARG, "ldw_hamming_stats: null argument");
+    for (int k = 0; k < 8; ++k) out[k] = c->ham_stat[k];
+    return LDW_OK;
 }
 
 extern "C" int ldw_hamming_counts(ldw_ctx *c, int32_t thresh, int32_t tile0, int32_t tile1, int64_t *counts_out) {

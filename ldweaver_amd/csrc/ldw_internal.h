@@ -242,6 +242,7 @@ struct ldw_ctx {
     size_t pin_fetch_cap = 0;
     ldw::DevBuf srm_pack, srm_key, srm_pack2, srm_key2, srm_pay, srm_pay2, srm_off, srm_q, srm_n, srm_md, srm_part, srm_shape, srm_cnt, srm_tmp;
     ldw::DevBuf srd_lower, srd_cur, srd_out, srd_seg;   // r05, the model over ranks (ldw_sr_tail_extract ...): per-group bounds, cursors, the extracted rows, block segments
+    double ham_stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ldw_hamming_stats: columns, padded K, stage times and algorithmic bytes of the last ldw_hamming_weights
     double gemm_stat[6] = {0, 0, 0, 0, 0, 0};   // ldw_gemm_stats: launches and executed int8 ops of the block-wide GEMMs
     ldw::DevBuf red_row, red_meta, red_srp, pool_a, pool_b, pool_mi, ar_key, ar_val, ar_key2, ar_val2, ar_off, ar_flags;
     int64_t n_red = 0, n_pool = 0;

@@ -58,6 +58,13 @@ class Engine:
         return dict(apx_launches=int(v[0]), apx_ops=float(v[1]), bits_launches=int(v[2]), bits_ops=float(v[3]), band_launches=int(v[4]),
                     apx_table_launches=int(v[5]))
 
+    def hamming_stats(self):
+        """What the last hamming_weights call did (ldw_hamming_stats): columns, stage times (HIP events), algorithmic bytes around the GEMM, host wall ms."""
+        v = np.zeros(8)
+        L.check(L.lib().ldw_hamming_stats(self._ctx, L.ptr(v)))
+        return dict(columns=int(v[0]), k_padded=int(v[1]), pre_ms=float(v[2]), gemm_ms=float(v[3]), post_ms=float(v[4]), pre_bytes=float(v[5]), post_bytes=float(v[6]),
+                    wall_ms=float(v[7]))
+
     def counters(self):
         v = np.zeros(8, dtype=np.int64)
         L.check(L.lib().ldw_ctx_counters2(self._ctx, L.ptr(v)))
