@@ -1,0 +1,10 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+bash tools/r06_l1_prof.sh
+for rep in 1 2; do for v in "" 1; do
+  if [ -n "$v" ]; then export LDW_NO_SCREEN_L1=1; else unset LDW_NO_SCREEN_L1; fi
+  timeout -k 10 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-extra-legs 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('NO_L1=[$v]', 'ms_per_step', round(d['ms_per_step'], 2), 'serial stages', {k: round(v, 2) for k, v in d['stages_ms_per_step'].items()}, d['links'], d['path']['pairs_listed'], d['spec_misses'])"
+done; done
