@@ -245,65 +245,19 @@ int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *pa
 // ------------------------------------------------------------------------------------------------
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
-// Wave tile of the pruned, table-fused launches (the default path's): APX_MT x 2 MFMA tiles of 32 x 32.  4 (128 to-rows x 64 from-rows, two
-// waves per SIMD) since r02; -DLDW_APX_MT=2: 64 x 64 at FOUR waves per SIMD (<= 128 VGPRs) with the tile list, the band mask test and the
-// epilogue's regions at 64-row granularity (r05).
-#ifndef LDW_APX_MT
-#define LDW_APX_MT 4
-#endif
-constexpr int APX_MT = LDW_APX_MT, APX_WPS = APX_MT == 2 ? 4 : 2;
-static_assert(APX_MT == 2 || APX_MT == 4 || APX_MT == 5, "LDW_APX_MT must be 2, 4 or 5");
+// Wave tile of the pruned, table-fused launches (the default path's): APX_MT x 2 MFMA tiles of 32 x 32 = 128 to-rows x 64 from-rows, two waves per SIMD.
+// (Measured and NOT kept, r02-r05 — numbers in docs/HISTORY.md and profiles/r05_*: 2 x 2 at four waves per SIMD, 3 x 2 at three, 3 x 3, 5 x 2; the table
+// index as one SDWA instruction; the table reads one k-step ahead; a 16-way replicated table.  Their code left this file in r06: git history has it.)
+constexpr int APX_MT = 4, APX_WPS = 2;
 
-#ifdef LDW_APX_SDWA
-// r05 experiment, measured SLOWER (DESIGN 5.1c "r05: SDWA"; tools/r05_sdwa_ab.sh): byte B of a dword, times 8 (the byte offset of its entry in the
-// 0xFF expansion table), in ONE instruction — an SDWA source-byte select on the shift — instead of the v_bfe_u32 + v_lshl_add_u32 hipcc emits for
-// lutFF[(w >> 8 B) & 0xFF]: 12 of the 48 VALU instructions per 8 MFMAs.  The compiler folds the select by itself once the table is addressed
-// without its base (LDS address 0: the kernel has no static LDS and checks it); with `smem + offset` the base, a link-time constant, comes back
-// as a v_add_u32 per read.  -DLDW_APX_SDWA=2: the same through inline assembly.
-template <int B>
-__device__ __forceinline__ uint32_t lut_off(uint32_t dw) {
-#if LDW_APX_SDWA == 2
-    uint32_t r;
-    if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(3u), "v"(dw));
-    else if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(3u), "v"(dw));
-    else if constexpr (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(3u), "v"(dw));
-    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(3u), "v"(dw));
-    return r;
-#else
-    return ((dw >> (8 * B)) & 0xFFu) << 3;
-#endif
-}
-typedef __attribute__((address_space(3))) const uint64_t lds_cu64;
-// the 16 expanded bytes (0xFF / 0x00) of the 16 bits of k-step KK of a 64-bit panel word
-template <int KK>
-__device__ __forceinline__ v4i expand16(const uint64_t *, uint64_t w) {
-    typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
-    const uint32_t dw = KK < 2 ? (uint32_t)w : (uint32_t)(w >> 32);
-    const u64x2v q = {*(lds_cu64 *)(uintptr_t)lut_off<2 * (KK & 1)>(dw), *(lds_cu64 *)(uintptr_t)lut_off<2 * (KK & 1) + 1>(dw)};
-    return __builtin_bit_cast(v4i, q);
-}
-#elif defined(LDW_APX_LUT16)
-// r05 experiment: the expansion table replicated 16 times — entry e of lane l at byte e * 128 + (l & 15) * 8, so that the 32 lanes of a
-// ds_read_b64 group meet two by two on a bank pair whatever they look up (4 LDS cycles per instruction instead of ~7 with 32 random
-// entries on 32 bank pairs); lutFF here = the table's base + the lane's slot.  30 KB more LDS per workgroup.
-constexpr int APX_LUT_BYTES = 32768;
-template <int KK>
-__device__ __forceinline__ v4i expand16(const uint64_t *lutFF, uint64_t w) {
-    typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
-    const u64x2v q = {lutFF[((w >> (16 * KK)) & 0xFFu) * 16u], lutFF[((w >> (16 * KK + 8)) & 0xFFu) * 16u]};
-    return __builtin_bit_cast(v4i, q);
-}
-#else
+// the 16 expanded bytes (0xFF / 0x00) of the 16 bits of k-step KK of a 64-bit panel word: two look-ups in the 256-entry byte -> 8 x 0xFF table (LDS)
 template <int KK>
 __device__ __forceinline__ v4i expand16(const uint64_t *lutFF, uint64_t w) {
     typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
     const u64x2v q = {lutFF[(w >> (16 * KK)) & 0xFFu], lutFF[(w >> (16 * KK + 8)) & 0xFFu]};
     return __builtin_bit_cast(v4i, q);
 }
-#endif
-#ifndef LDW_APX_LUT16
 constexpr int APX_LUT_BYTES = 2048;
-#endif
 
 // Epilogue of a wave tile (MT x NT MFMA tiles at wave-tile coordinates ty, tx): the threshold-table test per region of 32 to-rows x
 // the wave's from-rows (P.fuse) and the store of the regions that are not clean.  s_bt: 256 wave-private LDS bytes.
@@ -508,19 +462,12 @@ __global__ __launch_bounds__(256) void k_apx_live_tiles(ApxGemmArgs P) {
 template <int MT, int NT, bool FINE, int WPS = 2>
 __global__ __launch_bounds__(256, WPS) void gemm_apx_kernel(ApxGemmArgs P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-#ifdef LDW_APX_LUT16
-    const uint64_t *lutFF = reinterpret_cast<const uint64_t *>(smem) + (threadIdx.x & 15);   // this lane's slot of every entry
-#else
     uint64_t *lutFF = reinterpret_cast<uint64_t *>(smem);           // [256]: byte of bits -> 8 bytes of 0xFF / 0x00
-#endif
     uint8_t *sA = smem + APX_LUT_BYTES, *sB = sA + (size_t)P.M2 * 128;       // digits by position
     int2 *s_tab = reinterpret_cast<int2 *>(sB + (size_t)P.M2 * 128);  // threshold table (P.fuse)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int TH = 32 * MT, TWd = 32 * NT;
-#ifdef LDW_APX_SDWA
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap();   // expand16 reads the table at LDS address 0
-#endif
     int ty = 2 * blockIdx.y + (wave >> 1), tx = 2 * blockIdx.x + (wave & 1);
     bool outside;
     if (P.tile_list) {
@@ -543,16 +490,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_apx_kernel(ApxGemmArgs P) {
         uint64_t e = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) e |= ((tid >> k) & 1) ? (0xFFull << (8 * k)) : 0ull;
-#ifdef LDW_APX_LUT16
-        {
-            typedef unsigned long long u64x2w __attribute__((ext_vector_type(2)));
-            const u64x2w e2 = {e, e};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) reinterpret_cast<u64x2w *>(smem + (size_t)tid * 128)[k] = e2;
-        }
-#else
         lutFF[tid] = e;
-#endif
         const int n16 = P.M2 * 8;   // 16-byte pieces per digit array
         for (int i = tid; i < n16; i += 256) {
             reinterpret_cast<uint4 *>(sA)[i] = reinterpret_cast<const uint4 *>(P.dig_a)[i];
@@ -589,15 +527,6 @@ __global__ __launch_bounds__(256, WPS) void gemm_apx_kernel(ApxGemmArgs P) {
         for (int i = 0; i < MT; ++i) na[i] = pa[i][0];
 #pragma unroll
         for (int i = 0; i < NT; ++i) nb[i] = pb[i][0];
-#ifdef LDW_APX_PREFETCH
-        // r05 experiment, measured slower still (256 VGPRs, 2 spilled): the table reads of k-step s + 1 issued BEFORE the MFMAs of k-step s (a
-        // scheduling barrier keeps them there), 12 pending 64-bit reads.
-        v4i ra_[MT], rb_[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) ra_[i] = expand16<0>(lutFF, na[i]);
-#pragma unroll
-        for (int i = 0; i < NT; ++i) rb_[i] = expand16<0>(lutFF, nb[i]);
-#endif
         for (int m = 0; m < P.M2; ++m) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) wa[i] = na[i];
@@ -629,33 +558,14 @@ __global__ __launch_bounds__(256, WPS) void gemm_apx_kernel(ApxGemmArgs P) {
                 const v4i da = *reinterpret_cast<const v4i *>(dA + (FINE ? 32 : 16) * kk);
                 const v4i db = *reinterpret_cast<const v4i *>(dB + (FINE ? 32 : 16) * kk);
                 v4i fa[MT], fb[NT];
-#ifdef LDW_APX_PREFETCH
-                v4i xa[MT], xb[NT];   // the next k-step's expansions (k-step 0 of the next macro step after the last one: its words are in na / nb)
-#pragma unroll
-                for (int i = 0; i < MT; ++i) xa[i] = expand16<(kk + 1) & 3>(lutFF, kk == 3 ? na[i] : wa[i]);
-#pragma unroll
-                for (int i = 0; i < NT; ++i) xb[i] = expand16<(kk + 1) & 3>(lutFF, kk == 3 ? nb[i] : wb[i]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) fa[i] = ra_[i] & da;
-#pragma unroll
-                for (int i = 0; i < NT; ++i) fb[i] = rb_[i] & db;
-#else
 #pragma unroll
                 for (int i = 0; i < MT; ++i) fa[i] = expand16<kk>(lutFF, wa[i]) & da;
 #pragma unroll
                 for (int i = 0; i < NT; ++i) fb[i] = expand16<kk>(lutFF, wb[i]) & db;
-#endif
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-#ifdef LDW_APX_PREFETCH
-#pragma unroll
-                for (int i = 0; i < MT; ++i) ra_[i] = xa[i];
-#pragma unroll
-                for (int i = 0; i < NT; ++i) rb_[i] = xb[i];
-#endif
             };
             kstep(std::integral_constant<int, 0>{});
             kstep(std::integral_constant<int, 1>{});
@@ -959,17 +869,7 @@ int launch_gemm_apx(ldw_ctx *c, const ApxGemmArgs &P, hipStream_t st) {
     LDW_REQUIRE(P.RTpad % APX_TW == 0 && P.RFpad % APX_TW == 0 && P.M2 > 0, LDW_ERR_ARG, "launch_gemm_apx: padding violated (RT %d RF %d M2 %d)", P.RTpad,
                 P.RFpad, P.M2);
     const size_t lds = APX_LUT_BYTES + (size_t)P.M2 * 256 + (P.fuse ? (size_t)P.tab_nb * P.tab_nb * 8 + 1024 : 0);
-#ifdef LDW_APX_LUT16
-    LDW_REQUIRE(lds <= 81920, LDW_ERR_ARG, "launch_gemm_apx: %d positions do not fit the LDS digit arrays", P.M2 * 128);
-    static const bool attr_set = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_apx_kernel<4, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_apx_kernel<4, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
-        return true;
-    }();
-    (void)attr_set;
-#else
     LDW_REQUIRE(lds <= 65536, LDW_ERR_ARG, "launch_gemm_apx: %d positions do not fit the LDS digit arrays", P.M2 * 128);
-#endif
     LDW_REQUIRE(!P.fuse || (P.tab_nb == 64 && P.bin_t && P.bin_f && P.tab && P.clean), LDW_ERR_ARG, "launch_gemm_apx: bad table arguments");
     static const int tile = [] {
         const char *e = exp_env("LDW_APX_TILE");   // tuning: wave tile in MFMA tiles, to side x from side (default 4 x 2)
