@@ -65,7 +65,7 @@ def parse():
                     help="run the timed region with the GEMM/epilogue stream overlap off too (kernel-exclusive times everywhere; "
                          "the command profiles/*_serial_kernel_stats.csv was collected with)")
     ap.add_argument("--fused", action="store_true", help="GEMM + MI epilogue as one kernel (ldw_set_fused(1)); default is GEMM -> G -> "
-                                                         "k_mi_screen -> k_mi_units, which is faster (DESIGN.md 5.2)")
+                                                         "k_mi_screen -> k_mi_units, which is faster (docs/HISTORY.md 5.2)")
     ap.add_argument("--no-mixed", action="store_true", help="block-wide GEMM with all 5 limbs instead of 3 high limbs + gathered low limbs")
     ap.add_argument("--path", type=int, default=0, help="block-wide pass of the speculative blocks: 0 auto, 1 limb GEMM paths, 2 approximate GEMM + popcount sums")
     ap.add_argument("--screen", type=int, default=1, help="fp32 screen before the fp64 MI evaluation: 0 off, 1 on, 2 verify")
@@ -874,7 +874,7 @@ def main():
                               f"{pr['tiles_pruned']} of {pr['tiles_total']} wave tiles = {100.0 * pr['tiles_pruned'] / pr['tiles_total']:.1f} % pruned; pruned tiles are "
                               f"not in `achieved`, and the shorter launches pay a larger share of ramp and tail" +
                               (f": the same K loop on full launches (`full_launches_without_pruning`: the same replay with ldw_set_prune(0), measured "
-                               f"live) runs at {unpruned['frac']:.2f} of the peak (DESIGN.md 5.1c/d).  " if unpruned else ".  "))
+                               f"live) runs at {unpruned['frac']:.2f} of the peak (docs/HISTORY.md 5.1c/d).  " if unpruned else ".  "))
             roof.update(kernel=kname, achieved=achieved, frac=achieved / i8_peak, avg_launch_ms=avg_ms, launches=n_launch,
                         executed_ops_per_launch=exec_per_launch,
                         alg_work_reduction=alg_per_launch / exec_per_launch,

@@ -134,7 +134,7 @@ int ldw_hamming_stats(ldw_ctx *ctx, double out[8]);
 /* ---- MI set-up ------------------------------------------------------------------------------ */
 /* Per-sequence weights hdw[N] (R/computePairwiseMI.R:77,89).  The engine uses v_s = fl(sqrt(hdw_s))^2
  * like the reference's sqrt-scaled one-hots, quantised to nlimbs*8-bit fixed point (nlimbs in 1..6,
- * 0 = default 5; see DESIGN.md "fixed-point weights"). */
+ * 0 = default 5). */
 int ldw_set_weights(ldw_ctx *ctx, const double *hdw, int64_t N, int nlimbs);
 /* r[L] (snp.dat$r), uqe[L][5] row-major 0/1 (snp.dat$uqe), POS[L] (snp.dat$POS: any order, like the reference — its own parser emits
  * ascending positions, and blocks whose lists ascend take the fast paths; a block in another order runs the plain path and a
@@ -391,7 +391,7 @@ int ldw_aracne_device(ldw_ctx *ctx, int64_t capacity, uint8_t *flags_out);
 /* ---- (7b) r05 — the same model with the short-range table LEFT on the GPUs that computed it (multi-GPU jobs: SURVEY.md 8(e); the
  *          reference's mergeNsort_sr_links, R/computePairwiseMI.R:400-495, sees one table).  Every rank calls (7) on its own rows; what
  *          travels between ranks is per-group bounds and counts, ~7 % of the MI column, five sums per block and cluster, the kept links and
- *          the ARACNE pool — not the table (host side: ldweaver_amd/dist_srp.py; protocol and proof of the bound: DESIGN.md 7b). ---- */
+ *          the ARACNE pool — not the table (host side: ldweaver_amd/dist_srp.py; protocol and proof of the bound: BOUNDS.md 10, docs/HISTORY.md 7b). ---- */
 /* Rows of the context's table at or above a per-(cluster, len) bound.  lower[c*S + l-1] (host; NaN: send nothing, -inf: every member).  A group's
  * rows are the table rows with that len whose pos1 or pos2 lies in cluster c+1 (a row of two clusters is a member of both, :411-414).
  * cnt_out[(l-1)*nclust + c] (host, len-major) = rows passing, *n_out their sum; mi_out (host or device, `capacity` doubles; NULL: count
@@ -485,7 +485,7 @@ int ldw_write_links_tsv_end(ldw_ctx *ctx, int64_t *rows_out, int64_t *bytes_out)
 int ldw_tsv_join(ldw_ctx *ctx);
 /* Host memory the library keeps between calls — the tsv writers' pooled buffers (process-wide, ~100 MB after a C4 job) and the context's pinned
  * fetch arena (16 B per row of the largest table written, <= 2.25 GB) — is released here (ctx may be NULL: the pool only).  Call it BETWEEN jobs:
- * on this driver stack giving large host regions back next to GPU work stalls the process's next GPU call.  bytes_out: released.
+ * on this driver stack giving large host regions back next to GPU work stalls the process's next GPU call (docs/HISTORY.md 8).  bytes_out: released.
  * r05: also the DEVICE blocks (>= 64 MB each, <= LDW_DEVPOOL_GB = 48 GB in all) that released buffers and destroyed contexts leave for the next taker — fetching
  * device memory from the driver costs up to 40 ms per GB on this stack, a second for every context created after another one was destroyed. */
 int ldw_host_trim(ldw_ctx *ctx, int64_t *bytes_out);

@@ -111,7 +111,7 @@ int prepare_apx_weights(ldw_ctx *c) {
     for (int k = 1; k < S4; ++k)
         if (sh[(size_t)k] > 0) c->apx_lost_units += std::ldexp(1.0, em[(size_t)k] - c->apx_e_last);
     // (experiments build, a PRICING switch: LDW_APX_EXTRA_UNITS=x treats every GEMM entry as up to x WEIGHT units low on top of that — what an absolute
-    // slack per entry, e.g. of a contraction over compressed clone groups, would cost the screen in listed pairs; results stay exact)
+    // slack per entry, e.g. of a contraction over compressed clone groups (docs/HISTORY.md 10), would cost the screen in listed pairs; results stay exact)
     if (const char *xs = exp_env("LDW_APX_EXTRA_UNITS")) {
         const double x = atof(xs);
         if (x > 0) c->apx_lost_units += x / std::ldexp(1.0, c->apx_e_last - c->frac_bits);
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256, 2) void gemm_apx_pipe_kernel(ApxGemmArgs P) {
                     nxt[ORD[4]] = nxt[ORD[4]] & dna;
                     nxt[ORD[5]] = nxt[ORD[5]] & dna;
                 }
-#ifdef LDW_PIPE_SGB   // pinning the interleave (MFMA, 2 table reads, 8 VALU per slot): 0.572 ms; without it (the compiler's own order): see DESIGN 5.1c
+#ifdef LDW_PIPE_SGB   // pinning the interleave (MFMA, 2 table reads, 8 VALU per slot): 0.572 ms; without it (the compiler's own order): see docs/HISTORY.md 5.1c
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);

@@ -16,6 +16,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "ldw_internal.h"
@@ -137,6 +139,14 @@ __global__ void k_shared_i32(const int64_t *__restrict__ G, int ld, const int32_
 static int hamming_impl(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *shared_out, int tile0, int tile1, int64_t *counts_out) {
     if (int rc = check_gpu(c)) return rc;
     const auto wall0 = std::chrono::steady_clock::now();
+    static const bool host_timing = getenv("LDW_HOST_TIMING") != nullptr;
+    double t_last = 0;
+    auto lap = [&](const char *what) {
+        if (!host_timing) return;
+        const double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        fprintf(stderr, "[ldw host] hamming: %-28s %7.3f ms (+%.3f)\n", what, t, t - t_last);
+        t_last = t;
+    };
     LDW_REQUIRE(c->L > 0, LDW_ERR_STATE, "ldw_hamming_weights: set the alignment first");
     const bool strip = tile0 >= 0;
     LDW_REQUIRE(strip ? counts_out != nullptr : hdw_out != nullptr, LDW_ERR_ARG, "ldw_hamming_weights: output is null");
@@ -163,6 +173,7 @@ static int hamming_impl(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *sh
     // per-SNP state counts -> which state is dropped, which columns exist
     std::vector<int32_t> hc((size_t)L * 5);   // [L][5]
     if ((rc = ldw_state_counts(c, hc.data()))) return done(rc);
+    lap("state counts on the host");
     std::vector<int32_t> colinfo;
     std::vector<int8_t> weight;
     std::vector<uint8_t> isA;
@@ -190,6 +201,7 @@ static int hamming_impl(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *sh
         }
     }
     const int64_t KR = (int64_t)colinfo.size();
+    lap("column list");
     LDW_REQUIRE(L < (1ll << 27), LDW_ERR_ARG, "ldw_hamming_weights: too many SNPs");
     int64_t KWr = (KR + 63) / 64;
     KWr = std::max<int64_t>(2, (KWr + 1) / 2 * 2);  // the GEMM loads word pairs
@@ -205,12 +217,14 @@ static int hamming_impl(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *sh
         (rc = Gh.reserve((size_t)Rp * Rp * 8)) || (rc = rl.reserve((size_t)Rp * 4)) || (rc = scnt.reserve((size_t)Rp * 4)) ||
         (rc = dhdw.reserve((size_t)N * 8)))
         return done(rc);
+    lap("device buffers");
     std::vector<int32_t> rowlist((size_t)Rp);
     for (int i = 0; i < Rp; ++i) rowlist[i] = i;
     if (KR > 0) HC(hipMemcpyAsync(info.p, colinfo.data(), (size_t)KR * 4, hipMemcpyHostToDevice, c->stream));
     HC(hipMemcpyAsync(dig.p, digits.data(), (size_t)Kpad, hipMemcpyHostToDevice, c->stream));
     HC(hipMemcpyAsync(um.p, umask.data(), (size_t)KWr * 8, hipMemcpyHostToDevice, c->stream));
     HC(hipMemcpyAsync(rl.p, rowlist.data(), (size_t)Rp * 4, hipMemcpyHostToDevice, c->stream));
+    lap("uploads queued");
     HC(hipEventRecord(c->ev[4], c->stream));   // (r06: the kernels in front of the GEMM bracketed on their own — ev[0] also sees the host work above)
     if (KR > 0) {
         if (KR * KW >= ((int64_t)1 << 39)) {
@@ -265,7 +279,9 @@ static int hamming_impl(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *sh
         s32.release();
         if (he != hipSuccess) return done(ldw::hip_fail(he, "shared copy", __FILE__, __LINE__));
     }
+    lap("kernels queued");
     HC(hipStreamSynchronize(c->stream));
+    lap("stream drained");
     float t = 0, tg = 0;
     HC(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
     HC(hipEventElapsedTime(&tg, c->ev[2], c->ev[1]));

@@ -6,7 +6,7 @@
 //                           tiled through LDS, exact int64; then the same fp64 epilogue as the MFMA engine.
 //   LDW_ENGINE_HIST_STATES  k_mi_hist — the first version: byte states staged in LDS, 25 fixed-point sums per pair updated one
 //                           sequence at a time.  Kept as the independent on-device cross-check (it shares nothing with the other
-//                           engines but the quantised weights) and as the record of what the bit planes buy (233x).
+//                           engines but the quantised weights) and as the record of what the bit planes buy (233x, docs/HISTORY.md 5.5).
 //
 // k_mi_hist: the per-pair 5x5 Hamming-weighted joint histogram kernel (VALU + LDS).
 //

@@ -151,14 +151,14 @@ struct ldw_ctx {
     ldw::DevBuf apx_mini[LDW_NSLOT];           // per slot: the 32-byte per-SNP extracts k_screen_maybe reads (MiniCol [nt], MiniRow [64 * from-tiles])
     ldw::DevBuf apx_units[LDW_NSLOT], apx_packs[LDW_NSLOT];   // per slot: per-(tile, class) unit lists + counters; per-block SNP constants
     int64_t apx_blocks = 0, apx_units_listed = 0, apx_pairs_listed = 0, probe_blocks = 0, generic_blocks = 0;
-    // Tile pruning: in blocks without a short-range pair the one-row SNPs are ordered by the weight of their minor
+    // Tile pruning (docs/HISTORY.md 5.1d): in blocks without a short-range pair the one-row SNPs are ordered by the weight of their minor
     // state, so that a wave tile of the approximate GEMM spans few bins of the threshold table; a tile whose whole bin rectangle is
     // unconditionally below the level (no joint count can lift such a pair to it) is flagged clean without being computed.
     bool prune = true;                 // LDW_NO_PRUNE switches ordering and skipping off (A/B measurements)
     ldw::DevBuf apx_skip;              // uint64: wave tiles the GEMM skipped since the counter was last read
     double apx_ops_per_wave = 0;       // executed-operation accounting of the skipped tiles (ldw_gemm_stats)
     int64_t apx_waves_skipped = 0, apx_waves_total = 0;
-    // Spans (r04): consecutive long-range-only blocks of one block row run as ONE launch sequence over their concatenated to side
+    // Spans (r04, docs/HISTORY.md 6b): consecutive long-range-only blocks of one block row run as ONE launch sequence over their concatenated to side
     bool span_on = true;               // ldw_set_span / LDW_NO_SPAN
     bool diag_split = false;           // ldw_set_span(on | 4) / LDW_DIAG_SPLIT: diagonal blocks as SR sub-pass + weight-ordered long-range pass
     bool span_corners = false;         // ldw_set_span(on | 2) / LDW_SPAN_CORNERS: corner blocks join the spans (SR sub-passes); measured slower, off by default
@@ -266,7 +266,7 @@ struct ldw_ctx {
     hipEvent_t ev_lrc = nullptr;
     bool lrc_recorded = false;
     bool fused = false;                  // GEMM + epilogue in one kernel whenever a bucket guess exists (ldw_fused.hip); off:
-                                         // GEMM -> k_mi_screen -> k_mi_units, which measures 7 % faster on C4
+                                         // GEMM -> k_mi_screen -> k_mi_units, which measures 7 % faster on C4 (docs/HISTORY.md 5.2)
     bool spec_seen[2] = {false, false};  // a block of this kind (off-diagonal, diagonal) has set its own guess
     bool spec_probed[2] = {false, false};   // the kind's current guess came from a cold-start probe of the kind itself
     std::vector<hipEvent_t> ev_pool;     // 4 timing events per block

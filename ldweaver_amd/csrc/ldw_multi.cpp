@@ -387,7 +387,7 @@ int ldw_sr_len_quantiles_multi(ldw_ctx **ctx, int n_ctx, int nclust, double sr_d
             return ldw_sr_len_quantiles(ctx[k], nclust, sr_dist, prob, S, qlo[(size_t)k].data(), qhi[(size_t)k].data(), cnt[(size_t)k].data());
         }))
         return rc;
-    // 2) the bound: the smallest local lower statistic of a group lies at or below the group's own
+    // 2) the bound: the smallest local lower statistic of a group lies at or below the group's own (docs/HISTORY.md 7b)
     std::vector<double> lower(G, std::nan(""));
     std::vector<int64_t> total(G, 0);
     for (size_t i = 0; i < G; ++i)

@@ -827,7 +827,7 @@ static int srm_reserve_select(ldw_ctx *c, int64_t n) {
     return c->srm_tmp.reserve(srm_sort_temp_bytes(n) + 256);
 }
 // ------------------------------------------------------------------------------------------------
-// r05: the short-range model with the rows LEFT on the rank that computed them.  What travels instead of the table:
+// r05: the short-range model with the rows LEFT on the rank that computed them (docs/HISTORY.md 7b).  What travels instead of the table:
 // per (cluster, len) group the rows at or above a bound that is known to lie below the group's order statistics (k_sr_tail: ~7 % of the MI
 // column), five sums per reference block and cluster, the kept links and the ARACNE pool.
 // ------------------------------------------------------------------------------------------------
@@ -1282,7 +1282,7 @@ int ldw_aracne_device(ldw_ctx *c, int64_t capacity, uint8_t *flags_out) {
     return LDW_OK;
 }
 
-// ---- r05: the short-range model over ranks: the table stays where it was computed ----------------------------------------
+// ---- r05: the short-range model over ranks (docs/HISTORY.md 7b): the table stays where it was computed ----------------------------------------
 
 int ldw_sr_tail_extract(ldw_ctx *c, int nclust, int32_t S, const double *lower, int64_t *cnt_out, double *mi_out, int64_t capacity, int on_device,
                         int64_t *n_out) {

@@ -744,7 +744,7 @@ int ldw_write_links_tsv_begin(ldw_ctx *c, int which, const char *path, int appen
 int ldw_host_trim(ldw_ctx *c, int64_t *bytes_out) {
     // a long-lived R / Python session keeps, after one big job, the writer's pooled thread buffers (process-wide) and the context's
     // pinned fetch arena (up to 2 GB x 1.125) until the context dies.  They are kept on purpose WHILE jobs run (an munmap next to GPU work
-    // stalls the process's next GPU call by ~20 ms: DESIGN.md 8); this gives them back between jobs, when the caller says so.
+    // stalls the process's next GPU call by ~20 ms: docs/HISTORY.md 8); this gives them back between jobs, when the caller says so.
     int64_t n = (int64_t)host_pool().trim();
     n += (int64_t)ldw::device_pool_trim();   // r05: + the released DEVICE blocks kept for the next context (ldw_api.hip)
     if (c) {

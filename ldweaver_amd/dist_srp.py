@@ -1,5 +1,5 @@
 """The short-range model of ``mergeNsort_sr_links`` (R/computePairwiseMI.R:400-495) + ``runARACNE`` over the ranks of a multi-GPU job
-WITHOUT assembling the short-range table on one GPU (r05).
+WITHOUT assembling the short-range table on one GPU (r05; docs/HISTORY.md 7b).
 
 The reference sees one table.  Here every rank keeps the rows of the block pairs it computed (99 % of a job's links: 1.44 GB at C4,
 36 GB at C5) and the ranks exchange only what the model's four data reductions need:

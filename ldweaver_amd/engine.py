@@ -708,7 +708,7 @@ def write_table_tsv(path: str, columns, append: bool = True, nthreads: int = 0) 
 class EngineGroup:
     """The short-range model's view of SEVERAL engines of this process after ``Engine.mi_all_pairs_multi(.., sr_rows_stay=True)``: the reductions
     of ``srp.merge_n_sort_sr_links_device`` run over the engines' own rows inside the library (ldw_sr_len_quantiles_multi / _excess_stats_multi /
-    _pvalues_multi: a worker thread per context), everything after them on engines[0]."""
+    _pvalues_multi: a worker thread per context; docs/HISTORY.md 7b), everything after them on engines[0]."""
 
     def __init__(self, engines):
         self.engines = list(engines)

@@ -6,7 +6,7 @@ import pytest
 
 # OpenMP threads that find nothing to do sleep instead of spinning (must be set before the first OpenMP runtime of the process starts).  The C
 # oracle's loops over 25 million pairs share the box with whatever the subprocess-based tests before them have left running; spinning teams on
-# oversubscribed cores are the one known way for a 9-s test to take minutes (r05: one such run, never located: DESIGN.md 0).
+# oversubscribed cores are the one known way for a 9-s test to take minutes (r05: one such run, never located: docs/HISTORY.md 0).
 os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

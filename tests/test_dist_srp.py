@@ -414,7 +414,7 @@ def test_sr_model_over_ranks_equals_one_table(tmp_path):
             for rk in range(1, world):
                 # what a rank sent against its MI column alone (the r04 gather's 8 B per row).  At this small shape a (cluster, len) group has ~10
                 # rows per rank, so "the rows from the smallest local 95 % order statistic up" are a third of them; at C4's shape (375 rows per
-                # group and rank) they are ~7 % (bench.py --sr-tail dist: DESIGN.md 7b)
+                # group and rank) they are ~7 % (bench.py --sr-tail dist: docs/HISTORY.md 7b)
                 # (the per-group tables — counts, bounds: 4 x 480 KB — are most of what travels here; they do not grow with the table)
                 assert cand[rk] < 0.6 * rows[rk] and sent[rk] < 8 * cand[rk] + 3_000_000, (world, rk, sent, rows, cand)
 

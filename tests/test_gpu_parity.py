@@ -28,7 +28,7 @@ EXP = None
 
 def _need_exp(what=""):
     """Skip unless the loaded library is the experiments build (make EXPERIMENTS=1, LDW_AMD_LIB=.../libldweaver_amd_exp.so): the default
-    library ships without the measured-slower variants (DESIGN.md 11); the builder's loop runs these cases against the experiments build."""
+    library ships without the measured-slower variants (DESIGN.md 14); the builder's loop runs these cases against the experiments build."""
     global EXP
     if EXP is None:
         EXP = L.has_experiments()
@@ -1987,7 +1987,7 @@ def test_spans_equal_block_by_block(engine):
             # shorter spans give the same tables
             engine.set_span(True, 2)
             same(plain, run(quirk, True), (quirk, "spans of 2"))
-            if L.has_experiments():   # (the two measured-slower span variants are not in the default library: DESIGN.md 11)
+            if L.has_experiments():   # (the two measured-slower span variants are not in the default library: DESIGN.md 14)
                 # corner block pairs inside the spans (their short-range pairs through SR sub-passes): the same tables, short-range rows included
                 engine.set_span(True, 8, corners=True)
                 s2 = engine.span_report()
@@ -2479,7 +2479,7 @@ def _mi11(n, pa, pb, W):
 @pytest.mark.parametrize("W,lo", [(6.614192337876547, 0.98 * 0.314453125), (6.614192337876547, 0.33), (3.0, 0.2), (41.5, 0.5), (41.5, 0.05), (100.0, 0.1), (1000.0, 0.05), (1000.0, 0.62),
                                   (4321.0, 0.2), (4321.0, 0.66)])
 def test_threshold_table_never_dismisses_a_pair_that_reaches_the_level(engine, W, lo):
-    """The threshold table of the biallelic pairs (k_build_tab11) against the MI formula on a grid of joint tables: whenever MI >= lo the sum must lie
+    """The threshold table of the biallelic pairs (k_build_tab11, BOUNDS.md 5) against the MI formula on a grid of joint tables: whenever MI >= lo the sum must lie
     outside (Lq, Hq) of its marginals' bin.  The grid holds what the 3 x 3 corner sampling cannot see by itself: tables on the line pa + pb = W with an EMPTY joint cell
     (perfect anti-association — r05: tools/fuzz_paths.py --seed 203 --only 96 found two such pairs dismissed at W = 6.6, the first parameter set here) and on the
     diagonal pa = pb with a full one, next to a dense sweep.  The table must also still DO something: most tables far below the level are dismissed."""

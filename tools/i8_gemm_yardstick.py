@@ -3,7 +3,7 @@
 int8 x int8 -> int32) deliver on this box at the block's shape — 11648 x 11648 x 5120, the row lists of a 10k x 10k C4 block — and at a
 span's shape (7 blocks on the to side)?  Tools only: never linked into or called by the product.  The product's kernel
 (gemm_apx_kernel) feeds its MFMAs from BIT-packed operands expanded in registers (15 MB of panels per block instead of 120 MB of
-bytes); this is the byte-operand feed it is compared with in DESIGN.md 5.1c(b).
+bytes); this is the byte-operand feed it is compared with in docs/HISTORY.md 5.1c(b).
 usage: python tools/i8_gemm_yardstick.py [out.json]"""
 import json
 import sys
