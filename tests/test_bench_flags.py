@@ -68,3 +68,26 @@ def test_bench_multi_rank_rehearsal():
     sent = sum(r["bytes_sent"] for r in pr)
     assert sent <= 8 * one["links"]["n_sr"] + 16 * one["links"]["n_lr"]
     assert sent < 0.6 * 16 * (one["links"]["n_sr"] + one["links"]["n_lr"]) * 3 / 4 + 16 * one["links"]["n_lr"]
+
+
+def test_bench_line_carries_roofline_hamming_and_the_scaling_model():
+    """r06: `roofline_hamming` (the Hamming stage priced: its GEMM against the int8 peak on executed operations, the kernels around it against HBM, the
+    rest of the call as host time) and `scaling_model` (every share of the N = 1, 2, 4, 8 deals run alone on this GPU + a modelled gather; marked as a model)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = _bench_line([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--L", "30000", "--N", "1500", "--max-blk-sz", "5000", "--steps", "2", "--warmup", "1",
+                     "--no-cpu-baseline", "--no-adversarial", "--no-job", "--sustain-s", "0"], 600)
+    rh = d["roofline_hamming"]
+    assert rh["columns"] > 30000 and 0 < rh["gemm"]["frac"] < 1 and rh["gemm"]["executed_ops"] > 0 and rh["gemm"]["bound"] == "mfma"
+    assert rh["pre"]["bound"] == "hbm" and 0 < rh["pre"]["frac"] < 1 and 0 < rh["post"]["frac"] < 1
+    assert abs(rh["kernels_ms"] + rh["host_ms"] - rh["wall_ms"]) < 1e-6 and rh["host_ms"] > 0
+    sm = d["scaling_model"]
+    assert sm["status"].startswith("MODEL, UNMEASURED")
+    pred = sm["predicted"]
+    assert sorted(pred) == ["1", "2", "4", "8"]
+    assert all(p["predicted_ms_per_step"] > 0 and len(p["per_rank"]) == int(n) for n, p in pred.items())
+    assert sum(r["blocks"] for r in pred["8"]["per_rank"]) == 21     # make_blocks(30000, 5000): 6 from-blocks -> 21 block pairs, every one dealt once
+    assert pred["1"]["exposed_gather_model_ms"] == 0 and pred["8"]["exposed_gather_model_ms"] > 0
+    assert 0.5 < pred["1"]["predicted_ms_per_step"] / d["ms_per_step"] < 2.0
+    assert pred["8"]["slowest_share_compute_ms"] < pred["1"]["slowest_share_compute_ms"]
+    ep = d["roofline_mi_produced"]["epilogue"]
+    assert ep["kernel"] == "k_mi_epilogue" and ep["ps_per_pair"] > 0 and ep["valu_issue_frac"] is None   # (the counters are those of the 100k x 5k shape only)
