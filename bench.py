@@ -816,14 +816,14 @@ def main():
                 measured_in=f"{n_rp} serialized replay steps of the plain path (overlap off), HIP events around the kernels",
                 note="achieved = executed int8 operations (2 x rows x rows x positions x 5 limbs of every workgroup tile that runs; one indicator row per minor "
                      "state: 1.16 rows per SNP) / launch time; alg_frac prices SURVEY 8(d)'s 50 N flops per pair against the same peak — above `frac` "
-                     "because the row reduction removes 18x of the one-hot formulation's work and the 5 limbs put 5x back.  profiles/r05_c4_plain_serial_kernel_stats.csv "
+                     "because the row reduction removes 18x of the one-hot formulation's work and the 5 limbs put 5x back.  profiles/r06_c4_plain_serial_kernel_stats.csv "
                      "holds rocprofv3's average for the same kernel")
-        tp = os.path.join(ROOT, "profiles", "r05_pmc_traffic_plain.json")   # (PMC passes of `bench.py --no-mixed --screen 0 --path 1`, tools/r05_final.sh)
+        tp = os.path.join(ROOT, "profiles", "r06_pmc_traffic_plain.json")   # (PMC passes of `bench.py --no-mixed --screen 0 --path 1`, tools/r06_final.sh)
         if "roofline_mi_produced" in legs and os.path.exists(tp) and (L, N, world) == (100_000, 5_000, 1):
             ent = json.load(open(tp)).get(legs["roofline_mi_produced"]["kernel"])
             if ent:
                 legs["roofline_mi_produced"].update(traffic=ent.get("hbm_bytes_per_launch"), traffic_range=ent.get("hbm_bytes_per_launch_range"),
-                                                    traffic_source="profiles/r05_pmc_traffic_plain.json (FETCH_SIZE x 2 + WRITE_SIZE per launch, separate --pmc passes)")
+                                                    traffic_source="profiles/r06_pmc_traffic_plain.json (FETCH_SIZE x 2 + WRITE_SIZE per launch, separate --pmc passes)")
         eng.set_mixed(not args.no_mixed)
         eng.set_screen(args.screen)
         eng.set_path(args.path)
@@ -894,9 +894,9 @@ def main():
                              "kernel's own accumulators (the regions that pass are neither stored nor screened).  " + prune_note +
                              "`overlapped_avg_launch_ms` "
                              "is the bracket inside the timed region, where the GEMM shares the GPU with the previous block's screens and selection")
-            tpath = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
+            tpath = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
             if not os.path.exists(tpath):
-                tpath = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+                tpath = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
             if os.path.exists(tpath) and (L, N, world) == (100_000, 5_000, 1):   # the configuration the PMC passes were collected on
                 ent = json.load(open(tpath)).get(kname)
                 if ent:

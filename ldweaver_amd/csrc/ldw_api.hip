@@ -482,7 +482,7 @@ int ldw_ctx_reserve(ldw_ctx *c, int64_t L, int64_t N, int64_t max_blk_sz) {
     const int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(c->span_on ? c->span_max : 1, nblk - 2));
     // the packed staging image of a span (prep_block): index, row and permutation lists of both sides, 48 bytes of intervals per to-side SNP
     const int64_t nt = blk * nseg, rows_f = blk * 5 / 4 + 512, rows_t = nt * 5 / 4 + 512;
-    const size_t stage = (size_t)((blk + nt) * 12 + (rows_f + rows_t) * 9 + nt * 52 + (blk + 64) * 16 + (rows_t / 128 + 1) * (rows_f / 64 + 1) + 65536);
+    const size_t stage = (size_t)((blk + nt) * 12 + (rows_f + rows_t) * 9 + nt * 52 + (blk + 64) * 16 + 3 * (rows_t / 128 + 1) * (rows_f / 64 + 1) + 65536);   // (r06: + the band's tile list, at most 2 bytes per tile of the mask)
     const int64_t Npad = (N + ldw::KSTEP - 1) / ldw::KSTEP * ldw::KSTEP;
     c->prep_thread2 = new std::thread([c, stage, Npad, blk, nseg] {
         int rc = LDW_OK;

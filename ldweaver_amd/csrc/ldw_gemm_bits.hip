@@ -38,12 +38,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bits_kernel(const uint64_t *__res
                                                               const int8_t *__restrict__ digits, int64_t Kpad,
                                                               int64_t *__restrict__ G, int RFpad, int lower_only,
                                                               int shift_bits, int accumulate, int by0,
-                                                              const uint8_t *__restrict__ tile_mask) {
-    const int bx = blockIdx.x, by = blockIdx.y + by0;  // bx: from-side tile of 64 rows, by: to-side tile of 128 rows (grid.y may
-                                                       // cover a strip of them starting at by0: sharded Hamming weights)
-    if (lower_only && bx * TILE_F4 + TILE_F4 - 1 < by * TILE) return;
-    // tile_mask[by][bx] == 0: nobody reads this tile (approximate path: only the tiles that hold a short-range pair are needed)
-    if (tile_mask && tile_mask[by * (RFpad / TILE_F4) + bx] == 0) return;
+                                                              const uint8_t *__restrict__ tile_mask, const uint32_t *__restrict__ tile_list) {
+    int bx = blockIdx.x, by = blockIdx.y + by0;  // bx: from-side tile of 64 rows, by: to-side tile of 128 rows (grid.y may
+                                                 // cover a strip of them starting at by0: sharded Hamming weights)
+    if (tile_list) {
+        // r06: the band launches of the approximate path run over the LIST of their live tiles (the host builds it with the mask: prep_block) — a 1-D grid of
+        // exactly those.  With the mask alone the launch dispatched the whole 182 x 91 grid of a 10k x 10k block for the ~1 700 tiles of its short-range band,
+        // and ~15 000 workgroups that leave at once still cost ~4 ns each: a third of the launch (profiles/r06_band_tile_list.txt).
+        const uint32_t t = tile_list[blockIdx.x];
+        bx = (int)(t & 0xFFFFu);
+        by = (int)(t >> 16);
+    } else {
+        if (lower_only && bx * TILE_F4 + TILE_F4 - 1 < by * TILE) return;
+        // tile_mask[by][bx] == 0: nobody reads this tile (approximate path: only the tiles that hold a short-range pair are needed)
+        if (tile_mask && tile_mask[by * (RFpad / TILE_F4) + bx] == 0) return;
+    }
 
     __shared__ GemmSmem<J> S;
 #include "ldw_gemm_kloop.inc"
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(256) void k_fill_rows_bits(const uint8_t *__restric
 
 int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f,
                      int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only, hipStream_t stream, int by0, int by1,
-                     const uint8_t *tile_mask) {
+                     const uint8_t *tile_mask, const uint32_t *tile_list, int n_tile_list) {
     if (!stream) stream = ctx->stream;
     const int64_t Kpad = KW * 64;
     LDW_REQUIRE(RTpad % TILE == 0 && RFpad % TILE == 0 && KW > 0 && KW % 2 == 0 && Kpad == KW * 64, LDW_ERR_ARG,
@@ -189,6 +198,14 @@ int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int3
     if (by1 < 0) by1 = RTpad / TILE;
     LDW_REQUIRE(by0 >= 0 && by0 < by1 && by1 <= RTpad / TILE, LDW_ERR_ARG, "launch_gemm_bits: bad tile-row range %d..%d", by0, by1);
     dim3 grid(RFpad / TILE_F4, by1 - by0), block(256);
+    if (tile_list) {   // (the mask's tiles as a list: tile = by << 16 | bx, tiles above the diagonal of a lower_only launch already left out)
+        LDW_REQUIRE(n_tile_list >= 0 && by0 == 0 && RFpad / TILE_F4 < 65536 && RTpad / TILE < 65536, LDW_ERR_ARG, "launch_gemm_bits: bad tile list");
+        if (n_tile_list == 0) {
+            ctx->gemm_stat[4] += 1;
+            return LDW_OK;
+        }
+        grid = dim3((unsigned)n_tile_list, 1);
+    }
     int done = 0;
     while (done < nlimbs) {  // up to 5 limbs share one pass over K; 6 limbs run as 3 + 3
         const int J = (nlimbs == 6) ? 3 : nlimbs;
@@ -197,7 +214,7 @@ int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int3
 #define LDW_LAUNCH_B(JJ)                                                                                        \
     case JJ:                                                                                                    \
         hipLaunchKernelGGL(gemm_bits_kernel<JJ>, grid, block, 0, stream, Mbits, KW,                                 \
-                           rowlist_t, rowlist_f, dg, Kpad, G, RFpad, lower_only, shift, accum, by0, tile_mask); \
+                           rowlist_t, rowlist_f, dg, Kpad, G, RFpad, lower_only, shift, accum, by0, tile_mask, tile_list); \
         break;
         switch (J) {
             LDW_LAUNCH_B(1)
@@ -210,7 +227,7 @@ int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int3
         LDW_HIP(hipGetLastError());
         done += J;
     }
-    if (!tile_mask) {   // executed work (ldw_gemm_stats): workgroup tiles that do not leave at once, all limbs
+    if (!tile_mask && !tile_list) {   // executed work (ldw_gemm_stats): workgroup tiles that do not leave at once, all limbs
         int64_t tiles = 0;
         const int nbx = RFpad / TILE_F4;
         for (int by = by0; by < by1; ++by) {

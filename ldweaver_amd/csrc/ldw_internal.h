@@ -296,7 +296,8 @@ int launch_hist(ldw_ctx *ctx, const int32_t *idx_f, int nf, const int32_t *idx_t
 int launch_gemm_bits(ldw_ctx *ctx, const uint64_t *Mbits, int64_t KW, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f,
                      int RFpad, int64_t *G, int nlimbs, const int8_t *digits, int lower_only, hipStream_t stream = nullptr, int by0 = 0,
                      int by1 = -1,    // by0..by1: strip of 128-row to-side tiles to compute (default: all)
-                     const uint8_t *tile_mask = nullptr);   // [RTpad / 128][RFpad / 64]: 0 = skip the tile (default: all tiles)
+                     const uint8_t *tile_mask = nullptr,    // [RTpad / 128][RFpad / 64]: 0 = skip the tile (default: all tiles)
+                     const uint32_t *tile_list = nullptr, int n_tile_list = 0);   // r06: the same tiles as a list (by << 16 | bx): a 1-D grid of exactly those
 // the same exact sums (all limbs) by class-wise popcounts over the bit rows (ldw_hist.hip, LDW_ENGINE_HIST)
 int launch_cooc_popc(ldw_ctx *ctx, const int32_t *rowlist_t, int RTpad, const int32_t *rowlist_f, int RFpad, int64_t *G, int lower_only,
                      hipStream_t stream = nullptr);
