@@ -198,6 +198,8 @@ hipError_t dev_alloc(void **out, size_t want, size_t &cap_out) {
 }  // namespace
 
 size_t device_pool_trim() { return pool_flush(); }
+// the per-SNP state counts into ctx->counts ([L][5] int32) on the context's stream; no copy, no synchronisation (ldw_state_counts, ldw_hamming_weights)
+int launch_state_counts(ldw_ctx *c);
 void ctx_count(int d) {
     if (g_live_ctx.fetch_add(d) + d <= 0 && d < 0) (void)pool_flush(pool_idle_limit() ? pool_idle_limit() : 0);   // the last context of the process has gone
 }
@@ -389,6 +391,15 @@ __global__ void k_fast_hadamard(double *__restrict__ MI, const double *__restric
         const double d = ((pxpy[c] + RXY[c]) + pXrX[c]) + pYrY[c];
         MI[c] += ((uq[c] * pxy[c]) / den[c]) * log((pxy[c] / d) * den[c]);
     }
+}
+
+int launch_state_counts(ldw_ctx *c) {
+    LDW_REQUIRE(c->L > 0, LDW_ERR_STATE, "state counts: no alignment resident");
+    if (int rc = c->counts.reserve((size_t)c->L * 5 * 4)) return rc;
+    hipLaunchKernelGGL(k_counts_marginals, dim3((unsigned)((c->L + 3) / 4)), dim3(256), 0, c->stream, c->states.as<uint8_t>(), c->L, c->Npad, (const int64_t *)nullptr,
+                       c->counts.as<int32_t>(), (int64_t *)nullptr);
+    LDW_HIP(hipGetLastError());
+    return LDW_OK;
 }
 
 }  // namespace ldw
@@ -808,11 +819,7 @@ int ldw_get_alignment(ldw_ctx *c, uint8_t *out) {
 int ldw_state_counts(ldw_ctx *c, int32_t *counts_out) {
     if (int rc = check_gpu(c)) return rc;
     LDW_REQUIRE(counts_out && c->L > 0, LDW_ERR_STATE, "ldw_state_counts: no alignment resident");
-    if (int rc = c->counts.reserve((size_t)c->L * 5 * 4)) return rc;
-    hipLaunchKernelGGL(k_counts_marginals, dim3((unsigned)((c->L + 3) / 4)), dim3(256), 0, c->stream,
-                       c->states.as<uint8_t>(), c->L, c->Npad, (const int64_t *)nullptr, c->counts.as<int32_t>(),
-                       (int64_t *)nullptr);
-    LDW_HIP(hipGetLastError());
+    if (int rc = ldw::launch_state_counts(c)) return rc;
     // stored [L][5] row-major == 5 x L column-major (ACGTN_table layout)
     LDW_HIP(hipMemcpyAsync(counts_out, c->counts.p, (size_t)c->L * 20, hipMemcpyDeviceToHost, c->stream));
     LDW_HIP(hipStreamSynchronize(c->stream));

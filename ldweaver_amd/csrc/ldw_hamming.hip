@@ -16,11 +16,13 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 #include "ldw_internal.h"
+#include "ldw_prim.h"
 
 using namespace ldw;
 
@@ -56,6 +58,59 @@ __global__ __launch_bounds__(256) void k_hamming_cols(const uint8_t *__restrict_
         }
     }
     Hb[t] = bits;
+}
+
+// r06: the column list on the DEVICE (the host loop over L SNPs + the download of the state counts + the uploads of the list were 2.8 of the call's 6.3 ms at
+// config 4: profiles/r06_hamming_host_timing.txt).  k_ham_ncols: columns of every SNP — none for a monomorphic SNP, one for a biallelic SNP (the minor state,
+// weight 2: it is its own "not the major state" column), otherwise one per minor state + the A column; an exclusive scan gives every SNP its first column;
+// k_ham_fill writes the same records the host loop wrote, in the same order.
+__device__ __forceinline__ int ham_drop(const int32_t *cnt, int &present) {
+    int drop = -1;
+    present = 0;
+#pragma unroll
+    for (int x = 0; x < 5; ++x)
+        if (cnt[x] > 0) {
+            ++present;
+            if (drop < 0 || cnt[x] > cnt[drop]) drop = x;
+        }
+    return drop;
+}
+__global__ __launch_bounds__(256) void k_ham_ncols(const int32_t *__restrict__ counts, int64_t L, int32_t *__restrict__ ncol) {
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a > L) return;
+    int n = 0;
+    if (a < L) {
+        int cnt[5], present;
+#pragma unroll
+        for (int x = 0; x < 5; ++x) cnt[x] = counts[a * 5 + x];
+        (void)ham_drop(cnt, present);
+        n = present <= 1 ? 0 : (present == 2 ? 1 : present);
+    }
+    ncol[a] = n;   // (ncol[L] = 0: the scan's last entry is the total)
+}
+__global__ __launch_bounds__(256) void k_ham_fill(const int32_t *__restrict__ counts, int64_t L, const int32_t *__restrict__ off, int32_t *__restrict__ info,
+                                                  int8_t *__restrict__ digits, unsigned long long *__restrict__ umask) {
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= L) return;
+    int cnt[5], present;
+#pragma unroll
+    for (int x = 0; x < 5; ++x) cnt[x] = counts[a * 5 + x];
+    const int drop = ham_drop(cnt, present);
+    if (present <= 1) return;
+    const bool single = present == 2;
+    int64_t k = off[a];
+    for (int x = 0; x < 5; ++x)
+        if (x != drop && cnt[x] > 0) {
+            info[k] = (int32_t)(a * 16 + x);
+            digits[k] = single ? 2 : 1;
+            if (single) atomicOr(&umask[k >> 6], 1ull << (k & 63));
+            ++k;
+        }
+    if (!single) {
+        info[k] = (int32_t)(a * 16 + 8 + drop);
+        digits[k] = 1;
+        atomicOr(&umask[k >> 6], 1ull << (k & 63));
+    }
 }
 
 // 64 x 64 bit-tile transpose: Hb[KR][KW] (columns x sequence words) -> T[KW*64][KWr] (sequences x column words).
@@ -154,75 +209,61 @@ static int hamming_impl(ldw_ctx *c, int32_t thresh, double *hdw_out, int32_t *sh
     const int Rp = (int)Npad;  // sequences padded to the GEMM tile (Npad is a multiple of 128)
     LDW_REQUIRE(!strip || (tile0 < tile1 && tile1 <= Rp / ldw::TILE), LDW_ERR_ARG, "ldw_hamming_counts: tile range %d..%d outside 0..%d", tile0,
                 tile1, Rp / ldw::TILE);
-    ldw::DevBuf info, Hb, T, dig, um, Gh, rl, scnt, dhdw;
+    ldw::DevBuf info, Hb, T, dig, um, Gh, rl, scnt, dhdw, tmp;
     int rc = LDW_OK;
     auto done = [&](int code) {
         // (the stream has been drained on every path that reaches this with work queued; a failed launch has queued nothing behind it)
         const bool drained = hipStreamSynchronize(c->stream) == hipSuccess;
         if (drained) {
             ldw::DrainedScope quiet;   // no device-wide synchronisation per released block (other contexts of the device may be in the middle of a pass)
-            for (ldw::DevBuf *b : {&info, &Hb, &T, &dig, &um, &Gh, &rl, &scnt, &dhdw}) b->release();
+            for (ldw::DevBuf *b : {&info, &Hb, &T, &dig, &um, &Gh, &rl, &scnt, &dhdw, &tmp}) b->release();
         } else {
-            for (ldw::DevBuf *b : {&info, &Hb, &T, &dig, &um, &Gh, &rl, &scnt, &dhdw}) b->release();
+            for (ldw::DevBuf *b : {&info, &Hb, &T, &dig, &um, &Gh, &rl, &scnt, &dhdw, &tmp}) b->release();
         }
         return code;
     };
     hipError_t he;
 #define HC(x) do { he = (x); if (he != hipSuccess) return done(ldw::hip_fail(he, #x, __FILE__, __LINE__)); } while (0)
     HC(hipEventRecord(c->ev[0], c->stream));
-    // per-SNP state counts -> which state is dropped, which columns exist
-    std::vector<int32_t> hc((size_t)L * 5);   // [L][5]
-    if ((rc = ldw_state_counts(c, hc.data()))) return done(rc);
-    lap("state counts on the host");
-    std::vector<int32_t> colinfo;
-    std::vector<int8_t> weight;
-    std::vector<uint8_t> isA;
-    colinfo.reserve((size_t)L * 2);
-    for (int64_t a = 0; a < L; ++a) {
-        const int32_t *cnt = &hc[(size_t)a * 5];
-        int drop = -1, present = 0;
-        for (int x = 0; x < 5; ++x)
-            if (cnt[x] > 0) {
-                ++present;
-                if (drop < 0 || cnt[x] > cnt[drop]) drop = x;
-            }
-        if (present <= 1) continue;  // monomorphic: every pair of sequences shares it, the constant L covers that
-        const bool single = present == 2;
-        for (int x = 0; x < 5; ++x)
-            if (x != drop && cnt[x] > 0) {
-                colinfo.push_back((int32_t)(a * 16 + x));
-                weight.push_back(single ? 2 : 1);
-                isA.push_back(single ? 1 : 0);
-            }
-        if (!single) {
-            colinfo.push_back((int32_t)(a * 16 + 8 + drop));
-            weight.push_back(1);
-            isA.push_back(1);
-        }
-    }
-    const int64_t KR = (int64_t)colinfo.size();
-    lap("column list");
+    // per-SNP state counts -> which state is dropped, which columns exist: on the device (k_ham_ncols, a prefix sum, k_ham_fill); the host learns the column
+    // count alone (one 4-byte copy) to size the bit matrices
     LDW_REQUIRE(L < (1ll << 27), LDW_ERR_ARG, "ldw_hamming_weights: too many SNPs");
+    auto done2 = [&](int code) { return done(code); };
+    if ((rc = ldw::launch_state_counts(c))) return done(rc);
+    size_t scan_bytes = 0;
+    HC(ldw::prim_exclusive_sum<int32_t>(nullptr, scan_bytes, (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)L + 1, c->stream));
+    const size_t o_off = ((size_t)(L + 1) * 4 + 255) / 256 * 256, o_scan = 2 * o_off;
+    if ((rc = tmp.reserve(o_scan + scan_bytes + 256))) return done(rc);
+    int32_t *d_ncol = tmp.as<int32_t>(), *d_off = reinterpret_cast<int32_t *>(tmp.as<char>() + o_off);
+    hipLaunchKernelGGL(k_ham_ncols, dim3((unsigned)((L + 1 + 255) / 256)), dim3(256), 0, c->stream, c->counts.as<int32_t>(), L, d_ncol);
+    he = hipGetLastError();
+    if (he == hipSuccess) he = ldw::prim_exclusive_sum<int32_t>(tmp.as<char>() + o_scan, scan_bytes, d_ncol, d_off, (size_t)L + 1, c->stream);
+    int32_t kr32 = 0;
+    if (he == hipSuccess) he = hipMemcpyAsync(&kr32, d_off + L, 4, hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (he != hipSuccess) return done2(ldw::hip_fail(he, "column count of the Hamming GEMM", __FILE__, __LINE__));
+    lap("column count on the host");
+    const int64_t KR = (int64_t)kr32;
     int64_t KWr = (KR + 63) / 64;
     KWr = std::max<int64_t>(2, (KWr + 1) / 2 * 2);  // the GEMM loads word pairs
     const int64_t Kpad = KWr * 64;
-    std::vector<int8_t> digits((size_t)Kpad, 0);
-    std::vector<uint64_t> umask((size_t)KWr, 0);
-    for (int64_t k = 0; k < KR; ++k) {
-        digits[(size_t)k] = weight[(size_t)k];
-        if (isA[(size_t)k]) umask[(size_t)(k >> 6)] |= 1ull << (k & 63);
-    }
     if ((rc = info.reserve((size_t)std::max<int64_t>(KR, 1) * 4)) || (rc = Hb.reserve((size_t)std::max<int64_t>(KR, 1) * KW * 8)) ||
         (rc = T.reserve((size_t)Rp * KWr * 8)) || (rc = dig.reserve((size_t)Kpad)) || (rc = um.reserve((size_t)KWr * 8)) ||
         (rc = Gh.reserve((size_t)Rp * Rp * 8)) || (rc = rl.reserve((size_t)Rp * 4)) || (rc = scnt.reserve((size_t)Rp * 4)) ||
         (rc = dhdw.reserve((size_t)N * 8)))
-        return done(rc);
+        return done2(rc);
     lap("device buffers");
+    he = hipMemsetAsync(dig.p, 0, (size_t)Kpad, c->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(um.p, 0, (size_t)KWr * 8, c->stream);
+    if (he != hipSuccess) return done2(ldw::hip_fail(he, "zeroing the column weights", __FILE__, __LINE__));
+    if (KR > 0) {
+        hipLaunchKernelGGL(k_ham_fill, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, c->stream, c->counts.as<int32_t>(), L, d_off, info.as<int32_t>(), dig.as<int8_t>(),
+                           um.as<unsigned long long>());
+        he = hipGetLastError();
+        if (he != hipSuccess) return done2(ldw::hip_fail(he, "k_ham_fill", __FILE__, __LINE__));
+    }
     std::vector<int32_t> rowlist((size_t)Rp);
     for (int i = 0; i < Rp; ++i) rowlist[i] = i;
-    if (KR > 0) HC(hipMemcpyAsync(info.p, colinfo.data(), (size_t)KR * 4, hipMemcpyHostToDevice, c->stream));
-    HC(hipMemcpyAsync(dig.p, digits.data(), (size_t)Kpad, hipMemcpyHostToDevice, c->stream));
-    HC(hipMemcpyAsync(um.p, umask.data(), (size_t)KWr * 8, hipMemcpyHostToDevice, c->stream));
     HC(hipMemcpyAsync(rl.p, rowlist.data(), (size_t)Rp * 4, hipMemcpyHostToDevice, c->stream));
     lap("uploads queued");
     HC(hipEventRecord(c->ev[4], c->stream));   // (r06: the kernels in front of the GEMM bracketed on their own — ev[0] also sees the host work above)

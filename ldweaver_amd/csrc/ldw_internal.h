@@ -315,6 +315,7 @@ void warm_apx();
 void warm_gemm_bits();
 void ctx_count(int d);               // ldw_api.hip: live contexts of the process (the last one to go trims the device free list to its idle cap)
 struct DrainedScope { DrainedScope(); ~DrainedScope(); };   // releases inside: the caller has drained every stream that could touch the blocks
+int launch_state_counts(ldw_ctx *ctx);   // ldw_api.hip: per-SNP state counts into ctx->counts on the context's stream (no copy, no synchronisation)
 size_t device_pool_trim();          // ldw_api.hip: give the released device blocks kept for re-use back to the runtime (ldw_host_trim); bytes
 void warm_srp();
 // ldw_srp.hip: ldw_sr_reduced_import with the kept links' meta words (clust_c | first << 8 | dup << 16) and srp values (both may be null)
