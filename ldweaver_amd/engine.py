@@ -22,10 +22,16 @@ class Engine:
             self.set_stream(stream)
 
     # -- lifetime ------------------------------------------------------------
-    def close(self):
+    def close(self, trim: bool = False):
+        """Destroy the context.  Its large device blocks go to the process-wide free list for the next engine (capped; trimmed to LDW_DEVPOOL_IDLE_GB when the
+        process's last context goes); trim=True gives everything back to the runtime at once — for a process that shares the GPU with other allocators
+        (torch, RCCL buffers, other ranks on the same device)."""
         if self._ctx:
             L.lib().ldw_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
+            if trim:
+                n = C.c_int64(0)
+                L.lib().ldw_host_trim(None, C.byref(n))
 
     def __del__(self):
         try:

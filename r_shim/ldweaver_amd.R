@@ -29,6 +29,14 @@
   invisible(devs)
 }
 
+# r06: between jobs of a long session (or before another package allocates on the same GPUs): destroy the contexts and give the library's pooled device
+# blocks and host buffers back; the next call makes its contexts again.  Returns the bytes released.
+ldwamd_release <- function() {
+  n <- .Call("ldwamd_release")
+  .ldwamd_devices_set <<- NULL
+  invisible(n)
+}
+
 .ACGTN2num <- function(nv, cv, ncores) invisible(.Call("ldwamd_ACGTN2num", nv, cv, as.integer(ncores)))
 
 estimate_Hamming_distance_weights <- function(snp.dat, threshold = 0.1, mega_dset = F) {

@@ -44,6 +44,16 @@ SEXP ldwamd_set_devices(SEXP devices) {
     return ScalarInteger(g_nctx);
 }
 
+/* ldwamd_release(): destroy every context and give the library's pooled device blocks and host buffers back (ldw_host_trim): between jobs of a long R
+ * session, or before another package allocates on the same GPUs.  Returns the bytes released. */
+SEXP ldwamd_release(void) {
+    int64_t n = 0;
+    for (int k = 0; k < g_nctx; ++k) { ldw_ctx_destroy(g_ctxs[k]); g_ctxs[k] = NULL; }
+    g_nctx = 0;
+    CHK(ldw_host_trim(NULL, &n));
+    return ScalarReal((double)n);
+}
+
 /* .ACGTN2num(nv, cv, ncores): nv REALSXP 5 x L mutated in place, returns R_NilValue (src/RcppExports.cpp:16-25) */
 SEXP ldwamd_ACGTN2num(SEXP nv, SEXP cv, SEXP ncores) {
     const R_xlen_t L = XLENGTH(cv);
@@ -401,6 +411,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"ldwamd_ctx_reserve", (DL_FUNC)&ldwamd_ctx_reserve, 3},
     {"ldwamd_set_span", (DL_FUNC)&ldwamd_set_span, 2},
     {"ldwamd_set_devices", (DL_FUNC)&ldwamd_set_devices, 1},
+    {"ldwamd_release", (DL_FUNC)&ldwamd_release, 0},
     {"ldwamd_hamming_weights", (DL_FUNC)&ldwamd_hamming_weights, 2},
     {"ldwamd_set_weights", (DL_FUNC)&ldwamd_set_weights, 1},
     {"ldwamd_set_snp_meta", (DL_FUNC)&ldwamd_set_snp_meta, 5},
