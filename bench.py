@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--path", type=int, default=0, help="block-wide pass of the speculative blocks: 0 auto, 1 limb GEMM paths, 2 approximate GEMM + popcount sums")
     ap.add_argument("--screen", type=int, default=1, help="fp32 screen before the fp64 MI evaluation: 0 off, 1 on, 2 verify")
     ap.add_argument("--gather-phases", type=int, default=3, help="N > 1: phases of the link-table gather (1 = one gather after all blocks)")
+    ap.add_argument("--min-blocks-per-phase", type=int, default=12, help="N > 1: a phase of the gather holds at least this many block pairs of a rank's share (a phase is its own "
+                                                                            "ldw_mi_all_pairs call: ~0.65 ms + a shorter span plan; measured in profiles/r06_gather_phases_model.txt)")
     ap.add_argument("--full-sr-rows", dest="sr_mi_only", action="store_false", help="N > 1: send all three columns of the short-range rows (r03) instead of "
                                                                                    "their MI column alone (rank 0 rebuilds the index columns: 8 instead of 16 bytes per row)")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="CPU baseline on the sample BASELINE.md 3 states: one diagonal + one off-diagonal 10 000 x 10 000 "
@@ -114,7 +116,15 @@ def cpu_baseline(states_np, hdw, r, uqe, N, sample):
                         f"minutes on these cores — `--cpu-baseline-full` runs it); the cost is linear in pairs at fixed N, so the sample rate extrapolates"))
 
 
-def scaling_model_leg(eng, blocks, sr_dist, lr_retain, approx, pairs, gather_phases, measured_n, measured_ms):
+def phases_for(nblocks, world, max_phases, min_blocks=12):
+    """Phases of the gather for a rank's share.  A phase is its own ldw_mi_all_pairs call: ~0.65 ms of fixed cost, its own span plan over fewer blocks.  Measured
+    on one GPU (every share run alone, profiles/r06_gather_phases_model.txt): slowest share at N = 2 / 4 / 8 with 1 phase 20.0 / 11.2 / 6.8 ms, with 3 (2 at N = 8)
+    phases 22.0 / 13.4 / 8.4 ms — more than the transfer a phase hides at 153 GB/s per link.  r06: a phase holds at least NINE block pairs (r03-r05: three), so at
+    config 4 only N = 2 is phased (two phases: predicted 23.5 ms against 23.8 with one and 25.1 with three)."""
+    return 1 if world == 1 else max(1, min(max_phases, (nblocks // world) // max(1, min_blocks)))
+
+
+def scaling_model_leg(eng, blocks, sr_dist, lr_retain, approx, pairs, gather_phases, measured_n, measured_ms, min_blocks=12):
     """a PREDICTED strong-scaling curve on every line, so that the first multi-GPU record has a stated expectation to be held against.
     No number here was measured on more than one GPU.  What is measured, on THIS GPU: for N = 1, 2, 4, 8 the cost-weighted deal of the block pairs
     (dist.deal_blocks, the deal the N-rank run makes) and every rank's share run ALONE as the N-rank run runs it — a cold start (probes), its phases as
@@ -131,7 +141,7 @@ def scaling_model_leg(eng, blocks, sr_dist, lr_retain, approx, pairs, gather_pha
     pred = {}
     for n in (1, 2, 4, 8):
         shares = deal_blocks(blocks, n)
-        n_phase = 1 if n == 1 else max(1, min(gather_phases, (nblocks // n) // 3))
+        n_phase = phases_for(nblocks, n, gather_phases, min_blocks)
         ranks = []
         for rk, mine in enumerate(shares):
             phases = np.array_split(mine, n_phase)
@@ -643,8 +653,8 @@ def main():
 
     # N > 1: the gather runs in phases, so that the rows of the blocks a rank has finished travel over xGMI while it
     # computes its next ones; only the last phase's transfer is exposed.  Every rank runs the same number of phases.
-    # (every phase is its own pass of the block pipeline, which costs a start-up / drain: at least 3 blocks per phase)
-    n_phase = 1 if world == 1 else max(1, min(args.gather_phases, (nblocks // world) // 3))
+    # (every phase is its own pass of the block pipeline, which costs a start-up / drain: at least --min-blocks-per-phase blocks per phase — phases_for)
+    n_phase = phases_for(nblocks, world, args.gather_phases, args.min_blocks_per_phase)
     my_phases = np.array_split(mine, n_phase)
 
     rk_acc = dict(compute_ms=0.0, gather_begin_ms=0.0, exposed_gather_ms=0.0, bytes_sent=0, steps=0)
@@ -839,7 +849,7 @@ def main():
 
     # ---- a predicted strong-scaling curve on every line (rank 0 runs every share of the N = 1, 2, 4, 8 deals alone; the other ranks wait at the next fence) ----
     if rank == 0 and not args.no_extra_legs and args.engine == "mfma" and nblocks >= 8:
-        legs["scaling_model"] = scaling_model_leg(eng, blocks, sr_dist, lr_retain, approx, pairs, args.gather_phases, world, dt / args.steps * 1e3)
+        legs["scaling_model"] = scaling_model_leg(eng, blocks, sr_dist, lr_retain, approx, pairs, args.gather_phases, world, dt / args.steps * 1e3, args.min_blocks_per_phase)
 
     if rank == 0:
         K = args.steps
@@ -936,6 +946,17 @@ def main():
             cpu_base = cpu_baseline(st_np, hdw, r[: 2 * sample], uqe[: 2 * sample], N, sample)
             del st_np
         if cpu_base is not None:
+            # the STATED sample (one diagonal + one off-diagonal 10 000 x 10 000 block, 235 s on these cores) is too long for the default line; the
+            # committed run of it is quoted beside the bounded sample so that the two can be compared on the line itself (`--cpu-baseline-full` re-runs it)
+            ref = os.path.join(ROOT, "profiles", "r05_c4_bench_cpu_full.json")
+            if not cpu_base.get("sample_is_stated_block") and os.path.exists(ref) and (L, N) == (100_000, 5_000):
+                try:
+                    full = json.loads([l for l in open(ref) if l.startswith("{")][-1])["cpu_baseline"]
+                    cpu_base["stated_sample_committed_run"] = dict(value=full["value"], cores=full["cores"], sample_s=full["sample_s"], sample_pairs=full["sample_pairs"],
+                                                                   source="profiles/r05_c4_bench_cpu_full.json (bench.py --cpu-baseline-full)",
+                                                                   ratio_bounded_over_stated=cpu_base["value"] / full["value"])
+                except (OSError, ValueError, KeyError, IndexError):
+                    pass
             out["cpu_baseline"] = cpu_base
         out.update(legs)
         if "mi_values_produced" in legs:   # SURVEY 8(d)'s metric — pairs whose MI is PRODUCED — as a first-class number beside the job rate

@@ -45,7 +45,8 @@ def test_bench_multi_rank_rehearsal():
     # --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` itself (a child process, before this one touches the GPU),
     # relays rank 0's line and the exit code
     # (the 4-rank line runs its extra leg: `sr_tail`, the short-range model + ARACNE behind the pass with the table gathered / the rows left on their ranks)
-    many = _bench_line([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo"] + [a for a in base if a != "--no-extra-legs"], 900)
+    # (--min-blocks-per-phase 3: the rehearsal keeps the three-phase gather in it — at 9 block pairs per rank the default, 12, would run one phase)
+    many = _bench_line([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--min-blocks-per-phase", "3"] + [a for a in base if a != "--no-extra-legs"], 900)
     assert many["ranks_seen"] == world and many["backend"] == "gloo" and many["self_launched"] is True
     assert one["ranks_seen"] == 1 and one["self_launched"] is False
     assert many["n_gpus"] == world and one["n_gpus"] == 1
@@ -53,7 +54,7 @@ def test_bench_multi_rank_rehearsal():
     assert many["config"]["pairs"] == one["config"]["pairs"]
     pr = many["per_rank"]
     assert [r["rank"] for r in pr] == list(range(world)) and sum(r["blocks"] for r in pr) == 36
-    assert all(r["compute_ms"] > 0 and r["exposed_gather_ms"] >= 0 for r in pr)
+    assert all(r["compute_ms"] > 0 and r["exposed_gather_ms"] >= 0 and r["phases"] == 3 for r in pr)
     assert pr[0]["bytes_sent"] == 0 and all(r["bytes_sent"] > 0 for r in pr[1:])
     # every rank but 0 sends exactly its rows: r04: 8 bytes per short-range row (the MI column; rank 0 rebuilds the index columns from the
     # positions), 16 per long-range row — about half of r03's 16 bytes per row
