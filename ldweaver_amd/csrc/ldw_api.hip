@@ -530,10 +530,9 @@ int ldw_ctx_destroy(ldw_ctx *c) {
     if (c->lr_st) (void)hipStreamSynchronize(c->lr_st);
     {
     ldw::DrainedScope drained;   // every stream that could touch this context's blocks is idle: no device-wide synchronisation per released block
-    c->logtab.release();
     ldw::DevBuf *bufs[] = {&c->srm_tmp, &c->chars, &c->states, &c->digits, &c->vfixed, &c->r, &c->uqe, &c->POS, &c->paint, &c->Mbits, &c->row0,
                            &c->slot_meta, &c->slot_pfix, &c->apx_skip, &c->snp_sup, &c->counts, &c->pfix_state, &c->G, &c->MIblk, &c->rowlist_f, &c->rowlist_t,
-                           &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->perm_t, &c->scr_units, &c->slot_pfix_hi, &c->glo, &c->lo_rows, &c->packs, &c->colcnt,
+                           &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->perm_t, &c->scr_units, &c->epi_rest, &c->slot_pfix_hi, &c->glo, &c->lo_rows, &c->packs, &c->colcnt,
                            &c->cand_key2, &c->cand_val2, &c->sel_bitmap, &c->sel_chunks, &c->sel_prefix, &c->scratch, &c->small, &c->sr_a, &c->sr_b,
                            &c->sr_mi, &c->lr_a, &c->lr_b, &c->lr_mi, &c->srm_pack, &c->srm_key, &c->srm_pack2, &c->srm_key2, &c->srm_pay, &c->srm_pay2, &c->srm_off,
                            &c->srm_q, &c->srm_n, &c->srm_md, &c->srm_part, &c->srm_shape, &c->srm_cnt, &c->red_row, &c->red_meta,
@@ -903,7 +902,7 @@ int ldw_set_weights(ldw_ctx *c, const double *hdw, int64_t N, int nlimbs) {
         if (mask & 16)
             g.insert(g.end(), {&c->Mbits, &c->row0, &c->slot_meta, &c->slot_pfix, &c->slot_pfix_hi, &c->counts, &c->pfix_state, &c->snp_sup, &c->packs, &c->glo, &c->lo_rows});
         if (mask & 32) {
-            g.insert(g.end(), {&c->G, &c->G2, &c->G3, &c->MIblk, &c->rowlist_f, &c->rowlist_t, &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->perm_t, &c->scr_units, &c->colcnt,
+            g.insert(g.end(), {&c->G, &c->G2, &c->G3, &c->MIblk, &c->rowlist_f, &c->rowlist_t, &c->idx_f, &c->idx_t, &c->lrow_f, &c->lrow_t, &c->perm_f, &c->perm_t, &c->scr_units, &c->epi_rest, &c->colcnt,
                                &c->cand_key2, &c->cand_val2, &c->sel_bitmap, &c->sel_chunks, &c->sel_prefix, &c->scratch, &c->small, &c->pair_sums, &c->tab11[0], &c->tab11[1], &c->miss_key,
                                &c->miss_val});
             for (int k = 0; k < LDW_NSLOT; ++k) g.insert(g.end(), {&c->hist[k], &c->cand_key[k], &c->cand_val[k], &c->dstage[k]});
@@ -1163,19 +1162,6 @@ int ensure_rows(ldw_ctx *c) {
     LDW_REQUIRE(c->L > 0 && c->have_weights && c->have_meta, LDW_ERR_STATE,
                 "MI needs the alignment, the weights and the SNP meta data to be set first");
     const int64_t L = c->L, Npad = c->Npad;
-#ifdef LDW_LOG_TABLE   // (measurement build only: tools/r05_logtab.sh)
-    if (!c->logtab.p) {   // the table of the table-based fp64 logarithm (ldw_epi.h, -DLDW_LOG_TABLE): 128 x {1 / c_i, log c_i}, c_i = 1 + (i + 1/2) / 128
-        double h[256];
-        for (int i = 0; i < 128; ++i) {
-            const double ci = 1.0 + ((double)i + 0.5) / 128.0;
-            h[2 * i] = 1.0 / ci;
-            h[2 * i + 1] = std::log(ci);
-        }
-        if (int rc = c->logtab.reserve(sizeof(h))) return rc;
-        LDW_HIP(hipMemcpyAsync(c->logtab.p, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-        LDW_HIP(hipStreamSynchronize(c->stream));   // (h is on this frame)
-    }
-#endif
     if (int rc = c->counts.reserve((size_t)L * 20)) return rc;
     if (int rc = c->slot_pfix.reserve((size_t)L * 40)) return rc;
     if (int rc = c->pfix_state.reserve((size_t)L * 40)) return rc;

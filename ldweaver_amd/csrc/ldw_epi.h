@@ -71,65 +71,34 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r;
 }
 
-// exact conversion of an integer 0 <= n < 2^52 to double (two integer ops and one add instead of the
-// multi-instruction int64 -> f64 sequence)
-__device__ __forceinline__ double u52_to_double(int64_t n) {
-    return __longlong_as_double(n | 0x4330000000000000LL) - 4503599627370496.0;
-}
-
-// log(N / D) for positive, finite, normal doubles with ONE reciprocal: D is rescaled by a power of two so that
-// N / D' lies in [1/sqrt2, sqrt2]; then log(N/D') = 2 atanh(s), s = (N - D')/(N + D'), |s| <= 0.1716, odd series
-// to s^17 (absolute error < 1e-15), and log(N/D) = k ln2 + log(N/D').
-__device__ __forceinline__ double fast_log_ratio(double N, double D) {
+// HALF of log(N / D) for positive, finite, normal doubles with ONE reciprocal and no floating-point compare (r06; before: D rescaled by the
+// exponent difference, then two fp64 multiplications and compares against sqrt 2 to fold N / D' into [1/sqrt2, sqrt2], 8 Taylor terms).
+// The high words of N and D read as integers are the piecewise-linear logarithm L(x) = e + m (exponent + mantissa fraction), within
+// [-0.0861, 0] of log2 x; k = round(L(N) - L(D)) therefore leaves log2(N / (D 2^k)) in [-0.5862, 0.5862] (the low words' 2^-20 included),
+// N / D' in [0.666, 1.502], and with s = (N - D') / (N + D'), |s| <= 0.2006:  log(N / D') = 2 atanh(s) = 2 s (1 + z q(z)), z = s^2 <= 0.0403.
+// q is a degree-6 polynomial interpolated at the Chebyshev nodes of [0, 0.2006^2] (tools/scratch/log_poly_fit.py, 60-digit arithmetic:
+// the logarithm's truncation error is < 3e-17 absolute; a degree-5 one would give 2.6e-15).  The factor 2 is left to the caller, which
+// divides the sum over the cells by den / 2 instead of den.
+__device__ __forceinline__ double fast_half_log_ratio(double N, double D) {
     const int hn = __double2hiint(N), hd = __double2hiint(D);
-    int k = ((hn >> 20) & 0x7FF) - ((hd >> 20) & 0x7FF);
-    double Dp = __hiloint2double(hd + (k << 20), __double2loint(D));   // D * 2^k: same exponent as N
-    // N / Dp is in (1/2, 2): fold it into [1/sqrt2, sqrt2]
-    const bool big = N > Dp * 1.4142135623730951, small = N * 1.4142135623730951 < Dp;
-    const int adj = big ? 1 : (small ? -1 : 0);
-    Dp = __hiloint2double(__double2hiint(Dp) + (adj << 20), __double2loint(Dp));
-    k += adj;
+    const int k = (hn - hd + 0x80000) >> 20;
+    const double Dp = __hiloint2double(hd + (k << 20), __double2loint(D));   // D 2^k
     const double s = (N - Dp) * fast_rcp(N + Dp);
     const double z = s * s;
-    double p = 1.0 / 17.0;           // truncation z^9/19 <= 9e-16 relative to 2s
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
+    double p = 0x1.35c3cc8164535p-4;
+    p = fma(p, z, 0x1.38feb8144a860p-4);
+    p = fma(p, z, 0x1.746be3c11806ap-4);
+    p = fma(p, z, 0x1.c71c3c1108301p-4);
+    p = fma(p, z, 0x1.24924952daa42p-3);
+    p = fma(p, z, 0x1.999999997bbebp-3);
+    p = fma(p, z, 0x1.555555555556ep-2);
     p = p * z;  // atanh(s)/s - 1
-    const double lm = fma(s + s, p, s + s);
-    return fma((double)k, 0.693147180559945309417, lm);
+    return fma((double)k, 0.5 * 0.693147180559945309417, fma(s, p, s));
 }
-
-// r05 experiment (-DLDW_LOG_TABLE, a measurement build: tools/r05_logtab.sh; NOT shipped — measured SLOWER: k_mi_epilogue 60.5 -> 68.8 ms per C4 pass of
-// the plain path, the two 16-byte table gathers per cell cost more than the reciprocal + three series terms they replace; same tables, parity tests green):
-// the same logarithm WITHOUT the reciprocal — log N - log D from a 128-entry table.  x = 2^e m, m in [1, 2);
-// i = the top 7 bits of the mantissa, c_i = 1 + (i + 1/2) / 128; r = m / c_i - 1 as ONE fma with the tabulated 1 / c_i (|r| <= 2^-8);
-// log m = log c_i + log1p(r), log1p by its series to r^6 (r^7 / 7 < 2e-18).  tab[i] = {1 / c_i, log c_i} (ldw_ctx::logtab, 2 KB).
-struct LogEnt {
-    double inv_c, log_c;
-};
-__device__ __forceinline__ double log1p_small(double r) {
-    double p = -1.0 / 6.0;
-    p = fma(p, r, 1.0 / 5.0);
-    p = fma(p, r, -1.0 / 4.0);
-    p = fma(p, r, 1.0 / 3.0);
-    p = fma(p, r, -1.0 / 2.0);
-    p = p * r;
-    return fma(p, r, r);
-}
-__device__ __forceinline__ double fast_log_ratio_tab(double N, double D, const LogEnt *__restrict__ tab) {
-    const int hn = __double2hiint(N), hd = __double2hiint(D);
-    const int k = ((hn >> 20) & 0x7FF) - ((hd >> 20) & 0x7FF);
-    const LogEnt tn = tab[(hn >> 13) & 0x7F], td = tab[(hd >> 13) & 0x7F];
-    const double mn = __hiloint2double((hn & 0x000FFFFF) | 0x3FF00000, __double2loint(N));
-    const double md = __hiloint2double((hd & 0x000FFFFF) | 0x3FF00000, __double2loint(D));
-    const double rn = fma(mn, tn.inv_c, -1.0), rd = fma(md, td.inv_c, -1.0);
-    const double lm = (tn.log_c - td.log_c) + (log1p_small(rn) - log1p_small(rd));
-    return fma((double)k, 0.693147180559945309417, lm);
+// pxy of a fixed-point joint sum 0 <= n < 2^52: n scale + 1/2 (scale = 2^-F, a power of two) as ONE fma on the bit pattern of 2^52 + n —
+// exact, the same bits as the conversion followed by fma(n, scale, 0.5)
+__device__ __forceinline__ double pxy_of(int64_t n, double scale, double half_m) {   // half_m = 0.5 - 2^52 scale (exact: 0.5 - an integer, F <= 52)
+    return fma(__longlong_as_double(n | 0x4330000000000000LL), scale, half_m);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -191,6 +160,14 @@ inline void apx_screen_params(const ldw_ctx *c, EmitArgs &E, bool r02_bound = fa
     E.apx_MU = c->apx_e_last == 0 ? 0.0f : 1.0f;
 }
 
+// H16: the LDS histogram holds two 16-bit counters per word (bucket b in half b & 1 of word b >> 1) — for a workgroup that sees at most 65 535
+// pairs (k_mi_epilogue_fast: 64 x EPI_COLS), so that its LDS footprint lets five workgroups share a CU
+template <bool H16>
+__device__ __forceinline__ void hist_bump(unsigned int *sh_hist, int bk) {
+    if (H16) atomicAdd(&sh_hist[bk >> 1], 1u << ((bk & 1) << 4));
+    else atomicAdd(&sh_hist[bk], 1u);
+}
+template <bool H16 = false>
 __device__ __forceinline__ void emit_pair(const EmitArgs &E, const ColInfo &c, int a_loc, int b_loc, int sa, int sb,
                                           double mi, unsigned int *sh_hist) {
     if (E.write_dense) E.MI[(int64_t)a_loc + (int64_t)b_loc * E.nf] = mi;
@@ -210,14 +187,14 @@ __device__ __forceinline__ void emit_pair(const EmitArgs &E, const ColInfo &c, i
             if (mi >= E.spec_lo) {
                 const int bk = mi_bucket(mi);
                 if (bk >= E.spec_B) {
-                    atomicAdd(&sh_hist[bk], 1u);
+                    hist_bump<H16>(sh_hist, bk);
                     const unsigned long long p = atomicAdd(E.n_cand, 1ull);
                     E.ckey[p] = f64_key(mi);
                     E.cval[p] = ((uint64_t)seg << 62) | ((uint64_t)a_loc + (uint64_t)b_loc * (uint64_t)E.nf);
                 }
             }
         } else {
-            atomicAdd(&sh_hist[mi_bucket(mi)], 1u);
+            hist_bump<H16>(sh_hist, mi_bucket(mi));
         }
     }
 }
@@ -348,7 +325,6 @@ struct EpiArgs {
                               // screens only keep them out of the long-range candidates and never list a unit for them (E.any_sr is 0 then)
     const MiniCol *mini_c;    // [nt] / [64 * from-tiles] (k_screen_maybe); null: not built
     const MiniRow *mini_r;
-    const struct LogEnt *logtab;   // (-DLDW_LOG_TABLE) 128 x {1 / c_i, log c_i}: ldw_ctx::logtab
     int span;                 // > 0: the to side is the concatenation of `span` reference blocks (segments), nt of each = nf
     SpanSeg sseg[LDW_SPAN_MAX];
     EmitArgs E;
@@ -505,6 +481,7 @@ __device__ __forceinline__ double pair_mi(const EpiArgs &A, const RowSide &R, co
 
     // sum over cells of pxy * log(pxy / (pX pY + RXY + pX rX + pY rY) * den), divided by den at the end
     double acc = 0.0;
+    const double half_m = fma(-4503599627370496.0, A.scale, 0.5);
 #pragma unroll
     for (int i = 0; i <= NAM; ++i) {
         if (i <= na && ((ma >> (3 + i)) & 1)) {
@@ -519,18 +496,14 @@ __device__ __forceinline__ double pair_mi(const EpiArgs &A, const RowSide &R, co
                     else if (j < NB && j < nb) nfix = M.pb[j] - cs[j < NB ? j : 0];     // i == na
                     else nfix = dd;
                     const double pY = M.pYd[j];
-                    const double pxy = fma(u52_to_double(nfix), A.scale, 0.5);
+                    const double pxy = pxy_of(nfix, A.scale, half_m);
                     const double d = fma(pY, rY, fma(pX, pY, pXr));
-#ifdef LDW_LOG_TABLE
-                    acc = fma(pxy, fast_log_ratio_tab(pxy * den, d, A.logtab), acc);
-#else
-                    acc = fma(pxy, fast_log_ratio(pxy * den, d), acc);
-#endif
+                    acc = fma(pxy, fast_half_log_ratio(pxy * den, d), acc);
                 }
             }
         }
     }
-    return acc * fast_rcp(den);
+    return acc * fast_rcp(0.5 * den);   // (the cells summed HALF logarithms)
 }
 
 // Straight-line variant for the common case: every lane has exactly NA row slots, the column has exactly NB,
@@ -621,6 +594,7 @@ __device__ __forceinline__ double full_cells_mi(const EpiArgs &A, const RowSide 
     const double den = A.neff + (ra * rb) * 0.5;
     const double rX = 0.5 * ra, rY = 0.5 * rb;
     double acc = 0.0;
+    const double half_m = fma(-4503599627370496.0, A.scale, 0.5);
 #pragma unroll
     for (int i = 0; i <= NA; ++i) {
         const double pX = R.pXd[i];
@@ -628,16 +602,12 @@ __device__ __forceinline__ double full_cells_mi(const EpiArgs &A, const RowSide 
 #pragma unroll
         for (int j = 0; j <= NB; ++j) {
             const double pY = M.pYd[j];
-            const double pxy = fma(u52_to_double(C.n[i][j]), A.scale, 0.5);
+            const double pxy = pxy_of(C.n[i][j], A.scale, half_m);
             const double d = fma(pY, rY, fma(pX, pY, pXr));
-#ifdef LDW_LOG_TABLE
-            acc = fma(pxy, fast_log_ratio_tab(pxy * den, d, A.logtab), acc);
-#else
-            acc = fma(pxy, fast_log_ratio(pxy * den, d), acc);
-#endif
+            acc = fma(pxy, fast_half_log_ratio(pxy * den, d), acc);
         }
     }
-    return acc * fast_rcp(den);
+    return acc * fast_rcp(0.5 * den);   // (the cells summed HALF logarithms)
 }
 
 // The same sum in fp32 with v_log_f32, an order of magnitude cheaper than the fp64 evaluation: a SCREEN.  In the
@@ -857,7 +827,8 @@ __device__ __forceinline__ void load_col(const EpiArgs &A, const int32_t *__rest
         if (hi_cells) m.pb[j] = A.lo.slot_pfix_hi[(int64_t)m.sb * 5 + j];
     }
     m.pad2 = A.tab11 ? tab_bin(m.pYf[0], A.tab_c, A.tab_nb) : 0;   // bin of the minor-state marginal (threshold table)
-    m.ci = A.E.cols[b_loc];
+    if (A.E.cols) m.ci = A.E.cols[b_loc];   // (null: dense store only, ldw_mi_block — emit_pair does not look at the intervals then)
+    else m.ci = ColInfo{};
 }
 
 // per-lane constants of the from-side SNP; returns whether the lane holds one

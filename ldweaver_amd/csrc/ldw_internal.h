@@ -216,6 +216,7 @@ struct ldw_ctx {
     ldw::DevBuf G, G2, G3;       // int64 [RTpad][RFpad] fixed-point joint sums, one per pipeline slot (gx())
     ldw::DevBuf MIblk;           // double [nf*nt]
     ldw::DevBuf rowlist_f, rowlist_t, idx_f, idx_t, lrow_f, lrow_t, perm_f, perm_t;
+    ldw::DevBuf epi_rest;        // plain path's epilogue: counter (64-B slot) + list of the units k_mi_epilogue_fast left to k_mi_epilogue_rest
     ldw::DevBuf scr_units;       // uint32 count (64-B slot) + list of the block's units the fp32 screen wants evaluated exactly
     ldw::DevBuf hist[LDW_NSLOT], cand_key[LDW_NSLOT], cand_val[LDW_NSLOT];   // per pipeline slot: histogram of the lr candidates, candidate list
     ldw::DevBuf colcnt, cand_key2, cand_val2, scratch, small;
@@ -229,7 +230,6 @@ struct ldw_ctx {
     int64_t blk_capacity = 0, blk_cursor = 0;  // ldw_links_begin / ldw_mi_block_links / ldw_links_end
 
     // ---- short-range model and ARACNE on the device-resident sr table (ldw_srp.hip) ----
-    ldw::DevBuf logtab;          // (-DLDW_LOG_TABLE) 128 x {1 / c_i, log c_i} of the table-based fp64 logarithm (ldw_epi.h)
     void *lr_stream = nullptr;   // r05: lr_links.tsv appended while the pass runs (ldw_tsv.cpp: LrStream), if ldw_lr_stream_begin opened one
     // its device-side resources, made once with the context's other streams (hipStreamCreate is a 12-ms call: not inside a job's pass)
     hipStream_t lr_st = nullptr;

@@ -1226,6 +1226,79 @@ def test_screen_and_mixed_paths_on_multiallelic_alignment(engine):
     assert np.abs(Mg[np.ix_([0, 3, 500, 999], [0, 500, 999])] - Mo).max() < MI_TIGHT
 
 
+def test_epilogue_split_equals_the_one_kernel_epilogue(engine):
+    """r06: the plain path's fp64 epilogue is two kernels — k_mi_epilogue_fast (straight-line code: tiles and columns of SNPs with 1 or 2 fully
+    flagged minor states) and k_mi_epilogue_rest (the units it lists: everything else, predicated code) — against the one-kernel epilogue
+    (LDW_NO_EPI_SPLIT): every unit evaluated exactly once and by the same arithmetic, so link tables and dense blocks are equal BIT FOR BIT.
+    The alignment mixes all kinds: biallelic SNPs, 3-5 states, monomorphic ones, and uqe that disagrees with the data (a tile of
+    one-row SNPs with an unflagged slot is not 'full': the whole tile goes to the list)."""
+    rng = np.random.default_rng(606)
+    Ls, N = 2300, 520
+    st = np.zeros((Ls, N), dtype=np.uint8)
+    for a in range(Ls):
+        k = rng.integers(0, 12)
+        if k == 0:
+            st[a] = rng.integers(0, 5)
+        elif k <= 2:
+            st[a] = rng.choice(5, size=N, p=rng.dirichlet(np.ones(5)))
+        elif k <= 4:
+            s3 = rng.choice(5, size=3, replace=False)
+            st[a] = s3[rng.choice(3, size=N, p=(0.7, 0.2, 0.1))]
+        else:
+            maj, mnr = rng.choice(5, size=2, replace=False)
+            st[a] = np.where(rng.random(N) < rng.uniform(0.05, 0.5), mnr, maj)
+    uqe, r = orc.uqe_r(st)
+    for a in rng.choice(Ls, size=40, replace=False):          # uqe that disagrees with the data
+        present = np.flatnonzero(uqe[a] > 0)
+        if rng.random() < 0.5 and len(present) > 1:
+            uqe[a, rng.choice(present)] = 0.0                  # present but masked
+        else:
+            uqe[a, rng.integers(0, 5)] = 1.0                   # (possibly) flagged but absent
+    r = uqe.sum(axis=1)
+    POS = np.sort(rng.choice(np.arange(1, 300000), size=Ls, replace=False)).astype(np.int32)
+    hdw = 1.0 / rng.integers(1, 30, size=N).astype(np.float64)
+    d = dict(states=st, hdw=hdw, r=r, uqe=uqe, POS=POS, paint=rng.integers(1, 4, Ls).astype(np.int32), g=300000.0)
+    _setup(engine, d)
+    approx = orc.lr_links_approx(POS, d["g"], 20000.0)
+    blocks = np.array(orc.make_blocks(Ls, 1000), dtype=np.int32)
+    fi, ti = np.arange(0, 1000), np.arange(1000, 2300)
+    out = {}
+    engine.set_mixed(False)
+    engine.set_screen(0)
+    engine.set_path(1)
+    try:
+        for key in ("split", "one"):
+            if key == "one":
+                os.environ["LDW_NO_EPI_SPLIT"] = "1"
+            else:
+                os.environ.pop("LDW_NO_EPI_SPLIT", None)
+            tabs = {}
+            for quirk in (L.QUIRK_INTENDED, L.QUIRK_REFERENCE):
+                engine.mi_all_pairs(blocks, 20000.0, 30000.0, approx, quirk=quirk)
+                tabs[quirk] = (engine.links(0), engine.links(1), engine.block_stats())
+            out[key] = (tabs, engine.mi_block(fi, ti), engine.mi_block(fi, fi), engine.mi_block(np.arange(Ls), np.arange(Ls), quirk=L.QUIRK_INTENDED))
+    finally:
+        os.environ.pop("LDW_NO_EPI_SPLIT", None)
+        engine.set_mixed(True)
+        engine.set_screen(1)
+        engine.set_path(0)
+    for quirk in (L.QUIRK_INTENDED, L.QUIRK_REFERENCE):
+        a, b = out["split"][0][quirk], out["one"][0][quirk]
+        for which in (0, 1):
+            for x, y in zip(a[which], b[which]):
+                assert np.array_equal(x, y), (quirk, which)
+        for k in ("n_lr_total", "n_lr_kept", "n_sr", "disc_thresh"):
+            assert np.array_equal(a[2][k], b[2][k]), (quirk, k)
+        assert len(a[0][2]) > 1000 and len(a[1][2]) > 10000
+    for k in (1, 2, 3):
+        assert np.array_equal(out["split"][k], out["one"][k]), k
+    # and the split epilogue against the oracle: rows of every kind at columns of every kind
+    rows = np.concatenate([np.flatnonzero(r == k)[:3] for k in (1, 2, 3, 4, 5) if (r == k).any()])
+    cols = np.concatenate([np.flatnonzero(r == k)[-3:] for k in (1, 2, 3, 4, 5) if (r == k).any()])
+    Mo = np.array([[orc.mi_pair_direct(st, hdw, r, uqe, int(a), int(b)) for b in cols] for a in rows])
+    assert np.abs(out["split"][3][np.ix_(rows, cols)] - Mo).max() < MI_TIGHT
+
+
 def test_616_distinct_weights_take_the_approximate_path(engine):
     """The weight structure of BASELINE config 3 at its worst: N = 616 sequences with 616 DISTINCT Hamming weights 1 / (k + 1)
     (R/performPopulationStuctureCorrection.R:76: hdw = 1 / (#neighbours + 1); a real alignment has up to N distinct values, not
