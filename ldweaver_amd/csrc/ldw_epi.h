@@ -587,27 +587,37 @@ __device__ __forceinline__ double pair_rxy(const EpiArgs &A, const RowSide &R, c
     return (R.ra * M.rb) * 0.25;
 }
 
+// The sum over the cells of a fully flagged (NA + 1) x (NB + 1) table from the cells' pxy (src/computeMI.cpp:19): the ONE fma chain every
+// straight-line kernel runs, whatever way it came by the pxy (full_cells_mi: from the integer cells; k_mi_epilogue_fast: exact fp64 sums) and
+// by den, rX, rY, hrcp = 1 / (den / 2) (per pair, or once per slot-count class where r is the class's) — equal tables give equal bits.
+template <int NA, int NB>
+__device__ __forceinline__ double cells_mi_x(const double (&x)[NA + 1][NB + 1], const double *pX, const double *pY, double RXY, double den, double rX,
+                                             double rY, double hrcp) {
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i <= NA; ++i) {
+        const double pXr = fma(pX[i], rX, RXY);
+#pragma unroll
+        for (int j = 0; j <= NB; ++j) {
+            const double d = fma(pY[j], rY, fma(pX[i], pY[j], pXr));
+            acc = fma(x[i][j], fast_half_log_ratio(x[i][j] * den, d), acc);
+        }
+    }
+    return acc * hrcp;   // (the cells summed HALF logarithms)
+}
+
 template <int NA, int NB>
 __device__ __forceinline__ double full_cells_mi(const EpiArgs &A, const RowSide &R, const ColMeta &M, double RXY,
                                                 const FullCells<NA, NB> &C) {
     const double ra = R.ra, rb = M.rb;
     const double den = A.neff + (ra * rb) * 0.5;
-    const double rX = 0.5 * ra, rY = 0.5 * rb;
-    double acc = 0.0;
     const double half_m = fma(-4503599627370496.0, A.scale, 0.5);
+    double x[NA + 1][NB + 1];
 #pragma unroll
-    for (int i = 0; i <= NA; ++i) {
-        const double pX = R.pXd[i];
-        const double pXr = fma(pX, rX, RXY);
+    for (int i = 0; i <= NA; ++i)
 #pragma unroll
-        for (int j = 0; j <= NB; ++j) {
-            const double pY = M.pYd[j];
-            const double pxy = pxy_of(C.n[i][j], A.scale, half_m);
-            const double d = fma(pY, rY, fma(pX, pY, pXr));
-            acc = fma(pxy, fast_half_log_ratio(pxy * den, d), acc);
-        }
-    }
-    return acc * fast_rcp(0.5 * den);   // (the cells summed HALF logarithms)
+        for (int j = 0; j <= NB; ++j) x[i][j] = pxy_of(C.n[i][j], A.scale, half_m);
+    return cells_mi_x<NA, NB>(x, R.pXd, M.pYd, RXY, den, 0.5 * ra, 0.5 * rb, fast_rcp(0.5 * den));
 }
 
 // The same sum in fp32 with v_log_f32, an order of magnitude cheaper than the fp64 evaluation: a SCREEN.  In the
