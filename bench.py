@@ -179,20 +179,26 @@ def scaling_model_leg(eng, blocks, sr_dist, lr_retain, approx, pairs, gather_pha
 
 
 def epilogue_roofline(ms_per_step, pairs, shape):
-    """k_mi_epilogue (one fp64 MI per pair) against the VALU issue port: SQ counters of the same command, collected in their own rocprofv3 --pmc passes
-    (tools/pmc_run.sh -> profiles/r06_pmc_epilogue.json; the bench cannot run under the counters itself).  A wave64 VALU instruction holds its SIMD's issue
-    port for 4 cycles and a CU has 4 SIMDs: one VALU instruction per CU-cycle is the roof; valu_issue_frac = SQ_INSTS_VALU / SQ_BUSY_CU_CYCLES."""
-    out = dict(kernel="k_mi_epilogue", bound="valu issue (fp64)", ms_per_step=ms_per_step, ps_per_pair=ms_per_step * 1e-3 / pairs * 1e12, valu_issue_frac=None)
-    path = os.path.join(ROOT, "profiles", "r06_pmc_epilogue.json")
+    """The plain path's fp64 epilogue (one MI per pair; r06: k_mi_epilogue_fast for the straight-line units + k_mi_epilogue_rest for the listed rest) against
+    the VALU issue port: SQ counters of the same command, collected in their own rocprofv3 --pmc passes (tools/pmc_epilogue.sh ->
+    profiles/r06s_pmc_epilogue.json; the bench cannot run under the counters itself).  A wave64 VALU instruction holds its SIMD's issue port for 4 cycles
+    and a CU has 4 SIMDs: one VALU instruction per CU-cycle is the roof; valu_issue_frac = SQ_INSTS_VALU / SQ_BUSY_CU_CYCLES, valu_busy_frac counts the
+    quarter-rate v_rcp_f64's extra cycles (SQ_ACTIVE_INST_VALU)."""
+    out = dict(kernel="k_mi_epilogue_fast + k_mi_epilogue_rest", bound="valu issue (fp64)", ms_per_step=ms_per_step, ps_per_pair=ms_per_step * 1e-3 / pairs * 1e12,
+               valu_issue_frac=None)
+    path = os.path.join(ROOT, "profiles", "r06s_pmc_epilogue.json")
     if os.path.exists(path) and shape == (100_000, 5_000, 1):
-        ent = json.load(open(path)).get("ldw::k_mi_epilogue")
-        if ent:
+        allk = json.load(open(path))
+        fast = [(k, e) for k, e in allk.items() if isinstance(e, dict) and "k_mi_epilogue_fast" in k and "derived" in e]
+        if fast:
+            k, ent = max(fast, key=lambda ke: ke[1]["SQ_INSTS_VALU"] * ke[1]["launches"])   # (the instantiation the pass runs: reference quirk, speculative candidates)
             d = ent["derived"]
-            out.update(valu_issue_frac=d["valu_issue_frac"], valu_busy_frac=d["valu_busy_frac"], valu_insts_per_pair=ent["SQ_INSTS_VALU"] * 64.0 * 55 / pairs,
-                       salu_per_valu=d["salu_per_valu"], lanes_active_per_valu=d["lanes_active_per_valu"], wait_inst_any_frac=d["wait_inst_any_frac"],
-                       counters_source="profiles/r06_pmc_epilogue.json (per-launch averages over 169 launches of the plain path; separate --pmc passes)",
-                       note="~4.6 cells per pair x (1 v_rcp_f64 + ~45 fp64 / integer operations): the kernel issues VALU instructions on 0.66 of the cycles its CUs are busy "
-                            "(0.70 counting the quarter-rate reciprocal's extra cycles), 58 of 64 lanes active")
+            out.update(valu_issue_frac=d["valu_issue_frac"], valu_busy_frac=d["valu_busy_frac"], counters_kernel=k.replace("void ", ""),
+                       valu_insts_per_pair=ent["SQ_INSTS_VALU"] * 64.0 * 55 / pairs, salu_per_valu=d["salu_per_valu"],
+                       wait_inst_any_frac=d["wait_inst_any_frac"], waves_per_simd=5,
+                       counters_source="profiles/r06s_pmc_epilogue.json (per-launch averages of the plain path's launches; separate --pmc passes)",
+                       note="~4.6 cells per pair x (1 v_rcp_f64 + ~27 fp64 / integer operations) + ~45 per pair of addressing, loads and emission; "
+                            "r05's one-kernel epilogue: 268 VALU instructions per pair at 0.655 of the port (3 waves per SIMD, 156 VGPRs, 102 spilled SGPRs)")
     return out
 
 
@@ -796,7 +802,7 @@ def main():
         n_pl = max(10, min(args.steps, 20))   # (at least 10 steps, like the headline)
         t_pl = timed(n_pl)
         legs["mi_values_produced"] = dict(ms_per_step=t_pl / n_pl * 1e3, value=pairs * n_pl / t_pl, steps=n_pl, links=dict(result),
-                                          what="--no-mixed --screen 0 --path 1: gemm_bits_kernel<5> + k_mi_epilogue: an fp64 MI VALUE for every pair "
+                                          what="--no-mixed --screen 0 --path 1: gemm_bits_kernel<5> + k_mi_epilogue_fast / _rest: an fp64 MI VALUE for every pair "
                                                "(the headline counts pairs DECIDED: the default path bounds 99.7 % of the pairs below their block's "
                                                "threshold instead of evaluating them; same link tables)")
         # its own roofline: the 5-limb exact GEMM, timed kernel-exclusively (overlap off) with HIP events, executed int8 operations counted by the library
