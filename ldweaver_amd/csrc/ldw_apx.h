@@ -27,7 +27,7 @@ struct PopSeg {
 
 constexpr int APX_TW = 128;      // rows per side of one wave tile of the approximate GEMM (4 x 4 MFMA tiles of 32 x 32)
 struct ApxGemmArgs {
-    const uint64_t *panel_t, *panel_f;   // [M2][Rpad][2]: words 2m, 2m+1 of row list position r
+    const uint64_t *panel_t, *panel_f;   // [M2][Rpad][2]: words 2m, 2m+1 of row list position r — for gemm_apx_kernel as the SCALED pieces of k_pack_panel (16 bytes per word)
     int RTpad, RFpad, M2;
     const uint8_t *dig_a, *dig_b;        // [128 * M2] by position
     const int32_t *shift;                // [4 M2]: right shift before k-step k (32 positions)

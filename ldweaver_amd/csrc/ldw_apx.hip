@@ -181,16 +181,20 @@ int prepare_apx_weights(ldw_ctx *c) {
 
 // ------------------------------------------------------------------------------------------------
 // k_pack_panel: the 128 bits of macro step m of row-list position r as ONE 16-byte piece panel[m][r] (consecutive rows are
-// consecutive pieces: the GEMM's loads are contiguous runs).  interleave != 0 (gemm_apx_kernel): the eight 16-bit groups g of the
-// macro step are stored as word 0 = groups (0, 2, 4, 6), word 1 = groups (1, 3, 5, 7), so that the lane half fh of an MFMA
-// k-step kk finds ITS sixteen positions 32 kk + 16 fh .. + 15 — a k-step covers 32 CONSECUTIVE positions, one block exponent —
-// at bits 16 kk of word fh.  interleave == 0 (gemm_apx_lds_kernel): the words as they are.
+// consecutive pieces: the GEMM's loads are contiguous runs).  interleave != 0 (gemm_apx_kernel, one block exponent per k-step): the eight
+// 16-bit groups g of the macro step are stored as word 0 = groups (0, 2, 4, 6), word 1 = groups (1, 3, 5, 7), so that the lane half fh of an
+// MFMA k-step kk finds ITS sixteen positions 32 kk + 16 fh .. + 15 — a k-step covers 32 CONSECUTIVE positions, one block exponent —
+// at bits 16 kk of word fh.  interleave == 0 (gemm_apx_lds_kernel; gemm_apx_kernel with one exponent per macro step): the words as they are.
+// scaled != 0 (r06, gemm_apx_kernel): every word goes out as FOUR dwords, dword kk = the word's bytes 2 kk and 2 kk + 1 each multiplied by 8 in
+// a 16-bit field — the byte offsets of the two entries of the kernel's 8-byte expansion table that k-step kk looks up: the kernel gets an offset
+// with ONE VALU instruction (and / shift) instead of two (extract, then scale); piece ((m Rpad + r) 2 + word) of 16 bytes, a panel twice the size.
 // ------------------------------------------------------------------------------------------------
 // blockIdx.y = 1: the second row list of the launch (rowlist2 / Rpad2 / panel2: the to side of an off-diagonal block — both panels in ONE launch).
 __global__ __launch_bounds__(256) void k_pack_panel(const uint64_t *__restrict__ Mbits, int64_t KW, const int32_t *__restrict__ rowlist,
-                                                    int Rpad, int M2, uint64_t *__restrict__ panel, int interleave,
+                                                    int Rpad, int M2, uint64_t *__restrict__ panel, int interleave, int scaled,
                                                     const int32_t *__restrict__ rowlist2 = nullptr, int Rpad2 = 0, uint64_t *__restrict__ panel2 = nullptr) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     if (blockIdx.y == 1) {
         rowlist = rowlist2;
         Rpad = Rpad2;
@@ -200,6 +204,7 @@ __global__ __launch_bounds__(256) void k_pack_panel(const uint64_t *__restrict__
     if (r >= Rpad) return;
     const u64x2 *src = reinterpret_cast<const u64x2 *>(Mbits + (int64_t)rowlist[r] * KW);
     u64x2 *dst = reinterpret_cast<u64x2 *>(panel);
+    u32x4 *dst4 = reinterpret_cast<u32x4 *>(panel);
     for (int m = threadIdx.x >> 6; m < M2; m += 4) {
         u64x2 v = src[m];
         if (interleave) {
@@ -210,7 +215,19 @@ __global__ __launch_bounds__(256) void k_pack_panel(const uint64_t *__restrict__
             v[0] = ex;   // g0 g2 g4 g6
             v[1] = ox;   // g1 g3 g5 g7
         }
-        dst[(int64_t)m * Rpad + r] = v;
+        if (scaled) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned long long w = v[h];
+                u32x4 o;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    o[kk] = (((unsigned int)(w >> (16 * kk)) & 0xFFu) << 3) | (((unsigned int)(w >> (16 * kk + 8)) & 0xFFu) << 19);
+                dst4[((int64_t)m * Rpad + r) * 2 + h] = o;
+            }
+        } else {
+            dst[(int64_t)m * Rpad + r] = v;
+        }
     }
 }
 
@@ -224,10 +241,19 @@ static bool apx_kernel_is_lds() {
     return lds;
 }
 
+// the register-expansion kernel (gemm_apx_kernel: the production one) reads the SCALED panel, the experiment kernels the plain words
+static bool apx_kernel_is_reg() {
+    static const bool reg = [] {
+        const char *e = exp_env("LDW_APX_KERNEL");
+        return !(e && (e[0] == 'l' || e[0] == 'p'));
+    }();
+    return reg;
+}
+
 int launch_pack_panel(ldw_ctx *c, const int32_t *rowlist, int Rpad, uint64_t *panel, hipStream_t st, const int32_t *rowlist2, int Rpad2, uint64_t *panel2) {
     const int rmax = (rowlist2 && Rpad2 > Rpad) ? Rpad2 : Rpad;
     hipLaunchKernelGGL(k_pack_panel, dim3((unsigned)((rmax + 63) / 64), rowlist2 ? 2u : 1u), dim3(256), 0, st, c->Mbits.as<uint64_t>(), c->KW, rowlist, Rpad,
-                       (int)(c->KW / 2), panel, (c->apx_fine && !apx_kernel_is_lds()) ? 1 : 0, rowlist2, Rpad2, panel2);
+                       (int)(c->KW / 2), panel, (c->apx_fine && !apx_kernel_is_lds()) ? 1 : 0, apx_kernel_is_reg() ? 1 : 0, rowlist2, Rpad2, panel2);
     LDW_HIP(hipGetLastError());
     return LDW_OK;
 }
@@ -255,6 +281,15 @@ template <int KK>
 __device__ __forceinline__ v4i expand16(const uint64_t *lutFF, uint64_t w) {
     typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
     const u64x2v q = {lutFF[(w >> (16 * KK)) & 0xFFu], lutFF[(w >> (16 * KK + 8)) & 0xFFu]};
+    return __builtin_bit_cast(v4i, q);
+}
+// the same from a piece of the SCALED panel (k_pack_panel): dword KK holds the two table offsets, in bytes, as 16-bit fields
+typedef unsigned int apx_u32x4 __attribute__((ext_vector_type(4)));
+template <int KK>
+__device__ __forceinline__ v4i expand16s(const uint8_t *lut_bytes, const apx_u32x4 &w) {
+    typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
+    const unsigned int d = w[KK];
+    const u64x2v q = {*reinterpret_cast<const uint64_t *>(lut_bytes + (d & 0xFFFFu)), *reinterpret_cast<const uint64_t *>(lut_bytes + (d >> 16))};
     return __builtin_bit_cast(v4i, q);
 }
 constexpr int APX_LUT_BYTES = 2048;
@@ -502,18 +537,18 @@ __global__ __launch_bounds__(256, WPS) void gemm_apx_kernel(ApxGemmArgs P) {
     const int frow = lane & 31, fh = lane >> 5;
     const int64_t sta = (int64_t)P.RTpad * 2, stb = (int64_t)P.RFpad * 2;
     {
-        const uint64_t *pa[MT], *pb[NT];
+        const apx_u32x4 *pa[MT], *pb[NT];   // (pieces of the scaled panel: k_pack_panel)
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             int rt = ty * TH + 32 * i + frow;
             if (128 % TH != 0 && rt >= P.RTpad) rt = P.RTpad - 1;   // (only the 96-row tiles of the r05 experiment can run past RTpad, a multiple of 128)
-            pa[i] = P.panel_t + ((int64_t)rt * 2 + fh);
+            pa[i] = reinterpret_cast<const apx_u32x4 *>(P.panel_t) + ((int64_t)rt * 2 + fh);
         }
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             int rf = tx * TWd + 32 * i + frow;
             if (64 % TWd != 0 && rf >= P.RFpad) rf = P.RFpad - 1;   // (only the 96-column tiles of the r05 experiments can run past RFpad, a multiple of 64)
-            pb[i] = P.panel_f + ((int64_t)rf * 2 + fh);
+            pb[i] = reinterpret_cast<const apx_u32x4 *>(P.panel_f) + ((int64_t)rf * 2 + fh);
         }
         v16i acc[MT][NT];
 #pragma unroll
@@ -522,7 +557,8 @@ __global__ __launch_bounds__(256, WPS) void gemm_apx_kernel(ApxGemmArgs P) {
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
-        uint64_t wa[MT], wb[NT], na[MT], nb[NT];
+        apx_u32x4 wa[MT], wb[NT], na[MT], nb[NT];
+        const uint8_t *lut_bytes = smem;
 #pragma unroll
         for (int i = 0; i < MT; ++i) na[i] = pa[i][0];
 #pragma unroll
@@ -559,9 +595,9 @@ __global__ __launch_bounds__(256, WPS) void gemm_apx_kernel(ApxGemmArgs P) {
                 const v4i db = *reinterpret_cast<const v4i *>(dB + (FINE ? 32 : 16) * kk);
                 v4i fa[MT], fb[NT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[i] = expand16<kk>(lutFF, wa[i]) & da;
+                for (int i = 0; i < MT; ++i) fa[i] = expand16s<kk>(lut_bytes, wa[i]) & da;
 #pragma unroll
-                for (int i = 0; i < NT; ++i) fb[i] = expand16<kk>(lutFF, wb[i]) & db;
+                for (int i = 0; i < NT; ++i) fb[i] = expand16s<kk>(lut_bytes, wb[i]) & db;
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll

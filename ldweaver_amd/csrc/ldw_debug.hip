@@ -174,7 +174,7 @@ int ldw_debug_apx_gemm(ldw_ctx *c, const int32_t *rows_t, int nrt, const int32_t
     std::copy(rows_f, rows_f + nrf, rl.begin() + RTpad);
     DevBuf d_rl, d_pt, d_pf, d_G;
     int rc = LDW_OK;
-    if ((rc = d_rl.reserve(rl.size() * 4)) || (rc = d_pt.reserve((size_t)M2 * RTpad * 16)) || (rc = d_pf.reserve((size_t)M2 * RFpad * 16)) ||
+    if ((rc = d_rl.reserve(rl.size() * 4)) || (rc = d_pt.reserve((size_t)M2 * RTpad * 32)) || (rc = d_pf.reserve((size_t)M2 * RFpad * 32)) ||
         (rc = d_G.reserve((size_t)RTpad * RFpad * 4))) {
         d_rl.release(); d_pt.release(); d_pf.release(); d_G.release();
         return rc;

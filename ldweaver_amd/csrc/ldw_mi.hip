@@ -137,8 +137,8 @@ int reserve_slot_buffers(ldw_ctx *c, int64_t Npad, int64_t blk, int64_t nseg) {
     const size_t o_cph = ((size_t)nt * sizeof(ColMeta) + 255) / 256 * 256, o_rph = ((size_t)nf_slots * sizeof(RowPack) + 255) / 256 * 256;
     const size_t one = (size_t)blk * (size_t)blk;
     for (int s = 0; s < LDW_NSLOT; ++s) {
-        if (int rc = c->panel[s][0].reserve(RF * (size_t)KW * 8)) return rc;
-        if (int rc = c->panel[s][1].reserve(RT * (size_t)KW * 8)) return rc;
+        if (int rc = c->panel[s][0].reserve(RF * (size_t)KW * 16)) return rc;   // (the scaled panel of k_pack_panel: 16 bytes per word)
+        if (int rc = c->panel[s][1].reserve(RT * (size_t)KW * 16)) return rc;
         if (int rc = c->Gapx[s].reserve(RF * RT * 4)) return rc;
         if (int rc = c->apx_units[s].reserve(64 + 2 * n_units * 8 + 64)) return rc;
         if (int rc = c->apx_packs[s].reserve(2 * o_cph + 2 * o_rph + ((size_t)blk + (size_t)nt) * 4 + 1024)) return rc;

@@ -5,6 +5,8 @@
 //   level 2: registers ANDed with a per-iteration mask                  (24 VALU feeding the MFMAs: VALU -> MFMA dependency)
 //   level 3: a 256-entry LDS table read at indices taken from a rotating register word (12 index pairs = 24 VALU, 12 ds_read_b64), then the AND (24 VALU)
 //   level 4: level 3 + the two digit vectors read from LDS per k-step (2 ds_read_b128)
+//   level 41 / 42 / 43 (r06): level 4 with 1 / 2 / 3 of the six fragments expanded ARITHMETICALLY (per 4 positions: nibble, x 0x204081 & 0x01010101 -> a 0/1 byte per bit,
+//            (t << 8) - t -> 0xFF bytes, AND: 6 VALU per dword instead of 2 + a table read per two dwords) — trading LDS reads for VALU
 // Operands are sparse (about 15 % of the bytes non-zero) so that the clock stays at its nominal value (profiles/r05_mfma_rate_by_data.txt).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void k(const u64 *__restrict__ words, unsig
             for (int r = 0; r < 6; ++r) f[r] = base[r] & mk;
         } else {
             v4i da = {0x11223344, 0x0A0B0C0D, 0x21314151, 0x07060504}, db = da;
-            if (LEVEL == 4) {
+            if (LEVEL == 4 || LEVEL >= 40) {
                 da = *reinterpret_cast<const v4i *>(&dig[0][((it & 63) * 64 + fh * 16) & 4080]);
                 db = *reinterpret_cast<const v4i *>(&dig[1][((it & 63) * 64 + fh * 16) & 4080]);
             }
@@ -90,6 +92,18 @@ __global__ __launch_bounds__(256, 2) void k(const u64 *__restrict__ words, unsig
             } else
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
+                if (LEVEL >= 40 && r >= 6 - (LEVEL - 40)) {   // arithmetic expansion of the 16 positions at bit sh of w[r]
+                    const v4i dg = r < 4 ? da : db;
+                    v4i o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned nib = (unsigned)(w[r] >> (sh + 4 * q)) & 0xFu;
+                        const unsigned t = __umul24(nib, 0x204081u) & 0x01010101u;
+                        o[q] = (int)((t << 8) - t) & dg[q];
+                    }
+                    f[r] = o;
+                    continue;
+                }
                 // level 6: the second read of every fragment, level 7: both reads of fragments 4 and 5 (a third of the reads) go through the vector L1
                 const bool ga = LEVEL == 7 && r >= 4, gb = LEVEL == 6 || (LEVEL == 7 && r >= 4);
                 const u64 a = ga ? glut[(w[r] >> sh) & 0xFF] : lt[((w[r] >> sh) & 0xFF) * REP];
@@ -381,6 +395,10 @@ int main() {
     run<2>(d, o, g, iters, "24 VALU (AND with a changing mask) FEEDING the MFMAs");
     run<3>(d, o, g, iters, "12 table reads (ds_read_b64) + 24 index VALU + 24 AND feeding the MFMAs");
     run<4>(d, o, g, iters, "level 3 + the two digit vectors from LDS (2 ds_read_b128 per k-step)");
+    run<41>(d, o, g, iters, "level 4 with ONE of the six fragments expanded arithmetically (10 table reads)");
+    run<42>(d, o, g, iters, "level 4 with TWO fragments expanded arithmetically (8 table reads)");
+    run<43>(d, o, g, iters, "level 4 with THREE fragments expanded arithmetically (6 table reads)");
+    run<46>(d, o, g, iters, "level 4 with ALL SIX fragments expanded arithmetically (no table read)");
     run<5>(d, o, g, iters, "level 3 with the same indices in every lane (broadcast: no bank conflicts)");
     run<3, 16>(d, o, g, iters, "level 3, table replicated 16 x (2-way conflicts by construction)");
     run<3, 32>(d, o, g, iters, "level 3, table replicated 32 x (conflict-free, 64 KB)");
