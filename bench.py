@@ -876,7 +876,7 @@ def main():
             apx = gst["apx_launches"] >= gst["bits_launches"]
             mixed_blocks = cnt_replay.get("mixed_blocks", 0)
             fine = "per 32" in (path_report or {}).get("apx_gate", "")
-            apx_name = "gemm_apx_lds_kernel" if os.environ.get("LDW_APX_KERNEL", "r")[:1] == "l" else f"gemm_apx_kernel<4, 2, {'true' if fine else 'false'}>"
+            apx_name = "gemm_apx_lds_kernel" if os.environ.get("LDW_APX_KERNEL", "r")[:1] == "l" else f"gemm_apx_kernel<4, 2, {'true' if fine else 'false'}, 2>"   # (MT, NT, FINE, waves per SIMD: the name rocprofv3 reports)
             kname = apx_name if apx else (f"gemm_mi_fused_kernel<{J}>" if args.fused else f"gemm_bits_kernel<{3 if mixed_blocks else J}>")
             avg_ms = tim["gemm_ms"] / n_launch
             exec_per_launch = (gst["apx_ops"] + gst["bits_ops"]) / n_launch
@@ -910,9 +910,9 @@ def main():
                              "kernel's own accumulators (the regions that pass are neither stored nor screened).  " + prune_note +
                              "`overlapped_avg_launch_ms` "
                              "is the bracket inside the timed region, where the GEMM shares the GPU with the previous block's screens and selection")
-            tpath = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
-            if not os.path.exists(tpath):
-                tpath = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r06t_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
+            if not os.path.exists(tpath):                                    # (r06t: with the scaled panel of gemm_apx_kernel; r06: before it)
+                tpath = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
             if os.path.exists(tpath) and (L, N, world) == (100_000, 5_000, 1):   # the configuration the PMC passes were collected on
                 ent = json.load(open(tpath)).get(kname)
                 if ent:
