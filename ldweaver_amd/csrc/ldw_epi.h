@@ -39,8 +39,10 @@ struct ColInfo {
     int64_t off_u, off_l;
 };
 
+// (bitwise on purpose: with && / || the compiler branches per interval under a divergent exec mask — three s_and_saveexec chains per pair in the screens of
+// the blocks with short-range pairs)
 __host__ __device__ __forceinline__ bool col_is_sr(const ColInfo &c, int a) {
-    return (a >= c.s[0] && a < c.e[0]) || (a >= c.s[1] && a < c.e[1]) || (a >= c.s[2] && a < c.e[2]);
+    return (((a >= c.s[0]) & (a < c.e[0])) | ((a >= c.s[1]) & (a < c.e[1])) | ((a >= c.s[2]) & (a < c.e[2]))) != 0;
 }
 // number of short-range partners in [lo, hi)
 __host__ __device__ __forceinline__ int col_count(const ColInfo &c, int lo, int hi) {
