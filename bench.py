@@ -910,9 +910,9 @@ def main():
                              "kernel's own accumulators (the regions that pass are neither stored nor screened).  " + prune_note +
                              "`overlapped_avg_launch_ms` "
                              "is the bracket inside the timed region, where the GEMM shares the GPU with the previous block's screens and selection")
-            tpath = os.path.join(ROOT, "profiles", "r06t_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
-            if not os.path.exists(tpath):                                    # (r06t: with the scaled panel of gemm_apx_kernel; r06: before it)
-                tpath = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r06u_pmc_traffic.json")   # rocprofv3 cannot run inside the bench: quoted only for
+            if not os.path.exists(tpath):                                    # (r06u: the code as committed; r06t: before the deferred pair-list appends)
+                tpath = os.path.join(ROOT, "profiles", "r06t_pmc_traffic.json")
             if os.path.exists(tpath) and (L, N, world) == (100_000, 5_000, 1):   # the configuration the PMC passes were collected on
                 ent = json.load(open(tpath)).get(kname)
                 if ent:

@@ -1,9 +1,9 @@
 #!/bin/bash
 # round 6, second session: final evidence at the committed code — the driver's bench line, kernel stats of the default path (serial + overlapped) and of the plain path,
-# PMC traffic + SQ counters of the GEMMs (the scaled panel changed gemm_apx_kernel's instruction mix), the C3 shape, whole-job stages.  Tag r06t.
+# PMC traffic + SQ counters of the GEMMs (the scaled panel changed gemm_apx_kernel's instruction mix), the C3 shape, whole-job stages.  Tag r06u (r06t: before the deferred pair-list appends).
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-T=r06t
+T=r06u
 PLAIN="--no-mixed --screen 0 --path 1"
 timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_c4_driver_bench.json 2> gpurun_out/${T}_c4_driver_bench.err; echo "bench rc $?"
 bash tools/prof_run.sh ${T}_c4 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > /dev/null 2>&1; echo "prof rc $?"
