@@ -5,6 +5,7 @@
 #include <cmath>
 #include "ldw_internal.h"
 #include "ldw_dev.h"
+#include "ldw_log.h"
 
 namespace ldw {
 
@@ -73,33 +74,14 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r;
 }
 
-// HALF of log(N / D) for positive, finite, normal doubles with ONE reciprocal and no floating-point compare (r06; before: D rescaled by the
-// exponent difference, then two fp64 multiplications and compares against sqrt 2 to fold N / D' into [1/sqrt2, sqrt2], 8 Taylor terms).
-// The high words of N and D read as integers are the piecewise-linear logarithm L(x) = e + m (exponent + mantissa fraction), within
-// [-0.0861, 0] of log2 x; k = round(L(N) - L(D)) therefore leaves log2(N / (D 2^k)) in [-0.5862, 0.5862] (the low words' 2^-20 included),
-// N / D' in [0.666, 1.502], and with s = (N - D') / (N + D'), |s| <= 0.2006:  log(N / D') = 2 atanh(s) = 2 s (1 + z q(z)), z = s^2 <= 0.0403.
-// q is a degree-6 polynomial interpolated at the Chebyshev nodes of [0, 0.2006^2] (tools/scratch/log_poly_fit.py, 60-digit arithmetic:
-// the logarithm's truncation error is < 3e-17 absolute; a degree-5 one would give 2.6e-15).  The factor 2 is left to the caller, which
-// divides the sum over the cells by den / 2 instead of den.
+// HALF of log(N / D): ldw_log.h (one source for the device and for the host check tests/test_log_host.py), with v_rcp_f64 as the estimate.
 // Measured and NOT shipped (profiles/r06_epi_split.txt): one reciprocal shared by the four cells of a table (1 / (b0 b1 b2 b3) and nine
 // multiplications instead of four quarter-rate v_rcp_f64 + Newton steps) saves 9 of ~115 issue slots per 2 x 2 table on paper and costs 1.6 of
 // 33.4 ms: the four cells' operands stay live together, k_mi_epilogue_fast spills 68 registers and k_mi_units<true> falls from 4 to 3 waves.
-__device__ __forceinline__ double fast_half_log_ratio(double N, double D) {
-    const int hn = __double2hiint(N), hd = __double2hiint(D);
-    const int k20 = (hn - hd + 0x80000) & (int)0xFFF00000;                   // k 2^20
-    const double Dp = __hiloint2double(hd + k20, __double2loint(D));   // D 2^k
-    const double s = (N - Dp) * fast_rcp(N + Dp);
-    const double z = s * s;
-    double p = 0x1.35c3cc8164535p-4;
-    p = fma(p, z, 0x1.38feb8144a860p-4);
-    p = fma(p, z, 0x1.746be3c11806ap-4);
-    p = fma(p, z, 0x1.c71c3c1108301p-4);
-    p = fma(p, z, 0x1.24924952daa42p-3);
-    p = fma(p, z, 0x1.999999997bbebp-3);
-    p = fma(p, z, 0x1.555555555556ep-2);
-    p = p * z;  // atanh(s)/s - 1
-    return fma((double)k20, 0x1p-20 * (0.5 * 0.693147180559945309417), fma(s, p, s));   // (k 2^20 converts exactly; the constant is ln2 / 2 scaled by a power of two)
-}
+struct DeviceRcpEstimate {
+    __device__ __forceinline__ double operator()(double x) const { return __builtin_amdgcn_rcp(x); }
+};
+__device__ __forceinline__ double fast_half_log_ratio(double N, double D) { return half_log_ratio_core(N, D, DeviceRcpEstimate{}); }
 // pxy of a fixed-point joint sum 0 <= n < 2^52: n scale + 1/2 (scale = 2^-F, a power of two) as ONE fma on the bit pattern of 2^52 + n —
 // exact, the same bits as the conversion followed by fma(n, scale, 0.5)
 __device__ __forceinline__ double pxy_of(int64_t n, double scale, double half_m) {   // half_m = 0.5 - 2^52 scale (exact: 0.5 - an integer, F <= 52)
