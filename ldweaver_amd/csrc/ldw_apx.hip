@@ -1405,8 +1405,11 @@ int launch_pairs_exact(ldw_ctx *c, const EpiArgs &A, unsigned long long *ghist, 
         hipLaunchKernelGGL(k_pair_sums_bits<false>, dim3(256, PAIR_SHARDS, 4), dim3(256), lds_bits, st, P, c->pop_vpos.as<int64_t>(), stride);
         hipLaunchKernelGGL(k_pair_sums_bits<true>, dim3(256, PAIR_SHARDS, 1), dim3(256), lds_bits, st, P, c->pop_vpos.as<int64_t>(), stride);
     } else {
-        hipLaunchKernelGGL(k_pair_sums<false>, dim3(256, PAIR_SHARDS, 4), dim3(256), lds, st, P);
-        hipLaunchKernelGGL(k_pair_sums<true>, dim3(256, PAIR_SHARDS, 1), dim3(256), lds, st, P);
+        // (grid: r06 — 512 / 1024 workgroups per list instead of 256: 67 -> 61 and 34 -> 23 us per launch; 128 / 64 / 32: 96 / 150 / 236 us.  A 1-D grid whose
+        // waves share the pairs of all lists evenly was built too: no better (64 / 42 us) — the long launches are not a matter of balance.  LDW_PAIR_GRID: A/B)
+        static const unsigned gx_env = [] { const char *e = getenv("LDW_PAIR_GRID"); return e ? (unsigned)atoi(e) : 0u; }();
+        hipLaunchKernelGGL(k_pair_sums<false>, dim3(gx_env ? gx_env : 512u, PAIR_SHARDS, 4), dim3(256), lds, st, P);
+        hipLaunchKernelGGL(k_pair_sums<true>, dim3(gx_env ? gx_env : 1024u, PAIR_SHARDS, 1), dim3(256), lds, st, P);
     }
     hipLaunchKernelGGL(k_pair_mi, dim3(64, PAIR_SHARDS, PAIR_PATHS), dim3(256), 0, st, P);
     LDW_HIP(hipGetLastError());
