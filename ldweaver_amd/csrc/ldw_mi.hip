@@ -2,7 +2,7 @@
 // R/computePairwiseMI.R:167-386, and of the block loop of perform_MI_computation, :103-116).
 //
 // First block of a call sequence (no histogram-bucket guess yet), speculation misses, ldw_mi_block:
-//   GEMM, 5 limbs (ldw_gemm_bits.hip) -> k_mi_epilogue: one thread per SNP pair turns the fixed-point joint sums into MI
+//   GEMM, 5 limbs (ldw_gemm_bits.hip) -> k_mi_epilogue_fast / _rest (ldw_mi_eval.inc): one thread per SNP pair turns the fixed-point joint sums into MI
 //   (src/computeMI.cpp:19), writes the dense MI block, scatters the short-range links straight to their final rows and
 //   histograms the long-range MI values in LDS -> k_pick_bucket: ranks of the two order statistics of quantile type 7
 //   and the histogram bucket holding them -> k_lr_gather: every long-range pair at or above that bucket.
